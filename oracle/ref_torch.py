@@ -1,0 +1,701 @@
+"""ORACLE (test infrastructure only) -- stock-PyTorch CPU restatement of the reference hot path.
+
+PARITY UNPINNED against TensorFlow: the reference's arithmetic lives in TensorFlow 1.x (version
+unpinned, not installable here) and the reference ships no tests or golden
+vectors.  This file restates the reference graph from its source lines plus documented TF-1 op
+semantics, using only stock torch CPU ops + autograd.  It is cross-checked against the independent
+NumPy restatement in `oracle/ref_np.py` (tests/test_oracle.py) and frozen into tests/golden/*.npz.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product path (transferable3d_amd/) never does.
+
+Tensors are (B, N, C) channel-fastest, exactly the reference's NHWC with H=N, W=1.  Parameters are
+a flat dict keyed by the reference's TF variable names (`<scope>/weights`, `<scope>/biases`,
+`<scope>/bn/{beta,gamma,moving_mean,moving_variance}`).
+"""
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from transferable3d_amd.constants import (NUM_HEADING_BIN, NUM_SIZE_CLUSTER, NUM_CLASS,
+                                          MEAN_DIMS_ARR, ORIENT_ANCHORS, BN_EPS, BOX_OUT_DIMS)
+
+
+# ----------------------------------------------------------------------------------------------
+# parameters
+# ----------------------------------------------------------------------------------------------
+# (scope, kind, Cin, Cout, bn) in creation order.  kind: 'conv' = tf_util.conv2d per-point layer,
+# 'fc' = tf_util.fully_connected.  `cin` of the first conv of each net is filled from the channels.
+def layer_table(num_channels, model='A', use_one_hot=False, prefix_agnostic='', boxpc_channels=None):
+    """Layer list of the nets on the path.
+
+    model 'A': inst_seg + tnet + box_est (semisup_models.py:69-291).
+    model 'F': same under `class_agnostic/` + `class_dependent/box_refine` (semisup_v1_sunrgbd.py:132-230).
+    model 'boxpc': `box_pc_mask_model` (semisup_models.py:326-398).
+    """
+    oh = NUM_CLASS if use_one_hot else 0
+    L = []
+    if model in ('A', 'F'):
+        p = 'class_agnostic/' if model == 'F' else ''
+        ohA = oh if model == 'A' else 0      # model F never feeds one_hot to the agnostic nets
+        seg = [('conv1', num_channels, 64), ('conv2', 64, 64), ('conv3', 64, 64), ('conv4', 64, 128),
+               ('conv5', 128, 1024), ('conv6', 64 + 1024 + ohA, 512), ('conv7', 512, 256),
+               ('conv8', 256, 128), ('conv9', 128, 128)]
+        for n, ci, co in seg:
+            L.append((p + 'inst_seg/' + n, 'conv', ci, co, True))
+        L.append((p + 'inst_seg/conv10', 'conv', 128, 2, False))
+        for n, ci, co in [('conv-reg1-stage1', 3, 128), ('conv-reg2-stage1', 128, 128),
+                          ('conv-reg3-stage1', 128, 256)]:
+            L.append((p + 'tnet/' + n, 'conv', ci, co, True))
+        L.append((p + 'tnet/fc1-stage1', 'fc', 256 + ohA, 256, True))
+        L.append((p + 'tnet/fc2-stage1', 'fc', 256, 128, True))
+        L.append((p + 'tnet/fc3-stage1', 'fc', 128, 3, False))
+        for n, ci, co in [('conv-reg1', 3, 128), ('conv-reg2', 128, 128), ('conv-reg3', 128, 256),
+                          ('conv-reg4', 256, 512)]:
+            L.append((p + 'box_est/' + n, 'conv', ci, co, True))
+        L.append((p + 'box_est/fc1', 'fc', 512 + ohA, 512, True))
+        L.append((p + 'box_est/fc2', 'fc', 512, 256, True))
+        L.append((p + 'box_est/fc3', 'fc', 256, BOX_OUT_DIMS, False))
+        if model == 'F':
+            q = 'class_dependent/box_refine/'
+            L.append((q + 'fc0', 'fc', 512 + oh, 512, True))
+            L.append((q + 'fc1', 'fc', 512, 256, True))
+            L.append((q + 'fc2', 'fc', 256, BOX_OUT_DIMS, False))
+    elif model == 'boxpc':
+        p = prefix_agnostic + 'box_pc_mask_model/'
+        d = (boxpc_channels if boxpc_channels is not None else num_channels) + 6
+        for n, ci, co in [('conv-reg1', d, 128), ('conv-reg2', 128, 128), ('conv-reg3', 128, 256),
+                          ('conv-reg4', 256, 512)]:
+            L.append((p + n, 'conv', ci, co, True))
+        L.append((p + 'fc1', 'fc', 512 + oh, 512, True))
+        L.append((p + 'fc2', 'fc', 512, 256, True))
+        L.append((p + 'fc3', 'fc', 256, 9, False))
+    else:
+        raise ValueError(model)
+    return L
+
+
+def init_params(rng, table, dtype=torch.float64, first_conv_kernel_is_1xD=True):
+    """Xavier-uniform weights, zero biases, gamma=1, beta=0, moving_mean=0, moving_variance=1
+    (tf_util.py:1165-1190,1312; tf.contrib.layers.batch_norm defaults).
+
+    xavier_initializer(): limit = sqrt(6/(fan_in+fan_out)); for a conv kernel [kh,kw,Cin,Cout],
+    fan_in = kh*kw*Cin and fan_out = kh*kw*Cout.  The first layer of each net that reads the raw
+    point channels is a `[1,D]` kernel over a 1-channel image (semisup_models.py:76, 354), i.e.
+    shape [1,D,1,Cout]: fan_in = D, fan_out = D*Cout.  1x1 kernels [1,1,Cin,Cout]: fan_in = Cin,
+    fan_out = Cout.
+    """
+    P = {}
+    for scope, kind, ci, co, bn in table:
+        one_x_d = kind == 'conv' and (scope.endswith('inst_seg/conv1')
+                                      or scope.endswith('box_pc_mask_model/conv-reg1'))
+        if one_x_d:
+            fan_in, fan_out = ci, ci * co
+            shape = (1, ci, 1, co)
+        elif kind == 'conv':
+            fan_in, fan_out = ci, co
+            shape = (1, 1, ci, co)
+        else:
+            fan_in, fan_out = ci, co
+            shape = (ci, co)
+        lim = math.sqrt(6.0 / (fan_in + fan_out))
+        w = rng.uniform(-lim, lim, size=shape)
+        P[scope + '/weights'] = torch.tensor(w, dtype=dtype)
+        P[scope + '/biases'] = torch.zeros(co, dtype=dtype)
+        if bn:
+            P[scope + '/bn/beta'] = torch.zeros(co, dtype=dtype)
+            P[scope + '/bn/gamma'] = torch.ones(co, dtype=dtype)
+            P[scope + '/bn/moving_mean'] = torch.zeros(co, dtype=dtype)
+            P[scope + '/bn/moving_variance'] = torch.ones(co, dtype=dtype)
+    return P
+
+
+def trainable_names(P):
+    return [k for k in P if not (k.endswith('moving_mean') or k.endswith('moving_variance'))]
+
+
+# ----------------------------------------------------------------------------------------------
+# layer wrappers (tf_util.py:1258-1323, 1463-1499, 1501-1524, 1645-1705, 1720-1741)
+# ----------------------------------------------------------------------------------------------
+class Ctx:
+    """Carries params, training flag, bn_decay, injected dropout masks and collects EMA updates."""
+
+    def __init__(self, P, is_training=True, bn_decay=None, dropout_masks=None, ema_unbiased=True):
+        self.P = P
+        self.is_training = is_training
+        self.bn_decay = 0.9 if bn_decay is None else bn_decay   # tf_util.py:1659
+        self.dropout_masks = dropout_masks or {}
+        self.ema_unbiased = ema_unbiased
+        self.ema_updates = {}
+        self.is_training_override = {}   # scope prefix -> bool (stage c: frozen BoxPC net)
+
+    def training_for(self, scope):
+        for pre, val in self.is_training_override.items():
+            if scope.startswith(pre):
+                return val
+        return self.is_training
+
+
+def batch_norm(ctx, y, scope):
+    """tf.contrib.layers.batch_norm(center, scale, eps=1e-3, decay, updates_collections=None).
+
+    Train: biased batch variance normalises; EMA `m <- m*d + batch*(1-d)`, with the Bessel-corrected
+    variance on the fused path (default; SURVEY Appendix D / E.3, switchable).  Eval: moving stats.
+    """
+    P = ctx.P
+    g, b = P[scope + '/gamma'], P[scope + '/beta']
+    flat = y.reshape(-1, y.shape[-1])
+    if ctx.training_for(scope):
+        mean = flat.mean(0)
+        var = ((flat - mean) ** 2).mean(0)
+        n = flat.shape[0]
+        d = ctx.bn_decay
+        var_ema = var * (n / max(n - 1, 1)) if ctx.ema_unbiased else var
+        ctx.ema_updates[scope + '/moving_mean'] = (P[scope + '/moving_mean'] * d + mean.detach() * (1 - d))
+        ctx.ema_updates[scope + '/moving_variance'] = (P[scope + '/moving_variance'] * d + var_ema.detach() * (1 - d))
+    else:
+        mean, var = P[scope + '/moving_mean'], P[scope + '/moving_variance']
+    return (y - mean) / torch.sqrt(var + BN_EPS) * g + b
+
+
+def _act(x, activation):
+    if activation is None:
+        return x
+    if activation == 'relu':
+        return torch.relu(x)
+    if activation == 'leaky_relu':
+        return F.leaky_relu(x, 0.2)         # tf.nn.leaky_relu default alpha
+    if activation == 'tanh':
+        return torch.tanh(x)
+    raise ValueError(activation)
+
+
+def conv2d(ctx, x, scope, bn=True, activation='relu'):
+    """Per-point 1x1 (or [1,D]) VALID conv == (B*N, Cin) x (Cin, Cout) + bias (+BN) (+act)."""
+    W = ctx.P[scope + '/weights']
+    W = W.reshape(-1, W.shape[-1])
+    y = x @ W + ctx.P[scope + '/biases']
+    if bn:
+        y = batch_norm(ctx, y, scope + '/bn')
+    return _act(y, activation)
+
+
+def fully_connected(ctx, x, scope, bn=False, activation='relu'):
+    y = x @ ctx.P[scope + '/weights'] + ctx.P[scope + '/biases']
+    if bn:
+        y = batch_norm(ctx, y, scope + '/bn')
+    return _act(y, activation)
+
+
+def dropout(ctx, x, scope, keep_prob):
+    """tf.nn.dropout: x * mask / keep in training (mask injected, 0/1), identity otherwise."""
+    if not ctx.training_for(scope):
+        return x
+    m = ctx.dropout_masks[scope]
+    return x * m.to(x.dtype) / keep_prob
+
+
+def max_pool_points(x):
+    """tf.nn.max_pool ksize [1,N,1,1] == max over the point axis."""
+    return x.max(dim=1).values
+
+
+# ----------------------------------------------------------------------------------------------
+# sub-networks (semisup_models.py)
+# ----------------------------------------------------------------------------------------------
+def v1_inst_seg(ctx, pc, one_hot_vec, scope='inst_seg', ep=None):
+    """semisup_models.py:69-139."""
+    B, N, _ = pc.shape
+    net = conv2d(ctx, pc, scope + '/conv1')
+    net = conv2d(ctx, net, scope + '/conv2')
+    point_feat = conv2d(ctx, net, scope + '/conv3')
+    net = conv2d(ctx, point_feat, scope + '/conv4')
+    net = conv2d(ctx, net, scope + '/conv5')
+    global_feat = max_pool_points(net)                              # (B,1024)
+    if ep is not None:
+        ep['seg_global_feat'] = global_feat
+    if one_hot_vec is not None:
+        global_feat = torch.cat([global_feat, one_hot_vec], dim=1)
+    concat = torch.cat([point_feat, global_feat[:, None, :].expand(B, N, global_feat.shape[1])], dim=2)
+    net = conv2d(ctx, concat, scope + '/conv6')
+    net = conv2d(ctx, net, scope + '/conv7')
+    net = conv2d(ctx, net, scope + '/conv8')
+    net = conv2d(ctx, net, scope + '/conv9')
+    net = dropout(ctx, net, scope + '/dp1', 0.5)
+    logits = conv2d(ctx, net, scope + '/conv10', bn=False, activation=None)
+    return logits                                                    # (B,N,2)
+
+
+def subtract_points_mean(pc, logits):
+    """semisup_models.py:145-162.  mask is a hard comparison: no gradient."""
+    mask = (logits[:, :, 0:1] < logits[:, :, 1:2]).to(pc.dtype)      # (B,N,1)
+    mask_count = mask.sum(dim=1, keepdim=True).expand(-1, -1, 3)
+    xyz = pc[:, :, 0:3]
+    mean = (mask * xyz).sum(dim=1, keepdim=True) / torch.clamp(mask_count, min=1.0)
+    return mask, mean, xyz, xyz - mean
+
+
+def v1_tnet(ctx, xyz_stage1, mask, mask_xyz_mean, one_hot_vec, ep, scope='tnet'):
+    """semisup_models.py:164-202."""
+    net = conv2d(ctx, xyz_stage1, scope + '/conv-reg1-stage1')
+    net = conv2d(ctx, net, scope + '/conv-reg2-stage1')
+    net = conv2d(ctx, net, scope + '/conv-reg3-stage1')
+    net = max_pool_points(net * mask)
+    ep['tnet_feats'] = net
+    if one_hot_vec is not None:
+        net = torch.cat([net, one_hot_vec], dim=1)
+    net = fully_connected(ctx, net, scope + '/fc1-stage1', bn=True)
+    net = fully_connected(ctx, net, scope + '/fc2-stage1', bn=True)
+    c = fully_connected(ctx, net, scope + '/fc3-stage1', activation=None)
+    c = c + mask_xyz_mean[:, 0, :]
+    ep['stage1_center'] = c
+    return c
+
+
+def _slice_box_heads(out, stage1_center, ep, prefix, dtype):
+    """semisup_models.py:265-290 / semisup_v1_sunrgbd.py:203-222."""
+    B = out.shape[0]
+    NH, NS = NUM_HEADING_BIN, NUM_SIZE_CLUSTER
+    mean_dims = torch.tensor(MEAN_DIMS_ARR, dtype=torch.float32).to(dtype)
+    ep[prefix + 'center'] = out[:, 0:3] + stage1_center
+    ep[prefix + 'heading_scores'] = out[:, 3:3 + NH]
+    hrn = out[:, 3 + NH:3 + 2 * NH]
+    ep[prefix + 'heading_residuals_normalized'] = hrn
+    ep[prefix + 'heading_residuals'] = hrn * (np.pi / NH)
+    ep[prefix + 'size_scores'] = out[:, 3 + 2 * NH:3 + 2 * NH + NS]
+    srn = out[:, 3 + 2 * NH + NS:3 + 2 * NH + 4 * NS].reshape(B, NS, 3)
+    ep[prefix + 'size_residuals_normalized'] = srn
+    ep[prefix + 'size_residuals'] = srn * mean_dims[None]
+    return (ep[prefix + 'center'], ep[prefix + 'size_scores'], ep[prefix + 'size_residuals'],
+            ep[prefix + 'heading_scores'], ep[prefix + 'heading_residuals'])
+
+
+def v1_box_est(ctx, xyz_submean, stage1_center, mask, one_hot_vec, ep, prefix='', scope='box_est'):
+    """semisup_models.py:215-291."""
+    net = conv2d(ctx, xyz_submean, scope + '/conv-reg1')
+    net = conv2d(ctx, net, scope + '/conv-reg2')
+    net = conv2d(ctx, net, scope + '/conv-reg3')
+    net = conv2d(ctx, net, scope + '/conv-reg4')
+    net = max_pool_points(net * mask)
+    ep[prefix + 'feats_lv1'] = net
+    if one_hot_vec is not None:
+        net = torch.cat([net, one_hot_vec], dim=1)
+    net = fully_connected(ctx, net, scope + '/fc1', bn=True)
+    ep[prefix + 'feats_lv2'] = net
+    net = fully_connected(ctx, net, scope + '/fc2', bn=True)
+    ep[prefix + 'feats_lv3'] = net
+    out = fully_connected(ctx, net, scope + '/fc3', activation=None)
+    ep[prefix + 'box_params'] = out
+    return _slice_box_heads(out, stage1_center, ep, prefix, out.dtype)
+
+
+def anchor_to_reg(pred_box, dtype):
+    """tf_util.py:1001-1041: argmax size/heading bin -> dims=max(anchor+res,1e-5), theta=bin+res."""
+    center, size_scores, size_res, heading_scores, heading_res = pred_box
+    B = center.shape[0]
+    anchors = torch.tensor(MEAN_DIMS_ARR, dtype=torch.float32).to(dtype)
+    orient = torch.tensor(ORIENT_ANCHORS, dtype=torch.float32).to(dtype)
+    k = torch.argmax(size_scores, dim=1)
+    j = torch.argmax(heading_scores, dim=1)
+    ar = torch.arange(B)
+    dims = torch.clamp(anchors[k] + size_res[ar, k], min=1e-5)
+    theta = orient[j] + heading_res[ar, j]
+    return center, dims, theta
+
+
+def get_semi_model_backbone(ctx, pc, one_hot_vec, use_one_hot=False):
+    """semisup_v1_sunrgbd.py:81-130 (SEMI_MODEL A)."""
+    ep = {'point_cloud': pc, 'class_one_hot': one_hot_vec,
+          'class_ids': torch.argmax(one_hot_vec, dim=1).to(torch.int32)}
+    oh = one_hot_vec if use_one_hot else None
+    logits = v1_inst_seg(ctx, pc, oh, 'inst_seg', ep)
+    ep['logits'] = logits
+    ep['soft_mask'] = torch.softmax(logits, dim=-1)[:, :, 1]
+    mask, mean, xyz, xyz1 = subtract_points_mean(pc, logits)
+    ep['mask'] = mask
+    ep['mask_xyz_mean'] = mean
+    s1 = v1_tnet(ctx, xyz1, mask, mean, oh, ep, 'tnet')
+    xyz2 = xyz - s1[:, None, :]
+    pred_box = v1_box_est(ctx, xyz2, s1, mask, oh, ep, '', 'box_est')
+    ep['S_pred_box'] = pred_box
+    ep['S_pred_box_reg'] = anchor_to_reg(pred_box, pc.dtype)
+    return (logits, pred_box), ep
+
+
+def mlps_with_dropout(ctx, x, scope, n_layers, activations, keep_probs):
+    """semisup_models.py:44-63: hidden = FC+BN+act then dropout; last = FC, no BN."""
+    net = x
+    for i in range(n_layers):
+        last = i == n_layers - 1
+        net = fully_connected(ctx, net, '%s/fc%d' % (scope, i), bn=not last, activation=activations[i])
+        if not last:
+            net = dropout(ctx, net, '%s/dp%d' % (scope, i), keep_probs[i])
+    return net
+
+
+def get_semi_model_final(ctx, pc, one_hot_vec, use_one_hot, c):
+    """semisup_v1_sunrgbd.py:132-230 (SEMI_MODEL F)."""
+    ep = {'point_cloud': pc, 'class_one_hot': one_hot_vec,
+          'class_ids': torch.argmax(one_hot_vec, dim=1).to(torch.int32)}
+    p = 'class_agnostic/'
+    logits = v1_inst_seg(ctx, pc, None, p + 'inst_seg', ep)
+    ep['logits'] = logits
+    mask, mean, xyz, xyz1 = subtract_points_mean(pc, logits)
+    ep['mask'] = mask
+    ep['mask_xyz_mean'] = mean
+    s1 = v1_tnet(ctx, xyz1, mask, mean, None, ep, p + 'tnet')
+    xyz2 = xyz - s1[:, None, :]
+    W_pred_box = v1_box_est(ctx, xyz2, s1, mask, None, ep, '', p + 'box_est')
+    feat = ep['feats_lv1']
+    if use_one_hot:
+        feat = torch.cat([feat, one_hot_vec], dim=1)
+    act = 'leaky_relu' if c.SEMI_ADV_LEAKY_RELU else 'relu'
+    last = 'tanh' if c.SEMI_ADV_TANH_FOR_LAST_LAYER_OF_G else act
+    dp = c.SEMI_ADV_DROPOUTS_FOR_G
+    out = mlps_with_dropout(ctx, feat, 'class_dependent/box_refine', 3, [act, last, None], [dp, dp, None])
+    ep['F_box_params'] = out
+    F_pred_box = _slice_box_heads(out, s1, ep, 'F_', out.dtype)
+    ep['F_pred_box_reg'] = anchor_to_reg(F_pred_box, pc.dtype)
+    return (logits, W_pred_box, F_pred_box), ep
+
+
+# ----------------------------------------------------------------------------------------------
+# Box-PC Fit net (tf_util.py:764-795, 893-955; semisup_models.py:326-398; boxpc_sunrgbd.py)
+# ----------------------------------------------------------------------------------------------
+def box_pc_representation(box_reg, pc):
+    """Six signed point-to-face distances of every point to the (centre, (l,w,h), theta) box,
+    concatenated to the raw point channels (tf_util.py:764-795, 893-942)."""
+    center, dims, theta = box_reg
+    l, w, h = dims[:, 0], dims[:, 1], dims[:, 2]
+    s, c = torch.sin(theta), torch.cos(theta)
+    z = torch.zeros_like(s)
+    o = torch.ones_like(s)
+    R = torch.stack([torch.stack([c, z, s], 1), torch.stack([z, o, z], 1), torch.stack([-s, z, c], 1)], 1)  # (B,3,3)
+    pts = torch.stack([torch.stack([l / 2, -l / 2, z, z, z, z], 1),
+                       torch.stack([z, z, h / 2, -h / 2, z, z], 1),
+                       torch.stack([z, z, z, z, w / 2, -w / 2], 1)], 1)                                     # (B,3,6)
+    nrm = torch.tensor([[-1., 1., 0., 0., 0., 0.], [0., 0., -1., 1., 0., 0.], [0., 0., 0., 0., -1., 1.]],
+                       dtype=pc.dtype)
+    spts = torch.matmul(R, pts).transpose(1, 2)                     # (B,6,3)
+    snrm = torch.matmul(R, nrm[None].expand(R.shape[0], 3, 6)).transpose(1, 2)
+    t = pc[:, :, 0:3] - center[:, None, :]                           # (B,N,3)
+    ray = t[:, :, None, :] - spts[:, None, :, :]                     # (B,N,6,3)
+    d = (snrm[:, None, :, :] * ray).sum(-1)                          # (B,N,6)
+    return torch.cat([pc, d], dim=2)
+
+
+def boxpc_get_model(ctx, box_reg, pc, one_hot_vec, use_one_hot_vec, c, scope_prefix=''):
+    """boxpc_sunrgbd.py:56-100 + semisup_models.py:326-398 (representation 'A')."""
+    ep = {'class_ids': torch.argmax(one_hot_vec, dim=1).to(torch.int32)}
+    sc = scope_prefix + 'box_pc_mask_model'
+    rep = box_pc_representation(box_reg, pc)
+    ep['box_pc_rep'] = rep
+    net = conv2d(ctx, rep, sc + '/conv-reg1')
+    net = conv2d(ctx, net, sc + '/conv-reg2')
+    net = conv2d(ctx, net, sc + '/conv-reg3')
+    net = conv2d(ctx, net, sc + '/conv-reg4')
+    net = max_pool_points(net)
+    if use_one_hot_vec:
+        net = torch.cat([net, one_hot_vec], dim=1)
+    f1 = net
+    net = fully_connected(ctx, net, sc + '/fc1', bn=True)
+    f2 = net
+    net = dropout(ctx, net, sc + '/dp1', 0.7)
+    net = fully_connected(ctx, net, sc + '/fc2', bn=True)
+    f3 = net
+    net = dropout(ctx, net, sc + '/dp2', 0.7)
+    out = fully_connected(ctx, net, sc + '/fc3', activation=None)
+    ep['boxpc_out'] = out
+    ep['boxpc_feats_dict'] = {'box_pc_mask_model_feats_lv1': f1, 'box_pc_mask_model_feats_lv2': f2,
+                              'box_pc_mask_model_feats_lv3': f3}
+    fit_logits = out[:, -2:]
+    p1 = torch.softmax(fit_logits, dim=-1)[:, 1]
+    ep['boxpc_fit_logits'] = fit_logits
+    ep['pred_boxpc_fit'] = (p1 > 0.5).to(torch.int32)
+    lw = p1.detach() if c.BOXPC_STOP_GRAD_OF_CLS_VIA_DELTA else p1
+    ep['logits_for_weigh'] = lw
+    dc, ds, da = out[:, 0:3], out[:, 3:6], out[:, 6]
+    if c.BOXPC_WEIGH_DELTA_PRED_BY_CLS_CONF:
+        wd = 1.0 - lw
+        dc, ds, da = dc * wd[:, None], ds * wd[:, None], da * wd
+    ep['boxpc_delta_center'], ep['boxpc_delta_size'], ep['boxpc_delta_angle'] = dc, ds, da
+    return (fit_logits, (dc, ds, da)), ep
+
+
+def tf_huber(labels, pred, delta=1.0):
+    """tf.losses.huber_loss elementwise (reduction NONE)."""
+    e = (pred - labels).abs()
+    q = torch.clamp(e, max=delta)
+    return 0.5 * q * q + delta * (e - q)
+
+
+def boxpc_get_loss(pred, labels, ep, c, reduce_loss=True):
+    """boxpc_sunrgbd.py:106-193."""
+    logits, (dc, ds, da) = pred
+    y_iou, (ydc, yds, yda) = labels
+    cls = (y_iou > c.BOXPC_FIT_BOUNDS[0]).long()
+    cls_losses = F.cross_entropy(logits, cls, reduction='none')
+    lc = tf_huber(ydc, dc).mean(1)
+    ls = tf_huber(yds, ds).mean(1)
+    la = tf_huber(yda, da)
+    wl = 1.0
+    if c.BOXPC_WEIGH_DELTA_LOSS_BY_CLS_CONF:
+        wl = 1.0 - ep['logits_for_weigh']
+    if c.BOXPC_WEIGH_DELTA_LOSS_BY_CLS_GT:
+        wl = 1.0 - y_iou
+    delta_losses = (c.BOXPC_WEIGHT_DELTA_CENTER_PERCENT * lc * wl + c.BOXPC_WEIGHT_DELTA_SIZE_PERCENT * ls * wl
+                    + c.BOXPC_WEIGHT_DELTA_ANGLE_PERCENT * la * wl)
+    ep['boxpc_cls_losses'] = cls_losses
+    ep['boxpc_delta_losses'] = delta_losses
+    total = c.BOXPC_WEIGHT_CLS * cls_losses + c.BOXPC_WEIGHT_DELTA * delta_losses
+    return total.mean() if reduce_loss else total
+
+
+def convert_raw_y_box_to_reg_format(y_box, dtype):
+    """boxpc_sunrgbd.py:206-230: one-hot the GT bins, then the same anchor->reg op."""
+    yc, yoc, yor, ydc, ydr = y_box
+    anchors = torch.tensor(MEAN_DIMS_ARR, dtype=torch.float32).to(dtype)
+    orient = torch.tensor(ORIENT_ANCHORS, dtype=torch.float32).to(dtype)
+    dims = torch.clamp(anchors[ydc.long()] + ydr, min=1e-5)
+    theta = orient[yoc.long()] + yor
+    return yc, dims, theta
+
+
+# ----------------------------------------------------------------------------------------------
+# losses (semisup_v1_sunrgbd.py:248-564, model_util.py:94-167, weak_losses.py:267-291)
+# ----------------------------------------------------------------------------------------------
+def huber_loss(error, delta):
+    """semisup_v1_sunrgbd.py:555-564."""
+    a = error.abs()
+    q = torch.clamp(a, max=delta)
+    return 0.5 * q ** 2 + delta * (a - q)
+
+
+def box3d_corners_helper(centers, headings, sizes):
+    """model_util.py:94-119.  (N,3),(N,),(N,3) -> (N,8,3)."""
+    l, w, h = sizes[:, 0:1], sizes[:, 1:2], sizes[:, 2:3]
+    xc = torch.cat([l / 2, l / 2, -l / 2, -l / 2, l / 2, l / 2, -l / 2, -l / 2], 1)
+    yc = torch.cat([h / 2, h / 2, h / 2, h / 2, -h / 2, -h / 2, -h / 2, -h / 2], 1)
+    zc = torch.cat([w / 2, -w / 2, -w / 2, w / 2, w / 2, -w / 2, -w / 2, w / 2], 1)
+    corners = torch.stack([xc, yc, zc], 1)                          # (N,3,8)
+    c, s = torch.cos(headings), torch.sin(headings)
+    z, o = torch.zeros_like(c), torch.ones_like(c)
+    R = torch.stack([torch.stack([c, z, s], 1), torch.stack([z, o, z], 1), torch.stack([-s, z, c], 1)], 1)
+    out = torch.matmul(R, corners) + centers[:, :, None]
+    return out.transpose(1, 2)
+
+
+def get_strong_loss(pred, labels, ep, c, prefix=''):
+    """semisup_v1_sunrgbd.py:423-553.  Returns per-frustum (mask_losses, box_losses)."""
+    pred_seg, _ = pred
+    y_seg, y_center, y_orient_cls, y_orient_reg, y_dims_cls, y_dims_reg = labels
+    dtype = pred_seg.dtype
+    B, N, _ = pred_seg.shape
+    NH, NS = NUM_HEADING_BIN, NUM_SIZE_CLUSTER
+    mean_dims = torch.tensor(MEAN_DIMS_ARR, dtype=torch.float32).to(dtype)
+
+    mask_losses = F.cross_entropy(pred_seg.reshape(B * N, 2), y_seg.reshape(-1).long(),
+                                  reduction='none').reshape(B, N).mean(1)
+    center_dist = torch.norm(y_center - ep[prefix + 'center'], dim=-1)
+    center_losses = huber_loss(center_dist, 2.0)
+    s1_dist = torch.norm(y_center - ep['stage1_center'], dim=-1)
+    s1_losses = huber_loss(s1_dist, 1.0)
+
+    hcls_losses = F.cross_entropy(ep[prefix + 'heading_scores'], y_orient_cls.long(), reduction='none')
+    hoh = F.one_hot(y_orient_cls.long(), NH).to(dtype)
+    hres_label = y_orient_reg / (np.pi / NH)
+    hres_losses = huber_loss((ep[prefix + 'heading_residuals_normalized'] * hoh).sum(1) - hres_label, 1.0)
+
+    scls_losses = F.cross_entropy(ep[prefix + 'size_scores'], y_dims_cls.long(), reduction='none')
+    soh = F.one_hot(y_dims_cls.long(), NS).to(dtype)
+    pred_srn = (ep[prefix + 'size_residuals_normalized'] * soh[:, :, None]).sum(1)
+    mean_size_label = (soh[:, :, None] * mean_dims[None]).sum(1)
+    srn_label = y_dims_reg / mean_size_label
+    sres_losses = huber_loss(torch.norm(srn_label - pred_srn, dim=-1), 1.0)
+
+    # Corner loss.  get_box3d_corners_sunrgbd adds the size residual TWICE (model_util.py:158-159).
+    center = ep[prefix + 'center']
+    hres = ep[prefix + 'heading_residuals']
+    sres = ep[prefix + 'size_residuals']
+    bins = torch.tensor(ORIENT_ANCHORS, dtype=torch.float32).to(dtype)
+    headings = hres + bins[None]                                    # (B,NH)
+    sizes = (mean_dims[None] + sres) + sres                         # (B,NS,3)
+    sizes_t = sizes[:, None].expand(B, NH, NS, 3).reshape(-1, 3)
+    head_t = headings[:, :, None].expand(B, NH, NS).reshape(-1)
+    cent_t = center[:, None, None, :].expand(B, NH, NS, 3).reshape(-1, 3)
+    corners = box3d_corners_helper(cent_t, head_t, sizes_t).reshape(B, NH, NS, 8, 3)
+    gt_mask = hoh[:, :, None] * soh[:, None, :]
+    corners_pred = (gt_mask[:, :, :, None, None] * corners).sum(dim=(1, 2))       # (B,8,3)
+    heading_label = ((y_orient_reg[:, None] + bins[None]) * hoh).sum(1)
+    size_label = (soh[:, :, None] * (mean_dims[None] + y_dims_reg[:, None, :])).sum(1)
+    cg = box3d_corners_helper(y_center, heading_label, size_label)
+    cgf = box3d_corners_helper(y_center, heading_label + np.pi, size_label)
+    cdist = torch.minimum(torch.norm(corners_pred - cg, dim=-1), torch.norm(corners_pred - cgf, dim=-1))
+    corner_losses = huber_loss(cdist, 1.0).mean(1)
+
+    terms = dict(mask=mask_losses, center=center_losses, stage1=s1_losses, hcls=hcls_losses,
+                 hres=hres_losses, scls=scls_losses, sres=sres_losses, corner=corner_losses)
+    ep[prefix + 'loss_terms'] = terms
+    mask_l = c.STRONG_WEIGHT_CROSS_ENTROPY * mask_losses
+    box_l = c.STRONG_BOX_MULTIPLER * (c.STRONG_WEIGHT_CENTER * center_losses
+                                      + c.STRONG_WEIGHT_ORIENT_CLS * hcls_losses
+                                      + c.STRONG_WEIGHT_DIMS_CLS * scls_losses
+                                      + c.STRONG_WEIGHT_ORIENT_REG * hres_losses
+                                      + c.STRONG_WEIGHT_DIMS_REG * sres_losses
+                                      + c.STRONG_WEIGHT_TNET_CENTER * s1_losses) \
+        + c.STRONG_WEIGHT_CORNER * corner_losses
+    return mask_l, box_l
+
+
+def get_semi_loss_backbone(pred, labels, ep, c):
+    """semisup_v1_sunrgbd.py:256-321 with the zero-weight weak losses skipped (SURVEY App. E.4:
+    recipe a sets WEAK_WEIGHT_REPROJECTION = WEAK_WEIGHT_SURFACE = 0)."""
+    assert c.WEAK_WEIGHT_REPROJECTION == 0 and c.WEAK_WEIGHT_SURFACE == 0, \
+        'weak reprojection/surface losses are out of scope (zero weight in every published recipe)'
+    y_seg, y_center, yoc, yor, ydc, ydr, is2d = labels
+    mask_l, box_l = get_strong_loss(pred, (y_seg, y_center, yoc, yor, ydc, ydr), ep, c)
+    w3 = (1 - is2d).to(mask_l.dtype)
+    total = w3 * (mask_l + box_l)        # + is2d * 0
+    ep['total_losses'] = total
+    return total.mean()
+
+
+def intraclass_variance_loss(dims_reg, class_ids, train_classes):
+    """weak_losses.py:267-291 (huber): per trained class, tf.losses.huber_loss(mean over elements,
+    0 for an empty partition) of the dims to the stop-gradient class-batch mean; mean over the
+    trained classes."""
+    losses = []
+    for i, on in enumerate(train_classes):
+        if not on:
+            continue
+        sel = dims_reg[class_ids.long() == i]
+        if sel.shape[0] == 0:
+            losses.append(torch.zeros((), dtype=dims_reg.dtype))
+            continue
+        m = sel.mean(0).detach()
+        losses.append(tf_huber(m[None].expand_as(sel), sel).mean())
+    return torch.stack(losses).mean()
+
+
+def get_semi_loss_final(pred, labels, ep, c):
+    """semisup_v1_sunrgbd.py:323-421 (SEMI_MODEL F)."""
+    pred_seg, _, F_pred_box = pred
+    y_seg, y_center, yoc, yor, ydc, ydr, is2d = labels
+    mask_l, box_l = get_strong_loss((pred_seg, F_pred_box), (y_seg, y_center, yoc, yor, ydc, ydr), ep, c,
+                                    prefix='F_')
+    w3 = (1 - is2d).to(mask_l.dtype)
+    denom = w3.sum() + 1e-3
+    strong = (mask_l * w3).sum() / denom + (box_l * w3).sum() / denom
+    weak = torch.zeros((), dtype=mask_l.dtype)
+    if c.WEAK_WEIGHT_INTRACLASSVAR != 0:
+        _, F_dims, _ = ep['F_pred_box_reg']
+        icv = intraclass_variance_loss(F_dims, ep['class_ids'], ep['intraclsdims_train_classes'])
+        ep['intraclass_variance_loss'] = icv
+        weak = weak + c.WEAK_WEIGHT_INTRACLASSVAR * icv
+    assert c.WEAK_WEIGHT_REPROJECTION == 0 and c.WEAK_WEIGHT_INACTIVE_VOLUME == 0
+    total = strong + c.SEMI_MULTIPLIER_FOR_WEAK_LOSS * weak
+    if c.SEMI_WEIGHT_BOXPC_FIT_LOSS != 0:
+        fit = -torch.log(0.01 + ep['boxpc_fit_prob'])
+        if c.SEMI_BOXPC_FIT_ONLY_ON_2D_CLS:
+            fit = fit * is2d.to(fit.dtype)
+        total = total + c.SEMI_WEIGHT_BOXPC_FIT_LOSS * fit.mean()
+    return total
+
+
+# ----------------------------------------------------------------------------------------------
+# optimiser + schedules (train_semisup.py:127-145, 229-231; tf.train.AdamOptimizer)
+# ----------------------------------------------------------------------------------------------
+def learning_rate(step, batch_size, base=1e-3, decay_step=800000, decay_rate=0.5):
+    """exponential_decay(staircase=True); the clip at train_semisup.py:134 is a no-op (typo)."""
+    return base * decay_rate ** math.floor(step * batch_size / decay_step)
+
+
+def bn_decay(step, batch_size, decay_step=800000.0):
+    """train_semisup.py:137-145: min(0.99, 1 - 0.5*0.5^floor(step*B/decay_step))."""
+    return min(0.99, 1 - 0.5 * 0.5 ** math.floor(step * batch_size / decay_step))
+
+
+def adam_tf_step(P, grads, m, v, t, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    """TF form: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); w -= lr_t*m/(sqrt(v)+eps); t starts at 1."""
+    lr_t = lr * math.sqrt(1 - beta2 ** t) / (1 - beta1 ** t)
+    for k, g in grads.items():
+        m[k] = beta1 * m[k] + (1 - beta1) * g
+        v[k] = beta2 * v[k] + (1 - beta2) * g * g
+        P[k] = P[k] - lr_t * m[k] / (torch.sqrt(v[k]) + eps)
+
+
+# ----------------------------------------------------------------------------------------------
+# one full training step (what bench.py's cpu_baseline leg times and the fixtures freeze)
+# ----------------------------------------------------------------------------------------------
+def default_config(**over):
+    c = SimpleNamespace(
+        SEMI_MODEL='A', WEAK_WEIGHT_REPROJECTION=0.0, WEAK_WEIGHT_SURFACE=0.0, WEAK_WEIGHT_INACTIVE_VOLUME=0.0,
+        WEAK_WEIGHT_INTRACLASSVAR=0.0, SEMI_MULTIPLIER_FOR_WEAK_LOSS=1.0, SEMI_WEIGHT_BOXPC_FIT_LOSS=1.0,
+        SEMI_BOXPC_FIT_ONLY_ON_2D_CLS=False, SEMI_ADV_LEAKY_RELU=True, SEMI_ADV_TANH_FOR_LAST_LAYER_OF_G=True,
+        SEMI_ADV_DROPOUTS_FOR_G=0.5, SEMI_REFINE_USING_BOXPC_DELTA_NUM=1, SEMI_BOXPC_MIN_FIT_LOSS_AFT_REFINE=False,
+        SEMI_WEIGH_BOXPC_DELTA_DURING_TEST=False,
+        STRONG_WEIGHT_CROSS_ENTROPY=1.0, STRONG_BOX_MULTIPLER=0.1, STRONG_WEIGHT_CENTER=1.0,
+        STRONG_WEIGHT_ORIENT_CLS=1.0, STRONG_WEIGHT_ORIENT_REG=20.0, STRONG_WEIGHT_DIMS_CLS=1.0,
+        STRONG_WEIGHT_DIMS_REG=20.0, STRONG_WEIGHT_TNET_CENTER=1.0, STRONG_WEIGHT_CORNER=1.0,
+        BOXPC_FIT_BOUNDS=[0.7, 1.0], BOXPC_STOP_GRAD_OF_CLS_VIA_DELTA=True,
+        BOXPC_WEIGH_DELTA_PRED_BY_CLS_CONF=False, BOXPC_WEIGH_DELTA_LOSS_BY_CLS_CONF=False,
+        BOXPC_WEIGH_DELTA_LOSS_BY_CLS_GT=False, BOXPC_WEIGHT_CLS=1.0, BOXPC_WEIGHT_DELTA=1.0,
+        BOXPC_WEIGHT_DELTA_CENTER_PERCENT=0.34, BOXPC_WEIGHT_DELTA_SIZE_PERCENT=0.33,
+        BOXPC_WEIGHT_DELTA_ANGLE_PERCENT=0.33, BOXPC_DELTA_LOSS_TYPE='huber', BOX_PC_MASK_REPRESENTATION='A')
+    for k, val in over.items():
+        setattr(c, k, val)
+    return c
+
+
+def _labels_to_torch(batch, dtype):
+    return (torch.as_tensor(batch['y_seg']), torch.as_tensor(batch['y_center'], dtype=dtype),
+            torch.as_tensor(batch['y_orient_cls']), torch.as_tensor(batch['y_orient_reg'], dtype=dtype),
+            torch.as_tensor(batch['y_dims_cls']), torch.as_tensor(batch['y_dims_reg'], dtype=dtype),
+            torch.as_tensor(batch['is_data_2D']))
+
+
+def model_a_forward_backward(P, batch, c, bn_decay_val=0.5, dtype=torch.float64, use_one_hot=False,
+                             is_training=True, want_grads=True):
+    """fwd (+bwd) of SEMI_MODEL A on one batch.  Returns (loss, end_points, grads, ema_updates)."""
+    names = trainable_names(P)
+    Pl = {k: (val.detach().to(dtype).requires_grad_(k in names and want_grads)) for k, val in P.items()}
+    masks = {k: torch.as_tensor(val) for k, val in batch.get('dropout_masks', {}).items()}
+    ctx = Ctx(Pl, is_training=is_training, bn_decay=bn_decay_val, dropout_masks=masks)
+    pc = torch.as_tensor(batch['pc'], dtype=dtype)
+    oh = torch.as_tensor(batch['one_hot_vec'], dtype=dtype)
+    pred, ep = get_semi_model_backbone(ctx, pc, oh, use_one_hot)
+    loss = get_semi_loss_backbone(pred, _labels_to_torch(batch, dtype), ep, c)
+    grads = {}
+    if want_grads:
+        gl = torch.autograd.grad(loss, [Pl[k] for k in names], allow_unused=True)
+        grads = {k: (g if g is not None else torch.zeros_like(Pl[k])) for k, g in zip(names, gl)}
+    return loss, ep, grads, ctx.ema_updates
+
+
+def boxpc_forward_backward(P, batch, c, bn_decay_val=0.5, dtype=torch.float64, is_training=True,
+                           want_grads=True):
+    """fwd (+bwd) of the Box-PC Fit net (train_boxpc.py path) on one batch."""
+    names = trainable_names(P)
+    Pl = {k: (val.detach().to(dtype).requires_grad_(k in names and want_grads)) for k, val in P.items()}
+    masks = {k: torch.as_tensor(val) for k, val in batch.get('dropout_masks', {}).items()}
+    ctx = Ctx(Pl, is_training=is_training, bn_decay=bn_decay_val, dropout_masks=masks)
+    pc = torch.as_tensor(batch['pc'], dtype=dtype)
+    oh = torch.as_tensor(batch['one_hot_vec'], dtype=dtype)
+    y_box = (torch.as_tensor(batch['y_center'], dtype=dtype), torch.as_tensor(batch['y_orient_cls']),
+             torch.as_tensor(batch['y_orient_reg'], dtype=dtype), torch.as_tensor(batch['y_dims_cls']),
+             torch.as_tensor(batch['y_dims_reg'], dtype=dtype))
+    box_reg = convert_raw_y_box_to_reg_format(y_box, dtype)
+    pred, ep = boxpc_get_model(ctx, box_reg, pc, oh, False, c)
+    labels = (torch.as_tensor(batch['y_box_iou'], dtype=dtype),
+              (torch.as_tensor(batch['y_center_delta'], dtype=dtype),
+               torch.as_tensor(batch['y_dims_delta'], dtype=dtype),
+               torch.as_tensor(batch['y_orient_delta'], dtype=dtype)))
+    loss = boxpc_get_loss(pred, labels, ep, c)
+    grads = {}
+    if want_grads:
+        gl = torch.autograd.grad(loss, [Pl[k] for k in names], allow_unused=True)
+        grads = {k: (g if g is not None else torch.zeros_like(Pl[k])) for k, g in zip(names, gl)}
+    return loss, ep, grads, ctx.ema_updates
