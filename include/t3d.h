@@ -1,0 +1,383 @@
+/*
+ * t3d.h -- C ABI of the MI355X-native Frustum-PointNet training path (libt3d.so).
+ *
+ * The reference (yewsiang/Transferable3D) has no FFI layer: its hot path is stock TensorFlow-1 ops
+ * reached through the Python wrappers in models/tf_util.py.  Each entry point below therefore cites
+ * the reference call site(s) whose arithmetic it replaces; the Python side of the boundary
+ * (transferable3d_amd/tf_util.py, semisup_models.py, ...) keeps the reference's function names.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, `int` return: 0 = T3D_OK, negative = T3D_ERR_*.
+ *   - every buffer is a caller-owned DEVICE pointer (the library never allocates or frees);
+ *     scratch (partials, slabs) is passed in explicitly.
+ *   - all matrices are row-major, channel fastest: a (B, N, C) point tensor is an (M = B*N, C)
+ *     matrix, exactly the reference's NHWC layout with H = N, W = 1.
+ *   - `stream` is a hipStream_t; kernels are enqueued, never synchronised.  No global state.
+ *   - "partials" are per-128-row-tile column reductions ([M/128, C], T3D_TILE_ROWS rows each) that a
+ *     finalize kernel combines deterministically (no float atomics anywhere on the path).
+ *   - M must be a multiple of T3D_TILE_ROWS and rows_per_frustum (the point count N) a multiple of
+ *     T3D_TILE_ROWS, so that a tile never straddles two frustums.
+ */
+#ifndef T3D_H_
+#define T3D_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define T3D_OK 0
+#define T3D_ERR_ARG (-1)     /* null / inconsistent argument */
+#define T3D_ERR_SHAPE (-2)   /* unsupported shape (alignment, divisibility) */
+#define T3D_ERR_LAUNCH (-3)  /* HIP launch failure */
+
+#define T3D_TILE_ROWS 128
+
+typedef void* t3d_stream_t;
+
+enum { T3D_ACT_NONE = 0, T3D_ACT_RELU = 1, T3D_ACT_LEAKY_RELU = 2, T3D_ACT_TANH = 3 };
+
+int t3d_abi_version(void);
+
+/* ---- operand descriptors ------------------------------------------------------------------ */
+
+/* A per-point activation operand produced lazily from the RAW output of the previous layer:
+ *   a[m,k] = relu?( x[m, coff+k] * scale[k] + shift[k] ) - sub[b(m), k]
+ * scale/shift (batch-norm apply, tf_util.py:1316-1322) and sub (per-frustum recentring,
+ * semisup_models.py:159,207) are optional (NULL).  ldx and coff must be multiples of 4. */
+typedef struct {
+  const float* x;
+  int ldx;
+  int coff;
+  const float* scale;
+  const float* shift;
+  int relu;
+  const float* sub;      /* [B, sub_ld] */
+  int sub_ld;
+} t3d_act_src;
+
+/* The gradient w.r.t. a layer's RAW conv output, produced lazily while loading:
+ *   dy[m,n] = coef[0,n]*dz[m,n] + coef[1,n]*y[m,n] + coef[2,n]
+ * (training-mode batch-norm backward folded into three per-channel constants by
+ * t3d_bn_bwd_finalize).  dz is either dense [M,N] or, for a max-pooled layer, sparse:
+ * dz[m,n] = dpool[b,n] if argidx[b,n] == m - b*rows_per_frustum else 0. */
+typedef struct {
+  const float* dz;        /* dense [M,N], or NULL for the pooled-sparse form */
+  const float* y;         /* [M,N] raw conv output of this layer */
+  const float* coef;      /* [3,N] */
+  const int32_t* argidx;  /* [B,N] (pooled-sparse form) */
+  const float* dpool;     /* [B,N] (pooled-sparse form) */
+} t3d_dy_src;
+
+/* ---- K1: per-point shared-MLP layer, forward ---------------------------------------------------
+ * Replaces tf_util.conv2d's tf.nn.conv2d(1x1 | [1,D], VALID) + bias_add (tf_util.py:1308-1314) at
+ * semisup_models.py:76-95,115-130 (seg), 172-183 (T-Net), 224-239 (box), 354-369 (Box-PC); the
+ * batch-norm + ReLU of the PREVIOUS layer is applied while loading `a` (t3d_act_src), this layer's
+ * batch-norm statistics are reduced in the epilogue, and conv6's tile+concat of the global feature
+ * (semisup_models.py:107-108) enters as the per-frustum `rowbias` (= global . W[64:]).
+ *   y[m,n] = sum_k a[m,k] w[k,n] + bias[n] + rowbias[b(m), n]
+ *   psum[t,n] = sum_{m in tile t} y[m,n];  psumsq[t,n] = sum y^2
+ * Optional max-pool partials over the rows with rowmask != 0 (tf_util.max_pool2d over N after the
+ * mask multiply, semisup_models.py:96,184-188,240-244,375): per tile the max and min of raw y and
+ * their row indices within the frustum (the finalize kernel picks max or min by the sign of the
+ * batch-norm scale). */
+typedef struct {
+  t3d_act_src a;
+  const float* w;        /* [K,N] */
+  const float* bias;     /* [N] or NULL */
+  const float* rowbias;  /* [B,N] or NULL */
+  float* y;              /* [M,N] */
+  float* psum;           /* [M/128, N] */
+  float* psumsq;         /* [M/128, N] */
+  const float* rowmask;  /* [M] or NULL (pool over all rows) */
+  float* pmax;           /* [M/128, N] or NULL (no pooling) */
+  float* pmin;
+  int32_t* pamax;
+  int32_t* pamin;
+  int M, K, N;
+  int rows_per_frustum;
+} t3d_pointmlp_fwd_args;
+int t3d_pointmlp_fwd(const t3d_pointmlp_fwd_args* args, t3d_stream_t stream);
+
+/* ---- K2: batch-norm statistics -> per-channel scale/shift (+ EMA) ------------------------------
+ * Replaces tf.contrib.layers.batch_norm (tf_util.py:1660-1664; eps 1e-3, updates_collections=None).
+ * Training: mean/biased variance from the partials, scale = gamma/sqrt(var+eps),
+ * shift = beta - mean*scale, moving <- moving*decay + batch*(1-decay) (variance Bessel-corrected
+ * when `unbiased_ema`).  Eval: scale/shift from the moving statistics.  `decay` is a DEVICE scalar
+ * (it follows the step counter under graph replay). */
+typedef struct {
+  const float* psum;
+  const float* psumsq;
+  int n_tiles;
+  int count;             /* rows reduced = M */
+  int N;
+  const float* gamma;
+  const float* beta;
+  float* moving_mean;
+  float* moving_var;
+  const float* decay;    /* device scalar */
+  float eps;
+  int is_training;
+  int unbiased_ema;
+  float* scale;          /* [N] out */
+  float* shift;          /* [N] out */
+  float* mean;           /* [N] out (saved for backward) */
+  float* invstd;         /* [N] out */
+} t3d_bn_fwd_finalize_args;
+int t3d_bn_fwd_finalize(const t3d_bn_fwd_finalize_args* args, t3d_stream_t stream);
+
+/* ---- K3: masked global max-pool finalize -------------------------------------------------------
+ * pooled[b,n] = max_m mask*relu(scale*y+shift)  (tf_util.py:1519-1523 after semisup_models.py:185).
+ * argidx[b,n] = row (within the frustum) that receives the gradient, -1 when pooled == 0. */
+typedef struct {
+  const float* scale;
+  const float* shift;
+  const float* pmax;
+  const float* pmin;
+  const int32_t* pamax;
+  const int32_t* pamin;
+  int B, N, tiles_per_frustum;
+  float* pooled;         /* [B, ld_pooled] */
+  int ld_pooled;
+  int32_t* argidx;       /* [B,N] */
+  float* ysel;           /* [B,N] raw y at argidx */
+} t3d_pool_finalize_args;
+int t3d_pool_finalize(const t3d_pool_finalize_args* args, t3d_stream_t stream);
+
+/* ---- K11a: per-point layer, data gradient ------------------------------------------------------
+ * The dgrad twin of K1 (autodiff of tf_util.conv2d, train_semisup.py:249):
+ *   da[m,k] = sum_n dy[m,n] w[k,n]  (+ add_in[m,k])
+ * and, when the producer of `a` has batch-norm + ReLU (prev_y != NULL), the ReLU mask and the
+ * producer's batch-norm-backward partials in the epilogue:
+ *   out = da * 1[prev_y*prev_scale + prev_shift > 0];  psum_dz = sum out;  psum_dzy = sum out*prev_y */
+typedef struct {
+  t3d_dy_src dy;
+  const float* w;          /* [K,N] */
+  const float* add_in;     /* [M,K] or NULL */
+  const float* prev_y;     /* [M,K] or NULL */
+  const float* prev_scale; /* [K] */
+  const float* prev_shift; /* [K] */
+  float* out;              /* [M,K] */
+  float* psum_dz;          /* [M/128,K] or NULL */
+  float* psum_dzy;         /* [M/128,K] or NULL */
+  int M, K, N;
+  int rows_per_frustum;
+} t3d_pointmlp_dgrad_args;
+int t3d_pointmlp_dgrad(const t3d_pointmlp_dgrad_args* args, t3d_stream_t stream);
+
+/* ---- K11b: per-point layer, weight gradient (split over rows) ----------------------------------
+ *   slab[s,k,n] = sum_{m in split s} a[m,k] dy[m,n],  s = 0 .. M/rows_per_split - 1
+ * t3d_reduce_slabs sums the slabs in a fixed order (deterministic). rows_per_split % 32 == 0. */
+typedef struct {
+  t3d_act_src a;
+  t3d_dy_src dy;
+  float* slabs;            /* [M/rows_per_split, K, N] */
+  int M, K, N;
+  int rows_per_frustum;
+  int rows_per_split;
+} t3d_pointmlp_wgrad_args;
+int t3d_pointmlp_wgrad(const t3d_pointmlp_wgrad_args* args, t3d_stream_t stream);
+
+/* ---- K11c: batch-norm backward statistics -> dgamma, dbeta and the three dy coefficients -------
+ * dense form: from the dgrad epilogue partials.  pooled form (psum_dz == NULL): from the gradient
+ * of the pooled feature, dpool_in[B,N]; writes the ReLU-masked dpool[B,N] the sparse dy form reads.
+ * `frozen` (eval-mode batch-norm, stage c): dy = scale*dz, no batch terms, no dgamma/dbeta. */
+typedef struct {
+  const float* psum_dz;
+  const float* psum_dzy;
+  int n_tiles;
+  const float* dpool_in;   /* [B, ld_dpool_in] (pooled form) */
+  int ld_dpool_in;
+  const float* pooled;     /* [B, ld_pooled] */
+  int ld_pooled;
+  const float* ysel;       /* [B,N] */
+  float* dpool;            /* [B,N] out */
+  int B;
+  int count;               /* M */
+  int N;
+  const float* gamma;
+  const float* mean;
+  const float* invstd;
+  const float* scale;      /* used when frozen */
+  int frozen;
+  float* dgamma;           /* [N] or NULL */
+  float* dbeta;            /* [N] or NULL */
+  float* coef;             /* [3,N] */
+} t3d_bn_bwd_finalize_args;
+int t3d_bn_bwd_finalize(const t3d_bn_bwd_finalize_args* args, t3d_stream_t stream);
+
+/* Per-frustum column sums of a dense dy, from partials only:
+ *   out[b,n] = alpha * ( coef0*sum_dz + coef1*sum_y + coef2*rows_per_frustum )
+ * (gradient of a per-frustum broadcast: conv6's global feature, semisup_models.py:107-108, and
+ * box_est's `xyz - stage1_center`, semisup_models.py:207). */
+typedef struct {
+  const float* psum_dz;    /* [M/128,N] */
+  const float* psum_y;     /* [M/128,N] forward psum of the same layer */
+  const float* coef;       /* [3,N] */
+  int B, N, tiles_per_frustum, rows_per_frustum;
+  float alpha;
+  float* out;              /* [B,N] */
+} t3d_dy_colsum_args;
+int t3d_dy_colsum(const t3d_dy_colsum_args* args, t3d_stream_t stream);
+
+/* ---- K6: per-frustum fully-connected layer -----------------------------------------------------
+ * Replaces tf_util.fully_connected (tf_util.py:1463-1499: matmul + bias [+ batch_norm over the B
+ * rows] [+ activation]) and the tf_util.dropout that follows it in mlps_with_dropout /
+ * combined_box_pc_mask_features_model (semisup_models.py:56-62, 385-390).
+ *   y = [in | in2] . w + bias ; z = BN(y) ; out = dropout(act(z)) (+ add_in on the first add_n cols)
+ * drop_mask holds 0/1 keep flags; out *= mask/keep_prob. */
+typedef struct {
+  const float* in;  int ld_in;  int K;
+  const float* in2; int ld_in2; int K2;      /* optional concat (one_hot_vec), K2 = 0 if none */
+  const float* w;                            /* [K+K2, N] */
+  const float* bias;                         /* [N] or NULL */
+  const float* gamma; const float* beta;     /* NULL -> no batch-norm */
+  float* moving_mean; float* moving_var;
+  const float* decay;                        /* device scalar */
+  float eps; int is_training; int unbiased_ema;
+  int act; float leaky_alpha;
+  const float* drop_mask; float keep_prob;   /* [B,N] or NULL */
+  const float* add_in; int ld_add; int add_n;
+  float* y;                                  /* [B,N] raw (pre-BN), may be NULL when no BN */
+  float* out; int ld_out;                    /* [B, ld_out] */
+  float* mean; float* invstd;                /* [N] saved for backward */
+  int B, N;
+} t3d_fc_fwd_args;
+int t3d_fc_fwd(const t3d_fc_fwd_args* args, t3d_stream_t stream);
+
+/* Backward of one fully-connected layer for all of its columns.  The incoming gradient w.r.t. `out`
+ * is either `dout` or formed on the fly as dy_next . w_next^T (the next layer's input gradient).
+ * Writes dy (grad w.r.t. the raw matmul output), dW, dbias, dgamma, dbeta. */
+typedef struct {
+  const float* dout; int ld_dout;                         /* [B, ld_dout] or NULL */
+  const float* dy_next; const float* w_next; int N_next;  /* [B,N_next], [*, N_next] rows 0..N-1 */
+  const float* in;  int ld_in;  int K;
+  const float* in2; int ld_in2; int K2;
+  const float* y; const float* out; int ld_out;
+  const float* gamma; const float* beta; const float* mean; const float* invstd;
+  int bn_training;                                         /* 0: gamma*invstd only (frozen) */
+  int act; float leaky_alpha;
+  const float* drop_mask; float keep_prob;
+  float* dy;                                               /* [B,N] */
+  float* dw; float* dbias; float* dgamma; float* dbeta;    /* NULL -> not computed (frozen net) */
+  int B, N;
+} t3d_fc_bwd_args;
+int t3d_fc_bwd(const t3d_fc_bwd_args* args, t3d_stream_t stream);
+
+/* din[b,k] = alpha * sum_n dy[b,n] w[k,n] (+ add_in[b,k]) : the input gradient of an FC layer
+ * (pooled-feature gradient, stage1_center gradient, global-feature gradient). */
+typedef struct {
+  const float* dy; int N;       /* [B,N] */
+  const float* w;               /* [K,N] */
+  const float* add_in; int ld_add;
+  float alpha;
+  float* din; int ld_din;
+  int B, K;
+} t3d_fc_dinput_args;
+int t3d_fc_dinput(const t3d_fc_dinput_args* args, t3d_stream_t stream);
+
+/* ---- K5 + K7 + K10: segmentation head, forward + backward in one pass --------------------------
+ * Replaces, for the last seg layer: tf_util.dropout (semisup_models.py:131), conv10 128->2 without
+ * BN/activation (133-135), sparse_softmax_cross_entropy_with_logits (semisup_v1_sunrgbd.py:430),
+ * the hard mask and masked xyz sums of subtract_points_mean (semisup_models.py:150-158), and their
+ * gradients back to conv9's batch-norm output.
+ * Per-frustum loss weight: w_b = ce_weight * (1 - is_data_2D[b]) / (B * rows_per_frustum). */
+typedef struct {
+  const float* y;            /* [M,K] raw conv9 output */
+  const float* scale; const float* shift;
+  const float* drop_mask;    /* [M,K] 0/1 or NULL */
+  float keep_prob;
+  const float* w;            /* [K,2] */
+  const float* bias;         /* [2] */
+  const int32_t* labels;     /* [M] or NULL (inference) */
+  const int32_t* is_data_2D; /* [B] */
+  const float* pc; int ld_pc;/* [M, ld_pc] xyz in cols 0..2 */
+  float ce_weight;
+  float* logits;             /* [M,2] */
+  float* mask;               /* [M] */
+  float* part;               /* [M/128, 8]: ce_sum, mask_cnt, sx, sy, sz, db0, db1, n_correct */
+  float* dz;                 /* [M,K] grad wrt conv9 BN output (ReLU-masked) or NULL (no backward) */
+  float* psum_dz;            /* [M/128,K] */
+  float* psum_dzy;           /* [M/128,K] */
+  float* dw_part;            /* [M/128,K,2] */
+  int M, K, rows_per_frustum, B;
+} t3d_seg_head_args;
+int t3d_seg_head(const t3d_seg_head_args* args, t3d_stream_t stream);
+
+/* Combines the seg-head tile partials per frustum: mask_xyz_mean[B,3] (semisup_models.py:157-158),
+ * seg CE per frustum (mean over points), and the conv10 weight/bias gradient. */
+typedef struct {
+  const float* part; const float* dw_part;
+  int B, tiles_per_frustum, rows_per_frustum, K;
+  float* mask_xyz_mean;      /* [B,3] */
+  float* seg_loss;           /* [B] mean CE per frustum */
+  float* dw;                 /* [K,2] or NULL */
+  float* dbias;              /* [2] or NULL */
+  float* n_correct;          /* [1] or NULL */
+} t3d_seg_finalize_args;
+int t3d_seg_finalize(const t3d_seg_finalize_args* args, t3d_stream_t stream);
+
+/* ---- K9 + K10: box losses, forward + backward ---------------------------------------------------
+ * Replaces get_strong_loss (semisup_v1_sunrgbd.py:423-553), huber_loss (555-564), the corner boxes of
+ * model_util.get_box3d_corners_sunrgbd / _helper (model_util.py:94-119,145-167) and the anchor->reg
+ * conversion tf_convert_box_params_from_anchor_to_reg_format_multi (tf_util.py:1001-1041), for the
+ * 67-wide head output `box` and the T-Net centre.  total[b] = w3d[b]*(seg_w*seg_loss[b] + box_l[b]),
+ * loss = sum_b total[b] * (mean_over_B ? 1/B : 1/(sum w3d + 1e-3)).   w3d = 1 - is_data_2D. */
+typedef struct {
+  float center, orient_cls, orient_reg, dims_cls, dims_reg, tnet_center, corner, box_multiplier,
+        cross_entropy;
+} t3d_strong_weights;
+typedef struct {
+  const float* box; int ld_box;          /* [B,67] head output (centre residual first) */
+  const float* stage1_center;            /* [B,3] */
+  const float* seg_loss;                 /* [B] or NULL */
+  const float* y_center; const int32_t* y_orient_cls; const float* y_orient_reg;
+  const int32_t* y_dims_cls; const float* y_dims_reg; const int32_t* is_data_2D;
+  t3d_strong_weights wts;
+  int normalize_by_3d_count;             /* 0: mean over B (model A); 1: /(sum w3d + 1e-3) (model F) */
+  float* dbox;                           /* [B,67] */
+  float* dstage1;                        /* [B,3] */
+  float* terms;                          /* [B,8]: mask, center, stage1, hcls, hres, scls, sres, corner */
+  float* total_losses;                   /* [B] */
+  float* loss;                           /* [1] */
+  float* center;                         /* [B,3] end_points['center'] */
+  float* reg_dims;                       /* [B,3] anchor->reg dims */
+  float* reg_theta;                      /* [B] */
+  int B;
+} t3d_strong_loss_args;
+int t3d_strong_loss(const t3d_strong_loss_args* args, t3d_stream_t stream);
+
+/* ---- K11d / K12 / schedules --------------------------------------------------------------------- */
+
+/* grad[off_i + e] = sum_s slabs_i[s, e]  for every tensor i of a device-side table. */
+typedef struct { int64_t slab_off; int64_t grad_off; int32_t numel; int32_t n_slabs; } t3d_slab_desc;
+int t3d_reduce_slabs(const float* slab_base, float* grad_base, const t3d_slab_desc* table_dev,
+                     int n_tensors, int max_numel, t3d_stream_t stream);
+
+/* hyper[0] = step (as float, incremented), [1] = lr, [2] = bn_decay, [3] = adam lr_t.
+ * Replaces tf.train.exponential_decay(staircase) for lr and bn momentum (train_semisup.py:127-145)
+ * and the Adam bias correction.  Device-resident so a captured graph advances by itself. */
+typedef struct {
+  float base_lr, lr_decay_rate, lr_decay_step;
+  float bn_init_decay, bn_decay_rate, bn_decay_step, bn_decay_clip;
+  float beta1, beta2;
+  int batch_size;
+} t3d_schedule;
+int t3d_schedule_step(float* hyper, const t3d_schedule* s, t3d_stream_t stream);
+
+/* tf.train.AdamOptimizer (train_semisup.py:230), TF form: w -= lr_t * m / (sqrt(v) + eps).
+ * `grad_scale` divides the (all-reduced) gradient sum by the world size. */
+int t3d_adam_tf_step(float* params, const float* grads, float* m, float* v, int64_t n,
+                     const float* hyper, float beta1, float beta2, float eps, float grad_scale,
+                     t3d_stream_t stream);
+
+/* tf.nn.dropout keep mask (tf_util.py:1738-1740): mask[i] = 1[u_i < keep], u from a counter-based
+ * generator keyed by (seed, hyper step, i).  Tests inject masks instead. */
+int t3d_dropout_mask(float* mask, int64_t n, float keep_prob, uint32_t seed, const float* hyper,
+                     t3d_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* T3D_H_ */

@@ -1,0 +1,532 @@
+"""TEST INFRASTRUCTURE ONLY -- NumPy executable specification of include/t3d.h.
+
+Each function takes the same ctypes argument struct as the HIP entry point it mirrors and operates
+on HOST memory, so that (a) the host-side step plan can be exercised on CPU tensors in this GPU-less
+container and checked end to end against the oracle, and (b) every HIP kernel can be checked on the
+GPU against the same inputs.  The product package never imports this module: `abi.load()` is the only
+way the product obtains a library object and it raises when libt3d.so is missing.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from transferable3d_amd import abi
+from transferable3d_amd.constants import MEAN_DIMS_ARR, NUM_HEADING_BIN as NH, NUM_SIZE_CLUSTER as NS
+
+MEAN32 = MEAN_DIMS_ARR.astype(np.float32)
+BINS32 = (np.arange(NH) * (2.0 * np.pi / 12.0)).astype(np.float32)
+
+
+def arr(ptr, *shape):
+    if not ptr:
+        return None
+    n = int(np.prod(shape))
+    return np.ctypeslib.as_array(ptr, shape=(n,)).reshape(shape)
+
+
+def _struct(a):
+    return a._obj if hasattr(a, '_obj') else a.contents
+
+
+def _act(src, M, K, rpf):
+    x = arr(src.x, M, src.ldx)[:, src.coff:src.coff + K].astype(np.float64)
+    if src.scale:
+        x = x * arr(src.scale, K).astype(np.float64) + arr(src.shift, K).astype(np.float64)
+    if src.relu:
+        x = np.maximum(x, 0.0)
+    if src.sub:
+        B = M // rpf
+        sub = arr(src.sub, B, src.sub_ld)[:, :K].astype(np.float64)
+        x = x - np.repeat(sub, rpf, axis=0)
+    return x
+
+
+def _dy(src, M, N, rpf):
+    y = arr(src.y, M, N).astype(np.float64)
+    coef = arr(src.coef, 3, N).astype(np.float64)
+    if src.dz:
+        dz = arr(src.dz, M, N).astype(np.float64)
+    else:
+        B = M // rpf
+        ai = arr(src.argidx, B, N)
+        dp = arr(src.dpool, B, N).astype(np.float64)
+        dz = np.zeros((B, rpf, N))
+        bb, cc = np.nonzero(ai >= 0)
+        dz[bb, ai[bb, cc], cc] = dp[bb, cc]
+        dz = dz.reshape(M, N)
+    return coef[0] * dz + coef[1] * y + coef[2]
+
+
+class FakeLib:
+    """Drop-in for the ctypes library object (same call signatures, host pointers)."""
+
+    def t3d_abi_version(self):
+        return 1
+
+    def t3d_pointmlp_fwd(self, a, stream):
+        p = _struct(a)
+        M, K, N, rpf = p.M, p.K, p.N, p.rows_per_frustum
+        x = _act(p.a, M, K, rpf)
+        y = x @ arr(p.w, K, N).astype(np.float64)
+        if p.bias:
+            y = y + arr(p.bias, N)
+        if p.rowbias:
+            y = y + np.repeat(arr(p.rowbias, M // rpf, N).astype(np.float64), rpf, axis=0)
+        y32 = y.astype(np.float32)
+        arr(p.y, M, N)[:] = y32
+        T = M // 128
+        yt = y32.astype(np.float64).reshape(T, 128, N)
+        arr(p.psum, T, N)[:] = yt.sum(1)
+        arr(p.psumsq, T, N)[:] = (yt * yt).sum(1)
+        if p.pmax:
+            keep = np.ones(M, bool) if not p.rowmask else arr(p.rowmask, M) != 0
+            kt = keep.reshape(T, 128)
+            tile_in_frustum = (np.arange(T) * 128) % rpf
+            ymax = np.where(kt[:, :, None], y32.reshape(T, 128, N), -np.inf)
+            ymin = np.where(kt[:, :, None], y32.reshape(T, 128, N), np.inf)
+            anyk = kt.any(1)
+            amax = ymax.argmax(1) + tile_in_frustum[:, None]
+            amin = ymin.argmin(1) + tile_in_frustum[:, None]
+            arr(p.pmax, T, N)[:] = ymax.max(1)
+            arr(p.pmin, T, N)[:] = ymin.min(1)
+            arr(p.pamax, T, N)[:] = np.where(anyk[:, None], amax, -1)
+            arr(p.pamin, T, N)[:] = np.where(anyk[:, None], amin, -1)
+        return 0
+
+    def t3d_bn_fwd_finalize(self, a, stream):
+        p = _struct(a)
+        N = p.N
+        g, b = arr(p.gamma, N).astype(np.float64), arr(p.beta, N).astype(np.float64)
+        mm, mv = arr(p.moving_mean, N), arr(p.moving_var, N)
+        if p.is_training:
+            s = arr(p.psum, p.n_tiles, N).astype(np.float64).sum(0)
+            ss = arr(p.psumsq, p.n_tiles, N).astype(np.float64).sum(0)
+            n = float(p.count)
+            mean = s / n
+            var = np.maximum(ss / n - mean * mean, 0.0)
+            d = float(arr(p.decay, 1)[0])
+            var_ema = var * (n / max(n - 1, 1)) if p.unbiased_ema else var
+            mm[:] = mm.astype(np.float64) * d + mean * (1 - d)
+            mv[:] = mv.astype(np.float64) * d + var_ema * (1 - d)
+        else:
+            mean, var = mm.astype(np.float64), mv.astype(np.float64)
+        invstd = 1.0 / np.sqrt(var + p.eps)
+        arr(p.scale, N)[:] = g * invstd
+        arr(p.shift, N)[:] = b - mean * g * invstd
+        arr(p.mean, N)[:] = mean
+        arr(p.invstd, N)[:] = invstd
+        return 0
+
+    def t3d_pool_finalize(self, a, stream):
+        p = _struct(a)
+        B, N, tpf = p.B, p.N, p.tiles_per_frustum
+        sc, sh = arr(p.scale, N), arr(p.shift, N)
+        pmax, pmin = arr(p.pmax, B, tpf, N), arr(p.pmin, B, tpf, N)
+        pamax, pamin = arr(p.pamax, B, tpf, N), arr(p.pamin, B, tpf, N)
+        vmax = np.where(pamax >= 0, pmax, -np.inf)
+        vmin = np.where(pamin >= 0, pmin, np.inf)
+        tmax, tmin = vmax.argmax(1), vmin.argmin(1)
+        bmax = np.take_along_axis(vmax, tmax[:, None, :], 1)[:, 0]
+        bmin = np.take_along_axis(vmin, tmin[:, None, :], 1)[:, 0]
+        amax = np.take_along_axis(pamax, tmax[:, None, :], 1)[:, 0]
+        amin = np.take_along_axis(pamin, tmin[:, None, :], 1)[:, 0]
+        use_max = sc >= 0
+        best = np.where(use_max, bmax, bmin)
+        arg = np.where(use_max, amax, amin)
+        valid = arg >= 0
+        with np.errstate(invalid='ignore'):
+            out = np.where(valid, np.maximum(np.where(valid, best, 0.0).astype(np.float32) * sc + sh, 0.0), 0.0).astype(np.float32)
+        live = out > 0
+        arr(p.pooled, B, p.ld_pooled)[:, :N] = out
+        arr(p.argidx, B, N)[:] = np.where(live, arg, -1)
+        arr(p.ysel, B, N)[:] = np.where(live, np.where(valid, best, 0.0), 0.0)
+        return 0
+
+    def t3d_pointmlp_dgrad(self, a, stream):
+        p = _struct(a)
+        M, K, N, rpf = p.M, p.K, p.N, p.rows_per_frustum
+        dy = _dy(p.dy, M, N, rpf)
+        da = dy @ arr(p.w, K, N).astype(np.float64).T
+        if p.add_in:
+            da = da + arr(p.add_in, M, K)
+        if p.prev_y:
+            yp = arr(p.prev_y, M, K).astype(np.float64)
+            z = yp * arr(p.prev_scale, K) + arr(p.prev_shift, K)
+            da = np.where(z > 0, da, 0.0)
+        out32 = da.astype(np.float32)
+        arr(p.out, M, K)[:] = out32
+        if p.psum_dz:
+            T = M // 128
+            o = out32.astype(np.float64).reshape(T, 128, K)
+            arr(p.psum_dz, T, K)[:] = o.sum(1)
+            arr(p.psum_dzy, T, K)[:] = (o * yp.reshape(T, 128, K)).sum(1)
+        return 0
+
+    def t3d_pointmlp_wgrad(self, a, stream):
+        p = _struct(a)
+        M, K, N, rpf, rps = p.M, p.K, p.N, p.rows_per_frustum, p.rows_per_split
+        x = _act(p.a, M, K, rpf)
+        dy = _dy(p.dy, M, N, rpf)
+        S = M // rps
+        slabs = arr(p.slabs, S, K, N)
+        for s in range(S):
+            slabs[s] = x[s * rps:(s + 1) * rps].T @ dy[s * rps:(s + 1) * rps]
+        return 0
+
+    def t3d_bn_bwd_finalize(self, a, stream):
+        p = _struct(a)
+        N = p.N
+        if p.psum_dz:
+            s1 = arr(p.psum_dz, p.n_tiles, N).astype(np.float64).sum(0)
+            s2 = arr(p.psum_dzy, p.n_tiles, N).astype(np.float64).sum(0)
+        else:
+            B = p.B
+            live = arr(p.pooled, B, p.ld_pooled)[:, :N] > 0
+            g = (arr(p.dpool_in, B, p.ld_dpool_in)[:, :N] * live).astype(np.float32)
+            arr(p.dpool, B, N)[:] = g
+            s1 = g.astype(np.float64).sum(0)
+            s2 = (g.astype(np.float64) * arr(p.ysel, B, N)).sum(0)
+        coef = arr(p.coef, 3, N)
+        if p.frozen:
+            coef[0] = arr(p.scale, N)
+            coef[1] = 0
+            coef[2] = 0
+            return 0
+        mean, invstd = arr(p.mean, N).astype(np.float64), arr(p.invstd, N).astype(np.float64)
+        gamma, n = arr(p.gamma, N).astype(np.float64), float(p.count)
+        dbeta = s1
+        dgamma = invstd * (s2 - mean * s1)
+        if p.dbeta:
+            arr(p.dbeta, N)[:] = dbeta
+        if p.dgamma:
+            arr(p.dgamma, N)[:] = dgamma
+        c1 = gamma * invstd
+        k3 = dgamma / n * invstd
+        coef[0] = c1
+        coef[1] = -c1 * k3
+        coef[2] = c1 * (k3 * mean - dbeta / n)
+        return 0
+
+    def t3d_dy_colsum(self, a, stream):
+        p = _struct(a)
+        B, N, tpf = p.B, p.N, p.tiles_per_frustum
+        sdz = arr(p.psum_dz, B, tpf, N).astype(np.float64).sum(1)
+        sy = arr(p.psum_y, B, tpf, N).astype(np.float64).sum(1)
+        coef = arr(p.coef, 3, N).astype(np.float64)
+        arr(p.out, B, N)[:] = p.alpha * (coef[0] * sdz + coef[1] * sy + coef[2] * p.rows_per_frustum)
+        return 0
+
+    # ---- FC --------------------------------------------------------------------------------------
+    @staticmethod
+    def _fc_in(p):
+        x = arr(p.in_, p.B, p.ld_in)[:, :p.K].astype(np.float64)
+        if p.K2 > 0:
+            x = np.concatenate([x, arr(p.in2, p.B, p.ld_in2)[:, :p.K2].astype(np.float64)], 1)
+        return x
+
+    @staticmethod
+    def _actf(z, act, alpha):
+        if act == abi.ACT_RELU:
+            return np.maximum(z, 0)
+        if act == abi.ACT_LEAKY_RELU:
+            return np.where(z > 0, z, alpha * z)
+        if act == abi.ACT_TANH:
+            return np.tanh(z)
+        return z
+
+    @staticmethod
+    def _actd(z, act, alpha):
+        if act == abi.ACT_RELU:
+            return (z > 0).astype(np.float64)
+        if act == abi.ACT_LEAKY_RELU:
+            return np.where(z > 0, 1.0, alpha)
+        if act == abi.ACT_TANH:
+            return 1 - np.tanh(z) ** 2
+        return np.ones_like(z)
+
+    def t3d_fc_fwd(self, a, stream):
+        p = _struct(a)
+        B, N = p.B, p.N
+        x = self._fc_in(p)
+        y = x @ arr(p.w, p.K + p.K2, N).astype(np.float64)
+        if p.bias:
+            y = y + arr(p.bias, N)
+        y = y.astype(np.float32).astype(np.float64)
+        if p.y:
+            arr(p.y, B, N)[:] = y
+        z = y
+        if p.gamma:
+            mm, mv = arr(p.moving_mean, N), arr(p.moving_var, N)
+            if p.is_training:
+                mean = y.mean(0)
+                var = ((y - mean) ** 2).mean(0)
+                d = float(arr(p.decay, 1)[0])
+                var_ema = var * (B / max(B - 1, 1)) if p.unbiased_ema else var
+                mm[:] = mm * d + mean * (1 - d)
+                mv[:] = mv * d + var_ema * (1 - d)
+            else:
+                mean, var = mm.astype(np.float64), mv.astype(np.float64)
+            invstd = 1 / np.sqrt(var + p.eps)
+            arr(p.mean, N)[:] = mean
+            arr(p.invstd, N)[:] = invstd
+            z = (y - mean) * invstd * arr(p.gamma, N) + arr(p.beta, N)
+        z = self._actf(z, p.act, p.leaky_alpha)
+        if p.drop_mask:
+            z = z * arr(p.drop_mask, B, N) / p.keep_prob
+        if p.add_in:
+            z[:, :p.add_n] += arr(p.add_in, B, p.ld_add)[:, :p.add_n]
+        arr(p.out, B, p.ld_out)[:, :N] = z
+        return 0
+
+    def t3d_fc_bwd(self, a, stream):
+        p = _struct(a)
+        B, N = p.B, p.N
+        if p.dout:
+            g = arr(p.dout, B, p.ld_dout)[:, :N].astype(np.float64)
+        else:
+            wn = arr(p.w_next, N, p.N_next).astype(np.float64)
+            g = arr(p.dy_next, B, p.N_next).astype(np.float64) @ wn.T
+        y = arr(p.y, B, N).astype(np.float64) if p.y else np.zeros((B, N))
+        bn = bool(p.gamma)
+        if bn:
+            mean, invstd = arr(p.mean, N).astype(np.float64), arr(p.invstd, N).astype(np.float64)
+            gam = arr(p.gamma, N).astype(np.float64)
+            xh = (y - mean) * invstd
+            z = xh * gam + arr(p.beta, N)
+        else:
+            xh = y
+            z = y
+        if p.drop_mask:
+            g = g * arr(p.drop_mask, B, N) / p.keep_prob
+        dz = g * self._actd(z, p.act, p.leaky_alpha)
+        dbias = np.zeros(N)
+        if bn and p.bn_training:
+            dbeta, dgamma = dz.sum(0), (dz * xh).sum(0)
+            if p.dbeta:
+                arr(p.dbeta, N)[:] = dbeta
+            if p.dgamma:
+                arr(p.dgamma, N)[:] = dgamma
+            dy = gam * invstd * (dz - dbeta / B - xh * dgamma / B)
+        elif bn:
+            dy = gam * invstd * dz
+        else:
+            dy = dz
+            dbias = dz.sum(0)
+        if p.dbias:
+            arr(p.dbias, N)[:] = dbias
+        dy32 = dy.astype(np.float32)
+        arr(p.dy, B, N)[:] = dy32
+        if p.dw:
+            arr(p.dw, p.K + p.K2, N)[:] = self._fc_in(p).T @ dy32.astype(np.float64)
+        return 0
+
+    def t3d_fc_dinput(self, a, stream):
+        p = _struct(a)
+        v = p.alpha * (arr(p.dy, p.B, p.N).astype(np.float64) @ arr(p.w, p.K, p.N).astype(np.float64).T)
+        if p.add_in:
+            v = v + arr(p.add_in, p.B, p.ld_add)[:, :p.K]
+        arr(p.din, p.B, p.ld_din)[:, :p.K] = v
+        return 0
+
+    # ---- heads -----------------------------------------------------------------------------------
+    def t3d_seg_head(self, a, stream):
+        p = _struct(a)
+        M, K, rpf, B = p.M, p.K, p.rows_per_frustum, p.B
+        T = M // 128
+        y = arr(p.y, M, K).astype(np.float64)
+        z = y * arr(p.scale, K) + arr(p.shift, K)
+        keep = np.full((M, K), 1.0)
+        if p.drop_mask:
+            keep = arr(p.drop_mask, M, K).astype(np.float64) / p.keep_prob
+        d = np.maximum(z, 0) * keep
+        w = arr(p.w, K, 2).astype(np.float64)
+        logits = (d @ w + arr(p.bias, 2)).astype(np.float32)
+        arr(p.logits, M, 2)[:] = logits
+        mask = (logits[:, 0] < logits[:, 1]).astype(np.float32)
+        arr(p.mask, M)[:] = mask
+        part = arr(p.part, T, 8)
+        part[:] = 0
+        xyz = arr(p.pc, M, p.ld_pc)[:, :3].astype(np.float64)
+        part[:, 1] = mask.reshape(T, 128).sum(1)
+        part[:, 2:5] = (mask[:, None] * xyz).reshape(T, 128, 3).sum(1)
+        if p.labels:
+            lab = arr(p.labels, M).astype(np.int64)
+            l64 = logits.astype(np.float64)
+            mx = l64.max(1, keepdims=True)
+            lse = mx[:, 0] + np.log(np.exp(l64 - mx).sum(1))
+            ce = lse - l64[np.arange(M), lab]
+            part[:, 0] = ce.reshape(T, 128).sum(1)
+            part[:, 7] = ((l64[:, 1] > l64[:, 0]).astype(np.int64) == lab).reshape(T, 128).sum(1)
+            if p.dz:
+                is2d = arr(p.is_data_2D, B)
+                wb = np.repeat(p.ce_weight * (1 - is2d) / (B * rpf), rpf)
+                g = (np.exp(l64 - lse[:, None]) - np.eye(2)[lab]) * wb[:, None]
+                part[:, 5:7] = g.reshape(T, 128, 2).sum(1)
+                arr(p.dw_part, T, K, 2)[:] = np.einsum('tik,tij->tkj', d.reshape(T, 128, K), g.reshape(T, 128, 2))
+                dz = np.where(z > 0, (g @ w.T) * keep, 0.0).astype(np.float32)
+                arr(p.dz, M, K)[:] = dz
+                dz64 = dz.astype(np.float64).reshape(T, 128, K)
+                arr(p.psum_dz, T, K)[:] = dz64.sum(1)
+                arr(p.psum_dzy, T, K)[:] = (dz64 * y.reshape(T, 128, K)).sum(1)
+        return 0
+
+    def t3d_seg_finalize(self, a, stream):
+        p = _struct(a)
+        B, tpf, rpf, K = p.B, p.tiles_per_frustum, p.rows_per_frustum, p.K
+        part = arr(p.part, B, tpf, 8).astype(np.float64)
+        s = part.sum(1)
+        arr(p.mask_xyz_mean, B, 3)[:] = s[:, 2:5] / np.maximum(s[:, 1:2], 1.0)
+        if p.seg_loss:
+            arr(p.seg_loss, B)[:] = s[:, 0] / rpf
+        if p.dw:
+            arr(p.dw, K, 2)[:] = arr(p.dw_part, B * tpf, K, 2).astype(np.float64).sum(0)
+        if p.dbias:
+            arr(p.dbias, 2)[:] = part[:, :, 5:7].sum((0, 1))
+        if p.n_correct:
+            arr(p.n_correct, 1)[0] = part[:, :, 7].sum()
+        return 0
+
+    def t3d_strong_loss(self, a, stream):
+        """Analytic restatement in float64 of the loss kernel (forward and hand-derived backward)."""
+        p = _struct(a)
+        B = p.B
+        W = p.wts
+        box = arr(p.box, B, p.ld_box)[:, :67].astype(np.float64)
+        s1 = arr(p.stage1_center, B, 3).astype(np.float64)
+        yc = arr(p.y_center, B, 3).astype(np.float64)
+        yoc, yor = arr(p.y_orient_cls, B), arr(p.y_orient_reg, B).astype(np.float64)
+        ydc, ydr = arr(p.y_dims_cls, B), arr(p.y_dims_reg, B, 3).astype(np.float64)
+        w3d = (1 - arr(p.is_data_2D, B)).astype(np.float64)
+        norm = 1.0 / (w3d.sum() + 1e-3) if p.normalize_by_3d_count else 1.0 / B
+        seg = arr(p.seg_loss, B).astype(np.float64) if p.seg_loss else np.zeros(B)
+        dbox, ds1 = arr(p.dbox, B, 67), arr(p.dstage1, B, 3)
+        terms, tot = arr(p.terms, B, 8), arr(p.total_losses, B)
+        mean = MEAN32.astype(np.float64)
+        bins = BINS32.astype(np.float64)
+        sx = np.array([1, 1, -1, -1, 1, 1, -1, -1.])
+        sy = np.array([1, 1, 1, 1, -1, -1, -1, -1.])
+        sz = np.array([1, -1, -1, 1, 1, -1, -1, 1.])
+
+        def hub(e, d):
+            q = min(abs(e), d)
+            return 0.5 * q * q + d * (abs(e) - q)
+
+        def ce(z, lab, g, gsc):
+            m = z.max()
+            lse = m + math.log(np.exp(z - m).sum())
+            g += gsc * (np.exp(z - lse) - np.eye(len(z))[lab])
+            return lse - z[lab]
+
+        total_sum = 0.0
+        for b in range(B):
+            o = box[b]
+            g = np.zeros(67)
+            gc, gs1 = np.zeros(3), np.zeros(3)
+            gs = w3d[b] * norm
+            bm = W.box_multiplier
+            cen = o[0:3] + s1[b]
+            j, k = int(yoc[b]), int(ydc[b])
+            dist = np.linalg.norm(yc[b] - cen)
+            l_c = hub(dist, 2.0)
+            if dist > 0:
+                gc += gs * bm * W.center * min(dist, 2.0) / dist * (cen - yc[b])
+            dist = np.linalg.norm(yc[b] - s1[b])
+            l_s1 = hub(dist, 1.0)
+            if dist > 0:
+                gs1 += gs * bm * W.tnet_center * min(dist, 1.0) / dist * (s1[b] - yc[b])
+            l_hc = ce(o[3:3 + NH], j, g[3:3 + NH], gs * bm * W.orient_cls)
+            hrn = o[3 + NH + j]
+            eh = hrn - yor[b] / (np.pi / NH)
+            l_hr = hub(eh, 1.0)
+            g[3 + NH + j] += gs * bm * W.orient_reg * np.clip(eh, -1, 1)
+            l_sc = ce(o[3 + 2 * NH:3 + 2 * NH + NS], k, g[3 + 2 * NH:3 + 2 * NH + NS], gs * bm * W.dims_cls)
+            so = 3 + 2 * NH + NS + 3 * k
+            srn = o[so:so + 3]
+            dsv = srn - ydr[b] / mean[k]
+            sd = np.linalg.norm(dsv)
+            l_sr = hub(sd, 1.0)
+            if sd > 0:
+                g[so:so + 3] += gs * bm * W.dims_reg * min(sd, 1.0) / sd * dsv
+            th = bins[j] + hrn * (np.pi / NH)
+            c, s = math.cos(th), math.sin(th)
+            size = mean[k] + 2 * srn * mean[k]
+            hl = bins[j] + yor[b]
+            gl = mean[k] + ydr[b]
+            l_co = 0.0
+            gth = 0.0
+            gsize = np.zeros(3)
+            for i in range(8):
+                x, y, z = sx[i] * size[0] / 2, sy[i] * size[2] / 2, sz[i] * size[1] / 2
+                cp = np.array([c * x + s * z, y, -s * x + c * z]) + cen
+                xg, yg, zg = sx[i] * gl[0] / 2, sy[i] * gl[2] / 2, sz[i] * gl[1] / 2
+                tg = []
+                for ang in (hl, hl + np.pi):
+                    ca, sa = math.cos(ang), math.sin(ang)
+                    tg.append(np.array([ca * xg + sa * zg, yg, -sa * xg + ca * zg]) + yc[b])
+                d1, d2 = np.linalg.norm(cp - tg[0]), np.linalg.norm(cp - tg[1])
+                t, dm = (tg[0], d1) if d1 <= d2 else (tg[1], d2)
+                l_co += hub(dm, 1.0) / 8
+                if dm > 0:
+                    gv = gs * W.corner / 8 * min(dm, 1.0) / dm * (cp - t)
+                    gc += gv
+                    gth += gv[0] * (-s * x + c * z) + gv[2] * (-c * x - s * z)
+                    gsize[0] += (gv[0] * c - gv[2] * s) * sx[i] / 2
+                    gsize[2] += gv[1] * sy[i] / 2
+                    gsize[1] += (gv[0] * s + gv[2] * c) * sz[i] / 2
+            g[3 + NH + j] += gth * (np.pi / NH)
+            g[so:so + 3] += gsize * 2 * mean[k]
+            g[0:3] = gc
+            box_l = bm * (W.center * l_c + W.orient_cls * l_hc + W.dims_cls * l_sc + W.orient_reg * l_hr
+                          + W.dims_reg * l_sr + W.tnet_center * l_s1) + W.corner * l_co
+            t_b = w3d[b] * (W.cross_entropy * seg[b] + box_l)
+            total_sum += t_b
+            dbox[b] = g
+            ds1[b] = gc + gs1
+            arr(p.center, B, 3)[b] = cen
+            terms[b] = [seg[b], l_c, l_s1, l_hc, l_hr, l_sc, l_sr, l_co]
+            tot[b] = t_b
+            js = int(np.argmax(o[3:3 + NH]))
+            ks = int(np.argmax(o[3 + 2 * NH:3 + 2 * NH + NS]))
+            so2 = 3 + 2 * NH + NS + 3 * ks
+            arr(p.reg_dims, B, 3)[b] = np.maximum(mean[ks] + o[so2:so2 + 3] * mean[ks], 1e-5)
+            arr(p.reg_theta, B)[b] = bins[js] + o[3 + NH + js] * (np.pi / NH)
+        arr(p.loss, 1)[0] = total_sum * norm
+        return 0
+
+    # ---- optimiser -------------------------------------------------------------------------------
+    def t3d_reduce_slabs(self, slab_base, grad_base, table, n_tensors, max_numel, stream):
+        for i in range(n_tensors):
+            d = table[i]
+            sl = np.ctypeslib.as_array(slab_base, shape=(d.slab_off + d.n_slabs * d.numel,))[d.slab_off:]
+            g = np.ctypeslib.as_array(grad_base, shape=(d.grad_off + d.numel,))[d.grad_off:]
+            g[:] = sl.reshape(d.n_slabs, d.numel).astype(np.float64).sum(0)
+        return 0
+
+    def t3d_schedule_step(self, hyper, s, stream):
+        h = arr(hyper, 4)
+        s = _struct(s)
+        step = float(h[0])
+        seen = step * s.batch_size
+        lr = s.base_lr * s.lr_decay_rate ** math.floor(seen / s.lr_decay_step)
+        bnd = min(s.bn_decay_clip, 1 - s.bn_init_decay * s.bn_decay_rate ** math.floor(seen / s.bn_decay_step))
+        t = step + 1
+        h[1], h[2] = lr, bnd
+        h[3] = lr * math.sqrt(1 - s.beta2 ** t) / (1 - s.beta1 ** t)
+        h[0] = t
+        return 0
+
+    def t3d_adam_tf_step(self, params, grads, m, v, n, hyper, b1, b2, eps, gscale, stream):
+        w, g, mm, vv = arr(params, n), arr(grads, n), arr(m, n), arr(v, n)
+        lr_t = arr(hyper, 4)[3]
+        gi = g * np.float32(gscale)
+        mm[:] = np.float32(b1) * mm + np.float32(1 - b1) * gi
+        vv[:] = np.float32(b2) * vv + np.float32(1 - b2) * gi * gi
+        w[:] = w - lr_t * mm / (np.sqrt(vv) + np.float32(eps))
+        return 0
+
+    def t3d_dropout_mask(self, mask, n, keep, seed, hyper, stream):
+        step = int(arr(hyper, 4)[0])
+        r = np.random.RandomState((seed * 1000003 + step) % (2 ** 31))
+        arr(mask, n)[:] = (r.uniform(size=n) < keep).astype(np.float32)
+        return 0

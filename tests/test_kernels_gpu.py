@@ -1,0 +1,517 @@
+"""GPU: every HIP entry point of libt3d.so against the NumPy executable specification (tests/fake_t3d.py)
+on identical seeded inputs, called through the C ABI (ctypes).  Sizes are small enough that the fp64 spec
+finishes in seconds; tolerances are fp32 accumulation bounds, written per test."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from fake_t3d import FakeLib
+from transferable3d_amd import abi
+from transferable3d_amd.abi import fptr, iptr
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(name):
+    return torch.device(name)
+
+
+def _mk(dev, a):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(dev)
+
+
+def _run_both(hip_lib, make, name):
+    """make(dev) -> (args, outputs dict).  Runs the spec on CPU and the HIP kernel on the GPU."""
+    fake = FakeLib()
+    a_c, out_c = make(_dev('cpu'))
+    assert getattr(fake, name)(C.byref(a_c), None) == 0
+    a_g, out_g = make(_dev('cuda'))
+    rc = getattr(hip_lib, name)(C.byref(a_g), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    return out_c, {k: v.cpu() for k, v in out_g.items()}
+
+
+def _close(a, b, rtol, atol, what):
+    a, b = a.double().numpy(), b.double().numpy()
+    err = np.abs(a - b)
+    tol = atol + rtol * np.abs(a)
+    assert (err <= tol).all(), (what, float(err.max()), float(np.abs(a).max()), int((err > tol).sum()))
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M,K,N,rpf,mode', [
+    (512, 64, 64, 256, 'bn'), (512, 4, 64, 128, 'raw'), (256, 3, 128, 128, 'sub'), (512, 128, 256, 256, 'bn_pool'),
+    (256, 64, 512, 128, 'bn_rowbias'), (256, 128, 1024, 128, 'bn_pool_nomask'), (384, 512, 256, 128, 'bn')])
+def test_pointmlp_fwd(hip_lib, M, K, N, rpf, mode):
+    r = np.random.RandomState(hash((M, K, N)) % 1000)
+    B, T = M // rpf, M // 128
+    ldx = 4 if K <= 4 else K
+    x = r.normal(size=(M, ldx)).astype(np.float32)
+    w = (r.normal(size=(K, N)) / np.sqrt(K)).astype(np.float32)
+    bias = r.normal(size=N).astype(np.float32) * 0.1
+    sc = (0.5 + r.uniform(size=K)).astype(np.float32)
+    sc[::3] *= -1
+    sh = r.normal(size=K).astype(np.float32) * 0.2
+    sub = r.normal(size=(B, 3)).astype(np.float32)
+    rb = r.normal(size=(B, N)).astype(np.float32)
+    mask = (r.uniform(size=M) < 0.4).astype(np.float32)
+    mask[:128] = 0                                                   # one tile with no kept row
+
+    def make(dev):
+        t = {k: _mk(dev, v) for k, v in dict(x=x, w=w, bias=bias, sc=sc, sh=sh, sub=sub, rb=rb, mask=mask).items()}
+        o = dict(y=torch.zeros(M, N, device=dev), psum=torch.zeros(T, N, device=dev), psumsq=torch.zeros(T, N, device=dev))
+        a = abi.PointMlpFwdArgs()
+        a.a = abi.ActSrc(fptr(t['x']), ldx, 0, fptr(t['sc'] if 'bn' in mode else None), fptr(t['sh'] if 'bn' in mode else None),
+                         int('bn' in mode), fptr(t['sub'] if mode == 'sub' else None), 3)
+        a.w, a.bias, a.y, a.psum, a.psumsq = fptr(t['w']), fptr(t['bias']), fptr(o['y']), fptr(o['psum']), fptr(o['psumsq'])
+        if 'rowbias' in mode:
+            a.rowbias = fptr(t['rb'])
+        if 'pool' in mode:
+            o.update(pmax=torch.zeros(T, N, device=dev), pmin=torch.zeros(T, N, device=dev),
+                     pamax=torch.zeros(T, N, dtype=torch.int32, device=dev), pamin=torch.zeros(T, N, dtype=torch.int32, device=dev))
+            a.pmax, a.pmin, a.pamax, a.pamin = fptr(o['pmax']), fptr(o['pmin']), iptr(o['pamax']), iptr(o['pamin'])
+            if 'nomask' not in mode:
+                a.rowmask = fptr(t['mask'])
+        a.M, a.K, a.N, a.rows_per_frustum = M, K, N, rpf
+        a._keep = (t, o)
+        return a, o
+
+    c, g = _run_both(hip_lib, make, 't3d_pointmlp_fwd')
+    _close(c['y'], g['y'], 2e-5, 2e-5, 'y')
+    _close(c['psum'], g['psum'], 1e-4, 2e-3, 'psum')
+    _close(c['psumsq'], g['psumsq'], 1e-4, 2e-3, 'psumsq')
+    if 'pool' in mode:
+        _close(c['pmax'][c['pamax'] >= 0], g['pmax'][g['pamax'] >= 0], 2e-5, 2e-5, 'pmax')
+        _close(c['pmin'][c['pamin'] >= 0], g['pmin'][g['pamin'] >= 0], 2e-5, 2e-5, 'pmin')
+        assert ((c['pamax'] >= 0) == (g['pamax'] >= 0)).all()
+        # arg indices may differ only where two rows tie to within rounding: check the value at the GPU's index
+        yv = g['y'].reshape(T, 128, N)
+        sel = g['pamax'].long() % 128
+        got = torch.gather(yv, 1, sel.clamp(min=0)[:, None, :])[:, 0]
+        assert torch.equal(got[g['pamax'] >= 0], g['pmax'][g['pamax'] >= 0])
+        assert (c['pamax'] == g['pamax']).float().mean() > 0.999
+
+
+@pytest.mark.parametrize('M,K,N,rpf,mode', [(512, 64, 128, 256, 'dense'), (256, 128, 256, 128, 'pooled'),
+                                            (256, 64, 512, 128, 'raw_addin'), (384, 512, 256, 128, 'dense'),
+                                            (256, 256, 128, 128, 'dense_addin')])
+def test_pointmlp_dgrad(hip_lib, M, K, N, rpf, mode):
+    r = np.random.RandomState(hash((M, K, N, 1)) % 1000)
+    B, T = M // rpf, M // 128
+    dz = (r.normal(size=(M, N)) * 1e-2).astype(np.float32)
+    y = r.normal(size=(M, N)).astype(np.float32)
+    coef = r.normal(size=(3, N)).astype(np.float32)
+    coef[2] *= 1e-3
+    w = (r.normal(size=(K, N)) / np.sqrt(N)).astype(np.float32)
+    argidx = r.randint(-1, rpf, size=(B, N)).astype(np.int32)
+    dpool = r.normal(size=(B, N)).astype(np.float32)
+    add = (r.normal(size=(M, K)) * 1e-2).astype(np.float32)
+    py = r.normal(size=(M, K)).astype(np.float32)
+    psc = (0.5 + r.uniform(size=K)).astype(np.float32)
+    psh = (r.normal(size=K) * 0.3).astype(np.float32)
+
+    def make(dev):
+        t = {k: _mk(dev, v) for k, v in dict(dz=dz, y=y, coef=coef, w=w, argidx=argidx, dpool=dpool, add=add, py=py,
+                                             psc=psc, psh=psh).items()}
+        o = dict(out=torch.zeros(M, K, device=dev), s1=torch.zeros(T, K, device=dev), s2=torch.zeros(T, K, device=dev))
+        a = abi.PointMlpDgradArgs()
+        if mode == 'pooled':
+            a.dy = abi.DySrc(fptr(None), fptr(t['y']), fptr(t['coef']), iptr(t['argidx']), fptr(t['dpool']))
+        else:
+            a.dy = abi.DySrc(fptr(t['dz']), fptr(t['y']), fptr(t['coef']), iptr(None), fptr(None))
+        a.w, a.out = fptr(t['w']), fptr(o['out'])
+        if 'addin' in mode:
+            a.add_in = fptr(t['add'])
+        if not mode.startswith('raw'):
+            a.prev_y, a.prev_scale, a.prev_shift = fptr(t['py']), fptr(t['psc']), fptr(t['psh'])
+            a.psum_dz, a.psum_dzy = fptr(o['s1']), fptr(o['s2'])
+        a.M, a.K, a.N, a.rows_per_frustum = M, K, N, rpf
+        a._keep = (t, o)
+        return a, o
+
+    c, g = _run_both(hip_lib, make, 't3d_pointmlp_dgrad')
+    scale = float(c['out'].abs().max())
+    _close(c['out'], g['out'], 1e-4, 2e-5 * scale, 'out')
+    if not mode.startswith('raw'):
+        _close(c['s1'], g['s1'], 1e-3, 1e-3 * scale, 'psum_dz')
+        _close(c['s2'], g['s2'], 1e-3, 2e-3 * scale, 'psum_dzy')
+
+
+@pytest.mark.parametrize('M,K,N,rpf,rps,mode', [(512, 64, 64, 256, 128, 'dense'), (512, 3, 128, 128, 256, 'sub'),
+                                                (256, 128, 1024, 128, 64, 'pooled'), (512, 256, 128, 256, 512, 'dense'),
+                                                (256, 4, 64, 128, 32, 'raw'), (256, 512, 256, 128, 128, 'dense')])
+def test_pointmlp_wgrad(hip_lib, M, K, N, rpf, rps, mode):
+    r = np.random.RandomState(hash((M, K, N, 2)) % 1000)
+    B, S = M // rpf, M // rps
+    ldx = 4 if K <= 4 else K
+    x = r.normal(size=(M, ldx)).astype(np.float32)
+    sc = (0.5 + r.uniform(size=K)).astype(np.float32)
+    sh = r.normal(size=K).astype(np.float32) * 0.2
+    sub = r.normal(size=(B, 3)).astype(np.float32)
+    dz = (r.normal(size=(M, N)) * 1e-2).astype(np.float32)
+    y = r.normal(size=(M, N)).astype(np.float32)
+    coef = r.normal(size=(3, N)).astype(np.float32)
+    coef[2] *= 1e-3
+    argidx = r.randint(-1, rpf, size=(B, N)).astype(np.int32)
+    dpool = r.normal(size=(B, N)).astype(np.float32)
+
+    def make(dev):
+        t = {k: _mk(dev, v) for k, v in dict(x=x, sc=sc, sh=sh, sub=sub, dz=dz, y=y, coef=coef, argidx=argidx, dpool=dpool).items()}
+        o = dict(slabs=torch.zeros(S, K, N, device=dev))
+        a = abi.PointMlpWgradArgs()
+        bn = mode in ('dense', 'pooled')
+        a.a = abi.ActSrc(fptr(t['x']), ldx, 0, fptr(t['sc'] if bn else None), fptr(t['sh'] if bn else None), int(bn),
+                         fptr(t['sub'] if mode == 'sub' else None), 3)
+        if mode == 'pooled':
+            a.dy = abi.DySrc(fptr(None), fptr(t['y']), fptr(t['coef']), iptr(t['argidx']), fptr(t['dpool']))
+        else:
+            a.dy = abi.DySrc(fptr(t['dz']), fptr(t['y']), fptr(t['coef']), iptr(None), fptr(None))
+        a.slabs = fptr(o['slabs'])
+        a.M, a.K, a.N, a.rows_per_frustum, a.rows_per_split = M, K, N, rpf, rps
+        a._keep = (t, o)
+        return a, o
+
+    c, g = _run_both(hip_lib, make, 't3d_pointmlp_wgrad')
+    scale = float(c['slabs'].abs().max())
+    _close(c['slabs'], g['slabs'], 1e-4, 3e-5 * scale, 'slabs')
+
+
+def test_bn_finalizers_pool_colsum(hip_lib):
+    r = np.random.RandomState(5)
+    B, tpf, N = 4, 2, 192
+    T, M = B * tpf, B * tpf * 128
+    psum = r.normal(size=(T, N)).astype(np.float32) * 128
+    psumsq = (np.abs(r.normal(size=(T, N))) * 128 + psum ** 2 / 128).astype(np.float32)
+    gamma = (r.normal(size=N)).astype(np.float32)
+    beta = r.normal(size=N).astype(np.float32)
+    mm, mv = r.normal(size=N).astype(np.float32), (0.5 + r.uniform(size=N)).astype(np.float32)
+    for training in (1, 0):
+        def make(dev):
+            t = {k: _mk(dev, v) for k, v in dict(psum=psum, psumsq=psumsq, gamma=gamma, beta=beta, mm=mm.copy(), mv=mv.copy(),
+                                                 decay=np.array([0.7], np.float32)).items()}
+            o = dict(scale=torch.zeros(N, device=dev), shift=torch.zeros(N, device=dev), mean=torch.zeros(N, device=dev),
+                     invstd=torch.zeros(N, device=dev), mm=t['mm'], mv=t['mv'])
+            a = abi.BnFwdFinalizeArgs(fptr(t['psum']), fptr(t['psumsq']), T, M, N, fptr(t['gamma']), fptr(t['beta']),
+                                      fptr(t['mm']), fptr(t['mv']), fptr(t['decay']), 1e-3, training, 1,
+                                      fptr(o['scale']), fptr(o['shift']), fptr(o['mean']), fptr(o['invstd']))
+            a._keep = (t, o)
+            return a, o
+        c, g = _run_both(hip_lib, make, 't3d_bn_fwd_finalize')
+        for k in c:
+            _close(c[k], g[k], 1e-5, 1e-6, 'bn_fwd ' + k)
+
+    # pool finalize
+    scale = r.normal(size=N).astype(np.float32)
+    shift = r.normal(size=N).astype(np.float32)
+    pmax = r.normal(size=(T, N)).astype(np.float32)
+    pmin = (pmax - np.abs(r.normal(size=(T, N)))).astype(np.float32)
+    pamax = r.randint(0, 128, size=(T, N)).astype(np.int32) + (np.arange(T) % tpf)[:, None].astype(np.int32) * 128
+    pamin = r.randint(0, 128, size=(T, N)).astype(np.int32) + (np.arange(T) % tpf)[:, None].astype(np.int32) * 128
+    dead = r.uniform(size=(T, N)) < 0.3
+    pamax[dead] = -1
+    pamin[dead] = -1
+
+    def make_pool(dev):
+        t = {k: _mk(dev, v) for k, v in dict(scale=scale, shift=shift, pmax=pmax, pmin=pmin, pamax=pamax, pamin=pamin).items()}
+        o = dict(pooled=torch.zeros(B, N, device=dev), argidx=torch.zeros(B, N, dtype=torch.int32, device=dev),
+                 ysel=torch.zeros(B, N, device=dev))
+        a = abi.PoolFinalizeArgs(fptr(t['scale']), fptr(t['shift']), fptr(t['pmax']), fptr(t['pmin']), iptr(t['pamax']),
+                                 iptr(t['pamin']), B, N, tpf, fptr(o['pooled']), N, iptr(o['argidx']), fptr(o['ysel']))
+        a._keep = (t, o)
+        return a, o
+    c, g = _run_both(hip_lib, make_pool, 't3d_pool_finalize')
+    _close(c['pooled'], g['pooled'], 1e-6, 1e-6, 'pooled')
+    assert torch.equal(c['argidx'], g['argidx'])
+    _close(c['ysel'], g['ysel'], 0, 0, 'ysel')
+
+    # bn backward finalize (dense, pooled, frozen) + colsum
+    s1 = r.normal(size=(T, N)).astype(np.float32)
+    s2 = r.normal(size=(T, N)).astype(np.float32)
+    mean, invstd = r.normal(size=N).astype(np.float32), (0.5 + r.uniform(size=N)).astype(np.float32)
+    dpin = r.normal(size=(B, N)).astype(np.float32)
+    pooled = np.maximum(r.normal(size=(B, N)), 0).astype(np.float32)
+    ysel = r.normal(size=(B, N)).astype(np.float32)
+    for form in ('dense', 'pooled', 'frozen'):
+        def make_b(dev):
+            t = {k: _mk(dev, v) for k, v in dict(s1=s1, s2=s2, mean=mean, invstd=invstd, gamma=gamma, scale=scale, dpin=dpin,
+                                                 pooled=pooled, ysel=ysel).items()}
+            o = dict(coef=torch.zeros(3, N, device=dev), dgamma=torch.zeros(N, device=dev), dbeta=torch.zeros(N, device=dev),
+                     dpool=torch.zeros(B, N, device=dev))
+            a = abi.BnBwdFinalizeArgs()
+            if form == 'pooled':
+                a.dpool_in, a.ld_dpool_in, a.pooled, a.ld_pooled = fptr(t['dpin']), N, fptr(t['pooled']), N
+                a.ysel, a.dpool, a.B = fptr(t['ysel']), fptr(o['dpool']), B
+            else:
+                a.psum_dz, a.psum_dzy, a.n_tiles = fptr(t['s1']), fptr(t['s2']), T
+            a.count, a.N = M, N
+            a.gamma, a.mean, a.invstd, a.scale = fptr(t['gamma']), fptr(t['mean']), fptr(t['invstd']), fptr(t['scale'])
+            a.frozen = int(form == 'frozen')
+            a.dgamma, a.dbeta, a.coef = fptr(o['dgamma']), fptr(o['dbeta']), fptr(o['coef'])
+            a._keep = (t, o)
+            return a, o
+        c, g = _run_both(hip_lib, make_b, 't3d_bn_bwd_finalize')
+        for k in c:
+            _close(c[k], g[k], 1e-5, 1e-6, 'bn_bwd %s %s' % (form, k))
+
+    coef = r.normal(size=(3, N)).astype(np.float32)
+
+    def make_c(dev):
+        t = {k: _mk(dev, v) for k, v in dict(s1=s1, psum=psum, coef=coef).items()}
+        o = dict(out=torch.zeros(B, N, device=dev))
+        a = abi.DyColsumArgs(fptr(t['s1']), fptr(t['psum']), fptr(t['coef']), B, N, tpf, tpf * 128, -1.0, fptr(o['out']))
+        a._keep = (t, o)
+        return a, o
+    c, g = _run_both(hip_lib, make_c, 't3d_dy_colsum')
+    _close(c['out'], g['out'], 1e-5, 1e-4, 'colsum')
+
+
+@pytest.mark.parametrize('B,K,K2,N,bn,act,drop,train', [
+    (32, 256, 0, 256, True, 'relu', False, 1), (32, 512, 10, 512, True, 'leaky_relu', True, 1),
+    (32, 256, 0, 67, False, None, False, 1), (8, 128, 0, 3, False, None, False, 1),
+    (64, 512, 0, 256, True, 'tanh', True, 1), (32, 1024, 0, 512, False, None, False, 1),
+    (32, 512, 0, 512, True, 'relu', False, 0), (128, 256, 0, 9, False, None, False, 1)])
+def test_fc_fwd_bwd_dinput(hip_lib, B, K, K2, N, bn, act, drop, train):
+    r = np.random.RandomState(hash((B, K, N)) % 1000)
+    x = r.normal(size=(B, K)).astype(np.float32)
+    x2 = r.normal(size=(B, max(K2, 1))).astype(np.float32)
+    w = (r.normal(size=(K + K2, N)) / np.sqrt(K)).astype(np.float32)
+    bias = (r.normal(size=N) * 0.1).astype(np.float32)
+    gamma, beta = (0.5 + r.uniform(size=N)).astype(np.float32), (r.normal(size=N) * 0.1).astype(np.float32)
+    mm, mv = r.normal(size=N).astype(np.float32) * 0.1, (0.5 + r.uniform(size=N)).astype(np.float32)
+    mask = (r.uniform(size=(B, N)) < 0.7).astype(np.float32)
+    add = r.normal(size=(B, 3)).astype(np.float32)
+    dout = r.normal(size=(B, N)).astype(np.float32)
+    Nn = 96
+    dyn = r.normal(size=(B, Nn)).astype(np.float32)
+    wn = (r.normal(size=(N, Nn)) / np.sqrt(N)).astype(np.float32)
+    saved = {}
+
+    def make_f(dev):
+        t = {k: _mk(dev, v) for k, v in dict(x=x, x2=x2, w=w, bias=bias, gamma=gamma, beta=beta, mm=mm.copy(), mv=mv.copy(),
+                                             mask=mask, add=add, decay=np.array([0.6], np.float32)).items()}
+        o = dict(y=torch.zeros(B, N, device=dev), out=torch.zeros(B, N, device=dev), mean=torch.zeros(N, device=dev),
+                 invstd=torch.ones(N, device=dev), mm=t['mm'], mv=t['mv'])
+        a = abi.FcFwdArgs()
+        a.in_, a.ld_in, a.K, a.in2, a.ld_in2, a.K2 = fptr(t['x']), K, K, fptr(t['x2'] if K2 else None), max(K2, 1), K2
+        a.w, a.bias = fptr(t['w']), fptr(t['bias'])
+        if bn:
+            a.gamma, a.beta, a.moving_mean, a.moving_var = fptr(t['gamma']), fptr(t['beta']), fptr(t['mm']), fptr(t['mv'])
+            a.mean, a.invstd = fptr(o['mean']), fptr(o['invstd'])
+        a.decay, a.eps, a.is_training, a.unbiased_ema = fptr(t['decay']), 1e-3, train, 1
+        a.act, a.leaky_alpha = abi.ACT_BY_NAME[act], 0.2
+        if drop:
+            a.drop_mask, a.keep_prob = fptr(t['mask']), 0.7
+        if N >= 3 and not bn:
+            a.add_in, a.ld_add, a.add_n = fptr(t['add']), 3, 3
+        a.y, a.out, a.ld_out, a.B, a.N = fptr(o['y']), fptr(o['out']), N, B, N
+        a._keep = (t, o)
+        saved[dev.type] = (t, o)
+        return a, o
+    c, g = _run_both(hip_lib, make_f, 't3d_fc_fwd')
+    for k in c:
+        _close(c[k], g[k], 2e-4, 2e-4, 'fc_fwd ' + k)
+
+    for src in ('dout', 'next'):
+        def make_b(dev):
+            tf, of = saved[dev.type]
+            t = {k: _mk(dev, v) for k, v in dict(dout=dout, dyn=dyn, wn=wn).items()}
+            yc = _mk(dev, saved['cpu'][1]['y'].numpy())          # identical saved activations on both sides
+            mc, ic = _mk(dev, saved['cpu'][1]['mean'].numpy()), _mk(dev, saved['cpu'][1]['invstd'].numpy())
+            o = dict(dy=torch.zeros(B, N, device=dev), dw=torch.zeros(K + K2, N, device=dev), db=torch.zeros(N, device=dev),
+                     dgamma=torch.zeros(N, device=dev), dbeta=torch.zeros(N, device=dev))
+            a = abi.FcBwdArgs()
+            if src == 'dout':
+                a.dout, a.ld_dout = fptr(t['dout']), N
+            else:
+                a.dy_next, a.w_next, a.N_next = fptr(t['dyn']), fptr(t['wn']), Nn
+            a.in_, a.ld_in, a.K, a.in2, a.ld_in2, a.K2 = fptr(tf['x']), K, K, fptr(tf['x2'] if K2 else None), max(K2, 1), K2
+            a.y, a.out, a.ld_out = fptr(yc), fptr(of['out']), N
+            if bn:
+                a.gamma, a.beta, a.mean, a.invstd = fptr(tf['gamma']), fptr(tf['beta']), fptr(mc), fptr(ic)
+            a.bn_training, a.act, a.leaky_alpha = train, abi.ACT_BY_NAME[act], 0.2
+            if drop:
+                a.drop_mask, a.keep_prob = fptr(tf['mask']), 0.7
+            a.dy, a.dw, a.dbias, a.dgamma, a.dbeta = fptr(o['dy']), fptr(o['dw']), fptr(o['db']), fptr(o['dgamma']), fptr(o['dbeta'])
+            a.B, a.N = B, N
+            a._keep = (t, o, yc, mc, ic)
+            return a, o
+        c, g = _run_both(hip_lib, make_b, 't3d_fc_bwd')
+        for k in c:
+            sc = max(float(c[k].abs().max()), 1e-6)
+            _close(c[k], g[k], 5e-4, 2e-4 * sc, 'fc_bwd %s %s' % (src, k))
+
+    def make_d(dev):
+        t = {k: _mk(dev, v) for k, v in dict(dy=dout, w=w, add=r.normal(size=(B, K)).astype(np.float32) * 0 + 0.5).items()}
+        o = dict(din=torch.zeros(B, K, device=dev))
+        a = abi.FcDinputArgs(fptr(t['dy']), N, fptr(t['w']), fptr(t['add']), K, -1.0, fptr(o['din']), K, B, K)
+        a._keep = (t, o)
+        return a, o
+    c, g = _run_both(hip_lib, make_d, 't3d_fc_dinput')
+    _close(c['din'], g['din'], 2e-4, 2e-4 * float(c['din'].abs().max()), 'fc_dinput')
+
+
+@pytest.mark.parametrize('mode', ['train', 'infer', 'train_nodrop'])
+def test_seg_head_and_finalize(hip_lib, mode):
+    r = np.random.RandomState(9)
+    B, rpf, K, Cc = 3, 256, 128, 4
+    M, T, tpf = B * rpf, B * rpf // 128, rpf // 128
+    y = r.normal(size=(M, K)).astype(np.float32)
+    sc, sh = (0.5 + r.uniform(size=K)).astype(np.float32), (r.normal(size=K) * 0.3).astype(np.float32)
+    dm = (r.uniform(size=(M, K)) < 0.5).astype(np.float32)
+    w, b = (r.normal(size=(K, 2)) * 0.2).astype(np.float32), np.array([0.1, -0.2], np.float32)
+    lab = (r.uniform(size=M) < 0.3).astype(np.int32)
+    is2d = np.array([0, 1, 0], np.int32)
+    pc = r.normal(size=(M, Cc)).astype(np.float32)
+    saved = {}
+
+    def make(dev):
+        t = {k: _mk(dev, v) for k, v in dict(y=y, sc=sc, sh=sh, dm=dm, w=w, b=b, lab=lab, is2d=is2d, pc=pc).items()}
+        o = dict(logits=torch.zeros(M, 2, device=dev), mask=torch.zeros(M, device=dev), part=torch.zeros(T, 8, device=dev))
+        a = abi.SegHeadArgs()
+        a.y, a.scale, a.shift = fptr(t['y']), fptr(t['sc']), fptr(t['sh'])
+        if mode == 'train':
+            a.drop_mask, a.keep_prob = fptr(t['dm']), 0.5
+        a.w, a.bias, a.pc, a.ld_pc, a.ce_weight = fptr(t['w']), fptr(t['b']), fptr(t['pc']), Cc, 1.0
+        if mode != 'infer':
+            a.labels, a.is_data_2D = iptr(t['lab']), iptr(t['is2d'])
+            o.update(dz=torch.zeros(M, K, device=dev), s1=torch.zeros(T, K, device=dev), s2=torch.zeros(T, K, device=dev),
+                     dwp=torch.zeros(T, K, 2, device=dev))
+            a.dz, a.psum_dz, a.psum_dzy, a.dw_part = fptr(o['dz']), fptr(o['s1']), fptr(o['s2']), fptr(o['dwp'])
+        a.logits, a.mask, a.part = fptr(o['logits']), fptr(o['mask']), fptr(o['part'])
+        a.M, a.K, a.rows_per_frustum, a.B = M, K, rpf, B
+        a._keep = (t, o)
+        saved[dev.type] = o
+        return a, o
+    c, g = _run_both(hip_lib, make, 't3d_seg_head')
+    _close(c['logits'], g['logits'], 1e-5, 2e-5, 'logits')
+    # the hard mask may legitimately differ only where |l0-l1| is at rounding level
+    diff = (c['mask'] != g['mask'])
+    assert (c['logits'][diff, 0] - c['logits'][diff, 1]).abs().max().item() < 1e-4 if diff.any() else True
+    if not diff.any():
+        _close(c['part'], g['part'], 1e-4, 1e-3, 'part')
+    if mode != 'infer':
+        _close(c['dz'], g['dz'], 1e-4, 1e-8, 'dz')
+        _close(c['s1'], g['s1'], 1e-3, 1e-6, 'psum_dz')
+        _close(c['s2'], g['s2'], 1e-3, 1e-6, 'psum_dzy')
+        _close(c['dwp'], g['dwp'], 1e-3, 1e-6, 'dw_part')
+
+    def make_f(dev):
+        o_prev = saved[dev.type]
+        part = _mk(dev, saved['cpu']['part'].numpy())
+        o = dict(mean=torch.zeros(B, 3, device=dev), seg=torch.zeros(B, device=dev), dw=torch.zeros(K, 2, device=dev),
+                 db=torch.zeros(2, device=dev), nc=torch.zeros(1, device=dev))
+        a = abi.SegFinalizeArgs()
+        a.part, a.B, a.tiles_per_frustum, a.rows_per_frustum, a.K = fptr(part), B, tpf, rpf, K
+        a.mask_xyz_mean, a.seg_loss, a.n_correct = fptr(o['mean']), fptr(o['seg']), fptr(o['nc'])
+        if mode != 'infer':
+            dwp = _mk(dev, saved['cpu']['dwp'].numpy())
+            a.dw_part, a.dw, a.dbias = fptr(dwp), fptr(o['dw']), fptr(o['db'])
+            a._keep2 = dwp
+        a._keep = (part, o)
+        return a, o
+    c, g = _run_both(hip_lib, make_f, 't3d_seg_finalize')
+    for k in c:
+        _close(c[k], g[k], 1e-5, 1e-6, 'seg_finalize ' + k)
+
+
+@pytest.mark.parametrize('norm3d', [0, 1])
+def test_strong_loss(hip_lib, norm3d):
+    r = np.random.RandomState(21)
+    B = 32
+    box = r.normal(size=(B, 67)).astype(np.float32) * 0.5
+    s1 = r.normal(size=(B, 3)).astype(np.float32)
+    seg = np.abs(r.normal(size=B)).astype(np.float32)
+    yc = (s1 + r.normal(size=(B, 3)) * 1.5).astype(np.float32)
+    yoc, ydc = r.randint(0, 12, size=B).astype(np.int32), r.randint(0, 10, size=B).astype(np.int32)
+    yor = r.uniform(-0.26, 0.26, size=B).astype(np.float32)
+    ydr = (r.normal(size=(B, 3)) * 0.1).astype(np.float32)
+    is2d = (r.uniform(size=B) < 0.3).astype(np.int32)
+
+    def make(dev):
+        t = {k: _mk(dev, v) for k, v in dict(box=box, s1=s1, seg=seg, yc=yc, yoc=yoc, ydc=ydc, yor=yor, ydr=ydr, is2d=is2d).items()}
+        o = dict(dbox=torch.zeros(B, 67, device=dev), ds1=torch.zeros(B, 3, device=dev), terms=torch.zeros(B, 8, device=dev),
+                 tot=torch.zeros(B, device=dev), loss=torch.zeros(1, device=dev), center=torch.zeros(B, 3, device=dev),
+                 dims=torch.zeros(B, 3, device=dev), theta=torch.zeros(B, device=dev))
+        a = abi.StrongLossArgs()
+        a.box, a.ld_box, a.stage1_center, a.seg_loss = fptr(t['box']), 67, fptr(t['s1']), fptr(t['seg'])
+        a.y_center, a.y_orient_cls, a.y_orient_reg = fptr(t['yc']), iptr(t['yoc']), fptr(t['yor'])
+        a.y_dims_cls, a.y_dims_reg, a.is_data_2D = iptr(t['ydc']), fptr(t['ydr']), iptr(t['is2d'])
+        a.wts = abi.StrongWeights(1.0, 1.0, 20.0, 1.0, 20.0, 1.0, 1.0, 0.1, 1.0)
+        a.normalize_by_3d_count = norm3d
+        a.dbox, a.dstage1, a.terms, a.total_losses, a.loss = fptr(o['dbox']), fptr(o['ds1']), fptr(o['terms']), fptr(o['tot']), fptr(o['loss'])
+        a.center, a.reg_dims, a.reg_theta, a.B = fptr(o['center']), fptr(o['dims']), fptr(o['theta']), B
+        a._keep = (t, o)
+        return a, o
+    c, g = _run_both(hip_lib, make, 't3d_strong_loss')
+    for k in c:
+        sc = max(float(c[k].abs().max()), 1e-6)
+        _close(c[k], g[k], 1e-4, 2e-5 * sc, 'strong_loss ' + k)
+
+
+def test_reduce_slabs_adam_schedule_dropout(hip_lib):
+    r = np.random.RandomState(4)
+    fake = FakeLib()
+    s = torch.cuda.current_stream().cuda_stream
+    # reduce slabs
+    sizes = [(5, 640), (3, 67), (16, 4096)]
+    slab = np.concatenate([r.normal(size=ns * ne) for ns, ne in sizes]).astype(np.float32)
+    table = (abi.SlabDesc * 3)()
+    so, go = 0, 8
+    for i, (ns, ne) in enumerate(sizes):
+        table[i] = abi.SlabDesc(so, go, ne, ns)
+        so += ns * ne
+        go += ne + 4
+    gc, gg = torch.zeros(go), torch.zeros(go, device='cuda')
+    sc_, sg = torch.as_tensor(slab), torch.as_tensor(slab).cuda()
+    fake.t3d_reduce_slabs(fptr(sc_), fptr(gc), table, 3, 4096, None)
+    tab_dev = torch.as_tensor(np.frombuffer(bytes(table), dtype=np.uint8).copy()).cuda()
+    assert hip_lib.t3d_reduce_slabs(fptr(sg), fptr(gg), C.cast(C.c_void_p(tab_dev.data_ptr()), C.POINTER(abi.SlabDesc)), 3, 4096, s) == 0
+    torch.cuda.synchronize()
+    _close(gc, gg.cpu(), 1e-5, 1e-5, 'reduce_slabs')
+
+    # schedule + adam, three steps, incl. a step across the lr staircase
+    sched = abi.Schedule(1e-3, 0.5, 800000.0, 0.5, 0.5, 800000.0, 0.99, 0.9, 0.999, 32)
+    n = 10007
+    w0, g0 = r.normal(size=n).astype(np.float32), (r.normal(size=n) * 1e-2).astype(np.float32)
+    for start in (0.0, 24999.0):
+        hc, hg = torch.tensor([start, 0, 0, 0]), torch.tensor([start, 0, 0, 0]).cuda()
+        ws = [torch.as_tensor(w0.copy()), torch.as_tensor(w0.copy()).cuda()]
+        ms = [torch.zeros(n), torch.zeros(n).cuda()]
+        vs = [torch.zeros(n), torch.zeros(n).cuda()]
+        gs = [torch.as_tensor(g0), torch.as_tensor(g0).cuda()]
+        for it in range(3):
+            fake.t3d_schedule_step(fptr(hc), C.byref(sched), None)
+            assert hip_lib.t3d_schedule_step(fptr(hg), C.byref(sched), s) == 0
+            fake.t3d_adam_tf_step(fptr(ws[0]), fptr(gs[0]), fptr(ms[0]), fptr(vs[0]), n, fptr(hc), 0.9, 0.999, 1e-8, 0.5, None)
+            assert hip_lib.t3d_adam_tf_step(fptr(ws[1]), fptr(gs[1]), fptr(ms[1]), fptr(vs[1]), n, fptr(hg), 0.9, 0.999, 1e-8, 0.5, s) == 0
+        torch.cuda.synchronize()
+        _close(hc, hg.cpu(), 1e-6, 1e-9, 'hyper')
+        _close(ws[0], ws[1].cpu(), 1e-6, 1e-7, 'adam w')
+        _close(vs[0], vs[1].cpu(), 1e-5, 1e-12, 'adam v')
+    assert abs(float(hc[1]) - 5e-4) < 1e-9 and abs(float(hc[2]) - 0.75) < 1e-7      # 25000*32 >= 800000
+
+    # dropout mask: 0/1 valued, keep fraction, fresh per step
+    n = 1 << 20
+    m1, m2 = torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
+    h = torch.tensor([3.0, 0, 0, 0]).cuda()
+    assert hip_lib.t3d_dropout_mask(fptr(m1), n, 0.7, 1234, fptr(h), s) == 0
+    h2 = torch.tensor([4.0, 0, 0, 0]).cuda()
+    assert hip_lib.t3d_dropout_mask(fptr(m2), n, 0.7, 1234, fptr(h2), s) == 0
+    torch.cuda.synchronize()
+    assert set(m1.unique().tolist()) == {0.0, 1.0}
+    assert abs(float(m1.mean()) - 0.7) < 5e-3 and abs(float(m2.mean()) - 0.7) < 5e-3
+    assert abs(float((m1 == m2).float().mean()) - (0.49 + 0.09)) < 5e-3
+
+
+def test_bad_arguments_are_rejected(hip_lib):
+    a = abi.PointMlpFwdArgs()
+    assert hip_lib.t3d_pointmlp_fwd(C.byref(a), None) == -1                     # T3D_ERR_ARG
+    x = torch.zeros(130, 64, device='cuda')
+    o = torch.zeros(130, 64, device='cuda')
+    a.a = abi.ActSrc(fptr(x), 64, 0, fptr(None), fptr(None), 0, fptr(None), 0)
+    a.w, a.y, a.psum, a.psumsq = fptr(x), fptr(o), fptr(o), fptr(o)
+    a.M, a.K, a.N, a.rows_per_frustum = 130, 64, 64, 130
+    assert hip_lib.t3d_pointmlp_fwd(C.byref(a), None) == -2                     # T3D_ERR_SHAPE

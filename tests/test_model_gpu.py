@@ -1,0 +1,81 @@
+"""GPU: the whole SEMI_MODEL A step (seg PointNet + T-Net + box PointNet, forward + backward) through the
+C ABI on the MI355X, against the fp64 oracle and the committed golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from model_check import check_against_oracle, load_golden, run_model_a
+from oracle import ref_torch as R
+from transferable3d_amd.engine import Runtime
+from transferable3d_amd.synthetic import make_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(C, seed):
+    return R.init_params(np.random.RandomState(seed), R.layer_table(C, 'A'))
+
+
+@pytest.mark.parametrize('B,N,seed', [(4, 256, 1), (8, 512, 2)])
+def test_model_a_step_matches_oracle(hip_lib, B, N, seed):
+    C = 4
+    batch = make_batch(B, N, C, seed=seed, dropout_scopes={'inst_seg/dp1': ((B, N, 128), 0.5)})
+    P = _params(C, 7 + seed)
+    c = R.default_config()
+    g, m = run_model_a(Runtime(lib=hip_lib), batch, P, c)
+    res = check_against_oracle(g, m, batch, P, c)
+    print(res)
+
+
+def test_model_a_matches_golden_vectors(hip_lib):
+    batch, P, z = load_golden('model_a_B2_N128.npz')
+    g, m = run_model_a(Runtime(lib=hip_lib), batch, P, R.default_config())
+    e = m.end_points()
+    for k in ('logits', 'stage1_center', 'center', 'box_params', 'feats_lv1', 'mask_xyz_mean'):
+        ref = z['out/' + k]
+        got = e[k].cpu().numpy().reshape(ref.shape)
+        assert np.abs(got - ref).max() < 1e-4 * max(1.0, np.abs(ref).max()), k     # BASELINE.json: 1e-4 fp32
+    assert abs(float(e['loss'].cpu()) - float(z['out/loss'])) < 1e-4 * float(z['out/loss'])
+    gmax = max(float(np.abs(z[k]).max()) for k in z.files if k.startswith('grad/'))
+    for k in z.files:
+        if k.startswith('grad/') and k != 'grad/box_est/fc1/weights':
+            ref = z[k]
+            mine = g.vars.grad(k[5:]).cpu().numpy().reshape(ref.shape)
+            assert np.abs(mine - ref).max() < 5e-3 * max(np.abs(ref).max(), 1e-2 * gmax), k
+
+
+def test_full_size_properties(hip_lib):
+    """BASELINE size (B=32, N=1024): size-independent properties instead of an fp64 oracle run.
+    (1) batch-norm'd activations have zero mean / unit variance per channel; (2) the analytically-zero
+    gradients (conv biases, beta of a layer feeding only a batch-norm) vanish; (3) permuting the frustums
+    permutes the per-frustum outputs and leaves the weight gradients unchanged; (4) two runs are bit-identical
+    (no atomics anywhere on the path)."""
+    B, N, C = 32, 1024, 4
+    batch = make_batch(B, N, C, seed=1234, dropout_scopes={'inst_seg/dp1': ((B, N, 128), 0.5)})
+    P = _params(C, 99)
+    c = R.default_config()
+    rt = Runtime(lib=hip_lib)
+    g, m = run_model_a(rt, batch, P, c)
+    L = m.seg.L7
+    z = L.y * L.scale + L.shift
+    assert float(z.mean(0).abs().max()) < 1e-4 and float((z.var(0, unbiased=False) - 1).abs().max()) < 2e-2
+    gscale = float(g.vars.grads.abs().max())
+    assert float(g.vars.grad('inst_seg/conv5/bn/beta').abs().max()) < 1e-5 * gscale
+    e1 = {k: v.clone() for k, v in m.end_points().items()}
+    grads1 = g.vars.grads.clone()
+    g.fwd.run()
+    g.bwd.run()
+    torch.cuda.synchronize()
+    assert torch.equal(grads1, g.vars.grads)
+    assert torch.equal(e1['logits'], m.end_points()['logits'])
+    perm = np.random.RandomState(0).permutation(B)
+    b2 = {k: (v[perm] if isinstance(v, np.ndarray) and v.shape[0] == B else v) for k, v in batch.items()}
+    b2['dropout_masks'] = {k: v[perm] for k, v in batch['dropout_masks'].items()}
+    g2, m2 = run_model_a(rt, b2, P, c)
+    e2 = m2.end_points()
+    pt = torch.as_tensor(perm, device=e2['logits'].device)
+    assert float((e2['logits'] - e1['logits'][pt]).abs().max()) < 1e-4
+    assert float((e2['box_params'] - e1['box_params'][pt]).abs().max()) < 1e-4
+    assert abs(float(e2['loss']) - float(e1['loss'])) < 1e-5 * float(e1['loss'])
+    rel = float((g2.vars.grads - grads1).norm() / grads1.norm())
+    assert rel < 1e-3, rel

@@ -1,0 +1,87 @@
+"""CPU: the two independently written oracle restatements agree, autograd matches finite differences,
+and the committed golden fixture still reproduces (parity is unpinned against TF, so the
+pins are these cross-checks)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_np, ref_torch as R
+from transferable3d_amd.synthetic import make_batch
+
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def _setup(B=4, N=128, C=4, seed=1, pseed=7):
+    batch = make_batch(B, N, C, seed=seed, dropout_scopes={'inst_seg/dp1': ((B, N, 128), 0.5)})
+    P = R.init_params(np.random.RandomState(pseed), R.layer_table(C, 'A'))
+    return batch, P, R.default_config()
+
+
+def test_param_count_matches_survey():
+    _, P, _ = _setup()
+    assert sum(P[k].numel() for k in R.trainable_names(P)) == 1639688
+
+
+def test_torch_and_numpy_restatements_agree():
+    batch, P, c = _setup()
+    loss, ep, _, _ = R.model_a_forward_backward(P, batch, c, want_grads=False)
+    ln, o = ref_np.model_a_forward({k: v.numpy() for k, v in P.items()}, batch, c)
+    assert abs(float(loss) - ln) < 1e-9
+    for k in ('logits', 'stage1_center', 'center', 'box_params', 'feats_lv1', 'tnet_feats', 'seg_global_feat'):
+        assert np.abs(ep[k].detach().numpy() - o[k]).max() < 1e-9, k
+    for k, v in ep['loss_terms'].items():
+        assert np.abs(v.detach().numpy() - o['loss_terms'][k]).max() < 1e-9, k
+    _, dims, theta = ep['S_pred_box_reg']
+    assert np.abs(dims.detach().numpy() - o['S_dims']).max() < 1e-9
+    assert np.abs(theta.detach().numpy() - o['S_theta']).max() < 1e-9
+
+
+def test_autograd_matches_finite_differences_of_numpy_forward():
+    batch, P, c = _setup()
+    _, _, grads, _ = R.model_a_forward_backward(P, batch, c)
+    Pn = {k: v.numpy().copy() for k, v in P.items()}
+    probes = [('inst_seg/conv2/weights', (0, 0, 3, 5)), ('inst_seg/conv6/weights', (0, 0, 700, 11)),
+              ('inst_seg/conv10/weights', (0, 0, 5, 1)), ('tnet/fc2-stage1/weights', (7, 9)),
+              ('tnet/conv-reg1-stage1/weights', (0, 0, 1, 3)), ('box_est/conv-reg2/bn/gamma', (4,)),
+              ('box_est/fc3/biases', (20,)), ('box_est/conv-reg1/weights', (0, 0, 2, 77))]
+    for name, idx in probes:
+        h = 1e-6
+        Pp = {k: v.copy() for k, v in Pn.items()}
+        Pm = {k: v.copy() for k, v in Pn.items()}
+        Pp[name][idx] += h
+        Pm[name][idx] -= h
+        fd = (ref_np.model_a_forward(Pp, batch, c)[0] - ref_np.model_a_forward(Pm, batch, c)[0]) / (2 * h)
+        assert abs(fd - grads[name][idx].item()) < 1e-6 * max(1.0, abs(fd)), (name, fd, grads[name][idx].item())
+
+
+def test_conv_bias_gradient_vanishes_under_batch_norm():
+    batch, P, c = _setup()
+    _, _, grads, _ = R.model_a_forward_backward(P, batch, c)
+    assert grads['inst_seg/conv3/biases'].abs().max() < 1e-12
+    assert grads['box_est/fc3/biases'].abs().max() > 1e-3
+
+
+def test_adam_tf_form_and_schedules():
+    assert R.learning_rate(0, 32) == 1e-3 and R.learning_rate(25000, 32) == 5e-4
+    assert R.bn_decay(0, 32) == 0.5 and R.bn_decay(25000, 32) == 0.75 and R.bn_decay(10 ** 7, 32) == 0.99
+    P = {'w': torch.tensor([1.0, -2.0], dtype=torch.float64)}
+    g = {'w': torch.tensor([0.1, -0.3], dtype=torch.float64)}
+    m = {'w': torch.zeros(2, dtype=torch.float64)}
+    v = {'w': torch.zeros(2, dtype=torch.float64)}
+    R.adam_tf_step(P, g, m, v, 1, 1e-3)
+    # first step: m_hat/sqrt(v_hat) = sign(g) up to eps placement -> w moves by ~lr
+    assert np.allclose(P['w'].numpy(), [1.0 - 1e-3, -2.0 + 1e-3], atol=1e-9)
+
+
+def test_golden_fixture_reproduces():
+    """The committed vectors were produced by tests/golden/make_fixtures.py from this oracle."""
+    from model_check import load_golden
+    batch, P, z = load_golden('model_a_B2_N128.npz')
+    loss, ep, grads, ema = R.model_a_forward_backward(P, batch, R.default_config())
+    assert abs(float(loss) - float(z['out/loss'])) < 1e-10
+    assert np.abs(ep['logits'].detach().numpy() - z['out/logits']).max() < 1e-10
+    assert np.abs(grads['box_est/fc1/weights'].numpy()[:8] - z['grad/box_est/fc1/weights']).max() < 1e-10
+    for k, g in grads.items():
+        assert abs(float(g.norm()) - float(z['gradnorm/' + k])) < 1e-9 * max(1.0, float(z['gradnorm/' + k])), k

@@ -1,0 +1,191 @@
+"""ctypes view of include/t3d.h: argument structs + loader for libt3d.so.
+
+The product path has no fallback: `load()` raises if the HIP library is missing or does not export
+every entry point the header declares.
+"""
+import ctypes as C
+import os
+
+F = C.POINTER(C.c_float)
+I = C.POINTER(C.c_int32)
+i32, f32 = C.c_int, C.c_float
+
+TILE_ROWS = 128
+ACT_NONE, ACT_RELU, ACT_LEAKY_RELU, ACT_TANH = 0, 1, 2, 3
+ACT_BY_NAME = {None: ACT_NONE, 'relu': ACT_RELU, 'leaky_relu': ACT_LEAKY_RELU, 'tanh': ACT_TANH}
+
+
+class ActSrc(C.Structure):
+    _fields_ = [('x', F), ('ldx', i32), ('coff', i32), ('scale', F), ('shift', F), ('relu', i32),
+                ('sub', F), ('sub_ld', i32)]
+
+
+class DySrc(C.Structure):
+    _fields_ = [('dz', F), ('y', F), ('coef', F), ('argidx', I), ('dpool', F)]
+
+
+class PointMlpFwdArgs(C.Structure):
+    _fields_ = [('a', ActSrc), ('w', F), ('bias', F), ('rowbias', F), ('y', F), ('psum', F), ('psumsq', F),
+                ('rowmask', F), ('pmax', F), ('pmin', F), ('pamax', I), ('pamin', I),
+                ('M', i32), ('K', i32), ('N', i32), ('rows_per_frustum', i32)]
+
+
+class BnFwdFinalizeArgs(C.Structure):
+    _fields_ = [('psum', F), ('psumsq', F), ('n_tiles', i32), ('count', i32), ('N', i32), ('gamma', F), ('beta', F),
+                ('moving_mean', F), ('moving_var', F), ('decay', F), ('eps', f32), ('is_training', i32),
+                ('unbiased_ema', i32), ('scale', F), ('shift', F), ('mean', F), ('invstd', F)]
+
+
+class PoolFinalizeArgs(C.Structure):
+    _fields_ = [('scale', F), ('shift', F), ('pmax', F), ('pmin', F), ('pamax', I), ('pamin', I),
+                ('B', i32), ('N', i32), ('tiles_per_frustum', i32), ('pooled', F), ('ld_pooled', i32),
+                ('argidx', I), ('ysel', F)]
+
+
+class PointMlpDgradArgs(C.Structure):
+    _fields_ = [('dy', DySrc), ('w', F), ('add_in', F), ('prev_y', F), ('prev_scale', F), ('prev_shift', F),
+                ('out', F), ('psum_dz', F), ('psum_dzy', F), ('M', i32), ('K', i32), ('N', i32),
+                ('rows_per_frustum', i32)]
+
+
+class PointMlpWgradArgs(C.Structure):
+    _fields_ = [('a', ActSrc), ('dy', DySrc), ('slabs', F), ('M', i32), ('K', i32), ('N', i32),
+                ('rows_per_frustum', i32), ('rows_per_split', i32)]
+
+
+class BnBwdFinalizeArgs(C.Structure):
+    _fields_ = [('psum_dz', F), ('psum_dzy', F), ('n_tiles', i32), ('dpool_in', F), ('ld_dpool_in', i32),
+                ('pooled', F), ('ld_pooled', i32), ('ysel', F), ('dpool', F), ('B', i32), ('count', i32), ('N', i32),
+                ('gamma', F), ('mean', F), ('invstd', F), ('scale', F), ('frozen', i32), ('dgamma', F), ('dbeta', F),
+                ('coef', F)]
+
+
+class DyColsumArgs(C.Structure):
+    _fields_ = [('psum_dz', F), ('psum_y', F), ('coef', F), ('B', i32), ('N', i32), ('tiles_per_frustum', i32),
+                ('rows_per_frustum', i32), ('alpha', f32), ('out', F)]
+
+
+class FcFwdArgs(C.Structure):
+    _fields_ = [('in_', F), ('ld_in', i32), ('K', i32), ('in2', F), ('ld_in2', i32), ('K2', i32), ('w', F), ('bias', F),
+                ('gamma', F), ('beta', F), ('moving_mean', F), ('moving_var', F), ('decay', F), ('eps', f32),
+                ('is_training', i32), ('unbiased_ema', i32), ('act', i32), ('leaky_alpha', f32), ('drop_mask', F),
+                ('keep_prob', f32), ('add_in', F), ('ld_add', i32), ('add_n', i32), ('y', F), ('out', F),
+                ('ld_out', i32), ('mean', F), ('invstd', F), ('B', i32), ('N', i32)]
+
+
+class FcBwdArgs(C.Structure):
+    _fields_ = [('dout', F), ('ld_dout', i32), ('dy_next', F), ('w_next', F), ('N_next', i32),
+                ('in_', F), ('ld_in', i32), ('K', i32), ('in2', F), ('ld_in2', i32), ('K2', i32),
+                ('y', F), ('out', F), ('ld_out', i32), ('gamma', F), ('beta', F), ('mean', F), ('invstd', F),
+                ('bn_training', i32), ('act', i32), ('leaky_alpha', f32), ('drop_mask', F), ('keep_prob', f32),
+                ('dy', F), ('dw', F), ('dbias', F), ('dgamma', F), ('dbeta', F), ('B', i32), ('N', i32)]
+
+
+class FcDinputArgs(C.Structure):
+    _fields_ = [('dy', F), ('N', i32), ('w', F), ('add_in', F), ('ld_add', i32), ('alpha', f32), ('din', F),
+                ('ld_din', i32), ('B', i32), ('K', i32)]
+
+
+class SegHeadArgs(C.Structure):
+    _fields_ = [('y', F), ('scale', F), ('shift', F), ('drop_mask', F), ('keep_prob', f32), ('w', F), ('bias', F),
+                ('labels', I), ('is_data_2D', I), ('pc', F), ('ld_pc', i32), ('ce_weight', f32), ('logits', F),
+                ('mask', F), ('part', F), ('dz', F), ('psum_dz', F), ('psum_dzy', F), ('dw_part', F),
+                ('M', i32), ('K', i32), ('rows_per_frustum', i32), ('B', i32)]
+
+
+class SegFinalizeArgs(C.Structure):
+    _fields_ = [('part', F), ('dw_part', F), ('B', i32), ('tiles_per_frustum', i32), ('rows_per_frustum', i32),
+                ('K', i32), ('mask_xyz_mean', F), ('seg_loss', F), ('dw', F), ('dbias', F), ('n_correct', F)]
+
+
+class StrongWeights(C.Structure):
+    _fields_ = [(n, f32) for n in ('center', 'orient_cls', 'orient_reg', 'dims_cls', 'dims_reg', 'tnet_center',
+                                   'corner', 'box_multiplier', 'cross_entropy')]
+
+
+class StrongLossArgs(C.Structure):
+    _fields_ = [('box', F), ('ld_box', i32), ('stage1_center', F), ('seg_loss', F), ('y_center', F),
+                ('y_orient_cls', I), ('y_orient_reg', F), ('y_dims_cls', I), ('y_dims_reg', F), ('is_data_2D', I),
+                ('wts', StrongWeights), ('normalize_by_3d_count', i32), ('dbox', F), ('dstage1', F), ('terms', F),
+                ('total_losses', F), ('loss', F), ('center', F), ('reg_dims', F), ('reg_theta', F), ('B', i32)]
+
+
+class SlabDesc(C.Structure):
+    _fields_ = [('slab_off', C.c_int64), ('grad_off', C.c_int64), ('numel', C.c_int32), ('n_slabs', C.c_int32)]
+
+
+class Schedule(C.Structure):
+    _fields_ = [('base_lr', f32), ('lr_decay_rate', f32), ('lr_decay_step', f32), ('bn_init_decay', f32),
+                ('bn_decay_rate', f32), ('bn_decay_step', f32), ('bn_decay_clip', f32), ('beta1', f32), ('beta2', f32),
+                ('batch_size', i32)]
+
+
+class BoxPcRepArgs(C.Structure):
+    _fields_ = [('pc', F), ('ld_pc', i32), ('C', i32), ('center', F), ('dims', F), ('theta', F), ('rep', F),
+                ('ld_rep', i32), ('M', i32), ('rows_per_frustum', i32)]
+
+
+class BoxPcRepBwdArgs(C.Structure):
+    _fields_ = [('pc', F), ('ld_pc', i32), ('C', i32), ('center', F), ('dims', F), ('theta', F),
+                ('colsum', F), ('ld_colsum', i32), ('drep', F), ('ld_drep', i32),
+                ('dcenter', F), ('ddims', F), ('dtheta', F), ('M', i32), ('rows_per_frustum', i32), ('B', i32)]
+
+
+VP = C.c_void_p
+# name -> argtypes.  Struct entry points take (const args*, stream).
+ENTRY_POINTS = {
+    't3d_abi_version': [],
+    't3d_pointmlp_fwd': [C.POINTER(PointMlpFwdArgs), VP],
+    't3d_bn_fwd_finalize': [C.POINTER(BnFwdFinalizeArgs), VP],
+    't3d_pool_finalize': [C.POINTER(PoolFinalizeArgs), VP],
+    't3d_pointmlp_dgrad': [C.POINTER(PointMlpDgradArgs), VP],
+    't3d_pointmlp_wgrad': [C.POINTER(PointMlpWgradArgs), VP],
+    't3d_bn_bwd_finalize': [C.POINTER(BnBwdFinalizeArgs), VP],
+    't3d_dy_colsum': [C.POINTER(DyColsumArgs), VP],
+    't3d_fc_fwd': [C.POINTER(FcFwdArgs), VP],
+    't3d_fc_bwd': [C.POINTER(FcBwdArgs), VP],
+    't3d_fc_dinput': [C.POINTER(FcDinputArgs), VP],
+    't3d_seg_head': [C.POINTER(SegHeadArgs), VP],
+    't3d_seg_finalize': [C.POINTER(SegFinalizeArgs), VP],
+    't3d_strong_loss': [C.POINTER(StrongLossArgs), VP],
+    't3d_reduce_slabs': [F, F, C.POINTER(SlabDesc), i32, i32, VP],
+    't3d_schedule_step': [F, C.POINTER(Schedule), VP],
+    't3d_adam_tf_step': [F, F, F, F, C.c_int64, F, f32, f32, f32, f32, VP],
+    't3d_dropout_mask': [F, C.c_int64, f32, C.c_uint32, F, VP],
+}
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libt3d.so')
+ERRORS = {-1: 'T3D_ERR_ARG', -2: 'T3D_ERR_SHAPE', -3: 'T3D_ERR_LAUNCH'}
+
+
+class T3DError(RuntimeError):
+    pass
+
+
+def load(path=None):
+    """dlopen libt3d.so and bind every entry point of include/t3d.h; raises if anything is missing."""
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise T3DError('HIP library %s not built: run `python -m transferable3d_amd.build` (no CPU fallback exists)' % path)
+    lib = C.CDLL(path)
+    for name, argtypes in ENTRY_POINTS.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            raise T3DError('%s does not export %s' % (path, name))
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    return lib
+
+
+def fptr(t):
+    """float* of a tensor (None -> NULL)."""
+    return C.cast(C.c_void_p(0 if t is None else t.data_ptr()), F)
+
+
+def iptr(t):
+    return C.cast(C.c_void_p(0 if t is None else t.data_ptr()), I)
+
+
+def check(rc, what):
+    if rc != 0:
+        raise T3DError('%s failed: %s' % (what, ERRORS.get(rc, rc)))

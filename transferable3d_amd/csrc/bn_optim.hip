@@ -1,0 +1,284 @@
+// Batch-norm finalizers, max-pool finalize, per-frustum dy column sums, slab reduction, schedules,
+// TF-form Adam and the dropout mask generator.  All are short bandwidth/latency-bound kernels that
+// sit between the MFMA GEMMs of pointmlp.hip; reductions combine tile partials in a fixed order
+// (double accumulators), so results are run-to-run reproducible.
+#include "common.h"
+
+namespace {
+
+// 256 threads = 64 channels x 4 tile groups
+__global__ __launch_bounds__(256) void k_bn_fwd_finalize(const t3d_bn_fwd_finalize_args p) {
+  __shared__ double red[2][4][64];
+  const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const bool ok = c < p.N;
+  if (p.is_training) {
+    double s = 0.0, ss = 0.0;
+    if (ok)
+      for (int t = grp; t < p.n_tiles; t += 4) {
+        s += (double)p.psum[(size_t)t * p.N + c];
+        ss += (double)p.psumsq[(size_t)t * p.N + c];
+      }
+    red[0][grp][cl] = s;
+    red[1][grp][cl] = ss;
+    __syncthreads();
+    if (grp == 0 && ok) {
+      s = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+      ss = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+      const double n = (double)p.count;
+      const double mean = s / n;
+      double var = ss / n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const double invstd = 1.0 / sqrt(var + (double)p.eps);
+      const double sc = (double)p.gamma[c] * invstd;
+      p.scale[c] = (float)sc;
+      p.shift[c] = (float)((double)p.beta[c] - mean * sc);
+      p.mean[c] = (float)mean;
+      p.invstd[c] = (float)invstd;
+      const double d = (double)p.decay[0];
+      const double var_ema = p.unbiased_ema ? var * (n / (n > 1.0 ? n - 1.0 : 1.0)) : var;
+      p.moving_mean[c] = (float)((double)p.moving_mean[c] * d + mean * (1.0 - d));
+      p.moving_var[c] = (float)((double)p.moving_var[c] * d + var_ema * (1.0 - d));
+    }
+  } else if (grp == 0 && ok) {
+    const double invstd = 1.0 / sqrt((double)p.moving_var[c] + (double)p.eps);
+    const double sc = (double)p.gamma[c] * invstd;
+    p.scale[c] = (float)sc;
+    p.shift[c] = (float)((double)p.beta[c] - (double)p.moving_mean[c] * sc);
+    p.mean[c] = p.moving_mean[c];
+    p.invstd[c] = (float)invstd;
+  }
+}
+
+// one thread per (frustum, channel)
+__global__ __launch_bounds__(256) void k_pool_finalize(const t3d_pool_finalize_args p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.B * p.N) return;
+  const int b = i / p.N, c = i % p.N;
+  const float sc = p.scale[c], sh = p.shift[c];
+  const bool use_max = sc >= 0.f;
+  float best = use_max ? -INFINITY : INFINITY;
+  int arg = -1;
+  for (int t = 0; t < p.tiles_per_frustum; ++t) {
+    const size_t o = (size_t)(b * p.tiles_per_frustum + t) * p.N + c;
+    if (use_max) {
+      const int a = p.pamax[o];
+      const float v = p.pmax[o];
+      if (a >= 0 && (arg < 0 || v > best)) { best = v; arg = a; }
+    } else {
+      const int a = p.pamin[o];
+      const float v = p.pmin[o];
+      if (a >= 0 && (arg < 0 || v < best)) { best = v; arg = a; }
+    }
+  }
+  float out = 0.f;
+  if (arg >= 0) out = fmaxf(fmaf(best, sc, sh), 0.f);
+  const bool live = out > 0.f;
+  p.pooled[(size_t)b * p.ld_pooled + c] = out;
+  p.argidx[i] = live ? arg : -1;
+  p.ysel[i] = live ? best : 0.f;
+}
+
+__global__ __launch_bounds__(256) void k_bn_bwd_finalize(const t3d_bn_bwd_finalize_args p) {
+  __shared__ double red[2][4][64];
+  const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const bool ok = c < p.N;
+  double s1 = 0.0, s2 = 0.0;   // sum dz, sum dz*y
+  if (ok) {
+    if (p.psum_dz != nullptr) {
+      for (int t = grp; t < p.n_tiles; t += 4) {
+        s1 += (double)p.psum_dz[(size_t)t * p.N + c];
+        s2 += (double)p.psum_dzy[(size_t)t * p.N + c];
+      }
+    } else {
+      for (int b = grp; b < p.B; b += 4) {
+        const float live = p.pooled[(size_t)b * p.ld_pooled + c] > 0.f ? 1.f : 0.f;
+        const float g = p.dpool_in[(size_t)b * p.ld_dpool_in + c] * live;
+        p.dpool[(size_t)b * p.N + c] = g;
+        s1 += (double)g;
+        s2 += (double)g * (double)p.ysel[(size_t)b * p.N + c];
+      }
+    }
+  }
+  red[0][grp][cl] = s1;
+  red[1][grp][cl] = s2;
+  __syncthreads();
+  if (grp == 0 && ok) {
+    s1 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+    s2 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+    if (p.frozen) {
+      p.coef[c] = p.scale[c];
+      p.coef[p.N + c] = 0.f;
+      p.coef[2 * p.N + c] = 0.f;
+      return;
+    }
+    const double mean = p.mean[c], invstd = p.invstd[c], gamma = p.gamma[c], n = p.count;
+    const double dbeta = s1;
+    const double dgamma = invstd * (s2 - mean * s1);       // sum dz * xhat
+    if (p.dbeta) p.dbeta[c] = (float)dbeta;
+    if (p.dgamma) p.dgamma[c] = (float)dgamma;
+    // dy = gamma*invstd*(dz - dbeta/n - xhat*dgamma/n), xhat = (y-mean)*invstd
+    const double c1 = gamma * invstd;
+    const double k3 = dgamma / n * invstd;
+    p.coef[c] = (float)c1;
+    p.coef[p.N + c] = (float)(-c1 * k3);
+    p.coef[2 * p.N + c] = (float)(c1 * (k3 * mean - dbeta / n));
+  }
+}
+
+__global__ __launch_bounds__(256) void k_dy_colsum(const t3d_dy_colsum_args p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.B * p.N) return;
+  const int b = i / p.N, c = i % p.N;
+  double sdz = 0.0, sy = 0.0;
+  for (int t = 0; t < p.tiles_per_frustum; ++t) {
+    const size_t o = (size_t)(b * p.tiles_per_frustum + t) * p.N + c;
+    sdz += (double)p.psum_dz[o];
+    sy += (double)p.psum_y[o];
+  }
+  const double v = (double)p.coef[c] * sdz + (double)p.coef[p.N + c] * sy +
+                   (double)p.coef[2 * p.N + c] * (double)p.rows_per_frustum;
+  p.out[i] = (float)((double)p.alpha * v);
+}
+
+__global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ slab_base, float* __restrict__ grad_base,
+                                                      const t3d_slab_desc* __restrict__ table) {
+  const t3d_slab_desc d = table[blockIdx.y];
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < d.numel; e += gridDim.x * blockDim.x) {
+    const float* s = slab_base + d.slab_off + e;
+    float acc = 0.f;
+    for (int k = 0; k < d.n_slabs; ++k) acc += s[(size_t)k * d.numel];
+    grad_base[d.grad_off + e] = acc;
+  }
+}
+
+__global__ void k_schedule_step(float* hyper, const t3d_schedule s) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  // global step BEFORE this update drives lr / bn_decay (tf: minimize() increments after use)
+  const double step = (double)hyper[0];
+  const double seen = step * (double)s.batch_size;
+  const double lr = (double)s.base_lr * pow((double)s.lr_decay_rate, floor(seen / (double)s.lr_decay_step));
+  const double bnm = (double)s.bn_init_decay * pow((double)s.bn_decay_rate, floor(seen / (double)s.bn_decay_step));
+  const double bnd = fmin((double)s.bn_decay_clip, 1.0 - bnm);
+  const double t = step + 1.0;   // Adam's t starts at 1
+  const double lr_t = lr * sqrt(1.0 - pow((double)s.beta2, t)) / (1.0 - pow((double)s.beta1, t));
+  hyper[1] = (float)lr;
+  hyper[2] = (float)bnd;
+  hyper[3] = (float)lr_t;
+  hyper[0] = (float)t;
+}
+
+__global__ __launch_bounds__(256) void k_adam_tf(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
+                                                 float* __restrict__ v, int64_t n, const float* __restrict__ hyper,
+                                                 float b1, float b2, float eps, float gscale) {
+  const float lr_t = hyper[3];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * gscale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    w[i] -= lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+
+// counter-based generator: 2 rounds of a 64-bit mix over (seed, step, index)
+__device__ __forceinline__ uint32_t mix_u32(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
+  x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
+  x ^= x >> 33;
+  return (uint32_t)(x >> 16);
+}
+__global__ __launch_bounds__(256) void k_dropout_mask(float* __restrict__ mask, int64_t n, float keep, uint32_t seed,
+                                                      const float* __restrict__ hyper) {
+  const uint64_t step = (uint64_t)hyper[0];
+  const uint64_t key = ((uint64_t)seed << 32) ^ (step * 0x9E3779B97F4A7C15ULL);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t r = mix_u32(key + (uint64_t)i * 0xD6E8FEB86659FD93ULL);
+    const float u = (float)(r >> 8) * (1.0f / 16777216.0f);
+    mask[i] = u < keep ? 1.f : 0.f;
+  }
+}
+
+}  // namespace
+
+extern "C" int t3d_abi_version(void) { return 1; }
+
+extern "C" int t3d_bn_fwd_finalize(const t3d_bn_fwd_finalize_args* a, t3d_stream_t stream) {
+  if (!a || !a->gamma || !a->beta || !a->moving_mean || !a->moving_var || !a->scale || !a->shift || !a->mean ||
+      !a->invstd)
+    return T3D_ERR_ARG;
+  if (a->is_training && (!a->psum || !a->psumsq || !a->decay || a->count <= 0)) return T3D_ERR_ARG;
+  hipLaunchKernelGGL(k_bn_fwd_finalize, dim3((a->N + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_pool_finalize(const t3d_pool_finalize_args* a, t3d_stream_t stream) {
+  if (!a || !a->scale || !a->shift || !a->pmax || !a->pmin || !a->pamax || !a->pamin || !a->pooled || !a->argidx ||
+      !a->ysel)
+    return T3D_ERR_ARG;
+  hipLaunchKernelGGL(k_pool_finalize, dim3((a->B * a->N + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     *a);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_bn_bwd_finalize(const t3d_bn_bwd_finalize_args* a, t3d_stream_t stream) {
+  if (!a || !a->coef) return T3D_ERR_ARG;
+  if (a->psum_dz == nullptr && (!a->dpool_in || !a->pooled || !a->ysel || !a->dpool)) return T3D_ERR_ARG;
+  if (a->psum_dz != nullptr && !a->psum_dzy) return T3D_ERR_ARG;
+  if (a->frozen ? !a->scale : (!a->gamma || !a->mean || !a->invstd)) return T3D_ERR_ARG;
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((a->N + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_dy_colsum(const t3d_dy_colsum_args* a, t3d_stream_t stream) {
+  if (!a || !a->psum_dz || !a->psum_y || !a->coef || !a->out) return T3D_ERR_ARG;
+  hipLaunchKernelGGL(k_dy_colsum, dim3((a->B * a->N + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_reduce_slabs(const float* slab_base, float* grad_base, const t3d_slab_desc* table_dev, int n_tensors,
+                                int max_numel, t3d_stream_t stream) {
+  if (!slab_base || !grad_base || !table_dev || n_tensors <= 0) return T3D_ERR_ARG;
+  int gx = (max_numel + 255) / 256;
+  if (gx > 64) gx = 64;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(k_reduce_slabs, dim3(gx, n_tensors), dim3(256), 0, static_cast<hipStream_t>(stream), slab_base,
+                     grad_base, table_dev);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_schedule_step(float* hyper, const t3d_schedule* s, t3d_stream_t stream) {
+  if (!hyper || !s) return T3D_ERR_ARG;
+  hipLaunchKernelGGL(k_schedule_step, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), hyper, *s);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_adam_tf_step(float* params, const float* grads, float* m, float* v, int64_t n, const float* hyper,
+                                float beta1, float beta2, float eps, float grad_scale, t3d_stream_t stream) {
+  if (!params || !grads || !m || !v || !hyper || n <= 0) return T3D_ERR_ARG;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_adam_tf, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), params, grads, m,
+                     v, n, hyper, beta1, beta2, eps, grad_scale);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_dropout_mask(float* mask, int64_t n, float keep_prob, uint32_t seed, const float* hyper,
+                                t3d_stream_t stream) {
+  if (!mask || !hyper || n <= 0) return T3D_ERR_ARG;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_dropout_mask, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), mask, n,
+                     keep_prob, seed, hyper);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}

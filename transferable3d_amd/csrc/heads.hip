@@ -1,0 +1,312 @@
+// Segmentation head (dropout + conv10 + softmax-CE + hard mask, forward AND backward in one pass) and the
+// per-frustum box losses (forward + backward).
+//
+// seg head: semisup_models.py:131-136 (dropout, conv10), 150-158 (mask, masked xyz sums),
+//           semisup_v1_sunrgbd.py:430-431 (sparse softmax CE).
+// box loss: semisup_v1_sunrgbd.py:423-564, model_util.py:94-119,145-167, tf_util.py:1001-1041.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// seg head.  One workgroup = one 128-row tile, wave w owns rows 32w..32w+31, lane owns channels
+// 2*lane, 2*lane+1 of the K = 128 wide conv9 output (coalesced 512-B row loads).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_seg_head(const t3d_seg_head_args p) {
+  __shared__ float red[4][128 * 4 + 8];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tile = blockIdx.x, row0 = tile * 128;
+  const int b = row0 / p.rows_per_frustum;
+  const int ch = 2 * lane;
+  const float2 sc = *reinterpret_cast<const float2*>(p.scale + ch);
+  const float2 sh = *reinterpret_cast<const float2*>(p.shift + ch);
+  const float w00 = p.w[ch * 2 + 0], w01 = p.w[ch * 2 + 1], w10 = p.w[ch * 2 + 2], w11 = p.w[ch * 2 + 3];
+  const float b0 = p.bias[0], b1 = p.bias[1];
+  const bool train = p.labels != nullptr;
+  const bool bwd = p.dz != nullptr;
+  const float wb = train ? p.ce_weight * (float)(1 - p.is_data_2D[b]) / ((float)p.B * (float)p.rows_per_frustum) : 0.f;
+  const float inv_keep = p.drop_mask ? 1.0f / p.keep_prob : 1.f;
+
+  float sdz0 = 0.f, sdz1 = 0.f, sdzy0 = 0.f, sdzy1 = 0.f, dw00 = 0.f, dw01 = 0.f, dw10 = 0.f, dw11 = 0.f;
+  float ce_sum = 0.f, cnt = 0.f, sx = 0.f, sy = 0.f, sz = 0.f, db0 = 0.f, db1 = 0.f, ncorr = 0.f;
+
+  for (int i = 0; i < 32; ++i) {
+    const int row = row0 + wid * 32 + i;
+    const size_t o = (size_t)row * 128 + ch;
+    const float2 y = *reinterpret_cast<const float2*>(p.y + o);
+    const float z0 = fmaf(y.x, sc.x, sh.x), z1 = fmaf(y.y, sc.y, sh.y);
+    float k0 = inv_keep, k1 = inv_keep;
+    if (p.drop_mask) {
+      const float2 m = *reinterpret_cast<const float2*>(p.drop_mask + o);
+      k0 *= m.x; k1 *= m.y;
+    }
+    const float d0 = fmaxf(z0, 0.f) * k0, d1 = fmaxf(z1, 0.f) * k1;
+    const float l0 = wave_sum(fmaf(d0, w00, d1 * w10)) + b0;
+    const float l1 = wave_sum(fmaf(d0, w01, d1 * w11)) + b1;
+    const float m = l0 < l1 ? 1.f : 0.f;
+    if (lane == 0) {
+      *reinterpret_cast<float2*>(p.logits + (size_t)row * 2) = make_float2(l0, l1);
+      p.mask[row] = m;
+    }
+    const float px = p.pc[(size_t)row * p.ld_pc], py = p.pc[(size_t)row * p.ld_pc + 1], pz = p.pc[(size_t)row * p.ld_pc + 2];
+    cnt += m; sx += m * px; sy += m * py; sz += m * pz;
+    if (train) {
+      const int lab = p.labels[row];
+      const float mx = fmaxf(l0, l1);
+      const float lse = mx + logf(expf(l0 - mx) + expf(l1 - mx));
+      ce_sum += lse - (lab ? l1 : l0);
+      ncorr += ((l1 > l0 ? 1 : 0) == lab) ? 1.f : 0.f;
+      if (bwd) {
+        const float g0 = wb * (expf(l0 - lse) - (lab == 0 ? 1.f : 0.f));
+        const float g1 = wb * (expf(l1 - lse) - (lab == 1 ? 1.f : 0.f));
+        db0 += g0; db1 += g1;
+        dw00 = fmaf(d0, g0, dw00); dw01 = fmaf(d0, g1, dw01);
+        dw10 = fmaf(d1, g0, dw10); dw11 = fmaf(d1, g1, dw11);
+        const float dz0 = z0 > 0.f ? (g0 * w00 + g1 * w01) * k0 : 0.f;
+        const float dz1 = z1 > 0.f ? (g0 * w10 + g1 * w11) * k1 : 0.f;
+        *reinterpret_cast<float2*>(p.dz + o) = make_float2(dz0, dz1);
+        sdz0 += dz0; sdz1 += dz1;
+        sdzy0 = fmaf(dz0, y.x, sdzy0); sdzy1 = fmaf(dz1, y.y, sdzy1);
+      }
+    }
+  }
+  float* r = red[wid];
+  r[ch] = sdz0; r[ch + 1] = sdz1;
+  r[128 + ch] = sdzy0; r[128 + ch + 1] = sdzy1;
+  r[256 + ch * 2] = dw00; r[256 + ch * 2 + 1] = dw01; r[256 + ch * 2 + 2] = dw10; r[256 + ch * 2 + 3] = dw11;
+  if (lane == 0) {
+    r[512] = ce_sum; r[513] = cnt; r[514] = sx; r[515] = sy; r[516] = sz; r[517] = db0; r[518] = db1; r[519] = ncorr;
+  }
+  __syncthreads();
+  if (bwd) {
+    if (tid < 128) {
+      p.psum_dz[(size_t)tile * 128 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    } else {
+      const int c = tid - 128;
+      p.psum_dzy[(size_t)tile * 128 + c] = red[0][128 + c] + red[1][128 + c] + red[2][128 + c] + red[3][128 + c];
+    }
+    p.dw_part[(size_t)tile * 256 + tid] = red[0][256 + tid] + red[1][256 + tid] + red[2][256 + tid] + red[3][256 + tid];
+  }
+  if (tid < 8) p.part[(size_t)tile * 8 + tid] = red[0][512 + tid] + red[1][512 + tid] + red[2][512 + tid] + red[3][512 + tid];
+}
+
+__global__ __launch_bounds__(256) void k_seg_finalize(const t3d_seg_finalize_args p) {
+  const int tid = threadIdx.x;
+  const int T = p.B * p.tiles_per_frustum;
+  for (int b = tid; b < p.B; b += 256) {
+    double ce = 0, cnt = 0, sx = 0, sy = 0, sz = 0;
+    for (int t = 0; t < p.tiles_per_frustum; ++t) {
+      const float* q = p.part + (size_t)(b * p.tiles_per_frustum + t) * 8;
+      ce += q[0]; cnt += q[1]; sx += q[2]; sy += q[3]; sz += q[4];
+    }
+    const double den = cnt > 1.0 ? cnt : 1.0;
+    p.mask_xyz_mean[b * 3 + 0] = (float)(sx / den);
+    p.mask_xyz_mean[b * 3 + 1] = (float)(sy / den);
+    p.mask_xyz_mean[b * 3 + 2] = (float)(sz / den);
+    if (p.seg_loss) p.seg_loss[b] = (float)(ce / (double)p.rows_per_frustum);
+  }
+  if (p.dw != nullptr) {
+    for (int e = tid; e < p.K * 2; e += 256) {
+      double a = 0;
+      for (int t = 0; t < T; ++t) a += p.dw_part[(size_t)t * p.K * 2 + e];
+      p.dw[e] = (float)a;
+    }
+  }
+  if (tid < 3) {
+    double a = 0;
+    for (int t = 0; t < T; ++t) a += p.part[(size_t)t * 8 + 5 + tid];
+    if (tid < 2) { if (p.dbias) p.dbias[tid] = (float)a; }
+    else if (p.n_correct) p.n_correct[0] = (float)a;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// box losses
+// ---------------------------------------------------------------------------------------------
+constexpr int NH = 12, NS = 10;
+__device__ const float kMeanDims[NS][3] = {   // class2type order: bed,table,sofa,chair,toilet,desk,dresser,night_stand,bookshelf,bathtub
+    {2.114256f, 1.620300f, 0.927272f}, {0.791118f, 1.279516f, 0.718182f}, {0.923508f, 1.867419f, 0.845495f},
+    {0.591958f, 0.552978f, 0.827272f}, {0.699104f, 0.454178f, 0.756250f}, {0.695190f, 1.346299f, 0.736364f},
+    {0.528526f, 1.002642f, 1.172878f}, {0.500618f, 0.632163f, 0.683424f}, {0.404671f, 1.071108f, 1.688889f},
+    {0.765840f, 1.398258f, 0.472728f}};
+
+__device__ __forceinline__ float bin_center(int j) { return (float)((double)j * (2.0 * 3.14159265358979323846 / 12.0)); }
+__device__ __forceinline__ float huber_f(float e, float delta) {
+  const float a = fabsf(e), q = fminf(a, delta);
+  return 0.5f * q * q + delta * (a - q);
+}
+__device__ __forceinline__ float huber_d(float a, float delta) { return a < delta ? a : delta; }   // d/da for a >= 0
+__device__ float softmax_ce(const float* z, int n, int ld, int label, float* grad, float gs) {
+  float mx = z[0];
+  for (int i = 1; i < n; ++i) mx = fmaxf(mx, z[i * ld]);
+  float s = 0.f;
+  for (int i = 0; i < n; ++i) s += expf(z[i * ld] - mx);
+  const float lse = mx + logf(s);
+  for (int i = 0; i < n; ++i) grad[i] += gs * (expf(z[i * ld] - lse) - (i == label ? 1.f : 0.f));
+  return lse - z[label * ld];
+}
+
+__global__ __launch_bounds__(1024) void k_strong_loss(const t3d_strong_loss_args p) {
+  __shared__ float red[1024];
+  __shared__ float s_norm;
+  const int b = threadIdx.x;
+  const bool ok = b < p.B;
+  const float w3d = ok ? (float)(1 - p.is_data_2D[b]) : 0.f;
+  red[b] = w3d;
+  __syncthreads();
+  if (b == 0) {
+    float s = 0.f;
+    for (int i = 0; i < p.B; ++i) s += red[i];
+    s_norm = p.normalize_by_3d_count ? 1.0f / (s + 1e-3f) : 1.0f / (float)p.B;
+  }
+  __syncthreads();
+  const float norm = s_norm;
+  float total = 0.f;
+  if (ok) {
+    const float* o = p.box + (size_t)b * p.ld_box;
+    const t3d_strong_weights& W = p.wts;
+    const float gs = w3d * norm;
+    float g[67];
+    for (int i = 0; i < 67; ++i) g[i] = 0.f;
+    float gc[3] = {0.f, 0.f, 0.f}, gs1[3] = {0.f, 0.f, 0.f};
+    const float s1[3] = {p.stage1_center[b * 3], p.stage1_center[b * 3 + 1], p.stage1_center[b * 3 + 2]};
+    const float cen[3] = {o[0] + s1[0], o[1] + s1[1], o[2] + s1[2]};
+    const float yc[3] = {p.y_center[b * 3], p.y_center[b * 3 + 1], p.y_center[b * 3 + 2]};
+    const int j = p.y_orient_cls[b], k = p.y_dims_cls[b];
+    const float yor = p.y_orient_reg[b];
+    const float ydr[3] = {p.y_dims_reg[b * 3], p.y_dims_reg[b * 3 + 1], p.y_dims_reg[b * 3 + 2]};
+    const float bm = W.box_multiplier;
+
+    // centre (delta 2) and stage-1 centre (delta 1)
+    float dist = sqrtf((yc[0] - cen[0]) * (yc[0] - cen[0]) + (yc[1] - cen[1]) * (yc[1] - cen[1]) + (yc[2] - cen[2]) * (yc[2] - cen[2]));
+    const float l_center = huber_f(dist, 2.f);
+    if (dist > 0.f) {
+      const float f = gs * bm * W.center * huber_d(dist, 2.f) / dist;
+      for (int d = 0; d < 3; ++d) gc[d] += f * (cen[d] - yc[d]);
+    }
+    dist = sqrtf((yc[0] - s1[0]) * (yc[0] - s1[0]) + (yc[1] - s1[1]) * (yc[1] - s1[1]) + (yc[2] - s1[2]) * (yc[2] - s1[2]));
+    const float l_s1 = huber_f(dist, 1.f);
+    if (dist > 0.f) {
+      const float f = gs * bm * W.tnet_center * huber_d(dist, 1.f) / dist;
+      for (int d = 0; d < 3; ++d) gs1[d] += f * (s1[d] - yc[d]);
+    }
+    // heading
+    const float l_hcls = softmax_ce(o + 3, NH, 1, j, g + 3, gs * bm * W.orient_cls);
+    const float hrn = o[3 + NH + j];
+    const float eh = hrn - yor / (3.14159265358979323846f / NH);
+    const float l_hres = huber_f(eh, 1.f);
+    g[3 + NH + j] += gs * bm * W.orient_reg * fmaxf(-1.f, fminf(1.f, eh));
+    // size
+    const float l_scls = softmax_ce(o + 3 + 2 * NH, NS, 1, k, g + 3 + 2 * NH, gs * bm * W.dims_cls);
+    const float* srn = o + 3 + 2 * NH + NS + 3 * k;
+    float ds[3], sd = 0.f;
+    for (int d = 0; d < 3; ++d) { ds[d] = srn[d] - ydr[d] / kMeanDims[k][d]; sd += ds[d] * ds[d]; }
+    sd = sqrtf(sd);
+    const float l_sres = huber_f(sd, 1.f);
+    if (sd > 0.f) {
+      const float f = gs * bm * W.dims_reg * huber_d(sd, 1.f) / sd;
+      for (int d = 0; d < 3; ++d) g[3 + 2 * NH + NS + 3 * k + d] += f * ds[d];
+    }
+    // corners of the GT-bin box; sizes = anchor + 2*residual (model_util.py:158-159)
+    const float th = bin_center(j) + hrn * (3.14159265358979323846f / NH);
+    const float c = cosf(th), s = sinf(th);
+    float sz3[3];
+    for (int d = 0; d < 3; ++d) { const float r = srn[d] * kMeanDims[k][d]; sz3[d] = (kMeanDims[k][d] + r) + r; }
+    const float hl = bin_center(j) + yor;
+    const float cg = cosf(hl), sg = sinf(hl);
+    const float cgf = cosf(hl + 3.14159265358979323846f), sgf = sinf(hl + 3.14159265358979323846f);
+    const float gl[3] = {kMeanDims[k][0] + ydr[0], kMeanDims[k][1] + ydr[1], kMeanDims[k][2] + ydr[2]};
+    float l_corner = 0.f, gth = 0.f, gl_ = 0.f, gw_ = 0.f, gh_ = 0.f;
+    for (int i = 0; i < 8; ++i) {
+      const float sxi = ((i >> 1) & 1) ? -1.f : 1.f;             // + + - - + + - -
+      const float syi = (i >> 2) ? -1.f : 1.f;                    // + + + + - - - -
+      const float szi = (((i + 1) >> 1) & 1) ? -1.f : 1.f;        // + - - + + - - +
+      const float x = sxi * sz3[0] * 0.5f, y = syi * sz3[2] * 0.5f, z = szi * sz3[1] * 0.5f;
+      const float cp[3] = {c * x + s * z + cen[0], y + cen[1], -s * x + c * z + cen[2]};
+      const float xg = sxi * gl[0] * 0.5f, yg = syi * gl[2] * 0.5f, zg = szi * gl[1] * 0.5f;
+      const float t1[3] = {cg * xg + sg * zg + yc[0], yg + yc[1], -sg * xg + cg * zg + yc[2]};
+      const float t2[3] = {cgf * xg + sgf * zg + yc[0], yg + yc[1], -sgf * xg + cgf * zg + yc[2]};
+      float d1 = 0.f, d2 = 0.f;
+      for (int d = 0; d < 3; ++d) { d1 += (cp[d] - t1[d]) * (cp[d] - t1[d]); d2 += (cp[d] - t2[d]) * (cp[d] - t2[d]); }
+      d1 = sqrtf(d1); d2 = sqrtf(d2);
+      const bool first = d1 <= d2;
+      const float dm = first ? d1 : d2;
+      l_corner += huber_f(dm, 1.f) * 0.125f;
+      if (dm > 0.f) {
+        const float f = gs * W.corner * 0.125f * huber_d(dm, 1.f) / dm;
+        const float gv[3] = {f * (cp[0] - (first ? t1[0] : t2[0])), f * (cp[1] - (first ? t1[1] : t2[1])),
+                             f * (cp[2] - (first ? t1[2] : t2[2]))};
+        for (int d = 0; d < 3; ++d) gc[d] += gv[d];
+        gth += gv[0] * (-s * x + c * z) + gv[2] * (-c * x - s * z);
+        gl_ += (gv[0] * c - gv[2] * s) * sxi * 0.5f;
+        gh_ += gv[1] * syi * 0.5f;
+        gw_ += (gv[0] * s + gv[2] * c) * szi * 0.5f;
+      }
+    }
+    g[3 + NH + j] += gth * (3.14159265358979323846f / NH);
+    g[3 + 2 * NH + NS + 3 * k + 0] += gl_ * 2.f * kMeanDims[k][0];
+    g[3 + 2 * NH + NS + 3 * k + 1] += gw_ * 2.f * kMeanDims[k][1];
+    g[3 + 2 * NH + NS + 3 * k + 2] += gh_ * 2.f * kMeanDims[k][2];
+    for (int d = 0; d < 3; ++d) g[d] = gc[d];
+
+    const float box_l = bm * (W.center * l_center + W.orient_cls * l_hcls + W.dims_cls * l_scls + W.orient_reg * l_hres +
+                              W.dims_reg * l_sres + W.tnet_center * l_s1) + W.corner * l_corner;
+    const float seg_l = p.seg_loss ? p.seg_loss[b] : 0.f;
+    total = w3d * (W.cross_entropy * seg_l + box_l);
+    for (int i = 0; i < 67; ++i) p.dbox[(size_t)b * 67 + i] = g[i];
+    for (int d = 0; d < 3; ++d) {
+      p.dstage1[b * 3 + d] = gc[d] + gs1[d];
+      p.center[b * 3 + d] = cen[d];
+    }
+    float* t = p.terms + (size_t)b * 8;
+    t[0] = seg_l; t[1] = l_center; t[2] = l_s1; t[3] = l_hcls; t[4] = l_hres; t[5] = l_scls; t[6] = l_sres; t[7] = l_corner;
+    p.total_losses[b] = total;
+    // anchor -> reg of the PREDICTED bins (first arg-max)
+    int js = 0, ks = 0;
+    for (int i = 1; i < NH; ++i) if (o[3 + i] > o[3 + js]) js = i;
+    for (int i = 1; i < NS; ++i) if (o[3 + 2 * NH + i] > o[3 + 2 * NH + ks]) ks = i;
+    for (int d = 0; d < 3; ++d)
+      p.reg_dims[b * 3 + d] = fmaxf(kMeanDims[ks][d] + o[3 + 2 * NH + NS + 3 * ks + d] * kMeanDims[ks][d], 1e-5f);
+    p.reg_theta[b] = bin_center(js) + o[3 + NH + js] * (3.14159265358979323846f / NH);
+  }
+  __syncthreads();
+  red[b] = total;
+  __syncthreads();
+  if (b == 0) {
+    double s = 0.0;
+    for (int i = 0; i < p.B; ++i) s += (double)red[i];
+    p.loss[0] = (float)(s * (double)norm);
+  }
+}
+
+}  // namespace
+
+extern "C" int t3d_seg_head(const t3d_seg_head_args* a, t3d_stream_t stream) {
+  if (!a || !a->y || !a->scale || !a->shift || !a->w || !a->bias || !a->pc || !a->logits || !a->mask || !a->part)
+    return T3D_ERR_ARG;
+  if (a->labels && !a->is_data_2D) return T3D_ERR_ARG;
+  if (a->dz && (!a->labels || !a->psum_dz || !a->psum_dzy || !a->dw_part)) return T3D_ERR_ARG;
+  if (a->K != 128 || a->M % T3D_TILE_ROWS || a->rows_per_frustum % T3D_TILE_ROWS) return T3D_ERR_SHAPE;
+  hipLaunchKernelGGL(k_seg_head, dim3(a->M / 128), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_seg_finalize(const t3d_seg_finalize_args* a, t3d_stream_t stream) {
+  if (!a || !a->part || !a->mask_xyz_mean) return T3D_ERR_ARG;
+  if (a->dw && !a->dw_part) return T3D_ERR_ARG;
+  hipLaunchKernelGGL(k_seg_finalize, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_strong_loss(const t3d_strong_loss_args* a, t3d_stream_t stream) {
+  if (!a || !a->box || !a->stage1_center || !a->y_center || !a->y_orient_cls || !a->y_orient_reg || !a->y_dims_cls ||
+      !a->y_dims_reg || !a->is_data_2D || !a->dbox || !a->dstage1 || !a->terms || !a->total_losses || !a->loss ||
+      !a->center || !a->reg_dims || !a->reg_theta)
+    return T3D_ERR_ARG;
+  if (a->B <= 0 || a->B > 1024) return T3D_ERR_SHAPE;
+  hipLaunchKernelGGL(k_strong_loss, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), *a);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}

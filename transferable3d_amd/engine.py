@@ -1,0 +1,450 @@
+"""Host-side engine: runtime, variable store, launch plan and the fused layer building blocks.
+
+This is the analogue of the reference's TF-1 graph + session (train_semisup.py:204-277): model
+builders record kernel launches into a static `Plan` whose argument structs point at pre-allocated
+HBM buffers; a step is one replay of the plan (captured into a hipGraph on the GPU).  PyTorch is used
+only to own device memory / streams / the RCCL process group.
+
+Per-point tensors are never materialised in their normalised form: a layer writes its RAW conv
+output y plus per-tile statistics, and every consumer applies `relu(y*scale+shift)` while loading
+(t3d_act_src).  Gradients likewise travel as dz (grad w.r.t. the batch-norm output) + three
+per-channel coefficients (t3d_dy_src).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import abi
+from .abi import fptr, iptr
+from .constants import BN_EPS
+
+TILE = abi.TILE_ROWS
+
+
+class Runtime:
+    """Owns the library handle and the device.  `lib` defaults to the HIP library (no fallback)."""
+
+    def __init__(self, device=None, lib=None):
+        self.lib = lib if lib is not None else abi.load()
+        if device is None:
+            if not torch.cuda.is_available():
+                raise abi.T3DError('no GPU visible: the product path runs on an MI355X only')
+            device = torch.device('cuda', torch.cuda.current_device())
+        self.device = torch.device(device)
+        self.allocs = []     # every buffer lives as long as the runtime (launch structs hold raw pointers)
+
+    def stream(self):
+        if self.device.type == 'cuda':
+            return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return C.c_void_p(0)
+
+    def zeros(self, *shape, dtype=torch.float32):
+        t = torch.zeros(*shape, dtype=dtype, device=self.device)
+        self.allocs.append(t)
+        return t
+
+    def full(self, shape, val, dtype=torch.float32):
+        t = torch.full(shape, val, dtype=dtype, device=self.device)
+        self.allocs.append(t)
+        return t
+
+
+class Plan:
+    """Ordered list of kernel launches with frozen argument structs."""
+
+    def __init__(self, rt):
+        self.rt = rt
+        self.calls = []      # (name, callable(stream) -> rc)
+        self.keep = []       # keep-alive for structs / tensors
+
+    def add(self, name, args):
+        fn = getattr(self.rt.lib, name)
+        ref = C.byref(args)
+        self.keep.append(args)
+        self.calls.append((name, lambda s, fn=fn, ref=ref: fn(ref, s)))
+
+    def add_raw(self, name, thunk, *keep):
+        self.keep.extend(keep)
+        self.calls.append((name, thunk))
+
+    def run(self):
+        s = self.rt.stream()
+        for name, call in self.calls:
+            rc = call(s)
+            if rc != 0:
+                abi.check(rc, name)
+
+    def __len__(self):
+        return len(self.calls)
+
+
+class VarStore:
+    """TF-named variables as views of flat fp32 buffers (params | grads | adam m | adam v, and a
+    separate flat buffer for the non-trainable moving statistics).  Names follow the reference's
+    checkpoint layout: <scope>/weights, /biases, /bn/{beta,gamma,moving_mean,
+    moving_variance}."""
+
+    def __init__(self, rt, capacity=4 << 20, state_capacity=1 << 16, seed=0):
+        self.rt = rt
+        self.params = rt.zeros(capacity)
+        self.grads = rt.zeros(capacity)
+        self.adam_m = rt.zeros(capacity)
+        self.adam_v = rt.zeros(capacity)
+        self.state = rt.zeros(state_capacity)
+        self.used = 0
+        self.state_used = 0
+        self.index = {}        # name -> (offset, shape, trainable)
+        self.rng = np.random.RandomState(seed)
+
+    def _alloc(self, name, shape, trainable, init):
+        if name in self.index:
+            off, shp, tr = self.index[name]
+            assert tuple(shp) == tuple(shape) and tr == trainable, 'variable %s re-declared with a different shape' % name
+            return self.get(name)
+        n = int(np.prod(shape))
+        n_pad = (n + 3) // 4 * 4            # keep every view 16-byte aligned
+        if trainable:
+            off = self.used
+            assert off + n_pad <= self.params.numel(), 'VarStore capacity exceeded'
+            self.used += n_pad
+            buf = self.params
+        else:
+            off = self.state_used
+            assert off + n_pad <= self.state.numel()
+            self.state_used += n_pad
+            buf = self.state
+        self.index[name] = (off, tuple(shape), trainable)
+        view = buf[off:off + n].view(*shape)
+        view.copy_(torch.as_tensor(np.asarray(init, dtype=np.float32).reshape(shape)))
+        return view
+
+    def get(self, name):
+        off, shape, trainable = self.index[name]
+        buf = self.params if trainable else self.state
+        return buf[off:off + int(np.prod(shape))].view(*shape)
+
+    def grad(self, name):
+        off, shape, trainable = self.index[name]
+        assert trainable
+        return self.grads[off:off + int(np.prod(shape))].view(*shape)
+
+    def offset(self, name):
+        return self.index[name][0]
+
+    def xavier(self, name, shape, fan_in, fan_out):
+        """tf.contrib.layers.xavier_initializer (uniform), tf_util.py:1183."""
+        if name in self.index:
+            return self.get(name)
+        lim = math.sqrt(6.0 / (fan_in + fan_out))
+        return self._alloc(name, shape, True, self.rng.uniform(-lim, lim, size=shape))
+
+    def const(self, name, shape, val, trainable=True):
+        return self._alloc(name, shape, trainable, np.full(shape, val, np.float32))
+
+    # ---- state dict in the reference's naming --------------------------------------------------
+    def state_dict(self):
+        return {k: self.get(k).detach().cpu().numpy().copy() for k in self.index}
+
+    def load_state_dict(self, sd, strict=True):
+        for k, v in sd.items():
+            if k not in self.index:
+                if strict:
+                    raise KeyError(k)
+                continue
+            self.get(k).copy_(torch.as_tensor(np.asarray(v, dtype=np.float32)).reshape(self.index[k][1]))
+
+    def trainable_ranges(self, prefixes=None):
+        """Contiguous [offset, n) ranges of the trainable variables whose name starts with one of
+        `prefixes` (regex-prefix semantics of tf.get_collection(scope=...), train_semisup_adv.py:415-422)."""
+        items = sorted((off, int(np.prod(shape)), name) for name, (off, shape, tr) in self.index.items() if tr)
+        out = []
+        for off, n, name in items:
+            if prefixes is not None and not any(name.startswith(p) for p in prefixes):
+                continue
+            n_pad = (n + 3) // 4 * 4
+            if out and out[-1][0] + out[-1][1] == off:
+                out[-1][1] += n_pad
+            else:
+                out.append([off, n_pad])
+        return [(o, n) for o, n in out]
+
+
+class Workspace:
+    """Bump allocator for wgrad slabs + the device-side slab table of t3d_reduce_slabs."""
+
+    def __init__(self, rt):
+        self.rt = rt
+        self.entries = []      # (slab_off, grad_off, numel, n_slabs)
+        self.total = 0
+        self.buf = None
+        self.table = None
+
+    def reserve(self, grad_off, numel, n_slabs):
+        off = self.total
+        self.entries.append((off, grad_off, numel, n_slabs))
+        self.total += numel * n_slabs
+        return off
+
+    def finalize(self):
+        self.buf = self.rt.zeros(max(self.total, 4))
+        n = len(self.entries)
+        host = (abi.SlabDesc * max(n, 1))()
+        for i, (so, go, ne, ns) in enumerate(self.entries):
+            host[i] = abi.SlabDesc(so, go, ne, ns)
+        raw = np.frombuffer(bytes(host), dtype=np.uint8).copy()
+        self.table = torch.as_tensor(raw).to(self.rt.device)
+        return self
+
+
+# ------------------------------------------------------------------------------------------------
+# lazy per-point activation handle
+# ------------------------------------------------------------------------------------------------
+class ActSpec:
+    """a[m,k] = relu?(x[m, coff+k]*scale[k] + shift[k]) - sub[b(m),k]  (t3d_act_src)."""
+
+    def __init__(self, x, ldx, K, coff=0, scale=None, shift=None, relu=False, sub=None, sub_ld=0, producer=None):
+        self.x, self.ldx, self.K, self.coff = x, ldx, K, coff
+        self.scale, self.shift, self.relu, self.sub, self.sub_ld = scale, shift, relu, sub, sub_ld
+        self.producer = producer     # PointLayer that owns x (None for raw inputs)
+
+    def struct(self):
+        return abi.ActSrc(fptr(self.x), self.ldx, self.coff, fptr(self.scale), fptr(self.shift), int(self.relu),
+                          fptr(self.sub), self.sub_ld)
+
+
+def wgrad_rows_per_split(M, K, N, target_wgs=512):
+    tiles = (1 if K <= 64 else (K + 127) // 128) * (N // 128 if N % 128 == 0 else N // 64)
+    splits = max(1, min(M // 128, target_wgs // max(tiles, 1)))
+    # largest power-of-two split count <= splits that divides M into multiples of 32 rows
+    s = 1
+    while s * 2 <= splits and M % (s * 2) == 0 and (M // (s * 2)) % 32 == 0:
+        s *= 2
+    return M // s
+
+
+class PointLayer:
+    """tf_util.conv2d 1x1 (+ batch_norm + ReLU) over M = B*N point rows (tf_util.py:1258-1323)."""
+
+    def __init__(self, g, scope, K, N, w=None, bias=None, kernel_1xD=False, w_name=None, w_row0=0, pool=False):
+        self.g, self.scope, self.K, self.N = g, scope, K, N
+        self.w_name, self.w_row0 = w_name, w_row0
+        rt, vs = g.rt, g.vars
+        M, T = g.M, g.M // TILE
+        self.M, self.T = M, T
+        if w is None:
+            shape = (1, K, 1, N) if kernel_1xD else (1, 1, K, N)
+            fan_in, fan_out = (K, K * N) if kernel_1xD else (K, N)
+            w = vs.xavier(scope + '/weights', shape, fan_in, fan_out).view(K, N)
+            self.w_name = scope + '/weights'
+            self.w_row0 = 0
+        self.w = w
+        self.bias = bias if bias is not None else vs.const(scope + '/biases', (N,), 0.0)
+        self.gamma = vs.const(scope + '/bn/gamma', (N,), 1.0)
+        self.beta = vs.const(scope + '/bn/beta', (N,), 0.0)
+        self.mm = vs.const(scope + '/bn/moving_mean', (N,), 0.0, trainable=False)
+        self.mv = vs.const(scope + '/bn/moving_variance', (N,), 1.0, trainable=False)
+        self.y = rt.zeros(M, N)
+        self.psum, self.psumsq = rt.zeros(T, N), rt.zeros(T, N)
+        self.scale, self.shift = rt.zeros(N), rt.zeros(N)
+        self.mean, self.invstd = rt.zeros(N), rt.zeros(N)
+        self.pool = pool
+        if pool:
+            B = g.B
+            self.pmax, self.pmin = rt.zeros(T, N), rt.zeros(T, N)
+            self.pamax, self.pamin = rt.zeros(T, N, dtype=torch.int32), rt.zeros(T, N, dtype=torch.int32)
+            self.pooled, self.argidx, self.ysel = rt.zeros(B, N), rt.zeros(B, N, dtype=torch.int32), rt.zeros(B, N)
+        self.src = None
+        self.dz = None
+        self.coef = None
+
+    # ---- forward -------------------------------------------------------------------------------
+    def fwd(self, plan, src, is_training, rowbias=None, rowmask=None):
+        g, rt = self.g, self.g.rt
+        assert src.K == self.K
+        pool = self.pool
+        self.src, self.rowmask, self.is_training = src, rowmask, is_training
+        a = abi.PointMlpFwdArgs()
+        a.a = src.struct()
+        a.w, a.bias, a.rowbias, a.y = fptr(self.w), fptr(self.bias), fptr(rowbias), fptr(self.y)
+        a.psum, a.psumsq = fptr(self.psum), fptr(self.psumsq)
+        if pool:
+            a.rowmask = fptr(rowmask)
+            a.pmax, a.pmin, a.pamax, a.pamin = fptr(self.pmax), fptr(self.pmin), iptr(self.pamax), iptr(self.pamin)
+        a.M, a.K, a.N, a.rows_per_frustum = self.M, self.K, self.N, g.rpf
+        plan.add('t3d_pointmlp_fwd', a)
+        f = abi.BnFwdFinalizeArgs()
+        f.psum, f.psumsq, f.n_tiles, f.count, f.N = fptr(self.psum), fptr(self.psumsq), self.T, self.M, self.N
+        f.gamma, f.beta, f.moving_mean, f.moving_var = fptr(self.gamma), fptr(self.beta), fptr(self.mm), fptr(self.mv)
+        f.decay, f.eps, f.is_training, f.unbiased_ema = fptr(g.bn_decay_ptr), BN_EPS, int(is_training), int(g.unbiased_ema)
+        f.scale, f.shift, f.mean, f.invstd = fptr(self.scale), fptr(self.shift), fptr(self.mean), fptr(self.invstd)
+        plan.add('t3d_bn_fwd_finalize', f)
+        if pool:
+            q = abi.PoolFinalizeArgs()
+            q.scale, q.shift = fptr(self.scale), fptr(self.shift)
+            q.pmax, q.pmin, q.pamax, q.pamin = fptr(self.pmax), fptr(self.pmin), iptr(self.pamax), iptr(self.pamin)
+            q.B, q.N, q.tiles_per_frustum = g.B, self.N, g.rpf // TILE
+            q.pooled, q.ld_pooled, q.argidx, q.ysel = fptr(self.pooled), self.N, iptr(self.argidx), fptr(self.ysel)
+            plan.add('t3d_pool_finalize', q)
+        self.out = ActSpec(self.y, self.N, self.N, 0, self.scale, self.shift, True, producer=self)
+        return self.out
+
+    # ---- backward ------------------------------------------------------------------------------
+    def _ensure_bwd_buffers(self):
+        rt = self.g.rt
+        if self.coef is None:
+            self.coef = rt.zeros(3, self.N)
+            if self.pool:
+                self.dpool = rt.zeros(self.g.B, self.N)
+            else:
+                self.dz = rt.zeros(self.M, self.N)
+                self.psum_dz, self.psum_dzy = rt.zeros(self.T, self.N), rt.zeros(self.T, self.N)
+
+    def dy_struct(self):
+        if self.pool:
+            return abi.DySrc(fptr(None), fptr(self.y), fptr(self.coef), iptr(self.argidx), fptr(self.dpool))
+        return abi.DySrc(fptr(self.dz), fptr(self.y), fptr(self.coef), iptr(None), fptr(None))
+
+    def bn_bwd(self, plan, dpool_in=None, ld_dpool_in=0, param_grads=True):
+        """dgamma/dbeta + the three dy coefficients.  `frozen` nets (eval-mode BN) use scale only."""
+        g, vs = self.g, self.g.vars
+        self._ensure_bwd_buffers()
+        a = abi.BnBwdFinalizeArgs()
+        if self.pool:
+            a.dpool_in, a.ld_dpool_in = fptr(dpool_in), ld_dpool_in
+            a.pooled, a.ld_pooled, a.ysel, a.dpool, a.B = fptr(self.pooled), self.N, fptr(self.ysel), fptr(self.dpool), g.B
+        else:
+            a.psum_dz, a.psum_dzy, a.n_tiles = fptr(self.psum_dz), fptr(self.psum_dzy), self.T
+        a.count, a.N = self.M, self.N
+        a.gamma, a.mean, a.invstd, a.scale = fptr(self.gamma), fptr(self.mean), fptr(self.invstd), fptr(self.scale)
+        a.frozen = int(not self.is_training)
+        if param_grads and self.is_training:
+            a.dgamma, a.dbeta = fptr(vs.grad(self.scope + '/bn/gamma')), fptr(vs.grad(self.scope + '/bn/beta'))
+        a.coef = fptr(self.coef)
+        plan.add('t3d_bn_bwd_finalize', a)
+
+    def wgrad(self, plan):
+        g = self.g
+        rps = wgrad_rows_per_split(self.M, self.K, self.N)
+        n_slabs = self.M // rps
+        goff = g.vars.offset(self.w_name) + self.w_row0 * self.N
+        soff = g.ws.reserve(goff, self.K * self.N, n_slabs)
+        a = abi.PointMlpWgradArgs()
+        a.a, a.dy = self.src.struct(), self.dy_struct()
+        a.M, a.K, a.N, a.rows_per_frustum, a.rows_per_split = self.M, self.K, self.N, g.rpf, rps
+        g.deferred_slab_ptrs.append((a, soff))
+        plan.add('t3d_pointmlp_wgrad', a)
+
+    def dgrad(self, plan, out_raw=None, add_in=None):
+        """Input gradient.  If the input's producer is a PointLayer, writes its dz (ReLU-masked) and
+        batch-norm-backward partials; otherwise writes the raw gradient into `out_raw`."""
+        prev = self.src.producer if out_raw is None else None
+        a = abi.PointMlpDgradArgs()
+        a.dy, a.w, a.add_in = self.dy_struct(), fptr(self.w), fptr(add_in)
+        if prev is not None:
+            prev._ensure_bwd_buffers()
+            assert not prev.pool
+            a.prev_y, a.prev_scale, a.prev_shift = fptr(prev.y), fptr(prev.scale), fptr(prev.shift)
+            a.out, a.psum_dz, a.psum_dzy = fptr(prev.dz), fptr(prev.psum_dz), fptr(prev.psum_dzy)
+        else:
+            a.out = fptr(out_raw)
+        a.M, a.K, a.N, a.rows_per_frustum = self.M, self.K, self.N, self.g.rpf
+        plan.add('t3d_pointmlp_dgrad', a)
+
+    def dy_colsum(self, plan, alpha=1.0):
+        """[B,N] per-frustum column sums of dy (dense layers only)."""
+        g = self.g
+        out = g.rt.zeros(g.B, self.N)
+        a = abi.DyColsumArgs(fptr(self.psum_dz), fptr(self.psum), fptr(self.coef), g.B, self.N, g.rpf // TILE, g.rpf,
+                             alpha, fptr(out))
+        plan.add('t3d_dy_colsum', a)
+        return out
+
+
+class FcLayer:
+    """tf_util.fully_connected (+ batch_norm over the batch + activation) + following dropout."""
+
+    def __init__(self, g, scope, K, N, bn=True, act='relu', K2=0, w=None, bias='own', keep_prob=None, drop_scope=None):
+        self.g, self.scope, self.K, self.K2, self.N, self.bn, self.act = g, scope, K, K2, N, bn, act
+        rt, vs = g.rt, g.vars
+        B = g.B
+        if w is None:
+            w = vs.xavier(scope + '/weights', (K + K2, N), K + K2, N)
+            self.w_grad = vs.grad(scope + '/weights')
+        else:
+            self.w_grad = None
+        self.w = w
+        if isinstance(bias, str):
+            self.bias = vs.const(scope + '/biases', (N,), 0.0)
+            self.bias_grad = vs.grad(scope + '/biases')
+        else:
+            self.bias, self.bias_grad = bias, None
+        if bn:
+            self.gamma = vs.const(scope + '/bn/gamma', (N,), 1.0)
+            self.beta = vs.const(scope + '/bn/beta', (N,), 0.0)
+            self.mm = vs.const(scope + '/bn/moving_mean', (N,), 0.0, trainable=False)
+            self.mv = vs.const(scope + '/bn/moving_variance', (N,), 1.0, trainable=False)
+            self.mean, self.invstd = rt.zeros(N), rt.zeros(N)
+        self.y = rt.zeros(B, N)
+        self.out = rt.zeros(B, N)
+        self.dy = None
+        self.keep_prob = keep_prob
+        self.drop_scope = drop_scope
+        self.drop_mask = rt.full((B, N), 1.0) if keep_prob is not None else None
+        if keep_prob is not None:
+            g.dropout_masks[drop_scope] = (self.drop_mask, keep_prob)
+
+    def fwd(self, plan, x, ld_in, is_training, in2=None, ld_in2=0, add_in=None, ld_add=0, add_n=0):
+        g = self.g
+        self.x, self.ld_in, self.in2, self.ld_in2, self.is_training = x, ld_in, in2, ld_in2, is_training
+        a = abi.FcFwdArgs()
+        a.in_, a.ld_in, a.K, a.in2, a.ld_in2, a.K2 = fptr(x), ld_in, self.K, fptr(in2), ld_in2, self.K2
+        a.w, a.bias = fptr(self.w), fptr(self.bias)
+        if self.bn:
+            a.gamma, a.beta, a.moving_mean, a.moving_var = fptr(self.gamma), fptr(self.beta), fptr(self.mm), fptr(self.mv)
+            a.mean, a.invstd = fptr(self.mean), fptr(self.invstd)
+        a.decay, a.eps, a.is_training, a.unbiased_ema = fptr(g.bn_decay_ptr), BN_EPS, int(is_training), int(g.unbiased_ema)
+        a.act, a.leaky_alpha = abi.ACT_BY_NAME[self.act], 0.2
+        self.use_drop = self.drop_mask is not None and is_training
+        if self.use_drop:
+            a.drop_mask, a.keep_prob = fptr(self.drop_mask), self.keep_prob
+        a.add_in, a.ld_add, a.add_n = fptr(add_in), ld_add, add_n
+        a.y, a.out, a.ld_out, a.B, a.N = fptr(self.y), fptr(self.out), self.N, g.B, self.N
+        plan.add('t3d_fc_fwd', a)
+        return self.out
+
+    def bwd(self, plan, dout=None, ld_dout=0, nxt=None, param_grads=True):
+        g, vs = self.g, self.g.vars
+        if self.dy is None:
+            self.dy = g.rt.zeros(g.B, self.N)
+        a = abi.FcBwdArgs()
+        if dout is not None:
+            a.dout, a.ld_dout = fptr(dout), ld_dout
+        else:
+            a.dy_next, a.w_next, a.N_next = fptr(nxt.dy), fptr(nxt.w), nxt.N
+        a.in_, a.ld_in, a.K, a.in2, a.ld_in2, a.K2 = fptr(self.x), self.ld_in, self.K, fptr(self.in2), self.ld_in2, self.K2
+        a.y, a.out, a.ld_out = fptr(self.y), fptr(self.out), self.N
+        if self.bn:
+            a.gamma, a.beta, a.mean, a.invstd = fptr(self.gamma), fptr(self.beta), fptr(self.mean), fptr(self.invstd)
+        a.bn_training = int(self.is_training)
+        a.act, a.leaky_alpha = abi.ACT_BY_NAME[self.act], 0.2
+        if self.use_drop:
+            a.drop_mask, a.keep_prob = fptr(self.drop_mask), self.keep_prob
+        a.dy = fptr(self.dy)
+        if param_grads:
+            a.dw = fptr(self.w_grad) if self.w_grad is not None else fptr(None)
+            a.dbias = fptr(self.bias_grad)
+            if self.bn and self.is_training:
+                a.dgamma, a.dbeta = fptr(vs.grad(self.scope + '/bn/gamma')), fptr(vs.grad(self.scope + '/bn/beta'))
+        a.B, a.N = g.B, self.N
+        plan.add('t3d_fc_bwd', a)
+
+    def dinput(self, plan, K=None, alpha=1.0, add_in=None, ld_add=0):
+        """[B,K] gradient w.r.t. the first K input columns."""
+        g = self.g
+        K = K or self.K
+        out = g.rt.zeros(g.B, K)
+        a = abi.FcDinputArgs(fptr(self.dy), self.N, fptr(self.w), fptr(add_in), ld_add, alpha, fptr(out), K, g.B, K)
+        plan.add('t3d_fc_dinput', a)
+        return out

@@ -1,0 +1,382 @@
+"""Graph context + the sub-networks of the hot path as fused launch schedules.
+
+Each class mirrors one builder of the reference's `semisup_models.py` and emits, into the graph's
+plans, the kernel launches of its forward pass and (separately) of its backward pass:
+  InstSegNet  <- v1_inst_seg (semisup_models.py:69-139) + subtract_points_mean (145-162)
+  TNet        <- v1_tnet (164-202)
+  BoxEstNet   <- subtract_1st_stage_center (204-209) + v1_box_est (215-291)
+  StrongLoss  <- get_strong_loss (semisup_v1_sunrgbd.py:423-553) + anchor->reg (tf_util.py:1001-1041)
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import abi
+from .abi import fptr, iptr
+from .constants import BOX_OUT_DIMS, NUM_CLASS
+from .engine import ActSpec, FcLayer, Plan, PointLayer, Runtime, VarStore, Workspace, TILE
+
+
+class Graph:
+    """Static launch graph for one (batch_size, num_point, num_channel) problem; the analogue of the
+    reference's tf.Graph + tf.Session (train_semisup.py:204-277)."""
+
+    def __init__(self, batch_size, num_point, num_channel, rt=None, seed=0, unbiased_ema=True, vars=None):
+        if num_point % TILE:
+            raise abi.T3DError('num_point must be a multiple of %d' % TILE)
+        self.rt = rt or Runtime()
+        self.B, self.rpf, self.C = batch_size, num_point, num_channel
+        self.M = batch_size * num_point
+        self.vars = vars or VarStore(self.rt, seed=seed)
+        self.ws = Workspace(self.rt)
+        self.unbiased_ema = unbiased_ema
+        self.hyper = self.rt.zeros(4)              # step, lr, bn_decay, adam lr_t
+        self.hyper[2] = 0.5
+        self.bn_decay_ptr = self.hyper[2:3]
+        self.dropout_masks = {}                    # scope -> (mask tensor, keep_prob)
+        self.deferred_slab_ptrs = []
+        self.fwd = Plan(self.rt)
+        self.bwd = Plan(self.rt)
+        self.opt = Plan(self.rt)
+        self.pre = Plan(self.rt)                   # schedule + dropout mask generation
+        self.finalized = False
+
+    def finalize(self):
+        self.ws.finalize()
+        base = self.ws.buf.data_ptr()
+        for a, soff in self.deferred_slab_ptrs:
+            a.slabs = C.cast(C.c_void_p(base + 4 * soff), abi.F)
+        self.finalized = True
+        return self
+
+    # ---- optimiser ---------------------------------------------------------------------------------
+    def emit_reduce_slabs(self, plan):
+        """Must be emitted after every wgrad has been recorded; resolved at run time (post-finalize)."""
+        ws, vs, lib = self.ws, self.vars, self.rt.lib
+
+        def thunk(s):
+            n = len(ws.entries)
+            if n == 0:
+                return 0
+            mx = max(e[2] for e in ws.entries)
+            return lib.t3d_reduce_slabs(fptr(ws.buf), fptr(vs.grads), C.cast(C.c_void_p(ws.table.data_ptr()), C.POINTER(abi.SlabDesc)),
+                                        n, mx, s)
+        plan.add_raw('t3d_reduce_slabs', thunk)
+
+    def emit_schedule(self, plan, sched):
+        lib, hyper = self.rt.lib, self.hyper
+        plan.add_raw('t3d_schedule_step', lambda s: lib.t3d_schedule_step(fptr(hyper), C.byref(sched), s), sched)
+
+    def emit_dropout_masks(self, plan, seed=1234):
+        lib, hyper = self.rt.lib, self.hyper
+        for i, (scope, (mask, keep)) in enumerate(sorted(self.dropout_masks.items())):
+            plan.add_raw('t3d_dropout_mask',
+                         lambda s, mask=mask, keep=keep, sd=seed + 7919 * i: lib.t3d_dropout_mask(
+                             fptr(mask), mask.numel(), keep, sd, fptr(hyper), s))
+
+    def emit_adam(self, plan, prefixes=None, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+        lib, vs, hyper = self.rt.lib, self.vars, self.hyper
+        for off, n in vs.trainable_ranges(prefixes):
+            plan.add_raw('t3d_adam_tf_step',
+                         lambda s, off=off, n=n: lib.t3d_adam_tf_step(
+                             fptr(vs.params[off:]), fptr(vs.grads[off:]), fptr(vs.adam_m[off:]), fptr(vs.adam_v[off:]),
+                             n, fptr(hyper), beta1, beta2, eps, grad_scale, s))
+
+
+def make_schedule(batch_size, base_lr=1e-3, decay_step=800000, decay_rate=0.5, bn_init_decay=0.5,
+                  bn_decay_rate=0.5, bn_decay_clip=0.99, beta1=0.9, beta2=0.999):
+    """train_semisup.py:53-67,127-145 defaults."""
+    return abi.Schedule(base_lr, decay_rate, float(decay_step), bn_init_decay, bn_decay_rate, float(decay_step),
+                        bn_decay_clip, beta1, beta2, batch_size)
+
+
+class InstSegNet:
+    def __init__(self, g, scope, use_one_hot):
+        self.g, self.scope = g, scope
+        C_, vs = g.C, g.vars
+        s = scope + '/'
+        self.L1 = PointLayer(g, s + 'conv1', C_, 64, kernel_1xD=True)
+        self.L2 = PointLayer(g, s + 'conv2', 64, 64)
+        self.L3 = PointLayer(g, s + 'conv3', 64, 64)
+        self.L4 = PointLayer(g, s + 'conv4', 64, 128)
+        self.L5 = PointLayer(g, s + 'conv5', 128, 1024, pool=True)
+        # conv6 reads [point_feat(64) | global(1024) | one_hot]; split into a per-point K=64 GEMM and a
+        # per-frustum FC on the global feature (identical math, tile+concat never materialised).
+        self.oh = NUM_CLASS if use_one_hot else 0
+        k6 = 64 + 1024 + self.oh
+        w6 = vs.xavier(s + 'conv6/weights', (1, 1, k6, 512), k6, 512).view(k6, 512)
+        self.L6 = PointLayer(g, s + 'conv6', 64, 512, w=w6[0:64], w_name=s + 'conv6/weights', w_row0=0)
+        self.G6 = FcLayer(g, s + 'conv6/global', 1024, 512, bn=False, act=None, K2=self.oh, w=w6[64:], bias=None)
+        self.G6.w_grad = vs.grad(s + 'conv6/weights').view(k6, 512)[64:]
+        self.L7 = PointLayer(g, s + 'conv7', 512, 256)
+        self.L8 = PointLayer(g, s + 'conv8', 256, 128)
+        self.L9 = PointLayer(g, s + 'conv9', 128, 128)
+        self.w10 = vs.xavier(s + 'conv10/weights', (1, 1, 128, 2), 128, 2).view(128, 2)
+        self.b10 = vs.const(s + 'conv10/biases', (2,), 0.0)
+        rt, M, T, B = g.rt, g.M, g.M // TILE, g.B
+        self.drop_mask = rt.full((M, 128), 1.0)
+        g.dropout_masks[s + 'dp1'] = (self.drop_mask, 0.5)
+        self.logits, self.mask = rt.zeros(M, 2), rt.zeros(M)
+        self.part = rt.zeros(T, 8)
+        self.mask_xyz_mean, self.seg_loss, self.n_correct = rt.zeros(B, 3), rt.zeros(B), rt.zeros(1)
+
+    def fwd(self, plan, pc, one_hot, labels, is_data_2D, is_training, train_seg, ce_weight=1.0):
+        """`train_seg`: emit the seg-loss backward (dz of conv9 etc.) inside the head kernel."""
+        g, rt = self.g, self.g.rt
+        M, T = g.M, g.M // TILE
+        a = ActSpec(pc, g.C, g.C)
+        a = self.L1.fwd(plan, a, is_training)
+        a = self.L2.fwd(plan, a, is_training)
+        a3 = self.L3.fwd(plan, a, is_training)
+        a = self.L4.fwd(plan, a3, is_training)
+        self.L5.fwd(plan, a, is_training)
+        rb = self.G6.fwd(plan, self.L5.pooled, 1024, is_training, in2=one_hot if self.oh else None, ld_in2=NUM_CLASS)
+        a = self.L6.fwd(plan, a3, is_training, rowbias=rb)
+        a = self.L7.fwd(plan, a, is_training)
+        a = self.L8.fwd(plan, a, is_training)
+        self.L9.fwd(plan, a, is_training)
+        self.train_seg = train_seg
+        h = abi.SegHeadArgs()
+        L9 = self.L9
+        h.y, h.scale, h.shift = fptr(L9.y), fptr(L9.scale), fptr(L9.shift)
+        if is_training:
+            h.drop_mask, h.keep_prob = fptr(self.drop_mask), 0.5
+        h.w, h.bias = fptr(self.w10), fptr(self.b10)
+        h.labels, h.is_data_2D = iptr(labels), iptr(is_data_2D)
+        h.pc, h.ld_pc, h.ce_weight = fptr(pc), g.C, ce_weight
+        h.logits, h.mask, h.part = fptr(self.logits), fptr(self.mask), fptr(self.part)
+        if train_seg:
+            L9._ensure_bwd_buffers()
+            self.dw_part = rt.zeros(T, 128, 2)
+            h.dz, h.psum_dz, h.psum_dzy, h.dw_part = fptr(L9.dz), fptr(L9.psum_dz), fptr(L9.psum_dzy), fptr(self.dw_part)
+        h.M, h.K, h.rows_per_frustum, h.B = M, 128, g.rpf, g.B
+        plan.add('t3d_seg_head', h)
+        f = abi.SegFinalizeArgs()
+        f.part, f.B, f.tiles_per_frustum, f.rows_per_frustum, f.K = fptr(self.part), g.B, g.rpf // TILE, g.rpf, 128
+        f.mask_xyz_mean, f.seg_loss, f.n_correct = fptr(self.mask_xyz_mean), fptr(self.seg_loss), fptr(self.n_correct)
+        if train_seg:
+            f.dw_part = fptr(self.dw_part)
+            f.dw = fptr(g.vars.grad(self.scope + '/conv10/weights'))
+            f.dbias = fptr(g.vars.grad(self.scope + '/conv10/biases'))
+        plan.add('t3d_seg_finalize', f)
+        return self.logits
+
+    def bwd(self, plan):
+        assert self.train_seg
+        g = self.g
+        L = self
+        for lay in (L.L9, L.L8, L.L7):
+            lay.bn_bwd(plan)
+            lay.wgrad(plan)
+            lay.dgrad(plan)
+        L.L6.bn_bwd(plan)
+        L.L6.wgrad(plan)
+        colsum6 = L.L6.dy_colsum(plan)                                   # [B,512]
+        L.G6.bwd(plan, dout=colsum6, ld_dout=512)                        # dW6[64:], no bias
+        dg5 = L.G6.dinput(plan, K=1024)                                  # [B,1024]
+        self.da3_part = g.rt.zeros(g.M, 64)
+        L.L6.dgrad(plan, out_raw=self.da3_part)
+        L.L5.bn_bwd(plan, dpool_in=dg5, ld_dpool_in=1024)
+        L.L5.wgrad(plan)
+        L.L5.dgrad(plan)
+        L.L4.bn_bwd(plan)
+        L.L4.wgrad(plan)
+        L.L4.dgrad(plan, add_in=self.da3_part)
+        for lay in (L.L3, L.L2):
+            lay.bn_bwd(plan)
+            lay.wgrad(plan)
+            lay.dgrad(plan)
+        L.L1.bn_bwd(plan)
+        L.L1.wgrad(plan)
+
+
+class TNet:
+    def __init__(self, g, scope, use_one_hot):
+        self.g, self.scope = g, scope
+        s = scope + '/'
+        oh = NUM_CLASS if use_one_hot else 0
+        self.oh = oh
+        self.T1 = PointLayer(g, s + 'conv-reg1-stage1', 3, 128)
+        self.T2 = PointLayer(g, s + 'conv-reg2-stage1', 128, 128)
+        self.T3 = PointLayer(g, s + 'conv-reg3-stage1', 128, 256, pool=True)
+        self.F1 = FcLayer(g, s + 'fc1-stage1', 256, 256, K2=oh)
+        self.F2 = FcLayer(g, s + 'fc2-stage1', 256, 128)
+        self.F3 = FcLayer(g, s + 'fc3-stage1', 128, 3, bn=False, act=None)
+
+    def fwd(self, plan, pc, mask, mask_xyz_mean, one_hot, is_training):
+        g = self.g
+        a = ActSpec(pc, g.C, 3, sub=mask_xyz_mean, sub_ld=3)
+        a = self.T1.fwd(plan, a, is_training)
+        a = self.T2.fwd(plan, a, is_training)
+        self.T3.fwd(plan, a, is_training, rowmask=mask)
+        x = self.F1.fwd(plan, self.T3.pooled, 256, is_training, in2=one_hot if self.oh else None, ld_in2=NUM_CLASS)
+        x = self.F2.fwd(plan, x, 256, is_training)
+        self.stage1_center = self.F3.fwd(plan, x, 128, is_training, add_in=mask_xyz_mean, ld_add=3, add_n=3)
+        return self.stage1_center
+
+    def bwd(self, plan, dstage1):
+        self.F3.bwd(plan, dout=dstage1, ld_dout=3)
+        self.F2.bwd(plan, nxt=self.F3)
+        self.F1.bwd(plan, nxt=self.F2)
+        dft = self.F1.dinput(plan, K=256)
+        self.T3.bn_bwd(plan, dpool_in=dft, ld_dpool_in=256)
+        self.T3.wgrad(plan)
+        self.T3.dgrad(plan)
+        self.T2.bn_bwd(plan)
+        self.T2.wgrad(plan)
+        self.T2.dgrad(plan)
+        self.T1.bn_bwd(plan)
+        self.T1.wgrad(plan)
+
+
+class BoxEstNet:
+    def __init__(self, g, scope, use_one_hot):
+        self.g, self.scope = g, scope
+        s = scope + '/'
+        oh = NUM_CLASS if use_one_hot else 0
+        self.oh = oh
+        self.B1 = PointLayer(g, s + 'conv-reg1', 3, 128)
+        self.B2 = PointLayer(g, s + 'conv-reg2', 128, 128)
+        self.B3 = PointLayer(g, s + 'conv-reg3', 128, 256)
+        self.B4 = PointLayer(g, s + 'conv-reg4', 256, 512, pool=True)
+        self.G1 = FcLayer(g, s + 'fc1', 512, 512, K2=oh)
+        self.G2 = FcLayer(g, s + 'fc2', 512, 256)
+        self.G3 = FcLayer(g, s + 'fc3', 256, BOX_OUT_DIMS, bn=False, act=None)
+
+    def fwd(self, plan, pc, mask, stage1_center, one_hot, is_training):
+        g = self.g
+        a = ActSpec(pc, g.C, 3, sub=stage1_center, sub_ld=3)
+        a = self.B1.fwd(plan, a, is_training)
+        a = self.B2.fwd(plan, a, is_training)
+        a = self.B3.fwd(plan, a, is_training)
+        self.B4.fwd(plan, a, is_training, rowmask=mask)
+        self.feats_lv1 = self.B4.pooled
+        self.feats_lv2 = self.G1.fwd(plan, self.feats_lv1, 512, is_training, in2=one_hot if self.oh else None,
+                                     ld_in2=NUM_CLASS)
+        self.feats_lv3 = self.G2.fwd(plan, self.feats_lv2, 512, is_training)
+        self.box_params = self.G3.fwd(plan, self.feats_lv3, 256, is_training)
+        return self.box_params
+
+    def bwd_convs(self, plan, dfeats, ld, dstage1_in):
+        """Backward of the per-point stack given d(feats_lv1); returns the total d(stage1_center)."""
+        self.B4.bn_bwd(plan, dpool_in=dfeats, ld_dpool_in=ld)
+        self.B4.wgrad(plan)
+        self.B4.dgrad(plan)
+        for lay in (self.B3, self.B2):
+            lay.bn_bwd(plan)
+            lay.wgrad(plan)
+            lay.dgrad(plan)
+        self.B1.bn_bwd(plan)
+        self.B1.wgrad(plan)
+        # input = xyz - stage1_center  =>  d stage1_center -= sum_n dX = (per-frustum colsum of dy1) . W1^T
+        colsum1 = self.B1.dy_colsum(plan)                                # [B,128]
+        g = self.g
+        out = g.rt.zeros(g.B, 3)
+        a = abi.FcDinputArgs(fptr(colsum1), 128, fptr(self.B1.w), fptr(dstage1_in), 3, -1.0, fptr(out), 3, g.B, 3)
+        plan.add('t3d_fc_dinput', a)
+        return out
+
+    def bwd(self, plan, dbox, dstage1_in):
+        self.G3.bwd(plan, dout=dbox, ld_dout=BOX_OUT_DIMS)
+        self.G2.bwd(plan, nxt=self.G3)
+        self.G1.bwd(plan, nxt=self.G2)
+        dfb = self.G1.dinput(plan, K=512)
+        return self.bwd_convs(plan, dfb, 512, dstage1_in)
+
+
+class StrongLoss:
+    def __init__(self, g):
+        self.g = g
+        rt, B = g.rt, g.B
+        self.dbox, self.dstage1 = rt.zeros(B, BOX_OUT_DIMS), rt.zeros(B, 3)
+        self.terms, self.total_losses, self.loss = rt.zeros(B, 8), rt.zeros(B), rt.zeros(1)
+        self.center, self.reg_dims, self.reg_theta = rt.zeros(B, 3), rt.zeros(B, 3), rt.zeros(B)
+
+    def emit(self, plan, box, stage1_center, seg_loss, labels, c, normalize_by_3d_count=False):
+        y_center, y_orient_cls, y_orient_reg, y_dims_cls, y_dims_reg, is_data_2D = labels
+        a = abi.StrongLossArgs()
+        a.box, a.ld_box, a.stage1_center, a.seg_loss = fptr(box), BOX_OUT_DIMS, fptr(stage1_center), fptr(seg_loss)
+        a.y_center, a.y_orient_cls, a.y_orient_reg = fptr(y_center), iptr(y_orient_cls), fptr(y_orient_reg)
+        a.y_dims_cls, a.y_dims_reg, a.is_data_2D = iptr(y_dims_cls), fptr(y_dims_reg), iptr(is_data_2D)
+        a.wts = abi.StrongWeights(c.STRONG_WEIGHT_CENTER, c.STRONG_WEIGHT_ORIENT_CLS, c.STRONG_WEIGHT_ORIENT_REG,
+                                  c.STRONG_WEIGHT_DIMS_CLS, c.STRONG_WEIGHT_DIMS_REG, c.STRONG_WEIGHT_TNET_CENTER,
+                                  c.STRONG_WEIGHT_CORNER, c.STRONG_BOX_MULTIPLER, c.STRONG_WEIGHT_CROSS_ENTROPY)
+        a.normalize_by_3d_count = int(normalize_by_3d_count)
+        a.dbox, a.dstage1, a.terms = fptr(self.dbox), fptr(self.dstage1), fptr(self.terms)
+        a.total_losses, a.loss = fptr(self.total_losses), fptr(self.loss)
+        a.center, a.reg_dims, a.reg_theta, a.B = fptr(self.center), fptr(self.reg_dims), fptr(self.reg_theta), self.g.B
+        plan.add('t3d_strong_loss', a)
+
+
+class Inputs:
+    """Device-resident feed buffers in the reference's batch layout (roi_semi_dataset.py:531-534;
+    semisup_v1_sunrgbd.placeholder_inputs 37-67).  `load(batch)` copies a NumPy batch in (H2D)."""
+
+    FIELDS = [('pc', torch.float32, lambda B, N, C: (B * N, C)), ('one_hot_vec', torch.float32, lambda B, N, C: (B, NUM_CLASS)),
+              ('y_seg', torch.int32, lambda B, N, C: (B * N,)), ('y_center', torch.float32, lambda B, N, C: (B, 3)),
+              ('y_orient_cls', torch.int32, lambda B, N, C: (B,)), ('y_orient_reg', torch.float32, lambda B, N, C: (B,)),
+              ('y_dims_cls', torch.int32, lambda B, N, C: (B,)), ('y_dims_reg', torch.float32, lambda B, N, C: (B, 3)),
+              ('is_data_2D', torch.int32, lambda B, N, C: (B,)),
+              ('y_box_iou', torch.float32, lambda B, N, C: (B,)), ('y_center_delta', torch.float32, lambda B, N, C: (B, 3)),
+              ('y_dims_delta', torch.float32, lambda B, N, C: (B, 3)), ('y_orient_delta', torch.float32, lambda B, N, C: (B,))]
+
+    def __init__(self, g):
+        self.g = g
+        for name, dt, shp in self.FIELDS:
+            setattr(self, name, g.rt.zeros(*shp(g.B, g.rpf, g.C), dtype=dt))
+
+    def load(self, batch):
+        for name, dt, _ in self.FIELDS:
+            if name in batch:
+                t = getattr(self, name)
+                t.copy_(torch.as_tensor(np.ascontiguousarray(batch[name])).to(dt).reshape(t.shape))
+        for scope, m in batch.get('dropout_masks', {}).items():
+            if scope in self.g.dropout_masks:
+                t = self.g.dropout_masks[scope][0]
+                t.copy_(torch.as_tensor(np.ascontiguousarray(m)).to(torch.float32).reshape(t.shape))
+
+
+class SemiModelA:
+    """SEMI_MODEL A (get_semi_model_backbone + get_semi_loss_backbone, semisup_v1_sunrgbd.py:81-130,
+    256-321): seg PointNet -> masked centroid -> T-Net -> box PointNet -> strong loss, forward and
+    backward, as one static launch schedule."""
+
+    def __init__(self, g, c, use_one_hot=False, scope_prefix=''):
+        self.g, self.c, self.use_one_hot = g, c, use_one_hot
+        self.inputs = Inputs(g)
+        self.seg = InstSegNet(g, scope_prefix + 'inst_seg', use_one_hot)
+        self.tnet = TNet(g, scope_prefix + 'tnet', use_one_hot)
+        self.box = BoxEstNet(g, scope_prefix + 'box_est', use_one_hot)
+        self.loss_op = StrongLoss(g)
+
+    def emit_forward(self, plan, is_training, with_loss):
+        g, x, c = self.g, self.inputs, self.c
+        labels = x.y_seg if with_loss else None
+        train_seg = with_loss and is_training
+        self.seg.fwd(plan, x.pc, x.one_hot_vec, labels, x.is_data_2D, is_training, train_seg,
+                     ce_weight=c.STRONG_WEIGHT_CROSS_ENTROPY)
+        s1 = self.tnet.fwd(plan, x.pc, self.seg.mask, self.seg.mask_xyz_mean, x.one_hot_vec, is_training)
+        box = self.box.fwd(plan, x.pc, self.seg.mask, s1, x.one_hot_vec, is_training)
+        if with_loss:
+            lab = (x.y_center, x.y_orient_cls, x.y_orient_reg, x.y_dims_cls, x.y_dims_reg, x.is_data_2D)
+            self.loss_op.emit(plan, box, s1, self.seg.seg_loss, lab, c)
+
+    def emit_backward(self, plan):
+        ds1 = self.box.bwd(plan, self.loss_op.dbox, self.loss_op.dstage1)
+        self.tnet.bwd(plan, ds1)
+        self.seg.bwd(plan)
+        self.g.emit_reduce_slabs(plan)
+
+    def end_points(self):
+        g = self.g
+        B, N = g.B, g.rpf
+        return {
+            'logits': self.seg.logits.view(B, N, 2), 'mask': self.seg.mask.view(B, N),
+            'mask_xyz_mean': self.seg.mask_xyz_mean, 'stage1_center': self.tnet.stage1_center,
+            'box_params': self.box.box_params, 'feats_lv1': self.box.feats_lv1, 'feats_lv2': self.box.feats_lv2,
+            'feats_lv3': self.box.feats_lv3, 'center': self.loss_op.center, 'tnet_feats': self.tnet.T3.pooled,
+            'seg_global_feat': self.seg.L5.pooled, 'loss_terms': self.loss_op.terms,
+            'total_losses': self.loss_op.total_losses, 'loss': self.loss_op.loss,
+            'S_dims': self.loss_op.reg_dims, 'S_theta': self.loss_op.reg_theta,
+        }
