@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frustums/sec of one SEMI_MODEL A training step (seg PointNet + T-Net + box PointNet,
+forward + backward + TF-form Adam) on synthetic B=32, N=1024, C=4 frustum batches resident in HBM
+(BASELINE.json configs[1]), one process per GPU, data-parallel gradient all-reduce over RCCL for N > 1.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task description), with `roofline` for the dominant kernel
+(per-launch HIP-event timing on the launch stream) and `cpu_baseline` (the oracle's torch-CPU restatement of
+the same step timed on this host's cores; baseline, not target).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+
+MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
+SPLIT_GFLOP_PER_FRUSTUM = 3.638   # fwd+bwd, split-conv6 count (the algorithm actually run)
+DENSE_GFLOP_PER_FRUSTUM = 6.856   # as-written dense concat count (reported for reference only)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--batch_size', type=int, default=32)
+    ap.add_argument('--num_point', type=int, default=1024)
+    ap.add_argument('--num_channel', type=int, default=4)
+    ap.add_argument('--no_graph', action='store_true', help='eager launches instead of hipGraph replay')
+    ap.add_argument('--no_cpu_baseline', action='store_true')
+    ap.add_argument('--cpu_steps', type=int, default=2)
+    ap.add_argument('--cpu_threads', type=int, default=32,
+                    help='host threads for the CPU baseline (torch CPU ops stop scaling / oversubscribe beyond this)')
+    ap.add_argument('--profile_steps', type=int, default=5)
+    return ap.parse_args()
+
+
+def gemm_label_and_flops(name, a):
+    """Mirror of the template dispatch in csrc/pointmlp.hip -> rocprof kernel name + algorithmic FLOPs."""
+    flops = 2.0 * a.M * a.K * a.N
+    if name == 't3d_pointmlp_fwd':
+        return 'k_pointmlp_fwd<%d>' % (128 if a.N % 128 == 0 else 64), flops
+    if name == 't3d_pointmlp_dgrad':
+        return 'k_pointmlp_dgrad<%d>' % (128 if a.K % 128 == 0 else 64), flops
+    return 'k_pointmlp_wgrad<%d,%d>' % (128 if a.K > 64 else 64, 128 if a.N % 128 == 0 else 64), flops
+
+
+def profile_kernels(plans, steps):
+    """Per-launch HIP events (torch events on the stream the kernels are launched on), eager replay."""
+    acc = {}
+    for _ in range(steps):
+        evs = []
+        for plan in plans:
+            s = plan.rt.stream()
+            for name, call, arg in plan.calls:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = call(s)
+                assert rc == 0, (name, rc)
+                e1.record()
+                evs.append((name, arg, e0, e1))
+        torch.cuda.synchronize()
+        for name, arg, e0, e1 in evs:
+            label, flops = (gemm_label_and_flops(name, arg) if name.startswith('t3d_pointmlp') else (name, 0.0))
+            d = acc.setdefault(label, [0.0, 0, 0.0])
+            d[0] += e0.elapsed_time(e1) * 1e-3
+            d[1] += 1
+            d[2] += flops
+    return acc
+
+
+def cpu_baseline(args, batch):
+    """The oracle's torch-CPU fp32 restatement of the identical step (fwd + bwd + TF-form Adam), all host
+    threads.  TF1 itself cannot run, so kind = "port"."""
+    from oracle import ref_torch as R
+    torch.set_num_threads(min(os.cpu_count(), args.cpu_threads))
+    C = args.num_channel
+    P = R.init_params(np.random.RandomState(0), R.layer_table(C, 'A'), dtype=torch.float32)
+    c = R.default_config()
+    names = R.trainable_names(P)
+    m = {k: torch.zeros_like(P[k]) for k in names}
+    v = {k: torch.zeros_like(P[k]) for k in names}
+    batch = dict(batch)
+    batch['dropout_masks'] = {'inst_seg/dp1': (np.random.RandomState(1).uniform(size=(args.batch_size, args.num_point, 128)) < 0.5)
+                              .astype(np.float32)}
+    times = []
+    for it in range(args.cpu_steps + 1):
+        t0 = time.perf_counter()
+        _, _, grads, ema = R.model_a_forward_backward(P, batch, c, dtype=torch.float32)
+        R.adam_tf_step(P, grads, m, v, it + 1, 1e-3)
+        for k, val in ema.items():
+            P[k] = val.detach()
+        times.append(time.perf_counter() - t0)
+    t = float(np.median(times[1:]))
+    return {'value': args.batch_size / t, 'unit': 'frustums/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '%d timed steps (after 1 warm-up) of the same B=%d N=%d C=%d fp32 fwd+bwd+Adam step, torch-CPU '
+                      'restatement of the reference graph (TF1 not installable)' % (args.cpu_steps, args.batch_size,
+                                                                                     args.num_point, C)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback on the product path)'
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+
+    from oracle import ref_torch as R     # config defaults only (SimpleNamespace); not on the timed path
+    from transferable3d_amd.engine import Runtime, Plan
+    from transferable3d_amd.nets import Graph, SemiModelA, make_schedule
+    from transferable3d_amd.synthetic import make_batch
+
+    B, N, C = args.batch_size, args.num_point, args.num_channel
+    rt = Runtime()
+    g = Graph(B, N, C, rt=rt, seed=0)              # identical initial weights on every rank
+    c = R.default_config()
+    model = SemiModelA(g, c)
+    sched = make_schedule(B * world)
+    g.emit_schedule(g.pre, sched)
+    g.emit_dropout_masks(g.pre, seed=1234 + rank)
+    model.emit_forward(g.fwd, True, True)
+    model.emit_backward(g.bwd)
+    g.emit_adam(g.opt, grad_scale=1.0 / world)
+    g.finalize()
+    batch = make_batch(B, N, C, seed=1234 + rank)  # per-rank shard of the global batch (weak scaling)
+    model.inputs.load(batch)
+    torch.cuda.synchronize()
+
+    nparam = g.vars.used
+    flat_grads = g.vars.grads[:nparam]
+
+    def run_compute():
+        g.pre.run()
+        g.fwd.run()
+        g.bwd.run()
+
+    use_graph = not args.no_graph
+    if use_graph:
+        # warm the kernels once eagerly, then capture the step into hipGraphs
+        run_compute()
+        g.opt.run()
+        torch.cuda.synchronize()
+        s = torch.cuda.Stream()
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1, stream=s):
+            run_compute()
+            if world == 1:
+                g.opt.run()
+        g2 = None
+        if world > 1:
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, stream=s):
+                g.opt.run()
+
+    def step():
+        if use_graph:
+            g1.replay()
+            if world > 1:
+                dist.all_reduce(flat_grads)
+                g2.replay()
+        else:
+            run_compute()
+            if world > 1:
+                dist.all_reduce(flat_grads)
+            g.opt.run()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = float(model.loss_op.loss.item())
+    assert np.isfinite(loss), 'non-finite loss'
+
+    roofline = None
+    cpu = None
+    if rank == 0:
+        # per-kernel timing for the roofline object (eager, per-launch events on the launch stream)
+        acc = profile_kernels([g.pre, g.fwd, g.bwd, g.opt], args.profile_steps)
+        total = sum(v[0] for v in acc.values())
+        dom = max((k for k in acc if k.startswith('k_pointmlp')), key=lambda k: acc[k][0])
+        tsec, n, fl = acc[dom]
+        achieved = fl / tsec / 1e12
+        gemm_t = sum(v[0] for k, v in acc.items() if k.startswith('k_pointmlp'))
+        gemm_f = sum(v[2] for k, v in acc.items() if k.startswith('k_pointmlp'))
+        roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': achieved, 'peak': MFMA_F32_PEAK_TFLOPS,
+                    'unit': 'TFLOP/s', 'frac': achieved / MFMA_F32_PEAK_TFLOPS, 'traffic': None,
+                    'avg_launch_us': tsec / n * 1e6, 'launches_per_step': n // args.profile_steps,
+                    'flops_per_launch': fl / n,
+                    'all_gemm_kernels': {'achieved': gemm_f / gemm_t / 1e12, 'frac': gemm_f / gemm_t / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                                         'share_of_step_kernel_time': gemm_t / total},
+                    'whole_step': {'gflop_per_frustum_split': SPLIT_GFLOP_PER_FRUSTUM,
+                                   'achieved': SPLIT_GFLOP_PER_FRUSTUM * B * args.steps / elapsed / 1e3,
+                                   'frac': SPLIT_GFLOP_PER_FRUSTUM * B * args.steps / elapsed / 1e3 / MFMA_F32_PEAK_TFLOPS},
+                    'per_kernel_us_per_step': {k: v[0] / args.profile_steps * 1e6 for k, v in sorted(acc.items(), key=lambda kv: -kv[1][0])}}
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args, batch)
+
+    if rank == 0:
+        value = B * world * args.steps / elapsed
+        out = {'metric': 'frustums/sec fwd+bwd', 'value': value, 'unit': 'frustums/s', 'n_gpus': world, 'steps': args.steps,
+               'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
+               'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': 'seg-PointNet + T-Net + box-est fwd+bwd+Adam (SEMI_MODEL A), B=%d N=%d C=%d fp32 per GPU, '
+                                      'dp%d' % (B, N, C, world), 'global_batch': B * world, 'hipgraph': use_graph,
+                          'launches_per_step': len(g.pre) + len(g.fwd) + len(g.bwd) + len(g.opt), 'final_loss': loss},
+               'roofline': roofline, 'cpu_baseline': cpu}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

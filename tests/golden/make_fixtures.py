@@ -18,7 +18,7 @@ from transferable3d_amd.synthetic import make_batch    # noqa: E402
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def model_a(B=2, N=128, C=4, seed=11, pseed=5):
+def model_a(B=4, N=128, C=4, seed=11, pseed=5):
     batch = make_batch(B, N, C, seed=seed, dropout_scopes={'inst_seg/dp1': ((B, N, 128), 0.5)})
     P = R.init_params(np.random.RandomState(pseed), R.layer_table(C, 'A'))
     c = R.default_config()

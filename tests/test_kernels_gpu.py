@@ -490,7 +490,7 @@ def test_reduce_slabs_adam_schedule_dropout(hip_lib):
         torch.cuda.synchronize()
         _close(hc, hg.cpu(), 1e-6, 1e-9, 'hyper')
         _close(ws[0], ws[1].cpu(), 1e-6, 1e-7, 'adam w')
-        _close(vs[0], vs[1].cpu(), 1e-5, 1e-12, 'adam v')
+        _close(vs[0], vs[1].cpu(), 1e-4, 1e-12, 'adam v')
     assert abs(float(hc[1]) - 5e-4) < 1e-9 and abs(float(hc[2]) - 0.75) < 1e-7      # 25000*32 >= 800000
 
     # dropout mask: 0/1 valued, keep fraction, fresh per step

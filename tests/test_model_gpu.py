@@ -16,19 +16,23 @@ def _params(C, seed):
     return R.init_params(np.random.RandomState(seed), R.layer_table(C, 'A'))
 
 
-@pytest.mark.parametrize('B,N,seed', [(4, 256, 1), (8, 512, 2)])
-def test_model_a_step_matches_oracle(hip_lib, B, N, seed):
+@pytest.mark.parametrize('B,N,seed,med_tol', [(4, 256, 1, 1e-4), (8, 512, 2, 3e-3)])
+def test_model_a_step_matches_oracle(hip_lib, B, N, seed, med_tol):
+    """med_tol: at M = B*N = 4096 rows a layer has millions of ReLU inputs, a few of which sit within fp32
+    rounding of zero and flip relative to the fp64 oracle; each flip moves every gradient below it by about one
+    element's worth (~1/M relative), which the CPU specification run reproduces (DESIGN.md, 'ReLU-boundary
+    flips').  The forward tolerance stays 1e-4."""
     C = 4
     batch = make_batch(B, N, C, seed=seed, dropout_scopes={'inst_seg/dp1': ((B, N, 128), 0.5)})
     P = _params(C, 7 + seed)
     c = R.default_config()
     g, m = run_model_a(Runtime(lib=hip_lib), batch, P, c)
-    res = check_against_oracle(g, m, batch, P, c)
+    res = check_against_oracle(g, m, batch, P, c, grad_median_tol=med_tol)
     print(res)
 
 
 def test_model_a_matches_golden_vectors(hip_lib):
-    batch, P, z = load_golden('model_a_B2_N128.npz')
+    batch, P, z = load_golden('model_a_B4_N128.npz')
     g, m = run_model_a(Runtime(lib=hip_lib), batch, P, R.default_config())
     e = m.end_points()
     for k in ('logits', 'stage1_center', 'center', 'box_params', 'feats_lv1', 'mask_xyz_mean'):

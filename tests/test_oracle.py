@@ -78,7 +78,7 @@ def test_adam_tf_form_and_schedules():
 def test_golden_fixture_reproduces():
     """The committed vectors were produced by tests/golden/make_fixtures.py from this oracle."""
     from model_check import load_golden
-    batch, P, z = load_golden('model_a_B2_N128.npz')
+    batch, P, z = load_golden('model_a_B4_N128.npz')
     loss, ep, grads, ema = R.model_a_forward_backward(P, batch, R.default_config())
     assert abs(float(loss) - float(z['out/loss'])) < 1e-10
     assert np.abs(ep['logits'].detach().numpy() - z['out/logits']).max() < 1e-10

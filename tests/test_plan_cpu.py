@@ -29,7 +29,7 @@ def test_model_a_plan_matches_oracle(B, N, seed):
 
 
 def test_model_a_plan_matches_golden_vectors():
-    batch, P, z = load_golden('model_a_B2_N128.npz')
+    batch, P, z = load_golden('model_a_B4_N128.npz')
     g, m = run_model_a(_rt(), batch, P, R.default_config())
     e = m.end_points()
     for k in ('logits', 'stage1_center', 'center', 'box_params', 'feats_lv1', 'mask_xyz_mean'):

@@ -164,6 +164,9 @@ class T3DError(RuntimeError):
 
 def load(path=None):
     """dlopen libt3d.so and bind every entry point of include/t3d.h; raises if anything is missing."""
+    # torch bundles its own libamdhip64: import it FIRST so that libt3d.so binds to the same HIP runtime
+    # instance that owns torch's streams and allocations (two runtimes in one process cannot share them).
+    import torch  # noqa: F401
     path = path or LIB_PATH
     if not os.path.exists(path):
         raise T3DError('HIP library %s not built: run `python -m transferable3d_amd.build` (no CPU fallback exists)' % path)

@@ -210,7 +210,7 @@ extern "C" int t3d_bn_fwd_finalize(const t3d_bn_fwd_finalize_args* a, t3d_stream
       !a->invstd)
     return T3D_ERR_ARG;
   if (a->is_training && (!a->psum || !a->psumsq || !a->decay || a->count <= 0)) return T3D_ERR_ARG;
-  hipLaunchKernelGGL(k_bn_fwd_finalize, dim3((a->N + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+  T3D_LAUNCH(k_bn_fwd_finalize, dim3((a->N + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -219,7 +219,7 @@ extern "C" int t3d_pool_finalize(const t3d_pool_finalize_args* a, t3d_stream_t s
   if (!a || !a->scale || !a->shift || !a->pmax || !a->pmin || !a->pamax || !a->pamin || !a->pooled || !a->argidx ||
       !a->ysel)
     return T3D_ERR_ARG;
-  hipLaunchKernelGGL(k_pool_finalize, dim3((a->B * a->N + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+  T3D_LAUNCH(k_pool_finalize, dim3((a->B * a->N + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
                      *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -230,14 +230,14 @@ extern "C" int t3d_bn_bwd_finalize(const t3d_bn_bwd_finalize_args* a, t3d_stream
   if (a->psum_dz == nullptr && (!a->dpool_in || !a->pooled || !a->ysel || !a->dpool)) return T3D_ERR_ARG;
   if (a->psum_dz != nullptr && !a->psum_dzy) return T3D_ERR_ARG;
   if (a->frozen ? !a->scale : (!a->gamma || !a->mean || !a->invstd)) return T3D_ERR_ARG;
-  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((a->N + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+  T3D_LAUNCH(k_bn_bwd_finalize, dim3((a->N + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
 
 extern "C" int t3d_dy_colsum(const t3d_dy_colsum_args* a, t3d_stream_t stream) {
   if (!a || !a->psum_dz || !a->psum_y || !a->coef || !a->out) return T3D_ERR_ARG;
-  hipLaunchKernelGGL(k_dy_colsum, dim3((a->B * a->N + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+  T3D_LAUNCH(k_dy_colsum, dim3((a->B * a->N + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -248,7 +248,7 @@ extern "C" int t3d_reduce_slabs(const float* slab_base, float* grad_base, const 
   int gx = (max_numel + 255) / 256;
   if (gx > 64) gx = 64;
   if (gx < 1) gx = 1;
-  hipLaunchKernelGGL(k_reduce_slabs, dim3(gx, n_tensors), dim3(256), 0, static_cast<hipStream_t>(stream), slab_base,
+  T3D_LAUNCH(k_reduce_slabs, dim3(gx, n_tensors), dim3(256), 0, static_cast<hipStream_t>(stream), slab_base,
                      grad_base, table_dev);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -256,7 +256,7 @@ extern "C" int t3d_reduce_slabs(const float* slab_base, float* grad_base, const 
 
 extern "C" int t3d_schedule_step(float* hyper, const t3d_schedule* s, t3d_stream_t stream) {
   if (!hyper || !s) return T3D_ERR_ARG;
-  hipLaunchKernelGGL(k_schedule_step, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), hyper, *s);
+  T3D_LAUNCH(k_schedule_step, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), hyper, *s);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -266,7 +266,7 @@ extern "C" int t3d_adam_tf_step(float* params, const float* grads, float* m, flo
   if (!params || !grads || !m || !v || !hyper || n <= 0) return T3D_ERR_ARG;
   int64_t blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(k_adam_tf, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), params, grads, m,
+  T3D_LAUNCH(k_adam_tf, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), params, grads, m,
                      v, n, hyper, beta1, beta2, eps, grad_scale);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -277,7 +277,7 @@ extern "C" int t3d_dropout_mask(float* mask, int64_t n, float keep_prob, uint32_
   if (!mask || !hyper || n <= 0) return T3D_ERR_ARG;
   int64_t blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(k_dropout_mask, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), mask, n,
+  T3D_LAUNCH(k_dropout_mask, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), mask, n,
                      keep_prob, seed, hyper);
   T3D_CHECK_LAUNCH();
   return T3D_OK;

@@ -7,6 +7,14 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// hipGetLastError() is process-wide and sticky: clear whatever an earlier (unrelated) HIP call left behind
+// before launching, so that T3D_CHECK_LAUNCH reports only this launch.
+#define T3D_LAUNCH(...)          \
+  do {                           \
+    (void)hipGetLastError();     \
+    hipLaunchKernelGGL(__VA_ARGS__); \
+  } while (0)
+
 #define T3D_CHECK_LAUNCH()                                  \
   do {                                                      \
     hipError_t e__ = hipGetLastError();                     \

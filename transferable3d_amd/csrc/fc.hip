@@ -326,7 +326,7 @@ extern "C" int t3d_fc_fwd(const t3d_fc_fwd_args* a, t3d_stream_t stream) {
   if (a->gamma && (!a->beta || !a->moving_mean || !a->moving_var || !a->mean || !a->invstd || !a->y)) return T3D_ERR_ARG;
   if (a->gamma && a->is_training && !a->decay) return T3D_ERR_ARG;
   if (a->B <= 0 || a->B > 32 * MAXRB || a->N <= 0 || a->K <= 0) return T3D_ERR_SHAPE;
-  hipLaunchKernelGGL(k_fc_fwd, dim3((a->N + CB - 1) / CB), dim3(256), fc_lds_bytes(a->B, false),
+  T3D_LAUNCH(k_fc_fwd, dim3((a->N + CB - 1) / CB), dim3(256), fc_lds_bytes(a->B, false),
                      static_cast<hipStream_t>(stream), *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -338,7 +338,7 @@ extern "C" int t3d_fc_bwd(const t3d_fc_bwd_args* a, t3d_stream_t stream) {
   if (a->gamma && (!a->beta || !a->mean || !a->invstd || !a->y)) return T3D_ERR_ARG;
   if (a->act != T3D_ACT_NONE && !a->y) return T3D_ERR_ARG;
   if (a->B <= 0 || a->B > 32 * MAXRB || a->N <= 0) return T3D_ERR_SHAPE;
-  hipLaunchKernelGGL(k_fc_bwd, dim3((a->N + CB - 1) / CB), dim3(256), fc_lds_bytes(a->B, true),
+  T3D_LAUNCH(k_fc_bwd, dim3((a->N + CB - 1) / CB), dim3(256), fc_lds_bytes(a->B, true),
                      static_cast<hipStream_t>(stream), *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -347,7 +347,7 @@ extern "C" int t3d_fc_bwd(const t3d_fc_bwd_args* a, t3d_stream_t stream) {
 extern "C" int t3d_fc_dinput(const t3d_fc_dinput_args* a, t3d_stream_t stream) {
   if (!a || !a->dy || !a->w || !a->din) return T3D_ERR_ARG;
   if (a->B <= 0 || a->B > 32 * MAXRB || a->N <= 0 || a->K <= 0) return T3D_ERR_SHAPE;
-  hipLaunchKernelGGL(k_fc_dinput, dim3((a->K + CB - 1) / CB), dim3(256), fc_lds_bytes(a->B, false),
+  T3D_LAUNCH(k_fc_dinput, dim3((a->K + CB - 1) / CB), dim3(256), fc_lds_bytes(a->B, false),
                      static_cast<hipStream_t>(stream), *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;

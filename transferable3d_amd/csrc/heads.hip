@@ -287,7 +287,7 @@ extern "C" int t3d_seg_head(const t3d_seg_head_args* a, t3d_stream_t stream) {
   if (a->labels && !a->is_data_2D) return T3D_ERR_ARG;
   if (a->dz && (!a->labels || !a->psum_dz || !a->psum_dzy || !a->dw_part)) return T3D_ERR_ARG;
   if (a->K != 128 || a->M % T3D_TILE_ROWS || a->rows_per_frustum % T3D_TILE_ROWS) return T3D_ERR_SHAPE;
-  hipLaunchKernelGGL(k_seg_head, dim3(a->M / 128), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+  T3D_LAUNCH(k_seg_head, dim3(a->M / 128), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -295,7 +295,7 @@ extern "C" int t3d_seg_head(const t3d_seg_head_args* a, t3d_stream_t stream) {
 extern "C" int t3d_seg_finalize(const t3d_seg_finalize_args* a, t3d_stream_t stream) {
   if (!a || !a->part || !a->mask_xyz_mean) return T3D_ERR_ARG;
   if (a->dw && !a->dw_part) return T3D_ERR_ARG;
-  hipLaunchKernelGGL(k_seg_finalize, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+  T3D_LAUNCH(k_seg_finalize, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -306,7 +306,7 @@ extern "C" int t3d_strong_loss(const t3d_strong_loss_args* a, t3d_stream_t strea
       !a->center || !a->reg_dims || !a->reg_theta)
     return T3D_ERR_ARG;
   if (a->B <= 0 || a->B > 1024) return T3D_ERR_SHAPE;
-  hipLaunchKernelGGL(k_strong_loss, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), *a);
+  T3D_LAUNCH(k_strong_loss, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

@@ -496,9 +496,9 @@ extern "C" int t3d_pointmlp_fwd(const t3d_pointmlp_fwd_args* a, t3d_stream_t str
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int tiles_m = a->M / 128;
   if (a->N % 128 == 0)
-    hipLaunchKernelGGL(k_pointmlp_fwd<128>, dim3(tiles_m * (a->N / 128)), dim3(NT), 0, s, *a);
+    T3D_LAUNCH(k_pointmlp_fwd<128>, dim3(tiles_m * (a->N / 128)), dim3(NT), 0, s, *a);
   else
-    hipLaunchKernelGGL(k_pointmlp_fwd<64>, dim3(tiles_m * (a->N / 64)), dim3(NT), 0, s, *a);
+    T3D_LAUNCH(k_pointmlp_fwd<64>, dim3(tiles_m * (a->N / 64)), dim3(NT), 0, s, *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -513,9 +513,9 @@ extern "C" int t3d_pointmlp_dgrad(const t3d_pointmlp_dgrad_args* a, t3d_stream_t
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int tiles_m = a->M / 128;
   if (a->K % 128 == 0)
-    hipLaunchKernelGGL(k_pointmlp_dgrad<128>, dim3(tiles_m * (a->K / 128)), dim3(NT), 0, s, *a);
+    T3D_LAUNCH(k_pointmlp_dgrad<128>, dim3(tiles_m * (a->K / 128)), dim3(NT), 0, s, *a);
   else
-    hipLaunchKernelGGL(k_pointmlp_dgrad<64>, dim3(tiles_m * (a->K / 64)), dim3(NT), 0, s, *a);
+    T3D_LAUNCH(k_pointmlp_dgrad<64>, dim3(tiles_m * (a->K / 64)), dim3(NT), 0, s, *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -531,10 +531,10 @@ extern "C" int t3d_pointmlp_wgrad(const t3d_pointmlp_wgrad_args* a, t3d_stream_t
   const int tiles_k = bigk ? (a->K + 127) / 128 : 1;
   const int tiles_n = bign ? a->N / 128 : a->N / 64;
   const dim3 grid(tiles_k * tiles_n * splits);
-  if (bigk && bign) hipLaunchKernelGGL((k_pointmlp_wgrad<128, 128>), grid, dim3(NT), 0, s, *a);
-  else if (bigk) hipLaunchKernelGGL((k_pointmlp_wgrad<128, 64>), grid, dim3(NT), 0, s, *a);
-  else if (bign) hipLaunchKernelGGL((k_pointmlp_wgrad<64, 128>), grid, dim3(NT), 0, s, *a);
-  else hipLaunchKernelGGL((k_pointmlp_wgrad<64, 64>), grid, dim3(NT), 0, s, *a);
+  if (bigk && bign) T3D_LAUNCH((k_pointmlp_wgrad<128, 128>), grid, dim3(NT), 0, s, *a);
+  else if (bigk) T3D_LAUNCH((k_pointmlp_wgrad<128, 64>), grid, dim3(NT), 0, s, *a);
+  else if (bign) T3D_LAUNCH((k_pointmlp_wgrad<64, 128>), grid, dim3(NT), 0, s, *a);
+  else T3D_LAUNCH((k_pointmlp_wgrad<64, 64>), grid, dim3(NT), 0, s, *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

@@ -56,22 +56,22 @@ class Plan:
 
     def __init__(self, rt):
         self.rt = rt
-        self.calls = []      # (name, callable(stream) -> rc)
+        self.calls = []      # (name, callable(stream) -> rc, argument struct or None)
         self.keep = []       # keep-alive for structs / tensors
 
     def add(self, name, args):
         fn = getattr(self.rt.lib, name)
         ref = C.byref(args)
         self.keep.append(args)
-        self.calls.append((name, lambda s, fn=fn, ref=ref: fn(ref, s)))
+        self.calls.append((name, lambda s, fn=fn, ref=ref: fn(ref, s), args))
 
     def add_raw(self, name, thunk, *keep):
         self.keep.extend(keep)
-        self.calls.append((name, thunk))
+        self.calls.append((name, thunk, None))
 
     def run(self):
         s = self.rt.stream()
-        for name, call in self.calls:
+        for name, call, _ in self.calls:
             rc = call(s)
             if rc != 0:
                 abi.check(rc, name)
