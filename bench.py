@@ -42,7 +42,11 @@ def parse():
     ap.add_argument('--cpu_threads', type=int, default=32,
                     help='host threads for the CPU baseline (torch CPU ops stop scaling / oversubscribe beyond this)')
     ap.add_argument('--profile_steps', type=int, default=5)
+    ap.add_argument('--gemm_detail', action='store_true', help='per-shape GEMM timings on stderr')
     return ap.parse_args()
+
+
+LIB = None
 
 
 def gemm_label_and_flops(name, a):
@@ -52,12 +56,18 @@ def gemm_label_and_flops(name, a):
         return 'k_pointmlp_fwd<%d>' % (128 if a.N % 128 == 0 else 64), flops
     if name == 't3d_pointmlp_dgrad':
         return 'k_pointmlp_dgrad<%d>' % (128 if a.K % 128 == 0 else 64), flops
-    return 'k_pointmlp_wgrad<%d,%d>' % (128 if a.K > 64 else 64, 128 if a.N % 128 == 0 else 64), flops
+    import ctypes
+    rps, tk, tn = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    LIB.t3d_wgrad_plan(a.M, a.K, a.N, ctypes.byref(rps), ctypes.byref(tk), ctypes.byref(tn))
+    if rps.value != a.rows_per_split:
+        tk.value, tn.value = (128 if a.K > 64 else 64), (128 if a.N % 128 == 0 else 64)
+    return 'k_pointmlp_wgrad<%d,%d>' % (tk.value, tn.value), flops
 
 
 def profile_kernels(plans, steps):
     """Per-launch HIP events (torch events on the stream the kernels are launched on), eager replay."""
     acc = {}
+    detail = {}
     for _ in range(steps):
         evs = []
         for plan in plans:
@@ -73,10 +83,15 @@ def profile_kernels(plans, steps):
         for name, arg, e0, e1 in evs:
             label, flops = (gemm_label_and_flops(name, arg) if name.startswith('t3d_pointmlp') else (name, 0.0))
             d = acc.setdefault(label, [0.0, 0, 0.0])
-            d[0] += e0.elapsed_time(e1) * 1e-3
+            dt = e0.elapsed_time(e1) * 1e-3
+            d[0] += dt
             d[1] += 1
             d[2] += flops
-    return acc
+            if flops:
+                dd = detail.setdefault('%s M%d K%d N%d' % (label, arg.M, arg.K, arg.N), [0.0, 0, flops])
+                dd[0] += dt
+                dd[1] += 1
+    return acc, detail
 
 
 def cpu_baseline(args, batch):
@@ -128,6 +143,8 @@ def main():
 
     B, N, C = args.batch_size, args.num_point, args.num_channel
     rt = Runtime()
+    global LIB
+    LIB = rt.lib
     g = Graph(B, N, C, rt=rt, seed=0)              # identical initial weights on every rank
     c = R.default_config()
     model = SemiModelA(g, c)
@@ -205,7 +222,7 @@ def main():
     cpu = None
     if rank == 0:
         # per-kernel timing for the roofline object (eager, per-launch events on the launch stream)
-        acc = profile_kernels([g.pre, g.fwd, g.bwd, g.opt], args.profile_steps)
+        acc, detail = profile_kernels([g.pre, g.fwd, g.bwd, g.opt], args.profile_steps)
         total = sum(v[0] for v in acc.values())
         dom = max((k for k in acc if k.startswith('k_pointmlp')), key=lambda k: acc[k][0])
         tsec, n, fl = acc[dom]
@@ -222,6 +239,9 @@ def main():
                                    'achieved': SPLIT_GFLOP_PER_FRUSTUM * B * args.steps / elapsed / 1e3,
                                    'frac': SPLIT_GFLOP_PER_FRUSTUM * B * args.steps / elapsed / 1e3 / MFMA_F32_PEAK_TFLOPS},
                     'per_kernel_us_per_step': {k: v[0] / args.profile_steps * 1e6 for k, v in sorted(acc.items(), key=lambda kv: -kv[1][0])}}
+        if args.gemm_detail:
+            for k, (t_, n_, f_) in sorted(detail.items(), key=lambda kv: -kv[1][0]):
+                sys.stderr.write('%-44s x%d  %8.1f us  %6.1f TF/s\n' % (k, n_ // args.profile_steps, t_ / n_ * 1e6, f_ / (t_ / n_) / 1e12))
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args, batch)
 

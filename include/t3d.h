@@ -178,6 +178,8 @@ typedef struct {
   int rows_per_split;
 } t3d_pointmlp_wgrad_args;
 int t3d_pointmlp_wgrad(const t3d_pointmlp_wgrad_args* args, t3d_stream_t stream);
+/* Recommended row split (and the tile the launcher will then use) for a K x N weight gradient over M rows. */
+int t3d_wgrad_plan(int M, int K, int N, int* rows_per_split, int* tile_k, int* tile_n);
 
 /* ---- K11c: batch-norm backward statistics -> dgamma, dbeta and the three dy coefficients -------
  * dense form: from the dgrad epilogue partials.  pooled form (psum_dz == NULL): from the gradient

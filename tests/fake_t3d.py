@@ -174,6 +174,24 @@ class FakeLib:
             slabs[s] = x[s * rps:(s + 1) * rps].T @ dy[s * rps:(s + 1) * rps]
         return 0
 
+    def t3d_wgrad_plan(self, M, K, N, rps, tk, tn):
+        cap = max(64, (1 << 21) // (K * N))
+        cap = max(1, min(cap, M // 128))
+        ck, cn, tiles = 64, 64, ((K + 63) // 64) * (N // 64)
+        for a_, b_ in ((128, 128), (128, 64), (64, 128), (64, 64)):
+            if (a_ == 128 and K <= 64) or N % b_:
+                continue
+            t = ((K + a_ - 1) // a_) * (N // b_)
+            if t * cap >= 512:
+                ck, cn, tiles = a_, b_, t
+                break
+        want = min((512 + tiles - 1) // tiles, cap)
+        s = 1
+        while s * 2 <= want and M % (s * 2) == 0 and (M // (s * 2)) % 32 == 0:
+            s *= 2
+        rps._obj.value, tk._obj.value, tn._obj.value = M // s, ck, cn
+        return 0
+
     def t3d_bn_bwd_finalize(self, a, stream):
         p = _struct(a)
         N = p.N

@@ -6,25 +6,53 @@
 
 namespace {
 
-// 256 threads = 64 channels x 4 tile groups
+// 256 threads = 16 channels x 16 tile groups: short, unrolled, independent loads (the 64-iteration serial
+// loop of the first version was pure L2 latency: 19 us per launch in profiles/r01_baseline).
+constexpr int FC_CH = 16, FC_GR = 16;
+
+template <int NQ>
+__device__ __forceinline__ void tile_sums(const float* const (&src)[NQ], int n_tiles, int N, int c, int grp, bool ok,
+                                          double (&acc)[NQ]) {
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
+  if (!ok) return;
+  int t = grp;
+  for (; t + 3 * FC_GR < n_tiles; t += 4 * FC_GR) {
+    float v[NQ][4];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[q][u] = src[q][(size_t)(t + u * FC_GR) * N + c];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] += ((double)v[q][0] + (double)v[q][1]) + ((double)v[q][2] + (double)v[q][3]);
+  }
+  for (; t < n_tiles; t += FC_GR)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] += (double)src[q][(size_t)t * N + c];
+}
+
+__device__ __forceinline__ double group_reduce(double v, double (*red)[FC_CH], int grp, int cl) {
+  __syncthreads();
+  red[grp][cl] = v;
+  __syncthreads();
+  double s = 0.0;
+#pragma unroll
+  for (int g = 0; g < FC_GR; ++g) s += red[g][cl];
+  return s;
+}
+
 __global__ __launch_bounds__(256) void k_bn_fwd_finalize(const t3d_bn_fwd_finalize_args p) {
-  __shared__ double red[2][4][64];
-  const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+  __shared__ double red[FC_GR][FC_CH];
+  const int cl = threadIdx.x & (FC_CH - 1), grp = threadIdx.x / FC_CH;
+  const int c = blockIdx.x * FC_CH + cl;
   const bool ok = c < p.N;
   if (p.is_training) {
-    double s = 0.0, ss = 0.0;
-    if (ok)
-      for (int t = grp; t < p.n_tiles; t += 4) {
-        s += (double)p.psum[(size_t)t * p.N + c];
-        ss += (double)p.psumsq[(size_t)t * p.N + c];
-      }
-    red[0][grp][cl] = s;
-    red[1][grp][cl] = ss;
-    __syncthreads();
+    const float* const src[2] = {p.psum, p.psumsq};
+    double acc[2];
+    tile_sums<2>(src, p.n_tiles, p.N, c, grp, ok, acc);
+    const double s = group_reduce(acc[0], red, grp, cl);
+    const double ss = group_reduce(acc[1], red, grp, cl);
     if (grp == 0 && ok) {
-      s = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
-      ss = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
       const double n = (double)p.count;
       const double mean = s / n;
       double var = ss / n - mean * mean;
@@ -80,33 +108,26 @@ __global__ __launch_bounds__(256) void k_pool_finalize(const t3d_pool_finalize_a
 }
 
 __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const t3d_bn_bwd_finalize_args p) {
-  __shared__ double red[2][4][64];
-  const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+  __shared__ double red[FC_GR][FC_CH];
+  const int cl = threadIdx.x & (FC_CH - 1), grp = threadIdx.x / FC_CH;
+  const int c = blockIdx.x * FC_CH + cl;
   const bool ok = c < p.N;
-  double s1 = 0.0, s2 = 0.0;   // sum dz, sum dz*y
-  if (ok) {
-    if (p.psum_dz != nullptr) {
-      for (int t = grp; t < p.n_tiles; t += 4) {
-        s1 += (double)p.psum_dz[(size_t)t * p.N + c];
-        s2 += (double)p.psum_dzy[(size_t)t * p.N + c];
-      }
-    } else {
-      for (int b = grp; b < p.B; b += 4) {
-        const float live = p.pooled[(size_t)b * p.ld_pooled + c] > 0.f ? 1.f : 0.f;
-        const float g = p.dpool_in[(size_t)b * p.ld_dpool_in + c] * live;
-        p.dpool[(size_t)b * p.N + c] = g;
-        s1 += (double)g;
-        s2 += (double)g * (double)p.ysel[(size_t)b * p.N + c];
-      }
+  double acc[2] = {0.0, 0.0};   // sum dz, sum dz*y
+  if (p.psum_dz != nullptr) {
+    const float* const src[2] = {p.psum_dz, p.psum_dzy};
+    tile_sums<2>(src, p.n_tiles, p.N, c, grp, ok, acc);
+  } else if (ok) {
+    for (int b = grp; b < p.B; b += FC_GR) {
+      const float live = p.pooled[(size_t)b * p.ld_pooled + c] > 0.f ? 1.f : 0.f;
+      const float g = p.dpool_in[(size_t)b * p.ld_dpool_in + c] * live;
+      p.dpool[(size_t)b * p.N + c] = g;
+      acc[0] += (double)g;
+      acc[1] += (double)g * (double)p.ysel[(size_t)b * p.N + c];
     }
   }
-  red[0][grp][cl] = s1;
-  red[1][grp][cl] = s2;
-  __syncthreads();
+  const double s1 = group_reduce(acc[0], red, grp, cl);
+  const double s2 = group_reduce(acc[1], red, grp, cl);
   if (grp == 0 && ok) {
-    s1 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
-    s2 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
     if (p.frozen) {
       p.coef[c] = p.scale[c];
       p.coef[p.N + c] = 0.f;
@@ -142,14 +163,40 @@ __global__ __launch_bounds__(256) void k_dy_colsum(const t3d_dy_colsum_args p) {
   p.out[i] = (float)((double)p.alpha * v);
 }
 
+// every slab region starts 16-byte aligned and numel % 4 == 0 (checked on the host side of the ABI)
 __global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ slab_base, float* __restrict__ grad_base,
                                                       const t3d_slab_desc* __restrict__ table) {
   const t3d_slab_desc d = table[blockIdx.y];
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < d.numel; e += gridDim.x * blockDim.x) {
-    const float* s = slab_base + d.slab_off + e;
-    float acc = 0.f;
-    for (int k = 0; k < d.n_slabs; ++k) acc += s[(size_t)k * d.numel];
-    grad_base[d.grad_off + e] = acc;
+  // float4 path needs 16-byte aligned regions (always true for the engine's allocations)
+  const bool vec = ((d.slab_off | d.grad_off | (int64_t)d.numel) & 3) == 0;
+  const int n4 = vec ? (d.numel >> 2) : 0;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += gridDim.x * blockDim.x) {
+    const float4* s = reinterpret_cast<const float4*>(slab_base + d.slab_off) + e;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+    int k = 0;
+    for (; k + 3 < d.n_slabs; k += 4) {
+      const float4 v0 = s[(size_t)(k + 0) * n4], v1 = s[(size_t)(k + 1) * n4], v2 = s[(size_t)(k + 2) * n4],
+                   v3 = s[(size_t)(k + 3) * n4];
+      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+      a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+      a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+      a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+    }
+    for (; k < d.n_slabs; ++k) {
+      const float4 v = s[(size_t)k * n4];
+      a0.x += v.x; a0.y += v.y; a0.z += v.z; a0.w += v.w;
+    }
+    float4 r;
+    r.x = (a0.x + a1.x) + (a2.x + a3.x); r.y = (a0.y + a1.y) + (a2.y + a3.y);
+    r.z = (a0.z + a1.z) + (a2.z + a3.z); r.w = (a0.w + a1.w) + (a2.w + a3.w);
+    reinterpret_cast<float4*>(grad_base + d.grad_off)[e] = r;
+  }
+  if (!vec) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < d.numel; e += gridDim.x * blockDim.x) {
+      float acc = 0.f;
+      for (int k = 0; k < d.n_slabs; ++k) acc += slab_base[d.slab_off + (size_t)k * d.numel + e];
+      grad_base[d.grad_off + e] = acc;
+    }
   }
 }
 
@@ -210,7 +257,7 @@ extern "C" int t3d_bn_fwd_finalize(const t3d_bn_fwd_finalize_args* a, t3d_stream
       !a->invstd)
     return T3D_ERR_ARG;
   if (a->is_training && (!a->psum || !a->psumsq || !a->decay || a->count <= 0)) return T3D_ERR_ARG;
-  T3D_LAUNCH(k_bn_fwd_finalize, dim3((a->N + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+  T3D_LAUNCH(k_bn_fwd_finalize, dim3((a->N + FC_CH - 1) / FC_CH), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -230,7 +277,7 @@ extern "C" int t3d_bn_bwd_finalize(const t3d_bn_bwd_finalize_args* a, t3d_stream
   if (a->psum_dz == nullptr && (!a->dpool_in || !a->pooled || !a->ysel || !a->dpool)) return T3D_ERR_ARG;
   if (a->psum_dz != nullptr && !a->psum_dzy) return T3D_ERR_ARG;
   if (a->frozen ? !a->scale : (!a->gamma || !a->mean || !a->invstd)) return T3D_ERR_ARG;
-  T3D_LAUNCH(k_bn_bwd_finalize, dim3((a->N + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+  T3D_LAUNCH(k_bn_bwd_finalize, dim3((a->N + FC_CH - 1) / FC_CH), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -245,8 +292,8 @@ extern "C" int t3d_dy_colsum(const t3d_dy_colsum_args* a, t3d_stream_t stream) {
 extern "C" int t3d_reduce_slabs(const float* slab_base, float* grad_base, const t3d_slab_desc* table_dev, int n_tensors,
                                 int max_numel, t3d_stream_t stream) {
   if (!slab_base || !grad_base || !table_dev || n_tensors <= 0) return T3D_ERR_ARG;
-  int gx = (max_numel + 255) / 256;
-  if (gx > 64) gx = 64;
+  int gx = (max_numel / 4 + 255) / 256;
+  if (gx > 128) gx = 128;
   if (gx < 1) gx = 1;
   T3D_LAUNCH(k_reduce_slabs, dim3(gx, n_tensors), dim3(256), 0, static_cast<hipStream_t>(stream), slab_base,
                      grad_base, table_dev);

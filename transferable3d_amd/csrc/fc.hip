@@ -1,73 +1,124 @@
-// Per-frustum fully-connected layers (B rows): forward, backward, input gradient.
+// Per-frustum fully-connected layers (B rows): forward, backward, input gradient -- fp32 MFMA.
 //
 // Replaces tf_util.fully_connected (models/tf_util.py:1463-1499) with its batch-norm over the B rows
 // (tf_util.py:1666-1677), activation and the tf_util.dropout that follows it (tf_util.py:1720-1741) at
-// semisup_models.py:196-198, 253-261, 385-392 and mlps_with_dropout (44-63).  These layers are latency
-// bound (M = B = 32..128 rows, weights <= 1 MB): one workgroup owns 32 output columns for ALL rows, so the
-// batch-norm reductions over the batch stay inside the workgroup and a layer is a single launch.
+// semisup_models.py:196-198, 253-261, 385-392 and mlps_with_dropout (44-63).
+//
+// These layers are latency bound (M = B = 32..128 rows, weights <= 2 MB).  One workgroup owns 32 output
+// columns for ALL rows, so the batch-norm reductions over the batch stay inside the workgroup and a layer is a
+// single launch.  The reduction dimension is split over the workgroup's 4 waves (interleaved 8-deep k groups);
+// every wave feeds v_mfma_f32_32x32x2_f32 straight from global/L2 (operands are tiny and cache resident, no LDS
+// staging), the 4 partial 32x32 tiles are summed through LDS, and the epilogue runs on all 256 threads.
 #include "common.h"
 
 namespace {
 
-constexpr int KC = 64;       // reduction chunk
 constexpr int CB = 32;       // columns per workgroup
 constexpr int MAXRB = 4;     // B <= 128
+constexpr int LDT = 33;      // padded row stride of the LDS tiles
 
-struct RowSrc {              // [in | in2] row-concatenated input
+struct RowSrc {              // [in | in2] row-concatenated input, B valid rows
   const float* in; int ld_in; int K;
   const float* in2; int ld_in2; int K2;
+  int B;
   __device__ __forceinline__ float at(int r, int k) const {
     if (k < K) return in[(size_t)r * ld_in + k];
     if (k < K + K2) return in2[(size_t)r * ld_in2 + (k - K)];
     return 0.f;
   }
+  // 4 consecutive reduction elements of one row
+  __device__ __forceinline__ void load4(int r, int k, float (&v)[4]) const {
+    if (r >= B) { v[0] = v[1] = v[2] = v[3] = 0.f; return; }
+    if (k + 3 < K && (ld_in & 3) == 0) {
+      const float4 t = *reinterpret_cast<const float4*>(in + (size_t)r * ld_in + k);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = at(r, k + e);
+    }
+  }
 };
 
-// acc[rb][j] += sum_k src(row, k) * W(k, col) for rows rb*32 + rg*4 + j.
-// WT == false: W(k,col) = w[k*ldw + c0+col]; WT == true: W(k,col) = w[(c0+col)*ldw + k].
+// acc[rb] (32x32 tiles, rows rb*32.., cols c0..c0+31) += sum over this wave's k groups of A[row,k] * W(k,col)
+//   WT == false: W(k,col) = w[k*ldw + c0+col]   (forward: weights [K,N])
+//   WT == true : W(k,col) = w[(c0+col)*ldw + k] (input gradient: dy . W^T)
 template <bool WT>
-__device__ __forceinline__ void rows_gemm(float (&acc)[MAXRB][4], const RowSrc& src, int B, int RB, int BP, const float* w,
-                                          int ldw, int c0, int ncols_valid, float* in_s, float* w_s) {
-  const int tid = threadIdx.x, col = tid & 31, rg = tid >> 5;
-  const int Kt = src.K + src.K2;
+__device__ __forceinline__ void wave_gemm(f32x16 (&acc)[MAXRB], const RowSrc& src, int RB, const float* __restrict__ w, int ldw,
+                                          int Kred, int c0, int ncols, int wave, int lane) {
+  const int l31 = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int rb = 0; rb < MAXRB; ++rb)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[rb][j] = 0.f;
-  for (int k0 = 0; k0 < Kt; k0 += KC) {
-    for (int idx = tid; idx < RB * 32 * KC; idx += 256) {
-      const int r = idx / KC, kk = idx % KC;
-      in_s[kk * BP + r] = (r < B) ? src.at(r, k0 + kk) : 0.f;
-    }
-    for (int idx = tid; idx < KC * CB; idx += 256) {
-      float v = 0.f;
-      if (!WT) {
-        const int kk = idx / CB, c = idx % CB;
-        if (k0 + kk < Kt && c < ncols_valid) v = w[(size_t)(k0 + kk) * ldw + c0 + c];
-        w_s[kk * CB + c] = v;
-      } else {
-        const int c = idx / KC, kk = idx % KC;
-        if (k0 + kk < Kt && c < ncols_valid) v = w[(size_t)(c0 + c) * ldw + k0 + kk];
-        w_s[kk * CB + c] = v;
-      }
-    }
-    __syncthreads();
-#pragma unroll 8
-    for (int kk = 0; kk < KC; ++kk) {
-      const float wv = w_s[kk * CB + col];
+    for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
+  const int ngroups = (Kred + 7) >> 3;
+  const bool cok = l31 < ncols;
+  auto load_group = [&](int g, float (&a)[MAXRB][4], float (&b)[4]) {
+    const int k = 8 * g + 4 * h;
 #pragma unroll
-      for (int rb = 0; rb < MAXRB; ++rb) {
-        if (rb < RB) {
-          const float4 x = *reinterpret_cast<const float4*>(in_s + kk * BP + rb * 32 + rg * 4);
-          acc[rb][0] = fmaf(x.x, wv, acc[rb][0]);
-          acc[rb][1] = fmaf(x.y, wv, acc[rb][1]);
-          acc[rb][2] = fmaf(x.z, wv, acc[rb][2]);
-          acc[rb][3] = fmaf(x.w, wv, acc[rb][3]);
-        }
+    for (int rb = 0; rb < MAXRB; ++rb)
+      if (rb < RB) src.load4(rb * 32 + l31, k, a[rb]);
+    if (!WT) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) b[i] = (cok && k + i < Kred) ? w[(size_t)(k + i) * ldw + c0 + l31] : 0.f;
+    } else {
+      if (cok && k + 3 < Kred && (ldw & 3) == 0) {
+        const float4 t = *reinterpret_cast<const float4*>(w + (size_t)(c0 + l31) * ldw + k);
+        b[0] = t.x; b[1] = t.y; b[2] = t.z; b[3] = t.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b[i] = (cok && k + i < Kred) ? w[(size_t)(c0 + l31) * ldw + k + i] : 0.f;
       }
     }
-    __syncthreads();
+  };
+  auto mma_group = [&](const float (&a)[MAXRB][4], const float (&b)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int rb = 0; rb < MAXRB; ++rb)
+        if (rb < RB) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rb][i], b[i], acc[rb], 0, 0, 0);
+  };
+  // two groups per iteration: both groups' loads are in flight before the first MFMA
+  int g = wave;
+  for (; g + 4 < ngroups; g += 8) {
+    float a0[MAXRB][4], b0[4], a1[MAXRB][4], b1[4];
+    load_group(g, a0, b0);
+    load_group(g + 4, a1, b1);
+    mma_group(a0, b0);
+    mma_group(a1, b1);
   }
+  if (g < ngroups) {
+    float a0[MAXRB][4], b0[4];
+    load_group(g, a0, b0);
+    mma_group(a0, b0);
+  }
+}
+
+// Sum the 4 waves' tiles through LDS.  Afterwards thread t owns column (t & 31) and rows (t >> 5) + 8*j.
+__device__ __forceinline__ void reduce_tiles(const f32x16 (&acc)[MAXRB], int RB, float* red, float (&val)[MAXRB * 4]) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int rows = RB * 32;
+#pragma unroll
+  for (int rb = 0; rb < MAXRB; ++rb)
+    if (rb < RB) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        red[(wave * rows + row) * LDT + l31] = acc[rb][r];
+      }
+    }
+  __syncthreads();
+  const int col = tid & 31, rg = tid >> 5;
+#pragma unroll
+  for (int j = 0; j < MAXRB * 4; ++j) {
+    const int row = rg + 8 * j;
+    float s = 0.f;
+    if (row < rows) {
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) s += red[(wv * rows + row) * LDT + col];
+    }
+    val[j] = s;
+  }
+  __syncthreads();
 }
 
 // sum over all rows of the workgroup's per-thread partial, per column; result broadcast to every thread
@@ -101,44 +152,37 @@ __device__ __forceinline__ float act_bwd(float z, int act, float alpha) {
 
 __global__ __launch_bounds__(256) void k_fc_fwd(const t3d_fc_fwd_args p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int RB = (p.B + 31) / 32, BP = RB * 32 + 4;
-  float* in_s = sm;
-  float* w_s = in_s + KC * BP;
-  float* red = w_s + KC * CB;
-  const int tid = threadIdx.x, col = tid & 31, rg = tid >> 5;
+  const int RB = (p.B + 31) / 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = tid & 31, rg = tid >> 5;
   const int c0 = blockIdx.x * CB, c = c0 + col;
   const int nvalid = min(CB, p.N - c0);
   const bool cok = c < p.N;
 
-  float acc[MAXRB][4];
-  RowSrc src{p.in, p.ld_in, p.K, p.in2, p.ld_in2, p.K2};
-  rows_gemm<false>(acc, src, p.B, RB, BP, p.w, p.N, c0, nvalid, in_s, w_s);
+  f32x16 acc[MAXRB];
+  RowSrc src{p.in, p.ld_in, p.K, p.in2, p.ld_in2, p.K2, p.B};
+  wave_gemm<false>(acc, src, RB, p.w, p.N, p.K + p.K2, c0, nvalid, wave, lane);
+  float y[MAXRB * 4];
+  reduce_tiles(acc, RB, sm, y);
 
   const float bias = (cok && p.bias) ? p.bias[c] : 0.f;
   float part = 0.f;
 #pragma unroll
-  for (int rb = 0; rb < MAXRB; ++rb)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      acc[rb][j] += bias;
-      const int r = rb * 32 + rg * 4 + j;
-      if (rb < RB && r < p.B) part += acc[rb][j];
-    }
+  for (int j = 0; j < MAXRB * 4; ++j) {
+    y[j] += bias;
+    if (rg + 8 * j < p.B) part += y[j];
+  }
   const bool bn = p.gamma != nullptr;
   float mean = 0.f, invstd = 1.f, g = 1.f, be = 0.f;
   if (bn) {
     if (cok) { g = p.gamma[c]; be = p.beta[c]; }
     if (p.is_training) {
-      mean = col_reduce(part, red) / (float)p.B;
+      mean = col_reduce(part, sm) / (float)p.B;
       float vpart = 0.f;
 #pragma unroll
-      for (int rb = 0; rb < MAXRB; ++rb)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int r = rb * 32 + rg * 4 + j;
-          if (rb < RB && r < p.B) { const float d = acc[rb][j] - mean; vpart = fmaf(d, d, vpart); }
-        }
-      const float var = col_reduce(vpart, red) / (float)p.B;
+      for (int j = 0; j < MAXRB * 4; ++j)
+        if (rg + 8 * j < p.B) { const float d = y[j] - mean; vpart = fmaf(d, d, vpart); }
+      const float var = col_reduce(vpart, sm) / (float)p.B;
       invstd = 1.0f / sqrtf(var + p.eps);
       if (cok && rg == 0) {
         const float d = p.decay[0];
@@ -155,47 +199,42 @@ __global__ __launch_bounds__(256) void k_fc_fwd(const t3d_fc_fwd_args p) {
   if (!cok) return;
   const float inv_keep = p.drop_mask ? 1.0f / p.keep_prob : 1.f;
 #pragma unroll
-  for (int rb = 0; rb < MAXRB; ++rb)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = rb * 32 + rg * 4 + j;
-      if (rb < RB && r < p.B) {
-        const float y = acc[rb][j];
-        if (p.y) p.y[(size_t)r * p.N + c] = y;
-        float z = bn ? (y - mean) * invstd * g + be : y;
-        z = act_fwd(z, p.act, p.leaky_alpha);
-        if (p.drop_mask) z *= p.drop_mask[(size_t)r * p.N + c] * inv_keep;
-        if (p.add_in && c < p.add_n) z += p.add_in[(size_t)r * p.ld_add + c];
-        p.out[(size_t)r * p.ld_out + c] = z;
-      }
+  for (int j = 0; j < MAXRB * 4; ++j) {
+    const int r = rg + 8 * j;
+    if (r < p.B) {
+      const float yv = y[j];
+      if (p.y) p.y[(size_t)r * p.N + c] = yv;
+      float z = bn ? (yv - mean) * invstd * g + be : yv;
+      z = act_fwd(z, p.act, p.leaky_alpha);
+      if (p.drop_mask) z *= p.drop_mask[(size_t)r * p.N + c] * inv_keep;
+      if (p.add_in && c < p.add_n) z += p.add_in[(size_t)r * p.ld_add + c];
+      p.out[(size_t)r * p.ld_out + c] = z;
     }
+  }
 }
 
 __global__ __launch_bounds__(256) void k_fc_bwd(const t3d_fc_bwd_args p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int RB = (p.B + 31) / 32, BP = RB * 32 + 4;
-  float* in_s = sm;
-  float* w_s = in_s + KC * BP;
-  float* red = w_s + KC * CB;
-  float* dy_s = red + 8 * CB;            // [RB*32][CB]
-  const int tid = threadIdx.x, col = tid & 31, rg = tid >> 5;
+  const int RB = (p.B + 31) / 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = tid & 31, rg = tid >> 5;
   const int c0 = blockIdx.x * CB, c = c0 + col;
   const int nvalid = min(CB, p.N - c0);
   const bool cok = c < p.N;
 
-  // (a) gradient w.r.t. this layer's output
-  float gout[MAXRB][4];
+  // (a) gradient w.r.t. this layer's output: given, or dy_next . w_next^T on the fly
+  float gout[MAXRB * 4];
   if (p.dout != nullptr) {
 #pragma unroll
-    for (int rb = 0; rb < MAXRB; ++rb)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r = rb * 32 + rg * 4 + j;
-        gout[rb][j] = (rb < RB && r < p.B && cok) ? p.dout[(size_t)r * p.ld_dout + c] : 0.f;
-      }
+    for (int j = 0; j < MAXRB * 4; ++j) {
+      const int r = rg + 8 * j;
+      gout[j] = (r < p.B && cok) ? p.dout[(size_t)r * p.ld_dout + c] : 0.f;
+    }
   } else {
-    RowSrc src{p.dy_next, p.N_next, p.N_next, nullptr, 0, 0};
-    rows_gemm<true>(gout, src, p.B, RB, BP, p.w_next, p.N_next, c0, nvalid, in_s, w_s);
+    f32x16 acc[MAXRB];
+    RowSrc src{p.dy_next, p.N_next, p.N_next, nullptr, 0, 0, p.B};
+    wave_gemm<true>(acc, src, RB, p.w_next, p.N_next, p.N_next, c0, nvalid, wave, lane);
+    reduce_tiles(acc, RB, sm, gout);
   }
 
   // (b) dropout / activation backward, (c) batch-norm backward over the B rows
@@ -203,120 +242,118 @@ __global__ __launch_bounds__(256) void k_fc_bwd(const t3d_fc_bwd_args p) {
   float mean = 0.f, invstd = 1.f, g = 1.f, be = 0.f;
   if (bn && cok) { mean = p.mean[c]; invstd = p.invstd[c]; g = p.gamma[c]; be = p.beta[c]; }
   const float inv_keep = p.drop_mask ? 1.0f / p.keep_prob : 1.f;
-  float xh[MAXRB][4];
+  float xh[MAXRB * 4];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-  for (int rb = 0; rb < MAXRB; ++rb)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = rb * 32 + rg * 4 + j;
-      float dz = 0.f, x = 0.f;
-      if (rb < RB && r < p.B && cok) {
-        const float y = p.y ? p.y[(size_t)r * p.N + c] : 0.f;
-        x = bn ? (y - mean) * invstd : y;
-        const float z = bn ? x * g + be : y;
-        dz = gout[rb][j];
-        if (p.drop_mask) dz *= p.drop_mask[(size_t)r * p.N + c] * inv_keep;
-        dz *= act_bwd(z, p.act, p.leaky_alpha);
-        s1 += dz;
-        s2 = fmaf(dz, x, s2);
-      }
-      gout[rb][j] = dz;
-      xh[rb][j] = x;
+  for (int j = 0; j < MAXRB * 4; ++j) {
+    const int r = rg + 8 * j;
+    float dz = 0.f, x = 0.f;
+    if (r < p.B && cok) {
+      const float yv = p.y ? p.y[(size_t)r * p.N + c] : 0.f;
+      x = bn ? (yv - mean) * invstd : yv;
+      const float z = bn ? x * g + be : yv;
+      dz = gout[j];
+      if (p.drop_mask) dz *= p.drop_mask[(size_t)r * p.N + c] * inv_keep;
+      dz *= act_bwd(z, p.act, p.leaky_alpha);
+      s1 += dz;
+      s2 = fmaf(dz, x, s2);
     }
+    gout[j] = dz;
+    xh[j] = x;
+  }
   float dbias = 0.f;
   if (bn && p.bn_training) {
-    const float dbeta = col_reduce(s1, red);
-    const float dgamma = col_reduce(s2, red);
+    const float dbeta = col_reduce(s1, sm);
+    const float dgamma = col_reduce(s2, sm);
     if (cok && rg == 0) {
       if (p.dbeta) p.dbeta[c] = dbeta;
       if (p.dgamma) p.dgamma[c] = dgamma;
     }
     const float invB = 1.0f / (float)p.B, c1 = g * invstd;
 #pragma unroll
-    for (int rb = 0; rb < MAXRB; ++rb)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) gout[rb][j] = c1 * (gout[rb][j] - dbeta * invB - xh[rb][j] * dgamma * invB);
+    for (int j = 0; j < MAXRB * 4; ++j) gout[j] = c1 * (gout[j] - dbeta * invB - xh[j] * dgamma * invB);
   } else if (bn) {
     const float c1 = g * invstd;
 #pragma unroll
-    for (int rb = 0; rb < MAXRB; ++rb)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) gout[rb][j] *= c1;
+    for (int j = 0; j < MAXRB * 4; ++j) gout[j] *= c1;
   } else {
-    dbias = col_reduce(s1, red);
+    dbias = col_reduce(s1, sm);
   }
   if (cok && rg == 0 && p.dbias) p.dbias[c] = dbias;   // exactly 0 under training-mode BN
 
+  // dy -> global and LDS ([rows][LDT], zero padded)
+  float* dy_s = sm;
   __syncthreads();
 #pragma unroll
-  for (int rb = 0; rb < MAXRB; ++rb)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = rb * 32 + rg * 4 + j;
-      if (rb < RB) {
-        const float v = (r < p.B && cok) ? gout[rb][j] : 0.f;
-        dy_s[r * CB + col] = v;
-        if (r < p.B && cok) p.dy[(size_t)r * p.N + c] = v;
-      }
+  for (int j = 0; j < MAXRB * 4; ++j) {
+    const int r = rg + 8 * j;
+    if (r < RB * 32) {
+      const float v = (r < p.B && cok) ? gout[j] : 0.f;
+      dy_s[r * LDT + col] = v;
+      if (r < p.B && cok) p.dy[(size_t)r * p.N + c] = v;
     }
+  }
   __syncthreads();
   if (p.dw == nullptr) return;
 
-  // (d) dW[k, c] = sum_r in[r,k] * dy[r,c]; thread = (col, k-group of 8)
-  RowSrc src{p.in, p.ld_in, p.K, p.in2, p.ld_in2, p.K2};
+  // (d) dW[k, c] = sum_r in[r,k] * dy[r,c]: one 32x32 MFMA tile per 32 input channels, reduction over rows
+  RowSrc src{p.in, p.ld_in, p.K, p.in2, p.ld_in2, p.K2, p.B};
   const int Kt = p.K + p.K2;
-  for (int k0 = 0; k0 < Kt; k0 += KC) {
-    for (int idx = tid; idx < RB * 32 * KC; idx += 256) {
-      const int r = idx / KC, kk = idx % KC;
-      in_s[kk * BP + r] = (r < p.B) ? src.at(r, k0 + kk) : 0.f;
-    }
-    __syncthreads();
-    for (int kk = rg; kk < KC; kk += 8) {
-      float a = 0.f;
-      for (int r = 0; r < RB * 32; r += 4) {
-        const float4 x = *reinterpret_cast<const float4*>(in_s + kk * BP + r);
-        a = fmaf(x.x, dy_s[(r + 0) * CB + col], a);
-        a = fmaf(x.y, dy_s[(r + 1) * CB + col], a);
-        a = fmaf(x.z, dy_s[(r + 2) * CB + col], a);
-        a = fmaf(x.w, dy_s[(r + 3) * CB + col], a);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int nkb = (Kt + 31) / 32;
+  for (int kb = wave; kb < nkb; kb += 4) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int k = kb * 32 + l31;
+    for (int g8 = 0; g8 < RB * 4; ++g8) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int rr = 8 * g8 + 4 * h + i;
+        a[i] = (rr < p.B && k < Kt) ? src.at(rr, k) : 0.f;
+        b[i] = dy_s[rr * LDT + l31];
       }
-      if (cok && k0 + kk < Kt) p.dw[(size_t)(k0 + kk) * p.N + c] = a;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc, 0, 0, 0);
     }
-    __syncthreads();
+    if (l31 < nvalid) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kk = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (kk < Kt) p.dw[(size_t)kk * p.N + c0 + l31] = acc[r];
+      }
+    }
   }
 }
 
 __global__ __launch_bounds__(256) void k_fc_dinput(const t3d_fc_dinput_args p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int RB = (p.B + 31) / 32, BP = RB * 32 + 4;
-  float* in_s = sm;
-  float* w_s = in_s + KC * BP;
-  const int tid = threadIdx.x, col = tid & 31, rg = tid >> 5;
+  const int RB = (p.B + 31) / 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = tid & 31, rg = tid >> 5;
   const int c0 = blockIdx.x * CB, c = c0 + col;
   const int nvalid = min(CB, p.K - c0);
-  float acc[MAXRB][4];
-  RowSrc src{p.dy, p.N, p.N, nullptr, 0, 0};
-  rows_gemm<true>(acc, src, p.B, RB, BP, p.w, p.N, c0, nvalid, in_s, w_s);
+  f32x16 acc[MAXRB];
+  RowSrc src{p.dy, p.N, p.N, nullptr, 0, 0, p.B};
+  wave_gemm<true>(acc, src, RB, p.w, p.N, p.N, c0, nvalid, wave, lane);
+  float v[MAXRB * 4];
+  reduce_tiles(acc, RB, sm, v);
   if (c >= p.K) return;
 #pragma unroll
-  for (int rb = 0; rb < MAXRB; ++rb)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = rb * 32 + rg * 4 + j;
-      if (rb < RB && r < p.B) {
-        float v = p.alpha * acc[rb][j];
-        if (p.add_in) v += p.add_in[(size_t)r * p.ld_add + c];
-        p.din[(size_t)r * p.ld_din + c] = v;
-      }
+  for (int j = 0; j < MAXRB * 4; ++j) {
+    const int r = rg + 8 * j;
+    if (r < p.B) {
+      float o = p.alpha * v[j];
+      if (p.add_in) o += p.add_in[(size_t)r * p.ld_add + c];
+      p.din[(size_t)r * p.ld_din + c] = o;
     }
+  }
 }
 
-size_t fc_lds_bytes(int B, bool bwd) {
-  const int RB = (B + 31) / 32, BP = RB * 32 + 4;
-  size_t f = (size_t)KC * BP + KC * CB + 8 * CB;
-  if (bwd) f += (size_t)RB * 32 * CB;
-  return f * sizeof(float);
+size_t fc_lds_bytes(int B) {
+  const int RB = (B + 31) / 32;
+  return (size_t)4 * RB * 32 * LDT * sizeof(float);
 }
 
 }  // namespace
@@ -326,8 +363,7 @@ extern "C" int t3d_fc_fwd(const t3d_fc_fwd_args* a, t3d_stream_t stream) {
   if (a->gamma && (!a->beta || !a->moving_mean || !a->moving_var || !a->mean || !a->invstd || !a->y)) return T3D_ERR_ARG;
   if (a->gamma && a->is_training && !a->decay) return T3D_ERR_ARG;
   if (a->B <= 0 || a->B > 32 * MAXRB || a->N <= 0 || a->K <= 0) return T3D_ERR_SHAPE;
-  T3D_LAUNCH(k_fc_fwd, dim3((a->N + CB - 1) / CB), dim3(256), fc_lds_bytes(a->B, false),
-                     static_cast<hipStream_t>(stream), *a);
+  T3D_LAUNCH(k_fc_fwd, dim3((a->N + CB - 1) / CB), dim3(256), fc_lds_bytes(a->B), static_cast<hipStream_t>(stream), *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -338,8 +374,7 @@ extern "C" int t3d_fc_bwd(const t3d_fc_bwd_args* a, t3d_stream_t stream) {
   if (a->gamma && (!a->beta || !a->mean || !a->invstd || !a->y)) return T3D_ERR_ARG;
   if (a->act != T3D_ACT_NONE && !a->y) return T3D_ERR_ARG;
   if (a->B <= 0 || a->B > 32 * MAXRB || a->N <= 0) return T3D_ERR_SHAPE;
-  T3D_LAUNCH(k_fc_bwd, dim3((a->N + CB - 1) / CB), dim3(256), fc_lds_bytes(a->B, true),
-                     static_cast<hipStream_t>(stream), *a);
+  T3D_LAUNCH(k_fc_bwd, dim3((a->N + CB - 1) / CB), dim3(256), fc_lds_bytes(a->B), static_cast<hipStream_t>(stream), *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -347,8 +382,7 @@ extern "C" int t3d_fc_bwd(const t3d_fc_bwd_args* a, t3d_stream_t stream) {
 extern "C" int t3d_fc_dinput(const t3d_fc_dinput_args* a, t3d_stream_t stream) {
   if (!a || !a->dy || !a->w || !a->din) return T3D_ERR_ARG;
   if (a->B <= 0 || a->B > 32 * MAXRB || a->N <= 0 || a->K <= 0) return T3D_ERR_SHAPE;
-  T3D_LAUNCH(k_fc_dinput, dim3((a->K + CB - 1) / CB), dim3(256), fc_lds_bytes(a->B, false),
-                     static_cast<hipStream_t>(stream), *a);
+  T3D_LAUNCH(k_fc_dinput, dim3((a->K + CB - 1) / CB), dim3(256), fc_lds_bytes(a->B), static_cast<hipStream_t>(stream), *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

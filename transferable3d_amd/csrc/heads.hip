@@ -91,6 +91,7 @@ __global__ __launch_bounds__(256) void k_seg_head(const t3d_seg_head_args p) {
 }
 
 __global__ __launch_bounds__(256) void k_seg_finalize(const t3d_seg_finalize_args p) {
+  __shared__ double red[3][256];
   const int tid = threadIdx.x;
   const int T = p.B * p.tiles_per_frustum;
   for (int b = tid; b < p.B; b += 256) {
@@ -105,18 +106,32 @@ __global__ __launch_bounds__(256) void k_seg_finalize(const t3d_seg_finalize_arg
     p.mask_xyz_mean[b * 3 + 2] = (float)(sz / den);
     if (p.seg_loss) p.seg_loss[b] = (float)(ce / (double)p.rows_per_frustum);
   }
+  // conv10 bias gradient + accuracy counter: strided partial sums, then a fixed-order tree
+  double a0 = 0, a1 = 0, a2 = 0;
+  for (int t = tid; t < T; t += 256) {
+    const float* q = p.part + (size_t)t * 8;
+    a0 += q[5]; a1 += q[6]; a2 += q[7];
+  }
+  red[0][tid] = a0; red[1][tid] = a1; red[2][tid] = a2;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) {
+      red[0][tid] += red[0][tid + s]; red[1][tid] += red[1][tid + s]; red[2][tid] += red[2][tid + s];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (p.dbias) { p.dbias[0] = (float)red[0][0]; p.dbias[1] = (float)red[1][0]; }
+    if (p.n_correct) p.n_correct[0] = (float)red[2][0];
+  }
+  // conv10 weight gradient: normally summed by t3d_reduce_slabs (dw_part registered as slabs); this
+  // path serves callers that pass dw explicitly.
   if (p.dw != nullptr) {
     for (int e = tid; e < p.K * 2; e += 256) {
       double a = 0;
       for (int t = 0; t < T; ++t) a += p.dw_part[(size_t)t * p.K * 2 + e];
       p.dw[e] = (float)a;
     }
-  }
-  if (tid < 3) {
-    double a = 0;
-    for (int t = 0; t < T; ++t) a += p.part[(size_t)t * 8 + 5 + tid];
-    if (tid < 2) { if (p.dbias) p.dbias[tid] = (float)a; }
-    else if (p.n_correct) p.n_correct[0] = (float)a;
   }
 }
 

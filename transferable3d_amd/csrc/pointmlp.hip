@@ -520,6 +520,35 @@ extern "C" int t3d_pointmlp_dgrad(const t3d_pointmlp_dgrad_args* a, t3d_stream_t
   return T3D_OK;
 }
 
+// Split/tile policy of the weight gradient, shared by the host (slab allocation) and the launcher.
+// Goal: >= ~512 workgroups (2 per CU) without drowning HBM in partial slabs: the split count is capped so
+// that a layer's slabs stay <= 2M floats (or 64 splits), and small K x N layers drop to 64-wide tiles to
+// regain parallelism instead of splitting the rows finer.
+extern "C" int t3d_wgrad_plan(int M, int K, int N, int* rows_per_split, int* tile_k, int* tile_n) {
+  if (M <= 0 || K <= 0 || N <= 0 || N % 64 || M % 128 || !rows_per_split || !tile_k || !tile_n) return T3D_ERR_SHAPE;
+  long cap = (1L << 21) / ((long)K * N);
+  if (cap < 64) cap = 64;
+  if (cap > M / 128) cap = M / 128;
+  if (cap < 1) cap = 1;
+  const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+  int tk = 64, tn = 64;
+  long tiles = (long)((K + 63) / 64) * (N / 64);
+  for (int i = 0; i < 4; ++i) {
+    const int ck = cand[i][0], cn = cand[i][1];
+    if ((ck == 128 && K <= 64) || N % cn) continue;
+    const long t = (long)((K + ck - 1) / ck) * (N / cn);
+    if (t * cap >= 512) { tk = ck; tn = cn; tiles = t; break; }
+  }
+  long want = (512 + tiles - 1) / tiles;
+  if (want > cap) want = cap;
+  int s = 1;
+  while ((long)s * 2 <= want && M % (s * 2) == 0 && (M / (s * 2)) % BK == 0) s *= 2;
+  *rows_per_split = M / s;
+  *tile_k = tk;
+  *tile_n = tn;
+  return T3D_OK;
+}
+
 extern "C" int t3d_pointmlp_wgrad(const t3d_pointmlp_wgrad_args* a, t3d_stream_t stream) {
   if (!a || !a->slabs || !act_ok(a->a, a->K) || !dy_ok(a->dy)) return T3D_ERR_ARG;
   if (a->M <= 0 || a->rows_per_split <= 0 || a->rows_per_split % BK || a->M % a->rows_per_split || a->N % 64 ||
@@ -527,13 +556,18 @@ extern "C" int t3d_pointmlp_wgrad(const t3d_pointmlp_wgrad_args* a, t3d_stream_t
     return T3D_ERR_SHAPE;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int splits = a->M / a->rows_per_split;
-  const bool bigk = a->K > 64, bign = a->N % 128 == 0;
-  const int tiles_k = bigk ? (a->K + 127) / 128 : 1;
-  const int tiles_n = bign ? a->N / 128 : a->N / 64;
+  // tile choice: the plan's tile if the caller used t3d_wgrad_plan's split, else by shape
+  int rps = 0, tk = 0, tn = 0;
+  if (a->M % 128 == 0 && t3d_wgrad_plan(a->M, a->K, a->N, &rps, &tk, &tn) == T3D_OK && rps == a->rows_per_split) {
+  } else {
+    tk = a->K > 64 ? 128 : 64;
+    tn = a->N % 128 == 0 ? 128 : 64;
+  }
+  const int tiles_k = (a->K + tk - 1) / tk, tiles_n = a->N / tn;
   const dim3 grid(tiles_k * tiles_n * splits);
-  if (bigk && bign) T3D_LAUNCH((k_pointmlp_wgrad<128, 128>), grid, dim3(NT), 0, s, *a);
-  else if (bigk) T3D_LAUNCH((k_pointmlp_wgrad<128, 64>), grid, dim3(NT), 0, s, *a);
-  else if (bign) T3D_LAUNCH((k_pointmlp_wgrad<64, 128>), grid, dim3(NT), 0, s, *a);
+  if (tk == 128 && tn == 128) T3D_LAUNCH((k_pointmlp_wgrad<128, 128>), grid, dim3(NT), 0, s, *a);
+  else if (tk == 128) T3D_LAUNCH((k_pointmlp_wgrad<128, 64>), grid, dim3(NT), 0, s, *a);
+  else if (tn == 128) T3D_LAUNCH((k_pointmlp_wgrad<64, 128>), grid, dim3(NT), 0, s, *a);
   else T3D_LAUNCH((k_pointmlp_wgrad<64, 64>), grid, dim3(NT), 0, s, *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;

@@ -214,14 +214,11 @@ class ActSpec:
                           fptr(self.sub), self.sub_ld)
 
 
-def wgrad_rows_per_split(M, K, N, target_wgs=512):
-    tiles = (1 if K <= 64 else (K + 127) // 128) * (N // 128 if N % 128 == 0 else N // 64)
-    splits = max(1, min(M // 128, target_wgs // max(tiles, 1)))
-    # largest power-of-two split count <= splits that divides M into multiples of 32 rows
-    s = 1
-    while s * 2 <= splits and M % (s * 2) == 0 and (M // (s * 2)) % 32 == 0:
-        s *= 2
-    return M // s
+def wgrad_rows_per_split(lib, M, K, N):
+    """Row split of a weight gradient, from the library's own policy (t3d_wgrad_plan)."""
+    rps, tk, tn = C.c_int(0), C.c_int(0), C.c_int(0)
+    abi.check(lib.t3d_wgrad_plan(M, K, N, C.byref(rps), C.byref(tk), C.byref(tn)), 't3d_wgrad_plan')
+    return rps.value
 
 
 class PointLayer:
@@ -326,14 +323,14 @@ class PointLayer:
 
     def wgrad(self, plan):
         g = self.g
-        rps = wgrad_rows_per_split(self.M, self.K, self.N)
+        rps = wgrad_rows_per_split(g.rt.lib, self.M, self.K, self.N)
         n_slabs = self.M // rps
         goff = g.vars.offset(self.w_name) + self.w_row0 * self.N
         soff = g.ws.reserve(goff, self.K * self.N, n_slabs)
         a = abi.PointMlpWgradArgs()
         a.a, a.dy = self.src.struct(), self.dy_struct()
         a.M, a.K, a.N, a.rows_per_frustum, a.rows_per_split = self.M, self.K, self.N, g.rpf, rps
-        g.deferred_slab_ptrs.append((a, soff))
+        g.deferred_slab_ptrs.append((a, 'slabs', soff))
         plan.add('t3d_pointmlp_wgrad', a)
 
     def dgrad(self, plan, out_raw=None, add_in=None):

@@ -45,8 +45,8 @@ class Graph:
     def finalize(self):
         self.ws.finalize()
         base = self.ws.buf.data_ptr()
-        for a, soff in self.deferred_slab_ptrs:
-            a.slabs = C.cast(C.c_void_p(base + 4 * soff), abi.F)
+        for a, field, soff in self.deferred_slab_ptrs:
+            setattr(a, field, C.cast(C.c_void_p(base + 4 * soff), abi.F))
         self.finalized = True
         return self
 
@@ -148,16 +148,16 @@ class InstSegNet:
         h.logits, h.mask, h.part = fptr(self.logits), fptr(self.mask), fptr(self.part)
         if train_seg:
             L9._ensure_bwd_buffers()
-            self.dw_part = rt.zeros(T, 128, 2)
-            h.dz, h.psum_dz, h.psum_dzy, h.dw_part = fptr(L9.dz), fptr(L9.psum_dz), fptr(L9.psum_dzy), fptr(self.dw_part)
+            h.dz, h.psum_dz, h.psum_dzy = fptr(L9.dz), fptr(L9.psum_dz), fptr(L9.psum_dzy)
+            # per-tile conv10 weight-gradient partials live in the slab workspace: summed by t3d_reduce_slabs
+            soff = g.ws.reserve(g.vars.offset(self.scope + '/conv10/weights'), 256, T)
+            g.deferred_slab_ptrs.append((h, 'dw_part', soff))
         h.M, h.K, h.rows_per_frustum, h.B = M, 128, g.rpf, g.B
         plan.add('t3d_seg_head', h)
         f = abi.SegFinalizeArgs()
         f.part, f.B, f.tiles_per_frustum, f.rows_per_frustum, f.K = fptr(self.part), g.B, g.rpf // TILE, g.rpf, 128
         f.mask_xyz_mean, f.seg_loss, f.n_correct = fptr(self.mask_xyz_mean), fptr(self.seg_loss), fptr(self.n_correct)
         if train_seg:
-            f.dw_part = fptr(self.dw_part)
-            f.dw = fptr(g.vars.grad(self.scope + '/conv10/weights'))
             f.dbias = fptr(g.vars.grad(self.scope + '/conv10/biases'))
         plan.add('t3d_seg_finalize', f)
         return self.logits
