@@ -53,9 +53,9 @@ def gemm_label_and_flops(name, a):
     """Mirror of the template dispatch in csrc/pointmlp.hip -> rocprof kernel name + algorithmic FLOPs."""
     flops = 2.0 * a.M * a.K * a.N
     if name == 't3d_pointmlp_fwd':
-        return 'k_pointmlp_fwd<%d>' % (128 if a.N % 128 == 0 else 64), flops
+        return 'k_pointmlp_fwd<%d>' % (128 if a.N % 128 == 0 and (a.M // 128) * (a.N // 128) >= 512 else 64), flops
     if name == 't3d_pointmlp_dgrad':
-        return 'k_pointmlp_dgrad<%d>' % (128 if a.K % 128 == 0 else 64), flops
+        return 'k_pointmlp_dgrad<%d>' % (128 if a.K % 128 == 0 and (a.M // 128) * (a.K // 128) >= 512 else 64), flops
     import ctypes
     rps, tk, tn = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
     LIB.t3d_wgrad_plan(a.M, a.K, a.N, ctypes.byref(rps), ctypes.byref(tk), ctypes.byref(tn))

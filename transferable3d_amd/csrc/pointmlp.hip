@@ -24,6 +24,10 @@ __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0
 // ---------------------------------------------------------------------------------------------
 // loaders: fetch() issues the global loads, xform() does the fused element-wise math afterwards
 // ---------------------------------------------------------------------------------------------
+// All loads are UNCONDITIONAL on clamped addresses and masked afterwards with selects: a per-lane
+// `cond ? load : 0` compiles to an exec-masked branch with its own s_waitcnt, which serialises the global
+// latency of every k-tile (seen in the first version's ISA).  Only wave-uniform conditions branch.
+template <bool HAS_SUB>
 struct ActLoader {
   t3d_act_src s;
   int K;     // valid columns
@@ -34,48 +38,40 @@ struct ActLoader {
     Coef c;
     c.sc = make_float4(1.f, 1.f, 1.f, 1.f);
     c.sh = f4zero();
-    if (s.scale != nullptr && col < K) {
-      if (col + 3 < K) {
-        c.sc = *reinterpret_cast<const float4*>(s.scale + col);
-        c.sh = *reinterpret_cast<const float4*>(s.shift + col);
-      } else {
-        float a[4] = {1.f, 1.f, 1.f, 1.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int e = 0; e < 4; ++e)
-          if (col + e < K) { a[e] = s.scale[col + e]; b[e] = s.shift[col + e]; }
-        c.sc = make_float4(a[0], a[1], a[2], a[3]);
-        c.sh = make_float4(b[0], b[1], b[2], b[3]);
-      }
+    if (s.scale != nullptr) {                 // uniform; scale/shift hold >= roundup4(K) floats (host contract)
+      const int cc = min(col, ((K + 3) & ~3) - 4);
+      c.sc = *reinterpret_cast<const float4*>(s.scale + cc);
+      c.sh = *reinterpret_cast<const float4*>(s.shift + cc);
     }
     return c;
   }
   __device__ __forceinline__ Raw fetch(int row, int col) const {
     Raw r;
-    r.x = (col < K) ? *reinterpret_cast<const float4*>(s.x + (size_t)row * s.ldx + s.coff + col) : f4zero();
+    const int cc = min(col, ((K + 3) & ~3) - 4);
+    r.x = *reinterpret_cast<const float4*>(s.x + (size_t)row * s.ldx + s.coff + cc);
     return r;
   }
+  // straight-line (no branches): identity scale/shift when there is no batch-norm, ReLU floor -inf when off
   __device__ __forceinline__ float4 xform(const Raw& r, const Coef& c, int row, int col) const {
     float v[4] = {r.x.x, r.x.y, r.x.z, r.x.w};
     const float sc[4] = {c.sc.x, c.sc.y, c.sc.z, c.sc.w};
     const float sh[4] = {c.sh.x, c.sh.y, c.sh.z, c.sh.w};
-    const bool has_bn = s.scale != nullptr;
+    const float floor_ = s.relu ? 0.f : -INFINITY;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float t = v[e];
-      if (has_bn) t = fmaf(t, sc[e], sh[e]);
-      if (s.relu) t = fmaxf(t, 0.f);
-      v[e] = (col + e < K) ? t : 0.f;
-    }
-    if (s.sub != nullptr) {
+    for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), floor_);
+    if (HAS_SUB) {                            // raw point inputs only (K <= 4)
       const int b = row / rpf;
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (col + e < K) v[e] -= s.sub[(size_t)b * s.sub_ld + col + e];
+      for (int e = 0; e < 4; ++e) v[e] -= s.sub[(size_t)b * s.sub_ld + min(col + e, K - 1)];
     }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (col + e < K) ? v[e] : 0.f;
     return make_float4(v[0], v[1], v[2], v[3]);
   }
 };
 
-struct DyLoader {
+template <bool POOLED>
+struct DyLoader {      // N % 32 == 0: every tile column is valid
   t3d_dy_src s;
   int N;
   int rpf;
@@ -83,20 +79,15 @@ struct DyLoader {
   struct Coef { float4 c0, c1, c2; };
   __device__ __forceinline__ Coef fetch_coef(int col) const {
     Coef c;
-    if (col < N) {
-      c.c0 = *reinterpret_cast<const float4*>(s.coef + col);
-      c.c1 = *reinterpret_cast<const float4*>(s.coef + N + col);
-      c.c2 = *reinterpret_cast<const float4*>(s.coef + 2 * N + col);
-    } else {
-      c.c0 = c.c1 = c.c2 = f4zero();
-    }
+    c.c0 = *reinterpret_cast<const float4*>(s.coef + col);
+    c.c1 = *reinterpret_cast<const float4*>(s.coef + N + col);
+    c.c2 = *reinterpret_cast<const float4*>(s.coef + 2 * N + col);
     return c;
   }
   __device__ __forceinline__ Raw fetch(int row, int col) const {
     Raw r;
-    if (col >= N) { r.dz = r.y = f4zero(); return r; }
     r.y = *reinterpret_cast<const float4*>(s.y + (size_t)row * N + col);
-    if (s.dz != nullptr) {
+    if (!POOLED) {
       r.dz = *reinterpret_cast<const float4*>(s.dz + (size_t)row * N + col);
     } else {
       const int b = row / rpf, rin = row - b * rpf;
@@ -122,10 +113,13 @@ struct WLoader {
   __device__ __forceinline__ Coef fetch_coef(int) const { return Coef(); }
   __device__ __forceinline__ Raw fetch(int row, int col) const {
     Raw r;
-    r.x = (row < rows && col < cols) ? *reinterpret_cast<const float4*>(w + (size_t)row * ld + col) : f4zero();
+    r.x = *reinterpret_cast<const float4*>(w + (size_t)min(row, rows - 1) * ld + min(col, cols - 4));
     return r;
   }
-  __device__ __forceinline__ float4 xform(const Raw& r, const Coef&, int, int) const { return r.x; }
+  __device__ __forceinline__ float4 xform(const Raw& r, const Coef&, int row, int col) const {
+    const bool ok = row < rows && col < cols;      // masked AFTER the MFMA phase, never right behind the load
+    return make_float4(ok ? r.x.x : 0.f, ok ? r.x.y : 0.f, ok ? r.x.z : 0.f, ok ? r.x.w : 0.f);
+  }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -160,7 +154,10 @@ struct Stager {
   }
   __device__ __forceinline__ void store(const L& l, float* tile, int tid) {
 #pragma unroll
-    for (int q = 0; q < NV; ++q) {
+    for (int q = 0; q < NV; ++q) store_piece(l, tile, tid, q);
+  }
+  __device__ __forceinline__ void store_piece(const L& l, float* tile, int tid, int q) {
+    {
       int li, ri; coords(tid, q, li, ri);
       if (TYPE_R) {
         const float4 v = l.xform(raw[q], coef, lane0 + li, red0 + ri);
@@ -173,14 +170,12 @@ struct Stager {
   }
 };
 
-// one BK-deep step of the wave's TM x TN grid of 32x32 MFMA tiles
+// one BK-deep step of the wave's TM x TN grid of 32x32 MFMA tiles; the fragments of group g+1 are read from
+// LDS before the 16 MFMAs of group g are issued, so ds_read latency hides under the matrix pipe.
 template <int TM, int TN, bool AR, int DIMA, bool BR, int DIMB>
-__device__ __forceinline__ void mma_step(const float* As, const float* Bs, int a0, int b0, f32x16 (&acc)[TM][TN],
-                                         int lane) {
-  const int l31 = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int g = 0; g < BK / 8; ++g) {
-    float a[TM][4], b[TN][4];
+struct Frags {
+  float a[TM][4], b[TN][4];
+  __device__ __forceinline__ void load(const float* As, const float* Bs, int a0, int b0, int g, int l31, int h) {
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       if (AR) {
@@ -201,13 +196,31 @@ __device__ __forceinline__ void mma_step(const float* As, const float* Bs, int a
         for (int i = 0; i < 4; ++i) b[tn][i] = Bs[(8 * g + 4 * h + i) * DIMB + b0 + tn * 32 + l31];
       }
     }
+  }
+};
+
+// MFMAs of k-groups [G0, G1) of the current tile.  Fragments of group g+1 are requested before the MFMAs of
+// group g.  After every cluster of TM*TN MFMAs (one k step) `filler(step)` is invoked: the main loop uses it to
+// drop one staging piece (transform + ds_write of the NEXT tile) into the 64-cycle shadows of the MFMAs, in
+// program order, which is what an in-order wave needs to keep the matrix pipe busy.
+template <int TM, int TN, bool AR, int DIMA, bool BR, int DIMB, int G0, int G1, class F>
+__device__ __forceinline__ void mma_groups(const float* As, const float* Bs, int a0, int b0, f32x16 (&acc)[TM][TN],
+                                           int lane, F&& filler) {
+  const int l31 = lane & 31, h = lane >> 5;
+  Frags<TM, TN, AR, DIMA, BR, DIMB> f[2];
+  f[G0 & 1].load(As, Bs, a0, b0, G0, l31, h);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+  for (int g = G0; g < G1; ++g) {
+    if (g + 1 < G1) f[(g + 1) & 1].load(As, Bs, a0, b0, g + 1, l31, h);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][i], b[tn][i], acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[g & 1].a[tm][i], f[g & 1].b[tn][i], acc[tm][tn], 0, 0, 0);
+      filler((g - G0) * 4 + i);
+    }
   }
 }
 
@@ -221,38 +234,67 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[TM][TN]) {
       for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 }
 
-// register-prefetched main loop over the reduction range [red_begin, red_end)
+// Software-pipelined main loop over the reduction range [red_begin, red_end), two LDS stages, ONE barrier per
+// k-tile.  Iteration t: MFMAs of tile t read stage t&1; meanwhile tile t+1 (whose global loads were issued one
+// iteration earlier) is transformed and written into the other stage between the MFMAs of the second half,
+// and the loads of tile t+2 are issued.  The last tile is peeled so that the steady-state body is branch-free.
+//   RAW: stage (t+1)&1 is written during iteration t and read after the barrier that ends it.
+//   WAR: stage t&1 is overwritten (tile t+2) during iteration t+1, after the same barrier.
 template <int TM, int TN, class SA, class SB, class LA, class LB, bool AR, int DIMA, bool BR, int DIMB>
-__device__ __forceinline__ void gemm_mainloop(SA& sa, SB& sb, const LA& la, const LB& lb, float* As, float* Bs,
-                                              int red_begin, int red_end, int a0, int b0, f32x16 (&acc)[TM][TN],
-                                              int tid) {
+__device__ __forceinline__ void gemm_mainloop(SA& sa, SB& sb, const LA& la, const LB& lb, float* smem, int red_begin,
+                                              int red_end, int a0, int b0, f32x16 (&acc)[TM][TN], int tid) {
+  constexpr int STAGE = SA::LDS_FLOATS + SB::LDS_FLOATS;
+  static_assert(SA::NV + SB::NV <= 8, "staging pieces must fit the 8 MFMA clusters of the second half");
   const int lane = tid & 63;
+  auto nofill = [](int) {};
   sa.fetch(la, red_begin, tid);
   sb.fetch(lb, red_begin, tid);
-  sa.store(la, As, tid);
-  sb.store(lb, Bs, tid);
+  sa.store(la, smem, tid);
+  sb.store(lb, smem + SA::LDS_FLOATS, tid);
+  if (red_begin + BK < red_end) { sa.fetch(la, red_begin + BK, tid); sb.fetch(lb, red_begin + BK, tid); }
   __syncthreads();
-  for (int red = red_begin; red < red_end; red += BK) {
-    const bool more = red + BK < red_end;
-    if (more) { sa.fetch(la, red + BK, tid); sb.fetch(lb, red + BK, tid); }
-    mma_step<TM, TN, AR, DIMA, BR, DIMB>(As, Bs, a0, b0, acc, lane);
+  int cur = 0;
+  int red = red_begin;
+  for (; red + BK < red_end; red += BK) {
+    const float* As = smem + cur * STAGE;
+    const float* Bs = As + SA::LDS_FLOATS;
+    float* An = smem + (cur ^ 1) * STAGE;
+    float* Bn = An + SA::LDS_FLOATS;
+    mma_groups<TM, TN, AR, DIMA, BR, DIMB, 0, 2>(As, Bs, a0, b0, acc, lane, nofill);
+    // nothing of the staging work may be hoisted into the first half: the next tile's global loads were
+    // issued only one barrier ago and get the first half's MFMAs (>= 2048 cycles) to land
+    __builtin_amdgcn_sched_barrier(0);
+    mma_groups<TM, TN, AR, DIMA, BR, DIMB, 2, 4>(As, Bs, a0, b0, acc, lane, [&](int step) {
+      if (step < SA::NV) sa.store_piece(la, An, tid, step);
+      else if (step - SA::NV < SB::NV) sb.store_piece(lb, Bn, tid, step - SA::NV);
+    });
+    // keep the new loads BEHIND every wait on the previous batch (vmcnt counts in issue order)
+    __builtin_amdgcn_sched_barrier(0);
+    // clamp instead of branching: the (unused) tile past the end re-reads the last one
+    const int nxt = min(red + 2 * BK, red_end - BK);
+    sa.fetch(la, nxt, tid);
+    sb.fetch(lb, nxt, tid);
     __syncthreads();
-    if (more) { sa.store(la, As, tid); sb.store(lb, Bs, tid); }
-    __syncthreads();
+    cur ^= 1;
   }
+  {
+    const float* As = smem + cur * STAGE;
+    const float* Bs = As + SA::LDS_FLOATS;
+    mma_groups<TM, TN, AR, DIMA, BR, DIMB, 0, 4>(As, Bs, a0, b0, acc, lane, nofill);
+  }
+  __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
-template <int BN>
+template <int BN, bool HAS_SUB>
 __global__ __launch_bounds__(NT, 2) void k_pointmlp_fwd(const t3d_pointmlp_fwd_args p) {
   constexpr int BM = 128, TM = 2, TN = BN / 64;
-  using SA = Stager<BM, true, ActLoader>;
+  using LA = ActLoader<HAS_SUB>;
+  using SA = Stager<BM, true, LA>;
   using SB = Stager<BN, false, WLoader>;
-  __shared__ __attribute__((aligned(16))) float smem[SA::LDS_FLOATS + SB::LDS_FLOATS];
-  float* As = smem;
-  float* Bs = smem + SA::LDS_FLOATS;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
@@ -261,7 +303,7 @@ __global__ __launch_bounds__(NT, 2) void k_pointmlp_fwd(const t3d_pointmlp_fwd_a
   const int tile_m = lin / tiles_n, tile_n = lin % tiles_n;
   const int row0 = tile_m * BM, col0 = tile_n * BN;
 
-  ActLoader la{p.a, p.K, p.rows_per_frustum};
+  LA la{p.a, p.K, p.rows_per_frustum};
   WLoader lb{p.w, p.N, p.K, p.N};
   SA sa; SB sb;
   sa.init(la, row0, tid);
@@ -270,7 +312,7 @@ __global__ __launch_bounds__(NT, 2) void k_pointmlp_fwd(const t3d_pointmlp_fwd_a
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
   const int kred = (p.K + BK - 1) / BK * BK;
-  gemm_mainloop<TM, TN, SA, SB, ActLoader, WLoader, true, BM, false, BN>(sa, sb, la, lb, As, Bs, 0, kred, wm * 64,
+  gemm_mainloop<TM, TN, SA, SB, LA, WLoader, true, BM, false, BN>(sa, sb, la, lb, smem, 0, kred, wm * 64,
                                                                         wn * (BN / 2), acc, tid);
 
   // epilogue: + bias (+ per-frustum row bias), store y, column statistics, optional pool partials
@@ -351,14 +393,13 @@ __global__ __launch_bounds__(NT, 2) void k_pointmlp_fwd(const t3d_pointmlp_fwd_a
 // ---------------------------------------------------------------------------------------------
 // data gradient
 // ---------------------------------------------------------------------------------------------
-template <int BN>   // BN = tile width over the layer's INPUT channels K
+template <int BN, bool POOLED>   // BN = tile width over the layer's INPUT channels K
 __global__ __launch_bounds__(NT, 2) void k_pointmlp_dgrad(const t3d_pointmlp_dgrad_args p) {
   constexpr int BM = 128, TM = 2, TN = BN / 64;
-  using SA = Stager<BM, true, DyLoader>;
+  using LA = DyLoader<POOLED>;
+  using SA = Stager<BM, true, LA>;
   using SB = Stager<BN, true, WLoader>;
-  __shared__ __attribute__((aligned(16))) float smem[SA::LDS_FLOATS + SB::LDS_FLOATS];
-  float* As = smem;
-  float* Bs = smem + SA::LDS_FLOATS;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
@@ -367,7 +408,7 @@ __global__ __launch_bounds__(NT, 2) void k_pointmlp_dgrad(const t3d_pointmlp_dgr
   const int tile_m = lin / tiles_n, tile_n = lin % tiles_n;
   const int row0 = tile_m * BM, col0 = tile_n * BN;
 
-  DyLoader la{p.dy, p.N, p.rows_per_frustum};
+  LA la{p.dy, p.N, p.rows_per_frustum};
   WLoader lb{p.w, p.N, p.K, p.N};
   SA sa; SB sb;
   sa.init(la, row0, tid);
@@ -376,7 +417,7 @@ __global__ __launch_bounds__(NT, 2) void k_pointmlp_dgrad(const t3d_pointmlp_dgr
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
   const int nred = (p.N + BK - 1) / BK * BK;
-  gemm_mainloop<TM, TN, SA, SB, DyLoader, WLoader, true, BM, true, BN>(sa, sb, la, lb, As, Bs, 0, nred, wm * 64,
+  gemm_mainloop<TM, TN, SA, SB, LA, WLoader, true, BM, true, BN>(sa, sb, la, lb, smem, 0, nred, wm * 64,
                                                                       wn * (BN / 2), acc, tid);
 
   const int l31 = lane & 31, h = lane >> 5;
@@ -432,14 +473,14 @@ __global__ __launch_bounds__(NT, 2) void k_pointmlp_dgrad(const t3d_pointmlp_dgr
 // ---------------------------------------------------------------------------------------------
 // weight gradient (split over rows)
 // ---------------------------------------------------------------------------------------------
-template <int BMK, int BN>
+template <int BMK, int BN, bool HAS_SUB, bool POOLED>
 __global__ __launch_bounds__(NT, 2) void k_pointmlp_wgrad(const t3d_pointmlp_wgrad_args p) {
   constexpr int TM = BMK / 64, TN = BN / 64;
-  using SA = Stager<BMK, false, ActLoader>;
-  using SB = Stager<BN, false, DyLoader>;
-  __shared__ __attribute__((aligned(16))) float smem[SA::LDS_FLOATS + SB::LDS_FLOATS];
-  float* As = smem;
-  float* Bs = smem + SA::LDS_FLOATS;
+  using LA = ActLoader<HAS_SUB>;
+  using LB = DyLoader<POOLED>;
+  using SA = Stager<BMK, false, LA>;
+  using SB = Stager<BN, false, LB>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
@@ -449,8 +490,8 @@ __global__ __launch_bounds__(NT, 2) void k_pointmlp_wgrad(const t3d_pointmlp_wgr
   const int t = lin % (tiles_k * tiles_n);
   const int k0 = (t / tiles_n) * BMK, n0 = (t % tiles_n) * BN;
 
-  ActLoader la{p.a, p.K, p.rows_per_frustum};
-  DyLoader lb{p.dy, p.N, p.rows_per_frustum};
+  LA la{p.a, p.K, p.rows_per_frustum};
+  LB lb{p.dy, p.N, p.rows_per_frustum};
   SA sa; SB sb;
   sa.init(la, k0, tid);
   sb.init(lb, n0, tid);
@@ -458,7 +499,7 @@ __global__ __launch_bounds__(NT, 2) void k_pointmlp_wgrad(const t3d_pointmlp_wgr
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
   const int m_begin = split * p.rows_per_split;
-  gemm_mainloop<TM, TN, SA, SB, ActLoader, DyLoader, false, BMK, false, BN>(sa, sb, la, lb, As, Bs, m_begin,
+  gemm_mainloop<TM, TN, SA, SB, LA, LB, false, BMK, false, BN>(sa, sb, la, lb, smem, m_begin,
                                                                            m_begin + p.rows_per_split, wm * (BMK / 2),
                                                                            wn * (BN / 2), acc, tid);
   const int l31 = lane & 31, h = lane >> 5;
@@ -476,6 +517,18 @@ __global__ __launch_bounds__(NT, 2) void k_pointmlp_wgrad(const t3d_pointmlp_wgr
     }
   }
 }
+
+// dynamic-LDS launch: two pipeline stages exceed the 64 KB static limit for the 128-wide tiles
+template <class Args>
+void launch_lds(void (*kernel)(const Args), dim3 grid, size_t lds_bytes, hipStream_t s, const Args& a) {
+  if (lds_bytes > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds_bytes);
+  T3D_LAUNCH(kernel, grid, dim3(NT), lds_bytes, s, a);
+}
+constexpr size_t lds_fwd(int bn) { return 2 * (size_t)(128 * LDR + BK * bn) * sizeof(float); }
+constexpr size_t lds_dgrad(int bn) { return 2 * (size_t)(128 * LDR + bn * LDR) * sizeof(float); }
+constexpr size_t lds_wgrad(int bmk, int bn) { return 2 * (size_t)BK * (bmk + bn) * sizeof(float); }
 
 bool act_ok(const t3d_act_src& a, int K) {
   return a.x != nullptr && (a.ldx % 4) == 0 && (a.coff % 4) == 0 && a.coff + (K + 3) / 4 * 4 <= a.ldx &&
@@ -495,10 +548,17 @@ extern "C" int t3d_pointmlp_fwd(const t3d_pointmlp_fwd_args* a, t3d_stream_t str
     return T3D_ERR_SHAPE;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int tiles_m = a->M / 128;
-  if (a->N % 128 == 0)
-    T3D_LAUNCH(k_pointmlp_fwd<128>, dim3(tiles_m * (a->N / 128)), dim3(NT), 0, s, *a);
-  else
-    T3D_LAUNCH(k_pointmlp_fwd<64>, dim3(tiles_m * (a->N / 64)), dim3(NT), 0, s, *a);
+  // 128-wide column tiles only when they still give >= 2 workgroups per CU
+  const bool sub = a->a.sub != nullptr;
+  if (a->N % 128 == 0 && (long)tiles_m * (a->N / 128) >= 512) {
+    const dim3 grid(tiles_m * (a->N / 128));
+    if (sub) launch_lds(k_pointmlp_fwd<128, true>, grid, lds_fwd(128), s, *a);
+    else launch_lds(k_pointmlp_fwd<128, false>, grid, lds_fwd(128), s, *a);
+  } else {
+    const dim3 grid(tiles_m * (a->N / 64));
+    if (sub) launch_lds(k_pointmlp_fwd<64, true>, grid, lds_fwd(64), s, *a);
+    else launch_lds(k_pointmlp_fwd<64, false>, grid, lds_fwd(64), s, *a);
+  }
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -512,10 +572,16 @@ extern "C" int t3d_pointmlp_dgrad(const t3d_pointmlp_dgrad_args* a, t3d_stream_t
     return T3D_ERR_SHAPE;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int tiles_m = a->M / 128;
-  if (a->K % 128 == 0)
-    T3D_LAUNCH(k_pointmlp_dgrad<128>, dim3(tiles_m * (a->K / 128)), dim3(NT), 0, s, *a);
-  else
-    T3D_LAUNCH(k_pointmlp_dgrad<64>, dim3(tiles_m * (a->K / 64)), dim3(NT), 0, s, *a);
+  const bool pooled = a->dy.dz == nullptr;
+  if (a->K % 128 == 0 && (long)tiles_m * (a->K / 128) >= 512) {
+    const dim3 grid(tiles_m * (a->K / 128));
+    if (pooled) launch_lds(k_pointmlp_dgrad<128, true>, grid, lds_dgrad(128), s, *a);
+    else launch_lds(k_pointmlp_dgrad<128, false>, grid, lds_dgrad(128), s, *a);
+  } else {
+    const dim3 grid(tiles_m * (a->K / 64));
+    if (pooled) launch_lds(k_pointmlp_dgrad<64, true>, grid, lds_dgrad(64), s, *a);
+    else launch_lds(k_pointmlp_dgrad<64, false>, grid, lds_dgrad(64), s, *a);
+  }
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -565,10 +631,19 @@ extern "C" int t3d_pointmlp_wgrad(const t3d_pointmlp_wgrad_args* a, t3d_stream_t
   }
   const int tiles_k = (a->K + tk - 1) / tk, tiles_n = a->N / tn;
   const dim3 grid(tiles_k * tiles_n * splits);
-  if (tk == 128 && tn == 128) T3D_LAUNCH((k_pointmlp_wgrad<128, 128>), grid, dim3(NT), 0, s, *a);
-  else if (tk == 128) T3D_LAUNCH((k_pointmlp_wgrad<128, 64>), grid, dim3(NT), 0, s, *a);
-  else if (tn == 128) T3D_LAUNCH((k_pointmlp_wgrad<64, 128>), grid, dim3(NT), 0, s, *a);
-  else T3D_LAUNCH((k_pointmlp_wgrad<64, 64>), grid, dim3(NT), 0, s, *a);
+  const bool sub = a->a.sub != nullptr, pooled = a->dy.dz == nullptr;
+#define T3D_WG(TK, TN_)                                                                                   \
+  do {                                                                                                    \
+    if (sub && pooled) launch_lds(k_pointmlp_wgrad<TK, TN_, true, true>, grid, lds_wgrad(TK, TN_), s, *a);        \
+    else if (sub) launch_lds(k_pointmlp_wgrad<TK, TN_, true, false>, grid, lds_wgrad(TK, TN_), s, *a);             \
+    else if (pooled) launch_lds(k_pointmlp_wgrad<TK, TN_, false, true>, grid, lds_wgrad(TK, TN_), s, *a);          \
+    else launch_lds(k_pointmlp_wgrad<TK, TN_, false, false>, grid, lds_wgrad(TK, TN_), s, *a);                     \
+  } while (0)
+  if (tk == 128 && tn == 128) T3D_WG(128, 128);
+  else if (tk == 128) T3D_WG(128, 64);
+  else if (tn == 128) T3D_WG(64, 128);
+  else T3D_WG(64, 64);
+#undef T3D_WG
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
