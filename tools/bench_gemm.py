@@ -22,15 +22,18 @@ SHAPES = [('fwd', 128, 1024, True), ('fwd', 512, 256, False), ('fwd', 256, 512, 
 
 
 def main():
-    lib = abi.load()
+    lib = abi.load(os.environ.get('T3D_LIB'))
     M, rpf, R = 32768, 1024, 20
     B, T = M // rpf, M // 128
     dev = 'cuda'
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     only = sys.argv[1] if len(sys.argv) > 1 else None
+    big = os.environ.get('T3D_BIG')
     tot = {}
     for kind, K, N, pooled in SHAPES:
         if only and kind != only:
+            continue
+        if big and 2.0 * K * N < 2 * 128 * 256:
             continue
         ldx = 4 if K <= 4 else K
         x = torch.randn(M, ldx, device=dev)

@@ -264,17 +264,28 @@ __device__ __forceinline__ void gemm_mainloop(SA& sa, SB& sb, const LA& la, cons
     // nothing of the staging work may be hoisted into the first half: the next tile's global loads were
     // issued only one barrier ago and get the first half's MFMAs (>= 2048 cycles) to land
     __builtin_amdgcn_sched_barrier(0);
+#ifndef T3D_ABL_NOSTAGE
     mma_groups<TM, TN, AR, DIMA, BR, DIMB, 2, 4>(As, Bs, a0, b0, acc, lane, [&](int step) {
       if (step < SA::NV) sa.store_piece(la, An, tid, step);
       else if (step - SA::NV < SB::NV) sb.store_piece(lb, Bn, tid, step - SA::NV);
     });
+#else
+    (void)An; (void)Bn;
+    mma_groups<TM, TN, AR, DIMA, BR, DIMB, 2, 4>(As, Bs, a0, b0, acc, lane, nofill);
+#endif
     // keep the new loads BEHIND every wait on the previous batch (vmcnt counts in issue order)
     __builtin_amdgcn_sched_barrier(0);
     // clamp instead of branching: the (unused) tile past the end re-reads the last one
     const int nxt = min(red + 2 * BK, red_end - BK);
+#ifndef T3D_ABL_NOSTAGE
     sa.fetch(la, nxt, tid);
     sb.fetch(lb, nxt, tid);
+#else
+    (void)nxt;
+#endif
+#ifndef T3D_ABL_NOBAR
     __syncthreads();
+#endif
     cur ^= 1;
   }
   {
@@ -315,6 +326,15 @@ __global__ __launch_bounds__(NT, 2) void k_pointmlp_fwd(const t3d_pointmlp_fwd_a
   gemm_mainloop<TM, TN, SA, SB, LA, WLoader, true, BM, false, BN>(sa, sb, la, lb, smem, 0, kred, wm * 64,
                                                                         wn * (BN / 2), acc, tid);
 
+#ifdef T3D_ABL_NOEPI
+  {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) asm volatile("" ::"v"(acc[tm][tn]));
+    return;
+  }
+#endif
   // epilogue: + bias (+ per-frustum row bias), store y, column statistics, optional pool partials
   const int l31 = lane & 31, h = lane >> 5;
   const int b = row0 / p.rows_per_frustum;
