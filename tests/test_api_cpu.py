@@ -1,0 +1,100 @@
+"""CPU: the reference-named builder API (placeholder_inputs / get_semi_model / get_semi_loss / AdamOptimizer /
+Session.run with a feed_dict) drives the same plan as the oracle's SEMI_MODEL A step, including the TF-form Adam
+update and the device-side schedules."""
+import numpy as np
+import torch
+
+from fake_t3d import FakeLib
+from oracle import ref_torch as R
+from transferable3d_amd import api, semisup_v1_sunrgbd as MODEL
+from transferable3d_amd.config import make_parser
+from transferable3d_amd.engine import Runtime
+from transferable3d_amd.synthetic import make_batch
+
+
+def _flags(extra=()):
+    return make_parser().parse_special_args(['--SEMI_MODEL', 'A', '--WEAK_WEIGHT_REPROJECTION', '0',
+                                             '--WEAK_WEIGHT_SURFACE', '0'] + list(extra))
+
+
+def test_reference_call_sequence_runs_a_training_step():
+    B, N, C = 4, 128, 4
+    FLAGS = _flags()
+    batch = make_batch(B, N, C, seed=8, dropout_scopes={'inst_seg/dp1': ((B, N, 128), 0.5)})
+    with api.Graph(rt=Runtime(device='cpu', lib=FakeLib()), seed=3).as_default() as g:
+        pls = MODEL.placeholder_inputs(B, N, C)
+        pc_pl, bg_pc_pl, img_pl, one_hot_vec_pl, y_seg_pl, y_centers_pl, y_orient_cls_pl, y_orient_reg_pl, y_dims_cls_pl, \
+            y_dims_reg_pl, R0_rect_pl, P_pl, Rtilt_pl, K_pl, rot_frust_pl, box2D_pl, img_dim_pl, is_data_2D_pl = pls
+        pred, end_points = MODEL.get_semi_model(pc_pl, bg_pc_pl, img_pl, one_hot_vec_pl, True, use_one_hot=False,
+                                                norm_box2D=None, bn_decay=None, c=FLAGS)
+        labels = (y_seg_pl, y_centers_pl, y_orient_cls_pl, y_orient_reg_pl, y_dims_cls_pl, y_dims_reg_pl, R0_rect_pl, P_pl,
+                  Rtilt_pl, K_pl, rot_frust_pl, box2D_pl, img_dim_pl, is_data_2D_pl)
+        semi_loss = MODEL.get_semi_loss(pred, labels, end_points, c=FLAGS)
+        train_op = api.AdamOptimizer(1e-3).minimize(semi_loss)
+        sess = api.Session()
+        P0 = {k: torch.tensor(v, dtype=torch.float64) for k, v in g.vars.state_dict().items()}
+        feed = {pc_pl: batch['pc'], one_hot_vec_pl: batch['one_hot_vec'], y_seg_pl: batch['y_seg'],
+                y_centers_pl: batch['y_center'], y_orient_cls_pl: batch['y_orient_cls'], y_orient_reg_pl: batch['y_orient_reg'],
+                y_dims_cls_pl: batch['y_dims_cls'], y_dims_reg_pl: batch['y_dims_reg'], is_data_2D_pl: batch['is_data_2D'],
+                box2D_pl: np.zeros((B, 4)), 'inst_seg/dp1': batch['dropout_masks']['inst_seg/dp1']}
+        logits_val, loss_val, center_val, _ = sess.run([pred[0], semi_loss, end_points['center'], train_op], feed_dict=feed)
+        P1 = g.vars.state_dict()
+        hyper = g.engine.hyper.numpy().copy()
+
+    # oracle: same weights, same batch, one TF-form Adam step at lr(step 0), bn_decay(step 0)
+    c = R.default_config()
+    loss, ep, grads, ema = R.model_a_forward_backward(P0, batch, c, bn_decay_val=R.bn_decay(0, B))
+    assert logits_val.shape == (B, N, 2)
+    assert np.abs(logits_val - ep['logits'].detach().numpy()).max() < 1e-4
+    assert abs(float(loss_val) - float(loss)) < 1e-4 * float(loss)
+    assert np.abs(center_val - ep['center'].detach().numpy()).max() < 1e-4
+    assert hyper[0] == 1.0 and abs(hyper[1] - 1e-3) < 1e-9 and abs(hyper[2] - 0.5) < 1e-7
+    names = R.trainable_names(P0)
+    Pn = {k: P0[k].clone() for k in P0}
+    m = {k: torch.zeros_like(P0[k]) for k in names}
+    v = {k: torch.zeros_like(P0[k]) for k in names}
+    R.adam_tf_step(Pn, grads, m, v, 1, R.learning_rate(0, B))
+    checked = 0
+    for k in names:
+        if k.endswith('/biases') and (k[:-7] + '/bn/gamma') in P0:
+            continue      # bias feeding a batch-norm: analytically zero gradient, Adam amplifies rounding noise
+        if k.endswith('/bn/beta') and float(grads[k].abs().max()) < 1e-12:
+            continue      # same for the beta of a layer that only feeds a batch-norm through the max-pool
+        ref, got = Pn[k].numpy(), P1[k].astype(np.float64).reshape(Pn[k].shape)
+        moved = np.abs(ref - P0[k].numpy())
+        # the first Adam step is ~lr*sign(g): only entries whose gradient is well above fp32 noise are comparable
+        gk = np.abs(grads[k].numpy())
+        sel = gk > 1e-2 * gk.max()
+        if sel.any():
+            assert np.abs(got - ref)[sel].max() < 2e-5, k
+            checked += 1
+    assert checked > 40
+    for k, val in ema.items():
+        assert np.abs(P1[k].reshape(val.shape) - val.detach().numpy()).max() < 1e-4, k
+
+
+def test_forward_only_fetch_compiles_the_inference_plan():
+    B, N, C = 2, 128, 4
+    FLAGS = _flags()
+    batch = make_batch(B, N, C, seed=9)
+    with api.Graph(rt=Runtime(device='cpu', lib=FakeLib()), seed=4).as_default() as g:
+        pls = MODEL.placeholder_inputs(B, N, C)
+        pred, end_points = MODEL.get_semi_model(pls[0], pls[1], pls[2], pls[3], False, use_one_hot=False, c=FLAGS)
+        sess = api.Session()
+        P0 = {k: torch.tensor(v, dtype=torch.float64) for k, v in g.vars.state_dict().items()}
+        logits, s1 = sess.run([pred[0], end_points['stage1_center']], feed_dict={pls[0]: batch['pc'], pls[3]: batch['one_hot_vec']})
+    ctx = R.Ctx(P0, is_training=False)
+    _, ep = R.get_semi_model_backbone(ctx, torch.as_tensor(batch['pc'], dtype=torch.float64),
+                                      torch.as_tensor(batch['one_hot_vec'], dtype=torch.float64))
+    assert np.abs(logits - ep['logits'].numpy()).max() < 1e-4          # eval-mode batch-norm (moving statistics)
+    assert np.abs(s1 - ep['stage1_center'].numpy()).max() < 1e-4
+
+
+def test_unknown_semi_model_raises_like_the_reference():
+    import pytest
+    FLAGS = _flags()
+    FLAGS.SEMI_MODEL = 'Z'
+    with api.Graph(rt=Runtime(device='cpu', lib=FakeLib())).as_default():
+        pls = MODEL.placeholder_inputs(2, 128, 4)
+        with pytest.raises(Exception, match='Not implemented SEMI_MODEL'):
+            MODEL.get_semi_model(pls[0], pls[1], pls[2], pls[3], True, False, c=FLAGS)

@@ -1,0 +1,105 @@
+"""CPU: the train_semisup command line runs end to end on synthetic frustums (spec library), the loss goes down,
+and the data-parallel path (world_size 2, gloo) produces the mean of the two replicas' gradients and keeps the
+replicas' weights identical."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+from fake_t3d import FakeLib
+from transferable3d_amd.engine import Runtime
+from transferable3d_amd.train_semisup import build_flags, train
+
+ARGS = ['--SEMI_MODEL', 'A', '--WEAK_WEIGHT_REPROJECTION', '0', '--WEAK_WEIGHT_SURFACE', '0', '--num_point', '128',
+        '--batch_size', '4', '--num_channels', '4', '--max_epoch', '2', '--steps_per_epoch', '6', '--synthetic']
+
+
+def test_cli_trains_and_loss_decreases(tmp_path):
+    FLAGS = build_flags(ARGS + ['--log_dir', str(tmp_path)])
+    logs = []
+    _, last = train(FLAGS, rt=Runtime(device='cpu', lib=FakeLib()), log=logs.append)
+    epochs = [l for l in logs if l.startswith('**** EPOCH')]
+    first = float(epochs[0].split('mean loss: ')[1].split()[0])
+    assert len(epochs) == 2 and last < first, (first, last)
+    assert os.path.exists(os.path.join(str(tmp_path), 'model_epoch_0.npz'))
+    sd = np.load(os.path.join(str(tmp_path), 'model_epoch_0.npz'))
+    assert 'inst_seg/conv1/weights' in sd.files and sd['inst_seg/conv1/weights'].shape == (1, 4, 1, 64)
+    assert 'box_est/fc3/biases' in sd.files and 'tnet/conv-reg1-stage1/bn/moving_variance' in sd.files
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dp_worker(rank, world, port, tmp, q):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from fake_t3d import FakeLib as FL
+    FLAGS = build_flags(ARGS[:-5] + ['--max_epoch', '1', '--steps_per_epoch', '1', '--synthetic', '--log_dir',
+                                     os.path.join(tmp, 'r%d' % rank)])
+    sd, _ = train(FLAGS, rt=Runtime(device='cpu', lib=FL()), log=lambda *_: None)
+    q.put((rank, {k: v for k, v in sd.items() if k.endswith('weights') or k.endswith('gamma')}))
+
+
+def test_data_parallel_world_size_2_gloo(tmp_path):
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # replicas stay bit-identical (same init, same all-reduced gradients, same Adam)
+    for k in res[0]:
+        assert np.array_equal(res[0][k], res[1][k]), k
+
+    # reference: average of the two replicas' single-process gradients at step 0
+    from model_check import run_model_a
+    from oracle import ref_torch as R
+    from transferable3d_amd.nets import Graph, SemiModelA
+    from transferable3d_amd.synthetic import make_batch
+    rt = Runtime(device='cpu', lib=FakeLib())
+    grads = []
+    for rank in range(world):
+        g = Graph(4, 128, 4, rt=rt, seed=0)
+        m = SemiModelA(g, R.default_config())
+        m.emit_forward(g.fwd, True, True)
+        m.emit_backward(g.bwd)
+        g.finalize()
+        g.emit_dropout_masks(g.pre, seed=1234 + rank)
+        g.hyper[0] = 1.0                     # masks are drawn after the schedule kernel bumped the step to 1
+        g.pre.run()
+        m.inputs.load(make_batch(4, 128, 4, seed=0 * 1000003 + 0 * world + rank))
+        g.fwd.run()
+        g.bwd.run()
+        grads.append(g.vars.grads[:g.vars.used].clone())
+        w0 = g.vars.params[:g.vars.used].clone()
+        off = g.vars.offset('box_est/fc3/weights')
+    mean_grad = ((grads[0] + grads[1]) / world).double().numpy()
+    # one TF-form Adam step from the common initial weights with the MEAN gradient (what the all-reduce must produce)
+    b1, b2, eps, lr = 0.9, 0.999, 1e-8, 1e-3
+    lr_t = lr * np.sqrt(1 - b2) / (1 - b1)
+    w1 = w0.double().numpy() - lr_t * ((1 - b1) * mean_grad) / (np.sqrt((1 - b2) * mean_grad ** 2) + eps)
+    checked = 0
+    for k, got in res[0].items():
+        o = g.vars.offset(k)
+        n = got.size
+        gk = np.abs(mean_grad[o:o + n])
+        sel = gk > 1e-2 * gk.max()           # Adam's first step is ~lr*sign(g): compare where g is above fp32 noise
+        if sel.sum() == 0:
+            continue
+        assert np.abs(got.reshape(-1).astype(np.float64) - w1[o:o + n])[sel].max() < 2e-5, k
+        checked += int(sel.sum())
+    assert checked > 10000

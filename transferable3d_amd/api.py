@@ -1,0 +1,283 @@
+"""Graph / placeholder / session layer that the reference-named builder modules sit on.
+
+The reference drives TensorFlow 1 like this (train_semisup.py:204-277, 405-411):
+
+    with tf.Graph().as_default():
+        pls = MODEL.placeholder_inputs(B, N, C)
+        pred, end_points = MODEL.get_semi_model(...)
+        loss = MODEL.get_semi_loss(pred, labels, end_points, c=FLAGS)
+        train_op = tf.train.AdamOptimizer(lr).minimize(loss, global_step=batch)
+        sess = tf.Session(); sess.run(init)
+        sess.run([loss, train_op], feed_dict={pc_pl: batch, ...})
+
+The same sequence works here with `api.Graph`, `api.AdamOptimizer`, `api.Session`.  Builders only RECORD which
+sub-networks exist and allocate their HBM buffers; the fused launch schedule is emitted on the first
+`Session.run`, pruned by what is fetched (a fetch list without the train op compiles the forward-only plan,
+exactly like TF prunes its graph), and on the GPU the schedule is captured into a hipGraph and replayed.
+
+Deviation (documented in DESIGN.md): `is_training` must be a Python bool at build time -- build a second
+graph that shares the variable store for evaluation, as TF code does with `reuse=True`.
+"""
+import contextlib
+
+import numpy as np
+import torch
+
+from . import abi
+from .engine import Runtime, VarStore
+from .nets import Graph as _EngineGraph, Inputs, ModelAssembly, make_schedule
+
+_stack = []
+
+
+class Tensor:
+    """Handle of a device buffer that holds a value after `Session.run` (the analogue of a tf.Tensor)."""
+
+    def __init__(self, ctx, buf=None, shape=None, name=None, producer=None, field=None):
+        self.ctx, self.buf, self.name, self.producer, self.field = ctx, buf, name, producer, field
+        self._shape = tuple(shape) if shape is not None else (tuple(buf.shape) if buf is not None else None)
+
+    def get_shape(self):
+        return self._shape
+
+    shape = property(get_shape)
+
+    def numpy(self):
+        return self.buf.detach().reshape(self._shape).cpu().numpy()
+
+    def __repr__(self):
+        return 'Tensor(%s, shape=%s)' % (self.name, self._shape)
+
+
+class Placeholder(Tensor):
+    """Feedable device buffer; `field` names the slot of nets.Inputs it aliases (None: accepted and ignored)."""
+
+
+class LazyPoints(Tensor):
+    """xyz columns of the point cloud minus a per-frustum vector -- never materialised: the subtraction is folded
+    into the first layer's operand load (semisup_models.py:159, 207)."""
+
+    def __init__(self, ctx, pc, ncols, sub=None):
+        Tensor.__init__(self, ctx, None, (pc.shape[0], pc.shape[1], ncols), 'lazy_points')
+        self.pc, self.ncols, self.sub = pc, ncols, sub
+
+
+class Graph:
+    """tf.Graph analogue: owns the runtime, the variable store and the recorded model assembly."""
+
+    def __init__(self, rt=None, seed=0, vars=None):
+        self._rt, self.seed, self._vars = rt, seed, vars
+        self.engine = None          # nets.Graph, created by the first placeholder_inputs
+        self.inputs = None
+        self.assembly = None
+        self.is_training = None
+        self.loss = None
+        self.train_op = None
+        self.compiled = {}
+
+    @contextlib.contextmanager
+    def as_default(self):
+        _stack.append(self)
+        try:
+            yield self
+        finally:
+            _stack.pop()
+
+    @property
+    def rt(self):
+        if self._rt is None:
+            self._rt = Runtime()
+        return self._rt
+
+    def ensure_engine(self, batch_size, num_point, num_channel):
+        if self.engine is None:
+            vs = self._vars or VarStore(self.rt, seed=self.seed)
+            self.engine = _EngineGraph(batch_size, num_point, num_channel, rt=self.rt, seed=self.seed, vars=vs)
+            self.inputs = Inputs(self.engine)
+        else:
+            e = self.engine
+            assert (e.B, e.rpf, e.C) == (batch_size, num_point, num_channel), 'one problem size per graph'
+        return self.engine
+
+    @property
+    def vars(self):
+        return self.engine.vars
+
+    def ensure_assembly(self, c, use_one_hot=False):
+        if self.assembly is None:
+            self.assembly = ModelAssembly(self.engine, c, self.inputs, use_one_hot)
+        return self.assembly
+
+
+def get_default_graph():
+    if not _stack:
+        _stack.append(Graph())
+    return _stack[-1]
+
+
+def reset_default_graph():
+    del _stack[:]
+
+
+def placeholder(field, shape, dtype=torch.float32, name=None):
+    g = get_default_graph()
+    buf = getattr(g.inputs, field, None) if field else None
+    return Placeholder(g, buf, shape, name or field, field=field)
+
+
+class TrainOp:
+    def __init__(self, ctx, loss, var_prefixes, sched):
+        self.ctx, self.loss, self.var_prefixes, self.sched = ctx, loss, var_prefixes, sched
+
+
+class AdamOptimizer:
+    """tf.train.AdamOptimizer (train_semisup.py:230) with the reference's staircase schedules
+    (train_semisup.py:127-145) evaluated on the device each step."""
+
+    def __init__(self, learning_rate=1e-3, beta1=0.9, beta2=0.999, epsilon=1e-8, decay_step=800000, decay_rate=0.5,
+                 world_size=1):
+        self.lr, self.b1, self.b2, self.eps = learning_rate, beta1, beta2, epsilon
+        self.decay_step, self.decay_rate, self.world_size = decay_step, decay_rate, world_size
+
+    def minimize(self, loss, global_step=None, var_list=None):
+        """var_list: iterable of scope prefixes (tf.get_collection(scope=...) regex-prefix semantics,
+        train_semisup_adv.py:415-422) or None for every trainable variable."""
+        ctx = loss.ctx
+        sched = make_schedule(ctx.engine.B * self.world_size, self.lr, self.decay_step, self.decay_rate, beta1=self.b1,
+                              beta2=self.b2)
+        ctx.train_op = TrainOp(ctx, loss, list(var_list) if var_list is not None else None, sched)
+        ctx.optimizer = self
+        return ctx.train_op
+
+
+class Session:
+    """tf.Session analogue.  run(fetches, feed_dict): H2D copies of the fed arrays, one replay of the compiled
+    launch schedule, D2H of the fetched tensors."""
+
+    def __init__(self, graph=None, use_hip_graph=None, dropout_seed=1234, process_group=None):
+        self.g = graph or get_default_graph()
+        self.use_hip_graph = use_hip_graph
+        self.dropout_seed = dropout_seed
+        self.pg = process_group
+        self.steps = {}
+
+    # -- compilation ------------------------------------------------------------------------------------
+    def _compile(self, train):
+        key = 'train' if train else 'infer'
+        if key in self.steps:
+            return self.steps[key]
+        from .engine import Plan
+        g, e = self.g, self.g.engine
+        assert not e.finalized or key in g.compiled, 'graph already finalised: build train and eval graphs separately'
+        asm = g.assembly
+        pre, fwd, bwd, opt = Plan(e.rt), Plan(e.rt), Plan(e.rt), Plan(e.rt)
+        is_training = bool(g.is_training)
+        with_loss = g.loss is not None
+        if train:
+            top = g.train_op
+            e.emit_schedule(pre, top.sched)
+            e.emit_dropout_masks(pre, seed=self.dropout_seed)
+        asm.emit_forward(fwd, is_training, with_loss)
+        if train:
+            asm.emit_backward(bwd)
+            o = g.optimizer
+            world = self.pg.size() if self.pg is not None else 1
+            e.emit_adam(opt, prefixes=top.var_prefixes, beta1=o.b1, beta2=o.b2, eps=o.eps, grad_scale=1.0 / world)
+        e.finalize()
+        step = _Step(self, pre, fwd, bwd, opt, train)
+        self.steps[key] = step
+        g.compiled[key] = True
+        return step
+
+    def run(self, fetches, feed_dict=None):
+        single = not isinstance(fetches, (list, tuple))
+        flist = [fetches] if single else list(fetches)
+        train = any(isinstance(f, TrainOp) for f in flist)
+        batch, masks = {}, {}
+        for pl, val in (feed_dict or {}).items():
+            if isinstance(pl, Placeholder):
+                if pl.field is not None:
+                    batch[pl.field] = np.asarray(val)
+            elif isinstance(pl, str):                      # dropout-mask injection for parity tests: scope -> mask
+                masks[pl] = np.asarray(val)
+        if masks:
+            batch['dropout_masks'] = masks
+        step = self._compile(train)
+        self.g.inputs.load(batch)
+        step.run(skip_mask_generation=bool(masks))
+        out = []
+        for f in flist:
+            if isinstance(f, TrainOp):
+                out.append(None)
+            elif isinstance(f, Tensor):
+                out.append(f.numpy())
+            elif isinstance(f, (tuple, list)):
+                out.append(type(f)(x.numpy() for x in f))
+            else:
+                raise TypeError('cannot fetch %r' % (f,))
+        return out[0] if single else out
+
+
+class _Step:
+    """pre (schedules, dropout masks) -> fwd -> bwd -> [all-reduce] -> adam; hipGraph-captured on the GPU."""
+
+    def __init__(self, sess, pre, fwd, bwd, opt, train):
+        self.sess, self.pre, self.fwd, self.bwd, self.opt, self.train = sess, pre, fwd, bwd, opt, train
+        e = sess.g.engine
+        self.on_gpu = e.rt.device.type == 'cuda'
+        want = sess.use_hip_graph if sess.use_hip_graph is not None else self.on_gpu
+        self.graphs = None
+        self.want_graph = want and self.on_gpu
+        self.n_runs = 0
+
+    def _eager(self, skip_mask_generation):
+        e = self.sess.g.engine
+        pg = self.sess.pg
+        if self.train:
+            if skip_mask_generation:
+                for name, call, _ in self.pre.calls:
+                    if name != 't3d_dropout_mask':
+                        abi.check(call(e.rt.stream()), name)
+            else:
+                self.pre.run()
+        self.fwd.run()
+        if self.train:
+            self.bwd.run()
+            if pg is not None and pg.size() > 1:
+                import torch.distributed as dist
+                dist.all_reduce(e.vars.grads[:e.vars.used], group=pg)
+            self.opt.run()
+
+    def run(self, skip_mask_generation=False):
+        self.n_runs += 1
+        # the first run is eager (it also loads the code objects); capture happens on the second run, and
+        # capturing executes nothing, so step semantics are unchanged
+        if not self.want_graph or skip_mask_generation or self.n_runs == 1:
+            return self._eager(skip_mask_generation)
+        e = self.sess.g.engine
+        pg = self.sess.pg
+        multi = pg is not None and pg.size() > 1
+        if self.graphs is None:
+            torch.cuda.synchronize()
+            s = torch.cuda.Stream()
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1, stream=s):
+                if self.train:
+                    self.pre.run()
+                self.fwd.run()
+                if self.train:
+                    self.bwd.run()
+                    if not multi:
+                        self.opt.run()
+            g2 = None
+            if self.train and multi:
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, stream=s):
+                    self.opt.run()
+            self.graphs = (g1, g2)
+        g1, g2 = self.graphs
+        g1.replay()
+        if g2 is not None:
+            import torch.distributed as dist
+            dist.all_reduce(e.vars.grads[:e.vars.used], group=pg)
+            g2.replay()

@@ -337,27 +337,30 @@ class Inputs:
                 t.copy_(torch.as_tensor(np.ascontiguousarray(m)).to(torch.float32).reshape(t.shape))
 
 
-class SemiModelA:
-    """SEMI_MODEL A (get_semi_model_backbone + get_semi_loss_backbone, semisup_v1_sunrgbd.py:81-130,
-    256-321): seg PointNet -> masked centroid -> T-Net -> box PointNet -> strong loss, forward and
-    backward, as one static launch schedule."""
+class ModelAssembly:
+    """Orchestrates whichever sub-networks have been built on a graph (seg -> T-Net -> box -> loss), forward and
+    backward.  The reference wires these in get_semi_model_backbone (semisup_v1_sunrgbd.py:81-130) and lets TF
+    autodiff derive the backward; here both directions are explicit launch schedules."""
 
-    def __init__(self, g, c, use_one_hot=False, scope_prefix=''):
+    def __init__(self, g, c, inputs=None, use_one_hot=False):
         self.g, self.c, self.use_one_hot = g, c, use_one_hot
-        self.inputs = Inputs(g)
-        self.seg = InstSegNet(g, scope_prefix + 'inst_seg', use_one_hot)
-        self.tnet = TNet(g, scope_prefix + 'tnet', use_one_hot)
-        self.box = BoxEstNet(g, scope_prefix + 'box_est', use_one_hot)
-        self.loss_op = StrongLoss(g)
+        self.inputs = inputs or Inputs(g)
+        self.seg = self.tnet = self.box = self.loss_op = None
 
     def emit_forward(self, plan, is_training, with_loss):
         g, x, c = self.g, self.inputs, self.c
         labels = x.y_seg if with_loss else None
         train_seg = with_loss and is_training
-        self.seg.fwd(plan, x.pc, x.one_hot_vec, labels, x.is_data_2D, is_training, train_seg,
-                     ce_weight=c.STRONG_WEIGHT_CROSS_ENTROPY)
-        s1 = self.tnet.fwd(plan, x.pc, self.seg.mask, self.seg.mask_xyz_mean, x.one_hot_vec, is_training)
-        box = self.box.fwd(plan, x.pc, self.seg.mask, s1, x.one_hot_vec, is_training)
+        oh = x.one_hot_vec
+        self.seg.fwd(plan, x.pc, oh, labels, x.is_data_2D, is_training, train_seg, ce_weight=c.STRONG_WEIGHT_CROSS_ENTROPY)
+        if self.tnet is None:
+            return
+        s1 = self.tnet.fwd(plan, x.pc, self.seg.mask, self.seg.mask_xyz_mean, oh, is_training)
+        if self.box is None:
+            return
+        box = self.box.fwd(plan, x.pc, self.seg.mask, s1, oh, is_training)
+        if self.loss_op is None:
+            self.loss_op = StrongLoss(g)
         if with_loss:
             lab = (x.y_center, x.y_orient_cls, x.y_orient_reg, x.y_dims_cls, x.y_dims_reg, x.is_data_2D)
             self.loss_op.emit(plan, box, s1, self.seg.seg_loss, lab, c)
@@ -371,12 +374,28 @@ class SemiModelA:
     def end_points(self):
         g = self.g
         B, N = g.B, g.rpf
-        return {
-            'logits': self.seg.logits.view(B, N, 2), 'mask': self.seg.mask.view(B, N),
-            'mask_xyz_mean': self.seg.mask_xyz_mean, 'stage1_center': self.tnet.stage1_center,
-            'box_params': self.box.box_params, 'feats_lv1': self.box.feats_lv1, 'feats_lv2': self.box.feats_lv2,
-            'feats_lv3': self.box.feats_lv3, 'center': self.loss_op.center, 'tnet_feats': self.tnet.T3.pooled,
-            'seg_global_feat': self.seg.L5.pooled, 'loss_terms': self.loss_op.terms,
-            'total_losses': self.loss_op.total_losses, 'loss': self.loss_op.loss,
-            'S_dims': self.loss_op.reg_dims, 'S_theta': self.loss_op.reg_theta,
-        }
+        ep = {'logits': self.seg.logits.view(B, N, 2), 'mask': self.seg.mask.view(B, N),
+              'mask_xyz_mean': self.seg.mask_xyz_mean, 'seg_global_feat': self.seg.L5.pooled}
+        if self.tnet is not None:
+            ep.update({'stage1_center': self.tnet.stage1_center, 'tnet_feats': self.tnet.T3.pooled})
+        if self.box is not None:
+            ep.update({'box_params': self.box.box_params, 'feats_lv1': self.box.feats_lv1,
+                       'feats_lv2': self.box.feats_lv2, 'feats_lv3': self.box.feats_lv3})
+        if self.loss_op is not None:
+            ep.update({'center': self.loss_op.center, 'loss_terms': self.loss_op.terms,
+                       'total_losses': self.loss_op.total_losses, 'loss': self.loss_op.loss,
+                       'S_dims': self.loss_op.reg_dims, 'S_theta': self.loss_op.reg_theta})
+        return ep
+
+
+class SemiModelA(ModelAssembly):
+    """SEMI_MODEL A (get_semi_model_backbone + get_semi_loss_backbone, semisup_v1_sunrgbd.py:81-130,
+    256-321): seg PointNet -> masked centroid -> T-Net -> box PointNet -> strong loss, forward and
+    backward, as one static launch schedule."""
+
+    def __init__(self, g, c, use_one_hot=False, scope_prefix='', inputs=None):
+        ModelAssembly.__init__(self, g, c, inputs, use_one_hot)
+        self.seg = InstSegNet(g, scope_prefix + 'inst_seg', use_one_hot)
+        self.tnet = TNet(g, scope_prefix + 'tnet', use_one_hot)
+        self.box = BoxEstNet(g, scope_prefix + 'box_est', use_one_hot)
+        self.loss_op = StrongLoss(g)

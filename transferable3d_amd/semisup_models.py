@@ -1,0 +1,116 @@
+"""Sub-network builders under the reference's names and signatures
+(sunrgbd/sunrgbd_detection/semisup_models.py: v1_inst_seg 69, subtract_points_mean 145, v1_tnet 164,
+subtract_1st_stage_center 204, v1_box_est 215).  Each call allocates the sub-network (variables in the reference's
+scopes, HBM buffers) on the default graph and links it into the graph's ModelAssembly; the fused launch
+schedule is emitted when a Session first runs."""
+import numpy as np
+
+from . import api
+from .constants import BOX_OUT_DIMS, MEAN_DIMS_ARR, NUM_HEADING_BIN, NUM_SIZE_CLUSTER
+from .nets import BoxEstNet, InstSegNet, TNet
+
+
+def _asm(ctx, use_one_hot):
+    asm = ctx.assembly
+    assert asm is not None, 'call semisup_v1_sunrgbd.get_semi_model (or api.Graph.ensure_assembly) first'
+    return asm
+
+
+def v1_inst_seg(point_cloud, img_feats, one_hot_vec, end_points, is_training, bn_decay=None, scope=None):
+    """Instance-segmentation PointNet -> per-point logits (B,N,2)."""
+    ctx = point_cloud.ctx
+    asm = _asm(ctx, one_hot_vec is not None)
+    asm.seg = InstSegNet(ctx.engine, scope, one_hot_vec is not None)
+    ctx.is_training = bool(is_training)
+    e = ctx.engine
+    logits = api.Tensor(ctx, asm.seg.logits, (e.B, e.rpf, 2), scope + '/logits', producer=asm.seg)
+    end_points['seg_global_feat'] = api.Tensor(ctx, asm.seg.L5.pooled, (e.B, 1024), scope + '/global_feat')
+    return logits
+
+
+def subtract_points_mean(point_cloud, logits, scope=None):
+    """mask = logit0 < logit1 (hard, no gradient); masked xyz mean; recentred xyz.  Computed by the segmentation-head
+    kernel; the recentred cloud stays lazy."""
+    ctx = point_cloud.ctx
+    seg = logits.producer
+    e = ctx.engine
+    mask = api.Tensor(ctx, seg.mask, (e.B, e.rpf, 1), 'mask', producer=seg)
+    mean = api.Tensor(ctx, seg.mask_xyz_mean, (e.B, 1, 3), 'mask_xyz_mean', producer=seg)
+    xyz = api.LazyPoints(ctx, point_cloud, 3)
+    return mask, mean, xyz, api.LazyPoints(ctx, point_cloud, 3, sub=mean)
+
+
+def v1_tnet(point_cloud_xyz_stage1, mask, mask_xyz_mean, one_hot_vec, end_points, is_training, norm_box2D=None,
+            bn_decay=None, scope=None):
+    if norm_box2D is not None:
+        raise NotImplementedError('USE_NORMALIZED_BOX2D_AS_FEATS is off in every published recipe')
+    ctx = point_cloud_xyz_stage1.ctx
+    asm = _asm(ctx, one_hot_vec is not None)
+    asm.tnet = TNet(ctx.engine, scope, one_hot_vec is not None)
+    s1 = api.Tensor(ctx, asm.tnet.F3.out, (ctx.engine.B, 3), scope + '/stage1_center', producer=asm.tnet)
+    end_points['stage1_center'] = s1
+    return s1
+
+
+def subtract_1st_stage_center(point_cloud_xyz, stage1_center, scope=None):
+    return api.LazyPoints(point_cloud_xyz.ctx, point_cloud_xyz.pc, 3, sub=stage1_center)
+
+
+def v1_box_est(point_cloud_xyz_submean, stage1_center, mask, one_hot_vec, end_points, is_training, norm_box2D=None,
+               bn_decay=None, prefix='', c=None, scope=None):
+    if norm_box2D is not None:
+        raise NotImplementedError('USE_NORMALIZED_BOX2D_AS_FEATS is off in every published recipe')
+    ctx = point_cloud_xyz_submean.ctx
+    asm = _asm(ctx, one_hot_vec is not None)
+    asm.box = BoxEstNet(ctx.engine, scope, one_hot_vec is not None)
+    B = ctx.engine.B
+    NH, NS = NUM_HEADING_BIN, NUM_SIZE_CLUSTER
+    box = asm.box
+    out = api.Tensor(ctx, box.G3.out, (B, BOX_OUT_DIMS), scope + '/box_params', producer=box)
+    end_points[prefix + 'feats_lv1'] = api.Tensor(ctx, box.B4.pooled, (B, 512), 'feats_lv1')
+    end_points[prefix + 'feats_lv2'] = api.Tensor(ctx, box.G1.out, (B, 512), 'feats_lv2')
+    end_points[prefix + 'feats_lv3'] = api.Tensor(ctx, box.G2.out, (B, 256), 'feats_lv3')
+    end_points[prefix + 'box_params'] = out
+    heads = BoxHeads(out, stage1_center, prefix)
+    end_points.update(heads.end_points())
+    return heads.pred_box()
+
+
+class SlicedTensor(api.Tensor):
+    """Column slice / affine view of a (B,67) head output, evaluated on the host at fetch time
+    (semisup_models.py:265-290 slicing and scaling)."""
+
+    def __init__(self, src, fn, shape, name):
+        api.Tensor.__init__(self, src.ctx, None, shape, name)
+        self.src, self.fn = src, fn
+
+    def numpy(self):
+        return self.fn()
+
+
+class BoxHeads:
+    def __init__(self, out, stage1_center, prefix):
+        self.out, self.s1, self.prefix = out, stage1_center, prefix
+
+    def end_points(self):
+        o, s1, p = self.out, self.s1, self.prefix
+        B = o.shape[0]
+        NH, NS = NUM_HEADING_BIN, NUM_SIZE_CLUSTER
+        mean = MEAN_DIMS_ARR.astype(np.float32)
+        mk = lambda fn, shape, name: SlicedTensor(o, fn, shape, p + name)
+        return {
+            p + 'center': mk(lambda: o.numpy()[:, 0:3] + s1.numpy(), (B, 3), 'center'),
+            p + 'heading_scores': mk(lambda: o.numpy()[:, 3:3 + NH], (B, NH), 'heading_scores'),
+            p + 'heading_residuals_normalized': mk(lambda: o.numpy()[:, 3 + NH:3 + 2 * NH], (B, NH), 'heading_residuals_normalized'),
+            p + 'heading_residuals': mk(lambda: o.numpy()[:, 3 + NH:3 + 2 * NH] * np.float32(np.pi / NH), (B, NH), 'heading_residuals'),
+            p + 'size_scores': mk(lambda: o.numpy()[:, 3 + 2 * NH:3 + 2 * NH + NS], (B, NS), 'size_scores'),
+            p + 'size_residuals_normalized': mk(lambda: o.numpy()[:, 3 + 2 * NH + NS:].reshape(B, NS, 3), (B, NS, 3),
+                                                'size_residuals_normalized'),
+            p + 'size_residuals': mk(lambda: o.numpy()[:, 3 + 2 * NH + NS:].reshape(B, NS, 3) * mean[None], (B, NS, 3),
+                                     'size_residuals'),
+        }
+
+    def pred_box(self):
+        ep, p = self.end_points(), self.prefix
+        return (ep[p + 'center'], ep[p + 'size_scores'], ep[p + 'size_residuals'], ep[p + 'heading_scores'],
+                ep[p + 'heading_residuals'])

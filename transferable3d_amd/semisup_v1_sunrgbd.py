@@ -1,0 +1,106 @@
+"""Model builder under the reference's names and signatures
+(sunrgbd/sunrgbd_detection/semisup_v1_sunrgbd.py: placeholder_inputs 37-67, get_semi_model 69-79,
+get_semi_model_backbone 81-130, get_semi_loss 248-254, get_semi_loss_backbone 256-321,
+convert_raw_y_box_to_reg_format 584-608)."""
+import numpy as np
+
+from . import api, semisup_models
+from .constants import MEAN_DIMS_ARR, NUM_CLASS, NUM_HEADING_BIN, ORIENT_ANCHORS
+
+INPUT_IMG_CHANNELS = 3
+
+
+def placeholder_inputs(batch_size, num_point, num_channel):
+    """The reference's 18 placeholders, same order.  Those that feed only out-of-scope paths (bg_pc, img, KITTI
+    and SUN-RGBD camera matrices, 2-D boxes: weak losses with zero weight) are accepted and ignored."""
+    ctx = api.get_default_graph()
+    ctx.ensure_engine(batch_size, num_point, num_channel)
+    B, N, C = batch_size, num_point, num_channel
+    P = api.placeholder
+    return (P('pc', (B, N, C)), P(None, (B, N, C), name='bg_pc'), P(None, (B, None, None, INPUT_IMG_CHANNELS), name='img'),
+            P('one_hot_vec', (B, NUM_CLASS)), P('y_seg', (B, N)), P('y_center', (B, 3)), P('y_orient_cls', (B,)),
+            P('y_orient_reg', (B,)), P('y_dims_cls', (B,)), P('y_dims_reg', (B, 3)), P(None, (B, 3, 3), name='R0_rect'),
+            P(None, (B, 3, 4), name='P'), P(None, (B, 3, 3), name='Rtilt'), P(None, (B, 3, 3), name='K'),
+            P(None, (B, 1), name='rot_frust'), P(None, (B, 4), name='box2D'), P(None, (B, 2), name='img_dim'),
+            P('is_data_2D', (B,)))
+
+
+def get_semi_model(pc, bg_pc, img, one_hot_vec, is_training, use_one_hot, oracle_mask=None, norm_box2D=None,
+                   bn_decay=None, c=None):
+    if c.SEMI_MODEL == 'A':
+        return get_semi_model_backbone(pc, bg_pc, img, one_hot_vec, is_training, use_one_hot, oracle_mask=oracle_mask,
+                                       norm_box2D=norm_box2D, bn_decay=bn_decay, c=c)
+    elif c.SEMI_MODEL == 'F':
+        raise NotImplementedError('SEMI_MODEL F (stage c) is the next row of SURVEY.md section 8')
+    else:
+        raise Exception('Not implemented SEMI_MODEL: %s' % c.SEMI_MODEL)
+
+
+def get_semi_model_backbone(pc, bg_pc, img, one_hot_vec, is_training, use_one_hot, oracle_mask=None, norm_box2D=None,
+                            bn_decay=None, c=None):
+    """seg PointNet -> masked centroid -> T-Net -> box PointNet (semisup_v1_sunrgbd.py:81-130)."""
+    ctx = pc.ctx
+    e = ctx.engine
+    ctx.ensure_assembly(c, use_one_hot)
+    if isinstance(bn_decay, (int, float)):
+        e.hyper[2] = float(bn_decay)
+    end_points = {'point_cloud': pc, 'class_one_hot': one_hot_vec,
+                  'dims_anchors': MEAN_DIMS_ARR.astype(np.float32), 'orient_anchors': ORIENT_ANCHORS.astype(np.float32)}
+    if not use_one_hot:
+        one_hot_vec = None
+    if oracle_mask is not None:
+        raise NotImplementedError
+    if not c.USE_NORMALIZED_BOX2D_AS_FEATS:
+        norm_box2D = None
+    logits = semisup_models.v1_inst_seg(pc, None, one_hot_vec, end_points, is_training, bn_decay=bn_decay, scope='inst_seg')
+    mask, mask_xyz_mean, pc_xyz, pc_xyz_stage1 = semisup_models.subtract_points_mean(pc, logits, scope='subtract_points_mean')
+    stage1_center = semisup_models.v1_tnet(pc_xyz_stage1, mask, mask_xyz_mean, one_hot_vec, end_points, is_training,
+                                           norm_box2D=norm_box2D, bn_decay=bn_decay, scope='tnet')
+    pc_xyz_submean = semisup_models.subtract_1st_stage_center(pc_xyz, stage1_center, scope='subtract_tnet_center')
+    pred_box = semisup_models.v1_box_est(pc_xyz_submean, stage1_center, mask, one_hot_vec, end_points, is_training,
+                                         norm_box2D=norm_box2D, bn_decay=bn_decay, c=c, scope='box_est')
+    end_points['S_pred_box'] = pred_box
+    end_points['mask'] = mask
+    end_points['mask_xyz_mean'] = mask_xyz_mean
+    asm = ctx.assembly
+    from .nets import StrongLoss
+    asm.loss_op = StrongLoss(e)
+    B = e.B
+    T = lambda buf, shape, name: api.Tensor(ctx, buf, shape, name)
+    end_points['S_pred_box_reg'] = (T(asm.loss_op.center, (B, 3), 'reg_center'), T(asm.loss_op.reg_dims, (B, 3), 'reg_dims'),
+                                    T(asm.loss_op.reg_theta, (B,), 'reg_theta'))
+    return (logits, pred_box), end_points
+
+
+def get_semi_loss(pred, labels, end_points, reduce_loss=True, c=None):
+    if c.SEMI_MODEL == 'A':
+        return get_semi_loss_backbone(pred, labels, end_points, reduce_loss=reduce_loss, c=c)
+    elif c.SEMI_MODEL == 'F':
+        raise NotImplementedError('SEMI_MODEL F (stage c) is the next row of SURVEY.md section 8')
+    else:
+        raise Exception('Not implemented SEMI_MODEL: %s' % c.SEMI_MODEL)
+
+
+def get_semi_loss_backbone(pred, labels, end_points, reduce_loss=True, c=None):
+    """mean_b (1-is2D)*(seg CE + strong box loss) (semisup_v1_sunrgbd.py:256-321).  The weak reprojection / surface
+    losses have weight 0 in the published recipe a (README.md:65-66) and are not evaluated (documented deviation)."""
+    if c.WEAK_WEIGHT_REPROJECTION != 0 or c.WEAK_WEIGHT_SURFACE != 0:
+        raise NotImplementedError('weak reprojection / surface losses are out of scope (zero weight in recipe a); '
+                                  'pass --WEAK_WEIGHT_REPROJECTION 0 --WEAK_WEIGHT_SURFACE 0')
+    logits = pred[0]
+    ctx = logits.ctx
+    asm, B = ctx.assembly, ctx.engine.B
+    T = lambda buf, shape, name: api.Tensor(ctx, buf, shape, name)
+    end_points['loss_terms'] = T(asm.loss_op.terms, (B, 8), 'loss_terms')
+    end_points['center'] = T(asm.loss_op.center, (B, 3), 'center')
+    total = T(asm.loss_op.loss, (), 'semi_loss')
+    ctx.loss = total if reduce_loss else T(asm.loss_op.total_losses, (B,), 'semi_losses')
+    return ctx.loss
+
+
+def convert_raw_y_box_to_reg_format(y_box, one_hot_vec):
+    """GT (center, heading bin/residual, size bin/residual) -> (center, dims, theta), NumPy
+    (semisup_v1_sunrgbd.py:584-608)."""
+    y_centers, y_orient_cls, y_orient_reg, y_dims_cls, y_dims_reg = [np.asarray(x) for x in y_box]
+    dims = np.maximum(MEAN_DIMS_ARR.astype(np.float32)[y_dims_cls] + y_dims_reg, 1e-5)
+    return y_centers, dims, ORIENT_ANCHORS.astype(np.float32)[y_orient_cls] + y_orient_reg

@@ -1,0 +1,127 @@
+#!/usr/bin/env python3
+"""Stage-a training driver (SEMI_MODEL A) with the reference's command line
+(sunrgbd/sunrgbd_detection/train_semisup.py: flags 28-48, graph build 199-260, epoch loop 305-318, train_one_epoch
+320-436).  Differences, all forced by the environment and documented in DESIGN.md:
+  * `--synthetic` batches (transferable3d_amd/synthetic.py) replace the SUN-RGBD frustum pickles, which are not
+    available; `--train_data` is therefore optional.
+  * one process per GPU: launch with `python -m torch.distributed.run --nproc-per-node N ... train_semisup.py` for
+    data-parallel training (gradient all-reduce on RCCL); `--gpu` selects the device in the single-process case.
+  * checkpoints are `.npz` state dicts keyed by the reference's TF variable names.
+
+Example (README.md:58-67 recipe a, synthetic data):
+  python -m transferable3d_amd.train_semisup --SEMI_MODEL A --WEAK_WEIGHT_REPROJECTION 0 --WEAK_WEIGHT_SURFACE 0 \
+      --num_point 1024 --no_rgb_channels 4 --max_epoch 1 --steps_per_epoch 100
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+if __package__ in (None, ''):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from transferable3d_amd import api, semisup_v1_sunrgbd as MODEL       # noqa: E402
+from transferable3d_amd.config import make_parser                        # noqa: E402
+from transferable3d_amd.synthetic import make_batch                      # noqa: E402
+
+
+def build_flags(argv=None):
+    cfg = make_parser()
+    cfg.add_argument('--train_data', type=str, default='synthetic', choices=['train_mini', 'train_aug5x', 'trainval_aug5x', 'synthetic'])
+    cfg.add_argument('--train_data3D_keep_prob', type=float, default=1)
+    cfg.add_argument('--add3D_for_classes2D_prob', type=float, default=-1)
+    cfg.add_argument('--gpu', type=int, default=0, help='GPU to use [default: GPU 0]')
+    cfg.add_argument('--model', default='semisup_v1_sunrgbd', help='Model name [default: model]')
+    cfg.add_argument('--log_dir', default='log', help='Log dir [default: log]')
+    cfg.add_argument('--num_point', type=int, default=2048, help='Point Number [default: 2048]')
+    cfg.add_argument('--max_epoch', type=int, default=31, help='Epoch to run [default: 51]')
+    cfg.add_argument('--batch_size', type=int, default=32, help='Batch Size during training [default: 32]')
+    cfg.add_argument('--learning_rate', type=float, default=0.001, help='Initial learning rate [default: 0.001]')
+    cfg.add_argument('--momentum', type=float, default=0.9)
+    cfg.add_argument('--optimizer', default='adam', help='adam or momentum [default: adam]')
+    cfg.add_argument('--decay_step', type=int, default=800000, help='Decay step for lr decay [default: 200000]')
+    cfg.add_argument('--decay_rate', type=float, default=0.5, help='Decay rate for lr decay [default: 0.7]')
+    cfg.add_argument('--use_mini', action='store_true')
+    cfg.add_argument('--use_one_hot', action='store_true', help='Use one hot vector during training')
+    cfg.add_argument('--no_aug', action='store_true')
+    cfg.add_argument('--no_rgb', action='store_true', help='Only use XYZ for training')
+    cfg.add_argument('--init_model_path', default=None)
+    cfg.add_argument('--restore_model_path', default=None, help='Restore model path e.g. log/model_epoch_0.npz')
+    # additions
+    cfg.add_argument('--synthetic', action='store_true', help='synthetic frustums (the only data source available)')
+    cfg.add_argument('--num_channels', type=int, default=None, help='override point channels (reference: 6, or 3 with --no_rgb)')
+    cfg.add_argument('--steps_per_epoch', type=int, default=100)
+    cfg.add_argument('--seed', type=int, default=0)
+    FLAGS = cfg.parse_special_args(argv)
+    FLAGS.NUM_CHANNELS = FLAGS.num_channels if FLAGS.num_channels else (3 if FLAGS.no_rgb else 6)
+    return FLAGS
+
+
+def train(FLAGS, rt=None, log=print):
+    import torch
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        on_gpu = torch.cuda.is_available() and rt is None
+        if on_gpu:
+            torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+        dist.init_process_group('nccl' if on_gpu else 'gloo')
+        pg = dist.group.WORLD
+    elif rt is None and torch.cuda.is_available():
+        torch.cuda.set_device(FLAGS.gpu)
+    if FLAGS.optimizer != 'adam':
+        raise NotImplementedError('only --optimizer adam (every published recipe) is on the hot path')
+    B, N, C = FLAGS.batch_size, FLAGS.num_point, FLAGS.NUM_CHANNELS
+    os.makedirs(FLAGS.log_dir, exist_ok=True)
+    if rank == 0:
+        log(FLAGS.config_str)
+    with api.Graph(rt=rt, seed=FLAGS.seed).as_default() as g:
+        pls = MODEL.placeholder_inputs(B, N, C)
+        pc_pl, bg_pc_pl, img_pl, one_hot_vec_pl, y_seg_pl, y_centers_pl, y_orient_cls_pl, y_orient_reg_pl, y_dims_cls_pl, \
+            y_dims_reg_pl, R0_rect_pl, P_pl, Rtilt_pl, K_pl, rot_frust_pl, box2D_pl, img_dim_pl, is_data_2D_pl = pls
+        pred, end_points = MODEL.get_semi_model(pc_pl, bg_pc_pl, img_pl, one_hot_vec_pl, True, use_one_hot=FLAGS.use_one_hot,
+                                                norm_box2D=None, bn_decay=None, c=FLAGS)
+        labels = (y_seg_pl, y_centers_pl, y_orient_cls_pl, y_orient_reg_pl, y_dims_cls_pl, y_dims_reg_pl, R0_rect_pl, P_pl,
+                  Rtilt_pl, K_pl, rot_frust_pl, box2D_pl, img_dim_pl, is_data_2D_pl)
+        semi_loss = MODEL.get_semi_loss(pred, labels, end_points, c=FLAGS)
+        optimizer = api.AdamOptimizer(FLAGS.learning_rate, decay_step=FLAGS.decay_step, decay_rate=FLAGS.decay_rate,
+                                      world_size=world)
+        train_op = optimizer.minimize(semi_loss)
+        sess = api.Session(process_group=pg, dropout_seed=1234 + rank)
+        if FLAGS.restore_model_path:
+            g.vars.load_state_dict(dict(np.load(FLAGS.restore_model_path)))
+        n_correct = api.Tensor(g, g.assembly.seg.n_correct, (1,), 'n_correct')
+        step = 0
+        for epoch in range(FLAGS.max_epoch):
+            t0 = time.time()
+            loss_sum, correct = 0.0, 0.0
+            for it in range(FLAGS.steps_per_epoch):
+                batch = make_batch(B, N, C, seed=FLAGS.seed * 1000003 + step * world + rank)
+                feed = {pc_pl: batch['pc'], one_hot_vec_pl: batch['one_hot_vec'], y_seg_pl: batch['y_seg'],
+                        y_centers_pl: batch['y_center'], y_orient_cls_pl: batch['y_orient_cls'],
+                        y_orient_reg_pl: batch['y_orient_reg'], y_dims_cls_pl: batch['y_dims_cls'],
+                        y_dims_reg_pl: batch['y_dims_reg'], is_data_2D_pl: batch['is_data_2D']}
+                loss_val, nc, _ = sess.run([semi_loss, n_correct, train_op], feed_dict=feed)
+                loss_sum += float(loss_val)
+                correct += float(nc[0])
+                step += 1
+            if rank == 0:
+                log('**** EPOCH %03d ****  mean loss: %f  accuracy: %f  (%.1f frustums/s incl. host batch synthesis)' % (
+                    epoch, loss_sum / FLAGS.steps_per_epoch, correct / (FLAGS.steps_per_epoch * B * N),
+                    FLAGS.steps_per_epoch * B * world / (time.time() - t0)))
+                if epoch % 5 == 0:                       # train_semisup.py:316-318
+                    path = os.path.join(FLAGS.log_dir, 'model_epoch_%d.npz' % epoch)
+                    np.savez(path, **g.vars.state_dict())
+                    log('Model saved in file: %s' % path)
+        final = g.vars.state_dict()
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+    return final, loss_sum / max(FLAGS.steps_per_epoch, 1)
+
+
+if __name__ == '__main__':
+    train(build_flags())
