@@ -350,6 +350,52 @@ typedef struct {
 } t3d_strong_loss_args;
 int t3d_strong_loss(const t3d_strong_loss_args* args, t3d_stream_t stream);
 
+/* ---- K8: Box-PC representation ----------------------------------------------------------------------
+ * Replaces tf_get_box_pc_representation (tf_util.py:764-795) + tf_create_3D_box_by_surface_centers_multi
+ * (893-955): rep[m, 0:C] = pc[m, 0:C]; rep[m, C:C+6] = the six signed point-to-face distances of point m to the
+ * box of its frustum (centre, dims (l,w,h), heading); columns C+6 .. ld_rep-1 are zero padding.
+ * Box in regression form (center, dims, theta), or, when y_dims_cls != NULL, in label form: dims/theta hold the
+ * residuals and the box is max(anchor[cls] + res, 1e-5) / bin[cls] + res (boxpc_sunrgbd.py:206-230).
+ * box_out[B,7] (optional) receives (cx,cy,cz,l,w,h,theta) for the backward.  rows_per_frustum % 256 == 0. */
+typedef struct {
+  const float* pc; int ld_pc; int C;
+  const float* center;            /* [B,3] */
+  const float* dims;              /* [B,3] */
+  const float* theta;             /* [B]   */
+  const int32_t* y_dims_cls;      /* [B] or NULL */
+  const int32_t* y_orient_cls;    /* [B] or NULL */
+  float* rep; int ld_rep;         /* [M, ld_rep] */
+  float* box_out;                 /* [B,7] or NULL */
+  int M, rows_per_frustum;
+} t3d_boxpc_rep_args;
+int t3d_boxpc_rep(const t3d_boxpc_rep_args* args, t3d_stream_t stream);
+
+/* Gradient of the representation w.r.t. the box: dbox[B,7] = d(cx,cy,cz,l,w,h,theta), reduced over the points,
+ * from drep[m, coff .. coff+5] = gradient w.r.t. the six distance channels (stage c: train_semisup_adv.py:331-411). */
+typedef struct {
+  const float* pc; int ld_pc;
+  const float* box;               /* [B,7] from t3d_boxpc_rep */
+  const float* drep; int ld_drep; int coff;
+  float* dbox;                    /* [B,7] */
+  int B, rows_per_frustum;
+} t3d_boxpc_rep_bwd_args;
+int t3d_boxpc_rep_bwd(const t3d_boxpc_rep_bwd_args* args, t3d_stream_t stream);
+
+/* Box-PC loss, forward + backward (boxpc_sunrgbd.py:106-193, huber form): out[B,9] = [dcentre(3), dsize(3), dangle,
+ * fit logits(2)];  loss = mean_b( w_cls*CE(logits, iou > fit_bound) + w_delta*wl*(w_center*mean3 Huber + w_size*mean3
+ * Huber + w_angle*Huber) ).  terms[B,4] = (CE, delta loss, p_fit, total). */
+typedef struct {
+  const float* out;               /* [B,9] */
+  const float* y_box_iou; const float* y_center_delta; const float* y_dims_delta; const float* y_orient_delta;
+  float fit_bound, w_cls, w_delta, w_center, w_size, w_angle;
+  int weigh_by_cls_conf, weigh_by_cls_gt;
+  float* dout;                    /* [B,9] */
+  float* terms;                   /* [B,4] */
+  float* loss;                    /* [1] */
+  int B;
+} t3d_boxpc_loss_args;
+int t3d_boxpc_loss(const t3d_boxpc_loss_args* args, t3d_stream_t stream);
+
 /* ---- K11d / K12 / schedules --------------------------------------------------------------------- */
 
 /* grad[off_i + e] = sum_s slabs_i[s, e]  for every tensor i of a device-side table. */

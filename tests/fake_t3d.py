@@ -512,6 +512,86 @@ class FakeLib:
         arr(p.loss, 1)[0] = total_sum * norm
         return 0
 
+    # ---- Box-PC --------------------------------------------------------------------------------------
+    @staticmethod
+    def _box(p, B):
+        center = arr(p.center, B, 3).astype(np.float64)
+        if p.y_dims_cls:
+            k, j = arr(p.y_dims_cls, B), arr(p.y_orient_cls, B)
+            dims = np.maximum(MEAN32.astype(np.float64)[k] + arr(p.dims, B, 3), 1e-5)
+            theta = BINS32.astype(np.float64)[j] + arr(p.theta, B)
+        else:
+            dims, theta = arr(p.dims, B, 3).astype(np.float64), arr(p.theta, B).astype(np.float64)
+        return center, dims, theta
+
+    def t3d_boxpc_rep(self, a, stream):
+        p = _struct(a)
+        M, rpf, Cc = p.M, p.rows_per_frustum, p.C
+        B = M // rpf
+        center, dims, theta = self._box(p, B)
+        if p.box_out:
+            arr(p.box_out, B, 7)[:] = np.concatenate([center, dims, theta[:, None]], 1)
+        pc = arr(p.pc, M, p.ld_pc).astype(np.float64)
+        rep = arr(p.rep, M, p.ld_rep)
+        rep[:] = 0
+        rep[:, :Cc] = pc[:, :Cc]
+        t = pc[:, :3] - np.repeat(center, rpf, 0)
+        c, s = np.repeat(np.cos(theta), rpf), np.repeat(np.sin(theta), rpf)
+        l, w, h = [np.repeat(dims[:, i], rpf) for i in range(3)]
+        u, q = c * t[:, 0] - s * t[:, 2], s * t[:, 0] + c * t[:, 2]
+        rep[:, Cc:Cc + 6] = np.stack([l / 2 - u, l / 2 + u, h / 2 - t[:, 1], h / 2 + t[:, 1], w / 2 - q, w / 2 + q], 1)
+        return 0
+
+    def t3d_boxpc_rep_bwd(self, a, stream):
+        p = _struct(a)
+        B, rpf = p.B, p.rows_per_frustum
+        M = B * rpf
+        box = arr(p.box, B, 7).astype(np.float64)
+        g = arr(p.drep, M, p.ld_drep)[:, p.coff:p.coff + 6].astype(np.float64).reshape(B, rpf, 6)
+        pc = arr(p.pc, M, p.ld_pc).astype(np.float64).reshape(B, rpf, -1)
+        c, s = np.cos(box[:, 6])[:, None], np.sin(box[:, 6])[:, None]
+        tx, tz = pc[:, :, 0] - box[:, 0:1], pc[:, :, 2] - box[:, 2:3]
+        u, q = c * tx - s * tz, s * tx + c * tz
+        du, dv, dq = g[:, :, 1] - g[:, :, 0], g[:, :, 3] - g[:, :, 2], g[:, :, 5] - g[:, :, 4]
+        out = arr(p.dbox, B, 7)
+        out[:, 0] = -(du * c + dq * s).sum(1)
+        out[:, 1] = -dv.sum(1)
+        out[:, 2] = -(-du * s + dq * c).sum(1)
+        out[:, 3] = 0.5 * (g[:, :, 0] + g[:, :, 1]).sum(1)
+        out[:, 4] = 0.5 * (g[:, :, 4] + g[:, :, 5]).sum(1)
+        out[:, 5] = 0.5 * (g[:, :, 2] + g[:, :, 3]).sum(1)
+        out[:, 6] = (-du * q + dq * u).sum(1)
+        return 0
+
+    def t3d_boxpc_loss(self, a, stream):
+        p = _struct(a)
+        B = p.B
+        o = arr(p.out, B, 9).astype(np.float64)
+        iou = arr(p.y_box_iou, B).astype(np.float64)
+        cls = (iou > p.fit_bound).astype(np.int64)
+        lg = o[:, 7:9]
+        mx = lg.max(1, keepdims=True)
+        lse = mx[:, 0] + np.log(np.exp(lg - mx).sum(1))
+        ce = lse - lg[np.arange(B), cls]
+        prob = np.exp(lg - lse[:, None])
+        wl = np.ones(B)
+        if p.weigh_by_cls_gt:
+            wl = 1 - iou
+        if p.weigh_by_cls_conf:
+            wl = 1 - prob[:, 1]
+        hub = lambda e: 0.5 * np.minimum(np.abs(e), 1) ** 2 + (np.abs(e) - np.minimum(np.abs(e), 1))
+        ec, es, ea = o[:, 0:3] - arr(p.y_center_delta, B, 3), o[:, 3:6] - arr(p.y_dims_delta, B, 3), o[:, 6] - arr(p.y_orient_delta, B)
+        delta = wl * (p.w_center * hub(ec).mean(1) + p.w_size * hub(es).mean(1) + p.w_angle * hub(ea))
+        total = p.w_cls * ce + p.w_delta * delta
+        g = arr(p.dout, B, 9)
+        g[:, 7:9] = p.w_cls * (prob - np.eye(2)[cls]) / B
+        g[:, 0:3] = p.w_delta * p.w_center * wl[:, None] * np.clip(ec, -1, 1) / 3 / B
+        g[:, 3:6] = p.w_delta * p.w_size * wl[:, None] * np.clip(es, -1, 1) / 3 / B
+        g[:, 6] = p.w_delta * p.w_angle * wl * np.clip(ea, -1, 1) / B
+        arr(p.terms, B, 4)[:] = np.stack([ce, delta, prob[:, 1], total], 1)
+        arr(p.loss, 1)[0] = total.mean()
+        return 0
+
     # ---- optimiser -------------------------------------------------------------------------------
     def t3d_reduce_slabs(self, slab_base, grad_base, table, n_tensors, max_numel, stream):
         for i in range(n_tensors):

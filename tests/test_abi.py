@@ -33,7 +33,8 @@ def test_ctypes_structs_follow_header_field_order():
              't3d_fc_fwd_args': abi.FcFwdArgs, 't3d_fc_bwd_args': abi.FcBwdArgs, 't3d_fc_dinput_args': abi.FcDinputArgs,
              't3d_seg_head_args': abi.SegHeadArgs, 't3d_seg_finalize_args': abi.SegFinalizeArgs,
              't3d_strong_loss_args': abi.StrongLossArgs, 't3d_slab_desc': abi.SlabDesc, 't3d_schedule': abi.Schedule,
-             't3d_strong_weights': abi.StrongWeights}
+             't3d_strong_weights': abi.StrongWeights, 't3d_boxpc_rep_args': abi.BoxPcRepArgs,
+             't3d_boxpc_rep_bwd_args': abi.BoxPcRepBwdArgs, 't3d_boxpc_loss_args': abi.BoxPcLossArgs}
     for cname, cls in pairs.items():
         m = re.search(r'typedef struct \{([^}]*)\}\s*%s;' % cname, h)
         assert m, cname

@@ -98,3 +98,31 @@ def test_unknown_semi_model_raises_like_the_reference():
         pls = MODEL.placeholder_inputs(2, 128, 4)
         with pytest.raises(Exception, match='Not implemented SEMI_MODEL'):
             MODEL.get_semi_model(pls[0], pls[1], pls[2], pls[3], True, False, c=FLAGS)
+
+
+def test_boxpc_reference_call_sequence():
+    """train_boxpc.py:219-261: placeholder_inputs -> convert_raw_y_box_to_reg_format -> get_model -> get_loss -> minimize."""
+    from transferable3d_amd import boxpc_sunrgbd as BOXPC
+    B, N, C = 4, 256, 4
+    FLAGS = make_parser().parse_special_args(['--BOX_PC_MASK_REPRESENTATION', 'A', '--BOXPC_WEIGHT_DELTA', '4'])
+    batch = make_batch(B, N, C, seed=12, boxpc=True)
+    with api.Graph(rt=Runtime(device='cpu', lib=FakeLib()), seed=5).as_default() as g:
+        pls = BOXPC.placeholder_inputs(B, N, C)
+        pc_pl, one_hot_vec_pl, y_seg_pl, x_center_pl, x_orient_cls_pl, x_orient_reg_pl, x_dims_cls_pl, x_dims_reg_pl, \
+            y_box_iou_pl, y_center_delta_pl, y_dims_delta_pl, y_orient_delta_pl = pls
+        box_reg = BOXPC.convert_raw_y_box_to_reg_format((x_center_pl, x_orient_cls_pl, x_orient_reg_pl, x_dims_cls_pl, x_dims_reg_pl),
+                                                        one_hot_vec_pl)
+        pred, end_points = BOXPC.get_model((box_reg, pc_pl), False, one_hot_vec_pl, use_one_hot_vec=False, c=FLAGS)
+        loss = BOXPC.get_loss(pred, (y_box_iou_pl, (y_center_delta_pl, y_dims_delta_pl, y_orient_delta_pl)), end_points, c=FLAGS)
+        sess = api.Session()
+        P0 = {k: torch.tensor(v, dtype=torch.float64) for k, v in g.vars.state_dict().items()}
+        feed = {pc_pl: batch['pc'], one_hot_vec_pl: batch['one_hot_vec'], x_center_pl: batch['y_center'],
+                x_orient_cls_pl: batch['y_orient_cls'], x_orient_reg_pl: batch['y_orient_reg'], x_dims_cls_pl: batch['y_dims_cls'],
+                x_dims_reg_pl: batch['y_dims_reg'], y_box_iou_pl: batch['y_box_iou'], y_center_delta_pl: batch['y_center_delta'],
+                y_dims_delta_pl: batch['y_dims_delta'], y_orient_delta_pl: batch['y_orient_delta']}
+        logits, dc, loss_val = sess.run([pred[0], pred[1][0], loss], feed_dict=feed)
+    c = R.default_config(BOXPC_WEIGHT_DELTA=4.0)
+    lref, ep, _, _ = R.boxpc_forward_backward(P0, batch, c, is_training=False, want_grads=False)
+    assert np.abs(logits - ep['boxpc_fit_logits'].numpy()).max() < 1e-4
+    assert np.abs(dc - ep['boxpc_delta_center'].numpy()).max() < 1e-4
+    assert abs(float(loss_val) - float(lref)) < 1e-4 * float(lref)

@@ -1,0 +1,55 @@
+"""CPU: the Box-PC Fit net plan (train_boxpc.py path, BASELINE config 2) on the NumPy specification library against
+the oracle: representation, forward, loss, gradients, EMA."""
+import numpy as np
+import torch
+
+from fake_t3d import FakeLib
+from model_check import grad_errors
+from oracle import ref_torch as R
+from transferable3d_amd.engine import Runtime
+from transferable3d_amd.nets import BoxPCModel, Graph
+from transferable3d_amd.synthetic import make_batch
+
+SCOPES = lambda B: {'box_pc_mask_model/dp1': ((B, 512), 0.7), 'box_pc_mask_model/dp2': ((B, 256), 0.7)}
+
+
+def run_boxpc(rt, batch, P, c, train=True):
+    B, N, C = batch['pc'].shape
+    g = Graph(B, N, C, rt=rt)
+    m = BoxPCModel(g, c)
+    g.vars.load_state_dict({k: v.detach().cpu().numpy() for k, v in P.items()})
+    m.emit_forward(g.fwd, True, True)
+    if train:
+        m.emit_backward(g.bwd)
+    g.finalize()
+    m.inputs.load(batch)
+    g.fwd.run()
+    if train:
+        g.bwd.run()
+    return g, m
+
+
+def check_boxpc(g, m, batch, P, c):
+    loss, ep, grads, ema = R.boxpc_forward_backward(P, batch, c)
+    e = m.end_points()
+    C = batch['pc'].shape[-1]
+    rep = e['box_pc_rep'].detach().cpu().numpy()[:, :C + 6]
+    assert np.abs(rep - ep['box_pc_rep'].detach().numpy().reshape(rep.shape)).max() < 1e-5
+    out = e['boxpc_out'].detach().cpu().numpy()
+    ref = ep['boxpc_out'].detach().numpy()
+    assert np.abs(out - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+    assert abs(float(e['loss'].detach().cpu()) - float(loss.detach())) < 1e-4 * float(loss.detach())
+    per, glob = grad_errors(g, {k: v.numpy() for k, v in grads.items()})
+    assert np.median(list(per.values())) < 2e-4 and glob < 1e-2, (np.median(list(per.values())), glob)
+    for k, v in ema.items():
+        assert np.abs(g.vars.get(k).detach().cpu().numpy() - v.detach().numpy()).max() < 1e-4 * max(1.0, float(v.abs().max())), k
+
+
+def test_boxpc_plan_matches_oracle():
+    B, N, C = 4, 256, 4
+    batch = make_batch(B, N, C, seed=3, boxpc=True, dropout_scopes=SCOPES(B))
+    P = R.init_params(np.random.RandomState(5), R.layer_table(C, 'boxpc'))
+    c = R.default_config(BOXPC_WEIGHT_DELTA=4.0)         # README.md:79 recipe b
+    assert sum(P[k].numel() for k in R.trainable_names(P)) == 582409 + (C - 4) * 128     # SURVEY 8(a) a15 (C+6=10)
+    g, m = run_boxpc(Runtime(device='cpu', lib=FakeLib()), batch, P, c)
+    check_boxpc(g, m, batch, P, c)

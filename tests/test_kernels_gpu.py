@@ -515,3 +515,58 @@ def test_bad_arguments_are_rejected(hip_lib):
     a.w, a.y, a.psum, a.psumsq = fptr(x), fptr(o), fptr(o), fptr(o)
     a.M, a.K, a.N, a.rows_per_frustum = 130, 64, 64, 130
     assert hip_lib.t3d_pointmlp_fwd(C.byref(a), None) == -2                     # T3D_ERR_SHAPE
+
+
+@pytest.mark.parametrize('label_form', [0, 1])
+def test_boxpc_rep_fwd_bwd_and_loss(hip_lib, label_form):
+    r = np.random.RandomState(31)
+    B, rpf, Cc = 3, 256, 4
+    M, ld = B * rpf, 12
+    pc = r.normal(size=(M, Cc)).astype(np.float32)
+    center = r.normal(size=(B, 3)).astype(np.float32)
+    dims = (r.normal(size=(B, 3)) * 0.1 + (0 if label_form else 1.0)).astype(np.float32)
+    theta = r.uniform(-0.3, 0.3, size=B).astype(np.float32) + (0 if label_form else 1.0)
+    ydc, yoc = r.randint(0, 10, size=B).astype(np.int32), r.randint(0, 12, size=B).astype(np.int32)
+    saved = {}
+
+    def make(dev):
+        t = {k: _mk(dev, v) for k, v in dict(pc=pc, center=center, dims=dims, theta=theta, ydc=ydc, yoc=yoc).items()}
+        o = dict(rep=torch.full((M, ld), 7.0, device=dev), box=torch.zeros(B, 7, device=dev))
+        a = abi.BoxPcRepArgs(fptr(t['pc']), Cc, Cc, fptr(t['center']), fptr(t['dims']), fptr(t['theta']),
+                             iptr(t['ydc'] if label_form else None), iptr(t['yoc'] if label_form else None), fptr(o['rep']), ld,
+                             fptr(o['box']), M, rpf)
+        a._keep = (t, o)
+        saved[dev.type] = (t, o)
+        return a, o
+    c, g = _run_both(hip_lib, make, 't3d_boxpc_rep')
+    _close(c['rep'], g['rep'], 1e-5, 1e-5, 'rep')
+    _close(c['box'], g['box'], 1e-6, 1e-6, 'box')
+
+    drep = (r.normal(size=(M, 16)) * 1e-2).astype(np.float32)
+
+    def make_b(dev):
+        t, o = saved[dev.type]
+        d = _mk(dev, drep)
+        box = _mk(dev, saved['cpu'][1]['box'].numpy())
+        out = dict(dbox=torch.zeros(B, 7, device=dev))
+        a = abi.BoxPcRepBwdArgs(fptr(t['pc']), Cc, fptr(box), fptr(d), 16, 4, fptr(out['dbox']), B, rpf)
+        a._keep = (d, box, out)
+        return a, out
+    c, g = _run_both(hip_lib, make_b, 't3d_boxpc_rep_bwd')
+    _close(c['dbox'], g['dbox'], 1e-4, 1e-5, 'dbox')
+
+    Bl = 32
+    out9 = r.normal(size=(Bl, 9)).astype(np.float32)
+    iou = r.uniform(size=Bl).astype(np.float32)
+    dc, ds, da = [(r.normal(size=s) * 0.7).astype(np.float32) for s in ((Bl, 3), (Bl, 3), (Bl,))]
+    for conf, gt in ((0, 0), (1, 0), (0, 1)):
+        def make_l(dev):
+            t = {k: _mk(dev, v) for k, v in dict(o=out9, iou=iou, dc=dc, ds=ds, da=da).items()}
+            o = dict(dout=torch.zeros(Bl, 9, device=dev), terms=torch.zeros(Bl, 4, device=dev), loss=torch.zeros(1, device=dev))
+            a = abi.BoxPcLossArgs(fptr(t['o']), fptr(t['iou']), fptr(t['dc']), fptr(t['ds']), fptr(t['da']), 0.7, 1.0, 4.0, 0.34,
+                                  0.33, 0.33, conf, gt, fptr(o['dout']), fptr(o['terms']), fptr(o['loss']), Bl)
+            a._keep = (t, o)
+            return a, o
+        c, g = _run_both(hip_lib, make_l, 't3d_boxpc_loss')
+        for k in c:
+            _close(c[k], g[k], 1e-5, 1e-6, 'boxpc_loss ' + k)

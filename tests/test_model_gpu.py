@@ -83,3 +83,15 @@ def test_full_size_properties(hip_lib):
     assert abs(float(e2['loss']) - float(e1['loss'])) < 1e-5 * float(e1['loss'])
     rel = float((g2.vars.grads - grads1).norm() / grads1.norm())
     assert rel < 1e-3, rel
+
+
+def test_boxpc_step_matches_oracle(hip_lib):
+    """BASELINE config 2: Box-PC Fit net (train_boxpc.py path), forward + backward on the GPU vs the oracle."""
+    from test_boxpc_cpu import SCOPES, check_boxpc, run_boxpc
+    B, N, C = 8, 256, 4
+    batch = make_batch(B, N, C, seed=4, boxpc=True, dropout_scopes=SCOPES(B))
+    P = R.init_params(np.random.RandomState(6), R.layer_table(C, 'boxpc'))
+    c = R.default_config(BOXPC_WEIGHT_DELTA=4.0)
+    g, m = run_boxpc(Runtime(lib=hip_lib), batch, P, c)
+    torch.cuda.synchronize()
+    check_boxpc(g, m, batch, P, c)

@@ -121,14 +121,19 @@ class Schedule(C.Structure):
 
 
 class BoxPcRepArgs(C.Structure):
-    _fields_ = [('pc', F), ('ld_pc', i32), ('C', i32), ('center', F), ('dims', F), ('theta', F), ('rep', F),
-                ('ld_rep', i32), ('M', i32), ('rows_per_frustum', i32)]
+    _fields_ = [('pc', F), ('ld_pc', i32), ('C', i32), ('center', F), ('dims', F), ('theta', F), ('y_dims_cls', I),
+                ('y_orient_cls', I), ('rep', F), ('ld_rep', i32), ('box_out', F), ('M', i32), ('rows_per_frustum', i32)]
 
 
 class BoxPcRepBwdArgs(C.Structure):
-    _fields_ = [('pc', F), ('ld_pc', i32), ('C', i32), ('center', F), ('dims', F), ('theta', F),
-                ('colsum', F), ('ld_colsum', i32), ('drep', F), ('ld_drep', i32),
-                ('dcenter', F), ('ddims', F), ('dtheta', F), ('M', i32), ('rows_per_frustum', i32), ('B', i32)]
+    _fields_ = [('pc', F), ('ld_pc', i32), ('box', F), ('drep', F), ('ld_drep', i32), ('coff', i32), ('dbox', F),
+                ('B', i32), ('rows_per_frustum', i32)]
+
+
+class BoxPcLossArgs(C.Structure):
+    _fields_ = [('out', F), ('y_box_iou', F), ('y_center_delta', F), ('y_dims_delta', F), ('y_orient_delta', F),
+                ('fit_bound', f32), ('w_cls', f32), ('w_delta', f32), ('w_center', f32), ('w_size', f32), ('w_angle', f32),
+                ('weigh_by_cls_conf', i32), ('weigh_by_cls_gt', i32), ('dout', F), ('terms', F), ('loss', F), ('B', i32)]
 
 
 VP = C.c_void_p
@@ -149,6 +154,9 @@ ENTRY_POINTS = {
     't3d_seg_head': [C.POINTER(SegHeadArgs), VP],
     't3d_seg_finalize': [C.POINTER(SegFinalizeArgs), VP],
     't3d_strong_loss': [C.POINTER(StrongLossArgs), VP],
+    't3d_boxpc_rep': [C.POINTER(BoxPcRepArgs), VP],
+    't3d_boxpc_rep_bwd': [C.POINTER(BoxPcRepBwdArgs), VP],
+    't3d_boxpc_loss': [C.POINTER(BoxPcLossArgs), VP],
     't3d_reduce_slabs': [F, F, C.POINTER(SlabDesc), i32, i32, VP],
     't3d_schedule_step': [F, C.POINTER(Schedule), VP],
     't3d_adam_tf_step': [F, F, F, F, C.c_int64, F, f32, f32, f32, f32, VP],

@@ -43,7 +43,7 @@ class Tensor:
     shape = property(get_shape)
 
     def numpy(self):
-        return self.buf.detach().reshape(self._shape).cpu().numpy()
+        return self.buf.detach().cpu().numpy().reshape(self._shape)
 
     def __repr__(self):
         return 'Tensor(%s, shape=%s)' % (self.name, self._shape)

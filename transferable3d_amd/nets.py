@@ -399,3 +399,103 @@ class SemiModelA(ModelAssembly):
         self.tnet = TNet(g, scope_prefix + 'tnet', use_one_hot)
         self.box = BoxEstNet(g, scope_prefix + 'box_est', use_one_hot)
         self.loss_op = StrongLoss(g)
+
+
+class BoxPCNet:
+    """Box-PC Fit network, representation 'A' (combined_box_pc_mask_features_model, semisup_models.py:326-398, under
+    the literal scope `box_pc_mask_model`; boxpc_sunrgbd.get_model 56-100)."""
+
+    def __init__(self, g, scope_prefix='', use_one_hot=False):
+        self.g = g
+        s = scope_prefix + 'box_pc_mask_model/'
+        self.scope = s
+        C_ = g.C
+        self.ld_rep = (C_ + 6 + 3) // 4 * 4
+        self.rep = g.rt.zeros(g.M, self.ld_rep)
+        self.box7 = g.rt.zeros(g.B, 7)
+        oh = NUM_CLASS if use_one_hot else 0
+        self.oh = oh
+        self.P1 = PointLayer(g, s + 'conv-reg1', C_ + 6, 128, kernel_1xD=True)
+        self.P2 = PointLayer(g, s + 'conv-reg2', 128, 128)
+        self.P3 = PointLayer(g, s + 'conv-reg3', 128, 256)
+        self.P4 = PointLayer(g, s + 'conv-reg4', 256, 512, pool=True)
+        self.F1 = FcLayer(g, s + 'fc1', 512, 512, K2=oh, keep_prob=0.7, drop_scope=s + 'dp1')
+        self.F2 = FcLayer(g, s + 'fc2', 512, 256, keep_prob=0.7, drop_scope=s + 'dp2')
+        self.F3 = FcLayer(g, s + 'fc3', 256, 9, bn=False, act=None)
+
+    def fwd(self, plan, pc, center, dims, theta, one_hot, is_training, y_dims_cls=None, y_orient_cls=None):
+        g = self.g
+        a = abi.BoxPcRepArgs(fptr(pc), g.C, g.C, fptr(center), fptr(dims), fptr(theta), iptr(y_dims_cls), iptr(y_orient_cls),
+                             fptr(self.rep), self.ld_rep, fptr(self.box7), g.M, g.rpf)
+        plan.add('t3d_boxpc_rep', a)
+        x = ActSpec(self.rep, self.ld_rep, g.C + 6)
+        x = self.P1.fwd(plan, x, is_training)
+        x = self.P2.fwd(plan, x, is_training)
+        x = self.P3.fwd(plan, x, is_training)
+        self.P4.fwd(plan, x, is_training)
+        f = self.F1.fwd(plan, self.P4.pooled, 512, is_training, in2=one_hot if self.oh else None, ld_in2=NUM_CLASS)
+        f = self.F2.fwd(plan, f, 512, is_training)
+        self.out = self.F3.fwd(plan, f, 256, is_training)
+        return self.out
+
+    def bwd(self, plan, dout, param_grads=True):
+        self.F3.bwd(plan, dout=dout, ld_dout=9, param_grads=param_grads)
+        self.F2.bwd(plan, nxt=self.F3, param_grads=param_grads)
+        self.F1.bwd(plan, nxt=self.F2, param_grads=param_grads)
+        dfeat = self.F1.dinput(plan, K=512)
+        self.P4.bn_bwd(plan, dpool_in=dfeat, ld_dpool_in=512, param_grads=param_grads)
+        if param_grads:
+            self.P4.wgrad(plan)
+        self.P4.dgrad(plan)
+        for lay in (self.P3, self.P2):
+            lay.bn_bwd(plan, param_grads=param_grads)
+            if param_grads:
+                lay.wgrad(plan)
+            lay.dgrad(plan)
+        self.P1.bn_bwd(plan, param_grads=param_grads)
+        if param_grads:
+            self.P1.wgrad(plan)
+
+
+class BoxPCLoss:
+    def __init__(self, g):
+        self.g = g
+        rt, B = g.rt, g.B
+        self.dout, self.terms, self.loss = rt.zeros(B, 9), rt.zeros(B, 4), rt.zeros(1)
+
+    def emit(self, plan, out, x, c):
+        a = abi.BoxPcLossArgs(fptr(out), fptr(x.y_box_iou), fptr(x.y_center_delta), fptr(x.y_dims_delta), fptr(x.y_orient_delta),
+                              c.BOXPC_FIT_BOUNDS[0], c.BOXPC_WEIGHT_CLS, c.BOXPC_WEIGHT_DELTA, c.BOXPC_WEIGHT_DELTA_CENTER_PERCENT,
+                              c.BOXPC_WEIGHT_DELTA_SIZE_PERCENT, c.BOXPC_WEIGHT_DELTA_ANGLE_PERCENT,
+                              int(c.BOXPC_WEIGH_DELTA_LOSS_BY_CLS_CONF), int(c.BOXPC_WEIGH_DELTA_LOSS_BY_CLS_GT),
+                              fptr(self.dout), fptr(self.terms), fptr(self.loss), self.g.B)
+        plan.add('t3d_boxpc_loss', a)
+
+
+class BoxPCModel:
+    """Stage-b training graph (train_boxpc.py:219-261): GT box (label form) + point cloud -> Box-PC net -> loss."""
+
+    def __init__(self, g, c, use_one_hot=False, inputs=None):
+        assert c.BOX_PC_MASK_REPRESENTATION in ('A', ''), 'representation B is in no published recipe (out of scope)'
+        assert c.BOXPC_DELTA_LOSS_TYPE == 'huber' and not c.BOXPC_WEIGH_DELTA_PRED_BY_CLS_CONF
+        self.g, self.c = g, c
+        self.inputs = inputs or Inputs(g)
+        self.net = BoxPCNet(g, '', use_one_hot)
+        self.loss_op = BoxPCLoss(g)
+
+    def emit_forward(self, plan, is_training, with_loss):
+        x = self.inputs
+        out = self.net.fwd(plan, x.pc, x.y_center, x.y_dims_reg, x.y_orient_reg, x.one_hot_vec, is_training,
+                           y_dims_cls=x.y_dims_cls, y_orient_cls=x.y_orient_cls)
+        if with_loss:
+            self.loss_op.emit(plan, out, x, self.c)
+
+    def emit_backward(self, plan):
+        self.net.bwd(plan, self.loss_op.dout)
+        self.g.emit_reduce_slabs(plan)
+
+    def end_points(self):
+        n = self.net
+        return {'boxpc_out': n.out, 'box_pc_rep': n.rep, 'loss': self.loss_op.loss, 'terms': self.loss_op.terms,
+                'boxpc_fit_logits': n.out[:, 7:9], 'boxpc_delta_center': n.out[:, 0:3], 'boxpc_delta_size': n.out[:, 3:6],
+                'boxpc_delta_angle': n.out[:, 6], 'feats_lv1': n.P4.pooled}
