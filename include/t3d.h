@@ -396,6 +396,55 @@ typedef struct {
 } t3d_boxpc_loss_args;
 int t3d_boxpc_loss(const t3d_boxpc_loss_args* args, t3d_stream_t stream);
 
+/* ---- stage-c glue (SEMI_MODEL F with the frozen Box-PC net; train_semisup_adv.py:331-411) ---------------- */
+
+/* Input gradient of a per-point layer restricted to kn <= 8 input channels k0..k0+kn-1 (dense dy only):
+ * out[m, j] = sum_n dy[m,n] w[k0+j, n].  Used for the six distance channels of the Box-PC representation.
+ * M % 64 == 0, N % 128 == 0. */
+typedef struct {
+  t3d_dy_src dy;
+  const float* w;          /* [K,N] */
+  int k0, kn;
+  float* out; int ld_out;  /* [M, ld_out] */
+  int M, N;
+} t3d_pointmlp_dgrad_narrow_args;
+int t3d_pointmlp_dgrad_narrow(const t3d_pointmlp_dgrad_narrow_args* args, t3d_stream_t stream);
+
+/* get_semi_loss_final's weak terms (semisup_v1_sunrgbd.py:343-407) on top of the strong loss already computed by
+ * t3d_strong_loss(normalize_by_3d_count = 1):
+ *   loss = strong + w_weak * intraclass(reg_dims | class) + w_fit * mean_b(-log(0.01 + p_fit[b]) * (fit_only_2d ? is2D : 1))
+ * with w_weak = SEMI_MULTIPLIER_FOR_WEAK_LOSS * WEAK_WEIGHT_INTRACLASSVAR, the intraclass-variance loss of
+ * weak_losses.py:267-291 (huber), p_fit = softmax(out9[:,7:9])[:,1].  Writes the gradients w.r.t. reg_dims and out9. */
+typedef struct {
+  const float* strong_loss;       /* [1] device scalar */
+  const float* reg_dims;          /* [B,3] */
+  const float* one_hot;           /* [B,10] class one-hot (class_ids = argmax) */
+  const int32_t* is_data_2D;      /* [B] */
+  const float* out9;              /* [B,9] Box-PC output */
+  int32_t train_classes[10];
+  float w_weak, w_fit;
+  int fit_only_2d;
+  float* d_dims;                  /* [B,3] */
+  float* dout9;                   /* [B,9] */
+  float* fit_prob;                /* [B] end_points['boxpc_fit_prob'] */
+  float* terms;                   /* [2]: intraclass loss, fit loss */
+  float* loss;                    /* [1] */
+  int B;
+} t3d_semi_final_loss_args;
+int t3d_semi_final_loss(const t3d_semi_final_loss_args* args, t3d_stream_t stream);
+
+/* Backward of the anchor->reg conversion (tf_util.py:1017-1031): accumulates the gradient of (centre, dims, theta)
+ * -- dbox7[B,7] from the Box-PC path and/or d_dims[B,3] -- into dbox[B,67] and dstage1[B,3] (both in/out). */
+typedef struct {
+  const float* box; int ld_box;   /* [B,67] head output (scores pick the bins) */
+  const float* dbox7;             /* [B,7] or NULL */
+  const float* d_dims;            /* [B,3] or NULL */
+  float* dbox;                    /* [B,67] in/out */
+  float* dstage1;                 /* [B,3] in/out */
+  int B;
+} t3d_anchor_reg_bwd_args;
+int t3d_anchor_reg_bwd(const t3d_anchor_reg_bwd_args* args, t3d_stream_t stream);
+
 /* ---- K11d / K12 / schedules --------------------------------------------------------------------- */
 
 /* grad[off_i + e] = sum_s slabs_i[s, e]  for every tensor i of a device-side table. */

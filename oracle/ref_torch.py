@@ -699,3 +699,36 @@ def boxpc_forward_backward(P, batch, c, bn_decay_val=0.5, dtype=torch.float64, i
         gl = torch.autograd.grad(loss, [Pl[k] for k in names], allow_unused=True)
         grads = {k: (g if g is not None else torch.zeros_like(Pl[k])) for k, g in zip(names, gl)}
     return loss, ep, grads, ctx.ema_updates
+
+
+def stage_c_forward_backward(P, batch, c, train_classes, bn_decay_val=0.5, dtype=torch.float64, use_one_hot=True,
+                             var_prefixes=('class_dependent', 'class_agnostic/tnet', 'class_agnostic/box'), want_grads=True):
+    """One stage-c step (train_semisup_adv.py:308-422, SEMI_MODEL F): class-agnostic nets + box_refine, the frozen
+    Box-PC net (`D_boxpc_branch/`, is_training_D = False when SEMI_TRAIN_BOXPC_MODEL = 0) applied to F_pred_box_reg,
+    get_semi_loss_final, gradients w.r.t. the var_list (regex-prefix semantics of get_scope_vars)."""
+    names = [k for k in trainable_names(P) if any(k.startswith(p) for p in var_prefixes)]
+    Pl = {k: (val.detach().to(dtype).requires_grad_(k in names and want_grads)) for k, val in P.items()}
+    masks = {k: torch.as_tensor(val) for k, val in batch.get('dropout_masks', {}).items()}
+    ctx = Ctx(Pl, is_training=True, bn_decay=bn_decay_val, dropout_masks=masks)
+    ctx.is_training_override['D_boxpc_branch/'] = False
+    pc = torch.as_tensor(batch['pc'], dtype=dtype)
+    oh = torch.as_tensor(batch['one_hot_vec'], dtype=dtype)
+    pred, ep = get_semi_model_final(ctx, pc, oh, use_one_hot, c)
+    _, ep_b = boxpc_get_model(ctx, ep['F_pred_box_reg'], pc, oh, False, c, scope_prefix='D_boxpc_branch/')
+    ep['boxpc_fit_prob'] = torch.softmax(ep_b['boxpc_fit_logits'], dim=-1)[:, 1]
+    ep['boxpc_out'] = ep_b['boxpc_out']
+    ep['box_pc_rep'] = ep_b['box_pc_rep']
+    ep['intraclsdims_train_classes'] = train_classes
+    loss = get_semi_loss_final(pred, _labels_to_torch(batch, dtype), ep, c)
+    grads = {}
+    if want_grads:
+        gl = torch.autograd.grad(loss, [Pl[k] for k in names], allow_unused=True)
+        grads = {k: (g if g is not None else torch.zeros_like(Pl[k])) for k, g in zip(names, gl)}
+    return loss, ep, grads, ctx.ema_updates
+
+
+def stage_c_params(rng, num_channels, dtype=torch.float64, use_one_hot=True):
+    """Variables of the stage-c graph: model F under class_agnostic/ + class_dependent/, Box-PC under D_boxpc_branch/."""
+    P = init_params(rng, layer_table(num_channels, 'F', use_one_hot=use_one_hot), dtype)
+    P.update(init_params(rng, layer_table(num_channels, 'boxpc', prefix_agnostic='D_boxpc_branch/'), dtype))
+    return P

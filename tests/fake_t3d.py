@@ -592,6 +592,73 @@ class FakeLib:
         arr(p.loss, 1)[0] = total.mean()
         return 0
 
+    # ---- stage-c glue --------------------------------------------------------------------------------
+    def t3d_pointmlp_dgrad_narrow(self, a, stream):
+        p = _struct(a)
+        dy = _dy(p.dy, p.M, p.N, p.M)
+        K = p.k0 + p.kn
+        w = arr(p.w, K, p.N).astype(np.float64)[p.k0:]
+        arr(p.out, p.M, p.ld_out)[:, :p.kn] = dy @ w.T
+        return 0
+
+    def t3d_semi_final_loss(self, a, stream):
+        p = _struct(a)
+        B = p.B
+        dims = arr(p.reg_dims, B, 3).astype(np.float64)
+        cls = arr(p.one_hot, B, 10).argmax(1)
+        tc = [bool(p.train_classes[i]) for i in range(10)]
+        T = sum(tc)
+        gd = np.zeros((B, 3))
+        intra = 0.0
+        hub = lambda e: 0.5 * np.minimum(np.abs(e), 1) ** 2 + (np.abs(e) - np.minimum(np.abs(e), 1))
+        if p.w_weak != 0 and T > 0:
+            for i in range(10):
+                sel = cls == i
+                if not tc[i] or sel.sum() == 0:
+                    continue
+                e = dims[sel] - dims[sel].mean(0)
+                intra += hub(e).mean() / T
+                gd[sel] = p.w_weak * np.clip(e, -1, 1) / (3 * sel.sum() * T)
+        arr(p.d_dims, B, 3)[:] = gd
+        o = arr(p.out9, B, 9).astype(np.float64)
+        lg = o[:, 7:9]
+        mx = lg.max(1, keepdims=True)
+        lse = mx[:, 0] + np.log(np.exp(lg - mx).sum(1))
+        pf = np.exp(lg[:, 1] - lse)
+        m = arr(p.is_data_2D, B).astype(np.float64) if p.fit_only_2d else np.ones(B)
+        fit = (-np.log(0.01 + pf) * m).mean()
+        dp = -p.w_fit * m / ((0.01 + pf) * B)
+        g = arr(p.dout9, B, 9)
+        g[:] = 0
+        g[:, 7] = -dp * pf * (1 - pf)
+        g[:, 8] = dp * pf * (1 - pf)
+        arr(p.fit_prob, B)[:] = pf
+        arr(p.terms, 2)[:] = [intra, fit]
+        arr(p.loss, 1)[0] = float(arr(p.strong_loss, 1)[0]) + p.w_weak * intra + p.w_fit * fit
+        return 0
+
+    def t3d_anchor_reg_bwd(self, a, stream):
+        p = _struct(a)
+        B = p.B
+        o = arr(p.box, B, p.ld_box)[:, :67].astype(np.float64)
+        g, ds1 = arr(p.dbox, B, 67), arr(p.dstage1, B, 3)
+        js, ks = o[:, 3:15].argmax(1), o[:, 27:37].argmax(1)
+        gc, gd, gt = np.zeros((B, 3)), np.zeros((B, 3)), np.zeros(B)
+        if p.dbox7:
+            q = arr(p.dbox7, B, 7).astype(np.float64)
+            gc, gd, gt = q[:, 0:3].copy(), q[:, 3:6].copy(), q[:, 6].copy()
+        if p.d_dims:
+            gd = gd + arr(p.d_dims, B, 3)
+        mean = MEAN32.astype(np.float64)
+        for b in range(B):
+            g[b, 0:3] += gc[b]
+            ds1[b] += gc[b]
+            k = ks[b]
+            raw = mean[k] + o[b, 37 + 3 * k:40 + 3 * k] * mean[k]
+            g[b, 37 + 3 * k:40 + 3 * k] += np.where(raw > 1e-5, gd[b] * mean[k], 0.0)
+            g[b, 15 + js[b]] += gt[b] * (np.pi / 12)
+        return 0
+
     # ---- optimiser -------------------------------------------------------------------------------
     def t3d_reduce_slabs(self, slab_base, grad_base, table, n_tensors, max_numel, stream):
         for i in range(n_tensors):

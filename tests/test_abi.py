@@ -34,7 +34,9 @@ def test_ctypes_structs_follow_header_field_order():
              't3d_seg_head_args': abi.SegHeadArgs, 't3d_seg_finalize_args': abi.SegFinalizeArgs,
              't3d_strong_loss_args': abi.StrongLossArgs, 't3d_slab_desc': abi.SlabDesc, 't3d_schedule': abi.Schedule,
              't3d_strong_weights': abi.StrongWeights, 't3d_boxpc_rep_args': abi.BoxPcRepArgs,
-             't3d_boxpc_rep_bwd_args': abi.BoxPcRepBwdArgs, 't3d_boxpc_loss_args': abi.BoxPcLossArgs}
+             't3d_boxpc_rep_bwd_args': abi.BoxPcRepBwdArgs, 't3d_boxpc_loss_args': abi.BoxPcLossArgs,
+             't3d_pointmlp_dgrad_narrow_args': abi.DgradNarrowArgs, 't3d_semi_final_loss_args': abi.SemiFinalLossArgs,
+             't3d_anchor_reg_bwd_args': abi.AnchorRegBwdArgs}
     for cname, cls in pairs.items():
         m = re.search(r'typedef struct \{([^}]*)\}\s*%s;' % cname, h)
         assert m, cname
@@ -45,7 +47,7 @@ def test_ctypes_structs_follow_header_field_order():
             if not decl:
                 continue
             for part in decl.split(','):
-                names.append(re.findall(r'(\w+)\s*$', part.strip())[0])
+                names.append(re.findall(r'(\w+)(?:\[\d+\])?\s*$', part.strip())[0])
         py = [f[0].rstrip('_') for f in cls._fields_]
         assert names == py, (cname, names, py)
 

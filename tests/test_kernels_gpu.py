@@ -570,3 +570,62 @@ def test_boxpc_rep_fwd_bwd_and_loss(hip_lib, label_form):
         c, g = _run_both(hip_lib, make_l, 't3d_boxpc_loss')
         for k in c:
             _close(c[k], g[k], 1e-5, 1e-6, 'boxpc_loss ' + k)
+
+
+def test_stage_c_glue_kernels(hip_lib):
+    r = np.random.RandomState(41)
+    M, N, Kin = 512, 128, 10
+    dz = (r.normal(size=(M, N)) * 1e-2).astype(np.float32)
+    y = r.normal(size=(M, N)).astype(np.float32)
+    coef = r.normal(size=(3, N)).astype(np.float32)
+    w = r.normal(size=(Kin, N)).astype(np.float32)
+
+    def make_n(dev):
+        t = {k: _mk(dev, v) for k, v in dict(dz=dz, y=y, coef=coef, w=w).items()}
+        o = dict(out=torch.zeros(M, 8, device=dev))
+        a = abi.DgradNarrowArgs(abi.DySrc(fptr(t['dz']), fptr(t['y']), fptr(t['coef']), iptr(None), fptr(None)), fptr(t['w']), 4, 6,
+                                fptr(o['out']), 8, M, N)
+        a._keep = (t, o)
+        return a, o
+    c, g = _run_both(hip_lib, make_n, 't3d_pointmlp_dgrad_narrow')
+    _close(c['out'], g['out'], 1e-4, 1e-4 * float(c['out'].abs().max()), 'dgrad_narrow')
+
+    B = 32
+    strong = np.array([3.25], np.float32)
+    dims = (1.0 + r.normal(size=(B, 3)) * 0.8).astype(np.float32)
+    cls = r.randint(0, 10, size=B)
+    oh = np.eye(10, dtype=np.float32)[cls]
+    is2d = (r.uniform(size=B) < 0.5).astype(np.int32)
+    out9 = r.normal(size=(B, 9)).astype(np.float32)
+    for only2d in (0, 1):
+        def make_l(dev):
+            t = {k: _mk(dev, v) for k, v in dict(strong=strong, dims=dims, oh=oh, is2d=is2d, out9=out9).items()}
+            o = dict(d_dims=torch.zeros(B, 3, device=dev), dout9=torch.zeros(B, 9, device=dev), fit=torch.zeros(B, device=dev),
+                     terms=torch.zeros(2, device=dev), loss=torch.zeros(1, device=dev))
+            a = abi.SemiFinalLossArgs()
+            a.strong_loss, a.reg_dims, a.one_hot, a.is_data_2D, a.out9 = fptr(t['strong']), fptr(t['dims']), fptr(t['oh']), iptr(t['is2d']), fptr(t['out9'])
+            for i in range(10):
+                a.train_classes[i] = int(i in (1, 2, 6, 7, 8))
+            a.w_weak, a.w_fit, a.fit_only_2d = 0.1, 1.0, only2d
+            a.d_dims, a.dout9, a.fit_prob, a.terms, a.loss, a.B = fptr(o['d_dims']), fptr(o['dout9']), fptr(o['fit']), fptr(o['terms']), fptr(o['loss']), B
+            a._keep = (t, o)
+            return a, o
+        c, g = _run_both(hip_lib, make_l, 't3d_semi_final_loss')
+        for k in c:
+            _close(c[k], g[k], 1e-5, 1e-6, 'semi_final_loss ' + k)
+
+    box = r.normal(size=(B, 67)).astype(np.float32)
+    box[0, 37:67] = -1.5                                   # anchor + res*mean < 1e-5: the max() clamp kills that gradient
+    dbox7 = r.normal(size=(B, 7)).astype(np.float32)
+    dd = r.normal(size=(B, 3)).astype(np.float32)
+    g0, s0 = r.normal(size=(B, 67)).astype(np.float32), r.normal(size=(B, 3)).astype(np.float32)
+
+    def make_a(dev):
+        t = {k: _mk(dev, v) for k, v in dict(box=box, dbox7=dbox7, dd=dd).items()}
+        o = dict(dbox=_mk(dev, g0.copy()), ds1=_mk(dev, s0.copy()))
+        a = abi.AnchorRegBwdArgs(fptr(t['box']), 67, fptr(t['dbox7']), fptr(t['dd']), fptr(o['dbox']), fptr(o['ds1']), B)
+        a._keep = (t, o)
+        return a, o
+    c, g = _run_both(hip_lib, make_a, 't3d_anchor_reg_bwd')
+    _close(c['dbox'], g['dbox'], 1e-5, 1e-6, 'anchor_reg_bwd dbox')
+    _close(c['ds1'], g['ds1'], 1e-6, 1e-6, 'anchor_reg_bwd ds1')

@@ -95,3 +95,15 @@ def test_boxpc_step_matches_oracle(hip_lib):
     g, m = run_boxpc(Runtime(lib=hip_lib), batch, P, c)
     torch.cuda.synchronize()
     check_boxpc(g, m, batch, P, c)
+
+
+def test_stage_c_step_matches_oracle(hip_lib):
+    """BASELINE config 3 (one replica): SEMI_MODEL F + frozen Box-PC net, forward + backward on the GPU vs the oracle."""
+    from test_stage_c_cpu import check_stage_c, run_stage_c, stage_c_batch, stage_c_config, stage_c_params
+    B, N, C = 8, 256, 4
+    batch = stage_c_batch(B, N, C, seed=7, n2d=4)
+    P = stage_c_params(C, 9)
+    c = stage_c_config()
+    g, m = run_stage_c(Runtime(lib=hip_lib), batch, P, c)
+    torch.cuda.synchronize()
+    print(check_stage_c(g, m, batch, P, c, grad_median_tol=1e-3))

@@ -1,0 +1,97 @@
+"""CPU: SEMI_MODEL F / stage c (BASELINE config 3, single replica) on the NumPy specification library against the
+oracle: forward tensors, the three loss parts, and the gradients of the reference's var_list."""
+import numpy as np
+import torch
+
+from fake_t3d import FakeLib
+from model_check import grad_errors
+from oracle import ref_torch as R
+from transferable3d_amd.engine import Runtime
+from transferable3d_amd.nets import Graph, SemiModelF
+from transferable3d_amd.synthetic import make_batch
+
+TRAIN_CLASSES = [i in (1, 2, 6, 7, 8) for i in range(10)]     # SUNRGBD_SEMI_TEST_CLS of recipe c (README.md:84-99)
+
+
+def stage_c_config():
+    return R.default_config(SEMI_MODEL='F', WEAK_WEIGHT_INTRACLASSVAR=2.0, SEMI_MULTIPLIER_FOR_WEAK_LOSS=0.05,
+                            SEMI_BOXPC_FIT_ONLY_ON_2D_CLS=True, SEMI_WEIGHT_BOXPC_FIT_LOSS=1.0)
+
+
+def stage_c_batch(B, N, C, seed, n2d):
+    b = make_batch(B, N, C, seed=seed, dropout_scopes={'class_agnostic/inst_seg/dp1': ((B, N, 128), 0.5),
+                                                       'class_dependent/box_refine/dp0': ((B, 512), 0.5),
+                                                       'class_dependent/box_refine/dp1': ((B, 256), 0.5)})
+    b['is_data_2D'][:n2d] = 1
+    return b
+
+
+def stage_c_params(C, seed):
+    P = R.stage_c_params(np.random.RandomState(seed), C)
+    r = np.random.RandomState(seed + 1)
+    for k in P:                                  # a "pre-trained" frozen Box-PC net: non-trivial moving statistics
+        if k.startswith('D_boxpc') and k.endswith('moving_variance'):
+            P[k] = torch.tensor(r.uniform(0.5, 1.5, size=P[k].shape))
+        if k.startswith('D_boxpc') and k.endswith('moving_mean'):
+            P[k] = torch.tensor(r.normal(0, 0.2, size=P[k].shape))
+    return P
+
+
+def run_stage_c(rt, batch, P, c):
+    B, N, C = batch['pc'].shape
+    g = Graph(B, N, C, rt=rt)
+    m = SemiModelF(g, c, use_one_hot=True, train_classes=TRAIN_CLASSES)
+    g.vars.load_state_dict({k: v.detach().cpu().numpy() for k, v in P.items()})
+    m.emit_forward(g.fwd, True, True)
+    m.emit_backward(g.bwd)
+    g.finalize()
+    m.inputs.load(batch)
+    g.fwd.run()
+    g.bwd.run()
+    return g, m
+
+
+def check_stage_c(g, m, batch, P, c, grad_median_tol=2e-4):
+    loss, ep, grads, ema = R.stage_c_forward_backward(P, batch, c, TRAIN_CLASSES)
+    e = m.end_points()
+    num = lambda t: t.detach().cpu().numpy()
+    for mine, ref in (('logits', ep['logits']), ('stage1_center', ep['stage1_center']), ('feats_lv1', ep['feats_lv1']),
+                      ('F_box_params', ep['F_box_params']), ('F_center', ep['F_center']), ('boxpc_out', ep['boxpc_out']),
+                      ('boxpc_fit_prob', ep['boxpc_fit_prob']), ('F_dims', ep['F_pred_box_reg'][1]), ('F_theta', ep['F_pred_box_reg'][2])):
+        r = ref.detach().numpy()
+        assert np.abs(num(e[mine]).reshape(r.shape) - r).max() < 1e-4 * max(1.0, np.abs(r).max()), mine
+    assert abs(float(num(e['loss'])) - float(loss.detach())) < 1e-4 * float(loss.detach())
+    assert abs(float(num(e['terms'])[0]) - float(ep['intraclass_variance_loss'].detach())) < 1e-5
+    per, glob = grad_errors(g, {k: v.numpy() for k, v in grads.items()})
+    med = float(np.median(list(per.values())))
+    assert med < grad_median_tol and glob < 1e-2, (med, glob, sorted(per.items(), key=lambda kv: -kv[1])[:4])
+    # nothing outside the var_list may receive a gradient
+    assert float(g.vars.grad('class_agnostic/inst_seg/conv3/weights').abs().max()) == 0.0
+    assert float(g.vars.grad('D_boxpc_branch/box_pc_mask_model/fc1/weights').abs().max()) == 0.0
+    assert float(g.vars.grad('class_agnostic/box_est/fc2/weights').abs().max()) == 0.0
+    for k, v in ema.items():                                 # seg / tnet / box EMAs update, the frozen Box-PC ones do not
+        assert np.abs(num(g.vars.get(k)) - v.detach().numpy()).max() < 1e-4 * max(1.0, float(v.abs().max())), k
+    k = 'D_boxpc_branch/box_pc_mask_model/conv-reg2/bn/moving_mean'
+    assert np.array_equal(num(g.vars.get(k)), P[k].numpy().astype(np.float32))
+    return med, glob
+
+
+def test_stage_c_plan_matches_oracle():
+    B, N, C = 6, 256, 4
+    batch = stage_c_batch(B, N, C, seed=2, n2d=3)
+    P = stage_c_params(C, 1)
+    c = stage_c_config()
+    g, m = run_stage_c(Runtime(device='cpu', lib=FakeLib()), batch, P, c)
+    check_stage_c(g, m, batch, P, c)
+
+
+def test_stage_c_all_3d_batch_has_zero_fit_and_intraclass_terms():
+    """ALTERNATE_BATCH's all-3D batch: FIT_ONLY_ON_2D masks the fit loss; the trained (2-D) classes still get an intraclass
+    term from whatever frustums of those classes are present (semisup_v1_sunrgbd.py:361-407)."""
+    B, N, C = 4, 256, 4
+    batch = stage_c_batch(B, N, C, seed=5, n2d=0)
+    P = stage_c_params(C, 3)
+    c = stage_c_config()
+    g, m = run_stage_c(Runtime(device='cpu', lib=FakeLib()), batch, P, c)
+    assert float(m.end_points()['terms'][1]) == 0.0
+    check_stage_c(g, m, batch, P, c)

@@ -136,6 +136,20 @@ class BoxPcLossArgs(C.Structure):
                 ('weigh_by_cls_conf', i32), ('weigh_by_cls_gt', i32), ('dout', F), ('terms', F), ('loss', F), ('B', i32)]
 
 
+class DgradNarrowArgs(C.Structure):
+    _fields_ = [('dy', DySrc), ('w', F), ('k0', i32), ('kn', i32), ('out', F), ('ld_out', i32), ('M', i32), ('N', i32)]
+
+
+class SemiFinalLossArgs(C.Structure):
+    _fields_ = [('strong_loss', F), ('reg_dims', F), ('one_hot', F), ('is_data_2D', I), ('out9', F),
+                ('train_classes', C.c_int32 * 10), ('w_weak', f32), ('w_fit', f32), ('fit_only_2d', i32), ('d_dims', F),
+                ('dout9', F), ('fit_prob', F), ('terms', F), ('loss', F), ('B', i32)]
+
+
+class AnchorRegBwdArgs(C.Structure):
+    _fields_ = [('box', F), ('ld_box', i32), ('dbox7', F), ('d_dims', F), ('dbox', F), ('dstage1', F), ('B', i32)]
+
+
 VP = C.c_void_p
 # name -> argtypes.  Struct entry points take (const args*, stream).
 ENTRY_POINTS = {
@@ -157,6 +171,9 @@ ENTRY_POINTS = {
     't3d_boxpc_rep': [C.POINTER(BoxPcRepArgs), VP],
     't3d_boxpc_rep_bwd': [C.POINTER(BoxPcRepBwdArgs), VP],
     't3d_boxpc_loss': [C.POINTER(BoxPcLossArgs), VP],
+    't3d_pointmlp_dgrad_narrow': [C.POINTER(DgradNarrowArgs), VP],
+    't3d_semi_final_loss': [C.POINTER(SemiFinalLossArgs), VP],
+    't3d_anchor_reg_bwd': [C.POINTER(AnchorRegBwdArgs), VP],
     't3d_reduce_slabs': [F, F, C.POINTER(SlabDesc), i32, i32, VP],
     't3d_schedule_step': [F, C.POINTER(Schedule), VP],
     't3d_adam_tf_step': [F, F, F, F, C.c_int64, F, f32, f32, f32, f32, VP],

@@ -145,6 +145,150 @@ __global__ __launch_bounds__(1024) void k_boxpc_loss(const t3d_boxpc_loss_args p
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// stage-c glue (train_semisup_adv.py:331-411, semisup_v1_sunrgbd.py:343-407)
+// ---------------------------------------------------------------------------------------------
+
+// out[m, j] = sum_n dy[m,n] * w[(k0+j), n], j < kn <= 8: the input gradient of a per-point layer restricted to a few
+// input channels (the six distance channels of the Box-PC representation).  64 rows per workgroup.
+__global__ __launch_bounds__(256) void k_dgrad_narrow(const t3d_pointmlp_dgrad_narrow_args p) {
+  __shared__ float dy_s[64][129];
+  __shared__ float w_s[8][128];
+  const int tid = threadIdx.x, row0 = blockIdx.x * 64;
+  const int r = tid & 63, kq = tid >> 6;
+  float acc0 = 0.f, acc1 = 0.f;
+  for (int n0 = 0; n0 < p.N; n0 += 128) {
+    __syncthreads();
+    for (int i = tid; i < 8 * 128; i += 256) {
+      const int k = i >> 7, n = i & 127;
+      w_s[k][n] = (k < p.kn) ? p.w[(size_t)(p.k0 + k) * p.N + n0 + n] : 0.f;
+    }
+    for (int i = tid; i < 64 * 32; i += 256) {
+      const int rr = i >> 5, c4 = (i & 31) * 4;
+      const size_t o = (size_t)(row0 + rr) * p.N + n0 + c4;
+      const float4 dz = *reinterpret_cast<const float4*>(p.dy.dz + o);
+      const float4 y = *reinterpret_cast<const float4*>(p.dy.y + o);
+      const float4 c0 = *reinterpret_cast<const float4*>(p.dy.coef + n0 + c4);
+      const float4 c1 = *reinterpret_cast<const float4*>(p.dy.coef + p.N + n0 + c4);
+      const float4 c2 = *reinterpret_cast<const float4*>(p.dy.coef + 2 * p.N + n0 + c4);
+      dy_s[rr][c4 + 0] = fmaf(c0.x, dz.x, fmaf(c1.x, y.x, c2.x));
+      dy_s[rr][c4 + 1] = fmaf(c0.y, dz.y, fmaf(c1.y, y.y, c2.y));
+      dy_s[rr][c4 + 2] = fmaf(c0.z, dz.z, fmaf(c1.z, y.z, c2.z));
+      dy_s[rr][c4 + 3] = fmaf(c0.w, dz.w, fmaf(c1.w, y.w, c2.w));
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int n = 0; n < 128; ++n) {
+      const float d = dy_s[r][n];
+      acc0 = fmaf(d, w_s[kq][n], acc0);
+      acc1 = fmaf(d, w_s[kq + 4][n], acc1);
+    }
+  }
+  float* o = p.out + (size_t)(row0 + r) * p.ld_out;
+  if (kq < p.kn) o[kq] = acc0;
+  if (kq + 4 < p.kn) o[kq + 4] = acc1;
+}
+
+__device__ const float kMeanG[10][3] = {
+    {2.114256f, 1.620300f, 0.927272f}, {0.791118f, 1.279516f, 0.718182f}, {0.923508f, 1.867419f, 0.845495f},
+    {0.591958f, 0.552978f, 0.827272f}, {0.699104f, 0.454178f, 0.756250f}, {0.695190f, 1.346299f, 0.736364f},
+    {0.528526f, 1.002642f, 1.172878f}, {0.500618f, 0.632163f, 0.683424f}, {0.404671f, 1.071108f, 1.688889f},
+    {0.765840f, 1.398258f, 0.472728f}};
+
+// total = strong + w_weak * intraclass + w_fit * mean_b( -log(0.01 + p_fit) * (only_2d ? is2D : 1) )
+// intraclass (weak_losses.py:267-291, huber): mean over the trained classes of mean_{b in class, d} huber(dims - stopgrad(mean)),
+// an empty class contributing 0.
+__global__ __launch_bounds__(1024) void k_semi_final_loss(const t3d_semi_final_loss_args p) {
+  __shared__ float cmean[10][3];
+  __shared__ float ccount[10];
+  __shared__ float red[2][1024];
+  const int b = threadIdx.x;
+  int cls = 0;
+  if (b < p.B) {
+    const float* oh = p.one_hot + (size_t)b * 10;
+    for (int i = 1; i < 10; ++i) if (oh[i] > oh[cls]) cls = i;
+  }
+  if (b < 10) {
+    float s[3] = {0.f, 0.f, 0.f}, n = 0.f;
+    for (int i = 0; i < p.B; ++i) {
+      const float* oh = p.one_hot + (size_t)i * 10;
+      int ci = 0;
+      for (int k = 1; k < 10; ++k) if (oh[k] > oh[ci]) ci = k;
+      if (ci == b) { n += 1.f; for (int d = 0; d < 3; ++d) s[d] += p.reg_dims[i * 3 + d]; }
+    }
+    ccount[b] = n;
+    for (int d = 0; d < 3; ++d) cmean[b][d] = n > 0.f ? s[d] / n : 0.f;
+  }
+  __syncthreads();
+  int T = 0;
+  for (int i = 0; i < 10; ++i) T += p.train_classes[i] ? 1 : 0;
+  float intra = 0.f, fit = 0.f;
+  if (b < p.B) {
+    float gd[3] = {0.f, 0.f, 0.f};
+    if (p.w_weak != 0.f && T > 0 && p.train_classes[cls]) {
+      const float sc = 1.0f / (3.0f * ccount[cls] * (float)T);
+      for (int d = 0; d < 3; ++d) {
+        const float e = p.reg_dims[b * 3 + d] - cmean[cls][d];
+        intra += hub(e) * sc;
+        gd[d] = p.w_weak * hubd(e) * sc;
+      }
+    }
+    for (int d = 0; d < 3; ++d) p.d_dims[b * 3 + d] = gd[d];
+    const float* o = p.out9 + (size_t)b * 9;
+    const float l0 = o[7], l1 = o[8];
+    const float mx = fmaxf(l0, l1);
+    const float lse = mx + logf(expf(l0 - mx) + expf(l1 - mx));
+    const float pf = expf(l1 - lse);
+    const float m = p.fit_only_2d ? (float)p.is_data_2D[b] : 1.f;
+    fit = -logf(0.01f + pf) * m;
+    const float dp = -p.w_fit * m / ((0.01f + pf) * (float)p.B);
+    float* g = p.dout9 + (size_t)b * 9;
+    for (int i = 0; i < 7; ++i) g[i] = 0.f;
+    g[7] = -dp * pf * (1.f - pf);
+    g[8] = dp * pf * (1.f - pf);
+    p.fit_prob[b] = pf;
+  }
+  red[0][b] = intra;
+  red[1][b] = fit;
+  __syncthreads();
+  if (b == 0) {
+    double si = 0.0, sf = 0.0;
+    for (int i = 0; i < p.B; ++i) { si += red[0][i]; sf += red[1][i]; }
+    const double fl = sf / (double)p.B;
+    p.terms[0] = (float)si;
+    p.terms[1] = (float)fl;
+    p.loss[0] = (float)((double)p.strong_loss[0] + (double)p.w_weak * si + (double)p.w_fit * fl);
+  }
+}
+
+// Backward of tf_convert_box_params_from_anchor_to_reg_format (tf_util.py:1017-1031) for the refined heads:
+//   centre = box[0:3] + stage1_center            -> dbox[0:3] += g_c,  dstage1 += g_c
+//   dims   = max(anchor[k*] + srn[k*]*mean[k*], 1e-5)  -> dbox[srn k*] += g_d * mean[k*] * 1[dims > 1e-5]
+//   theta  = bin[j*] + hrn[j*]*pi/NH             -> dbox[hrn j*] += g_t * pi/NH          (k*, j* = first arg-max of the scores)
+__global__ __launch_bounds__(1024) void k_anchor_reg_bwd(const t3d_anchor_reg_bwd_args p) {
+  const int b = threadIdx.x;
+  if (b >= p.B) return;
+  const float* o = p.box + (size_t)b * p.ld_box;
+  float* g = p.dbox + (size_t)b * 67;
+  int js = 0, ks = 0;
+  for (int i = 1; i < 12; ++i) if (o[3 + i] > o[3 + js]) js = i;
+  for (int i = 1; i < 10; ++i) if (o[27 + i] > o[27 + ks]) ks = i;
+  float gc[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f}, gt = 0.f;
+  if (p.dbox7) {
+    const float* q = p.dbox7 + (size_t)b * 7;
+    for (int d = 0; d < 3; ++d) { gc[d] = q[d]; gd[d] = q[3 + d]; }
+    gt = q[6];
+  }
+  if (p.d_dims) for (int d = 0; d < 3; ++d) gd[d] += p.d_dims[b * 3 + d];
+  for (int d = 0; d < 3; ++d) {
+    g[d] += gc[d];
+    p.dstage1[b * 3 + d] += gc[d];
+    const float raw = kMeanG[ks][d] + o[37 + 3 * ks + d] * kMeanG[ks][d];
+    if (raw > 1e-5f) g[37 + 3 * ks + d] += gd[d] * kMeanG[ks][d];
+  }
+  g[15 + js] += gt * (3.14159265358979323846f / 12.0f);
+}
+
 }  // namespace
 
 extern "C" int t3d_boxpc_rep(const t3d_boxpc_rep_args* a, t3d_stream_t stream) {
@@ -170,6 +314,32 @@ extern "C" int t3d_boxpc_loss(const t3d_boxpc_loss_args* a, t3d_stream_t stream)
     return T3D_ERR_ARG;
   if (a->B <= 0 || a->B > 1024) return T3D_ERR_SHAPE;
   T3D_LAUNCH(k_boxpc_loss, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), *a);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_pointmlp_dgrad_narrow(const t3d_pointmlp_dgrad_narrow_args* a, t3d_stream_t stream) {
+  if (!a || !a->dy.dz || !a->dy.y || !a->dy.coef || !a->w || !a->out) return T3D_ERR_ARG;
+  if (a->M <= 0 || a->M % 64 || a->N % 128 || a->kn <= 0 || a->kn > 8 || a->ld_out < a->kn) return T3D_ERR_SHAPE;
+  T3D_LAUNCH(k_dgrad_narrow, dim3(a->M / 64), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_semi_final_loss(const t3d_semi_final_loss_args* a, t3d_stream_t stream) {
+  if (!a || !a->strong_loss || !a->reg_dims || !a->one_hot || !a->is_data_2D || !a->out9 || !a->d_dims || !a->dout9 ||
+      !a->fit_prob || !a->terms || !a->loss)
+    return T3D_ERR_ARG;
+  if (a->B <= 0 || a->B > 1024) return T3D_ERR_SHAPE;
+  T3D_LAUNCH(k_semi_final_loss, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), *a);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_anchor_reg_bwd(const t3d_anchor_reg_bwd_args* a, t3d_stream_t stream) {
+  if (!a || !a->box || !a->dbox || !a->dstage1) return T3D_ERR_ARG;
+  if (a->B <= 0 || a->B > 1024) return T3D_ERR_SHAPE;
+  T3D_LAUNCH(k_anchor_reg_bwd, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

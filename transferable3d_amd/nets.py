@@ -499,3 +499,93 @@ class BoxPCModel:
         return {'boxpc_out': n.out, 'box_pc_rep': n.rep, 'loss': self.loss_op.loss, 'terms': self.loss_op.terms,
                 'boxpc_fit_logits': n.out[:, 7:9], 'boxpc_delta_center': n.out[:, 0:3], 'boxpc_delta_size': n.out[:, 3:6],
                 'boxpc_delta_angle': n.out[:, 6], 'feats_lv1': n.P4.pooled}
+
+
+class SemiModelF:
+    """SEMI_MODEL F, stage c (get_semi_model_final semisup_v1_sunrgbd.py:132-230 + the Box-PC glue of
+    train_semisup_adv.py:331-411 + get_semi_loss_final 323-421): class-agnostic seg / T-Net / box nets, the
+    class-dependent box_refine MLP, the FROZEN Box-PC Fit net applied to the refined box, strong + intraclass + fit loss.
+
+    Backward follows the var_list of train_semisup_adv.py:415-422: nothing for the seg net, box_est/fc1-3 receive no
+    gradient (the loss never reads the class-agnostic heads); the Box-PC net back-propagates data gradients only."""
+
+    def __init__(self, g, c, use_one_hot=True, train_classes=None, inputs=None):
+        self.g, self.c = g, c
+        self.inputs = inputs or Inputs(g)
+        p = 'class_agnostic/'
+        self.seg = InstSegNet(g, p + 'inst_seg', False)
+        self.tnet = TNet(g, p + 'tnet', False)
+        self.box = BoxEstNet(g, p + 'box_est', False)
+        q = 'class_dependent/box_refine/'
+        oh = NUM_CLASS if use_one_hot else 0
+        self.oh = oh
+        act = 'leaky_relu' if c.SEMI_ADV_LEAKY_RELU else 'relu'
+        last = 'tanh' if c.SEMI_ADV_TANH_FOR_LAST_LAYER_OF_G else act
+        dp = c.SEMI_ADV_DROPOUTS_FOR_G
+        self.R0 = FcLayer(g, q + 'fc0', 512, 512, act=act, K2=oh, keep_prob=dp, drop_scope=q + 'dp0')
+        self.R1 = FcLayer(g, q + 'fc1', 512, 256, act=last, keep_prob=dp, drop_scope=q + 'dp1')
+        self.R2 = FcLayer(g, q + 'fc2', 256, BOX_OUT_DIMS, bn=False, act=None)
+        self.loss_op = StrongLoss(g)
+        self.boxpc = BoxPCNet(g, 'D_boxpc_branch/', False)
+        self.train_classes = list(train_classes) if train_classes is not None else [True] * NUM_CLASS
+        rt, B = g.rt, g.B
+        self.d_dims, self.dout9, self.fit_prob = rt.zeros(B, 3), rt.zeros(B, 9), rt.zeros(B)
+        self.terms, self.loss = rt.zeros(2), rt.zeros(1)
+        self.drep, self.dbox7 = rt.zeros(g.M, 8), rt.zeros(B, 7)
+
+    def emit_forward(self, plan, is_training, with_loss):
+        g, x, c = self.g, self.inputs, self.c
+        self.seg.fwd(plan, x.pc, x.one_hot_vec, x.y_seg if with_loss else None, x.is_data_2D, is_training, False,
+                     ce_weight=c.STRONG_WEIGHT_CROSS_ENTROPY)
+        s1 = self.tnet.fwd(plan, x.pc, self.seg.mask, self.seg.mask_xyz_mean, x.one_hot_vec, is_training)
+        self.box.fwd(plan, x.pc, self.seg.mask, s1, x.one_hot_vec, is_training)
+        f = self.R0.fwd(plan, self.box.feats_lv1, 512, is_training, in2=x.one_hot_vec if self.oh else None, ld_in2=NUM_CLASS)
+        f = self.R1.fwd(plan, f, 512, is_training)
+        self.F_out = self.R2.fwd(plan, f, 256, is_training)
+        lab = (x.y_center, x.y_orient_cls, x.y_orient_reg, x.y_dims_cls, x.y_dims_reg, x.is_data_2D)
+        self.loss_op.emit(plan, self.F_out, s1, self.seg.seg_loss, lab, c, normalize_by_3d_count=True)
+        # frozen Box-PC net on F_pred_box_reg (is_training_D = False: eval-mode batch-norm, no dropout)
+        lo = self.loss_op
+        out9 = self.boxpc.fwd(plan, x.pc, lo.center, lo.reg_dims, lo.reg_theta, x.one_hot_vec, False)
+        a = abi.SemiFinalLossArgs()
+        a.strong_loss, a.reg_dims, a.one_hot, a.is_data_2D, a.out9 = fptr(lo.loss), fptr(lo.reg_dims), fptr(x.one_hot_vec), \
+            iptr(x.is_data_2D), fptr(out9)
+        for i in range(NUM_CLASS):
+            a.train_classes[i] = int(bool(self.train_classes[i]))
+        a.w_weak = float(c.SEMI_MULTIPLIER_FOR_WEAK_LOSS * c.WEAK_WEIGHT_INTRACLASSVAR)
+        a.w_fit, a.fit_only_2d = float(c.SEMI_WEIGHT_BOXPC_FIT_LOSS), int(bool(c.SEMI_BOXPC_FIT_ONLY_ON_2D_CLS))
+        a.d_dims, a.dout9, a.fit_prob, a.terms, a.loss, a.B = fptr(self.d_dims), fptr(self.dout9), fptr(self.fit_prob), \
+            fptr(self.terms), fptr(self.loss), g.B
+        plan.add('t3d_semi_final_loss', a)
+
+    def emit_backward(self, plan):
+        g, x = self.g, self.inputs
+        bp = self.boxpc
+        bp.bwd(plan, self.dout9, param_grads=False)
+        n = abi.DgradNarrowArgs(bp.P1.dy_struct(), fptr(bp.P1.w), g.C, 6, fptr(self.drep), 8, g.M, 128)
+        plan.add('t3d_pointmlp_dgrad_narrow', n)
+        r = abi.BoxPcRepBwdArgs(fptr(x.pc), g.C, fptr(bp.box7), fptr(self.drep), 8, 0, fptr(self.dbox7), g.B, g.rpf)
+        plan.add('t3d_boxpc_rep_bwd', r)
+        lo = self.loss_op
+        q = abi.AnchorRegBwdArgs(fptr(self.F_out), BOX_OUT_DIMS, fptr(self.dbox7), fptr(self.d_dims), fptr(lo.dbox),
+                                 fptr(lo.dstage1), g.B)
+        plan.add('t3d_anchor_reg_bwd', q)
+        self.R2.bwd(plan, dout=lo.dbox, ld_dout=BOX_OUT_DIMS)
+        self.R1.bwd(plan, nxt=self.R2)
+        self.R0.bwd(plan, nxt=self.R1)
+        dfeat = self.R0.dinput(plan, K=512)
+        ds1 = self.box.bwd_convs(plan, dfeat, 512, lo.dstage1)
+        self.tnet.bwd(plan, ds1)
+        g.emit_reduce_slabs(plan)
+
+    VAR_LIST = ('class_dependent', 'class_agnostic/tnet', 'class_agnostic/box')
+
+    def end_points(self):
+        g = self.g
+        B, N = g.B, g.rpf
+        lo = self.loss_op
+        return {'logits': self.seg.logits.view(B, N, 2), 'stage1_center': self.tnet.stage1_center,
+                'feats_lv1': self.box.feats_lv1, 'box_params': self.box.box_params, 'F_box_params': self.F_out,
+                'F_center': lo.center, 'F_dims': lo.reg_dims, 'F_theta': lo.reg_theta, 'boxpc_fit_prob': self.fit_prob,
+                'boxpc_out': self.boxpc.F3.out, 'loss': self.loss, 'strong_loss': lo.loss, 'terms': self.terms,
+                'loss_terms': lo.terms}
