@@ -1,14 +1,13 @@
 #!/bin/bash
-# diagnostic: build libt3d variants with ablation macros into gpurun-visible paths
+# diagnostic: build libt3d variants:  build_variant.sh name "-DFLAG -DFLAG2" [name2 "flags2" ...]  -> tools/libt3d_<name>.so
 set -e
 cd "$(dirname "$0")/.."
-for v in NOSTAGE NOBAR NOEPI "NOSTAGE -DT3D_ABL_NOBAR" "NOSTAGE -DT3D_ABL_NOBAR -DT3D_ABL_NOEPI"; do
-  name=$(echo $v | tr -d ' ' | sed 's/-DT3D_ABL_/_/g')
-  objs=""
-  for f in pointmlp bn_optim fc heads; do
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -DT3D_ABL_$v -c transferable3d_amd/csrc/$f.hip -o /tmp/abl_$f.o &
+while [ $# -gt 1 ]; do
+  name=$1; flags=$2; shift 2
+  for f in pointmlp bn_optim fc heads boxpc; do
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude $flags -c transferable3d_amd/csrc/$f.hip -o /tmp/abl_${name}_$f.o &
   done
   wait
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/libt3d_$name.so /tmp/abl_pointmlp.o /tmp/abl_bn_optim.o /tmp/abl_fc.o /tmp/abl_heads.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/libt3d_$name.so /tmp/abl_${name}_pointmlp.o /tmp/abl_${name}_bn_optim.o /tmp/abl_${name}_fc.o /tmp/abl_${name}_heads.o /tmp/abl_${name}_boxpc.o
   echo built tools/libt3d_$name.so
 done

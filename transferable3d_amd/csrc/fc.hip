@@ -6,15 +6,19 @@
 //
 // These layers are latency bound (M = B = 32..128 rows, weights <= 2 MB).  One workgroup owns 32 output
 // columns for ALL rows, so the batch-norm reductions over the batch stay inside the workgroup and a layer is a
-// single launch.  The reduction dimension is split over the workgroup's 4 waves (interleaved 8-deep k groups);
+// single launch.  The reduction dimension is split over the workgroup's 8 waves (interleaved 8-deep k groups);
 // every wave feeds v_mfma_f32_32x32x2_f32 straight from global/L2 (operands are tiny and cache resident, no LDS
-// staging), the 4 partial 32x32 tiles are summed through LDS, and the epilogue runs on all 256 threads.
+// staging), the partial 32x32 tiles are summed through LDS, and the epilogue runs on all 512 threads.
 #include "common.h"
 
 namespace {
 
 constexpr int CB = 32;       // columns per workgroup
 constexpr int MAXRB = 4;     // B <= 128
+constexpr int NW = 8;        // waves per workgroup (the reduction dimension is split over them)
+constexpr int NTH = NW * 64;
+constexpr int RG = NTH / 32; // row groups of the epilogue thread map
+constexpr int NVAL = MAXRB * 32 / RG;
 constexpr int LDT = 33;      // padded row stride of the LDS tiles
 
 struct RowSrc {              // [in | in2] row-concatenated input, B valid rows
@@ -77,24 +81,29 @@ __device__ __forceinline__ void wave_gemm(f32x16 (&acc)[MAXRB], const RowSrc& sr
       for (int rb = 0; rb < MAXRB; ++rb)
         if (rb < RB) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rb][i], b[i], acc[rb], 0, 0, 0);
   };
-  // two groups per iteration: both groups' loads are in flight before the first MFMA
+  // four k-groups per iteration: all their loads are in flight before the first MFMA (these layers are pure
+  // latency: the operands are tiny and L2 resident, so memory-level parallelism per wave is what matters)
   int g = wave;
-  for (; g + 4 < ngroups; g += 8) {
-    float a0[MAXRB][4], b0[4], a1[MAXRB][4], b1[4];
+  for (; g + 3 * NW < ngroups; g += 4 * NW) {
+    float a0[MAXRB][4], b0[4], a1[MAXRB][4], b1[4], a2[MAXRB][4], b2[4], a3[MAXRB][4], b3[4];
     load_group(g, a0, b0);
-    load_group(g + 4, a1, b1);
+    load_group(g + NW, a1, b1);
+    load_group(g + 2 * NW, a2, b2);
+    load_group(g + 3 * NW, a3, b3);
     mma_group(a0, b0);
     mma_group(a1, b1);
+    mma_group(a2, b2);
+    mma_group(a3, b3);
   }
-  if (g < ngroups) {
+  for (; g < ngroups; g += NW) {
     float a0[MAXRB][4], b0[4];
     load_group(g, a0, b0);
     mma_group(a0, b0);
   }
 }
 
-// Sum the 4 waves' tiles through LDS.  Afterwards thread t owns column (t & 31) and rows (t >> 5) + 8*j.
-__device__ __forceinline__ void reduce_tiles(const f32x16 (&acc)[MAXRB], int RB, float* red, float (&val)[MAXRB * 4]) {
+// Sum the NW waves' tiles through LDS.  Afterwards thread t owns column (t & 31) and rows (t >> 5) + RG*j.
+__device__ __forceinline__ void reduce_tiles(const f32x16 (&acc)[MAXRB], int RB, float* red, float (&val)[NVAL]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int rows = RB * 32;
 #pragma unroll
@@ -109,12 +118,12 @@ __device__ __forceinline__ void reduce_tiles(const f32x16 (&acc)[MAXRB], int RB,
   __syncthreads();
   const int col = tid & 31, rg = tid >> 5;
 #pragma unroll
-  for (int j = 0; j < MAXRB * 4; ++j) {
-    const int row = rg + 8 * j;
+  for (int j = 0; j < NVAL; ++j) {
+    const int row = rg + RG * j;
     float s = 0.f;
     if (row < rows) {
 #pragma unroll
-      for (int wv = 0; wv < 4; ++wv) s += red[(wv * rows + row) * LDT + col];
+      for (int wv = 0; wv < NW; ++wv) s += red[(wv * rows + row) * LDT + col];
     }
     val[j] = s;
   }
@@ -129,7 +138,7 @@ __device__ __forceinline__ float col_reduce(float part, float* red) {
   __syncthreads();
   float s = 0.f;
 #pragma unroll
-  for (int g = 0; g < 8; ++g) s += red[g * CB + col];
+  for (int g = 0; g < RG; ++g) s += red[g * CB + col];
   return s;
 }
 
@@ -150,7 +159,7 @@ __device__ __forceinline__ float act_bwd(float z, int act, float alpha) {
   }
 }
 
-__global__ __launch_bounds__(256) void k_fc_fwd(const t3d_fc_fwd_args p) {
+__global__ __launch_bounds__(NTH) void k_fc_fwd(const t3d_fc_fwd_args p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int RB = (p.B + 31) / 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -162,15 +171,15 @@ __global__ __launch_bounds__(256) void k_fc_fwd(const t3d_fc_fwd_args p) {
   f32x16 acc[MAXRB];
   RowSrc src{p.in, p.ld_in, p.K, p.in2, p.ld_in2, p.K2, p.B};
   wave_gemm<false>(acc, src, RB, p.w, p.N, p.K + p.K2, c0, nvalid, wave, lane);
-  float y[MAXRB * 4];
+  float y[NVAL];
   reduce_tiles(acc, RB, sm, y);
 
   const float bias = (cok && p.bias) ? p.bias[c] : 0.f;
   float part = 0.f;
 #pragma unroll
-  for (int j = 0; j < MAXRB * 4; ++j) {
+  for (int j = 0; j < NVAL; ++j) {
     y[j] += bias;
-    if (rg + 8 * j < p.B) part += y[j];
+    if (rg + RG * j < p.B) part += y[j];
   }
   const bool bn = p.gamma != nullptr;
   float mean = 0.f, invstd = 1.f, g = 1.f, be = 0.f;
@@ -180,8 +189,8 @@ __global__ __launch_bounds__(256) void k_fc_fwd(const t3d_fc_fwd_args p) {
       mean = col_reduce(part, sm) / (float)p.B;
       float vpart = 0.f;
 #pragma unroll
-      for (int j = 0; j < MAXRB * 4; ++j)
-        if (rg + 8 * j < p.B) { const float d = y[j] - mean; vpart = fmaf(d, d, vpart); }
+      for (int j = 0; j < NVAL; ++j)
+        if (rg + RG * j < p.B) { const float d = y[j] - mean; vpart = fmaf(d, d, vpart); }
       const float var = col_reduce(vpart, sm) / (float)p.B;
       invstd = 1.0f / sqrtf(var + p.eps);
       if (cok && rg == 0) {
@@ -199,8 +208,8 @@ __global__ __launch_bounds__(256) void k_fc_fwd(const t3d_fc_fwd_args p) {
   if (!cok) return;
   const float inv_keep = p.drop_mask ? 1.0f / p.keep_prob : 1.f;
 #pragma unroll
-  for (int j = 0; j < MAXRB * 4; ++j) {
-    const int r = rg + 8 * j;
+  for (int j = 0; j < NVAL; ++j) {
+    const int r = rg + RG * j;
     if (r < p.B) {
       const float yv = y[j];
       if (p.y) p.y[(size_t)r * p.N + c] = yv;
@@ -213,7 +222,7 @@ __global__ __launch_bounds__(256) void k_fc_fwd(const t3d_fc_fwd_args p) {
   }
 }
 
-__global__ __launch_bounds__(256) void k_fc_bwd(const t3d_fc_bwd_args p) {
+__global__ __launch_bounds__(NTH) void k_fc_bwd(const t3d_fc_bwd_args p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int RB = (p.B + 31) / 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -223,11 +232,11 @@ __global__ __launch_bounds__(256) void k_fc_bwd(const t3d_fc_bwd_args p) {
   const bool cok = c < p.N;
 
   // (a) gradient w.r.t. this layer's output: given, or dy_next . w_next^T on the fly
-  float gout[MAXRB * 4];
+  float gout[NVAL];
   if (p.dout != nullptr) {
 #pragma unroll
-    for (int j = 0; j < MAXRB * 4; ++j) {
-      const int r = rg + 8 * j;
+    for (int j = 0; j < NVAL; ++j) {
+      const int r = rg + RG * j;
       gout[j] = (r < p.B && cok) ? p.dout[(size_t)r * p.ld_dout + c] : 0.f;
     }
   } else {
@@ -242,11 +251,11 @@ __global__ __launch_bounds__(256) void k_fc_bwd(const t3d_fc_bwd_args p) {
   float mean = 0.f, invstd = 1.f, g = 1.f, be = 0.f;
   if (bn && cok) { mean = p.mean[c]; invstd = p.invstd[c]; g = p.gamma[c]; be = p.beta[c]; }
   const float inv_keep = p.drop_mask ? 1.0f / p.keep_prob : 1.f;
-  float xh[MAXRB * 4];
+  float xh[NVAL];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-  for (int j = 0; j < MAXRB * 4; ++j) {
-    const int r = rg + 8 * j;
+  for (int j = 0; j < NVAL; ++j) {
+    const int r = rg + RG * j;
     float dz = 0.f, x = 0.f;
     if (r < p.B && cok) {
       const float yv = p.y ? p.y[(size_t)r * p.N + c] : 0.f;
@@ -271,11 +280,11 @@ __global__ __launch_bounds__(256) void k_fc_bwd(const t3d_fc_bwd_args p) {
     }
     const float invB = 1.0f / (float)p.B, c1 = g * invstd;
 #pragma unroll
-    for (int j = 0; j < MAXRB * 4; ++j) gout[j] = c1 * (gout[j] - dbeta * invB - xh[j] * dgamma * invB);
+    for (int j = 0; j < NVAL; ++j) gout[j] = c1 * (gout[j] - dbeta * invB - xh[j] * dgamma * invB);
   } else if (bn) {
     const float c1 = g * invstd;
 #pragma unroll
-    for (int j = 0; j < MAXRB * 4; ++j) gout[j] *= c1;
+    for (int j = 0; j < NVAL; ++j) gout[j] *= c1;
   } else {
     dbias = col_reduce(s1, sm);
   }
@@ -285,8 +294,8 @@ __global__ __launch_bounds__(256) void k_fc_bwd(const t3d_fc_bwd_args p) {
   float* dy_s = sm;
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < MAXRB * 4; ++j) {
-    const int r = rg + 8 * j;
+  for (int j = 0; j < NVAL; ++j) {
+    const int r = rg + RG * j;
     if (r < RB * 32) {
       const float v = (r < p.B && cok) ? gout[j] : 0.f;
       dy_s[r * LDT + col] = v;
@@ -301,7 +310,7 @@ __global__ __launch_bounds__(256) void k_fc_bwd(const t3d_fc_bwd_args p) {
   const int Kt = p.K + p.K2;
   const int l31 = lane & 31, h = lane >> 5;
   const int nkb = (Kt + 31) / 32;
-  for (int kb = wave; kb < nkb; kb += 4) {
+  for (int kb = wave; kb < nkb; kb += NW) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -327,7 +336,7 @@ __global__ __launch_bounds__(256) void k_fc_bwd(const t3d_fc_bwd_args p) {
   }
 }
 
-__global__ __launch_bounds__(256) void k_fc_dinput(const t3d_fc_dinput_args p) {
+__global__ __launch_bounds__(NTH) void k_fc_dinput(const t3d_fc_dinput_args p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int RB = (p.B + 31) / 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -337,12 +346,12 @@ __global__ __launch_bounds__(256) void k_fc_dinput(const t3d_fc_dinput_args p) {
   f32x16 acc[MAXRB];
   RowSrc src{p.dy, p.N, p.N, nullptr, 0, 0, p.B};
   wave_gemm<true>(acc, src, RB, p.w, p.N, p.N, c0, nvalid, wave, lane);
-  float v[MAXRB * 4];
+  float v[NVAL];
   reduce_tiles(acc, RB, sm, v);
   if (c >= p.K) return;
 #pragma unroll
-  for (int j = 0; j < MAXRB * 4; ++j) {
-    const int r = rg + 8 * j;
+  for (int j = 0; j < NVAL; ++j) {
+    const int r = rg + RG * j;
     if (r < p.B) {
       float o = p.alpha * v[j];
       if (p.add_in) o += p.add_in[(size_t)r * p.ld_add + c];
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(256) void k_fc_dinput(const t3d_fc_dinput_args p) {
 
 size_t fc_lds_bytes(int B) {
   const int RB = (B + 31) / 32;
-  return (size_t)4 * RB * 32 * LDT * sizeof(float);
+  return (size_t)NW * RB * 32 * LDT * sizeof(float);
 }
 
 }  // namespace
@@ -363,7 +372,7 @@ extern "C" int t3d_fc_fwd(const t3d_fc_fwd_args* a, t3d_stream_t stream) {
   if (a->gamma && (!a->beta || !a->moving_mean || !a->moving_var || !a->mean || !a->invstd || !a->y)) return T3D_ERR_ARG;
   if (a->gamma && a->is_training && !a->decay) return T3D_ERR_ARG;
   if (a->B <= 0 || a->B > 32 * MAXRB || a->N <= 0 || a->K <= 0) return T3D_ERR_SHAPE;
-  T3D_LAUNCH(k_fc_fwd, dim3((a->N + CB - 1) / CB), dim3(256), fc_lds_bytes(a->B), static_cast<hipStream_t>(stream), *a);
+  T3D_LAUNCH(k_fc_fwd, dim3((a->N + CB - 1) / CB), dim3(NTH), fc_lds_bytes(a->B), static_cast<hipStream_t>(stream), *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -374,7 +383,7 @@ extern "C" int t3d_fc_bwd(const t3d_fc_bwd_args* a, t3d_stream_t stream) {
   if (a->gamma && (!a->beta || !a->mean || !a->invstd || !a->y)) return T3D_ERR_ARG;
   if (a->act != T3D_ACT_NONE && !a->y) return T3D_ERR_ARG;
   if (a->B <= 0 || a->B > 32 * MAXRB || a->N <= 0) return T3D_ERR_SHAPE;
-  T3D_LAUNCH(k_fc_bwd, dim3((a->N + CB - 1) / CB), dim3(256), fc_lds_bytes(a->B), static_cast<hipStream_t>(stream), *a);
+  T3D_LAUNCH(k_fc_bwd, dim3((a->N + CB - 1) / CB), dim3(NTH), fc_lds_bytes(a->B), static_cast<hipStream_t>(stream), *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -382,7 +391,7 @@ extern "C" int t3d_fc_bwd(const t3d_fc_bwd_args* a, t3d_stream_t stream) {
 extern "C" int t3d_fc_dinput(const t3d_fc_dinput_args* a, t3d_stream_t stream) {
   if (!a || !a->dy || !a->w || !a->din) return T3D_ERR_ARG;
   if (a->B <= 0 || a->B > 32 * MAXRB || a->N <= 0 || a->K <= 0) return T3D_ERR_SHAPE;
-  T3D_LAUNCH(k_fc_dinput, dim3((a->K + CB - 1) / CB), dim3(256), fc_lds_bytes(a->B), static_cast<hipStream_t>(stream), *a);
+  T3D_LAUNCH(k_fc_dinput, dim3((a->K + CB - 1) / CB), dim3(NTH), fc_lds_bytes(a->B), static_cast<hipStream_t>(stream), *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

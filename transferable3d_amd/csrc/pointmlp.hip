@@ -15,7 +15,16 @@
 
 namespace {
 
-constexpr int BK = 32;
+#ifndef T3D_BK
+#define T3D_BK 32
+#endif
+constexpr int BK = T3D_BK;      // reduction depth of one LDS stage
+#ifndef T3D_WAVES
+#define T3D_WAVES 2
+#endif
+#ifndef T3D_FORCE_TILE
+#define T3D_FORCE_TILE 0       // diagnostic: 64 / 128 forces the column tile of fwd and dgrad
+#endif
 constexpr int LDR = BK + 4;
 constexpr int NT = 256;
 
@@ -135,7 +144,7 @@ struct Stager {
 
   __device__ __forceinline__ static void coords(int tid, int q, int& lane_i, int& red_i) {
     const int f = tid + NT * q;
-    if (TYPE_R) { lane_i = f >> 3; red_i = (f & 7) * 4; }
+    if (TYPE_R) { constexpr int CH = BK / 4; lane_i = f / CH; red_i = (f % CH) * 4; }
     else { constexpr int C4 = DIM / 4; red_i = f / C4; lane_i = (f % C4) * 4; }
   }
   // TYPE_C: the thread's column chunk never changes -> fetch its coefficients once
@@ -212,6 +221,9 @@ __device__ __forceinline__ void mma_groups(const float* As, const float* Bs, int
 #pragma unroll
   for (int g = G0; g < G1; ++g) {
     if (g + 1 < G1) f[(g + 1) & 1].load(As, Bs, a0, b0, g + 1, l31, h);
+#ifdef T3D_PIN_FRAGS
+    __builtin_amdgcn_sched_barrier(0);   // keep the next group's ds_reads ahead of this group's 16 MFMAs
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -244,7 +256,8 @@ template <int TM, int TN, class SA, class SB, class LA, class LB, bool AR, int D
 __device__ __forceinline__ void gemm_mainloop(SA& sa, SB& sb, const LA& la, const LB& lb, float* smem, int red_begin,
                                               int red_end, int a0, int b0, f32x16 (&acc)[TM][TN], int tid) {
   constexpr int STAGE = SA::LDS_FLOATS + SB::LDS_FLOATS;
-  static_assert(SA::NV + SB::NV <= 8, "staging pieces must fit the 8 MFMA clusters of the second half");
+  constexpr int GH = BK / 16, GT = BK / 8;     // k-groups in the first half / in the whole tile
+  static_assert(SA::NV + SB::NV <= (GT - GH) * 4, "staging pieces must fit the MFMA clusters of the second half");
   const int lane = tid & 63;
   auto nofill = [](int) {};
   sa.fetch(la, red_begin, tid);
@@ -260,18 +273,18 @@ __device__ __forceinline__ void gemm_mainloop(SA& sa, SB& sb, const LA& la, cons
     const float* Bs = As + SA::LDS_FLOATS;
     float* An = smem + (cur ^ 1) * STAGE;
     float* Bn = An + SA::LDS_FLOATS;
-    mma_groups<TM, TN, AR, DIMA, BR, DIMB, 0, 2>(As, Bs, a0, b0, acc, lane, nofill);
+    mma_groups<TM, TN, AR, DIMA, BR, DIMB, 0, GH>(As, Bs, a0, b0, acc, lane, nofill);
     // nothing of the staging work may be hoisted into the first half: the next tile's global loads were
     // issued only one barrier ago and get the first half's MFMAs (>= 2048 cycles) to land
     __builtin_amdgcn_sched_barrier(0);
 #ifndef T3D_ABL_NOSTAGE
-    mma_groups<TM, TN, AR, DIMA, BR, DIMB, 2, 4>(As, Bs, a0, b0, acc, lane, [&](int step) {
+    mma_groups<TM, TN, AR, DIMA, BR, DIMB, GH, GT>(As, Bs, a0, b0, acc, lane, [&](int step) {
       if (step < SA::NV) sa.store_piece(la, An, tid, step);
       else if (step - SA::NV < SB::NV) sb.store_piece(lb, Bn, tid, step - SA::NV);
     });
 #else
     (void)An; (void)Bn;
-    mma_groups<TM, TN, AR, DIMA, BR, DIMB, 2, 4>(As, Bs, a0, b0, acc, lane, nofill);
+    mma_groups<TM, TN, AR, DIMA, BR, DIMB, GH, GT>(As, Bs, a0, b0, acc, lane, nofill);
 #endif
     // keep the new loads BEHIND every wait on the previous batch (vmcnt counts in issue order)
     __builtin_amdgcn_sched_barrier(0);
@@ -291,7 +304,7 @@ __device__ __forceinline__ void gemm_mainloop(SA& sa, SB& sb, const LA& la, cons
   {
     const float* As = smem + cur * STAGE;
     const float* Bs = As + SA::LDS_FLOATS;
-    mma_groups<TM, TN, AR, DIMA, BR, DIMB, 0, 4>(As, Bs, a0, b0, acc, lane, nofill);
+    mma_groups<TM, TN, AR, DIMA, BR, DIMB, 0, GT>(As, Bs, a0, b0, acc, lane, nofill);
   }
   __syncthreads();
 }
@@ -300,7 +313,7 @@ __device__ __forceinline__ void gemm_mainloop(SA& sa, SB& sb, const LA& la, cons
 // forward
 // ---------------------------------------------------------------------------------------------
 template <int BN, bool HAS_SUB>
-__global__ __launch_bounds__(NT, 2) void k_pointmlp_fwd(const t3d_pointmlp_fwd_args p) {
+__global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd(const t3d_pointmlp_fwd_args p) {
   constexpr int BM = 128, TM = 2, TN = BN / 64;
   using LA = ActLoader<HAS_SUB>;
   using SA = Stager<BM, true, LA>;
@@ -327,11 +340,15 @@ __global__ __launch_bounds__(NT, 2) void k_pointmlp_fwd(const t3d_pointmlp_fwd_a
                                                                         wn * (BN / 2), acc, tid);
 
 #ifdef T3D_ABL_NOEPI
-  {
+  if (p.M > 0) {          // diagnostic build: skip the epilogue but keep the accumulators live
+    if (p.K < 0) {
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
+      for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) asm volatile("" ::"v"(acc[tm][tn]));
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) p.y[tm * 32 + tn * 16 + r] = acc[tm][tn][r];
+    }
     return;
   }
 #endif
@@ -414,7 +431,7 @@ __global__ __launch_bounds__(NT, 2) void k_pointmlp_fwd(const t3d_pointmlp_fwd_a
 // data gradient
 // ---------------------------------------------------------------------------------------------
 template <int BN, bool POOLED>   // BN = tile width over the layer's INPUT channels K
-__global__ __launch_bounds__(NT, 2) void k_pointmlp_dgrad(const t3d_pointmlp_dgrad_args p) {
+__global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_dgrad(const t3d_pointmlp_dgrad_args p) {
   constexpr int BM = 128, TM = 2, TN = BN / 64;
   using LA = DyLoader<POOLED>;
   using SA = Stager<BM, true, LA>;
@@ -494,7 +511,7 @@ __global__ __launch_bounds__(NT, 2) void k_pointmlp_dgrad(const t3d_pointmlp_dgr
 // weight gradient (split over rows)
 // ---------------------------------------------------------------------------------------------
 template <int BMK, int BN, bool HAS_SUB, bool POOLED>
-__global__ __launch_bounds__(NT, 2) void k_pointmlp_wgrad(const t3d_pointmlp_wgrad_args p) {
+__global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_wgrad(const t3d_pointmlp_wgrad_args p) {
   constexpr int TM = BMK / 64, TN = BN / 64;
   using LA = ActLoader<HAS_SUB>;
   using LB = DyLoader<POOLED>;
@@ -570,7 +587,7 @@ extern "C" int t3d_pointmlp_fwd(const t3d_pointmlp_fwd_args* a, t3d_stream_t str
   const int tiles_m = a->M / 128;
   // 128-wide column tiles only when they still give >= 2 workgroups per CU
   const bool sub = a->a.sub != nullptr;
-  if (a->N % 128 == 0 && (long)tiles_m * (a->N / 128) >= 512) {
+  if (T3D_FORCE_TILE != 64 && a->N % 128 == 0 && (T3D_FORCE_TILE == 128 || (long)tiles_m * (a->N / 128) >= 512)) {
     const dim3 grid(tiles_m * (a->N / 128));
     if (sub) launch_lds(k_pointmlp_fwd<128, true>, grid, lds_fwd(128), s, *a);
     else launch_lds(k_pointmlp_fwd<128, false>, grid, lds_fwd(128), s, *a);
@@ -593,7 +610,7 @@ extern "C" int t3d_pointmlp_dgrad(const t3d_pointmlp_dgrad_args* a, t3d_stream_t
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int tiles_m = a->M / 128;
   const bool pooled = a->dy.dz == nullptr;
-  if (a->K % 128 == 0 && (long)tiles_m * (a->K / 128) >= 512) {
+  if (T3D_FORCE_TILE != 64 && a->K % 128 == 0 && (T3D_FORCE_TILE == 128 || (long)tiles_m * (a->K / 128) >= 512)) {
     const dim3 grid(tiles_m * (a->K / 128));
     if (pooled) launch_lds(k_pointmlp_dgrad<128, true>, grid, lds_dgrad(128), s, *a);
     else launch_lds(k_pointmlp_dgrad<128, false>, grid, lds_dgrad(128), s, *a);
