@@ -126,3 +126,44 @@ def test_boxpc_reference_call_sequence():
     assert np.abs(logits - ep['boxpc_fit_logits'].numpy()).max() < 1e-4
     assert np.abs(dc - ep['boxpc_delta_center'].numpy()).max() < 1e-4
     assert abs(float(loss_val) - float(lref)) < 1e-4 * float(lref)
+
+
+def test_stage_c_reference_call_sequence_with_var_list():
+    """train_semisup_adv.py:308-422 in miniature: get_semi_model(F) -> end_points.update(train classes) -> get_semi_loss ->
+    minimize(var_list=class_dependent + class_agnostic/tnet + class_agnostic/box); only the var_list moves."""
+    from test_stage_c_cpu import TRAIN_CLASSES, stage_c_batch
+    B, N, C = 4, 256, 4
+    FLAGS = make_parser().parse_special_args(['--SEMI_MODEL', 'F', '--BOX_PC_MASK_REPRESENTATION', 'A', '--WEAK_WEIGHT_INTRACLASSVAR', '2',
+                                              '--WEAK_WEIGHT_REPROJECTION', '0', '--SEMI_MULTIPLIER_FOR_WEAK_LOSS', '0.05',
+                                              '--SEMI_BOXPC_FIT_ONLY_ON_2D_CLS', '1', '--SEMI_WEIGHT_BOXPC_FIT_LOSS', '1'])
+    batch = stage_c_batch(B, N, C, seed=3, n2d=2)
+    with api.Graph(rt=Runtime(device='cpu', lib=FakeLib()), seed=6).as_default() as g:
+        pls = MODEL.placeholder_inputs(B, N, C)
+        pred, end_points = MODEL.get_semi_model(pls[0], pls[1], pls[2], pls[3], True, use_one_hot=True, c=FLAGS)
+        end_points.update({'intraclsdims_train_classes': TRAIN_CLASSES})
+        labels = tuple(pls[4:])
+        loss = MODEL.get_semi_loss(pred, labels, end_points, c=FLAGS)
+        train_vars = ['class_dependent', 'class_agnostic/tnet', 'class_agnostic/box']
+        train_op = api.AdamOptimizer(1e-3).minimize(loss, var_list=train_vars)
+        sess = api.Session()
+        P0 = g.vars.state_dict()
+        feed = {pls[0]: batch['pc'], pls[3]: batch['one_hot_vec'], pls[4]: batch['y_seg'], pls[5]: batch['y_center'],
+                pls[6]: batch['y_orient_cls'], pls[7]: batch['y_orient_reg'], pls[8]: batch['y_dims_cls'], pls[9]: batch['y_dims_reg'],
+                pls[17]: batch['is_data_2D']}
+        feed.update(batch['dropout_masks'])
+        loss_val, f2c, fit, _ = sess.run([loss, end_points['F2_center'], end_points['boxpc_fit_prob'], train_op], feed_dict=feed)
+        P1 = g.vars.state_dict()
+    c = R.default_config(SEMI_MODEL='F', WEAK_WEIGHT_INTRACLASSVAR=2.0, SEMI_MULTIPLIER_FOR_WEAK_LOSS=0.05,
+                         SEMI_BOXPC_FIT_ONLY_ON_2D_CLS=True, SEMI_WEIGHT_BOXPC_FIT_LOSS=1.0)
+    P0t = {k: torch.tensor(v, dtype=torch.float64) for k, v in P0.items()}
+    lref, ep, _, _ = R.stage_c_forward_backward(P0t, batch, c, TRAIN_CLASSES, bn_decay_val=R.bn_decay(0, B), want_grads=False)
+    assert abs(float(loss_val) - float(lref)) < 1e-4 * float(lref)
+    assert np.abs(fit - ep['boxpc_fit_prob'].numpy()).max() < 1e-4
+    ref_f2c = ep['F_center'].numpy() - ep['boxpc_out'].numpy()[:, 0:3]
+    assert np.abs(f2c - ref_f2c).max() < 1e-4
+    moved = {k for k in P0 if not np.array_equal(P0[k], P1[k])}
+    assert any(k.startswith('class_dependent/box_refine') for k in moved)
+    assert any(k.startswith('class_agnostic/tnet/conv') for k in moved) and any(k.startswith('class_agnostic/box_est/conv') for k in moved)
+    frozen = [k for k in moved if k.startswith('D_boxpc_branch') or (k.startswith('class_agnostic/inst_seg') and 'moving' not in k)]
+    assert not frozen, frozen[:4]
+    assert any(k.startswith('class_agnostic/inst_seg') and 'moving_mean' in k for k in moved)      # seg EMA still updates

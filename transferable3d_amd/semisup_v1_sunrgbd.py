@@ -31,9 +31,62 @@ def get_semi_model(pc, bg_pc, img, one_hot_vec, is_training, use_one_hot, oracle
         return get_semi_model_backbone(pc, bg_pc, img, one_hot_vec, is_training, use_one_hot, oracle_mask=oracle_mask,
                                        norm_box2D=norm_box2D, bn_decay=bn_decay, c=c)
     elif c.SEMI_MODEL == 'F':
-        raise NotImplementedError('SEMI_MODEL F (stage c) is the next row of SURVEY.md section 8')
+        return get_semi_model_final(pc, bg_pc, img, one_hot_vec, is_training, use_one_hot, oracle_mask=oracle_mask,
+                                    norm_box2D=norm_box2D, bn_decay=bn_decay, c=c)
     else:
         raise Exception('Not implemented SEMI_MODEL: %s' % c.SEMI_MODEL)
+
+
+def get_semi_model_final(pc, bg_pc, img, one_hot_vec, is_training, use_one_hot, oracle_mask=None, norm_box2D=None,
+                         bn_decay=None, c=None):
+    """SEMI_MODEL F (semisup_v1_sunrgbd.py:132-230): class-agnostic seg / T-Net / box nets + class-dependent box_refine.
+    The stage-c training graph also contains the frozen Box-PC branch (train_semisup_adv.py:331-411); it is built here as
+    part of the same assembly (nets.SemiModelF) and exposed through end_points exactly as the driver adds it."""
+    from .nets import SemiModelF
+    ctx = pc.ctx
+    e = ctx.engine
+    if oracle_mask is not None:
+        raise NotImplementedError('oracle_mask (debug path, semisup_v1_sunrgbd.py:161-162) is not on the hot path')
+    if isinstance(bn_decay, (int, float)):
+        e.hyper[2] = float(bn_decay)
+    train_classes = getattr(c, 'intraclsdims_train_classes', None)
+    m = SemiModelF(e, c, use_one_hot=use_one_hot, train_classes=train_classes, inputs=ctx.inputs)
+    ctx.assembly = m
+    ctx.is_training = bool(is_training)
+    B, N = e.B, e.rpf
+    T = lambda buf, shape, name: api.Tensor(ctx, buf, shape, name)
+    logits = T(m.seg.logits, (B, N, 2), 'logits')
+    s1 = T(m.tnet.F3.out, (B, 3), 'stage1_center')
+    end_points = {'point_cloud': pc, 'class_one_hot': one_hot_vec, 'stage1_center': s1,
+                  'dims_anchors': MEAN_DIMS_ARR.astype(np.float32), 'orient_anchors': ORIENT_ANCHORS.astype(np.float32),
+                  'feats_lv1': T(m.box.B4.pooled, (B, 512), 'feats_lv1')}
+    W = semisup_models.BoxHeads(T(m.box.G3.out, (B, 67), 'box_params'), s1, '')
+    F = semisup_models.BoxHeads(T(m.R2.out, (B, 67), 'F_box_params'), s1, 'F_')
+    end_points.update(W.end_points())
+    end_points.update(F.end_points())
+    lo = m.loss_op
+    end_points['F_pred_box_reg'] = (T(lo.center, (B, 3), 'F_center_reg'), T(lo.reg_dims, (B, 3), 'F_dims_reg'),
+                                    T(lo.reg_theta, (B,), 'F_orient_reg'))
+    # Box-PC branch outputs and the refined F2_ heads (train_semisup_adv.py:376-411), evaluated on the host at fetch time
+    out9 = T(m.boxpc.F3.out, (B, 9), 'boxpc_out')
+    end_points['boxpc_fit_prob'] = T(m.fit_prob, (B,), 'boxpc_fit_prob')
+    end_points['boxpc_delta_center'] = T(m.boxpc.F3.out[:, 0:3], (B, 3), 'boxpc_delta_center')
+    end_points['boxpc_delta_size'] = T(m.boxpc.F3.out[:, 3:6], (B, 3), 'boxpc_delta_size')
+    end_points['boxpc_delta_angle'] = T(m.boxpc.F3.out[:, 6], (B,), 'boxpc_delta_angle')
+    ST = semisup_models.SlicedTensor
+
+    def wgt():
+        if c.SEMI_WEIGH_BOXPC_DELTA_DURING_TEST:
+            return 1.0 - end_points['boxpc_fit_prob'].numpy()
+        return np.ones(B, np.float32)
+    end_points['F2_center'] = ST(out9, lambda: end_points['F_center'].numpy() - out9.numpy()[:, 0:3] * wgt()[:, None], (B, 3), 'F2_center')
+    end_points['F2_heading_scores'] = end_points['F_heading_scores']
+    end_points['F2_heading_residuals'] = ST(out9, lambda: end_points['F_heading_residuals'].numpy() - (out9.numpy()[:, 6] * wgt())[:, None],
+                                            (B, 12), 'F2_heading_residuals')
+    end_points['F2_size_scores'] = end_points['F_size_scores']
+    end_points['F2_size_residuals'] = ST(out9, lambda: end_points['F_size_residuals'].numpy() - (out9.numpy()[:, 3:6] * wgt()[:, None])[:, None, :],
+                                         (B, 10, 3), 'F2_size_residuals')
+    return (logits, W.pred_box(), F.pred_box()), end_points
 
 
 def get_semi_model_backbone(pc, bg_pc, img, one_hot_vec, is_training, use_one_hot, oracle_mask=None, norm_box2D=None,
@@ -76,9 +129,25 @@ def get_semi_loss(pred, labels, end_points, reduce_loss=True, c=None):
     if c.SEMI_MODEL == 'A':
         return get_semi_loss_backbone(pred, labels, end_points, reduce_loss=reduce_loss, c=c)
     elif c.SEMI_MODEL == 'F':
-        raise NotImplementedError('SEMI_MODEL F (stage c) is the next row of SURVEY.md section 8')
+        return get_semi_loss_final(pred, labels, end_points, reduce_loss=reduce_loss, c=c)
     else:
         raise Exception('Not implemented SEMI_MODEL: %s' % c.SEMI_MODEL)
+
+
+def get_semi_loss_final(pred, labels, end_points, reduce_loss=True, c=None):
+    """strong(F_ heads, normalised by the 3-D count) + SEMI_MULTIPLIER*WEAK_WEIGHT_INTRACLASSVAR*intraclass +
+    SEMI_WEIGHT_BOXPC_FIT_LOSS*fit (semisup_v1_sunrgbd.py:323-421)."""
+    if not reduce_loss:
+        raise Exception('Not implemented')                                  # semisup_v1_sunrgbd.py:420-421
+    if c.WEAK_WEIGHT_REPROJECTION != 0 or c.WEAK_WEIGHT_INACTIVE_VOLUME != 0:
+        raise NotImplementedError('reprojection / inactive-volume losses have weight 0 in recipe c (README.md:84-99)')
+    ctx = pred[0].ctx
+    m = ctx.assembly
+    if 'intraclsdims_train_classes' in end_points:
+        m.train_classes = list(end_points['intraclsdims_train_classes'])
+    ctx.loss = api.Tensor(ctx, m.loss, (), 'semi_loss')
+    end_points['loss_terms'] = api.Tensor(ctx, m.loss_op.terms, (ctx.engine.B, 8), 'loss_terms')
+    return ctx.loss
 
 
 def get_semi_loss_backbone(pred, labels, end_points, reduce_loss=True, c=None):

@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Stage-b training driver (Box-PC Fit net) with the reference's command line
+(sunrgbd/sunrgbd_detection/train_boxpc.py: flags 28-47, graph 219-261, loop 301-366).  The GT-box perturbation sampler
+(box_pc_fit_dataset.py, needs the missing `box_util`) is out of scope: `--synthetic` batches carry the perturbed box in
+label form, its IoU with the GT and the delta labels (transferable3d_amd/synthetic.py).
+
+  python -m transferable3d_amd.train_boxpc --BOX_PC_MASK_REPRESENTATION A --BOXPC_WEIGHT_DELTA 4 --num_point 1024 \
+      --num_channels 4 --max_epoch 1 --steps_per_epoch 100
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+if __package__ in (None, ''):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from transferable3d_amd import api, boxpc_sunrgbd as MODEL            # noqa: E402
+from transferable3d_amd.config import make_parser                       # noqa: E402
+from transferable3d_amd.synthetic import make_batch                     # noqa: E402
+
+
+def build_flags(argv=None):
+    cfg = make_parser()
+    cfg.add_argument('--train_data', type=str, default='synthetic')
+    cfg.add_argument('--gpu', type=int, default=0)
+    cfg.add_argument('--model', default='boxpc_sunrgbd')
+    cfg.add_argument('--log_dir', default='log_boxpc')
+    cfg.add_argument('--num_point', type=int, default=2048)
+    cfg.add_argument('--max_epoch', type=int, default=31)
+    cfg.add_argument('--batch_size', type=int, default=32)
+    cfg.add_argument('--learning_rate', type=float, default=0.001)
+    cfg.add_argument('--optimizer', default='adam')
+    cfg.add_argument('--decay_step', type=int, default=800000)
+    cfg.add_argument('--decay_rate', type=float, default=0.5)
+    cfg.add_argument('--use_one_hot', action='store_true')
+    cfg.add_argument('--no_rgb', action='store_true')
+    cfg.add_argument('--restore_model_path', default=None)
+    cfg.add_argument('--synthetic', action='store_true')
+    cfg.add_argument('--num_channels', type=int, default=None)
+    cfg.add_argument('--steps_per_epoch', type=int, default=100)
+    cfg.add_argument('--seed', type=int, default=0)
+    FLAGS = cfg.parse_special_args(argv)
+    FLAGS.NUM_CHANNELS = FLAGS.num_channels if FLAGS.num_channels else (3 if FLAGS.no_rgb else 6)
+    return FLAGS
+
+
+def train(FLAGS, rt=None, log=print):
+    import torch
+    if rt is None and torch.cuda.is_available():
+        torch.cuda.set_device(FLAGS.gpu)
+    B, N, C = FLAGS.batch_size, FLAGS.num_point, FLAGS.NUM_CHANNELS
+    os.makedirs(FLAGS.log_dir, exist_ok=True)
+    with api.Graph(rt=rt, seed=FLAGS.seed).as_default() as g:
+        pls = MODEL.placeholder_inputs(B, N, C)
+        pc_pl, one_hot_vec_pl, y_seg_pl, x_center_pl, x_orient_cls_pl, x_orient_reg_pl, x_dims_cls_pl, x_dims_reg_pl, \
+            y_box_iou_pl, y_center_delta_pl, y_dims_delta_pl, y_orient_delta_pl = pls
+        box_reg = MODEL.convert_raw_y_box_to_reg_format((x_center_pl, x_orient_cls_pl, x_orient_reg_pl, x_dims_cls_pl, x_dims_reg_pl),
+                                                        one_hot_vec_pl)
+        pred, end_points = MODEL.get_model((box_reg, pc_pl), True, one_hot_vec_pl, use_one_hot_vec=FLAGS.use_one_hot, c=FLAGS)
+        loss = MODEL.get_loss(pred, (y_box_iou_pl, (y_center_delta_pl, y_dims_delta_pl, y_orient_delta_pl)), end_points, c=FLAGS)
+        train_op = api.AdamOptimizer(FLAGS.learning_rate, decay_step=FLAGS.decay_step, decay_rate=FLAGS.decay_rate).minimize(loss)
+        sess = api.Session()
+        if FLAGS.restore_model_path:
+            g.vars.load_state_dict(dict(np.load(FLAGS.restore_model_path)))
+        step, mean_loss = 0, 0.0
+        for epoch in range(FLAGS.max_epoch):
+            t0, loss_sum = time.time(), 0.0
+            for _ in range(FLAGS.steps_per_epoch):
+                b = make_batch(B, N, C, seed=FLAGS.seed * 1000003 + step, boxpc=True)
+                feed = {pc_pl: b['pc'], one_hot_vec_pl: b['one_hot_vec'], x_center_pl: b['y_center'], x_orient_cls_pl: b['y_orient_cls'],
+                        x_orient_reg_pl: b['y_orient_reg'], x_dims_cls_pl: b['y_dims_cls'], x_dims_reg_pl: b['y_dims_reg'],
+                        y_box_iou_pl: b['y_box_iou'], y_center_delta_pl: b['y_center_delta'], y_dims_delta_pl: b['y_dims_delta'],
+                        y_orient_delta_pl: b['y_orient_delta']}
+                loss_val, _ = sess.run([loss, train_op], feed_dict=feed)
+                loss_sum += float(loss_val)
+                step += 1
+            mean_loss = loss_sum / FLAGS.steps_per_epoch
+            log('**** EPOCH %03d ****  mean loss: %f  (%.1f frustums/s incl. host batch synthesis)' % (
+                epoch, mean_loss, FLAGS.steps_per_epoch * B / (time.time() - t0)))
+            if epoch % 5 == 0:
+                path = os.path.join(FLAGS.log_dir, 'model_epoch_%d.npz' % epoch)
+                np.savez(path, **g.vars.state_dict())
+                log('Model saved in file: %s' % path)
+        return g.vars.state_dict(), mean_loss
+
+
+if __name__ == '__main__':
+    train(build_flags())

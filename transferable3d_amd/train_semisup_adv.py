@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""Stage-c training driver (SEMI_MODEL F + frozen Box-PC net) with the reference's command line
+(sunrgbd/sunrgbd_detection/train_semisup_adv.py: flags 30-60, graph 267-433, partial restore 224-237/450-467,
+ALTERNATE_BATCH loop 520-620).  Synthetic frustums replace the SUN-RGBD pickles.
+
+  python -m transferable3d_amd.train_semisup_adv --SEMI_MODEL F --BOX_PC_MASK_REPRESENTATION A --use_one_hot \
+      --SEMI_TRAIN_BOX_TRAIN_CLASS_AG_TNET 1 --SEMI_TRAIN_BOX_TRAIN_CLASS_AG_BOX 1 --SEMI_BOXPC_FIT_ONLY_ON_2D_CLS 1 \
+      --WEAK_WEIGHT_INTRACLASSVAR 2 --WEAK_WEIGHT_REPROJECTION 0 --SEMI_MULTIPLIER_FOR_WEAK_LOSS 0.05 \
+      --init_class_ag_path logA/model_epoch_30.npz --init_boxpc_path logB/model_epoch_30.npz --num_point 1024 --num_channels 4
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+if __package__ in (None, ''):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from transferable3d_amd import api, semisup_v1_sunrgbd as MODEL        # noqa: E402
+from transferable3d_amd.config import make_parser                        # noqa: E402
+from transferable3d_amd.constants import type2class                      # noqa: E402
+from transferable3d_amd.synthetic import make_batch                      # noqa: E402
+
+ALL_CLASSES = ['bed', 'table', 'sofa', 'chair', 'toilet', 'desk', 'dresser', 'night_stand', 'bookshelf', 'bathtub']
+
+
+def build_flags(argv=None):
+    cfg = make_parser()
+    cfg.add_argument('--train_data', type=str, default='synthetic')
+    cfg.add_argument('--gpu', type=int, default=0)
+    cfg.add_argument('--model', default='semisup_v1_sunrgbd')
+    cfg.add_argument('--log_dir', default='log_adv')
+    cfg.add_argument('--num_point', type=int, default=2048)
+    cfg.add_argument('--max_epoch', type=int, default=31)
+    cfg.add_argument('--batch_size', type=int, default=32)
+    cfg.add_argument('--learning_rate', type=float, default=0.001)
+    cfg.add_argument('--optimizer', default='adam')
+    cfg.add_argument('--decay_step', type=int, default=800000)
+    cfg.add_argument('--decay_rate', type=float, default=0.5)
+    cfg.add_argument('--use_one_hot', action='store_true')
+    cfg.add_argument('--use_one_hot_boxpc', action='store_true')
+    cfg.add_argument('--no_rgb', action='store_true')
+    cfg.add_argument('--init_class_ag_path', default=None, help='stage-a state dict (class-agnostic branch)')
+    cfg.add_argument('--init_boxpc_path', default=None, help='stage-b state dict (Box-PC Fit net)')
+    cfg.add_argument('--restore_model_path', default=None)
+    cfg.add_argument('--synthetic', action='store_true')
+    cfg.add_argument('--num_channels', type=int, default=None)
+    cfg.add_argument('--steps_per_epoch', type=int, default=100)
+    cfg.add_argument('--seed', type=int, default=0)
+    FLAGS = cfg.parse_special_args(argv)
+    FLAGS.NUM_CHANNELS = FLAGS.num_channels if FLAGS.num_channels else (3 if FLAGS.no_rgb else 6)
+    FLAGS.TEST_CLS = FLAGS.SUNRGBD_SEMI_TEST_CLS
+    return FLAGS
+
+
+def load_variable_scopes_from_ckpt(vars_, path, scope):
+    """train_semisup_adv.py:224-237: restore every variable under `scope/` from a checkpoint whose names lack that prefix
+    (stage-a / stage-b checkpoints are saved without `class_agnostic/` / `D_boxpc_branch/`)."""
+    sd = dict(np.load(path))
+    n = 0
+    for name in list(vars_.index):
+        if name.startswith(scope + '/') and name[len(scope) + 1:] in sd:
+            vars_.load_state_dict({name: sd[name[len(scope) + 1:]]})
+            n += 1
+    return n
+
+
+def train(FLAGS, rt=None, log=print):
+    import torch
+    if rt is None and torch.cuda.is_available():
+        torch.cuda.set_device(FLAGS.gpu)
+    B, N, C = FLAGS.batch_size, FLAGS.num_point, FLAGS.NUM_CHANNELS
+    os.makedirs(FLAGS.log_dir, exist_ok=True)
+    if FLAGS.SEMI_TRAIN_BOXPC_MODEL or FLAGS.SEMI_ADV_ITERS_FOR_D:
+        raise NotImplementedError('training the Box-PC branch in stage c is dead code in the reference (SEMI_ADV_ITERS_FOR_D = 0)')
+    with api.Graph(rt=rt, seed=FLAGS.seed).as_default() as g:
+        pls = MODEL.placeholder_inputs(B, N, C)
+        pred, end_points = MODEL.get_semi_model(pls[0], pls[1], pls[2], pls[3], True, use_one_hot=FLAGS.use_one_hot, c=FLAGS)
+        intraclsdims_train_classes = [(cls_type in FLAGS.TEST_CLS) for cls_type in ALL_CLASSES] \
+            if FLAGS.SEMI_INTRACLSDIMS_ONLY_ON_2D_CLS else [True] * len(ALL_CLASSES)
+        end_points.update({'intraclsdims_train_classes': intraclsdims_train_classes})
+        semi_loss = MODEL.get_semi_loss(pred, tuple(pls[4:]), end_points, c=FLAGS)
+        train_vars = ['class_dependent']
+        if FLAGS.SEMI_TRAIN_BOX_TRAIN_CLASS_AG_TNET:
+            train_vars.append('class_agnostic/tnet')
+        if FLAGS.SEMI_TRAIN_BOX_TRAIN_CLASS_AG_BOX:
+            train_vars.append('class_agnostic/box')
+        train_op = api.AdamOptimizer(FLAGS.learning_rate, decay_step=FLAGS.decay_step, decay_rate=FLAGS.decay_rate).minimize(
+            semi_loss, var_list=train_vars)
+        sess = api.Session()
+        if FLAGS.init_class_ag_path:
+            log('restored %d class_agnostic variables' % load_variable_scopes_from_ckpt(g.vars, FLAGS.init_class_ag_path, 'class_agnostic'))
+        if FLAGS.init_boxpc_path:
+            log('restored %d D_boxpc_branch variables' % load_variable_scopes_from_ckpt(g.vars, FLAGS.init_boxpc_path, 'D_boxpc_branch'))
+        if FLAGS.restore_model_path:
+            g.vars.load_state_dict(dict(np.load(FLAGS.restore_model_path)))
+        test_ids = [type2class[t] for t in FLAGS.TEST_CLS]
+        train_ids = [i for i in range(10) if i not in test_ids]
+        step, mean_loss = 0, 0.0
+        iters = 2 if FLAGS.SEMI_SAMPLING_METHOD == 'ALTERNATE_BATCH' else 1
+        for epoch in range(FLAGS.max_epoch):
+            t0, loss_sum = time.time(), 0.0
+            for _ in range(FLAGS.steps_per_epoch):
+                for iteration in range(iters):
+                    b = make_batch(B, N, C, seed=FLAGS.seed * 1000003 + step)
+                    if iters == 2:                         # all-2D batch (classes without 3-D labels), then all-3D batch
+                        ids = test_ids if iteration == 0 else train_ids
+                        cls = np.asarray(ids)[np.random.RandomState(step).randint(0, len(ids), size=B)]
+                        b['one_hot_vec'] = np.eye(10, dtype=np.float32)[cls]
+                        b['y_dims_cls'] = cls.astype(np.int32)
+                        b['is_data_2D'][:] = 1 if iteration == 0 else 0
+                    feed = {pls[0]: b['pc'], pls[3]: b['one_hot_vec'], pls[4]: b['y_seg'], pls[5]: b['y_center'], pls[6]: b['y_orient_cls'],
+                            pls[7]: b['y_orient_reg'], pls[8]: b['y_dims_cls'], pls[9]: b['y_dims_reg'], pls[17]: b['is_data_2D']}
+                    loss_val, _ = sess.run([semi_loss, train_op], feed_dict=feed)
+                    loss_sum += float(loss_val)
+                    step += 1
+            mean_loss = loss_sum / (FLAGS.steps_per_epoch * iters)
+            log('**** EPOCH %03d ****  mean loss: %f  (%.1f frustums/s incl. host batch synthesis)' % (
+                epoch, mean_loss, FLAGS.steps_per_epoch * iters * B / (time.time() - t0)))
+            if epoch % 5 == 0:
+                path = os.path.join(FLAGS.log_dir, 'model_epoch_%d.npz' % epoch)
+                np.savez(path, **g.vars.state_dict())
+                log('Model saved in file: %s' % path)
+        return g.vars.state_dict(), mean_loss
+
+
+if __name__ == '__main__':
+    train(build_flags())
