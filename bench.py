@@ -94,6 +94,17 @@ def profile_kernels(plans, steps):
     return acc, detail
 
 
+def pmc_traffic(label):
+    """HBM bytes per launch of `label` from the committed PMC summary (tools/pmc_traffic.py; counters cannot be read from inside
+    the process being timed).  None when the summary is absent or was taken at another problem size."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')
+    try:
+        with open(path) as fh:
+            return json.load(fh)['kernels'][label]['bytes_per_launch']
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(args, batch):
     """The oracle's torch-CPU fp32 restatement of the identical step (fwd + bwd + TF-form Adam), all host
     threads.  TF1 itself cannot run, so kind = "port"."""
@@ -220,7 +231,7 @@ def main():
 
     roofline = None
     cpu = None
-    if rank == 0:
+    if rank == 0 and args.profile_steps > 0:
         # per-kernel timing for the roofline object (eager, per-launch events on the launch stream)
         acc, detail = profile_kernels([g.pre, g.fwd, g.bwd, g.opt], args.profile_steps)
         total = sum(v[0] for v in acc.values())
@@ -230,7 +241,8 @@ def main():
         gemm_t = sum(v[0] for k, v in acc.items() if k.startswith('k_pointmlp'))
         gemm_f = sum(v[2] for k, v in acc.items() if k.startswith('k_pointmlp'))
         roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': achieved, 'peak': MFMA_F32_PEAK_TFLOPS,
-                    'unit': 'TFLOP/s', 'frac': achieved / MFMA_F32_PEAK_TFLOPS, 'traffic': None,
+                    'unit': 'TFLOP/s', 'frac': achieved / MFMA_F32_PEAK_TFLOPS, 'traffic': pmc_traffic(dom),
+                    'traffic_unit': 'HBM bytes per launch, rocprofv3 PMC passes of this workload (profiles/pmc_traffic.json)',
                     'avg_launch_us': tsec / n * 1e6, 'launches_per_step': n // args.profile_steps,
                     'flops_per_launch': fl / n,
                     'all_gemm_kernels': {'achieved': gemm_f / gemm_t / 1e12, 'frac': gemm_f / gemm_t / 1e12 / MFMA_F32_PEAK_TFLOPS,
@@ -242,8 +254,8 @@ def main():
         if args.gemm_detail:
             for k, (t_, n_, f_) in sorted(detail.items(), key=lambda kv: -kv[1][0]):
                 sys.stderr.write('%-44s x%d  %8.1f us  %6.1f TF/s\n' % (k, n_ // args.profile_steps, t_ / n_ * 1e6, f_ / (t_ / n_) / 1e12))
-        if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(args, batch)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, batch)
 
     if rank == 0:
         value = B * world * args.steps / elapsed
