@@ -43,20 +43,29 @@ def parse():
                     help='host threads for the CPU baseline (torch CPU ops stop scaling / oversubscribe beyond this)')
     ap.add_argument('--profile_steps', type=int, default=5)
     ap.add_argument('--gemm_detail', action='store_true', help='per-shape GEMM timings on stderr')
+    ap.add_argument('--call_detail', action='store_true', help='every launch of the step in order with its time, on stderr')
     return ap.parse_args()
 
 
 LIB = None
+CALLS = {}
 
 
 def gemm_label_and_flops(name, a):
     """Mirror of the template dispatch in csrc/pointmlp.hip -> rocprof kernel name + algorithmic FLOPs."""
+    import ctypes
+    if name == 't3d_pointmlp_dgrad_gram':
+        return 'k_pointmlp_dgrad_gram<%d>' % (128 if a.K % 128 == 0 and (a.M // 128) * (a.K // 128) >= 512 else 64), 2.0 * a.M * a.K * a.K
+    if name == 't3d_pointmlp_gram':
+        rps, tk, tn = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        LIB.t3d_wgrad_plan(a.M, a.K, a.K, ctypes.byref(rps), ctypes.byref(tk), ctypes.byref(tn))
+        t = tk.value if (rps.value == a.rows_per_split and tk.value == tn.value) else 64
+        return 'k_pointmlp_gram<%d,%d>' % (t, t), 2.0 * a.M * a.K * a.K
     flops = 2.0 * a.M * a.K * a.N
     if name == 't3d_pointmlp_fwd':
         return 'k_pointmlp_fwd<%d>' % (128 if a.N % 128 == 0 and (a.M // 128) * (a.N // 128) >= 512 else 64), flops
     if name == 't3d_pointmlp_dgrad':
         return 'k_pointmlp_dgrad<%d>' % (128 if a.K % 128 == 0 and (a.M // 128) * (a.K // 128) >= 512 else 64), flops
-    import ctypes
     rps, tk, tn = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
     LIB.t3d_wgrad_plan(a.M, a.K, a.N, ctypes.byref(rps), ctypes.byref(tk), ctypes.byref(tn))
     if rps.value != a.rows_per_split:
@@ -68,6 +77,8 @@ def profile_kernels(plans, steps):
     """Per-launch HIP events (torch events on the stream the kernels are launched on), eager replay."""
     acc = {}
     detail = {}
+    global CALLS
+    CALLS = {}
     for _ in range(steps):
         evs = []
         for plan in plans:
@@ -80,7 +91,8 @@ def profile_kernels(plans, steps):
                 e1.record()
                 evs.append((name, arg, e0, e1))
         torch.cuda.synchronize()
-        for name, arg, e0, e1 in evs:
+        for ci, (name, arg, e0, e1) in enumerate(evs):
+            CALLS.setdefault(ci, [name, arg, 0.0])[2] += e0.elapsed_time(e1) * 1e-3 / steps
             label, flops = (gemm_label_and_flops(name, arg) if name.startswith('t3d_pointmlp') else (name, 0.0))
             d = acc.setdefault(label, [0.0, 0, 0.0])
             dt = e0.elapsed_time(e1) * 1e-3
@@ -88,7 +100,7 @@ def profile_kernels(plans, steps):
             d[1] += 1
             d[2] += flops
             if flops:
-                dd = detail.setdefault('%s M%d K%d N%d' % (label, arg.M, arg.K, arg.N), [0.0, 0, flops])
+                dd = detail.setdefault('%s M%d K%d N%d' % (label, arg.M, arg.K, getattr(arg, 'N', arg.K)), [0.0, 0, flops])
                 dd[0] += dt
                 dd[1] += 1
     return acc, detail
@@ -251,6 +263,11 @@ def main():
                                    'achieved': SPLIT_GFLOP_PER_FRUSTUM * B * args.steps / elapsed / 1e3,
                                    'frac': SPLIT_GFLOP_PER_FRUSTUM * B * args.steps / elapsed / 1e3 / MFMA_F32_PEAK_TFLOPS},
                     'per_kernel_us_per_step': {k: v[0] / args.profile_steps * 1e6 for k, v in sorted(acc.items(), key=lambda kv: -kv[1][0])}}
+        if args.call_detail:
+            for ci in sorted(CALLS):
+                name, arg, t_ = CALLS[ci]
+                dims = ' '.join('%s=%d' % (f, getattr(arg, f)) for f in ('M', 'K', 'N', 'B') if arg is not None and hasattr(arg, f))
+                sys.stderr.write('%3d %-28s %-28s %8.1f us\n' % (ci, name, dims, t_ * 1e6))
         if args.gemm_detail:
             for k, (t_, n_, f_) in sorted(detail.items(), key=lambda kv: -kv[1][0]):
                 sys.stderr.write('%-44s x%d  %8.1f us  %6.1f TF/s\n' % (k, n_ // args.profile_steps, t_ / n_ * 1e6, f_ / (t_ / n_) / 1e12))

@@ -87,7 +87,7 @@ typedef struct {
   const float* w;        /* [K,N] */
   const float* bias;     /* [N] or NULL */
   const float* rowbias;  /* [B,N] or NULL */
-  float* y;              /* [M,N] */
+  float* y;              /* [M,N], or NULL: statistics and pool partials only (Gram-form backward) */
   float* psum;           /* [M/128, N] */
   float* psumsq;         /* [M/128, N] */
   const float* rowmask;  /* [M] or NULL (pool over all rows) */
@@ -222,6 +222,90 @@ typedef struct {
   float* out;              /* [B,N] */
 } t3d_dy_colsum_args;
 int t3d_dy_colsum(const t3d_dy_colsum_args* args, t3d_stream_t stream);
+
+/* ---- K11e: backward of a max-pooled layer in "Gram form" ------------------------------------------
+ * The three pooled layers (seg conv5 128->1024, T-Net conv3 128->256, box conv4 256->512;
+ * semisup_models.py:92-96, 180-188, 236-244) are the widest of their nets.  Their dy is
+ *   dy = c0*dz_sparse + c1*y + c2   with  y = a.w + bias  and dz_sparse non-zero in one row per (b,n),
+ * so both gradients factor through the K x K Gram matrix of the layer INPUT and never touch [M,N]:
+ *   da = a.P + rowconst + S          P = w diag(c1) w^T,  rowconst = w.(c1*bias + c2)
+ *        S[m,:] = sum_{n : argidx[b,n] = m - b*rpf} dpool[b,n] * wc[n,:],   wc[n,k] = c0[n]*w[k,n]
+ *   dw = c1*(G.w + abar (x) bias) + abar (x) c2 + c0 * sum_b dpool[b,n] * a[b*rpf + argidx[b,n], :]
+ *        G = a^T a,  abar = column sums of a
+ * which replaces 4*M*K*N flops by 4*M*K*K and lets the forward pass skip the [M,N] store (y = NULL
+ * in t3d_pointmlp_fwd).  Same autodiff semantics as K11a/K11b (train_semisup.py:249). */
+typedef struct {
+  const float* w;          /* [K,N] */
+  const float* bias;       /* [N] or NULL */
+  const float* coef;       /* [3,N] from t3d_bn_bwd_finalize */
+  int K, N;
+  float* p_slabs;          /* [ceil(N/128), K, K] out: partial P per chunk of 128 columns n (sum with t3d_reduce_slabs) */
+  float* rc_slabs;         /* [ceil(N/128), K] out: partial rowconst */
+  float* wc;               /* [N,K] out */
+} t3d_pool_bwd_prep_args;
+int t3d_pool_bwd_prep(const t3d_pool_bwd_prep_args* args, t3d_stream_t stream);
+
+typedef struct {
+  const int32_t* argidx;   /* [B,N] row within the frustum, -1 = no gradient */
+  const float* dpool;      /* [B,N] */
+  const float* wc;         /* [N,K] */
+  int B, N, K;
+  int rows_per_frustum;
+  float* s;                /* [B*rows_per_frustum, K] out (every row written) */
+} t3d_pool_sparse_rows_args;
+int t3d_pool_sparse_rows(const t3d_pool_sparse_rows_args* args, t3d_stream_t stream);
+
+/* out = (a.p + rowconst + add_in) * 1[prev_y*prev_scale + prev_shift > 0], with the producer's
+ * batch-norm-backward partials, exactly like the epilogue of K11a. */
+typedef struct {
+  t3d_act_src a;           /* [M,K] input of the pooled layer */
+  const float* p;          /* [K,K] */
+  const float* rowconst;   /* [K] or NULL */
+  const float* add_in;     /* [M,K] or NULL (the sparse rows S) */
+  const float* prev_y;     /* [M,K] or NULL */
+  const float* prev_scale;
+  const float* prev_shift;
+  float* out;              /* [M,K] */
+  float* psum_dz;          /* [M/128,K] or NULL */
+  float* psum_dzy;
+  int M, K;
+  int rows_per_frustum;
+} t3d_pointmlp_dgrad_gram_args;
+int t3d_pointmlp_dgrad_gram(const t3d_pointmlp_dgrad_gram_args* args, t3d_stream_t stream);
+
+/* slab[s] = a_s^T a_s over the rows of split s; rows_per_split from t3d_wgrad_plan(M, K, K). */
+typedef struct {
+  t3d_act_src a;
+  float* slabs;            /* [M/rows_per_split, K, K] */
+  int M, K;
+  int rows_per_frustum;
+  int rows_per_split;
+} t3d_pointmlp_gram_args;
+int t3d_pointmlp_gram(const t3d_pointmlp_gram_args* args, t3d_stream_t stream);
+
+/* part[t,k] = sum over the 128 rows of tile t of a[m,k]. */
+typedef struct {
+  t3d_act_src a;
+  int M, K;
+  int rows_per_frustum;
+  float* part;             /* [M/128, K] */
+} t3d_act_colsum_args;
+int t3d_act_colsum(const t3d_act_colsum_args* args, t3d_stream_t stream);
+
+typedef struct {
+  t3d_act_src a;
+  const int32_t* argidx;   /* [B,N] */
+  const float* dpool;      /* [B,N] */
+  const float* coef;       /* [3,N] */
+  const float* w;          /* [K,N] */
+  const float* bias;       /* [N] or NULL */
+  const float* g;          /* [K,K] reduced Gram matrix */
+  const float* abar;       /* [K] column sums of a (t3d_act_colsum partials, reduced) */
+  int B, K, N;
+  int rows_per_frustum;
+  float* dw;               /* [K,N] out */
+} t3d_pool_wgrad_finish_args;
+int t3d_pool_wgrad_finish(const t3d_pool_wgrad_finish_args* args, t3d_stream_t stream);
 
 /* ---- K6: per-frustum fully-connected layer -----------------------------------------------------
  * Replaces tf_util.fully_connected (tf_util.py:1463-1499: matmul + bias [+ batch_norm over the B

@@ -74,7 +74,8 @@ class FakeLib:
         if p.rowbias:
             y = y + np.repeat(arr(p.rowbias, M // rpf, N).astype(np.float64), rpf, axis=0)
         y32 = y.astype(np.float32)
-        arr(p.y, M, N)[:] = y32
+        if p.y:
+            arr(p.y, M, N)[:] = y32
         T = M // 128
         yt = y32.astype(np.float64).reshape(T, 128, N)
         arr(p.psum, T, N)[:] = yt.sum(1)
@@ -161,6 +162,84 @@ class FakeLib:
             o = out32.astype(np.float64).reshape(T, 128, K)
             arr(p.psum_dz, T, K)[:] = o.sum(1)
             arr(p.psum_dzy, T, K)[:] = (o * yp.reshape(T, 128, K)).sum(1)
+        return 0
+
+    # ---- Gram-form backward of a pooled layer (t3d.h K11e) -------------------------------------------------
+    def t3d_pool_bwd_prep(self, a, stream):
+        p = _struct(a)
+        K, N = p.K, p.N
+        w = arr(p.w, K, N).astype(np.float64)
+        c = arr(p.coef, 3, N).astype(np.float64)
+        bias = arr(p.bias, N).astype(np.float64) if p.bias else np.zeros(N)
+        nch = (N + 127) // 128
+        ps, rs = arr(p.p_slabs, nch, K, K), arr(p.rc_slabs, nch, K)
+        for ch in range(nch):
+            sl = slice(ch * 128, min(N, (ch + 1) * 128))
+            ps[ch] = (w[:, sl] * c[1, sl]) @ w[:, sl].T
+            rs[ch] = w[:, sl] @ (bias[sl] * c[1, sl] + c[2, sl])
+        arr(p.wc, N, K)[:] = (w * c[0]).T
+        return 0
+
+    def t3d_pool_sparse_rows(self, a, stream):
+        p = _struct(a)
+        B, N, K, rpf = p.B, p.N, p.K, p.rows_per_frustum
+        ai, dp = arr(p.argidx, B, N), arr(p.dpool, B, N).astype(np.float64)
+        wc = arr(p.wc, N, K).astype(np.float64)
+        s = np.zeros((B * rpf, K))
+        for b in range(B):
+            for n in np.nonzero(ai[b] >= 0)[0]:
+                s[b * rpf + ai[b, n]] += dp[b, n] * wc[n]
+        arr(p.s, B * rpf, K)[:] = s
+        return 0
+
+    def t3d_pointmlp_dgrad_gram(self, a, stream):
+        p = _struct(a)
+        M, K, rpf = p.M, p.K, p.rows_per_frustum
+        da = _act(p.a, M, K, rpf) @ arr(p.p, K, K).astype(np.float64)
+        if p.rowconst:
+            da = da + arr(p.rowconst, K)
+        if p.add_in:
+            da = da + arr(p.add_in, M, K)
+        if p.prev_y:
+            yp = arr(p.prev_y, M, K).astype(np.float64)
+            da = np.where(yp * arr(p.prev_scale, K) + arr(p.prev_shift, K) > 0, da, 0.0)
+        out32 = da.astype(np.float32)
+        arr(p.out, M, K)[:] = out32
+        if p.psum_dz:
+            T = M // 128
+            o = out32.astype(np.float64).reshape(T, 128, K)
+            arr(p.psum_dz, T, K)[:] = o.sum(1)
+            arr(p.psum_dzy, T, K)[:] = (o * yp.reshape(T, 128, K)).sum(1)
+        return 0
+
+    def t3d_pointmlp_gram(self, a, stream):
+        p = _struct(a)
+        M, K, rps = p.M, p.K, p.rows_per_split
+        x = _act(p.a, M, K, p.rows_per_frustum)
+        slabs = arr(p.slabs, M // rps, K, K)
+        for s in range(M // rps):
+            slabs[s] = x[s * rps:(s + 1) * rps].T @ x[s * rps:(s + 1) * rps]
+        return 0
+
+    def t3d_act_colsum(self, a, stream):
+        p = _struct(a)
+        M, K = p.M, p.K
+        arr(p.part, M // 128, K)[:] = _act(p.a, M, K, p.rows_per_frustum).reshape(M // 128, 128, K).sum(1)
+        return 0
+
+    def t3d_pool_wgrad_finish(self, a, stream):
+        p = _struct(a)
+        B, K, N, rpf = p.B, p.K, p.N, p.rows_per_frustum
+        x = _act(p.a, B * rpf, K, rpf)
+        ai, dp = arr(p.argidx, B, N), arr(p.dpool, B, N).astype(np.float64)
+        c = arr(p.coef, 3, N).astype(np.float64)
+        w = arr(p.w, K, N).astype(np.float64)
+        bias = arr(p.bias, N).astype(np.float64) if p.bias else np.zeros(N)
+        g = arr(p.g, K, K).astype(np.float64)
+        abar = arr(p.abar, K).astype(np.float64)
+        rows = x[(np.arange(B)[:, None] * rpf + np.maximum(ai, 0)).reshape(-1)].reshape(B, N, K)
+        gat = (np.where(ai >= 0, dp, 0.0)[:, :, None] * rows).sum(0).T                        # [K,N]
+        arr(p.dw, K, N)[:] = c[1] * (g @ w + np.outer(abar, bias)) + np.outer(abar, c[2]) + c[0] * gat
         return 0
 
     def t3d_pointmlp_wgrad(self, a, stream):

@@ -36,7 +36,10 @@ def test_ctypes_structs_follow_header_field_order():
              't3d_strong_weights': abi.StrongWeights, 't3d_boxpc_rep_args': abi.BoxPcRepArgs,
              't3d_boxpc_rep_bwd_args': abi.BoxPcRepBwdArgs, 't3d_boxpc_loss_args': abi.BoxPcLossArgs,
              't3d_pointmlp_dgrad_narrow_args': abi.DgradNarrowArgs, 't3d_semi_final_loss_args': abi.SemiFinalLossArgs,
-             't3d_anchor_reg_bwd_args': abi.AnchorRegBwdArgs}
+             't3d_anchor_reg_bwd_args': abi.AnchorRegBwdArgs, 't3d_pool_bwd_prep_args': abi.PoolBwdPrepArgs,
+             't3d_pool_sparse_rows_args': abi.PoolSparseRowsArgs, 't3d_pointmlp_dgrad_gram_args': abi.PointMlpDgradGramArgs,
+             't3d_pointmlp_gram_args': abi.PointMlpGramArgs, 't3d_act_colsum_args': abi.ActColsumArgs,
+             't3d_pool_wgrad_finish_args': abi.PoolWgradFinishArgs}
     for cname, cls in pairs.items():
         m = re.search(r'typedef struct \{([^}]*)\}\s*%s;' % cname, h)
         assert m, cname

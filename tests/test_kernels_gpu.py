@@ -629,3 +629,220 @@ def test_stage_c_glue_kernels(hip_lib):
     c, g = _run_both(hip_lib, make_a, 't3d_anchor_reg_bwd')
     _close(c['dbox'], g['dbox'], 1e-5, 1e-6, 'anchor_reg_bwd dbox')
     _close(c['ds1'], g['ds1'], 1e-6, 1e-6, 'anchor_reg_bwd ds1')
+
+
+# ------------------------------------------------------------------------------------------------
+# Gram-form backward of a pooled layer (t3d.h K11e)
+# ------------------------------------------------------------------------------------------------
+def _pool_case(M, K, N, rpf, seed):
+    r = np.random.RandomState(seed)
+    B = M // rpf
+    d = dict(x=r.normal(size=(M, K)).astype(np.float32), sc=(0.5 + r.uniform(size=K)).astype(np.float32),
+             sh=(r.normal(size=K) * 0.3).astype(np.float32), w=(r.normal(size=(K, N)) / np.sqrt(K)).astype(np.float32),
+             bias=(r.normal(size=N) * 0.1).astype(np.float32), coef=r.normal(size=(3, N)).astype(np.float32),
+             dpool=r.normal(size=(B, N)).astype(np.float32))
+    d['sc'][::5] *= -1
+    d['coef'][1] *= 1e-2
+    d['coef'][2] *= 1e-3
+    # argmax rows cluster on few points, like PointNet critical points; some channels get no gradient
+    hot = r.randint(0, rpf, size=(B, 24))
+    d['argidx'] = np.take_along_axis(hot, r.randint(0, 24, size=(B, N)), 1).astype(np.int32)
+    d['argidx'][r.uniform(size=(B, N)) < 0.1] = -1
+    d['argidx'][0, :N // 2] = 5                                         # one row collects half of a frustum's channels
+    return d
+
+
+def _act_src(t, K):
+    return abi.ActSrc(fptr(t['x']), K, 0, fptr(t['sc']), fptr(t['sh']), 1, fptr(None), 0)
+
+
+@pytest.mark.parametrize('K,N', [(128, 1024), (256, 512), (128, 256), (64, 192)])
+def test_pool_bwd_prep(hip_lib, K, N):
+    d = _pool_case(256, K, N, 128, K + N)
+
+    def make(dev):
+        t = {k: _mk(dev, v) for k, v in d.items()}
+        nch = (N + 127) // 128
+        o = dict(p=torch.zeros(nch, K, K, device=dev), rowconst=torch.zeros(nch, K, device=dev), wc=torch.zeros(N, K, device=dev))
+        a = abi.PoolBwdPrepArgs(fptr(t['w']), fptr(t['bias']), fptr(t['coef']), K, N, fptr(o['p']), fptr(o['rowconst']), fptr(o['wc']))
+        a._keep = (t, o)
+        return a, o
+
+    c, g = _run_both(hip_lib, make, 't3d_pool_bwd_prep')
+    _close(c['p'], g['p'], 1e-4, 1e-5 * float(c['p'].abs().max()), 'P slabs')
+    _close(c['rowconst'], g['rowconst'], 1e-4, 1e-5 * float(c['rowconst'].abs().max()), 'rowconst slabs')
+    _close(c['wc'], g['wc'], 1e-6, 1e-7, 'wc')
+
+
+@pytest.mark.parametrize('M,K,N,rpf', [(512, 128, 1024, 256), (256, 256, 512, 128), (1024, 128, 256, 1024)])
+def test_pool_sparse_rows(hip_lib, M, K, N, rpf):
+    d = _pool_case(M, K, N, rpf, M + K)
+    wc = np.ascontiguousarray((d['w'] * d['coef'][0]).T)
+
+    def make(dev):
+        t = {k: _mk(dev, v) for k, v in dict(d, wc=wc).items()}
+        o = dict(s=torch.full((M, K), 7.0, device=dev))                 # every row must be overwritten
+        a = abi.PoolSparseRowsArgs(iptr(t['argidx']), fptr(t['dpool']), fptr(t['wc']), M // rpf, N, K, rpf, fptr(o['s']))
+        a._keep = (t, o)
+        return a, o
+
+    c, g = _run_both(hip_lib, make, 't3d_pool_sparse_rows')
+    _close(c['s'], g['s'], 1e-5, 1e-5 * float(c['s'].abs().max()), 'S')
+    # bit-reproducible: fixed summation order whatever the schedule
+    _, g2 = _run_both(hip_lib, make, 't3d_pool_sparse_rows')
+    assert torch.equal(g['s'], g2['s'])
+
+
+@pytest.mark.parametrize('M,K,rpf', [(512, 128, 256), (256, 256, 128), (8192, 128, 1024)])
+def test_pointmlp_dgrad_gram(hip_lib, M, K, rpf):
+    r = np.random.RandomState(M + K)
+    T = M // 128
+    x = r.normal(size=(M, K)).astype(np.float32)
+    sc, sh = (0.5 + r.uniform(size=K)).astype(np.float32), (r.normal(size=K) * 0.3).astype(np.float32)
+    P = (r.normal(size=(K, K)) / np.sqrt(K)).astype(np.float32)
+    rc = r.normal(size=K).astype(np.float32) * 0.1
+    S = (r.normal(size=(M, K)) * (r.uniform(size=(M, 1)) < 0.1)).astype(np.float32)
+
+    def make(dev):
+        t = {k: _mk(dev, v) for k, v in dict(x=x, sc=sc, sh=sh, P=P, rc=rc, S=S).items()}
+        o = dict(out=torch.zeros(M, K, device=dev), s1=torch.zeros(T, K, device=dev), s2=torch.zeros(T, K, device=dev))
+        a = abi.PointMlpDgradGramArgs()
+        a.a, a.p, a.rowconst, a.add_in = _act_src(t, K), fptr(t['P']), fptr(t['rc']), fptr(t['S'])
+        a.prev_y, a.prev_scale, a.prev_shift = fptr(t['x']), fptr(t['sc']), fptr(t['sh'])
+        a.out, a.psum_dz, a.psum_dzy = fptr(o['out']), fptr(o['s1']), fptr(o['s2'])
+        a.M, a.K, a.rows_per_frustum = M, K, rpf
+        a._keep = (t, o)
+        return a, o
+
+    c, g = _run_both(hip_lib, make, 't3d_pointmlp_dgrad_gram')
+    scale = float(c['out'].abs().max())
+    _close(c['out'], g['out'], 1e-4, 2e-5 * scale, 'out')
+    _close(c['s1'], g['s1'], 1e-3, 1e-3 * scale, 'psum_dz')
+    _close(c['s2'], g['s2'], 1e-3, 2e-3 * scale, 'psum_dzy')
+
+
+@pytest.mark.parametrize('M,K,rpf', [(1024, 128, 256), (512, 256, 128), (4096, 64, 1024)])
+def test_pointmlp_gram_and_act_colsum(hip_lib, M, K, rpf):
+    d = _pool_case(M, K, 64, rpf, M + 3 * K)
+    rps, tk, tn = C.c_int(0), C.c_int(0), C.c_int(0)
+    assert hip_lib.t3d_wgrad_plan(M, K, K, C.byref(rps), C.byref(tk), C.byref(tn)) == 0
+    S = M // rps.value
+
+    def make_g(dev):
+        t = {k: _mk(dev, v) for k, v in d.items()}
+        o = dict(slabs=torch.zeros(S, K, K, device=dev))
+        a = abi.PointMlpGramArgs(_act_src(t, K), fptr(o['slabs']), M, K, rpf, rps.value)
+        a._keep = (t, o)
+        return a, o
+
+    c, g = _run_both(hip_lib, make_g, 't3d_pointmlp_gram')
+    _close(c['slabs'], g['slabs'], 1e-4, 1e-5 * float(c['slabs'].abs().max()), 'gram slabs')
+    gs = g['slabs'].sum(0)
+    assert torch.equal(gs, gs.T.contiguous()), 'Gram matrix must be bitwise symmetric (finish kernel reads it transposed)'
+
+    def make_c(dev):
+        t = {k: _mk(dev, v) for k, v in d.items()}
+        o = dict(part=torch.zeros(M // 128, K, device=dev))
+        a = abi.ActColsumArgs(_act_src(t, K), M, K, rpf, fptr(o['part']))
+        a._keep = (t, o)
+        return a, o
+
+    c, g = _run_both(hip_lib, make_c, 't3d_act_colsum')
+    _close(c['part'], g['part'], 1e-5, 1e-4, 'abar partials')
+
+
+@pytest.mark.parametrize('M,K,N,rpf', [(512, 128, 1024, 256), (256, 256, 512, 128), (512, 64, 64, 128)])
+def test_pool_wgrad_finish(hip_lib, M, K, N, rpf):
+    d = _pool_case(M, K, N, rpf, M + N)
+    r = np.random.RandomState(5)
+    G = r.normal(size=(K, K)).astype(np.float32)
+    G = G + G.T
+    part = r.normal(size=K).astype(np.float32)
+
+    def make(dev):
+        t = {k: _mk(dev, v) for k, v in dict(d, G=G, part=part).items()}
+        o = dict(dw=torch.zeros(K, N, device=dev))
+        a = abi.PoolWgradFinishArgs()
+        a.a, a.argidx, a.dpool, a.coef = _act_src(t, K), iptr(t['argidx']), fptr(t['dpool']), fptr(t['coef'])
+        a.w, a.bias, a.g, a.abar = fptr(t['w']), fptr(t['bias']), fptr(t['G']), fptr(t['part'])
+        a.B, a.K, a.N, a.rows_per_frustum, a.dw = M // rpf, K, N, rpf, fptr(o['dw'])
+        a._keep = (t, o)
+        return a, o
+
+    c, g = _run_both(hip_lib, make, 't3d_pool_wgrad_finish')
+    _close(c['dw'], g['dw'], 1e-4, 1e-5 * float(c['dw'].abs().max()), 'dw')
+
+
+def test_pointmlp_fwd_without_y_store_gives_the_same_statistics(hip_lib):
+    M, K, N, rpf = 512, 128, 256, 256
+    r = np.random.RandomState(11)
+    x, w = r.normal(size=(M, K)).astype(np.float32), (r.normal(size=(K, N)) / np.sqrt(K)).astype(np.float32)
+    dev = _dev('cuda')
+    outs = []
+    for store in (True, False):
+        t = dict(x=_mk(dev, x), w=_mk(dev, w))
+        o = {k: torch.zeros(M // 128, N, device=dev) for k in ('psum', 'psumsq', 'pmax', 'pmin')}
+        o.update(pamax=torch.zeros(M // 128, N, dtype=torch.int32, device=dev), pamin=torch.zeros(M // 128, N, dtype=torch.int32, device=dev))
+        y = torch.zeros(M, N, device=dev)
+        a = abi.PointMlpFwdArgs()
+        a.a = abi.ActSrc(fptr(t['x']), K, 0, fptr(None), fptr(None), 0, fptr(None), 0)
+        a.w, a.y, a.psum, a.psumsq = fptr(t['w']), fptr(y if store else None), fptr(o['psum']), fptr(o['psumsq'])
+        a.pmax, a.pmin, a.pamax, a.pamin = fptr(o['pmax']), fptr(o['pmin']), iptr(o['pamax']), iptr(o['pamin'])
+        a.M, a.K, a.N, a.rows_per_frustum = M, K, N, rpf
+        assert hip_lib.t3d_pointmlp_fwd(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+        torch.cuda.synchronize()
+        outs.append({k: v.cpu() for k, v in o.items()})
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+
+
+def test_gram_form_equals_direct_form_through_the_kernels(hip_lib):
+    """da and dW of a pooled layer: Gram-form kernel chain vs the direct pooled-sparse dgrad / wgrad kernels."""
+    M, K, N, rpf = 1024, 128, 512, 256
+    B, T = M // rpf, M // 128
+    d = _pool_case(M, K, N, rpf, 77)
+    dev = _dev('cuda')
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    t = {k: _mk(dev, v) for k, v in d.items()}
+    act = _act_src(t, K)
+    z = lambda *s, **kw: torch.zeros(*s, device=dev, **kw)
+    # forward (stores y for the direct form)
+    y, ps, pq = z(M, N), z(T, N), z(T, N)
+    f = abi.PointMlpFwdArgs()
+    f.a, f.w, f.bias, f.y, f.psum, f.psumsq, f.M, f.K, f.N, f.rows_per_frustum = act, fptr(t['w']), fptr(t['bias']), fptr(y), fptr(ps), fptr(pq), M, K, N, rpf
+    assert hip_lib.t3d_pointmlp_fwd(C.byref(f), st) == 0
+    # direct form
+    dy = abi.DySrc(fptr(None), fptr(y), fptr(t['coef']), iptr(t['argidx']), fptr(t['dpool']))
+    out_d, s1d, s2d = z(M, K), z(T, K), z(T, K)
+    a = abi.PointMlpDgradArgs()
+    a.dy, a.w, a.prev_y, a.prev_scale, a.prev_shift = dy, fptr(t['w']), fptr(t['x']), fptr(t['sc']), fptr(t['sh'])
+    a.out, a.psum_dz, a.psum_dzy, a.M, a.K, a.N, a.rows_per_frustum = fptr(out_d), fptr(s1d), fptr(s2d), M, K, N, rpf
+    assert hip_lib.t3d_pointmlp_dgrad(C.byref(a), st) == 0
+    slab = z(1, K, N)
+    wg = abi.PointMlpWgradArgs(act, dy, fptr(slab), M, K, N, rpf, M)
+    assert hip_lib.t3d_pointmlp_wgrad(C.byref(wg), st) == 0
+    # Gram form
+    nch = N // 128
+    Ps, rcs, wc, S = z(nch, K, K), z(nch, K), z(N, K), z(M, K)
+    assert hip_lib.t3d_pool_bwd_prep(C.byref(abi.PoolBwdPrepArgs(fptr(t['w']), fptr(t['bias']), fptr(t['coef']), K, N, fptr(Ps), fptr(rcs), fptr(wc))), st) == 0
+    P, rc = Ps.sum(0), rcs.sum(0)
+    assert hip_lib.t3d_pool_sparse_rows(C.byref(abi.PoolSparseRowsArgs(iptr(t['argidx']), fptr(t['dpool']), fptr(wc), B, N, K, rpf, fptr(S))), st) == 0
+    out_g, s1g, s2g = z(M, K), z(T, K), z(T, K)
+    gg = abi.PointMlpDgradGramArgs()
+    gg.a, gg.p, gg.rowconst, gg.add_in, gg.prev_y, gg.prev_scale, gg.prev_shift = act, fptr(P), fptr(rc), fptr(S), fptr(t['x']), fptr(t['sc']), fptr(t['sh'])
+    gg.out, gg.psum_dz, gg.psum_dzy, gg.M, gg.K, gg.rows_per_frustum = fptr(out_g), fptr(s1g), fptr(s2g), M, K, rpf
+    assert hip_lib.t3d_pointmlp_dgrad_gram(C.byref(gg), st) == 0
+    gsl, part, dw = z(1, K, K), z(T, K), z(K, N)
+    assert hip_lib.t3d_pointmlp_gram(C.byref(abi.PointMlpGramArgs(act, fptr(gsl), M, K, rpf, M)), st) == 0
+    assert hip_lib.t3d_act_colsum(C.byref(abi.ActColsumArgs(act, M, K, rpf, fptr(part))), st) == 0
+    fin = abi.PoolWgradFinishArgs()
+    fin.a, fin.argidx, fin.dpool, fin.coef, fin.w, fin.bias = act, iptr(t['argidx']), fptr(t['dpool']), fptr(t['coef']), fptr(t['w']), fptr(t['bias'])
+    torch.cuda.synchronize()
+    abar = part.sum(0)
+    fin.g, fin.abar, fin.B, fin.K, fin.N, fin.rows_per_frustum, fin.dw = fptr(gsl), fptr(abar), B, K, N, rpf, fptr(dw)
+    assert hip_lib.t3d_pool_wgrad_finish(C.byref(fin), st) == 0
+    torch.cuda.synchronize()
+    sd, sw = float(out_d.abs().max()), float(slab.abs().max())
+    _close(out_d.cpu(), out_g.cpu(), 1e-4, 3e-5 * sd, 'da gram vs direct')
+    _close(slab[0].cpu(), dw.cpu(), 1e-4, 3e-5 * sw, 'dW gram vs direct')
+    _close(s1d.cpu(), s1g.cpu(), 1e-3, 1e-3 * sd, 'psum_dz gram vs direct')

@@ -4,8 +4,8 @@
 Units and gfx950 corrections per /opt/skills/guides (cdna_hip_programming.md section 7, MI355X_MICROARCH.md "HBM"):
 both counters are in KiB; FETCH_SIZE reads exactly half of a wide coalesced streaming read on gfx950, so
     bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.
-Kernels are keyed the way bench.py labels them: k_pointmlp_fwd<BN>, k_pointmlp_dgrad<BN>, k_pointmlp_wgrad<BMK,BN>, other kernels by
-bare name.
+Kernels are keyed the way bench.py labels them: the GEMM kernels by name + tile sizes (k_pointmlp_fwd<BN>,
+k_pointmlp_wgrad<BMK,BN>, ...), other kernels by bare name.
 
   python tools/pmc_traffic.py gpurun_out/r01/pmc_fetch gpurun_out/r01/pmc_write -o profiles/pmc_traffic.json
 """
@@ -25,10 +25,9 @@ def label(kernel_name):
     if not m:
         return None
     name, targs = m.group(1), [t.strip() for t in (m.group(2) or '').split(',') if t.strip()]
-    if name in ('k_pointmlp_fwd', 'k_pointmlp_dgrad'):
-        return '%s<%s>' % (name, targs[0])
-    if name == 'k_pointmlp_wgrad':
-        return '%s<%s,%s>' % (name, targs[0], targs[1])
+    ints = [t for t in targs if t.isdigit()]          # tile sizes; the bool template flags are not part of the label
+    if name.startswith('k_pointmlp') and ints:
+        return '%s<%s>' % (name, ','.join(ints))
     return name
 
 

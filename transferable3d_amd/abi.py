@@ -53,6 +53,32 @@ class PointMlpWgradArgs(C.Structure):
                 ('rows_per_frustum', i32), ('rows_per_split', i32)]
 
 
+class PoolBwdPrepArgs(C.Structure):
+    _fields_ = [('w', F), ('bias', F), ('coef', F), ('K', i32), ('N', i32), ('p_slabs', F), ('rc_slabs', F), ('wc', F)]
+
+
+class PoolSparseRowsArgs(C.Structure):
+    _fields_ = [('argidx', I), ('dpool', F), ('wc', F), ('B', i32), ('N', i32), ('K', i32), ('rows_per_frustum', i32), ('s', F)]
+
+
+class PointMlpDgradGramArgs(C.Structure):
+    _fields_ = [('a', ActSrc), ('p', F), ('rowconst', F), ('add_in', F), ('prev_y', F), ('prev_scale', F), ('prev_shift', F),
+                ('out', F), ('psum_dz', F), ('psum_dzy', F), ('M', i32), ('K', i32), ('rows_per_frustum', i32)]
+
+
+class PointMlpGramArgs(C.Structure):
+    _fields_ = [('a', ActSrc), ('slabs', F), ('M', i32), ('K', i32), ('rows_per_frustum', i32), ('rows_per_split', i32)]
+
+
+class ActColsumArgs(C.Structure):
+    _fields_ = [('a', ActSrc), ('M', i32), ('K', i32), ('rows_per_frustum', i32), ('part', F)]
+
+
+class PoolWgradFinishArgs(C.Structure):
+    _fields_ = [('a', ActSrc), ('argidx', I), ('dpool', F), ('coef', F), ('w', F), ('bias', F), ('g', F), ('abar', F),
+                ('B', i32), ('K', i32), ('N', i32), ('rows_per_frustum', i32), ('dw', F)]
+
+
 class BnBwdFinalizeArgs(C.Structure):
     _fields_ = [('psum_dz', F), ('psum_dzy', F), ('n_tiles', i32), ('dpool_in', F), ('ld_dpool_in', i32),
                 ('pooled', F), ('ld_pooled', i32), ('ysel', F), ('dpool', F), ('B', i32), ('count', i32), ('N', i32),
@@ -162,6 +188,12 @@ ENTRY_POINTS = {
     't3d_wgrad_plan': [i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
     't3d_bn_bwd_finalize': [C.POINTER(BnBwdFinalizeArgs), VP],
     't3d_dy_colsum': [C.POINTER(DyColsumArgs), VP],
+    't3d_pool_bwd_prep': [C.POINTER(PoolBwdPrepArgs), VP],
+    't3d_pool_sparse_rows': [C.POINTER(PoolSparseRowsArgs), VP],
+    't3d_pointmlp_dgrad_gram': [C.POINTER(PointMlpDgradGramArgs), VP],
+    't3d_pointmlp_gram': [C.POINTER(PointMlpGramArgs), VP],
+    't3d_act_colsum': [C.POINTER(ActColsumArgs), VP],
+    't3d_pool_wgrad_finish': [C.POINTER(PoolWgradFinishArgs), VP],
     't3d_fc_fwd': [C.POINTER(FcFwdArgs), VP],
     't3d_fc_bwd': [C.POINTER(FcBwdArgs), VP],
     't3d_fc_dinput': [C.POINTER(FcDinputArgs), VP],

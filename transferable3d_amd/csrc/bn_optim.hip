@@ -163,33 +163,52 @@ __global__ __launch_bounds__(256) void k_dy_colsum(const t3d_dy_colsum_args p) {
   p.out[i] = (float)((double)p.alpha * v);
 }
 
-// every slab region starts 16-byte aligned and numel % 4 == 0 (checked on the host side of the ABI)
+// every slab region starts 16-byte aligned and numel % 4 == 0 for the engine's allocations (float4 path); anything
+// else takes the scalar path.  A block = 32 float4 elements x 8 slab groups: thread (e, g) sums slabs g, g+8, ... with
+// four loads in flight, the 8 group sums are combined through LDS in a fixed order.  Splitting the slab chain over
+// threads is what keeps the many-slab / few-element tensors (64x64 layers with 256 slabs) from being one long latency
+// chain while the rest of the chip idles.
 __global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ slab_base, float* __restrict__ grad_base,
                                                       const t3d_slab_desc* __restrict__ table) {
+  __shared__ float4 part[8][32];
   const t3d_slab_desc d = table[blockIdx.y];
-  // float4 path needs 16-byte aligned regions (always true for the engine's allocations)
   const bool vec = ((d.slab_off | d.grad_off | (int64_t)d.numel) & 3) == 0;
   const int n4 = vec ? (d.numel >> 2) : 0;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += gridDim.x * blockDim.x) {
-    const float4* s = reinterpret_cast<const float4*>(slab_base + d.slab_off) + e;
+  const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  for (int e0 = blockIdx.x * 32; e0 < n4; e0 += gridDim.x * 32) {
+    const int e = e0 + el;
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
-    int k = 0;
-    for (; k + 3 < d.n_slabs; k += 4) {
-      const float4 v0 = s[(size_t)(k + 0) * n4], v1 = s[(size_t)(k + 1) * n4], v2 = s[(size_t)(k + 2) * n4],
-                   v3 = s[(size_t)(k + 3) * n4];
-      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
-      a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
-      a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
-      a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
-    }
-    for (; k < d.n_slabs; ++k) {
-      const float4 v = s[(size_t)k * n4];
-      a0.x += v.x; a0.y += v.y; a0.z += v.z; a0.w += v.w;
+    if (e < n4) {
+      const float4* s = reinterpret_cast<const float4*>(slab_base + d.slab_off) + e;
+      int k = grp;
+      for (; k + 24 < d.n_slabs; k += 32) {
+        const float4 v0 = s[(size_t)(k + 0) * n4], v1 = s[(size_t)(k + 8) * n4], v2 = s[(size_t)(k + 16) * n4],
+                     v3 = s[(size_t)(k + 24) * n4];
+        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+        a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+        a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+        a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+      }
+      for (; k < d.n_slabs; k += 8) {
+        const float4 v = s[(size_t)k * n4];
+        a0.x += v.x; a0.y += v.y; a0.z += v.z; a0.w += v.w;
+      }
     }
     float4 r;
     r.x = (a0.x + a1.x) + (a2.x + a3.x); r.y = (a0.y + a1.y) + (a2.y + a3.y);
     r.z = (a0.z + a1.z) + (a2.z + a3.z); r.w = (a0.w + a1.w) + (a2.w + a3.w);
-    reinterpret_cast<float4*>(grad_base + d.grad_off)[e] = r;
+    part[grp][el] = r;
+    __syncthreads();
+    if (grp == 0 && e < n4) {
+      float4 t = part[0][el];
+#pragma unroll
+      for (int g = 1; g < 8; ++g) {
+        const float4 u = part[g][el];
+        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+      }
+      reinterpret_cast<float4*>(grad_base + d.grad_off)[e] = t;
+    }
+    __syncthreads();
   }
   if (!vec) {
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < d.numel; e += gridDim.x * blockDim.x) {
@@ -292,8 +311,8 @@ extern "C" int t3d_dy_colsum(const t3d_dy_colsum_args* a, t3d_stream_t stream) {
 extern "C" int t3d_reduce_slabs(const float* slab_base, float* grad_base, const t3d_slab_desc* table_dev, int n_tensors,
                                 int max_numel, t3d_stream_t stream) {
   if (!slab_base || !grad_base || !table_dev || n_tensors <= 0) return T3D_ERR_ARG;
-  int gx = (max_numel / 4 + 255) / 256;
-  if (gx > 128) gx = 128;
+  int gx = (max_numel / 4 + 31) / 32;      // one block per 32 float4 elements of the largest tensor
+  if (gx > 256) gx = 256;
   if (gx < 1) gx = 1;
   T3D_LAUNCH(k_reduce_slabs, dim3(gx, n_tensors), dim3(256), 0, static_cast<hipStream_t>(stream), slab_base,
                      grad_base, table_dev);

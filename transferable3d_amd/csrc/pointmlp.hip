@@ -356,6 +356,7 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd(const t3d_pointm
   const int l31 = lane & 31, h = lane >> 5;
   const int b = row0 / p.rows_per_frustum;
   const bool pool = p.pmax != nullptr;
+  const bool store_y = p.y != nullptr;      // Gram-form backward: statistics and pool partials only
   float* red = smem;   // [2][BN] x 6 quantities
   float csum[TN], csq[TN], cmax[TN], cmin[TN];
   int amax[TN], amin[TN];
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd(const t3d_pointm
       for (int r = 0; r < 16; ++r) {
         const int row = row0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const float v = acc[tm][tn][r] + add;
-        p.y[(size_t)row * p.N + col] = v;
+        if (store_y) p.y[(size_t)row * p.N + col] = v;
         s += v;
         ss = fmaf(v, v, ss);
         if (pool) {
@@ -430,42 +431,33 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd(const t3d_pointm
 // ---------------------------------------------------------------------------------------------
 // data gradient
 // ---------------------------------------------------------------------------------------------
-template <int BN, bool POOLED>   // BN = tile width over the layer's INPUT channels K
-__global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_dgrad(const t3d_pointmlp_dgrad_args p) {
-  constexpr int BM = 128, TM = 2, TN = BN / 64;
-  using LA = DyLoader<POOLED>;
-  using SA = Stager<BM, true, LA>;
-  using SB = Stager<BN, true, WLoader>;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+// Shared epilogue of the two data-gradient kernels: + add_in (+ per-column constant), ReLU mask of the producing
+// layer, that layer's batch-norm-backward partial sums, store.
+struct DgradEpilogue {
+  const float* add_in;
+  const float* colconst;
+  const float* prev_y;
+  const float* prev_scale;
+  const float* prev_shift;
+  float* out;
+  float* psum_dz;
+  float* psum_dzy;
+  int K;
+};
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1;
-  const int tiles_n = p.K / BN;
-  const int lin = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_m = lin / tiles_n, tile_n = lin % tiles_n;
-  const int row0 = tile_m * BM, col0 = tile_n * BN;
-
-  LA la{p.dy, p.N, p.rows_per_frustum};
-  WLoader lb{p.w, p.N, p.K, p.N};
-  SA sa; SB sb;
-  sa.init(la, row0, tid);
-  sb.init(lb, col0, tid);
-
-  f32x16 acc[TM][TN];
-  zero_acc<TM, TN>(acc);
-  const int nred = (p.N + BK - 1) / BK * BK;
-  gemm_mainloop<TM, TN, SA, SB, LA, WLoader, true, BM, true, BN>(sa, sb, la, lb, smem, 0, nred, wm * 64,
-                                                                      wn * (BN / 2), acc, tid);
-
+template <int BN, int TM, int TN>
+__device__ __forceinline__ void dgrad_epilogue(const DgradEpilogue& p, f32x16 (&acc)[TM][TN], float* red, int tid, int row0,
+                                               int col0, int tile_m) {
+  const int lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
   const int l31 = lane & 31, h = lane >> 5;
   const bool relu_mask = p.prev_y != nullptr;
   const bool stats = p.psum_dz != nullptr;
-  float* red = smem;
   float cs1[TN], cs2[TN];
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int col = col0 + wn * (BN / 2) + tn * 32 + l31;
     const float psc = relu_mask ? p.prev_scale[col] : 0.f, psh = relu_mask ? p.prev_shift[col] : 0.f;
+    const float cc = p.colconst ? p.colconst[col] : 0.f;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
@@ -473,7 +465,7 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_dgrad(const t3d_poin
       for (int r = 0; r < 16; ++r) {
         const int row = row0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const size_t o = (size_t)row * p.K + col;
-        float v = acc[tm][tn][r];
+        float v = acc[tm][tn][r] + cc;
         if (p.add_in) v += p.add_in[o];
         if (relu_mask) {
           const float yp = p.prev_y[o];
@@ -507,40 +499,92 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_dgrad(const t3d_poin
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// weight gradient (split over rows)
-// ---------------------------------------------------------------------------------------------
-template <int BMK, int BN, bool HAS_SUB, bool POOLED>
-__global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_wgrad(const t3d_pointmlp_wgrad_args p) {
-  constexpr int TM = BMK / 64, TN = BN / 64;
-  using LA = ActLoader<HAS_SUB>;
-  using LB = DyLoader<POOLED>;
-  using SA = Stager<BMK, false, LA>;
-  using SB = Stager<BN, false, LB>;
+template <int BN, bool POOLED>   // BN = tile width over the layer's INPUT channels K
+__global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_dgrad(const t3d_pointmlp_dgrad_args p) {
+  constexpr int BM = 128, TM = 2, TN = BN / 64;
+  using LA = DyLoader<POOLED>;
+  using SA = Stager<BM, true, LA>;
+  using SB = Stager<BN, true, WLoader>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
-  const int tiles_k = (p.K + BMK - 1) / BMK, tiles_n = p.N / BN;
+  const int tiles_n = p.K / BN;
+  const int lin = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = lin / tiles_n, tile_n = lin % tiles_n;
+  const int row0 = tile_m * BM, col0 = tile_n * BN;
+
+  LA la{p.dy, p.N, p.rows_per_frustum};
+  WLoader lb{p.w, p.N, p.K, p.N};
+  SA sa; SB sb;
+  sa.init(la, row0, tid);
+  sb.init(lb, col0, tid);
+
+  f32x16 acc[TM][TN];
+  zero_acc<TM, TN>(acc);
+  const int nred = (p.N + BK - 1) / BK * BK;
+  gemm_mainloop<TM, TN, SA, SB, LA, WLoader, true, BM, true, BN>(sa, sb, la, lb, smem, 0, nred, wm * 64,
+                                                                      wn * (BN / 2), acc, tid);
+
+  DgradEpilogue e{p.add_in, nullptr, p.prev_y, p.prev_scale, p.prev_shift, p.out, p.psum_dz, p.psum_dzy, p.K};
+  dgrad_epilogue<BN, TM, TN>(e, acc, smem, tid, row0, col0, tile_m);
+}
+
+// Gram-form data gradient of a max-pooled layer: out = act(a) . P + rowconst + S  (see t3d.h K11e); the operand
+// side is the forward kernel's (activations type R, the K x K matrix type C), the epilogue is the dgrad one.
+template <int BN>
+__global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_dgrad_gram(const t3d_pointmlp_dgrad_gram_args p) {
+  constexpr int BM = 128, TM = 2, TN = BN / 64;
+  using LA = ActLoader<false>;
+  using SA = Stager<BM, true, LA>;
+  using SB = Stager<BN, false, WLoader>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int tiles_n = p.K / BN;
+  const int lin = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = lin / tiles_n, tile_n = lin % tiles_n;
+  const int row0 = tile_m * BM, col0 = tile_n * BN;
+  LA la{p.a, p.K, p.rows_per_frustum};
+  WLoader lb{p.p, p.K, p.K, p.K};
+  SA sa; SB sb;
+  sa.init(la, row0, tid);
+  sb.init(lb, col0, tid);
+  f32x16 acc[TM][TN];
+  zero_acc<TM, TN>(acc);
+  gemm_mainloop<TM, TN, SA, SB, LA, WLoader, true, BM, false, BN>(sa, sb, la, lb, smem, 0, p.K, wm * 64, wn * (BN / 2), acc,
+                                                                        tid);
+  DgradEpilogue e{p.add_in, p.rowconst, p.prev_y, p.prev_scale, p.prev_shift, p.out, p.psum_dz, p.psum_dzy, p.K};
+  dgrad_epilogue<BN, TM, TN>(e, acc, smem, tid, row0, col0, tile_m);
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient (split over rows)
+// ---------------------------------------------------------------------------------------------
+// slab[split][k0.., n0..] = sum over the split's rows of A[m,k] B[m,n]; both operands type C (row index = reduction).
+template <int BMK, int BN, class LA, class LB>
+__device__ __forceinline__ void wgrad_body(const LA& la, const LB& lb, float* slabs, int K, int N, int rows_per_split,
+                                           float* smem) {
+  constexpr int TM = BMK / 64, TN = BN / 64;
+  using SA = Stager<BMK, false, LA>;
+  using SB = Stager<BN, false, LB>;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int tiles_k = (K + BMK - 1) / BMK, tiles_n = N / BN;
   const int lin = xcd_remap(blockIdx.x, gridDim.x);
   const int split = lin / (tiles_k * tiles_n);
   const int t = lin % (tiles_k * tiles_n);
   const int k0 = (t / tiles_n) * BMK, n0 = (t % tiles_n) * BN;
-
-  LA la{p.a, p.K, p.rows_per_frustum};
-  LB lb{p.dy, p.N, p.rows_per_frustum};
   SA sa; SB sb;
   sa.init(la, k0, tid);
   sb.init(lb, n0, tid);
-
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
-  const int m_begin = split * p.rows_per_split;
-  gemm_mainloop<TM, TN, SA, SB, LA, LB, false, BMK, false, BN>(sa, sb, la, lb, smem, m_begin,
-                                                                           m_begin + p.rows_per_split, wm * (BMK / 2),
-                                                                           wn * (BN / 2), acc, tid);
+  const int m_begin = split * rows_per_split;
+  gemm_mainloop<TM, TN, SA, SB, LA, LB, false, BMK, false, BN>(sa, sb, la, lb, smem, m_begin, m_begin + rows_per_split,
+                                                                           wm * (BMK / 2), wn * (BN / 2), acc, tid);
   const int l31 = lane & 31, h = lane >> 5;
-  float* slab = p.slabs + (size_t)split * p.K * p.N;
+  float* slab = slabs + (size_t)split * K * N;
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int col = n0 + wn * (BN / 2) + tn * 32 + l31;
@@ -549,10 +593,26 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_wgrad(const t3d_poin
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int k = k0 + wm * (BMK / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (k < p.K) slab[(size_t)k * p.N + col] = acc[tm][tn][r];
+        if (k < K) slab[(size_t)k * N + col] = acc[tm][tn][r];
       }
     }
   }
+}
+
+template <int BMK, int BN, bool HAS_SUB, bool POOLED>
+__global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_wgrad(const t3d_pointmlp_wgrad_args p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  ActLoader<HAS_SUB> la{p.a, p.K, p.rows_per_frustum};
+  DyLoader<POOLED> lb{p.dy, p.N, p.rows_per_frustum};
+  wgrad_body<BMK, BN>(la, lb, p.slabs, p.K, p.N, p.rows_per_split, smem);
+}
+
+// Gram matrix of a layer input, G = a^T a, as split-row slabs (t3d.h K11e).
+template <int BMK, int BN>
+__global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_gram(const t3d_pointmlp_gram_args p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  ActLoader<false> la{p.a, p.K, p.rows_per_frustum};
+  wgrad_body<BMK, BN>(la, la, p.slabs, p.K, p.K, p.rows_per_split, smem);
 }
 
 // dynamic-LDS launch: two pipeline stages exceed the 64 KB static limit for the 128-wide tiles
@@ -578,7 +638,7 @@ bool dy_ok(const t3d_dy_src& d) {
 }  // namespace
 
 extern "C" int t3d_pointmlp_fwd(const t3d_pointmlp_fwd_args* a, t3d_stream_t stream) {
-  if (!a || !a->w || !a->y || !a->psum || !a->psumsq || !act_ok(a->a, a->K)) return T3D_ERR_ARG;
+  if (!a || !a->w || !a->psum || !a->psumsq || !act_ok(a->a, a->K)) return T3D_ERR_ARG;
   if (a->pmax && (!a->pmin || !a->pamax || !a->pamin)) return T3D_ERR_ARG;
   if (a->M <= 0 || a->K <= 0 || a->N <= 0 || a->M % T3D_TILE_ROWS || a->rows_per_frustum % T3D_TILE_ROWS ||
       a->M % a->rows_per_frustum || a->N % 64)
@@ -681,6 +741,41 @@ extern "C" int t3d_pointmlp_wgrad(const t3d_pointmlp_wgrad_args* a, t3d_stream_t
   else if (tn == 128) T3D_WG(64, 128);
   else T3D_WG(64, 64);
 #undef T3D_WG
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_pointmlp_dgrad_gram(const t3d_pointmlp_dgrad_gram_args* a, t3d_stream_t stream) {
+  if (!a || !a->p || !a->out || !act_ok(a->a, a->K) || a->a.sub) return T3D_ERR_ARG;
+  if (a->prev_y && (!a->prev_scale || !a->prev_shift)) return T3D_ERR_ARG;
+  if (a->psum_dz && (!a->psum_dzy || !a->prev_y)) return T3D_ERR_ARG;
+  if (a->M <= 0 || a->M % T3D_TILE_ROWS || a->rows_per_frustum % T3D_TILE_ROWS || a->M % a->rows_per_frustum ||
+      a->K % 64)
+    return T3D_ERR_SHAPE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int tiles_m = a->M / 128;
+  if (a->K % 128 == 0 && (long)tiles_m * (a->K / 128) >= 512)
+    launch_lds(k_pointmlp_dgrad_gram<128>, dim3(tiles_m * (a->K / 128)), lds_fwd(128), s, *a);
+  else
+    launch_lds(k_pointmlp_dgrad_gram<64>, dim3(tiles_m * (a->K / 64)), lds_fwd(64), s, *a);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_pointmlp_gram(const t3d_pointmlp_gram_args* a, t3d_stream_t stream) {
+  if (!a || !a->slabs || !act_ok(a->a, a->K) || a->a.sub) return T3D_ERR_ARG;
+  if (a->M <= 0 || a->rows_per_split <= 0 || a->rows_per_split % BK || a->M % a->rows_per_split || a->K % 64 ||
+      a->rows_per_frustum % BK || a->M % a->rows_per_frustum)
+    return T3D_ERR_SHAPE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int splits = a->M / a->rows_per_split;
+  int rps = 0, tk = 0, tn = 0;
+  if (!(a->M % 128 == 0 && t3d_wgrad_plan(a->M, a->K, a->K, &rps, &tk, &tn) == T3D_OK && rps == a->rows_per_split))
+    tk = tn = (a->K % 128 == 0 ? 128 : 64);
+  if (tk != tn) tk = tn = 64;               // square tiles only: two instantiations
+  const dim3 grid((a->K / tk) * (a->K / tn) * splits);
+  if (tk == 128) launch_lds(k_pointmlp_gram<128, 128>, grid, lds_wgrad(128, 128), s, *a);
+  else launch_lds(k_pointmlp_gram<64, 64>, grid, lds_wgrad(64, 64), s, *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

@@ -12,6 +12,7 @@ per-channel coefficients (t3d_dy_src).
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -224,8 +225,10 @@ def wgrad_rows_per_split(lib, M, K, N):
 class PointLayer:
     """tf_util.conv2d 1x1 (+ batch_norm + ReLU) over M = B*N point rows (tf_util.py:1258-1323)."""
 
-    def __init__(self, g, scope, K, N, w=None, bias=None, kernel_1xD=False, w_name=None, w_row0=0, pool=False):
+    def __init__(self, g, scope, K, N, w=None, bias=None, kernel_1xD=False, w_name=None, w_row0=0, pool=False, gram=None):
         self.g, self.scope, self.K, self.N = g, scope, K, N
+        # pooled layers: Gram-form backward (t3d.h K11e) -- the [M,N] output is never stored
+        self.gram = (pool and os.environ.get('T3D_POOL_GRAM', '1') != '0') if gram is None else (gram and pool)
         self.w_name, self.w_row0 = w_name, w_row0
         rt, vs = g.rt, g.vars
         M, T = g.M, g.M // TILE
@@ -242,7 +245,7 @@ class PointLayer:
         self.beta = vs.const(scope + '/bn/beta', (N,), 0.0)
         self.mm = vs.const(scope + '/bn/moving_mean', (N,), 0.0, trainable=False)
         self.mv = vs.const(scope + '/bn/moving_variance', (N,), 1.0, trainable=False)
-        self.y = rt.zeros(M, N)
+        self.y = None if self.gram else rt.zeros(M, N)
         self.psum, self.psumsq = rt.zeros(T, N), rt.zeros(T, N)
         self.scale, self.shift = rt.zeros(N), rt.zeros(N)
         self.mean, self.invstd = rt.zeros(N), rt.zeros(N)
@@ -284,7 +287,7 @@ class PointLayer:
             q.B, q.N, q.tiles_per_frustum = g.B, self.N, g.rpf // TILE
             q.pooled, q.ld_pooled, q.argidx, q.ysel = fptr(self.pooled), self.N, iptr(self.argidx), fptr(self.ysel)
             plan.add('t3d_pool_finalize', q)
-        self.out = ActSpec(self.y, self.N, self.N, 0, self.scale, self.shift, True, producer=self)
+        self.out = None if self.gram else ActSpec(self.y, self.N, self.N, 0, self.scale, self.shift, True, producer=self)
         return self.out
 
     # ---- backward ------------------------------------------------------------------------------
@@ -294,6 +297,9 @@ class PointLayer:
             self.coef = rt.zeros(3, self.N)
             if self.pool:
                 self.dpool = rt.zeros(self.g.B, self.N)
+                if self.gram:
+                    K, N = self.K, self.N
+                    self.wc, self.S = rt.zeros(N, K), rt.zeros(self.M, K)
             else:
                 self.dz = rt.zeros(self.M, self.N)
                 self.psum_dz, self.psum_dzy = rt.zeros(self.T, self.N), rt.zeros(self.T, self.N)
@@ -321,8 +327,80 @@ class PointLayer:
         a.coef = fptr(self.coef)
         plan.add('t3d_bn_bwd_finalize', a)
 
+    def _gram_prepare(self, plan, need_w):
+        """Everything K x K of the Gram-form backward (t3d.h K11e), summed by ONE t3d_reduce_slabs launch:
+        P and rowconst (always), G = a^T a and the column sums of a (only when dW is wanted)."""
+        g, rt, K, N = self.g, self.g.rt, self.K, self.N
+        nch = (N + 127) // 128
+        rps = wgrad_rows_per_split(rt.lib, self.M, K, K)
+        n_slabs = self.M // rps
+        # slab regions | reduced regions, in one buffer each
+        regions = [('G', K * K, n_slabs), ('abar', K, self.T)] if need_w else []
+        regions += [('P', K * K, nch), ('rowconst', K, nch)]
+        soff, ooff, table = {}, {}, []
+        st = ot = 0
+        for name, numel, ns in regions:
+            soff[name], ooff[name] = st, ot
+            table.append(abi.SlabDesc(st, ot, numel, ns))
+            st += numel * ns
+            ot += numel
+        slabs, out = rt.zeros(st), rt.zeros(ot)
+        self.gram_slabs, self.gram_out = slabs, out
+        view = lambda name, numel: out[ooff[name]:ooff[name] + numel]
+        self.P, self.rowconst = view('P', K * K), view('rowconst', K)
+        if need_w:
+            self.G, self.abar = view('G', K * K), view('abar', K)
+            a = abi.PointMlpGramArgs()
+            a.a, a.slabs = self.src.struct(), fptr(slabs[soff['G']:])
+            a.M, a.K, a.rows_per_frustum, a.rows_per_split = self.M, K, g.rpf, rps
+            plan.add('t3d_pointmlp_gram', a)
+            c = abi.ActColsumArgs()
+            c.a, c.M, c.K, c.rows_per_frustum, c.part = self.src.struct(), self.M, K, g.rpf, fptr(slabs[soff['abar']:])
+            plan.add('t3d_act_colsum', c)
+        q = abi.PoolBwdPrepArgs(fptr(self.w), fptr(self.bias), fptr(self.coef), K, N, fptr(slabs[soff['P']:]),
+                                fptr(slabs[soff['rowconst']:]), fptr(self.wc))
+        plan.add('t3d_pool_bwd_prep', q)
+        desc = (abi.SlabDesc * len(table))(*table)
+        tab = torch.as_tensor(np.frombuffer(bytes(desc), dtype=np.uint8).copy()).to(rt.device)
+        rt.allocs.append(tab)
+        lib, n = rt.lib, len(table)
+        plan.add_raw('t3d_reduce_slabs', lambda s: lib.t3d_reduce_slabs(
+            fptr(slabs), fptr(out), C.cast(C.c_void_p(tab.data_ptr()), C.POINTER(abi.SlabDesc)), n, K * K, s))
+        self._gram_plan = plan
+
+    def _wgrad_gram(self, plan):
+        """dW of a pooled layer from the K x K Gram matrix of its input."""
+        g, K, N = self.g, self.K, self.N
+        self._gram_prepare(plan, True)
+        f = abi.PoolWgradFinishArgs()
+        f.a, f.argidx, f.dpool, f.coef = self.src.struct(), iptr(self.argidx), fptr(self.dpool), fptr(self.coef)
+        f.w, f.bias, f.g, f.abar = fptr(self.w), fptr(self.bias), fptr(self.G), fptr(self.abar)
+        f.B, f.K, f.N, f.rows_per_frustum = g.B, K, N, g.rpf
+        goff = g.vars.offset(self.w_name) + self.w_row0 * N
+        f.dw = fptr(g.vars.grads[goff:goff + K * N])
+        plan.add('t3d_pool_wgrad_finish', f)
+
+    def _dgrad_gram(self, plan):
+        """Input gradient of a pooled layer: sparse argmax rows, then the act(a).P GEMM with the dgrad epilogue."""
+        g, K, N = self.g, self.K, self.N
+        prev = self.src.producer
+        assert prev is not None and not prev.pool, 'pooled layers follow a dense per-point layer in every reference net'
+        prev._ensure_bwd_buffers()
+        if getattr(self, '_gram_plan', None) is not plan:
+            self._gram_prepare(plan, False)
+        r = abi.PoolSparseRowsArgs(iptr(self.argidx), fptr(self.dpool), fptr(self.wc), g.B, N, K, g.rpf, fptr(self.S))
+        plan.add('t3d_pool_sparse_rows', r)
+        a = abi.PointMlpDgradGramArgs()
+        a.a, a.p, a.rowconst, a.add_in = self.src.struct(), fptr(self.P), fptr(self.rowconst), fptr(self.S)
+        a.prev_y, a.prev_scale, a.prev_shift = fptr(prev.y), fptr(prev.scale), fptr(prev.shift)
+        a.out, a.psum_dz, a.psum_dzy = fptr(prev.dz), fptr(prev.psum_dz), fptr(prev.psum_dzy)
+        a.M, a.K, a.rows_per_frustum = self.M, K, g.rpf
+        plan.add('t3d_pointmlp_dgrad_gram', a)
+
     def wgrad(self, plan):
         g = self.g
+        if self.gram:
+            return self._wgrad_gram(plan)
         rps = wgrad_rows_per_split(g.rt.lib, self.M, self.K, self.N)
         n_slabs = self.M // rps
         goff = g.vars.offset(self.w_name) + self.w_row0 * self.N
@@ -336,6 +414,9 @@ class PointLayer:
     def dgrad(self, plan, out_raw=None, add_in=None):
         """Input gradient.  If the input's producer is a PointLayer, writes its dz (ReLU-masked) and
         batch-norm-backward partials; otherwise writes the raw gradient into `out_raw`."""
+        if self.gram:
+            assert out_raw is None and add_in is None
+            return self._dgrad_gram(plan)
         prev = self.src.producer if out_raw is None else None
         a = abi.PointMlpDgradArgs()
         a.dy, a.w, a.add_in = self.dy_struct(), fptr(self.w), fptr(add_in)
