@@ -40,12 +40,18 @@ def test_model_a_matches_golden_vectors(hip_lib):
         got = e[k].cpu().numpy().reshape(ref.shape)
         assert np.abs(got - ref).max() < 1e-4 * max(1.0, np.abs(ref).max()), k     # BASELINE.json: 1e-4 fp32
     assert abs(float(e['loss'].cpu()) - float(z['out/loss'])) < 1e-4 * float(z['out/loss'])
-    gmax = max(float(np.abs(z[k]).max()) for k in z.files if k.startswith('grad/'))
-    for k in z.files:
-        if k.startswith('grad/') and k != 'grad/box_est/fc1/weights':
-            ref = z[k]
-            mine = g.vars.grad(k[5:]).cpu().numpy().reshape(ref.shape)
-            assert np.abs(mine - ref).max() < 5e-3 * max(np.abs(ref).max(), 1e-2 * gmax), k
+    # gradients: the two-level bound of model_check.check_against_oracle (median per-tensor relative L2 <= 1e-4, global
+    # <= 1e-2): a single ReLU whose pre-activation is within fp32 rounding of zero may flip against the fp64 fixture and
+    # moves individual elements of a few tensors by ~1 % at this tiny size (M = 512 rows); a systematic error moves the median
+    from model_check import grad_errors
+    # (the fixture keeps only the first rows of the largest weight gradient: checked separately below)
+    per, glob = grad_errors(g, {k[5:]: z[k] for k in z.files if k.startswith('grad/') and k != 'grad/box_est/fc1/weights'})
+    part = z['grad/box_est/fc1/weights']
+    mine = g.vars.grad('box_est/fc1/weights').cpu().numpy().reshape(-1, part.shape[1])[:part.shape[0]]
+    assert np.linalg.norm(mine - part) < 1e-2 * np.linalg.norm(part)
+    assert float(np.median(list(per.values()))) < 1e-4, sorted(per.items(), key=lambda kv: -kv[1])[:5]
+    assert glob < 1e-2, glob
+    assert max(per.values()) < 5e-2, max(per.items(), key=lambda kv: kv[1])
 
 
 def test_full_size_properties(hip_lib):

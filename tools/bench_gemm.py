@@ -61,7 +61,8 @@ def main():
         elif kind == 'dgrad':
             a = abi.PointMlpDgradArgs()
             a.dy, a.w, a.out = dy, fptr(w), fptr(out)
-            a.prev_y, a.prev_scale, a.prev_shift, a.psum_dz, a.psum_dzy = fptr(x), fptr(sc), fptr(sh), fptr(p1), fptr(p2)
+            if not os.environ.get('T3D_DGRAD_RAW'):
+                a.prev_y, a.prev_scale, a.prev_shift, a.psum_dz, a.psum_dzy = fptr(x), fptr(sc), fptr(sh), fptr(p1), fptr(p2)
             a.M, a.K, a.N, a.rows_per_frustum = M, K, N, rpf
             fn = lib.t3d_pointmlp_dgrad
         else:

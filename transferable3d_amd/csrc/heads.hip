@@ -9,11 +9,14 @@
 namespace {
 
 // ---------------------------------------------------------------------------------------------
-// seg head.  One workgroup = one 128-row tile, wave w owns rows 32w..32w+31, lane owns channels
-// 2*lane, 2*lane+1 of the K = 128 wide conv9 output (coalesced 512-B row loads).
+// seg head.  One workgroup = one 128-row tile = 16 waves (4 per SIMD, so that the per-row chain load -> dot ->
+// wave reduction -> exp/log -> dz store of one wave hides under the others); wave w owns rows 8w..8w+7, two rows
+// in flight; lane owns channels 2*lane, 2*lane+1 of the K = 128 wide conv9 output (coalesced 512-B row loads).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_seg_head(const t3d_seg_head_args p) {
-  __shared__ float red[4][128 * 4 + 8];
+constexpr int SH_WAVES = 16, SH_ROWS = 128 / SH_WAVES, SH_LD = 128 * 4 + 8;
+
+__global__ __launch_bounds__(64 * SH_WAVES) void k_seg_head(const t3d_seg_head_args p) {
+  __shared__ float red[SH_WAVES][SH_LD];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int tile = blockIdx.x, row0 = tile * 128;
   const int b = row0 / p.rows_per_frustum;
@@ -30,43 +33,62 @@ __global__ __launch_bounds__(256) void k_seg_head(const t3d_seg_head_args p) {
   float sdz0 = 0.f, sdz1 = 0.f, sdzy0 = 0.f, sdzy1 = 0.f, dw00 = 0.f, dw01 = 0.f, dw10 = 0.f, dw11 = 0.f;
   float ce_sum = 0.f, cnt = 0.f, sx = 0.f, sy = 0.f, sz = 0.f, db0 = 0.f, db1 = 0.f, ncorr = 0.f;
 
-  for (int i = 0; i < 32; ++i) {
-    const int row = row0 + wid * 32 + i;
-    const size_t o = (size_t)row * 128 + ch;
-    const float2 y = *reinterpret_cast<const float2*>(p.y + o);
-    const float z0 = fmaf(y.x, sc.x, sh.x), z1 = fmaf(y.y, sc.y, sh.y);
-    float k0 = inv_keep, k1 = inv_keep;
-    if (p.drop_mask) {
-      const float2 m = *reinterpret_cast<const float2*>(p.drop_mask + o);
-      k0 *= m.x; k1 *= m.y;
+  for (int i = 0; i < SH_ROWS; i += 2) {
+    float2 y[2], km[2];
+    float z0[2], z1[2], d0[2], d1[2], l0[2], l1[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const size_t o = (size_t)(row0 + wid * SH_ROWS + i + u) * 128 + ch;
+      y[u] = *reinterpret_cast<const float2*>(p.y + o);
+      km[u] = p.drop_mask ? *reinterpret_cast<const float2*>(p.drop_mask + o) : make_float2(1.f, 1.f);
     }
-    const float d0 = fmaxf(z0, 0.f) * k0, d1 = fmaxf(z1, 0.f) * k1;
-    const float l0 = wave_sum(fmaf(d0, w00, d1 * w10)) + b0;
-    const float l1 = wave_sum(fmaf(d0, w01, d1 * w11)) + b1;
-    const float m = l0 < l1 ? 1.f : 0.f;
-    if (lane == 0) {
-      *reinterpret_cast<float2*>(p.logits + (size_t)row * 2) = make_float2(l0, l1);
-      p.mask[row] = m;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      z0[u] = fmaf(y[u].x, sc.x, sh.x); z1[u] = fmaf(y[u].y, sc.y, sh.y);
+      km[u].x *= inv_keep; km[u].y *= inv_keep;
+      d0[u] = fmaxf(z0[u], 0.f) * km[u].x; d1[u] = fmaxf(z1[u], 0.f) * km[u].y;
+      l0[u] = fmaf(d0[u], w00, d1[u] * w10);
+      l1[u] = fmaf(d0[u], w01, d1[u] * w11);
     }
-    const float px = p.pc[(size_t)row * p.ld_pc], py = p.pc[(size_t)row * p.ld_pc + 1], pz = p.pc[(size_t)row * p.ld_pc + 2];
-    cnt += m; sx += m * px; sy += m * py; sz += m * pz;
-    if (train) {
-      const int lab = p.labels[row];
-      const float mx = fmaxf(l0, l1);
-      const float lse = mx + logf(expf(l0 - mx) + expf(l1 - mx));
-      ce_sum += lse - (lab ? l1 : l0);
-      ncorr += ((l1 > l0 ? 1 : 0) == lab) ? 1.f : 0.f;
-      if (bwd) {
-        const float g0 = wb * (expf(l0 - lse) - (lab == 0 ? 1.f : 0.f));
-        const float g1 = wb * (expf(l1 - lse) - (lab == 1 ? 1.f : 0.f));
-        db0 += g0; db1 += g1;
-        dw00 = fmaf(d0, g0, dw00); dw01 = fmaf(d0, g1, dw01);
-        dw10 = fmaf(d1, g0, dw10); dw11 = fmaf(d1, g1, dw11);
-        const float dz0 = z0 > 0.f ? (g0 * w00 + g1 * w01) * k0 : 0.f;
-        const float dz1 = z1 > 0.f ? (g0 * w10 + g1 * w11) * k1 : 0.f;
-        *reinterpret_cast<float2*>(p.dz + o) = make_float2(dz0, dz1);
-        sdz0 += dz0; sdz1 += dz1;
-        sdzy0 = fmaf(dz0, y.x, sdzy0); sdzy1 = fmaf(dz1, y.y, sdzy1);
+    // four independent butterfly reductions, interleaved
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        l0[u] += __shfl_xor(l0[u], off, 64);
+        l1[u] += __shfl_xor(l1[u], off, 64);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int row = row0 + wid * SH_ROWS + i + u;
+      const size_t o = (size_t)row * 128 + ch;
+      const float q0 = l0[u] + b0, q1 = l1[u] + b1;
+      const float m = q0 < q1 ? 1.f : 0.f;
+      if (lane == 0) {
+        *reinterpret_cast<float2*>(p.logits + (size_t)row * 2) = make_float2(q0, q1);
+        p.mask[row] = m;
+      }
+      const float px = p.pc[(size_t)row * p.ld_pc], py = p.pc[(size_t)row * p.ld_pc + 1], pz = p.pc[(size_t)row * p.ld_pc + 2];
+      cnt += m; sx += m * px; sy += m * py; sz += m * pz;
+      if (train) {
+        const int lab = p.labels[row];
+        const float mx = fmaxf(q0, q1);
+        const float lse = mx + logf(expf(q0 - mx) + expf(q1 - mx));
+        ce_sum += lse - (lab ? q1 : q0);
+        ncorr += ((q1 > q0 ? 1 : 0) == lab) ? 1.f : 0.f;
+        if (bwd) {
+          const float g0 = wb * (expf(q0 - lse) - (lab == 0 ? 1.f : 0.f));
+          const float g1 = wb * (expf(q1 - lse) - (lab == 1 ? 1.f : 0.f));
+          db0 += g0; db1 += g1;
+          dw00 = fmaf(d0[u], g0, dw00); dw01 = fmaf(d0[u], g1, dw01);
+          dw10 = fmaf(d1[u], g0, dw10); dw11 = fmaf(d1[u], g1, dw11);
+          const float dz0 = z0[u] > 0.f ? (g0 * w00 + g1 * w01) * km[u].x : 0.f;
+          const float dz1 = z1[u] > 0.f ? (g0 * w10 + g1 * w11) * km[u].y : 0.f;
+          *reinterpret_cast<float2*>(p.dz + o) = make_float2(dz0, dz1);
+          sdz0 += dz0; sdz1 += dz1;
+          sdzy0 = fmaf(dz0, y[u].x, sdzy0); sdzy1 = fmaf(dz1, y[u].y, sdzy1);
+        }
       }
     }
   }
@@ -78,16 +100,16 @@ __global__ __launch_bounds__(256) void k_seg_head(const t3d_seg_head_args p) {
     r[512] = ce_sum; r[513] = cnt; r[514] = sx; r[515] = sy; r[516] = sz; r[517] = db0; r[518] = db1; r[519] = ncorr;
   }
   __syncthreads();
-  if (bwd) {
-    if (tid < 128) {
-      p.psum_dz[(size_t)tile * 128 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-    } else {
-      const int c = tid - 128;
-      p.psum_dzy[(size_t)tile * 128 + c] = red[0][128 + c] + red[1][128 + c] + red[2][128 + c] + red[3][128 + c];
-    }
-    p.dw_part[(size_t)tile * 256 + tid] = red[0][256 + tid] + red[1][256 + tid] + red[2][256 + tid] + red[3][256 + tid];
+  // fixed-order combination of the 16 wave partials: thread e < 520 owns one quantity
+  if (tid < 520) {
+    float acc = 0.f;
+#pragma unroll
+    for (int w = 0; w < SH_WAVES; ++w) acc += red[w][tid];
+    if (tid < 128) { if (bwd) p.psum_dz[(size_t)tile * 128 + tid] = acc; }
+    else if (tid < 256) { if (bwd) p.psum_dzy[(size_t)tile * 128 + tid - 128] = acc; }
+    else if (tid < 512) { if (bwd) p.dw_part[(size_t)tile * 256 + tid - 256] = acc; }
+    else p.part[(size_t)tile * 8 + tid - 512] = acc;
   }
-  if (tid < 8) p.part[(size_t)tile * 8 + tid] = red[0][512 + tid] + red[1][512 + tid] + red[2][512 + tid] + red[3][512 + tid];
 }
 
 __global__ __launch_bounds__(256) void k_seg_finalize(const t3d_seg_finalize_args p) {
@@ -302,7 +324,7 @@ extern "C" int t3d_seg_head(const t3d_seg_head_args* a, t3d_stream_t stream) {
   if (a->labels && !a->is_data_2D) return T3D_ERR_ARG;
   if (a->dz && (!a->labels || !a->psum_dz || !a->psum_dzy || !a->dw_part)) return T3D_ERR_ARG;
   if (a->K != 128 || a->M % T3D_TILE_ROWS || a->rows_per_frustum % T3D_TILE_ROWS) return T3D_ERR_SHAPE;
-  T3D_LAUNCH(k_seg_head, dim3(a->M / 128), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+  T3D_LAUNCH(k_seg_head, dim3(a->M / 128), dim3(64 * SH_WAVES), 0, static_cast<hipStream_t>(stream), *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

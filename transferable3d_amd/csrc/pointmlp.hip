@@ -367,13 +367,15 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd(const t3d_pointm
     if (p.rowbias) add += p.rowbias[(size_t)b * p.N + col];
     float s = 0.f, ss = 0.f, mx = -INFINITY, mn = INFINITY;
     int ax = -1, an = -1;
+    // 32-bit element offsets (M*N < 2^30 is checked by the launcher): one VGPR per store instead of an address pair
+    const unsigned off0 = (unsigned)(row0 + wm * 64 + 4 * h) * (unsigned)p.N + (unsigned)col;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = row0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const float v = acc[tm][tn][r] + add;
-        if (store_y) p.y[(size_t)row * p.N + col] = v;
+        if (store_y) p.y[off0 + (unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)p.N] = v;
         s += v;
         ss = fmaf(v, v, ss);
         if (pool) {
@@ -445,35 +447,55 @@ struct DgradEpilogue {
   int K;
 };
 
-template <int BN, int TM, int TN>
-__device__ __forceinline__ void dgrad_epilogue(const DgradEpilogue& p, f32x16 (&acc)[TM][TN], float* red, int tid, int row0,
-                                               int col0, int tile_m) {
+// Element offsets are 32-bit (the launchers check M*K < 2^30): one VGPR per element instead of a 64-bit address pair,
+// and the compiler can use the scalar-base + vector-offset addressing form.  ADD / MASK are compile-time so that the
+// loads are unconditional (a uniform `ptr ? load : 0` becomes a branch around every load), and the loads of a batch
+// are issued ahead of the batch's stores: `out` may alias the inputs as far as the compiler knows, so a load placed
+// after a store is never hoisted above it and every element would pay a full memory round trip.
+template <int BN, int TM, int TN, bool ADD, bool MASK>
+__device__ __forceinline__ void dgrad_epilogue_body(const DgradEpilogue& p, f32x16 (&acc)[TM][TN], float* red, int tid,
+                                                    int row0, int col0, int tile_m) {
   const int lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
   const int l31 = lane & 31, h = lane >> 5;
-  const bool relu_mask = p.prev_y != nullptr;
-  const bool stats = p.psum_dz != nullptr;
+  const bool stats = MASK && p.psum_dz != nullptr;
+  const unsigned K = (unsigned)p.K;
   float cs1[TN], cs2[TN];
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int col = col0 + wn * (BN / 2) + tn * 32 + l31;
-    const float psc = relu_mask ? p.prev_scale[col] : 0.f, psh = relu_mask ? p.prev_shift[col] : 0.f;
+    const float psc = MASK ? p.prev_scale[col] : 0.f, psh = MASK ? p.prev_shift[col] : 0.f;
     const float cc = p.colconst ? p.colconst[col] : 0.f;
+    const unsigned off0 = (unsigned)(row0 + wm * 64 + 4 * h) * K + (unsigned)col;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
+      constexpr int EB = 8;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = row0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const size_t o = (size_t)row * p.K + col;
-        float v = acc[tm][tn][r] + cc;
-        if (p.add_in) v += p.add_in[o];
-        if (relu_mask) {
-          const float yp = p.prev_y[o];
-          if (!(fmaf(yp, psc, psh) > 0.f)) v = 0.f;
-          s1 += v;
-          s2 = fmaf(v, yp, s2);
+      for (int r0 = 0; r0 < 16; r0 += EB) {
+        float yp[EB], ad[EB];
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+          const int r = r0 + e;
+          const unsigned o = off0 + (unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) * K;
+#ifdef T3D_ABL_DG_NOLOAD
+          yp[e] = psc + (float)r;
+#else
+          yp[e] = MASK ? p.prev_y[o] : 0.f;
+#endif
+          ad[e] = ADD ? p.add_in[o] : 0.f;
         }
-        p.out[o] = v;
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+          const int r = r0 + e;
+          const unsigned o = off0 + (unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) * K;
+          float v = acc[tm][tn][r] + cc + ad[e];
+          if (MASK) {
+            if (!(fmaf(yp[e], psc, psh) > 0.f)) v = 0.f;
+            s1 += v;
+            s2 = fmaf(v, yp[e], s2);
+          }
+          p.out[o] = v;
+        }
       }
     }
     s1 += __shfl_xor(s1, 32, 64);
@@ -496,6 +518,19 @@ __device__ __forceinline__ void dgrad_epilogue(const DgradEpilogue& p, f32x16 (&
       p.psum_dz[o] = red[(0 * 2 + 0) * BN + tid] + red[(0 * 2 + 1) * BN + tid];
       p.psum_dzy[o] = red[(1 * 2 + 0) * BN + tid] + red[(1 * 2 + 1) * BN + tid];
     }
+  }
+}
+
+template <int BN, int TM, int TN>
+__device__ __forceinline__ void dgrad_epilogue(const DgradEpilogue& p, f32x16 (&acc)[TM][TN], float* red, int tid, int row0,
+                                               int col0, int tile_m) {
+  const bool add = p.add_in != nullptr, mask = p.prev_y != nullptr;      // workgroup-uniform
+  if (mask) {
+    if (add) dgrad_epilogue_body<BN, TM, TN, true, true>(p, acc, red, tid, row0, col0, tile_m);
+    else dgrad_epilogue_body<BN, TM, TN, false, true>(p, acc, red, tid, row0, col0, tile_m);
+  } else {
+    if (add) dgrad_epilogue_body<BN, TM, TN, true, false>(p, acc, red, tid, row0, col0, tile_m);
+    else dgrad_epilogue_body<BN, TM, TN, false, false>(p, acc, red, tid, row0, col0, tile_m);
   }
 }
 
@@ -641,7 +676,7 @@ extern "C" int t3d_pointmlp_fwd(const t3d_pointmlp_fwd_args* a, t3d_stream_t str
   if (!a || !a->w || !a->psum || !a->psumsq || !act_ok(a->a, a->K)) return T3D_ERR_ARG;
   if (a->pmax && (!a->pmin || !a->pamax || !a->pamin)) return T3D_ERR_ARG;
   if (a->M <= 0 || a->K <= 0 || a->N <= 0 || a->M % T3D_TILE_ROWS || a->rows_per_frustum % T3D_TILE_ROWS ||
-      a->M % a->rows_per_frustum || a->N % 64)
+      a->M % a->rows_per_frustum || a->N % 64 || (long)a->M * a->N >= (1L << 30))
     return T3D_ERR_SHAPE;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int tiles_m = a->M / 128;
@@ -665,7 +700,7 @@ extern "C" int t3d_pointmlp_dgrad(const t3d_pointmlp_dgrad_args* a, t3d_stream_t
   if (a->prev_y && (!a->prev_scale || !a->prev_shift)) return T3D_ERR_ARG;
   if (a->psum_dz && (!a->psum_dzy || !a->prev_y)) return T3D_ERR_ARG;
   if (a->M <= 0 || a->M % T3D_TILE_ROWS || a->rows_per_frustum % T3D_TILE_ROWS || a->M % a->rows_per_frustum ||
-      a->K % 64 || a->N % 4)
+      a->K % 64 || a->N % 4 || (long)a->M * a->K >= (1L << 30))
     return T3D_ERR_SHAPE;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int tiles_m = a->M / 128;
@@ -750,7 +785,7 @@ extern "C" int t3d_pointmlp_dgrad_gram(const t3d_pointmlp_dgrad_gram_args* a, t3
   if (a->prev_y && (!a->prev_scale || !a->prev_shift)) return T3D_ERR_ARG;
   if (a->psum_dz && (!a->psum_dzy || !a->prev_y)) return T3D_ERR_ARG;
   if (a->M <= 0 || a->M % T3D_TILE_ROWS || a->rows_per_frustum % T3D_TILE_ROWS || a->M % a->rows_per_frustum ||
-      a->K % 64)
+      a->K % 64 || (long)a->M * a->K >= (1L << 30))
     return T3D_ERR_SHAPE;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int tiles_m = a->M / 128;
