@@ -84,6 +84,8 @@ def profile_kernels(plans, steps):
         for plan in plans:
             s = plan.rt.stream()
             for name, call, arg in plan.calls:
+                if name.startswith('__'):          # lane-join marker, not a launch
+                    continue
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 rc = call(s)

@@ -27,6 +27,19 @@ constexpr int BK = T3D_BK;      // reduction depth of one LDS stage
 #endif
 constexpr int LDR = BK + 4;
 constexpr int NT = 256;
+// prefetch distance (register slots) per kernel family.  Distance 2 was measured on MI355X (64-column kernels and
+// dgrad_gram<128>, B=32 N=1024 step): no gain (1.843 ms vs 1.822 ms per step) at 30-90 more VGPRs -- the narrow kernels
+// are bound by their fixed per-workgroup latency (first load, epilogue), not by the per-tile load latency -- so the
+// default stays 1; the variant is kept for other shapes.
+#ifndef T3D_PF_NARROW
+#define T3D_PF_NARROW 1      // 64-column tiles
+#endif
+#ifndef T3D_PF_WIDE
+#define T3D_PF_WIDE 1        // 128-column tiles of fwd / dgrad / wgrad (213-233 VGPRs already)
+#endif
+#ifndef T3D_PF_GRAM128
+#define T3D_PF_GRAM128 1     // dgrad_gram<128>
+#endif
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
@@ -134,47 +147,52 @@ struct WLoader {
 // ---------------------------------------------------------------------------------------------
 // staging of one [DIM x BK] operand tile through registers into LDS
 // ---------------------------------------------------------------------------------------------
-template <int DIM, bool TYPE_R, class L>
+// PF = prefetch distance in k-tiles = number of register slots: with PF = 2 the loads of tile t+2 are already in flight
+// while tile t+1 is transformed into LDS, so a load has about two k-tile MFMA phases to land instead of one.  The narrow
+// (64-column) kernels need that: their k-tile is only 32 MFMAs per wave, shorter than the memory latency under load.
+template <int DIM, bool TYPE_R, class L, int PF_ = 1>
 struct Stager {
+  static constexpr int PF = PF_;
   static constexpr int NV = DIM * (BK / 4) / NT;
   static constexpr int LDS_FLOATS = TYPE_R ? DIM * LDR : BK * DIM;
-  typename L::Raw raw[NV];
-  typename L::Coef coef;
-  int lane0, red0;
+  typename L::Raw raw[PF][NV];
+  typename L::Coef coef[PF];      // TYPE_C uses coef[0] only (the thread's column chunk never changes)
+  int lane0, red0[PF];
 
   __device__ __forceinline__ static void coords(int tid, int q, int& lane_i, int& red_i) {
     const int f = tid + NT * q;
     if (TYPE_R) { constexpr int CH = BK / 4; lane_i = f / CH; red_i = (f % CH) * 4; }
     else { constexpr int C4 = DIM / 4; red_i = f / C4; lane_i = (f % C4) * 4; }
   }
-  // TYPE_C: the thread's column chunk never changes -> fetch its coefficients once
   __device__ __forceinline__ void init(const L& l, int lane0_, int tid) {
     lane0 = lane0_;
-    if (!TYPE_R) { int li, ri; coords(tid, 0, li, ri); coef = l.fetch_coef(lane0 + li); }
+    if (!TYPE_R) { int li, ri; coords(tid, 0, li, ri); coef[0] = l.fetch_coef(lane0 + li); }
   }
+  template <int S = 0>
   __device__ __forceinline__ void fetch(const L& l, int red0_, int tid) {
-    red0 = red0_;
-    if (TYPE_R) { int li, ri; coords(tid, 0, li, ri); coef = l.fetch_coef(red0 + ri); }
+    red0[S] = red0_;
+    if (TYPE_R) { int li, ri; coords(tid, 0, li, ri); coef[S] = l.fetch_coef(red0_ + ri); }
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
       int li, ri; coords(tid, q, li, ri);
-      raw[q] = TYPE_R ? l.fetch(lane0 + li, red0 + ri) : l.fetch(red0 + ri, lane0 + li);
+      raw[S][q] = TYPE_R ? l.fetch(lane0 + li, red0_ + ri) : l.fetch(red0_ + ri, lane0 + li);
     }
   }
+  template <int S = 0>
   __device__ __forceinline__ void store(const L& l, float* tile, int tid) {
 #pragma unroll
-    for (int q = 0; q < NV; ++q) store_piece(l, tile, tid, q);
+    for (int q = 0; q < NV; ++q) store_piece<S>(l, tile, tid, q);
   }
+  template <int S = 0>
   __device__ __forceinline__ void store_piece(const L& l, float* tile, int tid, int q) {
-    {
-      int li, ri; coords(tid, q, li, ri);
-      if (TYPE_R) {
-        const float4 v = l.xform(raw[q], coef, lane0 + li, red0 + ri);
-        *reinterpret_cast<float4*>(tile + li * LDR + ri) = v;
-      } else {
-        const float4 v = l.xform(raw[q], coef, red0 + ri, lane0 + li);
-        *reinterpret_cast<float4*>(tile + ri * DIM + li) = v;
-      }
+    int li, ri; coords(tid, q, li, ri);
+    const typename L::Coef& c = coef[TYPE_R ? S : 0];
+    if (TYPE_R) {
+      const float4 v = l.xform(raw[S][q], c, lane0 + li, red0[S] + ri);
+      *reinterpret_cast<float4*>(tile + li * LDR + ri) = v;
+    } else {
+      const float4 v = l.xform(raw[S][q], c, red0[S] + ri, lane0 + li);
+      *reinterpret_cast<float4*>(tile + ri * DIM + li) = v;
     }
   }
 };
@@ -252,9 +270,77 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[TM][TN]) {
 // and the loads of tile t+2 are issued.  The last tile is peeled so that the steady-state body is branch-free.
 //   RAW: stage (t+1)&1 is written during iteration t and read after the barrier that ends it.
 //   WAR: stage t&1 is overwritten (tile t+2) during iteration t+1, after the same barrier.
+// Prefetch-distance-2 variant (SA::PF == 2).  Register slot (t+1)&1 holds tile t+1 (landed), slot t&1 holds tile t+2
+// (in flight).  Iteration t: MFMAs of tile t from LDS stage t&1; tile t+1 goes from its slot into the other stage
+// between the MFMAs of the second half; the freed slot is refilled with tile t+3.  Unrolled by two so that the slot
+// index is a compile-time constant (register arrays).
+template <int S, int TM, int TN, class SA, class SB, class LA, class LB, bool AR, int DIMA, bool BR, int DIMB>
+__device__ __forceinline__ void pf2_body(SA& sa, SB& sb, const LA& la, const LB& lb, float* smem, int cur, int red_fetch,
+                                         bool do_fetch, int a0, int b0, f32x16 (&acc)[TM][TN], int tid) {
+  constexpr int STAGE = SA::LDS_FLOATS + SB::LDS_FLOATS;
+  constexpr int GH = BK / 16, GT = BK / 8;
+  const int lane = tid & 63;
+  const float* As = smem + cur * STAGE;
+  const float* Bs = As + SA::LDS_FLOATS;
+  float* An = smem + (cur ^ 1) * STAGE;
+  float* Bn = An + SA::LDS_FLOATS;
+  mma_groups<TM, TN, AR, DIMA, BR, DIMB, 0, GH>(As, Bs, a0, b0, acc, lane, [](int) {});
+  __builtin_amdgcn_sched_barrier(0);
+  mma_groups<TM, TN, AR, DIMA, BR, DIMB, GH, GT>(As, Bs, a0, b0, acc, lane, [&](int step) {
+    if (step < SA::NV) sa.template store_piece<S>(la, An, tid, step);
+    else if (step - SA::NV < SB::NV) sb.template store_piece<S>(lb, Bn, tid, step - SA::NV);
+  });
+  __builtin_amdgcn_sched_barrier(0);
+  if (do_fetch) {                        // workgroup-uniform; short reductions would otherwise re-read their last tile
+    sa.template fetch<S>(la, red_fetch, tid);
+    sb.template fetch<S>(lb, red_fetch, tid);
+  }
+  __syncthreads();
+}
+
+template <int TM, int TN, class SA, class SB, class LA, class LB, bool AR, int DIMA, bool BR, int DIMB>
+__device__ __forceinline__ void gemm_mainloop_pf2(SA& sa, SB& sb, const LA& la, const LB& lb, float* smem, int red_begin,
+                                                  int red_end, int a0, int b0, f32x16 (&acc)[TM][TN], int tid) {
+  constexpr int STAGE = SA::LDS_FLOATS + SB::LDS_FLOATS;
+  constexpr int GT = BK / 8;
+  static_assert(SA::NV + SB::NV <= (GT - BK / 16) * 4, "staging pieces must fit the MFMA clusters of the second half");
+  const int nt = (red_end - red_begin) / BK;
+  sa.template fetch<0>(la, red_begin, tid);
+  sb.template fetch<0>(lb, red_begin, tid);
+  if (nt > 1) { sa.template fetch<1>(la, red_begin + BK, tid); sb.template fetch<1>(lb, red_begin + BK, tid); }
+  sa.template store<0>(la, smem, tid);
+  sb.template store<0>(lb, smem + SA::LDS_FLOATS, tid);
+  if (nt > 2) { sa.template fetch<0>(la, red_begin + 2 * BK, tid); sb.template fetch<0>(lb, red_begin + 2 * BK, tid); }
+  __syncthreads();
+  int cur = 0, t = 0;
+  for (; t + 2 < nt; t += 2) {
+    pf2_body<1, TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, cur, red_begin + (t + 3) * BK, t + 3 < nt, a0, b0,
+                                                           acc, tid);
+    cur ^= 1;
+    pf2_body<0, TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, cur, red_begin + (t + 4) * BK, t + 4 < nt, a0, b0,
+                                                           acc, tid);
+    cur ^= 1;
+  }
+  if (t + 1 < nt) {                      // two tiles left: t is even here, tile t+1 sits in slot 1
+    pf2_body<1, TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, cur, red_begin, false, a0, b0, acc, tid);
+    cur ^= 1;
+  }
+  {
+    const float* As = smem + cur * STAGE;
+    const float* Bs = As + SA::LDS_FLOATS;
+    mma_groups<TM, TN, AR, DIMA, BR, DIMB, 0, GT>(As, Bs, a0, b0, acc, tid & 63, [](int) {});
+  }
+  __syncthreads();
+}
+
 template <int TM, int TN, class SA, class SB, class LA, class LB, bool AR, int DIMA, bool BR, int DIMB>
 __device__ __forceinline__ void gemm_mainloop(SA& sa, SB& sb, const LA& la, const LB& lb, float* smem, int red_begin,
                                               int red_end, int a0, int b0, f32x16 (&acc)[TM][TN], int tid) {
+  static_assert(SA::PF == SB::PF, "both operands use the same prefetch distance");
+  if constexpr (SA::PF == 2) {
+    gemm_mainloop_pf2<TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, red_begin, red_end, a0, b0, acc, tid);
+    return;
+  }
   constexpr int STAGE = SA::LDS_FLOATS + SB::LDS_FLOATS;
   constexpr int GH = BK / 16, GT = BK / 8;     // k-groups in the first half / in the whole tile
   static_assert(SA::NV + SB::NV <= (GT - GH) * 4, "staging pieces must fit the MFMA clusters of the second half");
@@ -316,8 +402,9 @@ template <int BN, bool HAS_SUB>
 __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd(const t3d_pointmlp_fwd_args p) {
   constexpr int BM = 128, TM = 2, TN = BN / 64;
   using LA = ActLoader<HAS_SUB>;
-  using SA = Stager<BM, true, LA>;
-  using SB = Stager<BN, false, WLoader>;
+  constexpr int PF = BN == 64 ? T3D_PF_NARROW : T3D_PF_WIDE;
+  using SA = Stager<BM, true, LA, PF>;
+  using SB = Stager<BN, false, WLoader, PF>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -538,8 +625,9 @@ template <int BN, bool POOLED>   // BN = tile width over the layer's INPUT chann
 __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_dgrad(const t3d_pointmlp_dgrad_args p) {
   constexpr int BM = 128, TM = 2, TN = BN / 64;
   using LA = DyLoader<POOLED>;
-  using SA = Stager<BM, true, LA>;
-  using SB = Stager<BN, true, WLoader>;
+  constexpr int PF = BN == 64 ? T3D_PF_NARROW : T3D_PF_WIDE;
+  using SA = Stager<BM, true, LA, PF>;
+  using SB = Stager<BN, true, WLoader, PF>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -571,8 +659,9 @@ template <int BN>
 __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_dgrad_gram(const t3d_pointmlp_dgrad_gram_args p) {
   constexpr int BM = 128, TM = 2, TN = BN / 64;
   using LA = ActLoader<false>;
-  using SA = Stager<BM, true, LA>;
-  using SB = Stager<BN, false, WLoader>;
+  constexpr int PF = BN == 64 ? T3D_PF_NARROW : T3D_PF_GRAM128;
+  using SA = Stager<BM, true, LA, PF>;
+  using SB = Stager<BN, false, WLoader, PF>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
@@ -601,8 +690,9 @@ template <int BMK, int BN, class LA, class LB>
 __device__ __forceinline__ void wgrad_body(const LA& la, const LB& lb, float* slabs, int K, int N, int rows_per_split,
                                            float* smem) {
   constexpr int TM = BMK / 64, TN = BN / 64;
-  using SA = Stager<BMK, false, LA>;
-  using SB = Stager<BN, false, LB>;
+  constexpr int PF = (BMK == 64 && BN == 64) ? T3D_PF_NARROW : T3D_PF_WIDE;
+  using SA = Stager<BMK, false, LA, PF>;
+  using SB = Stager<BN, false, LB, PF>;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int tiles_k = (K + BMK - 1) / BMK, tiles_n = N / BN;

@@ -10,6 +10,7 @@ output y plus per-tile statistics, and every consumer applies `relu(y*scale+shif
 (t3d_act_src).  Gradients likewise travel as dz (grad w.r.t. the batch-norm output) + three
 per-channel coefficients (t3d_dy_src).
 """
+import contextlib
 import ctypes as C
 import math
 import os
@@ -35,6 +36,13 @@ class Runtime:
             device = torch.device('cuda', torch.cuda.current_device())
         self.device = torch.device(device)
         self.allocs = []     # every buffer lives as long as the runtime (launch structs hold raw pointers)
+        self._side = None
+
+    def side_stream(self):
+        """Second HIP stream for work off the critical path (weight gradients): see Plan.side()."""
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+        return self._side
 
     def stream(self):
         if self.device.type == 'cuda':
@@ -52,33 +60,108 @@ class Runtime:
         return t
 
 
+# Two-stream execution of a plan (see Plan.side).  Measured on MI355X / ROCm 7.2 with the step captured into a hipGraph:
+# forking the weight gradients into a parallel graph branch is SLOWER than the linear graph (2.04 ms with a fork per
+# layer, 1.86 ms with two batched forks, 1.82 ms linear) -- cross-stream graph edges cost more than the overlap returns --
+# so it is off unless T3D_SIDE_STREAM=1.
+SIDE_STREAM = os.environ.get('T3D_SIDE_STREAM', '0') == '1'
+
+
 class Plan:
-    """Ordered list of kernel launches with frozen argument structs."""
+    """Ordered list of kernel launches with frozen argument structs.
+
+    Launches recorded inside `with plan.side():` are off the critical path (the weight gradients: nothing but the
+    optimiser consumes them).  On the GPU they go to a second HIP stream, forked from the main stream at the point
+    at the next `plan.flush()` and joined at `plan.join()` / the end of the plan, so that under hipGraph capture they
+    become a parallel branch of the graph.  On one stream (the default, see SIDE_STREAM) the recorded order is a valid
+    serial schedule."""
+
+    JOIN, FLUSH = '__join__', '__flush__'
 
     def __init__(self, rt):
         self.rt = rt
         self.calls = []      # (name, callable(stream) -> rc, argument struct or None)
+        self.lanes = []      # 0 = main stream, 1 = side stream, parallel to `calls`
         self.keep = []       # keep-alive for structs / tensors
+        self._lane = 0
+
+    @contextlib.contextmanager
+    def side(self):
+        prev, self._lane = self._lane, 1
+        try:
+            yield self
+        finally:
+            self._lane = prev
 
     def add(self, name, args):
         fn = getattr(self.rt.lib, name)
         ref = C.byref(args)
         self.keep.append(args)
         self.calls.append((name, lambda s, fn=fn, ref=ref: fn(ref, s), args))
+        self.lanes.append(self._lane)
 
     def add_raw(self, name, thunk, *keep):
         self.keep.extend(keep)
         self.calls.append((name, thunk, None))
+        self.lanes.append(self._lane)
+
+    def join(self):
+        """Everything recorded so far (both lanes) completes before what follows."""
+        self.calls.append((Plan.JOIN, lambda s: 0, None))
+        self.lanes.append(0)
+
+    def flush(self):
+        """Fork point: the side-lane launches recorded so far are issued here, behind one cross-stream dependency
+        (every graph edge between streams costs microseconds, so the side work is forked in a few large batches
+        rather than launch by launch)."""
+        self.calls.append((Plan.FLUSH, lambda s: 0, None))
+        self.lanes.append(0)
 
     def run(self):
+        if self.rt.device.type == 'cuda' and any(self.lanes) and SIDE_STREAM:
+            return self._run_two_streams()
         s = self.rt.stream()
         for name, call, _ in self.calls:
             rc = call(s)
             if rc != 0:
                 abi.check(rc, name)
 
+    def _run_two_streams(self):
+        main, side = torch.cuda.current_stream(self.rt.device), self.rt.side_stream()
+        ms, ss = C.c_void_p(main.cuda_stream), C.c_void_p(side.cuda_stream)
+        deferred, pending = [], False
+
+        def issue_side():
+            nonlocal pending
+            if deferred:
+                side.wait_stream(main)           # fork: the batch sees everything recorded on main so far
+                for name, call in deferred:
+                    rc = call(ss)
+                    if rc != 0:
+                        abi.check(rc, name)
+                del deferred[:]
+                pending = True
+
+        for (name, call, _), lane in zip(self.calls, self.lanes):
+            if name == Plan.FLUSH:
+                issue_side()
+            elif name == Plan.JOIN:
+                issue_side()
+                if pending:
+                    main.wait_stream(side)
+                pending = False
+            elif lane == 1:
+                deferred.append((name, call))
+            else:
+                rc = call(ms)
+                if rc != 0:
+                    abi.check(rc, name)
+        issue_side()
+        if pending:
+            main.wait_stream(side)
+
     def __len__(self):
-        return len(self.calls)
+        return sum(1 for name, _, _ in self.calls if not name.startswith('__'))
 
 
 class VarStore:
@@ -327,16 +410,9 @@ class PointLayer:
         a.coef = fptr(self.coef)
         plan.add('t3d_bn_bwd_finalize', a)
 
-    def _gram_prepare(self, plan, need_w):
-        """Everything K x K of the Gram-form backward (t3d.h K11e), summed by ONE t3d_reduce_slabs launch:
-        P and rowconst (always), G = a^T a and the column sums of a (only when dW is wanted)."""
-        g, rt, K, N = self.g, self.g.rt, self.K, self.N
-        nch = (N + 127) // 128
-        rps = wgrad_rows_per_split(rt.lib, self.M, K, K)
-        n_slabs = self.M // rps
-        # slab regions | reduced regions, in one buffer each
-        regions = [('G', K * K, n_slabs), ('abar', K, self.T)] if need_w else []
-        regions += [('P', K * K, nch), ('rowconst', K, nch)]
+    def _gram_reduce(self, plan, regions):
+        """regions: [(name, numel, n_slabs)] -> (slab views, reduced views); ONE t3d_reduce_slabs launch sums them."""
+        rt = self.g.rt
         soff, ooff, table = {}, {}, []
         st = ot = 0
         for name, numel, ns in regions:
@@ -345,59 +421,84 @@ class PointLayer:
             st += numel * ns
             ot += numel
         slabs, out = rt.zeros(st), rt.zeros(ot)
-        self.gram_slabs, self.gram_out = slabs, out
-        view = lambda name, numel: out[ooff[name]:ooff[name] + numel]
-        self.P, self.rowconst = view('P', K * K), view('rowconst', K)
-        if need_w:
-            self.G, self.abar = view('G', K * K), view('abar', K)
-            a = abi.PointMlpGramArgs()
-            a.a, a.slabs = self.src.struct(), fptr(slabs[soff['G']:])
-            a.M, a.K, a.rows_per_frustum, a.rows_per_split = self.M, K, g.rpf, rps
-            plan.add('t3d_pointmlp_gram', a)
-            c = abi.ActColsumArgs()
-            c.a, c.M, c.K, c.rows_per_frustum, c.part = self.src.struct(), self.M, K, g.rpf, fptr(slabs[soff['abar']:])
-            plan.add('t3d_act_colsum', c)
-        q = abi.PoolBwdPrepArgs(fptr(self.w), fptr(self.bias), fptr(self.coef), K, N, fptr(slabs[soff['P']:]),
-                                fptr(slabs[soff['rowconst']:]), fptr(self.wc))
-        plan.add('t3d_pool_bwd_prep', q)
         desc = (abi.SlabDesc * len(table))(*table)
         tab = torch.as_tensor(np.frombuffer(bytes(desc), dtype=np.uint8).copy()).to(rt.device)
         rt.allocs.append(tab)
-        lib, n = rt.lib, len(table)
-        plan.add_raw('t3d_reduce_slabs', lambda s: lib.t3d_reduce_slabs(
-            fptr(slabs), fptr(out), C.cast(C.c_void_p(tab.data_ptr()), C.POINTER(abi.SlabDesc)), n, K * K, s))
-        self._gram_plan = plan
+        lib, n, mx = rt.lib, len(table), max(r[1] for r in regions)
+
+        def emit():
+            plan.add_raw('t3d_reduce_slabs', lambda s: lib.t3d_reduce_slabs(
+                fptr(slabs), fptr(out), C.cast(C.c_void_p(tab.data_ptr()), C.POINTER(abi.SlabDesc)), n, mx, s))
+        return ({k: slabs[v:] for k, v in soff.items()}, {name: out[ooff[name]:ooff[name] + numel] for name, numel, _ in regions},
+                emit)
 
     def _wgrad_gram(self, plan):
-        """dW of a pooled layer from the K x K Gram matrix of its input."""
-        g, K, N = self.g, self.K, self.N
-        self._gram_prepare(plan, True)
+        """dW of a pooled layer from the K x K Gram matrix of its input (t3d.h K11e): gram + column sums of the input,
+        one slab reduction, then the assembly kernel.  Independent of the dgrad chain."""
+        g, rt, K, N = self.g, self.g.rt, self.K, self.N
+        rps = wgrad_rows_per_split(rt.lib, self.M, K, K)
+        regions = [('G', K * K, self.M // rps), ('abar', K, self.T)]
+        merged = not SIDE_STREAM            # one stream: P / rowconst ride in the same slab reduction (one launch less)
+        if merged:
+            nch = (N + 127) // 128
+            regions += [('P', K * K, nch), ('rowconst', K, nch)]
+        sl, red, emit_reduce = self._gram_reduce(plan, regions)
+        a = abi.PointMlpGramArgs()
+        a.a, a.slabs = self.src.struct(), fptr(sl['G'])
+        a.M, a.K, a.rows_per_frustum, a.rows_per_split = self.M, K, g.rpf, rps
+        plan.add('t3d_pointmlp_gram', a)
+        c = abi.ActColsumArgs()
+        c.a, c.M, c.K, c.rows_per_frustum, c.part = self.src.struct(), self.M, K, g.rpf, fptr(sl['abar'])
+        plan.add('t3d_act_colsum', c)
+        if merged:
+            self._emit_prep(plan, sl)
+            self._gram_prepped = (plan, red)
+        emit_reduce()
         f = abi.PoolWgradFinishArgs()
         f.a, f.argidx, f.dpool, f.coef = self.src.struct(), iptr(self.argidx), fptr(self.dpool), fptr(self.coef)
-        f.w, f.bias, f.g, f.abar = fptr(self.w), fptr(self.bias), fptr(self.G), fptr(self.abar)
+        f.w, f.bias, f.g, f.abar = fptr(self.w), fptr(self.bias), fptr(red['G']), fptr(red['abar'])
         f.B, f.K, f.N, f.rows_per_frustum = g.B, K, N, g.rpf
         goff = g.vars.offset(self.w_name) + self.w_row0 * N
         f.dw = fptr(g.vars.grads[goff:goff + K * N])
         plan.add('t3d_pool_wgrad_finish', f)
+        self._gram_keep_w = (sl, red)
 
     def _dgrad_gram(self, plan):
-        """Input gradient of a pooled layer: sparse argmax rows, then the act(a).P GEMM with the dgrad epilogue."""
+        """Input gradient of a pooled layer: P / rowconst / wc, the sparse argmax rows, then the act(a).P GEMM with
+        the dgrad epilogue."""
         g, K, N = self.g, self.K, self.N
         prev = self.src.producer
         assert prev is not None and not prev.pool, 'pooled layers follow a dense per-point layer in every reference net'
         prev._ensure_bwd_buffers()
-        if getattr(self, '_gram_plan', None) is not plan:
-            self._gram_prepare(plan, False)
+        prepped = getattr(self, '_gram_prepped', (None, None))
+        if prepped[0] is plan:
+            red = prepped[1]
+        else:
+            nch = (N + 127) // 128
+            sl, red, emit_reduce = self._gram_reduce(plan, [('P', K * K, nch), ('rowconst', K, nch)])
+            self._emit_prep(plan, sl)
+            emit_reduce()
+            self._gram_keep_d = (sl, red)
         r = abi.PoolSparseRowsArgs(iptr(self.argidx), fptr(self.dpool), fptr(self.wc), g.B, N, K, g.rpf, fptr(self.S))
         plan.add('t3d_pool_sparse_rows', r)
         a = abi.PointMlpDgradGramArgs()
-        a.a, a.p, a.rowconst, a.add_in = self.src.struct(), fptr(self.P), fptr(self.rowconst), fptr(self.S)
+        a.a, a.p, a.rowconst, a.add_in = self.src.struct(), fptr(red['P']), fptr(red['rowconst']), fptr(self.S)
         a.prev_y, a.prev_scale, a.prev_shift = fptr(prev.y), fptr(prev.scale), fptr(prev.shift)
         a.out, a.psum_dz, a.psum_dzy = fptr(prev.dz), fptr(prev.psum_dz), fptr(prev.psum_dzy)
         a.M, a.K, a.rows_per_frustum = self.M, K, g.rpf
         plan.add('t3d_pointmlp_dgrad_gram', a)
 
+    def _emit_prep(self, plan, sl):
+        q = abi.PoolBwdPrepArgs(fptr(self.w), fptr(self.bias), fptr(self.coef), self.K, self.N, fptr(sl['P']),
+                                fptr(sl['rowconst']), fptr(self.wc))
+        plan.add('t3d_pool_bwd_prep', q)
+
     def wgrad(self, plan):
+        """Weight gradient: off the critical path, recorded on the plan's side lane."""
+        with plan.side():
+            self._wgrad(plan)
+
+    def _wgrad(self, plan):
         g = self.g
         if self.gram:
             return self._wgrad_gram(plan)

@@ -54,6 +54,7 @@ class Graph:
     def emit_reduce_slabs(self, plan):
         """Must be emitted after every wgrad has been recorded; resolved at run time (post-finalize)."""
         ws, vs, lib = self.ws, self.vars, self.rt.lib
+        plan.join()                       # the weight gradients were recorded on the side lane
 
         def thunk(s):
             n = len(ws.entries)
@@ -367,7 +368,9 @@ class ModelAssembly:
 
     def emit_backward(self, plan):
         ds1 = self.box.bwd(plan, self.loss_op.dbox, self.loss_op.dstage1)
+        plan.flush()                     # box-net weight gradients run beside the T-Net / seg-net dgrad chain
         self.tnet.bwd(plan, ds1)
+        plan.flush()
         self.seg.bwd(plan)
         self.g.emit_reduce_slabs(plan)
 
