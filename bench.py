@@ -54,6 +54,11 @@ CALLS = {}
 def gemm_label_and_flops(name, a):
     """Mirror of the template dispatch in csrc/pointmlp.hip -> rocprof kernel name + algorithmic FLOPs."""
     import ctypes
+    if name == 't3d_pointmlp_bwd':
+        d, w = a
+        dl, df = gemm_label_and_flops('t3d_pointmlp_dgrad', d)
+        wl, wf = gemm_label_and_flops('t3d_pointmlp_wgrad', w)
+        return 'k_pointmlp_bwd<%s,%s>' % (dl[dl.index('<') + 1:-1], wl[wl.index('<') + 1:-1]), df + wf
     if name == 't3d_pointmlp_dgrad_gram':
         return 'k_pointmlp_dgrad_gram<%d>' % (128 if a.K % 128 == 0 and (a.M // 128) * (a.K // 128) >= 512 else 64), 2.0 * a.M * a.K * a.K
     if name == 't3d_pointmlp_gram':
@@ -102,7 +107,8 @@ def profile_kernels(plans, steps):
             d[1] += 1
             d[2] += flops
             if flops:
-                dd = detail.setdefault('%s M%d K%d N%d' % (label, arg.M, arg.K, getattr(arg, 'N', arg.K)), [0.0, 0, flops])
+                a0 = arg[0] if isinstance(arg, tuple) else arg
+                dd = detail.setdefault('%s M%d K%d N%d' % (label, a0.M, a0.K, getattr(a0, 'N', a0.K)), [0.0, 0, flops])
                 dd[0] += dt
                 dd[1] += 1
     return acc, detail
@@ -268,6 +274,7 @@ def main():
         if args.call_detail:
             for ci in sorted(CALLS):
                 name, arg, t_ = CALLS[ci]
+                arg = arg[0] if isinstance(arg, tuple) else arg
                 dims = ' '.join('%s=%d' % (f, getattr(arg, f)) for f in ('M', 'K', 'N', 'B') if arg is not None and hasattr(arg, f))
                 sys.stderr.write('%3d %-28s %-28s %8.1f us\n' % (ci, name, dims, t_ * 1e6))
         if args.gemm_detail:

@@ -178,6 +178,10 @@ typedef struct {
   int rows_per_split;
 } t3d_pointmlp_wgrad_args;
 int t3d_pointmlp_wgrad(const t3d_pointmlp_wgrad_args* args, t3d_stream_t stream);
+/* K11a + K11b of one dense layer in ONE launch (the two are independent; sharing a launch saves a kernel's fill/drain
+ * latency per layer and lets both kinds of tile share the CUs).  Same arguments and results as the two separate calls;
+ * dense dy only (dy.dz != NULL in both), same M, K, N. */
+int t3d_pointmlp_bwd(const t3d_pointmlp_dgrad_args* dgrad, const t3d_pointmlp_wgrad_args* wgrad, t3d_stream_t stream);
 /* Recommended row split (and the tile the launcher will then use) for a K x N weight gradient over M rows. */
 int t3d_wgrad_plan(int M, int K, int N, int* rows_per_split, int* tile_k, int* tile_n);
 

@@ -253,6 +253,9 @@ class FakeLib:
             slabs[s] = x[s * rps:(s + 1) * rps].T @ dy[s * rps:(s + 1) * rps]
         return 0
 
+    def t3d_pointmlp_bwd(self, d, w, stream):
+        return self.t3d_pointmlp_dgrad(d, stream) or self.t3d_pointmlp_wgrad(w, stream)
+
     def t3d_wgrad_plan(self, M, K, N, rps, tk, tn):
         cap = max(64, (1 << 21) // (K * N))
         cap = max(1, min(cap, M // 128))

@@ -846,3 +846,45 @@ def test_gram_form_equals_direct_form_through_the_kernels(hip_lib):
     _close(out_d.cpu(), out_g.cpu(), 1e-4, 3e-5 * sd, 'da gram vs direct')
     _close(slab[0].cpu(), dw.cpu(), 1e-4, 3e-5 * sw, 'dW gram vs direct')
     _close(s1d.cpu(), s1g.cpu(), 1e-3, 1e-3 * sd, 'psum_dz gram vs direct')
+
+
+@pytest.mark.parametrize('M,K,N,rpf,mode', [(1024, 128, 128, 256, 'mask'), (512, 64, 512, 128, 'raw'), (1024, 512, 256, 256, 'mask_addin'),
+                                            (65536, 64, 64, 1024, 'mask')])
+def test_fused_bwd_equals_separate_dgrad_and_wgrad(hip_lib, M, K, N, rpf, mode):
+    """t3d_pointmlp_bwd is the two kernels in one launch: bit-identical outputs."""
+    r = np.random.RandomState(M + K + N)
+    dev = _dev('cuda')
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    T = M // 128
+    t = {k: _mk(dev, v) for k, v in dict(
+        x=r.normal(size=(M, K)).astype(np.float32), sc=(0.5 + r.uniform(size=K)).astype(np.float32),
+        sh=(r.normal(size=K) * 0.3).astype(np.float32), w=(r.normal(size=(K, N)) / np.sqrt(N)).astype(np.float32),
+        dz=(r.normal(size=(M, N)) * 1e-2).astype(np.float32), y=r.normal(size=(M, N)).astype(np.float32),
+        coef=r.normal(size=(3, N)).astype(np.float32), add=(r.normal(size=(M, K)) * 1e-2).astype(np.float32)).items()}
+    rps, tk, tn = C.c_int(0), C.c_int(0), C.c_int(0)
+    assert hip_lib.t3d_wgrad_plan(M, K, N, C.byref(rps), C.byref(tk), C.byref(tn)) == 0
+    S = M // rps.value
+    act = _act_src(t, K)
+    dy = abi.DySrc(fptr(t['dz']), fptr(t['y']), fptr(t['coef']), iptr(None), fptr(None))
+    res = []
+    for fused in (False, True):
+        out, s1, s2 = torch.zeros(M, K, device=dev), torch.zeros(T, K, device=dev), torch.zeros(T, K, device=dev)
+        slabs = torch.zeros(S, K, N, device=dev)
+        d = abi.PointMlpDgradArgs()
+        d.dy, d.w, d.out = dy, fptr(t['w']), fptr(out)
+        if 'addin' in mode:
+            d.add_in = fptr(t['add'])
+        if 'mask' in mode:
+            d.prev_y, d.prev_scale, d.prev_shift, d.psum_dz, d.psum_dzy = fptr(t['x']), fptr(t['sc']), fptr(t['sh']), fptr(s1), fptr(s2)
+        d.M, d.K, d.N, d.rows_per_frustum = M, K, N, rpf
+        w = abi.PointMlpWgradArgs(act, dy, fptr(slabs), M, K, N, rpf, rps.value)
+        if fused:
+            assert hip_lib.t3d_pointmlp_bwd(C.byref(d), C.byref(w), st) == 0
+        else:
+            assert hip_lib.t3d_pointmlp_dgrad(C.byref(d), st) == 0
+            assert hip_lib.t3d_pointmlp_wgrad(C.byref(w), st) == 0
+        torch.cuda.synchronize()
+        res.append((out, s1, s2, slabs))
+    for a, b, what in zip(res[0], res[1], ('out', 'psum_dz', 'psum_dzy', 'slabs')):
+        assert torch.equal(a, b), what
+    assert float(res[1][3].abs().max()) > 0 and float(res[1][0].abs().max()) > 0

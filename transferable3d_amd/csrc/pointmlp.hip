@@ -622,18 +622,17 @@ __device__ __forceinline__ void dgrad_epilogue(const DgradEpilogue& p, f32x16 (&
 }
 
 template <int BN, bool POOLED>   // BN = tile width over the layer's INPUT channels K
-__global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_dgrad(const t3d_pointmlp_dgrad_args p) {
+__device__ __forceinline__ void dgrad_body(const t3d_pointmlp_dgrad_args& p, float* smem, int bid, int nblocks) {
   constexpr int BM = 128, TM = 2, TN = BN / 64;
-  using LA = DyLoader<POOLED>;
   constexpr int PF = BN == 64 ? T3D_PF_NARROW : T3D_PF_WIDE;
+  using LA = DyLoader<POOLED>;
   using SA = Stager<BM, true, LA, PF>;
   using SB = Stager<BN, true, WLoader, PF>;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int tiles_n = p.K / BN;
-  const int lin = xcd_remap(blockIdx.x, gridDim.x);
+  const int lin = xcd_remap(bid, nblocks);
   const int tile_m = lin / tiles_n, tile_n = lin % tiles_n;
   const int row0 = tile_m * BM, col0 = tile_n * BN;
 
@@ -651,6 +650,12 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_dgrad(const t3d_poin
 
   DgradEpilogue e{p.add_in, nullptr, p.prev_y, p.prev_scale, p.prev_shift, p.out, p.psum_dz, p.psum_dzy, p.K};
   dgrad_epilogue<BN, TM, TN>(e, acc, smem, tid, row0, col0, tile_m);
+}
+
+template <int BN, bool POOLED>
+__global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_dgrad(const t3d_pointmlp_dgrad_args p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  dgrad_body<BN, POOLED>(p, smem, blockIdx.x, gridDim.x);
 }
 
 // Gram-form data gradient of a max-pooled layer: out = act(a) . P + rowconst + S  (see t3d.h K11e); the operand
@@ -688,7 +693,7 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_dgrad_gram(const t3d
 // slab[split][k0.., n0..] = sum over the split's rows of A[m,k] B[m,n]; both operands type C (row index = reduction).
 template <int BMK, int BN, class LA, class LB>
 __device__ __forceinline__ void wgrad_body(const LA& la, const LB& lb, float* slabs, int K, int N, int rows_per_split,
-                                           float* smem) {
+                                           float* smem, int bid, int nblocks) {
   constexpr int TM = BMK / 64, TN = BN / 64;
   constexpr int PF = (BMK == 64 && BN == 64) ? T3D_PF_NARROW : T3D_PF_WIDE;
   using SA = Stager<BMK, false, LA, PF>;
@@ -696,7 +701,7 @@ __device__ __forceinline__ void wgrad_body(const LA& la, const LB& lb, float* sl
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int tiles_k = (K + BMK - 1) / BMK, tiles_n = N / BN;
-  const int lin = xcd_remap(blockIdx.x, gridDim.x);
+  const int lin = xcd_remap(bid, nblocks);
   const int split = lin / (tiles_k * tiles_n);
   const int t = lin % (tiles_k * tiles_n);
   const int k0 = (t / tiles_n) * BMK, n0 = (t % tiles_n) * BN;
@@ -729,7 +734,7 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_wgrad(const t3d_poin
   extern __shared__ __attribute__((aligned(16))) float smem[];
   ActLoader<HAS_SUB> la{p.a, p.K, p.rows_per_frustum};
   DyLoader<POOLED> lb{p.dy, p.N, p.rows_per_frustum};
-  wgrad_body<BMK, BN>(la, lb, p.slabs, p.K, p.N, p.rows_per_split, smem);
+  wgrad_body<BMK, BN>(la, lb, p.slabs, p.K, p.N, p.rows_per_split, smem, blockIdx.x, gridDim.x);
 }
 
 // Gram matrix of a layer input, G = a^T a, as split-row slabs (t3d.h K11e).
@@ -737,7 +742,23 @@ template <int BMK, int BN>
 __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_gram(const t3d_pointmlp_gram_args p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   ActLoader<false> la{p.a, p.K, p.rows_per_frustum};
-  wgrad_body<BMK, BN>(la, la, p.slabs, p.K, p.K, p.rows_per_split, smem);
+  wgrad_body<BMK, BN>(la, la, p.slabs, p.K, p.K, p.rows_per_split, smem, blockIdx.x, gridDim.x);
+}
+
+// One launch for both gradients of a dense layer: the first `n_wgrad` workgroups run weight-gradient tiles, the rest
+// data-gradient tiles.  The two are independent (both read dy = c0*dz + c1*y + c2), so sharing a launch removes one
+// kernel's fill/drain latency per layer and lets the tiles of one kind fill the holes the other leaves on a CU.
+template <int DBN, int WBMK, int WBN>
+__global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_bwd(const t3d_pointmlp_dgrad_args d, const t3d_pointmlp_wgrad_args w,
+                                                                const int n_wgrad) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((int)blockIdx.x < n_wgrad) {
+    ActLoader<false> la{w.a, w.K, w.rows_per_frustum};
+    DyLoader<false> lb{w.dy, w.N, w.rows_per_frustum};
+    wgrad_body<WBMK, WBN>(la, lb, w.slabs, w.K, w.N, w.rows_per_split, smem, blockIdx.x, n_wgrad);
+  } else {
+    dgrad_body<DBN, false>(d, smem, blockIdx.x - n_wgrad, gridDim.x - n_wgrad);
+  }
 }
 
 // dynamic-LDS launch: two pipeline stages exceed the 64 KB static limit for the 128-wide tiles
@@ -785,17 +806,26 @@ extern "C" int t3d_pointmlp_fwd(const t3d_pointmlp_fwd_args* a, t3d_stream_t str
   return T3D_OK;
 }
 
-extern "C" int t3d_pointmlp_dgrad(const t3d_pointmlp_dgrad_args* a, t3d_stream_t stream) {
+static int check_dgrad(const t3d_pointmlp_dgrad_args* a) {
   if (!a || !a->w || !a->out || !dy_ok(a->dy)) return T3D_ERR_ARG;
   if (a->prev_y && (!a->prev_scale || !a->prev_shift)) return T3D_ERR_ARG;
   if (a->psum_dz && (!a->psum_dzy || !a->prev_y)) return T3D_ERR_ARG;
   if (a->M <= 0 || a->M % T3D_TILE_ROWS || a->rows_per_frustum % T3D_TILE_ROWS || a->M % a->rows_per_frustum ||
       a->K % 64 || a->N % 4 || (long)a->M * a->K >= (1L << 30))
     return T3D_ERR_SHAPE;
+  return T3D_OK;
+}
+static bool dgrad_wide(const t3d_pointmlp_dgrad_args* a) {
+  return T3D_FORCE_TILE != 64 && a->K % 128 == 0 && (T3D_FORCE_TILE == 128 || (long)(a->M / 128) * (a->K / 128) >= 512);
+}
+
+extern "C" int t3d_pointmlp_dgrad(const t3d_pointmlp_dgrad_args* a, t3d_stream_t stream) {
+  const int rc = check_dgrad(a);
+  if (rc != T3D_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int tiles_m = a->M / 128;
   const bool pooled = a->dy.dz == nullptr;
-  if (T3D_FORCE_TILE != 64 && a->K % 128 == 0 && (T3D_FORCE_TILE == 128 || (long)tiles_m * (a->K / 128) >= 512)) {
+  if (dgrad_wide(a)) {
     const dim3 grid(tiles_m * (a->K / 128));
     if (pooled) launch_lds(k_pointmlp_dgrad<128, true>, grid, lds_dgrad(128), s, *a);
     else launch_lds(k_pointmlp_dgrad<128, false>, grid, lds_dgrad(128), s, *a);
@@ -837,20 +867,28 @@ extern "C" int t3d_wgrad_plan(int M, int K, int N, int* rows_per_split, int* til
   return T3D_OK;
 }
 
-extern "C" int t3d_pointmlp_wgrad(const t3d_pointmlp_wgrad_args* a, t3d_stream_t stream) {
+static int check_wgrad(const t3d_pointmlp_wgrad_args* a) {
   if (!a || !a->slabs || !act_ok(a->a, a->K) || !dy_ok(a->dy)) return T3D_ERR_ARG;
   if (a->M <= 0 || a->rows_per_split <= 0 || a->rows_per_split % BK || a->M % a->rows_per_split || a->N % 64 ||
       a->rows_per_frustum % BK || a->M % a->rows_per_frustum)
     return T3D_ERR_SHAPE;
+  return T3D_OK;
+}
+// tile choice: the plan's tile if the caller used t3d_wgrad_plan's split, else by shape
+static void wgrad_tile(const t3d_pointmlp_wgrad_args* a, int* tk, int* tn) {
+  int rps = 0;
+  if (a->M % 128 == 0 && t3d_wgrad_plan(a->M, a->K, a->N, &rps, tk, tn) == T3D_OK && rps == a->rows_per_split) return;
+  *tk = a->K > 64 ? 128 : 64;
+  *tn = a->N % 128 == 0 ? 128 : 64;
+}
+
+extern "C" int t3d_pointmlp_wgrad(const t3d_pointmlp_wgrad_args* a, t3d_stream_t stream) {
+  const int rc = check_wgrad(a);
+  if (rc != T3D_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int splits = a->M / a->rows_per_split;
-  // tile choice: the plan's tile if the caller used t3d_wgrad_plan's split, else by shape
-  int rps = 0, tk = 0, tn = 0;
-  if (a->M % 128 == 0 && t3d_wgrad_plan(a->M, a->K, a->N, &rps, &tk, &tn) == T3D_OK && rps == a->rows_per_split) {
-  } else {
-    tk = a->K > 64 ? 128 : 64;
-    tn = a->N % 128 == 0 ? 128 : 64;
-  }
+  int tk = 0, tn = 0;
+  wgrad_tile(a, &tk, &tn);
   const int tiles_k = (a->K + tk - 1) / tk, tiles_n = a->N / tn;
   const dim3 grid(tiles_k * tiles_n * splits);
   const bool sub = a->a.sub != nullptr, pooled = a->dy.dz == nullptr;
@@ -901,6 +939,45 @@ extern "C" int t3d_pointmlp_gram(const t3d_pointmlp_gram_args* a, t3d_stream_t s
   const dim3 grid((a->K / tk) * (a->K / tn) * splits);
   if (tk == 128) launch_lds(k_pointmlp_gram<128, 128>, grid, lds_wgrad(128, 128), s, *a);
   else launch_lds(k_pointmlp_gram<64, 64>, grid, lds_wgrad(64, 64), s, *a);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_pointmlp_bwd(const t3d_pointmlp_dgrad_args* d, const t3d_pointmlp_wgrad_args* w, t3d_stream_t stream) {
+  int rc = check_dgrad(d);
+  if (rc != T3D_OK) return rc;
+  rc = check_wgrad(w);
+  if (rc != T3D_OK) return rc;
+  // the fused launch covers the dense form only (pooled layers take the Gram path, raw-point layers have no dgrad)
+  if (!d->dy.dz || !w->dy.dz || w->a.sub) return T3D_ERR_ARG;
+  if (d->M != w->M || d->K != w->K || d->N != w->N) return T3D_ERR_SHAPE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int tk = 0, tn = 0;
+  wgrad_tile(w, &tk, &tn);
+  const int n_w = ((w->K + tk - 1) / tk) * (w->N / tn) * (w->M / w->rows_per_split);
+  const bool wide = dgrad_wide(d);
+  const int n_d = (d->M / 128) * (d->K / (wide ? 128 : 64));
+  const dim3 grid(n_w + n_d);
+#define T3D_BWD(DBN, TK, TN_)                                                                                      \
+  do {                                                                                                              \
+    const size_t lds = lds_dgrad(DBN) > lds_wgrad(TK, TN_) ? lds_dgrad(DBN) : lds_wgrad(TK, TN_);                   \
+    auto kern = k_pointmlp_bwd<DBN, TK, TN_>;                                                                       \
+    if (lds > 64 * 1024)                                                                                            \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                (int)lds);                                                                          \
+    T3D_LAUNCH(kern, grid, dim3(NT), lds, s, *d, *w, n_w);                                                          \
+  } while (0)
+#define T3D_BWD_W(DBN)                              \
+  do {                                              \
+    if (tk == 128 && tn == 128) T3D_BWD(DBN, 128, 128); \
+    else if (tk == 128) T3D_BWD(DBN, 128, 64);      \
+    else if (tn == 128) T3D_BWD(DBN, 64, 128);      \
+    else T3D_BWD(DBN, 64, 64);                      \
+  } while (0)
+  if (wide) T3D_BWD_W(128);
+  else T3D_BWD_W(64);
+#undef T3D_BWD_W
+#undef T3D_BWD
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

@@ -65,6 +65,8 @@ class Runtime:
 # layer, 1.86 ms with two batched forks, 1.82 ms linear) -- cross-stream graph edges cost more than the overlap returns --
 # so it is off unless T3D_SIDE_STREAM=1.
 SIDE_STREAM = os.environ.get('T3D_SIDE_STREAM', '0') == '1'
+# dgrad + wgrad of a dense layer in one launch (t3d_pointmlp_bwd); T3D_FUSE_BWD=0 restores the two launches
+FUSE_BWD = os.environ.get('T3D_FUSE_BWD', '1') != '0'
 
 
 class Plan:
@@ -498,10 +500,8 @@ class PointLayer:
         with plan.side():
             self._wgrad(plan)
 
-    def _wgrad(self, plan):
+    def _wgrad_args(self):
         g = self.g
-        if self.gram:
-            return self._wgrad_gram(plan)
         rps = wgrad_rows_per_split(g.rt.lib, self.M, self.K, self.N)
         n_slabs = self.M // rps
         goff = g.vars.offset(self.w_name) + self.w_row0 * self.N
@@ -510,14 +510,14 @@ class PointLayer:
         a.a, a.dy = self.src.struct(), self.dy_struct()
         a.M, a.K, a.N, a.rows_per_frustum, a.rows_per_split = self.M, self.K, self.N, g.rpf, rps
         g.deferred_slab_ptrs.append((a, 'slabs', soff))
-        plan.add('t3d_pointmlp_wgrad', a)
+        return a
 
-    def dgrad(self, plan, out_raw=None, add_in=None):
-        """Input gradient.  If the input's producer is a PointLayer, writes its dz (ReLU-masked) and
-        batch-norm-backward partials; otherwise writes the raw gradient into `out_raw`."""
+    def _wgrad(self, plan):
         if self.gram:
-            assert out_raw is None and add_in is None
-            return self._dgrad_gram(plan)
+            return self._wgrad_gram(plan)
+        plan.add('t3d_pointmlp_wgrad', self._wgrad_args())
+
+    def _dgrad_args(self, out_raw=None, add_in=None):
         prev = self.src.producer if out_raw is None else None
         a = abi.PointMlpDgradArgs()
         a.dy, a.w, a.add_in = self.dy_struct(), fptr(self.w), fptr(add_in)
@@ -529,7 +529,26 @@ class PointLayer:
         else:
             a.out = fptr(out_raw)
         a.M, a.K, a.N, a.rows_per_frustum = self.M, self.K, self.N, self.g.rpf
-        plan.add('t3d_pointmlp_dgrad', a)
+        return a
+
+    def dgrad(self, plan, out_raw=None, add_in=None):
+        """Input gradient.  If the input's producer is a PointLayer, writes its dz (ReLU-masked) and
+        batch-norm-backward partials; otherwise writes the raw gradient into `out_raw`."""
+        if self.gram:
+            assert out_raw is None and add_in is None
+            return self._dgrad_gram(plan)
+        plan.add('t3d_pointmlp_dgrad', self._dgrad_args(out_raw, add_in))
+
+    def bwd_pair(self, plan, out_raw=None, add_in=None):
+        """Weight gradient + input gradient.  Dense layers: ONE launch (t3d_pointmlp_bwd); pooled layers: the Gram path."""
+        if self.gram or self.pool or not FUSE_BWD:
+            self.wgrad(plan)
+            return self.dgrad(plan, out_raw=out_raw, add_in=add_in)
+        d, w = self._dgrad_args(out_raw, add_in), self._wgrad_args()
+        fn, dref, wref = self.g.rt.lib.t3d_pointmlp_bwd, C.byref(d), C.byref(w)
+        plan.keep.extend([d, w])
+        plan.calls.append(('t3d_pointmlp_bwd', lambda s: fn(dref, wref, s), (d, w)))
+        plan.lanes.append(0)
 
     def dy_colsum(self, plan, alpha=1.0):
         """[B,N] per-frustum column sums of dy (dense layers only)."""

@@ -169,25 +169,21 @@ class InstSegNet:
         L = self
         for lay in (L.L9, L.L8, L.L7):
             lay.bn_bwd(plan)
-            lay.wgrad(plan)
-            lay.dgrad(plan)
+            lay.bwd_pair(plan)
         L.L6.bn_bwd(plan)
-        L.L6.wgrad(plan)
         colsum6 = L.L6.dy_colsum(plan)                                   # [B,512]
         L.G6.bwd(plan, dout=colsum6, ld_dout=512)                        # dW6[64:], no bias
         dg5 = L.G6.dinput(plan, K=1024)                                  # [B,1024]
         self.da3_part = g.rt.zeros(g.M, 64)
-        L.L6.dgrad(plan, out_raw=self.da3_part)
+        L.L6.bwd_pair(plan, out_raw=self.da3_part)
         L.L5.bn_bwd(plan, dpool_in=dg5, ld_dpool_in=1024)
         L.L5.wgrad(plan)
         L.L5.dgrad(plan)
         L.L4.bn_bwd(plan)
-        L.L4.wgrad(plan)
-        L.L4.dgrad(plan, add_in=self.da3_part)
+        L.L4.bwd_pair(plan, add_in=self.da3_part)
         for lay in (L.L3, L.L2):
             lay.bn_bwd(plan)
-            lay.wgrad(plan)
-            lay.dgrad(plan)
+            lay.bwd_pair(plan)
         L.L1.bn_bwd(plan)
         L.L1.wgrad(plan)
 
@@ -225,8 +221,7 @@ class TNet:
         self.T3.wgrad(plan)
         self.T3.dgrad(plan)
         self.T2.bn_bwd(plan)
-        self.T2.wgrad(plan)
-        self.T2.dgrad(plan)
+        self.T2.bwd_pair(plan)
         self.T1.bn_bwd(plan)
         self.T1.wgrad(plan)
 
@@ -266,8 +261,7 @@ class BoxEstNet:
         self.B4.dgrad(plan)
         for lay in (self.B3, self.B2):
             lay.bn_bwd(plan)
-            lay.wgrad(plan)
-            lay.dgrad(plan)
+            lay.bwd_pair(plan)
         self.B1.bn_bwd(plan)
         self.B1.wgrad(plan)
         # input = xyz - stage1_center  =>  d stage1_center -= sum_n dX = (per-frustum colsum of dy1) . W1^T
@@ -453,8 +447,9 @@ class BoxPCNet:
         for lay in (self.P3, self.P2):
             lay.bn_bwd(plan, param_grads=param_grads)
             if param_grads:
-                lay.wgrad(plan)
-            lay.dgrad(plan)
+                lay.bwd_pair(plan)
+            else:
+                lay.dgrad(plan)
         self.P1.bn_bwd(plan, param_grads=param_grads)
         if param_grads:
             self.P1.wgrad(plan)
