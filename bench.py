@@ -54,6 +54,12 @@ CALLS = {}
 def gemm_label_and_flops(name, a):
     """Mirror of the template dispatch in csrc/pointmlp.hip -> rocprof kernel name + algorithmic FLOPs."""
     import ctypes
+    if name == 't3d_pool_bwd_stage1':
+        gl, gf = gemm_label_and_flops('t3d_pointmlp_gram', a[0])
+        return 'k_pool_bwd_stage1<%s>' % gl[gl.index('<') + 1:gl.index(',')], gf + 2.0 * a[2].K * a[2].K * a[2].N
+    if name == 't3d_pool_bwd_stage2':
+        dl, df = gemm_label_and_flops('t3d_pointmlp_dgrad_gram', a[1])
+        return 'k_pool_bwd_stage2<%s>' % dl[dl.index('<') + 1:-1], df + 2.0 * a[0].K * a[0].K * a[0].N
     if name == 't3d_pointmlp_bwd':
         d, w = a
         dl, df = gemm_label_and_flops('t3d_pointmlp_dgrad', d)
@@ -100,14 +106,14 @@ def profile_kernels(plans, steps):
         torch.cuda.synchronize()
         for ci, (name, arg, e0, e1) in enumerate(evs):
             CALLS.setdefault(ci, [name, arg, 0.0])[2] += e0.elapsed_time(e1) * 1e-3 / steps
-            label, flops = (gemm_label_and_flops(name, arg) if name.startswith('t3d_pointmlp') else (name, 0.0))
+            label, flops = (gemm_label_and_flops(name, arg) if name.startswith(('t3d_pointmlp', 't3d_pool_bwd_stage')) else (name, 0.0))
             d = acc.setdefault(label, [0.0, 0, 0.0])
             dt = e0.elapsed_time(e1) * 1e-3
             d[0] += dt
             d[1] += 1
             d[2] += flops
             if flops:
-                a0 = arg[0] if isinstance(arg, tuple) else arg
+                a0 = (arg[1] if name == 't3d_pool_bwd_stage2' else arg[0]) if isinstance(arg, tuple) else arg
                 dd = detail.setdefault('%s M%d K%d N%d' % (label, a0.M, a0.K, getattr(a0, 'N', a0.K)), [0.0, 0, flops])
                 dd[0] += dt
                 dd[1] += 1
@@ -255,11 +261,11 @@ def main():
         # per-kernel timing for the roofline object (eager, per-launch events on the launch stream)
         acc, detail = profile_kernels([g.pre, g.fwd, g.bwd, g.opt], args.profile_steps)
         total = sum(v[0] for v in acc.values())
-        dom = max((k for k in acc if k.startswith('k_pointmlp')), key=lambda k: acc[k][0])
+        dom = max((k for k in acc if k.startswith(('k_pointmlp', 'k_pool_bwd_stage'))), key=lambda k: acc[k][0])
         tsec, n, fl = acc[dom]
         achieved = fl / tsec / 1e12
-        gemm_t = sum(v[0] for k, v in acc.items() if k.startswith('k_pointmlp'))
-        gemm_f = sum(v[2] for k, v in acc.items() if k.startswith('k_pointmlp'))
+        gemm_t = sum(v[0] for k, v in acc.items() if k.startswith(('k_pointmlp', 'k_pool_bwd_stage')))
+        gemm_f = sum(v[2] for k, v in acc.items() if k.startswith(('k_pointmlp', 'k_pool_bwd_stage')))
         roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': achieved, 'peak': MFMA_F32_PEAK_TFLOPS,
                     'unit': 'TFLOP/s', 'frac': achieved / MFMA_F32_PEAK_TFLOPS, 'traffic': pmc_traffic(dom),
                     'traffic_unit': 'HBM bytes per launch, rocprofv3 PMC passes of this workload (profiles/pmc_traffic.json)',

@@ -245,7 +245,7 @@ typedef struct {
   int K, N;
   float* p_slabs;          /* [ceil(N/128), K, K] out: partial P per chunk of 128 columns n (sum with t3d_reduce_slabs) */
   float* rc_slabs;         /* [ceil(N/128), K] out: partial rowconst */
-  float* wc;               /* [N,K] out */
+  float* wc;               /* [N,K] out, or NULL */
 } t3d_pool_bwd_prep_args;
 int t3d_pool_bwd_prep(const t3d_pool_bwd_prep_args* args, t3d_stream_t stream);
 
@@ -310,6 +310,14 @@ typedef struct {
   float* dw;               /* [K,N] out */
 } t3d_pool_wgrad_finish_args;
 int t3d_pool_wgrad_finish(const t3d_pool_wgrad_finish_args* args, t3d_stream_t stream);
+
+/* The K11e launches that are independent of each other, fused (same arguments and results as the separate calls):
+ * stage 1 = t3d_pointmlp_gram + t3d_act_colsum + t3d_pool_bwd_prep; after the slab reduction,
+ * stage 2 = t3d_pool_wgrad_finish + t3d_pointmlp_dgrad_gram. */
+int t3d_pool_bwd_stage1(const t3d_pointmlp_gram_args* gram, const t3d_act_colsum_args* colsum,
+                        const t3d_pool_bwd_prep_args* prep, t3d_stream_t stream);
+int t3d_pool_bwd_stage2(const t3d_pool_wgrad_finish_args* finish, const t3d_pointmlp_dgrad_gram_args* dgrad,
+                        t3d_stream_t stream);
 
 /* ---- K6: per-frustum fully-connected layer -----------------------------------------------------
  * Replaces tf_util.fully_connected (tf_util.py:1463-1499: matmul + bias [+ batch_norm over the B

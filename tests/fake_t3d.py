@@ -177,7 +177,8 @@ class FakeLib:
             sl = slice(ch * 128, min(N, (ch + 1) * 128))
             ps[ch] = (w[:, sl] * c[1, sl]) @ w[:, sl].T
             rs[ch] = w[:, sl] @ (bias[sl] * c[1, sl] + c[2, sl])
-        arr(p.wc, N, K)[:] = (w * c[0]).T
+        if p.wc:
+            arr(p.wc, N, K)[:] = (w * c[0]).T
         return 0
 
     def t3d_pool_sparse_rows(self, a, stream):
@@ -252,6 +253,12 @@ class FakeLib:
         for s in range(S):
             slabs[s] = x[s * rps:(s + 1) * rps].T @ dy[s * rps:(s + 1) * rps]
         return 0
+
+    def t3d_pool_bwd_stage1(self, g, c, q, stream):
+        return self.t3d_pointmlp_gram(g, stream) or self.t3d_act_colsum(c, stream) or self.t3d_pool_bwd_prep(q, stream)
+
+    def t3d_pool_bwd_stage2(self, f, d, stream):
+        return self.t3d_pool_wgrad_finish(f, stream) or self.t3d_pointmlp_dgrad_gram(d, stream)
 
     def t3d_pointmlp_bwd(self, d, w, stream):
         return self.t3d_pointmlp_dgrad(d, stream) or self.t3d_pointmlp_wgrad(w, stream)

@@ -888,3 +888,50 @@ def test_fused_bwd_equals_separate_dgrad_and_wgrad(hip_lib, M, K, N, rpf, mode):
     for a, b, what in zip(res[0], res[1], ('out', 'psum_dz', 'psum_dzy', 'slabs')):
         assert torch.equal(a, b), what
     assert float(res[1][3].abs().max()) > 0 and float(res[1][0].abs().max()) > 0
+
+
+def test_fused_pool_stages_equal_the_separate_launches(hip_lib):
+    """t3d_pool_bwd_stage1 / stage2 are the separate K11e launches sharing a grid: bit-identical outputs."""
+    M, K, N, rpf = 2048, 128, 512, 512
+    B, T = M // rpf, M // 128
+    d = _pool_case(M, K, N, rpf, 31)
+    dev = _dev('cuda')
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    t = {k: _mk(dev, v) for k, v in d.items()}
+    act = _act_src(t, K)
+    z = lambda *s: torch.zeros(*s, device=dev)
+    rps, tk, tn = C.c_int(0), C.c_int(0), C.c_int(0)
+    assert hip_lib.t3d_wgrad_plan(M, K, K, C.byref(rps), C.byref(tk), C.byref(tn)) == 0
+    S, nch = M // rps.value, N // 128
+    out = []
+    for fused in (False, True):
+        gsl, part, ps, rcs, wc = z(S, K, K), z(T, K), z(nch, K, K), z(nch, K), z(N, K)
+        ga = abi.PointMlpGramArgs(act, fptr(gsl), M, K, rpf, rps.value)
+        ca = abi.ActColsumArgs(act, M, K, rpf, fptr(part))
+        qa = abi.PoolBwdPrepArgs(fptr(t['w']), fptr(t['bias']), fptr(t['coef']), K, N, fptr(ps), fptr(rcs), fptr(wc))
+        if fused:
+            assert hip_lib.t3d_pool_bwd_stage1(C.byref(ga), C.byref(ca), C.byref(qa), st) == 0
+        else:
+            assert hip_lib.t3d_pointmlp_gram(C.byref(ga), st) == 0
+            assert hip_lib.t3d_act_colsum(C.byref(ca), st) == 0
+            assert hip_lib.t3d_pool_bwd_prep(C.byref(qa), st) == 0
+        torch.cuda.synchronize()
+        G, abar, P, rc = gsl.sum(0), part.sum(0), ps.sum(0), rcs.sum(0)
+        Sm = (torch.randn(M, K, device=dev) * (torch.rand(M, 1, device=dev) < 0.1)).contiguous() if not out else out[0][-1]
+        dw, o, s1, s2 = z(K, N), z(M, K), z(T, K), z(T, K)
+        f = abi.PoolWgradFinishArgs()
+        f.a, f.argidx, f.dpool, f.coef, f.w, f.bias = act, iptr(t['argidx']), fptr(t['dpool']), fptr(t['coef']), fptr(t['w']), fptr(t['bias'])
+        f.g, f.abar, f.B, f.K, f.N, f.rows_per_frustum, f.dw = fptr(G), fptr(abar), B, K, N, rpf, fptr(dw)
+        dg = abi.PointMlpDgradGramArgs()
+        dg.a, dg.p, dg.rowconst, dg.add_in, dg.prev_y, dg.prev_scale, dg.prev_shift = act, fptr(P), fptr(rc), fptr(Sm), fptr(t['x']), fptr(t['sc']), fptr(t['sh'])
+        dg.out, dg.psum_dz, dg.psum_dzy, dg.M, dg.K, dg.rows_per_frustum = fptr(o), fptr(s1), fptr(s2), M, K, rpf
+        if fused:
+            assert hip_lib.t3d_pool_bwd_stage2(C.byref(f), C.byref(dg), st) == 0
+        else:
+            assert hip_lib.t3d_pool_wgrad_finish(C.byref(f), st) == 0
+            assert hip_lib.t3d_pointmlp_dgrad_gram(C.byref(dg), st) == 0
+        torch.cuda.synchronize()
+        out.append((gsl, part, ps, rcs, wc, dw, o, s1, s2, Sm))
+    for a, b, what in zip(out[0], out[1], ('gram', 'abar', 'P', 'rowconst', 'wc', 'dw', 'da', 'psum_dz', 'psum_dzy', 'S')):
+        assert torch.equal(a, b), what
+    assert float(out[1][5].abs().max()) > 0 and float(out[1][6].abs().max()) > 0

@@ -195,6 +195,8 @@ ENTRY_POINTS = {
     't3d_pointmlp_gram': [C.POINTER(PointMlpGramArgs), VP],
     't3d_act_colsum': [C.POINTER(ActColsumArgs), VP],
     't3d_pool_wgrad_finish': [C.POINTER(PoolWgradFinishArgs), VP],
+    't3d_pool_bwd_stage1': [C.POINTER(PointMlpGramArgs), C.POINTER(ActColsumArgs), C.POINTER(PoolBwdPrepArgs), VP],
+    't3d_pool_bwd_stage2': [C.POINTER(PoolWgradFinishArgs), C.POINTER(PointMlpDgradGramArgs), VP],
     't3d_fc_fwd': [C.POINTER(FcFwdArgs), VP],
     't3d_fc_bwd': [C.POINTER(FcBwdArgs), VP],
     't3d_fc_dinput': [C.POINTER(FcDinputArgs), VP],

@@ -12,6 +12,7 @@
 // The MFMA k index of step i of group g on lane half h is 8g+4h+i for both operands, so either
 // format can be paired with either.
 #include "common.h"
+#include "poolbwd_dev.h"
 
 namespace {
 
@@ -661,17 +662,16 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_dgrad(const t3d_poin
 // Gram-form data gradient of a max-pooled layer: out = act(a) . P + rowconst + S  (see t3d.h K11e); the operand
 // side is the forward kernel's (activations type R, the K x K matrix type C), the epilogue is the dgrad one.
 template <int BN>
-__global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_dgrad_gram(const t3d_pointmlp_dgrad_gram_args p) {
+__device__ __forceinline__ void dgrad_gram_body(const t3d_pointmlp_dgrad_gram_args& p, float* smem, int bid, int nblocks) {
   constexpr int BM = 128, TM = 2, TN = BN / 64;
   using LA = ActLoader<false>;
   constexpr int PF = BN == 64 ? T3D_PF_NARROW : T3D_PF_GRAM128;
   using SA = Stager<BM, true, LA, PF>;
   using SB = Stager<BN, false, WLoader, PF>;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int tiles_n = p.K / BN;
-  const int lin = xcd_remap(blockIdx.x, gridDim.x);
+  const int lin = xcd_remap(bid, nblocks);
   const int tile_m = lin / tiles_n, tile_n = lin % tiles_n;
   const int row0 = tile_m * BM, col0 = tile_n * BN;
   LA la{p.a, p.K, p.rows_per_frustum};
@@ -685,6 +685,12 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_dgrad_gram(const t3d
                                                                         tid);
   DgradEpilogue e{p.add_in, p.rowconst, p.prev_y, p.prev_scale, p.prev_shift, p.out, p.psum_dz, p.psum_dzy, p.K};
   dgrad_epilogue<BN, TM, TN>(e, acc, smem, tid, row0, col0, tile_m);
+}
+
+template <int BN>
+__global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_dgrad_gram(const t3d_pointmlp_dgrad_gram_args p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  dgrad_gram_body<BN>(p, smem, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -758,6 +764,40 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_bwd(const t3d_pointm
     wgrad_body<WBMK, WBN>(la, lb, w.slabs, w.K, w.N, w.rows_per_split, smem, blockIdx.x, n_wgrad);
   } else {
     dgrad_body<DBN, false>(d, smem, blockIdx.x - n_wgrad, gridDim.x - n_wgrad);
+  }
+}
+
+// Gram-form backward of a pooled layer, stage 1: the three jobs that need nothing but the layer input and the
+// batch-norm-backward coefficients -- Gram slabs a^T a, column sums of a, and the P / rowconst slabs (+ wc) -- in one launch.
+template <int GT>
+__global__ __launch_bounds__(NT, T3D_WAVES) void k_pool_bwd_stage1(const t3d_pointmlp_gram_args g, const t3d_act_colsum_args c,
+                                                                   const t3d_pool_bwd_prep_args q, const int n_gram,
+                                                                   const int n_colsum) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x;
+  if (b < n_gram) {
+    ActLoader<false> la{g.a, g.K, g.rows_per_frustum};
+    wgrad_body<GT, GT>(la, la, g.slabs, g.K, g.K, g.rows_per_split, smem, b, n_gram);
+  } else if (b < n_gram + n_colsum) {
+    act_colsum_body(c, smem, b - n_gram);
+  } else {
+    const int r = b - n_gram - n_colsum, kb = q.K / 32;
+    pool_bwd_prep_body(q, smem, r % kb, (r / kb) % kb, r / (kb * kb));
+  }
+}
+
+// Stage 2: the weight-gradient assembly and the input-gradient GEMM (both after the slab reduction, independent of each
+// other) in one launch.
+template <int BN>
+__global__ __launch_bounds__(NT, T3D_WAVES) void k_pool_bwd_stage2(const t3d_pool_wgrad_finish_args f,
+                                                                   const t3d_pointmlp_dgrad_gram_args d, const int n_finish) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x;
+  if (b < n_finish) {
+    const int kb = f.K / FK;
+    pool_wgrad_finish_body(f, smem, b % kb, b / kb);
+  } else {
+    dgrad_gram_body<BN>(d, smem, b - n_finish, gridDim.x - n_finish);
   }
 }
 
@@ -908,16 +948,25 @@ extern "C" int t3d_pointmlp_wgrad(const t3d_pointmlp_wgrad_args* a, t3d_stream_t
   return T3D_OK;
 }
 
-extern "C" int t3d_pointmlp_dgrad_gram(const t3d_pointmlp_dgrad_gram_args* a, t3d_stream_t stream) {
+static int check_dgrad_gram(const t3d_pointmlp_dgrad_gram_args* a) {
   if (!a || !a->p || !a->out || !act_ok(a->a, a->K) || a->a.sub) return T3D_ERR_ARG;
   if (a->prev_y && (!a->prev_scale || !a->prev_shift)) return T3D_ERR_ARG;
   if (a->psum_dz && (!a->psum_dzy || !a->prev_y)) return T3D_ERR_ARG;
   if (a->M <= 0 || a->M % T3D_TILE_ROWS || a->rows_per_frustum % T3D_TILE_ROWS || a->M % a->rows_per_frustum ||
       a->K % 64 || (long)a->M * a->K >= (1L << 30))
     return T3D_ERR_SHAPE;
+  return T3D_OK;
+}
+static bool dgrad_gram_wide(const t3d_pointmlp_dgrad_gram_args* a) {
+  return a->K % 128 == 0 && (long)(a->M / 128) * (a->K / 128) >= 512;
+}
+
+extern "C" int t3d_pointmlp_dgrad_gram(const t3d_pointmlp_dgrad_gram_args* a, t3d_stream_t stream) {
+  const int rc = check_dgrad_gram(a);
+  if (rc != T3D_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int tiles_m = a->M / 128;
-  if (a->K % 128 == 0 && (long)tiles_m * (a->K / 128) >= 512)
+  if (dgrad_gram_wide(a))
     launch_lds(k_pointmlp_dgrad_gram<128>, dim3(tiles_m * (a->K / 128)), lds_fwd(128), s, *a);
   else
     launch_lds(k_pointmlp_dgrad_gram<64>, dim3(tiles_m * (a->K / 64)), lds_fwd(64), s, *a);
@@ -925,17 +974,26 @@ extern "C" int t3d_pointmlp_dgrad_gram(const t3d_pointmlp_dgrad_gram_args* a, t3
   return T3D_OK;
 }
 
-extern "C" int t3d_pointmlp_gram(const t3d_pointmlp_gram_args* a, t3d_stream_t stream) {
+static int check_gram(const t3d_pointmlp_gram_args* a) {
   if (!a || !a->slabs || !act_ok(a->a, a->K) || a->a.sub) return T3D_ERR_ARG;
   if (a->M <= 0 || a->rows_per_split <= 0 || a->rows_per_split % BK || a->M % a->rows_per_split || a->K % 64 ||
       a->rows_per_frustum % BK || a->M % a->rows_per_frustum)
     return T3D_ERR_SHAPE;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  const int splits = a->M / a->rows_per_split;
+  return T3D_OK;
+}
+static int gram_tile(const t3d_pointmlp_gram_args* a) {      // square tiles only: two instantiations
   int rps = 0, tk = 0, tn = 0;
   if (!(a->M % 128 == 0 && t3d_wgrad_plan(a->M, a->K, a->K, &rps, &tk, &tn) == T3D_OK && rps == a->rows_per_split))
     tk = tn = (a->K % 128 == 0 ? 128 : 64);
-  if (tk != tn) tk = tn = 64;               // square tiles only: two instantiations
+  return (tk == 128 && tn == 128) ? 128 : 64;
+}
+
+extern "C" int t3d_pointmlp_gram(const t3d_pointmlp_gram_args* a, t3d_stream_t stream) {
+  const int rc = check_gram(a);
+  if (rc != T3D_OK) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int splits = a->M / a->rows_per_split;
+  const int tk = gram_tile(a), tn = tk;
   const dim3 grid((a->K / tk) * (a->K / tn) * splits);
   if (tk == 128) launch_lds(k_pointmlp_gram<128, 128>, grid, lds_wgrad(128, 128), s, *a);
   else launch_lds(k_pointmlp_gram<64, 64>, grid, lds_wgrad(64, 64), s, *a);
@@ -978,6 +1036,60 @@ extern "C" int t3d_pointmlp_bwd(const t3d_pointmlp_dgrad_args* d, const t3d_poin
   else T3D_BWD_W(64);
 #undef T3D_BWD_W
 #undef T3D_BWD
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_pool_bwd_stage1(const t3d_pointmlp_gram_args* g, const t3d_act_colsum_args* c,
+                                   const t3d_pool_bwd_prep_args* q, t3d_stream_t stream) {
+  int rc = check_gram(g);
+  if (rc != T3D_OK) return rc;
+  if ((rc = check_colsum(c)) != T3D_OK) return rc;
+  if ((rc = check_prep(q)) != T3D_OK) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int gt = gram_tile(g);
+  const int n_gram = (g->K / gt) * (g->K / gt) * (g->M / g->rows_per_split);
+  const int n_colsum = c->M / 128;
+  const int n_prep = (q->K / 32) * (q->K / 32) * ((q->N + PCH - 1) / PCH);
+  const dim3 grid(n_gram + n_colsum + n_prep);
+  size_t lds = lds_wgrad(gt, gt);
+  if (PREP_LDS > lds) lds = PREP_LDS;
+  if (COLSUM_LDS > lds) lds = COLSUM_LDS;
+  if (gt == 128) {
+    auto kern = k_pool_bwd_stage1<128>;
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    T3D_LAUNCH(kern, grid, dim3(NT), lds, s, *g, *c, *q, n_gram, n_colsum);
+  } else {
+    T3D_LAUNCH(k_pool_bwd_stage1<64>, grid, dim3(NT), lds, s, *g, *c, *q, n_gram, n_colsum);
+  }
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_pool_bwd_stage2(const t3d_pool_wgrad_finish_args* f, const t3d_pointmlp_dgrad_gram_args* d,
+                                   t3d_stream_t stream) {
+  int rc = check_finish(f);
+  if (rc != T3D_OK) return rc;
+  if ((rc = check_dgrad_gram(d)) != T3D_OK) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int n_finish = (f->K / FK) * (f->N / FN);
+  const bool wide = dgrad_gram_wide(d);
+  const int n_d = (d->M / 128) * (d->K / (wide ? 128 : 64));
+  const dim3 grid(n_finish + n_d);
+  size_t lds = wide ? lds_fwd(128) : lds_fwd(64);
+  if (finish_lds(f->K) > lds) lds = finish_lds(f->K);
+  if (wide) {
+    auto kern = k_pool_bwd_stage2<128>;
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    T3D_LAUNCH(kern, grid, dim3(NT), lds, s, *f, *d, n_finish);
+  } else {
+    auto kern = k_pool_bwd_stage2<64>;
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    T3D_LAUNCH(kern, grid, dim3(NT), lds, s, *f, *d, n_finish);
+  }
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

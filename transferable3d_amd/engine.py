@@ -490,6 +490,48 @@ class PointLayer:
         a.M, a.K, a.rows_per_frustum = self.M, K, g.rpf
         plan.add('t3d_pointmlp_dgrad_gram', a)
 
+    def _bwd_pair_gram(self, plan):
+        """Both gradients of a pooled layer in five launches: stage 1 (Gram slabs + column sums + P/rowconst slabs),
+        one slab reduction, the sparse argmax rows, stage 2 (dW assembly + input-gradient GEMM)."""
+        g, rt, K, N = self.g, self.g.rt, self.K, self.N
+        lib = rt.lib
+        prev = self.src.producer
+        assert prev is not None and not prev.pool
+        prev._ensure_bwd_buffers()
+        rps = wgrad_rows_per_split(lib, self.M, K, K)
+        nch = (N + 127) // 128
+        sl, red, emit_reduce = self._gram_reduce(plan, [('G', K * K, self.M // rps), ('abar', K, self.T), ('P', K * K, nch),
+                                                        ('rowconst', K, nch)])
+        ga = abi.PointMlpGramArgs()
+        ga.a, ga.slabs = self.src.struct(), fptr(sl['G'])
+        ga.M, ga.K, ga.rows_per_frustum, ga.rows_per_split = self.M, K, g.rpf, rps
+        ca = abi.ActColsumArgs()
+        ca.a, ca.M, ca.K, ca.rows_per_frustum, ca.part = self.src.struct(), self.M, K, g.rpf, fptr(sl['abar'])
+        qa = abi.PoolBwdPrepArgs(fptr(self.w), fptr(self.bias), fptr(self.coef), K, N, fptr(sl['P']), fptr(sl['rowconst']),
+                                 fptr(self.wc))
+        fn1, r1 = lib.t3d_pool_bwd_stage1, (C.byref(ga), C.byref(ca), C.byref(qa))
+        plan.keep.extend([ga, ca, qa, sl, red])
+        plan.calls.append(('t3d_pool_bwd_stage1', lambda s: fn1(r1[0], r1[1], r1[2], s), (ga, ca, qa)))
+        plan.lanes.append(0)
+        emit_reduce()
+        r = abi.PoolSparseRowsArgs(iptr(self.argidx), fptr(self.dpool), fptr(self.wc), g.B, N, K, g.rpf, fptr(self.S))
+        plan.add('t3d_pool_sparse_rows', r)
+        f = abi.PoolWgradFinishArgs()
+        f.a, f.argidx, f.dpool, f.coef = self.src.struct(), iptr(self.argidx), fptr(self.dpool), fptr(self.coef)
+        f.w, f.bias, f.g, f.abar = fptr(self.w), fptr(self.bias), fptr(red['G']), fptr(red['abar'])
+        f.B, f.K, f.N, f.rows_per_frustum = g.B, K, N, g.rpf
+        goff = g.vars.offset(self.w_name) + self.w_row0 * N
+        f.dw = fptr(g.vars.grads[goff:goff + K * N])
+        d = abi.PointMlpDgradGramArgs()
+        d.a, d.p, d.rowconst, d.add_in = self.src.struct(), fptr(red['P']), fptr(red['rowconst']), fptr(self.S)
+        d.prev_y, d.prev_scale, d.prev_shift = fptr(prev.y), fptr(prev.scale), fptr(prev.shift)
+        d.out, d.psum_dz, d.psum_dzy = fptr(prev.dz), fptr(prev.psum_dz), fptr(prev.psum_dzy)
+        d.M, d.K, d.rows_per_frustum = self.M, K, g.rpf
+        fn2, r2 = lib.t3d_pool_bwd_stage2, (C.byref(f), C.byref(d))
+        plan.keep.extend([f, d])
+        plan.calls.append(('t3d_pool_bwd_stage2', lambda s: fn2(r2[0], r2[1], s), (f, d)))
+        plan.lanes.append(0)
+
     def _emit_prep(self, plan, sl):
         q = abi.PoolBwdPrepArgs(fptr(self.w), fptr(self.bias), fptr(self.coef), self.K, self.N, fptr(sl['P']),
                                 fptr(sl['rowconst']), fptr(self.wc))
@@ -541,6 +583,9 @@ class PointLayer:
 
     def bwd_pair(self, plan, out_raw=None, add_in=None):
         """Weight gradient + input gradient.  Dense layers: ONE launch (t3d_pointmlp_bwd); pooled layers: the Gram path."""
+        if self.gram and FUSE_BWD and not SIDE_STREAM:
+            assert out_raw is None and add_in is None
+            return self._bwd_pair_gram(plan)
         if self.gram or self.pool or not FUSE_BWD:
             self.wgrad(plan)
             return self.dgrad(plan, out_raw=out_raw, add_in=add_in)

@@ -177,8 +177,7 @@ class InstSegNet:
         self.da3_part = g.rt.zeros(g.M, 64)
         L.L6.bwd_pair(plan, out_raw=self.da3_part)
         L.L5.bn_bwd(plan, dpool_in=dg5, ld_dpool_in=1024)
-        L.L5.wgrad(plan)
-        L.L5.dgrad(plan)
+        L.L5.bwd_pair(plan)
         L.L4.bn_bwd(plan)
         L.L4.bwd_pair(plan, add_in=self.da3_part)
         for lay in (L.L3, L.L2):
@@ -218,8 +217,7 @@ class TNet:
         self.F1.bwd(plan, nxt=self.F2)
         dft = self.F1.dinput(plan, K=256)
         self.T3.bn_bwd(plan, dpool_in=dft, ld_dpool_in=256)
-        self.T3.wgrad(plan)
-        self.T3.dgrad(plan)
+        self.T3.bwd_pair(plan)
         self.T2.bn_bwd(plan)
         self.T2.bwd_pair(plan)
         self.T1.bn_bwd(plan)
@@ -257,8 +255,7 @@ class BoxEstNet:
     def bwd_convs(self, plan, dfeats, ld, dstage1_in):
         """Backward of the per-point stack given d(feats_lv1); returns the total d(stage1_center)."""
         self.B4.bn_bwd(plan, dpool_in=dfeats, ld_dpool_in=ld)
-        self.B4.wgrad(plan)
-        self.B4.dgrad(plan)
+        self.B4.bwd_pair(plan)
         for lay in (self.B3, self.B2):
             lay.bn_bwd(plan)
             lay.bwd_pair(plan)
@@ -442,8 +439,9 @@ class BoxPCNet:
         dfeat = self.F1.dinput(plan, K=512)
         self.P4.bn_bwd(plan, dpool_in=dfeat, ld_dpool_in=512, param_grads=param_grads)
         if param_grads:
-            self.P4.wgrad(plan)
-        self.P4.dgrad(plan)
+            self.P4.bwd_pair(plan)
+        else:
+            self.P4.dgrad(plan)
         for lay in (self.P3, self.P2):
             lay.bn_bwd(plan, param_grads=param_grads)
             if param_grads:
