@@ -10,25 +10,33 @@ namespace {
 // loop of the first version was pure L2 latency: 19 us per launch in profiles/r01_baseline).
 constexpr int FC_CH = 16, FC_GR = 16;
 
+// Sixteen tiles per quantity are in flight per thread (32 loads for the two-quantity reductions): at 256 tiles the whole
+// reduction is ONE memory round trip instead of four.
 template <int NQ>
 __device__ __forceinline__ void tile_sums(const float* const (&src)[NQ], int n_tiles, int N, int c, int grp, bool ok,
                                           double (&acc)[NQ]) {
+  constexpr int U = 16;
 #pragma unroll
   for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
   if (!ok) return;
-  int t = grp;
-  for (; t + 3 * FC_GR < n_tiles; t += 4 * FC_GR) {
-    float v[NQ][4];
+  for (int t0 = grp; t0 < n_tiles; t0 += U * FC_GR) {
+    float v[NQ][U];
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[q][u] = src[q][(size_t)(t + u * FC_GR) * N + c];
+      for (int u = 0; u < U; ++u) {
+        const int t = t0 + u * FC_GR;
+        const float x = src[q][(size_t)min(t, n_tiles - 1) * N + c];     // clamped: no branch around the load
+        v[q][u] = t < n_tiles ? x : 0.f;
+      }
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) acc[q] += ((double)v[q][0] + (double)v[q][1]) + ((double)v[q][2] + (double)v[q][3]);
+    for (int q = 0; q < NQ; ++q) {
+      double a = 0.0;
+#pragma unroll
+      for (int u = 0; u < U; u += 4) a += ((double)v[q][u] + (double)v[q][u + 1]) + ((double)v[q][u + 2] + (double)v[q][u + 3]);
+      acc[q] += a;
+    }
   }
-  for (; t < n_tiles; t += FC_GR)
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) acc[q] += (double)src[q][(size_t)t * N + c];
 }
 
 __device__ __forceinline__ double group_reduce(double v, double (*red)[FC_CH], int grp, int cl) {
@@ -47,6 +55,9 @@ __global__ __launch_bounds__(256) void k_bn_fwd_finalize(const t3d_bn_fwd_finali
   const int c = blockIdx.x * FC_CH + cl;
   const bool ok = c < p.N;
   if (p.is_training) {
+    // parameters first: their latency hides under the tile reduction instead of following it
+    const int cc = ok ? c : 0;
+    const float gam = p.gamma[cc], bet = p.beta[cc], mm = p.moving_mean[cc], mv = p.moving_var[cc], dec = p.decay[0];
     const float* const src[2] = {p.psum, p.psumsq};
     double acc[2];
     tile_sums<2>(src, p.n_tiles, p.N, c, grp, ok, acc);
@@ -58,15 +69,15 @@ __global__ __launch_bounds__(256) void k_bn_fwd_finalize(const t3d_bn_fwd_finali
       double var = ss / n - mean * mean;
       if (var < 0.0) var = 0.0;
       const double invstd = 1.0 / sqrt(var + (double)p.eps);
-      const double sc = (double)p.gamma[c] * invstd;
+      const double sc = (double)gam * invstd;
       p.scale[c] = (float)sc;
-      p.shift[c] = (float)((double)p.beta[c] - mean * sc);
+      p.shift[c] = (float)((double)bet - mean * sc);
       p.mean[c] = (float)mean;
       p.invstd[c] = (float)invstd;
-      const double d = (double)p.decay[0];
+      const double d = (double)dec;
       const double var_ema = p.unbiased_ema ? var * (n / (n > 1.0 ? n - 1.0 : 1.0)) : var;
-      p.moving_mean[c] = (float)((double)p.moving_mean[c] * d + mean * (1.0 - d));
-      p.moving_var[c] = (float)((double)p.moving_var[c] * d + var_ema * (1.0 - d));
+      p.moving_mean[c] = (float)((double)mm * d + mean * (1.0 - d));
+      p.moving_var[c] = (float)((double)mv * d + var_ema * (1.0 - d));
     }
   } else if (grp == 0 && ok) {
     const double invstd = 1.0 / sqrt((double)p.moving_var[c] + (double)p.eps);
@@ -112,6 +123,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const t3d_bn_bwd_finali
   const int cl = threadIdx.x & (FC_CH - 1), grp = threadIdx.x / FC_CH;
   const int c = blockIdx.x * FC_CH + cl;
   const bool ok = c < p.N;
+  const int cc = ok ? c : 0;
+  const float mean_f = p.mean[cc], invstd_f = p.invstd[cc], gamma_f = p.gamma[cc];   // ahead of the reduction
   double acc[2] = {0.0, 0.0};   // sum dz, sum dz*y
   if (p.psum_dz != nullptr) {
     const float* const src[2] = {p.psum_dz, p.psum_dzy};
@@ -134,7 +147,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const t3d_bn_bwd_finali
       p.coef[2 * p.N + c] = 0.f;
       return;
     }
-    const double mean = p.mean[c], invstd = p.invstd[c], gamma = p.gamma[c], n = p.count;
+    const double mean = mean_f, invstd = invstd_f, gamma = gamma_f, n = p.count;
     const double dbeta = s1;
     const double dgamma = invstd * (s2 - mean * s1);       // sum dz * xhat
     if (p.dbeta) p.dbeta[c] = (float)dbeta;

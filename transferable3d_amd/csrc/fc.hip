@@ -18,7 +18,6 @@ constexpr int MAXRB = 4;     // B <= 128
 constexpr int NW = 8;        // waves per workgroup (the reduction dimension is split over them)
 constexpr int NTH = NW * 64;
 constexpr int RG = NTH / 32; // row groups of the epilogue thread map
-constexpr int NVAL = MAXRB * 32 / RG;
 constexpr int LDT = 33;      // padded row stride of the LDS tiles
 
 struct RowSrc {              // [in | in2] row-concatenated input, B valid rows
@@ -29,6 +28,15 @@ struct RowSrc {              // [in | in2] row-concatenated input, B valid rows
     if (k < K) return in[(size_t)r * ld_in + k];
     if (k < K + K2) return in2[(size_t)r * ld_in2 + (k - K)];
     return 0.f;
+  }
+  // branch-free: clamped address, value masked afterwards (a load never sits behind a per-lane branch)
+  __device__ __forceinline__ float at_nb(int r, int k) const {
+    const bool first = k < K, valid = r < B && k < K + K2;
+    const int rc = min(r, B - 1);
+    const float* base = (first || in2 == nullptr) ? in : in2;
+    const size_t off = (first || in2 == nullptr) ? (size_t)rc * ld_in + min(k, K - 1) : (size_t)rc * ld_in2 + min(k - K, K2 - 1);
+    const float v = base[off];
+    return valid ? v : 0.f;
   }
   // 4 consecutive reduction elements of one row
   __device__ __forceinline__ void load4(int r, int k, float (&v)[4]) const {
@@ -46,69 +54,65 @@ struct RowSrc {              // [in | in2] row-concatenated input, B valid rows
 // acc[rb] (32x32 tiles, rows rb*32.., cols c0..c0+31) += sum over this wave's k groups of A[row,k] * W(k,col)
 //   WT == false: W(k,col) = w[k*ldw + c0+col]   (forward: weights [K,N])
 //   WT == true : W(k,col) = w[(c0+col)*ldw + k] (input gradient: dy . W^T)
-template <bool WT>
-__device__ __forceinline__ void wave_gemm(f32x16 (&acc)[MAXRB], const RowSrc& src, int RB, const float* __restrict__ w, int ldw,
+// RBT = compile-time number of 32-row blocks (1 for B <= 32: the shapes of the hot path; MAXRB otherwise).  GIF k-groups
+// are loaded before the first MFMA of a batch: these layers are pure latency (operands tiny, read once per step from
+// HBM/L2), so memory-level parallelism per wave is what matters -- with RBT = 1 a wave has its whole share of a
+// K <= 1024 reduction in flight at once.
+template <bool WT, int RBT>
+__device__ __forceinline__ void wave_gemm(f32x16 (&acc)[RBT], const RowSrc& src, const float* __restrict__ w, int ldw,
                                           int Kred, int c0, int ncols, int wave, int lane) {
+  constexpr int GIF = RBT == 1 ? 16 : 4;
   const int l31 = lane & 31, h = lane >> 5;
 #pragma unroll
-  for (int rb = 0; rb < MAXRB; ++rb)
+  for (int rb = 0; rb < RBT; ++rb)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
   const int ngroups = (Kred + 7) >> 3;
   const bool cok = l31 < ncols;
-  auto load_group = [&](int g, float (&a)[MAXRB][4], float (&b)[4]) {
-    const int k = 8 * g + 4 * h;
+  for (int g0 = wave; g0 < ngroups; g0 += GIF * NW) {
+    float a[GIF][RBT][4], b[GIF][4];
 #pragma unroll
-    for (int rb = 0; rb < MAXRB; ++rb)
-      if (rb < RB) src.load4(rb * 32 + l31, k, a[rb]);
-    if (!WT) {
+    for (int u = 0; u < GIF; ++u) {
+      const int g = g0 + u * NW;
+      const int k = 8 * g + 4 * h;
+      if (g < ngroups) {                      // wave-uniform: groups past the end issue nothing
 #pragma unroll
-      for (int i = 0; i < 4; ++i) b[i] = (cok && k + i < Kred) ? w[(size_t)(k + i) * ldw + c0 + l31] : 0.f;
-    } else {
-      if (cok && k + 3 < Kred && (ldw & 3) == 0) {
-        const float4 t = *reinterpret_cast<const float4*>(w + (size_t)(c0 + l31) * ldw + k);
-        b[0] = t.x; b[1] = t.y; b[2] = t.z; b[3] = t.w;
-      } else {
+        for (int rb = 0; rb < RBT; ++rb) src.load4(rb * 32 + l31, k, a[u][rb]);
+        if (!WT) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) b[i] = (cok && k + i < Kred) ? w[(size_t)(c0 + l31) * ldw + k + i] : 0.f;
+          for (int i = 0; i < 4; ++i) b[u][i] = (cok && k + i < Kred) ? w[(size_t)(k + i) * ldw + c0 + l31] : 0.f;
+        } else {
+          if (cok && k + 3 < Kred && (ldw & 3) == 0) {
+            const float4 t = *reinterpret_cast<const float4*>(w + (size_t)(c0 + l31) * ldw + k);
+            b[u][0] = t.x; b[u][1] = t.y; b[u][2] = t.z; b[u][3] = t.w;
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) b[u][i] = (cok && k + i < Kred) ? w[(size_t)(c0 + l31) * ldw + k + i] : 0.f;
+          }
+        }
       }
     }
-  };
-  auto mma_group = [&](const float (&a)[MAXRB][4], const float (&b)[4]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int u = 0; u < GIF; ++u) {
+      if (g0 + u * NW < ngroups) {
 #pragma unroll
-      for (int rb = 0; rb < MAXRB; ++rb)
-        if (rb < RB) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rb][i], b[i], acc[rb], 0, 0, 0);
-  };
-  // four k-groups per iteration: all their loads are in flight before the first MFMA (these layers are pure
-  // latency: the operands are tiny and L2 resident, so memory-level parallelism per wave is what matters)
-  int g = wave;
-  for (; g + 3 * NW < ngroups; g += 4 * NW) {
-    float a0[MAXRB][4], b0[4], a1[MAXRB][4], b1[4], a2[MAXRB][4], b2[4], a3[MAXRB][4], b3[4];
-    load_group(g, a0, b0);
-    load_group(g + NW, a1, b1);
-    load_group(g + 2 * NW, a2, b2);
-    load_group(g + 3 * NW, a3, b3);
-    mma_group(a0, b0);
-    mma_group(a1, b1);
-    mma_group(a2, b2);
-    mma_group(a3, b3);
-  }
-  for (; g < ngroups; g += NW) {
-    float a0[MAXRB][4], b0[4];
-    load_group(g, a0, b0);
-    mma_group(a0, b0);
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int rb = 0; rb < RBT; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][rb][i], b[u][i], acc[rb], 0, 0, 0);
+      }
+    }
   }
 }
 
 // Sum the NW waves' tiles through LDS.  Afterwards thread t owns column (t & 31) and rows (t >> 5) + RG*j.
-__device__ __forceinline__ void reduce_tiles(const f32x16 (&acc)[MAXRB], int RB, float* red, float (&val)[NVAL]) {
+template <int RBT>
+__device__ __forceinline__ void reduce_tiles(const f32x16 (&acc)[RBT], float* red, float (&val)[RBT * 32 / RG]) {
+  constexpr int RB = RBT, NVAL = RBT * 32 / RG;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int rows = RB * 32;
 #pragma unroll
-  for (int rb = 0; rb < MAXRB; ++rb)
-    if (rb < RB) {
+  for (int rb = 0; rb < RBT; ++rb)
+    {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -159,20 +163,21 @@ __device__ __forceinline__ float act_bwd(float z, int act, float alpha) {
   }
 }
 
+template <int RBT>
 __global__ __launch_bounds__(NTH) void k_fc_fwd(const t3d_fc_fwd_args p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int RB = (p.B + 31) / 32;
+  constexpr int RB = RBT, NVAL = RBT * 32 / RG;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = tid & 31, rg = tid >> 5;
   const int c0 = blockIdx.x * CB, c = c0 + col;
   const int nvalid = min(CB, p.N - c0);
   const bool cok = c < p.N;
 
-  f32x16 acc[MAXRB];
+  f32x16 acc[RBT];
   RowSrc src{p.in, p.ld_in, p.K, p.in2, p.ld_in2, p.K2, p.B};
-  wave_gemm<false>(acc, src, RB, p.w, p.N, p.K + p.K2, c0, nvalid, wave, lane);
+  wave_gemm<false, RBT>(acc, src, p.w, p.N, p.K + p.K2, c0, nvalid, wave, lane);
   float y[NVAL];
-  reduce_tiles(acc, RB, sm, y);
+  reduce_tiles<RBT>(acc, sm, y);
 
   const float bias = (cok && p.bias) ? p.bias[c] : 0.f;
   float part = 0.f;
@@ -222,14 +227,29 @@ __global__ __launch_bounds__(NTH) void k_fc_fwd(const t3d_fc_fwd_args p) {
   }
 }
 
+template <int RBT>
 __global__ __launch_bounds__(NTH) void k_fc_bwd(const t3d_fc_bwd_args p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int RB = (p.B + 31) / 32;
+  constexpr int RB = RBT, NVAL = RBT * 32 / RG;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = tid & 31, rg = tid >> 5;
   const int c0 = blockIdx.x * CB, c = c0 + col;
   const int nvalid = min(CB, p.N - c0);
   const bool cok = c < p.N;
+
+  // the dW phase's input operand does not depend on anything computed here: request it first, it lands under (a)-(c)
+  constexpr int XKB = RBT == 1 ? 4 : 0;                  // 32-channel blocks per wave held in registers
+  float xa[XKB > 0 ? XKB : 1][16];
+  const int Kt = p.K + p.K2, nkb = (Kt + 31) / 32;
+  if (XKB > 0 && p.dw != nullptr) {
+    RowSrc xs{p.in, p.ld_in, p.K, p.in2, p.ld_in2, p.K2, p.B};
+#pragma unroll
+    for (int j = 0; j < XKB; ++j) {
+      const int k = (wave + NW * j) * 32 + (lane & 31);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) xa[j][e] = xs.at_nb(8 * (e >> 2) + 4 * (lane >> 5) + (e & 3), k);   // k >= Kt reads as 0
+    }
+  }
 
   // (a) gradient w.r.t. this layer's output: given, or dy_next . w_next^T on the fly
   float gout[NVAL];
@@ -240,10 +260,10 @@ __global__ __launch_bounds__(NTH) void k_fc_bwd(const t3d_fc_bwd_args p) {
       gout[j] = (r < p.B && cok) ? p.dout[(size_t)r * p.ld_dout + c] : 0.f;
     }
   } else {
-    f32x16 acc[MAXRB];
+    f32x16 acc[RBT];
     RowSrc src{p.dy_next, p.N_next, p.N_next, nullptr, 0, 0, p.B};
-    wave_gemm<true>(acc, src, RB, p.w_next, p.N_next, p.N_next, c0, nvalid, wave, lane);
-    reduce_tiles(acc, RB, sm, gout);
+    wave_gemm<true, RBT>(acc, src, p.w_next, p.N_next, p.N_next, c0, nvalid, wave, lane);
+    reduce_tiles<RBT>(acc, sm, gout);
   }
 
   // (b) dropout / activation backward, (c) batch-norm backward over the B rows
@@ -307,10 +327,30 @@ __global__ __launch_bounds__(NTH) void k_fc_bwd(const t3d_fc_bwd_args p) {
 
   // (d) dW[k, c] = sum_r in[r,k] * dy[r,c]: one 32x32 MFMA tile per 32 input channels, reduction over rows
   RowSrc src{p.in, p.ld_in, p.K, p.in2, p.ld_in2, p.K2, p.B};
-  const int Kt = p.K + p.K2;
   const int l31 = lane & 31, h = lane >> 5;
-  const int nkb = (Kt + 31) / 32;
-  for (int kb = wave; kb < nkb; kb += NW) {
+  auto store_block = [&](int kb, const f32x16& acc) {
+    if (l31 < nvalid) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kk = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (kk < Kt) p.dw[(size_t)kk * p.N + c0 + l31] = acc[r];
+      }
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < XKB; ++j) {                        // blocks whose operand was prefetched at kernel start
+    const int kb = wave + NW * j;
+    if (kb < nkb) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[j][e], dy_s[(8 * (e >> 2) + 4 * h + (e & 3)) * LDT + l31], acc, 0, 0, 0);
+      store_block(kb, acc);
+    }
+  }
+  for (int kb = wave + NW * XKB; kb < nkb; kb += NW) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -320,34 +360,29 @@ __global__ __launch_bounds__(NTH) void k_fc_bwd(const t3d_fc_bwd_args p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int rr = 8 * g8 + 4 * h + i;
-        a[i] = (rr < p.B && k < Kt) ? src.at(rr, k) : 0.f;
+        a[i] = src.at_nb(rr, k);
         b[i] = dy_s[rr * LDT + l31];
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc, 0, 0, 0);
     }
-    if (l31 < nvalid) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kk = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (kk < Kt) p.dw[(size_t)kk * p.N + c0 + l31] = acc[r];
-      }
-    }
+    store_block(kb, acc);
   }
 }
 
+template <int RBT>
 __global__ __launch_bounds__(NTH) void k_fc_dinput(const t3d_fc_dinput_args p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int RB = (p.B + 31) / 32;
+  constexpr int RB = RBT, NVAL = RBT * 32 / RG;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = tid & 31, rg = tid >> 5;
   const int c0 = blockIdx.x * CB, c = c0 + col;
   const int nvalid = min(CB, p.K - c0);
-  f32x16 acc[MAXRB];
+  f32x16 acc[RBT];
   RowSrc src{p.dy, p.N, p.N, nullptr, 0, 0, p.B};
-  wave_gemm<true>(acc, src, RB, p.w, p.N, p.N, c0, nvalid, wave, lane);
+  wave_gemm<true, RBT>(acc, src, p.w, p.N, p.N, c0, nvalid, wave, lane);
   float v[NVAL];
-  reduce_tiles(acc, RB, sm, v);
+  reduce_tiles<RBT>(acc, sm, v);
   if (c >= p.K) return;
 #pragma unroll
   for (int j = 0; j < NVAL; ++j) {
@@ -372,7 +407,8 @@ extern "C" int t3d_fc_fwd(const t3d_fc_fwd_args* a, t3d_stream_t stream) {
   if (a->gamma && (!a->beta || !a->moving_mean || !a->moving_var || !a->mean || !a->invstd || !a->y)) return T3D_ERR_ARG;
   if (a->gamma && a->is_training && !a->decay) return T3D_ERR_ARG;
   if (a->B <= 0 || a->B > 32 * MAXRB || a->N <= 0 || a->K <= 0) return T3D_ERR_SHAPE;
-  T3D_LAUNCH(k_fc_fwd, dim3((a->N + CB - 1) / CB), dim3(NTH), fc_lds_bytes(a->B), static_cast<hipStream_t>(stream), *a);
+  if (a->B <= 32) T3D_LAUNCH(k_fc_fwd<1>, dim3((a->N + CB - 1) / CB), dim3(NTH), fc_lds_bytes(32), static_cast<hipStream_t>(stream), *a);
+  else T3D_LAUNCH(k_fc_fwd<MAXRB>, dim3((a->N + CB - 1) / CB), dim3(NTH), fc_lds_bytes(128), static_cast<hipStream_t>(stream), *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -383,7 +419,8 @@ extern "C" int t3d_fc_bwd(const t3d_fc_bwd_args* a, t3d_stream_t stream) {
   if (a->gamma && (!a->beta || !a->mean || !a->invstd || !a->y)) return T3D_ERR_ARG;
   if (a->act != T3D_ACT_NONE && !a->y) return T3D_ERR_ARG;
   if (a->B <= 0 || a->B > 32 * MAXRB || a->N <= 0) return T3D_ERR_SHAPE;
-  T3D_LAUNCH(k_fc_bwd, dim3((a->N + CB - 1) / CB), dim3(NTH), fc_lds_bytes(a->B), static_cast<hipStream_t>(stream), *a);
+  if (a->B <= 32) T3D_LAUNCH(k_fc_bwd<1>, dim3((a->N + CB - 1) / CB), dim3(NTH), fc_lds_bytes(32), static_cast<hipStream_t>(stream), *a);
+  else T3D_LAUNCH(k_fc_bwd<MAXRB>, dim3((a->N + CB - 1) / CB), dim3(NTH), fc_lds_bytes(128), static_cast<hipStream_t>(stream), *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -391,7 +428,8 @@ extern "C" int t3d_fc_bwd(const t3d_fc_bwd_args* a, t3d_stream_t stream) {
 extern "C" int t3d_fc_dinput(const t3d_fc_dinput_args* a, t3d_stream_t stream) {
   if (!a || !a->dy || !a->w || !a->din) return T3D_ERR_ARG;
   if (a->B <= 0 || a->B > 32 * MAXRB || a->N <= 0 || a->K <= 0) return T3D_ERR_SHAPE;
-  T3D_LAUNCH(k_fc_dinput, dim3((a->K + CB - 1) / CB), dim3(NTH), fc_lds_bytes(a->B), static_cast<hipStream_t>(stream), *a);
+  if (a->B <= 32) T3D_LAUNCH(k_fc_dinput<1>, dim3((a->K + CB - 1) / CB), dim3(NTH), fc_lds_bytes(32), static_cast<hipStream_t>(stream), *a);
+  else T3D_LAUNCH(k_fc_dinput<MAXRB>, dim3((a->K + CB - 1) / CB), dim3(NTH), fc_lds_bytes(128), static_cast<hipStream_t>(stream), *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
