@@ -23,14 +23,14 @@ def load_golden(name):
     return batch, P, z
 
 
-def run_model_a(rt, batch, P, c, bn_decay=0.5, train=True):
+def run_model_a(rt, batch, P, c, bn_decay=0.5, train=True, is_training=True):
     """One fwd(+bwd) of the product plan; returns (graph, model)."""
     B, N, C = batch['pc'].shape
     g = Graph(B, N, C, rt=rt)
     m = SemiModelA(g, c)
     g.vars.load_state_dict({k: v.detach().cpu().numpy() for k, v in P.items()})
     g.hyper[2] = bn_decay
-    m.emit_forward(g.fwd, True, True)
+    m.emit_forward(g.fwd, is_training, True)
     if train:
         m.emit_backward(g.bwd)
     g.finalize()
@@ -94,3 +94,32 @@ def check_against_oracle(g, m, batch, P, c, fwd_atol=1e-4, grad_median_tol=1e-4)
         mine = g.vars.get(k).detach().cpu().numpy()
         assert np.abs(mine - v.detach().numpy()).max() < 1e-4 * max(1.0, float(v.abs().max())), k
     return dict(fwd=out, grad_median=med, grad_global=glob, loss=(lmine, lref))
+
+
+def check_config0_single_frustum_forward(rt, seed=5):
+    """BASELINE.json configs[0]: SEMI_MODEL A forward on ONE synthetic frustum (N=1024, C=4), inference-mode batch-norm
+    (moving statistics; a training-mode FC batch-norm over one row is degenerate).  Outputs within 1e-4 of the oracle."""
+    import numpy as np
+    from oracle import ref_torch as R
+    from transferable3d_amd.synthetic import make_batch
+    B, N, C = 1, 1024, 4
+    batch = make_batch(B, N, C, seed=seed)
+    rng = np.random.RandomState(seed)
+    P = R.init_params(rng, R.layer_table(C, 'A'))
+    for k in P:                                     # non-trivial moving statistics, as after training
+        if k.endswith('moving_mean'):
+            P[k] = torch.as_tensor(rng.normal(size=tuple(P[k].shape)) * 0.2)
+        elif k.endswith('moving_variance'):
+            P[k] = torch.as_tensor(0.5 + rng.uniform(size=tuple(P[k].shape)))
+    c = R.default_config()
+    g, m = run_model_a(rt, batch, P, c, train=False, is_training=False)
+    loss, ep, _, _ = R.model_a_forward_backward(P, batch, c, is_training=False, want_grads=False)
+    e = m.end_points()
+    worst = {}
+    for k in FWD_KEYS:
+        ref = ep[k].detach().numpy()
+        mine = e[k].detach().cpu().numpy().reshape(ref.shape)
+        worst[k] = float(np.abs(mine - ref).max() / max(1.0, np.abs(ref).max()))
+        assert worst[k] < 1e-4, (k, worst[k])
+    assert abs(float(e['loss'].cpu()) - float(loss)) < 1e-4 * max(1.0, abs(float(loss)))
+    return worst

@@ -113,3 +113,9 @@ def test_stage_c_step_matches_oracle(hip_lib):
     g, m = run_stage_c(Runtime(lib=hip_lib), batch, P, c)
     torch.cuda.synchronize()
     print(check_stage_c(g, m, batch, P, c, grad_median_tol=1e-3))
+
+
+def test_config0_single_frustum_forward(hip_lib):
+    """BASELINE.json configs[0] (B=1, N=1024, C=4, forward only) through the HIP kernels."""
+    from model_check import check_config0_single_frustum_forward
+    check_config0_single_frustum_forward(Runtime(lib=hip_lib))

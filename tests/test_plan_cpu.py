@@ -70,3 +70,8 @@ def test_all_points_background_gives_empty_mask_and_zero_centroid():
     # saturated logits make single-point CE gradients O(1): one fp32 ReLU-boundary flip moves the whole seg
     # chain by ~3e-3, so only the global bound is meaningful here
     check_against_oracle(g, m, batch, P, c, grad_median_tol=None)
+
+
+def test_config0_single_frustum_forward_plumbing():
+    from model_check import check_config0_single_frustum_forward
+    check_config0_single_frustum_forward(Runtime(device='cpu', lib=FakeLib()))

@@ -14,6 +14,9 @@
 #include "common.h"
 #include "poolbwd_dev.h"
 
+#include <mutex>
+#include <unordered_map>
+
 namespace {
 
 #ifndef T3D_BK
@@ -802,11 +805,22 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pool_bwd_stage2(const t3d_poo
 }
 
 // dynamic-LDS launch: two pipeline stages exceed the 64 KB static limit for the 128-wide tiles
+// > 64 KB of dynamic LDS needs the function attribute; set once per kernel and size (a driver call per launch would
+// sit on the host path of every eager launch)
+void allow_lds(const void* kernel, size_t lds_bytes) {
+  if (lds_bytes <= 64 * 1024) return;
+  static std::mutex mu;
+  static std::unordered_map<const void*, size_t> done;
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& cur = done[kernel];
+  if (cur >= lds_bytes) return;
+  (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  cur = lds_bytes;
+}
+
 template <class Args>
 void launch_lds(void (*kernel)(const Args), dim3 grid, size_t lds_bytes, hipStream_t s, const Args& a) {
-  if (lds_bytes > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds_bytes);
+  allow_lds(reinterpret_cast<const void*>(kernel), lds_bytes);
   T3D_LAUNCH(kernel, grid, dim3(NT), lds_bytes, s, a);
 }
 constexpr size_t lds_fwd(int bn) { return 2 * (size_t)(128 * LDR + BK * bn) * sizeof(float); }
@@ -1020,9 +1034,7 @@ extern "C" int t3d_pointmlp_bwd(const t3d_pointmlp_dgrad_args* d, const t3d_poin
   do {                                                                                                              \
     const size_t lds = lds_dgrad(DBN) > lds_wgrad(TK, TN_) ? lds_dgrad(DBN) : lds_wgrad(TK, TN_);                   \
     auto kern = k_pointmlp_bwd<DBN, TK, TN_>;                                                                       \
-    if (lds > 64 * 1024)                                                                                            \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                (int)lds);                                                                          \
+    allow_lds(reinterpret_cast<const void*>(kern), lds);                                                            \
     T3D_LAUNCH(kern, grid, dim3(NT), lds, s, *d, *w, n_w);                                                          \
   } while (0)
 #define T3D_BWD_W(DBN)                              \
@@ -1057,8 +1069,7 @@ extern "C" int t3d_pool_bwd_stage1(const t3d_pointmlp_gram_args* g, const t3d_ac
   if (COLSUM_LDS > lds) lds = COLSUM_LDS;
   if (gt == 128) {
     auto kern = k_pool_bwd_stage1<128>;
-    if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    allow_lds(reinterpret_cast<const void*>(kern), lds);
     T3D_LAUNCH(kern, grid, dim3(NT), lds, s, *g, *c, *q, n_gram, n_colsum);
   } else {
     T3D_LAUNCH(k_pool_bwd_stage1<64>, grid, dim3(NT), lds, s, *g, *c, *q, n_gram, n_colsum);
@@ -1081,13 +1092,11 @@ extern "C" int t3d_pool_bwd_stage2(const t3d_pool_wgrad_finish_args* f, const t3
   if (finish_lds(f->K) > lds) lds = finish_lds(f->K);
   if (wide) {
     auto kern = k_pool_bwd_stage2<128>;
-    if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    allow_lds(reinterpret_cast<const void*>(kern), lds);
     T3D_LAUNCH(kern, grid, dim3(NT), lds, s, *f, *d, n_finish);
   } else {
     auto kern = k_pool_bwd_stage2<64>;
-    if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    allow_lds(reinterpret_cast<const void*>(kern), lds);
     T3D_LAUNCH(kern, grid, dim3(NT), lds, s, *f, *d, n_finish);
   }
   T3D_CHECK_LAUNCH();

@@ -38,9 +38,12 @@ extern "C" int t3d_pool_sparse_rows(const t3d_pool_sparse_rows_args* a, t3d_stre
     return T3D_ERR_SHAPE;
   const size_t lds = (size_t)128 * SR_KC * sizeof(float) + (size_t)4 * a->N * sizeof(int);
   if (lds > 160 * 1024) return T3D_ERR_SHAPE;
-  if (lds > 64 * 1024)
+  static size_t allowed = 0;          // set the > 64 KB attribute once per size, not per launch
+  if (lds > 64 * 1024 && lds > allowed) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pool_sparse_rows), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
+    allowed = lds;
+  }
   const long M = (long)a->B * a->rows_per_frustum;
   T3D_LAUNCH(k_pool_sparse_rows, dim3(M / 128, a->K / SR_KC), dim3(256), lds, static_cast<hipStream_t>(stream), *a);
   T3D_CHECK_LAUNCH();
