@@ -2,6 +2,7 @@
 Session.run with a feed_dict) drives the same plan as the oracle's SEMI_MODEL A step, including the TF-form Adam
 update and the device-side schedules."""
 import numpy as np
+import pytest
 import torch
 
 from fake_t3d import FakeLib
@@ -121,6 +122,16 @@ def test_boxpc_reference_call_sequence():
                 x_dims_reg_pl: batch['y_dims_reg'], y_box_iou_pl: batch['y_box_iou'], y_center_delta_pl: batch['y_center_delta'],
                 y_dims_delta_pl: batch['y_dims_delta'], y_orient_delta_pl: batch['y_orient_delta']}
         logits, dc, loss_val = sess.run([pred[0], pred[1][0], loss], feed_dict=feed)
+        # the remaining contractual end_points of boxpc_sunrgbd.get_model (boxpc_sunrgbd.py:58-96)
+        assert np.array_equal(end_points['class_ids'].numpy(), np.argmax(batch['one_hot_vec'], 1))
+        p_fit = end_points['logits_for_weigh'].numpy()
+        assert np.array_equal(end_points['pred_boxpc_fit'].numpy(), (p_fit > 0.5).astype(np.int32))
+        assert set(end_points['boxpc_feats_dict']) == {'box_pc_mask_model_feats_lv%d' % i for i in (1, 2, 3)}
+        # semisup_models.box_pc_mask_features_model keeps the reference's error for an unknown representation
+        from transferable3d_amd import semisup_models
+        bad = make_parser().parse_special_args(['--BOX_PC_MASK_REPRESENTATION', 'Z'])
+        with pytest.raises(Exception, match='Box pc mask representation not implemented: Z'):
+            semisup_models.box_pc_mask_features_model(box_reg, pc_pl, None, 9, False, {}, False, False, c=bad, scope='box_pc_mask_model')
     c = R.default_config(BOXPC_WEIGHT_DELTA=4.0)
     lref, ep, _, _ = R.boxpc_forward_backward(P0, batch, c, is_training=False, want_grads=False)
     assert np.abs(logits - ep['boxpc_fit_logits'].numpy()).max() < 1e-4
@@ -152,6 +163,13 @@ def test_stage_c_reference_call_sequence_with_var_list():
                 pls[17]: batch['is_data_2D']}
         feed.update(batch['dropout_masks'])
         loss_val, f2c, fit, _ = sess.run([loss, end_points['F2_center'], end_points['boxpc_fit_prob'], train_op], feed_dict=feed)
+        # semisup_models.mlps_with_dropout names the box_refine head of this graph (semisup_v1_sunrgbd.py:183-197)
+        from transferable3d_amd import semisup_models
+        head = semisup_models.mlps_with_dropout(end_points['feats_lv1'], [512, 256, 67], ['leaky_relu', 'tanh', None], [0.5, 0.5, 0.5],
+                                                True, c=FLAGS, scope='box_refine')
+        assert head.numpy().shape == (B, 67)
+        with pytest.raises(NotImplementedError):
+            semisup_models.mlps_with_dropout(end_points['feats_lv1'], [64, 3], ['relu', None], [0.5, 0.5], True, c=FLAGS, scope='other')
         P1 = g.vars.state_dict()
     c = R.default_config(SEMI_MODEL='F', WEAK_WEIGHT_INTRACLASSVAR=2.0, SEMI_MULTIPLIER_FOR_WEAK_LOSS=0.05,
                          SEMI_BOXPC_FIT_ONLY_ON_2D_CLS=True, SEMI_WEIGHT_BOXPC_FIT_LOSS=1.0)

@@ -5,7 +5,6 @@ import numpy as np
 
 from . import api
 from .constants import MEAN_DIMS_ARR, NUM_CLASS, ORIENT_ANCHORS
-from .nets import BoxPCModel
 
 
 def placeholder_inputs(batch_size, num_point, num_channels):
@@ -35,29 +34,32 @@ def convert_raw_y_box_to_reg_format(y_box, one_hot_vec):
 
 
 def get_model(boxpc, is_training, one_hot_vec, use_one_hot_vec=False, bn_decay=None, c=None):
-    """boxpc = (box_reg, pc).  Returns (pred, end_points) with pred = (fit logits, (delta centre, size, angle))."""
+    """boxpc = (box_reg, pc).  Returns (pred, end_points) with pred = (fit logits, (delta centre, size, angle))
+    (boxpc_sunrgbd.py:56-100)."""
+    from . import semisup_models
+    from .semisup_models import SlicedTensor
     box_reg, pc = boxpc
     ctx = pc.ctx
-    e = ctx.engine
-    if not isinstance(box_reg, BoxRegHandle):
-        raise NotImplementedError('stage b feeds the GT box through convert_raw_y_box_to_reg_format (train_boxpc.py:233); '
-                                  'a predicted box enters in stage c (SEMI_MODEL F, next row of SURVEY section 8)')
-    ctx.assembly = BoxPCModel(e, c, use_one_hot_vec, inputs=ctx.inputs)
-    ctx.is_training = bool(is_training)
-    if isinstance(bn_decay, (int, float)):
-        e.hyper[2] = float(bn_decay)
-    net = ctx.assembly.net
-    B = e.B
-    out = net.F3.out
+    B = ctx.engine.B
+    oh_pl = one_hot_vec
+    end_points = {'class_ids': SlicedTensor(pc, lambda: np.argmax(ctx.inputs.one_hot_vec.cpu().numpy(), axis=1).astype(np.int32),
+                                            (B,), 'class_ids')}
+    if not use_one_hot_vec:
+        one_hot_vec = None
+    if c.BOXPC_WEIGH_DELTA_PRED_BY_CLS_CONF:
+        raise NotImplementedError('BOXPC_WEIGH_DELTA_PRED_BY_CLS_CONF is off in every published recipe (config.py default)')
+    output, feats = semisup_models.box_pc_mask_features_model(box_reg, pc, None, 2 + 7, is_training, end_points=end_points,
+                                                              reuse=False, bn_for_output=False, one_hot_vec=one_hot_vec,
+                                                              norm_box2D=None, bn_decay=bn_decay, c=c, scope='box_pc_mask_model')
+    out = output.buf
     T = lambda buf, shape, name: api.Tensor(ctx, buf, shape, name)
     logits = T(out[:, 7:9], (B, 2), 'boxpc_fit_logits')
     dc, ds, da = T(out[:, 0:3], (B, 3), 'boxpc_delta_center'), T(out[:, 3:6], (B, 3), 'boxpc_delta_size'), T(out[:, 6], (B,), 'boxpc_delta_angle')
     terms = ctx.assembly.loss_op.terms
-    end_points = {'boxpc_fit_logits': logits, 'boxpc_delta_center': dc, 'boxpc_delta_size': ds, 'boxpc_delta_angle': da,
-                  'logits_for_weigh': T(terms[:, 2], (B,), 'logits_for_weigh'),
-                  'boxpc_feats_dict': {'box_pc_mask_model_feats_lv1': T(net.P4.pooled, (B, 512), 'feats_lv1'),
-                                       'box_pc_mask_model_feats_lv2': T(net.F1.out, (B, 512), 'feats_lv2'),
-                                       'box_pc_mask_model_feats_lv3': T(net.F2.out, (B, 256), 'feats_lv3')}}
+    lw = T(terms[:, 2], (B,), 'logits_for_weigh')
+    end_points.update({'boxpc_feats_dict': feats, 'boxpc_fit_logits': logits,
+                       'pred_boxpc_fit': SlicedTensor(lw, lambda: (lw.numpy() > 0.5).astype(np.int32), (B,), 'pred_boxpc_fit'),
+                       'logits_for_weigh': lw, 'boxpc_delta_center': dc, 'boxpc_delta_size': ds, 'boxpc_delta_angle': da})
     return (logits, (dc, ds, da)), end_points
 
 

@@ -1,6 +1,6 @@
 """Sub-network builders under the reference's names and signatures
-(sunrgbd/sunrgbd_detection/semisup_models.py: v1_inst_seg 69, subtract_points_mean 145, v1_tnet 164,
-subtract_1st_stage_center 204, v1_box_est 215).  Each call allocates the sub-network (variables in the reference's
+(sunrgbd/sunrgbd_detection/semisup_models.py: mlps_with_dropout 44, v1_inst_seg 69, subtract_points_mean 145,
+v1_tnet 164, subtract_1st_stage_center 204, v1_box_est 215, box_pc_mask_features_model 297).  Each call allocates the sub-network (variables in the reference's
 scopes, HBM buffers) on the default graph and links it into the graph's ModelAssembly; the fused launch
 schedule is emitted when a Session first runs."""
 import numpy as np
@@ -114,3 +114,54 @@ class BoxHeads:
         ep, p = self.end_points(), self.prefix
         return (ep[p + 'center'], ep[p + 'size_scores'], ep[p + 'size_residuals'], ep[p + 'heading_scores'],
                 ep[p + 'heading_residuals'])
+
+
+def mlps_with_dropout(input_feat, layers, activation_fns, keep_probs, is_training, bn=True, bn_decay=None, c=None, scope=None,
+                      reuse=None):
+    """FC stack with dropout after every hidden layer (semisup_models.py:44-63).  Its one call site on the hot path is
+    the class-dependent `box_refine` head of SEMI_MODEL F (semisup_v1_sunrgbd.py:183-197: feats_lv1 (+ one_hot) -> 512 ->
+    256 -> 67); the stack is part of the fused stage-c assembly (nets.SemiModelF.R0-R2) and this returns its output."""
+    assert(len(layers) == len(activation_fns) == len(keep_probs))
+    from .nets import SemiModelF
+    ctx = input_feat.ctx
+    m = ctx.assembly
+    if not isinstance(m, SemiModelF) or tuple(layers) != (512, 256, BOX_OUT_DIMS) or scope != 'box_refine':
+        raise NotImplementedError('mlps_with_dropout: only the box_refine head of SEMI_MODEL F is on the hot path '
+                                  '(layers (512, 256, %d)); got %r in scope %r' % (BOX_OUT_DIMS, tuple(layers), scope))
+    if not bn:
+        raise NotImplementedError('box_refine is built with batch-norm on its hidden layers (semisup_v1_sunrgbd.py:196)')
+    return api.Tensor(ctx, m.R2.out, (ctx.engine.B, layers[-1]), 'class_dependent/' + scope + '/fc2')
+
+
+def box_pc_mask_features_model(box, pc, logits, num_outputs, is_training, end_points, reuse, bn_for_output, normalize_pc=False,
+                               normalize_method='SD', one_hot_vec=None, norm_box2D=None, bn_decay=None, c=None, scope=None):
+    """The Box-PC Fit net on a (box, point cloud) pair -> ((B, num_outputs) output, {feature level: tensor})
+    (semisup_models.py:297-324 -> combined_box_pc_mask_features_model 326-398).  Representation 'A' (the only one in a
+    published recipe): the 6 signed face distances per point appended to the raw channels, conv D->128->128->256->512,
+    max-pool, FC 512 -> 256 -> num_outputs with dropout 0.7.  Variables live under the literal scope box_pc_mask_model/."""
+    from .boxpc_sunrgbd import BoxRegHandle
+    from .nets import BoxPCModel
+    if c.BOX_PC_MASK_REPRESENTATION == 'B':
+        raise NotImplementedError('BOX_PC_MASK_REPRESENTATION B (independent_box_pc_mask_features_model) is in no published recipe')
+    if c.BOX_PC_MASK_REPRESENTATION != 'A':
+        raise Exception('Box pc mask representation not implemented: %s' % c.BOX_PC_MASK_REPRESENTATION)
+    if logits is not None or normalize_pc or norm_box2D is not None or bn_for_output:
+        raise NotImplementedError('mask / normalize_pc / norm_box2D / bn_for_output are off at every call site of the reference')
+    if num_outputs != 9:
+        raise NotImplementedError('the fit net has 2 fit logits + 7 delta terms (boxpc_sunrgbd.py:60,65)')
+    ctx = pc.ctx
+    e = ctx.engine
+    if not isinstance(box, BoxRegHandle):
+        raise NotImplementedError('a GT box enters through convert_raw_y_box_to_reg_format (train_boxpc.py:233); a predicted box '
+                                  'enters inside SEMI_MODEL F (get_semi_model_final), which owns its own frozen Box-PC branch')
+    ctx.assembly = BoxPCModel(e, c, one_hot_vec is not None, inputs=ctx.inputs)
+    ctx.is_training = bool(is_training)
+    if isinstance(bn_decay, (int, float)):
+        e.hyper[2] = float(bn_decay)
+    net = ctx.assembly.net
+    B = e.B
+    T = lambda buf, shape, name: api.Tensor(ctx, buf, shape, name)
+    feats = {'box_pc_mask_model_feats_lv1': T(net.P4.pooled, (B, 512), 'feats_lv1'),
+             'box_pc_mask_model_feats_lv2': T(net.F1.out, (B, 512), 'feats_lv2'),
+             'box_pc_mask_model_feats_lv3': T(net.F2.out, (B, 256), 'feats_lv3')}
+    return T(net.F3.out, (B, 9), 'box_pc_mask_model/output'), feats
