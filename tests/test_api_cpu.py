@@ -74,6 +74,11 @@ def test_reference_call_sequence_runs_a_training_step():
         assert np.abs(P1[k].reshape(val.shape) - val.detach().numpy()).max() < 1e-4, k
 
 
+def _soft_mask_ref(logits):
+    e = np.exp(logits - logits.max(axis=2, keepdims=True))
+    return e[:, :, 1] / e.sum(axis=2)
+
+
 def test_forward_only_fetch_compiles_the_inference_plan():
     B, N, C = 2, 128, 4
     FLAGS = _flags()
@@ -83,7 +88,10 @@ def test_forward_only_fetch_compiles_the_inference_plan():
         pred, end_points = MODEL.get_semi_model(pls[0], pls[1], pls[2], pls[3], False, use_one_hot=False, c=FLAGS)
         sess = api.Session()
         P0 = {k: torch.tensor(v, dtype=torch.float64) for k, v in g.vars.state_dict().items()}
-        logits, s1 = sess.run([pred[0], end_points['stage1_center']], feed_dict={pls[0]: batch['pc'], pls[3]: batch['one_hot_vec']})
+        logits, s1, soft, cls = sess.run([pred[0], end_points['stage1_center'], end_points['soft_mask'], end_points['class_ids']],
+                                         feed_dict={pls[0]: batch['pc'], pls[3]: batch['one_hot_vec']})
+    assert np.abs(soft - _soft_mask_ref(logits.astype(np.float64))).max() < 1e-6          # semisup_v1_sunrgbd.py:102
+    assert np.array_equal(cls, np.argmax(batch['one_hot_vec'], axis=1))                    # semisup_v1_sunrgbd.py:91
     ctx = R.Ctx(P0, is_training=False)
     _, ep = R.get_semi_model_backbone(ctx, torch.as_tensor(batch['pc'], dtype=torch.float64),
                                       torch.as_tensor(batch['one_hot_vec'], dtype=torch.float64))

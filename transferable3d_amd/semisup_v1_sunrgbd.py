@@ -60,6 +60,7 @@ def get_semi_model_final(pc, bg_pc, img, one_hot_vec, is_training, use_one_hot, 
     end_points = {'point_cloud': pc, 'class_one_hot': one_hot_vec, 'stage1_center': s1,
                   'dims_anchors': MEAN_DIMS_ARR.astype(np.float32), 'orient_anchors': ORIENT_ANCHORS.astype(np.float32),
                   'feats_lv1': T(m.box.B4.pooled, (B, 512), 'feats_lv1')}
+    _common_end_points(ctx, end_points, logits)
     W = semisup_models.BoxHeads(T(m.box.G3.out, (B, 67), 'box_params'), s1, '')
     F = semisup_models.BoxHeads(T(m.R2.out, (B, 67), 'F_box_params'), s1, 'F_')
     end_points.update(W.end_points())
@@ -89,6 +90,21 @@ def get_semi_model_final(pc, bg_pc, img, one_hot_vec, is_training, use_one_hot, 
     return (logits, W.pred_box(), F.pred_box()), end_points
 
 
+def _common_end_points(ctx, end_points, logits):
+    """class_ids = argmax(one_hot) (semisup_v1_sunrgbd.py:91,143) and soft_mask = softmax(logits)[:,:,1] (102,165),
+    evaluated on the host at fetch time."""
+    B, N = ctx.engine.B, ctx.engine.rpf
+    ST = semisup_models.SlicedTensor
+    end_points['class_ids'] = ST(logits, lambda: np.argmax(ctx.inputs.one_hot_vec.cpu().numpy(), axis=1).astype(np.int32), (B,),
+                                 'class_ids')
+
+    def soft():
+        l = logits.numpy().astype(np.float64)
+        e = np.exp(l - l.max(axis=2, keepdims=True))
+        return (e[:, :, 1] / e.sum(axis=2)).astype(np.float32)
+    end_points['soft_mask'] = ST(logits, soft, (B, N), 'soft_mask')
+
+
 def get_semi_model_backbone(pc, bg_pc, img, one_hot_vec, is_training, use_one_hot, oracle_mask=None, norm_box2D=None,
                             bn_decay=None, c=None):
     """seg PointNet -> masked centroid -> T-Net -> box PointNet (semisup_v1_sunrgbd.py:81-130)."""
@@ -113,6 +129,7 @@ def get_semi_model_backbone(pc, bg_pc, img, one_hot_vec, is_training, use_one_ho
     pred_box = semisup_models.v1_box_est(pc_xyz_submean, stage1_center, mask, one_hot_vec, end_points, is_training,
                                          norm_box2D=norm_box2D, bn_decay=bn_decay, c=c, scope='box_est')
     end_points['S_pred_box'] = pred_box
+    _common_end_points(ctx, end_points, logits)
     end_points['mask'] = mask
     end_points['mask_xyz_mean'] = mask_xyz_mean
     asm = ctx.assembly
