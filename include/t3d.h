@@ -541,6 +541,22 @@ typedef struct {
 } t3d_anchor_reg_bwd_args;
 int t3d_anchor_reg_bwd(const t3d_anchor_reg_bwd_args* args, t3d_stream_t stream);
 
+/* One step of the iterated Box-PC refinement of the inference graph (test_semisup.py:101-134):
+ *   p_fit = softmax(out9[:,7:9])[:,1];  w = weigh_by_conf ? 1 - p_fit : 1   (SEMI_WEIGH_BOXPC_DELTA_DURING_TEST)
+ *   box_out = box_in - w * out9[:,0:7]  (centre 0:3, size 3:6, angle 6);  total (+)= w * out9[:,0:7]  (`first`: =)
+ * The F2_ heads are the F_ heads minus `total` (test_semisup.py:136-142). */
+typedef struct {
+  const float* out9;              /* [B,9] Box-PC net output */
+  const float* center_in; const float* dims_in; const float* theta_in;   /* [B,3],[B,3],[B] */
+  float* center_out; float* dims_out; float* theta_out;                  /* may alias the inputs */
+  float* total;                   /* [B,7] accumulated deltas */
+  float* fit_prob;                /* [B] or NULL */
+  int weigh_by_conf;
+  int first;
+  int B;
+} t3d_box_refine_step_args;
+int t3d_box_refine_step(const t3d_box_refine_step_args* args, t3d_stream_t stream);
+
 /* ---- K11d / K12 / schedules --------------------------------------------------------------------- */
 
 /* grad[off_i + e] = sum_s slabs_i[s, e]  for every tensor i of a device-side table. */

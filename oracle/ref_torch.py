@@ -727,6 +727,54 @@ def stage_c_forward_backward(P, batch, c, train_classes, bn_decay_val=0.5, dtype
     return loss, ep, grads, ctx.ema_updates
 
 
+def stage_c_inference(P, batch, c, refine_num, dtype=torch.float64, use_one_hot=True):
+    """The inference graph of test_semisup.py:61-149 for SEMI_MODEL F: every net in inference mode (moving statistics,
+    no dropout); the F_ box in regression form is refined `refine_num` times by the Box-PC net,
+    box <- box - w * delta(box, pc), w = 1 - p_fit if SEMI_WEIGH_BOXPC_DELTA_DURING_TEST else 1; the F2_ heads are
+    the F_ heads minus the accumulated deltas (136-142)."""
+    Pl = {k: val.detach().to(dtype) for k, val in P.items()}
+    ctx = Ctx(Pl, is_training=False, bn_decay=0.5, dropout_masks={})
+    pc = torch.as_tensor(batch['pc'], dtype=dtype)
+    oh = torch.as_tensor(batch['one_hot_vec'], dtype=dtype)
+    pred, ep = get_semi_model_final(ctx, pc, oh, use_one_hot, c)
+    cur = ep['F_pred_box_reg']
+    tot_c, tot_s, tot_a = torch.zeros_like(cur[0]), torch.zeros_like(cur[1]), torch.zeros_like(cur[2])
+    fit = None
+    for _ in range(int(refine_num)):
+        _, ep_b = boxpc_get_model(ctx, cur, pc, oh, False, c, scope_prefix='D_boxpc_branch/')
+        fit = torch.softmax(ep_b['boxpc_fit_logits'], dim=-1)[:, 1]
+        w = (1 - ep_b['logits_for_weigh']) if c.SEMI_WEIGH_BOXPC_DELTA_DURING_TEST else torch.ones_like(fit)
+        dc, da, ds = ep_b['boxpc_delta_center'] * w[:, None], ep_b['boxpc_delta_angle'] * w, ep_b['boxpc_delta_size'] * w[:, None]
+        cur = (cur[0] - dc, cur[1] - ds, cur[2] - da)
+        tot_c, tot_s, tot_a = tot_c + dc, tot_s + ds, tot_a + da
+    ep['boxpc_fit_prob'] = fit
+    ep['F2_center'] = ep['F_center'] - tot_c
+    ep['F2_heading_scores'] = ep['F_heading_scores']
+    ep['F2_heading_residuals'] = ep['F_heading_residuals'] - tot_a[:, None]
+    ep['F2_size_scores'] = ep['F_size_scores']
+    ep['F2_size_residuals'] = ep['F_size_residuals'] - tot_s[:, None, :]
+    ep['refined_box'] = cur
+    return pred, ep
+
+
+def inference_scores(logits, heading_scores, size_scores, boxpc_fit_prob=None):
+    """Detection confidence of test_semisup.py:233-246 (NumPy): log(mean mask prob + .01) + log(max heading prob + .01) +
+    log(max size prob + .01) [+ log(p_fit + .01)], mask mean over the predicted-foreground points with the reference's
+    `+ 1` in the denominator."""
+    import numpy as np
+
+    def softmax(x):
+        e = np.exp(x - x.max(axis=-1, keepdims=True))
+        return e / e.sum(axis=-1, keepdims=True)
+    seg_prob = softmax(logits)[:, :, 1]
+    seg_mask = np.argmax(logits, 2)
+    mask_mean_prob = (seg_prob * seg_mask).sum(1) / (seg_mask.sum(1) + 1)
+    s = np.log(mask_mean_prob + 0.01) + np.log(softmax(heading_scores).max(1) + 0.01) + np.log(softmax(size_scores).max(1) + 0.01)
+    if boxpc_fit_prob is not None:
+        s = s + np.log(boxpc_fit_prob + 0.01)
+    return s
+
+
 def stage_c_params(rng, num_channels, dtype=torch.float64, use_one_hot=True):
     """Variables of the stage-c graph: model F under class_agnostic/ + class_dependent/, Box-PC under D_boxpc_branch/."""
     P = init_params(rng, layer_table(num_channels, 'F', use_one_hot=use_one_hot), dtype)

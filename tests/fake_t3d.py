@@ -254,6 +254,24 @@ class FakeLib:
             slabs[s] = x[s * rps:(s + 1) * rps].T @ dy[s * rps:(s + 1) * rps]
         return 0
 
+    def t3d_box_refine_step(self, a, stream):
+        p = _struct(a)
+        B = p.B
+        o = arr(p.out9, B, 9).astype(np.float64)
+        z = o[:, 7:9] - o[:, 7:9].max(1, keepdims=True)
+        pfit = np.exp(z[:, 1]) / np.exp(z).sum(1)
+        w = (1.0 - pfit) if p.weigh_by_conf else np.ones(B)
+        if p.fit_prob:
+            arr(p.fit_prob, B)[:] = pfit
+        d = o[:, :7] * w[:, None]
+        cin, din, tin = arr(p.center_in, B, 3).astype(np.float64), arr(p.dims_in, B, 3).astype(np.float64), arr(p.theta_in, B).astype(np.float64)
+        arr(p.center_out, B, 3)[:] = cin - d[:, 0:3]
+        arr(p.dims_out, B, 3)[:] = din - d[:, 3:6]
+        arr(p.theta_out, B)[:] = tin - d[:, 6]
+        tot = arr(p.total, B, 7)
+        tot[:] = d if p.first else tot + d
+        return 0
+
     def t3d_pool_bwd_stage1(self, g, c, q, stream):
         return self.t3d_pointmlp_gram(g, stream) or self.t3d_act_colsum(c, stream) or self.t3d_pool_bwd_prep(q, stream)
 

@@ -123,3 +123,40 @@ def check_config0_single_frustum_forward(rt, seed=5):
         assert worst[k] < 1e-4, (k, worst[k])
     assert abs(float(e['loss'].cpu()) - float(loss)) < 1e-4 * max(1.0, abs(float(loss)))
     return worst
+
+
+def check_stage_c_inference(rt, refine):
+    """test_semisup.py:61-262 on synthetic frustums: the inference graph of SEMI_MODEL F (inference-mode batch-norm, no
+    dropout, `--refine` Box-PC refinement steps), the F2_ heads and the detection score, against the oracle."""
+    from transferable3d_amd import test_semisup as TS
+    from transferable3d_amd.synthetic import make_batch
+    B, N, C = 4, 256, 4
+    FLAGS = TS.build_flags(['--semi_type', 'F', '--use_one_hot', '--num_point', str(N), '--num_channels', str(C), '--batch_size', str(B),
+                            '--refine', str(refine), '--pred_prefix', 'F2_', '--use_boxpc_fit_prob' if refine else '--synthetic'])
+    rng = np.random.RandomState(3)
+    P = R.stage_c_params(rng, C)
+    for k in P:                                     # non-trivial moving statistics
+        if k.endswith('moving_mean'):
+            P[k] = torch.as_tensor(rng.normal(size=tuple(P[k].shape)) * 0.2)
+        elif k.endswith('moving_variance'):
+            P[k] = torch.as_tensor(0.5 + rng.uniform(size=tuple(P[k].shape)))
+    sess, ops = TS.get_model(FLAGS, B, N, C, rt=rt,
+                             state_dict={k: v.numpy() for k, v in P.items()})
+    batches = [make_batch(B, N, C, seed=40 + i) for i in range(2)]
+    pc, oh = np.concatenate([b['pc'] for b in batches]), np.concatenate([b['one_hot_vec'] for b in batches])
+    seg, centers, hcls, hres, scls, sres, scores = TS.inference(sess, ops, pc, oh, B, prefix='F2_', use_boxpc_fit_prob=bool(refine))
+    c = R.default_config(SEMI_REFINE_USING_BOXPC_DELTA_NUM=refine)
+    for i, b in enumerate(batches):
+        pred, ep = R.stage_c_inference(P, b, c, refine)
+        sl = slice(i * B, (i + 1) * B)
+        num = lambda t: t.detach().numpy()
+        assert np.abs(centers[sl] - num(ep['F2_center'])).max() < 1e-4
+        assert np.array_equal(hcls[sl], np.argmax(num(ep['F2_heading_scores']), 1))
+        assert np.array_equal(scls[sl], np.argmax(num(ep['F2_size_scores']), 1))
+        hr = num(ep['F2_heading_residuals'])[np.arange(B), hcls[sl]]
+        sr = num(ep['F2_size_residuals'])[np.arange(B), scls[sl]]
+        assert np.abs(hres[sl] - hr).max() < 1e-4 and np.abs(sres[sl] - sr).max() < 1e-4
+        ref_scores = R.inference_scores(num(ep['logits']), num(ep['F2_heading_scores']), num(ep['F2_size_scores']),
+                                        num(ep['boxpc_fit_prob']) if refine else None)
+        assert np.abs(scores[sl] - ref_scores).max() < 1e-3
+        assert (seg[sl] == np.argmax(num(ep['logits']), 2)).mean() > 0.999

@@ -935,3 +935,25 @@ def test_fused_pool_stages_equal_the_separate_launches(hip_lib):
     for a, b, what in zip(out[0], out[1], ('gram', 'abar', 'P', 'rowconst', 'wc', 'dw', 'da', 'psum_dz', 'psum_dzy', 'S')):
         assert torch.equal(a, b), what
     assert float(out[1][5].abs().max()) > 0 and float(out[1][6].abs().max()) > 0
+
+
+@pytest.mark.parametrize('weigh,first', [(0, 1), (1, 0)])
+def test_box_refine_step(hip_lib, weigh, first):
+    r = np.random.RandomState(3 + weigh)
+    B = 37
+    d = dict(out9=r.normal(size=(B, 9)).astype(np.float32), c=r.normal(size=(B, 3)).astype(np.float32),
+             s=(1 + r.uniform(size=(B, 3))).astype(np.float32), th=r.normal(size=B).astype(np.float32),
+             tot=r.normal(size=(B, 7)).astype(np.float32))
+
+    def make(dev):
+        t = {k: _mk(dev, v) for k, v in d.items()}
+        o = dict(c=torch.zeros(B, 3, device=dev), s=torch.zeros(B, 3, device=dev), th=torch.zeros(B, device=dev), tot=t['tot'].clone(),
+                 fit=torch.zeros(B, device=dev))
+        a = abi.BoxRefineStepArgs(fptr(t['out9']), fptr(t['c']), fptr(t['s']), fptr(t['th']), fptr(o['c']), fptr(o['s']), fptr(o['th']),
+                                  fptr(o['tot']), fptr(o['fit']), weigh, first, B)
+        a._keep = (t, o)
+        return a, o
+
+    c, g = _run_both(hip_lib, make, 't3d_box_refine_step')
+    for k in c:
+        _close(c[k], g[k], 1e-5, 1e-6, 'refine_step ' + k)

@@ -119,3 +119,10 @@ def test_config0_single_frustum_forward(hip_lib):
     """BASELINE.json configs[0] (B=1, N=1024, C=4, forward only) through the HIP kernels."""
     from model_check import check_config0_single_frustum_forward
     check_config0_single_frustum_forward(Runtime(lib=hip_lib))
+
+
+@pytest.mark.parametrize('refine', [0, 2])
+def test_inference_graph_with_iterated_boxpc_refinement(hip_lib, refine):
+    """test_semisup.py inference graph (SEMI_MODEL F, inference-mode batch-norm, `--refine` Box-PC steps) + scoring."""
+    from model_check import check_stage_c_inference
+    check_stage_c_inference(Runtime(lib=hip_lib), refine)

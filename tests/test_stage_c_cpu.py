@@ -1,6 +1,7 @@
 """CPU: SEMI_MODEL F / stage c (BASELINE config 3, single replica) on the NumPy specification library against the
 oracle: forward tensors, the three loss parts, and the gradients of the reference's var_list."""
 import numpy as np
+import pytest
 import torch
 
 from fake_t3d import FakeLib
@@ -95,3 +96,9 @@ def test_stage_c_all_3d_batch_has_zero_fit_and_intraclass_terms():
     g, m = run_stage_c(Runtime(device='cpu', lib=FakeLib()), batch, P, c)
     assert float(m.end_points()['terms'][1]) == 0.0
     check_stage_c(g, m, batch, P, c)
+
+
+@pytest.mark.parametrize('refine', [0, 1, 3])
+def test_inference_graph_with_iterated_boxpc_refinement(refine):
+    from model_check import check_stage_c_inference
+    check_stage_c_inference(Runtime(device='cpu', lib=FakeLib()), refine)

@@ -79,6 +79,11 @@ class PoolWgradFinishArgs(C.Structure):
                 ('B', i32), ('K', i32), ('N', i32), ('rows_per_frustum', i32), ('dw', F)]
 
 
+class BoxRefineStepArgs(C.Structure):
+    _fields_ = [('out9', F), ('center_in', F), ('dims_in', F), ('theta_in', F), ('center_out', F), ('dims_out', F), ('theta_out', F),
+                ('total', F), ('fit_prob', F), ('weigh_by_conf', i32), ('first', i32), ('B', i32)]
+
+
 class BnBwdFinalizeArgs(C.Structure):
     _fields_ = [('psum_dz', F), ('psum_dzy', F), ('n_tiles', i32), ('dpool_in', F), ('ld_dpool_in', i32),
                 ('pooled', F), ('ld_pooled', i32), ('ysel', F), ('dpool', F), ('B', i32), ('count', i32), ('N', i32),
@@ -195,6 +200,7 @@ ENTRY_POINTS = {
     't3d_pointmlp_gram': [C.POINTER(PointMlpGramArgs), VP],
     't3d_act_colsum': [C.POINTER(ActColsumArgs), VP],
     't3d_pool_wgrad_finish': [C.POINTER(PoolWgradFinishArgs), VP],
+    't3d_box_refine_step': [C.POINTER(BoxRefineStepArgs), VP],
     't3d_pool_bwd_stage1': [C.POINTER(PointMlpGramArgs), C.POINTER(ActColsumArgs), C.POINTER(PoolBwdPrepArgs), VP],
     't3d_pool_bwd_stage2': [C.POINTER(PoolWgradFinishArgs), C.POINTER(PointMlpDgradGramArgs), VP],
     't3d_fc_fwd': [C.POINTER(FcFwdArgs), VP],

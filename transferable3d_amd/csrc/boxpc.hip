@@ -289,7 +289,41 @@ __global__ __launch_bounds__(1024) void k_anchor_reg_bwd(const t3d_anchor_reg_bw
   g[15 + js] += gt * (3.14159265358979323846f / 12.0f);
 }
 
+// one refinement step of the inference loop (test_semisup.py:101-134): box <- box - w * delta(box, pc)
+__global__ __launch_bounds__(256) void k_box_refine_step(const t3d_box_refine_step_args p) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= p.B) return;
+  const float* o = p.out9 + (size_t)b * 9;
+  const float mx = fmaxf(o[7], o[8]);
+  const float e0 = expf(o[7] - mx), e1 = expf(o[8] - mx);
+  const float pfit = e1 / (e0 + e1);
+  const float w = p.weigh_by_conf ? 1.f - pfit : 1.f;
+  if (p.fit_prob) p.fit_prob[b] = pfit;
+  float* tot = p.total + (size_t)b * 7;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float dc = o[i] * w, ds = o[3 + i] * w;
+    p.center_out[b * 3 + i] = p.center_in[b * 3 + i] - dc;
+    p.dims_out[b * 3 + i] = p.dims_in[b * 3 + i] - ds;
+    tot[i] = (p.first ? 0.f : tot[i]) + dc;
+    tot[3 + i] = (p.first ? 0.f : tot[3 + i]) + ds;
+  }
+  const float da = o[6] * w;
+  p.theta_out[b] = p.theta_in[b] - da;
+  tot[6] = (p.first ? 0.f : tot[6]) + da;
+}
+
 }  // namespace
+
+extern "C" int t3d_box_refine_step(const t3d_box_refine_step_args* a, t3d_stream_t stream) {
+  if (!a || !a->out9 || !a->center_in || !a->dims_in || !a->theta_in || !a->center_out || !a->dims_out || !a->theta_out ||
+      !a->total)
+    return T3D_ERR_ARG;
+  if (a->B <= 0) return T3D_ERR_SHAPE;
+  T3D_LAUNCH(k_box_refine_step, dim3((a->B + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
 
 extern "C" int t3d_boxpc_rep(const t3d_boxpc_rep_args* a, t3d_stream_t stream) {
   if (!a || !a->pc || !a->center || !a->dims || !a->theta || !a->rep) return T3D_ERR_ARG;

@@ -528,8 +528,13 @@ class SemiModelF:
         self.d_dims, self.dout9, self.fit_prob = rt.zeros(B, 3), rt.zeros(B, 9), rt.zeros(B)
         self.terms, self.loss = rt.zeros(2), rt.zeros(1)
         self.drep, self.dbox7 = rt.zeros(g.M, 8), rt.zeros(B, 7)
+        # inference graph (test_semisup.py:95-149): iterated Box-PC refinement of the F_ box
+        self.refine_num = None
+        self.cur_center, self.cur_dims, self.cur_theta, self.total_delta = rt.zeros(B, 3), rt.zeros(B, 3), rt.zeros(B), rt.zeros(B, 7)
 
     def emit_forward(self, plan, is_training, with_loss):
+        if not is_training and self.refine_num is not None:
+            return self.emit_forward_inference(plan, self.refine_num)
         g, x, c = self.g, self.inputs, self.c
         self.seg.fwd(plan, x.pc, x.one_hot_vec, x.y_seg if with_loss else None, x.is_data_2D, is_training, False,
                      ce_weight=c.STRONG_WEIGHT_CROSS_ENTROPY)
@@ -553,6 +558,31 @@ class SemiModelF:
         a.d_dims, a.dout9, a.fit_prob, a.terms, a.loss, a.B = fptr(self.d_dims), fptr(self.dout9), fptr(self.fit_prob), \
             fptr(self.terms), fptr(self.loss), g.B
         plan.add('t3d_semi_final_loss', a)
+
+    def emit_forward_inference(self, plan, refine_num):
+        """test_semisup.py:61-149: every net in inference mode; the F_ box in regression form is refined `refine_num`
+        times, box <- box - w * delta(box, pc), with the deltas accumulated in total_delta (the F2_ heads are the F_ heads
+        minus the totals).  The strong-loss kernel runs for its anchor->reg outputs only (labels are whatever the label
+        buffers hold; its loss values are not part of this graph)."""
+        g, x, c = self.g, self.inputs, self.c
+        self.seg.fwd(plan, x.pc, x.one_hot_vec, None, x.is_data_2D, False, False, ce_weight=c.STRONG_WEIGHT_CROSS_ENTROPY)
+        s1 = self.tnet.fwd(plan, x.pc, self.seg.mask, self.seg.mask_xyz_mean, x.one_hot_vec, False)
+        self.box.fwd(plan, x.pc, self.seg.mask, s1, x.one_hot_vec, False)
+        f = self.R0.fwd(plan, self.box.feats_lv1, 512, False, in2=x.one_hot_vec if self.oh else None, ld_in2=NUM_CLASS)
+        f = self.R1.fwd(plan, f, 512, False)
+        self.F_out = self.R2.fwd(plan, f, 256, False)
+        lab = (x.y_center, x.y_orient_cls, x.y_orient_reg, x.y_dims_cls, x.y_dims_reg, x.is_data_2D)
+        lo = self.loss_op
+        lo.emit(plan, self.F_out, s1, self.seg.seg_loss, lab, c, normalize_by_3d_count=True)
+        src = (lo.center, lo.reg_dims, lo.reg_theta)
+        cur = (self.cur_center, self.cur_dims, self.cur_theta)
+        for i in range(int(refine_num)):
+            out9 = self.boxpc.fwd(plan, x.pc, src[0], src[1], src[2], x.one_hot_vec, False)
+            a = abi.BoxRefineStepArgs(fptr(out9), fptr(src[0]), fptr(src[1]), fptr(src[2]), fptr(cur[0]), fptr(cur[1]), fptr(cur[2]),
+                                      fptr(self.total_delta), fptr(self.fit_prob), int(bool(c.SEMI_WEIGH_BOXPC_DELTA_DURING_TEST)),
+                                      int(i == 0), g.B)
+            plan.add('t3d_box_refine_step', a)
+            src = cur
 
     def emit_backward(self, plan):
         g, x = self.g, self.inputs
@@ -584,4 +614,5 @@ class SemiModelF:
                 'feats_lv1': self.box.feats_lv1, 'box_params': self.box.box_params, 'F_box_params': self.F_out,
                 'F_center': lo.center, 'F_dims': lo.reg_dims, 'F_theta': lo.reg_theta, 'boxpc_fit_prob': self.fit_prob,
                 'boxpc_out': self.boxpc.F3.out, 'loss': self.loss, 'strong_loss': lo.loss, 'terms': self.terms,
-                'loss_terms': lo.terms}
+                'loss_terms': lo.terms, 'total_delta': self.total_delta, 'refined_center': self.cur_center,
+                'refined_dims': self.cur_dims, 'refined_theta': self.cur_theta}

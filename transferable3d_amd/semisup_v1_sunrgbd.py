@@ -75,6 +75,19 @@ def get_semi_model_final(pc, bg_pc, img, one_hot_vec, is_training, use_one_hot, 
     end_points['boxpc_delta_size'] = T(m.boxpc.F3.out[:, 3:6], (B, 3), 'boxpc_delta_size')
     end_points['boxpc_delta_angle'] = T(m.boxpc.F3.out[:, 6], (B,), 'boxpc_delta_angle')
     ST = semisup_models.SlicedTensor
+    if not ctx.is_training:
+        # inference graph (test_semisup.py:95-149): SEMI_REFINE_USING_BOXPC_DELTA_NUM refinement steps on the device,
+        # F2_ = F_ - accumulated deltas
+        m.refine_num = int(c.SEMI_REFINE_USING_BOXPC_DELTA_NUM)
+        tot = T(m.total_delta, (B, 7), 'total_delta')
+        end_points['F2_center'] = ST(tot, lambda: end_points['F_center'].numpy() - tot.numpy()[:, 0:3], (B, 3), 'F2_center')
+        end_points['F2_heading_scores'] = end_points['F_heading_scores']
+        end_points['F2_heading_residuals'] = ST(tot, lambda: end_points['F_heading_residuals'].numpy() - tot.numpy()[:, 6:7],
+                                                (B, 12), 'F2_heading_residuals')
+        end_points['F2_size_scores'] = end_points['F_size_scores']
+        end_points['F2_size_residuals'] = ST(tot, lambda: end_points['F_size_residuals'].numpy() - tot.numpy()[:, None, 3:6],
+                                             (B, 10, 3), 'F2_size_residuals')
+        return (logits, W.pred_box(), F.pred_box()), end_points
 
     def wgt():
         if c.SEMI_WEIGH_BOXPC_DELTA_DURING_TEST:

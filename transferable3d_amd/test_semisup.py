@@ -1,0 +1,137 @@
+#!/usr/bin/env python3
+"""Inference + scoring driver with the reference's command line (sunrgbd/sunrgbd_detection/test_semisup.py: flags
+527-544, get_model 61-180, inference 188-262, predictions layout 509-511).  The SUN-RGBD frustum pickles and the
+box-IoU / MATLAB evaluation are out of scope: `--synthetic` frustums stand in for the dataset
+and the predictions are written as the reference's 14-list (entries that need the dataset are None).
+
+  python -m transferable3d_amd.test_semisup --semi_type F --model semisup_v1_sunrgbd --model_path log_adv/model_epoch_0.npz \
+      --pred_prefix F2_ --refine 2 --use_one_hot --num_point 1024 --num_channels 4 --output preds.pickle --test AB --synthetic
+"""
+import gzip
+import os
+import pickle
+import sys
+
+import numpy as np
+
+if __package__ in (None, ''):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from transferable3d_amd import api, semisup_v1_sunrgbd as MODEL        # noqa: E402
+from transferable3d_amd.config import make_parser                        # noqa: E402
+from transferable3d_amd.constants import NUM_HEADING_BIN, NUM_SIZE_CLUSTER   # noqa: E402
+from transferable3d_amd.synthetic import make_batch                      # noqa: E402
+
+
+def build_flags(argv=None):
+    cfg = make_parser()
+    cfg.add_argument('--test', type=str, nargs='+', default=['AB'])
+    cfg.add_argument('--semi_type', type=str, choices=['A', 'F'], default='F')
+    cfg.add_argument('--gpu', type=int, default=0)
+    cfg.add_argument('--num_point', type=int, default=2048)
+    cfg.add_argument('--model', default='semisup_v1_sunrgbd')
+    cfg.add_argument('--model_path', default=None, help='state dict (.npz) written by train_semisup*.py')
+    cfg.add_argument('--boxpc_model_path', default=None)
+    cfg.add_argument('--pred_prefix', default='F2_')
+    cfg.add_argument('--refine', default=None)
+    cfg.add_argument('--output', default=None)
+    cfg.add_argument('--no_rgb', action='store_true')
+    cfg.add_argument('--mask_pc_for_boxpc', action='store_true')
+    cfg.add_argument('--use_boxpc_fit_prob', action='store_true')
+    cfg.add_argument('--use_one_hot', action='store_true')
+    cfg.add_argument('--batch_size', type=int, default=32)
+    cfg.add_argument('--synthetic', action='store_true')
+    cfg.add_argument('--num_channels', type=int, default=None)
+    cfg.add_argument('--num_frustums', type=int, default=64)
+    cfg.add_argument('--seed', type=int, default=0)
+    FLAGS = cfg.parse_special_args(argv)
+    FLAGS.NUM_CHANNELS = FLAGS.num_channels if FLAGS.num_channels else (3 if FLAGS.no_rgb else 6)
+    FLAGS.SEMI_MODEL = FLAGS.semi_type
+    return FLAGS
+
+
+def get_model(FLAGS, batch_size, num_point, num_channel, rt=None, state_dict=None):
+    """test_semisup.py:61-180: the inference graph; returns (sess, ops)."""
+    if FLAGS.mask_pc_for_boxpc:
+        raise NotImplementedError('--mask_pc_for_boxpc is in no published recipe')
+    FLAGS.SEMI_REFINE_USING_BOXPC_DELTA_NUM = int(FLAGS.refine) if FLAGS.refine is not None else 0
+    FLAGS.SEMI_WEIGH_BOXPC_DELTA_DURING_TEST = False                       # test_semisup.py:93
+    FLAGS.BOX_PC_MASK_REPRESENTATION = 'A'
+    graph = api.Graph(rt=rt, seed=FLAGS.seed)
+    with graph.as_default():
+        pls = MODEL.placeholder_inputs(batch_size, num_point, num_channel)
+        pred, end_points = MODEL.get_semi_model(pls[0], pls[1], pls[2], pls[3], False, use_one_hot=FLAGS.use_one_hot, c=FLAGS)
+        sess = api.Session()
+    if state_dict is not None:
+        graph.vars.load_state_dict(state_dict, strict=False)
+    ops = {'pc_pl': pls[0], 'one_hot_vec_pl': pls[3], 'logits': pred[0], 'end_points': end_points, 'graph': graph}
+    return sess, ops
+
+
+def softmax(x):
+    probs = np.exp(x - np.max(x, axis=len(x.shape) - 1, keepdims=True))
+    probs /= np.sum(probs, axis=len(x.shape) - 1, keepdims=True)
+    return probs
+
+
+def inference(sess, ops, pc, one_hot_vec, batch_size, prefix='', use_boxpc_fit_prob=False):
+    """test_semisup.py:188-262, same return tuple: (pred_seg, centers, orient_cls, orient_reg, dims_cls, dims_reg, scores)."""
+    assert pc.shape[0] % batch_size == 0
+    n = pc.shape[0]
+    logits = np.zeros((n, pc.shape[1], 2))
+    centers = np.zeros((n, 3))
+    heading_logits, heading_residuals = np.zeros((n, NUM_HEADING_BIN)), np.zeros((n, NUM_HEADING_BIN))
+    size_logits, size_residuals = np.zeros((n, NUM_SIZE_CLUSTER)), np.zeros((n, NUM_SIZE_CLUSTER, 3))
+    scores = np.zeros((n,))
+    ep = ops['end_points']
+    for i in range(n // batch_size):
+        sl = slice(i * batch_size, (i + 1) * batch_size)
+        run_ops = [ops['logits'], ep[prefix + 'center'], ep[prefix + 'heading_scores'], ep[prefix + 'heading_residuals'],
+                   ep[prefix + 'size_scores'], ep[prefix + 'size_residuals']]
+        if use_boxpc_fit_prob:
+            run_ops.append(ep['boxpc_fit_prob'])
+        out = sess.run(run_ops, feed_dict={ops['pc_pl']: pc[sl], ops['one_hot_vec_pl']: one_hot_vec[sl]})
+        logits[sl], centers[sl], heading_logits[sl], heading_residuals[sl], size_logits[sl], size_residuals[sl] = out[:6]
+        seg_prob = softmax(out[0])[:, :, 1]
+        seg_mask = np.argmax(out[0], 2)
+        mask_mean_prob = np.sum(seg_prob * seg_mask, 1) / (np.sum(seg_mask, 1) + 1)
+        heading_prob = np.max(softmax(out[2]), 1)
+        size_prob = np.max(softmax(out[4]), 1)
+        s = np.log(mask_mean_prob + 0.01) + np.log(heading_prob + 0.01) + np.log(size_prob + 0.01)
+        if use_boxpc_fit_prob:
+            s = s + np.log(out[6] + 0.01)
+        scores[sl] = s
+    heading_cls, size_cls = np.argmax(heading_logits, 1), np.argmax(size_logits, 1)
+    pred_orient_reg = heading_residuals[np.arange(n), heading_cls]
+    pred_dims_reg = size_residuals[np.arange(n), size_cls, :]
+    return np.argmax(logits, 2), centers, heading_cls, pred_orient_reg, size_cls, pred_dims_reg, scores
+
+
+def test(FLAGS, rt=None, log=print):
+    B, N, C = FLAGS.batch_size, FLAGS.num_point, FLAGS.NUM_CHANNELS
+    sd = dict(np.load(FLAGS.model_path)) if FLAGS.model_path else None
+    if FLAGS.boxpc_model_path:
+        sd = dict(sd or {})
+        sd.update({'D_boxpc_branch/' + k: v for k, v in np.load(FLAGS.boxpc_model_path).items()})
+    sess, ops = get_model(FLAGS, B, N, C, rt=rt, state_dict=sd)
+    n = (FLAGS.num_frustums + B - 1) // B * B                     # the reference pads the last batch (test_semisup.py:450-471)
+    batches = [make_batch(B, N, C, seed=FLAGS.seed * 1000003 + i) for i in range(n // B)]
+    pc = np.concatenate([b['pc'] for b in batches])
+    oh = np.concatenate([b['one_hot_vec'] for b in batches])
+    seg_gt = np.concatenate([b['y_seg'] for b in batches])
+    seg, centers, hcls, hres, scls, sres, scores = inference(sess, ops, pc, oh, B, prefix=FLAGS.pred_prefix,
+                                                             use_boxpc_fit_prob=FLAGS.use_boxpc_fit_prob)
+    iou = np.mean([(np.logical_and(seg[i], seg_gt[i]).sum() + 1e-9) / (np.logical_or(seg[i], seg_gt[i]).sum() + 1e-9) for i in range(n)])
+    log('Mean segmentation IOU: %f' % iou)
+    # test_semisup.py:509-511: [ps, seg_gt, seg_pred, center, heading_cls, heading_res, size_cls, size_res, rot_angle, score, cls,
+    #                           file_num, box2d, box3d]
+    predictions = [list(pc), list(seg_gt), list(seg), list(centers), list(hcls), list(hres), list(scls), list(sres), None,
+                   list(scores), list(np.argmax(oh, 1)), None, None, None]
+    if FLAGS.output:
+        with gzip.open(FLAGS.output, 'wb') as f:
+            pickle.dump(predictions, f, -1)
+        log('predictions written to %s' % FLAGS.output)
+    return predictions
+
+
+if __name__ == '__main__':
+    test(build_flags())
