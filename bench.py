@@ -212,14 +212,15 @@ def main():
         torch.cuda.synchronize()
         s = torch.cuda.Stream()
         g1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1, stream=s):
+        # thread_local: calls of other threads (the RCCL watchdog) during capture must not invalidate it
+        with torch.cuda.graph(g1, stream=s, capture_error_mode='thread_local'):
             run_compute()
             if world == 1:
                 g.opt.run()
         g2 = None
         if world > 1:
             g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, stream=s):
+            with torch.cuda.graph(g2, stream=s, capture_error_mode='thread_local'):
                 g.opt.run()
 
     def step():

@@ -261,7 +261,7 @@ class _Step:
             torch.cuda.synchronize()
             s = torch.cuda.Stream()
             g1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1, stream=s):
+            with torch.cuda.graph(g1, stream=s, capture_error_mode='thread_local'):
                 if self.train:
                     self.pre.run()
                 self.fwd.run()
@@ -272,7 +272,7 @@ class _Step:
             g2 = None
             if self.train and multi:
                 g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2, stream=s):
+                with torch.cuda.graph(g2, stream=s, capture_error_mode='thread_local'):
                     self.opt.run()
             self.graphs = (g1, g2)
         g1, g2 = self.graphs
