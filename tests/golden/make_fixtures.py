@@ -43,6 +43,45 @@ def model_a(B=4, N=128, C=4, seed=11, pseed=5):
     np.savez_compressed(os.path.join(HERE, 'model_a_B%d_N%d.npz' % (B, N)), **out)
 
 
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+
+def boxpc(B=4, N=256, C=4):
+    """Box-PC Fit net step (config 2) on the inputs of tests/test_boxpc_cpu.py: outputs, loss, gradient norms."""
+    import test_boxpc_cpu as TB
+    batch = make_batch(B, N, C, seed=3, boxpc=True, dropout_scopes=TB.SCOPES(B))
+    P = R.init_params(np.random.RandomState(5), R.layer_table(C, 'boxpc'))
+    c = R.default_config(BOXPC_WEIGHT_DELTA=4.0)
+    loss, ep, grads, _ = R.boxpc_forward_backward(P, batch, c)
+    out = {'out/loss': np.float64(loss.detach()), 'out/boxpc_out': ep['boxpc_out'].detach().numpy()}
+    for k, g in grads.items():
+        out['gradnorm/' + k] = np.float64(g.norm())
+    np.savez_compressed(os.path.join(HERE, 'boxpc_B%d_N%d.npz' % (B, N)), **out)
+
+
+def stage_c(B=4, N=256, C=4, refine=2):
+    """Stage-c step (config 3) on the inputs of tests/test_stage_c_cpu.py, and the inference graph with `refine` Box-PC
+    refinement steps (test_semisup.py) on the same weights."""
+    import test_stage_c_cpu as TC
+    P = TC.stage_c_params(C, 21)
+    batch = TC.stage_c_batch(B, N, C, 22, 2)
+    c = TC.stage_c_config()
+    loss, ep, grads, _ = R.stage_c_forward_backward(P, batch, c, TC.TRAIN_CLASSES)
+    out = {'out/loss': np.float64(loss.detach()), 'out/boxpc_fit_prob': ep['boxpc_fit_prob'].detach().numpy(),
+           'out/F_center': ep['F_center'].detach().numpy()}
+    for k, g in grads.items():
+        out['gradnorm/' + k] = np.float64(g.norm())
+    _, epi = R.stage_c_inference(P, batch, c, refine)
+    out['infer/refine'] = np.int64(refine)
+    for k in ('F2_center', 'F2_heading_residuals', 'F2_size_residuals', 'boxpc_fit_prob'):
+        out['infer/' + k] = epi[k].detach().numpy()
+    out['infer/score'] = R.inference_scores(epi['logits'].detach().numpy(), epi['F2_heading_scores'].detach().numpy(),
+                                            epi['F2_size_scores'].detach().numpy(), epi['boxpc_fit_prob'].detach().numpy())
+    np.savez_compressed(os.path.join(HERE, 'stage_c_B%d_N%d.npz' % (B, N)), **out)
+
+
 if __name__ == '__main__':
     model_a()
+    boxpc()
+    stage_c()
     print('fixtures written to', HERE)

@@ -160,3 +160,49 @@ def check_stage_c_inference(rt, refine):
                                         num(ep['boxpc_fit_prob']) if refine else None)
         assert np.abs(scores[sl] - ref_scores).max() < 1e-3
         assert (seg[sl] == np.argmax(num(ep['logits']), 2)).mean() > 0.999
+
+
+def check_golden_boxpc(rt):
+    """Committed vectors of the Box-PC Fit net step (tests/golden/boxpc_B4_N256.npz, make_fixtures.boxpc)."""
+    import test_boxpc_cpu as TB
+    from transferable3d_amd.synthetic import make_batch
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'boxpc_B4_N256.npz'))
+    B, N, C = 4, 256, 4
+    batch = make_batch(B, N, C, seed=3, boxpc=True, dropout_scopes=TB.SCOPES(B))
+    P = R.init_params(np.random.RandomState(5), R.layer_table(C, 'boxpc'))
+    g, m = TB.run_boxpc(rt, batch, P, R.default_config(BOXPC_WEIGHT_DELTA=4.0))
+    e = m.end_points()
+    assert np.abs(e['boxpc_out'].detach().cpu().numpy() - z['out/boxpc_out']).max() < 1e-4
+    assert abs(float(e['loss'].cpu()) - float(z['out/loss'])) < 1e-4 * float(z['out/loss'])
+    rel = [abs(float(g.vars.grad(k[9:]).norm()) - float(z[k])) / max(float(z[k]), 1e-12) for k in z.files
+           if k.startswith('gradnorm/') and float(z[k]) > 1e-9]
+    assert np.median(rel) < 1e-4 and max(rel) < 5e-2, (np.median(rel), max(rel))
+
+
+def check_golden_stage_c(rt):
+    """Committed vectors of the stage-c step and of the inference graph with two Box-PC refinement steps
+    (tests/golden/stage_c_B4_N256.npz, make_fixtures.stage_c)."""
+    import test_stage_c_cpu as TC
+    from transferable3d_amd import test_semisup as TS
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'stage_c_B4_N256.npz'))
+    B, N, C = 4, 256, 4
+    P, batch, c = TC.stage_c_params(C, 21), TC.stage_c_batch(B, N, C, 22, 2), TC.stage_c_config()
+    g, m = TC.run_stage_c(rt, batch, P, c)
+    e = m.end_points()
+    num = lambda t: t.detach().cpu().numpy()
+    assert np.abs(num(e['F_center']) - z['out/F_center']).max() < 1e-4
+    assert np.abs(num(e['boxpc_fit_prob']) - z['out/boxpc_fit_prob']).max() < 1e-4
+    assert abs(float(num(e['loss'])) - float(z['out/loss'])) < 1e-4 * float(z['out/loss'])
+    rel = [abs(float(g.vars.grad(k[9:]).norm()) - float(z[k])) / max(float(z[k]), 1e-12) for k in z.files
+           if k.startswith('gradnorm/') and float(z[k]) > 1e-9]
+    assert np.median(rel) < 2e-4 and max(rel) < 5e-2, (np.median(rel), max(rel))
+    refine = int(z['infer/refine'])
+    FLAGS = TS.build_flags(['--semi_type', 'F', '--use_one_hot', '--num_point', str(N), '--num_channels', str(C), '--batch_size', str(B),
+                            '--refine', str(refine), '--use_boxpc_fit_prob'])
+    sess, ops = TS.get_model(FLAGS, B, N, C, rt=rt, state_dict={k: v.numpy() for k, v in P.items()})
+    _, centers, hcls, hres, scls, sres, scores = TS.inference(sess, ops, batch['pc'], batch['one_hot_vec'], B, prefix='F2_',
+                                                              use_boxpc_fit_prob=True)
+    assert np.abs(centers - z['infer/F2_center']).max() < 1e-4
+    assert np.abs(hres - z['infer/F2_heading_residuals'][np.arange(B), hcls]).max() < 1e-4
+    assert np.abs(sres - z['infer/F2_size_residuals'][np.arange(B), scls]).max() < 1e-4
+    assert np.abs(scores - z['infer/score']).max() < 1e-3

@@ -53,3 +53,8 @@ def test_boxpc_plan_matches_oracle():
     assert sum(P[k].numel() for k in R.trainable_names(P)) == 582409 + (C - 4) * 128     # SURVEY 8(a) a15 (C+6=10)
     g, m = run_boxpc(Runtime(device='cpu', lib=FakeLib()), batch, P, c)
     check_boxpc(g, m, batch, P, c)
+
+
+def test_boxpc_matches_golden_vectors():
+    from model_check import check_golden_boxpc
+    check_golden_boxpc(Runtime(device='cpu', lib=FakeLib()))

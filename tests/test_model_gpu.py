@@ -126,3 +126,9 @@ def test_inference_graph_with_iterated_boxpc_refinement(hip_lib, refine):
     """test_semisup.py inference graph (SEMI_MODEL F, inference-mode batch-norm, `--refine` Box-PC steps) + scoring."""
     from model_check import check_stage_c_inference
     check_stage_c_inference(Runtime(lib=hip_lib), refine)
+
+
+def test_boxpc_and_stage_c_match_golden_vectors(hip_lib):
+    from model_check import check_golden_boxpc, check_golden_stage_c
+    check_golden_boxpc(Runtime(lib=hip_lib))
+    check_golden_stage_c(Runtime(lib=hip_lib))

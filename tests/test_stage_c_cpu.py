@@ -102,3 +102,8 @@ def test_stage_c_all_3d_batch_has_zero_fit_and_intraclass_terms():
 def test_inference_graph_with_iterated_boxpc_refinement(refine):
     from model_check import check_stage_c_inference
     check_stage_c_inference(Runtime(device='cpu', lib=FakeLib()), refine)
+
+
+def test_stage_c_and_inference_match_golden_vectors():
+    from model_check import check_golden_stage_c
+    check_golden_stage_c(Runtime(device='cpu', lib=FakeLib()))
