@@ -957,3 +957,41 @@ def test_box_refine_step(hip_lib, weigh, first):
     c, g = _run_both(hip_lib, make, 't3d_box_refine_step')
     for k in c:
         _close(c[k], g[k], 1e-5, 1e-6, 'refine_step ' + k)
+
+
+@pytest.mark.parametrize('M,K,N,rpf,masked', [(512, 128, 1024, 256, True), (1024, 256, 512, 512, True), (256, 128, 256, 128, False),
+                                              (32768, 128, 1024, 1024, True)])
+def test_pooled_forward_kernel_equals_generic_kernel(hip_lib, M, K, N, rpf, masked):
+    """y = NULL on a pooled layer with K in {128, 256} takes the A-resident persistent kernel; with a y buffer the generic
+    kernel runs.  Same accumulation and reduction order by construction: statistics and pool partials bit-identical."""
+    r = np.random.RandomState(M + K + N)
+    dev = _dev('cuda')
+    T, B = M // 128, M // rpf
+    t = {k: _mk(dev, v) for k, v in dict(
+        x=r.normal(size=(M, K)).astype(np.float32), sc=(0.5 + r.uniform(size=K)).astype(np.float32) * np.where(r.uniform(size=K) < 0.2, -1, 1).astype(np.float32),
+        sh=(r.normal(size=K) * 0.3).astype(np.float32), w=(r.normal(size=(K, N)) / np.sqrt(K)).astype(np.float32),
+        bias=(r.normal(size=N) * 0.1).astype(np.float32), rb=r.normal(size=(B, N)).astype(np.float32),
+        mask=(r.uniform(size=M) < 0.4).astype(np.float32)).items()}
+    t['mask'][:128] = 0
+    outs = []
+    for store in (True, False):
+        o = {k: torch.zeros(T, N, device=dev) for k in ('psum', 'psumsq', 'pmax', 'pmin')}
+        o.update(pamax=torch.zeros(T, N, dtype=torch.int32, device=dev), pamin=torch.zeros(T, N, dtype=torch.int32, device=dev))
+        y = torch.zeros(M, N, device=dev)
+        a = abi.PointMlpFwdArgs()
+        a.a = abi.ActSrc(fptr(t['x']), K, 0, fptr(t['sc']), fptr(t['sh']), 1, fptr(None), 0)
+        a.w, a.bias, a.rowbias, a.y = fptr(t['w']), fptr(t['bias']), fptr(t['rb']), fptr(y if store else None)
+        a.psum, a.psumsq = fptr(o['psum']), fptr(o['psumsq'])
+        if masked:
+            a.rowmask = fptr(t['mask'])
+        a.pmax, a.pmin, a.pamax, a.pamin = fptr(o['pmax']), fptr(o['pmin']), iptr(o['pamax']), iptr(o['pamin'])
+        a.M, a.K, a.N, a.rows_per_frustum = M, K, N, rpf
+        assert hip_lib.t3d_pointmlp_fwd(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+        torch.cuda.synchronize()
+        outs.append({k: v.cpu() for k, v in o.items()})
+    valid = outs[0]['pamax'] >= 0
+    assert torch.equal(outs[0]['pamax'], outs[1]['pamax']) and torch.equal(outs[0]['pamin'], outs[1]['pamin'])
+    for k in ('psum', 'psumsq'):
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    assert torch.equal(outs[0]['pmax'][valid], outs[1]['pmax'][valid]) and torch.equal(outs[0]['pmin'][valid], outs[1]['pmin'][valid])
+    assert int(valid.sum()) > 0

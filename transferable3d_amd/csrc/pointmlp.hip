@@ -14,6 +14,7 @@
 #include "common.h"
 #include "poolbwd_dev.h"
 
+#include <cstdlib>
 #include <mutex>
 #include <unordered_map>
 
@@ -804,6 +805,281 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pool_bwd_stage2(const t3d_poo
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// forward of a max-pooled layer (K = 128 or 256 input channels, no [M,N] store): A-resident, persistent over n
+// ---------------------------------------------------------------------------------------------
+// The pooled layers are the widest (N = 1024 / 512 / 256 columns from K = 128 / 256 inputs) and keep nothing but
+// column statistics and pool partials.  One workgroup owns a 128-row tile for ALL column tiles: the activated input
+// panel act(a)[128,K] is staged into LDS once (instead of once per column tile), only the weight tiles stream through
+// the two-stage pipeline, the MFMA stream never drains between column tiles, and the epilogue of column tile j
+// (statistics, masked max/min + arg-max over the tile's rows) runs in the MFMA shadows of column tile j+1 on a copy
+// of the accumulators.  One barrier per k-tile; the cross-wave combination of the epilogue rides on those barriers.
+template <int K, int BKB, int NW>
+struct FwdPool {
+  // NW waves per workgroup: 4 = 2x2 waves of 64x64, one wave per SIMD; 8 = 2x4 waves of 64x32, two waves per SIMD (the
+  // side work of one -- weight staging, the running epilogue, barrier waits -- hides under the MFMAs of the other)
+  static constexpr int NTP = 64 * NW, WN = NW / 2, TN = 64 / (32 * (WN / 2)), WCOLS = 128 / WN;
+  static constexpr int LDA = K + 4, KT = K / BKB, G = BKB / 8, SLOTS = G * 4, NVB = BKB * 32 / NTP;
+  static constexpr int NQUADS = 8 * TN, QSTRIDE = SLOTS >= NQUADS ? SLOTS / NQUADS : 1;
+  static constexpr int EPI_TILES = SLOTS >= NQUADS ? 1 : NQUADS / SLOTS;   // k-tiles over which the epilogue quads are spread
+  static constexpr int A_FLOATS = 128 * LDA, B_FLOATS = BKB * 128, RED_FLOATS = 6 * 2 * 128;
+  static constexpr size_t LDS_BYTES = (size_t)(A_FLOATS + 2 * B_FLOATS + RED_FLOATS) * sizeof(float);
+  static_assert(KT % 2 == 0, "the LDS stage of a k-tile is a compile-time constant");
+  static_assert(NVB >= 1 && EPI_TILES < KT, "tile shape");
+
+  struct Epi {                       // per-lane column accumulators of the tile being finished
+    float s[TN], ss[TN], mx[TN], mn[TN];
+    int ax[TN], an[TN];
+  };
+
+  const t3d_pointmlp_fwd_args& p;
+  float* Ap; float* Bst; float* red;
+  int tid, lane, l31, h, wm, wn, row0, tile_m, rin_base;
+  unsigned keepbits;
+  float4 braw[NVB];
+
+  __device__ __forceinline__ void fetch_b(int nt, int kt) {
+#pragma unroll
+    for (int q = 0; q < NVB; ++q) {
+      const int f = tid + NTP * q, kr = f >> 5, c4 = (f & 31) * 4;
+      braw[q] = *reinterpret_cast<const float4*>(p.w + (size_t)(kt * BKB + kr) * p.N + nt * 128 + c4);
+    }
+  }
+  __device__ __forceinline__ void store_b_piece(int stage, int q) {
+    const int f = tid + NTP * q, kr = f >> 5, c4 = (f & 31) * 4;
+    *reinterpret_cast<float4*>(Bst + stage * B_FLOATS + kr * 128 + c4) = braw[q];
+  }
+
+  // epilogue phase A, one quad = 4 accumulator elements of one (tn, tm): same visiting order as k_pointmlp_fwd
+  __device__ __forceinline__ void epi_quad(const f32x16 (&accp)[2][TN], Epi& e, const float (&add)[TN], int quad) {
+    const int tn = quad >> 3, tm = (quad >> 2) & 1, rq = quad & 3;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = rq * 4 + j;
+      const float v = accp[tm][tn][r] + add[tn];
+      e.s[tn] += v;
+      e.ss[tn] = fmaf(v, v, e.ss[tn]);
+      const bool keep = (keepbits >> (tm * 16 + r)) & 1u;
+      const int rin = rin_base + tm * 32 + (r & 3) + 8 * (r >> 2);
+      // selects, not branches: this code sits between MFMAs and must stay one basic block
+      const bool up = keep & (v > e.mx[tn]), dn = keep & (v < e.mn[tn]);
+      e.mx[tn] = up ? v : e.mx[tn];
+      e.ax[tn] = up ? rin : e.ax[tn];
+      e.mn[tn] = dn ? v : e.mn[tn];
+      e.an[tn] = dn ? rin : e.an[tn];
+    }
+  }
+  __device__ __forceinline__ void epi_reset(Epi& e) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) { e.s[tn] = 0.f; e.ss[tn] = 0.f; e.mx[tn] = -INFINITY; e.mn[tn] = INFINITY; e.ax[tn] = -1; e.an[tn] = -1; }
+  }
+  // end of phase A: combine the two lane halves (rows +4), lower row index wins ties; lanes h == 0 publish to LDS
+  __device__ __forceinline__ void epi_publish(Epi& e) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      e.s[tn] += __shfl_xor(e.s[tn], 32, 64);
+      e.ss[tn] += __shfl_xor(e.ss[tn], 32, 64);
+      const float omx = __shfl_xor(e.mx[tn], 32, 64), omn = __shfl_xor(e.mn[tn], 32, 64);
+      const int oax = __shfl_xor(e.ax[tn], 32, 64), oan = __shfl_xor(e.an[tn], 32, 64);
+      const bool tx = (oax >= 0) & ((omx > e.mx[tn]) | (e.ax[tn] < 0) | ((omx == e.mx[tn]) & (oax < e.ax[tn])));
+      const bool tn_ = (oan >= 0) & ((omn < e.mn[tn]) | (e.an[tn] < 0) | ((omn == e.mn[tn]) & (oan < e.an[tn])));
+      e.mx[tn] = tx ? omx : e.mx[tn];
+      e.ax[tn] = tx ? oax : e.ax[tn];
+      e.mn[tn] = tn_ ? omn : e.mn[tn];
+      e.an[tn] = tn_ ? oan : e.an[tn];
+      if (h == 0) {
+        const int c = wn * WCOLS + tn * 32 + l31;
+        red[(0 * 2 + wm) * 128 + c] = e.s[tn];
+        red[(1 * 2 + wm) * 128 + c] = e.ss[tn];
+        red[(2 * 2 + wm) * 128 + c] = e.mx[tn];
+        red[(3 * 2 + wm) * 128 + c] = e.mn[tn];
+        reinterpret_cast<int*>(red)[(4 * 2 + wm) * 128 + c] = e.ax[tn];
+        reinterpret_cast<int*>(red)[(5 * 2 + wm) * 128 + c] = e.an[tn];
+      }
+    }
+  }
+  // phase B (after a barrier): the two row halves of the tile -> global partials of column tile `nt`
+  __device__ __forceinline__ void epi_write(int nt) {
+    if (tid < 128) {
+      const int c = tid;
+      const size_t o = (size_t)tile_m * p.N + nt * 128 + c;
+      p.psum[o] = red[(0 * 2 + 0) * 128 + c] + red[(0 * 2 + 1) * 128 + c];
+      p.psumsq[o] = red[(1 * 2 + 0) * 128 + c] + red[(1 * 2 + 1) * 128 + c];
+      float mx = red[(2 * 2 + 0) * 128 + c], mn = red[(3 * 2 + 0) * 128 + c];
+      int ax = reinterpret_cast<int*>(red)[(4 * 2 + 0) * 128 + c], an = reinterpret_cast<int*>(red)[(5 * 2 + 0) * 128 + c];
+      const float mx1 = red[(2 * 2 + 1) * 128 + c], mn1 = red[(3 * 2 + 1) * 128 + c];
+      const int ax1 = reinterpret_cast<int*>(red)[(4 * 2 + 1) * 128 + c], an1 = reinterpret_cast<int*>(red)[(5 * 2 + 1) * 128 + c];
+      if (ax1 >= 0 && (ax < 0 || mx1 > mx)) { mx = mx1; ax = ax1; }
+      if (an1 >= 0 && (an < 0 || mn1 < mn)) { mn = mn1; an = an1; }
+      p.pmax[o] = mx; p.pmin[o] = mn; p.pamax[o] = ax; p.pamin[o] = an;
+    }
+  }
+  __device__ __forceinline__ void load_add(int nt, float (&add)[TN]) {
+    const int b = row0 / p.rows_per_frustum;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = nt * 128 + wn * WCOLS + tn * 32 + l31;
+      float a = p.bias ? p.bias[col] : 0.f;
+      if (p.rowbias) a += p.rowbias[(size_t)b * p.N + col];
+      add[tn] = a;
+    }
+  }
+
+  // one k-tile: MFMAs of (nt, KT_IDX) from stage KT_IDX & 1; fillers: the B tile of the next k-tile into the other
+  // stage (second half of the slots) and, when HAS_PREV, the epilogue quads of the previous column tile.
+  template <int KT_IDX, bool HAS_PREV>
+  __device__ __forceinline__ void ktile(f32x16 (&acc)[2][TN], const f32x16 (&accp)[2][TN], Epi& e, const float (&addp)[TN], int nt,
+                                        int n_tiles) {
+    constexpr int stage = KT_IDX & 1;
+    const float* Bs = Bst + stage * B_FLOATS;
+    float fa[2][2][4], fb[2][TN][4];
+    auto load_frags = [&](int g, int buf) {
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) {
+        const float4 v = *reinterpret_cast<const float4*>(Ap + (wm * 64 + tm * 32 + l31) * LDA + KT_IDX * BKB + 8 * g + 4 * h);
+        fa[buf][tm][0] = v.x; fa[buf][tm][1] = v.y; fa[buf][tm][2] = v.z; fa[buf][tm][3] = v.w;
+      }
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fb[buf][tn][i] = Bs[(8 * g + 4 * h + i) * 128 + wn * WCOLS + tn * 32 + l31];
+    };
+    if (HAS_PREV && KT_IDX == EPI_TILES) epi_write(nt - 1);          // phase B: partials published one barrier ago
+    load_frags(0, 0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if (g + 1 < G) load_frags(g + 1, (g + 1) & 1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][tm][i], fb[g & 1][tn][i], acc[tm][tn], 0, 0, 0);
+        const int slot = g * 4 + i;
+#ifndef T3D_ABL_FP_NOSTAGE
+        if (slot >= SLOTS / 2 && slot - SLOTS / 2 < NVB) store_b_piece(stage ^ 1, slot - SLOTS / 2);
+#endif
+        if (HAS_PREV && KT_IDX < EPI_TILES) {
+          const int sidx = KT_IDX * SLOTS + slot;
+          if (sidx % QSTRIDE == 0 && sidx / QSTRIDE < NQUADS) epi_quad(accp, e, addp, sidx / QSTRIDE);
+        }
+        // one MFMA cluster + its share of the side work per scheduling region: left alone, the scheduler gathers the
+        // epilogue's VALU into one long run that starves the matrix pipe
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (HAS_PREV && KT_IDX == EPI_TILES - 1) epi_publish(e);
+    __builtin_amdgcn_sched_barrier(0);
+    // loads of the tile after next (clamped past the end: re-reads the last tile)
+    {
+      int nt2 = nt, kt2 = KT_IDX + 2;
+      if (kt2 >= KT) { kt2 -= KT; nt2 = min(nt + 1, n_tiles - 1); }
+#ifndef T3D_ABL_FP_NOSTAGE
+      fetch_b(nt2, kt2);
+#endif
+    }
+    __syncthreads();
+  }
+
+  template <int KT_IDX, bool HAS_PREV>
+  __device__ __forceinline__ void ktiles(f32x16 (&acc)[2][TN], const f32x16 (&accp)[2][TN], Epi& e, const float (&addp)[TN], int nt,
+                                         int n_tiles) {
+    if constexpr (KT_IDX < KT) {
+      ktile<KT_IDX, HAS_PREV>(acc, accp, e, addp, nt, n_tiles);
+      ktiles<KT_IDX + 1, HAS_PREV>(acc, accp, e, addp, nt, n_tiles);
+    }
+  }
+};
+
+template <int K, int BKB, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 4) void k_pointmlp_fwd_pool(const t3d_pointmlp_fwd_args p) {
+  using F = FwdPool<K, BKB, NW>;
+  constexpr int TN = F::TN, NTP = F::NTP;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  F f{p, smem, smem + F::A_FLOATS, smem + F::A_FLOATS + 2 * F::B_FLOATS, tid, lane, lane & 31, lane >> 5, wid / F::WN, wid % F::WN,
+      0, 0, 0, 0u, {}};
+  f.tile_m = xcd_remap(blockIdx.x, gridDim.x);
+  f.row0 = f.tile_m * 128;
+  const int b = f.row0 / p.rows_per_frustum;
+  f.rin_base = f.row0 - b * p.rows_per_frustum + f.wm * 64 + 4 * f.h;
+  const int n_tiles = p.N / 128;
+
+  // ---- prologue: the activated input panel, once ----
+  {
+    ActLoader<false> la{p.a, K, p.rows_per_frustum};
+    constexpr int CH = K / 4, NVA = 128 * CH / NTP;       // float4 chunks per row / per thread
+    static_assert(NTP % CH == 0, "a thread keeps its column chunk");
+    const int c4 = (tid % CH) * 4;
+    const typename ActLoader<false>::Coef coef = la.fetch_coef(c4);
+    typename ActLoader<false>::Raw raw[NVA];
+#pragma unroll
+    for (int q = 0; q < NVA; ++q) raw[q] = la.fetch(f.row0 + (tid + NTP * q) / CH, c4);
+    f.fetch_b(0, 0);
+#pragma unroll
+    for (int q = 0; q < NVA; ++q) {
+      const int r = (tid + NTP * q) / CH;
+      *reinterpret_cast<float4*>(f.Ap + r * F::LDA + c4) = la.xform(raw[q], coef, f.row0 + r, c4);
+    }
+#pragma unroll
+    for (int q = 0; q < F::NVB; ++q) f.store_b_piece(0, q);
+    f.fetch_b(0, 1);
+    // keep flags of this lane's 32 rows (the same rows for every column tile)
+    unsigned bits = 0xffffffffu;
+    if (p.rowmask) {
+      bits = 0u;
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = f.row0 + f.wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * f.h;
+          bits |= (p.rowmask[row] != 0.f ? 1u : 0u) << (tm * 16 + r);
+        }
+    }
+    f.keepbits = bits;
+  }
+  __syncthreads();
+
+  f32x16 acc[2][TN], accp[2][TN];
+  zero_acc<2, TN>(acc);
+  zero_acc<2, TN>(accp);
+  typename F::Epi e;
+  // bias (+ row bias) of a column tile is requested one whole column tile before its epilogue needs it: a wait on it
+  // then never drags in the weight-tile loads that were issued only one barrier ago
+  float addp[TN], addn[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) addp[tn] = 0.f;
+  f.load_add(0, addn);
+  f.template ktiles<0, false>(acc, accp, e, addp, 0, n_tiles);
+  for (int nt = 1; nt < n_tiles; ++nt) {
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) { accp[tm][tn] = acc[tm][tn]; }
+    zero_acc<2, TN>(acc);
+    f.epi_reset(e);
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) addp[tn] = addn[tn];
+    f.load_add(nt, addn);
+#ifdef T3D_ABL_FP_NOEPI
+    f.template ktiles<0, false>(acc, accp, e, addp, nt, n_tiles);
+#else
+    f.template ktiles<0, true>(acc, accp, e, addp, nt, n_tiles);
+#endif
+  }
+  // the last column tile: its epilogue has no MFMAs left to hide under
+  f.epi_reset(e);
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) addp[tn] = addn[tn];
+#pragma unroll
+  for (int quad = 0; quad < F::NQUADS; ++quad) f.epi_quad(acc, e, addp, quad);
+  __syncthreads();                   // phase B of tile n_tiles-2 has read `red`
+  f.epi_publish(e);
+  __syncthreads();
+  f.epi_write(n_tiles - 1);
+}
+
 // dynamic-LDS launch: two pipeline stages exceed the 64 KB static limit for the 128-wide tiles
 // > 64 KB of dynamic LDS needs the function attribute; set once per kernel and size (a driver call per launch would
 // sit on the host path of every eager launch)
@@ -847,6 +1123,29 @@ extern "C" int t3d_pointmlp_fwd(const t3d_pointmlp_fwd_args* a, t3d_stream_t str
   const int tiles_m = a->M / 128;
   // 128-wide column tiles only when they still give >= 2 workgroups per CU
   const bool sub = a->a.sub != nullptr;
+  // max-pooled layer without an output tensor: the A-resident persistent kernel (T3D_FWD_POOL=0: the generic one)
+  static const bool use_pool_kernel = []() { const char* e = getenv("T3D_FWD_POOL"); return !(e && e[0] == '0'); }();
+  // K = 256 needs 16-deep weight tiles to fit the 133 KB panel next to them and measured slower than the generic kernel
+  // (109 vs 100 us on 256->512); K = 128: 92 vs 100 us on 128->1024, 26 vs 33 us on 128->256.  T3D_FWD_POOL=2 forces it on.
+  static const bool fp_k256 = []() { const char* e = getenv("T3D_FWD_POOL"); return e && e[0] == '2'; }();
+  if (use_pool_kernel && !a->y && a->pmax && !sub && a->N % 128 == 0 && a->N >= 256 && (a->K == 128 || (a->K == 256 && fp_k256))) {
+#ifndef T3D_FP_WAVES
+#define T3D_FP_WAVES 8
+#endif
+    if (a->K == 128) {
+      auto kern = k_pointmlp_fwd_pool<128, 32, T3D_FP_WAVES>;
+      constexpr size_t lds = FwdPool<128, 32, T3D_FP_WAVES>::LDS_BYTES;
+      allow_lds(reinterpret_cast<const void*>(kern), lds);
+      T3D_LAUNCH(kern, dim3(tiles_m), dim3(64 * T3D_FP_WAVES), lds, s, *a);
+    } else {
+      auto kern = k_pointmlp_fwd_pool<256, 16, T3D_FP_WAVES>;
+      constexpr size_t lds = FwdPool<256, 16, T3D_FP_WAVES>::LDS_BYTES;
+      allow_lds(reinterpret_cast<const void*>(kern), lds);
+      T3D_LAUNCH(kern, dim3(tiles_m), dim3(64 * T3D_FP_WAVES), lds, s, *a);
+    }
+    T3D_CHECK_LAUNCH();
+    return T3D_OK;
+  }
   if (T3D_FORCE_TILE != 64 && a->N % 128 == 0 && (T3D_FORCE_TILE == 128 || (long)tiles_m * (a->N / 128) >= 512)) {
     const dim3 grid(tiles_m * (a->N / 128));
     if (sub) launch_lds(k_pointmlp_fwd<128, true>, grid, lds_fwd(128), s, *a);
