@@ -124,6 +124,12 @@ typedef struct {
   float* shift;          /* [N] out */
   float* mean;           /* [N] out (saved for backward) */
   float* invstd;         /* [N] out */
+  /* optional: K3 (t3d_pool_finalize) for the same channels in the same launch; pool_pmax == NULL: none */
+  const float* pool_pmax; const float* pool_pmin; const int32_t* pool_pamax; const int32_t* pool_pamin;
+  int pool_B, pool_tiles_per_frustum;
+  float* pooled; int ld_pooled;      /* [B, ld_pooled] */
+  int32_t* argidx;                   /* [B,N] */
+  float* ysel;                       /* [B,N] */
 } t3d_bn_fwd_finalize_args;
 int t3d_bn_fwd_finalize(const t3d_bn_fwd_finalize_args* args, t3d_stream_t stream);
 
@@ -372,6 +378,16 @@ typedef struct {
   float alpha;
   float* din; int ld_din;
   int B, K;
+  /* optional: the pooled form of K11c (t3d_bn_bwd_finalize) on din's columns in the same launch -- din is the gradient
+   * of a max-pooled feature and column k is all that channel k's batch-norm backward needs; bn_coef == NULL: none */
+  const float* bn_pooled; int bn_ld_pooled;   /* [B, ld] */
+  const float* bn_ysel;                       /* [B,K] */
+  float* bn_dpool;                            /* [B,K] out */
+  int bn_count;
+  const float* bn_gamma; const float* bn_mean; const float* bn_invstd; const float* bn_scale;
+  int bn_frozen;
+  float* bn_dgamma; float* bn_dbeta;          /* [K] or NULL */
+  float* bn_coef;                             /* [3,K] out */
 } t3d_fc_dinput_args;
 int t3d_fc_dinput(const t3d_fc_dinput_args* args, t3d_stream_t stream);
 
@@ -563,6 +579,9 @@ int t3d_box_refine_step(const t3d_box_refine_step_args* args, t3d_stream_t strea
 typedef struct { int64_t slab_off; int64_t grad_off; int32_t numel; int32_t n_slabs; } t3d_slab_desc;
 int t3d_reduce_slabs(const float* slab_base, float* grad_base, const t3d_slab_desc* table_dev,
                      int n_tensors, int max_numel, t3d_stream_t stream);
+/* t3d_reduce_slabs + t3d_pool_sparse_rows (both wait only for stage 1) in one launch. */
+int t3d_pool_bwd_mid(const float* slab_base, float* grad_base, const t3d_slab_desc* table_dev, int n_tensors, int max_numel,
+                     const t3d_pool_sparse_rows_args* sparse, t3d_stream_t stream);
 
 /* hyper[0] = step (as float, incremented), [1] = lr, [2] = bn_decay, [3] = adam lr_t.
  * Replaces tf.train.exponential_decay(staircase) for lr and bn momentum (train_semisup.py:127-145)

@@ -117,6 +117,12 @@ class FakeLib:
         arr(p.shift, N)[:] = b - mean * g * invstd
         arr(p.mean, N)[:] = mean
         arr(p.invstd, N)[:] = invstd
+        if p.pool_pmax:
+            q = abi.PoolFinalizeArgs()
+            q.scale, q.shift, q.pmax, q.pmin, q.pamax, q.pamin = p.scale, p.shift, p.pool_pmax, p.pool_pmin, p.pool_pamax, p.pool_pamin
+            q.B, q.N, q.tiles_per_frustum = p.pool_B, N, p.pool_tiles_per_frustum
+            q.pooled, q.ld_pooled, q.argidx, q.ysel = p.pooled, p.ld_pooled, p.argidx, p.ysel
+            return self.t3d_pool_finalize(C.byref(q), stream)
         return 0
 
     def t3d_pool_finalize(self, a, stream):
@@ -271,6 +277,9 @@ class FakeLib:
         tot = arr(p.total, B, 7)
         tot[:] = d if p.first else tot + d
         return 0
+
+    def t3d_pool_bwd_mid(self, slab_base, grad_base, table, n, mx, sparse, stream):
+        return self.t3d_reduce_slabs(slab_base, grad_base, table, n, mx, stream) or self.t3d_pool_sparse_rows(sparse, stream)
 
     def t3d_pool_bwd_stage1(self, g, c, q, stream):
         return self.t3d_pointmlp_gram(g, stream) or self.t3d_act_colsum(c, stream) or self.t3d_pool_bwd_prep(q, stream)
@@ -452,6 +461,14 @@ class FakeLib:
         if p.add_in:
             v = v + arr(p.add_in, p.B, p.ld_add)[:, :p.K]
         arr(p.din, p.B, p.ld_din)[:, :p.K] = v
+        if p.bn_coef:                  # fused pooled-form batch-norm backward statistics on din's columns
+            q = abi.BnBwdFinalizeArgs()
+            q.dpool_in, q.ld_dpool_in, q.pooled, q.ld_pooled, q.ysel, q.dpool, q.B = p.din, p.ld_din, p.bn_pooled, p.bn_ld_pooled, \
+                p.bn_ysel, p.bn_dpool, p.B
+            q.count, q.N, q.gamma, q.mean, q.invstd, q.scale, q.frozen = p.bn_count, p.K, p.bn_gamma, p.bn_mean, p.bn_invstd, \
+                p.bn_scale, p.bn_frozen
+            q.dgamma, q.dbeta, q.coef = p.bn_dgamma, p.bn_dbeta, p.bn_coef
+            return self.t3d_bn_bwd_finalize(C.byref(q), stream)
         return 0
 
     # ---- heads -----------------------------------------------------------------------------------

@@ -995,3 +995,70 @@ def test_pooled_forward_kernel_equals_generic_kernel(hip_lib, M, K, N, rpf, mask
         assert torch.equal(outs[0][k], outs[1][k]), k
     assert torch.equal(outs[0]['pmax'][valid], outs[1]['pmax'][valid]) and torch.equal(outs[0]['pmin'][valid], outs[1]['pmin'][valid])
     assert int(valid.sum()) > 0
+
+
+def test_fc_dinput_with_fused_pooled_bn_bwd(hip_lib):
+    """t3d_fc_dinput with the bn_* fields = t3d_fc_dinput followed by t3d_bn_bwd_finalize (pooled form)."""
+    r = np.random.RandomState(21)
+    B, N, K = 32, 256, 512
+    d = dict(dy=r.normal(size=(B, N)).astype(np.float32), w=(r.normal(size=(K, N)) / 16).astype(np.float32),
+             pooled=np.maximum(r.normal(size=(B, K)), 0).astype(np.float32), ysel=r.normal(size=(B, K)).astype(np.float32),
+             gamma=(0.5 + r.uniform(size=K)).astype(np.float32), mean=r.normal(size=K).astype(np.float32),
+             invstd=(0.5 + r.uniform(size=K)).astype(np.float32), scale=r.normal(size=K).astype(np.float32))
+
+    def make(dev):
+        t = {k: _mk(dev, v) for k, v in d.items()}
+        o = dict(din=torch.zeros(B, K, device=dev), dpool=torch.zeros(B, K, device=dev), dg=torch.zeros(K, device=dev),
+                 db=torch.zeros(K, device=dev), coef=torch.zeros(3, K, device=dev))
+        a = abi.FcDinputArgs()
+        a.dy, a.N, a.w, a.alpha, a.din, a.ld_din, a.B, a.K = fptr(t['dy']), N, fptr(t['w']), 1.0, fptr(o['din']), K, B, K
+        a.bn_pooled, a.bn_ld_pooled, a.bn_ysel, a.bn_dpool, a.bn_count = fptr(t['pooled']), K, fptr(t['ysel']), fptr(o['dpool']), B * 1024
+        a.bn_gamma, a.bn_mean, a.bn_invstd, a.bn_scale = fptr(t['gamma']), fptr(t['mean']), fptr(t['invstd']), fptr(t['scale'])
+        a.bn_dgamma, a.bn_dbeta, a.bn_coef = fptr(o['dg']), fptr(o['db']), fptr(o['coef'])
+        a._keep = (t, o)
+        return a, o
+
+    c, g = _run_both(hip_lib, make, 't3d_fc_dinput')
+    _close(c['din'], g['din'], 1e-5, 1e-5, 'din')
+    _close(c['dpool'], g['dpool'], 1e-5, 1e-5, 'dpool')
+    _close(c['dg'], g['dg'], 1e-4, 1e-4, 'dgamma')
+    _close(c['db'], g['db'], 1e-4, 1e-4, 'dbeta')
+    _close(c['coef'], g['coef'], 1e-4, 1e-6, 'coef')
+
+
+def test_bn_fwd_finalize_with_fused_pool_pick(hip_lib):
+    """t3d_bn_fwd_finalize with the pool_* fields = t3d_bn_fwd_finalize followed by t3d_pool_finalize, bit for bit."""
+    r = np.random.RandomState(8)
+    B, tpf, N = 6, 4, 256
+    T = B * tpf
+    dev = _dev('cuda')
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    t = {k: _mk(dev, v) for k, v in dict(
+        psum=r.normal(size=(T, N)).astype(np.float32) * 10, psumsq=(100 + 50 * r.uniform(size=(T, N))).astype(np.float32),
+        gamma=r.normal(size=N).astype(np.float32), beta=r.normal(size=N).astype(np.float32), decay=np.array([0.5], np.float32),
+        pmax=r.normal(size=(T, N)).astype(np.float32), pmin=(r.normal(size=(T, N)) - 3).astype(np.float32),
+        pamax=r.randint(-1, 512, size=(T, N)).astype(np.int32), pamin=r.randint(-1, 512, size=(T, N)).astype(np.int32)).items()}
+    res = []
+    for fused in (False, True):
+        o = dict(scale=torch.zeros(N, device=dev), shift=torch.zeros(N, device=dev), mean=torch.zeros(N, device=dev), invstd=torch.zeros(N, device=dev),
+                 mm=torch.zeros(N, device=dev), mv=torch.ones(N, device=dev), pooled=torch.zeros(B, N, device=dev),
+                 argidx=torch.zeros(B, N, dtype=torch.int32, device=dev), ysel=torch.zeros(B, N, device=dev))
+        f = abi.BnFwdFinalizeArgs()
+        f.psum, f.psumsq, f.n_tiles, f.count, f.N = fptr(t['psum']), fptr(t['psumsq']), T, T * 128, N
+        f.gamma, f.beta, f.moving_mean, f.moving_var, f.decay = fptr(t['gamma']), fptr(t['beta']), fptr(o['mm']), fptr(o['mv']), fptr(t['decay'])
+        f.eps, f.is_training, f.unbiased_ema = 1e-3, 1, 1
+        f.scale, f.shift, f.mean, f.invstd = fptr(o['scale']), fptr(o['shift']), fptr(o['mean']), fptr(o['invstd'])
+        if fused:
+            f.pool_pmax, f.pool_pmin, f.pool_pamax, f.pool_pamin = fptr(t['pmax']), fptr(t['pmin']), iptr(t['pamax']), iptr(t['pamin'])
+            f.pool_B, f.pool_tiles_per_frustum, f.pooled, f.ld_pooled, f.argidx, f.ysel = B, tpf, fptr(o['pooled']), N, iptr(o['argidx']), fptr(o['ysel'])
+        assert hip_lib.t3d_bn_fwd_finalize(C.byref(f), st) == 0
+        if not fused:
+            q = abi.PoolFinalizeArgs()
+            q.scale, q.shift, q.pmax, q.pmin, q.pamax, q.pamin = fptr(o['scale']), fptr(o['shift']), fptr(t['pmax']), fptr(t['pmin']), iptr(t['pamax']), iptr(t['pamin'])
+            q.B, q.N, q.tiles_per_frustum, q.pooled, q.ld_pooled, q.argidx, q.ysel = B, N, tpf, fptr(o['pooled']), N, iptr(o['argidx']), fptr(o['ysel'])
+            assert hip_lib.t3d_pool_finalize(C.byref(q), st) == 0
+        torch.cuda.synchronize()
+        res.append(o)
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]), k
+    assert float(res[1]['pooled'].abs().max()) > 0

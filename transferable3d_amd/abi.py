@@ -33,7 +33,9 @@ class PointMlpFwdArgs(C.Structure):
 class BnFwdFinalizeArgs(C.Structure):
     _fields_ = [('psum', F), ('psumsq', F), ('n_tiles', i32), ('count', i32), ('N', i32), ('gamma', F), ('beta', F),
                 ('moving_mean', F), ('moving_var', F), ('decay', F), ('eps', f32), ('is_training', i32),
-                ('unbiased_ema', i32), ('scale', F), ('shift', F), ('mean', F), ('invstd', F)]
+                ('unbiased_ema', i32), ('scale', F), ('shift', F), ('mean', F), ('invstd', F),
+                ('pool_pmax', F), ('pool_pmin', F), ('pool_pamax', I), ('pool_pamin', I), ('pool_B', i32), ('pool_tiles_per_frustum', i32),
+                ('pooled', F), ('ld_pooled', i32), ('argidx', I), ('ysel', F)]
 
 
 class PoolFinalizeArgs(C.Structure):
@@ -114,7 +116,9 @@ class FcBwdArgs(C.Structure):
 
 class FcDinputArgs(C.Structure):
     _fields_ = [('dy', F), ('N', i32), ('w', F), ('add_in', F), ('ld_add', i32), ('alpha', f32), ('din', F),
-                ('ld_din', i32), ('B', i32), ('K', i32)]
+                ('ld_din', i32), ('B', i32), ('K', i32),
+                ('bn_pooled', F), ('bn_ld_pooled', i32), ('bn_ysel', F), ('bn_dpool', F), ('bn_count', i32), ('bn_gamma', F), ('bn_mean', F),
+                ('bn_invstd', F), ('bn_scale', F), ('bn_frozen', i32), ('bn_dgamma', F), ('bn_dbeta', F), ('bn_coef', F)]
 
 
 class SegHeadArgs(C.Structure):
@@ -202,6 +206,7 @@ ENTRY_POINTS = {
     't3d_pool_wgrad_finish': [C.POINTER(PoolWgradFinishArgs), VP],
     't3d_box_refine_step': [C.POINTER(BoxRefineStepArgs), VP],
     't3d_pool_bwd_stage1': [C.POINTER(PointMlpGramArgs), C.POINTER(ActColsumArgs), C.POINTER(PoolBwdPrepArgs), VP],
+    't3d_pool_bwd_mid': [F, F, C.POINTER(SlabDesc), i32, i32, C.POINTER(PoolSparseRowsArgs), VP],
     't3d_pool_bwd_stage2': [C.POINTER(PoolWgradFinishArgs), C.POINTER(PointMlpDgradGramArgs), VP],
     't3d_fc_fwd': [C.POINTER(FcFwdArgs), VP],
     't3d_fc_bwd': [C.POINTER(FcBwdArgs), VP],

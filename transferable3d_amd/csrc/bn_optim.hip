@@ -3,6 +3,7 @@
 // sit between the MFMA GEMMs of pointmlp.hip; reductions combine tile partials in a fixed order
 // (double accumulators), so results are run-to-run reproducible.
 #include "common.h"
+#include "poolbwd_dev.h"
 
 namespace {
 
@@ -49,6 +50,38 @@ __device__ __forceinline__ double group_reduce(double v, double (*red)[FC_CH], i
   return s;
 }
 
+// pooled[b,c], argidx, ysel from the per-tile max/min partials (shared by k_pool_finalize and the fused finalize)
+__device__ __forceinline__ void pool_pick_impl(const float* pmax, const float* pmin, const int32_t* pamax, const int32_t* pamin,
+                                               int tiles_per_frustum, int N, int b, int c, float sc, float sh, float* pooled,
+                                               int ld_pooled, int32_t* argidx, float* ysel) {
+  const bool use_max = sc >= 0.f;
+  float best = use_max ? -INFINITY : INFINITY;
+  int arg = -1;
+  for (int t = 0; t < tiles_per_frustum; ++t) {
+    const size_t o = (size_t)(b * tiles_per_frustum + t) * N + c;
+    if (use_max) {
+      const int a = pamax[o];
+      const float v = pmax[o];
+      if (a >= 0 && (arg < 0 || v > best)) { best = v; arg = a; }
+    } else {
+      const int a = pamin[o];
+      const float v = pmin[o];
+      if (a >= 0 && (arg < 0 || v < best)) { best = v; arg = a; }
+    }
+  }
+  float out = 0.f;
+  if (arg >= 0) out = fmaxf(fmaf(best, sc, sh), 0.f);
+  const bool live = out > 0.f;
+  const size_t i = (size_t)b * N + c;
+  pooled[(size_t)b * ld_pooled + c] = out;
+  argidx[i] = live ? arg : -1;
+  ysel[i] = live ? best : 0.f;
+}
+__device__ __forceinline__ void pool_pick(const t3d_bn_fwd_finalize_args& p, int b, int c, float sc, float sh) {
+  pool_pick_impl(p.pool_pmax, p.pool_pmin, p.pool_pamax, p.pool_pamin, p.pool_tiles_per_frustum, p.N, b, c, sc, sh, p.pooled,
+                 p.ld_pooled, p.argidx, p.ysel);
+}
+
 __global__ __launch_bounds__(256) void k_bn_fwd_finalize(const t3d_bn_fwd_finalize_args p) {
   __shared__ double red[FC_GR][FC_CH];
   const int cl = threadIdx.x & (FC_CH - 1), grp = threadIdx.x / FC_CH;
@@ -87,6 +120,17 @@ __global__ __launch_bounds__(256) void k_bn_fwd_finalize(const t3d_bn_fwd_finali
     p.mean[c] = p.moving_mean[c];
     p.invstd[c] = (float)invstd;
   }
+  // optional K3: the max-pool pick of the same 16 channels (scale/shift handed over through LDS, not through memory)
+  if (p.pool_pmax != nullptr) {
+    __shared__ float s_sc[FC_CH], s_sh[FC_CH];
+    __syncthreads();
+    if (grp == 0 && ok) { s_sc[cl] = p.scale[c]; s_sh[cl] = p.shift[c]; }     // this thread's own stores: visible to itself
+    __syncthreads();
+    if (ok) {
+      const float sc = s_sc[cl], sh = s_sh[cl];
+      for (int b = grp; b < p.pool_B; b += FC_GR) pool_pick(p, b, c, sc, sh);
+    }
+  }
 }
 
 // one thread per (frustum, channel)
@@ -94,28 +138,8 @@ __global__ __launch_bounds__(256) void k_pool_finalize(const t3d_pool_finalize_a
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p.B * p.N) return;
   const int b = i / p.N, c = i % p.N;
-  const float sc = p.scale[c], sh = p.shift[c];
-  const bool use_max = sc >= 0.f;
-  float best = use_max ? -INFINITY : INFINITY;
-  int arg = -1;
-  for (int t = 0; t < p.tiles_per_frustum; ++t) {
-    const size_t o = (size_t)(b * p.tiles_per_frustum + t) * p.N + c;
-    if (use_max) {
-      const int a = p.pamax[o];
-      const float v = p.pmax[o];
-      if (a >= 0 && (arg < 0 || v > best)) { best = v; arg = a; }
-    } else {
-      const int a = p.pamin[o];
-      const float v = p.pmin[o];
-      if (a >= 0 && (arg < 0 || v < best)) { best = v; arg = a; }
-    }
-  }
-  float out = 0.f;
-  if (arg >= 0) out = fmaxf(fmaf(best, sc, sh), 0.f);
-  const bool live = out > 0.f;
-  p.pooled[(size_t)b * p.ld_pooled + c] = out;
-  p.argidx[i] = live ? arg : -1;
-  p.ysel[i] = live ? best : 0.f;
+  pool_pick_impl(p.pmax, p.pmin, p.pamax, p.pamin, p.tiles_per_frustum, p.N, b, c, p.scale[c], p.shift[c], p.pooled, p.ld_pooled,
+                 p.argidx, p.ysel);
 }
 
 __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const t3d_bn_bwd_finalize_args p) {
@@ -181,14 +205,14 @@ __global__ __launch_bounds__(256) void k_dy_colsum(const t3d_dy_colsum_args p) {
 // four loads in flight, the 8 group sums are combined through LDS in a fixed order.  Splitting the slab chain over
 // threads is what keeps the many-slab / few-element tensors (64x64 layers with 256 slabs) from being one long latency
 // chain while the rest of the chip idles.
-__global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ slab_base, float* __restrict__ grad_base,
-                                                      const t3d_slab_desc* __restrict__ table) {
-  __shared__ float4 part[8][32];
-  const t3d_slab_desc d = table[blockIdx.y];
+__device__ __forceinline__ void reduce_slabs_body(const float* __restrict__ slab_base, float* __restrict__ grad_base,
+                                                  const t3d_slab_desc* __restrict__ table, float4 (*part)[32], int bx, int by,
+                                                  int gx) {
+  const t3d_slab_desc d = table[by];
   const bool vec = ((d.slab_off | d.grad_off | (int64_t)d.numel) & 3) == 0;
   const int n4 = vec ? (d.numel >> 2) : 0;
   const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  for (int e0 = blockIdx.x * 32; e0 < n4; e0 += gridDim.x * 32) {
+  for (int e0 = bx * 32; e0 < n4; e0 += gx * 32) {
     const int e = e0 + el;
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
     if (e < n4) {
@@ -224,11 +248,32 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ 
     __syncthreads();
   }
   if (!vec) {
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < d.numel; e += gridDim.x * blockDim.x) {
+    for (int e = bx * blockDim.x + threadIdx.x; e < d.numel; e += gx * blockDim.x) {
       float acc = 0.f;
       for (int k = 0; k < d.n_slabs; ++k) acc += slab_base[d.slab_off + (size_t)k * d.numel + e];
       grad_base[d.grad_off + e] = acc;
     }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ slab_base, float* __restrict__ grad_base,
+                                                      const t3d_slab_desc* __restrict__ table) {
+  __shared__ float4 part[8][32];
+  reduce_slabs_body(slab_base, grad_base, table, part, blockIdx.x, blockIdx.y, gridDim.x);
+}
+
+// slab reduction and the sparse arg-max rows of a pooled layer's backward in one launch: blocks [0, n_reduce) reduce
+// (logical grid gx x n_tensors), the rest run the sparse-row tiles
+__global__ __launch_bounds__(256) void k_pool_bwd_mid(const float* __restrict__ slab_base, float* __restrict__ grad_base,
+                                                      const t3d_slab_desc* __restrict__ table, const int gx, const int n_reduce,
+                                                      const t3d_pool_sparse_rows_args sp) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x;
+  if (b < n_reduce) {
+    reduce_slabs_body(slab_base, grad_base, table, reinterpret_cast<float4(*)[32]>(smem), b % gx, b / gx, gx);
+  } else {
+    const int r = b - n_reduce, tiles = sp.B * sp.rows_per_frustum / 128;
+    pool_sparse_rows_body(sp, smem, r % tiles, r / tiles);
   }
 }
 
@@ -358,6 +403,29 @@ extern "C" int t3d_dropout_mask(float* mask, int64_t n, float keep_prob, uint32_
   if (blocks > 4096) blocks = 4096;
   T3D_LAUNCH(k_dropout_mask, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), mask, n,
                      keep_prob, seed, hyper);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_pool_bwd_mid(const float* slab_base, float* grad_base, const t3d_slab_desc* table_dev, int n_tensors,
+                                int max_numel, const t3d_pool_sparse_rows_args* a, t3d_stream_t stream) {
+  if (!slab_base || !grad_base || !table_dev || n_tensors <= 0) return T3D_ERR_ARG;
+  const int rc = check_sparse_rows(a);
+  if (rc != T3D_OK) return rc;
+  int gx = (max_numel / 4 + 31) / 32;
+  if (gx > 256) gx = 256;
+  if (gx < 1) gx = 1;
+  const int n_reduce = gx * n_tensors;
+  const long M = (long)a->B * a->rows_per_frustum;
+  const int n_sparse = (int)(M / 128) * (a->K / SR_KC);
+  const size_t lds = sparse_rows_lds(a->N);
+  static size_t allowed = 0;
+  if (lds > 64 * 1024 && lds > allowed) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pool_bwd_mid), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    allowed = lds;
+  }
+  T3D_LAUNCH(k_pool_bwd_mid, dim3(n_reduce + n_sparse), dim3(256), lds, static_cast<hipStream_t>(stream), slab_base, grad_base,
+             table_dev, gx, n_reduce, *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

@@ -383,15 +383,42 @@ __global__ __launch_bounds__(NTH) void k_fc_dinput(const t3d_fc_dinput_args p) {
   wave_gemm<true, RBT>(acc, src, p.w, p.N, p.N, c0, nvalid, wave, lane);
   float v[NVAL];
   reduce_tiles<RBT>(acc, sm, v);
-  if (c >= p.K) return;
+  const bool cok = c < p.K;
+  float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int j = 0; j < NVAL; ++j) {
     const int r = rg + RG * j;
-    if (r < p.B) {
+    if (r < p.B && cok) {
       float o = p.alpha * v[j];
       if (p.add_in) o += p.add_in[(size_t)r * p.ld_add + c];
       p.din[(size_t)r * p.ld_din + c] = o;
+      if (p.bn_coef) {            // pooled form of the batch-norm backward statistics on this column (K11c)
+        const float live = p.bn_pooled[(size_t)r * p.bn_ld_pooled + c] > 0.f ? 1.f : 0.f;
+        const float g = o * live;
+        p.bn_dpool[(size_t)r * p.K + c] = g;
+        s1 += g;
+        s2 = fmaf(g, p.bn_ysel[(size_t)r * p.K + c], s2);
+      }
     }
+  }
+  if (p.bn_coef == nullptr) return;          // workgroup-uniform
+  const float t1 = col_reduce(s1, sm), t2 = col_reduce(s2, sm);
+  if (cok && rg == 0) {
+    if (p.bn_frozen) {
+      p.bn_coef[c] = p.bn_scale[c];
+      p.bn_coef[p.K + c] = 0.f;
+      p.bn_coef[2 * p.K + c] = 0.f;
+      return;
+    }
+    const double mean = p.bn_mean[c], invstd = p.bn_invstd[c], gamma = p.bn_gamma[c], n = p.bn_count;
+    const double dbeta = t1;
+    const double dgamma = invstd * ((double)t2 - mean * (double)t1);
+    if (p.bn_dbeta) p.bn_dbeta[c] = (float)dbeta;
+    if (p.bn_dgamma) p.bn_dgamma[c] = (float)dgamma;
+    const double c1 = gamma * invstd, k3 = dgamma / n * invstd;
+    p.bn_coef[c] = (float)c1;
+    p.bn_coef[p.K + c] = (float)(-c1 * k3);
+    p.bn_coef[2 * p.K + c] = (float)(c1 * (k3 * mean - dbeta / n));
   }
 }
 
@@ -427,6 +454,9 @@ extern "C" int t3d_fc_bwd(const t3d_fc_bwd_args* a, t3d_stream_t stream) {
 
 extern "C" int t3d_fc_dinput(const t3d_fc_dinput_args* a, t3d_stream_t stream) {
   if (!a || !a->dy || !a->w || !a->din) return T3D_ERR_ARG;
+  if (a->bn_coef && (!a->bn_pooled || !a->bn_ysel || !a->bn_dpool || !a->bn_scale ||
+                     (!a->bn_frozen && (!a->bn_gamma || !a->bn_mean || !a->bn_invstd))))
+    return T3D_ERR_ARG;
   if (a->B <= 0 || a->B > 32 * MAXRB || a->N <= 0 || a->K <= 0) return T3D_ERR_SHAPE;
   if (a->B <= 32) T3D_LAUNCH(k_fc_dinput<1>, dim3((a->K + CB - 1) / CB), dim3(NTH), fc_lds_bytes(32), static_cast<hipStream_t>(stream), *a);
   else T3D_LAUNCH(k_fc_dinput<MAXRB>, dim3((a->K + CB - 1) / CB), dim3(NTH), fc_lds_bytes(128), static_cast<hipStream_t>(stream), *a);

@@ -32,12 +32,9 @@ extern "C" int t3d_pool_bwd_prep(const t3d_pool_bwd_prep_args* a, t3d_stream_t s
 }
 
 extern "C" int t3d_pool_sparse_rows(const t3d_pool_sparse_rows_args* a, t3d_stream_t stream) {
-  if (!a || !a->argidx || !a->dpool || !a->wc || !a->s) return T3D_ERR_ARG;
-  if (a->B <= 0 || a->N <= 0 || a->N > 65535 || a->K % SR_KC || a->rows_per_frustum % T3D_TILE_ROWS ||
-      a->rows_per_frustum > 32767)
-    return T3D_ERR_SHAPE;
-  const size_t lds = (size_t)128 * SR_KC * sizeof(float) + (size_t)4 * a->N * sizeof(int);
-  if (lds > 160 * 1024) return T3D_ERR_SHAPE;
+  const int rc = check_sparse_rows(a);
+  if (rc != T3D_OK) return rc;
+  const size_t lds = sparse_rows_lds(a->N);
   static size_t allowed = 0;          // set the > 64 KB attribute once per size, not per launch
   if (lds > 64 * 1024 && lds > allowed) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pool_sparse_rows), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -279,6 +279,14 @@ inline int check_prep(const t3d_pool_bwd_prep_args* a) {
   if (a->K <= 0 || a->K % 32 || a->N <= 0 || a->N % 4) return T3D_ERR_SHAPE;
   return T3D_OK;
 }
+inline size_t sparse_rows_lds(int N) { return (size_t)128 * SR_KC * sizeof(float) + (size_t)4 * N * sizeof(int); }
+inline int check_sparse_rows(const t3d_pool_sparse_rows_args* a) {
+  if (!a || !a->argidx || !a->dpool || !a->wc || !a->s) return T3D_ERR_ARG;
+  if (a->B <= 0 || a->N <= 0 || a->N > 65535 || a->K % SR_KC || a->rows_per_frustum % T3D_TILE_ROWS ||
+      a->rows_per_frustum > 32767 || sparse_rows_lds(a->N) > 160 * 1024)
+    return T3D_ERR_SHAPE;
+  return T3D_OK;
+}
 inline int check_colsum(const t3d_act_colsum_args* a) {
   if (!a || !a->part || !pool_act_ok(a->a, a->K)) return T3D_ERR_ARG;
   if (a->M <= 0 || a->M % T3D_TILE_ROWS || (a->K != 64 && a->K != 128 && a->K != 256) || a->a.ldx % 4 || a->a.coff % 4)

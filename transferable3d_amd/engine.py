@@ -364,14 +364,11 @@ class PointLayer:
         f.gamma, f.beta, f.moving_mean, f.moving_var = fptr(self.gamma), fptr(self.beta), fptr(self.mm), fptr(self.mv)
         f.decay, f.eps, f.is_training, f.unbiased_ema = fptr(g.bn_decay_ptr), BN_EPS, int(is_training), int(g.unbiased_ema)
         f.scale, f.shift, f.mean, f.invstd = fptr(self.scale), fptr(self.shift), fptr(self.mean), fptr(self.invstd)
+        if pool:                      # the max-pool pick of the same channels rides in the finalize launch (K3)
+            f.pool_pmax, f.pool_pmin, f.pool_pamax, f.pool_pamin = fptr(self.pmax), fptr(self.pmin), iptr(self.pamax), iptr(self.pamin)
+            f.pool_B, f.pool_tiles_per_frustum = g.B, g.rpf // TILE
+            f.pooled, f.ld_pooled, f.argidx, f.ysel = fptr(self.pooled), self.N, iptr(self.argidx), fptr(self.ysel)
         plan.add('t3d_bn_fwd_finalize', f)
-        if pool:
-            q = abi.PoolFinalizeArgs()
-            q.scale, q.shift = fptr(self.scale), fptr(self.shift)
-            q.pmax, q.pmin, q.pamax, q.pamin = fptr(self.pmax), fptr(self.pmin), iptr(self.pamax), iptr(self.pamin)
-            q.B, q.N, q.tiles_per_frustum = g.B, self.N, g.rpf // TILE
-            q.pooled, q.ld_pooled, q.argidx, q.ysel = fptr(self.pooled), self.N, iptr(self.argidx), fptr(self.ysel)
-            plan.add('t3d_pool_finalize', q)
         self.out = None if self.gram else ActSpec(self.y, self.N, self.N, 0, self.scale, self.shift, True, producer=self)
         return self.out
 
@@ -398,6 +395,8 @@ class PointLayer:
         """dgamma/dbeta + the three dy coefficients.  `frozen` nets (eval-mode BN) use scale only."""
         g, vs = self.g, self.g.vars
         self._ensure_bwd_buffers()
+        if self.pool and getattr(self, '_bn_bwd_fused_in', None) is plan:
+            return                    # already done inside the t3d_fc_dinput launch that produced dpool_in
         a = abi.BnBwdFinalizeArgs()
         if self.pool:
             a.dpool_in, a.ld_dpool_in = fptr(dpool_in), ld_dpool_in
@@ -428,9 +427,13 @@ class PointLayer:
         rt.allocs.append(tab)
         lib, n, mx = rt.lib, len(table), max(r[1] for r in regions)
 
-        def emit():
-            plan.add_raw('t3d_reduce_slabs', lambda s: lib.t3d_reduce_slabs(
-                fptr(slabs), fptr(out), C.cast(C.c_void_p(tab.data_ptr()), C.POINTER(abi.SlabDesc)), n, mx, s))
+        def emit(sparse=None):
+            tp = lambda: C.cast(C.c_void_p(tab.data_ptr()), C.POINTER(abi.SlabDesc))
+            if sparse is None:
+                plan.add_raw('t3d_reduce_slabs', lambda s: lib.t3d_reduce_slabs(fptr(slabs), fptr(out), tp(), n, mx, s))
+            else:
+                ref = C.byref(sparse)
+                plan.add_raw('t3d_pool_bwd_mid', lambda s: lib.t3d_pool_bwd_mid(fptr(slabs), fptr(out), tp(), n, mx, ref, s), sparse)
         return ({k: slabs[v:] for k, v in soff.items()}, {name: out[ooff[name]:ooff[name] + numel] for name, numel, _ in regions},
                 emit)
 
@@ -513,9 +516,8 @@ class PointLayer:
         plan.keep.extend([ga, ca, qa, sl, red])
         plan.calls.append(('t3d_pool_bwd_stage1', lambda s: fn1(r1[0], r1[1], r1[2], s), (ga, ca, qa)))
         plan.lanes.append(0)
-        emit_reduce()
         r = abi.PoolSparseRowsArgs(iptr(self.argidx), fptr(self.dpool), fptr(self.wc), g.B, N, K, g.rpf, fptr(self.S))
-        plan.add('t3d_pool_sparse_rows', r)
+        emit_reduce(sparse=r)           # slab reduction + sparse rows share a launch (both wait only for stage 1)
         f = abi.PoolWgradFinishArgs()
         f.a, f.argidx, f.dpool, f.coef = self.src.struct(), iptr(self.argidx), fptr(self.dpool), fptr(self.coef)
         f.w, f.bias, f.g, f.abar = fptr(self.w), fptr(self.bias), fptr(red['G']), fptr(red['abar'])
@@ -683,11 +685,27 @@ class FcLayer:
         a.B, a.N = g.B, self.N
         plan.add('t3d_fc_bwd', a)
 
-    def dinput(self, plan, K=None, alpha=1.0, add_in=None, ld_add=0):
-        """[B,K] gradient w.r.t. the first K input columns."""
+    def dinput(self, plan, K=None, alpha=1.0, add_in=None, ld_add=0, bn_bwd_of=None, param_grads=True):
+        """[B,K] gradient w.r.t. the first K input columns.  `bn_bwd_of`: the max-pooled PointLayer whose pooled feature
+        these columns are -- its batch-norm-backward finalize (pooled form) then runs inside this launch and the layer's
+        later bn_bwd(plan, dpool_in=<this result>) call is a no-op."""
         g = self.g
         K = K or self.K
         out = g.rt.zeros(g.B, K)
-        a = abi.FcDinputArgs(fptr(self.dy), self.N, fptr(self.w), fptr(add_in), ld_add, alpha, fptr(out), K, g.B, K)
+        a = abi.FcDinputArgs()
+        a.dy, a.N, a.w, a.add_in, a.ld_add, a.alpha, a.din, a.ld_din, a.B, a.K = fptr(self.dy), self.N, fptr(self.w), fptr(add_in), \
+            ld_add, alpha, fptr(out), K, g.B, K
+        L = bn_bwd_of
+        if L is not None and FUSE_BWD:
+            assert L.pool and L.N == K
+            L._ensure_bwd_buffers()
+            vs = g.vars
+            a.bn_pooled, a.bn_ld_pooled, a.bn_ysel, a.bn_dpool, a.bn_count = fptr(L.pooled), L.N, fptr(L.ysel), fptr(L.dpool), L.M
+            a.bn_gamma, a.bn_mean, a.bn_invstd, a.bn_scale = fptr(L.gamma), fptr(L.mean), fptr(L.invstd), fptr(L.scale)
+            a.bn_frozen = int(not L.is_training)
+            if param_grads and L.is_training:
+                a.bn_dgamma, a.bn_dbeta = fptr(vs.grad(L.scope + '/bn/gamma')), fptr(vs.grad(L.scope + '/bn/beta'))
+            a.bn_coef = fptr(L.coef)
+            L._bn_bwd_fused_in = plan
         plan.add('t3d_fc_dinput', a)
         return out

@@ -173,7 +173,7 @@ class InstSegNet:
         L.L6.bn_bwd(plan)
         colsum6 = L.L6.dy_colsum(plan)                                   # [B,512]
         L.G6.bwd(plan, dout=colsum6, ld_dout=512)                        # dW6[64:], no bias
-        dg5 = L.G6.dinput(plan, K=1024)                                  # [B,1024]
+        dg5 = L.G6.dinput(plan, K=1024, bn_bwd_of=L.L5)                   # [B,1024] + conv5's BN-bwd finalize
         self.da3_part = g.rt.zeros(g.M, 64)
         L.L6.bwd_pair(plan, out_raw=self.da3_part)
         L.L5.bn_bwd(plan, dpool_in=dg5, ld_dpool_in=1024)
@@ -215,7 +215,7 @@ class TNet:
         self.F3.bwd(plan, dout=dstage1, ld_dout=3)
         self.F2.bwd(plan, nxt=self.F3)
         self.F1.bwd(plan, nxt=self.F2)
-        dft = self.F1.dinput(plan, K=256)
+        dft = self.F1.dinput(plan, K=256, bn_bwd_of=self.T3)
         self.T3.bn_bwd(plan, dpool_in=dft, ld_dpool_in=256)
         self.T3.bwd_pair(plan)
         self.T2.bn_bwd(plan)
@@ -273,7 +273,7 @@ class BoxEstNet:
         self.G3.bwd(plan, dout=dbox, ld_dout=BOX_OUT_DIMS)
         self.G2.bwd(plan, nxt=self.G3)
         self.G1.bwd(plan, nxt=self.G2)
-        dfb = self.G1.dinput(plan, K=512)
+        dfb = self.G1.dinput(plan, K=512, bn_bwd_of=self.B4)
         return self.bwd_convs(plan, dfb, 512, dstage1_in)
 
 
@@ -436,7 +436,7 @@ class BoxPCNet:
         self.F3.bwd(plan, dout=dout, ld_dout=9, param_grads=param_grads)
         self.F2.bwd(plan, nxt=self.F3, param_grads=param_grads)
         self.F1.bwd(plan, nxt=self.F2, param_grads=param_grads)
-        dfeat = self.F1.dinput(plan, K=512)
+        dfeat = self.F1.dinput(plan, K=512, bn_bwd_of=self.P4, param_grads=param_grads)
         self.P4.bn_bwd(plan, dpool_in=dfeat, ld_dpool_in=512, param_grads=param_grads)
         if param_grads:
             self.P4.bwd_pair(plan)
@@ -599,7 +599,7 @@ class SemiModelF:
         self.R2.bwd(plan, dout=lo.dbox, ld_dout=BOX_OUT_DIMS)
         self.R1.bwd(plan, nxt=self.R2)
         self.R0.bwd(plan, nxt=self.R1)
-        dfeat = self.R0.dinput(plan, K=512)
+        dfeat = self.R0.dinput(plan, K=512, bn_bwd_of=self.box.B4)
         ds1 = self.box.bwd_convs(plan, dfeat, 512, lo.dstage1)
         self.tnet.bwd(plan, ds1)
         g.emit_reduce_slabs(plan)
