@@ -57,16 +57,23 @@ __device__ __forceinline__ void pool_pick_impl(const float* pmax, const float* p
   const bool use_max = sc >= 0.f;
   float best = use_max ? -INFINITY : INFINITY;
   int arg = -1;
-  for (int t = 0; t < tiles_per_frustum; ++t) {
-    const size_t o = (size_t)(b * tiles_per_frustum + t) * N + c;
-    if (use_max) {
-      const int a = pamax[o];
-      const float v = pmax[o];
-      if (a >= 0 && (arg < 0 || v > best)) { best = v; arg = a; }
-    } else {
-      const int a = pamin[o];
-      const float v = pmin[o];
-      if (a >= 0 && (arg < 0 || v < best)) { best = v; arg = a; }
+  // only the side the sign of the scale selects is read; eight tiles' loads are in flight together (clamped, then masked)
+  const float* pv = use_max ? pmax : pmin;
+  const int32_t* pa = use_max ? pamax : pamin;
+  for (int t0 = 0; t0 < tiles_per_frustum; t0 += 8) {
+    float v[8];
+    int a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const size_t o = (size_t)(b * tiles_per_frustum + min(t0 + u, tiles_per_frustum - 1)) * N + c;
+      v[u] = pv[o];
+      a[u] = pa[o];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const bool take = (t0 + u < tiles_per_frustum) && a[u] >= 0 && (arg < 0 || (use_max ? v[u] > best : v[u] < best));
+      best = take ? v[u] : best;
+      arg = take ? a[u] : arg;
     }
   }
   float out = 0.f;
