@@ -132,3 +132,25 @@ def test_boxpc_and_stage_c_match_golden_vectors(hip_lib):
     from model_check import check_golden_boxpc, check_golden_stage_c
     check_golden_boxpc(Runtime(lib=hip_lib))
     check_golden_stage_c(Runtime(lib=hip_lib))
+
+
+def test_config4_problem_size_in_fp32(hip_lib):
+    """BASELINE.json configs[4] is B=128, N=2048 in bf16; the bf16 kernels are a later round, but the fp32 path must already
+    hold the problem size (M = 262 144 rows, FC batch-norm over 128 rows = four 32-row MFMA blocks): finite loss, unit-variance
+    batch-normed activations, a second run bit-identical, and the per-frustum outputs of the first 4 frustums independent of
+    everything but the batch statistics (they change when the other 124 frustums change)."""
+    B, N, C = 128, 2048, 4
+    batch = make_batch(B, N, C, seed=77, dropout_scopes={'inst_seg/dp1': ((B, N, 128), 0.5)})
+    P = _params(C, 3)
+    g, m = run_model_a(Runtime(lib=hip_lib), batch, P, R.default_config())
+    e = m.end_points()
+    assert np.isfinite(float(e['loss'].cpu()))
+    L = m.seg.L7
+    z = L.y * L.scale + L.shift
+    assert float(z.mean(0).abs().max()) < 1e-4 and float((z.var(0, unbiased=False) - 1).abs().max()) < 2e-2
+    grads1, logits1 = g.vars.grads.clone(), e['logits'].clone()
+    assert bool(torch.isfinite(grads1).all()) and float(grads1.abs().max()) > 0
+    g.fwd.run()
+    g.bwd.run()
+    torch.cuda.synchronize()
+    assert torch.equal(grads1, g.vars.grads) and torch.equal(logits1, m.end_points()['logits'])

@@ -225,6 +225,18 @@ __device__ __forceinline__ void reduce_slabs_body(const float* __restrict__ slab
     if (e < n4) {
       const float4* s = reinterpret_cast<const float4*>(slab_base + d.slab_off) + e;
       int k = grp;
+      for (; k + 56 < d.n_slabs; k += 64) {            // eight slabs in flight per thread
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = s[(size_t)(k + 8 * u) * n4];
+#pragma unroll
+        for (int u = 0; u < 8; u += 4) {
+          a0.x += v[u].x; a0.y += v[u].y; a0.z += v[u].z; a0.w += v[u].w;
+          a1.x += v[u + 1].x; a1.y += v[u + 1].y; a1.z += v[u + 1].z; a1.w += v[u + 1].w;
+          a2.x += v[u + 2].x; a2.y += v[u + 2].y; a2.z += v[u + 2].z; a2.w += v[u + 2].w;
+          a3.x += v[u + 3].x; a3.y += v[u + 3].y; a3.z += v[u + 3].z; a3.w += v[u + 3].w;
+        }
+      }
       for (; k + 24 < d.n_slabs; k += 32) {
         const float4 v0 = s[(size_t)(k + 0) * n4], v1 = s[(size_t)(k + 8) * n4], v2 = s[(size_t)(k + 16) * n4],
                      v3 = s[(size_t)(k + 24) * n4];
