@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 import numpy as np   # noqa: E402
 import torch         # noqa: E402
 
+HBM_PEAK_TBS = 8.0                 # MI355X_MICROARCH.md: HBM3E spec peak (about 6.3 TB/s achievable)
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
 SPLIT_GFLOP_PER_FRUSTUM = 3.638   # fwd+bwd, split-conv6 count (the algorithm actually run)
 DENSE_GFLOP_PER_FRUSTUM = 6.856   # as-written dense concat count (reported for reference only)
@@ -51,37 +52,61 @@ LIB = None
 CALLS = {}
 
 
+def _null(ptr):
+    return not bool(ptr)
+
+
 def gemm_label_and_flops(name, a):
-    """Mirror of the template dispatch in csrc/pointmlp.hip -> rocprof kernel name + algorithmic FLOPs."""
+    """(label, flops) -- see gemm_work."""
+    lab, fl, _ = gemm_work(name, a)
+    return lab, fl
+
+
+def gemm_work(name, a):
+    """Mirror of the template dispatch in csrc/pointmlp.hip -> (rocprof kernel name, algorithmic FLOPs, algorithmic HBM
+    bytes) of one launch.  Bytes: every operand and result once, fp32 (DESIGN.md section 4): fwd 4(MK + KN [+ MN if y is stored]);
+    dgrad 4(2MN + KN + MK out [+ MK prev_y] [+ MK add_in]); wgrad 4(MK + 2MN + slabs); Gram forms with K in place of N."""
     import ctypes
     if name == 't3d_pool_bwd_stage1':
-        gl, gf = gemm_label_and_flops('t3d_pointmlp_gram', a[0])
-        return 'k_pool_bwd_stage1<%s>' % gl[gl.index('<') + 1:gl.index(',')], gf + 2.0 * a[2].K * a[2].K * a[2].N
+        gl, gf, gb = gemm_work('t3d_pointmlp_gram', a[0])
+        q = a[2]
+        nch = (q.N + 127) // 128
+        by = gb + 4.0 * a[1].M * a[1].K + 4.0 * (2 * q.K * q.N + nch * q.K * q.K)
+        return 'k_pool_bwd_stage1<%s>' % gl[gl.index('<') + 1:gl.index(',')], gf + 2.0 * q.K * q.K * q.N, by
     if name == 't3d_pool_bwd_stage2':
-        dl, df = gemm_label_and_flops('t3d_pointmlp_dgrad_gram', a[1])
-        return 'k_pool_bwd_stage2<%s>' % dl[dl.index('<') + 1:-1], df + 2.0 * a[0].K * a[0].K * a[0].N
+        dl, df, db = gemm_work('t3d_pointmlp_dgrad_gram', a[1])
+        f = a[0]
+        by = db + 4.0 * (2 * f.K * f.N + f.K * f.K + f.B * f.N * f.K)
+        return 'k_pool_bwd_stage2<%s>' % dl[dl.index('<') + 1:-1], df + 2.0 * f.K * f.K * f.N, by
     if name == 't3d_pointmlp_bwd':
         d, w = a
-        dl, df = gemm_label_and_flops('t3d_pointmlp_dgrad', d)
-        wl, wf = gemm_label_and_flops('t3d_pointmlp_wgrad', w)
-        return 'k_pointmlp_bwd<%s,%s>' % (dl[dl.index('<') + 1:-1], wl[wl.index('<') + 1:-1]), df + wf
+        dl, df, db = gemm_work('t3d_pointmlp_dgrad', d)
+        wl, wf, wb = gemm_work('t3d_pointmlp_wgrad', w)
+        return 'k_pointmlp_bwd<%s,%s>' % (dl[dl.index('<') + 1:-1], wl[wl.index('<') + 1:-1]), df + wf, db + wb
     if name == 't3d_pointmlp_dgrad_gram':
-        return 'k_pointmlp_dgrad_gram<%d>' % (128 if a.K % 128 == 0 and (a.M // 128) * (a.K // 128) >= 512 else 64), 2.0 * a.M * a.K * a.K
+        by = 4.0 * a.M * a.K * (2 + (0 if _null(a.add_in) else 1) + (0 if _null(a.prev_y) else 1)) + 4.0 * a.K * a.K
+        return 'k_pointmlp_dgrad_gram<%d>' % (128 if a.K % 128 == 0 and (a.M // 128) * (a.K // 128) >= 512 else 64), 2.0 * a.M * a.K * a.K, by
     if name == 't3d_pointmlp_gram':
         rps, tk, tn = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
         LIB.t3d_wgrad_plan(a.M, a.K, a.K, ctypes.byref(rps), ctypes.byref(tk), ctypes.byref(tn))
         t = tk.value if (rps.value == a.rows_per_split and tk.value == tn.value) else 64
-        return 'k_pointmlp_gram<%d,%d>' % (t, t), 2.0 * a.M * a.K * a.K
+        return 'k_pointmlp_gram<%d,%d>' % (t, t), 2.0 * a.M * a.K * a.K, 4.0 * a.M * a.K + 4.0 * (a.M // a.rows_per_split) * a.K * a.K
     flops = 2.0 * a.M * a.K * a.N
     if name == 't3d_pointmlp_fwd':
-        return 'k_pointmlp_fwd<%d>' % (128 if a.N % 128 == 0 and (a.M // 128) * (a.N // 128) >= 512 else 64), flops
+        by = 4.0 * (a.M * a.K + a.K * a.N + (0 if _null(a.y) else a.M * a.N))
+        if os.environ.get('T3D_FWD_POOL', '1') != '0' and _null(a.y) and not _null(a.pmax) and _null(a.a.sub) and a.K == 128 and \
+                a.N % 128 == 0 and a.N >= 256:
+            return 'k_pointmlp_fwd_pool<128,32,8>', flops, by
+        return 'k_pointmlp_fwd<%d>' % (128 if a.N % 128 == 0 and (a.M // 128) * (a.N // 128) >= 512 else 64), flops, by
     if name == 't3d_pointmlp_dgrad':
-        return 'k_pointmlp_dgrad<%d>' % (128 if a.K % 128 == 0 and (a.M // 128) * (a.K // 128) >= 512 else 64), flops
+        by = 4.0 * (2 * a.M * a.N + a.K * a.N + a.M * a.K * (1 + (0 if _null(a.prev_y) else 1) + (0 if _null(a.add_in) else 1)))
+        return 'k_pointmlp_dgrad<%d>' % (128 if a.K % 128 == 0 and (a.M // 128) * (a.K // 128) >= 512 else 64), flops, by
     rps, tk, tn = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
     LIB.t3d_wgrad_plan(a.M, a.K, a.N, ctypes.byref(rps), ctypes.byref(tk), ctypes.byref(tn))
     if rps.value != a.rows_per_split:
         tk.value, tn.value = (128 if a.K > 64 else 64), (128 if a.N % 128 == 0 else 64)
-    return 'k_pointmlp_wgrad<%d,%d>' % (tk.value, tn.value), flops
+    by = 4.0 * (a.M * a.K + 2 * a.M * a.N + (a.M // a.rows_per_split) * a.K * a.N)
+    return 'k_pointmlp_wgrad<%d,%d>' % (tk.value, tn.value), flops, by
 
 
 def profile_kernels(plans, steps):
@@ -106,12 +131,13 @@ def profile_kernels(plans, steps):
         torch.cuda.synchronize()
         for ci, (name, arg, e0, e1) in enumerate(evs):
             CALLS.setdefault(ci, [name, arg, 0.0])[2] += e0.elapsed_time(e1) * 1e-3 / steps
-            label, flops = (gemm_label_and_flops(name, arg) if name.startswith(('t3d_pointmlp', 't3d_pool_bwd_stage')) else (name, 0.0))
-            d = acc.setdefault(label, [0.0, 0, 0.0])
+            label, flops, nbytes = (gemm_work(name, arg) if name.startswith(('t3d_pointmlp', 't3d_pool_bwd_stage')) else (name, 0.0, 0.0))
+            d = acc.setdefault(label, [0.0, 0, 0.0, 0.0])
             dt = e0.elapsed_time(e1) * 1e-3
             d[0] += dt
             d[1] += 1
             d[2] += flops
+            d[3] += nbytes
             if flops:
                 a0 = (arg[1] if name == 't3d_pool_bwd_stage2' else arg[0]) if isinstance(arg, tuple) else arg
                 dd = detail.setdefault('%s M%d K%d N%d' % (label, a0.M, a0.K, getattr(a0, 'N', a0.K)), [0.0, 0, flops])
@@ -263,12 +289,22 @@ def main():
         acc, detail = profile_kernels([g.pre, g.fwd, g.bwd, g.opt], args.profile_steps)
         total = sum(v[0] for v in acc.values())
         dom = max((k for k in acc if k.startswith(('k_pointmlp', 'k_pool_bwd_stage'))), key=lambda k: acc[k][0])
-        tsec, n, fl = acc[dom]
+        tsec, n, fl, nby = acc[dom]
+        # the roofline that bounds the dominant kernel: the larger of (algorithmic FLOPs / MFMA peak) and (algorithmic bytes / HBM peak)
+        mfma_bound = fl / (MFMA_F32_PEAK_TFLOPS * 1e12) >= nby / (HBM_PEAK_TBS * 1e12)
         achieved = fl / tsec / 1e12
+        hbm_achieved = nby / tsec / 1e9
         gemm_t = sum(v[0] for k, v in acc.items() if k.startswith(('k_pointmlp', 'k_pool_bwd_stage')))
         gemm_f = sum(v[2] for k, v in acc.items() if k.startswith(('k_pointmlp', 'k_pool_bwd_stage')))
-        roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': achieved, 'peak': MFMA_F32_PEAK_TFLOPS,
-                    'unit': 'TFLOP/s', 'frac': achieved / MFMA_F32_PEAK_TFLOPS, 'traffic': pmc_traffic(dom),
+        roofline = {'bound': 'mfma' if mfma_bound else 'hbm', 'kernel': dom,
+                    'achieved': achieved if mfma_bound else hbm_achieved,
+                    'peak': MFMA_F32_PEAK_TFLOPS if mfma_bound else HBM_PEAK_TBS * 1e3,
+                    'unit': 'TFLOP/s' if mfma_bound else 'GB/s',
+                    'frac': achieved / MFMA_F32_PEAK_TFLOPS if mfma_bound else hbm_achieved / (HBM_PEAK_TBS * 1e3),
+                    'mfma': {'achieved_tflops': achieved, 'frac': achieved / MFMA_F32_PEAK_TFLOPS},
+                    'hbm': {'achieved_gbs': hbm_achieved, 'frac': hbm_achieved / (HBM_PEAK_TBS * 1e3),
+                            'algorithmic_bytes_per_launch': nby / n},
+                    'traffic': pmc_traffic(dom),
                     'traffic_unit': 'HBM bytes per launch, rocprofv3 PMC passes of this workload (profiles/pmc_traffic.json)',
                     'avg_launch_us': tsec / n * 1e6, 'launches_per_step': n // args.profile_steps,
                     'flops_per_launch': fl / n,

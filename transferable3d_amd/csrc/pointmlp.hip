@@ -637,7 +637,7 @@ __device__ __forceinline__ void dgrad_body(const t3d_pointmlp_dgrad_args& p, flo
   const int tid = threadIdx.x, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int tiles_n = p.K / BN;
-  const int lin = xcd_remap(bid, nblocks);
+  const int lin = nblocks > 0 ? xcd_remap(bid, nblocks) : bid;      // nblocks == 0: `bid` already is the logical tile index
   const int tile_m = lin / tiles_n, tile_n = lin % tiles_n;
   const int row0 = tile_m * BM, col0 = tile_n * BN;
 
@@ -711,7 +711,7 @@ __device__ __forceinline__ void wgrad_body(const LA& la, const LB& lb, float* sl
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int tiles_k = (K + BMK - 1) / BMK, tiles_n = N / BN;
-  const int lin = xcd_remap(bid, nblocks);
+  const int lin = nblocks > 0 ? xcd_remap(bid, nblocks) : bid;      // nblocks == 0: `bid` already is the logical tile index
   const int split = lin / (tiles_k * tiles_n);
   const int t = lin % (tiles_k * tiles_n);
   const int k0 = (t / tiles_n) * BMK, n0 = (t % tiles_n) * BN;
@@ -760,11 +760,20 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_gram(const t3d_point
 // kernel's fill/drain latency per layer and lets the tiles of one kind fill the holes the other leaves on a CU.
 template <int DBN, int WBMK, int WBN>
 __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_bwd(const t3d_pointmlp_dgrad_args d, const t3d_pointmlp_wgrad_args w,
-                                                                const int n_wgrad) {
+                                                                const int n_wgrad, const int interleave) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if ((int)blockIdx.x < n_wgrad) {
-    ActLoader<false> la{w.a, w.K, w.rows_per_frustum};
-    DyLoader<false> lb{w.dy, w.N, w.rows_per_frustum};
+  ActLoader<false> la{w.a, w.K, w.rows_per_frustum};
+  DyLoader<false> lb{w.dy, w.N, w.rows_per_frustum};
+  if (interleave) {
+    // logical order: per row split, its weight-gradient tiles followed by the data-gradient tiles of the same rows; the
+    // XCD remap hands each XCD a contiguous piece of that order, so both readers of a dy row range share one L2
+    const int wt = ((w.K + WBMK - 1) / WBMK) * (w.N / WBN), tiles_nd = d.K / DBN;
+    const int dt = (w.rows_per_split / 128) * tiles_nd, grp_sz = wt + dt;
+    const int l = xcd_remap(blockIdx.x, gridDim.x);
+    const int grp = l / grp_sz, r = l % grp_sz;
+    if (r < wt) wgrad_body<WBMK, WBN>(la, lb, w.slabs, w.K, w.N, w.rows_per_split, smem, grp * wt + r, 0);
+    else dgrad_body<DBN, false>(d, smem, grp * dt + (r - wt), 0);
+  } else if ((int)blockIdx.x < n_wgrad) {
     wgrad_body<WBMK, WBN>(la, lb, w.slabs, w.K, w.N, w.rows_per_split, smem, blockIdx.x, n_wgrad);
   } else {
     dgrad_body<DBN, false>(d, smem, blockIdx.x - n_wgrad, gridDim.x - n_wgrad);
@@ -1329,12 +1338,16 @@ extern "C" int t3d_pointmlp_bwd(const t3d_pointmlp_dgrad_args* d, const t3d_poin
   const bool wide = dgrad_wide(d);
   const int n_d = (d->M / 128) * (d->K / (wide ? 128 : 64));
   const dim3 grid(n_w + n_d);
+  // interleaving the two kinds of tile by row range (so that both readers of a dy row range share an L2) measured SLOWER
+  // than weight-gradient tiles first (1.683 vs 1.630 ms per step): the long wgrad tiles are better started early.
+  static const bool il = []() { const char* e = getenv("T3D_BWD_INTERLEAVE"); return e && e[0] == '1'; }();
+  const int interleave = (il && w->rows_per_split % 128 == 0) ? 1 : 0;
 #define T3D_BWD(DBN, TK, TN_)                                                                                      \
   do {                                                                                                              \
     const size_t lds = lds_dgrad(DBN) > lds_wgrad(TK, TN_) ? lds_dgrad(DBN) : lds_wgrad(TK, TN_);                   \
     auto kern = k_pointmlp_bwd<DBN, TK, TN_>;                                                                       \
     allow_lds(reinterpret_cast<const void*>(kern), lds);                                                            \
-    T3D_LAUNCH(kern, grid, dim3(NT), lds, s, *d, *w, n_w);                                                          \
+    T3D_LAUNCH(kern, grid, dim3(NT), lds, s, *d, *w, n_w, interleave);                                              \
   } while (0)
 #define T3D_BWD_W(DBN)                              \
   do {                                              \
