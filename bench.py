@@ -37,6 +37,8 @@ def parse():
     ap.add_argument('--batch_size', type=int, default=32)
     ap.add_argument('--num_point', type=int, default=1024)
     ap.add_argument('--num_channel', type=int, default=4)
+    ap.add_argument('--workload', choices=['A', 'boxpc', 'F'], default='A',
+                    help='A = BASELINE configs[1] (the metric); boxpc / F = configs[2] / configs[3], informational')
     ap.add_argument('--no_graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--cpu_steps', type=int, default=2)
@@ -131,7 +133,8 @@ def profile_kernels(plans, steps):
         torch.cuda.synchronize()
         for ci, (name, arg, e0, e1) in enumerate(evs):
             CALLS.setdefault(ci, [name, arg, 0.0])[2] += e0.elapsed_time(e1) * 1e-3 / steps
-            label, flops, nbytes = (gemm_work(name, arg) if name.startswith(('t3d_pointmlp', 't3d_pool_bwd_stage')) else (name, 0.0, 0.0))
+            label, flops, nbytes = (gemm_work(name, arg) if name.startswith(('t3d_pointmlp', 't3d_pool_bwd_stage')) and
+                                    name != 't3d_pointmlp_dgrad_narrow' else (name, 0.0, 0.0))
             d = acc.setdefault(label, [0.0, 0, 0.0, 0.0])
             dt = e0.elapsed_time(e1) * 1e-3
             d[0] += dt
@@ -201,7 +204,7 @@ def main():
 
     from oracle import ref_torch as R     # config defaults only (SimpleNamespace); not on the timed path
     from transferable3d_amd.engine import Runtime, Plan
-    from transferable3d_amd.nets import Graph, SemiModelA, make_schedule
+    from transferable3d_amd.nets import BoxPCModel, Graph, SemiModelA, SemiModelF, make_schedule
     from transferable3d_amd.synthetic import make_batch
 
     B, N, C = args.batch_size, args.num_point, args.num_channel
@@ -209,16 +212,34 @@ def main():
     global LIB
     LIB = rt.lib
     g = Graph(B, N, C, rt=rt, seed=0)              # identical initial weights on every rank
-    c = R.default_config()
-    model = SemiModelA(g, c)
+    prefixes = None
+    if args.workload == 'A':
+        c = R.default_config()
+        model = SemiModelA(g, c)
+        loss_buf = lambda: model.loss_op.loss
+        desc = 'seg-PointNet + T-Net + box-est fwd+bwd+Adam (SEMI_MODEL A)'
+    elif args.workload == 'boxpc':
+        c = R.default_config(BOXPC_WEIGHT_DELTA=4.0)
+        model = BoxPCModel(g, c, False)
+        loss_buf = lambda: model.loss_op.loss
+        desc = 'Box-PC Fit net fwd+bwd+Adam (train_boxpc.py path)'
+    else:
+        c = R.default_config(SEMI_MODEL='F', WEAK_WEIGHT_INTRACLASSVAR=2.0, SEMI_MULTIPLIER_FOR_WEAK_LOSS=0.05,
+                             SEMI_BOXPC_FIT_ONLY_ON_2D_CLS=True, SEMI_WEIGHT_BOXPC_FIT_LOSS=1.0)
+        model = SemiModelF(g, c, use_one_hot=True, train_classes=[i in (1, 2, 6, 7, 8) for i in range(10)])
+        loss_buf = lambda: model.loss
+        prefixes = list(SemiModelF.VAR_LIST)
+        desc = 'SEMI_MODEL F stage c (frozen seg + Box-PC branch, var_list optimiser) fwd+bwd+Adam'
     sched = make_schedule(B * world)
     g.emit_schedule(g.pre, sched)
     g.emit_dropout_masks(g.pre, seed=1234 + rank)
     model.emit_forward(g.fwd, True, True)
     model.emit_backward(g.bwd)
-    g.emit_adam(g.opt, grad_scale=1.0 / world)
+    g.emit_adam(g.opt, prefixes=prefixes, grad_scale=1.0 / world)
     g.finalize()
-    batch = make_batch(B, N, C, seed=1234 + rank)  # per-rank shard of the global batch (weak scaling)
+    batch = make_batch(B, N, C, seed=1234 + rank, boxpc=args.workload == 'boxpc')  # per-rank shard (weak scaling)
+    if args.workload == 'F':
+        batch['is_data_2D'][::2] = 1
     model.inputs.load(batch)
     torch.cuda.synchronize()
 
@@ -279,7 +300,7 @@ def main():
         t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    loss = float(model.loss_op.loss.item())
+    loss = float(loss_buf().item())
     assert np.isfinite(loss), 'non-finite loss'
 
     roofline = None
@@ -310,7 +331,7 @@ def main():
                     'flops_per_launch': fl / n,
                     'all_gemm_kernels': {'achieved': gemm_f / gemm_t / 1e12, 'frac': gemm_f / gemm_t / 1e12 / MFMA_F32_PEAK_TFLOPS,
                                          'share_of_step_kernel_time': gemm_t / total},
-                    'whole_step': {'gflop_per_frustum_split': SPLIT_GFLOP_PER_FRUSTUM,
+                    'whole_step': None if args.workload != 'A' else {'gflop_per_frustum_split': SPLIT_GFLOP_PER_FRUSTUM,
                                    # what the GEMM kernels actually execute (the Gram-form backward of the pooled layers needs
                                    # fewer FLOPs than the split count the roofline figure is quoted on)
                                    'gflop_per_frustum_executed': gemm_f / args.profile_steps / B / 1e9,
@@ -327,7 +348,7 @@ def main():
         if args.gemm_detail:
             for k, (t_, n_, f_) in sorted(detail.items(), key=lambda kv: -kv[1][0]):
                 sys.stderr.write('%-44s x%d  %8.1f us  %6.1f TF/s\n' % (k, n_ // args.profile_steps, t_ / n_ * 1e6, f_ / (t_ / n_) / 1e12))
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'A':
         cpu = cpu_baseline(args, batch)
 
     if rank == 0:
@@ -335,8 +356,7 @@ def main():
         out = {'metric': 'frustums/sec fwd+bwd', 'value': value, 'unit': 'frustums/s', 'n_gpus': world, 'steps': args.steps,
                'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
                'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-               'config': {'workload': 'seg-PointNet + T-Net + box-est fwd+bwd+Adam (SEMI_MODEL A), B=%d N=%d C=%d fp32 per GPU, '
-                                      'dp%d' % (B, N, C, world), 'global_batch': B * world, 'hipgraph': use_graph,
+               'config': {'workload': '%s, B=%d N=%d C=%d fp32 per GPU, dp%d' % (desc, B, N, C, world), 'global_batch': B * world, 'hipgraph': use_graph,
                           'launches_per_step': len(g.pre) + len(g.fwd) + len(g.bwd) + len(g.opt), 'final_loss': loss},
                'roofline': roofline, 'cpu_baseline': cpu}
         print(json.dumps(out))
