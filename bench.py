@@ -202,7 +202,7 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
-    from oracle import ref_torch as R     # config defaults only (SimpleNamespace); not on the timed path
+    from transferable3d_amd.config import make_parser
     from transferable3d_amd.engine import Runtime, Plan
     from transferable3d_amd.nets import BoxPCModel, Graph, SemiModelA, SemiModelF, make_schedule
     from transferable3d_amd.synthetic import make_batch
@@ -214,18 +214,19 @@ def main():
     g = Graph(B, N, C, rt=rt, seed=0)              # identical initial weights on every rank
     prefixes = None
     if args.workload == 'A':
-        c = R.default_config()
+        c = make_parser().parse_special_args(['--SEMI_MODEL', 'A', '--WEAK_WEIGHT_REPROJECTION', '0', '--WEAK_WEIGHT_SURFACE', '0'])
         model = SemiModelA(g, c)
         loss_buf = lambda: model.loss_op.loss
         desc = 'seg-PointNet + T-Net + box-est fwd+bwd+Adam (SEMI_MODEL A)'
     elif args.workload == 'boxpc':
-        c = R.default_config(BOXPC_WEIGHT_DELTA=4.0)
+        c = make_parser().parse_special_args(['--BOX_PC_MASK_REPRESENTATION', 'A', '--BOXPC_WEIGHT_DELTA', '4'])
         model = BoxPCModel(g, c, False)
         loss_buf = lambda: model.loss_op.loss
         desc = 'Box-PC Fit net fwd+bwd+Adam (train_boxpc.py path)'
     else:
-        c = R.default_config(SEMI_MODEL='F', WEAK_WEIGHT_INTRACLASSVAR=2.0, SEMI_MULTIPLIER_FOR_WEAK_LOSS=0.05,
-                             SEMI_BOXPC_FIT_ONLY_ON_2D_CLS=True, SEMI_WEIGHT_BOXPC_FIT_LOSS=1.0)
+        c = make_parser().parse_special_args(
+            ['--SEMI_MODEL', 'F', '--BOX_PC_MASK_REPRESENTATION', 'A', '--WEAK_WEIGHT_INTRACLASSVAR', '2', '--WEAK_WEIGHT_REPROJECTION', '0',
+             '--SEMI_MULTIPLIER_FOR_WEAK_LOSS', '0.05', '--SEMI_BOXPC_FIT_ONLY_ON_2D_CLS', '1', '--SEMI_WEIGHT_BOXPC_FIT_LOSS', '1'])
         model = SemiModelF(g, c, use_one_hot=True, train_classes=[i in (1, 2, 6, 7, 8) for i in range(10)])
         loss_buf = lambda: model.loss
         prefixes = list(SemiModelF.VAR_LIST)
