@@ -1062,3 +1062,78 @@ def test_bn_fwd_finalize_with_fused_pool_pick(hip_lib):
     for k in res[0]:
         assert torch.equal(res[0][k], res[1][k]), k
     assert float(res[1]['pooled'].abs().max()) > 0
+
+
+def _sweep_cases(seed, n):
+    """Seeded random shapes on the contract of t3d.h (M, rows_per_frustum multiples of 128; widths multiples of 64; K any)."""
+    r = np.random.RandomState(seed)
+    out = []
+    for _ in range(n):
+        rpf = int(r.choice([128, 256, 384]))
+        M = rpf * int(r.randint(1, 5))
+        K = int(r.choice([3, 4, 64, 128, 192, 256, 320, 512]))
+        N = int(r.choice([64, 128, 192, 256, 384, 512]))
+        out.append((M, K, N, rpf))
+    return out
+
+
+@pytest.mark.parametrize('M,K,N,rpf', _sweep_cases(2024, 14))
+def test_pointmlp_shape_sweep_fwd_bwd_against_spec(hip_lib, M, K, N, rpf):
+    """Tile-edge coverage: widths that are not multiples of the 128-wide tile, reduction lengths that are not multiples of
+    the 32-deep k-tile, single-tile grids; forward, fused backward (when K % 64 == 0) or weight gradient alone."""
+    r = np.random.RandomState(M + 7 * K + 13 * N)
+    B, T = M // rpf, M // 128
+    ldx = 4 if K <= 4 else K
+    d = dict(x=r.normal(size=(M, ldx)).astype(np.float32), sc=(0.5 + r.uniform(size=max(K, 4))).astype(np.float32),
+             sh=(r.normal(size=max(K, 4)) * 0.3).astype(np.float32), w=(r.normal(size=(K, N)) / np.sqrt(K)).astype(np.float32),
+             bias=(r.normal(size=N) * 0.1).astype(np.float32), dz=(r.normal(size=(M, N)) * 1e-2).astype(np.float32),
+             y=r.normal(size=(M, N)).astype(np.float32), coef=r.normal(size=(3, N)).astype(np.float32))
+    bn = K > 4
+
+    def act(t):
+        return abi.ActSrc(fptr(t['x']), ldx, 0, fptr(t['sc'] if bn else None), fptr(t['sh'] if bn else None), int(bn), fptr(None), 0)
+
+    def make_f(dev):
+        t = {k: _mk(dev, v) for k, v in d.items()}
+        o = dict(y=torch.zeros(M, N, device=dev), psum=torch.zeros(T, N, device=dev), psumsq=torch.zeros(T, N, device=dev))
+        a = abi.PointMlpFwdArgs()
+        a.a, a.w, a.bias, a.y, a.psum, a.psumsq = act(t), fptr(t['w']), fptr(t['bias']), fptr(o['y']), fptr(o['psum']), fptr(o['psumsq'])
+        a.M, a.K, a.N, a.rows_per_frustum = M, K, N, rpf
+        a._keep = (t, o)
+        return a, o
+
+    c, g = _run_both(hip_lib, make_f, 't3d_pointmlp_fwd')
+    _close(c['y'], g['y'], 2e-5, 3e-5, 'y')
+    _close(c['psum'], g['psum'], 1e-4, 3e-3, 'psum')
+
+    rps, tk, tn = C.c_int(0), C.c_int(0), C.c_int(0)
+    assert hip_lib.t3d_wgrad_plan(M, K, N, C.byref(rps), C.byref(tk), C.byref(tn)) == 0
+    S = M // rps.value
+
+    def make_w(dev):
+        t = {k: _mk(dev, v) for k, v in d.items()}
+        o = dict(slabs=torch.zeros(S, K, N, device=dev))
+        dy = abi.DySrc(fptr(t['dz']), fptr(t['y']), fptr(t['coef']), iptr(None), fptr(None))
+        a = abi.PointMlpWgradArgs(act(t), dy, fptr(o['slabs']), M, K, N, rpf, rps.value)
+        a._keep = (t, o)
+        return a, o
+
+    c, g = _run_both(hip_lib, make_w, 't3d_pointmlp_wgrad')
+    _close(c['slabs'].sum(0), g['slabs'].sum(0), 1e-4, 3e-5 * float(c['slabs'].sum(0).abs().max()), 'dW')
+    if K % 64:
+        return
+
+    def make_d(dev):
+        t = {k: _mk(dev, v) for k, v in d.items()}
+        o = dict(out=torch.zeros(M, K, device=dev), s1=torch.zeros(T, K, device=dev), s2=torch.zeros(T, K, device=dev))
+        a = abi.PointMlpDgradArgs()
+        a.dy = abi.DySrc(fptr(t['dz']), fptr(t['y']), fptr(t['coef']), iptr(None), fptr(None))
+        a.w, a.out, a.prev_y, a.prev_scale, a.prev_shift = fptr(t['w']), fptr(o['out']), fptr(t['x']), fptr(t['sc']), fptr(t['sh'])
+        a.psum_dz, a.psum_dzy, a.M, a.K, a.N, a.rows_per_frustum = fptr(o['s1']), fptr(o['s2']), M, K, N, rpf
+        a._keep = (t, o)
+        return a, o
+
+    c, g = _run_both(hip_lib, make_d, 't3d_pointmlp_dgrad')
+    scale = float(c['out'].abs().max())
+    _close(c['out'], g['out'], 1e-4, 3e-5 * scale, 'dX')
+    _close(c['s1'], g['s1'], 1e-3, 1e-3 * scale, 'psum_dz')
