@@ -573,6 +573,46 @@ typedef struct {
 } t3d_box_refine_step_args;
 int t3d_box_refine_step(const t3d_box_refine_step_args* args, t3d_stream_t stream);
 
+/* ---- device-side batch assembly -------------------------------------------------------------------------------
+ * Replaces the host loop ROISemiDataset.get_batch -> get_classes3D (roi_semi_dataset.py:283-347, 482-535; helpers
+ * roi_seg_box3d_dataset.py:37-77, 346-368) for a data set of ragged frustums resident in HBM.  Per batch slot b with
+ * frustum f = sample[b]: N points drawn with replacement (np.random.choice(count, N, replace=True), 301-303), rotated to
+ * the centre view (rot = pi/2 + frustum_angle; [x,z] <- [x c - z s, x s + z c]), flipped in x with probability 1/2,
+ * shifted along z by clip(randn*dist*0.05, 0.8 dist, 1.2 dist) with dist = |centre.xy| (the reference's bounds, as
+ * written) and along y by U(-0.2, 0.2); labels: rotated/flipped/shifted box centre, heading -> (bin, residual) by
+ * angle2class over 12 bins, size -> (class, size - mean size of the class), one-hot class.
+ * Draws: `choice` [B,N] and `aug` [B,3] = (flip, randn, u) when given (parity tests), else generated from
+ * (seed, hyper[0] = step, b, n) -- so the whole input pipeline can sit inside the captured step. */
+typedef struct {
+  const float* points;         /* [total, C_src] all frustums, concatenated; xyz in columns 0..2 */
+  const int32_t* seg;          /* [total] per-point labels */
+  const int64_t* offsets;      /* [F+1] */
+  const float* frustum_angle;  /* [F] */
+  const float* box_center;     /* [F,3] */
+  const float* heading;        /* [F] */
+  const float* size;           /* [F,3] (l,w,h) */
+  const int32_t* cls;          /* [F] class id */
+  const int32_t* sample;       /* [B] frustum index per batch slot, or (sample_len > 0) a permutation [sample_len] of which slot b
+                                  of step s takes entry (s*B + b) mod sample_len */
+  int sample_len;
+  const int32_t* choice;       /* [B,N] or NULL */
+  const float* aug;            /* [B,3] or NULL */
+  int C_src, C, B, N;
+  int rotate_to_center, random_flip, random_shift;
+  uint32_t seed;
+  const float* hyper;          /* device step counter (hyper[0]); required when choice == NULL */
+  float* pc;                   /* [B,N,C] out */
+  int32_t* y_seg;              /* [B,N] out */
+  float* y_center;             /* [B,3] */
+  int32_t* y_orient_cls;       /* [B] */
+  float* y_orient_reg;         /* [B] */
+  int32_t* y_dims_cls;         /* [B] */
+  float* y_dims_reg;           /* [B,3] */
+  float* one_hot;              /* [B,10] */
+  float* rot_angle;            /* [B] or NULL */
+} t3d_batch_assemble_args;
+int t3d_batch_assemble(const t3d_batch_assemble_args* args, t3d_stream_t stream);
+
 /* ---- K11d / K12 / schedules --------------------------------------------------------------------- */
 
 /* grad[off_i + e] = sum_s slabs_i[s, e]  for every tensor i of a device-side table. */

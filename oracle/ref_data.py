@@ -1,0 +1,77 @@
+"""TEST INFRASTRUCTURE ONLY -- NumPy restatement of the reference's per-sample batch assembly.  PARITY UNPINNED (see
+oracle/README.md): the SUN-RGBD frustum pickles and cPickle/cv2 are absent, so this follows the code, not its outputs.
+
+Follows sunrgbd/sunrgbd_detection/roi_semi_dataset.py:283-347 (`get_classes3D`: resample to N points with replacement,
+rotate to the frustum's centre view, labels, flip / shift augmentation, angle and size classes) and 482-535 (`get_batch`),
+with the helpers of roi_seg_box3d_dataset.py:37-77,346-368.  The random draws of the reference (np.random.choice /
+random / randn) are arguments here, so that the device kernel can be checked on identical draws.
+"""
+import numpy as np
+
+from transferable3d_amd.constants import MEAN_DIMS_ARR, NUM_CLASS, NUM_HEADING_BIN
+
+
+def rotate_pc_along_y(pc, rot_angle):
+    """roi_seg_box3d_dataset.py:37-45 (on a copy)."""
+    pc = np.array(pc, dtype=np.float64, copy=True)
+    c, s = np.cos(rot_angle), np.sin(rot_angle)
+    rotmat = np.array([[c, -s], [s, c]])
+    pc[:, [0, 2]] = np.dot(pc[:, [0, 2]], rotmat.T)
+    return pc
+
+
+def angle2class(angle, num_class):
+    """roi_seg_box3d_dataset.py:47-62."""
+    angle = angle % (2 * np.pi)
+    per = 2 * np.pi / float(num_class)
+    shifted = (angle + per / 2) % (2 * np.pi)
+    cid = int(shifted / per)
+    return cid, shifted - (cid * per + per / 2)
+
+
+def get_sample(points, seg, frustum_angle, box_center, heading, size, cls, choice, flip, shift_randn, height_u, num_channel,
+               rotate_to_center=True, random_flip=True, random_shift=True):
+    """One frustum -> (point_set [N,C], seg [N], center [3], angle_class, angle_residual, size_class, size_residual [3],
+    rot_angle, one_hot [10]).  `choice` [N] ints, `flip` bool (the reference flips when np.random.random() > 0.5),
+    `shift_randn` ~ N(0,1), `height_u` ~ U(0,1)."""
+    rot_angle = np.pi / 2.0 + frustum_angle                                   # roi_seg_box3d_dataset.py:346-347
+    ps = rotate_pc_along_y(points, rot_angle) if rotate_to_center else np.array(points, dtype=np.float64)
+    ps = ps[choice, :]                                                        # roi_semi_dataset.py:301-303
+    sg = np.asarray(seg)[choice]
+    center = np.array(box_center, dtype=np.float64)
+    if rotate_to_center:
+        center = rotate_pc_along_y(center[None, :], rot_angle)[0]             # :319-320
+        heading_angle = heading - rot_angle                                   # :324-325
+    else:
+        heading_angle = heading
+    size_class, size_residual = int(cls), np.asarray(size, dtype=np.float64) - MEAN_DIMS_ARR[int(cls)]   # :330, size2class
+    if random_flip and flip:                                                  # :333-338
+        ps[:, 0] *= -1
+        center[0] *= -1
+        heading_angle = np.pi - heading_angle
+    if random_shift:                                                          # :339-346 (the clip bounds are the reference's)
+        dist = np.sqrt(np.sum(center[0] ** 2 + center[1] ** 2))
+        shift = np.clip(shift_randn * dist * 0.05, dist * 0.8, dist * 1.2)
+        ps[:, 2] += shift
+        center[2] += shift
+        hs = height_u * 0.4 - 0.2
+        ps[:, 1] += hs
+        center[1] += hs
+    acls, ares = angle2class(heading_angle, NUM_HEADING_BIN)
+    one_hot = np.zeros(NUM_CLASS)
+    one_hot[int(cls)] = 1
+    return ps[:, :num_channel], sg, center, acls, ares, size_class, size_residual, rot_angle, one_hot
+
+
+def get_batch(ds, sample, choice, flip, shift_randn, height_u, num_channel, **kw):
+    """roi_semi_dataset.py:482-535 on a ragged data set `ds` (dict: points [total,C], seg [total], offsets [F+1],
+    frustum_angle, box_center, heading, size, cls) for the frustum indices `sample` [B]."""
+    out = {k: [] for k in ('pc', 'y_seg', 'y_center', 'y_orient_cls', 'y_orient_reg', 'y_dims_cls', 'y_dims_reg', 'rot_angle',
+                           'one_hot_vec')}
+    for i, f in enumerate(sample):
+        lo, hi = int(ds['offsets'][f]), int(ds['offsets'][f + 1])
+        r = get_sample(ds['points'][lo:hi], ds['seg'][lo:hi], ds['frustum_angle'][f], ds['box_center'][f], ds['heading'][f],
+                       ds['size'][f], ds['cls'][f], choice[i], bool(flip[i]), shift_randn[i], height_u[i], num_channel, **kw)
+        for k, v in zip(out, r):
+            out[k].append(v)
+    return {k: np.asarray(v) for k, v in out.items()}

@@ -260,6 +260,88 @@ class FakeLib:
             slabs[s] = x[s * rps:(s + 1) * rps].T @ dy[s * rps:(s + 1) * rps]
         return 0
 
+    def t3d_batch_assemble(self, a, stream):
+        """Vectorised restatement of csrc/data.hip (the hash generator included, in uint64 NumPy arithmetic)."""
+        p = _struct(a)
+        B, N, Cc, Cs = p.B, p.N, p.C, p.C_src
+        step = int(arr(p.hyper, 1)[0]) if p.hyper else 0
+        M64 = (1 << 64) - 1
+
+        def mix(x):
+            x = np.asarray(x, dtype=np.uint64)
+            with np.errstate(over='ignore'):
+                x = x ^ (x >> np.uint64(33)); x = x * np.uint64(0xff51afd7ed558ccd)
+                x = x ^ (x >> np.uint64(33)); x = x * np.uint64(0xc4ceb9fe1a85ec53)
+                x = x ^ (x >> np.uint64(33))
+            return (x >> np.uint64(16)).astype(np.uint32)
+
+        def u01(r):
+            return ((r >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+        key = ((p.seed << 32) ^ ((step * 0x9E3779B97F4A7C15) & M64)) & M64
+        off = np.ctypeslib.as_array(p.offsets, shape=(1 << 30,))
+        if p.sample_len > 0:
+            perm = arr(p.sample, p.sample_len)
+            sample = perm[(step * B + np.arange(B)) % p.sample_len]
+        else:
+            sample = arr(p.sample, B)
+        F = int(sample.max()) + 1
+        total = int(off[F])
+        pts, seg = arr(p.points, total, Cs), arr(p.seg, total)
+        fang, bc, head, size, cls = arr(p.frustum_angle, F), arr(p.box_center, F, 3), arr(p.heading, F), arr(p.size, F, 3), arr(p.cls, F)
+        pc, yseg = arr(p.pc, B, N, Cc), arr(p.y_seg, B, N)
+        PI = np.float32(np.pi)
+        for b in range(B):
+            f = int(sample[b])
+            rot = PI * np.float32(0.5) + fang[f]
+            c, s_ = (np.cos(rot), np.sin(rot)) if p.rotate_to_center else (np.float32(1), np.float32(0))
+            cen = np.array([bc[f, 0] * c - bc[f, 2] * s_, bc[f, 1], bc[f, 0] * s_ + bc[f, 2] * c], np.float32)
+            heading = head[f] - rot if p.rotate_to_center else head[f]
+            if p.aug:
+                flip, rn, hu = arr(p.aug, B, 3)[b]
+            else:
+                kb = (key + (b + 1) * 0xA24BAED4963EE407) & M64
+                flip = np.float32(1.0) if u01(mix((kb + 1) & M64)) > 0.5 else np.float32(0.0)
+                rn = np.sqrt(np.float32(-2.0) * np.log(u01(mix((kb + 2) & M64)))) * np.cos(np.float32(2.0) * PI * u01(mix((kb + 3) & M64)))
+                hu = u01(mix((kb + 4) & M64))
+            flipx = np.float32(1)
+            if p.random_flip and flip != 0:
+                flipx, cen[0], heading = np.float32(-1), -cen[0], PI - heading
+            shift = hs = np.float32(0)
+            if p.random_shift:
+                dist = np.sqrt(cen[0] * cen[0] + cen[1] * cen[1])
+                shift = np.float32(min(max(rn * dist * np.float32(0.05), dist * np.float32(0.8)), dist * np.float32(1.2)))
+                hs = np.float32(hu * np.float32(0.4) - np.float32(0.2))
+                cen[2] += shift
+                cen[1] += hs
+            lo, cnt = int(off[f]), int(off[f + 1] - off[f])
+            if p.choice:
+                ch = arr(p.choice, B, N)[b].astype(np.int64)
+            else:
+                idx = (key + (np.uint64(b * N) + np.arange(N, dtype=np.uint64) + np.uint64(17)) * np.uint64(0xD6E8FEB86659FD93))
+                ch = ((mix(idx).astype(np.uint64) * np.uint64(cnt)) >> np.uint64(32)).astype(np.int64)
+            src = pts[lo + ch]
+            pc[b, :, 0] = (src[:, 0] * c - src[:, 2] * s_) * flipx
+            pc[b, :, 1] = src[:, 1] + hs
+            pc[b, :, 2] = src[:, 0] * s_ + src[:, 2] * c + shift
+            pc[b, :, 3:] = src[:, 3:Cc]
+            yseg[b] = seg[lo + ch]
+            two_pi, per = np.float32(2) * PI, np.float32(2) * PI / np.float32(12)
+            ang = np.fmod(np.float32(heading), two_pi)
+            ang = ang + two_pi if ang < 0 else ang
+            sh = np.fmod(ang + per * np.float32(0.5), two_pi)
+            cid = min(int(sh / per), 11)
+            arr(p.y_orient_cls, B)[b] = cid
+            arr(p.y_orient_reg, B)[b] = sh - (np.float32(cid) * per + per * np.float32(0.5))
+            arr(p.y_dims_cls, B)[b] = cls[f]
+            arr(p.y_center, B, 3)[b] = cen
+            arr(p.y_dims_reg, B, 3)[b] = size[f] - MEAN32[cls[f]]
+            oh = arr(p.one_hot, B, 10)
+            oh[b] = 0
+            oh[b, cls[f]] = 1
+            if p.rot_angle:
+                arr(p.rot_angle, B)[b] = rot
+        return 0
+
     def t3d_box_refine_step(self, a, stream):
         p = _struct(a)
         B = p.B

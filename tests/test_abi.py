@@ -39,7 +39,7 @@ def test_ctypes_structs_follow_header_field_order():
              't3d_anchor_reg_bwd_args': abi.AnchorRegBwdArgs, 't3d_pool_bwd_prep_args': abi.PoolBwdPrepArgs,
              't3d_pool_sparse_rows_args': abi.PoolSparseRowsArgs, 't3d_pointmlp_dgrad_gram_args': abi.PointMlpDgradGramArgs,
              't3d_pointmlp_gram_args': abi.PointMlpGramArgs, 't3d_act_colsum_args': abi.ActColsumArgs,
-             't3d_pool_wgrad_finish_args': abi.PoolWgradFinishArgs, 't3d_box_refine_step_args': abi.BoxRefineStepArgs}
+             't3d_pool_wgrad_finish_args': abi.PoolWgradFinishArgs, 't3d_box_refine_step_args': abi.BoxRefineStepArgs, 't3d_batch_assemble_args': abi.BatchAssembleArgs}
     for cname, cls in pairs.items():
         m = re.search(r'typedef struct \{([^}]*)\}\s*%s;' % cname, h)
         assert m, cname

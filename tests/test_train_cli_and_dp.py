@@ -131,3 +131,16 @@ def test_three_stage_recipe_on_synthetic_data(tmp_path):
     assert np.array_equal(sd_c['D_boxpc_branch/box_pc_mask_model/fc1/weights'], sd_b['box_pc_mask_model/fc1/weights'])
     assert np.array_equal(sd_c['class_agnostic/inst_seg/conv4/weights'], sd_a['inst_seg/conv4/weights'])
     assert not np.array_equal(sd_c['class_agnostic/tnet/fc1-stage1/weights'], sd_a['tnet/fc1-stage1/weights'])
+
+
+def test_cli_trains_from_a_device_resident_dataset(tmp_path):
+    """--device_data: nothing is fed, every batch is assembled by t3d_batch_assemble inside the step."""
+    logs = []
+    flags = build_flags(['--SEMI_MODEL', 'A', '--WEAK_WEIGHT_REPROJECTION', '0', '--WEAK_WEIGHT_SURFACE', '0', '--num_point', '128',
+                         '--batch_size', '4', '--num_channels', '4', '--max_epoch', '2', '--steps_per_epoch', '12', '--device_data', '24',
+                         '--log_dir', str(tmp_path)])
+    _, loss = train(flags, rt=Runtime(device='cpu', lib=FakeLib()), log=logs.append)
+    ep = [l for l in logs if 'EPOCH' in l]
+    assert len(ep) == 2 and 'assembled on the device' in ep[0]
+    l0, l1 = [float(l.split('mean loss: ')[1].split()[0]) for l in ep]
+    assert np.isfinite(l1) and l1 < l0

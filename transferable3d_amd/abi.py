@@ -86,6 +86,14 @@ class BoxRefineStepArgs(C.Structure):
                 ('total', F), ('fit_prob', F), ('weigh_by_conf', i32), ('first', i32), ('B', i32)]
 
 
+class BatchAssembleArgs(C.Structure):
+    _fields_ = [('points', F), ('seg', I), ('offsets', C.POINTER(C.c_int64)), ('frustum_angle', F), ('box_center', F), ('heading', F),
+                ('size', F), ('cls', I), ('sample', I), ('sample_len', i32), ('choice', I), ('aug', F), ('C_src', i32), ('C', i32), ('B', i32), ('N', i32),
+                ('rotate_to_center', i32), ('random_flip', i32), ('random_shift', i32), ('seed', C.c_uint32), ('hyper', F), ('pc', F),
+                ('y_seg', I), ('y_center', F), ('y_orient_cls', I), ('y_orient_reg', F), ('y_dims_cls', I), ('y_dims_reg', F),
+                ('one_hot', F), ('rot_angle', F)]
+
+
 class BnBwdFinalizeArgs(C.Structure):
     _fields_ = [('psum_dz', F), ('psum_dzy', F), ('n_tiles', i32), ('dpool_in', F), ('ld_dpool_in', i32),
                 ('pooled', F), ('ld_pooled', i32), ('ysel', F), ('dpool', F), ('B', i32), ('count', i32), ('N', i32),
@@ -204,6 +212,7 @@ ENTRY_POINTS = {
     't3d_pointmlp_gram': [C.POINTER(PointMlpGramArgs), VP],
     't3d_act_colsum': [C.POINTER(ActColsumArgs), VP],
     't3d_pool_wgrad_finish': [C.POINTER(PoolWgradFinishArgs), VP],
+    't3d_batch_assemble': [C.POINTER(BatchAssembleArgs), VP],
     't3d_box_refine_step': [C.POINTER(BoxRefineStepArgs), VP],
     't3d_pool_bwd_stage1': [C.POINTER(PointMlpGramArgs), C.POINTER(ActColsumArgs), C.POINTER(PoolBwdPrepArgs), VP],
     't3d_pool_bwd_mid': [F, F, C.POINTER(SlabDesc), i32, i32, C.POINTER(PoolSparseRowsArgs), VP],

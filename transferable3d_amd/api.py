@@ -74,6 +74,8 @@ class Graph:
         self.loss = None
         self.train_op = None
         self.compiled = {}
+        self.dataset = None         # dataset.DeviceFrustumSet: batches assembled on the device (Graph.use_device_dataset)
+        self.dataset_opts = {}
 
     @contextlib.contextmanager
     def as_default(self):
@@ -102,6 +104,11 @@ class Graph:
     @property
     def vars(self):
         return self.engine.vars
+
+    def use_device_dataset(self, dataset, seed=0, **aug):
+        """Feed the training plan from a data set resident in HBM: every Session.run of the train op assembles its own
+        batch on the device (t3d_batch_assemble), nothing needs to be fed."""
+        self.dataset, self.dataset_opts = dataset, dict(seed=seed, **aug)
 
     def ensure_assembly(self, c, use_one_hot=False):
         if self.assembly is None:
@@ -175,6 +182,8 @@ class Session:
         with_loss = g.loss is not None
         if train:
             top = g.train_op
+            if g.dataset is not None:
+                e.emit_batch_assemble(pre, g.dataset, g.inputs, **g.dataset_opts)
             e.emit_schedule(pre, top.sched)
             e.emit_dropout_masks(pre, seed=self.dropout_seed)
         asm.emit_forward(fwd, is_training, with_loss)

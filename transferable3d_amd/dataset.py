@@ -1,0 +1,110 @@
+"""A data set of ragged frustums resident in HBM + the launch that assembles a training batch from it on the device.
+
+The reference keeps the frustums as Python lists and builds every batch on the host (ROISemiDataset.get_batch ->
+get_classes3D, sunrgbd/sunrgbd_detection/roi_semi_dataset.py:283-347, 482-535): at ~20k frustums/s per GPU that loop, not
+the GPU, bounds training.  Here the whole data set (points, per-point labels, per-frustum box labels) is uploaded once
+-- SUN-RGBD's training frustums are a few GB of the 288 GB -- and `t3d_batch_assemble` (csrc/data.hip) draws, rotates,
+augments and labels a batch straight into the model's input buffers.  With an epoch permutation walked by the device step
+counter, the input pipeline becomes part of the captured step.
+
+The SUN-RGBD pickle reader itself is out of scope (gzip-pickle + cv2 + Python-2 cPickle); `from_lists`
+takes the same per-frustum fields the reference's loader produces, `synthetic` makes frustums of the SURVEY 8d distribution.
+"""
+import numpy as np
+import torch
+
+from . import abi
+from .abi import fptr, iptr
+from .constants import MEAN_DIMS_ARR, NUM_CLASS
+
+
+class DeviceFrustumSet:
+    def __init__(self, rt, points, seg, offsets, frustum_angle, box_center, heading, size, cls):
+        """points [total, C_src] fp32, seg [total] int32, offsets [F+1] int64 (ragged rows of frustum f:
+        offsets[f]..offsets[f+1]), per-frustum frustum_angle [F], box_center [F,3], heading [F], size [F,3] (l,w,h), cls [F]."""
+        dev = rt.device
+        up = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a)).to(dt).to(dev)
+        self.rt = rt
+        self.points, self.seg, self.offsets = up(points, torch.float32), up(seg, torch.int32), up(offsets, torch.int64)
+        self.frustum_angle, self.box_center = up(frustum_angle, torch.float32), up(box_center, torch.float32)
+        self.heading, self.size, self.cls = up(heading, torch.float32), up(size, torch.float32), up(cls, torch.int32)
+        self.F, self.C_src = int(self.cls.shape[0]), int(self.points.shape[1])
+        assert self.offsets.shape[0] == self.F + 1 and int(self.offsets[-1]) == self.points.shape[0]
+        self.perm = torch.arange(self.F, dtype=torch.int32, device=dev)
+        rt.allocs.extend([self.points, self.seg, self.offsets, self.frustum_angle, self.box_center, self.heading, self.size, self.cls,
+                          self.perm])
+
+    @classmethod
+    def from_lists(cls, rt, points_l, label_l, frustum_angle_l, box3d_center_l, heading_l, size_l, cls_id_l):
+        """The reference's per-frustum lists (roi_semi_dataset.py:240-252; box centre = (corner0 + corner6) / 2)."""
+        counts = np.array([len(p) for p in points_l], dtype=np.int64)
+        offsets = np.concatenate([[0], np.cumsum(counts)])
+        return cls(rt, np.concatenate(points_l).astype(np.float32), np.concatenate(label_l).astype(np.int32), offsets,
+                   np.asarray(frustum_angle_l), np.asarray(box3d_center_l), np.asarray(heading_l), np.asarray(size_l), np.asarray(cls_id_l))
+
+    @classmethod
+    def synthetic(cls, rt, n_frustums, num_channel=6, seed=0, min_points=400, max_points=3000):
+        """Frustums of the SURVEY 8d distribution with ragged point counts (real frustums have a few hundred to a few thousand)."""
+        host = synthetic_frustums(n_frustums, num_channel, seed, min_points, max_points)
+        return cls(rt, **host)
+
+    def shuffle(self, seed):
+        """New epoch order (the reference shuffles train_idxs once per epoch, train_semisup.py:343)."""
+        p = np.random.RandomState(seed).permutation(self.F).astype(np.int32)
+        self.perm.copy_(torch.as_tensor(p))
+
+    def assemble_args(self, inputs, hyper, B, N, C, seed=0, sample=None, choice=None, aug=None, rotate_to_center=True,
+                      random_flip=True, random_shift=True):
+        """Argument struct that writes a batch into `inputs` (nets.Inputs).  sample=None: walk the epoch permutation with the
+        device step counter; choice / aug given: explicit draws (parity tests)."""
+        a = abi.BatchAssembleArgs()
+        a.points, a.seg, a.offsets = fptr(self.points), iptr(self.seg), abi.C.cast(abi.C.c_void_p(self.offsets.data_ptr()),
+                                                                               abi.C.POINTER(abi.C.c_int64))
+        a.frustum_angle, a.box_center, a.heading, a.size, a.cls = fptr(self.frustum_angle), fptr(self.box_center), fptr(self.heading), \
+            fptr(self.size), iptr(self.cls)
+        if sample is None:
+            a.sample, a.sample_len = iptr(self.perm), self.F
+        else:
+            a.sample, a.sample_len = iptr(sample), 0
+        a.choice, a.aug = iptr(choice), fptr(aug)
+        a.C_src, a.C, a.B, a.N = self.C_src, C, B, N
+        a.rotate_to_center, a.random_flip, a.random_shift = int(rotate_to_center), int(random_flip), int(random_shift)
+        a.seed, a.hyper = seed, fptr(hyper)
+        a.pc, a.y_seg, a.y_center = fptr(inputs.pc), iptr(inputs.y_seg), fptr(inputs.y_center)
+        a.y_orient_cls, a.y_orient_reg = iptr(inputs.y_orient_cls), fptr(inputs.y_orient_reg)
+        a.y_dims_cls, a.y_dims_reg, a.one_hot = iptr(inputs.y_dims_cls), fptr(inputs.y_dims_reg), fptr(inputs.one_hot_vec)
+        a._keep = (sample, choice, aug)
+        return a
+
+
+def synthetic_frustums(n_frustums, num_channel=6, seed=0, min_points=400, max_points=3000):
+    """Host arrays for DeviceFrustumSet: xyz in camera-like coordinates before the centre-view rotation, extra channels
+    U(0,1), ~30 % foreground points clustered around the box centre, heading / size / class as in synthetic.make_batch."""
+    r = np.random.RandomState(seed)
+    counts = r.randint(min_points, max_points + 1, size=n_frustums).astype(np.int64)
+    offsets = np.concatenate([[0], np.cumsum(counts)])
+    total = int(offsets[-1])
+    fang = r.uniform(-0.6, 0.6, size=n_frustums) - np.pi / 2          # centre-view rotation pi/2 + angle in (-0.6, 0.6)
+    depth = r.uniform(1.5, 5.5, size=n_frustums)
+    cls_id = r.randint(0, NUM_CLASS, size=n_frustums).astype(np.int32)
+    size = MEAN_DIMS_ARR[cls_id] + r.normal(size=(n_frustums, 3)) * 0.1
+    heading = r.uniform(-np.pi, np.pi, size=n_frustums)
+    pts = np.zeros((total, num_channel), np.float32)
+    seg = np.zeros(total, np.int32)
+    center = np.zeros((n_frustums, 3))
+    for f in range(n_frustums):
+        lo, hi = offsets[f], offsets[f + 1]
+        n = hi - lo
+        rot = np.pi / 2 + fang[f]
+        fg = r.uniform(size=n) < 0.3
+        xc = np.where(fg[:, None], r.normal(size=(n, 3)) * 0.3 + [0.0, 0.2, depth[f]],
+                      np.stack([r.normal(size=n) * 0.6, r.normal(size=n) * 0.6, r.uniform(1.0, 6.0, size=n)], 1))
+        cen_c = np.array([0.0, 0.2, depth[f]]) + r.normal(size=3) * 0.1
+        # un-rotate: the stored frame is the one the centre-view rotation maps onto xc (inverse of [[c,-s],[s,c]])
+        c, s = np.cos(rot), np.sin(rot)
+        un = lambda v: np.stack([v[..., 0] * c + v[..., 2] * s, v[..., 1], -v[..., 0] * s + v[..., 2] * c], -1)
+        pts[lo:hi, :3] = un(xc)
+        pts[lo:hi, 3:] = r.uniform(size=(n, num_channel - 3))
+        seg[lo:hi] = fg
+        center[f] = un(cen_c)
+    return dict(points=pts, seg=seg, offsets=offsets, frustum_angle=fang, box_center=center, heading=heading, size=size, cls=cls_id)

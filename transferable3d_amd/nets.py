@@ -65,6 +65,12 @@ class Graph:
                                         n, mx, s)
         plan.add_raw('t3d_reduce_slabs', thunk)
 
+    def emit_batch_assemble(self, plan, dataset, inputs, seed=0, **aug):
+        """The input pipeline as a launch of the step: batch slot b of step s takes frustum perm[(s*B + b) % F] of the
+        HBM-resident data set (dataset.DeviceFrustumSet) -- recorded before the schedule kernel advances the step counter."""
+        a = dataset.assemble_args(inputs, self.hyper, self.B, self.rpf, self.C, seed=seed, **aug)
+        plan.add('t3d_batch_assemble', a)
+
     def emit_schedule(self, plan, sched):
         lib, hyper = self.rt.lib, self.hyper
         plan.add_raw('t3d_schedule_step', lambda s: lib.t3d_schedule_step(fptr(hyper), C.byref(sched), s), sched)

@@ -51,6 +51,9 @@ def build_flags(argv=None):
     cfg.add_argument('--synthetic', action='store_true', help='synthetic frustums (the only data source available)')
     cfg.add_argument('--num_channels', type=int, default=None, help='override point channels (reference: 6, or 3 with --no_rgb)')
     cfg.add_argument('--steps_per_epoch', type=int, default=100)
+    cfg.add_argument('--device_data', type=int, default=0, metavar='F',
+                     help='keep a synthetic data set of F ragged frustums in HBM and assemble every batch on the device '
+                          '(t3d_batch_assemble: resample / centre-view rotation / flip / shift / labels)')
     cfg.add_argument('--seed', type=int, default=0)
     FLAGS = cfg.parse_special_args(argv)
     FLAGS.NUM_CHANNELS = FLAGS.num_channels if FLAGS.num_channels else (3 if FLAGS.no_rgb else 6)
@@ -95,10 +98,32 @@ def train(FLAGS, rt=None, log=print):
             g.vars.load_state_dict(dict(np.load(FLAGS.restore_model_path)))
         n_correct = api.Tensor(g, g.assembly.seg.n_correct, (1,), 'n_correct')
         step = 0
+        ds = None
+        if FLAGS.device_data:
+            from transferable3d_amd.dataset import DeviceFrustumSet
+            ds = DeviceFrustumSet.synthetic(g.rt, FLAGS.device_data, num_channel=max(C, 6), seed=FLAGS.seed + 17 * rank)
+            g.use_device_dataset(ds, seed=FLAGS.seed * 7919 + rank)
         for epoch in range(FLAGS.max_epoch):
             t0 = time.time()
             loss_sum, correct = 0.0, 0.0
-            for it in range(FLAGS.steps_per_epoch):
+            if ds is not None:
+                # device pipeline: nothing is fed; the loss is fetched (a D2H sync) every 10th step only
+                ds.shuffle(FLAGS.seed * 1000003 + epoch * world + rank)      # train_semisup.py:343
+                n_logged = 0
+                for it in range(FLAGS.steps_per_epoch):
+                    if it % 10 == 9 or it == FLAGS.steps_per_epoch - 1:
+                        loss_val, nc, _ = sess.run([semi_loss, n_correct, train_op])
+                        loss_sum += float(loss_val)
+                        correct += float(nc[0])
+                        n_logged += 1
+                    else:
+                        sess.run([train_op])
+                    step += 1
+                if rank == 0:
+                    log('**** EPOCH %03d ****  mean loss: %f  accuracy: %f  (%.1f frustums/s, batches assembled on the device)' % (
+                        epoch, loss_sum / n_logged, correct / (n_logged * B * N), FLAGS.steps_per_epoch * B * world / (time.time() - t0)))
+                loss_sum = loss_sum / n_logged * FLAGS.steps_per_epoch
+            for it in range(0 if ds is not None else FLAGS.steps_per_epoch):
                 batch = make_batch(B, N, C, seed=FLAGS.seed * 1000003 + step * world + rank)
                 feed = {pc_pl: batch['pc'], one_hot_vec_pl: batch['one_hot_vec'], y_seg_pl: batch['y_seg'],
                         y_centers_pl: batch['y_center'], y_orient_cls_pl: batch['y_orient_cls'],
@@ -108,10 +133,11 @@ def train(FLAGS, rt=None, log=print):
                 loss_sum += float(loss_val)
                 correct += float(nc[0])
                 step += 1
-            if rank == 0:
+            if rank == 0 and ds is None:
                 log('**** EPOCH %03d ****  mean loss: %f  accuracy: %f  (%.1f frustums/s incl. host batch synthesis)' % (
                     epoch, loss_sum / FLAGS.steps_per_epoch, correct / (FLAGS.steps_per_epoch * B * N),
                     FLAGS.steps_per_epoch * B * world / (time.time() - t0)))
+            if rank == 0:
                 if epoch % 5 == 0:                       # train_semisup.py:316-318
                     path = os.path.join(FLAGS.log_dir, 'model_epoch_%d.npz' % epoch)
                     np.savez(path, **g.vars.state_dict())
