@@ -582,7 +582,8 @@ int t3d_box_refine_step(const t3d_box_refine_step_args* args, t3d_stream_t strea
  * written) and along y by U(-0.2, 0.2); labels: rotated/flipped/shifted box centre, heading -> (bin, residual) by
  * angle2class over 12 bins, size -> (class, size - mean size of the class), one-hot class.
  * Draws: `choice` [B,N] and `aug` [B,3] = (flip, randn, u) when given (parity tests), else generated from
- * (seed, hyper[0] = step, b, n) -- so the whole input pipeline can sit inside the captured step. */
+ * (seed, hyper[0] = step, b, n) -- so the whole input pipeline can sit inside the captured step.
+ * ALTERNATE_BATCH (train_semisup_adv.py:538-565, sample_pure_from_2D_cls / _3D_cls 589-596): see sample2. */
 typedef struct {
   const float* points;         /* [total, C_src] all frustums, concatenated; xyz in columns 0..2 */
   const int32_t* seg;          /* [total] per-point labels */
@@ -610,6 +611,11 @@ typedef struct {
   float* y_dims_reg;           /* [B,3] */
   float* one_hot;              /* [B,10] */
   float* rot_angle;            /* [B] or NULL */
+  const int32_t* sample2;      /* NULL, or the second list of ALTERNATE_BATCH sampling: even steps take slot b from
+                                  sample[((s/2)*B + b) mod sample_len] (2-D-label classes, is_data_2D = 1), odd steps from
+                                  sample2[((s/2)*B + b) mod sample2_len] (3-D-label classes, is_data_2D = 0) */
+  int sample2_len;
+  int32_t* is_data_2D;         /* [B] or NULL */
 } t3d_batch_assemble_args;
 int t3d_batch_assemble(const t3d_batch_assemble_args* args, t3d_stream_t stream);
 

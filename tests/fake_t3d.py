@@ -279,7 +279,12 @@ class FakeLib:
             return ((r >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
         key = ((p.seed << 32) ^ ((step * 0x9E3779B97F4A7C15) & M64)) & M64
         off = np.ctypeslib.as_array(p.offsets, shape=(1 << 30,))
-        if p.sample_len > 0:
+        from_first = True
+        if p.sample2:
+            from_first = step % 2 == 0
+            lst = arr(p.sample, p.sample_len) if from_first else arr(p.sample2, p.sample2_len)
+            sample = lst[((step // 2) * B + np.arange(B)) % len(lst)]
+        elif p.sample_len > 0:
             perm = arr(p.sample, p.sample_len)
             sample = perm[(step * B + np.arange(B)) % p.sample_len]
         else:
@@ -340,6 +345,8 @@ class FakeLib:
             oh[b, cls[f]] = 1
             if p.rot_angle:
                 arr(p.rot_angle, B)[b] = rot
+            if p.is_data_2D:
+                arr(p.is_data_2D, B)[b] = 1 if (p.sample2 and from_first) else 0
         return 0
 
     def t3d_box_refine_step(self, a, stream):

@@ -93,3 +93,35 @@ def test_batch_assembly_matches_the_reference_restatement():
 
 def test_generated_draws_and_permutation_walk():
     check_generated_draws(Runtime(device='cpu', lib=FakeLib()))
+
+
+def check_alternate_batch(rt):
+    """ALTERNATE_BATCH: even steps are pure weak (2-D-label classes, is_data_2D = 1), odd steps pure strong batches; a batch
+    holds distinct frustums (the reference samples without replacement within a batch)."""
+    B, N, Cc = 8, 128, 4
+    host = synthetic_frustums(120, num_channel=6, seed=2, min_points=64, max_points=200)
+    weak_cls = (1, 2, 6, 7, 8)
+    g = Graph(B, N, Cc, rt=rt)
+    x = Inputs(g)
+    ds = DeviceFrustumSet(rt, **host).split_by_class(weak_cls)
+    ds.shuffle(5)
+    a = ds.assemble_args(x, g.hyper, B, N, Cc, seed=1, alternate=True)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream) if rt.device.type == 'cuda' else None
+    seen = {0: [], 1: []}
+    for step in range(6):
+        g.hyper[0] = step
+        assert rt.lib.t3d_batch_assemble(C.byref(a), stream) == 0
+        if rt.device.type == 'cuda':
+            torch.cuda.synchronize()
+        cls, is2d = x.y_dims_cls.cpu().numpy(), x.is_data_2D.cpu().numpy()
+        weak = step % 2 == 0
+        assert (is2d == (1 if weak else 0)).all()
+        assert np.isin(cls, weak_cls).all() if weak else (~np.isin(cls, weak_cls)).all()
+        key = x.y_center.cpu().numpy()[:, 1].round(4)                # distinct frustums -> distinct (shifted) centres
+        assert len(np.unique(key)) == B
+        seen[step % 2].append(cls.copy())
+    assert not np.array_equal(seen[0][0], seen[0][1])               # the lists advance
+
+
+def test_alternate_batch_sampling():
+    check_alternate_batch(Runtime(device='cpu', lib=FakeLib()))

@@ -32,3 +32,8 @@ def test_generated_batch_equals_the_specification(hip_lib):
         assert np.array_equal(c['pc'][:, :, 3:], g['pc'][:, :, 3:])            # copied channels: same source points
         assert np.abs(c['pc'] - g['pc']).max() < 1e-4 and np.abs(c['y_center'] - g['y_center']).max() < 1e-4
         assert np.array_equal(c['y_orient_cls'], g['y_orient_cls']) and np.abs(c['y_orient_reg'] - g['y_orient_reg']).max() < 1e-5
+
+
+def test_alternate_batch_sampling(hip_lib):
+    from test_dataset_cpu import check_alternate_batch
+    check_alternate_batch(Runtime(lib=hip_lib))

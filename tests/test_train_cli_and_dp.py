@@ -144,3 +144,16 @@ def test_cli_trains_from_a_device_resident_dataset(tmp_path):
     assert len(ep) == 2 and 'assembled on the device' in ep[0]
     l0, l1 = [float(l.split('mean loss: ')[1].split()[0]) for l in ep]
     assert np.isfinite(l1) and l1 < l0
+
+
+def test_stage_c_cli_from_a_device_resident_dataset_alternates_weak_and_strong_batches(tmp_path):
+    from transferable3d_amd import train_semisup_adv
+    logs = []
+    flags = train_semisup_adv.build_flags(
+        ['--SEMI_MODEL', 'F', '--BOX_PC_MASK_REPRESENTATION', 'A', '--use_one_hot', '--SEMI_TRAIN_BOX_TRAIN_CLASS_AG_TNET', '1',
+         '--SEMI_TRAIN_BOX_TRAIN_CLASS_AG_BOX', '1', '--SEMI_BOXPC_FIT_ONLY_ON_2D_CLS', '1', '--WEAK_WEIGHT_INTRACLASSVAR', '2',
+         '--WEAK_WEIGHT_REPROJECTION', '0', '--SEMI_MULTIPLIER_FOR_WEAK_LOSS', '0.05', '--SUNRGBD_SEMI_TEST_CLS', 'table', 'sofa', 'dresser',
+         'night_stand', 'bookshelf', '--num_point', '128', '--batch_size', '4', '--num_channels', '4', '--max_epoch', '1',
+         '--steps_per_epoch', '4', '--device_data', '40', '--log_dir', str(tmp_path)])
+    sd, loss = train_semisup_adv.train(flags, rt=Runtime(device='cpu', lib=FakeLib()), log=logs.append)
+    assert np.isfinite(loss) and any('assembled on the device' in l for l in logs)

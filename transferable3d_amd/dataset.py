@@ -50,11 +50,26 @@ class DeviceFrustumSet:
 
     def shuffle(self, seed):
         """New epoch order (the reference shuffles train_idxs once per epoch, train_semisup.py:343)."""
-        p = np.random.RandomState(seed).permutation(self.F).astype(np.int32)
-        self.perm.copy_(torch.as_tensor(p))
+        r = np.random.RandomState(seed)
+        self.perm.copy_(torch.as_tensor(r.permutation(self.F).astype(np.int32)))
+        for lst, dev in getattr(self, 'subsets', []):
+            dev.copy_(torch.as_tensor(lst[r.permutation(len(lst))]))
+
+    def split_by_class(self, classes_2d):
+        """ALTERNATE_BATCH sampling (train_semisup_adv.py:538-565): the frustums of `classes_2d` (class ids whose 3-D labels
+        are withheld, SUNRGBD_SEMI_TEST_CLS) form the weak list, the rest the strong list; each is walked in its own shuffled
+        order on alternate steps."""
+        cls = self.cls.cpu().numpy()
+        weak = np.nonzero(np.isin(cls, list(classes_2d)))[0].astype(np.int32)
+        strong = np.nonzero(~np.isin(cls, list(classes_2d)))[0].astype(np.int32)
+        assert len(weak) and len(strong), 'both lists must be non-empty'
+        dev = self.rt.device
+        self.subsets = [(weak, torch.as_tensor(weak).to(dev)), (strong, torch.as_tensor(strong).to(dev))]
+        self.rt.allocs.extend([d for _, d in self.subsets])
+        return self
 
     def assemble_args(self, inputs, hyper, B, N, C, seed=0, sample=None, choice=None, aug=None, rotate_to_center=True,
-                      random_flip=True, random_shift=True):
+                      random_flip=True, random_shift=True, alternate=False):
         """Argument struct that writes a batch into `inputs` (nets.Inputs).  sample=None: walk the epoch permutation with the
         device step counter; choice / aug given: explicit draws (parity tests)."""
         a = abi.BatchAssembleArgs()
@@ -73,6 +88,10 @@ class DeviceFrustumSet:
         a.pc, a.y_seg, a.y_center = fptr(inputs.pc), iptr(inputs.y_seg), fptr(inputs.y_center)
         a.y_orient_cls, a.y_orient_reg = iptr(inputs.y_orient_cls), fptr(inputs.y_orient_reg)
         a.y_dims_cls, a.y_dims_reg, a.one_hot = iptr(inputs.y_dims_cls), fptr(inputs.y_dims_reg), fptr(inputs.one_hot_vec)
+        a.is_data_2D = iptr(inputs.is_data_2D)
+        if alternate:
+            (_, weak), (_, strong) = self.subsets
+            a.sample, a.sample_len, a.sample2, a.sample2_len = iptr(weak), int(weak.numel()), iptr(strong), int(strong.numel())
         a._keep = (sample, choice, aug)
         return a
 

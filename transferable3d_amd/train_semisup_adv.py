@@ -46,6 +46,9 @@ def build_flags(argv=None):
     cfg.add_argument('--synthetic', action='store_true')
     cfg.add_argument('--num_channels', type=int, default=None)
     cfg.add_argument('--steps_per_epoch', type=int, default=100)
+    cfg.add_argument('--device_data', type=int, default=0, metavar='F',
+                     help='keep a synthetic data set of F ragged frustums in HBM; batches (ALTERNATE_BATCH: weak / strong on '
+                          'alternate steps) are assembled on the device by t3d_batch_assemble')
     cfg.add_argument('--seed', type=int, default=0)
     FLAGS = cfg.parse_special_args(argv)
     FLAGS.NUM_CHANNELS = FLAGS.num_channels if FLAGS.num_channels else (3 if FLAGS.no_rgb else 6)
@@ -98,9 +101,30 @@ def train(FLAGS, rt=None, log=print):
         train_ids = [i for i in range(10) if i not in test_ids]
         step, mean_loss = 0, 0.0
         iters = 2 if FLAGS.SEMI_SAMPLING_METHOD == 'ALTERNATE_BATCH' else 1
+        ds = None
+        if FLAGS.device_data:
+            from transferable3d_amd.dataset import DeviceFrustumSet
+            ds = DeviceFrustumSet.synthetic(g.rt, FLAGS.device_data, num_channel=max(C, 6), seed=FLAGS.seed)
+            if iters == 2:
+                ds.split_by_class(test_ids)
+            g.use_device_dataset(ds, seed=FLAGS.seed * 7919, alternate=(iters == 2))
         for epoch in range(FLAGS.max_epoch):
             t0, loss_sum = time.time(), 0.0
-            for _ in range(FLAGS.steps_per_epoch):
+            if ds is not None:
+                ds.shuffle(FLAGS.seed * 1000003 + epoch)
+                n_steps, n_logged = FLAGS.steps_per_epoch * iters, 0
+                for it in range(n_steps):
+                    if it % 10 >= 8 or it >= n_steps - 2:              # a weak and a strong step out of every ten
+                        loss_val, _ = sess.run([semi_loss, train_op])
+                        loss_sum += float(loss_val)
+                        n_logged += 1
+                    else:
+                        sess.run([train_op])
+                    step += 1
+                mean_loss = loss_sum / n_logged
+                log('**** EPOCH %03d ****  mean loss: %f  (%.1f frustums/s, batches assembled on the device)' % (
+                    epoch, mean_loss, n_steps * B / (time.time() - t0)))
+            for _ in range(0 if ds is not None else FLAGS.steps_per_epoch):
                 for iteration in range(iters):
                     b = make_batch(B, N, C, seed=FLAGS.seed * 1000003 + step)
                     if iters == 2:                         # all-2D batch (classes without 3-D labels), then all-3D batch
@@ -114,9 +138,10 @@ def train(FLAGS, rt=None, log=print):
                     loss_val, _ = sess.run([semi_loss, train_op], feed_dict=feed)
                     loss_sum += float(loss_val)
                     step += 1
-            mean_loss = loss_sum / (FLAGS.steps_per_epoch * iters)
-            log('**** EPOCH %03d ****  mean loss: %f  (%.1f frustums/s incl. host batch synthesis)' % (
-                epoch, mean_loss, FLAGS.steps_per_epoch * iters * B / (time.time() - t0)))
+            if ds is None:
+                mean_loss = loss_sum / (FLAGS.steps_per_epoch * iters)
+                log('**** EPOCH %03d ****  mean loss: %f  (%.1f frustums/s incl. host batch synthesis)' % (
+                    epoch, mean_loss, FLAGS.steps_per_epoch * iters * B / (time.time() - t0)))
             if epoch % 5 == 0:
                 path = os.path.join(FLAGS.log_dir, 'model_epoch_%d.npz' % epoch)
                 np.savez(path, **g.vars.state_dict())
