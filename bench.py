@@ -259,17 +259,22 @@ def main():
         g.opt.run()
         torch.cuda.synchronize()
         s = torch.cuda.Stream()
-        g1 = torch.cuda.CUDAGraph()
-        # thread_local: calls of other threads (the RCCL watchdog) during capture must not invalidate it
-        with torch.cuda.graph(g1, stream=s, capture_error_mode='thread_local'):
-            run_compute()
-            if world == 1:
-                g.opt.run()
-        g2 = None
-        if world > 1:
-            g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, stream=s, capture_error_mode='thread_local'):
-                g.opt.run()
+        try:
+            g1 = torch.cuda.CUDAGraph()
+            # thread_local: calls of other threads (the RCCL watchdog) during capture must not invalidate it
+            with torch.cuda.graph(g1, stream=s, capture_error_mode='thread_local'):
+                run_compute()
+                if world == 1:
+                    g.opt.run()
+            g2 = None
+            if world > 1:
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, stream=s, capture_error_mode='thread_local'):
+                    g.opt.run()
+        except RuntimeError as err:          # a capture that the runtime refuses must not cost the measurement: eager launches
+            sys.stderr.write('hipGraph capture failed (%s); falling back to eager launches\n' % err)
+            torch.cuda.synchronize()
+            use_graph = False
 
     def step():
         if use_graph:
