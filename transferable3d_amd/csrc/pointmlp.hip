@@ -452,6 +452,17 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd(const t3d_pointm
   float* red = smem;   // [2][BN] x 6 quantities
   float csum[TN], csq[TN], cmax[TN], cmin[TN];
   int amax[TN], amin[TN];
+  // keep flags of this lane's 32 rows, loaded once (they were re-read per column group inside the compare chain)
+  unsigned keepbits = 0xffffffffu;
+  if (pool && p.rowmask) {
+    keepbits = 0u;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        keepbits |= (p.rowmask[row0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] != 0.f ? 1u : 0u) << (tm * 16 + r);
+  }
+  const int rin_base = row0 - b * p.rows_per_frustum + wm * 64 + 4 * h;
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int col = col0 + wn * (BN / 2) + tn * 32 + l31;
@@ -465,16 +476,18 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd(const t3d_pointm
     for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = row0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const float v = acc[tm][tn][r] + add;
         if (store_y) p.y[off0 + (unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)p.N] = v;
         s += v;
         ss = fmaf(v, v, ss);
-        if (pool) {
-          const bool keep = p.rowmask ? (p.rowmask[row] != 0.f) : true;
-          const int rin = row - b * p.rows_per_frustum;
-          if (keep && v > mx) { mx = v; ax = rin; }
-          if (keep && v < mn) { mn = v; an = rin; }
+        if (pool) {                                  // selects: same results as the branches they replace, no exec-mask juggling
+          const bool keep = (keepbits >> (tm * 16 + r)) & 1u;
+          const int rin = rin_base + tm * 32 + (r & 3) + 8 * (r >> 2);
+          const bool up = keep & (v > mx), dn = keep & (v < mn);
+          mx = up ? v : mx;
+          ax = up ? rin : ax;
+          mn = dn ? v : mn;
+          an = dn ? rin : an;
         }
       }
     }
