@@ -111,8 +111,11 @@ def gemm_work(name, a):
     return 'k_pointmlp_wgrad<%d,%d>' % (tk.value, tn.value), flops, by
 
 
-def profile_kernels(plans, steps):
-    """Per-launch HIP events (torch events on the stream the kernels are launched on), eager replay."""
+def profile_kernels(plans, steps, repeat=4):
+    """Per-launch HIP events (torch events on the stream the kernels are launched on), eager replay.  Every launch of the
+    step is issued `repeat` times back to back between its two events and the interval divided by `repeat`: a single eager
+    launch of a 5-30 us kernel is bounded by the host's submission time (~5 us per launch from Python), not by the kernel.
+    (Repeating is harmless here: this pass runs after the timed region and after the loss was read.)"""
     acc = {}
     detail = {}
     global CALLS
@@ -126,17 +129,18 @@ def profile_kernels(plans, steps):
                     continue
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                rc = call(s)
-                assert rc == 0, (name, rc)
+                for _r in range(repeat):
+                    rc = call(s)
+                    assert rc == 0, (name, rc)
                 e1.record()
                 evs.append((name, arg, e0, e1))
         torch.cuda.synchronize()
         for ci, (name, arg, e0, e1) in enumerate(evs):
-            CALLS.setdefault(ci, [name, arg, 0.0])[2] += e0.elapsed_time(e1) * 1e-3 / steps
+            dt = e0.elapsed_time(e1) * 1e-3 / repeat
+            CALLS.setdefault(ci, [name, arg, 0.0])[2] += dt / steps
             label, flops, nbytes = (gemm_work(name, arg) if name.startswith(('t3d_pointmlp', 't3d_pool_bwd_stage')) and
                                     name != 't3d_pointmlp_dgrad_narrow' else (name, 0.0, 0.0))
             d = acc.setdefault(label, [0.0, 0, 0.0, 0.0])
-            dt = e0.elapsed_time(e1) * 1e-3
             d[0] += dt
             d[1] += 1
             d[2] += flops
