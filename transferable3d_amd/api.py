@@ -105,6 +105,11 @@ class Graph:
     def vars(self):
         return self.engine.vars
 
+    @property
+    def hyper(self):
+        """Device schedule state [global step, lr, bn_decay, Adam lr_t] (the reference's `batch` variable lives in [0])."""
+        return self.engine.hyper
+
     def use_device_dataset(self, dataset, seed=0, **aug):
         """Feed the training plan from a data set resident in HBM: every Session.run of the train op assembles its own
         batch on the device (t3d_batch_assemble), nothing needs to be fed."""

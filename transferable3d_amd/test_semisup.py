@@ -20,6 +20,7 @@ from transferable3d_amd import api, semisup_v1_sunrgbd as MODEL        # noqa: E
 from transferable3d_amd.config import make_parser                        # noqa: E402
 from transferable3d_amd.constants import NUM_HEADING_BIN, NUM_SIZE_CLUSTER   # noqa: E402
 from transferable3d_amd.synthetic import make_batch                      # noqa: E402
+from transferable3d_amd.tf_checkpoint import load_state                  # noqa: E402
 
 
 def build_flags(argv=None):
@@ -29,7 +30,7 @@ def build_flags(argv=None):
     cfg.add_argument('--gpu', type=int, default=0)
     cfg.add_argument('--num_point', type=int, default=2048)
     cfg.add_argument('--model', default='semisup_v1_sunrgbd')
-    cfg.add_argument('--model_path', default=None, help='state dict (.npz) written by train_semisup*.py')
+    cfg.add_argument('--model_path', default=None, help='state dict (.npz) or TensorFlow checkpoint prefix written by train_semisup*.py')
     cfg.add_argument('--boxpc_model_path', default=None)
     cfg.add_argument('--pred_prefix', default='F2_')
     cfg.add_argument('--refine', default=None)
@@ -108,10 +109,10 @@ def inference(sess, ops, pc, one_hot_vec, batch_size, prefix='', use_boxpc_fit_p
 
 def test(FLAGS, rt=None, log=print):
     B, N, C = FLAGS.batch_size, FLAGS.num_point, FLAGS.NUM_CHANNELS
-    sd = dict(np.load(FLAGS.model_path)) if FLAGS.model_path else None
+    sd = load_state(FLAGS.model_path) if FLAGS.model_path else None
     if FLAGS.boxpc_model_path:
         sd = dict(sd or {})
-        sd.update({'D_boxpc_branch/' + k: v for k, v in np.load(FLAGS.boxpc_model_path).items()})
+        sd.update({'D_boxpc_branch/' + k: v for k, v in load_state(FLAGS.boxpc_model_path).items()})
     sess, ops = get_model(FLAGS, B, N, C, rt=rt, state_dict=sd)
     n = (FLAGS.num_frustums + B - 1) // B * B                     # the reference pads the last batch (test_semisup.py:450-471)
     batches = [make_batch(B, N, C, seed=FLAGS.seed * 1000003 + i) for i in range(n // B)]

@@ -6,7 +6,9 @@
     available; `--train_data` is therefore optional.
   * one process per GPU: launch with `python -m torch.distributed.run --nproc-per-node N ... train_semisup.py` for
     data-parallel training (gradient all-reduce on RCCL); `--gpu` selects the device in the single-process case.
-  * checkpoints are `.npz` state dicts keyed by the reference's TF variable names.
+  * checkpoints are `.npz` state dicts keyed by the reference's TF variable names or, with
+    `--ckpt_format tf`, TensorFlow Saver bundles (`model_epoch_<n>.ckpt.index/.data-*`, tf_checkpoint.py); `--restore_model_path`
+    takes either.
 
 Example (README.md:58-67 recipe a, synthetic data):
   python -m transferable3d_amd.train_semisup --SEMI_MODEL A --WEAK_WEIGHT_REPROJECTION 0 --WEAK_WEIGHT_SURFACE 0 \
@@ -23,6 +25,7 @@ if __package__ in (None, ''):
 from transferable3d_amd import api, semisup_v1_sunrgbd as MODEL       # noqa: E402
 from transferable3d_amd.config import make_parser                        # noqa: E402
 from transferable3d_amd.synthetic import make_batch                      # noqa: E402
+from transferable3d_amd.tf_checkpoint import restore_model, save_model   # noqa: E402
 
 
 def build_flags(argv=None):
@@ -46,7 +49,8 @@ def build_flags(argv=None):
     cfg.add_argument('--no_aug', action='store_true')
     cfg.add_argument('--no_rgb', action='store_true', help='Only use XYZ for training')
     cfg.add_argument('--init_model_path', default=None)
-    cfg.add_argument('--restore_model_path', default=None, help='Restore model path e.g. log/model_epoch_0.npz')
+    cfg.add_argument('--restore_model_path', default=None, help='Restore model path e.g. log/model_epoch_0.ckpt or .npz')
+    cfg.add_argument('--ckpt_format', default='npz', choices=['npz', 'tf'], help='tf: TensorFlow Saver bundle')
     # additions
     cfg.add_argument('--synthetic', action='store_true', help='synthetic frustums (the only data source available)')
     cfg.add_argument('--num_channels', type=int, default=None, help='override point channels (reference: 6, or 3 with --no_rgb)')
@@ -95,7 +99,7 @@ def train(FLAGS, rt=None, log=print):
         train_op = optimizer.minimize(semi_loss)
         sess = api.Session(process_group=pg, dropout_seed=1234 + rank)
         if FLAGS.restore_model_path:
-            g.vars.load_state_dict(dict(np.load(FLAGS.restore_model_path)))
+            restore_model(g, FLAGS.restore_model_path)
         n_correct = api.Tensor(g, g.assembly.seg.n_correct, (1,), 'n_correct')
         step = 0
         ds = None
@@ -139,8 +143,7 @@ def train(FLAGS, rt=None, log=print):
                     FLAGS.steps_per_epoch * B * world / (time.time() - t0)))
             if rank == 0:
                 if epoch % 5 == 0:                       # train_semisup.py:316-318
-                    path = os.path.join(FLAGS.log_dir, 'model_epoch_%d.npz' % epoch)
-                    np.savez(path, **g.vars.state_dict())
+                    path = save_model(FLAGS.log_dir, epoch, g, FLAGS.ckpt_format)
                     log('Model saved in file: %s' % path)
         final = g.vars.state_dict()
     if world > 1:

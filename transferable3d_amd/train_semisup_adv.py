@@ -20,6 +20,7 @@ from transferable3d_amd import api, semisup_v1_sunrgbd as MODEL        # noqa: E
 from transferable3d_amd.config import make_parser                        # noqa: E402
 from transferable3d_amd.constants import type2class                      # noqa: E402
 from transferable3d_amd.synthetic import make_batch                      # noqa: E402
+from transferable3d_amd.tf_checkpoint import load_state, restore_model, save_model   # noqa: E402
 
 ALL_CLASSES = ['bed', 'table', 'sofa', 'chair', 'toilet', 'desk', 'dresser', 'night_stand', 'bookshelf', 'bathtub']
 
@@ -43,6 +44,7 @@ def build_flags(argv=None):
     cfg.add_argument('--init_class_ag_path', default=None, help='stage-a state dict (class-agnostic branch)')
     cfg.add_argument('--init_boxpc_path', default=None, help='stage-b state dict (Box-PC Fit net)')
     cfg.add_argument('--restore_model_path', default=None)
+    cfg.add_argument('--ckpt_format', default='npz', choices=['npz', 'tf'], help='tf: TensorFlow Saver bundle')
     cfg.add_argument('--synthetic', action='store_true')
     cfg.add_argument('--num_channels', type=int, default=None)
     cfg.add_argument('--steps_per_epoch', type=int, default=100)
@@ -59,7 +61,7 @@ def build_flags(argv=None):
 def load_variable_scopes_from_ckpt(vars_, path, scope):
     """train_semisup_adv.py:224-237: restore every variable under `scope/` from a checkpoint whose names lack that prefix
     (stage-a / stage-b checkpoints are saved without `class_agnostic/` / `D_boxpc_branch/`)."""
-    sd = dict(np.load(path))
+    sd = load_state(path)
     n = 0
     for name in list(vars_.index):
         if name.startswith(scope + '/') and name[len(scope) + 1:] in sd:
@@ -96,7 +98,7 @@ def train(FLAGS, rt=None, log=print):
         if FLAGS.init_boxpc_path:
             log('restored %d D_boxpc_branch variables' % load_variable_scopes_from_ckpt(g.vars, FLAGS.init_boxpc_path, 'D_boxpc_branch'))
         if FLAGS.restore_model_path:
-            g.vars.load_state_dict(dict(np.load(FLAGS.restore_model_path)))
+            restore_model(g, FLAGS.restore_model_path)
         test_ids = [type2class[t] for t in FLAGS.TEST_CLS]
         train_ids = [i for i in range(10) if i not in test_ids]
         step, mean_loss = 0, 0.0
@@ -143,8 +145,7 @@ def train(FLAGS, rt=None, log=print):
                 log('**** EPOCH %03d ****  mean loss: %f  (%.1f frustums/s incl. host batch synthesis)' % (
                     epoch, mean_loss, FLAGS.steps_per_epoch * iters * B / (time.time() - t0)))
             if epoch % 5 == 0:
-                path = os.path.join(FLAGS.log_dir, 'model_epoch_%d.npz' % epoch)
-                np.savez(path, **g.vars.state_dict())
+                path = save_model(FLAGS.log_dir, epoch, g, FLAGS.ckpt_format, optimizer_scopes=train_vars)
                 log('Model saved in file: %s' % path)
         return g.vars.state_dict(), mean_loss
 
