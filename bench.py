@@ -201,9 +201,13 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback on the product path)'
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # T3D_FORCE_DIST=1: take the multi-rank code path (RCCL init, all-reduce between the two graphs) with a single rank, so
+    # that it can be exercised on a 1-GPU box
+    use_dist = world > 1 or os.environ.get('T3D_FORCE_DIST', '0') == '1'
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
     from transferable3d_amd.config import make_parser
@@ -268,10 +272,10 @@ def main():
             # thread_local: calls of other threads (the RCCL watchdog) during capture must not invalidate it
             with torch.cuda.graph(g1, stream=s, capture_error_mode='thread_local'):
                 run_compute()
-                if world == 1:
+                if not use_dist:
                     g.opt.run()
             g2 = None
-            if world > 1:
+            if use_dist:
                 g2 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g2, stream=s, capture_error_mode='thread_local'):
                     g.opt.run()
@@ -283,12 +287,12 @@ def main():
     def step():
         if use_graph:
             g1.replay()
-            if world > 1:
+            if use_dist:
                 dist.all_reduce(flat_grads)
                 g2.replay()
         else:
             run_compute()
-            if world > 1:
+            if use_dist:
                 dist.all_reduce(flat_grads)
             g.opt.run()
 

@@ -458,6 +458,10 @@ typedef struct {
   float* center;                         /* [B,3] end_points['center'] */
   float* reg_dims;                       /* [B,3] anchor->reg dims */
   float* reg_theta;                      /* [B] */
+  /* optional per-frustum IoU of the predicted box (arg-max bins) with the label box: the tf.py_func summary
+   * get_iou_summary / compute_box3d_iou (semisup_v1_sunrgbd.py:236-246, roi_seg_box3d_dataset.py:103-140).  NULL: skipped. */
+  float* iou2d;                          /* [B] ground-plane IoU */
+  float* iou3d;                          /* [B] */
   int B;
 } t3d_strong_loss_args;
 int t3d_strong_loss(const t3d_strong_loss_args* args, t3d_stream_t stream);
@@ -572,6 +576,42 @@ typedef struct {
   int B;
 } t3d_box_refine_step_args;
 int t3d_box_refine_step(const t3d_box_refine_step_args* args, t3d_stream_t stream);
+
+/* ---- K13: 3-D IoU of upright boxes ---------------------------------------------------------------------
+ * Replaces box_util.box3d_iou (the Frustum-PointNets module the reference imports but does not ship) at its call sites:
+ * roi_seg_box3d_dataset.py:103-140 (per-step IoU summary), box_pc_fit_dataset.py:38-42,211-244 (perturb a box until its IoU
+ * falls inside the fit / no-fit bounds), eval_det.py:60-66 (detection matching).  Ground-plane rectangle intersection (area of
+ * the clipped polygon), height overlap, iou3d = inter_vol / (vol1 + vol2 - inter_vol), iou2d = inter / (a1 + a2 - inter).
+ * Parameter form: centre (x,y,z), size (l,w,h), heading about y, as get_3d_box takes them (roi_seg_box3d_dataset.py:86-101);
+ * negative l / w count by magnitude (a mirrored rectangle), a negative h gives iou3d = 0 (inverted height range), as the
+ * reference's get_3d_box + box3d_iou behave on the sizes an untrained head produces. */
+typedef struct {
+  const float* center1; const float* size1; const float* heading1;      /* [n,3], [n,3], [n] */
+  const float* center2; const float* size2; const float* heading2;
+  float* iou3d; float* iou2d;                                           /* [n]; iou2d may be NULL */
+  int n;
+} t3d_box3d_iou_args;
+int t3d_box3d_iou(const t3d_box3d_iou_args* args, t3d_stream_t stream);
+
+/* Corner form, box3d_iou's own signature: corners[n,8,3] in get_3d_box order (0-3 the y-max face, 4-7 the y-min face). */
+typedef struct {
+  const float* corners1; const float* corners2;                         /* [n,8,3] */
+  float* iou3d; float* iou2d;
+  int n;
+} t3d_box3d_iou_corners_args;
+int t3d_box3d_iou_corners(const t3d_box3d_iou_corners_args* args, t3d_stream_t stream);
+
+/* compute_box3d_iou on raw box heads (roi_seg_box3d_dataset.py:103-140): box[B,67] = [centre - stage1_center (3), heading scores
+ * (12), normalised heading residuals (12), size scores (10), normalised size residuals (10x3)]; predicted box from the arg-max
+ * bins (class2angle / class2size), label box from the label bins + residuals. */
+typedef struct {
+  const float* box; int ld_box;
+  const float* stage1_center;            /* [B,3] or NULL (centre already absolute) */
+  const float* y_center; const int32_t* y_orient_cls; const float* y_orient_reg; const int32_t* y_dims_cls; const float* y_dims_reg;
+  float* iou2d; float* iou3d;            /* [B] */
+  int B;
+} t3d_box_head_iou_args;
+int t3d_box_head_iou(const t3d_box_head_iou_args* args, t3d_stream_t stream);
 
 /* ---- device-side batch assembly -------------------------------------------------------------------------------
  * Replaces the host loop ROISemiDataset.get_batch -> get_classes3D (roi_semi_dataset.py:283-347, 482-535; helpers

@@ -18,6 +18,64 @@ MEAN32 = MEAN_DIMS_ARR.astype(np.float32)
 BINS32 = (np.arange(NH) * (2.0 * np.pi / 12.0)).astype(np.float32)
 
 
+def _ccw(q):
+    a2 = np.sum(q[:, 0] * np.roll(q[:, 1], -1) - q[:, 1] * np.roll(q[:, 0], -1))
+    return q if a2 >= 0 else q[[0, 3, 2, 1]]
+
+
+def _boundary_inside(P, Q, closed):
+    """1/2 sum cross(a', b') over the parts of P's edges inside the convex CCW quad Q (boxgeom_dev.h)."""
+    acc = 0.0
+    for i in range(4):
+        a, b = P[i], P[(i + 1) % 4]
+        t0, t1, alive = 0.0, 1.0, True
+        for e in range(4):
+            q0, q1 = Q[e], Q[(e + 1) % 4]
+            ex, ez = q1 - q0
+            da = ex * (a[1] - q0[1]) - ez * (a[0] - q0[0])
+            db = ex * (b[1] - q0[1]) - ez * (b[0] - q0[0])
+            tol = 1e-5 * (ex * ex + ez * ez) + 1e-12
+            ina, inb = (da >= -tol, db >= -tol) if closed else (da > tol, db > tol)
+            if closed and abs(da) <= tol and abs(db) <= tol and (b[0] - a[0]) * ex + (b[1] - a[1]) * ez <= 0:
+                alive = False                 # collinear edges pointing opposite ways: the rectangles only touch
+            if not (ina or inb):
+                alive = False
+            if ina != inb:
+                t = min(max(da / (da - db), 0.0), 1.0)
+                if inb:
+                    t0 = max(t0, t)
+                else:
+                    t1 = min(t1, t)
+        if alive and t1 > t0:
+            p, q = a + t0 * (b - a), a + t1 * (b - a)
+            acc += 0.5 * (p[0] * q[1] - p[1] * q[0])
+    return acc
+
+
+def iou_from_quads(P, Q, ymax1, ymin1, ymax2, ymin2, vol1, vol2):
+    P, Q = _ccw(np.asarray(P, np.float64)), _ccw(np.asarray(Q, np.float64))
+    area = lambda q: 0.5 * abs(np.sum(q[:, 0] * np.roll(q[:, 1], -1) - q[:, 1] * np.roll(q[:, 0], -1)))
+    o = P[0].copy()
+    inter = max(_boundary_inside(P - o, Q - o, True) + _boundary_inside(Q - o, P - o, False), 0.0)
+    iou2 = inter / (area(P) + area(Q) - inter)
+    iv = inter * max(0.0, min(ymax1, ymax2) - max(ymin1, ymin2))
+    return iv / (vol1 + vol2 - iv), iou2
+
+
+def box3d_iou_spec(c1, s1, h1, c2, s2, h2):
+    """t3d_box3d_iou for one pair in float64: (iou3d, iou2d)."""
+    def rect(c, s, h):
+        hl, hw = 0.5 * abs(s[0]), 0.5 * abs(s[1])
+        lx, lz = np.array([hl, -hl, -hl, hl]), np.array([hw, hw, -hw, -hw])
+        cs, sn = math.cos(h), math.sin(h)
+        return np.stack([cs * lx + sn * lz + c[0], -sn * lx + cs * lz + c[2]], 1)
+    c1, s1, c2, s2 = [np.asarray(v, np.float64) for v in (c1, s1, c2, s2)]
+    a1, a2 = abs(s1[0] * s1[1]), abs(s2[0] * s2[1])
+    hh1, hh2 = 0.5 * s1[2], 0.5 * s2[2]          # signed: a negative h inverts the height range -> iou3d = 0 (boxgeom_dev.h)
+    return iou_from_quads(rect(c1, s1, float(h1)), rect(c2, s2, float(h2)), c1[1] + hh1, c1[1] - hh1, c2[1] + hh2, c2[1] - hh2,
+                          a1 * abs(s1[2]), a2 * abs(s2[2]))
+
+
 def arr(ptr, *shape):
     if not ptr:
         return None
@@ -722,7 +780,54 @@ class FakeLib:
             so2 = 3 + 2 * NH + NS + 3 * ks
             arr(p.reg_dims, B, 3)[b] = np.maximum(mean[ks] + o[so2:so2 + 3] * mean[ks], 1e-5)
             arr(p.reg_theta, B)[b] = bins[js] + o[3 + NH + js] * (np.pi / NH)
+            if p.iou3d:
+                sp = mean[ks] + o[so2:so2 + 3] * mean[ks]
+                i3, i2 = box3d_iou_spec(cen, sp, arr(p.reg_theta, B)[b], yc[b], mean[k] + ydr[b], bins[j] + yor[b])
+                arr(p.iou3d, B)[b], arr(p.iou2d, B)[b] = i3, i2
         arr(p.loss, 1)[0] = total_sum * norm
+        return 0
+
+    # ---- 3-D IoU (K13) ----------------------------------------------------------------------------------
+    def t3d_box3d_iou(self, a, stream):
+        p = _struct(a)
+        n = p.n
+        c1, s1, h1 = arr(p.center1, n, 3), arr(p.size1, n, 3), arr(p.heading1, n)
+        c2, s2, h2 = arr(p.center2, n, 3), arr(p.size2, n, 3), arr(p.heading2, n)
+        for i in range(n):
+            i3, i2 = box3d_iou_spec(c1[i], s1[i], h1[i], c2[i], s2[i], h2[i])
+            arr(p.iou3d, n)[i] = i3
+            if p.iou2d:
+                arr(p.iou2d, n)[i] = i2
+        return 0
+
+    def t3d_box3d_iou_corners(self, a, stream):
+        p = _struct(a)
+        n = p.n
+        k1, k2 = arr(p.corners1, n, 8, 3).astype(np.float64), arr(p.corners2, n, 8, 3).astype(np.float64)
+        vol = lambda k: np.linalg.norm(k[0] - k[1]) * np.linalg.norm(k[1] - k[2]) * np.linalg.norm(k[0] - k[4])
+        for i in range(n):
+            P, Q = k1[i][[3, 2, 1, 0]][:, [0, 2]], k2[i][[3, 2, 1, 0]][:, [0, 2]]
+            i3, i2 = iou_from_quads(P, Q, k1[i][0, 1], k1[i][4, 1], k2[i][0, 1], k2[i][4, 1], vol(k1[i]), vol(k2[i]))
+            arr(p.iou3d, n)[i] = i3
+            if p.iou2d:
+                arr(p.iou2d, n)[i] = i2
+        return 0
+
+    def t3d_box_head_iou(self, a, stream):
+        p = _struct(a)
+        B = p.B
+        box = arr(p.box, B, p.ld_box)[:, :67].astype(np.float64)
+        s1 = arr(p.stage1_center, B, 3).astype(np.float64) if p.stage1_center else np.zeros((B, 3))
+        yc, yoc, yor = arr(p.y_center, B, 3).astype(np.float64), arr(p.y_orient_cls, B), arr(p.y_orient_reg, B).astype(np.float64)
+        ydc, ydr = arr(p.y_dims_cls, B), arr(p.y_dims_reg, B, 3).astype(np.float64)
+        mean, bins = MEAN32.astype(np.float64), BINS32.astype(np.float64)
+        for b in range(B):
+            o = box[b]
+            js, ks = int(np.argmax(o[3:3 + NH])), int(np.argmax(o[3 + 2 * NH:3 + 2 * NH + NS]))
+            so = 3 + 2 * NH + NS + 3 * ks
+            i3, i2 = box3d_iou_spec(o[0:3] + s1[b], mean[ks] + o[so:so + 3] * mean[ks], bins[js] + o[3 + NH + js] * (np.pi / NH),
+                                    yc[b], mean[int(ydc[b])] + ydr[b], bins[int(yoc[b])] + yor[b])
+            arr(p.iou3d, B)[b], arr(p.iou2d, B)[b] = i3, i2
         return 0
 
     # ---- Box-PC --------------------------------------------------------------------------------------

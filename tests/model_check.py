@@ -61,6 +61,20 @@ def grad_errors(g, ref_grads):
     return per, float(np.sqrt(num / den))
 
 
+def iou_summary_check(e, ep, batch, mine_prefix, ref_prefix, tol=1e-4):
+    """end_points iou2ds / iou3ds (get_iou_summary, semisup_v1_sunrgbd.py:236-246) against the oracle's compute_box3d_iou on the
+    oracle's own heads."""
+    from oracle import ref_box as RB
+    h = lambda k: ep[ref_prefix + k].detach().numpy().astype(np.float64)
+    i2, i3 = RB.compute_box3d_iou(h('center'), h('heading_scores'), h('heading_residuals'), h('size_scores'), h('size_residuals'),
+                                  np.asarray(batch['y_center'], np.float64), np.asarray(batch['y_orient_cls']),
+                                  np.asarray(batch['y_orient_reg'], np.float64), np.asarray(batch['y_dims_cls']),
+                                  np.asarray(batch['y_dims_reg'], np.float64))
+    assert np.abs(e[mine_prefix + 'iou3ds'].detach().cpu().numpy() - i3).max() < tol, mine_prefix + 'iou3ds'
+    assert np.abs(e[mine_prefix + 'iou2ds'].detach().cpu().numpy() - i2).max() < tol, mine_prefix + 'iou2ds'
+    return i3
+
+
 def check_against_oracle(g, m, batch, P, c, fwd_atol=1e-4, grad_median_tol=1e-4):
     """Forward tensors within `fwd_atol` (BASELINE.json: fp32 outputs within 1e-4 of the reference
     restatement); gradients: median per-tensor relative L2 error <= 1e-4 and global <= 1e-2.  The two-level
@@ -85,6 +99,7 @@ def check_against_oracle(g, m, batch, P, c, fwd_atol=1e-4, grad_median_tol=1e-4)
     _, dims, theta = ep['S_pred_box_reg']
     assert np.abs(e['S_dims'].detach().cpu().numpy() - dims.detach().numpy()).max() < fwd_atol
     assert np.abs(e['S_theta'].detach().cpu().numpy() - theta.detach().numpy()).max() < fwd_atol
+    iou_summary_check(e, ep, batch, '', '')
     per, glob = grad_errors(g, {k: v.numpy() for k, v in grads.items()})
     med = float(np.median(list(per.values())))
     if grad_median_tol is not None:

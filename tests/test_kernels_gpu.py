@@ -1137,3 +1137,87 @@ def test_pointmlp_shape_sweep_fwd_bwd_against_spec(hip_lib, M, K, N, rpf):
     scale = float(c['out'].abs().max())
     _close(c['out'], g['out'], 1e-4, 3e-5 * scale, 'dX')
     _close(c['s1'], g['s1'], 1e-3, 1e-3 * scale, 'psum_dz')
+
+
+def _iou_boxes(r, n):
+    c1 = r.normal(0, 1.0, size=(n, 3)) + np.array([0, 0, 3.0])
+    s1 = r.uniform(0.3, 2.5, size=(n, 3))
+    h1 = r.uniform(-np.pi, np.pi, size=n)
+    c2 = c1 + r.normal(0, 0.3, size=(n, 3))
+    s2 = s1 * r.uniform(0.7, 1.3, size=(n, 3))
+    h2 = h1 + r.uniform(0, 0.8, size=n)
+    far = r.uniform(size=n) < 0.25                                     # a quarter of the pairs unrelated (many disjoint)
+    c2[far] = r.normal(0, 1.5, size=(int(far.sum()), 3)) + np.array([0, 0, 3.0])
+    h2[far] = r.uniform(-np.pi, np.pi, size=int(far.sum()))
+    # degenerate rows: identical, half turn, shared edge, negative l and w
+    c2[0], s2[0], h2[0] = c1[0], s1[0], h1[0]
+    c2[1], s2[1], h2[1] = c1[1], s1[1], h1[1] + np.pi
+    c1[2], s1[2], h1[2], c2[2], s2[2], h2[2] = [0, 0, 0], [1, 1, 1], 0.0, [1, 0, 0], [1, 1, 1], 0.0
+    c2[3], s2[3], h2[3] = c1[3], s1[3] * [-1, -1, 1], h1[3]
+    return [a.astype(np.float32) for a in (c1, s1, h1, c2, s2, h2)]
+
+
+def test_box3d_iou_parameter_and_corner_forms_against_oracle(hip_lib):
+    """t3d_box3d_iou / t3d_box3d_iou_corners (fp32, boundary integral) against the oracle's Sutherland-Hodgman restatement of
+    box_util.box3d_iou (fp64) on the same boxes.  Tolerance 2e-5 absolute on an IoU in [0,1]."""
+    from oracle import ref_box as RB
+    r = np.random.RandomState(11)
+    n = 1000
+    c1, s1, h1, c2, s2, h2 = _iou_boxes(r, n)
+    dev = _dev('cuda')
+    t = [_mk(dev, a) for a in (c1, s1, h1, c2, s2, h2)]
+    i3, i2 = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    a = abi.Box3dIouArgs(*[fptr(x) for x in t], fptr(i3), fptr(i2), n)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert hip_lib.t3d_box3d_iou(C.byref(a), st) == 0
+    k1 = np.stack([RB.get_3d_box(np.abs(s1[i]).astype(np.float64), float(h1[i]), c1[i].astype(np.float64)) for i in range(n)])
+    k2 = np.stack([RB.get_3d_box(np.abs(s2[i]).astype(np.float64), float(h2[i]), c2[i].astype(np.float64)) for i in range(n)])
+    tk1, tk2 = _mk(dev, k1.astype(np.float32)), _mk(dev, k2.astype(np.float32))
+    j3, j2 = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    b = abi.Box3dIouCornersArgs(fptr(tk1), fptr(tk2), fptr(j3), fptr(j2), n)
+    assert hip_lib.t3d_box3d_iou_corners(C.byref(b), st) == 0
+    torch.cuda.synchronize()
+    i3, i2, j3, j2 = [x.cpu().numpy().astype(np.float64) for x in (i3, i2, j3, j2)]
+    want = np.array([RB.box3d_iou(k1[i], k2[i]) for i in range(4, n)])
+    assert (want[:, 0] > 0.3).sum() > 300 and (want[:, 0] == 0).sum() > 50
+    for got3, got2, what in ((i3, i2, 'params'), (j3, j2, 'corners')):
+        assert np.abs(got3[4:] - want[:, 0]).max() < 2e-5, what
+        assert np.abs(got2[4:] - want[:, 1]).max() < 2e-5, what
+        assert abs(got3[0] - 1) < 1e-5 and abs(got3[1] - 1) < 1e-4 and got3[2] < 1e-5 and abs(got3[3] - 1) < 1e-5, (what, got3[:4])
+        assert np.all(got3 >= 0) and np.all(got3 <= 1 + 1e-5) and np.all(got3 <= got2 + 1e-6)
+
+
+def test_box_head_iou_and_strong_loss_summary(hip_lib):
+    """t3d_box_head_iou == the IoU outputs of t3d_strong_loss == oracle compute_box3d_iou on the decoded heads."""
+    from oracle import ref_box as RB
+    from transferable3d_amd.constants import MEAN_DIMS_ARR
+    r = np.random.RandomState(5)
+    B = 48
+    box = r.normal(size=(B, 67)).astype(np.float32) * 0.3
+    s1c = r.normal(size=(B, 3)).astype(np.float32) * 0.2
+    yc = (s1c + r.normal(size=(B, 3)) * 0.2).astype(np.float32)
+    yoc, ydc = r.randint(0, 12, B).astype(np.int32), r.randint(0, 10, B).astype(np.int32)
+    yor, ydr = (r.uniform(-1, 1, B) * np.pi / 12).astype(np.float32), (r.normal(size=(B, 3)) * 0.1).astype(np.float32)
+    # make half of the predictions agree with the label bins so that the IoUs are not all tiny
+    for b in range(0, B, 2):
+        box[b, 3 + yoc[b]] = 5.0
+        box[b, 27 + ydc[b]] = 5.0
+
+    def make(dev):
+        t = {k: _mk(dev, v) for k, v in dict(box=box, s1=s1c, yc=yc, yoc=yoc, yor=yor, ydc=ydc, ydr=ydr).items()}
+        o = dict(i2=torch.zeros(B, device=dev), i3=torch.zeros(B, device=dev))
+        a = abi.BoxHeadIouArgs(fptr(t['box']), 67, fptr(t['s1']), fptr(t['yc']), iptr(t['yoc']), fptr(t['yor']), iptr(t['ydc']),
+                               fptr(t['ydr']), fptr(o['i2']), fptr(o['i3']), B)
+        a._keep = (t, o)
+        return a, o
+
+    c, g = _run_both(hip_lib, make, 't3d_box_head_iou')
+    _close(c['i3'], g['i3'], 0, 2e-5, 'head iou3d')
+    _close(c['i2'], g['i2'], 0, 2e-5, 'head iou2d')
+    mean = MEAN_DIMS_ARR.astype(np.float64)
+    hres = box[:, 15:27].astype(np.float64) * (np.pi / 12)
+    sres = box[:, 37:67].astype(np.float64).reshape(B, 10, 3) * mean[None]
+    w2, w3 = RB.compute_box3d_iou(box[:, 0:3].astype(np.float64) + s1c, box[:, 3:15], hres, box[:, 27:37], sres, yc.astype(np.float64), yoc,
+                                  yor.astype(np.float64), ydc, ydr.astype(np.float64))
+    assert np.abs(g['i3'].numpy() - w3).max() < 2e-5 and np.abs(g['i2'].numpy() - w2).max() < 2e-5
+    assert (w3 > 0.2).sum() >= 5

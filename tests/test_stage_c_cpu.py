@@ -63,6 +63,9 @@ def check_stage_c(g, m, batch, P, c, grad_median_tol=2e-4):
         assert np.abs(num(e[mine]).reshape(r.shape) - r).max() < 1e-4 * max(1.0, np.abs(r).max()), mine
     assert abs(float(num(e['loss'])) - float(loss.detach())) < 1e-4 * float(loss.detach())
     assert abs(float(num(e['terms'])[0]) - float(ep['intraclass_variance_loss'].detach())) < 1e-5
+    from model_check import iou_summary_check
+    iou_summary_check(e, ep, batch, '', 'F_')                  # get_iou_summary(F_pred_box, ..., '')   semisup_v1_sunrgbd.py:416
+    iou_summary_check(e, ep, batch, 'W_', '')                  # get_iou_summary(W_pred_box, ..., 'W_') semisup_v1_sunrgbd.py:414
     per, glob = grad_errors(g, {k: v.numpy() for k, v in grads.items()})
     med = float(np.median(list(per.values())))
     assert med < grad_median_tol and glob < 1e-2, (med, glob, sorted(per.items(), key=lambda kv: -kv[1])[:4])

@@ -23,7 +23,7 @@ SHAPES = [('fwd', 128, 1024, True), ('fwd', 512, 256, False), ('fwd', 256, 512, 
 
 def main():
     lib = abi.load(os.environ.get('T3D_LIB'))
-    M, rpf, R = 32768, 1024, 20
+    M, rpf, R = int(os.environ.get('T3D_M', '32768')), 1024, 20     # T3D_M: more row tiles (how much of a launch is ramp / phase lock-step)
     B, T = M // rpf, M // 128
     dev = 'cuda'
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -86,8 +86,9 @@ def main():
         fl = 2.0 * M * K * N
         tot[kind] = tot.get(kind, 0) + us
         extra = ' split=%d tile=%dx%d' % (M // rps.value, tk.value, tn.value) if kind == 'wgrad' else ''
-        print('%-6s K%-4d N%-5d %s %8.1f us  %6.1f TF/s  (ideal %.1f us)%s' % (kind, K, N, 'pool' if pooled else '    ', us,
-                                                                             fl / us / 1e6, fl / 157.3e6, extra))
+        nbytes = 4.0 * M * (K + N)
+        print('%-6s K%-4d N%-5d %s %8.1f us  %6.1f TF/s  (ideal %.1f us)  %5.2f TB/s of x+y%s' % (
+            kind, K, N, 'pool' if pooled else '    ', us, fl / us / 1e6, fl / 157.3e6, nbytes / us / 1e6, extra))
     print('totals (one of each):', {k: round(v, 1) for k, v in tot.items()})
 
 

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Per-workgroup timeline of the forward GEMM kernel (diagnostic build: tools/build_variant.sh trace "-DT3D_TRACE").
+For each layer shape: dispatch ramp (spread of workgroup start times), workgroups per CU, time in main loop / epilogue,
+and how much of the launch the busiest and the idlest CU spend with at least one workgroup resident."""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from transferable3d_amd import abi
+from transferable3d_amd.abi import fptr, iptr
+
+SHAPES = [(512, 256, False), (256, 512, True), (64, 512, False), (256, 128, False), (128, 256, False), (128, 128, False),
+          (64, 128, False), (64, 64, False)]
+
+
+def main():
+    lib = abi.load(os.environ.get('T3D_LIB', 'tools/libt3d_trace.so'))
+    lib.t3d_set_trace.argtypes = [C.c_void_p]
+    M, rpf = int(os.environ.get('T3D_M', '32768')), 1024
+    T = M // 128
+    dev = 'cuda'
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for K, N, pooled in SHAPES:
+        x = torch.randn(M, K, device=dev)
+        sc, sh = torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev) * 0.1
+        w = torch.randn(K, N, device=dev) / K ** 0.5
+        y = torch.randn(M, N, device=dev)
+        p1, p2 = torch.zeros(T, N, device=dev), torch.zeros(T, N, device=dev)
+        pm = [torch.zeros(T, N, device=dev) for _ in range(2)] + [torch.zeros(T, N, dtype=torch.int32, device=dev) for _ in range(2)]
+        a = abi.PointMlpFwdArgs()
+        a.a = abi.ActSrc(fptr(x), K, 0, fptr(sc), fptr(sh), 1, fptr(None), 0)
+        a.w, a.y, a.psum, a.psumsq = fptr(w), fptr(y), fptr(p1), fptr(p2)
+        if pooled:
+            a.pmax, a.pmin, a.pamax, a.pamin = fptr(pm[0]), fptr(pm[1]), iptr(pm[2]), iptr(pm[3])
+        a.M, a.K, a.N, a.rows_per_frustum = M, K, N, rpf
+        nblk = 8192
+        trace = torch.zeros(nblk * 4, dtype=torch.int64, device=dev)
+        os.environ['T3D_FWD_POOL'] = '0'
+        for _ in range(3):
+            assert lib.t3d_pointmlp_fwd(C.byref(a), s) == 0
+        torch.cuda.synchronize()
+        assert lib.t3d_set_trace(C.c_void_p(trace.data_ptr())) == 0
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        assert lib.t3d_pointmlp_fwd(C.byref(a), s) == 0
+        e1.record()
+        torch.cuda.synchronize()
+        assert lib.t3d_set_trace(C.c_void_p(0)) == 0
+        tr = trace.cpu().numpy().reshape(nblk, 4)
+        tr = tr[tr[:, 0] != 0]
+        t0, t1, t2 = [(tr[:, i] - tr[:, 0].min()) / 100.0 for i in range(3)]     # 100 MHz -> us
+        cu = (tr[:, 3] >> 32 & 0xf) * 4096 + (tr[:, 3] & 0xff00) // 256             # xcc, (se, sh, cu) bits of HW_ID
+        ids, counts = np.unique(cu, return_counts=True)
+        span = np.array([t2[cu == i].max() - t0[cu == i].min() for i in ids])
+        print('K%-4d N%-4d %s: event %.1f us | %d workgroups on %d CUs (per CU min %d max %d) | start spread %.1f us (p50 %.1f) | '
+              'main loop %.1f us (min %.1f max %.1f) | epilogue %.1f us (max %.1f) | last exit %.1f us | CU busy span min %.1f max %.1f'
+              % (K, N, 'pool' if pooled else '    ', e0.elapsed_time(e1) * 1e3, len(tr), len(ids), counts.min(), counts.max(),
+                 t0.max(), np.median(t0), (t1 - t0).mean(), (t1 - t0).min(), (t1 - t0).max(), (t2 - t1).mean(), (t2 - t1).max(),
+                 t2.max(), span.min(), span.max()))
+        # second-round workgroups (start well after 0): when do they start relative to the first exits
+        late = t0 > 0.5 * t2.max()
+        if late.any():
+            print('        %d workgroups start after half the launch (first at %.1f us; first exit at %.1f us)' % (late.sum(), t0[late].min(), t2.min()))
+
+
+if __name__ == '__main__':
+    main()

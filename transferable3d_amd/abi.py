@@ -86,6 +86,20 @@ class BoxRefineStepArgs(C.Structure):
                 ('total', F), ('fit_prob', F), ('weigh_by_conf', i32), ('first', i32), ('B', i32)]
 
 
+class Box3dIouArgs(C.Structure):
+    _fields_ = [('center1', F), ('size1', F), ('heading1', F), ('center2', F), ('size2', F), ('heading2', F), ('iou3d', F), ('iou2d', F),
+                ('n', i32)]
+
+
+class Box3dIouCornersArgs(C.Structure):
+    _fields_ = [('corners1', F), ('corners2', F), ('iou3d', F), ('iou2d', F), ('n', i32)]
+
+
+class BoxHeadIouArgs(C.Structure):
+    _fields_ = [('box', F), ('ld_box', i32), ('stage1_center', F), ('y_center', F), ('y_orient_cls', I), ('y_orient_reg', F),
+                ('y_dims_cls', I), ('y_dims_reg', F), ('iou2d', F), ('iou3d', F), ('B', i32)]
+
+
 class BatchAssembleArgs(C.Structure):
     _fields_ = [('points', F), ('seg', I), ('offsets', C.POINTER(C.c_int64)), ('frustum_angle', F), ('box_center', F), ('heading', F),
                 ('size', F), ('cls', I), ('sample', I), ('sample_len', i32), ('choice', I), ('aug', F), ('C_src', i32), ('C', i32), ('B', i32), ('N', i32),
@@ -150,7 +164,7 @@ class StrongLossArgs(C.Structure):
     _fields_ = [('box', F), ('ld_box', i32), ('stage1_center', F), ('seg_loss', F), ('y_center', F),
                 ('y_orient_cls', I), ('y_orient_reg', F), ('y_dims_cls', I), ('y_dims_reg', F), ('is_data_2D', I),
                 ('wts', StrongWeights), ('normalize_by_3d_count', i32), ('dbox', F), ('dstage1', F), ('terms', F),
-                ('total_losses', F), ('loss', F), ('center', F), ('reg_dims', F), ('reg_theta', F), ('B', i32)]
+                ('total_losses', F), ('loss', F), ('center', F), ('reg_dims', F), ('reg_theta', F), ('iou2d', F), ('iou3d', F), ('B', i32)]
 
 
 class SlabDesc(C.Structure):
@@ -214,6 +228,9 @@ ENTRY_POINTS = {
     't3d_pool_wgrad_finish': [C.POINTER(PoolWgradFinishArgs), VP],
     't3d_batch_assemble': [C.POINTER(BatchAssembleArgs), VP],
     't3d_box_refine_step': [C.POINTER(BoxRefineStepArgs), VP],
+    't3d_box3d_iou': [C.POINTER(Box3dIouArgs), VP],
+    't3d_box3d_iou_corners': [C.POINTER(Box3dIouCornersArgs), VP],
+    't3d_box_head_iou': [C.POINTER(BoxHeadIouArgs), VP],
     't3d_pool_bwd_stage1': [C.POINTER(PointMlpGramArgs), C.POINTER(ActColsumArgs), C.POINTER(PoolBwdPrepArgs), VP],
     't3d_pool_bwd_mid': [F, F, C.POINTER(SlabDesc), i32, i32, C.POINTER(PoolSparseRowsArgs), VP],
     't3d_pool_bwd_stage2': [C.POINTER(PoolWgradFinishArgs), C.POINTER(PointMlpDgradGramArgs), VP],

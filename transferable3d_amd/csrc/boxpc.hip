@@ -10,6 +10,7 @@
 // loss:           boxpc_sunrgbd.py:106-193 (2-way softmax CE vs iou > bound; Huber(delta=1) on the centre / size /
 //                 angle deltas, weighted .34/.33/.33 and BOXPC_WEIGHT_DELTA).
 #include "common.h"
+#include "boxgeom_dev.h"
 
 namespace {
 
@@ -374,6 +375,47 @@ extern "C" int t3d_anchor_reg_bwd(const t3d_anchor_reg_bwd_args* a, t3d_stream_t
   if (!a || !a->box || !a->dbox || !a->dstage1) return T3D_ERR_ARG;
   if (a->B <= 0 || a->B > 1024) return T3D_ERR_SHAPE;
   T3D_LAUNCH(k_anchor_reg_bwd, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), *a);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+// ---- K13: 3-D IoU (t3d.h) -----------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void k_box3d_iou(const t3d_box3d_iou_args p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.n) return;
+  float c1[3], s1[3], c2[3], s2[3];
+  for (int d = 0; d < 3; ++d) {
+    c1[d] = p.center1[i * 3 + d]; s1[d] = p.size1[i * 3 + d];
+    c2[d] = p.center2[i * 3 + d]; s2[d] = p.size2[i * 3 + d];
+  }
+  float i2;
+  p.iou3d[i] = boxgeom::box3d_iou_params(c1, s1, p.heading1[i], c2, s2, p.heading2[i], &i2);
+  if (p.iou2d) p.iou2d[i] = i2;
+}
+__global__ __launch_bounds__(256) void k_box3d_iou_corners(const t3d_box3d_iou_corners_args p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.n) return;
+  float k1[24], k2[24];
+  for (int d = 0; d < 24; ++d) { k1[d] = p.corners1[(size_t)i * 24 + d]; k2[d] = p.corners2[(size_t)i * 24 + d]; }
+  float i2;
+  p.iou3d[i] = boxgeom::box3d_iou_corners(k1, k2, &i2);
+  if (p.iou2d) p.iou2d[i] = i2;
+}
+}  // namespace
+
+extern "C" int t3d_box3d_iou(const t3d_box3d_iou_args* a, t3d_stream_t stream) {
+  if (!a || !a->center1 || !a->size1 || !a->heading1 || !a->center2 || !a->size2 || !a->heading2 || !a->iou3d) return T3D_ERR_ARG;
+  if (a->n <= 0) return T3D_ERR_SHAPE;
+  T3D_LAUNCH(k_box3d_iou, dim3((a->n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_box3d_iou_corners(const t3d_box3d_iou_corners_args* a, t3d_stream_t stream) {
+  if (!a || !a->corners1 || !a->corners2 || !a->iou3d) return T3D_ERR_ARG;
+  if (a->n <= 0) return T3D_ERR_SHAPE;
+  T3D_LAUNCH(k_box3d_iou_corners, dim3((a->n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

@@ -5,6 +5,7 @@
 //           semisup_v1_sunrgbd.py:430-431 (sparse softmax CE).
 // box loss: semisup_v1_sunrgbd.py:423-564, model_util.py:94-119,145-167, tf_util.py:1001-1041.
 #include "common.h"
+#include "boxgeom_dev.h"
 
 namespace {
 
@@ -183,6 +184,36 @@ __device__ float softmax_ce(const float* z, int n, int ld, int label, float* gra
   return lse - z[label * ld];
 }
 
+// compute_box3d_iou for one frustum (roi_seg_box3d_dataset.py:103-140): predicted box = arg-max bins of the raw heads `o`
+// (class2angle: bin centre + residual; class2size: mean size + residual), label box from the label bins.
+__device__ float head_iou(const float* o, const float* cen, const float* yc, int j, float yor, int k, const float* ydr, float* iou2d) {
+  int js = 0, ks = 0;
+  for (int i = 1; i < NH; ++i) if (o[3 + i] > o[3 + js]) js = i;
+  for (int i = 1; i < NS; ++i) if (o[3 + 2 * NH + i] > o[3 + 2 * NH + ks]) ks = i;
+  const float hp = bin_center(js) + o[3 + NH + js] * (3.14159265358979323846f / NH);
+  float sp[3], sl[3];
+  for (int d = 0; d < 3; ++d) {
+    sp[d] = kMeanDims[ks][d] + o[3 + 2 * NH + NS + 3 * ks + d] * kMeanDims[ks][d];
+    sl[d] = kMeanDims[k][d] + ydr[d];
+  }
+  return boxgeom::box3d_iou_params(cen, sp, hp, yc, sl, bin_center(j) + yor, iou2d);
+}
+
+__global__ __launch_bounds__(1024) void k_box_head_iou(const t3d_box_head_iou_args p) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= p.B) return;
+  const float* o = p.box + (size_t)b * p.ld_box;
+  float cen[3], yc[3], ydr[3];
+  for (int d = 0; d < 3; ++d) {
+    cen[d] = o[d] + (p.stage1_center ? p.stage1_center[b * 3 + d] : 0.f);
+    yc[d] = p.y_center[b * 3 + d];
+    ydr[d] = p.y_dims_reg[b * 3 + d];
+  }
+  float i2;
+  p.iou3d[b] = head_iou(o, cen, yc, p.y_orient_cls[b], p.y_orient_reg[b], p.y_dims_cls[b], ydr, &i2);
+  p.iou2d[b] = i2;
+}
+
 __global__ __launch_bounds__(1024) void k_strong_loss(const t3d_strong_loss_args p) {
   __shared__ float red[1024];
   __shared__ float s_norm;
@@ -305,6 +336,11 @@ __global__ __launch_bounds__(1024) void k_strong_loss(const t3d_strong_loss_args
     for (int d = 0; d < 3; ++d)
       p.reg_dims[b * 3 + d] = fmaxf(kMeanDims[ks][d] + o[3 + 2 * NH + NS + 3 * ks + d] * kMeanDims[ks][d], 1e-5f);
     p.reg_theta[b] = bin_center(js) + o[3 + NH + js] * (3.14159265358979323846f / NH);
+    if (p.iou3d) {
+      float i2;
+      p.iou3d[b] = head_iou(o, cen, yc, j, yor, k, ydr, &i2);
+      p.iou2d[b] = i2;
+    }
   }
   __syncthreads();
   red[b] = total;
@@ -343,7 +379,18 @@ extern "C" int t3d_strong_loss(const t3d_strong_loss_args* a, t3d_stream_t strea
       !a->center || !a->reg_dims || !a->reg_theta)
     return T3D_ERR_ARG;
   if (a->B <= 0 || a->B > 1024) return T3D_ERR_SHAPE;
+  if ((a->iou2d == nullptr) != (a->iou3d == nullptr)) return T3D_ERR_ARG;
   T3D_LAUNCH(k_strong_loss, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), *a);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_box_head_iou(const t3d_box_head_iou_args* a, t3d_stream_t stream) {
+  if (!a || !a->box || !a->y_center || !a->y_orient_cls || !a->y_orient_reg || !a->y_dims_cls || !a->y_dims_reg || !a->iou2d ||
+      !a->iou3d)
+    return T3D_ERR_ARG;
+  if (a->B <= 0 || a->ld_box < 67) return T3D_ERR_SHAPE;
+  T3D_LAUNCH(k_box_head_iou, dim3((a->B + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

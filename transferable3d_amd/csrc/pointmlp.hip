@@ -48,6 +48,24 @@ constexpr int NT = 256;
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
+// Diagnostic builds (-DT3D_TRACE, tools/trace_blocks.py): every workgroup records the 100 MHz wall clock at kernel entry,
+// after the main loop and at exit, plus its XCC / HW id, into a buffer installed with t3d_set_trace().
+#ifdef T3D_TRACE
+__device__ unsigned long long* t3d_trace_ptr = nullptr;
+#define T3D_TRACE_MARK(slot)                                                                                  \
+  do {                                                                                                        \
+    if (threadIdx.x == 0 && t3d_trace_ptr) {                                                                  \
+      t3d_trace_ptr[(size_t)blockIdx.x * 4 + (slot)] = wall_clock64();                                        \
+      if ((slot) == 0)                                                                                        \
+        t3d_trace_ptr[(size_t)blockIdx.x * 4 + 3] =                                                           \
+            ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11)) << 32) |        \
+            (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | ((32 - 1) << 11));                 \
+    }                                                                                                         \
+  } while (0)
+#else
+#define T3D_TRACE_MARK(slot) do {} while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // loaders: fetch() issues the global loads, xform() does the fused element-wise math afterwards
 // ---------------------------------------------------------------------------------------------
@@ -418,6 +436,7 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd(const t3d_pointm
   const int lin = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_m = lin / tiles_n, tile_n = lin % tiles_n;
   const int row0 = tile_m * BM, col0 = tile_n * BN;
+  T3D_TRACE_MARK(0);
 
   LA la{p.a, p.K, p.rows_per_frustum};
   WLoader lb{p.w, p.N, p.K, p.N};
@@ -430,6 +449,7 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd(const t3d_pointm
   const int kred = (p.K + BK - 1) / BK * BK;
   gemm_mainloop<TM, TN, SA, SB, LA, WLoader, true, BM, false, BN>(sa, sb, la, lb, smem, 0, kred, wm * 64,
                                                                         wn * (BN / 2), acc, tid);
+  T3D_TRACE_MARK(1);
 
 #ifdef T3D_ABL_NOEPI
   if (p.M > 0) {          // diagnostic build: skip the epilogue but keep the accumulators live
@@ -533,6 +553,7 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd(const t3d_pointm
       p.pmax[o] = mx; p.pmin[o] = mn; p.pamax[o] = ax; p.pamin[o] = an;
     }
   }
+  T3D_TRACE_MARK(2);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1427,3 +1448,11 @@ extern "C" int t3d_pool_bwd_stage2(const t3d_pool_wgrad_finish_args* f, const t3
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
+
+#ifdef T3D_TRACE
+// diagnostic builds only (not part of include/t3d.h): install / remove the per-workgroup trace buffer
+extern "C" int t3d_set_trace(void* buf) {
+  unsigned long long* p = static_cast<unsigned long long*>(buf);
+  return hipMemcpyToSymbol(HIP_SYMBOL(t3d_trace_ptr), &p, sizeof(p)) == hipSuccess ? T3D_OK : T3D_ERR_LAUNCH;
+}
+#endif

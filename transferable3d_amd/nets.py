@@ -290,6 +290,7 @@ class StrongLoss:
         self.dbox, self.dstage1 = rt.zeros(B, BOX_OUT_DIMS), rt.zeros(B, 3)
         self.terms, self.total_losses, self.loss = rt.zeros(B, 8), rt.zeros(B), rt.zeros(1)
         self.center, self.reg_dims, self.reg_theta = rt.zeros(B, 3), rt.zeros(B, 3), rt.zeros(B)
+        self.iou2d, self.iou3d = rt.zeros(B), rt.zeros(B)        # get_iou_summary (semisup_v1_sunrgbd.py:236-246)
 
     def emit(self, plan, box, stage1_center, seg_loss, labels, c, normalize_by_3d_count=False):
         y_center, y_orient_cls, y_orient_reg, y_dims_cls, y_dims_reg, is_data_2D = labels
@@ -304,7 +305,16 @@ class StrongLoss:
         a.dbox, a.dstage1, a.terms = fptr(self.dbox), fptr(self.dstage1), fptr(self.terms)
         a.total_losses, a.loss = fptr(self.total_losses), fptr(self.loss)
         a.center, a.reg_dims, a.reg_theta, a.B = fptr(self.center), fptr(self.reg_dims), fptr(self.reg_theta), self.g.B
+        a.iou2d, a.iou3d = fptr(self.iou2d), fptr(self.iou3d)
         plan.add('t3d_strong_loss', a)
+
+
+def emit_box_head_iou(g, plan, box, stage1_center, labels, iou2d, iou3d):
+    """compute_box3d_iou on raw box heads (roi_seg_box3d_dataset.py:103-140) as its own launch: the `W_` summary of stage c."""
+    y_center, y_orient_cls, y_orient_reg, y_dims_cls, y_dims_reg, _ = labels
+    a = abi.BoxHeadIouArgs(fptr(box), BOX_OUT_DIMS, fptr(stage1_center), fptr(y_center), iptr(y_orient_cls), fptr(y_orient_reg),
+                           iptr(y_dims_cls), fptr(y_dims_reg), fptr(iou2d), fptr(iou3d), g.B)
+    plan.add('t3d_box_head_iou', a)
 
 
 class Inputs:
@@ -384,7 +394,8 @@ class ModelAssembly:
         if self.loss_op is not None:
             ep.update({'center': self.loss_op.center, 'loss_terms': self.loss_op.terms,
                        'total_losses': self.loss_op.total_losses, 'loss': self.loss_op.loss,
-                       'S_dims': self.loss_op.reg_dims, 'S_theta': self.loss_op.reg_theta})
+                       'S_dims': self.loss_op.reg_dims, 'S_theta': self.loss_op.reg_theta,
+                       'iou2ds': self.loss_op.iou2d, 'iou3ds': self.loss_op.iou3d})
         return ep
 
 
@@ -533,6 +544,7 @@ class SemiModelF:
         rt, B = g.rt, g.B
         self.d_dims, self.dout9, self.fit_prob = rt.zeros(B, 3), rt.zeros(B, 9), rt.zeros(B)
         self.terms, self.loss = rt.zeros(2), rt.zeros(1)
+        self.W_iou2d, self.W_iou3d = rt.zeros(B), rt.zeros(B)      # get_iou_summary(W_pred_box, ..., 'W_') (semisup_v1_sunrgbd.py:414)
         self.drep, self.dbox7 = rt.zeros(g.M, 8), rt.zeros(B, 7)
         # inference graph (test_semisup.py:95-149): iterated Box-PC refinement of the F_ box
         self.refine_num = None
@@ -551,6 +563,8 @@ class SemiModelF:
         self.F_out = self.R2.fwd(plan, f, 256, is_training)
         lab = (x.y_center, x.y_orient_cls, x.y_orient_reg, x.y_dims_cls, x.y_dims_reg, x.is_data_2D)
         self.loss_op.emit(plan, self.F_out, s1, self.seg.seg_loss, lab, c, normalize_by_3d_count=True)
+        if with_loss:
+            emit_box_head_iou(g, plan, self.box.box_params, s1, lab, self.W_iou2d, self.W_iou3d)
         # frozen Box-PC net on F_pred_box_reg (is_training_D = False: eval-mode batch-norm, no dropout)
         lo = self.loss_op
         out9 = self.boxpc.fwd(plan, x.pc, lo.center, lo.reg_dims, lo.reg_theta, x.one_hot_vec, False)
@@ -620,5 +634,6 @@ class SemiModelF:
                 'feats_lv1': self.box.feats_lv1, 'box_params': self.box.box_params, 'F_box_params': self.F_out,
                 'F_center': lo.center, 'F_dims': lo.reg_dims, 'F_theta': lo.reg_theta, 'boxpc_fit_prob': self.fit_prob,
                 'boxpc_out': self.boxpc.F3.out, 'loss': self.loss, 'strong_loss': lo.loss, 'terms': self.terms,
-                'loss_terms': lo.terms, 'total_delta': self.total_delta, 'refined_center': self.cur_center,
+                'loss_terms': lo.terms, 'iou2ds': lo.iou2d, 'iou3ds': lo.iou3d, 'W_iou2ds': self.W_iou2d, 'W_iou3ds': self.W_iou3d,
+                'total_delta': self.total_delta, 'refined_center': self.cur_center,
                 'refined_dims': self.cur_dims, 'refined_theta': self.cur_theta}

@@ -176,7 +176,11 @@ def get_semi_loss_final(pred, labels, end_points, reduce_loss=True, c=None):
     if 'intraclsdims_train_classes' in end_points:
         m.train_classes = list(end_points['intraclsdims_train_classes'])
     ctx.loss = api.Tensor(ctx, m.loss, (), 'semi_loss')
-    end_points['loss_terms'] = api.Tensor(ctx, m.loss_op.terms, (ctx.engine.B, 8), 'loss_terms')
+    B = ctx.engine.B
+    end_points['loss_terms'] = api.Tensor(ctx, m.loss_op.terms, (B, 8), 'loss_terms')
+    # get_iou_summary(W_pred_box, ..., 'W_') and (F_pred_box, ..., '') (semisup_v1_sunrgbd.py:414-416)
+    for key, buf in (('W_iou2ds', m.W_iou2d), ('W_iou3ds', m.W_iou3d), ('iou2ds', m.loss_op.iou2d), ('iou3ds', m.loss_op.iou3d)):
+        end_points[key] = api.Tensor(ctx, buf, (B,), key)
     return ctx.loss
 
 
@@ -192,6 +196,8 @@ def get_semi_loss_backbone(pred, labels, end_points, reduce_loss=True, c=None):
     T = lambda buf, shape, name: api.Tensor(ctx, buf, shape, name)
     end_points['loss_terms'] = T(asm.loss_op.terms, (B, 8), 'loss_terms')
     end_points['center'] = T(asm.loss_op.center, (B, 3), 'center')
+    end_points['iou2ds'] = T(asm.loss_op.iou2d, (B,), 'iou2ds')          # get_iou_summary (semisup_v1_sunrgbd.py:236-246,316)
+    end_points['iou3ds'] = T(asm.loss_op.iou3d, (B,), 'iou3ds')
     total = T(asm.loss_op.loss, (), 'semi_loss')
     ctx.loss = total if reduce_loss else T(asm.loss_op.total_losses, (B,), 'semi_losses')
     return ctx.loss

@@ -110,15 +110,18 @@ def train(FLAGS, rt=None, log=print):
         for epoch in range(FLAGS.max_epoch):
             t0 = time.time()
             loss_sum, correct = 0.0, 0.0
+            iou2_sum = iou3_sum = 0.0                 # 'Strong Box IoU (ground/3D)' of train_semisup.py:414-431
+            iou2ds, iou3ds = end_points['iou2ds'], end_points['iou3ds']
             if ds is not None:
                 # device pipeline: nothing is fed; the loss is fetched (a D2H sync) every 10th step only
                 ds.shuffle(FLAGS.seed * 1000003 + epoch * world + rank)      # train_semisup.py:343
                 n_logged = 0
                 for it in range(FLAGS.steps_per_epoch):
                     if it % 10 == 9 or it == FLAGS.steps_per_epoch - 1:
-                        loss_val, nc, _ = sess.run([semi_loss, n_correct, train_op])
+                        loss_val, nc, i2, i3, _ = sess.run([semi_loss, n_correct, iou2ds, iou3ds, train_op])
                         loss_sum += float(loss_val)
                         correct += float(nc[0])
+                        iou2_sum, iou3_sum = iou2_sum + float(np.sum(i2)), iou3_sum + float(np.sum(i3))
                         n_logged += 1
                     else:
                         sess.run([train_op])
@@ -126,6 +129,7 @@ def train(FLAGS, rt=None, log=print):
                 if rank == 0:
                     log('**** EPOCH %03d ****  mean loss: %f  accuracy: %f  (%.1f frustums/s, batches assembled on the device)' % (
                         epoch, loss_sum / n_logged, correct / (n_logged * B * N), FLAGS.steps_per_epoch * B * world / (time.time() - t0)))
+                    log('Strong Box IoU (ground/3D): %f / %f' % (iou2_sum / (n_logged * B), iou3_sum / (n_logged * B)))
                 loss_sum = loss_sum / n_logged * FLAGS.steps_per_epoch
             for it in range(0 if ds is not None else FLAGS.steps_per_epoch):
                 batch = make_batch(B, N, C, seed=FLAGS.seed * 1000003 + step * world + rank)
@@ -133,14 +137,16 @@ def train(FLAGS, rt=None, log=print):
                         y_centers_pl: batch['y_center'], y_orient_cls_pl: batch['y_orient_cls'],
                         y_orient_reg_pl: batch['y_orient_reg'], y_dims_cls_pl: batch['y_dims_cls'],
                         y_dims_reg_pl: batch['y_dims_reg'], is_data_2D_pl: batch['is_data_2D']}
-                loss_val, nc, _ = sess.run([semi_loss, n_correct, train_op], feed_dict=feed)
+                loss_val, nc, i2, i3, _ = sess.run([semi_loss, n_correct, iou2ds, iou3ds, train_op], feed_dict=feed)
                 loss_sum += float(loss_val)
                 correct += float(nc[0])
+                iou2_sum, iou3_sum = iou2_sum + float(np.sum(i2)), iou3_sum + float(np.sum(i3))
                 step += 1
             if rank == 0 and ds is None:
                 log('**** EPOCH %03d ****  mean loss: %f  accuracy: %f  (%.1f frustums/s incl. host batch synthesis)' % (
                     epoch, loss_sum / FLAGS.steps_per_epoch, correct / (FLAGS.steps_per_epoch * B * N),
                     FLAGS.steps_per_epoch * B * world / (time.time() - t0)))
+                log('Strong Box IoU (ground/3D): %f / %f' % (iou2_sum / (FLAGS.steps_per_epoch * B), iou3_sum / (FLAGS.steps_per_epoch * B)))
             if rank == 0:
                 if epoch % 5 == 0:                       # train_semisup.py:316-318
                     path = save_model(FLAGS.log_dir, epoch, g, FLAGS.ckpt_format)
