@@ -659,6 +659,36 @@ typedef struct {
 } t3d_batch_assemble_args;
 int t3d_batch_assemble(const t3d_batch_assemble_args* args, t3d_stream_t stream);
 
+/* Box-PC Fit training samples (box_pc_fit_dataset.py:105-185 `get`, 211-244 `perturb_box_to_diff_ious`, fed by
+ * train_boxpc.py:343-355): each frustum's label box is perturbed until its 3-D IoU with the label box falls strictly inside the
+ * "fit" bounds (with probability proportion_fit) or the "no-fit" bounds.  Candidate t of frustum b:
+ *   centre + U(-cp,cp)^3,  size + size*U(-sp,sp)^3,  heading + U(0,ap),   (cp,sp,ap) = perturbation * (1 - mean(bounds)).
+ * The reference draws candidates one after another; here the 64 lanes of a wave each test one candidate per round and the lowest
+ * accepted candidate index wins -- the same first-accepted law over the same candidate stream.  After max_rounds*64 rejected
+ * candidates the last candidate of lane 0 is taken and its true IoU reported (the reference would loop on).
+ * In place on the label buffers written by t3d_batch_assemble: centre / heading bin+residual / size residual become the
+ * perturbed box (the net's x_* inputs); the class is unchanged (size2class keeps the label's type, 179-180). */
+typedef struct {
+  float* center;                 /* [B,3] in: label centre; out: perturbed centre */
+  int32_t* orient_cls;           /* [B]   in/out heading bin  (angle2class of the perturbed heading) */
+  float* orient_reg;             /* [B]   in/out heading residual */
+  const int32_t* dims_cls;       /* [B]   size class */
+  float* dims_reg;               /* [B,3] in/out size residual w.r.t. the class mean size */
+  float* y_box_iou;              /* [B] out */
+  float* y_center_delta;         /* [B,3] out: perturbed - label */
+  float* y_dims_delta;           /* [B,3] out */
+  float* y_orient_delta;         /* [B] out */
+  float center_perturbation, size_perturbation, angle_perturbation;     /* BOXPC_*_PERTURBATION (config.py:27-29) */
+  float fit_lo, fit_hi, nofit_lo, nofit_hi, proportion_fit;              /* BOXPC_FIT_BOUNDS, BOXPC_NOFIT_BOUNDS, BOXPC_PROPORTION_OF_BOXPC_FIT */
+  const float* fit_draw;         /* [B] uniforms deciding fit / no-fit, or NULL (generated) */
+  const float* cand_draws;       /* [B, max_rounds*64, 7] uniforms in [0,1) of the candidates, or NULL (generated) */
+  int max_rounds;
+  uint32_t seed;
+  const float* hyper;            /* device step counter; required when draws are generated */
+  int B;
+} t3d_boxpc_perturb_args;
+int t3d_boxpc_perturb(const t3d_boxpc_perturb_args* args, t3d_stream_t stream);
+
 /* ---- K11d / K12 / schedules --------------------------------------------------------------------- */
 
 /* grad[off_i + e] = sum_s slabs_i[s, e]  for every tensor i of a device-side table. */

@@ -75,3 +75,37 @@ def get_batch(ds, sample, choice, flip, shift_randn, height_u, num_channel, **kw
         for k, v in zip(out, r):
             out[k].append(v)
     return {k: np.asarray(v) for k, v in out.items()}
+
+
+# ---- Box-PC Fit samples --------------------------------------------------------------------------------------------------------
+def perturb_box_to_diff_ious(box3d_center, size, heading_angle, iou_bounds, center_perturbation, size_perturbation, angle_perturbation,
+                             draws):
+    """box_pc_fit_dataset.py:211-244.  `draws` [T,7] are the uniforms in [0,1) the reference would take from np.random.uniform,
+    candidate after candidate: 3 for the centre (mapped to U(-p,p)), 3 for the size, 1 for the angle (mapped to U(0,p)).
+    Returns (new_center, new_size, new_heading, iou3d, y_center_delta, y_size_delta, y_angle_delta, tries)."""
+    from oracle.ref_box import get_box3d_iou
+    iou_mean = np.mean(iou_bounds)
+    cp, sp, ap = center_perturbation * (1 - iou_mean), size_perturbation * (1 - iou_mean), angle_perturbation * (1 - iou_mean)
+    box3d_center, size = np.asarray(box3d_center, np.float64), np.asarray(size, np.float64)
+    for count, u in enumerate(np.asarray(draws, np.float64)):
+        y_center_delta = (2 * u[0:3] - 1) * cp
+        y_size_delta = np.multiply(size, (2 * u[3:6] - 1) * sp)
+        y_angle_delta = u[6] * ap
+        new_center, new_size, new_heading = box3d_center + y_center_delta, size + y_size_delta, heading_angle + y_angle_delta
+        iou3d, _ = get_box3d_iou(box3d_center, size, heading_angle, new_center, new_size, new_heading)
+        assert 0.0 <= iou3d <= 1.0 + 1e-12
+        if iou_bounds[0] < iou3d < iou_bounds[1]:                       # inrange(): strict on both sides (44-45)
+            return new_center, new_size, new_heading, iou3d, y_center_delta, y_size_delta, y_angle_delta, count + 1
+    return None
+
+
+def boxpc_sample_labels(center, heading, size, cls, is_fit, fit_bounds, nofit_bounds, perturbations, draws):
+    """The label half of BoxPCFitDataset.get (box_pc_fit_dataset.py:170-185) for a frustum whose augmented label box is
+    (center, heading, size): the perturbed box in class / residual form and the regression targets."""
+    out = perturb_box_to_diff_ious(center, size, heading, fit_bounds if is_fit else nofit_bounds, *perturbations, draws)
+    if out is None:
+        return None
+    new_center, new_size, new_heading, iou, dc, ds, da, tries = out
+    acls, ares = angle2class(new_heading, NUM_HEADING_BIN)
+    return dict(x_center=new_center, x_orient_cls=acls, x_orient_reg=ares, x_dims_cls=cls, x_dims_reg=new_size - MEAN_DIMS_ARR[cls],
+                y_box_iou=iou, y_center_delta=dc, y_dims_delta=ds, y_orient_delta=da, tries=tries)

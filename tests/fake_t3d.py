@@ -407,6 +407,83 @@ class FakeLib:
                 arr(p.is_data_2D, B)[b] = 1 if (p.sample2 and from_first) else 0
         return 0
 
+    @staticmethod
+    def perturb_candidate_draws(seed, step, B, max_rounds):
+        """The uniforms csrc/data.hip (k_boxpc_perturb) generates: (fit_draw [B], cand_draws [B, max_rounds*64, 7])."""
+        M64 = (1 << 64) - 1
+
+        def mix(x):
+            x = np.asarray(x, dtype=np.uint64)
+            with np.errstate(over='ignore'):
+                x = x ^ (x >> np.uint64(33)); x = x * np.uint64(0xff51afd7ed558ccd)
+                x = x ^ (x >> np.uint64(33)); x = x * np.uint64(0xc4ceb9fe1a85ec53)
+                x = x ^ (x >> np.uint64(33))
+            return (x >> np.uint64(16)).astype(np.uint32)
+
+        def u01(r):
+            return ((r >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+        T = max_rounds * 64
+        fit, cand = np.zeros(B, np.float32), np.zeros((B, T, 7), np.float32)
+        idx = (np.arange(T, dtype=object)[:, None] * 8 + np.arange(7, dtype=object)[None, :] + 101)
+        for b in range(B):
+            key = ((((seed << 32) ^ ((step * 0x9E3779B97F4A7C15) & M64)) & M64) + (b + 1) * 0xC2B2AE3D27D4EB4F) & M64
+            fit[b] = u01(mix((key + 11) & M64))
+            ks = np.array([[(key + int(v) * 0xD6E8FEB86659FD93) & M64 for v in row] for row in idx], dtype=np.uint64)
+            cand[b] = u01(mix(ks))
+        return fit, cand
+
+    def t3d_boxpc_perturb(self, a, stream):
+        """csrc/data.hip k_boxpc_perturb in float32 (the same operation order), first accepted candidate of the stream."""
+        p = _struct(a)
+        B, T = p.B, p.max_rounds * 64
+        f32 = np.float32
+        if p.fit_draw and p.cand_draws:
+            fit_u, cand = arr(p.fit_draw, B), arr(p.cand_draws, B, T, 7)
+        else:
+            step = int(arr(p.hyper, 1)[0])
+            gf, gc = self.perturb_candidate_draws(p.seed, step, B, p.max_rounds)
+            fit_u = arr(p.fit_draw, B) if p.fit_draw else gf
+            cand = arr(p.cand_draws, B, T, 7) if p.cand_draws else gc
+        per = f32(2.0) * f32(np.pi) / f32(12.0)
+        two_pi = f32(2.0) * f32(np.pi)
+        for b in range(B):
+            cls = int(arr(p.dims_cls, B)[b])
+            c = arr(p.center, B, 3)[b].astype(f32).copy()
+            size = (MEAN32[cls] + arr(p.dims_reg, B, 3)[b]).astype(f32)
+            heading = f32(arr(p.orient_cls, B)[b]) * per + f32(arr(p.orient_reg, B)[b])
+            fit = fit_u[b] < f32(p.proportion_fit)
+            lo, hi = (f32(p.fit_lo), f32(p.fit_hi)) if fit else (f32(p.nofit_lo), f32(p.nofit_hi))
+            scale = f32(1.0) - f32(0.5) * (lo + hi)
+            cp, sp, ap = f32(p.center_perturbation) * scale, f32(p.size_perturbation) * scale, f32(p.angle_perturbation) * scale
+            chosen = None
+            for t in range(T):
+                u = cand[b, t].astype(f32)
+                dc = (f32(2.0) * u[0:3] - f32(1.0)) * cp
+                ds = size * ((f32(2.0) * u[3:6] - f32(1.0)) * sp)
+                da = u[6] * ap
+                iou, _ = box3d_iou_spec(c, size, heading, c + dc, size + ds, heading + da)
+                iou = f32(iou)
+                if iou > lo and iou < hi:
+                    chosen = (dc, ds, da, iou)
+                    break
+                if t == (p.max_rounds - 1) * 64:       # the fallback: lane 0 of the last round
+                    fallback = (dc, ds, da, iou)
+            dc, ds, da, iou = chosen if chosen is not None else fallback
+            a_ = np.fmod(heading + da, two_pi)
+            if a_ < 0:
+                a_ += two_pi
+            sh = np.fmod(f32(a_) + per * f32(0.5), two_pi)
+            cid = min(int(sh / per), 11)
+            arr(p.orient_cls, B)[b] = cid
+            arr(p.orient_reg, B)[b] = sh - (f32(cid) * per + per * f32(0.5))
+            arr(p.center, B, 3)[b] = c + dc
+            arr(p.dims_reg, B, 3)[b] = (size + ds) - MEAN32[cls]
+            arr(p.y_center_delta, B, 3)[b] = dc
+            arr(p.y_dims_delta, B, 3)[b] = ds
+            arr(p.y_orient_delta, B)[b] = da
+            arr(p.y_box_iou, B)[b] = iou
+        return 0
+
     def t3d_box_refine_step(self, a, stream):
         p = _struct(a)
         B = p.B

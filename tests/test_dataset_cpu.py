@@ -125,3 +125,96 @@ def check_alternate_batch(rt):
 
 def test_alternate_batch_sampling():
     check_alternate_batch(Runtime(device='cpu', lib=FakeLib()))
+
+
+def _stream(lib_is_fake):
+    if lib_is_fake:
+        return None
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _perturb_inputs(r, B):
+    return dict(center=(r.normal(size=(B, 3)) * 0.3 + [0, 0, 3]).astype(np.float32), ocls=r.randint(0, 12, B).astype(np.int32),
+                oreg=(r.uniform(-1, 1, B) * np.pi / 12).astype(np.float32), cls=r.randint(0, 10, B).astype(np.int32),
+                dreg=(r.normal(size=(B, 3)) * 0.1).astype(np.float32))
+
+
+def run_perturb(lib, dev, base, B, rounds, fit_u=None, cand=None, step=0, seed=77):
+    from transferable3d_amd import abi
+    from transferable3d_amd.abi import fptr, iptr
+    t = {k: torch.as_tensor(v.copy()).to(dev) for k, v in base.items()}
+    o = dict(iou=torch.zeros(B, device=dev), dc=torch.zeros(B, 3, device=dev), ds=torch.zeros(B, 3, device=dev), da=torch.zeros(B, device=dev))
+    hyper = torch.tensor([float(step), 0, 0, 0], device=dev)
+    fu = torch.as_tensor(fit_u).to(dev) if fit_u is not None else None
+    cd = torch.as_tensor(cand).to(dev) if cand is not None else None
+    a = abi.BoxPcPerturbArgs(fptr(t['center']), iptr(t['ocls']), fptr(t['oreg']), iptr(t['cls']), fptr(t['dreg']), fptr(o['iou']), fptr(o['dc']),
+                             fptr(o['ds']), fptr(o['da']), 0.8, 0.2, np.pi, 0.7, 1.0, 0.01, 0.25, 0.5, fptr(fu), fptr(cd), rounds, seed, fptr(hyper), B)
+    assert lib.t3d_boxpc_perturb(C.byref(a), _stream(isinstance(lib, FakeLib))) == 0
+    if dev != 'cpu':
+        torch.cuda.synchronize()
+    return {k: v.cpu() for k, v in t.items()}, {k: v.cpu() for k, v in o.items()}
+
+
+def check_boxpc_perturb_against_oracle(lib, dev):
+    """t3d_boxpc_perturb (first accepted candidate of a 64-wide candidate stream) against the oracle's restatement of
+    BoxPCFitDataset.perturb_box_to_diff_ious (sequential rejection sampling) consuming the same uniforms."""
+    from oracle import ref_data as RD
+    from transferable3d_amd.constants import MEAN_DIMS_ARR
+    r = np.random.RandomState(4)
+    B, R = 24, 6
+    base = _perturb_inputs(r, B)
+    fit_u = r.uniform(size=B).astype(np.float32)
+    cand = r.uniform(size=(B, R * 64, 7)).astype(np.float32)
+    t, o = run_perturb(lib, dev, base, B, R, fit_u, cand)
+    n_fit = 0
+    for b in range(B):
+        heading = base['ocls'][b] * (2 * np.pi / 12) + float(base['oreg'][b])
+        size = MEAN_DIMS_ARR[base['cls'][b]] + base['dreg'][b].astype(np.float64)
+        is_fit = fit_u[b] < 0.5
+        n_fit += is_fit
+        want = RD.boxpc_sample_labels(base['center'][b].astype(np.float64), heading, size, int(base['cls'][b]), is_fit, (0.7, 1.0), (0.01, 0.25),
+                                      (0.8, 0.2, np.pi), cand[b].astype(np.float64))
+        assert want is not None, b
+        lo, hi = ((0.7, 1.0) if is_fit else (0.01, 0.25))
+        assert lo < float(o['iou'][b]) < hi
+        assert abs(float(o['iou'][b]) - want['y_box_iou']) < 2e-5
+        assert np.abs(t['center'][b].numpy() - want['x_center']).max() < 1e-5
+        assert int(t['ocls'][b]) == want['x_orient_cls'] and abs(float(t['oreg'][b]) - want['x_orient_reg']) < 1e-5
+        assert np.abs(t['dreg'][b].numpy() - want['x_dims_reg']).max() < 1e-5
+        assert np.abs(o['dc'][b].numpy() - want['y_center_delta']).max() < 1e-6
+        assert np.abs(o['ds'][b].numpy() - want['y_dims_delta']).max() < 1e-6
+        assert abs(float(o['da'][b]) - want['y_orient_delta']) < 1e-6
+    assert 0 < n_fit < B
+
+
+def check_boxpc_perturb_generated(lib, dev):
+    """Generated draws (hash of seed, step, frustum, candidate): every sample lands inside its bounds, about half are "fit", the
+    deltas reproduce the perturbed box, and a different step gives different samples."""
+    from fake_t3d import box3d_iou_spec
+    from transferable3d_amd.constants import MEAN_DIMS_ARR
+    B = 64
+    base = _perturb_inputs(np.random.RandomState(9), B)
+    t, o = run_perturb(lib, dev, base, B, 4, step=3)
+    iou = o['iou'].numpy()
+    fit = iou > 0.7
+    assert np.all(((iou > 0.7) & (iou < 1.0)) | ((iou > 0.01) & (iou < 0.25))) and 16 < fit.sum() < 48
+    for b in range(0, B, 7):
+        h0 = base['ocls'][b] * (2 * np.pi / 12) + base['oreg'][b]
+        s0 = MEAN_DIMS_ARR[base['cls'][b]] + base['dreg'][b]
+        h1 = int(t['ocls'][b]) * (2 * np.pi / 12) + float(t['oreg'][b])
+        s1 = MEAN_DIMS_ARR[base['cls'][b]] + t['dreg'][b].numpy()
+        assert np.abs(t['center'][b].numpy() - base['center'][b] - o['dc'][b].numpy()).max() < 1e-6
+        assert np.abs(s1 - s0 - o['ds'][b].numpy()).max() < 1e-6
+        assert abs(np.angle(np.exp(1j * (h1 - h0 - float(o['da'][b]))))) < 1e-5
+        assert abs(box3d_iou_spec(base['center'][b], s0, h0, t['center'][b].numpy(), s1, h1)[0] - iou[b]) < 2e-5
+    _, o2 = run_perturb(lib, dev, base, B, 4, step=4)
+    assert not np.allclose(o2['iou'].numpy(), iou)
+    return base, t, o
+
+
+def test_boxpc_perturb_spec_against_oracle_on_identical_draws():
+    check_boxpc_perturb_against_oracle(FakeLib(), 'cpu')
+
+
+def test_boxpc_perturb_generated_draws_follow_the_sampling_law():
+    check_boxpc_perturb_generated(FakeLib(), 'cpu')

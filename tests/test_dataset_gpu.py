@@ -37,3 +37,19 @@ def test_generated_batch_equals_the_specification(hip_lib):
 def test_alternate_batch_sampling(hip_lib):
     from test_dataset_cpu import check_alternate_batch
     check_alternate_batch(Runtime(lib=hip_lib))
+
+
+def test_boxpc_perturb_against_the_reference_restatement(hip_lib):
+    from test_dataset_cpu import check_boxpc_perturb_against_oracle
+    check_boxpc_perturb_against_oracle(hip_lib, 'cuda')
+
+
+def test_boxpc_perturb_generated_draws_equal_the_specification(hip_lib):
+    """Same hash generator on both sides: the device picks the candidates the NumPy specification picks (an IoU within rounding
+    of a bound could flip one acceptance; none does for this seed)."""
+    from test_dataset_cpu import check_boxpc_perturb_generated
+    base, t, o = check_boxpc_perturb_generated(hip_lib, 'cuda')
+    _, tc, oc = check_boxpc_perturb_generated(FakeLib(), 'cpu')
+    assert np.abs(o['iou'].numpy() - oc['iou'].numpy()).max() < 2e-5
+    assert np.abs(o['dc'].numpy() - oc['dc'].numpy()).max() < 1e-6 and np.abs(o['da'].numpy() - oc['da'].numpy()).max() < 1e-6
+    assert np.array_equal(t['ocls'].numpy(), tc['ocls'].numpy())

@@ -157,3 +157,18 @@ def test_stage_c_cli_from_a_device_resident_dataset_alternates_weak_and_strong_b
          '--steps_per_epoch', '4', '--device_data', '40', '--log_dir', str(tmp_path)])
     sd, loss = train_semisup_adv.train(flags, rt=Runtime(device='cpu', lib=FakeLib()), log=logs.append)
     assert np.isfinite(loss) and any('assembled on the device' in l for l in logs)
+
+
+def test_train_boxpc_from_a_device_resident_dataset(tmp_path):
+    """train_boxpc --device_data: t3d_batch_assemble + t3d_boxpc_perturb make every (points, perturbed box, IoU / delta targets)
+    sample inside the step (the sampling law itself is checked in test_dataset_cpu.py / test_dataset_gpu.py)."""
+    from transferable3d_amd import train_boxpc
+    logs = []
+    flags = train_boxpc.build_flags(['--BOX_PC_MASK_REPRESENTATION', 'A', '--BOXPC_WEIGHT_DELTA', '4', '--num_point', '128', '--batch_size', '8',
+                                     '--num_channels', '4', '--max_epoch', '2', '--steps_per_epoch', '15', '--device_data', '32',
+                                     '--log_dir', str(tmp_path)])
+    _, loss = train_boxpc.train(flags, rt=Runtime(device='cpu', lib=FakeLib()), log=logs.append)
+    ep = [l for l in logs if 'EPOCH' in l]
+    assert len(ep) == 2 and 'samples made on the device' in ep[0]
+    l0, l1 = [float(l.split('mean loss: ')[1].split()[0]) for l in ep]
+    assert np.isfinite(l0) and np.isfinite(l1) and 0 < l1 < 20

@@ -86,6 +86,14 @@ class BoxRefineStepArgs(C.Structure):
                 ('total', F), ('fit_prob', F), ('weigh_by_conf', i32), ('first', i32), ('B', i32)]
 
 
+class BoxPcPerturbArgs(C.Structure):
+    _fields_ = [('center', F), ('orient_cls', I), ('orient_reg', F), ('dims_cls', I), ('dims_reg', F), ('y_box_iou', F),
+                ('y_center_delta', F), ('y_dims_delta', F), ('y_orient_delta', F), ('center_perturbation', f32),
+                ('size_perturbation', f32), ('angle_perturbation', f32), ('fit_lo', f32), ('fit_hi', f32), ('nofit_lo', f32),
+                ('nofit_hi', f32), ('proportion_fit', f32), ('fit_draw', F), ('cand_draws', F), ('max_rounds', i32),
+                ('seed', C.c_uint32), ('hyper', F), ('B', i32)]
+
+
 class Box3dIouArgs(C.Structure):
     _fields_ = [('center1', F), ('size1', F), ('heading1', F), ('center2', F), ('size2', F), ('heading2', F), ('iou3d', F), ('iou2d', F),
                 ('n', i32)]
@@ -228,6 +236,7 @@ ENTRY_POINTS = {
     't3d_pool_wgrad_finish': [C.POINTER(PoolWgradFinishArgs), VP],
     't3d_batch_assemble': [C.POINTER(BatchAssembleArgs), VP],
     't3d_box_refine_step': [C.POINTER(BoxRefineStepArgs), VP],
+    't3d_boxpc_perturb': [C.POINTER(BoxPcPerturbArgs), VP],
     't3d_box3d_iou': [C.POINTER(Box3dIouArgs), VP],
     't3d_box3d_iou_corners': [C.POINTER(Box3dIouCornersArgs), VP],
     't3d_box_head_iou': [C.POINTER(BoxHeadIouArgs), VP],

@@ -112,7 +112,8 @@ class Graph:
 
     def use_device_dataset(self, dataset, seed=0, **aug):
         """Feed the training plan from a data set resident in HBM: every Session.run of the train op assembles its own
-        batch on the device (t3d_batch_assemble), nothing needs to be fed."""
+        batch on the device (t3d_batch_assemble), nothing needs to be fed.  `boxpc_perturb=FLAGS` (the BOXPC_* flags) adds the
+        Box-PC Fit sampler (t3d_boxpc_perturb) behind it."""
         self.dataset, self.dataset_opts = dataset, dict(seed=seed, **aug)
 
     def ensure_assembly(self, c, use_one_hot=False):
@@ -188,7 +189,11 @@ class Session:
         if train:
             top = g.train_op
             if g.dataset is not None:
-                e.emit_batch_assemble(pre, g.dataset, g.inputs, **g.dataset_opts)
+                opts = dict(g.dataset_opts)
+                perturb = opts.pop('boxpc_perturb', None)
+                e.emit_batch_assemble(pre, g.dataset, g.inputs, **opts)
+                if perturb is not None:        # Box-PC Fit samples: the label box becomes a perturbed box with an IoU target
+                    e.emit_boxpc_perturb(pre, g.inputs, perturb, seed=opts.get('seed', 0) ^ 0x5bd1e995)
             e.emit_schedule(pre, top.sched)
             e.emit_dropout_masks(pre, seed=self.dropout_seed)
         asm.emit_forward(fwd, is_training, with_loss)

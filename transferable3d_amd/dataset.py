@@ -96,6 +96,23 @@ class DeviceFrustumSet:
         return a
 
 
+def boxpc_perturb_args(inputs, hyper, B, c, seed=0, max_rounds=16, fit_draw=None, cand_draws=None):
+    """Argument struct of t3d_boxpc_perturb working in place on `inputs` (nets.Inputs) after t3d_batch_assemble: the label box
+    becomes the perturbed box the Box-PC net sees, y_box_iou / y_*_delta its targets.  `c`: the BOXPC_* flags (config.py:22-29)."""
+    a = abi.BoxPcPerturbArgs()
+    a.center, a.orient_cls, a.orient_reg = fptr(inputs.y_center), iptr(inputs.y_orient_cls), fptr(inputs.y_orient_reg)
+    a.dims_cls, a.dims_reg = iptr(inputs.y_dims_cls), fptr(inputs.y_dims_reg)
+    a.y_box_iou, a.y_center_delta, a.y_dims_delta, a.y_orient_delta = fptr(inputs.y_box_iou), fptr(inputs.y_center_delta), \
+        fptr(inputs.y_dims_delta), fptr(inputs.y_orient_delta)
+    a.center_perturbation, a.size_perturbation, a.angle_perturbation = float(c.BOXPC_CENTER_PERTURBATION), \
+        float(c.BOXPC_SIZE_PERTURBATION), float(c.BOXPC_ANGLE_PERTURBATION)
+    (a.fit_lo, a.fit_hi), (a.nofit_lo, a.nofit_hi) = [float(v) for v in c.BOXPC_FIT_BOUNDS], [float(v) for v in c.BOXPC_NOFIT_BOUNDS]
+    a.proportion_fit = float(c.BOXPC_PROPORTION_OF_BOXPC_FIT)
+    a.fit_draw, a.cand_draws, a.max_rounds, a.seed, a.hyper, a.B = fptr(fit_draw), fptr(cand_draws), max_rounds, seed, fptr(hyper), B
+    a._keep = (fit_draw, cand_draws)
+    return a
+
+
 def synthetic_frustums(n_frustums, num_channel=6, seed=0, min_points=400, max_points=3000):
     """Host arrays for DeviceFrustumSet: xyz in camera-like coordinates before the centre-view rotation, extra channels
     U(0,1), ~30 % foreground points clustered around the box centre, heading / size / class as in synthetic.make_batch."""

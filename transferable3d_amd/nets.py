@@ -71,6 +71,12 @@ class Graph:
         a = dataset.assemble_args(inputs, self.hyper, self.B, self.rpf, self.C, seed=seed, **aug)
         plan.add('t3d_batch_assemble', a)
 
+    def emit_boxpc_perturb(self, plan, inputs, c, seed=0):
+        """Box-PC Fit training samples on the device (box_pc_fit_dataset.py:211-244): after the batch is assembled, perturb every
+        label box until its IoU falls inside the fit / no-fit bounds."""
+        from .dataset import boxpc_perturb_args
+        plan.add('t3d_boxpc_perturb', boxpc_perturb_args(inputs, self.hyper, self.B, c, seed=seed))
+
     def emit_schedule(self, plan, sched):
         lib, hyper = self.rt.lib, self.hyper
         plan.add_raw('t3d_schedule_step', lambda s: lib.t3d_schedule_step(fptr(hyper), C.byref(sched), s), sched)

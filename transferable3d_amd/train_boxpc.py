@@ -42,6 +42,8 @@ def build_flags(argv=None):
     cfg.add_argument('--num_channels', type=int, default=None)
     cfg.add_argument('--steps_per_epoch', type=int, default=100)
     cfg.add_argument('--seed', type=int, default=0)
+    cfg.add_argument('--device_data', type=int, default=0, metavar='F',
+                     help='F > 0: F synthetic frustums resident in HBM; batches and the perturbed-box samples are made on the device')
     FLAGS = cfg.parse_special_args(argv)
     FLAGS.NUM_CHANNELS = FLAGS.num_channels if FLAGS.num_channels else (3 if FLAGS.no_rgb else 6)
     return FLAGS
@@ -66,8 +68,31 @@ def train(FLAGS, rt=None, log=print):
         if FLAGS.restore_model_path:
             restore_model(g, FLAGS.restore_model_path)
         step, mean_loss = 0, 0.0
+        ds = None
+        if FLAGS.device_data:
+            from transferable3d_amd.dataset import DeviceFrustumSet
+            ds = DeviceFrustumSet.synthetic(g.rt, FLAGS.device_data, num_channel=max(C, 6), seed=FLAGS.seed)
+            g.use_device_dataset(ds, seed=FLAGS.seed * 7919, boxpc_perturb=FLAGS)
         for epoch in range(FLAGS.max_epoch):
             t0, loss_sum = time.time(), 0.0
+            if ds is not None:
+                # box_pc_fit_dataset.py 'BATCH' sampling: an epoch permutation; the loss is fetched every 10th step only
+                ds.shuffle(FLAGS.seed * 1000003 + epoch)
+                n_logged = 0
+                for it in range(FLAGS.steps_per_epoch):
+                    if it % 10 == 9 or it == FLAGS.steps_per_epoch - 1:
+                        loss_val, _ = sess.run([loss, train_op])
+                        loss_sum += float(loss_val)
+                        n_logged += 1
+                    else:
+                        sess.run([train_op])
+                    step += 1
+                mean_loss = loss_sum / n_logged
+                log('**** EPOCH %03d ****  mean loss: %f  (%.1f frustums/s, samples made on the device)' % (
+                    epoch, mean_loss, FLAGS.steps_per_epoch * B / (time.time() - t0)))
+                if epoch % 5 == 0:
+                    log('Model saved in file: %s' % save_model(FLAGS.log_dir, epoch, g, FLAGS.ckpt_format))
+                continue
             for _ in range(FLAGS.steps_per_epoch):
                 b = make_batch(B, N, C, seed=FLAGS.seed * 1000003 + step, boxpc=True)
                 feed = {pc_pl: b['pc'], one_hot_vec_pl: b['one_hot_vec'], x_center_pl: b['y_center'], x_orient_cls_pl: b['y_orient_cls'],
