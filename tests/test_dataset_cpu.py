@@ -218,3 +218,31 @@ def test_boxpc_perturb_spec_against_oracle_on_identical_draws():
 
 def test_boxpc_perturb_generated_draws_follow_the_sampling_law():
     check_boxpc_perturb_generated(FakeLib(), 'cpu')
+
+
+def test_frustum_pickle_reader(tmp_path):
+    """A file in the reference's format -- gzip'd protocol-2 pickle of the 13 lists, class names as Python-2 byte strings -- loads
+    into a DeviceFrustumSet: ragged point lists, box centre = (corner0 + corner6) / 2, class filter."""
+    import gzip
+    import pickle
+    from transferable3d_amd.dataset import load_zipped_pickle
+    r = np.random.RandomState(2)
+    names = [b'bed', b'chair', b'table', b'chair', b'sofa']
+    n = [300, 120, 77, 500, 64]
+    box3d = [r.normal(size=(8, 3)) for _ in names]
+    lists = [list(range(5)), [r.uniform(size=4) for _ in names], box3d, [None] * 5, [r.normal(size=(k, 6)) for k in n],
+             [(r.uniform(size=k) < 0.3).astype(np.float64) for k in n], names, list(r.uniform(-3, 3, 5)), [r.uniform(0.5, 2, 3) for _ in names],
+             [np.eye(3)] * 5, [np.eye(3)] * 5, list(r.uniform(-2, -1, 5)), [np.array([640, 480])] * 5]
+    path = str(tmp_path / 'train_mini.zip.pickle')
+    with gzip.open(path, 'wb') as f:
+        pickle.dump(lists, f, 2)
+    back = load_zipped_pickle(path)
+    assert back[6] == ['bed', 'chair', 'table', 'chair', 'sofa'] and np.array_equal(back[4][2], lists[4][2])
+    rt = Runtime(device='cpu', lib=FakeLib())
+    ds = DeviceFrustumSet.from_pickle(rt, path, classes=['chair', 'sofa'])
+    assert ds.F == 3 and ds.image_ids == [1, 3, 4]
+    assert ds.offsets.tolist() == [0, 120, 620, 684] and ds.cls.tolist() == [3, 3, 2]
+    assert np.allclose(ds.box_center[1].numpy(), (box3d[3][0] + box3d[3][6]) / 2, atol=1e-6)
+    assert np.allclose(ds.points[120:620].numpy(), lists[4][3].astype(np.float32)) and ds.seg[620:].tolist() == lists[5][4].astype(int).tolist()
+    all_ds = DeviceFrustumSet.from_pickle(rt, path)
+    assert all_ds.F == 5

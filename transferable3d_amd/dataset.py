@@ -15,7 +15,7 @@ import torch
 
 from . import abi
 from .abi import fptr, iptr
-from .constants import MEAN_DIMS_ARR, NUM_CLASS
+from .constants import MEAN_DIMS_ARR, NUM_CLASS, type2class
 
 
 class DeviceFrustumSet:
@@ -41,6 +41,23 @@ class DeviceFrustumSet:
         offsets = np.concatenate([[0], np.cumsum(counts)])
         return cls(rt, np.concatenate(points_l).astype(np.float32), np.concatenate(label_l).astype(np.int32), offsets,
                    np.asarray(frustum_angle_l), np.asarray(box3d_center_l), np.asarray(heading_l), np.asarray(size_l), np.asarray(cls_id_l))
+
+    @classmethod
+    def from_pickle(cls, rt, path, classes=None):
+        """A frustum file of the reference (`frustums/*.zip.pickle`, written by sunrgbd_data.py:193-195 and read by
+        roi_semi_dataset.py:204-252 / box_pc_fit_dataset.py:59-60): a gzip'd pickle of 13 lists [idx, box2d, box3d (8,3), image_crop,
+        points (n,6), label (n,), cls_type (str), heading, size (l,w,h), rtilt, k, frustum_angle, img_dims].  `classes`: keep only these
+        class names (the dataset classes' `classes` argument)."""
+        idx_l, box2d_l, box3d_l, _, points_l, label_l, cls_type_l, heading_l, size_l, _, _, frustum_angle_l, _ = load_zipped_pickle(path)
+        keep = [i for i, t in enumerate(cls_type_l) if classes is None or t in classes]
+        if not keep:
+            raise ValueError('%s: no frustum of classes %s' % (path, classes))
+        pick = lambda lst: [lst[i] for i in keep]
+        centers = [(np.asarray(b)[0, :] + np.asarray(b)[6, :]) / 2.0 for b in pick(box3d_l)]      # roi_semi_dataset.py:356-358
+        ds = cls.from_lists(rt, [np.asarray(p) for p in pick(points_l)], [np.asarray(l) for l in pick(label_l)], pick(frustum_angle_l),
+                            centers, pick(heading_l), pick(size_l), [type2class[t] for t in pick(cls_type_l)])
+        ds.image_ids = pick(idx_l)
+        return ds
 
     @classmethod
     def synthetic(cls, rt, n_frustums, num_channel=6, seed=0, min_points=400, max_points=3000):
@@ -94,6 +111,25 @@ class DeviceFrustumSet:
             a.sample, a.sample_len, a.sample2, a.sample2_len = iptr(weak), int(weak.numel()), iptr(strong), int(strong.numel())
         a._keep = (sample, choice, aug)
         return a
+
+
+def load_zipped_pickle(path):
+    """sunrgbd_data/utils.py:345-348.  The reference's files are Python-2 cPickle streams holding NumPy arrays and byte strings:
+    `latin1` decodes both (str class names included) under Python 3."""
+    import gzip
+    import pickle
+    with gzip.open(path, 'rb') as f:
+        obj = pickle.load(f, encoding='latin1')
+    return [[t.decode() if isinstance(t, bytes) else t for t in lst] if i == 6 else lst for i, lst in enumerate(obj)] \
+        if isinstance(obj, (list, tuple)) and len(obj) == 13 else obj
+
+
+def save_zipped_pickle(obj, path, protocol=2):
+    """sunrgbd_data/utils.py:341-343 (the reference passes -1, the highest protocol of its Python 2: protocol 2)."""
+    import gzip
+    import pickle
+    with gzip.open(path, 'wb') as f:
+        pickle.dump(obj, f, protocol)
 
 
 def boxpc_perturb_args(inputs, hyper, B, c, seed=0, max_rounds=16, fit_draw=None, cand_draws=None):

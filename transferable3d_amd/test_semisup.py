@@ -32,6 +32,7 @@ def build_flags(argv=None):
     cfg.add_argument('--model', default='semisup_v1_sunrgbd')
     cfg.add_argument('--model_path', default=None, help='state dict (.npz) or TensorFlow checkpoint prefix written by train_semisup*.py')
     cfg.add_argument('--boxpc_model_path', default=None)
+    cfg.add_argument('--evaluate', action='store_true', help='AP of the predictions against the label boxes (evaluate.py)')
     cfg.add_argument('--pred_prefix', default='F2_')
     cfg.add_argument('--refine', default=None)
     cfg.add_argument('--output', default=None)
@@ -125,8 +126,21 @@ def test(FLAGS, rt=None, log=print):
     log('Mean segmentation IOU: %f' % iou)
     # test_semisup.py:509-511: [ps, seg_gt, seg_pred, center, heading_cls, heading_res, size_cls, size_res, rot_angle, score, cls,
     #                           file_num, box2d, box3d]
-    predictions = [list(pc), list(seg_gt), list(seg), list(centers), list(hcls), list(hres), list(scls), list(sres), None,
-                   list(scores), list(np.argmax(oh, 1)), None, None, None]
+    # synthetic frustums are already in their centre view (rot_angle 0) and each is its own "image" (file_num = index)
+    predictions = [list(pc), list(seg_gt), list(seg), list(centers), list(hcls), list(hres), list(scls), list(sres), [0.0] * n,
+                   list(scores), list(np.argmax(oh, 1)), list(range(n)), None, None]
+    if FLAGS.evaluate:
+        # evaluate.py:27-76 against the label boxes of the same frustums (the reference builds them from the SUN-RGBD label files)
+        from transferable3d_amd.constants import MEAN_DIMS_ARR, class2type
+        from transferable3d_amd.eval_det import evaluate_predictions, get_3d_box, get_ap_info
+        classes = [class2type[i] for i in range(10)]
+        lab = {k: np.concatenate([b[k] for b in batches]) for k in ('y_center', 'y_orient_cls', 'y_orient_reg', 'y_dims_cls', 'y_dims_reg')}
+        gt_all = {i: [(classes[int(np.argmax(oh[i]))],
+                       get_3d_box(MEAN_DIMS_ARR[int(lab['y_dims_cls'][i])] + lab['y_dims_reg'][i],
+                                  int(lab['y_orient_cls'][i]) * (2 * np.pi / NUM_HEADING_BIN) + float(lab['y_orient_reg'][i]), lab['y_center'][i]))]
+                  for i in range(n)}
+        _, _, ap, mean_ap = evaluate_predictions(predictions, gt_all, classes, rt=sess.g.rt)
+        log(get_ap_info(ap, mean_ap))
     if FLAGS.output:
         with gzip.open(FLAGS.output, 'wb') as f:
             pickle.dump(predictions, f, -1)
