@@ -204,7 +204,13 @@ def main():
     # T3D_FORCE_DIST=1: take the multi-rank code path (RCCL init, all-reduce between the two graphs) with a single rank, so
     # that it can be exercised on a 1-GPU box
     use_dist = world > 1 or os.environ.get('T3D_FORCE_DIST', '0') == '1'
+    saved_stdout = None
     if use_dist:
+        # RCCL prints a version banner on the C-level stdout; the contract is ONE JSON line there.  Route fd 1 to stderr for the
+        # duration of the run and put it back just before the line is printed.
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
@@ -264,10 +270,27 @@ def main():
     if use_graph:
         # warm the kernels once eagerly, then capture the step into hipGraphs
         run_compute()
+        if use_dist:
+            dist.all_reduce(flat_grads)        # communicator set-up happens here, outside any capture
         g.opt.run()
         torch.cuda.synchronize()
         s = torch.cuda.Stream()
+        one_graph = False
+        if use_dist and os.environ.get('T3D_DP_ONE_GRAPH', '0') == '1':
+            # the gradient all-reduce captured between backward and Adam: one replay per step (RCCL supports stream capture)
+            try:
+                g1 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1, stream=s, capture_error_mode='thread_local'):
+                    run_compute()
+                    dist.all_reduce(flat_grads)
+                    g.opt.run()
+                one_graph = True
+            except RuntimeError as err:
+                sys.stderr.write('capture with the all-reduce inside failed (%s); two graphs around an eager all-reduce\n' % err)
+                torch.cuda.synchronize()
         try:
+            if one_graph:
+                raise StopIteration
             g1 = torch.cuda.CUDAGraph()
             # thread_local: calls of other threads (the RCCL watchdog) during capture must not invalidate it
             with torch.cuda.graph(g1, stream=s, capture_error_mode='thread_local'):
@@ -279,6 +302,8 @@ def main():
                 g2 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g2, stream=s, capture_error_mode='thread_local'):
                     g.opt.run()
+        except StopIteration:
+            pass
         except RuntimeError as err:          # a capture that the runtime refuses must not cost the measurement: eager launches
             sys.stderr.write('hipGraph capture failed (%s); falling back to eager launches\n' % err)
             torch.cuda.synchronize()
@@ -287,7 +312,7 @@ def main():
     def step():
         if use_graph:
             g1.replay()
-            if use_dist:
+            if use_dist and not one_graph:
                 dist.all_reduce(flat_grads)
                 g2.replay()
         else:
@@ -373,9 +398,17 @@ def main():
                'config': {'workload': '%s, B=%d N=%d C=%d fp32 per GPU, dp%d' % (desc, B, N, C, world), 'global_batch': B * world, 'hipgraph': use_graph,
                           'launches_per_step': len(g.pre) + len(g.fwd) + len(g.bwd) + len(g.opt), 'final_loss': loss},
                'roofline': roofline, 'cpu_baseline': cpu}
-        print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    if saved_stdout is not None:
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)          # whatever C stdio still holds goes to stderr too
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
+    if rank == 0:
+        print(json.dumps(out))
+        sys.stdout.flush()
 
 
 if __name__ == '__main__':

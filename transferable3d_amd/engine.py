@@ -67,6 +67,9 @@ class Runtime:
 SIDE_STREAM = os.environ.get('T3D_SIDE_STREAM', '0') == '1'
 # dgrad + wgrad of a dense layer in one launch (t3d_pointmlp_bwd); T3D_FUSE_BWD=0 restores the two launches
 FUSE_BWD = os.environ.get('T3D_FUSE_BWD', '1') != '0'
+# the fully-connected backward chains of the box / T-Net (a few workgroups each, ~100 us per step of dependent launches) on the
+# second stream beside the segmentation net's backward GEMMs, which do not depend on them
+FC_SIDE = os.environ.get('T3D_FC_SIDE', '0') == '1'
 
 
 class Plan:
@@ -86,6 +89,7 @@ class Plan:
         self.lanes = []      # 0 = main stream, 1 = side stream, parallel to `calls`
         self.keep = []       # keep-alive for structs / tensors
         self._lane = 0
+        self.two_streams = False   # this plan's side lane really runs on the second stream (FC_SIDE schedule)
 
     @contextlib.contextmanager
     def side(self):
@@ -120,7 +124,7 @@ class Plan:
         self.lanes.append(0)
 
     def run(self):
-        if self.rt.device.type == 'cuda' and any(self.lanes) and SIDE_STREAM:
+        if self.rt.device.type == 'cuda' and any(self.lanes) and (SIDE_STREAM or self.two_streams):
             return self._run_two_streams()
         s = self.rt.stream()
         for name, call, _ in self.calls:

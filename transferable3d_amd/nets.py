@@ -175,13 +175,23 @@ class InstSegNet:
         plan.add('t3d_seg_finalize', f)
         return self.logits
 
-    def bwd(self, plan):
+    def bwd(self, plan, part=None):
+        """part None: everything; 0 / 1 / 2: conv9..conv7 | conv6, conv5 | conv4..conv1 (the FC_SIDE schedule interleaves the
+        other nets between them)."""
         assert self.train_seg
         g = self.g
         L = self
-        for lay in (L.L9, L.L8, L.L7):
-            lay.bn_bwd(plan)
-            lay.bwd_pair(plan)
+        if part in (None, 0):
+            for lay in (L.L9, L.L8, L.L7):
+                lay.bn_bwd(plan)
+                lay.bwd_pair(plan)
+        if part in (None, 1):
+            self._bwd_mid(plan)
+        if part in (None, 2):
+            self._bwd_tail(plan)
+
+    def _bwd_mid(self, plan):
+        g, L = self.g, self
         L.L6.bn_bwd(plan)
         colsum6 = L.L6.dy_colsum(plan)                                   # [B,512]
         L.G6.bwd(plan, dout=colsum6, ld_dout=512)                        # dW6[64:], no bias
@@ -190,6 +200,9 @@ class InstSegNet:
         L.L6.bwd_pair(plan, out_raw=self.da3_part)
         L.L5.bn_bwd(plan, dpool_in=dg5, ld_dpool_in=1024)
         L.L5.bwd_pair(plan)
+
+    def _bwd_tail(self, plan):
+        L = self
         L.L4.bn_bwd(plan)
         L.L4.bwd_pair(plan, add_in=self.da3_part)
         for lay in (L.L3, L.L2):
@@ -223,11 +236,16 @@ class TNet:
         self.stage1_center = self.F3.fwd(plan, x, 128, is_training, add_in=mask_xyz_mean, ld_add=3, add_n=3)
         return self.stage1_center
 
-    def bwd(self, plan, dstage1):
+    def bwd_fc(self, plan, dstage1):
         self.F3.bwd(plan, dout=dstage1, ld_dout=3)
         self.F2.bwd(plan, nxt=self.F3)
         self.F1.bwd(plan, nxt=self.F2)
-        dft = self.F1.dinput(plan, K=256, bn_bwd_of=self.T3)
+        return self.F1.dinput(plan, K=256, bn_bwd_of=self.T3)
+
+    def bwd(self, plan, dstage1):
+        self.bwd_convs(plan, self.bwd_fc(plan, dstage1))
+
+    def bwd_convs(self, plan, dft):
         self.T3.bn_bwd(plan, dpool_in=dft, ld_dpool_in=256)
         self.T3.bwd_pair(plan)
         self.T2.bn_bwd(plan)
@@ -281,12 +299,14 @@ class BoxEstNet:
         plan.add('t3d_fc_dinput', a)
         return out
 
-    def bwd(self, plan, dbox, dstage1_in):
+    def bwd_fc(self, plan, dbox):
         self.G3.bwd(plan, dout=dbox, ld_dout=BOX_OUT_DIMS)
         self.G2.bwd(plan, nxt=self.G3)
         self.G1.bwd(plan, nxt=self.G2)
-        dfb = self.G1.dinput(plan, K=512, bn_bwd_of=self.B4)
-        return self.bwd_convs(plan, dfb, 512, dstage1_in)
+        return self.G1.dinput(plan, K=512, bn_bwd_of=self.B4)
+
+    def bwd(self, plan, dbox, dstage1_in):
+        return self.bwd_convs(plan, self.bwd_fc(plan, dbox), 512, dstage1_in)
 
 
 class StrongLoss:
@@ -380,6 +400,24 @@ class ModelAssembly:
             self.loss_op.emit(plan, box, s1, self.seg.seg_loss, lab, c)
 
     def emit_backward(self, plan):
+        from .engine import FC_SIDE
+        if FC_SIDE and self.seg.train_seg:
+            plan.two_streams = True
+            with plan.side():
+                dfb = self.box.bwd_fc(plan, self.loss_op.dbox)
+            plan.flush()                                    # fork: box FC chain || seg conv9..conv7
+            self.seg.bwd(plan, part=0)
+            plan.join()
+            ds1 = self.box.bwd_convs(plan, dfb, 512, self.loss_op.dstage1)
+            with plan.side():
+                dft = self.tnet.bwd_fc(plan, ds1)
+            plan.flush()                                    # fork: T-Net FC chain || seg conv6, conv5
+            self.seg.bwd(plan, part=1)
+            plan.join()
+            self.tnet.bwd_convs(plan, dft)
+            self.seg.bwd(plan, part=2)
+            self.g.emit_reduce_slabs(plan)
+            return
         ds1 = self.box.bwd(plan, self.loss_op.dbox, self.loss_op.dstage1)
         plan.flush()                     # box-net weight gradients run beside the T-Net / seg-net dgrad chain
         self.tnet.bwd(plan, ds1)
