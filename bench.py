@@ -399,6 +399,8 @@ def main():
                           'launches_per_step': len(g.pre) + len(g.fwd) + len(g.bwd) + len(g.opt), 'final_loss': loss},
                'roofline': roofline, 'cpu_baseline': cpu}
     if dist is not None:
+        dist.barrier()                        # rank 0 profiled its kernels meanwhile: every rank leaves together
+        torch.cuda.synchronize()
         dist.destroy_process_group()
     if saved_stdout is not None:
         import ctypes

@@ -110,3 +110,17 @@ def test_inference_graph_with_iterated_boxpc_refinement(refine):
 def test_stage_c_and_inference_match_golden_vectors():
     from model_check import check_golden_stage_c
     check_golden_stage_c(Runtime(device='cpu', lib=FakeLib()))
+
+
+def test_stage_c_all_2d_batch_has_zero_strong_loss_and_finite_gradients():
+    """ALTERNATE_BATCH's all-2D batch: no frustum carries 3-D labels, the strong loss is 0 / (0 + 1e-3) = 0
+    (semisup_v1_sunrgbd.py:331-337); the fit and intraclass terms still train box_refine."""
+    B, N, C = 4, 256, 4
+    batch = stage_c_batch(B, N, C, seed=8, n2d=B)
+    P = stage_c_params(C, 6)
+    c = stage_c_config()
+    g, m = run_stage_c(Runtime(device='cpu', lib=FakeLib()), batch, P, c)
+    e = m.end_points()
+    assert float(e['strong_loss']) == 0.0 and float(e['terms'][1]) > 0.0
+    assert np.isfinite(g.vars.grads[:g.vars.used].numpy()).all()
+    check_stage_c(g, m, batch, P, c)
