@@ -437,10 +437,6 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd(const t3d_pointm
   const int tile_m = lin / tiles_n, tile_n = lin % tiles_n;
   const int row0 = tile_m * BM, col0 = tile_n * BN;
   T3D_TRACE_MARK(0);
-#ifdef T3D_STAGGER
-  // diagnostic: the two workgroups that share a CU (b and b + 256 under round-robin dispatch) start half a k-tile apart
-  if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_sleep(T3D_STAGGER);
-#endif
 
   LA la{p.a, p.K, p.rows_per_frustum};
   WLoader lb{p.w, p.N, p.K, p.N};
