@@ -659,6 +659,36 @@ typedef struct {
 } t3d_batch_assemble_args;
 int t3d_batch_assemble(const t3d_batch_assemble_args* args, t3d_stream_t stream);
 
+/* Class-balanced batch composition: `equal_samples_per_class` of ROISemiDataset.sample_from_set (roi_semi_dataset.py:558-567) and
+ * BoxPCFitDataset.sample_batch (box_pc_fit_dataset.py:367-377).  The B slots are split over the n class groups like
+ * np.array_split([1]*B, n) -- B mod n groups get one slot more, WHICH groups is random per step (random.shuffle of the split) --
+ * slots are laid out group after group, and each slot draws a frustum of its group with replacement.  Writes sample[B] (the
+ * frustum index per slot) for t3d_batch_assemble's explicit-sample mode (sample_len = 0).
+ * Two sets = ALTERNATE_BATCH (train_semisup_adv.py:538-565): even steps draw from set[0] (classes with 2-D labels only,
+ * is_data_2D = 1), odd steps from set[1] (is_data_2D = 0). */
+typedef struct {
+  const int32_t* members;        /* frustum indices, grouped by class */
+  const int32_t* offsets;        /* [n_groups + 1] into members; every group non-empty */
+  int n_groups;                  /* 1..32; 0 = set not used */
+  const int32_t* perm;           /* [perm_len] epoch permutation of the set's frustums (the not-balanced batches), or NULL */
+  int perm_len;
+} t3d_class_groups;
+typedef struct {
+  t3d_class_groups set[2];
+  int B;                         /* <= 1024 */
+  uint32_t seed;
+  const float* hyper;            /* device step counter (hyper[0]) */
+  const float* order_draws;      /* [n_groups] keys: the groups with the smallest keys take the larger share; NULL: generated */
+  const float* member_draws;     /* [B] uniforms in [0,1) picking the member; NULL: generated */
+  float equal_prob;              /* *_SAMPLE_EQUAL_CLASS_WITH_PROB: a step is class-balanced when its uniform draw < equal_prob
+                                    (train_semisup.py:357, train_boxpc.py:323-328); otherwise B distinct frustums,
+                                    np.random.choice(len, B, replace=False): slot b takes perm[(steps_of_this_set * B + b) mod perm_len] */
+  const float* prob_draw;        /* [1] that uniform, or NULL (generated) */
+  int32_t* sample;               /* [B] out */
+  int32_t* is_data_2D;           /* [B] out, or NULL */
+} t3d_sample_equal_classes_args;
+int t3d_sample_equal_classes(const t3d_sample_equal_classes_args* args, t3d_stream_t stream);
+
 /* Box-PC Fit training samples (box_pc_fit_dataset.py:105-185 `get`, 211-244 `perturb_box_to_diff_ious`, fed by
  * train_boxpc.py:343-355): each frustum's label box is perturbed until its 3-D IoU with the label box falls strictly inside the
  * "fit" bounds (with probability proportion_fit) or the "no-fit" bounds.  Candidate t of frustum b:

@@ -109,3 +109,17 @@ def boxpc_sample_labels(center, heading, size, cls, is_fit, fit_bounds, nofit_bo
     acls, ares = angle2class(new_heading, NUM_HEADING_BIN)
     return dict(x_center=new_center, x_orient_cls=acls, x_orient_reg=ares, x_dims_cls=cls, x_dims_reg=new_size - MEAN_DIMS_ARR[cls],
                 y_box_iou=iou, y_center_delta=dc, y_dims_delta=ds, y_orient_delta=da, tries=tries)
+
+
+# ---- class-balanced batches -----------------------------------------------------------------------------------------------------
+def sample_equal_per_class(bsize, cls_to_idx, shuffled_split, member_draws):
+    """roi_semi_dataset.py:558-567 / box_pc_fit_dataset.py:367-377.  `cls_to_idx`: list of index lists, one per class key;
+    `shuffled_split`: np.array_split([1]*bsize, n) after random.shuffle (a list of n arrays of ones); `member_draws`: uniforms in
+    [0,1) standing for np.random.choice(list, len(group), replace=True) (index = floor(u * len(list)))."""
+    choices, k = [], 0
+    for i, group in enumerate(shuffled_split):
+        lst = cls_to_idx[i]
+        for _ in range(len(group)):
+            choices.append(lst[min(int(member_draws[k] * len(lst)), len(lst) - 1)])
+            k += 1
+    return choices

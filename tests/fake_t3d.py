@@ -407,6 +407,54 @@ class FakeLib:
                 arr(p.is_data_2D, B)[b] = 1 if (p.sample2 and from_first) else 0
         return 0
 
+    def t3d_sample_equal_classes(self, a, stream):
+        """csrc/data.hip k_sample_equal_classes (the hash generator included)."""
+        p = _struct(a)
+        B = p.B
+        step = int(arr(p.hyper, 1)[0])
+        M64 = (1 << 64) - 1
+
+        def mix(x):
+            x = np.asarray(x, dtype=np.uint64)
+            with np.errstate(over='ignore'):
+                x = x ^ (x >> np.uint64(33)); x = x * np.uint64(0xff51afd7ed558ccd)
+                x = x ^ (x >> np.uint64(33)); x = x * np.uint64(0xc4ceb9fe1a85ec53)
+                x = x ^ (x >> np.uint64(33))
+            return (x >> np.uint64(16)).astype(np.uint32)
+
+        def u01(r):
+            return ((r >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+        two = p.set[1].n_groups > 0
+        which = step % 2 if two else 0
+        g = p.set[which]
+        key = ((((p.seed << 32) ^ ((step * 0x9E3779B97F4A7C15) & M64)) & M64) + 0x632BE59BD9B4E019) & M64
+        flag = 1 if (two and which == 0) else 0
+        pu = arr(p.prob_draw, 1)[0] if p.prob_draw else u01(mix((key + 7) & M64))
+        out = arr(p.sample, B)
+        if not (pu < np.float32(p.equal_prob)):
+            s_set = step // 2 if two else step
+            perm = arr(g.perm, g.perm_len)
+            for b in range(B):
+                out[b] = perm[(s_set * B + b) % g.perm_len]
+        else:
+            n = g.n_groups
+            keys = arr(p.order_draws, n).copy() if p.order_draws else \
+                np.array([u01(mix((key + (i + 1) * 0xA24BAED4963EE407) & M64)) for i in range(n)], np.float32)
+            rank = [sum(1 for j in range(n) if keys[j] < keys[i] or (keys[j] == keys[i] and j < i)) for i in range(n)]
+            sizes = [B // n + (1 if rank[i] < B % n else 0) for i in range(n)]
+            off = arr(g.offsets, n + 1)
+            b = 0
+            for i in range(n):
+                lo, ln = int(off[i]), int(off[i + 1] - off[i])
+                mem = arr(g.members, int(off[n]))
+                for _ in range(sizes[i]):
+                    u = arr(p.member_draws, B)[b] if p.member_draws else u01(mix((key + (b + 1) * 0xD6E8FEB86659FD93) & M64))
+                    out[b] = mem[lo + min(int(np.float32(u) * np.float32(ln)), ln - 1)]
+                    b += 1
+        if p.is_data_2D:
+            arr(p.is_data_2D, B)[:] = flag
+        return 0
+
     @staticmethod
     def perturb_candidate_draws(seed, step, B, max_rounds):
         """The uniforms csrc/data.hip (k_boxpc_perturb) generates: (fit_draw [B], cand_draws [B, max_rounds*64, 7])."""

@@ -246,3 +246,70 @@ def test_frustum_pickle_reader(tmp_path):
     assert np.allclose(ds.points[120:620].numpy(), lists[4][3].astype(np.float32)) and ds.seg[620:].tolist() == lists[5][4].astype(int).tolist()
     all_ds = DeviceFrustumSet.from_pickle(rt, path)
     assert all_ds.F == 5
+
+
+def run_equal_sampler(lib, dev, ds, B, step, seed=5, alternate=False, equal_prob=1.0, order=None, member=None, prob=None):
+    hyper = torch.tensor([float(step), 0, 0, 0], device=dev)
+    out = torch.zeros(B, dtype=torch.int32, device=dev)
+    flag = torch.full((B,), -1, dtype=torch.int32, device=dev)
+    mk = lambda v: None if v is None else torch.as_tensor(np.asarray(v, np.float32)).to(dev)
+    a = ds.sample_equal_args(hyper, B, out, is_data_2D=flag, seed=seed, equal_prob=equal_prob, alternate=alternate, order_draws=mk(order),
+                             member_draws=mk(member), prob_draw=mk(prob))
+    assert lib.t3d_sample_equal_classes(C.byref(a), _stream(isinstance(lib, FakeLib))) == 0
+    if dev != 'cpu':
+        torch.cuda.synchronize()
+    return out.cpu().numpy(), flag.cpu().numpy()
+
+
+def check_equal_class_sampler(rt):
+    """t3d_sample_equal_classes against the oracle's restatement of `equal_samples_per_class` on identical draws, the law of the
+    generated draws, the two-list (ALTERNATE_BATCH) mode and the not-balanced fallback."""
+    lib, dev = rt.lib, rt.device.type if rt.device.type == 'cpu' else 'cuda'
+    host = synthetic_frustums(120, num_channel=4, seed=3, min_points=130, max_points=200)
+    ds = DeviceFrustumSet(rt, **host)
+    cls = host['cls']
+    present = sorted(set(int(c) for c in cls))
+    lists = [np.nonzero(cls == c)[0] for c in present]
+    n = len(present)
+    r = np.random.RandomState(1)
+    for B in (32, 7, 60):
+        order, member = r.uniform(size=n).astype(np.float32), r.uniform(size=B).astype(np.float32)
+        got, flag = run_equal_sampler(lib, dev, ds, B, step=3, order=order, member=member)
+        # the oracle's shuffled np.array_split: the `B % n` groups with the smallest keys are the larger ones
+        rank = np.argsort(np.argsort(order, kind='stable'), kind='stable')
+        split = [np.ones(B // n + (1 if rank[i] < B % n else 0)) for i in range(n)]
+        assert sorted(len(s) for s in split) == sorted(len(s) for s in np.array_split([1] * B, n))
+        want = D.sample_equal_per_class(B, lists, split, member.astype(np.float64))
+        assert got.tolist() == [int(w) for w in want] and (flag == 0).all()
+    # generated draws: every class gets floor(B/n) or ceil(B/n) slots, slots grouped by class, different steps differ
+    B = 32
+    a, _ = run_equal_sampler(lib, dev, ds, B, step=10)
+    b, _ = run_equal_sampler(lib, dev, ds, B, step=11)
+    counts = np.bincount(cls[a], minlength=10)[present]
+    assert counts.min() >= B // n and counts.max() <= B // n + 1 and (np.diff(cls[a]) >= 0).all()
+    assert not np.array_equal(a, b)
+    # over many steps every frustum of a class is drawn about equally often
+    hits = np.zeros(len(cls))
+    for s in range(200):
+        np.add.at(hits, run_equal_sampler(lib, dev, ds, B, step=s)[0], 1)
+    per_class = [hits[l] / hits[l].sum() for l in lists]
+    assert all(np.abs(p - 1.0 / len(p)).max() < 4.0 / np.sqrt(200 * B / n) / np.sqrt(len(p)) + 0.05 for p in per_class)
+    # two lists: even steps from the weak (2-D label) classes with is_data_2D = 1, odd steps from the others with 0
+    weak_ids = [1, 2, 6, 7, 8]
+    ds.split_by_class(weak_ids)
+    e, fe = run_equal_sampler(lib, dev, ds, B, step=4, alternate=True)
+    o, fo = run_equal_sampler(lib, dev, ds, B, step=5, alternate=True)
+    assert np.isin(cls[e], weak_ids).all() and (fe == 1).all() and (~np.isin(cls[o], weak_ids)).all() and (fo == 0).all()
+    # equal_prob = 0: the next B entries of the epoch permutation (B distinct frustums)
+    p0, _ = run_equal_sampler(lib, dev, DeviceFrustumSet(rt, **host), B, step=2, equal_prob=0.0)
+    ds2 = DeviceFrustumSet(rt, **host)
+    p1, _ = run_equal_sampler(lib, dev, ds2, B, step=2, equal_prob=0.0)
+    assert np.array_equal(p0, p1) and len(set(p1.tolist())) == B and np.array_equal(p1, ds2.perm.cpu().numpy()[2 * B:3 * B])
+    # a draw above equal_prob takes the permutation, below it the balanced composition
+    hi, _ = run_equal_sampler(lib, dev, ds2, B, step=2, equal_prob=0.5, prob=[0.7])
+    lo, _ = run_equal_sampler(lib, dev, ds2, B, step=2, equal_prob=0.5, prob=[0.3])
+    assert np.array_equal(hi, p1) and (np.diff(cls[lo]) >= 0).all()
+
+
+def test_equal_samples_per_class_sampler():
+    check_equal_class_sampler(Runtime(device='cpu', lib=FakeLib()))

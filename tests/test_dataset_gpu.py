@@ -53,3 +53,8 @@ def test_boxpc_perturb_generated_draws_equal_the_specification(hip_lib):
     assert np.abs(o['iou'].numpy() - oc['iou'].numpy()).max() < 2e-5
     assert np.abs(o['dc'].numpy() - oc['dc'].numpy()).max() < 1e-6 and np.abs(o['da'].numpy() - oc['da'].numpy()).max() < 1e-6
     assert np.array_equal(t['ocls'].numpy(), tc['ocls'].numpy())
+
+
+def test_equal_samples_per_class_sampler(hip_lib):
+    from test_dataset_cpu import check_equal_class_sampler
+    check_equal_class_sampler(Runtime(lib=hip_lib))

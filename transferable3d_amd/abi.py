@@ -86,6 +86,15 @@ class BoxRefineStepArgs(C.Structure):
                 ('total', F), ('fit_prob', F), ('weigh_by_conf', i32), ('first', i32), ('B', i32)]
 
 
+class ClassGroups(C.Structure):
+    _fields_ = [('members', I), ('offsets', I), ('n_groups', i32), ('perm', I), ('perm_len', i32)]
+
+
+class SampleEqualClassesArgs(C.Structure):
+    _fields_ = [('set', ClassGroups * 2), ('B', i32), ('seed', C.c_uint32), ('hyper', F), ('order_draws', F), ('member_draws', F),
+                ('equal_prob', f32), ('prob_draw', F), ('sample', I), ('is_data_2D', I)]
+
+
 class BoxPcPerturbArgs(C.Structure):
     _fields_ = [('center', F), ('orient_cls', I), ('orient_reg', F), ('dims_cls', I), ('dims_reg', F), ('y_box_iou', F),
                 ('y_center_delta', F), ('y_dims_delta', F), ('y_orient_delta', F), ('center_perturbation', f32),
@@ -237,6 +246,7 @@ ENTRY_POINTS = {
     't3d_batch_assemble': [C.POINTER(BatchAssembleArgs), VP],
     't3d_box_refine_step': [C.POINTER(BoxRefineStepArgs), VP],
     't3d_boxpc_perturb': [C.POINTER(BoxPcPerturbArgs), VP],
+    't3d_sample_equal_classes': [C.POINTER(SampleEqualClassesArgs), VP],
     't3d_box3d_iou': [C.POINTER(Box3dIouArgs), VP],
     't3d_box3d_iou_corners': [C.POINTER(Box3dIouCornersArgs), VP],
     't3d_box_head_iou': [C.POINTER(BoxHeadIouArgs), VP],

@@ -72,6 +72,38 @@ class DeviceFrustumSet:
         for lst, dev in getattr(self, 'subsets', []):
             dev.copy_(torch.as_tensor(lst[r.permutation(len(lst))]))
 
+    def class_groups(self, subset=None):
+        """Per-class index lists of the frustums in `subset` (default: all), cls_to_idx_map of the reference data sets
+        (roi_semi_dataset.py:222-238), on the device for t3d_sample_equal_classes."""
+        cls = self.cls.cpu().numpy()
+        idx = np.arange(self.F, dtype=np.int32) if subset is None else np.asarray(subset, np.int32)
+        present = sorted(set(int(c) for c in cls[idx]))
+        members = np.concatenate([idx[cls[idx] == c] for c in present]).astype(np.int32)
+        offsets = np.concatenate([[0], np.cumsum([int((cls[idx] == c).sum()) for c in present])]).astype(np.int32)
+        dev = self.rt.device
+        t = (torch.as_tensor(members).to(dev), torch.as_tensor(offsets).to(dev), len(present))
+        self.rt.allocs.extend(t[:2])
+        return t
+
+    def sample_equal_args(self, hyper, B, sample_out, is_data_2D=None, seed=0, equal_prob=1.0, alternate=False, order_draws=None,
+                          member_draws=None, prob_draw=None):
+        """Argument struct of t3d_sample_equal_classes writing the frustum index of every batch slot into `sample_out` [B]."""
+        a = abi.SampleEqualClassesArgs()
+        if alternate:
+            sets = [(lst, dev) for lst, dev in self.subsets]
+        else:
+            sets = [(None, self.perm)]
+        keep = []
+        for i, (lst, perm) in enumerate(sets):
+            m, o, n = self.class_groups(lst)
+            a.set[i] = abi.ClassGroups(iptr(m), iptr(o), n, iptr(perm), int(perm.numel()))
+            keep += [m, o]
+        a.B, a.seed, a.hyper = B, seed, fptr(hyper)
+        a.order_draws, a.member_draws, a.equal_prob, a.prob_draw = fptr(order_draws), fptr(member_draws), float(equal_prob), fptr(prob_draw)
+        a.sample, a.is_data_2D = iptr(sample_out), iptr(is_data_2D)
+        a._keep = (keep, order_draws, member_draws, prob_draw, sample_out)
+        return a
+
     def split_by_class(self, classes_2d):
         """ALTERNATE_BATCH sampling (train_semisup_adv.py:538-565): the frustums of `classes_2d` (class ids whose 3-D labels
         are withheld, SUNRGBD_SEMI_TEST_CLS) form the weak list, the rest the strong list; each is walked in its own shuffled

@@ -68,6 +68,20 @@ class Graph:
     def emit_batch_assemble(self, plan, dataset, inputs, seed=0, **aug):
         """The input pipeline as a launch of the step: batch slot b of step s takes frustum perm[(s*B + b) % F] of the
         HBM-resident data set (dataset.DeviceFrustumSet) -- recorded before the schedule kernel advances the step counter."""
+        equal_prob = aug.pop('equal_class_prob', 0.0)
+        if equal_prob > 0.0:
+            # class-balanced composition (equal_samples_per_class): a sampler launch writes the frustum index of every slot, the
+            # assembly then runs in its explicit-sample mode
+            slots = self.rt.zeros(self.B, dtype=torch.int32)
+            alternate = bool(aug.pop('alternate', False))
+            plan.add('t3d_sample_equal_classes', dataset.sample_equal_args(
+                self.hyper, self.B, slots, is_data_2D=inputs.is_data_2D if alternate else None, seed=seed ^ 0x2545F491,
+                equal_prob=equal_prob, alternate=alternate))
+            a = dataset.assemble_args(inputs, self.hyper, self.B, self.rpf, self.C, seed=seed, sample=slots, **aug)
+            if alternate:
+                a.is_data_2D = iptr(None)          # the sampler launch knows which list the step drew from
+            plan.add('t3d_batch_assemble', a)
+            return
         a = dataset.assemble_args(inputs, self.hyper, self.B, self.rpf, self.C, seed=seed, **aug)
         plan.add('t3d_batch_assemble', a)
 

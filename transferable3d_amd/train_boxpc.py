@@ -72,7 +72,10 @@ def train(FLAGS, rt=None, log=print):
         if FLAGS.device_data:
             from transferable3d_amd.dataset import DeviceFrustumSet
             ds = DeviceFrustumSet.synthetic(g.rt, FLAGS.device_data, num_channel=max(C, 6), seed=FLAGS.seed)
-            g.use_device_dataset(ds, seed=FLAGS.seed * 7919, boxpc_perturb=FLAGS)
+            # BOXPC_SAMPLING_METHOD 'SAMPLE': class-balanced batches with probability BOXPC_SAMPLE_EQUAL_CLASS_WITH_PROB
+            # (train_boxpc.py:323-328); 'BATCH': the epoch permutation
+            eq = float(FLAGS.BOXPC_SAMPLE_EQUAL_CLASS_WITH_PROB) if FLAGS.BOXPC_SAMPLING_METHOD == 'SAMPLE' else 0.0
+            g.use_device_dataset(ds, seed=FLAGS.seed * 7919, boxpc_perturb=FLAGS, equal_class_prob=eq)
         for epoch in range(FLAGS.max_epoch):
             t0, loss_sum = time.time(), 0.0
             if ds is not None:

@@ -109,7 +109,8 @@ def train(FLAGS, rt=None, log=print):
             ds = DeviceFrustumSet.synthetic(g.rt, FLAGS.device_data, num_channel=max(C, 6), seed=FLAGS.seed)
             if iters == 2:
                 ds.split_by_class(test_ids)
-            g.use_device_dataset(ds, seed=FLAGS.seed * 7919, alternate=(iters == 2))
+            g.use_device_dataset(ds, seed=FLAGS.seed * 7919, alternate=(iters == 2),
+                                 equal_class_prob=float(FLAGS.SEMI_SAMPLE_EQUAL_CLASS_WITH_PROB))   # train_semisup_adv.py:557,573
         for epoch in range(FLAGS.max_epoch):
             t0, loss_sum = time.time(), 0.0
             if ds is not None:
