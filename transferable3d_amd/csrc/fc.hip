@@ -20,6 +20,13 @@ constexpr int NTH = NW * 64;
 constexpr int RG = NTH / 32; // row groups of the epilogue thread map
 constexpr int LDT = 33;      // padded row stride of the LDS tiles
 
+#ifdef T3D_TRACE             // diagnostic builds: per-workgroup phase clock (tools/trace_fc.py)
+__device__ unsigned long long* t3d_trace_fc_ptr = nullptr;
+#define FC_MARK(slot) do { if (threadIdx.x == 0 && t3d_trace_fc_ptr) t3d_trace_fc_ptr[(size_t)blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define FC_MARK(slot) do {} while (0)
+#endif
+
 struct RowSrc {              // [in | in2] row-concatenated input, B valid rows
   const float* in; int ld_in; int K;
   const float* in2; int ld_in2; int K2;
@@ -69,13 +76,18 @@ __device__ __forceinline__ void wave_gemm(f32x16 (&acc)[RBT], const RowSrc& src,
     for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
   const int ngroups = (Kred + 7) >> 3;
   const bool cok = l31 < ncols;
-  for (int g0 = wave; g0 < ngroups; g0 += GIF * NW) {
+  // every wave owns a CONTIGUOUS run of k-groups: the four loads that share a 128-byte line of an input row (32 reduction
+  // elements) are then issued back to back by one wave and hit the line while it is in flight; with the groups dealt out round
+  // robin over the waves each line was fetched by four different waves (load + MFMA phase of the 512x512 layer 7.2 -> 6.2 us,
+  // tools/trace_fc.py)
+  const int gpw = (ngroups + NW - 1) / NW, gbeg = wave * gpw, gend = min(gbeg + gpw, ngroups);
+  for (int g0 = gbeg; g0 < gend; g0 += GIF) {
     float a[GIF][RBT][4], b[GIF][4];
 #pragma unroll
     for (int u = 0; u < GIF; ++u) {
-      const int g = g0 + u * NW;
+      const int g = g0 + u;
       const int k = 8 * g + 4 * h;
-      if (g < ngroups) {                      // wave-uniform: groups past the end issue nothing
+      if (g < gend) {                         // wave-uniform: groups past the end issue nothing
 #pragma unroll
         for (int rb = 0; rb < RBT; ++rb) src.load4(rb * 32 + l31, k, a[u][rb]);
         if (!WT) {
@@ -94,7 +106,7 @@ __device__ __forceinline__ void wave_gemm(f32x16 (&acc)[RBT], const RowSrc& src,
     }
 #pragma unroll
     for (int u = 0; u < GIF; ++u) {
-      if (g0 + u * NW < ngroups) {
+      if (g0 + u < gend) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -173,11 +185,14 @@ __global__ __launch_bounds__(NTH) void k_fc_fwd(const t3d_fc_fwd_args p) {
   const int nvalid = min(CB, p.N - c0);
   const bool cok = c < p.N;
 
+  FC_MARK(0);
   f32x16 acc[RBT];
   RowSrc src{p.in, p.ld_in, p.K, p.in2, p.ld_in2, p.K2, p.B};
   wave_gemm<false, RBT>(acc, src, p.w, p.N, p.K + p.K2, c0, nvalid, wave, lane);
+  FC_MARK(1);
   float y[NVAL];
   reduce_tiles<RBT>(acc, sm, y);
+  FC_MARK(2);
 
   const float bias = (cok && p.bias) ? p.bias[c] : 0.f;
   float part = 0.f;
@@ -210,6 +225,7 @@ __global__ __launch_bounds__(NTH) void k_fc_fwd(const t3d_fc_fwd_args p) {
     }
     if (cok && rg == 0) { p.mean[c] = mean; p.invstd[c] = invstd; }
   }
+  FC_MARK(3);
   if (!cok) return;
   const float inv_keep = p.drop_mask ? 1.0f / p.keep_prob : 1.f;
 #pragma unroll
@@ -225,6 +241,7 @@ __global__ __launch_bounds__(NTH) void k_fc_fwd(const t3d_fc_fwd_args p) {
       p.out[(size_t)r * p.ld_out + c] = z;
     }
   }
+  FC_MARK(4);
 }
 
 template <int RBT>
@@ -463,3 +480,10 @@ extern "C" int t3d_fc_dinput(const t3d_fc_dinput_args* a, t3d_stream_t stream) {
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
+
+#ifdef T3D_TRACE
+extern "C" int t3d_set_trace_fc(void* buf) {
+  unsigned long long* p = static_cast<unsigned long long*>(buf);
+  return hipMemcpyToSymbol(HIP_SYMBOL(t3d_trace_fc_ptr), &p, sizeof(p)) == hipSuccess ? T3D_OK : T3D_ERR_LAUNCH;
+}
+#endif
