@@ -199,6 +199,7 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback on the product path)'
+    local_rank %= torch.cuda.device_count()      # (T3D_DIST_BACKEND=gloo runs: several ranks may share the one GPU of a test box)
     torch.cuda.set_device(local_rank)
     dist = None
     # T3D_FORCE_DIST=1: take the multi-rank code path (RCCL init, all-reduce between the two graphs) with a single rank, so
@@ -214,7 +215,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        backend = os.environ.get('T3D_DIST_BACKEND', 'nccl')       # 'gloo': the multi-rank flow on a box with fewer GPUs than ranks
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from transferable3d_amd.config import make_parser
     from transferable3d_amd.engine import Runtime, Plan
