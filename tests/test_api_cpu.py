@@ -193,3 +193,47 @@ def test_stage_c_reference_call_sequence_with_var_list():
     frozen = [k for k in moved if k.startswith('D_boxpc_branch') or (k.startswith('class_agnostic/inst_seg') and 'moving' not in k)]
     assert not frozen, frozen[:4]
     assert any(k.startswith('class_agnostic/inst_seg') and 'moving_mean' in k for k in moved)      # seg EMA still updates
+
+
+def test_is_training_placeholder_selects_train_and_eval_schedules_of_one_graph():
+    """train_semisup.py:210: `is_training_pl = tf.placeholder(tf.bool, shape=())` fed True for the training step and False in
+    eval_one_epoch.  One graph, one set of variables: the eval run uses the moving statistics the training step just updated,
+    matches the oracle's inference-mode forward, and changes nothing."""
+    B, N, C = 4, 128, 4
+    FLAGS = _flags()
+    batch = make_batch(B, N, C, seed=8, dropout_scopes={'inst_seg/dp1': ((B, N, 128), 0.5)})
+    held_out = make_batch(B, N, C, seed=9)
+    with api.Graph(rt=Runtime(device='cpu', lib=FakeLib()), seed=3).as_default() as g:
+        pls = MODEL.placeholder_inputs(B, N, C)
+        pc_pl, bg_pc_pl, img_pl, one_hot_vec_pl, y_seg_pl, y_centers_pl, y_orient_cls_pl, y_orient_reg_pl, y_dims_cls_pl, \
+            y_dims_reg_pl, R0_rect_pl, P_pl, Rtilt_pl, K_pl, rot_frust_pl, box2D_pl, img_dim_pl, is_data_2D_pl = pls
+        is_training_pl = api.is_training_placeholder()
+        pred, end_points = MODEL.get_semi_model(pc_pl, bg_pc_pl, img_pl, one_hot_vec_pl, is_training_pl, use_one_hot=False,
+                                                norm_box2D=None, bn_decay=None, c=FLAGS)
+        labels = (y_seg_pl, y_centers_pl, y_orient_cls_pl, y_orient_reg_pl, y_dims_cls_pl, y_dims_reg_pl, R0_rect_pl, P_pl,
+                  Rtilt_pl, K_pl, rot_frust_pl, box2D_pl, img_dim_pl, is_data_2D_pl)
+        semi_loss = MODEL.get_semi_loss(pred, labels, end_points, c=FLAGS)
+        train_op = api.AdamOptimizer(1e-3).minimize(semi_loss)
+        sess = api.Session()
+
+        def feed_of(b, training):
+            return {pc_pl: b['pc'], one_hot_vec_pl: b['one_hot_vec'], y_seg_pl: b['y_seg'], y_centers_pl: b['y_center'],
+                    y_orient_cls_pl: b['y_orient_cls'], y_orient_reg_pl: b['y_orient_reg'], y_dims_cls_pl: b['y_dims_cls'],
+                    y_dims_reg_pl: b['y_dims_reg'], is_data_2D_pl: b['is_data_2D'], is_training_pl: training}
+        with pytest.raises(ValueError):                       # TF: "You must feed a value for placeholder tensor"
+            sess.run([semi_loss], feed_dict={k: v for k, v in feed_of(held_out, False).items() if k is not is_training_pl})
+        f = feed_of(batch, True)
+        f['inst_seg/dp1'] = batch['dropout_masks']['inst_seg/dp1']
+        sess.run([semi_loss, train_op], feed_dict=f)
+        P1 = {k: torch.tensor(v, dtype=torch.float64) for k, v in g.vars.state_dict().items()}
+        step_after_train = float(g.engine.hyper[0])
+        loss_eval, logits_eval, i3 = sess.run([semi_loss, pred[0], end_points['iou3ds']], feed_dict=feed_of(held_out, False))
+        P2 = g.vars.state_dict()
+        # nothing moved: no parameter update, no EMA update, no step
+        assert all(np.array_equal(P2[k], P1[k].numpy().astype(np.float32)) for k in P2) and float(g.engine.hyper[0]) == step_after_train
+        loss_ref, ep, _, _ = R.model_a_forward_backward(P1, held_out, R.default_config(), is_training=False, want_grads=False)
+        assert np.abs(logits_eval - ep['logits'].detach().numpy()).max() < 1e-4
+        assert abs(float(loss_eval) - float(loss_ref)) < 1e-4 * max(1.0, float(loss_ref))
+        # ... and a training step afterwards still works (its schedule was compiled first)
+        sess.run([semi_loss, train_op], feed_dict=f)
+        assert float(g.engine.hyper[0]) == step_after_train + 1

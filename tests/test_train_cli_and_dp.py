@@ -172,3 +172,27 @@ def test_train_boxpc_from_a_device_resident_dataset(tmp_path):
     assert len(ep) == 2 and 'samples made on the device' in ep[0]
     l0, l1 = [float(l.split('mean loss: ')[1].split()[0]) for l in ep]
     assert np.isfinite(l0) and np.isfinite(l1) and 0 < l1 < 20
+
+
+def test_cli_evaluates_after_every_epoch_in_the_training_graph(tmp_path):
+    """--eval_batches: eval_one_epoch (train_semisup.py:436-545) on held-out frustums with is_training fed False."""
+    logs = []
+    flags = build_flags(['--SEMI_MODEL', 'A', '--WEAK_WEIGHT_REPROJECTION', '0', '--WEAK_WEIGHT_SURFACE', '0', '--num_point', '128',
+                         '--batch_size', '4', '--num_channels', '4', '--max_epoch', '2', '--steps_per_epoch', '3', '--synthetic',
+                         '--eval_batches', '2', '--log_dir', str(tmp_path)])
+    train(flags, rt=Runtime(device='cpu', lib=FakeLib()), log=logs.append)
+    ev = [l for l in logs if str(l).startswith('eval ')]
+    assert len(ev) == 10 and sum('EVALUATION' in str(l) for l in logs) == 2
+    acc = [float(l.split(': ')[1]) for l in ev if l.startswith('eval accuracy')]
+    assert all(0.0 <= a <= 1.0 for a in acc) and all(np.isfinite(float(l.split(': ')[1].split()[0])) for l in ev if 'mean loss' in l)
+
+
+def test_cli_evaluates_on_device_assembled_held_out_frustums(tmp_path):
+    logs = []
+    flags = build_flags(['--SEMI_MODEL', 'A', '--WEAK_WEIGHT_REPROJECTION', '0', '--WEAK_WEIGHT_SURFACE', '0', '--num_point', '128',
+                         '--batch_size', '4', '--num_channels', '4', '--max_epoch', '1', '--steps_per_epoch', '4', '--device_data', '16',
+                         '--eval_batches', '2', '--log_dir', str(tmp_path)])
+    train(flags, rt=Runtime(device='cpu', lib=FakeLib()), log=logs.append)
+    ev = {l.split(':')[0]: l for l in logs if str(l).startswith('eval ')}
+    assert sorted(ev) == ['eval accuracy', 'eval avg class acc', 'eval box IoU (ground/3D)     ', 'eval mIoU', 'eval mean loss']
+    assert np.isfinite(float(ev['eval mean loss'].split(': ')[1]))

@@ -15,8 +15,10 @@ sub-networks exist and allocate their HBM buffers; the fused launch schedule is 
 `Session.run`, pruned by what is fetched (a fetch list without the train op compiles the forward-only plan,
 exactly like TF prunes its graph), and on the GPU the schedule is captured into a hipGraph and replayed.
 
-Deviation (documented in DESIGN.md): `is_training` must be a Python bool at build time -- build a second
-graph that shares the variable store for evaluation, as TF code does with `reuse=True`.
+`is_training` may be a Python bool, or -- as in the reference (train_semisup.py:210 `is_training_pl = tf.placeholder(tf.bool,
+shape=())`) -- a placeholder made by `is_training_placeholder()` and fed per `Session.run`: the session keeps one launch schedule
+per (train op fetched?, is_training) combination (batch statistics + EMA update + dropout vs moving statistics), all over the same
+variables and buffers, so `eval_one_epoch` runs in the graph that trains.
 """
 import contextlib
 
@@ -132,6 +134,21 @@ def reset_default_graph():
     del _stack[:]
 
 
+class BoolPlaceholder(Placeholder):
+    """`tf.placeholder(tf.bool, shape=())` for is_training: truthy at build time (graphs are assembled in their training form), its
+    fed value picks the schedule at run time."""
+
+    def __init__(self, ctx, name='is_training'):
+        Placeholder.__init__(self, ctx, None, (), name, field=None)
+
+    def __bool__(self):
+        return True
+
+
+def is_training_placeholder(name='is_training'):
+    return BoolPlaceholder(get_default_graph(), name)
+
+
 def placeholder(field, shape, dtype=torch.float32, name=None):
     g = get_default_graph()
     buf = getattr(g.inputs, field, None) if field else None
@@ -175,16 +192,20 @@ class Session:
         self.steps = {}
 
     # -- compilation ------------------------------------------------------------------------------------
-    def _compile(self, train):
-        key = 'train' if train else 'infer'
+    def _compile(self, train, is_training=None):
+        g, e = self.g, self.g.engine
+        if is_training is None or not isinstance(g.is_training, BoolPlaceholder):
+            is_training = bool(g.is_training)
+        key = ('train' if train else 'infer') + ('' if is_training else '_eval')
         if key in self.steps:
             return self.steps[key]
         from .engine import Plan
-        g, e = self.g, self.g.engine
-        assert not e.finalized or key in g.compiled, 'graph already finalised: build train and eval graphs separately'
+        # the training schedule reserves the weight-gradient slabs: it is compiled first, whatever is run first
+        if not train and g.train_op is not None and not e.finalized:
+            self._compile(True, True)
+        assert not (train and e.finalized), 'the training step must be compiled before any forward-only schedule of the graph'
         asm = g.assembly
         pre, fwd, bwd, opt = Plan(e.rt), Plan(e.rt), Plan(e.rt), Plan(e.rt)
-        is_training = bool(g.is_training)
         with_loss = g.loss is not None
         if train:
             top = g.train_op
@@ -202,7 +223,8 @@ class Session:
             o = g.optimizer
             world = self.pg.size() if self.pg is not None else 1
             e.emit_adam(opt, prefixes=top.var_prefixes, beta1=o.b1, beta2=o.b2, eps=o.eps, grad_scale=1.0 / world)
-        e.finalize()
+        if not e.finalized:
+            e.finalize()
         step = _Step(self, pre, fwd, bwd, opt, train)
         self.steps[key] = step
         g.compiled[key] = True
@@ -213,15 +235,22 @@ class Session:
         flist = [fetches] if single else list(fetches)
         train = any(isinstance(f, TrainOp) for f in flist)
         batch, masks = {}, {}
+        mode = None
         for pl, val in (feed_dict or {}).items():
-            if isinstance(pl, Placeholder):
+            if isinstance(pl, BoolPlaceholder):
+                mode = bool(val)
+            elif isinstance(pl, Placeholder):
                 if pl.field is not None:
                     batch[pl.field] = np.asarray(val)
             elif isinstance(pl, str):                      # dropout-mask injection for parity tests: scope -> mask
                 masks[pl] = np.asarray(val)
         if masks:
             batch['dropout_masks'] = masks
-        step = self._compile(train)
+        if isinstance(self.g.is_training, BoolPlaceholder) and mode is None:
+            if not train:
+                raise ValueError('You must feed a value for placeholder tensor %r' % self.g.is_training.name)
+            mode = True
+        step = self._compile(train, mode)
         self.g.inputs.load(batch)
         step.run(skip_mask_generation=bool(masks))
         out = []

@@ -21,7 +21,7 @@ def v1_inst_seg(point_cloud, img_feats, one_hot_vec, end_points, is_training, bn
     ctx = point_cloud.ctx
     asm = _asm(ctx, one_hot_vec is not None)
     asm.seg = InstSegNet(ctx.engine, scope, one_hot_vec is not None)
-    ctx.is_training = bool(is_training)
+    ctx.is_training = is_training if isinstance(is_training, api.BoolPlaceholder) else bool(is_training)
     e = ctx.engine
     logits = api.Tensor(ctx, asm.seg.logits, (e.B, e.rpf, 2), scope + '/logits', producer=asm.seg)
     end_points['seg_global_feat'] = api.Tensor(ctx, asm.seg.L5.pooled, (e.B, 1024), scope + '/global_feat')
@@ -155,7 +155,7 @@ def box_pc_mask_features_model(box, pc, logits, num_outputs, is_training, end_po
         raise NotImplementedError('a GT box enters through convert_raw_y_box_to_reg_format (train_boxpc.py:233); a predicted box '
                                   'enters inside SEMI_MODEL F (get_semi_model_final), which owns its own frozen Box-PC branch')
     ctx.assembly = BoxPCModel(e, c, one_hot_vec is not None, inputs=ctx.inputs)
-    ctx.is_training = bool(is_training)
+    ctx.is_training = is_training if isinstance(is_training, api.BoolPlaceholder) else bool(is_training)
     if isinstance(bn_decay, (int, float)):
         e.hyper[2] = float(bn_decay)
     net = ctx.assembly.net

@@ -52,7 +52,7 @@ def get_semi_model_final(pc, bg_pc, img, one_hot_vec, is_training, use_one_hot, 
     train_classes = getattr(c, 'intraclsdims_train_classes', None)
     m = SemiModelF(e, c, use_one_hot=use_one_hot, train_classes=train_classes, inputs=ctx.inputs)
     ctx.assembly = m
-    ctx.is_training = bool(is_training)
+    ctx.is_training = is_training if isinstance(is_training, api.BoolPlaceholder) else bool(is_training)
     B, N = e.B, e.rpf
     T = lambda buf, shape, name: api.Tensor(ctx, buf, shape, name)
     logits = T(m.seg.logits, (B, N, 2), 'logits')

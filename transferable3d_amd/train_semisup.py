@@ -59,9 +59,83 @@ def build_flags(argv=None):
                      help='keep a synthetic data set of F ragged frustums in HBM and assemble every batch on the device '
                           '(t3d_batch_assemble: resample / centre-view rotation / flip / shift / labels)')
     cfg.add_argument('--seed', type=int, default=0)
+    cfg.add_argument('--eval_batches', type=int, default=0, help='held-out synthetic batches evaluated after every epoch (eval_one_epoch)')
     FLAGS = cfg.parse_special_args(argv)
     FLAGS.NUM_CHANNELS = FLAGS.num_channels if FLAGS.num_channels else (3 if FLAGS.no_rgb else 6)
     return FLAGS
+
+
+class DeviceEvalSource:
+    """Held-out frustums from the generator of the training set, resident in HBM; batch i = frustums [i*B, (i+1)*B) assembled by
+    t3d_batch_assemble without augmentation (the reference's TEST_DATASET: random_flip / random_shift off)."""
+
+    def __init__(self, g, FLAGS, n_frustums, seed):
+        from transferable3d_amd.dataset import DeviceFrustumSet
+        from transferable3d_amd.engine import Plan
+        e = g.engine
+        self.g, self.B = g, e.B
+        self.ds = DeviceFrustumSet.synthetic(g.rt, n_frustums, num_channel=max(e.C, 6), seed=seed)
+        self.ds.perm.copy_(torch_arange(n_frustums))
+        self.counter = g.rt.zeros(4)
+        self.plan = Plan(g.rt)
+        self.plan.add('t3d_batch_assemble', self.ds.assemble_args(g.inputs, self.counter, e.B, e.rpf, e.C, seed=seed, random_flip=False,
+                                                                 random_shift=False))
+
+    def load(self, i):
+        self.counter[0] = float(i)
+        self.plan.run()
+        return self.g.inputs.y_seg.view(self.B, -1).cpu().numpy()
+
+
+def torch_arange(n):
+    import torch
+    return torch.arange(n, dtype=torch.int32)
+
+
+def eval_one_epoch(sess, ops, FLAGS, epoch, log, source=None):
+    """train_semisup.py:436-545 on held-out synthetic frustums: the SAME graph with is_training fed False (moving batch-norm
+    statistics, no dropout, no parameter or EMA update) -- loss, segmentation accuracy / class accuracy / IoU, box IoU."""
+    pls, is_training_pl, semi_loss, n_correct, end_points = ops
+    pc_pl, _, _, one_hot_vec_pl, y_seg_pl, y_centers_pl, y_orient_cls_pl, y_orient_reg_pl, y_dims_cls_pl, y_dims_reg_pl = pls[:10]
+    is_data_2D_pl = pls[-1]
+    B, N, C = FLAGS.batch_size, FLAGS.num_point, FLAGS.NUM_CHANNELS
+    log('---- EPOCH %03d EVALUATION ----' % epoch)
+    loss_sum = iou2 = iou3 = 0.0
+    seen, correct = np.zeros(2), np.zeros(2)
+    shape_ious = []
+    for i in range(FLAGS.eval_batches):
+        if source is not None:                               # batch assembled on the device: nothing but the mode is fed
+            lab = source.load(i)
+            feed = {is_training_pl: False}
+        else:
+            b = make_batch(B, N, C, seed=FLAGS.seed * 1000003 + 900000 + i)
+            lab = b['y_seg']
+            feed = {pc_pl: b['pc'], one_hot_vec_pl: b['one_hot_vec'], y_seg_pl: b['y_seg'], y_centers_pl: b['y_center'],
+                    y_orient_cls_pl: b['y_orient_cls'], y_orient_reg_pl: b['y_orient_reg'], y_dims_cls_pl: b['y_dims_cls'],
+                    y_dims_reg_pl: b['y_dims_reg'], is_data_2D_pl: np.zeros(B, np.int32), is_training_pl: False}
+        loss_val, logits, i2, i3 = sess.run([semi_loss, end_points_logits(end_points, sess), end_points['iou2ds'], end_points['iou3ds']],
+                                            feed_dict=feed)
+        pred = np.argmax(logits, 2)
+        loss_sum += float(loss_val)
+        iou2, iou3 = iou2 + float(np.sum(i2)), iou3 + float(np.sum(i3))
+        for l in range(2):
+            seen[l] += np.sum(lab == l)
+            correct[l] += np.sum((pred == l) & (lab == l))
+        for k in range(B):                                   # per-frustum part IoU; an absent part that is not predicted counts 1
+            shape_ious.append([1.0 if not (np.any(lab[k] == l) or np.any(pred[k] == l)) else
+                               np.sum((lab[k] == l) & (pred[k] == l)) / float(np.sum((lab[k] == l) | (pred[k] == l))) for l in range(2)])
+    n = float(FLAGS.eval_batches)
+    log('eval mean loss: %f' % (loss_sum / n))
+    log('eval accuracy: %f' % (correct.sum() / seen.sum()))
+    log('eval avg class acc: %f' % np.mean(correct / np.maximum(seen, 1)))
+    log('eval mIoU: %f' % np.mean(shape_ious))
+    log('eval box IoU (ground/3D)     : %f / %f' % (iou2 / (n * B), iou3 / (n * B)))
+    return loss_sum / n
+
+
+def end_points_logits(end_points, sess):
+    g = sess.g
+    return api.Tensor(g, g.assembly.seg.logits, (g.engine.B, g.engine.rpf, 2), 'logits')
 
 
 def train(FLAGS, rt=None, log=print):
@@ -89,7 +163,8 @@ def train(FLAGS, rt=None, log=print):
         pls = MODEL.placeholder_inputs(B, N, C)
         pc_pl, bg_pc_pl, img_pl, one_hot_vec_pl, y_seg_pl, y_centers_pl, y_orient_cls_pl, y_orient_reg_pl, y_dims_cls_pl, \
             y_dims_reg_pl, R0_rect_pl, P_pl, Rtilt_pl, K_pl, rot_frust_pl, box2D_pl, img_dim_pl, is_data_2D_pl = pls
-        pred, end_points = MODEL.get_semi_model(pc_pl, bg_pc_pl, img_pl, one_hot_vec_pl, True, use_one_hot=FLAGS.use_one_hot,
+        is_training_pl = api.is_training_placeholder()                     # train_semisup.py:210
+        pred, end_points = MODEL.get_semi_model(pc_pl, bg_pc_pl, img_pl, one_hot_vec_pl, is_training_pl, use_one_hot=FLAGS.use_one_hot,
                                                 norm_box2D=None, bn_decay=None, c=FLAGS)
         labels = (y_seg_pl, y_centers_pl, y_orient_cls_pl, y_orient_reg_pl, y_dims_cls_pl, y_dims_reg_pl, R0_rect_pl, P_pl,
                   Rtilt_pl, K_pl, rot_frust_pl, box2D_pl, img_dim_pl, is_data_2D_pl)
@@ -102,7 +177,7 @@ def train(FLAGS, rt=None, log=print):
             restore_model(g, FLAGS.restore_model_path)
         n_correct = api.Tensor(g, g.assembly.seg.n_correct, (1,), 'n_correct')
         step = 0
-        ds = None
+        ds = eval_source = None
         if FLAGS.device_data:
             from transferable3d_amd.dataset import DeviceFrustumSet
             ds = DeviceFrustumSet.synthetic(g.rt, FLAGS.device_data, num_channel=max(C, 6), seed=FLAGS.seed + 17 * rank)
@@ -137,6 +212,7 @@ def train(FLAGS, rt=None, log=print):
                         y_centers_pl: batch['y_center'], y_orient_cls_pl: batch['y_orient_cls'],
                         y_orient_reg_pl: batch['y_orient_reg'], y_dims_cls_pl: batch['y_dims_cls'],
                         y_dims_reg_pl: batch['y_dims_reg'], is_data_2D_pl: batch['is_data_2D']}
+                feed[is_training_pl] = True
                 loss_val, nc, i2, i3, _ = sess.run([semi_loss, n_correct, iou2ds, iou3ds, train_op], feed_dict=feed)
                 loss_sum += float(loss_val)
                 correct += float(nc[0])
@@ -147,6 +223,10 @@ def train(FLAGS, rt=None, log=print):
                     epoch, loss_sum / FLAGS.steps_per_epoch, correct / (FLAGS.steps_per_epoch * B * N),
                     FLAGS.steps_per_epoch * B * world / (time.time() - t0)))
                 log('Strong Box IoU (ground/3D): %f / %f' % (iou2_sum / (FLAGS.steps_per_epoch * B), iou3_sum / (FLAGS.steps_per_epoch * B)))
+            if rank == 0 and FLAGS.eval_batches > 0:
+                if ds is not None and eval_source is None:
+                    eval_source = DeviceEvalSource(g, FLAGS, FLAGS.eval_batches * B, FLAGS.seed + 424243)
+                eval_one_epoch(sess, (pls, is_training_pl, semi_loss, n_correct, end_points), FLAGS, epoch, log, eval_source)
             if rank == 0:
                 if epoch % 5 == 0:                       # train_semisup.py:316-318
                     path = save_model(FLAGS.log_dir, epoch, g, FLAGS.ckpt_format)
