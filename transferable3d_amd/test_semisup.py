@@ -75,6 +75,16 @@ def softmax(x):
     return probs
 
 
+def detection_scores(logits, heading_logits, size_logits, fit_prob=None):
+    """test_semisup.py:238-252: log(mean mask probability + .01) + log(max heading prob + .01) + log(max size prob + .01)
+    [+ log(fit prob + .01)] per frustum."""
+    seg_prob = softmax(logits)[:, :, 1]
+    seg_mask = np.argmax(logits, 2)
+    mask_mean_prob = np.sum(seg_prob * seg_mask, 1) / (np.sum(seg_mask, 1) + 1)
+    s = np.log(mask_mean_prob + 0.01) + np.log(np.max(softmax(heading_logits), 1) + 0.01) + np.log(np.max(softmax(size_logits), 1) + 0.01)
+    return s if fit_prob is None else s + np.log(fit_prob + 0.01)
+
+
 def inference(sess, ops, pc, one_hot_vec, batch_size, prefix='', use_boxpc_fit_prob=False):
     """test_semisup.py:188-262, same return tuple: (pred_seg, centers, orient_cls, orient_reg, dims_cls, dims_reg, scores)."""
     assert pc.shape[0] % batch_size == 0
@@ -93,15 +103,7 @@ def inference(sess, ops, pc, one_hot_vec, batch_size, prefix='', use_boxpc_fit_p
             run_ops.append(ep['boxpc_fit_prob'])
         out = sess.run(run_ops, feed_dict={ops['pc_pl']: pc[sl], ops['one_hot_vec_pl']: one_hot_vec[sl]})
         logits[sl], centers[sl], heading_logits[sl], heading_residuals[sl], size_logits[sl], size_residuals[sl] = out[:6]
-        seg_prob = softmax(out[0])[:, :, 1]
-        seg_mask = np.argmax(out[0], 2)
-        mask_mean_prob = np.sum(seg_prob * seg_mask, 1) / (np.sum(seg_mask, 1) + 1)
-        heading_prob = np.max(softmax(out[2]), 1)
-        size_prob = np.max(softmax(out[4]), 1)
-        s = np.log(mask_mean_prob + 0.01) + np.log(heading_prob + 0.01) + np.log(size_prob + 0.01)
-        if use_boxpc_fit_prob:
-            s = s + np.log(out[6] + 0.01)
-        scores[sl] = s
+        scores[sl] = detection_scores(out[0], out[2], out[4], out[6] if use_boxpc_fit_prob else None)
     heading_cls, size_cls = np.argmax(heading_logits, 1), np.argmax(size_logits, 1)
     pred_orient_reg = heading_residuals[np.arange(n), heading_cls]
     pred_dims_reg = size_residuals[np.arange(n), size_cls, :]

@@ -99,6 +99,11 @@ def eval_one_epoch(sess, ops, FLAGS, epoch, log, source=None):
     pc_pl, _, _, one_hot_vec_pl, y_seg_pl, y_centers_pl, y_orient_cls_pl, y_orient_reg_pl, y_dims_cls_pl, y_dims_reg_pl = pls[:10]
     is_data_2D_pl = pls[-1]
     B, N, C = FLAGS.batch_size, FLAGS.num_point, FLAGS.NUM_CHANNELS
+    from transferable3d_amd.constants import MEAN_DIMS_ARR, NUM_HEADING_BIN, class2type
+    from transferable3d_amd.eval_det import eval_det, get_3d_box, get_ap_info
+    from transferable3d_amd.test_semisup import detection_scores
+    classes = [class2type[i] for i in range(10)]
+    det_all, gt_all = {}, {}
     log('---- EPOCH %03d EVALUATION ----' % epoch)
     loss_sum = iou2 = iou3 = 0.0
     seen, correct = np.zeros(2), np.zeros(2)
@@ -113,9 +118,24 @@ def eval_one_epoch(sess, ops, FLAGS, epoch, log, source=None):
             feed = {pc_pl: b['pc'], one_hot_vec_pl: b['one_hot_vec'], y_seg_pl: b['y_seg'], y_centers_pl: b['y_center'],
                     y_orient_cls_pl: b['y_orient_cls'], y_orient_reg_pl: b['y_orient_reg'], y_dims_cls_pl: b['y_dims_cls'],
                     y_dims_reg_pl: b['y_dims_reg'], is_data_2D_pl: np.zeros(B, np.int32), is_training_pl: False}
-        loss_val, logits, i2, i3 = sess.run([semi_loss, end_points_logits(end_points, sess), end_points['iou2ds'], end_points['iou3ds']],
-                                            feed_dict=feed)
+        heads = [end_points[k] for k in ('center', 'heading_scores', 'heading_residuals', 'size_scores', 'size_residuals')]
+        loss_val, logits, i2, i3, cen, hs, hr, ss, sr = sess.run(
+            [semi_loss, end_points_logits(end_points, sess), end_points['iou2ds'], end_points['iou3ds']] + heads, feed_dict=feed)
         pred = np.argmax(logits, 2)
+        # detections of this batch and their label boxes (main_batch + evaluate_predictions, train_semisup.py:459-466); every
+        # frustum is its own image, boxes stay in the frustum's centre view
+        x = sess.g.inputs
+        lab_box = {k: getattr(x, k).cpu().numpy() for k in ('y_center', 'y_orient_cls', 'y_orient_reg', 'y_dims_cls', 'y_dims_reg', 'one_hot_vec')}
+        hc, sc = np.argmax(hs, 1), np.argmax(ss, 1)
+        score = detection_scores(logits, hs, ss)
+        for k in range(B):
+            cls = classes[int(np.argmax(lab_box['one_hot_vec'][k]))]
+            img = i * B + k
+            det_all[img] = [(cls, get_3d_box(MEAN_DIMS_ARR[sc[k]] + sr[k, sc[k]], hc[k] * (2 * np.pi / NUM_HEADING_BIN) + hr[k, hc[k]], cen[k]),
+                             float(score[k]))]
+            gt_all[img] = [(cls, get_3d_box(MEAN_DIMS_ARR[int(lab_box['y_dims_cls'][k])] + lab_box['y_dims_reg'][k],
+                                            int(lab_box['y_orient_cls'][k]) * (2 * np.pi / NUM_HEADING_BIN) + float(lab_box['y_orient_reg'][k]),
+                                            lab_box['y_center'][k]))]
         loss_sum += float(loss_val)
         iou2, iou3 = iou2 + float(np.sum(i2)), iou3 + float(np.sum(i3))
         for l in range(2):
@@ -130,6 +150,8 @@ def eval_one_epoch(sess, ops, FLAGS, epoch, log, source=None):
     log('eval avg class acc: %f' % np.mean(correct / np.maximum(seen, 1)))
     log('eval mIoU: %f' % np.mean(shape_ious))
     log('eval box IoU (ground/3D)     : %f / %f' % (iou2 / (n * B), iou3 / (n * B)))
+    _, _, ap = eval_det(det_all, gt_all, 0.25, rt=sess.g.rt)
+    log(get_ap_info(ap, float(np.mean(list(ap.values())))))
     return loss_sum / n
 
 
