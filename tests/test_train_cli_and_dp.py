@@ -196,3 +196,15 @@ def test_cli_evaluates_on_device_assembled_held_out_frustums(tmp_path):
     ev = {l.split(':')[0]: l for l in logs if str(l).startswith('eval ')}
     assert sorted(ev) == ['eval accuracy', 'eval avg class acc', 'eval box IoU (ground/3D)     ', 'eval mIoU', 'eval mean loss']
     assert np.isfinite(float(ev['eval mean loss'].split(': ')[1]))
+
+
+def test_train_boxpc_reports_the_reference_statistics_and_evaluates(tmp_path):
+    from transferable3d_amd import train_boxpc
+    logs = []
+    flags = train_boxpc.build_flags(['--BOX_PC_MASK_REPRESENTATION', 'A', '--BOXPC_WEIGHT_DELTA', '4', '--num_point', '128', '--batch_size', '8',
+                                     '--num_channels', '4', '--max_epoch', '1', '--steps_per_epoch', '10', '--device_data', '32',
+                                     '--eval_batches', '2', '--log_dir', str(tmp_path)])
+    train_boxpc.train(flags, rt=Runtime(device='cpu', lib=FakeLib()), log=logs.append)
+    text = '\n'.join(str(l) for l in logs)
+    assert text.count('Classname   Prec Recall  F1   Supp') == 2 and text.count('Before After ') == 4      # train + eval reports
+    assert 'EVALUATION' in text and 'eval mean loss' in text

@@ -212,3 +212,29 @@ def synthetic_frustums(n_frustums, num_channel=6, seed=0, min_points=400, max_po
         seg[lo:hi] = fg
         center[f] = un(cen_c)
     return dict(points=pts, seg=seg, offsets=offsets, frustum_angle=fang, box_center=center, heading=heading, size=size, cls=cls_id)
+
+
+class DeviceEvalSource:
+    """Held-out frustums from the generator of the training set, resident in HBM; batch i = frustums [i*B, (i+1)*B) assembled by
+    t3d_batch_assemble without augmentation (the reference's TEST_DATASET: random_flip / random_shift off) into the graph's feed
+    buffers.  `boxpc_perturb` (the BOXPC_* flags): followed by the Box-PC Fit sample generator, as BoxPCFitDataset does for its
+    test split (train_boxpc.py:119-124)."""
+
+    def __init__(self, graph, n_frustums, seed, boxpc_perturb=None):
+        from .engine import Plan
+        e = graph.engine
+        self.g, self.B = graph, e.B
+        self.ds = DeviceFrustumSet.synthetic(graph.rt, n_frustums, num_channel=max(e.C, 6), seed=seed)
+        self.ds.perm.copy_(torch.arange(n_frustums, dtype=torch.int32))
+        self.counter = graph.rt.zeros(4)
+        self.plan = Plan(graph.rt)
+        self.plan.add('t3d_batch_assemble', self.ds.assemble_args(graph.inputs, self.counter, e.B, e.rpf, e.C, seed=seed, random_flip=False,
+                                                                 random_shift=False))
+        if boxpc_perturb is not None:
+            self.plan.add('t3d_boxpc_perturb', boxpc_perturb_args(graph.inputs, self.counter, e.B, boxpc_perturb, seed=seed ^ 0x5bd1e995))
+
+    def load(self, i):
+        """Assemble batch i; returns its per-point labels [B, N]."""
+        self.counter[0] = float(i)
+        self.plan.run()
+        return self.g.inputs.y_seg.view(self.B, -1).cpu().numpy()

@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """Stage-b training driver (Box-PC Fit net) with the reference's command line
-(sunrgbd/sunrgbd_detection/train_boxpc.py: flags 28-47, graph 219-261, loop 301-366).  The GT-box perturbation sampler
-(box_pc_fit_dataset.py, needs the missing `box_util`) is out of scope: `--synthetic` batches carry the perturbed box in
-label form, its IoU with the GT and the delta labels (transferable3d_amd/synthetic.py).
+(sunrgbd/sunrgbd_detection/train_boxpc.py: flags 28-47, graph 219-261, loop 301-366).  `--device_data F` keeps a
+frustum set in HBM and makes every sample on the device: batch assembly, class-balanced composition and the perturbed box with its
+IoU target (box_pc_fit_dataset.py; t3d_batch_assemble, t3d_sample_equal_classes, t3d_boxpc_perturb).  Without it, `--synthetic`
+host batches carry a perturbed box in label form with drawn IoU / delta labels (transferable3d_amd/synthetic.py).  Per epoch the
+driver prints the reference's statistics (boxpc_stats.py): precision / recall / F1 of the fit decision per class and the 3-D IoU
+with the label box before / after the predicted deltas; `--eval_batches n` adds eval_one_epoch on held-out samples.
 
   python -m transferable3d_amd.train_boxpc --BOX_PC_MASK_REPRESENTATION A --BOXPC_WEIGHT_DELTA 4 --num_point 1024 \
       --num_channels 4 --max_epoch 1 --steps_per_epoch 100
@@ -42,6 +45,7 @@ def build_flags(argv=None):
     cfg.add_argument('--num_channels', type=int, default=None)
     cfg.add_argument('--steps_per_epoch', type=int, default=100)
     cfg.add_argument('--seed', type=int, default=0)
+    cfg.add_argument('--eval_batches', type=int, default=0, help='held-out synthetic batches evaluated after every epoch (eval_one_epoch)')
     cfg.add_argument('--device_data', type=int, default=0, metavar='F',
                      help='F > 0: F synthetic frustums resident in HBM; batches and the perturbed-box samples are made on the device')
     FLAGS = cfg.parse_special_args(argv)
@@ -61,17 +65,57 @@ def train(FLAGS, rt=None, log=print):
             y_box_iou_pl, y_center_delta_pl, y_dims_delta_pl, y_orient_delta_pl = pls
         box_reg = MODEL.convert_raw_y_box_to_reg_format((x_center_pl, x_orient_cls_pl, x_orient_reg_pl, x_dims_cls_pl, x_dims_reg_pl),
                                                         one_hot_vec_pl)
-        pred, end_points = MODEL.get_model((box_reg, pc_pl), True, one_hot_vec_pl, use_one_hot_vec=FLAGS.use_one_hot, c=FLAGS)
+        is_training_pl = api.is_training_placeholder()                   # train_boxpc.py:228
+        pred, end_points = MODEL.get_model((box_reg, pc_pl), is_training_pl, one_hot_vec_pl, use_one_hot_vec=FLAGS.use_one_hot, c=FLAGS)
         loss = MODEL.get_loss(pred, (y_box_iou_pl, (y_center_delta_pl, y_dims_delta_pl, y_orient_delta_pl)), end_points, c=FLAGS)
         train_op = api.AdamOptimizer(FLAGS.learning_rate, decay_step=FLAGS.decay_step, decay_rate=FLAGS.decay_rate).minimize(loss)
         sess = api.Session()
         if FLAGS.restore_model_path:
             restore_model(g, FLAGS.restore_model_path)
         step, mean_loss = 0, 0.0
-        ds = None
+        from transferable3d_amd.boxpc_stats import ALL_CLASSES, BoxDeltaIOUStats, ClassificationStats, record_batch
+        fit_lo = float(FLAGS.BOXPC_FIT_BOUNDS[0])
+        fetch_stats = [loss, end_points['pred_boxpc_fit'], end_points['boxpc_delta_center'], end_points['boxpc_delta_size'],
+                       end_points['boxpc_delta_angle']]
+
+        def new_stats():
+            return ClassificationStats(ALL_CLASSES), BoxDeltaIOUStats(ALL_CLASSES, g.rt), BoxDeltaIOUStats(ALL_CLASSES, g.rt)
+
+        def report(tag, stats):
+            cls_stats, pos, neg = stats
+            log('%s mean loss: %f' % (tag, cls_stats.get_mean_loss()))
+            log(cls_stats.summarize_stats(cls_stats.get_batch_stats()))
+            log('Box IoU before / after the predicted deltas, fit samples (IoU >= %.2f):' % fit_lo)
+            log(pos.summarize_stats(pos.get_batch_stats()))
+            log('Box IoU before / after the predicted deltas, no-fit samples:')
+            log(neg.summarize_stats(neg.get_batch_stats()))
+
+        def eval_one_epoch(epoch):
+            """train_boxpc.py:398-487: held-out samples, is_training fed False."""
+            log('---- EPOCH %03d EVALUATION ----' % epoch)
+            stats = new_stats()
+            for i in range(FLAGS.eval_batches):
+                if eval_source is not None:                  # held-out frustums, samples made on the device: only the mode is fed
+                    eval_source.load(i)
+                    feed = {}
+                else:
+                    feed = feed_of(make_batch(B, N, C, seed=FLAGS.seed * 1000003 + 900000 + i, boxpc=True))
+                feed[is_training_pl] = False
+                out = sess.run(fetch_stats, feed_dict=feed)
+                record_batch(stats[0], stats[1], stats[2], fit_lo, out[0], out[1], out[2:5], g.inputs)
+            report('eval', stats)
+
+        def feed_of(b):
+            return {pc_pl: b['pc'], one_hot_vec_pl: b['one_hot_vec'], x_center_pl: b['y_center'], x_orient_cls_pl: b['y_orient_cls'],
+                    x_orient_reg_pl: b['y_orient_reg'], x_dims_cls_pl: b['y_dims_cls'], x_dims_reg_pl: b['y_dims_reg'],
+                    y_box_iou_pl: b['y_box_iou'], y_center_delta_pl: b['y_center_delta'], y_dims_delta_pl: b['y_dims_delta'],
+                    y_orient_delta_pl: b['y_orient_delta']}
+        ds = eval_source = None
         if FLAGS.device_data:
-            from transferable3d_amd.dataset import DeviceFrustumSet
+            from transferable3d_amd.dataset import DeviceEvalSource, DeviceFrustumSet
             ds = DeviceFrustumSet.synthetic(g.rt, FLAGS.device_data, num_channel=max(C, 6), seed=FLAGS.seed)
+            if FLAGS.eval_batches > 0:
+                eval_source = DeviceEvalSource(g, FLAGS.eval_batches * B, FLAGS.seed + 424243, boxpc_perturb=FLAGS)
             # BOXPC_SAMPLING_METHOD 'SAMPLE': class-balanced batches with probability BOXPC_SAMPLE_EQUAL_CLASS_WITH_PROB
             # (train_boxpc.py:323-328); 'BATCH': the epoch permutation
             eq = float(FLAGS.BOXPC_SAMPLE_EQUAL_CLASS_WITH_PROB) if FLAGS.BOXPC_SAMPLING_METHOD == 'SAMPLE' else 0.0
@@ -82,10 +126,12 @@ def train(FLAGS, rt=None, log=print):
                 # box_pc_fit_dataset.py 'BATCH' sampling: an epoch permutation; the loss is fetched every 10th step only
                 ds.shuffle(FLAGS.seed * 1000003 + epoch)
                 n_logged = 0
+                stats = new_stats()
                 for it in range(FLAGS.steps_per_epoch):
                     if it % 10 == 9 or it == FLAGS.steps_per_epoch - 1:
-                        loss_val, _ = sess.run([loss, train_op])
-                        loss_sum += float(loss_val)
+                        out = sess.run(fetch_stats + [train_op])
+                        record_batch(stats[0], stats[1], stats[2], fit_lo, out[0], out[1], out[2:5], g.inputs)
+                        loss_sum += float(out[0])
                         n_logged += 1
                     else:
                         sess.run([train_op])
@@ -93,21 +139,26 @@ def train(FLAGS, rt=None, log=print):
                 mean_loss = loss_sum / n_logged
                 log('**** EPOCH %03d ****  mean loss: %f  (%.1f frustums/s, samples made on the device)' % (
                     epoch, mean_loss, FLAGS.steps_per_epoch * B / (time.time() - t0)))
+                report('train (every 10th step)', stats)
+                if FLAGS.eval_batches > 0:
+                    eval_one_epoch(epoch)
                 if epoch % 5 == 0:
                     log('Model saved in file: %s' % save_model(FLAGS.log_dir, epoch, g, FLAGS.ckpt_format))
                 continue
+            stats = new_stats()
             for _ in range(FLAGS.steps_per_epoch):
-                b = make_batch(B, N, C, seed=FLAGS.seed * 1000003 + step, boxpc=True)
-                feed = {pc_pl: b['pc'], one_hot_vec_pl: b['one_hot_vec'], x_center_pl: b['y_center'], x_orient_cls_pl: b['y_orient_cls'],
-                        x_orient_reg_pl: b['y_orient_reg'], x_dims_cls_pl: b['y_dims_cls'], x_dims_reg_pl: b['y_dims_reg'],
-                        y_box_iou_pl: b['y_box_iou'], y_center_delta_pl: b['y_center_delta'], y_dims_delta_pl: b['y_dims_delta'],
-                        y_orient_delta_pl: b['y_orient_delta']}
-                loss_val, _ = sess.run([loss, train_op], feed_dict=feed)
-                loss_sum += float(loss_val)
+                feed = feed_of(make_batch(B, N, C, seed=FLAGS.seed * 1000003 + step, boxpc=True))
+                feed[is_training_pl] = True
+                out = sess.run(fetch_stats + [train_op], feed_dict=feed)
+                record_batch(stats[0], stats[1], stats[2], fit_lo, out[0], out[1], out[2:5], g.inputs)
+                loss_sum += float(out[0])
                 step += 1
             mean_loss = loss_sum / FLAGS.steps_per_epoch
             log('**** EPOCH %03d ****  mean loss: %f  (%.1f frustums/s incl. host batch synthesis)' % (
                 epoch, mean_loss, FLAGS.steps_per_epoch * B / (time.time() - t0)))
+            report('train', stats)
+            if FLAGS.eval_batches > 0:
+                eval_one_epoch(epoch)
             if epoch % 5 == 0:
                 path = save_model(FLAGS.log_dir, epoch, g, FLAGS.ckpt_format)
                 log('Model saved in file: %s' % path)

@@ -65,33 +65,6 @@ def build_flags(argv=None):
     return FLAGS
 
 
-class DeviceEvalSource:
-    """Held-out frustums from the generator of the training set, resident in HBM; batch i = frustums [i*B, (i+1)*B) assembled by
-    t3d_batch_assemble without augmentation (the reference's TEST_DATASET: random_flip / random_shift off)."""
-
-    def __init__(self, g, FLAGS, n_frustums, seed):
-        from transferable3d_amd.dataset import DeviceFrustumSet
-        from transferable3d_amd.engine import Plan
-        e = g.engine
-        self.g, self.B = g, e.B
-        self.ds = DeviceFrustumSet.synthetic(g.rt, n_frustums, num_channel=max(e.C, 6), seed=seed)
-        self.ds.perm.copy_(torch_arange(n_frustums))
-        self.counter = g.rt.zeros(4)
-        self.plan = Plan(g.rt)
-        self.plan.add('t3d_batch_assemble', self.ds.assemble_args(g.inputs, self.counter, e.B, e.rpf, e.C, seed=seed, random_flip=False,
-                                                                 random_shift=False))
-
-    def load(self, i):
-        self.counter[0] = float(i)
-        self.plan.run()
-        return self.g.inputs.y_seg.view(self.B, -1).cpu().numpy()
-
-
-def torch_arange(n):
-    import torch
-    return torch.arange(n, dtype=torch.int32)
-
-
 def eval_one_epoch(sess, ops, FLAGS, epoch, log, source=None):
     """train_semisup.py:436-545 on held-out synthetic frustums: the SAME graph with is_training fed False (moving batch-norm
     statistics, no dropout, no parameter or EMA update) -- loss, segmentation accuracy / class accuracy / IoU, box IoU."""
@@ -247,7 +220,8 @@ def train(FLAGS, rt=None, log=print):
                 log('Strong Box IoU (ground/3D): %f / %f' % (iou2_sum / (FLAGS.steps_per_epoch * B), iou3_sum / (FLAGS.steps_per_epoch * B)))
             if rank == 0 and FLAGS.eval_batches > 0:
                 if ds is not None and eval_source is None:
-                    eval_source = DeviceEvalSource(g, FLAGS, FLAGS.eval_batches * B, FLAGS.seed + 424243)
+                    from transferable3d_amd.dataset import DeviceEvalSource
+                    eval_source = DeviceEvalSource(g, FLAGS.eval_batches * B, FLAGS.seed + 424243)
                 eval_one_epoch(sess, (pls, is_training_pl, semi_loss, n_correct, end_points), FLAGS, epoch, log, eval_source)
             if rank == 0:
                 if epoch % 5 == 0:                       # train_semisup.py:316-318
