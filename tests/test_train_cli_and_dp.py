@@ -208,3 +208,17 @@ def test_train_boxpc_reports_the_reference_statistics_and_evaluates(tmp_path):
     text = '\n'.join(str(l) for l in logs)
     assert text.count('Classname   Prec Recall  F1   Supp') == 2 and text.count('Before After ') == 4      # train + eval reports
     assert 'EVALUATION' in text and 'eval mean loss' in text
+
+
+def test_stage_c_cli_evaluates_intermediate_and_refined_boxes(tmp_path):
+    from transferable3d_amd import train_semisup_adv
+    logs = []
+    flags = train_semisup_adv.build_flags(
+        ['--SEMI_MODEL', 'F', '--BOX_PC_MASK_REPRESENTATION', 'A', '--use_one_hot', '--SEMI_BOXPC_FIT_ONLY_ON_2D_CLS', '1',
+         '--WEAK_WEIGHT_INTRACLASSVAR', '2', '--WEAK_WEIGHT_REPROJECTION', '0', '--SEMI_MULTIPLIER_FOR_WEAK_LOSS', '0.05', '--num_point', '128',
+         '--batch_size', '4', '--num_channels', '4', '--max_epoch', '1', '--steps_per_epoch', '2', '--device_data', '24', '--eval_batches', '2',
+         '--log_dir', str(tmp_path)])
+    train_semisup_adv.train(flags, rt=Runtime(device='cpu', lib=FakeLib()), log=logs.append)
+    text = '\n'.join(str(l) for l in logs)
+    assert 'intermediate (F_)' in text and 'refined by the Box-PC deltas (F2_)' in text and text.count('Mean AP:') == 2
+    assert 'class-agnostic heads' in text

@@ -44,6 +44,7 @@ def build_flags(argv=None):
     cfg.add_argument('--init_class_ag_path', default=None, help='stage-a state dict (class-agnostic branch)')
     cfg.add_argument('--init_boxpc_path', default=None, help='stage-b state dict (Box-PC Fit net)')
     cfg.add_argument('--restore_model_path', default=None)
+    cfg.add_argument('--eval_batches', type=int, default=0, help='held-out synthetic batches evaluated after every epoch (eval_one_epoch)')
     cfg.add_argument('--ckpt_format', default='npz', choices=['npz', 'tf'], help='tf: TensorFlow Saver bundle')
     cfg.add_argument('--synthetic', action='store_true')
     cfg.add_argument('--num_channels', type=int, default=None)
@@ -70,6 +71,54 @@ def load_variable_scopes_from_ckpt(vars_, path, scope):
     return n
 
 
+def eval_one_epoch(sess, pls, is_training_pl, logits_t, end_points, FLAGS, epoch, log, source=None):
+    """train_semisup_adv.py:663-709 on held-out synthetic frustums (is_training fed False, every frustum with its 3-D label): AP
+    of the intermediate `F_` boxes and of the `F2_` boxes refined by the Box-PC deltas, plus the `W_` / `F_` box IoU summaries."""
+    from transferable3d_amd.constants import MEAN_DIMS_ARR, NUM_HEADING_BIN, class2type
+    from transferable3d_amd.eval_det import eval_det, get_3d_box, get_ap_info
+    from transferable3d_amd.test_semisup import detection_scores
+    B, N, C = FLAGS.batch_size, FLAGS.num_point, FLAGS.NUM_CHANNELS
+    classes = [class2type[i] for i in range(10)]
+    dets, gt_all = {'F_': {}, 'F2_': {}}, {}
+    heads = lambda p: [end_points[p + k] for k in ('center', 'heading_scores', 'heading_residuals', 'size_scores', 'size_residuals')]
+    sums = np.zeros(4)
+    log('---- EPOCH %03d EVALUATION ----' % epoch)
+    for i in range(FLAGS.eval_batches):
+        if source is not None:
+            source.load(i)
+            feed = {}
+        else:
+            b = make_batch(B, N, C, seed=FLAGS.seed * 1000003 + 900000 + i)
+            feed = {pls[0]: b['pc'], pls[3]: b['one_hot_vec'], pls[4]: b['y_seg'], pls[5]: b['y_center'], pls[6]: b['y_orient_cls'],
+                    pls[7]: b['y_orient_reg'], pls[8]: b['y_dims_cls'], pls[9]: b['y_dims_reg'], pls[17]: np.zeros(B, np.int32)}
+        feed[is_training_pl] = False
+        out = sess.run([logits_t, end_points['iou2ds'], end_points['iou3ds'], end_points['W_iou2ds'], end_points['W_iou3ds']]
+                       + heads('F_') + heads('F2_'), feed_dict=feed)
+        logits = out[0]
+        sums += [float(np.sum(v)) for v in out[1:5]]
+        x = sess.g.inputs
+        lab = {k: getattr(x, k).cpu().numpy() for k in ('y_center', 'y_orient_cls', 'y_orient_reg', 'y_dims_cls', 'y_dims_reg', 'one_hot_vec')}
+        for p, (cen, hs, hr, ss, sr) in (('F_', out[5:10]), ('F2_', out[10:15])):
+            hc, sc, score = np.argmax(hs, 1), np.argmax(ss, 1), detection_scores(logits, hs, ss)
+            for k in range(B):
+                dets[p][i * B + k] = [(classes[int(np.argmax(lab['one_hot_vec'][k]))],
+                                       get_3d_box(MEAN_DIMS_ARR[sc[k]] + sr[k, sc[k]], hc[k] * (2 * np.pi / NUM_HEADING_BIN) + hr[k, hc[k]], cen[k]),
+                                       float(score[k]))]
+        for k in range(B):
+            gt_all[i * B + k] = [(classes[int(np.argmax(lab['one_hot_vec'][k]))],
+                                  get_3d_box(MEAN_DIMS_ARR[int(lab['y_dims_cls'][k])] + lab['y_dims_reg'][k],
+                                             int(lab['y_orient_cls'][k]) * (2 * np.pi / NUM_HEADING_BIN) + float(lab['y_orient_reg'][k]),
+                                             lab['y_center'][k]))]
+    n = float(FLAGS.eval_batches * B)
+    log('eval box IoU (ground/3D)     : %f / %f   class-agnostic heads: %f / %f' % (sums[0] / n, sums[1] / n, sums[2] / n, sums[3] / n))
+    out = {}
+    for p, tag in (('F_', 'intermediate (F_)'), ('F2_', 'refined by the Box-PC deltas (F2_)')):
+        _, _, ap = eval_det(dets[p], gt_all, 0.25, rt=sess.g.rt)
+        out[p] = float(np.mean(list(ap.values())))
+        log('%s\n%s' % (tag, get_ap_info(ap, out[p])))
+    return out
+
+
 def train(FLAGS, rt=None, log=print):
     import torch
     if rt is None and torch.cuda.is_available():
@@ -80,7 +129,8 @@ def train(FLAGS, rt=None, log=print):
         raise NotImplementedError('training the Box-PC branch in stage c is dead code in the reference (SEMI_ADV_ITERS_FOR_D = 0)')
     with api.Graph(rt=rt, seed=FLAGS.seed).as_default() as g:
         pls = MODEL.placeholder_inputs(B, N, C)
-        pred, end_points = MODEL.get_semi_model(pls[0], pls[1], pls[2], pls[3], True, use_one_hot=FLAGS.use_one_hot, c=FLAGS)
+        is_training_pl = api.is_training_placeholder()                    # train_semisup_adv.py:300 (is_training_D stays False)
+        pred, end_points = MODEL.get_semi_model(pls[0], pls[1], pls[2], pls[3], is_training_pl, use_one_hot=FLAGS.use_one_hot, c=FLAGS)
         intraclsdims_train_classes = [(cls_type in FLAGS.TEST_CLS) for cls_type in ALL_CLASSES] \
             if FLAGS.SEMI_INTRACLSDIMS_ONLY_ON_2D_CLS else [True] * len(ALL_CLASSES)
         end_points.update({'intraclsdims_train_classes': intraclsdims_train_classes})
@@ -103,7 +153,7 @@ def train(FLAGS, rt=None, log=print):
         train_ids = [i for i in range(10) if i not in test_ids]
         step, mean_loss = 0, 0.0
         iters = 2 if FLAGS.SEMI_SAMPLING_METHOD == 'ALTERNATE_BATCH' else 1
-        ds = None
+        ds = eval_source = None
         if FLAGS.device_data:
             from transferable3d_amd.dataset import DeviceFrustumSet
             ds = DeviceFrustumSet.synthetic(g.rt, FLAGS.device_data, num_channel=max(C, 6), seed=FLAGS.seed)
@@ -138,9 +188,15 @@ def train(FLAGS, rt=None, log=print):
                         b['is_data_2D'][:] = 1 if iteration == 0 else 0
                     feed = {pls[0]: b['pc'], pls[3]: b['one_hot_vec'], pls[4]: b['y_seg'], pls[5]: b['y_center'], pls[6]: b['y_orient_cls'],
                             pls[7]: b['y_orient_reg'], pls[8]: b['y_dims_cls'], pls[9]: b['y_dims_reg'], pls[17]: b['is_data_2D']}
+                    feed[is_training_pl] = True
                     loss_val, _ = sess.run([semi_loss, train_op], feed_dict=feed)
                     loss_sum += float(loss_val)
                     step += 1
+            if FLAGS.eval_batches > 0:
+                if ds is not None and eval_source is None:
+                    from transferable3d_amd.dataset import DeviceEvalSource
+                    eval_source = DeviceEvalSource(g, FLAGS.eval_batches * B, FLAGS.seed + 424243)
+                eval_one_epoch(sess, pls, is_training_pl, pred[0], end_points, FLAGS, epoch, log, eval_source)
             if ds is None:
                 mean_loss = loss_sum / (FLAGS.steps_per_epoch * iters)
                 log('**** EPOCH %03d ****  mean loss: %f  (%.1f frustums/s incl. host batch synthesis)' % (
