@@ -11,7 +11,8 @@ python -m transferable3d_amd.train_boxpc --BOX_PC_MASK_REPRESENTATION A --BOXPC_
     --max_epoch 2 --steps_per_epoch 1500 --log_dir $out/b 2>&1 | grep -v amdgpu > $out/b.log
 python -m transferable3d_amd.train_semisup_adv --SEMI_MODEL F --BOX_PC_MASK_REPRESENTATION A --use_one_hot --SEMI_TRAIN_BOX_TRAIN_CLASS_AG_TNET 1 \
     --SEMI_TRAIN_BOX_TRAIN_CLASS_AG_BOX 1 --SEMI_BOXPC_FIT_ONLY_ON_2D_CLS 1 --WEAK_WEIGHT_INTRACLASSVAR 2 --WEAK_WEIGHT_REPROJECTION 0 \
-    --SEMI_MULTIPLIER_FOR_WEAK_LOSS 0.05 --SUNRGBD_SEMI_TEST_CLS table sofa dresser night_stand bookshelf \
+    --SEMI_MULTIPLIER_FOR_WEAK_LOSS 0.05 --SEMI_SAMPLE_EQUAL_CLASS_WITH_PROB 1 --SEMI_BOXPC_MIN_FIT_LOSS_AFT_REFINE 1 \
+    --SUNRGBD_SEMI_TEST_CLS table sofa dresser night_stand bookshelf \
     --init_class_ag_path $out/a/model_epoch_0.ckpt --init_boxpc_path $out/b/model_epoch_0.ckpt $common \
     --max_epoch 2 --steps_per_epoch 750 --log_dir $out/c 2>&1 | grep -v amdgpu > $out/c.log
 grep -E "EPOCH|eval mean|eval box|Mean AP|restored|MEAN" $out/a.log $out/b.log $out/c.log

@@ -89,6 +89,13 @@ def get_semi_model_final(pc, bg_pc, img, one_hot_vec, is_training, use_one_hot, 
                                              (B, 10, 3), 'F2_size_residuals')
         return (logits, W.pred_box(), F.pred_box()), end_points
 
+    # training form of the stage-c glue (train_semisup_adv.py:362-399): one Box-PC evaluation on F_pred_box_reg serves the fit
+    # probability and the single refinement step of the published recipe (SEMI_REFINE_USING_BOXPC_DELTA_NUM = 1).  With one step
+    # SEMI_BOXPC_MIN_FIT_LOSS_AFT_REFINE (set in recipe c) changes nothing: the loop's evaluation sees the same unrefined box.
+    if int(c.SEMI_REFINE_USING_BOXPC_DELTA_NUM) > 1:
+        raise NotImplementedError('SEMI_REFINE_USING_BOXPC_DELTA_NUM > 1 in the training graph (the published recipe uses 1; the '
+                                  'inference graph of test_semisup supports any number through --refine)')
+
     def wgt():
         if c.SEMI_WEIGH_BOXPC_DELTA_DURING_TEST:
             return 1.0 - end_points['boxpc_fit_prob'].numpy()
