@@ -656,6 +656,9 @@ typedef struct {
                                   sample2[((s/2)*B + b) mod sample2_len] (3-D-label classes, is_data_2D = 0) */
   int sample2_len;
   int32_t* is_data_2D;         /* [B] or NULL */
+  const int32_t* frustum_is_2D; /* [F] or NULL: per-frustum flag of a combined data set (SEMI_SAMPLING_METHOD BATCH: get_batch walks the
+                                  3-D-label list followed by the 2-D-label list, roi_semi_dataset.py:482-535); when given it decides
+                                  is_data_2D in the one-list modes */
 } t3d_batch_assemble_args;
 int t3d_batch_assemble(const t3d_batch_assemble_args* args, t3d_stream_t stream);
 

@@ -404,7 +404,10 @@ class FakeLib:
             if p.rot_angle:
                 arr(p.rot_angle, B)[b] = rot
             if p.is_data_2D:
-                arr(p.is_data_2D, B)[b] = 1 if (p.sample2 and from_first) else 0
+                if p.sample2:
+                    arr(p.is_data_2D, B)[b] = 1 if from_first else 0
+                else:
+                    arr(p.is_data_2D, B)[b] = int(np.ctypeslib.as_array(p.frustum_is_2D, shape=(1 << 30,))[f]) if p.frustum_is_2D else 0
         return 0
 
     def t3d_sample_equal_classes(self, a, stream):

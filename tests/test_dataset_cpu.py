@@ -313,3 +313,19 @@ def check_equal_class_sampler(rt):
 
 def test_equal_samples_per_class_sampler():
     check_equal_class_sampler(Runtime(device='cpu', lib=FakeLib()))
+
+
+def test_combined_data_set_marks_two_d_frustums():
+    """SEMI_SAMPLING_METHOD BATCH: is_data_2D follows the per-frustum flag of the combined data set."""
+    rt = Runtime(device='cpu', lib=FakeLib())
+    host = synthetic_frustums(40, num_channel=4, seed=6, min_points=130, max_points=160)
+    ds = DeviceFrustumSet(rt, **host).mark_2d_classes([1, 2, 6, 7, 8])
+    B, N, Cc = 8, 128, 4
+    g = Graph(B, N, Cc, rt=rt)
+    x = Inputs(g)
+    g.hyper[0] = 2.0
+    a = ds.assemble_args(x, g.hyper, B, N, Cc, seed=3)
+    assert rt.lib.t3d_batch_assemble(C.byref(a), None) == 0
+    f = ds.perm.numpy()[2 * B:3 * B]
+    assert np.array_equal(x.is_data_2D.numpy(), np.isin(host['cls'][f], [1, 2, 6, 7, 8]).astype(np.int32))
+    assert 0 < x.is_data_2D.sum() < B

@@ -15,4 +15,4 @@ python -m transferable3d_amd.train_semisup_adv --SEMI_MODEL F --BOX_PC_MASK_REPR
     --SUNRGBD_SEMI_TEST_CLS table sofa dresser night_stand bookshelf \
     --init_class_ag_path $out/a/model_epoch_0.ckpt --init_boxpc_path $out/b/model_epoch_0.ckpt $common \
     --max_epoch 2 --steps_per_epoch 750 --log_dir $out/c 2>&1 | grep -v amdgpu > $out/c.log
-grep -E "EPOCH|eval mean|eval box|Mean AP|restored|MEAN" $out/a.log $out/b.log $out/c.log
+grep -E "EPOCH|eval mean|eval box|Mean AP|restored|MEAN|intermediate|refined" $out/a.log $out/b.log $out/c.log

@@ -104,6 +104,14 @@ class DeviceFrustumSet:
         a._keep = (keep, order_draws, member_draws, prob_draw, sample_out)
         return a
 
+    def mark_2d_classes(self, classes_2d):
+        """SEMI_SAMPLING_METHOD BATCH over the combined data set (roi_semi_dataset.py:482-535: the 3-D-label list followed by the
+        2-D-label list): frustums of `classes_2d` carry is_data_2D = 1, i.e. their 3-D labels are withheld from the loss."""
+        flag = np.isin(self.cls.cpu().numpy(), list(classes_2d)).astype(np.int32)
+        self.is_2D = torch.as_tensor(flag).to(self.rt.device)
+        self.rt.allocs.append(self.is_2D)
+        return self
+
     def split_by_class(self, classes_2d):
         """ALTERNATE_BATCH sampling (train_semisup_adv.py:538-565): the frustums of `classes_2d` (class ids whose 3-D labels
         are withheld, SUNRGBD_SEMI_TEST_CLS) form the weak list, the rest the strong list; each is walked in its own shuffled
@@ -138,6 +146,7 @@ class DeviceFrustumSet:
         a.y_orient_cls, a.y_orient_reg = iptr(inputs.y_orient_cls), fptr(inputs.y_orient_reg)
         a.y_dims_cls, a.y_dims_reg, a.one_hot = iptr(inputs.y_dims_cls), fptr(inputs.y_dims_reg), fptr(inputs.one_hot_vec)
         a.is_data_2D = iptr(inputs.is_data_2D)
+        a.frustum_is_2D = iptr(getattr(self, 'is_2D', None))
         if alternate:
             (_, weak), (_, strong) = self.subsets
             a.sample, a.sample_len, a.sample2, a.sample2_len = iptr(weak), int(weak.numel()), iptr(strong), int(strong.numel())

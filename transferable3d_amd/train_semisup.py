@@ -125,7 +125,17 @@ def eval_one_epoch(sess, ops, FLAGS, epoch, log, source=None):
     log('eval box IoU (ground/3D)     : %f / %f' % (iou2 / (n * B), iou3 / (n * B)))
     _, _, ap = eval_det(det_all, gt_all, 0.25, rt=sess.g.rt)
     log(get_ap_info(ap, float(np.mean(list(ap.values())))))
+    log(ap_by_label_kind(ap, FLAGS))
     return loss_sum / n
+
+
+def ap_by_label_kind(ap, FLAGS):
+    """Mean AP over the classes trained with 3-D labels and over the classes with 2-D labels only (the reference evaluates the
+    latter: TEST_DATASET holds FLAGS.TEST_CLS, train_semisup.py:113-117)."""
+    weak = [ap[k] for k in ap if k in FLAGS.SUNRGBD_SEMI_TEST_CLS]
+    strong = [ap[k] for k in ap if k not in FLAGS.SUNRGBD_SEMI_TEST_CLS]
+    m = lambda v: 100.0 * float(np.mean(v)) if v else float('nan')
+    return '    Mean AP, classes with 3-D labels: %.1f   classes with 2-D labels only: %.1f' % (m(strong), m(weak))
 
 
 def end_points_logits(end_points, sess):
@@ -176,6 +186,12 @@ def train(FLAGS, rt=None, log=print):
         if FLAGS.device_data:
             from transferable3d_amd.dataset import DeviceFrustumSet
             ds = DeviceFrustumSet.synthetic(g.rt, FLAGS.device_data, num_channel=max(C, 6), seed=FLAGS.seed + 17 * rank)
+            # SEMI_SAMPLING_METHOD BATCH over the combined data set (train_semisup.py:97-110, 343-349): frustums of the classes that
+            # have 2-D labels only (SUNRGBD_SEMI_TEST_CLS) run through the net with is_data_2D = 1 -- no strong loss, their points
+            # still enter the batch statistics.  (SEMI_USE_LABELS2D_OF_CLASSES3D also repeats the 3-D-label frustums as zero-loss
+            # 2-D samples; not reproduced.)
+            from transferable3d_amd.constants import type2class
+            ds.mark_2d_classes([type2class[t] for t in FLAGS.SUNRGBD_SEMI_TEST_CLS])
             g.use_device_dataset(ds, seed=FLAGS.seed * 7919 + rank)
         for epoch in range(FLAGS.max_epoch):
             t0 = time.time()

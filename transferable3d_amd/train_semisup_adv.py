@@ -21,6 +21,7 @@ from transferable3d_amd.config import make_parser                        # noqa:
 from transferable3d_amd.constants import type2class                      # noqa: E402
 from transferable3d_amd.synthetic import make_batch                      # noqa: E402
 from transferable3d_amd.tf_checkpoint import load_state, restore_model, save_model   # noqa: E402
+from transferable3d_amd.train_semisup import ap_by_label_kind                        # noqa: E402
 
 ALL_CLASSES = ['bed', 'table', 'sofa', 'chair', 'toilet', 'desk', 'dresser', 'night_stand', 'bookshelf', 'bathtub']
 
@@ -116,6 +117,7 @@ def eval_one_epoch(sess, pls, is_training_pl, logits_t, end_points, FLAGS, epoch
         _, _, ap = eval_det(dets[p], gt_all, 0.25, rt=sess.g.rt)
         out[p] = float(np.mean(list(ap.values())))
         log('%s\n%s' % (tag, get_ap_info(ap, out[p])))
+        log(ap_by_label_kind(ap, FLAGS))
     return out
 
 
