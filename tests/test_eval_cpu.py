@@ -43,3 +43,84 @@ def test_test_semisup_evaluate_flag_reports_average_precision():
     assert len(preds) == 14 and preds[8] == [0.0] * 8 and preds[11] == list(range(8))
     table = [l for l in logs if str(l).startswith('Average Precision:')]
     assert len(table) == 1 and 'Mean AP:' in table[0]
+
+
+def _write_frustum_file(path, n=10, seed=4):
+    """A file in the reference's 13-list format whose label corners come from get_3d_box in camera coordinates."""
+    import gzip
+    import pickle
+    from oracle import ref_box as RB
+    from transferable3d_amd.constants import MEAN_DIMS_ARR, class2type
+    r = np.random.RandomState(seed)
+    cls = r.randint(0, 10, n)
+    size = MEAN_DIMS_ARR[cls] * r.uniform(0.8, 1.2, (n, 3))
+    heading = r.uniform(-np.pi, np.pi, n)
+    fang = r.uniform(-0.5, 0.5, n) - np.pi / 2
+    depth = r.uniform(2, 5, n)
+    center = np.stack([depth * np.cos(-fang - np.pi / 2 + np.pi / 2) * 0 + depth * np.sin(fang + np.pi / 2) * 0, np.zeros(n), depth], 1)
+    center[:, 0] = r.normal(size=n) * 0.5
+    box3d = [RB.get_3d_box(size[i], heading[i], center[i]) for i in range(n)]
+    counts = r.randint(150, 400, n)
+    lists = [list(range(100, 100 + n)), [np.zeros(4)] * n, box3d, [None] * n,
+             [np.concatenate([center[i] + r.normal(size=(counts[i], 3)) * 0.4, r.uniform(size=(counts[i], 3))], 1) for i in range(n)],
+             [(r.uniform(size=counts[i]) < 0.3).astype(np.float64) for i in range(n)], [class2type[int(c)].encode() for c in cls],
+             list(heading), list(size), [np.eye(3)] * n, [np.eye(3)] * n, list(fang), [np.array([640, 480])] * n]
+    with gzip.open(path, 'wb') as f:
+        pickle.dump(lists, f, 2)
+    return box3d, cls
+
+
+def test_frustum_file_labels_round_trip_through_the_centre_view(tmp_path):
+    """Frame conventions of the file path of test_semisup: the label box of every frustum, as the device assembly hands it to the
+    net (centre view, bin + residual), written out as a 'prediction' and rotated back by evaluate.py's rule, is the file's own
+    label box: IoU 1 with it, AP 1."""
+    from transferable3d_amd.constants import class2type
+    from transferable3d_amd.dataset import DeviceEvalSource, DeviceFrustumSet
+    from transferable3d_amd.nets import Graph, Inputs
+    path = str(tmp_path / 'val.zip.pickle')
+    box3d, cls = _write_frustum_file(path, n=10)
+    rt = Runtime(device='cpu', lib=FakeLib())
+    B, N, C = 4, 128, 4
+
+    class G:                                         # the two attributes DeviceEvalSource needs of an api.Graph
+        pass
+    g = G()
+    g.rt, g.engine = rt, Graph(B, N, C, rt=rt)
+    g.inputs = Inputs(g.engine)
+    ds = DeviceFrustumSet.from_pickle(rt, path)
+    src = DeviceEvalSource(g, dataset=ds)
+    cen, hc, hr, sc, sr = [], [], [], [], []
+    for i in range(3):                               # 10 frustums, B = 4: the last batch wraps around
+        src.load(i)
+        x = g.inputs
+        cen.append(x.y_center.numpy().copy()); hc.append(x.y_orient_cls.numpy().copy()); hr.append(x.y_orient_reg.numpy().copy())
+        sc.append(x.y_dims_cls.numpy().copy()); sr.append(x.y_dims_reg.numpy().copy())
+    assert np.array_equal(src.frustums_of(2), [8, 9, 0, 1])
+    cat = lambda v: np.concatenate(v)[:10]
+    rot = np.pi / 2 + ds.frustum_angle.numpy().astype(np.float64)
+    preds = [None, None, None, list(cat(cen)), list(cat(hc)), list(cat(hr)), list(cat(sc)), list(cat(sr)), list(rot), [1.0] * 10, list(cls),
+             list(ds.image_ids), None, None]
+    classes = [class2type[i] for i in range(10)]
+    boxes = E.predictions_to_boxes(preds, classes)
+    gt_all = {img: [(name, k)] for img, name, k in zip(ds.image_ids, ds.class_names, ds.box3d)}
+    for img in ds.image_ids:
+        assert E.get_iou(boxes[img][0][1], gt_all[img][0][1], rt) > 0.999
+    _, _, ap, mean_ap = E.evaluate_predictions(preds, gt_all, classes, rt=rt)
+    assert abs(mean_ap - 1.0) < 1e-9
+
+
+def test_test_semisup_on_a_frustum_file(tmp_path):
+    from transferable3d_amd import test_semisup as TS
+    path = str(tmp_path / 'val.zip.pickle')
+    _write_frustum_file(path, n=10)
+    logs = []
+    FLAGS = TS.build_flags(['--semi_type', 'F', '--use_one_hot', '--num_point', '128', '--num_channels', '4', '--batch_size', '4', '--refine', '1',
+                            '--pred_prefix', 'F2_', '--test', 'AB', '--data_path', path, '--evaluate', '--SUNRGBD_SEMI_TEST_CLS', 'bed', 'table',
+                            'sofa', 'chair', 'toilet', 'desk', 'dresser', 'night_stand', 'bookshelf', 'bathtub',
+                            '--output', str(tmp_path / 'pred.zip.pickle')])
+    preds = TS.test(FLAGS, rt=Runtime(device='cpu', lib=FakeLib()), log=logs.append)
+    assert len(preds) == 14 and len(preds[3]) == 10 and preds[11] == list(range(100, 110)) and len(preds[13]) == 10
+    assert any(str(l).startswith('Average Precision:') for l in logs)
+    from transferable3d_amd.dataset import load_zipped_pickle
+    back = load_zipped_pickle(str(tmp_path / 'pred.zip.pickle'))
+    assert len(back) == 14 and np.allclose(back[8], preds[8])

@@ -57,6 +57,8 @@ class DeviceFrustumSet:
         ds = cls.from_lists(rt, [np.asarray(p) for p in pick(points_l)], [np.asarray(l) for l in pick(label_l)], pick(frustum_angle_l),
                             centers, pick(heading_l), pick(size_l), [type2class[t] for t in pick(cls_type_l)])
         ds.image_ids = pick(idx_l)
+        ds.box3d = [np.asarray(b, np.float64) for b in pick(box3d_l)]        # label corners in camera coordinates (evaluation)
+        ds.class_names = pick(cls_type_l)
         return ds
 
     @classmethod
@@ -229,18 +231,22 @@ class DeviceEvalSource:
     buffers.  `boxpc_perturb` (the BOXPC_* flags): followed by the Box-PC Fit sample generator, as BoxPCFitDataset does for its
     test split (train_boxpc.py:119-124)."""
 
-    def __init__(self, graph, n_frustums, seed, boxpc_perturb=None):
+    def __init__(self, graph, n_frustums=None, seed=0, boxpc_perturb=None, dataset=None):
         from .engine import Plan
         e = graph.engine
         self.g, self.B = graph, e.B
-        self.ds = DeviceFrustumSet.synthetic(graph.rt, n_frustums, num_channel=max(e.C, 6), seed=seed)
-        self.ds.perm.copy_(torch.arange(n_frustums, dtype=torch.int32))
+        self.ds = dataset if dataset is not None else DeviceFrustumSet.synthetic(graph.rt, n_frustums, num_channel=max(e.C, 6), seed=seed)
+        self.ds.perm.copy_(torch.arange(self.ds.F, dtype=torch.int32))      # file order; the walk wraps around past the end
         self.counter = graph.rt.zeros(4)
         self.plan = Plan(graph.rt)
         self.plan.add('t3d_batch_assemble', self.ds.assemble_args(graph.inputs, self.counter, e.B, e.rpf, e.C, seed=seed, random_flip=False,
                                                                  random_shift=False))
         if boxpc_perturb is not None:
             self.plan.add('t3d_boxpc_perturb', boxpc_perturb_args(graph.inputs, self.counter, e.B, boxpc_perturb, seed=seed ^ 0x5bd1e995))
+
+    def frustums_of(self, i):
+        """Indices (file order) of the frustums in batch i."""
+        return (i * self.B + np.arange(self.B)) % self.ds.F
 
     def load(self, i):
         """Assemble batch i; returns its per-point labels [B, N]."""

@@ -42,6 +42,7 @@ def build_flags(argv=None):
     cfg.add_argument('--use_one_hot', action='store_true')
     cfg.add_argument('--batch_size', type=int, default=32)
     cfg.add_argument('--synthetic', action='store_true')
+    cfg.add_argument('--data_path', default=None, help='frustum file of the reference (frustums/*.zip.pickle); classes: --SUNRGBD_SEMI_TEST_CLS')
     cfg.add_argument('--num_channels', type=int, default=None)
     cfg.add_argument('--num_frustums', type=int, default=64)
     cfg.add_argument('--seed', type=int, default=0)
@@ -85,11 +86,15 @@ def detection_scores(logits, heading_logits, size_logits, fit_prob=None):
     return s if fit_prob is None else s + np.log(fit_prob + 0.01)
 
 
-def inference(sess, ops, pc, one_hot_vec, batch_size, prefix='', use_boxpc_fit_prob=False):
-    """test_semisup.py:188-262, same return tuple: (pred_seg, centers, orient_cls, orient_reg, dims_cls, dims_reg, scores)."""
-    assert pc.shape[0] % batch_size == 0
-    n = pc.shape[0]
-    logits = np.zeros((n, pc.shape[1], 2))
+def inference(sess, ops, pc, one_hot_vec, batch_size, prefix='', use_boxpc_fit_prob=False, source=None, n_batches=None):
+    """test_semisup.py:188-262, same return tuple: (pred_seg, centers, orient_cls, orient_reg, dims_cls, dims_reg, scores).
+    `source` (dataset.DeviceEvalSource): the batches are assembled on the device from a frustum file instead of being fed."""
+    if source is not None:
+        n, npts = n_batches * batch_size, sess.g.engine.rpf
+    else:
+        assert pc.shape[0] % batch_size == 0
+        n, npts = pc.shape[0], pc.shape[1]
+    logits = np.zeros((n, npts, 2))
     centers = np.zeros((n, 3))
     heading_logits, heading_residuals = np.zeros((n, NUM_HEADING_BIN)), np.zeros((n, NUM_HEADING_BIN))
     size_logits, size_residuals = np.zeros((n, NUM_SIZE_CLUSTER)), np.zeros((n, NUM_SIZE_CLUSTER, 3))
@@ -101,7 +106,11 @@ def inference(sess, ops, pc, one_hot_vec, batch_size, prefix='', use_boxpc_fit_p
                    ep[prefix + 'size_scores'], ep[prefix + 'size_residuals']]
         if use_boxpc_fit_prob:
             run_ops.append(ep['boxpc_fit_prob'])
-        out = sess.run(run_ops, feed_dict={ops['pc_pl']: pc[sl], ops['one_hot_vec_pl']: one_hot_vec[sl]})
+        if source is not None:
+            source.load(i)
+            out = sess.run(run_ops)
+        else:
+            out = sess.run(run_ops, feed_dict={ops['pc_pl']: pc[sl], ops['one_hot_vec_pl']: one_hot_vec[sl]})
         logits[sl], centers[sl], heading_logits[sl], heading_residuals[sl], size_logits[sl], size_residuals[sl] = out[:6]
         scores[sl] = detection_scores(out[0], out[2], out[4], out[6] if use_boxpc_fit_prob else None)
     heading_cls, size_cls = np.argmax(heading_logits, 1), np.argmax(size_logits, 1)
@@ -117,6 +126,8 @@ def test(FLAGS, rt=None, log=print):
         sd = dict(sd or {})
         sd.update({'D_boxpc_branch/' + k: v for k, v in load_state(FLAGS.boxpc_model_path).items()})
     sess, ops = get_model(FLAGS, B, N, C, rt=rt, state_dict=sd)
+    if FLAGS.data_path:
+        return test_on_frustum_file(FLAGS, sess, ops, log)
     n = (FLAGS.num_frustums + B - 1) // B * B                     # the reference pads the last batch (test_semisup.py:450-471)
     batches = [make_batch(B, N, C, seed=FLAGS.seed * 1000003 + i) for i in range(n // B)]
     pc = np.concatenate([b['pc'] for b in batches])
@@ -142,6 +153,42 @@ def test(FLAGS, rt=None, log=print):
                                   int(lab['y_orient_cls'][i]) * (2 * np.pi / NUM_HEADING_BIN) + float(lab['y_orient_reg'][i]), lab['y_center'][i]))]
                   for i in range(n)}
         _, _, ap, mean_ap = evaluate_predictions(predictions, gt_all, classes, rt=sess.g.rt)
+        log(get_ap_info(ap, mean_ap))
+    if FLAGS.output:
+        with gzip.open(FLAGS.output, 'wb') as f:
+            pickle.dump(predictions, f, -1)
+        log('predictions written to %s' % FLAGS.output)
+    return predictions
+
+
+def test_on_frustum_file(FLAGS, sess, ops, log):
+    """main_batch (test_semisup.py:404-511) over a frustum file of the reference: the file's frustums of the test classes live in HBM,
+    every batch is resampled to N points and rotated to its centre view on the device (no augmentation), the last batch is padded
+    by wrapping around; predictions in the 14-list layout with the real image ids and rotation angles; --evaluate scores them
+    against the file's own label boxes (evaluate.py builds the same boxes from the SUN-RGBD label files)."""
+    from transferable3d_amd.constants import class2type
+    from transferable3d_amd.dataset import DeviceEvalSource, DeviceFrustumSet
+    from transferable3d_amd.eval_det import evaluate_predictions, get_ap_info
+    g = ops['graph']
+    B = FLAGS.batch_size
+    ds = DeviceFrustumSet.from_pickle(g.rt, FLAGS.data_path, classes=list(FLAGS.SUNRGBD_SEMI_TEST_CLS) or None)
+    source = DeviceEvalSource(g, dataset=ds, seed=FLAGS.seed)
+    n_batches = (ds.F + B - 1) // B
+    seg, centers, hcls, hres, scls, sres, scores = inference(sess, ops, None, None, B, prefix=FLAGS.pred_prefix,
+                                                             use_boxpc_fit_prob=FLAGS.use_boxpc_fit_prob, source=source, n_batches=n_batches)
+    keep = slice(0, ds.F)                                          # drop the padding of the last batch
+    cls = ds.cls.cpu().numpy()
+    rot = np.pi / 2.0 + ds.frustum_angle.cpu().numpy().astype(np.float64)
+    predictions = [None, None, list(seg[keep]), list(centers[keep]), list(hcls[keep]), list(hres[keep]), list(scls[keep]), list(sres[keep]),
+                   list(rot), list(scores[keep]), list(cls), list(ds.image_ids), None, list(ds.box3d)]
+    log('%d frustums of %s from %s' % (ds.F, sorted(set(ds.class_names)), FLAGS.data_path))
+    if FLAGS.evaluate:
+        classes = [class2type[i] for i in range(10)]
+        gt_all = {}
+        for img, name, k in zip(ds.image_ids, ds.class_names, ds.box3d):
+            k = k if k[0, 1] >= k[4, 1] else k[[4, 5, 6, 7, 0, 1, 2, 3]]      # y-max face first, as evaluate.py:49-52 arranges it
+            gt_all.setdefault(img, []).append((name, k))
+        _, _, ap, mean_ap = evaluate_predictions(predictions, gt_all, classes, rt=g.rt)
         log(get_ap_info(ap, mean_ap))
     if FLAGS.output:
         with gzip.open(FLAGS.output, 'wb') as f:
