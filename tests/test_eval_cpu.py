@@ -124,3 +124,29 @@ def test_test_semisup_on_a_frustum_file(tmp_path):
     from transferable3d_amd.dataset import load_zipped_pickle
     back = load_zipped_pickle(str(tmp_path / 'pred.zip.pickle'))
     assert len(back) == 14 and np.allclose(back[8], preds[8])
+
+
+def test_training_clis_read_frustum_files(tmp_path):
+    """--frustum_file / --eval_file: the three drivers train from a frustum file of the reference held in HBM and evaluate on
+    another one."""
+    from transferable3d_amd import train_boxpc, train_semisup, train_semisup_adv
+    tr, ev = str(tmp_path / 'train.zip.pickle'), str(tmp_path / 'val.zip.pickle')
+    _write_frustum_file(tr, n=40, seed=1)
+    _write_frustum_file(ev, n=9, seed=2)
+    rt = lambda: Runtime(device='cpu', lib=FakeLib())
+    small = ['--num_point', '128', '--batch_size', '4', '--num_channels', '4', '--max_epoch', '1', '--steps_per_epoch', '2', '--frustum_file', tr,
+             '--eval_file', ev]
+    logs = []
+    train_semisup.train(train_semisup.build_flags(['--SEMI_MODEL', 'A', '--WEAK_WEIGHT_REPROJECTION', '0', '--WEAK_WEIGHT_SURFACE', '0',
+                                                   '--log_dir', str(tmp_path / 'a')] + small), rt=rt(), log=logs.append)
+    assert any('Mean AP' in str(l) for l in logs) and any('assembled on the device' in str(l) for l in logs)
+    logs = []
+    train_boxpc.train(train_boxpc.build_flags(['--BOX_PC_MASK_REPRESENTATION', 'A', '--BOXPC_WEIGHT_DELTA', '4', '--log_dir', str(tmp_path / 'b')]
+                                              + small), rt=rt(), log=logs.append)
+    assert any('eval mean loss' in str(l) for l in logs)
+    logs = []
+    train_semisup_adv.train(train_semisup_adv.build_flags(
+        ['--SEMI_MODEL', 'F', '--BOX_PC_MASK_REPRESENTATION', 'A', '--use_one_hot', '--WEAK_WEIGHT_INTRACLASSVAR', '2', '--WEAK_WEIGHT_REPROJECTION', '0',
+         '--SEMI_MULTIPLIER_FOR_WEAK_LOSS', '0.05', '--SEMI_SAMPLE_EQUAL_CLASS_WITH_PROB', '1', '--log_dir', str(tmp_path / 'c')] + small),
+        rt=rt(), log=logs.append)
+    assert any('refined by the Box-PC deltas' in str(l) for l in logs)

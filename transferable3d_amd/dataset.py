@@ -225,6 +225,16 @@ def synthetic_frustums(n_frustums, num_channel=6, seed=0, min_points=400, max_po
     return dict(points=pts, seg=seg, offsets=offsets, frustum_angle=fang, box_center=center, heading=heading, size=size, cls=cls_id)
 
 
+def open_training_set(rt, FLAGS, num_channel, classes=None, seed=0):
+    """`--frustum_file path` (a frustum file of the reference, frustums/*.zip.pickle, restricted to `classes`) or
+    `--device_data F` (F synthetic frustums): the training set resident in HBM, or None for host-fed synthetic batches."""
+    if getattr(FLAGS, 'frustum_file', None):
+        return DeviceFrustumSet.from_pickle(rt, FLAGS.frustum_file, classes=classes)
+    if FLAGS.device_data:
+        return DeviceFrustumSet.synthetic(rt, FLAGS.device_data, num_channel=max(num_channel, 6), seed=seed)
+    return None
+
+
 class DeviceEvalSource:
     """Held-out frustums from the generator of the training set, resident in HBM; batch i = frustums [i*B, (i+1)*B) assembled by
     t3d_batch_assemble without augmentation (the reference's TEST_DATASET: random_flip / random_shift off) into the graph's feed
@@ -253,3 +263,15 @@ class DeviceEvalSource:
         self.counter[0] = float(i)
         self.plan.run()
         return self.g.inputs.y_seg.view(self.B, -1).cpu().numpy()
+
+
+def open_eval_source(graph, FLAGS, classes=None, boxpc_perturb=None):
+    """Held-out frustums for eval_one_epoch: `--eval_file path` (a frustum file of the reference restricted to `classes`; every frustum
+    is visited, FLAGS.eval_batches is set accordingly) or FLAGS.eval_batches synthetic batches from the generator of the training
+    set."""
+    B = graph.engine.B
+    if getattr(FLAGS, 'eval_file', None):
+        ds = DeviceFrustumSet.from_pickle(graph.rt, FLAGS.eval_file, classes=classes)
+        FLAGS.eval_batches = (ds.F + B - 1) // B
+        return DeviceEvalSource(graph, dataset=ds, seed=FLAGS.seed, boxpc_perturb=boxpc_perturb)
+    return DeviceEvalSource(graph, FLAGS.eval_batches * B, FLAGS.seed + 424243, boxpc_perturb=boxpc_perturb)

@@ -45,6 +45,8 @@ def build_flags(argv=None):
     cfg.add_argument('--num_channels', type=int, default=None)
     cfg.add_argument('--steps_per_epoch', type=int, default=100)
     cfg.add_argument('--seed', type=int, default=0)
+    cfg.add_argument('--eval_file', default=None, help='held-out frustum file of the reference for eval_one_epoch (with --frustum_file / --device_data)')
+    cfg.add_argument('--frustum_file', default=None, help='train from a frustum file of the reference (frustums/*.zip.pickle) held in HBM')
     cfg.add_argument('--eval_batches', type=int, default=0, help='held-out synthetic batches evaluated after every epoch (eval_one_epoch)')
     cfg.add_argument('--device_data', type=int, default=0, metavar='F',
                      help='F > 0: F synthetic frustums resident in HBM; batches and the perturbed-box samples are made on the device')
@@ -111,11 +113,12 @@ def train(FLAGS, rt=None, log=print):
                     y_box_iou_pl: b['y_box_iou'], y_center_delta_pl: b['y_center_delta'], y_dims_delta_pl: b['y_dims_delta'],
                     y_orient_delta_pl: b['y_orient_delta']}
         ds = eval_source = None
-        if FLAGS.device_data:
-            from transferable3d_amd.dataset import DeviceEvalSource, DeviceFrustumSet
-            ds = DeviceFrustumSet.synthetic(g.rt, FLAGS.device_data, num_channel=max(C, 6), seed=FLAGS.seed)
-            if FLAGS.eval_batches > 0:
-                eval_source = DeviceEvalSource(g, FLAGS.eval_batches * B, FLAGS.seed + 424243, boxpc_perturb=FLAGS)
+        from transferable3d_amd.dataset import open_eval_source, open_training_set
+        # BoxPCFitDataset(classes=FLAGS.TRAIN_CLS, ...) (train_boxpc.py:100-108)
+        ds = open_training_set(g.rt, FLAGS, C, classes=list(FLAGS.SUNRGBD_SEMI_TRAIN_CLS) if FLAGS.frustum_file else None, seed=FLAGS.seed)
+        if ds is not None:
+            if FLAGS.eval_batches > 0 or FLAGS.eval_file:
+                eval_source = open_eval_source(g, FLAGS, classes=list(FLAGS.SUNRGBD_SEMI_TRAIN_CLS), boxpc_perturb=FLAGS)
             # BOXPC_SAMPLING_METHOD 'SAMPLE': class-balanced batches with probability BOXPC_SAMPLE_EQUAL_CLASS_WITH_PROB
             # (train_boxpc.py:323-328); 'BATCH': the epoch permutation
             eq = float(FLAGS.BOXPC_SAMPLE_EQUAL_CLASS_WITH_PROB) if FLAGS.BOXPC_SAMPLING_METHOD == 'SAMPLE' else 0.0

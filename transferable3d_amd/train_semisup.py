@@ -59,6 +59,8 @@ def build_flags(argv=None):
                      help='keep a synthetic data set of F ragged frustums in HBM and assemble every batch on the device '
                           '(t3d_batch_assemble: resample / centre-view rotation / flip / shift / labels)')
     cfg.add_argument('--seed', type=int, default=0)
+    cfg.add_argument('--eval_file', default=None, help='held-out frustum file of the reference for eval_one_epoch (with --frustum_file / --device_data)')
+    cfg.add_argument('--frustum_file', default=None, help='train from a frustum file of the reference (frustums/*.zip.pickle) held in HBM')
     cfg.add_argument('--eval_batches', type=int, default=0, help='held-out synthetic batches evaluated after every epoch (eval_one_epoch)')
     FLAGS = cfg.parse_special_args(argv)
     FLAGS.NUM_CHANNELS = FLAGS.num_channels if FLAGS.num_channels else (3 if FLAGS.no_rgb else 6)
@@ -183,9 +185,10 @@ def train(FLAGS, rt=None, log=print):
         n_correct = api.Tensor(g, g.assembly.seg.n_correct, (1,), 'n_correct')
         step = 0
         ds = eval_source = None
-        if FLAGS.device_data:
-            from transferable3d_amd.dataset import DeviceFrustumSet
-            ds = DeviceFrustumSet.synthetic(g.rt, FLAGS.device_data, num_channel=max(C, 6), seed=FLAGS.seed + 17 * rank)
+        from transferable3d_amd.dataset import open_training_set
+        ds = open_training_set(g.rt, FLAGS, C, classes=list(FLAGS.SUNRGBD_SEMI_TRAIN_CLS) + list(FLAGS.SUNRGBD_SEMI_TEST_CLS),
+                               seed=FLAGS.seed + 17 * rank)
+        if ds is not None:
             # SEMI_SAMPLING_METHOD BATCH over the combined data set (train_semisup.py:97-110, 343-349): frustums of the classes that
             # have 2-D labels only (SUNRGBD_SEMI_TEST_CLS) run through the net with is_data_2D = 1 -- no strong loss, their points
             # still enter the batch statistics.  (SEMI_USE_LABELS2D_OF_CLASSES3D also repeats the 3-D-label frustums as zero-loss
@@ -234,10 +237,10 @@ def train(FLAGS, rt=None, log=print):
                     epoch, loss_sum / FLAGS.steps_per_epoch, correct / (FLAGS.steps_per_epoch * B * N),
                     FLAGS.steps_per_epoch * B * world / (time.time() - t0)))
                 log('Strong Box IoU (ground/3D): %f / %f' % (iou2_sum / (FLAGS.steps_per_epoch * B), iou3_sum / (FLAGS.steps_per_epoch * B)))
-            if rank == 0 and FLAGS.eval_batches > 0:
+            if rank == 0 and (FLAGS.eval_batches > 0 or FLAGS.eval_file):
                 if ds is not None and eval_source is None:
-                    from transferable3d_amd.dataset import DeviceEvalSource
-                    eval_source = DeviceEvalSource(g, FLAGS.eval_batches * B, FLAGS.seed + 424243)
+                    from transferable3d_amd.dataset import open_eval_source
+                    eval_source = open_eval_source(g, FLAGS, classes=list(FLAGS.SUNRGBD_SEMI_TEST_CLS))   # TEST_DATASET, train_semisup.py:113
                 eval_one_epoch(sess, (pls, is_training_pl, semi_loss, n_correct, end_points), FLAGS, epoch, log, eval_source)
             if rank == 0:
                 if epoch % 5 == 0:                       # train_semisup.py:316-318

@@ -45,6 +45,8 @@ def build_flags(argv=None):
     cfg.add_argument('--init_class_ag_path', default=None, help='stage-a state dict (class-agnostic branch)')
     cfg.add_argument('--init_boxpc_path', default=None, help='stage-b state dict (Box-PC Fit net)')
     cfg.add_argument('--restore_model_path', default=None)
+    cfg.add_argument('--eval_file', default=None, help='held-out frustum file of the reference for eval_one_epoch (with --frustum_file / --device_data)')
+    cfg.add_argument('--frustum_file', default=None, help='train from a frustum file of the reference (frustums/*.zip.pickle) held in HBM')
     cfg.add_argument('--eval_batches', type=int, default=0, help='held-out synthetic batches evaluated after every epoch (eval_one_epoch)')
     cfg.add_argument('--ckpt_format', default='npz', choices=['npz', 'tf'], help='tf: TensorFlow Saver bundle')
     cfg.add_argument('--synthetic', action='store_true')
@@ -156,9 +158,9 @@ def train(FLAGS, rt=None, log=print):
         step, mean_loss = 0, 0.0
         iters = 2 if FLAGS.SEMI_SAMPLING_METHOD == 'ALTERNATE_BATCH' else 1
         ds = eval_source = None
-        if FLAGS.device_data:
-            from transferable3d_amd.dataset import DeviceFrustumSet
-            ds = DeviceFrustumSet.synthetic(g.rt, FLAGS.device_data, num_channel=max(C, 6), seed=FLAGS.seed)
+        from transferable3d_amd.dataset import open_training_set
+        ds = open_training_set(g.rt, FLAGS, C, classes=None, seed=FLAGS.seed)
+        if ds is not None:
             if iters == 2:
                 ds.split_by_class(test_ids)
             g.use_device_dataset(ds, seed=FLAGS.seed * 7919, alternate=(iters == 2),
@@ -194,10 +196,10 @@ def train(FLAGS, rt=None, log=print):
                     loss_val, _ = sess.run([semi_loss, train_op], feed_dict=feed)
                     loss_sum += float(loss_val)
                     step += 1
-            if FLAGS.eval_batches > 0:
+            if FLAGS.eval_batches > 0 or FLAGS.eval_file:
                 if ds is not None and eval_source is None:
-                    from transferable3d_amd.dataset import DeviceEvalSource
-                    eval_source = DeviceEvalSource(g, FLAGS.eval_batches * B, FLAGS.seed + 424243)
+                    from transferable3d_amd.dataset import open_eval_source
+                    eval_source = open_eval_source(g, FLAGS, classes=list(FLAGS.TEST_CLS))
                 eval_one_epoch(sess, pls, is_training_pl, pred[0], end_points, FLAGS, epoch, log, eval_source)
             if ds is None:
                 mean_loss = loss_sum / (FLAGS.steps_per_epoch * iters)
