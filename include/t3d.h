@@ -659,6 +659,8 @@ typedef struct {
   const int32_t* frustum_is_2D; /* [F] or NULL: per-frustum flag of a combined data set (SEMI_SAMPLING_METHOD BATCH: get_batch walks the
                                   3-D-label list followed by the 2-D-label list, roi_semi_dataset.py:482-535); when given it decides
                                   is_data_2D in the one-list modes */
+  int ld_pc;                   /* row stride of pc in floats (>= C; 0 = C).  A multiple of 4 when the layers read pc (C = 6: xyz + rgb
+                                  rows padded to 8 floats; the padding is written as zeros) */
 } t3d_batch_assemble_args;
 int t3d_batch_assemble(const t3d_batch_assemble_args* args, t3d_stream_t stream);
 

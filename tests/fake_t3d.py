@@ -351,7 +351,10 @@ class FakeLib:
         total = int(off[F])
         pts, seg = arr(p.points, total, Cs), arr(p.seg, total)
         fang, bc, head, size, cls = arr(p.frustum_angle, F), arr(p.box_center, F, 3), arr(p.heading, F), arr(p.size, F, 3), arr(p.cls, F)
-        pc, yseg = arr(p.pc, B, N, Cc), arr(p.y_seg, B, N)
+        ld = p.ld_pc if p.ld_pc > 0 else Cc
+        pc_full = arr(p.pc, B, N, ld)
+        pc_full[:, :, Cc:] = 0
+        pc, yseg = pc_full[:, :, :Cc], arr(p.y_seg, B, N)
         PI = np.float32(np.pi)
         for b in range(B):
             f = int(sample[b])

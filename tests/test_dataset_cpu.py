@@ -26,7 +26,9 @@ def assemble(rt, host, B, N, Cc, sample=None, choice=None, aug=None, step=0, see
     if dev.type == 'cuda':
         torch.cuda.synchronize()
     num = lambda v: v.detach().cpu().numpy()
-    return {'pc': num(x.pc).reshape(B, N, Cc), 'y_seg': num(x.y_seg).reshape(B, N), 'y_center': num(x.y_center),
+    pc = num(x.pc).reshape(B, N, -1)
+    assert not pc[:, :, Cc:].any()                      # rows padded to 16 bytes; the padding is written as zeros
+    return {'pc': pc[:, :, :Cc], 'y_seg': num(x.y_seg).reshape(B, N), 'y_center': num(x.y_center),
             'y_orient_cls': num(x.y_orient_cls), 'y_orient_reg': num(x.y_orient_reg), 'y_dims_cls': num(x.y_dims_cls),
             'y_dims_reg': num(x.y_dims_reg), 'one_hot_vec': num(x.one_hot_vec)}, ds
 

@@ -154,3 +154,15 @@ def test_config4_problem_size_in_fp32(hip_lib):
     g.bwd.run()
     torch.cuda.synchronize()
     assert torch.equal(grads1, g.vars.grads) and torch.equal(logits1, m.end_points()['logits'])
+
+
+@pytest.mark.parametrize('C', [3, 6])
+def test_model_a_with_three_and_six_channel_point_clouds(hip_lib, C):
+    """NUM_CHANNELS = 6 is the reference's default (xyz + rgb), 3 with --no_rgb: point-cloud rows padded to 16 bytes in HBM."""
+    B, N = 4, 256
+    batch = make_batch(B, N, C, seed=6, dropout_scopes={'inst_seg/dp1': ((B, N, 128), 0.5)})
+    P = _params(C, 13)
+    c = R.default_config()
+    g, m = run_model_a(Runtime(lib=hip_lib), batch, P, c)
+    assert m.inputs.pc.shape == (B * N, 4 if C == 3 else 8)
+    check_against_oracle(g, m, batch, P, c, grad_median_tol=1e-3)

@@ -75,3 +75,16 @@ def test_all_points_background_gives_empty_mask_and_zero_centroid():
 def test_config0_single_frustum_forward_plumbing():
     from model_check import check_config0_single_frustum_forward
     check_config0_single_frustum_forward(Runtime(device='cpu', lib=FakeLib()))
+
+
+@pytest.mark.parametrize('C', [3, 6])
+def test_model_a_with_three_and_six_channel_point_clouds(C):
+    """The reference's default is NUM_CHANNELS = 6 (xyz + rgb; 3 with --no_rgb, train_semisup.py:67-75): the point cloud's rows are
+    padded to a multiple of four floats in HBM (16-byte operand loads), the [1,C] first convolution sees exactly C channels."""
+    B, N = 4, 128
+    batch = make_batch(B, N, C, seed=6, dropout_scopes={'inst_seg/dp1': ((B, N, 128), 0.5)})
+    P = R.init_params(np.random.RandomState(13), R.layer_table(C, 'A'))
+    c = R.default_config()
+    g, m = run_model_a(_rt(), batch, P, c)
+    assert g.ldpc == (4 if C == 3 else 8) and m.inputs.pc.shape == (B * N, g.ldpc)
+    check_against_oracle(g, m, batch, P, c)

@@ -4,7 +4,7 @@
 #   bash tools/three_stage_demo.sh [out_dir]
 out=${1:-gpurun_out/recipe}
 mkdir -p $out
-common="--num_point 1024 --batch_size 32 --num_channels 4 --device_data 4000 --eval_batches 10 --ckpt_format tf"
+common="--num_point ${T3D_DEMO_POINTS:-1024} --batch_size 32 --num_channels ${T3D_DEMO_CHANNELS:-4} --device_data 4000 --eval_batches 10 --ckpt_format tf"
 python -m transferable3d_amd.train_semisup --SEMI_MODEL A --WEAK_WEIGHT_REPROJECTION 0 --WEAK_WEIGHT_SURFACE 0 $common \
     --max_epoch 2 --steps_per_epoch 1500 --log_dir $out/a 2>&1 | grep -v amdgpu > $out/a.log
 python -m transferable3d_amd.train_boxpc --BOX_PC_MASK_REPRESENTATION A --BOXPC_WEIGHT_DELTA 4 $common \

@@ -45,7 +45,10 @@ class Tensor:
     shape = property(get_shape)
 
     def numpy(self):
-        return self.buf.detach().cpu().numpy().reshape(self._shape)
+        a = self.buf.detach().cpu().numpy()
+        if self._shape and a.size != int(np.prod(self._shape)):          # rows padded in HBM (the point cloud at C = 3 or 6)
+            a = a.reshape(-1, a.shape[-1])[:, :self._shape[-1]]
+        return a.reshape(self._shape)
 
     def __repr__(self):
         return 'Tensor(%s, shape=%s)' % (self.name, self._shape)

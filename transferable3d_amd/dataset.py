@@ -149,6 +149,7 @@ class DeviceFrustumSet:
         a.y_dims_cls, a.y_dims_reg, a.one_hot = iptr(inputs.y_dims_cls), fptr(inputs.y_dims_reg), fptr(inputs.one_hot_vec)
         a.is_data_2D = iptr(inputs.is_data_2D)
         a.frustum_is_2D = iptr(getattr(self, 'is_2D', None))
+        a.ld_pc = int(inputs.pc.shape[1])
         if alternate:
             (_, weak), (_, strong) = self.subsets
             a.sample, a.sample_len, a.sample2, a.sample2_len = iptr(weak), int(weak.numel()), iptr(strong), int(strong.numel())

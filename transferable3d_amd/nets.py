@@ -27,6 +27,7 @@ class Graph:
             raise abi.T3DError('num_point must be a multiple of %d' % TILE)
         self.rt = rt or Runtime()
         self.B, self.rpf, self.C = batch_size, num_point, num_channel
+        self.ldpc = (num_channel + 3) // 4 * 4     # row stride of the point cloud in HBM: 16-byte rows for the float4 operand loads (C = 6 -> 8)
         self.M = batch_size * num_point
         self.vars = vars or VarStore(self.rt, seed=seed)
         self.ws = Workspace(self.rt)
@@ -152,7 +153,7 @@ class InstSegNet:
         """`train_seg`: emit the seg-loss backward (dz of conv9 etc.) inside the head kernel."""
         g, rt = self.g, self.g.rt
         M, T = g.M, g.M // TILE
-        a = ActSpec(pc, g.C, g.C)
+        a = ActSpec(pc, g.ldpc, g.C)
         a = self.L1.fwd(plan, a, is_training)
         a = self.L2.fwd(plan, a, is_training)
         a3 = self.L3.fwd(plan, a, is_training)
@@ -171,7 +172,7 @@ class InstSegNet:
             h.drop_mask, h.keep_prob = fptr(self.drop_mask), 0.5
         h.w, h.bias = fptr(self.w10), fptr(self.b10)
         h.labels, h.is_data_2D = iptr(labels), iptr(is_data_2D)
-        h.pc, h.ld_pc, h.ce_weight = fptr(pc), g.C, ce_weight
+        h.pc, h.ld_pc, h.ce_weight = fptr(pc), g.ldpc, ce_weight
         h.logits, h.mask, h.part = fptr(self.logits), fptr(self.mask), fptr(self.part)
         if train_seg:
             L9._ensure_bwd_buffers()
@@ -241,7 +242,7 @@ class TNet:
 
     def fwd(self, plan, pc, mask, mask_xyz_mean, one_hot, is_training):
         g = self.g
-        a = ActSpec(pc, g.C, 3, sub=mask_xyz_mean, sub_ld=3)
+        a = ActSpec(pc, g.ldpc, 3, sub=mask_xyz_mean, sub_ld=3)
         a = self.T1.fwd(plan, a, is_training)
         a = self.T2.fwd(plan, a, is_training)
         self.T3.fwd(plan, a, is_training, rowmask=mask)
@@ -284,7 +285,7 @@ class BoxEstNet:
 
     def fwd(self, plan, pc, mask, stage1_center, one_hot, is_training):
         g = self.g
-        a = ActSpec(pc, g.C, 3, sub=stage1_center, sub_ld=3)
+        a = ActSpec(pc, g.ldpc, 3, sub=stage1_center, sub_ld=3)
         a = self.B1.fwd(plan, a, is_training)
         a = self.B2.fwd(plan, a, is_training)
         a = self.B3.fwd(plan, a, is_training)
@@ -372,13 +373,17 @@ class Inputs:
     def __init__(self, g):
         self.g = g
         for name, dt, shp in self.FIELDS:
-            setattr(self, name, g.rt.zeros(*shp(g.B, g.rpf, g.C), dtype=dt))
+            setattr(self, name, g.rt.zeros(*shp(g.B, g.rpf, g.ldpc if name == 'pc' else g.C), dtype=dt))
 
     def load(self, batch):
         for name, dt, _ in self.FIELDS:
             if name in batch:
                 t = getattr(self, name)
-                t.copy_(torch.as_tensor(np.ascontiguousarray(batch[name])).to(dt).reshape(t.shape))
+                src = torch.as_tensor(np.ascontiguousarray(batch[name])).to(dt)
+                if name == 'pc':                      # rows padded to g.ldpc floats; the padding stays zero
+                    t[:, :self.g.C].copy_(src.reshape(-1, self.g.C))
+                else:
+                    t.copy_(src.reshape(t.shape))
         for scope, m in batch.get('dropout_masks', {}).items():
             if scope in self.g.dropout_masks:
                 t = self.g.dropout_masks[scope][0]
@@ -494,7 +499,7 @@ class BoxPCNet:
 
     def fwd(self, plan, pc, center, dims, theta, one_hot, is_training, y_dims_cls=None, y_orient_cls=None):
         g = self.g
-        a = abi.BoxPcRepArgs(fptr(pc), g.C, g.C, fptr(center), fptr(dims), fptr(theta), iptr(y_dims_cls), iptr(y_orient_cls),
+        a = abi.BoxPcRepArgs(fptr(pc), g.ldpc, g.C, fptr(center), fptr(dims), fptr(theta), iptr(y_dims_cls), iptr(y_orient_cls),
                              fptr(self.rep), self.ld_rep, fptr(self.box7), g.M, g.rpf)
         plan.add('t3d_boxpc_rep', a)
         x = ActSpec(self.rep, self.ld_rep, g.C + 6)
@@ -668,7 +673,7 @@ class SemiModelF:
         bp.bwd(plan, self.dout9, param_grads=False)
         n = abi.DgradNarrowArgs(bp.P1.dy_struct(), fptr(bp.P1.w), g.C, 6, fptr(self.drep), 8, g.M, 128)
         plan.add('t3d_pointmlp_dgrad_narrow', n)
-        r = abi.BoxPcRepBwdArgs(fptr(x.pc), g.C, fptr(bp.box7), fptr(self.drep), 8, 0, fptr(self.dbox7), g.B, g.rpf)
+        r = abi.BoxPcRepBwdArgs(fptr(x.pc), g.ldpc, fptr(bp.box7), fptr(self.drep), 8, 0, fptr(self.dbox7), g.B, g.rpf)
         plan.add('t3d_boxpc_rep_bwd', r)
         lo = self.loss_op
         q = abi.AnchorRegBwdArgs(fptr(self.F_out), BOX_OUT_DIMS, fptr(self.dbox7), fptr(self.d_dims), fptr(lo.dbox),

@@ -29,10 +29,10 @@ def _as_spec(ctx, inputs):
         return inputs.spec
     if isinstance(inputs, api.LazyPoints):
         e = ctx.engine
-        return ActSpec(inputs.pc.buf, e.C, inputs.ncols, sub=inputs.sub.buf if inputs.sub is not None else None, sub_ld=3)
+        return ActSpec(inputs.pc.buf, e.ldpc, inputs.ncols, sub=inputs.sub.buf if inputs.sub is not None else None, sub_ld=3)
     if isinstance(inputs, api.Placeholder):          # the raw point cloud (B,N,C)
         e = ctx.engine
-        return ActSpec(inputs.buf, e.C, e.C)
+        return ActSpec(inputs.buf, e.ldpc, e.C)
     raise TypeError('conv2d input must be a point tensor, got %r' % (inputs,))
 
 
