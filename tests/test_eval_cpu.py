@@ -150,3 +150,27 @@ def test_training_clis_read_frustum_files(tmp_path):
          '--SEMI_MULTIPLIER_FOR_WEAK_LOSS', '0.05', '--SEMI_SAMPLE_EQUAL_CLASS_WITH_PROB', '1', '--log_dir', str(tmp_path / 'c')] + small),
         rt=rt(), log=logs.append)
     assert any('refined by the Box-PC deltas' in str(l) for l in logs)
+
+
+def test_test_semisup_from_rgb_detection(tmp_path):
+    """--from_rgb_detection: a 7-list detection file (no 3-D labels); the prediction score is the detector's; --gt_path evaluates
+    against the labelled file of the same images."""
+    import gzip
+    import pickle
+    from transferable3d_amd import test_semisup as TS
+    from transferable3d_amd.dataset import load_zipped_pickle
+    gt = str(tmp_path / 'val.zip.pickle')
+    _write_frustum_file(gt, n=8, seed=7)
+    lab = load_zipped_pickle(gt)
+    det = [lab[0], lab[1], [None] * 8, lab[4], [t.encode() for t in lab[6]], lab[11], list(np.linspace(0.2, 0.9, 8))]
+    dpath = str(tmp_path / 'det.zip.pickle')
+    with gzip.open(dpath, 'wb') as f:
+        pickle.dump(det, f, 2)
+    logs = []
+    all_cls = ['bed', 'table', 'sofa', 'chair', 'toilet', 'desk', 'dresser', 'night_stand', 'bookshelf', 'bathtub']
+    FLAGS = TS.build_flags(['--semi_type', 'F', '--use_one_hot', '--num_point', '128', '--num_channels', '4', '--batch_size', '4', '--refine', '1',
+                            '--pred_prefix', 'F2_', '--test', 'B', '--data_path', dpath, '--from_rgb_detection', '--evaluate', '--gt_path', gt,
+                            '--SUNRGBD_SEMI_TEST_CLS'] + all_cls)
+    preds = TS.test(FLAGS, rt=Runtime(device='cpu', lib=FakeLib()), log=logs.append)
+    assert np.allclose(preds[9], np.linspace(0.2, 0.9, 8)) and preds[11] == lab[0] and len(preds[12]) == 8 and preds[13] is None
+    assert any(str(l).startswith('Average Precision:') for l in logs)

@@ -62,6 +62,24 @@ class DeviceFrustumSet:
         return ds
 
     @classmethod
+    def from_detection_pickle(cls, rt, path, classes=None):
+        """A frustum file extracted from 2-D detections (`--from_rgb_detection`, roi_seg_box3d_dataset.py:207-222): a gzip'd pickle of 7
+        lists [idx, box2d, image_crop, points (n,6), cls_type, frustum_angle, prob].  There are no 3-D labels: the label slots hold a
+        zero centre / heading and the class' mean size (zero residual); `prob` is the detection score."""
+        idx_l, box2d_l, _, points_l, cls_type_l, frustum_angle_l, prob_l = load_zipped_pickle(path)
+        cls_type_l = [t.decode() if isinstance(t, bytes) else t for t in cls_type_l]
+        keep = [i for i, t in enumerate(cls_type_l) if classes is None or t in classes]
+        if not keep:
+            raise ValueError('%s: no frustum of classes %s' % (path, classes))
+        pick = lambda lst: [lst[i] for i in keep]
+        ids = [type2class[t] for t in pick(cls_type_l)]
+        pts = [np.asarray(p) for p in pick(points_l)]
+        ds = cls.from_lists(rt, pts, [np.zeros(len(p), np.int32) for p in pts], pick(frustum_angle_l), np.zeros((len(keep), 3)),
+                            np.zeros(len(keep)), MEAN_DIMS_ARR[ids], ids)
+        ds.image_ids, ds.class_names, ds.box2d, ds.prob = pick(idx_l), pick(cls_type_l), pick(box2d_l), [float(p) for p in pick(prob_l)]
+        return ds
+
+    @classmethod
     def synthetic(cls, rt, n_frustums, num_channel=6, seed=0, min_points=400, max_points=3000):
         """Frustums of the SURVEY 8d distribution with ragged point counts (real frustums have a few hundred to a few thousand)."""
         host = synthetic_frustums(n_frustums, num_channel, seed, min_points, max_points)

@@ -42,6 +42,8 @@ def build_flags(argv=None):
     cfg.add_argument('--use_one_hot', action='store_true')
     cfg.add_argument('--batch_size', type=int, default=32)
     cfg.add_argument('--synthetic', action='store_true')
+    cfg.add_argument('--from_rgb_detection', action='store_true', help='--data_path holds frustums of 2-D detections (7 lists, no 3-D labels)')
+    cfg.add_argument('--gt_path', default=None, help='frustum file with the 3-D labels to evaluate detections against (evaluate.py --gt_path)')
     cfg.add_argument('--data_path', default=None, help='frustum file of the reference (frustums/*.zip.pickle); classes: --SUNRGBD_SEMI_TEST_CLS')
     cfg.add_argument('--num_channels', type=int, default=None)
     cfg.add_argument('--num_frustums', type=int, default=64)
@@ -171,7 +173,11 @@ def test_on_frustum_file(FLAGS, sess, ops, log):
     from transferable3d_amd.eval_det import evaluate_predictions, get_ap_info
     g = ops['graph']
     B = FLAGS.batch_size
-    ds = DeviceFrustumSet.from_pickle(g.rt, FLAGS.data_path, classes=list(FLAGS.SUNRGBD_SEMI_TEST_CLS) or None)
+    test_classes = list(FLAGS.SUNRGBD_SEMI_TEST_CLS) or None
+    if FLAGS.from_rgb_detection:                # main_batch_from_rgb_detection (test_semisup.py:337-423)
+        ds = DeviceFrustumSet.from_detection_pickle(g.rt, FLAGS.data_path, classes=test_classes)
+    else:
+        ds = DeviceFrustumSet.from_pickle(g.rt, FLAGS.data_path, classes=test_classes)
     source = DeviceEvalSource(g, dataset=ds, seed=FLAGS.seed)
     n_batches = (ds.F + B - 1) // B
     seg, centers, hcls, hres, scls, sres, scores = inference(sess, ops, None, None, B, prefix=FLAGS.pred_prefix,
@@ -179,13 +185,30 @@ def test_on_frustum_file(FLAGS, sess, ops, log):
     keep = slice(0, ds.F)                                          # drop the padding of the last batch
     cls = ds.cls.cpu().numpy()
     rot = np.pi / 2.0 + ds.frustum_angle.cpu().numpy().astype(np.float64)
-    predictions = [None, None, list(seg[keep]), list(centers[keep]), list(hcls[keep]), list(hres[keep]), list(scls[keep]), list(sres[keep]),
-                   list(rot), list(scores[keep]), list(cls), list(ds.image_ids), None, list(ds.box3d)]
+    if FLAGS.from_rgb_detection:                # the score is the 2-D detection's (test_semisup.py:404-406); no labels in the file
+        predictions = [None, None, list(seg[keep]), list(centers[keep]), list(hcls[keep]), list(hres[keep]), list(scls[keep]),
+                       list(sres[keep]), list(rot), list(ds.prob), list(cls), list(ds.image_ids), list(ds.box2d), None]
+    else:
+        predictions = [None, None, list(seg[keep]), list(centers[keep]), list(hcls[keep]), list(hres[keep]), list(scls[keep]),
+                       list(sres[keep]), list(rot), list(scores[keep]), list(cls), list(ds.image_ids), None, list(ds.box3d)]
     log('%d frustums of %s from %s' % (ds.F, sorted(set(ds.class_names)), FLAGS.data_path))
     if FLAGS.evaluate:
         classes = [class2type[i] for i in range(10)]
         gt_all = {}
-        for img, name, k in zip(ds.image_ids, ds.class_names, ds.box3d):
+        gt_ds = ds
+        if FLAGS.gt_path:                       # evaluate.py --gt_path: the labelled frustum file of the same images
+            from transferable3d_amd.dataset import load_zipped_pickle
+
+            class _GT:
+                pass
+            lst = load_zipped_pickle(FLAGS.gt_path)
+            gt_ds = _GT()
+            sel = [i for i, t in enumerate(lst[6]) if test_classes is None or t in test_classes]
+            gt_ds.image_ids, gt_ds.class_names = [lst[0][i] for i in sel], [lst[6][i] for i in sel]
+            gt_ds.box3d = [np.asarray(lst[2][i], np.float64) for i in sel]
+        elif FLAGS.from_rgb_detection:
+            raise ValueError('--evaluate on detections needs --gt_path (the detection file holds no 3-D labels)')
+        for img, name, k in zip(gt_ds.image_ids, gt_ds.class_names, gt_ds.box3d):
             k = k if k[0, 1] >= k[4, 1] else k[[4, 5, 6, 7, 0, 1, 2, 3]]      # y-max face first, as evaluate.py:49-52 arranges it
             gt_all.setdefault(img, []).append((name, k))
         _, _, ap, mean_ap = evaluate_predictions(predictions, gt_all, classes, rt=g.rt)
