@@ -170,7 +170,16 @@ def test_test_semisup_from_rgb_detection(tmp_path):
     all_cls = ['bed', 'table', 'sofa', 'chair', 'toilet', 'desk', 'dresser', 'night_stand', 'bookshelf', 'bathtub']
     FLAGS = TS.build_flags(['--semi_type', 'F', '--use_one_hot', '--num_point', '128', '--num_channels', '4', '--batch_size', '4', '--refine', '1',
                             '--pred_prefix', 'F2_', '--test', 'B', '--data_path', dpath, '--from_rgb_detection', '--evaluate', '--gt_path', gt,
-                            '--SUNRGBD_SEMI_TEST_CLS'] + all_cls)
+                            '--result_dir', str(tmp_path / 'res'), '--SUNRGBD_SEMI_TEST_CLS'] + all_cls)
     preds = TS.test(FLAGS, rt=Runtime(device='cpu', lib=FakeLib()), log=logs.append)
     assert np.allclose(preds[9], np.linspace(0.2, 0.9, 8)) and preds[11] == lab[0] and len(preds[12]) == 8 and preds[13] is None
     assert any(str(l).startswith('Average Precision:') for l in logs)
+    # the MATLAB-evaluation text files: one line per detection, 17 fields, the box back in the camera frame with ty at its bottom
+    lines = [l.split() for c in all_cls for l in open(tmp_path / 'res' / (c + '_pred.txt'))]
+    assert len(lines) == 8 and all(len(l) == 17 and l[2:5] == ['-1', '-1', '-10'] for l in lines)
+    i = [int(l[0]) for l in lines].index(lab[0][0])
+    h, w, l_, tx, ty, tz, ry = TS.from_prediction_to_label_format(preds[3][0], preds[4][0], preds[5][0], preds[6][0], preds[7][0], preds[8][0])
+    assert np.allclose([float(v) for v in lines[i][9:16]], [h, w, l_, tx, ty, tz, ry], atol=1e-5)
+    from oracle import ref_data as RD
+    back = RD.rotate_pc_along_y(np.asarray(preds[3][0], np.float64).reshape(1, 3), -preds[8][0]).squeeze()
+    assert np.allclose([tx, ty - h / 2, tz], back, atol=1e-9)

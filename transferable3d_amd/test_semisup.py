@@ -43,6 +43,7 @@ def build_flags(argv=None):
     cfg.add_argument('--batch_size', type=int, default=32)
     cfg.add_argument('--synthetic', action='store_true')
     cfg.add_argument('--from_rgb_detection', action='store_true', help='--data_path holds frustums of 2-D detections (7 lists, no 3-D labels)')
+    cfg.add_argument('--result_dir', default=None, help='write <class>_pred.txt files for the MATLAB evaluation')
     cfg.add_argument('--gt_path', default=None, help='frustum file with the 3-D labels to evaluate detections against (evaluate.py --gt_path)')
     cfg.add_argument('--data_path', default=None, help='frustum file of the reference (frustums/*.zip.pickle); classes: --SUNRGBD_SEMI_TEST_CLS')
     cfg.add_argument('--num_channels', type=int, default=None)
@@ -163,6 +164,32 @@ def test(FLAGS, rt=None, log=print):
     return predictions
 
 
+def from_prediction_to_label_format(center, angle_class, angle_res, size_class, size_res, rot_angle):
+    """roi_seg_box3d_dataset.py:461-466: (h, w, l, tx, ty, tz, ry) in the camera frame, ty at the box bottom."""
+    from transferable3d_amd.constants import MEAN_DIMS_ARR
+    l, w, h = MEAN_DIMS_ARR[int(size_class)] + np.asarray(size_res, np.float64)
+    ry = int(angle_class) * (2 * np.pi / NUM_HEADING_BIN) + float(angle_res)
+    ry = (ry - 2 * np.pi if ry > np.pi else ry) + rot_angle
+    c, s = np.cos(-rot_angle), np.sin(-rot_angle)                      # rotate_pc_along_y(center, -rot_angle)
+    cx, cy, cz = [float(v) for v in np.asarray(center).reshape(3)]
+    return h, w, l, c * cx - s * cz, cy + h / 2.0, s * cx + c * cz, ry
+
+
+def write_detection_results(result_dir, test_classes, predictions, class_names):
+    """test_semisup.py:262-296: one `<class>_pred.txt` per test class for the MATLAB evaluation
+    (`evaluation/sunrgbd/detection/script_3Deval.m`): `idx cls -1 -1 -10 box2d(4) h w l tx ty tz ry score` per detection."""
+    os.makedirs(result_dir, exist_ok=True)
+    files = {c: open(os.path.join(result_dir, c + '_pred.txt'), 'w') for c in test_classes}
+    _, _, _, center_l, hcls_l, hres_l, scls_l, sres_l, rot_l, score_l, _, id_l, box2d_l, _ = predictions
+    for i in range(len(center_l)):
+        box2d = box2d_l[i] if box2d_l is not None else (0.0, 0.0, 0.0, 0.0)
+        vals = from_prediction_to_label_format(center_l[i], hcls_l[i], hres_l[i], scls_l[i], sres_l[i], float(rot_l[i]))
+        files[class_names[i]].write('%d %s -1 -1 -10 %f %f %f %f %f %f %f %f %f %f %f %f\n' % (
+            (int(id_l[i]), class_names[i], box2d[0], box2d[1], box2d[2], box2d[3]) + vals + (float(score_l[i]),)))
+    for f in files.values():
+        f.close()
+
+
 def test_on_frustum_file(FLAGS, sess, ops, log):
     """main_batch (test_semisup.py:404-511) over a frustum file of the reference: the file's frustums of the test classes live in HBM,
     every batch is resampled to N points and rotated to its centre view on the device (no augmentation), the last batch is padded
@@ -192,6 +219,9 @@ def test_on_frustum_file(FLAGS, sess, ops, log):
         predictions = [None, None, list(seg[keep]), list(centers[keep]), list(hcls[keep]), list(hres[keep]), list(scls[keep]),
                        list(sres[keep]), list(rot), list(scores[keep]), list(cls), list(ds.image_ids), None, list(ds.box3d)]
     log('%d frustums of %s from %s' % (ds.F, sorted(set(ds.class_names)), FLAGS.data_path))
+    if FLAGS.result_dir:
+        write_detection_results(FLAGS.result_dir, test_classes or sorted(set(ds.class_names)), predictions, ds.class_names)
+        log('detection results written to %s' % FLAGS.result_dir)
     if FLAGS.evaluate:
         classes = [class2type[i] for i in range(10)]
         gt_all = {}
