@@ -1244,6 +1244,9 @@ extern "C" int t3d_wgrad_plan(int M, int K, int N, int* rows_per_split, int* til
   if (cap < 64) cap = 64;
   if (cap > M / 128) cap = M / 128;
   if (cap < 1) cap = 1;
+  // number of weight-gradient workgroups aimed at: more splits = shorter workgroups but more slab traffic (every split writes a
+  // K x N slab that the slab reducer reads back)
+  static const long target = []() { const char* e = getenv("T3D_WGRAD_TARGET"); return e ? atol(e) : 384L; }();
   const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
   int tk = 64, tn = 64;
   long tiles = (long)((K + 63) / 64) * (N / 64);
@@ -1251,9 +1254,9 @@ extern "C" int t3d_wgrad_plan(int M, int K, int N, int* rows_per_split, int* til
     const int ck = cand[i][0], cn = cand[i][1];
     if ((ck == 128 && K <= 64) || N % cn) continue;
     const long t = (long)((K + ck - 1) / ck) * (N / cn);
-    if (t * cap >= 512) { tk = ck; tn = cn; tiles = t; break; }
+    if (t * cap >= target) { tk = ck; tn = cn; tiles = t; break; }
   }
-  long want = (512 + tiles - 1) / tiles;
+  long want = (target + tiles - 1) / tiles;
   if (want > cap) want = cap;
   int s = 1;
   while ((long)s * 2 <= want && M % (s * 2) == 0 && (M / (s * 2)) % BK == 0) s *= 2;
