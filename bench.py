@@ -231,6 +231,7 @@ def main():
     global LIB
     LIB = rt.lib
     g = Graph(B, N, C, rt=rt, seed=0)              # identical initial weights on every rank
+    g.inline_dropout, g.dropout_seed = True, 1234 + rank      # the seg head draws its dropout mask in its own kernel
     prefixes = None
     if args.workload == 'A':
         c = make_parser().parse_special_args(['--SEMI_MODEL', 'A', '--WEAK_WEIGHT_REPROJECTION', '0', '--WEAK_WEIGHT_SURFACE', '0'])

@@ -416,6 +416,10 @@ typedef struct {
   float* psum_dzy;           /* [M/128,K] */
   float* dw_part;            /* [M/128,K,2] */
   int M, K, rows_per_frustum, B;
+  /* drop_mask == NULL, keep_prob < 1, drop_hyper != NULL: the keep mask is generated where it is consumed, element (m,k) from
+   * (drop_seed, step = drop_hyper[0], index m*K + k) with the generator of t3d_dropout_mask -- no [M,K] mask tensor in HBM. */
+  uint32_t drop_seed;
+  const float* drop_hyper;
 } t3d_seg_head_args;
 int t3d_seg_head(const t3d_seg_head_args* args, t3d_stream_t stream);
 

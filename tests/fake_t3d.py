@@ -18,6 +18,20 @@ MEAN32 = MEAN_DIMS_ARR.astype(np.float32)
 BINS32 = (np.arange(NH) * (2.0 * np.pi / 12.0)).astype(np.float32)
 
 
+def hash_keep_mask(seed, step, n, keep):
+    """The keep mask of k_dropout_mask (bn_optim.hip) / the inline generator of k_seg_head: element i from (seed, step, i)."""
+    M64 = (1 << 64) - 1
+    key = np.uint64(((seed << 32) ^ ((step * 0x9E3779B97F4A7C15) & M64)) & M64)
+    with np.errstate(over='ignore'):
+        x = key + np.arange(n, dtype=np.uint64) * np.uint64(0xD6E8FEB86659FD93)
+        x = x ^ (x >> np.uint64(33)); x = x * np.uint64(0xff51afd7ed558ccd)
+        x = x ^ (x >> np.uint64(33)); x = x * np.uint64(0xc4ceb9fe1a85ec53)
+        x = x ^ (x >> np.uint64(33))
+    r = (x >> np.uint64(16)).astype(np.uint32)
+    u = (r >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return (u < np.float32(keep)).astype(np.float32)
+
+
 def _ccw(q):
     a2 = np.sum(q[:, 0] * np.roll(q[:, 1], -1) - q[:, 1] * np.roll(q[:, 0], -1))
     return q if a2 >= 0 else q[[0, 3, 2, 1]]
@@ -759,6 +773,8 @@ class FakeLib:
         keep = np.full((M, K), 1.0)
         if p.drop_mask:
             keep = arr(p.drop_mask, M, K).astype(np.float64) / p.keep_prob
+        elif p.drop_hyper and p.keep_prob < 1.0:
+            keep = hash_keep_mask(p.drop_seed, int(arr(p.drop_hyper, 1)[0]), M * K, p.keep_prob).reshape(M, K).astype(np.float64) / p.keep_prob
         d = np.maximum(z, 0) * keep
         w = arr(p.w, K, 2).astype(np.float64)
         logits = (d @ w + arr(p.bias, 2)).astype(np.float32)
@@ -1140,7 +1156,5 @@ class FakeLib:
         return 0
 
     def t3d_dropout_mask(self, mask, n, keep, seed, hyper, stream):
-        step = int(arr(hyper, 4)[0])
-        r = np.random.RandomState((seed * 1000003 + step) % (2 ** 31))
-        arr(mask, n)[:] = (r.uniform(size=n) < keep).astype(np.float32)
+        arr(mask, n)[:] = hash_keep_mask(seed, int(arr(hyper, 4)[0]), n, keep)
         return 0

@@ -1221,3 +1221,45 @@ def test_box_head_iou_and_strong_loss_summary(hip_lib):
                                   yor.astype(np.float64), ydc, ydr.astype(np.float64))
     assert np.abs(g['i3'].numpy() - w3).max() < 2e-5 and np.abs(g['i2'].numpy() - w2).max() < 2e-5
     assert (w3 > 0.2).sum() >= 5
+
+
+def test_seg_head_inline_dropout_equals_the_stored_mask(hip_lib):
+    """drop_mask == NULL with a seed: the head draws the keep mask itself; bit-identical to running it on the mask tensor that
+    t3d_dropout_mask writes for the same (seed, step)."""
+    r = np.random.RandomState(2)
+    M, K, rpf = 1024, 128, 256
+    B, T = M // rpf, M // 128
+    dev = _dev('cuda')
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    t = {k: _mk(dev, v) for k, v in dict(
+        y=r.normal(size=(M, K)).astype(np.float32), sc=(0.5 + r.uniform(size=K)).astype(np.float32), sh=(r.normal(size=K) * 0.1).astype(np.float32),
+        w=(r.normal(size=(K, 2)) * 0.2).astype(np.float32), b=np.zeros(2, np.float32), lab=(r.uniform(size=M) < 0.3).astype(np.int32),
+        is2d=np.zeros(B, np.int32), pc=r.normal(size=(M, 4)).astype(np.float32)).items()}
+    hyper = torch.tensor([7.0, 0, 0, 0], device=dev)
+    mask = torch.zeros(M, K, device=dev)
+    assert hip_lib.t3d_dropout_mask(fptr(mask), M * K, 0.5, 4321, fptr(hyper), st) == 0
+    assert 0.45 < float(mask.mean()) < 0.55
+
+    def run(inline):
+        o = dict(logits=torch.zeros(M, 2, device=dev), mask=torch.zeros(M, device=dev), part=torch.zeros(T, 8, device=dev),
+                 dz=torch.zeros(M, K, device=dev), p1=torch.zeros(T, K, device=dev), p2=torch.zeros(T, K, device=dev),
+                 dw=torch.zeros(T, K, 2, device=dev))
+        a = abi.SegHeadArgs()
+        a.y, a.scale, a.shift, a.keep_prob, a.w, a.bias = fptr(t['y']), fptr(t['sc']), fptr(t['sh']), 0.5, fptr(t['w']), fptr(t['b'])
+        a.labels, a.is_data_2D, a.pc, a.ld_pc, a.ce_weight = iptr(t['lab']), iptr(t['is2d']), fptr(t['pc']), 4, 1.0
+        a.logits, a.mask, a.part, a.dz, a.psum_dz, a.psum_dzy, a.dw_part = fptr(o['logits']), fptr(o['mask']), fptr(o['part']), fptr(o['dz']), \
+            fptr(o['p1']), fptr(o['p2']), fptr(o['dw'])
+        a.M, a.K, a.rows_per_frustum, a.B = M, K, rpf, B
+        if inline:
+            a.drop_seed, a.drop_hyper = 4321, fptr(hyper)
+        else:
+            a.drop_mask = fptr(mask)
+        assert hip_lib.t3d_seg_head(C.byref(a), st) == 0
+        torch.cuda.synchronize()
+        return {k: v.cpu() for k, v in o.items()}
+    a, b = run(True), run(False)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    # the specification draws the same mask
+    from fake_t3d import hash_keep_mask
+    assert np.array_equal(hash_keep_mask(4321, 7, M * K, 0.5).reshape(M, K), mask.cpu().numpy())

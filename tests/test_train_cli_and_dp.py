@@ -18,7 +18,8 @@ ARGS = ['--SEMI_MODEL', 'A', '--WEAK_WEIGHT_REPROJECTION', '0', '--WEAK_WEIGHT_S
 
 
 def test_cli_trains_and_loss_decreases(tmp_path):
-    FLAGS = build_flags(ARGS + ['--log_dir', str(tmp_path)])
+    # every step sees a fresh synthetic batch (and fresh dropout draws): a learning rate that moves the loss well beyond that noise
+    FLAGS = build_flags(ARGS + ['--log_dir', str(tmp_path), '--learning_rate', '0.005'])
     logs = []
     _, last = train(FLAGS, rt=Runtime(device='cpu', lib=FakeLib()), log=logs.append)
     epochs = [l for l in logs if l.startswith('**** EPOCH')]
@@ -74,13 +75,12 @@ def test_data_parallel_world_size_2_gloo(tmp_path):
     grads = []
     for rank in range(world):
         g = Graph(4, 128, 4, rt=rt, seed=0)
+        g.inline_dropout, g.dropout_seed = True, 1234 + rank       # as the driver: the seg head draws its own mask from (seed, step)
         m = SemiModelA(g, R.default_config())
         m.emit_forward(g.fwd, True, True)
         m.emit_backward(g.bwd)
         g.finalize()
-        g.emit_dropout_masks(g.pre, seed=1234 + rank)
         g.hyper[0] = 1.0                     # masks are drawn after the schedule kernel bumped the step to 1
-        g.pre.run()
         m.inputs.load(make_batch(4, 128, 4, seed=0 * 1000003 + 0 * world + rank))
         g.fwd.run()
         g.bwd.run()

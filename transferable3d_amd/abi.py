@@ -164,7 +164,7 @@ class SegHeadArgs(C.Structure):
     _fields_ = [('y', F), ('scale', F), ('shift', F), ('drop_mask', F), ('keep_prob', f32), ('w', F), ('bias', F),
                 ('labels', I), ('is_data_2D', I), ('pc', F), ('ld_pc', i32), ('ce_weight', f32), ('logits', F),
                 ('mask', F), ('part', F), ('dz', F), ('psum_dz', F), ('psum_dzy', F), ('dw_part', F),
-                ('M', i32), ('K', i32), ('rows_per_frustum', i32), ('B', i32)]
+                ('M', i32), ('K', i32), ('rows_per_frustum', i32), ('B', i32), ('drop_seed', C.c_uint32), ('drop_hyper', F)]
 
 
 class SegFinalizeArgs(C.Structure):

@@ -70,8 +70,10 @@ class LazyPoints(Tensor):
 class Graph:
     """tf.Graph analogue: owns the runtime, the variable store and the recorded model assembly."""
 
-    def __init__(self, rt=None, seed=0, vars=None):
-        self._rt, self.seed, self._vars = rt, seed, vars
+    def __init__(self, rt=None, seed=0, vars=None, inline_dropout=False):
+        """inline_dropout: the segmentation head draws its dropout mask inside its kernel (no [M,128] mask tensor, no mask launch); a
+        graph built this way cannot be fed an explicit mask for that scope."""
+        self._rt, self.seed, self._vars, self.inline_dropout = rt, seed, vars, inline_dropout
         self.engine = None          # nets.Graph, created by the first placeholder_inputs
         self.inputs = None
         self.assembly = None
@@ -100,6 +102,7 @@ class Graph:
         if self.engine is None:
             vs = self._vars or VarStore(self.rt, seed=self.seed)
             self.engine = _EngineGraph(batch_size, num_point, num_channel, rt=self.rt, seed=self.seed, vars=vs)
+            self.engine.inline_dropout = self.inline_dropout
             self.inputs = Inputs(self.engine)
         else:
             e = self.engine
@@ -209,6 +212,7 @@ class Session:
         assert not (train and e.finalized), 'the training step must be compiled before any forward-only schedule of the graph'
         asm = g.assembly
         pre, fwd, bwd, opt = Plan(e.rt), Plan(e.rt), Plan(e.rt), Plan(e.rt)
+        e.dropout_seed = self.dropout_seed
         with_loss = g.loss is not None
         if train:
             top = g.train_op

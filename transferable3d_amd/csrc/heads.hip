@@ -16,6 +16,15 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 constexpr int SH_WAVES = 16, SH_ROWS = 128 / SH_WAVES, SH_LD = 128 * 4 + 8;
 
+__device__ __forceinline__ float drop_keep(uint64_t key, size_t i, float keep) {
+  uint64_t x = key + (uint64_t)i * 0xD6E8FEB86659FD93ULL;
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
+  x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
+  x ^= x >> 33;
+  const uint32_t r = (uint32_t)(x >> 16);
+  return (float)(r >> 8) * (1.0f / 16777216.0f) < keep ? 1.f : 0.f;
+}
+
 __global__ __launch_bounds__(64 * SH_WAVES) void k_seg_head(const t3d_seg_head_args p) {
   __shared__ float red[SH_WAVES][SH_LD];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -29,7 +38,9 @@ __global__ __launch_bounds__(64 * SH_WAVES) void k_seg_head(const t3d_seg_head_a
   const bool train = p.labels != nullptr;
   const bool bwd = p.dz != nullptr;
   const float wb = train ? p.ce_weight * (float)(1 - p.is_data_2D[b]) / ((float)p.B * (float)p.rows_per_frustum) : 0.f;
-  const float inv_keep = p.drop_mask ? 1.0f / p.keep_prob : 1.f;
+  const bool gen = p.drop_mask == nullptr && p.drop_hyper != nullptr && p.keep_prob < 1.f;
+  const float inv_keep = (p.drop_mask || gen) ? 1.0f / p.keep_prob : 1.f;
+  const uint64_t dkey = gen ? (((uint64_t)p.drop_seed << 32) ^ ((uint64_t)p.drop_hyper[0] * 0x9E3779B97F4A7C15ULL)) : 0ull;
 
   float sdz0 = 0.f, sdz1 = 0.f, sdzy0 = 0.f, sdzy1 = 0.f, dw00 = 0.f, dw01 = 0.f, dw10 = 0.f, dw11 = 0.f;
   float ce_sum = 0.f, cnt = 0.f, sx = 0.f, sy = 0.f, sz = 0.f, db0 = 0.f, db1 = 0.f, ncorr = 0.f;
@@ -41,7 +52,12 @@ __global__ __launch_bounds__(64 * SH_WAVES) void k_seg_head(const t3d_seg_head_a
     for (int u = 0; u < 2; ++u) {
       const size_t o = (size_t)(row0 + wid * SH_ROWS + i + u) * 128 + ch;
       y[u] = *reinterpret_cast<const float2*>(p.y + o);
-      km[u] = p.drop_mask ? *reinterpret_cast<const float2*>(p.drop_mask + o) : make_float2(1.f, 1.f);
+      if (gen) {                      // same generator and element index as k_dropout_mask (bn_optim.hip)
+        km[u].x = drop_keep(dkey, o, p.keep_prob);
+        km[u].y = drop_keep(dkey, o + 1, p.keep_prob);
+      } else {
+        km[u] = p.drop_mask ? *reinterpret_cast<const float2*>(p.drop_mask + o) : make_float2(1.f, 1.f);
+      }
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {

@@ -36,6 +36,9 @@ class Graph:
         self.hyper[2] = 0.5
         self.bn_decay_ptr = self.hyper[2:3]
         self.dropout_masks = {}                    # scope -> (mask tensor, keep_prob)
+        # the seg head's [M,128] keep mask generated inside the head kernel instead of stored (production drivers); parity tests
+        # inject explicit masks and leave this off
+        self.inline_dropout, self.dropout_seed = False, 1234
         self.deferred_slab_ptrs = []
         self.fwd = Plan(self.rt)
         self.bwd = Plan(self.rt)
@@ -143,8 +146,10 @@ class InstSegNet:
         self.w10 = vs.xavier(s + 'conv10/weights', (1, 1, 128, 2), 128, 2).view(128, 2)
         self.b10 = vs.const(s + 'conv10/biases', (2,), 0.0)
         rt, M, T, B = g.rt, g.M, g.M // TILE, g.B
-        self.drop_mask = rt.full((M, 128), 1.0)
-        g.dropout_masks[s + 'dp1'] = (self.drop_mask, 0.5)
+        self.drop_mask = None
+        if not g.inline_dropout:
+            self.drop_mask = rt.full((M, 128), 1.0)
+            g.dropout_masks[s + 'dp1'] = (self.drop_mask, 0.5)
         self.logits, self.mask = rt.zeros(M, 2), rt.zeros(M)
         self.part = rt.zeros(T, 8)
         self.mask_xyz_mean, self.seg_loss, self.n_correct = rt.zeros(B, 3), rt.zeros(B), rt.zeros(1)
@@ -170,6 +175,8 @@ class InstSegNet:
         h.y, h.scale, h.shift = fptr(L9.y), fptr(L9.scale), fptr(L9.shift)
         if is_training:
             h.drop_mask, h.keep_prob = fptr(self.drop_mask), 0.5
+            if self.drop_mask is None:
+                h.drop_seed, h.drop_hyper = (g.dropout_seed + 0x5EED) & 0xffffffff, fptr(g.hyper)
         h.w, h.bias = fptr(self.w10), fptr(self.b10)
         h.labels, h.is_data_2D = iptr(labels), iptr(is_data_2D)
         h.pc, h.ld_pc, h.ce_weight = fptr(pc), g.ldpc, ce_weight

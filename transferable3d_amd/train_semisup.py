@@ -166,7 +166,7 @@ def train(FLAGS, rt=None, log=print):
     os.makedirs(FLAGS.log_dir, exist_ok=True)
     if rank == 0:
         log(FLAGS.config_str)
-    with api.Graph(rt=rt, seed=FLAGS.seed).as_default() as g:
+    with api.Graph(rt=rt, seed=FLAGS.seed, inline_dropout=True).as_default() as g:
         pls = MODEL.placeholder_inputs(B, N, C)
         pc_pl, bg_pc_pl, img_pl, one_hot_vec_pl, y_seg_pl, y_centers_pl, y_orient_cls_pl, y_orient_reg_pl, y_dims_cls_pl, \
             y_dims_reg_pl, R0_rect_pl, P_pl, Rtilt_pl, K_pl, rot_frust_pl, box2D_pl, img_dim_pl, is_data_2D_pl = pls

@@ -131,7 +131,7 @@ def train(FLAGS, rt=None, log=print):
     os.makedirs(FLAGS.log_dir, exist_ok=True)
     if FLAGS.SEMI_TRAIN_BOXPC_MODEL or FLAGS.SEMI_ADV_ITERS_FOR_D:
         raise NotImplementedError('training the Box-PC branch in stage c is dead code in the reference (SEMI_ADV_ITERS_FOR_D = 0)')
-    with api.Graph(rt=rt, seed=FLAGS.seed).as_default() as g:
+    with api.Graph(rt=rt, seed=FLAGS.seed, inline_dropout=True).as_default() as g:
         pls = MODEL.placeholder_inputs(B, N, C)
         is_training_pl = api.is_training_placeholder()                    # train_semisup_adv.py:300 (is_training_D stays False)
         pred, end_points = MODEL.get_semi_model(pls[0], pls[1], pls[2], pls[3], is_training_pl, use_one_hot=FLAGS.use_one_hot, c=FLAGS)
