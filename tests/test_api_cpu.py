@@ -237,3 +237,21 @@ def test_is_training_placeholder_selects_train_and_eval_schedules_of_one_graph()
         # ... and a training step afterwards still works (its schedule was compiled first)
         sess.run([semi_loss, train_op], feed_dict=f)
         assert float(g.engine.hyper[0]) == step_after_train + 1
+
+
+def test_inline_dropout_graph_rejects_an_explicit_mask():
+    B, N, C = 4, 128, 4
+    FLAGS = _flags()
+    batch = make_batch(B, N, C, seed=8, dropout_scopes={'inst_seg/dp1': ((B, N, 128), 0.5)})
+    with api.Graph(rt=Runtime(device='cpu', lib=FakeLib()), seed=3, inline_dropout=True).as_default() as g:
+        pls = MODEL.placeholder_inputs(B, N, C)
+        pred, end_points = MODEL.get_semi_model(pls[0], pls[1], pls[2], pls[3], True, use_one_hot=False, norm_box2D=None, bn_decay=None, c=FLAGS)
+        loss = MODEL.get_semi_loss(pred, tuple(pls[4:]), end_points, c=FLAGS)
+        train_op = api.AdamOptimizer(1e-3).minimize(loss)
+        sess = api.Session()
+        feed = {pls[0]: batch['pc'], pls[3]: batch['one_hot_vec'], pls[4]: batch['y_seg'], pls[5]: batch['y_center'], pls[6]: batch['y_orient_cls'],
+                pls[7]: batch['y_orient_reg'], pls[8]: batch['y_dims_cls'], pls[9]: batch['y_dims_reg'], pls[17]: batch['is_data_2D']}
+        with pytest.raises(ValueError):
+            sess.run([loss, train_op], feed_dict=dict(feed, **{'inst_seg/dp1': batch['dropout_masks']['inst_seg/dp1']}))
+        l1, _ = sess.run([loss, train_op], feed_dict=feed)
+        assert np.isfinite(l1) and 'inst_seg/dp1' not in g.engine.dropout_masks and len(sess.steps['train'].pre) == 1   # schedule only

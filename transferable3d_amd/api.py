@@ -252,6 +252,10 @@ class Session:
             elif isinstance(pl, str):                      # dropout-mask injection for parity tests: scope -> mask
                 masks[pl] = np.asarray(val)
         if masks:
+            unknown = [k for k in masks if k not in self.g.engine.dropout_masks]
+            if unknown:
+                raise ValueError('no stored dropout mask for scope(s) %s (a graph built with inline_dropout=True draws the segmentation '
+                                 'head mask inside its kernel)' % unknown)
             batch['dropout_masks'] = masks
         if isinstance(self.g.is_training, BoolPlaceholder) and mode is None:
             if not train:
