@@ -16,6 +16,22 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 constexpr int SH_WAVES = 16, SH_ROWS = 128 / SH_WAVES, SH_LD = 128 * 4 + 8;
 
+// Sum over the 64 lanes with data-parallel-primitive moves (six VALU adds) instead of six ds_bpermute round trips through the LDS
+// crossbar; the total is read from lane 63 and returned in every lane.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v = dpp_add<0xb1>(v);      // quad_perm [1,0,3,2]
+  v = dpp_add<0x4e>(v);      // quad_perm [2,3,0,1]
+  v = dpp_add<0x124>(v);     // row_ror:4
+  v = dpp_add<0x128>(v);     // row_ror:8   -> every lane holds the sum of its row of 16
+  v = dpp_add<0x142>(v);     // row_bcast:15 -> last lane of rows 1..3 adds the previous row's sum
+  v = dpp_add<0x143>(v);     // row_bcast:31 -> lane 63 holds the wave's sum
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 __device__ __forceinline__ float drop_keep(uint64_t key, size_t i, float keep) {
   uint64_t x = key + (uint64_t)i * 0xD6E8FEB86659FD93ULL;
   x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
@@ -67,14 +83,11 @@ __global__ __launch_bounds__(64 * SH_WAVES) void k_seg_head(const t3d_seg_head_a
       l0[u] = fmaf(d0[u], w00, d1[u] * w10);
       l1[u] = fmaf(d0[u], w01, d1[u] * w11);
     }
-    // four independent butterfly reductions, interleaved
+    // four independent wave sums
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        l0[u] += __shfl_xor(l0[u], off, 64);
-        l1[u] += __shfl_xor(l1[u], off, 64);
-      }
+    for (int u = 0; u < 2; ++u) {
+      l0[u] = wave_sum_dpp(l0[u]);
+      l1[u] = wave_sum_dpp(l1[u]);
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
