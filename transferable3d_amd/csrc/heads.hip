@@ -59,67 +59,75 @@ __global__ __launch_bounds__(64 * SH_WAVES) void k_seg_head(const t3d_seg_head_a
   const uint64_t dkey = gen ? (((uint64_t)p.drop_seed << 32) ^ ((uint64_t)p.drop_hyper[0] * 0x9E3779B97F4A7C15ULL)) : 0ull;
 
   float sdz0 = 0.f, sdz1 = 0.f, sdzy0 = 0.f, sdzy1 = 0.f, dw00 = 0.f, dw01 = 0.f, dw10 = 0.f, dw11 = 0.f;
-  float ce_sum = 0.f, cnt = 0.f, sx = 0.f, sy = 0.f, sz = 0.f, db0 = 0.f, db1 = 0.f, ncorr = 0.f;
 
-  for (int i = 0; i < SH_ROWS; i += 2) {
-    float2 y[2], km[2];
-    float z0[2], z1[2], d0[2], d1[2], l0[2], l1[2];
+  // Phase A -- the wave's SH_ROWS rows, channel-parallel: dropout(relu(bn(y))) and the two logits of every row (wave sums).
+  const int rbase = row0 + wid * SH_ROWS;
+  float2 y[SH_ROWS], km[SH_ROWS];
+  float d0[SH_ROWS], d1[SH_ROWS], q0r[SH_ROWS], q1r[SH_ROWS];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const size_t o = (size_t)(row0 + wid * SH_ROWS + i + u) * 128 + ch;
-      y[u] = *reinterpret_cast<const float2*>(p.y + o);
-      if (gen) {                      // same generator and element index as k_dropout_mask (bn_optim.hip)
-        km[u].x = drop_keep(dkey, o, p.keep_prob);
-        km[u].y = drop_keep(dkey, o + 1, p.keep_prob);
-      } else {
-        km[u] = p.drop_mask ? *reinterpret_cast<const float2*>(p.drop_mask + o) : make_float2(1.f, 1.f);
-      }
+  for (int i = 0; i < SH_ROWS; ++i) {
+    const size_t o = (size_t)(rbase + i) * 128 + ch;
+    y[i] = *reinterpret_cast<const float2*>(p.y + o);
+    if (gen) {                      // same generator and element index as k_dropout_mask (bn_optim.hip)
+      km[i].x = drop_keep(dkey, o, p.keep_prob);
+      km[i].y = drop_keep(dkey, o + 1, p.keep_prob);
+    } else {
+      km[i] = p.drop_mask ? *reinterpret_cast<const float2*>(p.drop_mask + o) : make_float2(1.f, 1.f);
     }
+  }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      z0[u] = fmaf(y[u].x, sc.x, sh.x); z1[u] = fmaf(y[u].y, sc.y, sh.y);
-      km[u].x *= inv_keep; km[u].y *= inv_keep;
-      d0[u] = fmaxf(z0[u], 0.f) * km[u].x; d1[u] = fmaxf(z1[u], 0.f) * km[u].y;
-      l0[u] = fmaf(d0[u], w00, d1[u] * w10);
-      l1[u] = fmaf(d0[u], w01, d1[u] * w11);
+  for (int i = 0; i < SH_ROWS; ++i) {
+    km[i].x *= inv_keep; km[i].y *= inv_keep;
+    d0[i] = fmaxf(fmaf(y[i].x, sc.x, sh.x), 0.f) * km[i].x;
+    d1[i] = fmaxf(fmaf(y[i].y, sc.y, sh.y), 0.f) * km[i].y;
+    q0r[i] = wave_sum_dpp(fmaf(d0[i], w00, d1[i] * w10)) + b0;
+    q1r[i] = wave_sum_dpp(fmaf(d0[i], w01, d1[i] * w11)) + b1;
+  }
+
+  // Phase B -- row-parallel: lane r < SH_ROWS owns row r.  The soft-max / cross-entropy arithmetic (three transcendentals per row)
+  // is issued once for the eight rows instead of once per row with all 64 lanes computing the same numbers.
+  float q0 = q0r[0], q1 = q1r[0];
+#pragma unroll
+  for (int i = 1; i < SH_ROWS; ++i) { q0 = lane == i ? q0r[i] : q0; q1 = lane == i ? q1r[i] : q1; }
+  const bool own = lane < SH_ROWS;
+  const int row = rbase + (lane & (SH_ROWS - 1));
+  const float m = q0 < q1 ? 1.f : 0.f;
+  if (own) {
+    *reinterpret_cast<float2*>(p.logits + (size_t)row * 2) = make_float2(q0, q1);
+    p.mask[row] = m;
+  }
+  const float ownf = own ? 1.f : 0.f;
+  const float px = p.pc[(size_t)row * p.ld_pc], py = p.pc[(size_t)row * p.ld_pc + 1], pz = p.pc[(size_t)row * p.ld_pc + 2];
+  float cnt = ownf * m, sx = cnt * px, sy = cnt * py, sz = cnt * pz;
+  float ce_sum = 0.f, ncorr = 0.f, g0 = 0.f, g1 = 0.f;
+  if (train) {
+    const int lab = p.labels[row];
+    const float mx = fmaxf(q0, q1);
+    const float lse = mx + logf(expf(q0 - mx) + expf(q1 - mx));
+    ce_sum = ownf * (lse - (lab ? q1 : q0));
+    ncorr = ownf * (((q1 > q0 ? 1 : 0) == lab) ? 1.f : 0.f);
+    if (bwd) {
+      g0 = ownf * wb * (expf(q0 - lse) - (lab == 0 ? 1.f : 0.f));
+      g1 = ownf * wb * (expf(q1 - lse) - (lab == 1 ? 1.f : 0.f));
     }
-    // four independent wave sums
+  }
+  cnt = wave_sum_dpp(cnt); sx = wave_sum_dpp(sx); sy = wave_sum_dpp(sy); sz = wave_sum_dpp(sz);
+  ce_sum = wave_sum_dpp(ce_sum); ncorr = wave_sum_dpp(ncorr);
+  const float db0 = wave_sum_dpp(g0), db1 = wave_sum_dpp(g1);
+
+  // Phase C -- channel-parallel again: the logit gradients of row i come back from lane i.
+  if (bwd) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      l0[u] = wave_sum_dpp(l0[u]);
-      l1[u] = wave_sum_dpp(l1[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int row = row0 + wid * SH_ROWS + i + u;
-      const size_t o = (size_t)row * 128 + ch;
-      const float q0 = l0[u] + b0, q1 = l1[u] + b1;
-      const float m = q0 < q1 ? 1.f : 0.f;
-      if (lane == 0) {
-        *reinterpret_cast<float2*>(p.logits + (size_t)row * 2) = make_float2(q0, q1);
-        p.mask[row] = m;
-      }
-      const float px = p.pc[(size_t)row * p.ld_pc], py = p.pc[(size_t)row * p.ld_pc + 1], pz = p.pc[(size_t)row * p.ld_pc + 2];
-      cnt += m; sx += m * px; sy += m * py; sz += m * pz;
-      if (train) {
-        const int lab = p.labels[row];
-        const float mx = fmaxf(q0, q1);
-        const float lse = mx + logf(expf(q0 - mx) + expf(q1 - mx));
-        ce_sum += lse - (lab ? q1 : q0);
-        ncorr += ((q1 > q0 ? 1 : 0) == lab) ? 1.f : 0.f;
-        if (bwd) {
-          const float g0 = wb * (expf(q0 - lse) - (lab == 0 ? 1.f : 0.f));
-          const float g1 = wb * (expf(q1 - lse) - (lab == 1 ? 1.f : 0.f));
-          db0 += g0; db1 += g1;
-          dw00 = fmaf(d0[u], g0, dw00); dw01 = fmaf(d0[u], g1, dw01);
-          dw10 = fmaf(d1[u], g0, dw10); dw11 = fmaf(d1[u], g1, dw11);
-          const float dz0 = z0[u] > 0.f ? (g0 * w00 + g1 * w01) * km[u].x : 0.f;
-          const float dz1 = z1[u] > 0.f ? (g0 * w10 + g1 * w11) * km[u].y : 0.f;
-          *reinterpret_cast<float2*>(p.dz + o) = make_float2(dz0, dz1);
-          sdz0 += dz0; sdz1 += dz1;
-          sdzy0 = fmaf(dz0, y[u].x, sdzy0); sdzy1 = fmaf(dz1, y[u].y, sdzy1);
-        }
-      }
+    for (int i = 0; i < SH_ROWS; ++i) {
+      const float G0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g0), i));
+      const float G1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g1), i));
+      dw00 = fmaf(d0[i], G0, dw00); dw01 = fmaf(d0[i], G1, dw01);
+      dw10 = fmaf(d1[i], G0, dw10); dw11 = fmaf(d1[i], G1, dw11);
+      const float dz0 = fmaf(y[i].x, sc.x, sh.x) > 0.f ? (G0 * w00 + G1 * w01) * km[i].x : 0.f;
+      const float dz1 = fmaf(y[i].y, sc.y, sh.y) > 0.f ? (G0 * w10 + G1 * w11) * km[i].y : 0.f;
+      *reinterpret_cast<float2*>(p.dz + (size_t)(rbase + i) * 128 + ch) = make_float2(dz0, dz1);
+      sdz0 += dz0; sdz1 += dz1;
+      sdzy0 = fmaf(dz0, y[i].x, sdzy0); sdzy1 = fmaf(dz1, y[i].y, sdzy1);
     }
   }
   float* r = red[wid];
