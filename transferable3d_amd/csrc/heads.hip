@@ -373,11 +373,25 @@ __global__ __launch_bounds__(1024) void k_strong_loss(const t3d_strong_loss_args
     for (int d = 0; d < 3; ++d)
       p.reg_dims[b * 3 + d] = fmaxf(kMeanDims[ks][d] + o[3 + 2 * NH + NS + 3 * ks + d] * kMeanDims[ks][d], 1e-5f);
     p.reg_theta[b] = bin_center(js) + o[3 + NH + js] * (3.14159265358979323846f / NH);
-    if (p.iou3d) {
+    if (p.iou3d && p.B > 512) {          // small batches: the summary runs beside the loss, in another wave (below)
       float i2;
       p.iou3d[b] = head_iou(o, cen, yc, j, yor, k, ydr, &i2);
       p.iou2d[b] = i2;
     }
+  }
+  // the IoU summary of frustum f on thread 512 + f: a different wave than the loss of f, so the two serial chains overlap
+  if (p.iou3d && p.B <= 512 && b >= 512 && b - 512 < p.B) {
+    const int f = b - 512;
+    const float* o = p.box + (size_t)f * p.ld_box;
+    float cen[3], yc[3], ydr[3];
+    for (int d = 0; d < 3; ++d) {
+      cen[d] = o[d] + p.stage1_center[f * 3 + d];
+      yc[d] = p.y_center[f * 3 + d];
+      ydr[d] = p.y_dims_reg[f * 3 + d];
+    }
+    float i2;
+    p.iou3d[f] = head_iou(o, cen, yc, p.y_orient_cls[f], p.y_orient_reg[f], p.y_dims_cls[f], ydr, &i2);
+    p.iou2d[f] = i2;
   }
   __syncthreads();
   red[b] = total;
