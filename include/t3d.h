@@ -261,7 +261,10 @@ typedef struct {
   const float* wc;         /* [N,K] */
   int B, N, K;
   int rows_per_frustum;
-  float* s;                /* [B*rows_per_frustum, K] out (every row written) */
+  float* s;                /* [B*rows_per_frustum, K] out (every row written when row_live is NULL) */
+  int32_t* row_live;       /* [B*rows_per_frustum] out or NULL: 1 where the row received a hit, else 0.  When given, rows of `s`
+                            * without a hit are NOT written (a few percent of the rows carry arg-max hits; the dense zero rows
+                            * were most of this kernel's HBM traffic) and the reader must gate on it (add_live below). */
 } t3d_pool_sparse_rows_args;
 int t3d_pool_sparse_rows(const t3d_pool_sparse_rows_args* args, t3d_stream_t stream);
 
@@ -272,6 +275,7 @@ typedef struct {
   const float* p;          /* [K,K] */
   const float* rowconst;   /* [K] or NULL */
   const float* add_in;     /* [M,K] or NULL (the sparse rows S) */
+  const int32_t* add_live; /* [M] or NULL: add_in is read only on rows whose flag is non-zero (row_live of t3d_pool_sparse_rows) */
   const float* prev_y;     /* [M,K] or NULL */
   const float* prev_scale;
   const float* prev_shift;

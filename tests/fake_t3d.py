@@ -268,6 +268,12 @@ class FakeLib:
         for b in range(B):
             for n in np.nonzero(ai[b] >= 0)[0]:
                 s[b * rpf + ai[b, n]] += dp[b, n] * wc[n]
+        if p.row_live:                 # rows without a hit are not written: poison them so that a reader that ignores the flags shows
+            live = np.zeros(B * rpf, np.int32)
+            for b in range(B):
+                live[b * rpf + ai[b][ai[b] >= 0]] = 1
+            arr(p.row_live, B * rpf)[:] = live
+            s[live == 0] = np.nan
         arr(p.s, B * rpf, K)[:] = s
         return 0
 
@@ -277,8 +283,12 @@ class FakeLib:
         da = _act(p.a, M, K, rpf) @ arr(p.p, K, K).astype(np.float64)
         if p.rowconst:
             da = da + arr(p.rowconst, K)
-        if p.add_in:
+        if p.add_in and p.add_live:
+            da = da + np.where(arr(p.add_live, M)[:, None] != 0, arr(p.add_in, M, K), 0.0)
+        elif p.add_in:
             da = da + arr(p.add_in, M, K)
+        elif p.add_live:
+            return -1
         if p.prev_y:
             yp = arr(p.prev_y, M, K).astype(np.float64)
             da = np.where(yp * arr(p.prev_scale, K) + arr(p.prev_shift, K) > 0, da, 0.0)

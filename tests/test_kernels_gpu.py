@@ -721,6 +721,46 @@ def test_pointmlp_dgrad_gram(hip_lib, M, K, rpf):
     _close(c['s2'], g['s2'], 1e-3, 2e-3 * scale, 'psum_dzy')
 
 
+@pytest.mark.parametrize('M,K,N,rpf,masked', [(512, 128, 1024, 256, True), (4096, 256, 512, 1024, True), (8192, 128, 256, 1024, True),
+                                              (1024, 128, 256, 256, False)])
+def test_row_gated_sparse_rows_and_dgrad_gram_equal_the_dense_form(hip_lib, M, K, N, rpf, masked):
+    """row_live / add_live: rows of S without an arg-max hit are neither written nor read (they hold NaN here), the flags
+    are exactly the hit rows, and the data gradient is bit-identical to the every-row-written form."""
+    d = _pool_case(M, K, N, rpf, M + K + N)
+    r = np.random.RandomState(5)
+    dev = _dev('cuda')
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    B, T = M // rpf, M // 128
+    t = {k: _mk(dev, v) for k, v in dict(d, P=(r.normal(size=(K, K)) / np.sqrt(K)).astype(np.float32),
+                                         rc=(r.normal(size=K) * 0.1).astype(np.float32)).items()}
+    wc = (t['coef'][0][:, None] * t['w'].t()).contiguous()
+    res = []
+    for gated in (False, True):
+        S = torch.full((M, K), float('nan'), device=dev)
+        live = torch.full((M,), 77, dtype=torch.int32, device=dev)
+        sp = abi.PoolSparseRowsArgs(iptr(t['argidx']), fptr(t['dpool']), fptr(wc), B, N, K, rpf, fptr(S), iptr(live if gated else None))
+        assert hip_lib.t3d_pool_sparse_rows(C.byref(sp), st) == 0
+        out, s1, s2 = torch.zeros(M, K, device=dev), torch.zeros(T, K, device=dev), torch.zeros(T, K, device=dev)
+        a = abi.PointMlpDgradGramArgs()
+        a.a, a.p, a.rowconst, a.add_in, a.add_live = _act_src(t, K), fptr(t['P']), fptr(t['rc']), fptr(S), iptr(live if gated else None)
+        if masked:
+            a.prev_y, a.prev_scale, a.prev_shift, a.psum_dz, a.psum_dzy = fptr(t['x']), fptr(t['sc']), fptr(t['sh']), fptr(s1), fptr(s2)
+        a.out, a.M, a.K, a.rows_per_frustum = fptr(out), M, K, rpf
+        assert hip_lib.t3d_pointmlp_dgrad_gram(C.byref(a), st) == 0
+        torch.cuda.synchronize()
+        res.append((out, s1, s2, S, live))
+    want = np.zeros(M, np.int32)
+    for b in range(B):
+        want[b * rpf + d['argidx'][b][d['argidx'][b] >= 0]] = 1
+    assert np.array_equal(res[1][4].cpu().numpy(), want) and 0 < want.sum() < M
+    assert bool(torch.isnan(res[1][3][torch.as_tensor(want == 0)]).all()), 'a row without a hit was written'
+    assert torch.equal(res[1][3][torch.as_tensor(want == 1)], res[0][3][torch.as_tensor(want == 1)])
+    for x, y, what in zip(res[0][:3], res[1][:3], ('out', 'psum_dz', 'psum_dzy')):
+        assert torch.equal(x, y) and bool(torch.isfinite(y).all()), what
+    a.add_in = fptr(None)
+    assert hip_lib.t3d_pointmlp_dgrad_gram(C.byref(a), st) == -1          # T3D_ERR_ARG: flags without the rows
+
+
 @pytest.mark.parametrize('M,K,rpf', [(1024, 128, 256), (512, 256, 128), (4096, 64, 1024)])
 def test_pointmlp_gram_and_act_colsum(hip_lib, M, K, rpf):
     d = _pool_case(M, K, 64, rpf, M + 3 * K)

@@ -60,11 +60,13 @@ class PoolBwdPrepArgs(C.Structure):
 
 
 class PoolSparseRowsArgs(C.Structure):
-    _fields_ = [('argidx', I), ('dpool', F), ('wc', F), ('B', i32), ('N', i32), ('K', i32), ('rows_per_frustum', i32), ('s', F)]
+    _fields_ = [('argidx', I), ('dpool', F), ('wc', F), ('B', i32), ('N', i32), ('K', i32), ('rows_per_frustum', i32), ('s', F),
+                ('row_live', I)]
 
 
 class PointMlpDgradGramArgs(C.Structure):
-    _fields_ = [('a', ActSrc), ('p', F), ('rowconst', F), ('add_in', F), ('prev_y', F), ('prev_scale', F), ('prev_shift', F),
+    _fields_ = [('a', ActSrc), ('p', F), ('rowconst', F), ('add_in', F), ('add_live', I), ('prev_y', F), ('prev_scale', F),
+                ('prev_shift', F),
                 ('out', F), ('psum_dz', F), ('psum_dzy', F), ('M', i32), ('K', i32), ('rows_per_frustum', i32)]
 
 

@@ -563,6 +563,7 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd(const t3d_pointm
 // layer, that layer's batch-norm-backward partial sums, store.
 struct DgradEpilogue {
   const float* add_in;
+  const int32_t* add_live;     // [M] or NULL: add_in is read only on rows whose flag is non-zero (the sparse arg-max rows)
   const float* colconst;
   const float* prev_y;
   const float* prev_scale;
@@ -578,7 +579,8 @@ struct DgradEpilogue {
 // loads are unconditional (a uniform `ptr ? load : 0` becomes a branch around every load), and the loads of a batch
 // are issued ahead of the batch's stores: `out` may alias the inputs as far as the compiler knows, so a load placed
 // after a store is never hoisted above it and every element would pay a full memory round trip.
-template <int BN, int TM, int TN, bool ADD, bool MASK>
+// ADD: 0 = no add_in, 1 = dense add_in, 2 = add_in gated by the per-row flags (rows without a flag are never read).
+template <int BN, int TM, int TN, int ADD, bool MASK>
 __device__ __forceinline__ void dgrad_epilogue_body(const DgradEpilogue& p, f32x16 (&acc)[TM][TN], float* red, int tid,
                                                     int row0, int col0, int tile_m) {
   const int lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
@@ -586,6 +588,16 @@ __device__ __forceinline__ void dgrad_epilogue_body(const DgradEpilogue& p, f32x
   const bool stats = MASK && p.psum_dz != nullptr;
   const unsigned K = (unsigned)p.K;
   float cs1[TN], cs2[TN];
+  unsigned live = 0u;                    // bit tm*16 + r: the lane's accumulator row (tm, r) has something to add
+  if (ADD == 2) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int4 f = *reinterpret_cast<const int4*>(p.add_live + row0 + wm * 64 + 4 * h + tm * 32 + 8 * j);
+        live |= (unsigned)((f.x != 0) | ((f.y != 0) << 1) | ((f.z != 0) << 2) | ((f.w != 0) << 3)) << (tm * 16 + 4 * j);
+      }
+  }
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int col = col0 + wn * (BN / 2) + tn * 32 + l31;
@@ -608,7 +620,8 @@ __device__ __forceinline__ void dgrad_epilogue_body(const DgradEpilogue& p, f32x
 #else
           yp[e] = MASK ? p.prev_y[o] : 0.f;
 #endif
-          ad[e] = ADD ? p.add_in[o] : 0.f;
+          if (ADD == 2) ad[e] = ((live >> (tm * 16 + r)) & 1u) ? p.add_in[o] : 0.f;
+          else ad[e] = ADD ? p.add_in[o] : 0.f;
         }
 #pragma unroll
         for (int e = 0; e < EB; ++e) {
@@ -652,11 +665,13 @@ __device__ __forceinline__ void dgrad_epilogue(const DgradEpilogue& p, f32x16 (&
                                                int col0, int tile_m) {
   const bool add = p.add_in != nullptr, mask = p.prev_y != nullptr;      // workgroup-uniform
   if (mask) {
-    if (add) dgrad_epilogue_body<BN, TM, TN, true, true>(p, acc, red, tid, row0, col0, tile_m);
-    else dgrad_epilogue_body<BN, TM, TN, false, true>(p, acc, red, tid, row0, col0, tile_m);
+    if (add && p.add_live) dgrad_epilogue_body<BN, TM, TN, 2, true>(p, acc, red, tid, row0, col0, tile_m);
+    else if (add) dgrad_epilogue_body<BN, TM, TN, 1, true>(p, acc, red, tid, row0, col0, tile_m);
+    else dgrad_epilogue_body<BN, TM, TN, 0, true>(p, acc, red, tid, row0, col0, tile_m);
   } else {
-    if (add) dgrad_epilogue_body<BN, TM, TN, true, false>(p, acc, red, tid, row0, col0, tile_m);
-    else dgrad_epilogue_body<BN, TM, TN, false, false>(p, acc, red, tid, row0, col0, tile_m);
+    if (add && p.add_live) dgrad_epilogue_body<BN, TM, TN, 2, false>(p, acc, red, tid, row0, col0, tile_m);
+    else if (add) dgrad_epilogue_body<BN, TM, TN, 1, false>(p, acc, red, tid, row0, col0, tile_m);
+    else dgrad_epilogue_body<BN, TM, TN, 0, false>(p, acc, red, tid, row0, col0, tile_m);
   }
 }
 
@@ -687,7 +702,7 @@ __device__ __forceinline__ void dgrad_body(const t3d_pointmlp_dgrad_args& p, flo
   gemm_mainloop<TM, TN, SA, SB, LA, WLoader, true, BM, true, BN>(sa, sb, la, lb, smem, 0, nred, wm * 64,
                                                                       wn * (BN / 2), acc, tid);
 
-  DgradEpilogue e{p.add_in, nullptr, p.prev_y, p.prev_scale, p.prev_shift, p.out, p.psum_dz, p.psum_dzy, p.K};
+  DgradEpilogue e{p.add_in, nullptr, nullptr, p.prev_y, p.prev_scale, p.prev_shift, p.out, p.psum_dz, p.psum_dzy, p.K};
   dgrad_epilogue<BN, TM, TN>(e, acc, smem, tid, row0, col0, tile_m);
 }
 
@@ -721,7 +736,7 @@ __device__ __forceinline__ void dgrad_gram_body(const t3d_pointmlp_dgrad_gram_ar
   zero_acc<TM, TN>(acc);
   gemm_mainloop<TM, TN, SA, SB, LA, WLoader, true, BM, false, BN>(sa, sb, la, lb, smem, 0, p.K, wm * 64, wn * (BN / 2), acc,
                                                                         tid);
-  DgradEpilogue e{p.add_in, p.rowconst, p.prev_y, p.prev_scale, p.prev_shift, p.out, p.psum_dz, p.psum_dzy, p.K};
+  DgradEpilogue e{p.add_in, p.add_live, p.rowconst, p.prev_y, p.prev_scale, p.prev_shift, p.out, p.psum_dz, p.psum_dzy, p.K};
   dgrad_epilogue<BN, TM, TN>(e, acc, smem, tid, row0, col0, tile_m);
 }
 
@@ -1309,6 +1324,7 @@ extern "C" int t3d_pointmlp_wgrad(const t3d_pointmlp_wgrad_args* a, t3d_stream_t
 
 static int check_dgrad_gram(const t3d_pointmlp_dgrad_gram_args* a) {
   if (!a || !a->p || !a->out || !act_ok(a->a, a->K) || a->a.sub) return T3D_ERR_ARG;
+  if (a->add_live && !a->add_in) return T3D_ERR_ARG;
   if (a->prev_y && (!a->prev_scale || !a->prev_shift)) return T3D_ERR_ARG;
   if (a->psum_dz && (!a->psum_dzy || !a->prev_y)) return T3D_ERR_ARG;
   if (a->M <= 0 || a->M % T3D_TILE_ROWS || a->rows_per_frustum % T3D_TILE_ROWS || a->M % a->rows_per_frustum ||

@@ -75,8 +75,9 @@ __device__ __forceinline__ void pool_bwd_prep_body(const t3d_pool_bwd_prep_args&
     if (q == 0) p.rc_slabs[(size_t)ch * p.K + 32 * bi + r] = rc;
     // transposed, c0-scaled copy: 32 consecutive k per column n
     const int k = tid & 31;
-    for (int c = tid >> 5; c < PCH; c += 8)
-      if (n0 + c < p.N) p.wc[(size_t)(n0 + c) * p.K + 32 * bi + k] = c0s[c] * wi[k][c];
+    if (p.wc != nullptr)
+      for (int c = tid >> 5; c < PCH; c += 8)
+        if (n0 + c < p.N) p.wc[(size_t)(n0 + c) * p.K + 32 * bi + k] = c0s[c] * wi[k][c];
   }
 }
 
@@ -93,10 +94,12 @@ constexpr int SR_PRE = 16;     // argidx chunks (of 64) loaded together
 __device__ __forceinline__ void pool_sparse_rows_body(const t3d_pool_sparse_rows_args& p, float* smem, int bx, int by) {
   float* tile = smem;                                            // [128][SR_KC]
   int* lists = reinterpret_cast<int*>(smem + 128 * SR_KC);        // [4][N]
+  int* hitrow = lists + 4 * p.N;                                  // [128] row received a hit
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int row0 = bx * 128, kc0 = by * SR_KC;
   const int b = row0 / p.rows_per_frustum, rin0 = row0 - b * p.rows_per_frustum;
   for (int f = tid; f < 128 * SR_KC / 4; f += 256) reinterpret_cast<float4*>(tile)[f] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (tid < 128) hitrow[tid] = 0;
   int* mine = lists + w * p.N;
   int cnt = 0;
   for (int nb = 0; nb < p.N; nb += 64 * SR_PRE) {
@@ -126,6 +129,7 @@ __device__ __forceinline__ void pool_sparse_rows_body(const t3d_pool_sparse_rows
       const int e = mine[min(i0 + u, cnt - 1)];
       const int n = e & 0xffff;
       rr[u] = e >> 16;
+      hitrow[rr[u]] = 1;                // same value from every lane; rows of this wave only
       g[u] = (i0 + u < cnt) ? p.dpool[(size_t)b * p.N + n] : 0.f;
       wv[u] = *reinterpret_cast<const float2*>(p.wc + (size_t)n * p.K + kc0 + 2 * lane);
     }
@@ -139,8 +143,11 @@ __device__ __forceinline__ void pool_sparse_rows_body(const t3d_pool_sparse_rows
     }
   }
   __syncthreads();
+  const bool gated = p.row_live != nullptr;                // rows without a hit stay unwritten: the reader consults row_live
+  if (gated && by == 0 && tid < 128) p.row_live[row0 + tid] = hitrow[tid];
   for (int f = tid; f < 128 * SR_KC / 4; f += 256) {
     const int r = f / (SR_KC / 4), c4 = f % (SR_KC / 4);
+    if (gated && !hitrow[r]) continue;
     *reinterpret_cast<float4*>(p.s + (size_t)(row0 + r) * p.K + kc0 + 4 * c4) = reinterpret_cast<const float4*>(tile)[f];
   }
 }
@@ -279,7 +286,7 @@ inline int check_prep(const t3d_pool_bwd_prep_args* a) {
   if (a->K <= 0 || a->K % 32 || a->N <= 0 || a->N % 4) return T3D_ERR_SHAPE;
   return T3D_OK;
 }
-inline size_t sparse_rows_lds(int N) { return (size_t)128 * SR_KC * sizeof(float) + (size_t)4 * N * sizeof(int); }
+inline size_t sparse_rows_lds(int N) { return (size_t)128 * SR_KC * sizeof(float) + ((size_t)4 * N + 128) * sizeof(int); }
 inline int check_sparse_rows(const t3d_pool_sparse_rows_args* a) {
   if (!a || !a->argidx || !a->dpool || !a->wc || !a->s) return T3D_ERR_ARG;
   if (a->B <= 0 || a->N <= 0 || a->N > 65535 || a->K % SR_KC || a->rows_per_frustum % T3D_TILE_ROWS ||

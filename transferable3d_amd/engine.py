@@ -70,6 +70,8 @@ FUSE_BWD = os.environ.get('T3D_FUSE_BWD', '1') != '0'
 # the fully-connected backward chains of the box / T-Net (a few workgroups each, ~100 us per step of dependent launches) on the
 # second stream beside the segmentation net's backward GEMMs, which do not depend on them
 FC_SIDE = os.environ.get('T3D_FC_SIDE', '0') == '1'
+# the sparse rows S are written / read only where a row received an arg-max hit (row flags beside S)
+SPARSE_GATED = os.environ.get('T3D_SPARSE_GATED', '1') != '0'
 
 
 class Plan:
@@ -386,6 +388,7 @@ class PointLayer:
                 if self.gram:
                     K, N = self.K, self.N
                     self.wc, self.S = rt.zeros(N, K), rt.zeros(self.M, K)
+                    self.S_live = rt.zeros(self.M, dtype=torch.int32) if SPARSE_GATED else None
             else:
                 self.dz = rt.zeros(self.M, self.N)
                 self.psum_dz, self.psum_dzy = rt.zeros(self.T, self.N), rt.zeros(self.T, self.N)
@@ -488,10 +491,12 @@ class PointLayer:
             self._emit_prep(plan, sl)
             emit_reduce()
             self._gram_keep_d = (sl, red)
-        r = abi.PoolSparseRowsArgs(iptr(self.argidx), fptr(self.dpool), fptr(self.wc), g.B, N, K, g.rpf, fptr(self.S))
+        r = abi.PoolSparseRowsArgs(iptr(self.argidx), fptr(self.dpool), fptr(self.wc), g.B, N, K, g.rpf, fptr(self.S),
+                                   iptr(self.S_live))
         plan.add('t3d_pool_sparse_rows', r)
         a = abi.PointMlpDgradGramArgs()
         a.a, a.p, a.rowconst, a.add_in = self.src.struct(), fptr(red['P']), fptr(red['rowconst']), fptr(self.S)
+        a.add_live = iptr(self.S_live)
         a.prev_y, a.prev_scale, a.prev_shift = fptr(prev.y), fptr(prev.scale), fptr(prev.shift)
         a.out, a.psum_dz, a.psum_dzy = fptr(prev.dz), fptr(prev.psum_dz), fptr(prev.psum_dzy)
         a.M, a.K, a.rows_per_frustum = self.M, K, g.rpf
@@ -520,7 +525,8 @@ class PointLayer:
         plan.keep.extend([ga, ca, qa, sl, red])
         plan.calls.append(('t3d_pool_bwd_stage1', lambda s: fn1(r1[0], r1[1], r1[2], s), (ga, ca, qa)))
         plan.lanes.append(0)
-        r = abi.PoolSparseRowsArgs(iptr(self.argidx), fptr(self.dpool), fptr(self.wc), g.B, N, K, g.rpf, fptr(self.S))
+        r = abi.PoolSparseRowsArgs(iptr(self.argidx), fptr(self.dpool), fptr(self.wc), g.B, N, K, g.rpf, fptr(self.S),
+                                   iptr(self.S_live))
         emit_reduce(sparse=r)           # slab reduction + sparse rows share a launch (both wait only for stage 1)
         f = abi.PoolWgradFinishArgs()
         f.a, f.argidx, f.dpool, f.coef = self.src.struct(), iptr(self.argidx), fptr(self.dpool), fptr(self.coef)
@@ -530,6 +536,7 @@ class PointLayer:
         f.dw = fptr(g.vars.grads[goff:goff + K * N])
         d = abi.PointMlpDgradGramArgs()
         d.a, d.p, d.rowconst, d.add_in = self.src.struct(), fptr(red['P']), fptr(red['rowconst']), fptr(self.S)
+        d.add_live = iptr(self.S_live)
         d.prev_y, d.prev_scale, d.prev_shift = fptr(prev.y), fptr(prev.scale), fptr(prev.shift)
         d.out, d.psum_dz, d.psum_dzy = fptr(prev.dz), fptr(prev.psum_dz), fptr(prev.psum_dzy)
         d.M, d.K, d.rows_per_frustum = self.M, K, g.rpf
