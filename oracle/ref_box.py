@@ -1,4 +1,6 @@
-"""TEST INFRASTRUCTURE ONLY -- NumPy (fp64) restatement of the 3-D box IoU the reference calls.  PARITY UNPINNED.
+"""TEST INFRASTRUCTURE ONLY -- NumPy (fp64) restatement of the 3-D box IoU the reference calls.  PARITY UNPINNED for box3d_iou
+(the module is absent upstream); roty / get_3d_box / class2angle / class2size are pinned on the reference's own functions
+(tests/test_reference_vectors.py).
 
 `box_util.box3d_iou` is imported by the reference (roi_seg_box3d_dataset.py:15, box_pc_fit_dataset.py:17, eval_det.py:59,
 evaluate.py:19) but is not in its tree: it is train/box_util.py of Frustum PointNets (charlesq34/frustum-pointnets, no version

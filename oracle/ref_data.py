@@ -1,5 +1,8 @@
-"""TEST INFRASTRUCTURE ONLY -- NumPy restatement of the reference's per-sample batch assembly.  PARITY UNPINNED (see
-oracle/README.md): the SUN-RGBD frustum pickles and cPickle/cv2 are absent, so this follows the code, not its outputs.
+"""TEST INFRASTRUCTURE ONLY -- NumPy restatement of the reference's per-sample batch assembly.  get_sample / angle2class /
+rotate_pc_along_y are PINNED on outputs of the reference's own ROISegBoxDataset.__getitem__ / get_batch and
+ROISemiDataset.get_classes3D, executed in the build container on a synthetic frustum file with the np.random draws recorded
+(tests/golden/make_reference_vectors.py -> tests/test_reference_vectors.py).  The Box-PC sample generator below needs the absent
+box_util.box3d_iou on rotated boxes and stays UNPINNED.
 
 Follows sunrgbd/sunrgbd_detection/roi_semi_dataset.py:283-347 (`get_classes3D`: resample to N points with replacement,
 rotate to the frustum's centre view, labels, flip / shift augmentation, angle and size classes) and 482-535 (`get_batch`),

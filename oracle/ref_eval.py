@@ -1,5 +1,6 @@
-"""TEST INFRASTRUCTURE ONLY -- restatement of the reference's detection evaluation loop.  PARITY UNPINNED (no test vectors in the
-reference; box_util absent, see ref_box.py).
+"""TEST INFRASTRUCTURE ONLY -- restatement of the reference's detection evaluation loop.  PINNED on outputs of the reference's own
+eval_det.py executed in the build container (voc_ap, eval_det_cls, eval_det on axis-aligned boxes, where the IoU of the absent
+box_util is a closed form: tests/golden/make_reference_vectors.py -> tests/test_reference_vectors.py).
 
 Follows sunrgbd/sunrgbd_detection/eval_det.py: voc_ap 25-57 (sentinels, backward running maximum, sum over recall steps; 11-point
 variant), eval_det_cls 69-151 (detections by decreasing confidence; per detection a scan over the image's ground-truth boxes with
