@@ -669,6 +669,12 @@ typedef struct {
                                   is_data_2D in the one-list modes */
   int ld_pc;                   /* row stride of pc in floats (>= C; 0 = C).  A multiple of 4 when the layers read pc (C = 6: xyz + rgb
                                   rows padded to 8 floats; the padding is written as zeros) */
+  const int32_t* slot_is_2D;   /* [B] or NULL: per-slot flag written earlier in the step by t3d_sample_equal_classes (its is_data_2D)
+                                  when neither sample2 nor frustum_is_2D decides */
+  /* A slot that holds a frustum of the 2-D-label list is assembled the way ROISemiDataset.get_classes2D does it
+   * (roi_semi_dataset.py:383-452): resampled and rotated to the centre view, but NOT flipped or shifted ("2D Classes cannot be
+   * augmented because the projection will no longer be accurate"), and every 3-D label (y_seg, y_center, orientation and size
+   * class / residual) is written as zero; one_hot and rot_angle are kept. */
 } t3d_batch_assemble_args;
 int t3d_batch_assemble(const t3d_batch_assemble_args* args, t3d_stream_t stream);
 

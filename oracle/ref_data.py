@@ -33,7 +33,7 @@ def angle2class(angle, num_class):
 
 
 def get_sample(points, seg, frustum_angle, box_center, heading, size, cls, choice, flip, shift_randn, height_u, num_channel,
-               rotate_to_center=True, random_flip=True, random_shift=True):
+               rotate_to_center=True, random_flip=True, random_shift=True, is_2D=False):
     """One frustum -> (point_set [N,C], seg [N], center [3], angle_class, angle_residual, size_class, size_residual [3],
     rot_angle, one_hot [10]).  `choice` [N] ints, `flip` bool (the reference flips when np.random.random() > 0.5),
     `shift_randn` ~ N(0,1), `height_u` ~ U(0,1)."""
@@ -63,21 +63,30 @@ def get_sample(points, seg, frustum_angle, box_center, heading, size, cls, choic
     acls, ares = angle2class(heading_angle, NUM_HEADING_BIN)
     one_hot = np.zeros(NUM_CLASS)
     one_hot[int(cls)] = 1
+    if is_2D:       # get_classes2D (roi_semi_dataset.py:383-452): the caller passes random_flip = random_shift = False; labels are zeros
+        return ps[:, :num_channel], np.zeros_like(sg), np.zeros_like(center), 0, 0.0, 0, np.zeros_like(size_residual), rot_angle, one_hot
     return ps[:, :num_channel], sg, center, acls, ares, size_class, size_residual, rot_angle, one_hot
 
 
-def get_batch(ds, sample, choice, flip, shift_randn, height_u, num_channel, **kw):
+def get_batch(ds, sample, choice, flip, shift_randn, height_u, num_channel, is_2D=None, **kw):
     """roi_semi_dataset.py:482-535 on a ragged data set `ds` (dict: points [total,C], seg [total], offsets [F+1],
-    frustum_angle, box_center, heading, size, cls) for the frustum indices `sample` [B]."""
+    frustum_angle, box_center, heading, size, cls) for the frustum indices `sample` [B].  `is_2D` [B]: the slot holds a frustum of
+    the 2-D-label list (get_classes2D: no flip / shift, zero labels, is_data_2D = 1)."""
     out = {k: [] for k in ('pc', 'y_seg', 'y_center', 'y_orient_cls', 'y_orient_reg', 'y_dims_cls', 'y_dims_reg', 'rot_angle',
                            'one_hot_vec')}
     for i, f in enumerate(sample):
         lo, hi = int(ds['offsets'][f]), int(ds['offsets'][f + 1])
+        kw_i = dict(kw)
+        if is_2D is not None and is_2D[i]:
+            kw_i.update(random_flip=False, random_shift=False, is_2D=True)
         r = get_sample(ds['points'][lo:hi], ds['seg'][lo:hi], ds['frustum_angle'][f], ds['box_center'][f], ds['heading'][f],
-                       ds['size'][f], ds['cls'][f], choice[i], bool(flip[i]), shift_randn[i], height_u[i], num_channel, **kw)
+                       ds['size'][f], ds['cls'][f], choice[i], bool(flip[i]), shift_randn[i], height_u[i], num_channel, **kw_i)
         for k, v in zip(out, r):
             out[k].append(v)
-    return {k: np.asarray(v) for k, v in out.items()}
+    res = {k: np.asarray(v) for k, v in out.items()}
+    if is_2D is not None:
+        res['is_data_2D'] = np.asarray(is_2D, dtype=np.int32)
+    return res
 
 
 # ---- Box-PC Fit samples --------------------------------------------------------------------------------------------------------

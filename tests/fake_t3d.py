@@ -386,6 +386,12 @@ class FakeLib:
             c, s_ = (np.cos(rot), np.sin(rot)) if p.rotate_to_center else (np.float32(1), np.float32(0))
             cen = np.array([bc[f, 0] * c - bc[f, 2] * s_, bc[f, 1], bc[f, 0] * s_ + bc[f, 2] * c], np.float32)
             heading = head[f] - rot if p.rotate_to_center else head[f]
+            if p.sample2:
+                is2d = bool(from_first)
+            elif p.frustum_is_2D:
+                is2d = bool(np.ctypeslib.as_array(p.frustum_is_2D, shape=(1 << 30,))[f])
+            else:
+                is2d = bool(arr(p.slot_is_2D, B)[b]) if p.slot_is_2D else False
             if p.aug:
                 flip, rn, hu = arr(p.aug, B, 3)[b]
             else:
@@ -394,10 +400,10 @@ class FakeLib:
                 rn = np.sqrt(np.float32(-2.0) * np.log(u01(mix((kb + 2) & M64)))) * np.cos(np.float32(2.0) * PI * u01(mix((kb + 3) & M64)))
                 hu = u01(mix((kb + 4) & M64))
             flipx = np.float32(1)
-            if p.random_flip and flip != 0:
+            if p.random_flip and not is2d and flip != 0:
                 flipx, cen[0], heading = np.float32(-1), -cen[0], PI - heading
             shift = hs = np.float32(0)
-            if p.random_shift:
+            if p.random_shift and not is2d:
                 dist = np.sqrt(cen[0] * cen[0] + cen[1] * cen[1])
                 shift = np.float32(min(max(rn * dist * np.float32(0.05), dist * np.float32(0.8)), dist * np.float32(1.2)))
                 hs = np.float32(hu * np.float32(0.4) - np.float32(0.2))
@@ -430,11 +436,15 @@ class FakeLib:
             oh[b, cls[f]] = 1
             if p.rot_angle:
                 arr(p.rot_angle, B)[b] = rot
+            if is2d:                        # get_classes2D: every 3-D label is zero
+                yseg[b] = 0
+                arr(p.y_orient_cls, B)[b] = 0
+                arr(p.y_orient_reg, B)[b] = 0
+                arr(p.y_dims_cls, B)[b] = 0
+                arr(p.y_center, B, 3)[b] = 0
+                arr(p.y_dims_reg, B, 3)[b] = 0
             if p.is_data_2D:
-                if p.sample2:
-                    arr(p.is_data_2D, B)[b] = 1 if from_first else 0
-                else:
-                    arr(p.is_data_2D, B)[b] = int(np.ctypeslib.as_array(p.frustum_is_2D, shape=(1 << 30,))[f]) if p.frustum_is_2D else 0
+                arr(p.is_data_2D, B)[b] = 1 if is2d else 0
         return 0
 
     def t3d_sample_equal_classes(self, a, stream):

@@ -251,7 +251,7 @@ def main():
         pickle.dump(L, f, protocol=2)
     back = utils.load_zipped_pickle(path)
     assert len(back) == 13 and len(back[0]) == 24
-    N = 64
+    N = 128          # the device graph takes multiples of 128 points
     classes = sorted(seg.type2class)
     ds = seg.ROISegBoxDataset(classes, N, 'train', random_flip=True, random_shift=True, rotate_to_center=True, overwritten_data_path=path,
                               one_hot=True)
@@ -297,6 +297,40 @@ def main():
     for j, k in ((0, 'point_set'), (2, 'seg'), (3, 'center'), (4, 'angle_cls'), (5, 'angle_res'), (6, 'size_cls'), (7, 'size_res'),
                  (11, 'rot_angle'), (13, 'one_hot')):
         out['semi/get3D/' + k] = np.stack([np.asarray(it[j]) for it in items])
+
+    # the 2-D-label list: no augmentation, zero labels
+    np.random.seed(14)
+    n2 = sd.get_len_classes2D()
+    with DrawRecorder() as rec_:
+        items = [sd.get_classes2D(i) for i in range(n2)]
+    assert not rec_.take('random') and not rec_.take('randn')
+    out['semi/get2D/choice'] = np.stack(rec_.take('choice'))
+    for j, k in ((0, 'point_set'), (2, 'seg'), (3, 'center'), (4, 'angle_cls'), (5, 'angle_res'), (6, 'size_cls'), (7, 'size_res'),
+                 (11, 'rot_angle'), (13, 'one_hot')):
+        out['semi/get2D/' + k] = np.stack([np.asarray(it[j]) for it in items])
+    # get_batch over the combined index space (3-D list first, 2-D list behind it), SEMI_SAMPLING_METHOD BATCH
+    np.random.seed(15)
+    idxs = np.random.RandomState(5).permutation(n3 + n2)
+    with DrawRecorder() as rec_:
+        b = sd.get_batch(idxs, 2, 14, N, 4)
+    out['semi/batch/idxs'] = idxs[2:14]
+    out['semi/batch/n3'] = n3
+    log = rec_.log
+    ch, fl, sh, hu = [], [], [], []
+    k = 0
+    for i in idxs[2:14]:                       # per slot: choice, then (3-D list only) flip u, shift randn, height u
+        assert log[k][0] == 'choice'
+        ch.append(log[k][1]); k += 1
+        if i < n3:
+            fl.append(float(log[k][1])); sh.append(float(log[k + 1][1])); hu.append(float(log[k + 2][1])); k += 3
+        else:
+            fl.append(0.0); sh.append(0.0); hu.append(0.0)
+    assert k == len(log)
+    out['semi/batch/choice'], out['semi/batch/flip_u'] = np.stack(ch), np.array(fl)
+    out['semi/batch/shift_randn'], out['semi/batch/height_u'] = np.array(sh), np.array(hu)
+    for j, kname in ((0, 'pc'), (2, 'seg'), (3, 'center'), (4, 'angle_cls'), (5, 'angle_res'), (6, 'size_cls'), (7, 'size_res'),
+                     (11, 'rot_angle'), (13, 'one_hot'), (14, 'is_data_2D')):
+        out['semi/batch/' + kname] = np.asarray(b[j])
 
     np.savez_compressed(os.path.join(HERE, 'reference_vectors.npz'), **out)
     with open(os.path.join(HERE, 'reference_config.json'), 'w') as f:

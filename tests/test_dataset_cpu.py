@@ -115,12 +115,15 @@ def check_alternate_batch(rt):
         assert rt.lib.t3d_batch_assemble(C.byref(a), stream) == 0
         if rt.device.type == 'cuda':
             torch.cuda.synchronize()
-        cls, is2d = x.y_dims_cls.cpu().numpy(), x.is_data_2D.cpu().numpy()
+        cls, is2d = x.one_hot_vec.cpu().numpy().argmax(1), x.is_data_2D.cpu().numpy()
         weak = step % 2 == 0
         assert (is2d == (1 if weak else 0)).all()
         assert np.isin(cls, weak_cls).all() if weak else (~np.isin(cls, weak_cls)).all()
-        key = x.y_center.cpu().numpy()[:, 1].round(4)                # distinct frustums -> distinct (shifted) centres
-        assert len(np.unique(key)) == B
+        # a weak batch carries no 3-D label at all (get_classes2D returns zeros), a strong batch does
+        lab = [x.y_seg, x.y_center, x.y_orient_cls, x.y_orient_reg, x.y_dims_cls, x.y_dims_reg]
+        assert all(not bool(t.cpu().numpy().any()) for t in lab) if weak else all(bool(t.cpu().numpy().any()) for t in lab)
+        key = x.pc.cpu().numpy().reshape(B, N, -1)[:, :, :3].mean(1).round(4)        # distinct frustums -> distinct point clouds
+        assert len(np.unique(key, axis=0)) == B
         seen[step % 2].append(cls.copy())
     assert not np.array_equal(seen[0][0], seen[0][1])               # the lists advance
 

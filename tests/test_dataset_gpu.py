@@ -34,6 +34,12 @@ def test_generated_batch_equals_the_specification(hip_lib):
         assert np.array_equal(c['y_orient_cls'], g['y_orient_cls']) and np.abs(c['y_orient_reg'] - g['y_orient_reg']).max() < 1e-5
 
 
+def test_device_batch_against_the_batch_the_reference_assembled(hip_lib):
+    """The kernel on the reference's own frustum file, slots and np.random draws (tests/golden/reference_vectors.npz)."""
+    from test_reference_vectors import check_device_batch_against_the_reference_batch
+    check_device_batch_against_the_reference_batch(Runtime(lib=hip_lib))
+
+
 def test_alternate_batch_sampling(hip_lib):
     from test_dataset_cpu import check_alternate_batch
     check_alternate_batch(Runtime(lib=hip_lib))

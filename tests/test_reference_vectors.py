@@ -183,6 +183,100 @@ def test_semi_dataset_split_and_3d_samples(V):
         assert np.array_equal(oh, V['semi/get3D/one_hot'][k])
 
 
+def _get_sample_of(L, f, choice, flip_u, randn, hu, **kw):
+    box3d = np.asarray(L[2][f])
+    return RD.get_sample(np.asarray(L[4][f]), np.asarray(L[5][f]), L[11][f], (box3d[0] + box3d[6]) / 2.0, L[7][f], L[8][f],
+                         K.type2class[L[6][f]], choice, bool(flip_u > 0.5), float(randn), float(hu), 6, **kw)
+
+
+def test_two_d_list_samples_are_not_augmented_and_carry_zero_labels(V):
+    """ROISemiDataset.get_classes2D: the reference draws only the resampling choice, and returns zeros for every 3-D label."""
+    L = _frustum_lists()
+    c2 = [str(c) for c in V['semi/classes2D']]
+    ids2 = [i for i, t in enumerate(L[6]) if t in c2]
+    assert len(ids2) == len(V['semi/get2D/choice']) > 0
+    for k, f in enumerate(ids2):
+        ps, sg, c, acls, ares, scls, sres, rot, oh = _get_sample_of(L, f, V['semi/get2D/choice'][k], 0.0, 0.0, 0.0, random_flip=False,
+                                                                    random_shift=False, is_2D=True)
+        assert np.allclose(ps, V['semi/get2D/point_set'][k], atol=1e-12)
+        for got, name in ((sg, 'seg'), (c, 'center'), (acls, 'angle_cls'), (ares, 'angle_res'), (scls, 'size_cls'), (sres, 'size_res')):
+            assert not np.any(V['semi/get2D/' + name][k]) and not np.any(got), name
+        assert abs(rot - V['semi/get2D/rot_angle'][k]) < 1e-15 and np.array_equal(oh, V['semi/get2D/one_hot'][k])
+
+
+def reference_semi_batch(V, L):
+    """The slots of ROISemiDataset.get_batch(idxs, 2, 14, N, 4) as (frustum id in the file, is_2D)."""
+    c3, c2 = [str(c) for c in V['semi/classes3D']], [str(c) for c in V['semi/classes2D']]
+    ids3 = [i for i, t in enumerate(L[6]) if t in c3]
+    ids2 = [i for i, t in enumerate(L[6]) if t in c2]
+    n3 = int(V['semi/batch/n3'])
+    assert n3 == len(ids3)
+    idxs = V['semi/batch/idxs']
+    return np.array([ids3[i] if i < n3 else ids2[i - n3] for i in idxs]), (idxs >= n3).astype(np.int32), c2
+
+
+def test_combined_batch_of_the_semi_dataset_oracle(V):
+    """get_batch over the combined index space (SEMI_SAMPLING_METHOD BATCH): 3-D-list slots augmented and labelled, 2-D-list slots
+    neither; is_data_2D marks them."""
+    L = _frustum_lists()
+    sample, is2d, _ = reference_semi_batch(V, L)
+    assert np.array_equal(is2d, V['semi/batch/is_data_2D']) and 0 < is2d.sum() < len(is2d)
+    counts = np.array([len(p) for p in L[4]])
+    ds = dict(points=np.concatenate([np.asarray(p) for p in L[4]]), seg=np.concatenate([np.asarray(s) for s in L[5]]),
+              offsets=np.concatenate([[0], np.cumsum(counts)]), frustum_angle=np.asarray(L[11]),
+              box_center=np.stack([(np.asarray(b)[0] + np.asarray(b)[6]) / 2.0 for b in L[2]]), heading=np.asarray(L[7]),
+              size=np.stack(L[8]), cls=np.array([K.type2class[t] for t in L[6]]))
+    ref = RD.get_batch(ds, sample, V['semi/batch/choice'], V['semi/batch/flip_u'] > 0.5, V['semi/batch/shift_randn'],
+                       V['semi/batch/height_u'], 4, is_2D=is2d)
+    assert np.allclose(ref['pc'], V['semi/batch/pc'], atol=1e-12) and np.array_equal(ref['y_seg'], V['semi/batch/seg'])
+    assert np.allclose(ref['y_center'], V['semi/batch/center'], atol=1e-12)
+    assert np.array_equal(ref['y_orient_cls'], V['semi/batch/angle_cls']) and np.allclose(ref['y_orient_reg'], V['semi/batch/angle_res'], atol=1e-12)
+    assert np.array_equal(ref['y_dims_cls'], V['semi/batch/size_cls']) and np.allclose(ref['y_dims_reg'], V['semi/batch/size_res'], atol=1e-12)
+    assert np.allclose(ref['rot_angle'], V['semi/batch/rot_angle'], atol=1e-15) and np.array_equal(ref['one_hot_vec'], V['semi/batch/one_hot'])
+    assert np.array_equal(ref['is_data_2D'], V['semi/batch/is_data_2D'])
+
+
+def check_device_batch_against_the_reference_batch(rt):
+    """t3d_batch_assemble on the reference's frustum file, slots and np.random draws: the batch ROISemiDataset.get_batch returned,
+    within fp32 (the reference assembles in fp64)."""
+    import ctypes as C
+    import torch
+    from transferable3d_amd.nets import Graph, Inputs
+    V = np.load(os.path.join(HERE, 'reference_vectors.npz'))
+    L = _frustum_lists()
+    sample, is2d, c2 = reference_semi_batch(V, L)
+    B, N, Cc = len(sample), int(V['getitem/npoints']), 4
+    ds = DeviceFrustumSet.from_pickle(rt, FRUSTUMS).mark_2d_classes([K.type2class[c] for c in c2])
+    g = Graph(B, N, Cc, rt=rt)
+    x = Inputs(g)
+    dev = rt.device
+    t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a)).to(dt).to(dev)
+    aug = np.stack([V['semi/batch/flip_u'] > 0.5, V['semi/batch/shift_randn'], V['semi/batch/height_u']], 1)
+    a = ds.assemble_args(x, g.hyper, B, N, Cc, seed=1, sample=t(sample, torch.int32), choice=t(V['semi/batch/choice'], torch.int32),
+                         aug=t(aug, torch.float32))
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream) if dev.type == 'cuda' else None
+    assert rt.lib.t3d_batch_assemble(C.byref(a), stream) == 0
+    if dev.type == 'cuda':
+        torch.cuda.synchronize()
+    num = lambda v: v.detach().cpu().numpy()
+    pc = num(x.pc).reshape(B, N, -1)[:, :, :Cc]
+    assert np.abs(pc - V['semi/batch/pc']).max() < 2e-5
+    assert np.array_equal(num(x.y_seg).reshape(B, N), V['semi/batch/seg'])
+    assert np.abs(num(x.y_center) - V['semi/batch/center']).max() < 2e-5
+    assert np.array_equal(num(x.y_dims_cls), V['semi/batch/size_cls']) and np.abs(num(x.y_dims_reg) - V['semi/batch/size_res']).max() < 1e-6
+    assert np.array_equal(num(x.one_hot_vec), V['semi/batch/one_hot']) and np.array_equal(num(x.is_data_2D), V['semi/batch/is_data_2D'])
+    per = 2 * np.pi / 12
+    ang = lambda c, rr: (c * per + rr) % (2 * np.pi)
+    d = np.abs(ang(num(x.y_orient_cls), num(x.y_orient_reg)) - ang(V['semi/batch/angle_cls'], V['semi/batch/angle_res']))
+    three_d = is2d == 0
+    assert np.minimum(d, 2 * np.pi - d)[three_d].max() < 1e-5
+    assert not num(x.y_orient_cls)[~three_d].any() and not num(x.y_orient_reg)[~three_d].any()
+
+
+def test_device_batch_specification_against_the_reference_batch():
+    check_device_batch_against_the_reference_batch(Runtime(device='cpu', lib=FakeLib()))
+
+
 def test_flag_parser_against_the_reference_parser():
     """Every flag of models/config.py: name, default, parsed type and value on the README's three recipes and on list / bool flags."""
     with open(os.path.join(HERE, 'reference_config.json')) as f:

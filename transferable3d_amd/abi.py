@@ -124,7 +124,8 @@ class BatchAssembleArgs(C.Structure):
                 ('size', F), ('cls', I), ('sample', I), ('sample_len', i32), ('choice', I), ('aug', F), ('C_src', i32), ('C', i32), ('B', i32), ('N', i32),
                 ('rotate_to_center', i32), ('random_flip', i32), ('random_shift', i32), ('seed', C.c_uint32), ('hyper', F), ('pc', F),
                 ('y_seg', I), ('y_center', F), ('y_orient_cls', I), ('y_orient_reg', F), ('y_dims_cls', I), ('y_dims_reg', F),
-                ('one_hot', F), ('rot_angle', F), ('sample2', I), ('sample2_len', i32), ('is_data_2D', I), ('frustum_is_2D', I), ('ld_pc', i32)]
+                ('one_hot', F), ('rot_angle', F), ('sample2', I), ('sample2_len', i32), ('is_data_2D', I), ('frustum_is_2D', I), ('ld_pc', i32),
+                ('slot_is_2D', I)]
 
 
 class BnBwdFinalizeArgs(C.Structure):

@@ -84,6 +84,7 @@ class Graph:
             a = dataset.assemble_args(inputs, self.hyper, self.B, self.rpf, self.C, seed=seed, sample=slots, **aug)
             if alternate:
                 a.is_data_2D = iptr(None)          # the sampler launch knows which list the step drew from
+                a.slot_is_2D = iptr(inputs.is_data_2D)
             plan.add('t3d_batch_assemble', a)
             return
         a = dataset.assemble_args(inputs, self.hyper, self.B, self.rpf, self.C, seed=seed, **aug)
