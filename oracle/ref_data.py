@@ -1,8 +1,8 @@
 """TEST INFRASTRUCTURE ONLY -- NumPy restatement of the reference's per-sample batch assembly.  get_sample / angle2class /
 rotate_pc_along_y are PINNED on outputs of the reference's own ROISegBoxDataset.__getitem__ / get_batch and
 ROISemiDataset.get_classes3D, executed in the build container on a synthetic frustum file with the np.random draws recorded
-(tests/golden/make_reference_vectors.py -> tests/test_reference_vectors.py).  The Box-PC sample generator below needs the absent
-box_util.box3d_iou on rotated boxes and stays UNPINNED.
+(tests/golden/make_reference_vectors.py -> tests/test_reference_vectors.py).  The Box-PC sample generator below is pinned the same way on BoxPCFitDataset.get, which
+the reference ran with oracle/ref_box.box3d_iou standing in for its absent box_util: the generator's law is pinned, the IoU is not.
 
 Follows sunrgbd/sunrgbd_detection/roi_semi_dataset.py:283-347 (`get_classes3D`: resample to N points with replacement,
 rotate to the frustum's centre view, labels, flip / shift augmentation, angle and size classes) and 482-535 (`get_batch`),

@@ -14,7 +14,11 @@ Three modules those files import do not exist in this image and are given placeh
     cPickle   the standard library's pickle (its Python-3 name);
     box_util  the module the reference imports from Frustum PointNets and does not ship.  Its box3d_iou is replaced by the closed-form
               IoU of AXIS-ALIGNED boxes written out below, and the detection fixtures use axis-aligned boxes only, so the recorded
-              precision / recall / AP pin the reference's matching loop, not an IoU routine.
+              precision / recall / AP pin the reference's matching loop, not an IoU routine.  For the Box-PC sample generator
+              (box_pc_fit_dataset.py BoxPCFitDataset.get / perturb_box_to_diff_ious, whose boxes are rotated) the placeholder
+              forwards to the oracle's own restatement of box3d_iou (oracle/ref_box.py): those vectors pin the generator's law --
+              which draws it takes, how it scales and applies them, the rejection test, the label format -- GIVEN that IoU; they
+              say nothing about the IoU routine itself, which stays unpinned.
 Everything that needs the TensorFlow graph (the networks, the losses) cannot run and stays unpinned (oracle/README.md).
 
 The reference draws its augmentation from the global np.random stream; the draws are recorded next to the outputs, so that the
@@ -45,6 +49,9 @@ def axis_aligned_iou(c1, c2):
     return iou3d, iou2d
 
 
+IOU_IMPL = [axis_aligned_iou]          # what the box_util placeholder forwards to (switched for the Box-PC generator, see header)
+
+
 def load(name, path):
     spec = importlib.util.spec_from_file_location(name, path)
     mod = importlib.util.module_from_spec(spec)
@@ -57,20 +64,21 @@ def reference_modules():
     sys.modules['cv2'] = types.ModuleType('cv2')
     sys.modules['cPickle'] = pickle
     bu = types.ModuleType('box_util')
-    bu.box3d_iou = axis_aligned_iou
+    bu.box3d_iou = lambda c1, c2: IOU_IMPL[0](c1, c2)
     sys.modules['box_util'] = bu
     det = os.path.join(REF, 'sunrgbd', 'sunrgbd_detection')
     utils = load('utils', os.path.join(REF, 'sunrgbd', 'sunrgbd_data', 'utils.py'))
     seg = load('roi_seg_box3d_dataset', os.path.join(det, 'roi_seg_box3d_dataset.py'))
     semi = load('roi_semi_dataset', os.path.join(det, 'roi_semi_dataset.py'))
     ev = load('eval_det', os.path.join(det, 'eval_det.py'))
-    return utils, seg, semi, ev
+    bp = load('box_pc_fit_dataset', os.path.join(det, 'box_pc_fit_dataset.py'))
+    return utils, seg, semi, ev, bp
 
 
 class DrawRecorder:
     """Records what the reference takes from the global np.random stream, in order."""
 
-    NAMES = ('choice', 'random', 'randn', 'rand')
+    NAMES = ('choice', 'random', 'randn', 'rand', 'uniform')
 
     def __init__(self):
         self.log = []
@@ -156,7 +164,7 @@ def synthetic_frustums(seg_mod, n_frustums, seed):
 
 
 def main():
-    utils, seg, semi, ev = reference_modules()
+    utils, seg, semi, ev, bp = reference_modules()
     out = {}
     r = np.random.RandomState(7)
 
@@ -331,6 +339,37 @@ def main():
     for j, kname in ((0, 'pc'), (2, 'seg'), (3, 'center'), (4, 'angle_cls'), (5, 'angle_res'), (6, 'size_cls'), (7, 'size_res'),
                      (11, 'rot_angle'), (13, 'one_hot'), (14, 'is_data_2D')):
         out['semi/batch/' + kname] = np.asarray(b[j])
+
+    # ---- the Box-PC Fit sample generator (IoU = the oracle's restatement, see header) ----------------------------------------------
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle.ref_box import box3d_iou as oracle_iou
+    IOU_IMPL[0] = oracle_iou
+    cp, sp, ap = 0.8, 0.2, np.pi                                       # config.py BOXPC_*_PERTURBATION defaults
+    nofit, fit = [0.01, 0.25], [0.7, 1.0]
+    bd = bp.BoxPCFitDataset(classes, N, cp, sp, ap, random_flip=True, random_shift=True, rotate_to_center=True, overwritten_data_path=path)
+    np.random.seed(16)
+    out['boxpc/perturbation'], out['boxpc/nofit'], out['boxpc/fit'], out['boxpc/count'] = np.array([cp, sp, ap]), np.array(nofit), np.array(fit), 16
+    for i in range(16):
+        is_fit = i % 2 == 0
+        with DrawRecorder() as rec_:
+            item = bd.get(i, is_fit, nofit, fit)
+        pfx = 'boxpc/%d/' % i
+        rnd = rec_.take('random')
+        out[pfx + 'is_fit'], out[pfx + 'choice'] = is_fit, rec_.take('choice')[0]
+        out[pfx + 'flip_u'], out[pfx + 'height_u'], out[pfx + 'shift_randn'] = rnd[0], rnd[1], rec_.take('randn')[0]
+        scale = 1 - np.mean(fit if is_fit else nofit)
+        u = rec_.take('uniform')
+        assert len(u) % 3 == 0
+        cand = []
+        for t in range(len(u) // 3):                                    # back to uniforms in [0,1): centre, size, angle of candidate t
+            cand.append(np.concatenate([(u[3 * t] + cp * scale) / (2 * cp * scale), (u[3 * t + 1] + sp * scale) / (2 * sp * scale),
+                                        [u[3 * t + 2] / (ap * scale)]]))
+        out[pfx + 'cand_u'] = np.stack(cand)
+        for j, k in ((0, 'point_set'), (2, 'seg'), (3, 'center'), (4, 'angle_cls'), (5, 'angle_res'), (6, 'size_cls'), (7, 'size_res'),
+                     (13, 'one_hot'), (14, 'new_center'), (15, 'new_angle_cls'), (16, 'new_angle_res'), (17, 'new_size_cls'),
+                     (18, 'new_size_res'), (19, 'box_iou'), (20, 'y_center_delta'), (21, 'y_size_delta'), (22, 'y_angle_delta')):
+            out[pfx + k] = np.asarray(item[j])
+    IOU_IMPL[0] = axis_aligned_iou
 
     np.savez_compressed(os.path.join(HERE, 'reference_vectors.npz'), **out)
     with open(os.path.join(HERE, 'reference_config.json'), 'w') as f:

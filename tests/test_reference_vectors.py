@@ -277,6 +277,37 @@ def test_device_batch_specification_against_the_reference_batch():
     check_device_batch_against_the_reference_batch(Runtime(device='cpu', lib=FakeLib()))
 
 
+def test_boxpc_sample_generator_on_the_recorded_draws(V):
+    """BoxPCFitDataset.get (box_pc_fit_dataset.py:105-185): augmentation, then candidates drawn until the IoU with the label box falls
+    inside the fit / no-fit bounds.  The reference ran with the oracle's IoU behind its missing box_util (generator header), so this
+    pins the generator's law -- draw order, scaling by (1 - mean bound), rejection test, label format -- not the IoU routine."""
+    L = _frustum_lists()
+    cp, sp, ap = V['boxpc/perturbation']
+    n_tries = []
+    for i in range(int(V['boxpc/count'])):
+        p = 'boxpc/%d/' % i
+        ps, sg, c, acls, ares, scls, sres, rot, oh = _get_sample_of(L, i, V[p + 'choice'], V[p + 'flip_u'], V[p + 'shift_randn'], V[p + 'height_u'])
+        assert np.allclose(ps, V[p + 'point_set'], atol=1e-12) and np.array_equal(sg, V[p + 'seg'])
+        assert np.allclose(c, V[p + 'center'], atol=1e-12) and acls == V[p + 'angle_cls'] and abs(ares - V[p + 'angle_res']) < 1e-12
+        assert scls == V[p + 'size_cls'] and np.allclose(sres, V[p + 'size_res'], atol=1e-12)
+        heading = RB.class2angle(acls, ares, to_label_format=False)
+        size = K.MEAN_DIMS_ARR[scls] + sres
+        cand = V[p + 'cand_u']
+        lab = RD.boxpc_sample_labels(c, heading, size, scls, bool(V[p + 'is_fit']), V['boxpc/fit'], V['boxpc/nofit'], (cp, sp, ap), cand)
+        assert lab is not None and lab['tries'] == len(cand)             # accepted exactly where the reference stopped drawing
+        n_tries.append(lab['tries'])
+        assert np.allclose(lab['x_center'], V[p + 'new_center'], atol=1e-9)
+        assert lab['x_orient_cls'] == V[p + 'new_angle_cls'] and abs(lab['x_orient_reg'] - V[p + 'new_angle_res']) < 1e-9
+        assert lab['x_dims_cls'] == V[p + 'new_size_cls'] and np.allclose(lab['x_dims_reg'], V[p + 'new_size_res'], atol=1e-9)
+        assert abs(lab['y_box_iou'] - float(V[p + 'box_iou'])) < 1e-9
+        lo, hi = V['boxpc/fit'] if V[p + 'is_fit'] else V['boxpc/nofit']
+        assert lo < float(V[p + 'box_iou']) < hi
+        assert np.allclose(lab['y_center_delta'], V[p + 'y_center_delta'], atol=1e-9)
+        assert np.allclose(lab['y_dims_delta'], V[p + 'y_size_delta'], atol=1e-9)
+        assert abs(lab['y_orient_delta'] - float(V[p + 'y_angle_delta'])) < 1e-9
+    assert max(n_tries) > 1                                               # the rejection loop was exercised
+
+
 def test_flag_parser_against_the_reference_parser():
     """Every flag of models/config.py: name, default, parsed type and value on the README's three recipes and on list / bool flags."""
     with open(os.path.join(HERE, 'reference_config.json')) as f:
