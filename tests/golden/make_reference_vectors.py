@@ -24,7 +24,6 @@ Everything that needs the TensorFlow graph (the networks, the losses) cannot run
 The reference draws its augmentation from the global np.random stream; the draws are recorded next to the outputs, so that the
 oracle (which takes the draws as arguments) and the device kernels can be checked on the same draws.
 """
-import gzip
 import importlib.util
 import json
 import os
@@ -255,10 +254,17 @@ def main():
     # ---- the frustum file readers and the per-sample assembly -------------------------------------------------------------------
     L = synthetic_frustums(seg, 24, seed=3)
     path = os.path.join(HERE, 'reference_frustums.zip.pickle')
-    with gzip.open(path, 'wb') as f:                 # the layout utils.save_zipped_pickle writes (gzip + pickle protocol 2 or below)
-        pickle.dump(L, f, protocol=2)
+    utils.save_zipped_pickle(L, path, protocol=2)    # the reference's own writer; protocol 2 = what its Python 2 `-1` means
     back = utils.load_zipped_pickle(path)
     assert len(back) == 13 and len(back[0]) == 24
+    # and the reference's reader takes what the product's writer produces
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from transferable3d_amd.dataset import save_zipped_pickle as product_save
+    tmp = os.path.join(HERE, '_roundtrip.zip.pickle')
+    product_save(L, tmp)
+    again = utils.load_zipped_pickle(tmp)
+    os.remove(tmp)
+    assert len(again) == 13 and all(np.array_equal(a, b) for a, b in zip(again[4], L[4])) and list(again[6]) == list(L[6])
     N = 128          # the device graph takes multiples of 128 points
     classes = sorted(seg.type2class)
     ds = seg.ROISegBoxDataset(classes, N, 'train', random_flip=True, random_shift=True, rotate_to_center=True, overwritten_data_path=path,
