@@ -7,7 +7,17 @@ What runs is the reference's own code, loaded from where it lies (nothing of it 
     sunrgbd/sunrgbd_detection/roi_seg_box3d_dataset.py angle2class, class2angle, size2class, class2size, rotate_pc_along_y,
                                                        get_3d_box, from_prediction_to_label_format, ROISegBoxDataset.__getitem__
     sunrgbd/sunrgbd_detection/roi_semi_dataset.py      ROISemiDataset.__init__ / get_classes3D / get_batch
-    sunrgbd/sunrgbd_data/utils.py                      roty, load_zipped_pickle
+    sunrgbd/sunrgbd_data/utils.py                      roty, load_zipped_pickle, save_zipped_pickle
+    sunrgbd/sunrgbd_detection/train_boxpc.py           ONLY the two NumPy statistics classes ClassificationStats / BoxDeltaIOUStats:
+                                                       the module imports TensorFlow, so the two `class` statements are taken out of
+                                                       its syntax tree and executed on their own (get_batch_stats; their
+                                                       summarize_stats sorts dict.keys() in place and is Python-2 only)
+    sunrgbd/sunrgbd_detection/test_semisup.py          ONLY the functions softmax, inference and write_detection_results, taken out of
+                                                       the syntax tree the same way.  `inference` gets a session object whose run()
+                                                       hands back prepared arrays in place of network outputs -- what is exercised is
+                                                       the reference's NumPy post-processing (detection score, arg-max decode), not a
+                                                       network; its Python-2 `pc.shape[0]/batch_size` is kept an integer by passing
+                                                       batch_size as an int whose reflected division floors
 
 Three modules those files import do not exist in this image and are given placeholders so that the `import` lines pass:
     cv2       an empty module (nothing recorded here calls it);
@@ -57,6 +67,24 @@ def load(name, path):
     sys.modules[name] = mod
     spec.loader.exec_module(mod)
     return mod
+
+
+class Py2Int(int):
+    """int / Py2Int floors, as `/` between two ints does in the Python 2 the reference was written for."""
+
+    def __rtruediv__(self, other):
+        return other // int(self)
+
+
+def reference_classes(path, names, namespace):
+    """Executes the named top-level `class` / `def` statements of a reference file without running the rest of the module."""
+    import ast
+    with open(path) as f:
+        tree = ast.parse(f.read(), filename=path)
+    body = [n for n in tree.body if isinstance(n, (ast.ClassDef, ast.FunctionDef)) and n.name in names]
+    assert len(body) == len(names)
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, 'exec'), namespace)
+    return [namespace[n] for n in names]
 
 
 def reference_modules():
@@ -375,7 +403,87 @@ def main():
                      (13, 'one_hot'), (14, 'new_center'), (15, 'new_angle_cls'), (16, 'new_angle_res'), (17, 'new_size_cls'),
                      (18, 'new_size_res'), (19, 'box_iou'), (20, 'y_center_delta'), (21, 'y_size_delta'), (22, 'y_angle_delta')):
             out[pfx + k] = np.asarray(item[j])
+    # ---- the stage-b statistics classes of train_boxpc.py (IoU = the oracle's, as above) ------------------------------------------
+    ns = {'np': np, 'class2size': seg.class2size, 'class2angle': seg.class2angle, 'get_3d_box': seg.get_3d_box,
+          'box3d_iou': lambda a, b: IOU_IMPL[0](a, b)}
+    BoxDeltaIOUStats, ClassificationStats = reference_classes(
+        os.path.join(REF, 'sunrgbd', 'sunrgbd_detection', 'train_boxpc.py'), ['BoxDeltaIOUStats', 'ClassificationStats'], ns)
+    n = 48
+    scls = r.randint(0, 6, size=n)
+    pred, yfit = (r.uniform(size=n) < 0.5).astype(np.int64), (r.uniform(size=n) < 0.5).astype(np.int64)
+    cs = ClassificationStats(types_)
+    cs.add_prediction(pred[:20], yfit[:20], scls[:20])
+    cs.add_prediction(pred[20:], yfit[20:], scls[20:])
+    cs.add_loss(1.5); cs.add_loss(0.25); cs.add_loss(2.0)
+    out['stats/cls/pred'], out['stats/cls/y_fit'], out['stats/cls/y_cls'], out['stats/cls/mean_loss'] = pred, yfit, scls, cs.get_mean_loss()
+    st = cs.get_batch_stats()
+    out['stats/cls/classes'] = np.array(sorted(st))
+    out['stats/cls/table'] = np.array([st[k] for k in sorted(st)], dtype=np.float64)
+
+    def boxes(noise):
+        return (c0 + r.normal(size=(n, 3)) * noise, hc.copy(), hr + r.normal(size=n) * noise, scls.copy(), sr + r.normal(size=(n, 3)) * noise * 0.3)
+    hc, hr, sr = r.randint(0, 12, size=n), r.uniform(-0.2, 0.2, size=n), r.normal(size=(n, 3)) * 0.1
+    c0 = r.normal(size=(n, 3)) * 0.3 + [0, 0, 3]
+    ybox, ori, dele = (c0, hc, hr, scls, sr), boxes(0.25), boxes(0.08)
+    bs = BoxDeltaIOUStats(types_)
+    half = lambda b, s: tuple(x[s] for x in b)
+    bs.add_prediction(half(ori, slice(0, 30)), half(dele, slice(0, 30)), half(ybox, slice(0, 30)), scls[:30])
+    bs.add_prediction(half(ori, slice(30, n)), half(dele, slice(30, n)), half(ybox, slice(30, n)), scls[30:])
+    st = bs.get_batch_stats()
+    for tag, b in (('y', ybox), ('ori', ori), ('del', dele)):
+        for nm, arr_ in zip(('center', 'heading_cls', 'heading_res', 'size_cls', 'size_res'), b):
+            out['stats/box/%s/%s' % (tag, nm)] = np.asarray(arr_)
+    out['stats/box/classes'] = np.array(sorted(st))
+    out['stats/box/table'] = np.array([st[k] for k in sorted(st)], dtype=np.float64)
     IOU_IMPL[0] = axis_aligned_iou
+
+    # ---- test_semisup.py: detection scores, decode, result files -------------------------------------------------------------------
+    ns = {'np': np, 'os': os, 'NUM_HEADING_BIN': seg.NUM_HEADING_BIN, 'NUM_SIZE_CLUSTER': seg.NUM_SIZE_CLUSTER, 'roi_seg_box3d_dataset': seg}
+    softmax, inference, write_results = reference_classes(os.path.join(REF, 'sunrgbd', 'sunrgbd_detection', 'test_semisup.py'),
+                                                          ['softmax', 'inference', 'write_detection_results'], ns)
+    nb, bsz, npt = 3, 4, 32
+    tot = nb * bsz
+    net = dict(logits=r.normal(size=(tot, npt, 2)) * 2, center=r.normal(size=(tot, 3)), hs=r.normal(size=(tot, 12)) * 3,
+               hr=r.normal(size=(tot, 12)) * 0.1, ss=r.normal(size=(tot, 10)) * 3, sr=r.normal(size=(tot, 10, 3)) * 0.1,
+               fit=r.uniform(size=tot))
+    net['logits'][5, :, 1] = -9.0                                        # a frustum whose mask is empty
+
+    class Session:                                                       # hands the prepared arrays back batch by batch
+        def __init__(self):
+            self.i = 0
+
+        def run(self, run_ops, feed_dict=None):
+            sl = slice(self.i * bsz, (self.i + 1) * bsz)
+            self.i += 1
+            return [net[k][sl] for k in run_ops]
+    ops = {'pc_pl': 'pc', 'one_hot_vec_pl': 'oh', 'is_training_pl': 'tr', 'logits': 'logits',
+           'end_points': {'F_center': 'center', 'F_heading_scores': 'hs', 'F_heading_residuals': 'hr', 'F_size_scores': 'ss',
+                          'F_size_residuals': 'sr', 'boxpc_fit_prob': 'fit'}}
+    pcs, ohs = np.zeros((tot, npt, 4)), np.zeros((tot, 10))
+    for k, v in net.items():
+        out['infer/net/' + k] = v
+    for tag, use_fit in (('plain', False), ('with_fit', True)):
+        res = inference(Session(), ops, pcs, ohs, Py2Int(bsz), prefix='F_', use_boxpc_fit_prob=use_fit)
+        for nm, v in zip(('seg', 'center', 'heading_cls', 'heading_res', 'size_cls', 'size_res', 'score'), res):
+            out['infer/%s/%s' % (tag, nm)] = np.asarray(v)
+    out['infer/softmax'] = softmax(net['hs'])
+    import shutil
+    import tempfile
+    tmpd = tempfile.mkdtemp()
+    test_classes = ['bed', 'chair', 'desk']
+    tcls = [test_classes[i] for i in r.randint(0, 3, size=tot)]
+    box2d = r.uniform(0, 500, size=(tot, 4))
+    rot = r.uniform(-np.pi, np.pi, size=tot)
+    ids = r.randint(1, 9999, size=tot)
+    res = [out['infer/plain/' + k] for k in ('center', 'heading_cls', 'heading_res', 'size_cls', 'size_res', 'score')]
+    write_results(os.path.join(tmpd, 'res'), test_classes, list(ids), tcls, list(box2d), [c.copy() for c in res[0]], list(res[1]),
+                  list(res[2]), list(res[3]), list(res[4]), list(rot), list(res[5]))
+    out['results/classes'], out['results/type'], out['results/box2d'], out['results/rot'], out['results/ids'] = \
+        np.array(test_classes), np.array(tcls), box2d, rot, ids
+    for c in test_classes:
+        with open(os.path.join(tmpd, 'res', c + '_pred.txt')) as f:
+            out['results/file/' + c] = np.array(f.read())
+    shutil.rmtree(tmpd)
 
     np.savez_compressed(os.path.join(HERE, 'reference_vectors.npz'), **out)
     with open(os.path.join(HERE, 'reference_config.json'), 'w') as f:

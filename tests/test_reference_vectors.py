@@ -308,6 +308,68 @@ def test_boxpc_sample_generator_on_the_recorded_draws(V):
     assert max(n_tries) > 1                                               # the rejection loop was exercised
 
 
+def test_stage_b_statistics_classes(V):
+    """train_boxpc.py ClassificationStats / BoxDeltaIOUStats.get_batch_stats (the two class statements executed out of the reference's
+    syntax tree; the IoU behind BoxDeltaIOUStats is the oracle's): the product's classes report the same tables, the IoU one
+    through the device IoU (its specification here) in fp32."""
+    from transferable3d_amd.boxpc_stats import ALL_CLASSES, BoxDeltaIOUStats, ClassificationStats
+    cs = ClassificationStats(ALL_CLASSES)
+    cs.add_prediction(V['stats/cls/pred'][:20], V['stats/cls/y_fit'][:20], V['stats/cls/y_cls'][:20])
+    cs.add_prediction(V['stats/cls/pred'][20:], V['stats/cls/y_fit'][20:], V['stats/cls/y_cls'][20:])
+    for v in (1.5, 0.25, 2.0):
+        cs.add_loss(v)
+    assert abs(cs.get_mean_loss() - float(V['stats/cls/mean_loss'])) < 1e-12
+    st = cs.get_batch_stats()
+    assert sorted(st) == [str(c) for c in V['stats/cls/classes']]
+    assert np.allclose(np.array([st[k] for k in sorted(st)], np.float64), V['stats/cls/table'], atol=1e-12)
+    bs = BoxDeltaIOUStats(ALL_CLASSES, Runtime(device='cpu', lib=FakeLib()))
+    box = lambda tag, sl: tuple(V['stats/box/%s/%s' % (tag, nm)][sl] for nm in ('center', 'heading_cls', 'heading_res', 'size_cls', 'size_res'))
+    n = len(V['stats/box/y/center'])
+    for sl in (slice(0, 30), slice(30, n)):
+        bs.add_prediction(box('ori', sl), box('del', sl), box('y', sl), V['stats/box/y/size_cls'][sl])
+    st = bs.get_batch_stats()
+    assert sorted(st) == [str(c) for c in V['stats/box/classes']]
+    got = np.array([st[k] for k in sorted(st)], np.float64)
+    assert np.allclose(got, V['stats/box/table'], atol=2e-5) and (V['stats/box/table'][:, 2] > 0).all()     # the closer boxes score higher
+
+
+def test_inference_post_processing_and_result_files(V, tmp_path):
+    """test_semisup.py inference (detection score, arg-max decode) and write_detection_results, the reference's functions executed with
+    a session that hands back prepared arrays in place of network outputs: the product's functions on the same arrays."""
+    from transferable3d_amd import test_semisup as TS
+    net = {k: V['infer/net/' + k] for k in ('logits', 'center', 'hs', 'hr', 'ss', 'sr', 'fit')}
+    tot, bsz = len(net['center']), 4
+    assert np.allclose(TS.softmax(net['hs']), V['infer/softmax'], atol=1e-15)
+
+    class Session:
+        def __init__(self):
+            self.i = 0
+
+        def run(self, run_ops, feed_dict=None):
+            sl = slice(self.i * bsz, (self.i + 1) * bsz)
+            self.i += 1
+            return [net[k][sl] for k in run_ops]
+    ops = {'pc_pl': 'pc', 'one_hot_vec_pl': 'oh', 'logits': 'logits',
+           'end_points': {'F_center': 'center', 'F_heading_scores': 'hs', 'F_heading_residuals': 'hr', 'F_size_scores': 'ss',
+                          'F_size_residuals': 'sr', 'boxpc_fit_prob': 'fit'}}
+    pcs, ohs = np.zeros((tot, net['logits'].shape[1], 4)), np.zeros((tot, 10))
+    for tag, use_fit in (('plain', False), ('with_fit', True)):
+        res = TS.inference(Session(), ops, pcs, ohs, bsz, prefix='F_', use_boxpc_fit_prob=use_fit)
+        for nm, v in zip(('seg', 'center', 'heading_cls', 'heading_res', 'size_cls', 'size_res', 'score'), res):
+            want = V['infer/%s/%s' % (tag, nm)]
+            assert np.asarray(v).shape == want.shape and np.allclose(v, want, atol=1e-12), (tag, nm)
+    assert not V['infer/plain/seg'][5].any()                              # the empty mask went through the "+ 1" denominator
+    res = [V['infer/plain/' + k] for k in ('center', 'heading_cls', 'heading_res', 'size_cls', 'size_res', 'score')]
+    names = [str(t) for t in V['results/type']]
+    predictions = [None, None, None, list(res[0]), list(res[1]), list(res[2]), list(res[3]), list(res[4]), list(V['results/rot']),
+                   list(res[5]), None, list(V['results/ids']), list(V['results/box2d']), None]
+    classes = [str(c) for c in V['results/classes']]
+    TS.write_detection_results(str(tmp_path / 'res'), classes, predictions, names)
+    for c in classes:
+        assert (tmp_path / 'res' / (c + '_pred.txt')).read_text() == str(V['results/file/' + c]), c
+    assert sum(len(str(V['results/file/' + c]).splitlines()) for c in classes) == tot
+
+
 def test_flag_parser_against_the_reference_parser():
     """Every flag of models/config.py: name, default, parsed type and value on the README's three recipes and on list / bool flags."""
     with open(os.path.join(HERE, 'reference_config.json')) as f:
