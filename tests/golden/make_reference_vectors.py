@@ -43,6 +43,7 @@ import types
 
 import numpy as np
 
+sys.dont_write_bytecode = True       # the reference checkout is read-only for this project: importing from it must not leave __pycache__ there
 REF = '/root/reference'
 HERE = os.path.dirname(os.path.abspath(__file__))
 
