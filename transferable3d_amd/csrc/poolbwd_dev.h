@@ -102,6 +102,7 @@ __device__ __forceinline__ void pool_sparse_rows_body(const t3d_pool_sparse_rows
   if (tid < 128) hitrow[tid] = 0;
   int* mine = lists + w * p.N;
   int cnt = 0;
+#ifndef T3D_ABL_SR_NOSCAN      // diagnostic builds (tools/bench_sparse_rows.py): the kernel without its scan / without its add loop
   for (int nb = 0; nb < p.N; nb += 64 * SR_PRE) {
     int rr[SR_PRE];                      // all argidx loads of the block in flight before the first ballot
 #pragma unroll
@@ -119,7 +120,12 @@ __device__ __forceinline__ void pool_sparse_rows_body(const t3d_pool_sparse_rows
       cnt += __popcll(m);
     }
   }
+#endif
   __syncthreads();
+#ifdef T3D_ABL_SR_NOADD
+  if (cnt > 0 && lane == 0) hitrow[mine[0] >> 16] = 1;
+  cnt = 0;
+#endif
   for (int i0 = 0; i0 < cnt; i0 += SR_UNROLL) {
     float2 wv[SR_UNROLL];
     float g[SR_UNROLL];
