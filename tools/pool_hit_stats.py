@@ -20,3 +20,15 @@ for name, L in (('seg conv5', m.seg.L5), ('tnet conv3', m.tnet.T3), ('box conv4'
         for r in v:
             per_tile[b, r // 128] += 1; per_wave[b, r // 128, r & 3] += 1
     print(name, 'channels', a.shape[1], 'live', (a >= 0).mean(), 'distinct rows/frustum', np.mean(distinct), 'hits/tile mean', per_tile.mean(), 'max', per_tile.max(), 'hits/wave max', per_wave.max())
+    # the hottest wave of the layer: how its hits are distributed over rows, and how long runs of equal rows are in channel order
+    best = None
+    for b in range(B):
+        for t in range(N // 128):
+            for w in range(4):
+                rows = [r for r in a[b] if r >= 0 and r // 128 == t and (r & 3) == w]
+                if best is None or len(rows) > len(best):
+                    best = rows
+    best = np.array(best)
+    runs = 1 + int((best[1:] != best[:-1]).sum())
+    vals, cnts = np.unique(best, return_counts=True)
+    print('   hottest wave: %d hits on %d rows (top rows %s), %d runs in channel order' % (len(best), len(vals), sorted(cnts.tolist())[::-1][:5], runs))
