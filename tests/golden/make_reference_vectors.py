@@ -202,6 +202,21 @@ def main():
     out['const/mean_size'] = np.stack([seg.type_mean_size[t] for t in types_])
     out['const/num_heading_bin'], out['const/num_size_cluster'], out['const/num_class'] = seg.NUM_HEADING_BIN, seg.NUM_SIZE_CLUSTER, seg.NUM_CLASS
 
+    # the anchor table the TensorFlow graph itself uses (models/model_util.py imports TensorFlow: its constant assignments are taken
+    # out of the syntax tree -- every top-level assignment / loop over names starting with SUN_ or sun_)
+    import ast
+    mu = os.path.join(REF, 'models', 'model_util.py')
+    with open(mu) as f:
+        src = f.read()
+    tree = ast.parse(src, filename=mu)
+    body = [n for n in tree.body if isinstance(n, (ast.Assign, ast.For)) and
+            any(isinstance(x, ast.Name) and x.id.startswith(('SUN_', 'sun_')) for x in ast.walk(n))]
+    ns_mu = {'np': np}
+    exec(compile(ast.Module(body=body, type_ignores=[]), mu, 'exec'), ns_mu)
+    out['const/graph_mean_size_arr'] = ns_mu['sun_mean_size_arr']
+    out['const/graph_num_heading_bin'], out['const/graph_num_size_cluster'] = ns_mu['SUN_NUM_HEADING_BIN'], ns_mu['SUN_NUM_SIZE_CLUSTER']
+    assert [ns_mu['sun_class2type'][i] for i in range(10)] == types_
+
     # ---- angle / size / box helpers -----------------------------------------------------------------------------------------
     ang = np.concatenate([r.uniform(-2 * np.pi, 4 * np.pi, size=40), [0.0, np.pi, -np.pi, 2 * np.pi - 1e-9, np.pi / 12, -np.pi / 12]])
     a2c = np.array([seg.angle2class(a, seg.NUM_HEADING_BIN) for a in ang])
