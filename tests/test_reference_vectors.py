@@ -46,7 +46,7 @@ def test_every_device_copy_of_the_anchor_table(V):
     found = 0
     for fn in sorted(os.listdir(root)):
         src = open(os.path.join(root, fn)).read()
-        for m in re.finditer(r'(?:float|const float)\s+\w*[Mm]ean\w*\[10\]\[3\]\s*=\s*\{(.*?)\};', src, re.S):
+        for m in re.finditer(r'const float\s+\w+\[(?:10|NS)\]\[3\]\s*=\s*\{(.*?)\};', src, re.S):
             vals = np.array([float(x) for x in re.findall(r'([0-9]+\.[0-9]+)f', m.group(1))], np.float32).reshape(10, 3)
             assert np.array_equal(vals, V['const/graph_mean_size_arr'].astype(np.float32)), fn
             found += 1
