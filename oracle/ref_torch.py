@@ -131,6 +131,15 @@ class Ctx:
         self.ema_unbiased = ema_unbiased
         self.ema_updates = {}
         self.is_training_override = {}   # scope prefix -> bool (stage c: frozen BoxPC net)
+        # Flip-aware gradient checks (tests/model_check.py): an fp32 implementation and this fp64 restatement can disagree on the
+        # side of a ReLU input that is within fp32 rounding of zero, or on which of two near-equal rows is the max-pool's arg-max;
+        # either moves every gradient below it by one element's contribution.  A test may therefore hand over the decisions the
+        # implementation under test actually took -- `forced_gates[scope]` (1 where its ReLU passed) and `forced_argmax[scope]`
+        # ((B, C) row index, -1 = keep the natural one) -- and the restatement differentiates THAT branch of the piecewise-linear
+        # function; forward values move by the size of the disputed pre-activations (~1e-6).  `flips` counts the disagreements.
+        self.forced_gates = {}
+        self.forced_argmax = {}
+        self.flips = {}
 
     def training_for(self, scope):
         for pre, val in self.is_training_override.items():
@@ -161,9 +170,14 @@ def batch_norm(ctx, y, scope):
     return (y - mean) / torch.sqrt(var + BN_EPS) * g + b
 
 
-def _act(x, activation):
+def _act(x, activation, ctx=None, scope=None):
     if activation is None:
         return x
+    gate = ctx.forced_gates.get(scope) if ctx is not None else None
+    if gate is not None and activation in ('relu', 'leaky_relu'):
+        gate = torch.as_tensor(gate).reshape(x.shape).to(x.dtype)
+        ctx.flips[scope] = int(((x.detach() > 0).to(x.dtype) != gate).sum())
+        return x * gate if activation == 'relu' else x * (gate + 0.2 * (1 - gate))
     if activation == 'relu':
         return torch.relu(x)
     if activation == 'leaky_relu':
@@ -180,14 +194,14 @@ def conv2d(ctx, x, scope, bn=True, activation='relu'):
     y = x @ W + ctx.P[scope + '/biases']
     if bn:
         y = batch_norm(ctx, y, scope + '/bn')
-    return _act(y, activation)
+    return _act(y, activation, ctx, scope)
 
 
 def fully_connected(ctx, x, scope, bn=False, activation='relu'):
     y = x @ ctx.P[scope + '/weights'] + ctx.P[scope + '/biases']
     if bn:
         y = batch_norm(ctx, y, scope + '/bn')
-    return _act(y, activation)
+    return _act(y, activation, ctx, scope)
 
 
 def dropout(ctx, x, scope, keep_prob):
@@ -198,9 +212,17 @@ def dropout(ctx, x, scope, keep_prob):
     return x * m.to(x.dtype) / keep_prob
 
 
-def max_pool_points(x):
-    """tf.nn.max_pool ksize [1,N,1,1] == max over the point axis."""
-    return x.max(dim=1).values
+def max_pool_points(x, ctx=None, scope=None):
+    """tf.nn.max_pool ksize [1,N,1,1] == max over the point axis.  (`scope` = the conv layer that feeds the pool: key of
+    Ctx.forced_argmax, see there.)"""
+    forced = ctx.forced_argmax.get(scope) if ctx is not None else None
+    if forced is None:
+        return x.max(dim=1).values
+    nat = x.detach().argmax(dim=1)
+    idx = torch.as_tensor(forced).reshape(nat.shape).to(nat.dtype)
+    idx = torch.where(idx < 0, nat, idx)
+    ctx.flips[scope + '#argmax'] = int((idx != nat).sum())
+    return torch.gather(x, 1, idx[:, None, :]).squeeze(1)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -214,7 +236,7 @@ def v1_inst_seg(ctx, pc, one_hot_vec, scope='inst_seg', ep=None):
     point_feat = conv2d(ctx, net, scope + '/conv3')
     net = conv2d(ctx, point_feat, scope + '/conv4')
     net = conv2d(ctx, net, scope + '/conv5')
-    global_feat = max_pool_points(net)                              # (B,1024)
+    global_feat = max_pool_points(net, ctx, scope + '/conv5')          # (B,1024)
     if ep is not None:
         ep['seg_global_feat'] = global_feat
     if one_hot_vec is not None:
@@ -243,7 +265,7 @@ def v1_tnet(ctx, xyz_stage1, mask, mask_xyz_mean, one_hot_vec, ep, scope='tnet')
     net = conv2d(ctx, xyz_stage1, scope + '/conv-reg1-stage1')
     net = conv2d(ctx, net, scope + '/conv-reg2-stage1')
     net = conv2d(ctx, net, scope + '/conv-reg3-stage1')
-    net = max_pool_points(net * mask)
+    net = max_pool_points(net * mask, ctx, scope + '/conv-reg3-stage1')
     ep['tnet_feats'] = net
     if one_hot_vec is not None:
         net = torch.cat([net, one_hot_vec], dim=1)
@@ -279,7 +301,7 @@ def v1_box_est(ctx, xyz_submean, stage1_center, mask, one_hot_vec, ep, prefix=''
     net = conv2d(ctx, net, scope + '/conv-reg2')
     net = conv2d(ctx, net, scope + '/conv-reg3')
     net = conv2d(ctx, net, scope + '/conv-reg4')
-    net = max_pool_points(net * mask)
+    net = max_pool_points(net * mask, ctx, scope + '/conv-reg4')
     ep[prefix + 'feats_lv1'] = net
     if one_hot_vec is not None:
         net = torch.cat([net, one_hot_vec], dim=1)
@@ -397,7 +419,7 @@ def boxpc_get_model(ctx, box_reg, pc, one_hot_vec, use_one_hot_vec, c, scope_pre
     net = conv2d(ctx, net, sc + '/conv-reg2')
     net = conv2d(ctx, net, sc + '/conv-reg3')
     net = conv2d(ctx, net, sc + '/conv-reg4')
-    net = max_pool_points(net)
+    net = max_pool_points(net, ctx, sc + '/conv-reg4')
     if use_one_hot_vec:
         net = torch.cat([net, one_hot_vec], dim=1)
     f1 = net
@@ -657,13 +679,21 @@ def _labels_to_torch(batch, dtype):
             torch.as_tensor(batch['is_data_2D']))
 
 
+def _apply_forced(ctx, forced):
+    """forced = {'gates': {scope: 0/1 array}, 'argmax': {scope: (B, C) int array}} -- see Ctx.forced_gates."""
+    if forced:
+        ctx.forced_gates = dict(forced.get('gates', {}))
+        ctx.forced_argmax = dict(forced.get('argmax', {}))
+
+
 def model_a_forward_backward(P, batch, c, bn_decay_val=0.5, dtype=torch.float64, use_one_hot=False,
-                             is_training=True, want_grads=True):
+                             is_training=True, want_grads=True, forced=None):
     """fwd (+bwd) of SEMI_MODEL A on one batch.  Returns (loss, end_points, grads, ema_updates)."""
     names = trainable_names(P)
     Pl = {k: (val.detach().to(dtype).requires_grad_(k in names and want_grads)) for k, val in P.items()}
     masks = {k: torch.as_tensor(val) for k, val in batch.get('dropout_masks', {}).items()}
     ctx = Ctx(Pl, is_training=is_training, bn_decay=bn_decay_val, dropout_masks=masks)
+    _apply_forced(ctx, forced)
     pc = torch.as_tensor(batch['pc'], dtype=dtype)
     oh = torch.as_tensor(batch['one_hot_vec'], dtype=dtype)
     pred, ep = get_semi_model_backbone(ctx, pc, oh, use_one_hot)
@@ -672,16 +702,18 @@ def model_a_forward_backward(P, batch, c, bn_decay_val=0.5, dtype=torch.float64,
     if want_grads:
         gl = torch.autograd.grad(loss, [Pl[k] for k in names], allow_unused=True)
         grads = {k: (g if g is not None else torch.zeros_like(Pl[k])) for k, g in zip(names, gl)}
+    ep['__flips__'] = dict(ctx.flips)
     return loss, ep, grads, ctx.ema_updates
 
 
 def boxpc_forward_backward(P, batch, c, bn_decay_val=0.5, dtype=torch.float64, is_training=True,
-                           want_grads=True):
+                           want_grads=True, forced=None):
     """fwd (+bwd) of the Box-PC Fit net (train_boxpc.py path) on one batch."""
     names = trainable_names(P)
     Pl = {k: (val.detach().to(dtype).requires_grad_(k in names and want_grads)) for k, val in P.items()}
     masks = {k: torch.as_tensor(val) for k, val in batch.get('dropout_masks', {}).items()}
     ctx = Ctx(Pl, is_training=is_training, bn_decay=bn_decay_val, dropout_masks=masks)
+    _apply_forced(ctx, forced)
     pc = torch.as_tensor(batch['pc'], dtype=dtype)
     oh = torch.as_tensor(batch['one_hot_vec'], dtype=dtype)
     y_box = (torch.as_tensor(batch['y_center'], dtype=dtype), torch.as_tensor(batch['y_orient_cls']),
@@ -698,11 +730,12 @@ def boxpc_forward_backward(P, batch, c, bn_decay_val=0.5, dtype=torch.float64, i
     if want_grads:
         gl = torch.autograd.grad(loss, [Pl[k] for k in names], allow_unused=True)
         grads = {k: (g if g is not None else torch.zeros_like(Pl[k])) for k, g in zip(names, gl)}
+    ep['__flips__'] = dict(ctx.flips)
     return loss, ep, grads, ctx.ema_updates
 
 
 def stage_c_forward_backward(P, batch, c, train_classes, bn_decay_val=0.5, dtype=torch.float64, use_one_hot=True,
-                             var_prefixes=('class_dependent', 'class_agnostic/tnet', 'class_agnostic/box'), want_grads=True):
+                             var_prefixes=('class_dependent', 'class_agnostic/tnet', 'class_agnostic/box'), want_grads=True, forced=None):
     """One stage-c step (train_semisup_adv.py:308-422, SEMI_MODEL F): class-agnostic nets + box_refine, the frozen
     Box-PC net (`D_boxpc_branch/`, is_training_D = False when SEMI_TRAIN_BOXPC_MODEL = 0) applied to F_pred_box_reg,
     get_semi_loss_final, gradients w.r.t. the var_list (regex-prefix semantics of get_scope_vars)."""
@@ -711,6 +744,7 @@ def stage_c_forward_backward(P, batch, c, train_classes, bn_decay_val=0.5, dtype
     masks = {k: torch.as_tensor(val) for k, val in batch.get('dropout_masks', {}).items()}
     ctx = Ctx(Pl, is_training=True, bn_decay=bn_decay_val, dropout_masks=masks)
     ctx.is_training_override['D_boxpc_branch/'] = False
+    _apply_forced(ctx, forced)
     pc = torch.as_tensor(batch['pc'], dtype=dtype)
     oh = torch.as_tensor(batch['one_hot_vec'], dtype=dtype)
     pred, ep = get_semi_model_final(ctx, pc, oh, use_one_hot, c)
@@ -724,6 +758,7 @@ def stage_c_forward_backward(P, batch, c, train_classes, bn_decay_val=0.5, dtype
     if want_grads:
         gl = torch.autograd.grad(loss, [Pl[k] for k in names], allow_unused=True)
         grads = {k: (g if g is not None else torch.zeros_like(Pl[k])) for k, g in zip(names, gl)}
+    ep['__flips__'] = dict(ctx.flips)
     return loss, ep, grads, ctx.ema_updates
 
 

@@ -16,18 +16,17 @@ def _params(C, seed):
     return R.init_params(np.random.RandomState(seed), R.layer_table(C, 'A'))
 
 
-@pytest.mark.parametrize('B,N,seed,med_tol', [(4, 256, 1, 3e-3), (8, 512, 2, 3e-3)])
-def test_model_a_step_matches_oracle(hip_lib, B, N, seed, med_tol):
-    """med_tol (the fp64 specification run of the same step meets 1e-4, tests/test_plan_cpu.py): a layer has millions of ReLU inputs, a few of which sit within fp32
-    rounding of zero and flip relative to the fp64 oracle; each flip moves every gradient below it by about one
-    element's worth (~1/M relative), which the CPU specification run reproduces (DESIGN.md, 'ReLU-boundary
-    flips').  The forward tolerance stays 1e-4."""
+@pytest.mark.parametrize('B,N,seed', [(4, 256, 1), (8, 512, 2)])
+def test_model_a_step_matches_oracle(hip_lib, B, N, seed):
+    """Forward heads and loss within 1e-4 (north-star); EVERY gradient tensor within 3e-4 relative L2, median 5e-5, global 1e-4
+    (model_check.tight_grad_check): the fp64 oracle differentiates the ReLU / arg-max branch the kernels actually took
+    (model_check.product_decisions), so a pre-activation within fp32 rounding of zero no longer needs a loose bound."""
     C = 4
     batch = make_batch(B, N, C, seed=seed, dropout_scopes={'inst_seg/dp1': ((B, N, 128), 0.5)})
     P = _params(C, 7 + seed)
     c = R.default_config()
     g, m = run_model_a(Runtime(lib=hip_lib), batch, P, c)
-    res = check_against_oracle(g, m, batch, P, c, grad_median_tol=med_tol)
+    res = check_against_oracle(g, m, batch, P, c)
     print(res)
 
 
@@ -40,33 +39,34 @@ def test_model_a_matches_golden_vectors(hip_lib):
         got = e[k].cpu().numpy().reshape(ref.shape)
         assert np.abs(got - ref).max() < 1e-4 * max(1.0, np.abs(ref).max()), k     # BASELINE.json: 1e-4 fp32
     assert abs(float(e['loss'].cpu()) - float(z['out/loss'])) < 1e-4 * float(z['out/loss'])
-    # gradients: the two-level bound of model_check.check_against_oracle (median per-tensor relative L2 <= 1e-4, global
-    # <= 1e-2): a single ReLU whose pre-activation is within fp32 rounding of zero may flip against the fp64 fixture and
-    # moves individual elements of a few tensors by ~1 % at this tiny size (M = 512 rows); a systematic error moves the median
+    # gradients against the frozen fp64 fixture: tight on every tensor unless a ReLU input of this run sits within fp32 rounding
+    # of zero on the other side than in the fixture -- in which case the oracle is re-run on the fixture's inputs along the branch
+    # the kernels took and THAT comparison is tight (check_against_oracle); a fixture mismatch beyond 1e-2 fails either way
     from model_check import grad_errors
     # (the fixture keeps only the first rows of the largest weight gradient: checked separately below)
-    per, glob = grad_errors(g, {k[5:]: z[k] for k in z.files if k.startswith('grad/') and k != 'grad/box_est/fc1/weights'})
+    per, glob = grad_errors(g, {k: v for k, v in ((k[5:], z[k]) for k in z.files if k.startswith('grad/')) if k != 'box_est/fc1/weights'})
     part = z['grad/box_est/fc1/weights']
     mine = g.vars.grad('box_est/fc1/weights').cpu().numpy().reshape(-1, part.shape[1])[:part.shape[0]]
     assert np.linalg.norm(mine - part) < 1e-2 * np.linalg.norm(part)
-    # (1e-4 in the fp64 specification run of this fixture, tests/test_plan_cpu.py; 3e-3 here: a ReLU-boundary flip at this tiny size)
-    assert float(np.median(list(per.values()))) < 3e-3, sorted(per.items(), key=lambda kv: -kv[1])[:5]
     assert glob < 1e-2, glob
-    assert max(per.values()) < 5e-2, max(per.items(), key=lambda kv: kv[1])
+    res = check_against_oracle(g, m, batch, P, R.default_config())
+    if not res['flips']:
+        assert max(per.values()) < 3e-4 and glob < 1e-4, (max(per.items(), key=lambda kv: kv[1]), glob)
 
 
-def test_full_size_properties(hip_lib):
-    """BASELINE size (B=32, N=1024): size-independent properties instead of an fp64 oracle run.
-    (1) batch-norm'd activations have zero mean / unit variance per channel; (2) the analytically-zero
-    gradients (conv biases, beta of a layer feeding only a batch-norm) vanish; (3) permuting the frustums
-    permutes the per-frustum outputs and leaves the weight gradients unchanged; (4) two runs are bit-identical
-    (no atomics anywhere on the path)."""
+def test_full_size_against_the_oracle_and_properties(hip_lib):
+    """BASELINE size (B=32, N=1024, C=4): (0) the fp64 oracle on the same batch -- forward heads / loss within 1e-4, every
+    gradient tensor tight (flip-aware), moving statistics; then size-independent properties: (1) batch-norm'd activations have
+    zero mean / unit variance per channel; (2) the analytically-zero gradients (conv biases, beta of a layer feeding only a
+    batch-norm) vanish; (3) permuting the frustums permutes the per-frustum outputs and leaves the weight gradients unchanged;
+    (4) two runs are bit-identical (no atomics anywhere on the path)."""
     B, N, C = 32, 1024, 4
     batch = make_batch(B, N, C, seed=1234, dropout_scopes={'inst_seg/dp1': ((B, N, 128), 0.5)})
     P = _params(C, 99)
     c = R.default_config()
     rt = Runtime(lib=hip_lib)
     g, m = run_model_a(rt, batch, P, c)
+    print(check_against_oracle(g, m, batch, P, c))
     L = m.seg.L7
     z = L.y * L.scale + L.shift
     assert float(z.mean(0).abs().max()) < 1e-4 and float((z.var(0, unbiased=False) - 1).abs().max()) < 2e-2
@@ -113,7 +113,7 @@ def test_stage_c_step_matches_oracle(hip_lib):
     c = stage_c_config()
     g, m = run_stage_c(Runtime(lib=hip_lib), batch, P, c)
     torch.cuda.synchronize()
-    print(check_stage_c(g, m, batch, P, c, grad_median_tol=1e-3))
+    print(check_stage_c(g, m, batch, P, c))
 
 
 def test_config0_single_frustum_forward(hip_lib):
@@ -166,4 +166,4 @@ def test_model_a_with_three_and_six_channel_point_clouds(hip_lib, C):
     c = R.default_config()
     g, m = run_model_a(Runtime(lib=hip_lib), batch, P, c)
     assert m.inputs.pc.shape == (B * N, 4 if C == 3 else 8)
-    check_against_oracle(g, m, batch, P, c, grad_median_tol=1e-3)
+    check_against_oracle(g, m, batch, P, c)

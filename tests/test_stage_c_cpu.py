@@ -53,7 +53,8 @@ def run_stage_c(rt, batch, P, c):
 
 
 def check_stage_c(g, m, batch, P, c, grad_median_tol=2e-4):
-    loss, ep, grads, ema = R.stage_c_forward_backward(P, batch, c, TRAIN_CLASSES)
+    from model_check import product_decisions, tight_grad_check
+    loss, ep, grads, ema = R.stage_c_forward_backward(P, batch, c, TRAIN_CLASSES, forced=product_decisions(m))
     e = m.end_points()
     num = lambda t: t.detach().cpu().numpy()
     for mine, ref in (('logits', ep['logits']), ('stage1_center', ep['stage1_center']), ('feats_lv1', ep['feats_lv1']),
@@ -66,9 +67,9 @@ def check_stage_c(g, m, batch, P, c, grad_median_tol=2e-4):
     from model_check import iou_summary_check
     iou_summary_check(e, ep, batch, '', 'F_')                  # get_iou_summary(F_pred_box, ..., '')   semisup_v1_sunrgbd.py:416
     iou_summary_check(e, ep, batch, 'W_', '')                  # get_iou_summary(W_pred_box, ..., 'W_') semisup_v1_sunrgbd.py:414
-    per, glob = grad_errors(g, {k: v.numpy() for k, v in grads.items()})
-    med = float(np.median(list(per.values())))
-    assert med < grad_median_tol and glob < 1e-2, (med, glob, sorted(per.items(), key=lambda kv: -kv[1])[:4])
+    # every tensor tight: the oracle differentiates the ReLU / arg-max branches the product took (model_check.product_decisions)
+    res = tight_grad_check(g, {k: v.numpy() for k, v in grads.items()}, what='stage c')
+    med, glob = res['grad_median'], res['grad_global']
     # nothing outside the var_list may receive a gradient
     assert float(g.vars.grad('class_agnostic/inst_seg/conv3/weights').abs().max()) == 0.0
     assert float(g.vars.grad('D_boxpc_branch/box_pc_mask_model/fc1/weights').abs().max()) == 0.0

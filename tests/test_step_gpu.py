@@ -1,0 +1,68 @@
+"""GPU: the step object bench.py times (transferable3d_amd.step.build_training_step -> TrainStep: device schedules, in-kernel
+dropout, forward, backward, TF-form Adam, hipGraph replay) against an oracle trajectory, step by step; the data-parallel program on
+a one-rank RCCL group against the single-replica step, bit for bit."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from model_check import trajectory_check
+from transferable3d_amd.engine import Runtime
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('workload', ['A', 'boxpc', 'F'])
+def test_five_replayed_steps_follow_the_oracle(hip_lib, workload):
+    """Step 0 runs eagerly, step 1 captures the hipGraph, steps 1-4 are replays of it: loss, heads, every gradient tensor, moving
+    statistics (EMA chaining with the device-side bn_decay), Adam moments and post-step weights (device-side lr, step counter,
+    var_list of stage c) of EVERY step against the oracle."""
+    rep = trajectory_check(Runtime(lib=hip_lib), workload, steps=5, B=8, N=256, use_hip_graph=True, verbose=True)
+    assert rep[-1]['graph_segments'] == 1
+    assert all(r['weight_entries_checked'] > 1000 for r in rep[:-1])
+
+
+def test_three_replayed_steps_at_the_headline_size_follow_the_oracle(hip_lib):
+    """BASELINE configs[1] itself: B=32, N=1024, C=4."""
+    rep = trajectory_check(Runtime(lib=hip_lib), 'A', steps=3, B=32, N=1024, use_hip_graph=True, verbose=True)
+    assert rep[-1]['graph_segments'] == 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_data_parallel_step_on_one_rank_rccl_equals_the_single_replica_step(hip_lib):
+    """The multi-rank program (three gradient buckets all-reduced on RCCL beside the rest of the backward, one hipGraph segment
+    between two collectives, Adam per bucket) with ONE rank must reproduce the single-replica step bit for bit -- weights after 4
+    steps (3 of them graph replays) and the loss; so must the flat variant (one all-reduce between backward and Adam)."""
+    import torch.distributed as dist
+    from transferable3d_amd.step import build_training_step
+    from transferable3d_amd.synthetic import make_batch
+    torch.cuda.set_device(0)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('nccl', rank=0, world_size=1, init_method='tcp://127.0.0.1:%d' % _free_port(),
+                            device_id=torch.device('cuda', 0))
+    try:
+        B, N, C = 8, 256, 4
+        out = {}
+        for mode in ('single', 'bucketed', 'flat'):
+            pg = None if mode == 'single' else dist.group.WORLD
+            g, model, step, loss = build_training_step(Runtime(lib=hip_lib), 'A', B, N, C, process_group=pg, force_dist=mode != 'single',
+                                                       flat_allreduce=mode == 'flat', seed=3, use_hip_graph=True)
+            for k in range(4):
+                model.inputs.load(make_batch(B, N, C, seed=70 + k))
+                step.run()
+            torch.cuda.synchronize()
+            out[mode] = (g.vars.params[:g.vars.used].clone(), float(loss), step.n_graph_segments())
+        assert out['single'][2] == 1 and out['bucketed'][2] == 6 and out['flat'][2] == 2, [v[2] for v in out.values()]
+        assert torch.equal(out['single'][0], out['bucketed'][0]) and torch.equal(out['single'][0], out['flat'][0])
+        assert out['single'][1] == out['bucketed'][1] == out['flat'][1]
+    finally:
+        dist.destroy_process_group()

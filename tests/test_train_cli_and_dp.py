@@ -39,10 +39,10 @@ def _free_port():
     return p
 
 
-def _dp_worker(rank, world, port, tmp, q):
+def _dp_worker(rank, world, port, tmp, q, flat=False):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
-                      MASTER_PORT=str(port))
+                      MASTER_PORT=str(port), T3D_DP_FLAT='1' if flat else '0')
     torch.set_num_threads(2)
     from fake_t3d import FakeLib as FL
     FLAGS = build_flags(ARGS[:-5] + ['--max_epoch', '1', '--steps_per_epoch', '1', '--synthetic', '--log_dir',
@@ -51,20 +51,31 @@ def _dp_worker(rank, world, port, tmp, q):
     q.put((rank, {k: v for k, v in sd.items() if k.endswith('weights') or k.endswith('gamma')}))
 
 
-def test_data_parallel_world_size_2_gloo(tmp_path):
-    world, port = 2, _free_port()
+def _run_dp(tmp, world, flat):
+    port = _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, tmp, q, flat)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=300) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    return res
+
+
+def test_data_parallel_world_size_2_gloo(tmp_path):
+    world = 2
+    res = _run_dp(str(tmp_path / 'bucketed'), world, flat=False)
     # replicas stay bit-identical (same init, same all-reduced gradients, same Adam)
     for k in res[0]:
         assert np.array_equal(res[0][k], res[1][k]), k
+    # three gradient buckets reduced beside the backward (box + T-Net | seg conv10..6 | seg conv5..1), Adam per bucket
+    # == ONE flat all-reduce between the backward and one Adam launch, bit for bit
+    flat = _run_dp(str(tmp_path / 'flat'), world, flat=True)
+    for k in res[0]:
+        assert np.array_equal(res[0][k], flat[0][k]), k
 
     # reference: average of the two replicas' single-process gradients at step 0
     from model_check import run_model_a

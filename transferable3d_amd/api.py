@@ -190,11 +190,16 @@ class Session:
     """tf.Session analogue.  run(fetches, feed_dict): H2D copies of the fed arrays, one replay of the compiled
     launch schedule, D2H of the fetched tensors."""
 
-    def __init__(self, graph=None, use_hip_graph=None, dropout_seed=1234, process_group=None):
+    def __init__(self, graph=None, use_hip_graph=None, dropout_seed=1234, process_group=None, force_dist=None):
+        """process_group: data-parallel replicas (one process per GPU); force_dist (default: env T3D_FORCE_DIST=1): take the
+        multi-rank path -- bucketed backward, collectives -- even when the group has one rank."""
+        import os
         self.g = graph or get_default_graph()
         self.use_hip_graph = use_hip_graph
         self.dropout_seed = dropout_seed
         self.pg = process_group
+        self.force_dist = (os.environ.get('T3D_FORCE_DIST', '0') == '1') if force_dist is None else bool(force_dist)
+        self.dp_flat = os.environ.get('T3D_DP_FLAT', '0') == '1'      # one all-reduce between backward and Adam (the A/B of the buckets)
         self.steps = {}
 
     # -- compilation ------------------------------------------------------------------------------------
@@ -226,6 +231,8 @@ class Session:
             e.emit_dropout_masks(pre, seed=self.dropout_seed)
         asm.emit_forward(fwd, is_training, with_loss)
         if train:
+            # data parallel: the backward declares its gradient buckets (all-reduce of a finished bucket beside the rest)
+            e.dp_buckets = self.pg is not None and (self.pg.size() > 1 or self.force_dist) and not self.dp_flat
             asm.emit_backward(bwd)
             o = g.optimizer
             world = self.pg.size() if self.pg is not None else 1
@@ -278,65 +285,20 @@ class Session:
 
 
 class _Step:
-    """pre (schedules, dropout masks) -> fwd -> bwd -> [all-reduce] -> adam; hipGraph-captured on the GPU."""
+    """pre (batch assembly, schedules, dropout masks) -> fwd -> bwd -> [bucketed all-reduce] -> adam: step.TrainStep, the object
+    bench.py times; hipGraph-captured on the GPU (also when dropout masks are fed: that variant is captured without the mask
+    generator launches)."""
 
     def __init__(self, sess, pre, fwd, bwd, opt, train):
+        from .step import TrainStep
         self.sess, self.pre, self.fwd, self.bwd, self.opt, self.train = sess, pre, fwd, bwd, opt, train
         e = sess.g.engine
-        self.on_gpu = e.rt.device.type == 'cuda'
-        want = sess.use_hip_graph if sess.use_hip_graph is not None else self.on_gpu
-        self.graphs = None
-        self.want_graph = want and self.on_gpu
-        self.n_runs = 0
+        self.impl = TrainStep(e, pre, fwd, bwd if train else None, opt if train else None, process_group=sess.pg,
+                              use_hip_graph=sess.use_hip_graph, force_dist=sess.force_dist)
 
-    def _eager(self, skip_mask_generation):
-        e = self.sess.g.engine
-        pg = self.sess.pg
-        if self.train:
-            if skip_mask_generation:
-                for name, call, _ in self.pre.calls:
-                    if name != 't3d_dropout_mask':
-                        abi.check(call(e.rt.stream()), name)
-            else:
-                self.pre.run()
-        self.fwd.run()
-        if self.train:
-            self.bwd.run()
-            if pg is not None and pg.size() > 1:
-                import torch.distributed as dist
-                dist.all_reduce(e.vars.grads[:e.vars.used], group=pg)
-            self.opt.run()
+    @property
+    def n_runs(self):
+        return self.impl.n_runs
 
     def run(self, skip_mask_generation=False):
-        self.n_runs += 1
-        # the first run is eager (it also loads the code objects); capture happens on the second run, and
-        # capturing executes nothing, so step semantics are unchanged
-        if not self.want_graph or skip_mask_generation or self.n_runs == 1:
-            return self._eager(skip_mask_generation)
-        e = self.sess.g.engine
-        pg = self.sess.pg
-        multi = pg is not None and pg.size() > 1
-        if self.graphs is None:
-            torch.cuda.synchronize()
-            s = torch.cuda.Stream()
-            g1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1, stream=s, capture_error_mode='thread_local'):
-                if self.train:
-                    self.pre.run()
-                self.fwd.run()
-                if self.train:
-                    self.bwd.run()
-                    if not multi:
-                        self.opt.run()
-            g2 = None
-            if self.train and multi:
-                g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2, stream=s, capture_error_mode='thread_local'):
-                    self.opt.run()
-            self.graphs = (g1, g2)
-        g1, g2 = self.graphs
-        g1.replay()
-        if g2 is not None:
-            import torch.distributed as dist
-            dist.all_reduce(e.vars.grads[:e.vars.used], group=pg)
-            g2.replay()
+        self.impl.run(generate_masks=not skip_mask_generation)

@@ -84,6 +84,7 @@ class Plan:
     serial schedule."""
 
     JOIN, FLUSH = '__join__', '__flush__'
+    BUCKET, WAIT = '__bucket__', '__wait__'       # data-parallel markers (step.TrainStep): gradient bucket i complete / needed
 
     def __init__(self, rt):
         self.rt = rt
@@ -167,6 +168,17 @@ class Plan:
         issue_side()
         if pending:
             main.wait_stream(side)
+
+    def bucket_ready(self, i):
+        """Every gradient of bucket i (nets.Graph.buckets[i]) has been written by the launches recorded so far: a data-parallel
+        step issues the bucket's all-reduce here, beside what follows.  No-op for a single replica."""
+        self.calls.append((Plan.BUCKET, lambda s: 0, i))
+        self.lanes.append(0)
+
+    def bucket_wait(self, i):
+        """What follows (the bucket's Adam launch) needs bucket i's all-reduced gradients."""
+        self.calls.append((Plan.WAIT, lambda s: 0, i))
+        self.lanes.append(0)
 
     def __len__(self):
         return sum(1 for name, _, _ in self.calls if not name.startswith('__'))

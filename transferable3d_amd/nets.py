@@ -22,7 +22,11 @@ class Graph:
     """Static launch graph for one (batch_size, num_point, num_channel) problem; the analogue of the
     reference's tf.Graph + tf.Session (train_semisup.py:204-277)."""
 
-    def __init__(self, batch_size, num_point, num_channel, rt=None, seed=0, unbiased_ema=True, vars=None):
+    def __init__(self, batch_size, num_point, num_channel, rt=None, seed=0, unbiased_ema=True, vars=None, dtype='f32'):
+        """dtype: 'f32' = exact-fp32 MFMA path (BASELINE configs[1..3]); 'bf16' = bf16 activation storage + bf16 MFMA with fp32
+        accumulation, statistics, parameters and optimiser (configs[4])."""
+        assert dtype in ('f32', 'bf16')
+        self.dtype = dtype
         if num_point % TILE:
             raise abi.T3DError('num_point must be a multiple of %d' % TILE)
         self.rt = rt or Runtime()
@@ -40,6 +44,11 @@ class Graph:
         # inject explicit masks and leave this off
         self.inline_dropout, self.dropout_seed = False, 1234
         self.deferred_slab_ptrs = []
+        # data parallelism: gradient buckets [[(offset, n), ...], ...] in the order the backward completes them (declare_bucket)
+        self.dp_buckets = False                    # set before emit_backward: cut the backward into buckets (step.TrainStep)
+        self.buckets = []
+        self.trained_prefixes = None               # var_list of the optimiser (None: everything)
+        self._slabs_reduced = 0
         self.fwd = Plan(self.rt)
         self.bwd = Plan(self.rt)
         self.opt = Plan(self.rt)
@@ -56,18 +65,34 @@ class Graph:
 
     # ---- optimiser ---------------------------------------------------------------------------------
     def emit_reduce_slabs(self, plan):
-        """Must be emitted after every wgrad has been recorded; resolved at run time (post-finalize)."""
+        """Sums the weight-gradient slabs recorded since the previous call into the gradient buffer (fixed order, no atomics).
+        Must follow the wgrads it covers; pointers are resolved at run time (post-finalize)."""
         ws, vs, lib = self.ws, self.vars, self.rt.lib
         plan.join()                       # the weight gradients were recorded on the side lane
+        i0, i1 = self._slabs_reduced, len(ws.entries)
+        self._slabs_reduced = i1
+        if i1 == i0:
+            return
+        mx = max(e[2] for e in ws.entries[i0:i1])
+        stride = C.sizeof(abi.SlabDesc)
 
         def thunk(s):
-            n = len(ws.entries)
-            if n == 0:
-                return 0
-            mx = max(e[2] for e in ws.entries)
-            return lib.t3d_reduce_slabs(fptr(ws.buf), fptr(vs.grads), C.cast(C.c_void_p(ws.table.data_ptr()), C.POINTER(abi.SlabDesc)),
-                                        n, mx, s)
+            return lib.t3d_reduce_slabs(fptr(ws.buf), fptr(vs.grads),
+                                        C.cast(C.c_void_p(ws.table.data_ptr() + i0 * stride), C.POINTER(abi.SlabDesc)), i1 - i0, mx, s)
         plan.add_raw('t3d_reduce_slabs', thunk)
+
+    def default_bucket(self):
+        """Every trained range: the one bucket of a step whose backward declares none."""
+        return self.vars.trainable_ranges(self.trained_prefixes)
+
+    def declare_bucket(self, plan, prefixes):
+        """Data-parallel gradient bucket: the trainable variables under `prefixes` are complete once the launches recorded so far
+        (and one slab reduction emitted here) have run.  No-op unless `dp_buckets` is set."""
+        if not self.dp_buckets:
+            return
+        self.emit_reduce_slabs(plan)
+        self.buckets.append(self.vars.trainable_ranges(prefixes))
+        plan.bucket_ready(len(self.buckets) - 1)
 
     def emit_batch_assemble(self, plan, dataset, inputs, seed=0, **aug):
         """The input pipeline as a launch of the step: batch slot b of step s takes frustum perm[(s*B + b) % F] of the
@@ -108,12 +133,29 @@ class Graph:
                              fptr(mask), mask.numel(), keep, sd, fptr(hyper), s))
 
     def emit_adam(self, plan, prefixes=None, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+        """TF-form Adam over the trained ranges.  With gradient buckets declared by the backward (data parallel): one launch per
+        bucket range behind that bucket's wait marker, in the order the buckets complete."""
         lib, vs, hyper = self.rt.lib, self.vars, self.hyper
-        for off, n in vs.trainable_ranges(prefixes):
+        self.trained_prefixes = prefixes
+
+        def adam(off, n):
             plan.add_raw('t3d_adam_tf_step',
                          lambda s, off=off, n=n: lib.t3d_adam_tf_step(
                              fptr(vs.params[off:]), fptr(vs.grads[off:]), fptr(vs.adam_m[off:]), fptr(vs.adam_v[off:]),
                              n, fptr(hyper), beta1, beta2, eps, grad_scale, s))
+        ranges = vs.trainable_ranges(prefixes)
+        if self.buckets:
+            covered = sorted(r for b in self.buckets for r in b)
+            assert sum(n for _, n in covered) == sum(n for _, n in ranges) and \
+                all(any(o >= ro and o + n <= ro + rn for ro, rn in ranges) for o, n in covered), \
+                'gradient buckets must partition the trained variables'
+            for i, b in enumerate(self.buckets):
+                plan.bucket_wait(i)
+                for off, n in b:
+                    adam(off, n)
+            return
+        for off, n in ranges:
+            adam(off, n)
 
 
 def make_schedule(batch_size, base_lr=1e-3, decay_step=800000, decay_rate=0.5, bn_init_decay=0.5,
@@ -449,8 +491,19 @@ class ModelAssembly:
         plan.flush()                     # box-net weight gradients run beside the T-Net / seg-net dgrad chain
         self.tnet.bwd(plan, ds1)
         plan.flush()
-        self.seg.bwd(plan)
-        self.g.emit_reduce_slabs(plan)
+        # data parallel: the box / T-Net gradients are complete here and nothing the seg net computes touches
+        # them (semisup_models.py:150-151), so their all-reduce runs beside the seg net's backward; the seg net's own gradients
+        # go in two buckets, conv10..conv6 (2.9 MB, ready after conv6) and conv5..conv1 (0.6 MB, the exposed tail)
+        g, sp = self.g, self.seg.scope + '/'
+        g.declare_bucket(plan, [self.tnet.scope + '/', self.box.scope + '/'])
+        self.seg.bwd(plan, part=0)
+        self.seg.bwd(plan, part=1)
+        g.declare_bucket(plan, [sp + 'conv%d/' % i for i in (6, 7, 8, 9, 10)])
+        self.seg.bwd(plan, part=2)
+        if g.dp_buckets:
+            g.declare_bucket(plan, [sp + 'conv%d/' % i for i in (1, 2, 3, 4, 5)])
+        else:
+            g.emit_reduce_slabs(plan)
 
     def end_points(self):
         g = self.g

@@ -1,0 +1,223 @@
+"""One training / inference step as the drivers run it: pre (batch assembly, schedules, dropout masks) -> forward -> backward
+[-> gradient all-reduce, bucketed and overlapped with the rest of the backward] -> Adam, captured into hipGraphs on the GPU.
+
+This is the ONE step object behind `api.Session.run`, `bench.py` and the trajectory parity tests, so that what is timed is what is
+parity-tested.  It replaces the reference's `sess.run([..., train_op], feed_dict)` (train_semisup.py:405-411).
+
+Data parallelism: one process per GPU; the only collective is the sum of the gradients.  The backward plan carries
+`bucket ready` markers (engine.Plan.bucket_ready): the step is cut into hipGraph segments at those markers, and after each
+segment the bucket's all-reduce is issued asynchronously on RCCL's own stream, so that it runs beside the next segment of the
+backward (the seg-net's gradients do not depend on the box / T-Net gradients: semisup_models.py:150-151 blocks that gradient).
+The optimiser plan carries `bucket wait` markers in front of each bucket's Adam launch.  With one rank the markers are ignored and
+the whole step is ONE graph.
+"""
+import os
+
+import torch
+
+from . import abi
+from .engine import Plan
+
+
+class TrainStep:
+    def __init__(self, engine, pre, fwd, bwd=None, opt=None, process_group=None, use_hip_graph=None, force_dist=False,
+                 one_graph=None):
+        """engine: nets.Graph; pre/fwd/bwd/opt: engine.Plan (bwd/opt None for a forward-only step).
+        process_group: torch.distributed group (None: single replica).  force_dist: take the multi-rank code path (segments,
+        collectives) even with one rank -- how a 1-GPU box exercises it."""
+        self.e, self.rt = engine, engine.rt
+        self.pre, self.fwd, self.bwd, self.opt = pre, fwd, bwd, opt
+        self.train = bwd is not None
+        self.pg = process_group
+        self.world = process_group.size() if process_group is not None else 1
+        self.dist = self.train and process_group is not None and (self.world > 1 or force_dist)
+        self.on_gpu = self.rt.device.type == 'cuda'
+        want = use_hip_graph if use_hip_graph is not None else self.on_gpu
+        self.want_graph = bool(want) and self.on_gpu
+        if one_graph is None:
+            one_graph = os.environ.get('T3D_DP_ONE_GRAPH', '0') == '1'
+        self.one_graph = one_graph
+        self.cache = {}            # generate_masks -> list of program items with captured graphs
+        self.n_runs = 0
+        self._capture_stream = None
+
+    # ---- program --------------------------------------------------------------------------------------------------------------
+    def _buckets(self):
+        """[[(off, n), ...], ...] -- bucket i of the backward plan's markers; one bucket with every trained range if none."""
+        b = list(getattr(self.e, 'buckets', []))
+        return b if b else [self.e.default_bucket()]
+
+    def _program(self, generate_masks):
+        """[('run', Plan) | ('allreduce', i) | ('wait', i)] in issue order."""
+        plans = ([self.pre] if self.train else []) + [self.fwd] + ([self.bwd, self.opt] if self.train else [])
+        calls, lanes, two = [], [], False
+        for p in plans:
+            for (name, call, arg), lane in zip(p.calls, p.lanes):
+                if name == 't3d_dropout_mask' and not generate_masks:
+                    continue
+                calls.append((name, call, arg))
+                lanes.append(lane)
+            calls.append((Plan.JOIN, lambda s: 0, None))      # plans are serial with respect to each other
+            lanes.append(0)
+            two = two or p.two_streams
+        if self.dist and not any(c[0] == Plan.BUCKET for c in calls):
+            # a backward plan without markers: ONE bucket (every trained range), reduced between the backward and the optimiser
+            k = next((i for i, c in enumerate(calls) if c[0] == 't3d_adam_tf_step'), len(calls))
+            calls[k:k] = [(Plan.BUCKET, lambda s: 0, 0), (Plan.WAIT, lambda s: 0, 0)]
+            lanes[k:k] = [0, 0]
+        prog, cur = [], Plan(self.rt)
+        cur.two_streams = two
+
+        def close():
+            nonlocal cur
+            if len(cur):
+                prog.append(('run', cur))
+            cur = Plan(self.rt)
+            cur.two_streams = two
+
+        for (name, call, arg), lane in zip(calls, lanes):
+            if name in (Plan.BUCKET, Plan.WAIT):
+                if self.dist:
+                    close()
+                    prog.append(('allreduce' if name == Plan.BUCKET else 'wait', arg))
+                continue
+            cur.calls.append((name, call, arg))
+            cur.lanes.append(lane)
+        close()
+        return prog
+
+    # ---- execution ------------------------------------------------------------------------------------------------------------
+    def _allreduce(self, i, async_op):
+        import torch.distributed as dist
+        g = self.e.vars.grads
+        works = []
+        for off, n in self._buckets()[i]:
+            works.append(dist.all_reduce(g[off:off + n], group=self.pg, async_op=async_op))
+        return works
+
+    def _run_program(self, prog, graphs=None):
+        pending = {}
+        for k, (kind, x) in enumerate(prog):
+            if kind == 'run':
+                if graphs is not None and graphs.get(k) is not None:
+                    graphs[k].replay()
+                else:
+                    x.run()
+            elif kind == 'allreduce':
+                pending[x] = self._allreduce(x, async_op=self.on_gpu)
+            else:
+                for w in pending.pop(x, []):
+                    if w is not None:
+                        w.wait()           # GPU: the current stream waits for the collective; the host does not block
+        for ws in pending.values():
+            for w in ws:
+                if w is not None:
+                    w.wait()
+
+    def _capture(self, prog):
+        torch.cuda.synchronize()
+        if self._capture_stream is None:
+            self._capture_stream = torch.cuda.Stream()
+        s = self._capture_stream
+        graphs = {}
+        if self.dist and self.one_graph:
+            # the collectives captured in line (RCCL supports stream capture): one replay per step, no overlap
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s, capture_error_mode='thread_local'):
+                for kind, x in prog:
+                    if kind == 'run':
+                        x.run()
+                    elif kind == 'allreduce':
+                        self._allreduce(x, async_op=False)
+            return [('run_graph', g)], {0: g}
+        for k, (kind, x) in enumerate(prog):
+            if kind == 'run':
+                g = torch.cuda.CUDAGraph()
+                # thread_local: calls of other threads (the RCCL watchdog) during capture must not invalidate it
+                with torch.cuda.graph(g, stream=s, capture_error_mode='thread_local'):
+                    x.run()
+                graphs[k] = g
+        return prog, graphs
+
+    def run(self, generate_masks=True):
+        """One step.  The first run of a variant is eager (it also loads the code objects); the second captures (capturing
+        executes nothing) and replays; later runs replay."""
+        self.n_runs += 1
+        key = bool(generate_masks)
+        ent = self.cache.get(key)
+        if ent is None:
+            ent = self.cache[key] = {'prog': self._program(key), 'graphs': None, 'runs': 0}
+        ent['runs'] += 1
+        if not self.want_graph or ent['runs'] == 1:
+            return self._run_program(ent['prog'])
+        if ent['graphs'] is None:
+            prog, graphs = self._capture(ent['prog'])
+            ent['cprog'], ent['graphs'] = prog, graphs
+        if ent['cprog'] and ent['cprog'][0][0] == 'run_graph':
+            ent['graphs'][0].replay()
+            return
+        self._run_program(ent['cprog'], ent['graphs'])
+
+    def n_launches(self):
+        return sum(len(p) for p in ([self.pre] if self.train else []) + [self.fwd] + ([self.bwd, self.opt] if self.train else []))
+
+    def n_graph_segments(self, generate_masks=True):
+        ent = self.cache.get(bool(generate_masks))
+        if ent is None or ent['graphs'] is None:
+            return 0
+        return len(ent['graphs'])
+
+
+WORKLOADS = ('A', 'boxpc', 'F')
+
+
+def workload_flags(workload):
+    """The recipe flags of the three training stages (README.md:58-99 of the reference): a = SEMI_MODEL A, b = Box-PC Fit net,
+    c = SEMI_MODEL F."""
+    from .config import make_parser
+    if workload == 'A':
+        return make_parser().parse_special_args(['--SEMI_MODEL', 'A', '--WEAK_WEIGHT_REPROJECTION', '0', '--WEAK_WEIGHT_SURFACE', '0'])
+    if workload == 'boxpc':
+        return make_parser().parse_special_args(['--BOX_PC_MASK_REPRESENTATION', 'A', '--BOXPC_WEIGHT_DELTA', '4'])
+    return make_parser().parse_special_args(
+        ['--SEMI_MODEL', 'F', '--BOX_PC_MASK_REPRESENTATION', 'A', '--WEAK_WEIGHT_INTRACLASSVAR', '2', '--WEAK_WEIGHT_REPROJECTION', '0',
+         '--SEMI_MULTIPLIER_FOR_WEAK_LOSS', '0.05', '--SEMI_BOXPC_FIT_ONLY_ON_2D_CLS', '1', '--SEMI_WEIGHT_BOXPC_FIT_LOSS', '1'])
+
+
+STAGE_C_TRAIN_CLASSES = [i in (1, 2, 6, 7, 8) for i in range(10)]     # SUNRGBD_SEMI_TEST_CLS of recipe c
+
+
+def build_training_step(rt, workload, B, N, C, world=1, rank=0, process_group=None, force_dist=False, flat_allreduce=False,
+                        use_hip_graph=None, inline_dropout=True, dropout_seed=1234, seed=0, state_dict=None, c=None, dtype='f32'):
+    """The step bench.py times and the trajectory tests check: graph + model of `workload` ('A' = BASELINE configs[1],
+    'boxpc' = configs[2], 'F' = configs[3]), the device-side schedules (train_semisup.py:127-145), forward, backward, TF-form Adam
+    over the recipe's var_list, wrapped in a TrainStep.  Returns (engine graph, model, step, loss buffer)."""
+    from .nets import BoxPCModel, Graph, SemiModelA, SemiModelF, make_schedule
+    assert workload in WORKLOADS
+    g = Graph(B, N, C, rt=rt, seed=seed, dtype=dtype)           # identical initial weights on every rank
+    g.inline_dropout, g.dropout_seed = inline_dropout, dropout_seed + rank
+    c = c if c is not None else workload_flags(workload)
+    prefixes = None
+    if workload == 'A':
+        model = SemiModelA(g, c)
+        loss = model.loss_op.loss
+    elif workload == 'boxpc':
+        model = BoxPCModel(g, c, False)
+        loss = model.loss_op.loss
+    else:
+        model = SemiModelF(g, c, use_one_hot=True, train_classes=STAGE_C_TRAIN_CLASSES)
+        loss = model.loss
+        prefixes = list(SemiModelF.VAR_LIST)
+    if state_dict is not None:
+        g.vars.load_state_dict(state_dict)
+    dist_on = process_group is not None and (world > 1 or force_dist)
+    g.dp_buckets = dist_on and not flat_allreduce
+    g.emit_schedule(g.pre, make_schedule(B * world))
+    g.emit_dropout_masks(g.pre, seed=dropout_seed + rank)
+    model.emit_forward(g.fwd, True, True)
+    model.emit_backward(g.bwd)
+    g.emit_adam(g.opt, prefixes=prefixes, grad_scale=1.0 / world)
+    g.finalize()
+    step = TrainStep(g, g.pre, g.fwd, g.bwd, g.opt, process_group=process_group, use_hip_graph=use_hip_graph,
+                     force_dist=force_dist)
+    return g, model, step, loss
