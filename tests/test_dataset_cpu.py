@@ -334,3 +334,30 @@ def test_combined_data_set_marks_two_d_frustums():
     f = ds.perm.numpy()[2 * B:3 * B]
     assert np.array_equal(x.is_data_2D.numpy(), np.isin(host['cls'][f], [1, 2, 6, 7, 8]).astype(np.int32))
     assert 0 < x.is_data_2D.sum() < B
+
+
+def test_epoch_is_one_pass_and_replicas_walk_disjoint_slices():
+    """train_semisup.py:330-349: an epoch visits every frustum once (whole batches; the remainder is dropped as in the reference);
+    data-parallel replicas share the epoch permutation and take disjoint slices of it; the device-side walk position
+    (step * B + b) % walk_len stays aligned with the epoch boundaries."""
+    from fake_t3d import FakeLib
+    from transferable3d_amd.dataset import DeviceFrustumSet
+    from transferable3d_amd.engine import Runtime
+    F, B, world = 50, 4, 2
+    seen = []
+    for rank in range(world):
+        ds = DeviceFrustumSet.synthetic(Runtime(device='cpu', lib=FakeLib()), F, 4, seed=1, min_points=8, max_points=16)
+        steps = ds.partition(rank, world, B)
+        assert steps == (F // world) // B == 6 and ds.walk_len == 24
+        per_epoch = []
+        for epoch in range(2):
+            ds.shuffle(1000 + epoch)                  # the same seed on every replica
+            perm = ds.perm.numpy()
+            walk = [int(perm[((epoch * steps + s) * B + b) % ds.walk_len]) for s in range(steps) for b in range(B)]
+            assert len(set(walk)) == len(walk) == 24          # nothing repeated inside a pass
+            per_epoch.append(set(walk))
+        seen.append(per_epoch)
+        assert ds.partition(rank, world, B, steps=3) == 3 and ds.walk_len == 12
+    for epoch in range(2):
+        assert not (seen[0][epoch] & seen[1][epoch])           # replicas see disjoint frustums
+        assert len(seen[0][epoch] | seen[1][epoch]) == 48      # 50 frustums, 2 dropped with the incomplete batch

@@ -2,13 +2,16 @@
 # The three-stage recipe of the reference's README (stage a: SEMI_MODEL A, stage b: Box-PC Fit net, stage c: SEMI_MODEL F from both
 # checkpoints) on synthetic frustums resident in HBM, checkpoints handed over as TensorFlow Saver bundles.  Run on the GPU box:
 #   bash tools/three_stage_demo.sh [out_dir]
+set -eo pipefail      # a stage that crashes stops the recipe (the next stage would start from missing or stale checkpoints)
 out=${1:-gpurun_out/recipe}
 mkdir -p $out
-common="--num_point ${T3D_DEMO_POINTS:-1024} --batch_size 32 --num_channels ${T3D_DEMO_CHANNELS:-4} --device_data 4000 --eval_batches 10 --ckpt_format tf"
+# stages a and b train ONE epoch: checkpoints are written after every 5th epoch starting with epoch 0 (train_semisup.py:316-318), so
+# model_epoch_0.ckpt then holds everything that was trained
+common="--num_point ${T3D_DEMO_POINTS:-1024} --batch_size 32 --num_channels ${T3D_DEMO_CHANNELS:-4} --device_data 100000 --eval_batches 10 --ckpt_format tf"
 python -m transferable3d_amd.train_semisup --SEMI_MODEL A --WEAK_WEIGHT_REPROJECTION 0 --WEAK_WEIGHT_SURFACE 0 $common \
-    --max_epoch 2 --steps_per_epoch 1500 --log_dir $out/a 2>&1 | grep -v amdgpu > $out/a.log
+    --max_epoch 1 --steps_per_epoch 3000 --log_dir $out/a 2>&1 | grep -v amdgpu > $out/a.log
 python -m transferable3d_amd.train_boxpc --BOX_PC_MASK_REPRESENTATION A --BOXPC_WEIGHT_DELTA 4 $common \
-    --max_epoch 2 --steps_per_epoch 1500 --log_dir $out/b 2>&1 | grep -v amdgpu > $out/b.log
+    --max_epoch 1 --steps_per_epoch 3000 --log_dir $out/b 2>&1 | grep -v amdgpu > $out/b.log
 python -m transferable3d_amd.train_semisup_adv --SEMI_MODEL F --BOX_PC_MASK_REPRESENTATION A --use_one_hot --SEMI_TRAIN_BOX_TRAIN_CLASS_AG_TNET 1 \
     --SEMI_TRAIN_BOX_TRAIN_CLASS_AG_BOX 1 --SEMI_BOXPC_FIT_ONLY_ON_2D_CLS 1 --WEAK_WEIGHT_INTRACLASSVAR 2 --WEAK_WEIGHT_REPROJECTION 0 \
     --SEMI_MULTIPLIER_FOR_WEAK_LOSS 0.05 --SEMI_SAMPLE_EQUAL_CLASS_WITH_PROB 1 --SEMI_BOXPC_MIN_FIT_LOSS_AFT_REFINE 1 \

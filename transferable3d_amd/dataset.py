@@ -85,10 +85,31 @@ class DeviceFrustumSet:
         host = synthetic_frustums(n_frustums, num_channel, seed, min_points, max_points)
         return cls(rt, **host)
 
+    def partition(self, rank, world, batch_size, steps=None):
+        """One pass over the data set per epoch, shared between `world` data-parallel replicas: every replica draws the SAME epoch
+        permutation and walks its own slice perm[rank::world], cut to whole batches -- the reference's
+        num_batches = len(TRAIN_DATASET) / BATCH_SIZE drops the remainder too (train_semisup.py:330-349).  The walk length is a
+        multiple of the batch size, so the device-side position (step * B + b) % length wraps exactly at the epoch boundaries and
+        no frustum is repeated or skipped inside a pass.  Returns the number of steps of an epoch (<= `steps` when given)."""
+        per_rank = self.F // world
+        n = per_rank // batch_size
+        if steps:
+            n = min(n, int(steps))
+        if n <= 0:
+            raise ValueError('data set of %d frustums is smaller than one batch of %d on each of %d replicas' % (self.F, batch_size, world))
+        self.rank, self.world, self.walk_len = rank, world, n * batch_size
+        return n
+
     def shuffle(self, seed):
-        """New epoch order (the reference shuffles train_idxs once per epoch, train_semisup.py:343)."""
+        """New epoch order (the reference shuffles train_idxs once per epoch, train_semisup.py:343).  After partition(): the
+        replica's slice of the common permutation (the seed must not depend on the rank)."""
         r = np.random.RandomState(seed)
-        self.perm.copy_(torch.as_tensor(r.permutation(self.F).astype(np.int32)))
+        perm = r.permutation(self.F).astype(np.int32)
+        if getattr(self, 'walk_len', None):
+            mine = perm[self.rank::self.world][:self.walk_len]
+            self.perm[:self.walk_len].copy_(torch.as_tensor(mine))
+        else:
+            self.perm.copy_(torch.as_tensor(perm))
         for lst, dev in getattr(self, 'subsets', []):
             dev.copy_(torch.as_tensor(lst[r.permutation(len(lst))]))
 
@@ -155,7 +176,7 @@ class DeviceFrustumSet:
         a.frustum_angle, a.box_center, a.heading, a.size, a.cls = fptr(self.frustum_angle), fptr(self.box_center), fptr(self.heading), \
             fptr(self.size), iptr(self.cls)
         if sample is None:
-            a.sample, a.sample_len = iptr(self.perm), self.F
+            a.sample, a.sample_len = iptr(self.perm), (getattr(self, 'walk_len', None) or self.F)
         else:
             a.sample, a.sample_len = iptr(sample), 0
         a.choice, a.aug = iptr(choice), fptr(aug)

@@ -123,6 +123,8 @@ def train(FLAGS, rt=None, log=print):
             # (train_boxpc.py:323-328); 'BATCH': the epoch permutation
             eq = float(FLAGS.BOXPC_SAMPLE_EQUAL_CLASS_WITH_PROB) if FLAGS.BOXPC_SAMPLING_METHOD == 'SAMPLE' else 0.0
             g.use_device_dataset(ds, seed=FLAGS.seed * 7919, boxpc_perturb=FLAGS, equal_class_prob=eq)
+            if eq == 0.0:            # 'BATCH': an epoch is at most one pass over the data set (whole batches, train_boxpc.py:316-321)
+                FLAGS.steps_per_epoch = ds.partition(0, 1, B, FLAGS.steps_per_epoch)
         for epoch in range(FLAGS.max_epoch):
             t0, loss_sum = time.time(), 0.0
             if ds is not None:

@@ -54,7 +54,9 @@ def build_flags(argv=None):
     # additions
     cfg.add_argument('--synthetic', action='store_true', help='synthetic frustums (the only data source available)')
     cfg.add_argument('--num_channels', type=int, default=None, help='override point channels (reference: 6, or 3 with --no_rgb)')
-    cfg.add_argument('--steps_per_epoch', type=int, default=100)
+    cfg.add_argument('--steps_per_epoch', type=int, default=None,
+                     help='steps of an epoch [default: one pass over the data set, len / (batch_size * replicas) as in the reference; '
+                          '100 for --synthetic batches]')
     cfg.add_argument('--device_data', type=int, default=0, metavar='F',
                      help='keep a synthetic data set of F ragged frustums in HBM and assemble every batch on the device '
                           '(t3d_batch_assemble: resample / centre-view rotation / flip / shift / labels)')
@@ -196,6 +198,14 @@ def train(FLAGS, rt=None, log=print):
             from transferable3d_amd.constants import type2class
             ds.mark_2d_classes([type2class[t] for t in FLAGS.SUNRGBD_SEMI_TEST_CLS])
             g.use_device_dataset(ds, seed=FLAGS.seed * 7919 + rank)
+            # an epoch = ONE pass (train_semisup.py:330-349: num_batches = len(TRAIN_DATASET) / BATCH_SIZE); data parallel: every
+            # replica walks its own slice of the common epoch permutation, so the replicas see disjoint frustums
+            n = ds.partition(rank, world, B, FLAGS.steps_per_epoch)
+            if FLAGS.steps_per_epoch and n < FLAGS.steps_per_epoch and rank == 0:
+                log('--steps_per_epoch %d exceeds one pass over the data set: %d steps per epoch' % (FLAGS.steps_per_epoch, n))
+            FLAGS.steps_per_epoch = n
+        elif not FLAGS.steps_per_epoch:
+            FLAGS.steps_per_epoch = 100
         for epoch in range(FLAGS.max_epoch):
             t0 = time.time()
             loss_sum, correct = 0.0, 0.0
@@ -203,7 +213,7 @@ def train(FLAGS, rt=None, log=print):
             iou2ds, iou3ds = end_points['iou2ds'], end_points['iou3ds']
             if ds is not None:
                 # device pipeline: nothing is fed; the loss is fetched (a D2H sync) every 10th step only
-                ds.shuffle(FLAGS.seed * 1000003 + epoch * world + rank)      # train_semisup.py:343
+                ds.shuffle(FLAGS.seed * 1000003 + epoch)      # train_semisup.py:343 (the same permutation on every replica)
                 n_logged = 0
                 for it in range(FLAGS.steps_per_epoch):
                     if it % 10 == 9 or it == FLAGS.steps_per_epoch - 1:

@@ -62,15 +62,33 @@ def build_flags(argv=None):
     return FLAGS
 
 
-def load_variable_scopes_from_ckpt(vars_, path, scope):
-    """train_semisup_adv.py:224-237: restore every variable under `scope/` from a checkpoint whose names lack that prefix
-    (stage-a / stage-b checkpoints are saved without `class_agnostic/` / `D_boxpc_branch/`)."""
+def load_variable_scopes_from_ckpt(vars_, path, scope, adam_scopes=()):
+    """train_semisup_adv.py:224-237, 450-457: restore every variable under `scope/` from a checkpoint whose names lack that prefix
+    (stage-a / stage-b checkpoints are saved without `class_agnostic/` / `D_boxpc_branch/`).  As `Saver.restore` does, a variable
+    of the scope that the checkpoint does not hold is an error (a wrong or swapped --init_*_path must not train from random
+    initial weights).  The reference builds its restore list with `trainable_only=False` AFTER `minimize()`, so the Adam slots
+    `<var>/Adam`, `<var>/Adam_1` of the sub-scopes that stage c trains (`adam_scopes`) are part of it: they are copied into the
+    optimiser state whenever the checkpoint holds them (Saver bundles do; a plain .npz state dict of weights does not)."""
+    import torch
     sd = load_state(path)
-    n = 0
+    n, missing = 0, []
     for name in list(vars_.index):
-        if name.startswith(scope + '/') and name[len(scope) + 1:] in sd:
-            vars_.load_state_dict({name: sd[name[len(scope) + 1:]]})
-            n += 1
+        if not name.startswith(scope + '/'):
+            continue
+        src = name[len(scope) + 1:]
+        if src not in sd:
+            missing.append(src)
+            continue
+        vars_.load_state_dict({name: sd[src]})
+        n += 1
+        off, shape, trainable = vars_.index[name]
+        if trainable and src + '/Adam' in sd and any(name.startswith(a) for a in adam_scopes):
+            k = int(np.prod(shape))
+            vars_.adam_m[off:off + k].copy_(torch.as_tensor(np.asarray(sd[src + '/Adam'], np.float32)).reshape(-1))
+            vars_.adam_v[off:off + k].copy_(torch.as_tensor(np.asarray(sd[src + '/Adam_1'], np.float32)).reshape(-1))
+    if missing:
+        raise KeyError('checkpoint %s holds no tensor for %d variable(s) of scope %s/ (first: %s): NotFoundError in the '
+                       "reference's Saver.restore" % (path, len(missing), scope, missing[:3]))
     return n
 
 
@@ -148,7 +166,8 @@ def train(FLAGS, rt=None, log=print):
             semi_loss, var_list=train_vars)
         sess = api.Session()
         if FLAGS.init_class_ag_path:
-            log('restored %d class_agnostic variables' % load_variable_scopes_from_ckpt(g.vars, FLAGS.init_class_ag_path, 'class_agnostic'))
+            log('restored %d class_agnostic variables' % load_variable_scopes_from_ckpt(
+                g.vars, FLAGS.init_class_ag_path, 'class_agnostic', adam_scopes=[v for v in train_vars if v.startswith('class_agnostic')]))
         if FLAGS.init_boxpc_path:
             log('restored %d D_boxpc_branch variables' % load_variable_scopes_from_ckpt(g.vars, FLAGS.init_boxpc_path, 'D_boxpc_branch'))
         if FLAGS.restore_model_path:
