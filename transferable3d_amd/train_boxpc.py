@@ -43,7 +43,7 @@ def build_flags(argv=None):
     cfg.add_argument('--ckpt_format', default='npz', choices=['npz', 'tf'], help='tf: TensorFlow Saver bundle')
     cfg.add_argument('--synthetic', action='store_true')
     cfg.add_argument('--num_channels', type=int, default=None)
-    cfg.add_argument('--steps_per_epoch', type=int, default=100)
+    cfg.add_argument('--steps_per_epoch', type=int, default=None, help='[default: one pass over the data set; 100 for --synthetic batches]')
     cfg.add_argument('--seed', type=int, default=0)
     cfg.add_argument('--eval_file', default=None, help='held-out frustum file of the reference for eval_one_epoch (with --frustum_file / --device_data)')
     cfg.add_argument('--frustum_file', default=None, help='train from a frustum file of the reference (frustums/*.zip.pickle) held in HBM')
@@ -125,6 +125,8 @@ def train(FLAGS, rt=None, log=print):
             g.use_device_dataset(ds, seed=FLAGS.seed * 7919, boxpc_perturb=FLAGS, equal_class_prob=eq)
             if eq == 0.0:            # 'BATCH': an epoch is at most one pass over the data set (whole batches, train_boxpc.py:316-321)
                 FLAGS.steps_per_epoch = ds.partition(0, 1, B, FLAGS.steps_per_epoch)
+        if not FLAGS.steps_per_epoch:
+            FLAGS.steps_per_epoch = 100
         for epoch in range(FLAGS.max_epoch):
             t0, loss_sum = time.time(), 0.0
             if ds is not None:
