@@ -80,48 +80,52 @@ def gemm_work(name, a):
       dgrad alone      4(2MN + KN + MK out [+ MK prev_y] [+ MK add_in]);   wgrad alone 4(MK + 2MN + KN)
       Gram forms       the same with K in place of N (the [M,N] tensor does not exist)."""
     import ctypes
+    es = lambda dt: 2.0 if dt == 1 else 4.0       # bytes per element of a [M, C] layer tensor (t3d.h T3D_BF16 / T3D_F32)
     if name == 't3d_pool_bwd_stage1':
         gl, gf, gb = gemm_work('t3d_pointmlp_gram', a[0])
         q = a[2]
         # the activation panel is read once for G = a'a and the column sums; w, coef in; G, abar, P, rowconst, wc out
-        by = 4.0 * a[0].M * a[0].K + 4.0 * (2 * q.K * q.K + 2 * q.K * q.N + 2 * q.K)
+        by = es(a[0].a.dtype) * a[0].M * a[0].K + 4.0 * (2 * q.K * q.K + 2 * q.K * q.N + 2 * q.K)
         return 'k_pool_bwd_stage1<%s>' % gl[gl.index('<') + 1:gl.index(',')], gf + 2.0 * q.K * q.K * q.N, by
     if name == 't3d_pool_bwd_stage2':
         dl, df, db = gemm_work('t3d_pointmlp_dgrad_gram', a[1])
         f = a[0]
         # + w in, dW out, G in, the B*N arg-max rows of the input
-        by = db + 4.0 * (2 * f.K * f.N + f.K * f.K + f.B * f.N * f.K)
+        by = db + 4.0 * (2 * f.K * f.N + f.K * f.K) + es(f.a.dtype) * f.B * f.N * f.K
         return 'k_pool_bwd_stage2<%s>' % dl[dl.index('<') + 1:-1], df + 2.0 * f.K * f.K * f.N, by
     if name == 't3d_pointmlp_bwd':
         d, w = a
         dl, df, _ = gemm_work('t3d_pointmlp_dgrad', d)
         wl, wf, _ = gemm_work('t3d_pointmlp_wgrad', w)
         M, K, N = d.M, d.K, d.N
-        by = 4.0 * (2 * M * N + M * K * (2 + (0 if _null(d.add_in) else 1)) + 2 * K * N)
+        by = es(d.dtype) * (2 * M * N + M * K * (2 + (0 if _null(d.add_in) else 1))) + 4.0 * 2 * K * N
         return 'k_pointmlp_bwd<%s,%s>' % (dl[dl.index('<') + 1:-1], wl[wl.index('<') + 1:-1]), df + wf, by
     if name == 't3d_pointmlp_dgrad_gram':
-        by = 4.0 * a.M * a.K * (2 + (0 if _null(a.add_in) else 1) + (0 if _null(a.prev_y) else 1)) + 4.0 * a.K * a.K
+        # (the sparse arg-max rows S behind add_live are read only where a row received a hit -- a data-dependent few percent of
+        # the rows: not counted; a dense add_in is a full pass)
+        dense_add = (not _null(a.add_in)) and _null(a.add_live)
+        by = es(a.dtype) * a.M * a.K * (2 + (0 if _null(a.prev_y) else 1) + (1 if dense_add else 0)) + 4.0 * a.K * a.K
         return 'k_pointmlp_dgrad_gram<%d>' % (128 if a.K % 128 == 0 and (a.M // 128) * (a.K // 128) >= 512 else 64), 2.0 * a.M * a.K * a.K, by
     if name == 't3d_pointmlp_gram':
         rps, tk, tn = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
         LIB.t3d_wgrad_plan(a.M, a.K, a.K, ctypes.byref(rps), ctypes.byref(tk), ctypes.byref(tn))
         t = tk.value if (rps.value == a.rows_per_split and tk.value == tn.value) else 64
-        return 'k_pointmlp_gram<%d,%d>' % (t, t), 2.0 * a.M * a.K * a.K, 4.0 * a.M * a.K + 4.0 * a.K * a.K
+        return 'k_pointmlp_gram<%d,%d>' % (t, t), 2.0 * a.M * a.K * a.K, es(a.a.dtype) * a.M * a.K + 4.0 * a.K * a.K
     flops = 2.0 * a.M * a.K * a.N
     if name == 't3d_pointmlp_fwd':
-        by = 4.0 * (a.M * a.K + a.K * a.N + (0 if _null(a.y) else a.M * a.N))
-        if os.environ.get('T3D_FWD_POOL', '1') != '0' and _null(a.y) and not _null(a.pmax) and _null(a.a.sub) and a.K == 128 and \
+        by = es(a.a.dtype) * a.M * a.K + es(a.dtype) * (a.K * a.N + (0 if _null(a.y) else a.M * a.N))
+        if a.dtype == 0 and os.environ.get('T3D_FWD_POOL', '1') != '0' and _null(a.y) and not _null(a.pmax) and _null(a.a.sub) and a.K == 128 and \
                 a.N % 128 == 0 and a.N >= 256:
             return 'k_pointmlp_fwd_pool<128,32,8>', flops, by
         return 'k_pointmlp_fwd<%d>' % (128 if a.N % 128 == 0 and (a.M // 128) * (a.N // 128) >= 512 else 64), flops, by
     if name == 't3d_pointmlp_dgrad':
-        by = 4.0 * (2 * a.M * a.N + a.K * a.N + a.M * a.K * (1 + (0 if _null(a.prev_y) else 1) + (0 if _null(a.add_in) else 1)))
+        by = es(a.dtype) * (2 * a.M * a.N + a.K * a.N + a.M * a.K * (1 + (0 if _null(a.prev_y) else 1) + (0 if _null(a.add_in) else 1)))
         return 'k_pointmlp_dgrad<%d>' % (128 if a.K % 128 == 0 and (a.M // 128) * (a.K // 128) >= 512 else 64), flops, by
     rps, tk, tn = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
     LIB.t3d_wgrad_plan(a.M, a.K, a.N, ctypes.byref(rps), ctypes.byref(tk), ctypes.byref(tn))
     if rps.value != a.rows_per_split:
         tk.value, tn.value = (128 if a.K > 64 else 64), (128 if a.N % 128 == 0 else 64)
-    by = 4.0 * (a.M * a.K + 2 * a.M * a.N + a.K * a.N)
+    by = es(a.a.dtype) * a.M * a.K + es(a.dy.dtype) * 2 * a.M * a.N + 4.0 * a.K * a.N
     return 'k_pointmlp_wgrad<%d,%d>' % (tk.value, tn.value), flops, by
 
 

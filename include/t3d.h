@@ -38,6 +38,16 @@ typedef void* t3d_stream_t;
 
 enum { T3D_ACT_NONE = 0, T3D_ACT_RELU = 1, T3D_ACT_LEAKY_RELU = 2, T3D_ACT_TANH = 3 };
 
+/* Element type of the per-point [M, C] layer tensors (raw conv outputs y, gradients dz) and, with it, the arithmetic of the GEMM
+ * that produces or consumes them (BASELINE.json configs[1..3] vs configs[4]):
+ *   T3D_F32   fp32 storage, v_mfma_f32_32x32x2_f32 (exact fp32)
+ *   T3D_BF16  bf16 storage (2 bytes per element in HBM), operands rounded to bf16 while they are staged into LDS,
+ *             v_mfma_f32_32x32x16_bf16 with fp32 accumulation; statistics, partials, weights, weight gradients, the sparse
+ *             arg-max rows, the per-frustum [B, C] tensors, the optimiser and the raw inputs (point cloud, Box-PC
+ *             representation) stay fp32.
+ * Every `dtype` field below takes one of these; 0 (fp32) is what a zero-initialised struct means. */
+enum { T3D_F32 = 0, T3D_BF16 = 1 };
+
 int t3d_abi_version(void);
 
 /* ---- operand descriptors ------------------------------------------------------------------ */
@@ -55,6 +65,7 @@ typedef struct {
   int relu;
   const float* sub;      /* [B, sub_ld] */
   int sub_ld;
+  int dtype;             /* element type of x (T3D_F32 / T3D_BF16: `x` then points at bf16 elements; ldx, coff in elements) */
 } t3d_act_src;
 
 /* The gradient w.r.t. a layer's RAW conv output, produced lazily while loading:
@@ -68,6 +79,7 @@ typedef struct {
   const float* coef;      /* [3,N] */
   const int32_t* argidx;  /* [B,N] (pooled-sparse form) */
   const float* dpool;     /* [B,N] (pooled-sparse form) */
+  int dtype;              /* element type of dz and y; T3D_BF16 supports the dense form only (pooled layers: K11e) */
 } t3d_dy_src;
 
 /* ---- K1: per-point shared-MLP layer, forward ---------------------------------------------------
@@ -97,6 +109,7 @@ typedef struct {
   int32_t* pamin;
   int M, K, N;
   int rows_per_frustum;
+  int dtype;             /* element type of y and arithmetic of the GEMM (a.dtype may still be T3D_F32: the raw inputs) */
 } t3d_pointmlp_fwd_args;
 int t3d_pointmlp_fwd(const t3d_pointmlp_fwd_args* args, t3d_stream_t stream);
 
@@ -169,6 +182,7 @@ typedef struct {
   float* psum_dzy;         /* [M/128,K] or NULL */
   int M, K, N;
   int rows_per_frustum;
+  int dtype;               /* element type of prev_y, out and add_in, and the arithmetic; must equal dy.dtype */
 } t3d_pointmlp_dgrad_args;
 int t3d_pointmlp_dgrad(const t3d_pointmlp_dgrad_args* args, t3d_stream_t stream);
 
@@ -181,7 +195,7 @@ typedef struct {
   float* slabs;            /* [M/rows_per_split, K, N] */
   int M, K, N;
   int rows_per_frustum;
-  int rows_per_split;
+  int rows_per_split;      /* the arithmetic follows dy.dtype (bf16: rows_per_split % 64 == 0); slabs are fp32 either way */
 } t3d_pointmlp_wgrad_args;
 int t3d_pointmlp_wgrad(const t3d_pointmlp_wgrad_args* args, t3d_stream_t stream);
 /* K11a + K11b of one dense layer in ONE launch (the two are independent; sharing a launch saves a kernel's fill/drain
@@ -284,6 +298,8 @@ typedef struct {
   float* psum_dzy;
   int M, K;
   int rows_per_frustum;
+  int dtype;               /* element type of prev_y and out, and the arithmetic (a.dtype gives the operand's); add_in with
+                            * add_live (the sparse rows S) is fp32 either way, a dense add_in has this type */
 } t3d_pointmlp_dgrad_gram_args;
 int t3d_pointmlp_dgrad_gram(const t3d_pointmlp_dgrad_gram_args* args, t3d_stream_t stream);
 
@@ -293,7 +309,7 @@ typedef struct {
   float* slabs;            /* [M/rows_per_split, K, K] */
   int M, K;
   int rows_per_frustum;
-  int rows_per_split;
+  int rows_per_split;      /* the arithmetic follows a.dtype */
 } t3d_pointmlp_gram_args;
 int t3d_pointmlp_gram(const t3d_pointmlp_gram_args* args, t3d_stream_t stream);
 
@@ -424,6 +440,7 @@ typedef struct {
    * (drop_seed, step = drop_hyper[0], index m*K + k) with the generator of t3d_dropout_mask -- no [M,K] mask tensor in HBM. */
   uint32_t drop_seed;
   const float* drop_hyper;
+  int dtype;                 /* element type of y and dz (T3D_F32 / T3D_BF16) */
 } t3d_seg_head_args;
 int t3d_seg_head(const t3d_seg_head_args* args, t3d_stream_t stream);
 
@@ -764,6 +781,10 @@ int t3d_schedule_step(float* hyper, const t3d_schedule* s, t3d_stream_t stream);
 int t3d_adam_tf_step(float* params, const float* grads, float* m, float* v, int64_t n,
                      const float* hyper, float beta1, float beta2, float eps, float grad_scale,
                      t3d_stream_t stream);
+
+/* dst[i] = bf16(src[i]): the copy of the weights the T3D_BF16 GEMMs read (`w` of t3d_pointmlp_fwd / _dgrad / _bwd then points into
+ * it); run once per step after the optimiser.  The fp32 master copy stays what Adam updates and what checkpoints hold. */
+int t3d_cast_bf16(const float* src, void* dst, int64_t n, t3d_stream_t stream);
 
 /* tf.nn.dropout keep mask (tf_util.py:1738-1740): mask[i] = 1[u_i < keep], u from a counter-based
  * generator keyed by (seed, hyper step, i).  Tests inject masks instead. */

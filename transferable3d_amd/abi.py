@@ -11,23 +11,25 @@ I = C.POINTER(C.c_int32)
 i32, f32 = C.c_int, C.c_float
 
 TILE_ROWS = 128
+F32, BF16 = 0, 1              # t3d.h: T3D_F32 / T3D_BF16 (element type of the per-point layer tensors + GEMM arithmetic)
+DTYPE_BY_NAME = {'f32': F32, 'bf16': BF16}
 ACT_NONE, ACT_RELU, ACT_LEAKY_RELU, ACT_TANH = 0, 1, 2, 3
 ACT_BY_NAME = {None: ACT_NONE, 'relu': ACT_RELU, 'leaky_relu': ACT_LEAKY_RELU, 'tanh': ACT_TANH}
 
 
 class ActSrc(C.Structure):
     _fields_ = [('x', F), ('ldx', i32), ('coff', i32), ('scale', F), ('shift', F), ('relu', i32),
-                ('sub', F), ('sub_ld', i32)]
+                ('sub', F), ('sub_ld', i32), ('dtype', i32)]
 
 
 class DySrc(C.Structure):
-    _fields_ = [('dz', F), ('y', F), ('coef', F), ('argidx', I), ('dpool', F)]
+    _fields_ = [('dz', F), ('y', F), ('coef', F), ('argidx', I), ('dpool', F), ('dtype', i32)]
 
 
 class PointMlpFwdArgs(C.Structure):
     _fields_ = [('a', ActSrc), ('w', F), ('bias', F), ('rowbias', F), ('y', F), ('psum', F), ('psumsq', F),
                 ('rowmask', F), ('pmax', F), ('pmin', F), ('pamax', I), ('pamin', I),
-                ('M', i32), ('K', i32), ('N', i32), ('rows_per_frustum', i32)]
+                ('M', i32), ('K', i32), ('N', i32), ('rows_per_frustum', i32), ('dtype', i32)]
 
 
 class BnFwdFinalizeArgs(C.Structure):
@@ -47,7 +49,7 @@ class PoolFinalizeArgs(C.Structure):
 class PointMlpDgradArgs(C.Structure):
     _fields_ = [('dy', DySrc), ('w', F), ('add_in', F), ('prev_y', F), ('prev_scale', F), ('prev_shift', F),
                 ('out', F), ('psum_dz', F), ('psum_dzy', F), ('M', i32), ('K', i32), ('N', i32),
-                ('rows_per_frustum', i32)]
+                ('rows_per_frustum', i32), ('dtype', i32)]
 
 
 class PointMlpWgradArgs(C.Structure):
@@ -67,7 +69,7 @@ class PoolSparseRowsArgs(C.Structure):
 class PointMlpDgradGramArgs(C.Structure):
     _fields_ = [('a', ActSrc), ('p', F), ('rowconst', F), ('add_in', F), ('add_live', I), ('prev_y', F), ('prev_scale', F),
                 ('prev_shift', F),
-                ('out', F), ('psum_dz', F), ('psum_dzy', F), ('M', i32), ('K', i32), ('rows_per_frustum', i32)]
+                ('out', F), ('psum_dz', F), ('psum_dzy', F), ('M', i32), ('K', i32), ('rows_per_frustum', i32), ('dtype', i32)]
 
 
 class PointMlpGramArgs(C.Structure):
@@ -167,7 +169,8 @@ class SegHeadArgs(C.Structure):
     _fields_ = [('y', F), ('scale', F), ('shift', F), ('drop_mask', F), ('keep_prob', f32), ('w', F), ('bias', F),
                 ('labels', I), ('is_data_2D', I), ('pc', F), ('ld_pc', i32), ('ce_weight', f32), ('logits', F),
                 ('mask', F), ('part', F), ('dz', F), ('psum_dz', F), ('psum_dzy', F), ('dw_part', F),
-                ('M', i32), ('K', i32), ('rows_per_frustum', i32), ('B', i32), ('drop_seed', C.c_uint32), ('drop_hyper', F)]
+                ('M', i32), ('K', i32), ('rows_per_frustum', i32), ('B', i32), ('drop_seed', C.c_uint32), ('drop_hyper', F),
+                ('dtype', i32)]
 
 
 class SegFinalizeArgs(C.Structure):
@@ -272,6 +275,7 @@ ENTRY_POINTS = {
     't3d_schedule_step': [F, C.POINTER(Schedule), VP],
     't3d_adam_tf_step': [F, F, F, F, C.c_int64, F, f32, f32, f32, f32, VP],
     't3d_dropout_mask': [F, C.c_int64, f32, C.c_uint32, F, VP],
+    't3d_cast_bf16': [F, VP, C.c_int64, VP],
 }
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libt3d.so')

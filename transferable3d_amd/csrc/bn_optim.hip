@@ -415,6 +415,29 @@ extern "C" int t3d_adam_tf_step(float* params, const float* grads, float* m, flo
   return T3D_OK;
 }
 
+// bf16 copy of the weights for the T3D_BF16 GEMMs (8 elements per thread: one 32-byte read, one 16-byte write)
+__global__ __launch_bounds__(256) void k_cast_bf16(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * 256 * 8;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += stride) {
+    if (i + 8 <= n) {
+      const float4 a = *reinterpret_cast<const float4*>(src + i), b = *reinterpret_cast<const float4*>(src + i + 4);
+      const bf16x8 h = {(bf16_t)a.x, (bf16_t)a.y, (bf16_t)a.z, (bf16_t)a.w, (bf16_t)b.x, (bf16_t)b.y, (bf16_t)b.z, (bf16_t)b.w};
+      *reinterpret_cast<bf16x8*>(dst + i) = h;
+    } else {
+      for (int64_t j = i; j < n; ++j) dst[j] = (bf16_t)src[j];
+    }
+  }
+}
+
+extern "C" int t3d_cast_bf16(const float* src, void* dst, int64_t n, t3d_stream_t stream) {
+  if (!src || !dst || n <= 0 || (reinterpret_cast<uintptr_t>(src) & 15) || (reinterpret_cast<uintptr_t>(dst) & 15)) return T3D_ERR_ARG;
+  int64_t blocks = (n + 2047) / 2048;
+  if (blocks > 2048) blocks = 2048;
+  T3D_LAUNCH(k_cast_bf16, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), src, static_cast<bf16_t*>(dst), n);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
 extern "C" int t3d_dropout_mask(float* mask, int64_t n, float keep_prob, uint32_t seed, const float* hyper,
                                 t3d_stream_t stream) {
   if (!mask || !hyper || n <= 0) return T3D_ERR_ARG;

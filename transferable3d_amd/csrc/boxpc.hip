@@ -167,8 +167,8 @@ __global__ __launch_bounds__(256) void k_dgrad_narrow(const t3d_pointmlp_dgrad_n
     for (int i = tid; i < 64 * 32; i += 256) {
       const int rr = i >> 5, c4 = (i & 31) * 4;
       const size_t o = (size_t)(row0 + rr) * p.N + n0 + c4;
-      const float4 dz = *reinterpret_cast<const float4*>(p.dy.dz + o);
-      const float4 y = *reinterpret_cast<const float4*>(p.dy.y + o);
+      const float4 dz = ld_elem4(p.dy.dz, o, p.dy.dtype);
+      const float4 y = ld_elem4(p.dy.y, o, p.dy.dtype);
       const float4 c0 = *reinterpret_cast<const float4*>(p.dy.coef + n0 + c4);
       const float4 c1 = *reinterpret_cast<const float4*>(p.dy.coef + p.N + n0 + c4);
       const float4 c2 = *reinterpret_cast<const float4*>(p.dy.coef + 2 * p.N + n0 + c4);

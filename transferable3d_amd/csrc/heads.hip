@@ -41,6 +41,7 @@ __device__ __forceinline__ float drop_keep(uint64_t key, size_t i, float keep) {
   return (float)(r >> 8) * (1.0f / 16777216.0f) < keep ? 1.f : 0.f;
 }
 
+template <class T>      // T: element type of conv9's raw output y and of dz (t3d_seg_head_args.dtype)
 __global__ __launch_bounds__(64 * SH_WAVES) void k_seg_head(const t3d_seg_head_args p) {
   __shared__ float red[SH_WAVES][SH_LD];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(64 * SH_WAVES) void k_seg_head(const t3d_seg_head_a
 #pragma unroll
   for (int i = 0; i < SH_ROWS; ++i) {
     const size_t o = (size_t)(rbase + i) * 128 + ch;
-    y[i] = *reinterpret_cast<const float2*>(p.y + o);
+    y[i] = Elem<T>::ld2(p.y, o);
     if (gen) {                      // same generator and element index as k_dropout_mask (bn_optim.hip)
       km[i].x = drop_keep(dkey, o, p.keep_prob);
       km[i].y = drop_keep(dkey, o + 1, p.keep_prob);
@@ -123,9 +124,10 @@ __global__ __launch_bounds__(64 * SH_WAVES) void k_seg_head(const t3d_seg_head_a
       const float G1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g1), i));
       dw00 = fmaf(d0[i], G0, dw00); dw01 = fmaf(d0[i], G1, dw01);
       dw10 = fmaf(d1[i], G0, dw10); dw11 = fmaf(d1[i], G1, dw11);
-      const float dz0 = fmaf(y[i].x, sc.x, sh.x) > 0.f ? (G0 * w00 + G1 * w01) * km[i].x : 0.f;
-      const float dz1 = fmaf(y[i].y, sc.y, sh.y) > 0.f ? (G0 * w10 + G1 * w11) * km[i].y : 0.f;
-      *reinterpret_cast<float2*>(p.dz + (size_t)(rbase + i) * 128 + ch) = make_float2(dz0, dz1);
+      // (bf16: the partial sums below are those of the gradient as stored, i.e. as the backward kernels read it)
+      const float dz0 = Elem<T>::rnd(fmaf(y[i].x, sc.x, sh.x) > 0.f ? (G0 * w00 + G1 * w01) * km[i].x : 0.f);
+      const float dz1 = Elem<T>::rnd(fmaf(y[i].y, sc.y, sh.y) > 0.f ? (G0 * w10 + G1 * w11) * km[i].y : 0.f);
+      Elem<T>::st2(p.dz, (size_t)(rbase + i) * 128 + ch, dz0, dz1);
       sdz0 += dz0; sdz1 += dz1;
       sdzy0 = fmaf(dz0, y[i].x, sdzy0); sdzy1 = fmaf(dz1, y[i].y, sdzy1);
     }
@@ -411,7 +413,9 @@ extern "C" int t3d_seg_head(const t3d_seg_head_args* a, t3d_stream_t stream) {
   if (a->labels && !a->is_data_2D) return T3D_ERR_ARG;
   if (a->dz && (!a->labels || !a->psum_dz || !a->psum_dzy || !a->dw_part)) return T3D_ERR_ARG;
   if (a->K != 128 || a->M % T3D_TILE_ROWS || a->rows_per_frustum % T3D_TILE_ROWS) return T3D_ERR_SHAPE;
-  T3D_LAUNCH(k_seg_head, dim3(a->M / 128), dim3(64 * SH_WAVES), 0, static_cast<hipStream_t>(stream), *a);
+  if (a->dtype == T3D_BF16) T3D_LAUNCH(k_seg_head<bf16_t>, dim3(a->M / 128), dim3(64 * SH_WAVES), 0, static_cast<hipStream_t>(stream), *a);
+  else if (a->dtype == T3D_F32) T3D_LAUNCH(k_seg_head<float>, dim3(a->M / 128), dim3(64 * SH_WAVES), 0, static_cast<hipStream_t>(stream), *a);
+  else return T3D_ERR_ARG;
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

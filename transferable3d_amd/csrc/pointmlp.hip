@@ -72,12 +72,12 @@ __device__ unsigned long long* t3d_trace_ptr = nullptr;
 // All loads are UNCONDITIONAL on clamped addresses and masked afterwards with selects: a per-lane
 // `cond ? load : 0` compiles to an exec-masked branch with its own s_waitcnt, which serialises the global
 // latency of every k-tile (seen in the first version's ISA).  Only wave-uniform conditions branch.
-template <bool HAS_SUB>
+template <bool HAS_SUB, class XT = float>      // XT: element type of the source tensor (t3d_act_src.dtype)
 struct ActLoader {
   t3d_act_src s;
   int K;     // valid columns
   int rpf;   // rows per frustum
-  struct Raw { float4 x; };
+  struct Raw { typename Elem<XT>::V4 x; };
   struct Coef { float4 sc, sh; };
   __device__ __forceinline__ Coef fetch_coef(int col) const {
     Coef c;
@@ -93,12 +93,13 @@ struct ActLoader {
   __device__ __forceinline__ Raw fetch(int row, int col) const {
     Raw r;
     const int cc = min(col, ((K + 3) & ~3) - 4);
-    r.x = *reinterpret_cast<const float4*>(s.x + (size_t)row * s.ldx + s.coff + cc);
+    r.x = Elem<XT>::ld4(s.x, (size_t)row * s.ldx + s.coff + cc);
     return r;
   }
   // straight-line (no branches): identity scale/shift when there is no batch-norm, ReLU floor -inf when off
   __device__ __forceinline__ float4 xform(const Raw& r, const Coef& c, int row, int col) const {
-    float v[4] = {r.x.x, r.x.y, r.x.z, r.x.w};
+    const float4 rx = Elem<XT>::widen(r.x);
+    float v[4] = {rx.x, rx.y, rx.z, rx.w};
     const float sc[4] = {c.sc.x, c.sc.y, c.sc.z, c.sc.w};
     const float sh[4] = {c.sh.x, c.sh.y, c.sh.z, c.sh.w};
     const float floor_ = s.relu ? 0.f : -INFINITY;
@@ -115,12 +116,12 @@ struct ActLoader {
   }
 };
 
-template <bool POOLED>
+template <bool POOLED, class T = float>      // T: element type of dz and y (t3d_dy_src.dtype); the pooled-sparse form is fp32 only
 struct DyLoader {      // N % 32 == 0: every tile column is valid
   t3d_dy_src s;
   int N;
   int rpf;
-  struct Raw { float4 dz, y; };
+  struct Raw { typename Elem<T>::V4 dz, y; };
   struct Coef { float4 c0, c1, c2; };
   __device__ __forceinline__ Coef fetch_coef(int col) const {
     Coef c;
@@ -131,10 +132,11 @@ struct DyLoader {      // N % 32 == 0: every tile column is valid
   }
   __device__ __forceinline__ Raw fetch(int row, int col) const {
     Raw r;
-    r.y = *reinterpret_cast<const float4*>(s.y + (size_t)row * N + col);
-    if (!POOLED) {
-      r.dz = *reinterpret_cast<const float4*>(s.dz + (size_t)row * N + col);
+    r.y = Elem<T>::ld4(s.y, (size_t)row * N + col);
+    if constexpr (!POOLED) {
+      r.dz = Elem<T>::ld4(s.dz, (size_t)row * N + col);
     } else {
+      static_assert(!Elem<T>::BF16, "pooled-sparse dy is an fp32 form (bf16 layers take the Gram path)");
       const int b = row / rpf, rin = row - b * rpf;
       const int4 a = *reinterpret_cast<const int4*>(s.argidx + (size_t)b * N + col);
       const float4 g = *reinterpret_cast<const float4*>(s.dpool + (size_t)b * N + col);
@@ -144,28 +146,32 @@ struct DyLoader {      // N % 32 == 0: every tile column is valid
     return r;
   }
   __device__ __forceinline__ float4 xform(const Raw& r, const Coef& c, int, int) const {
-    return make_float4(fmaf(c.c0.x, r.dz.x, fmaf(c.c1.x, r.y.x, c.c2.x)), fmaf(c.c0.y, r.dz.y, fmaf(c.c1.y, r.y.y, c.c2.y)),
-                       fmaf(c.c0.z, r.dz.z, fmaf(c.c1.z, r.y.z, c.c2.z)), fmaf(c.c0.w, r.dz.w, fmaf(c.c1.w, r.y.w, c.c2.w)));
+    const float4 dz = Elem<T>::widen(r.dz), y = Elem<T>::widen(r.y);
+    return make_float4(fmaf(c.c0.x, dz.x, fmaf(c.c1.x, y.x, c.c2.x)), fmaf(c.c0.y, dz.y, fmaf(c.c1.y, y.y, c.c2.y)),
+                       fmaf(c.c0.z, dz.z, fmaf(c.c1.z, y.z, c.c2.z)), fmaf(c.c0.w, dz.w, fmaf(c.c1.w, y.w, c.c2.w)));
   }
 };
 
-struct WLoader {
+template <class WT = float>      // WT: element type of the matrix (bf16 path: the optimiser's bf16 copy of the weights)
+struct WLoaderT {
   const float* w;
   int ld;
   int rows, cols;   // valid extent; cols % 4 == 0
-  struct Raw { float4 x; };
+  struct Raw { typename Elem<WT>::V4 x; };
   struct Coef {};
   __device__ __forceinline__ Coef fetch_coef(int) const { return Coef(); }
   __device__ __forceinline__ Raw fetch(int row, int col) const {
     Raw r;
-    r.x = *reinterpret_cast<const float4*>(w + (size_t)min(row, rows - 1) * ld + min(col, cols - 4));
+    r.x = Elem<WT>::ld4(w, (size_t)min(row, rows - 1) * ld + min(col, cols - 4));
     return r;
   }
   __device__ __forceinline__ float4 xform(const Raw& r, const Coef&, int row, int col) const {
     const bool ok = row < rows && col < cols;      // masked AFTER the MFMA phase, never right behind the load
-    return make_float4(ok ? r.x.x : 0.f, ok ? r.x.y : 0.f, ok ? r.x.z : 0.f, ok ? r.x.w : 0.f);
+    const float4 x = Elem<WT>::widen(r.x);
+    return make_float4(ok ? x.x : 0.f, ok ? x.y : 0.f, ok ? x.z : 0.f, ok ? x.w : 0.f);
   }
 };
+typedef WLoaderT<float> WLoader;
 
 // ---------------------------------------------------------------------------------------------
 // staging of one [DIM x BK] operand tile through registers into LDS
@@ -419,15 +425,199 @@ __device__ __forceinline__ void gemm_mainloop(SA& sa, SB& sb, const LA& la, cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// bf16 path (T3D_BF16, BASELINE configs[4]): the same kernels on v_mfma_f32_32x32x16_bf16
+// ---------------------------------------------------------------------------------------------
+// Operands are rounded to bf16 in the staging pass (after the fused fp32 element-wise work) and accumulated in fp32.  An MFMA step
+// covers 16 reduction indices: lane l holds, for operand row / column l & 31, the 8 consecutive indices 8 * (l >> 5) .. + 7.  LDS
+// images keep the layout the tile has in HBM, so global loads stay coalesced and every LDS store is an 8-byte one:
+//   R image [lane_dim][BKH + 8]   reduction index contiguous (activations in fwd / dgrad, w in dgrad): fragment = one ds_read_b128;
+//                                 rows are 144 B apart = 9 x 16 B, odd, so the 16 lanes a ds_read_b128 serves together hit 16
+//                                 different 16-byte slots of the 256-byte bank row
+//   C image [BKH][lane_dim + 32]  lane index contiguous (w in fwd, P, both operands of the weight gradient): fragment = two
+//                                 ds_read_b64_tr_b16 -- the hardware transposing read hands lane i of a 16-lane group column i of a
+//                                 4-row block; the 4 rows of a half-wave's two blocks are DIM/2 + 16 dwords apart, i.e. they tile
+//                                 the 64 banks without overlap
+constexpr int BKH = 64;
+constexpr int LDRH = BKH + 8;
+typedef bf16_t __attribute__((address_space(3))) lds_bf16_t;
+typedef s16x4 __attribute__((address_space(3))) lds_s16x4;
+
+template <int DIM, bool TYPE_R, class L>
+struct StagerH {
+  static constexpr int PF = 1;
+  static constexpr int NV = DIM * (BKH / 4) / NT;
+  static constexpr int LDC = DIM + 32;
+  static constexpr int LDS_ELEMS = TYPE_R ? DIM * LDRH : BKH * LDC;
+  typename L::Raw raw[PF][NV];
+  typename L::Coef coef[PF];
+  int lane0, red0[PF];
+
+  __device__ __forceinline__ static void coords(int tid, int q, int& lane_i, int& red_i) {
+    const int f = tid + NT * q;
+    if (TYPE_R) { constexpr int CH = BKH / 4; lane_i = f / CH; red_i = (f % CH) * 4; }
+    else { constexpr int C4 = DIM / 4; red_i = f / C4; lane_i = (f % C4) * 4; }
+  }
+  __device__ __forceinline__ void init(const L& l, int lane0_, int tid) {
+    lane0 = lane0_;
+    if (!TYPE_R) { int li, ri; coords(tid, 0, li, ri); coef[0] = l.fetch_coef(lane0 + li); }
+  }
+  template <int S>
+  __device__ __forceinline__ void fetch(const L& l, int red0_, int tid) {
+    red0[S] = red0_;
+    if (TYPE_R) { int li, ri; coords(tid, 0, li, ri); coef[S] = l.fetch_coef(red0_ + ri); }
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      int li, ri; coords(tid, q, li, ri);
+      raw[S][q] = TYPE_R ? l.fetch(lane0 + li, red0_ + ri) : l.fetch(red0_ + ri, lane0 + li);
+    }
+  }
+  template <int S>
+  __device__ __forceinline__ void store_piece(const L& l, bf16_t* tile, int tid, int q) {
+    int li, ri; coords(tid, q, li, ri);
+    const typename L::Coef& c = coef[TYPE_R ? S : 0];
+    const float4 v = TYPE_R ? l.xform(raw[S][q], c, lane0 + li, red0[S] + ri) : l.xform(raw[S][q], c, red0[S] + ri, lane0 + li);
+    const bf16x4 h = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
+    *reinterpret_cast<bf16x4*>(tile + (TYPE_R ? li * LDRH + ri : ri * LDC + li)) = h;
+  }
+  template <int S>
+  __device__ __forceinline__ void store(const L& l, bf16_t* tile, int tid) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q) store_piece<S>(l, tile, tid, q);
+  }
+};
+
+// fragment of MFMA step `st` (16 reduction indices) for the 32 operand rows / columns starting at `c0`
+template <bool TYPE_R, int DIM>
+__device__ __forceinline__ bf16x8 frag_h(const bf16_t* img, int c0, int st, int lane) {
+  if (TYPE_R) {
+    return *reinterpret_cast<const bf16x8*>(img + (c0 + (lane & 31)) * LDRH + 16 * st + 8 * (lane >> 5));
+  } else {
+    constexpr int LDC = DIM + 32;
+    // 16-lane group g: block columns c0 + 16 * (g & 1) .. + 15, rows k0 .. k0 + 3 (then + 4 .. + 7); lane 4q + p of the group
+    // supplies the address of row q, columns 4p .. 4p + 3 and receives column (lane & 15) of the 4 rows
+    const int k0 = 16 * st + 8 * (lane >> 5);
+    const bf16_t* base = img + (k0 + ((lane & 15) >> 2)) * LDC + c0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + 4 * LDC));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, both);
+  }
+}
+
+// MFMA steps [S0, S1) of the current k-tile; filler(step) runs after each step's TM*TN MFMAs (staging pieces of the next tile)
+template <int TM, int TN, bool AR, int DIMA, bool BR, int DIMB, int S0, int S1, class F>
+__device__ __forceinline__ void mma_steps_h(const bf16_t* As, const bf16_t* Bs, int a0, int b0, f32x16 (&acc)[TM][TN], int lane,
+                                            F&& filler) {
+  bf16x8 fa[2][TM], fb[2][TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) fa[S0 & 1][tm] = frag_h<AR, DIMA>(As, a0 + tm * 32, S0, lane);
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) fb[S0 & 1][tn] = frag_h<BR, DIMB>(Bs, b0 + tn * 32, S0, lane);
+#pragma unroll
+  for (int st = S0; st < S1; ++st) {
+    if (st + 1 < S1) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) fa[(st + 1) & 1][tm] = frag_h<AR, DIMA>(As, a0 + tm * 32, st + 1, lane);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) fb[(st + 1) & 1][tn] = frag_h<BR, DIMB>(Bs, b0 + tn * 32, st + 1, lane);
+    }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st & 1][tm], fb[st & 1][tn], acc[tm][tn], 0, 0, 0);
+    filler(st - S0);
+  }
+}
+
+// Two LDS stages, ONE register slot, one barrier per k-tile of BKH reduction indices (the structure of gemm_mainloop with
+// prefetch distance 1).  Iteration t: MFMAs of tile t from stage t&1; tile t+1 (its global loads were issued one iteration
+// earlier) is transformed, rounded to bf16 and written into the other stage between the MFMAs of the second half; then the loads
+// of tile t+2 are issued.  A second register slot was tried first: 350+ VGPRs per lane in the 128-wide kernels (spills).  One
+// slot is enough here because a k-tile is 16-32 KB per workgroup: two workgroups per CU keep >= 32 KB per CU in flight even
+// when every iteration waits out a full HBM round trip, which is more than the bandwidth-delay product per CU (~25 KB).
+template <int TM, int TN, class SA, class SB, class LA, class LB, bool AR, int DIMA, bool BR, int DIMB>
+__device__ __forceinline__ void gemm_mainloop_h(SA& sa, SB& sb, const LA& la, const LB& lb, float* smem_f, int red_begin,
+                                                int red_end, int a0, int b0, f32x16 (&acc)[TM][TN], int tid) {
+  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_f);
+  constexpr int STAGE = SA::LDS_ELEMS + SB::LDS_ELEMS;
+  constexpr int ST = BKH / 16, SH_ = ST / 2;
+  constexpr int PIECES = SA::NV + SB::NV, PER = (PIECES + (ST - SH_) - 1) / (ST - SH_);
+  const int lane = tid & 63;
+  auto nofill = [](int) {};
+  sa.template fetch<0>(la, red_begin, tid);
+  sb.template fetch<0>(lb, red_begin, tid);
+  sa.template store<0>(la, smem, tid);
+  sb.template store<0>(lb, smem + SA::LDS_ELEMS, tid);
+  if (red_begin + BKH < red_end) { sa.template fetch<0>(la, red_begin + BKH, tid); sb.template fetch<0>(lb, red_begin + BKH, tid); }
+  __syncthreads();
+  int cur = 0;
+  for (int red = red_begin; red + BKH < red_end; red += BKH) {
+    const bf16_t* As = smem + cur * STAGE;
+    const bf16_t* Bs = As + SA::LDS_ELEMS;
+    bf16_t* An = smem + (cur ^ 1) * STAGE;
+    bf16_t* Bn = An + SA::LDS_ELEMS;
+    mma_steps_h<TM, TN, AR, DIMA, BR, DIMB, 0, SH_>(As, Bs, a0, b0, acc, lane, nofill);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_steps_h<TM, TN, AR, DIMA, BR, DIMB, SH_, ST>(As, Bs, a0, b0, acc, lane, [&](int step) {
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        const int pc = step * PER + j;
+        if (pc < SA::NV) sa.template store_piece<0>(la, An, tid, pc);
+        else if (pc < PIECES) sb.template store_piece<0>(lb, Bn, tid, pc - SA::NV);
+      }
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    const int nxt = min(red + 2 * BKH, red_end - BKH);      // clamp instead of branching: the tile past the end re-reads the last
+    sa.template fetch<0>(la, nxt, tid);
+    sb.template fetch<0>(lb, nxt, tid);
+    __syncthreads();
+    cur ^= 1;
+  }
+  {
+    const bf16_t* As = smem + cur * STAGE;
+    const bf16_t* Bs = As + SA::LDS_ELEMS;
+    mma_steps_h<TM, TN, AR, DIMA, BR, DIMB, 0, ST>(As, Bs, a0, b0, acc, lane, nofill);
+  }
+  __syncthreads();
+}
+
+// Arithmetic of a GEMM kernel: which staging / MFMA loop, and the element type T of the layer tensors it writes.
+struct PathF32 {
+  typedef float T;
+  typedef WLoaderT<float> WL;            // loader of the layer's weight matrix
+  static constexpr bool BF16 = false;
+  static constexpr int RED = BK;         // reduction depth of an LDS stage
+  template <int DIM, bool TYPE_R, class L, int PF> using Stg = Stager<DIM, TYPE_R, L, PF>;
+};
+struct PathBF16 {
+  typedef bf16_t T;
+  typedef WLoaderT<bf16_t> WL;           // `w` points at the bf16 copy of the weights (t3d_adam_tf_step's params_bf16)
+  static constexpr bool BF16 = true;
+  static constexpr int RED = BKH;
+  template <int DIM, bool TYPE_R, class L, int PF> using Stg = StagerH<DIM, TYPE_R, L>;
+};
+template <class PR, int TM, int TN, class SA, class SB, class LA, class LB, bool AR, int DIMA, bool BR, int DIMB>
+__device__ __forceinline__ void run_mainloop(SA& sa, SB& sb, const LA& la, const LB& lb, float* smem, int red_begin, int red_end,
+                                             int a0, int b0, f32x16 (&acc)[TM][TN], int tid) {
+  if constexpr (PR::BF16) gemm_mainloop_h<TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, red_begin, red_end, a0, b0, acc, tid);
+  else gemm_mainloop<TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, red_begin, red_end, a0, b0, acc, tid);
+}
+
+// ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
-template <int BN, bool HAS_SUB>
+// PR: arithmetic + element type of y (PathF32 / PathBF16); XT: element type of the input tensor (fp32 for the raw inputs)
+template <int BN, bool HAS_SUB, class PR = PathF32, class XT = float>
 __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd(const t3d_pointmlp_fwd_args p) {
   constexpr int BM = 128, TM = 2, TN = BN / 64;
-  using LA = ActLoader<HAS_SUB>;
+  using LA = ActLoader<HAS_SUB, XT>;
+  using YT = typename PR::T;
   constexpr int PF = BN == 64 ? T3D_PF_NARROW : T3D_PF_WIDE;
-  using SA = Stager<BM, true, LA, PF>;
-  using SB = Stager<BN, false, WLoader, PF>;
+  using WL = typename PR::WL;
+  using SA = typename PR::template Stg<BM, true, LA, PF>;
+  using SB = typename PR::template Stg<BN, false, WL, PF>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -439,16 +629,16 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd(const t3d_pointm
   T3D_TRACE_MARK(0);
 
   LA la{p.a, p.K, p.rows_per_frustum};
-  WLoader lb{p.w, p.N, p.K, p.N};
+  WL lb{p.w, p.N, p.K, p.N};
   SA sa; SB sb;
   sa.init(la, row0, tid);
   sb.init(lb, col0, tid);
 
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
-  const int kred = (p.K + BK - 1) / BK * BK;
-  gemm_mainloop<TM, TN, SA, SB, LA, WLoader, true, BM, false, BN>(sa, sb, la, lb, smem, 0, kred, wm * 64,
-                                                                        wn * (BN / 2), acc, tid);
+  const int kred = (p.K + PR::RED - 1) / PR::RED * PR::RED;
+  run_mainloop<PR, TM, TN, SA, SB, LA, WL, true, BM, false, BN>(sa, sb, la, lb, smem, 0, kred, wm * 64,
+                                                                     wn * (BN / 2), acc, tid);
   T3D_TRACE_MARK(1);
 
 #ifdef T3D_ABL_NOEPI
@@ -496,8 +686,9 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd(const t3d_pointm
     for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float v = acc[tm][tn][r] + add;
-        if (store_y) p.y[off0 + (unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)p.N] = v;
+        // bf16 storage: statistics (and the pool's candidates) of the value as it is stored, i.e. as every reader sees it
+        const float v = store_y ? Elem<YT>::rnd(acc[tm][tn][r] + add) : acc[tm][tn][r] + add;
+        if (store_y) Elem<YT>::st1(p.y, off0 + (unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)p.N, v);
         s += v;
         ss = fmaf(v, v, ss);
         if (pool) {                                  // selects: same results as the branches they replace, no exec-mask juggling
@@ -580,7 +771,7 @@ struct DgradEpilogue {
 // are issued ahead of the batch's stores: `out` may alias the inputs as far as the compiler knows, so a load placed
 // after a store is never hoisted above it and every element would pay a full memory round trip.
 // ADD: 0 = no add_in, 1 = dense add_in, 2 = add_in gated by the per-row flags (rows without a flag are never read).
-template <int BN, int TM, int TN, int ADD, bool MASK>
+template <int BN, int TM, int TN, int ADD, bool MASK, class T>     // T: element type of prev_y, out and a dense add_in
 __device__ __forceinline__ void dgrad_epilogue_body(const DgradEpilogue& p, f32x16 (&acc)[TM][TN], float* red, int tid,
                                                     int row0, int col0, int tile_m) {
   const int lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
@@ -618,22 +809,22 @@ __device__ __forceinline__ void dgrad_epilogue_body(const DgradEpilogue& p, f32x
 #ifdef T3D_ABL_DG_NOLOAD
           yp[e] = psc + (float)r;
 #else
-          yp[e] = MASK ? p.prev_y[o] : 0.f;
+          yp[e] = MASK ? Elem<T>::ld1(p.prev_y, o) : 0.f;
 #endif
-          if (ADD == 2) ad[e] = ((live >> (tm * 16 + r)) & 1u) ? p.add_in[o] : 0.f;
-          else ad[e] = ADD ? p.add_in[o] : 0.f;
+          if (ADD == 2) ad[e] = ((live >> (tm * 16 + r)) & 1u) ? p.add_in[o] : 0.f;      // the sparse rows S: fp32
+          else ad[e] = ADD ? Elem<T>::ld1(p.add_in, o) : 0.f;
         }
 #pragma unroll
         for (int e = 0; e < EB; ++e) {
           const int r = r0 + e;
           const unsigned o = off0 + (unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) * K;
-          float v = acc[tm][tn][r] + cc + ad[e];
+          float v = Elem<T>::rnd(acc[tm][tn][r] + cc + ad[e]);
           if (MASK) {
             if (!(fmaf(yp[e], psc, psh) > 0.f)) v = 0.f;
             s1 += v;
             s2 = fmaf(v, yp[e], s2);
           }
-          p.out[o] = v;
+          Elem<T>::st1(p.out, o, v);
         }
       }
     }
@@ -660,28 +851,29 @@ __device__ __forceinline__ void dgrad_epilogue_body(const DgradEpilogue& p, f32x
   }
 }
 
-template <int BN, int TM, int TN>
+template <int BN, int TM, int TN, class T = float>
 __device__ __forceinline__ void dgrad_epilogue(const DgradEpilogue& p, f32x16 (&acc)[TM][TN], float* red, int tid, int row0,
                                                int col0, int tile_m) {
   const bool add = p.add_in != nullptr, mask = p.prev_y != nullptr;      // workgroup-uniform
   if (mask) {
-    if (add && p.add_live) dgrad_epilogue_body<BN, TM, TN, 2, true>(p, acc, red, tid, row0, col0, tile_m);
-    else if (add) dgrad_epilogue_body<BN, TM, TN, 1, true>(p, acc, red, tid, row0, col0, tile_m);
-    else dgrad_epilogue_body<BN, TM, TN, 0, true>(p, acc, red, tid, row0, col0, tile_m);
+    if (add && p.add_live) dgrad_epilogue_body<BN, TM, TN, 2, true, T>(p, acc, red, tid, row0, col0, tile_m);
+    else if (add) dgrad_epilogue_body<BN, TM, TN, 1, true, T>(p, acc, red, tid, row0, col0, tile_m);
+    else dgrad_epilogue_body<BN, TM, TN, 0, true, T>(p, acc, red, tid, row0, col0, tile_m);
   } else {
-    if (add && p.add_live) dgrad_epilogue_body<BN, TM, TN, 2, false>(p, acc, red, tid, row0, col0, tile_m);
-    else if (add) dgrad_epilogue_body<BN, TM, TN, 1, false>(p, acc, red, tid, row0, col0, tile_m);
-    else dgrad_epilogue_body<BN, TM, TN, 0, false>(p, acc, red, tid, row0, col0, tile_m);
+    if (add && p.add_live) dgrad_epilogue_body<BN, TM, TN, 2, false, T>(p, acc, red, tid, row0, col0, tile_m);
+    else if (add) dgrad_epilogue_body<BN, TM, TN, 1, false, T>(p, acc, red, tid, row0, col0, tile_m);
+    else dgrad_epilogue_body<BN, TM, TN, 0, false, T>(p, acc, red, tid, row0, col0, tile_m);
   }
 }
 
-template <int BN, bool POOLED>   // BN = tile width over the layer's INPUT channels K
+template <int BN, bool POOLED, class PR = PathF32>   // BN = tile width over the layer's INPUT channels K
 __device__ __forceinline__ void dgrad_body(const t3d_pointmlp_dgrad_args& p, float* smem, int bid, int nblocks) {
   constexpr int BM = 128, TM = 2, TN = BN / 64;
   constexpr int PF = BN == 64 ? T3D_PF_NARROW : T3D_PF_WIDE;
-  using LA = DyLoader<POOLED>;
-  using SA = Stager<BM, true, LA, PF>;
-  using SB = Stager<BN, true, WLoader, PF>;
+  using LA = DyLoader<POOLED, typename PR::T>;
+  using WL = typename PR::WL;
+  using SA = typename PR::template Stg<BM, true, LA, PF>;
+  using SB = typename PR::template Stg<BN, true, WL, PF>;
 
   const int tid = threadIdx.x, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
@@ -691,36 +883,36 @@ __device__ __forceinline__ void dgrad_body(const t3d_pointmlp_dgrad_args& p, flo
   const int row0 = tile_m * BM, col0 = tile_n * BN;
 
   LA la{p.dy, p.N, p.rows_per_frustum};
-  WLoader lb{p.w, p.N, p.K, p.N};
+  WL lb{p.w, p.N, p.K, p.N};
   SA sa; SB sb;
   sa.init(la, row0, tid);
   sb.init(lb, col0, tid);
 
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
-  const int nred = (p.N + BK - 1) / BK * BK;
-  gemm_mainloop<TM, TN, SA, SB, LA, WLoader, true, BM, true, BN>(sa, sb, la, lb, smem, 0, nred, wm * 64,
-                                                                      wn * (BN / 2), acc, tid);
+  const int nred = (p.N + PR::RED - 1) / PR::RED * PR::RED;
+  run_mainloop<PR, TM, TN, SA, SB, LA, WL, true, BM, true, BN>(sa, sb, la, lb, smem, 0, nred, wm * 64,
+                                                                    wn * (BN / 2), acc, tid);
 
   DgradEpilogue e{p.add_in, nullptr, nullptr, p.prev_y, p.prev_scale, p.prev_shift, p.out, p.psum_dz, p.psum_dzy, p.K};
-  dgrad_epilogue<BN, TM, TN>(e, acc, smem, tid, row0, col0, tile_m);
+  dgrad_epilogue<BN, TM, TN, typename PR::T>(e, acc, smem, tid, row0, col0, tile_m);
 }
 
-template <int BN, bool POOLED>
+template <int BN, bool POOLED, class PR = PathF32>
 __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_dgrad(const t3d_pointmlp_dgrad_args p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  dgrad_body<BN, POOLED>(p, smem, blockIdx.x, gridDim.x);
+  dgrad_body<BN, POOLED, PR>(p, smem, blockIdx.x, gridDim.x);
 }
 
 // Gram-form data gradient of a max-pooled layer: out = act(a) . P + rowconst + S  (see t3d.h K11e); the operand
 // side is the forward kernel's (activations type R, the K x K matrix type C), the epilogue is the dgrad one.
-template <int BN>
+template <int BN, class PR = PathF32>
 __device__ __forceinline__ void dgrad_gram_body(const t3d_pointmlp_dgrad_gram_args& p, float* smem, int bid, int nblocks) {
   constexpr int BM = 128, TM = 2, TN = BN / 64;
-  using LA = ActLoader<false>;
+  using LA = ActLoader<false, typename PR::T>;
   constexpr int PF = BN == 64 ? T3D_PF_NARROW : T3D_PF_GRAM128;
-  using SA = Stager<BM, true, LA, PF>;
-  using SB = Stager<BN, false, WLoader, PF>;
+  using SA = typename PR::template Stg<BM, true, LA, PF>;
+  using SB = typename PR::template Stg<BN, false, WLoader, PF>;
   const int tid = threadIdx.x, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int tiles_n = p.K / BN;
@@ -734,29 +926,29 @@ __device__ __forceinline__ void dgrad_gram_body(const t3d_pointmlp_dgrad_gram_ar
   sb.init(lb, col0, tid);
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
-  gemm_mainloop<TM, TN, SA, SB, LA, WLoader, true, BM, false, BN>(sa, sb, la, lb, smem, 0, p.K, wm * 64, wn * (BN / 2), acc,
-                                                                        tid);
+  run_mainloop<PR, TM, TN, SA, SB, LA, WLoader, true, BM, false, BN>(sa, sb, la, lb, smem, 0, p.K, wm * 64, wn * (BN / 2), acc,
+                                                                     tid);
   DgradEpilogue e{p.add_in, p.add_live, p.rowconst, p.prev_y, p.prev_scale, p.prev_shift, p.out, p.psum_dz, p.psum_dzy, p.K};
-  dgrad_epilogue<BN, TM, TN>(e, acc, smem, tid, row0, col0, tile_m);
+  dgrad_epilogue<BN, TM, TN, typename PR::T>(e, acc, smem, tid, row0, col0, tile_m);
 }
 
-template <int BN>
+template <int BN, class PR = PathF32>
 __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_dgrad_gram(const t3d_pointmlp_dgrad_gram_args p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  dgrad_gram_body<BN>(p, smem, blockIdx.x, gridDim.x);
+  dgrad_gram_body<BN, PR>(p, smem, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------
 // weight gradient (split over rows)
 // ---------------------------------------------------------------------------------------------
 // slab[split][k0.., n0..] = sum over the split's rows of A[m,k] B[m,n]; both operands type C (row index = reduction).
-template <int BMK, int BN, class LA, class LB>
+template <int BMK, int BN, class PR = PathF32, class LA, class LB>
 __device__ __forceinline__ void wgrad_body(const LA& la, const LB& lb, float* slabs, int K, int N, int rows_per_split,
                                            float* smem, int bid, int nblocks) {
   constexpr int TM = BMK / 64, TN = BN / 64;
   constexpr int PF = (BMK == 64 && BN == 64) ? T3D_PF_NARROW : T3D_PF_WIDE;
-  using SA = Stager<BMK, false, LA, PF>;
-  using SB = Stager<BN, false, LB, PF>;
+  using SA = typename PR::template Stg<BMK, false, LA, PF>;
+  using SB = typename PR::template Stg<BN, false, LB, PF>;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int tiles_k = (K + BMK - 1) / BMK, tiles_n = N / BN;
@@ -770,8 +962,8 @@ __device__ __forceinline__ void wgrad_body(const LA& la, const LB& lb, float* sl
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
   const int m_begin = split * rows_per_split;
-  gemm_mainloop<TM, TN, SA, SB, LA, LB, false, BMK, false, BN>(sa, sb, la, lb, smem, m_begin, m_begin + rows_per_split,
-                                                                           wm * (BMK / 2), wn * (BN / 2), acc, tid);
+  run_mainloop<PR, TM, TN, SA, SB, LA, LB, false, BMK, false, BN>(sa, sb, la, lb, smem, m_begin, m_begin + rows_per_split,
+                                                                  wm * (BMK / 2), wn * (BN / 2), acc, tid);
   const int l31 = lane & 31, h = lane >> 5;
   float* slab = slabs + (size_t)split * K * N;
 #pragma unroll
@@ -788,31 +980,32 @@ __device__ __forceinline__ void wgrad_body(const LA& la, const LB& lb, float* sl
   }
 }
 
-template <int BMK, int BN, bool HAS_SUB, bool POOLED>
+// XT: element type of the layer input `a` (fp32 for the raw inputs: the first layer of each net)
+template <int BMK, int BN, bool HAS_SUB, bool POOLED, class PR = PathF32, class XT = float>
 __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_wgrad(const t3d_pointmlp_wgrad_args p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  ActLoader<HAS_SUB> la{p.a, p.K, p.rows_per_frustum};
-  DyLoader<POOLED> lb{p.dy, p.N, p.rows_per_frustum};
-  wgrad_body<BMK, BN>(la, lb, p.slabs, p.K, p.N, p.rows_per_split, smem, blockIdx.x, gridDim.x);
+  ActLoader<HAS_SUB, XT> la{p.a, p.K, p.rows_per_frustum};
+  DyLoader<POOLED, typename PR::T> lb{p.dy, p.N, p.rows_per_frustum};
+  wgrad_body<BMK, BN, PR>(la, lb, p.slabs, p.K, p.N, p.rows_per_split, smem, blockIdx.x, gridDim.x);
 }
 
 // Gram matrix of a layer input, G = a^T a, as split-row slabs (t3d.h K11e).
-template <int BMK, int BN>
+template <int BMK, int BN, class PR = PathF32>
 __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_gram(const t3d_pointmlp_gram_args p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  ActLoader<false> la{p.a, p.K, p.rows_per_frustum};
-  wgrad_body<BMK, BN>(la, la, p.slabs, p.K, p.K, p.rows_per_split, smem, blockIdx.x, gridDim.x);
+  ActLoader<false, typename PR::T> la{p.a, p.K, p.rows_per_frustum};
+  wgrad_body<BMK, BN, PR>(la, la, p.slabs, p.K, p.K, p.rows_per_split, smem, blockIdx.x, gridDim.x);
 }
 
 // One launch for both gradients of a dense layer: the first `n_wgrad` workgroups run weight-gradient tiles, the rest
 // data-gradient tiles.  The two are independent (both read dy = c0*dz + c1*y + c2), so sharing a launch removes one
 // kernel's fill/drain latency per layer and lets the tiles of one kind fill the holes the other leaves on a CU.
-template <int DBN, int WBMK, int WBN>
+template <int DBN, int WBMK, int WBN, class PR = PathF32>
 __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_bwd(const t3d_pointmlp_dgrad_args d, const t3d_pointmlp_wgrad_args w,
                                                                 const int n_wgrad, const int interleave) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  ActLoader<false> la{w.a, w.K, w.rows_per_frustum};
-  DyLoader<false> lb{w.dy, w.N, w.rows_per_frustum};
+  ActLoader<false, typename PR::T> la{w.a, w.K, w.rows_per_frustum};
+  DyLoader<false, typename PR::T> lb{w.dy, w.N, w.rows_per_frustum};
   if (interleave) {
     // logical order: per row split, its weight-gradient tiles followed by the data-gradient tiles of the same rows; the
     // XCD remap hands each XCD a contiguous piece of that order, so both readers of a dy row range share one L2
@@ -820,26 +1013,26 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_bwd(const t3d_pointm
     const int dt = (w.rows_per_split / 128) * tiles_nd, grp_sz = wt + dt;
     const int l = xcd_remap(blockIdx.x, gridDim.x);
     const int grp = l / grp_sz, r = l % grp_sz;
-    if (r < wt) wgrad_body<WBMK, WBN>(la, lb, w.slabs, w.K, w.N, w.rows_per_split, smem, grp * wt + r, 0);
-    else dgrad_body<DBN, false>(d, smem, grp * dt + (r - wt), 0);
+    if (r < wt) wgrad_body<WBMK, WBN, PR>(la, lb, w.slabs, w.K, w.N, w.rows_per_split, smem, grp * wt + r, 0);
+    else dgrad_body<DBN, false, PR>(d, smem, grp * dt + (r - wt), 0);
   } else if ((int)blockIdx.x < n_wgrad) {
-    wgrad_body<WBMK, WBN>(la, lb, w.slabs, w.K, w.N, w.rows_per_split, smem, blockIdx.x, n_wgrad);
+    wgrad_body<WBMK, WBN, PR>(la, lb, w.slabs, w.K, w.N, w.rows_per_split, smem, blockIdx.x, n_wgrad);
   } else {
-    dgrad_body<DBN, false>(d, smem, blockIdx.x - n_wgrad, gridDim.x - n_wgrad);
+    dgrad_body<DBN, false, PR>(d, smem, blockIdx.x - n_wgrad, gridDim.x - n_wgrad);
   }
 }
 
 // Gram-form backward of a pooled layer, stage 1: the three jobs that need nothing but the layer input and the
 // batch-norm-backward coefficients -- Gram slabs a^T a, column sums of a, and the P / rowconst slabs (+ wc) -- in one launch.
-template <int GT>
+template <int GT, class PR = PathF32>
 __global__ __launch_bounds__(NT, T3D_WAVES) void k_pool_bwd_stage1(const t3d_pointmlp_gram_args g, const t3d_act_colsum_args c,
                                                                    const t3d_pool_bwd_prep_args q, const int n_gram,
                                                                    const int n_colsum) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x;
   if (b < n_gram) {
-    ActLoader<false> la{g.a, g.K, g.rows_per_frustum};
-    wgrad_body<GT, GT>(la, la, g.slabs, g.K, g.K, g.rows_per_split, smem, b, n_gram);
+    ActLoader<false, typename PR::T> la{g.a, g.K, g.rows_per_frustum};
+    wgrad_body<GT, GT, PR>(la, la, g.slabs, g.K, g.K, g.rows_per_split, smem, b, n_gram);
   } else if (b < n_gram + n_colsum) {
     act_colsum_body(c, smem, b - n_gram);
   } else {
@@ -850,7 +1043,7 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pool_bwd_stage1(const t3d_poi
 
 // Stage 2: the weight-gradient assembly and the input-gradient GEMM (both after the slab reduction, independent of each
 // other) in one launch.
-template <int BN>
+template <int BN, class PR = PathF32>
 __global__ __launch_bounds__(NT, T3D_WAVES) void k_pool_bwd_stage2(const t3d_pool_wgrad_finish_args f,
                                                                    const t3d_pointmlp_dgrad_gram_args d, const int n_finish) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -859,7 +1052,7 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pool_bwd_stage2(const t3d_poo
     const int kb = f.K / FK;
     pool_wgrad_finish_body(f, smem, b % kb, b / kb);
   } else {
-    dgrad_gram_body<BN>(d, smem, b - n_finish, gridDim.x - n_finish);
+    dgrad_gram_body<BN, PR>(d, smem, b - n_finish, gridDim.x - n_finish);
   }
 }
 
@@ -1160,13 +1353,21 @@ void launch_lds(void (*kernel)(const Args), dim3 grid, size_t lds_bytes, hipStre
 constexpr size_t lds_fwd(int bn) { return 2 * (size_t)(128 * LDR + BK * bn) * sizeof(float); }
 constexpr size_t lds_dgrad(int bn) { return 2 * (size_t)(128 * LDR + bn * LDR) * sizeof(float); }
 constexpr size_t lds_wgrad(int bmk, int bn) { return 2 * (size_t)BK * (bmk + bn) * sizeof(float); }
+// bf16 path: two stages of R images [dim][BKH + 8] / C images [BKH][dim + 32] of 2-byte elements; never less than the epilogues'
+// cross-wave scratch (6 x 2 x BN floats)
+constexpr size_t lds_min(size_t b, int bn) { return b > (size_t)12 * bn * sizeof(float) ? b : (size_t)12 * bn * sizeof(float); }
+constexpr size_t lds_fwd_h(int bn) { return lds_min(2 * (size_t)(128 * LDRH + BKH * (bn + 32)) * 2, bn); }
+constexpr size_t lds_dgrad_h(int bn) { return lds_min(2 * (size_t)(128 * LDRH + bn * LDRH) * 2, bn); }
+constexpr size_t lds_wgrad_h(int bmk, int bn) { return 2 * (size_t)BKH * (bmk + 32 + bn + 32) * 2; }
 
+bool dtype_ok(int dt) { return dt == T3D_F32 || dt == T3D_BF16; }
 bool act_ok(const t3d_act_src& a, int K) {
   return a.x != nullptr && (a.ldx % 4) == 0 && (a.coff % 4) == 0 && a.coff + (K + 3) / 4 * 4 <= a.ldx &&
-         (a.scale == nullptr || a.shift != nullptr);
+         (a.scale == nullptr || a.shift != nullptr) && dtype_ok(a.dtype) && !(a.dtype == T3D_BF16 && a.sub != nullptr);
 }
 bool dy_ok(const t3d_dy_src& d) {
-  return d.y != nullptr && d.coef != nullptr && (d.dz != nullptr || (d.argidx != nullptr && d.dpool != nullptr));
+  return d.y != nullptr && d.coef != nullptr && (d.dz != nullptr || (d.argidx != nullptr && d.dpool != nullptr)) && dtype_ok(d.dtype) &&
+         !(d.dtype == T3D_BF16 && d.dz == nullptr);      // bf16: dense form only (pooled layers take the Gram path)
 }
 
 }  // namespace
@@ -1181,6 +1382,26 @@ extern "C" int t3d_pointmlp_fwd(const t3d_pointmlp_fwd_args* a, t3d_stream_t str
   const int tiles_m = a->M / 128;
   // 128-wide column tiles only when they still give >= 2 workgroups per CU
   const bool sub = a->a.sub != nullptr;
+  if (!dtype_ok(a->dtype)) return T3D_ERR_ARG;
+  if (a->dtype == T3D_BF16) {
+    // bf16 storage + bf16 MFMA (configs[4]); the input is fp32 for the raw point cloud / Box-PC representation, bf16 for a layer output
+    const bool wide = T3D_FORCE_TILE != 64 && a->N % 128 == 0 && (T3D_FORCE_TILE == 128 || (long)tiles_m * (a->N / 128) >= 512);
+    const bool xh = a->a.dtype == T3D_BF16;
+    const dim3 grid(tiles_m * (a->N / (wide ? 128 : 64)));
+    const size_t lds = wide ? lds_fwd_h(128) : lds_fwd_h(64);
+#define T3D_FWD_H(BN_)                                                                                          \
+  do {                                                                                                          \
+    if (sub) launch_lds(k_pointmlp_fwd<BN_, true, PathBF16, float>, grid, lds, s, *a);                          \
+    else if (xh) launch_lds(k_pointmlp_fwd<BN_, false, PathBF16, bf16_t>, grid, lds, s, *a);                    \
+    else launch_lds(k_pointmlp_fwd<BN_, false, PathBF16, float>, grid, lds, s, *a);                             \
+  } while (0)
+    if (wide) T3D_FWD_H(128);
+    else T3D_FWD_H(64);
+#undef T3D_FWD_H
+    T3D_CHECK_LAUNCH();
+    return T3D_OK;
+  }
+  if (a->a.dtype != T3D_F32) return T3D_ERR_ARG;
   // max-pooled layer without an output tensor: the A-resident persistent kernel (T3D_FWD_POOL=0: the generic one)
   static const bool use_pool_kernel = []() { const char* e = getenv("T3D_FWD_POOL"); return !(e && e[0] == '0'); }();
   // K = 256 needs 16-deep weight tiles to fit the 133 KB panel next to them and measured slower than the generic kernel
@@ -1221,8 +1442,9 @@ static int check_dgrad(const t3d_pointmlp_dgrad_args* a) {
   if (!a || !a->w || !a->out || !dy_ok(a->dy)) return T3D_ERR_ARG;
   if (a->prev_y && (!a->prev_scale || !a->prev_shift)) return T3D_ERR_ARG;
   if (a->psum_dz && (!a->psum_dzy || !a->prev_y)) return T3D_ERR_ARG;
+  if (!dtype_ok(a->dtype) || a->dtype != a->dy.dtype) return T3D_ERR_ARG;
   if (a->M <= 0 || a->M % T3D_TILE_ROWS || a->rows_per_frustum % T3D_TILE_ROWS || a->M % a->rows_per_frustum ||
-      a->K % 64 || a->N % 4 || (long)a->M * a->K >= (1L << 30))
+      a->K % 64 || a->N % 4 || (long)a->M * a->K >= (1L << 30) || (a->dtype == T3D_BF16 && a->N % 64))
     return T3D_ERR_SHAPE;
   return T3D_OK;
 }
@@ -1236,6 +1458,12 @@ extern "C" int t3d_pointmlp_dgrad(const t3d_pointmlp_dgrad_args* a, t3d_stream_t
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int tiles_m = a->M / 128;
   const bool pooled = a->dy.dz == nullptr;
+  if (a->dtype == T3D_BF16) {
+    if (dgrad_wide(a)) launch_lds(k_pointmlp_dgrad<128, false, PathBF16>, dim3(tiles_m * (a->K / 128)), lds_dgrad_h(128), s, *a);
+    else launch_lds(k_pointmlp_dgrad<64, false, PathBF16>, dim3(tiles_m * (a->K / 64)), lds_dgrad_h(64), s, *a);
+    T3D_CHECK_LAUNCH();
+    return T3D_OK;
+  }
   if (dgrad_wide(a)) {
     const dim3 grid(tiles_m * (a->K / 128));
     if (pooled) launch_lds(k_pointmlp_dgrad<128, true>, grid, lds_dgrad(128), s, *a);
@@ -1274,7 +1502,7 @@ extern "C" int t3d_wgrad_plan(int M, int K, int N, int* rows_per_split, int* til
   long want = (target + tiles - 1) / tiles;
   if (want > cap) want = cap;
   int s = 1;
-  while ((long)s * 2 <= want && M % (s * 2) == 0 && (M / (s * 2)) % BK == 0) s *= 2;
+  while ((long)s * 2 <= want && M % (s * 2) == 0 && (M / (s * 2)) % BKH == 0) s *= 2;      // whole k-tiles of either path
   *rows_per_split = M / s;
   *tile_k = tk;
   *tile_n = tn;
@@ -1283,9 +1511,11 @@ extern "C" int t3d_wgrad_plan(int M, int K, int N, int* rows_per_split, int* til
 
 static int check_wgrad(const t3d_pointmlp_wgrad_args* a) {
   if (!a || !a->slabs || !act_ok(a->a, a->K) || !dy_ok(a->dy)) return T3D_ERR_ARG;
-  if (a->M <= 0 || a->rows_per_split <= 0 || a->rows_per_split % BK || a->M % a->rows_per_split || a->N % 64 ||
-      a->rows_per_frustum % BK || a->M % a->rows_per_frustum)
+  const int red = a->dy.dtype == T3D_BF16 ? BKH : BK;
+  if (a->M <= 0 || a->rows_per_split <= 0 || a->rows_per_split % red || a->M % a->rows_per_split || a->N % 64 ||
+      a->rows_per_frustum % red || a->M % a->rows_per_frustum)
     return T3D_ERR_SHAPE;
+  if (a->dy.dtype == T3D_F32 && a->a.dtype != T3D_F32) return T3D_ERR_ARG;
   return T3D_OK;
 }
 // tile choice: the plan's tile if the caller used t3d_wgrad_plan's split, else by shape
@@ -1306,6 +1536,22 @@ extern "C" int t3d_pointmlp_wgrad(const t3d_pointmlp_wgrad_args* a, t3d_stream_t
   const int tiles_k = (a->K + tk - 1) / tk, tiles_n = a->N / tn;
   const dim3 grid(tiles_k * tiles_n * splits);
   const bool sub = a->a.sub != nullptr, pooled = a->dy.dz == nullptr;
+  if (a->dy.dtype == T3D_BF16) {
+    const bool xh = a->a.dtype == T3D_BF16;
+#define T3D_WGH(TK, TN_)                                                                                                     \
+  do {                                                                                                                       \
+    if (sub) launch_lds(k_pointmlp_wgrad<TK, TN_, true, false, PathBF16, float>, grid, lds_wgrad_h(TK, TN_), s, *a);         \
+    else if (xh) launch_lds(k_pointmlp_wgrad<TK, TN_, false, false, PathBF16, bf16_t>, grid, lds_wgrad_h(TK, TN_), s, *a);   \
+    else launch_lds(k_pointmlp_wgrad<TK, TN_, false, false, PathBF16, float>, grid, lds_wgrad_h(TK, TN_), s, *a);            \
+  } while (0)
+    if (tk == 128 && tn == 128) T3D_WGH(128, 128);
+    else if (tk == 128) T3D_WGH(128, 64);
+    else if (tn == 128) T3D_WGH(64, 128);
+    else T3D_WGH(64, 64);
+#undef T3D_WGH
+    T3D_CHECK_LAUNCH();
+    return T3D_OK;
+  }
 #define T3D_WG(TK, TN_)                                                                                   \
   do {                                                                                                    \
     if (sub && pooled) launch_lds(k_pointmlp_wgrad<TK, TN_, true, true>, grid, lds_wgrad(TK, TN_), s, *a);        \
@@ -1327,6 +1573,7 @@ static int check_dgrad_gram(const t3d_pointmlp_dgrad_gram_args* a) {
   if (a->add_live && !a->add_in) return T3D_ERR_ARG;
   if (a->prev_y && (!a->prev_scale || !a->prev_shift)) return T3D_ERR_ARG;
   if (a->psum_dz && (!a->psum_dzy || !a->prev_y)) return T3D_ERR_ARG;
+  if (!dtype_ok(a->dtype) || a->dtype != a->a.dtype) return T3D_ERR_ARG;
   if (a->M <= 0 || a->M % T3D_TILE_ROWS || a->rows_per_frustum % T3D_TILE_ROWS || a->M % a->rows_per_frustum ||
       a->K % 64 || (long)a->M * a->K >= (1L << 30))
     return T3D_ERR_SHAPE;
@@ -1341,7 +1588,10 @@ extern "C" int t3d_pointmlp_dgrad_gram(const t3d_pointmlp_dgrad_gram_args* a, t3
   if (rc != T3D_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int tiles_m = a->M / 128;
-  if (dgrad_gram_wide(a))
+  if (a->dtype == T3D_BF16) {
+    if (dgrad_gram_wide(a)) launch_lds(k_pointmlp_dgrad_gram<128, PathBF16>, dim3(tiles_m * (a->K / 128)), lds_fwd_h(128), s, *a);
+    else launch_lds(k_pointmlp_dgrad_gram<64, PathBF16>, dim3(tiles_m * (a->K / 64)), lds_fwd_h(64), s, *a);
+  } else if (dgrad_gram_wide(a))
     launch_lds(k_pointmlp_dgrad_gram<128>, dim3(tiles_m * (a->K / 128)), lds_fwd(128), s, *a);
   else
     launch_lds(k_pointmlp_dgrad_gram<64>, dim3(tiles_m * (a->K / 64)), lds_fwd(64), s, *a);
@@ -1351,8 +1601,9 @@ extern "C" int t3d_pointmlp_dgrad_gram(const t3d_pointmlp_dgrad_gram_args* a, t3
 
 static int check_gram(const t3d_pointmlp_gram_args* a) {
   if (!a || !a->slabs || !act_ok(a->a, a->K) || a->a.sub) return T3D_ERR_ARG;
-  if (a->M <= 0 || a->rows_per_split <= 0 || a->rows_per_split % BK || a->M % a->rows_per_split || a->K % 64 ||
-      a->rows_per_frustum % BK || a->M % a->rows_per_frustum)
+  const int red = a->a.dtype == T3D_BF16 ? BKH : BK;
+  if (a->M <= 0 || a->rows_per_split <= 0 || a->rows_per_split % red || a->M % a->rows_per_split || a->K % 64 ||
+      a->rows_per_frustum % red || a->M % a->rows_per_frustum)
     return T3D_ERR_SHAPE;
   return T3D_OK;
 }
@@ -1370,7 +1621,10 @@ extern "C" int t3d_pointmlp_gram(const t3d_pointmlp_gram_args* a, t3d_stream_t s
   const int splits = a->M / a->rows_per_split;
   const int tk = gram_tile(a), tn = tk;
   const dim3 grid((a->K / tk) * (a->K / tn) * splits);
-  if (tk == 128) launch_lds(k_pointmlp_gram<128, 128>, grid, lds_wgrad(128, 128), s, *a);
+  if (a->a.dtype == T3D_BF16) {
+    if (tk == 128) launch_lds(k_pointmlp_gram<128, 128, PathBF16>, grid, lds_wgrad_h(128, 128), s, *a);
+    else launch_lds(k_pointmlp_gram<64, 64, PathBF16>, grid, lds_wgrad_h(64, 64), s, *a);
+  } else if (tk == 128) launch_lds(k_pointmlp_gram<128, 128>, grid, lds_wgrad(128, 128), s, *a);
   else launch_lds(k_pointmlp_gram<64, 64>, grid, lds_wgrad(64, 64), s, *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -1384,6 +1638,8 @@ extern "C" int t3d_pointmlp_bwd(const t3d_pointmlp_dgrad_args* d, const t3d_poin
   // the fused launch covers the dense form only (pooled layers take the Gram path, raw-point layers have no dgrad)
   if (!d->dy.dz || !w->dy.dz || w->a.sub) return T3D_ERR_ARG;
   if (d->M != w->M || d->K != w->K || d->N != w->N) return T3D_ERR_SHAPE;
+  if (d->dtype != w->dy.dtype || w->a.dtype != d->dtype) return T3D_ERR_ARG;      // one element type per layer
+  const bool bf16 = d->dtype == T3D_BF16;
   hipStream_t s = static_cast<hipStream_t>(stream);
   int tk = 0, tn = 0;
   wgrad_tile(w, &tk, &tn);
@@ -1397,10 +1653,17 @@ extern "C" int t3d_pointmlp_bwd(const t3d_pointmlp_dgrad_args* d, const t3d_poin
   const int interleave = (il && w->rows_per_split % 128 == 0) ? 1 : 0;
 #define T3D_BWD(DBN, TK, TN_)                                                                                      \
   do {                                                                                                              \
-    const size_t lds = lds_dgrad(DBN) > lds_wgrad(TK, TN_) ? lds_dgrad(DBN) : lds_wgrad(TK, TN_);                   \
-    auto kern = k_pointmlp_bwd<DBN, TK, TN_>;                                                                       \
-    allow_lds(reinterpret_cast<const void*>(kern), lds);                                                            \
-    T3D_LAUNCH(kern, grid, dim3(NT), lds, s, *d, *w, n_w, interleave);                                              \
+    if (bf16) {                                                                                                     \
+      const size_t lds = lds_dgrad_h(DBN) > lds_wgrad_h(TK, TN_) ? lds_dgrad_h(DBN) : lds_wgrad_h(TK, TN_);         \
+      auto kern = k_pointmlp_bwd<DBN, TK, TN_, PathBF16>;                                                           \
+      allow_lds(reinterpret_cast<const void*>(kern), lds);                                                          \
+      T3D_LAUNCH(kern, grid, dim3(NT), lds, s, *d, *w, n_w, interleave);                                            \
+    } else {                                                                                                        \
+      const size_t lds = lds_dgrad(DBN) > lds_wgrad(TK, TN_) ? lds_dgrad(DBN) : lds_wgrad(TK, TN_);                 \
+      auto kern = k_pointmlp_bwd<DBN, TK, TN_>;                                                                     \
+      allow_lds(reinterpret_cast<const void*>(kern), lds);                                                          \
+      T3D_LAUNCH(kern, grid, dim3(NT), lds, s, *d, *w, n_w, interleave);                                            \
+    }                                                                                                               \
   } while (0)
 #define T3D_BWD_W(DBN)                              \
   do {                                              \
@@ -1429,16 +1692,20 @@ extern "C" int t3d_pool_bwd_stage1(const t3d_pointmlp_gram_args* g, const t3d_ac
   const int n_colsum = c->M / 128;
   const int n_prep = (q->K / 32) * (q->K / 32) * ((q->N + PCH - 1) / PCH);
   const dim3 grid(n_gram + n_colsum + n_prep);
-  size_t lds = lds_wgrad(gt, gt);
+  const bool bf16 = g->a.dtype == T3D_BF16;
+  if (c->a.dtype != g->a.dtype) return T3D_ERR_ARG;
+  size_t lds = bf16 ? lds_wgrad_h(gt, gt) : lds_wgrad(gt, gt);
   if (PREP_LDS > lds) lds = PREP_LDS;
   if (COLSUM_LDS > lds) lds = COLSUM_LDS;
-  if (gt == 128) {
-    auto kern = k_pool_bwd_stage1<128>;
-    allow_lds(reinterpret_cast<const void*>(kern), lds);
-    T3D_LAUNCH(kern, grid, dim3(NT), lds, s, *g, *c, *q, n_gram, n_colsum);
-  } else {
-    T3D_LAUNCH(k_pool_bwd_stage1<64>, grid, dim3(NT), lds, s, *g, *c, *q, n_gram, n_colsum);
-  }
+#define T3D_ST1(GT_, PR_)                                                              \
+  do {                                                                                 \
+    auto kern = k_pool_bwd_stage1<GT_, PR_>;                                           \
+    allow_lds(reinterpret_cast<const void*>(kern), lds);                               \
+    T3D_LAUNCH(kern, grid, dim3(NT), lds, s, *g, *c, *q, n_gram, n_colsum);            \
+  } while (0)
+  if (bf16) { if (gt == 128) T3D_ST1(128, PathBF16); else T3D_ST1(64, PathBF16); }
+  else { if (gt == 128) T3D_ST1(128, PathF32); else T3D_ST1(64, PathF32); }
+#undef T3D_ST1
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -1453,17 +1720,19 @@ extern "C" int t3d_pool_bwd_stage2(const t3d_pool_wgrad_finish_args* f, const t3
   const bool wide = dgrad_gram_wide(d);
   const int n_d = (d->M / 128) * (d->K / (wide ? 128 : 64));
   const dim3 grid(n_finish + n_d);
-  size_t lds = wide ? lds_fwd(128) : lds_fwd(64);
+  const bool bf16 = d->dtype == T3D_BF16;
+  if (f->a.dtype != d->a.dtype) return T3D_ERR_ARG;
+  size_t lds = bf16 ? (wide ? lds_fwd_h(128) : lds_fwd_h(64)) : (wide ? lds_fwd(128) : lds_fwd(64));
   if (finish_lds(f->K) > lds) lds = finish_lds(f->K);
-  if (wide) {
-    auto kern = k_pool_bwd_stage2<128>;
-    allow_lds(reinterpret_cast<const void*>(kern), lds);
-    T3D_LAUNCH(kern, grid, dim3(NT), lds, s, *f, *d, n_finish);
-  } else {
-    auto kern = k_pool_bwd_stage2<64>;
-    allow_lds(reinterpret_cast<const void*>(kern), lds);
-    T3D_LAUNCH(kern, grid, dim3(NT), lds, s, *f, *d, n_finish);
-  }
+#define T3D_ST2(BN_, PR_)                                                              \
+  do {                                                                                 \
+    auto kern = k_pool_bwd_stage2<BN_, PR_>;                                           \
+    allow_lds(reinterpret_cast<const void*>(kern), lds);                               \
+    T3D_LAUNCH(kern, grid, dim3(NT), lds, s, *f, *d, n_finish);                        \
+  } while (0)
+  if (bf16) { if (wide) T3D_ST2(128, PathBF16); else T3D_ST2(64, PathBF16); }
+  else { if (wide) T3D_ST2(128, PathF32); else T3D_ST2(64, PathF32); }
+#undef T3D_ST2
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

@@ -162,7 +162,7 @@ __device__ __forceinline__ void pool_sparse_rows_body(const t3d_pool_sparse_rows
 // part[t,k] = sum of act(a)[m,k] over the 128 rows of tile t.  One workgroup per tile.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float act_elem(const t3d_act_src& s, size_t row, int k) {
-  float v = s.x[row * s.ldx + s.coff + k];
+  float v = ld_elem(s.x, row * s.ldx + s.coff + k, s.dtype);
   if (s.scale) v = fmaf(v, s.scale[k], s.shift[k]);
   if (s.relu) v = fmaxf(v, 0.f);
   return v;
@@ -183,10 +183,11 @@ __device__ __forceinline__ void act_colsum_body(const t3d_act_colsum_args& p, fl
   }
   const float floor_ = p.a.relu ? 0.f : -INFINITY;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float* base = p.a.x + (size_t)(row0 + grp * rows) * p.a.ldx + p.a.coff + 4 * c4;
+  const size_t base = (size_t)(row0 + grp * rows) * p.a.ldx + p.a.coff + 4 * c4;       // element offset (fp32 or bf16 source)
+  const int dt = p.a.dtype;
 #pragma unroll 16
   for (int r = 0; r < rows; ++r) {
-    const float4 x = *reinterpret_cast<const float4*>(base + (size_t)r * p.a.ldx);
+    const float4 x = ld_elem4(p.a.x, base + (size_t)r * p.a.ldx, dt);
     acc.x += fmaxf(fmaf(x.x, sc.x, sh.x), floor_);
     acc.y += fmaxf(fmaf(x.y, sc.y, sh.y), floor_);
     acc.z += fmaxf(fmaf(x.z, sc.z, sh.z), floor_);
@@ -234,7 +235,8 @@ __device__ __forceinline__ void pool_wgrad_finish_body(const t3d_pool_wgrad_fini
     const int k = tid & 31, q = tid >> 5;
     const float sc = p.a.scale ? p.a.scale[k0 + k] : 1.f, sh = p.a.scale ? p.a.shift[k0 + k] : 0.f;
     const float floor_ = p.a.relu ? 0.f : -INFINITY;
-    const float* xk = p.a.x + p.a.coff + k0 + k;
+    const size_t xk = (size_t)(p.a.coff + k0 + k);
+    const int dt = p.a.dtype;
     float g0 = 0.f, g1 = 0.f;
     for (int b0 = 0; b0 < p.B; b0 += FB) {
       __syncthreads();
@@ -251,8 +253,8 @@ __device__ __forceinline__ void pool_wgrad_finish_body(const t3d_pool_wgrad_fini
 #pragma unroll
       for (int bb = 0; bb < FB; ++bb) {              // 64 independent loads in flight
         const size_t rowbase = (size_t)min(b0 + bb, p.B - 1) * p.rows_per_frustum;
-        x0[bb] = xk[(rowbase + ais[bb * FN + q]) * p.a.ldx];
-        x1[bb] = xk[(rowbase + ais[bb * FN + q + 8]) * p.a.ldx];
+        x0[bb] = ld_elem(p.a.x, xk + (rowbase + ais[bb * FN + q]) * p.a.ldx, dt);
+        x1[bb] = ld_elem(p.a.x, xk + (rowbase + ais[bb * FN + q + 8]) * p.a.ldx, dt);
       }
 #pragma unroll
       for (int bb = 0; bb < FB; ++bb) {

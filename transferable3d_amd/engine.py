@@ -197,6 +197,7 @@ class VarStore:
         self.adam_m = rt.zeros(capacity)
         self.adam_v = rt.zeros(capacity)
         self.state = rt.zeros(state_capacity)
+        self.params16 = None       # bf16 copy of `params` for the T3D_BF16 GEMMs (enable_bf16; refreshed by t3d_cast_bf16 every step)
         self.used = 0
         self.state_used = 0
         self.index = {}        # name -> (offset, shape, trainable)
@@ -223,6 +224,17 @@ class VarStore:
         view = buf[off:off + n].view(*shape)
         view.copy_(torch.as_tensor(np.asarray(init, dtype=np.float32).reshape(shape)))
         return view
+
+    def enable_bf16(self):
+        if self.params16 is None:
+            self.params16 = self.rt.zeros(self.params.numel(), dtype=torch.bfloat16)
+        return self.params16
+
+    def bf16_view(self, w):
+        """The bf16 twin of a view `w` of the fp32 parameter buffer (same element offset, same shape)."""
+        off = (w.data_ptr() - self.params.data_ptr()) // 4
+        assert 0 <= off and off + w.numel() <= self.params.numel() and w.is_contiguous()
+        return self.enable_bf16()[off:off + w.numel()].view(*w.shape)
 
     def get(self, name):
         off, shape, trainable = self.index[name]
@@ -312,10 +324,11 @@ class ActSpec:
         self.x, self.ldx, self.K, self.coff = x, ldx, K, coff
         self.scale, self.shift, self.relu, self.sub, self.sub_ld = scale, shift, relu, sub, sub_ld
         self.producer = producer     # PointLayer that owns x (None for raw inputs)
+        self.dtype = abi.BF16 if x.dtype == torch.bfloat16 else abi.F32      # element type of x: the raw inputs are always fp32
 
     def struct(self):
         return abi.ActSrc(fptr(self.x), self.ldx, self.coff, fptr(self.scale), fptr(self.shift), int(self.relu),
-                          fptr(self.sub), self.sub_ld)
+                          fptr(self.sub), self.sub_ld, self.dtype)
 
 
 def wgrad_rows_per_split(lib, M, K, N):
@@ -343,12 +356,16 @@ class PointLayer:
             self.w_name = scope + '/weights'
             self.w_row0 = 0
         self.w = w
+        self.dt, self.adt = g.dt, g.adt                  # abi.F32 / abi.BF16 and the torch dtype of the [M, C] layer tensors
+        # what the GEMM kernels read as `w`: the fp32 weights, or their bf16 copy (refreshed every step: Graph.emit_cast_weights)
+        self.w_mm = vs.bf16_view(w) if self.dt == abi.BF16 else w
+        assert not (self.dt == abi.BF16 and pool and not self.gram), "bf16: max-pooled layers take the Gram-form backward"
         self.bias = bias if bias is not None else vs.const(scope + '/biases', (N,), 0.0)
         self.gamma = vs.const(scope + '/bn/gamma', (N,), 1.0)
         self.beta = vs.const(scope + '/bn/beta', (N,), 0.0)
         self.mm = vs.const(scope + '/bn/moving_mean', (N,), 0.0, trainable=False)
         self.mv = vs.const(scope + '/bn/moving_variance', (N,), 1.0, trainable=False)
-        self.y = None if self.gram else rt.zeros(M, N)
+        self.y = None if self.gram else rt.zeros(M, N, dtype=self.adt)
         self.psum, self.psumsq = rt.zeros(T, N), rt.zeros(T, N)
         self.scale, self.shift = rt.zeros(N), rt.zeros(N)
         self.mean, self.invstd = rt.zeros(N), rt.zeros(N)
@@ -370,7 +387,8 @@ class PointLayer:
         self.src, self.rowmask, self.is_training = src, rowmask, is_training
         a = abi.PointMlpFwdArgs()
         a.a = src.struct()
-        a.w, a.bias, a.rowbias, a.y = fptr(self.w), fptr(self.bias), fptr(rowbias), fptr(self.y)
+        a.w, a.bias, a.rowbias, a.y = fptr(self.w_mm), fptr(self.bias), fptr(rowbias), fptr(self.y)
+        a.dtype = self.dt
         a.psum, a.psumsq = fptr(self.psum), fptr(self.psumsq)
         if pool:
             a.rowmask = fptr(rowmask)
@@ -401,14 +419,15 @@ class PointLayer:
                     K, N = self.K, self.N
                     self.wc, self.S = rt.zeros(N, K), rt.zeros(self.M, K)
                     self.S_live = rt.zeros(self.M, dtype=torch.int32) if SPARSE_GATED else None
+                    assert self.S_live is not None or self.dt == abi.F32, "bf16: the fp32 sparse rows S need their row flags"
             else:
-                self.dz = rt.zeros(self.M, self.N)
+                self.dz = rt.zeros(self.M, self.N, dtype=self.adt)
                 self.psum_dz, self.psum_dzy = rt.zeros(self.T, self.N), rt.zeros(self.T, self.N)
 
     def dy_struct(self):
         if self.pool:
-            return abi.DySrc(fptr(None), fptr(self.y), fptr(self.coef), iptr(self.argidx), fptr(self.dpool))
-        return abi.DySrc(fptr(self.dz), fptr(self.y), fptr(self.coef), iptr(None), fptr(None))
+            return abi.DySrc(fptr(None), fptr(self.y), fptr(self.coef), iptr(self.argidx), fptr(self.dpool), self.dt)
+        return abi.DySrc(fptr(self.dz), fptr(self.y), fptr(self.coef), iptr(None), fptr(None), self.dt)
 
     def bn_bwd(self, plan, dpool_in=None, ld_dpool_in=0, param_grads=True):
         """dgamma/dbeta + the three dy coefficients.  `frozen` nets (eval-mode BN) use scale only."""
@@ -511,7 +530,7 @@ class PointLayer:
         a.add_live = iptr(self.S_live)
         a.prev_y, a.prev_scale, a.prev_shift = fptr(prev.y), fptr(prev.scale), fptr(prev.shift)
         a.out, a.psum_dz, a.psum_dzy = fptr(prev.dz), fptr(prev.psum_dz), fptr(prev.psum_dzy)
-        a.M, a.K, a.rows_per_frustum = self.M, K, g.rpf
+        a.M, a.K, a.rows_per_frustum, a.dtype = self.M, K, g.rpf, self.dt
         plan.add('t3d_pointmlp_dgrad_gram', a)
 
     def _bwd_pair_gram(self, plan):
@@ -551,7 +570,7 @@ class PointLayer:
         d.add_live = iptr(self.S_live)
         d.prev_y, d.prev_scale, d.prev_shift = fptr(prev.y), fptr(prev.scale), fptr(prev.shift)
         d.out, d.psum_dz, d.psum_dzy = fptr(prev.dz), fptr(prev.psum_dz), fptr(prev.psum_dzy)
-        d.M, d.K, d.rows_per_frustum = self.M, K, g.rpf
+        d.M, d.K, d.rows_per_frustum, d.dtype = self.M, K, g.rpf, self.dt
         fn2, r2 = lib.t3d_pool_bwd_stage2, (C.byref(f), C.byref(d))
         plan.keep.extend([f, d])
         plan.calls.append(('t3d_pool_bwd_stage2', lambda s: fn2(r2[0], r2[1], s), (f, d)))
@@ -587,7 +606,7 @@ class PointLayer:
     def _dgrad_args(self, out_raw=None, add_in=None):
         prev = self.src.producer if out_raw is None else None
         a = abi.PointMlpDgradArgs()
-        a.dy, a.w, a.add_in = self.dy_struct(), fptr(self.w), fptr(add_in)
+        a.dy, a.w, a.add_in, a.dtype = self.dy_struct(), fptr(self.w_mm), fptr(add_in), self.dt
         if prev is not None:
             prev._ensure_bwd_buffers()
             assert not prev.pool

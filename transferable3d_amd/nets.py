@@ -27,6 +27,8 @@ class Graph:
         accumulation, statistics, parameters and optimiser (configs[4])."""
         assert dtype in ('f32', 'bf16')
         self.dtype = dtype
+        self.dt = abi.DTYPE_BY_NAME[dtype]                                   # t3d.h T3D_F32 / T3D_BF16
+        self.adt = torch.bfloat16 if dtype == 'bf16' else torch.float32      # storage of the [M, C] layer tensors
         if num_point % TILE:
             raise abi.T3DError('num_point must be a multiple of %d' % TILE)
         self.rt = rt or Runtime()
@@ -80,6 +82,14 @@ class Graph:
             return lib.t3d_reduce_slabs(fptr(ws.buf), fptr(vs.grads),
                                         C.cast(C.c_void_p(ws.table.data_ptr() + i0 * stride), C.POINTER(abi.SlabDesc)), i1 - i0, mx, s)
         plan.add_raw('t3d_reduce_slabs', thunk)
+
+    def emit_cast_weights(self, plan):
+        """bf16 path: refresh the bf16 copy of the weights the GEMM kernels read (the optimiser updates the fp32 master copy)."""
+        if self.dt != abi.BF16:
+            return
+        vs, lib = self.vars, self.rt.lib
+        p16 = vs.enable_bf16()
+        plan.add_raw('t3d_cast_bf16', lambda s: lib.t3d_cast_bf16(fptr(vs.params), C.c_void_p(p16.data_ptr()), vs.used, s))
 
     def default_bucket(self):
         """Every trained range: the one bucket of a step whose backward declares none."""
@@ -230,7 +240,7 @@ class InstSegNet:
             # per-tile conv10 weight-gradient partials live in the slab workspace: summed by t3d_reduce_slabs
             soff = g.ws.reserve(g.vars.offset(self.scope + '/conv10/weights'), 256, T)
             g.deferred_slab_ptrs.append((h, 'dw_part', soff))
-        h.M, h.K, h.rows_per_frustum, h.B = M, 128, g.rpf, g.B
+        h.M, h.K, h.rows_per_frustum, h.B, h.dtype = M, 128, g.rpf, g.B, g.dt
         plan.add('t3d_seg_head', h)
         f = abi.SegFinalizeArgs()
         f.part, f.B, f.tiles_per_frustum, f.rows_per_frustum, f.K = fptr(self.part), g.B, g.rpf // TILE, g.rpf, 128
@@ -261,7 +271,7 @@ class InstSegNet:
         colsum6 = L.L6.dy_colsum(plan)                                   # [B,512]
         L.G6.bwd(plan, dout=colsum6, ld_dout=512)                        # dW6[64:], no bias
         dg5 = L.G6.dinput(plan, K=1024, bn_bwd_of=L.L5)                   # [B,1024] + conv5's BN-bwd finalize
-        self.da3_part = g.rt.zeros(g.M, 64)
+        self.da3_part = g.rt.zeros(g.M, 64, dtype=g.adt)
         L.L6.bwd_pair(plan, out_raw=self.da3_part)
         L.L5.bn_bwd(plan, dpool_in=dg5, ld_dpool_in=1024)
         L.L5.bwd_pair(plan)
@@ -452,6 +462,7 @@ class ModelAssembly:
 
     def emit_forward(self, plan, is_training, with_loss):
         g, x, c = self.g, self.inputs, self.c
+        g.emit_cast_weights(plan)
         labels = x.y_seg if with_loss else None
         train_seg = with_loss and is_training
         oh = x.one_hot_vec
@@ -622,6 +633,7 @@ class BoxPCModel:
 
     def emit_forward(self, plan, is_training, with_loss):
         x = self.inputs
+        self.g.emit_cast_weights(plan)
         out = self.net.fwd(plan, x.pc, x.y_center, x.y_dims_reg, x.y_orient_reg, x.one_hot_vec, is_training,
                            y_dims_cls=x.y_dims_cls, y_orient_cls=x.y_orient_cls)
         if with_loss:
@@ -678,6 +690,7 @@ class SemiModelF:
         if not is_training and self.refine_num is not None:
             return self.emit_forward_inference(plan, self.refine_num)
         g, x, c = self.g, self.inputs, self.c
+        g.emit_cast_weights(plan)
         self.seg.fwd(plan, x.pc, x.one_hot_vec, x.y_seg if with_loss else None, x.is_data_2D, is_training, False,
                      ce_weight=c.STRONG_WEIGHT_CROSS_ENTROPY)
         s1 = self.tnet.fwd(plan, x.pc, self.seg.mask, self.seg.mask_xyz_mean, x.one_hot_vec, is_training)
@@ -709,6 +722,7 @@ class SemiModelF:
         minus the totals).  The strong-loss kernel runs for its anchor->reg outputs only (labels are whatever the label
         buffers hold; its loss values are not part of this graph)."""
         g, x, c = self.g, self.inputs, self.c
+        g.emit_cast_weights(plan)
         self.seg.fwd(plan, x.pc, x.one_hot_vec, None, x.is_data_2D, False, False, ce_weight=c.STRONG_WEIGHT_CROSS_ENTROPY)
         s1 = self.tnet.fwd(plan, x.pc, self.seg.mask, self.seg.mask_xyz_mean, x.one_hot_vec, False)
         self.box.fwd(plan, x.pc, self.seg.mask, s1, x.one_hot_vec, False)
