@@ -139,6 +139,15 @@ class Ctx:
         # function; forward values move by the size of the disputed pre-activations (~1e-6).  `flips` counts the disagreements.
         self.forced_gates = {}
         self.forced_argmax = {}
+        # bf16 emulation (BASELINE configs[4]; tests/test_bf16_gpu.py): the roundings of the T3D_BF16 path injected at the points the
+        # kernels round -- both operands of every per-point GEMM (the activated input and the weights) and every STORED raw layer
+        # output; the max-pooled layers (no stored output), the conv10 logits (computed in the segmentation head from the stored
+        # conv9 output), the fully-connected heads, statistics and losses stay unrounded.  Roundings are straight-through for
+        # autograd: the gradient is that of the rounded forward, without the backward pass's own roundings (dz / dy to bf16).
+        self.bf16 = False
+        self.keep_raw = None         # dict: conv2d records its raw (pre-batch-norm) outputs here, for layer-wise comparisons
+        self.forced_mask = None      # (B, N) 0/1: the hard segmentation mask the implementation under test took (logit0 < logit1 with
+        #                              the two logits within fp32 rounding of each other is the same kind of decision)
         self.flips = {}
 
     def training_for(self, scope):
@@ -187,11 +196,33 @@ def _act(x, activation, ctx=None, scope=None):
     raise ValueError(activation)
 
 
-def conv2d(ctx, x, scope, bn=True, activation='relu'):
-    """Per-point 1x1 (or [1,D]) VALID conv == (B*N, Cin) x (Cin, Cout) + bias (+BN) (+act)."""
+def round_bf16(x):
+    """x rounded to bfloat16 (round to nearest even), straight-through for autograd."""
+    r = x.detach().to(torch.float32).to(torch.bfloat16).to(x.dtype)
+    return x + (r - x.detach())
+
+
+BF16_UNSTORED = ('/conv5', '/conv-reg3-stage1', '/conv-reg4')      # max-pooled layers: statistics / pool from the fp32 accumulators
+
+
+def conv2d(ctx, x, scope, bn=True, activation='relu', x_global=None):
+    """Per-point 1x1 (or [1,D]) VALID conv == (B*N, Cin) x (Cin, Cout) + bias (+BN) (+act).
+    x_global (conv6 only): the per-frustum part of the input, (B, Cg), multiplying the LAST Cg rows of the weights -- the same
+    arithmetic as the tile + concat of semisup_models.py:107-108, written so that the bf16 emulation can round the per-point
+    operands only (the global part is an fp32 fully-connected product in the T3D_BF16 path)."""
     W = ctx.P[scope + '/weights']
     W = W.reshape(-1, W.shape[-1])
-    y = x @ W + ctx.P[scope + '/biases']
+    head = ctx.bf16 and not bn                       # conv10: inside the segmentation head, fp32 arithmetic on the stored conv9 output
+    Wp, Wg = (W, None) if x_global is None else (W[:W.shape[0] - x_global.shape[1]], W[W.shape[0] - x_global.shape[1]:])
+    if ctx.bf16 and not head:
+        x, Wp = round_bf16(x), round_bf16(Wp)
+    y = x @ Wp + ctx.P[scope + '/biases']
+    if x_global is not None:
+        y = y + (x_global @ Wg)[:, None, :]
+    if ctx.bf16 and not head and not scope.endswith(BF16_UNSTORED):
+        y = round_bf16(y)
+    if ctx.keep_raw is not None:
+        ctx.keep_raw[scope] = y.detach()              # the layer's raw output as the implementation stores it
     if bn:
         y = batch_norm(ctx, y, scope + '/bn')
     return _act(y, activation, ctx, scope)
@@ -241,8 +272,11 @@ def v1_inst_seg(ctx, pc, one_hot_vec, scope='inst_seg', ep=None):
         ep['seg_global_feat'] = global_feat
     if one_hot_vec is not None:
         global_feat = torch.cat([global_feat, one_hot_vec], dim=1)
-    concat = torch.cat([point_feat, global_feat[:, None, :].expand(B, N, global_feat.shape[1])], dim=2)
-    net = conv2d(ctx, concat, scope + '/conv6')
+    if ctx.bf16:
+        net = conv2d(ctx, point_feat, scope + '/conv6', x_global=global_feat)
+    else:
+        concat = torch.cat([point_feat, global_feat[:, None, :].expand(B, N, global_feat.shape[1])], dim=2)
+        net = conv2d(ctx, concat, scope + '/conv6')
     net = conv2d(ctx, net, scope + '/conv7')
     net = conv2d(ctx, net, scope + '/conv8')
     net = conv2d(ctx, net, scope + '/conv9')
@@ -251,9 +285,13 @@ def v1_inst_seg(ctx, pc, one_hot_vec, scope='inst_seg', ep=None):
     return logits                                                    # (B,N,2)
 
 
-def subtract_points_mean(pc, logits):
+def subtract_points_mean(pc, logits, ctx=None):
     """semisup_models.py:145-162.  mask is a hard comparison: no gradient."""
     mask = (logits[:, :, 0:1] < logits[:, :, 1:2]).to(pc.dtype)      # (B,N,1)
+    if ctx is not None and ctx.forced_mask is not None:
+        forced = torch.as_tensor(ctx.forced_mask).reshape(mask.shape).to(pc.dtype)
+        ctx.flips['mask'] = int((forced != mask).sum())
+        mask = forced
     mask_count = mask.sum(dim=1, keepdim=True).expand(-1, -1, 3)
     xyz = pc[:, :, 0:3]
     mean = (mask * xyz).sum(dim=1, keepdim=True) / torch.clamp(mask_count, min=1.0)
@@ -336,7 +374,7 @@ def get_semi_model_backbone(ctx, pc, one_hot_vec, use_one_hot=False):
     logits = v1_inst_seg(ctx, pc, oh, 'inst_seg', ep)
     ep['logits'] = logits
     ep['soft_mask'] = torch.softmax(logits, dim=-1)[:, :, 1]
-    mask, mean, xyz, xyz1 = subtract_points_mean(pc, logits)
+    mask, mean, xyz, xyz1 = subtract_points_mean(pc, logits, ctx)
     ep['mask'] = mask
     ep['mask_xyz_mean'] = mean
     s1 = v1_tnet(ctx, xyz1, mask, mean, oh, ep, 'tnet')
@@ -365,7 +403,7 @@ def get_semi_model_final(ctx, pc, one_hot_vec, use_one_hot, c):
     p = 'class_agnostic/'
     logits = v1_inst_seg(ctx, pc, None, p + 'inst_seg', ep)
     ep['logits'] = logits
-    mask, mean, xyz, xyz1 = subtract_points_mean(pc, logits)
+    mask, mean, xyz, xyz1 = subtract_points_mean(pc, logits, ctx)
     ep['mask'] = mask
     ep['mask_xyz_mean'] = mean
     s1 = v1_tnet(ctx, xyz1, mask, mean, None, ep, p + 'tnet')
@@ -684,6 +722,9 @@ def _apply_forced(ctx, forced):
     if forced:
         ctx.forced_gates = dict(forced.get('gates', {}))
         ctx.forced_argmax = dict(forced.get('argmax', {}))
+        ctx.forced_mask = forced.get('mask')
+        ctx.bf16 = bool(forced.get('bf16', False))
+        ctx.keep_raw = forced.get('keep_raw')
 
 
 def model_a_forward_backward(P, batch, c, bn_decay_val=0.5, dtype=torch.float64, use_one_hot=False,

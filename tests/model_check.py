@@ -48,7 +48,8 @@ def product_decisions(model):
     forced_argmax wants them: for every dense per-point layer the sign of its ReLU input (the kernels evaluate
     fmaf(y, scale, shift) > 0, i.e. the sign of the exact product-sum, reproduced here in fp64), for every max-pooled layer the
     arg-max row per (frustum, channel) (-1 where the pooled value is 0), for every fully-connected layer with a (leaky) ReLU the
-    sign of its output.  Lets the gradient checks bound EVERY tensor near 1e-4 instead of tolerating ReLU-boundary flips."""
+    sign of its output; and the hard segmentation mask.  Lets the gradient checks bound EVERY tensor near 1e-4 instead of tolerating
+    ReLU-boundary flips."""
     from transferable3d_amd.engine import FcLayer, PointLayer
     gates, argmax, seen = {}, {}, set()
 
@@ -74,7 +75,13 @@ def product_decisions(model):
             for v in vars(o).values():
                 walk(v, depth + 1)
     walk(model)
-    return {'gates': gates, 'argmax': argmax}
+    out = {'gates': gates, 'argmax': argmax}
+    seg = getattr(model, 'seg', None)
+    if seg is not None and getattr(seg, 'mask', None) is not None:
+        # the hard segmentation mask (semisup_models.py:150: logit0 < logit1) is the same kind of decision: a point whose two logits
+        # agree to fp32 rounding may fall on either side, which moves the masked centroid and everything behind it
+        out['mask'] = seg.mask.detach().cpu().numpy().reshape(seg.g.B, seg.g.rpf)
+    return out
 
 
 def tight_grad_check(g, ref_grads, per_tol=1e-3, med_tol=5e-5, glob_tol=1e-4, what=''):

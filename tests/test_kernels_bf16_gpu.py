@@ -1,0 +1,177 @@
+"""GPU: the T3D_BF16 GEMM kernels (bf16 storage, v_mfma_f32_32x32x16_bf16, fp32 accumulation) against stock-torch matmuls of the
+SAME bf16-rounded operands in fp64.  What is checked is the kernels' index arithmetic -- the two LDS image formats, the
+transposing fragment reads, the accumulator -> row/column mapping of the typed epilogues -- so the bound is tight: the only error
+left is the fp32 accumulation order (1e-5 relative to the operand scale) plus ONE bf16 rounding of each stored output
+(2^-9 = 2e-3 relative)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from transferable3d_amd import abi
+from transferable3d_amd.abi import fptr, iptr
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+BF = torch.bfloat16
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def rb(t):
+    """round to bf16, back to fp64"""
+    return t.to(BF).double()
+
+
+def close_bf16(got, ref, what, acc_rel=2e-5, opmax=0.0):
+    """got: stored bf16 tensor; ref: fp64 value before the output rounding.  opmax = max|A| * max|B| of the two operands: the
+    kernel forms an operand element in fp32 and rounds it to bf16, the reference in fp64 -- about one element in 2^16 lands on the
+    other side of a bf16 rounding boundary and then differs by one bf16 spacing (2^-7 relative); allow two such elements per
+    output.  (A wrong index anywhere moves outputs by the operand scale itself.)"""
+    got, ref = got.double().cpu(), ref.double().cpu()
+    scale = float(ref.abs().max())
+    tol = 2.0 ** -8 * ref.abs() + acc_rel * scale + 2 * 2.0 ** -7 * opmax + 1e-30
+    bad = (got - ref).abs() > tol
+    assert not bool(bad.any()), (what, int(bad.sum()), float((got - ref).abs().max()), scale)
+
+
+@pytest.mark.parametrize('M,K,N,rpf,xbf,pool', [(512, 64, 64, 256, True, False), (256, 4, 64, 128, False, False),
+                                                (256, 3, 128, 128, False, False), (512, 128, 256, 256, True, True),
+                                                (256, 64, 512, 128, True, False), (384, 512, 256, 128, True, False),
+                                                (65536, 128, 128, 1024, True, False)])
+def test_bf16_forward(hip_lib, M, K, N, rpf, xbf, pool):
+    g = torch.Generator(device='cpu').manual_seed(M + K + N)
+    ldx = 4 if K <= 4 else K
+    x32 = torch.randn(M, ldx, generator=g)
+    x = (x32.to(BF) if xbf else x32).to(DEV)
+    w32 = torch.randn(K, N, generator=g) / np.sqrt(K)
+    w16 = w32.to(BF).to(DEV)
+    bias = (torch.randn(N, generator=g) * 0.1).to(DEV)
+    sc = (0.5 + torch.rand(K, generator=g)).to(DEV)
+    sh = (torch.randn(K, generator=g) * 0.2).to(DEV)
+    B, T = M // rpf, M // 128
+    sub = torch.randn(B, 3, generator=g).to(DEV)
+    mask = (torch.rand(M, generator=g) < 0.4).float().to(DEV)
+    bn = K > 4
+    y = torch.zeros(M, N, dtype=BF, device=DEV)
+    psum, psumsq = torch.zeros(T, N, device=DEV), torch.zeros(T, N, device=DEV)
+    a = abi.PointMlpFwdArgs()
+    a.a = abi.ActSrc(fptr(x), ldx, 0, fptr(sc if bn else None), fptr(sh if bn else None), int(bn), fptr(sub if K == 3 else None), 3,
+                     abi.BF16 if xbf else abi.F32)
+    a.w, a.bias, a.psum, a.psumsq = fptr(w16), fptr(bias), fptr(psum), fptr(psumsq)
+    if pool:
+        pmax, pmin = torch.zeros(T, N, device=DEV), torch.zeros(T, N, device=DEV)
+        pamax, pamin = torch.zeros(T, N, dtype=torch.int32, device=DEV), torch.zeros(T, N, dtype=torch.int32, device=DEV)
+        a.pmax, a.pmin, a.pamax, a.pamin, a.rowmask = fptr(pmax), fptr(pmin), iptr(pamax), iptr(pamin), fptr(mask)
+    else:
+        a.y = fptr(y)
+    a.M, a.K, a.N, a.rows_per_frustum, a.dtype = M, K, N, rpf, abi.BF16
+    assert hip_lib.t3d_pointmlp_fwd(C.byref(a), stream()) == 0
+    torch.cuda.synchronize()
+    act = x.double()[:, :K]
+    if bn:
+        act = torch.relu(act * sc.double() + sh.double())
+    if K == 3:
+        act = act - sub.double().repeat_interleave(rpf, 0)
+    ref = rb(act) @ w16.double() + bias.double()
+    if not pool:
+        close_bf16(y, ref, 'y', opmax=float(act.abs().max() * w16.double().abs().max()))
+        ys = y.double().reshape(T, 128, N)
+        assert float((psum.double() - ys.sum(1)).abs().max()) < 1e-4 * float(ys.abs().sum(1).max() + 1)
+        assert float((psumsq.double() - (ys * ys).sum(1)).abs().max()) < 1e-4 * float((ys * ys).sum(1).max() + 1)
+    else:
+        rt = ref.reshape(T, 128, N)
+        assert float((psum.double() - rt.sum(1)).abs().max()) < 1e-4 * float(rt.abs().sum(1).max() + 1)
+        keep = mask.reshape(T, 128, 1) > 0
+        mx = torch.where(keep, rt, torch.full_like(rt, -1e30)).max(1).values
+        has = keep.any(1).expand_as(mx)
+        assert float((pmax.double() - mx)[has].abs().max()) < 1e-4 * float(rt.abs().max())
+        assert bool(((pamax >= 0) == has).all())
+
+
+@pytest.mark.parametrize('M,K,N,rpf,addin', [(512, 64, 128, 256, False), (256, 64, 512, 128, True), (384, 512, 256, 128, False),
+                                             (256, 256, 128, 128, True), (65536, 128, 128, 1024, False)])
+def test_bf16_fused_backward(hip_lib, M, K, N, rpf, addin):
+    """t3d_pointmlp_bwd: dX = dy . W^T with the ReLU mask / batch-norm-backward partials of the producing layer, dW = a^T dy as
+    row-split slabs; dy = c0*dz + c1*y + c2 formed from bf16 dz, y while loading."""
+    g = torch.Generator(device='cpu').manual_seed(M + K + N + 1)
+    T = M // 128
+    dz = (torch.randn(M, N, generator=g) * 1e-2).to(BF).to(DEV)
+    y = torch.randn(M, N, generator=g).to(BF).to(DEV)
+    coef = torch.randn(3, N, generator=g)
+    coef[2] *= 1e-3
+    coef = coef.to(DEV)
+    w32 = torch.randn(K, N, generator=g) / np.sqrt(N)
+    w16 = w32.to(BF).to(DEV)
+    prev_y = torch.randn(M, K, generator=g).to(BF).to(DEV)
+    psc = (0.5 + torch.rand(K, generator=g)).to(DEV)
+    psh = (torch.randn(K, generator=g) * 0.3).to(DEV)
+    add = (torch.randn(M, K, generator=g) * 1e-2).to(BF).to(DEV)
+    out = torch.zeros(M, K, dtype=BF, device=DEV)
+    ps1, ps2 = torch.zeros(T, K, device=DEV), torch.zeros(T, K, device=DEV)
+    rps, tk, tn = C.c_int(0), C.c_int(0), C.c_int(0)
+    assert hip_lib.t3d_wgrad_plan(M, K, N, C.byref(rps), C.byref(tk), C.byref(tn)) == 0
+    ns = M // rps.value
+    slabs = torch.zeros(ns, K, N, device=DEV)
+    dy = abi.DySrc(fptr(dz), fptr(y), fptr(coef), iptr(None), fptr(None), abi.BF16)
+    d = abi.PointMlpDgradArgs()
+    d.dy, d.w, d.add_in = dy, fptr(w16), fptr(add if addin else None)
+    d.prev_y, d.prev_scale, d.prev_shift, d.out, d.psum_dz, d.psum_dzy = fptr(prev_y), fptr(psc), fptr(psh), fptr(out), fptr(ps1), fptr(ps2)
+    d.M, d.K, d.N, d.rows_per_frustum, d.dtype = M, K, N, rpf, abi.BF16
+    wa = abi.PointMlpWgradArgs()
+    wa.a = abi.ActSrc(fptr(prev_y), K, 0, fptr(psc), fptr(psh), 1, fptr(None), 0, abi.BF16)
+    wa.dy, wa.slabs = dy, fptr(slabs)
+    wa.M, wa.K, wa.N, wa.rows_per_frustum, wa.rows_per_split = M, K, N, rpf, rps.value
+    assert hip_lib.t3d_pointmlp_bwd(C.byref(d), C.byref(wa), stream()) == 0
+    torch.cuda.synchronize()
+    dyv = rb(coef[0].double() * dz.double() + coef[1].double() * y.double() + coef[2].double())
+    ref = dyv @ w16.double().t() + (add.double() if addin else 0)
+    z = prev_y.double() * psc.double() + psh.double()
+    refm = torch.where(z > 0, ref, torch.zeros_like(ref))
+    close_bf16(out, refm, 'dX', opmax=float(dyv.abs().max() * w16.double().abs().max()))
+    o = out.double().reshape(T, 128, K)
+    assert float((ps1.double() - o.sum(1)).abs().max()) < 1e-4 * float(o.abs().sum(1).max() + 1e-9)
+    assert float((ps2.double() - (o * prev_y.double().reshape(T, 128, K)).sum(1)).abs().max()) < 1e-4 * float(o.abs().sum(1).max() + 1e-9)
+    a = rb(torch.relu(z))
+    dw_ref = a.t() @ dyv
+    dw = slabs.double().sum(0)
+    flip = 2 * 2.0 ** -7 * float(a.abs().max() * dyv.abs().max()) * max(1.0, M / 65536.0 * 4)      # see close_bf16
+    assert float((dw - dw_ref).abs().max()) < 2e-5 * float(dw_ref.abs().max()) * max(1.0, np.sqrt(M / 512)) + flip, \
+        (float((dw - dw_ref).abs().max()), float(dw_ref.abs().max()))
+
+
+@pytest.mark.parametrize('M,K,rpf', [(512, 128, 256), (1024, 256, 128), (512, 64, 128)])
+def test_bf16_gram_forms(hip_lib, M, K, rpf):
+    """G = a^T a slabs (both operands through the transposing LDS reads) and out = act(a) . P + rowconst with the dgrad epilogue."""
+    g = torch.Generator(device='cpu').manual_seed(M + K)
+    T = M // 128
+    x = torch.randn(M, K, generator=g).to(BF).to(DEV)
+    sc = (0.5 + torch.rand(K, generator=g)).to(DEV)
+    sh = (torch.randn(K, generator=g) * 0.2).to(DEV)
+    src = abi.ActSrc(fptr(x), K, 0, fptr(sc), fptr(sh), 1, fptr(None), 0, abi.BF16)
+    rps, tk, tn = C.c_int(0), C.c_int(0), C.c_int(0)
+    assert hip_lib.t3d_wgrad_plan(M, K, K, C.byref(rps), C.byref(tk), C.byref(tn)) == 0
+    slabs = torch.zeros(M // rps.value, K, K, device=DEV)
+    ga = abi.PointMlpGramArgs(src, fptr(slabs), M, K, rpf, rps.value)
+    assert hip_lib.t3d_pointmlp_gram(C.byref(ga), stream()) == 0
+    a = rb(torch.relu(x.double() * sc.double() + sh.double()))
+    G = a.t() @ a
+    torch.cuda.synchronize()
+    assert float((slabs.double().sum(0) - G).abs().max()) < 2e-5 * float(G.abs().max())
+    P = (torch.randn(K, K, generator=g) / np.sqrt(K)).to(DEV)
+    rc = torch.randn(K, generator=g).to(DEV) * 0.1
+    prev_y = torch.randn(M, K, generator=g).to(BF).to(DEV)
+    out = torch.zeros(M, K, dtype=BF, device=DEV)
+    ps1, ps2 = torch.zeros(T, K, device=DEV), torch.zeros(T, K, device=DEV)
+    d = abi.PointMlpDgradGramArgs()
+    d.a, d.p, d.rowconst = src, fptr(P), fptr(rc)
+    d.prev_y, d.prev_scale, d.prev_shift, d.out, d.psum_dz, d.psum_dzy = fptr(prev_y), fptr(sc), fptr(sh), fptr(out), fptr(ps1), fptr(ps2)
+    d.M, d.K, d.rows_per_frustum, d.dtype = M, K, rpf, abi.BF16
+    assert hip_lib.t3d_pointmlp_dgrad_gram(C.byref(d), stream()) == 0
+    torch.cuda.synchronize()
+    ref = a @ rb(P) + rc.double()
+    ref = torch.where(prev_y.double() * sc.double() + sh.double() > 0, ref, torch.zeros_like(ref))
+    close_bf16(out, ref, 'dX gram', opmax=float(a.abs().max() * P.abs().max()))

@@ -20,23 +20,29 @@ def main():
     lib = abi.load(os.environ.get('T3D_LIB', 'tools/libt3d_trace.so'))
     lib.t3d_set_trace.argtypes = [C.c_void_p]
     M, rpf = int(os.environ.get('T3D_M', '32768')), 1024
+    bf16 = os.environ.get('T3D_DTYPE', 'f32') == 'bf16'      # the T3D_BF16 path: bf16 input / weights / output
     T = M // 128
     dev = 'cuda'
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     for K, N, pooled in SHAPES:
         x = torch.randn(M, K, device=dev)
+        if bf16:
+            x = x.to(torch.bfloat16)
         sc, sh = torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev) * 0.1
         w = torch.randn(K, N, device=dev) / K ** 0.5
         y = torch.randn(M, N, device=dev)
+        if bf16:
+            w, y = w.to(torch.bfloat16), y.to(torch.bfloat16)
         p1, p2 = torch.zeros(T, N, device=dev), torch.zeros(T, N, device=dev)
         pm = [torch.zeros(T, N, device=dev) for _ in range(2)] + [torch.zeros(T, N, dtype=torch.int32, device=dev) for _ in range(2)]
         a = abi.PointMlpFwdArgs()
-        a.a = abi.ActSrc(fptr(x), K, 0, fptr(sc), fptr(sh), 1, fptr(None), 0)
+        a.a = abi.ActSrc(fptr(x), K, 0, fptr(sc), fptr(sh), 1, fptr(None), 0, abi.BF16 if bf16 else abi.F32)
+        a.dtype = abi.BF16 if bf16 else abi.F32
         a.w, a.y, a.psum, a.psumsq = fptr(w), fptr(y), fptr(p1), fptr(p2)
         if pooled:
             a.pmax, a.pmin, a.pamax, a.pamin = fptr(pm[0]), fptr(pm[1]), iptr(pm[2]), iptr(pm[3])
         a.M, a.K, a.N, a.rows_per_frustum = M, K, N, rpf
-        nblk = 8192
+        nblk = max(8192, (M // 128) * (N // 64))
         trace = torch.zeros(nblk * 4, dtype=torch.int64, device=dev)
         os.environ['T3D_FWD_POOL'] = '0'
         for _ in range(3):

@@ -16,6 +16,7 @@
 
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 #include <unordered_map>
 
 namespace {
@@ -79,12 +80,14 @@ struct ActLoader {
   int rpf;   // rows per frustum
   struct Raw { typename Elem<XT>::V4 x; };
   struct Coef { float4 sc, sh; };
+  // a bf16 source is a layer output: K is a multiple of the 64-deep k-tile (launcher-checked), so no column is clamped or masked
+  static constexpr bool EXACT = Elem<XT>::BF16;
   __device__ __forceinline__ Coef fetch_coef(int col) const {
     Coef c;
     c.sc = make_float4(1.f, 1.f, 1.f, 1.f);
     c.sh = f4zero();
     if (s.scale != nullptr) {                 // uniform; scale/shift hold >= roundup4(K) floats (host contract)
-      const int cc = min(col, ((K + 3) & ~3) - 4);
+      const int cc = EXACT ? col : min(col, ((K + 3) & ~3) - 4);
       c.sc = *reinterpret_cast<const float4*>(s.scale + cc);
       c.sh = *reinterpret_cast<const float4*>(s.shift + cc);
     }
@@ -92,7 +95,7 @@ struct ActLoader {
   }
   __device__ __forceinline__ Raw fetch(int row, int col) const {
     Raw r;
-    const int cc = min(col, ((K + 3) & ~3) - 4);
+    const int cc = EXACT ? col : min(col, ((K + 3) & ~3) - 4);
     r.x = Elem<XT>::ld4(s.x, (size_t)row * s.ldx + s.coff + cc);
     return r;
   }
@@ -110,8 +113,10 @@ struct ActLoader {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] -= s.sub[(size_t)b * s.sub_ld + min(col + e, K - 1)];
     }
+    if (!EXACT) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = (col + e < K) ? v[e] : 0.f;
+      for (int e = 0; e < 4; ++e) v[e] = (col + e < K) ? v[e] : 0.f;
+    }
     return make_float4(v[0], v[1], v[2], v[3]);
   }
 };
@@ -152,26 +157,32 @@ struct DyLoader {      // N % 32 == 0: every tile column is valid
   }
 };
 
-template <class WT = float>      // WT: element type of the matrix (bf16 path: the optimiser's bf16 copy of the weights)
+// WT: element type of the matrix (bf16 path: the optimiser's bf16 copy of the weights).  EXACT: every tile lies inside the matrix
+// (no clamped address, no mask); a bf16 EXACT tile is copied into the LDS image as it is (PASS_BF16).
+template <class WT = float, bool EXACT_ = false>
 struct WLoaderT {
   const float* w;
   int ld;
   int rows, cols;   // valid extent; cols % 4 == 0
+  static constexpr bool PASS_BF16 = EXACT_ && Elem<WT>::BF16;
   struct Raw { typename Elem<WT>::V4 x; };
   struct Coef {};
   __device__ __forceinline__ Coef fetch_coef(int) const { return Coef(); }
   __device__ __forceinline__ Raw fetch(int row, int col) const {
     Raw r;
-    r.x = Elem<WT>::ld4(w, (size_t)min(row, rows - 1) * ld + min(col, cols - 4));
+    if (EXACT_) r.x = Elem<WT>::ld4(w, (size_t)row * ld + col);
+    else r.x = Elem<WT>::ld4(w, (size_t)min(row, rows - 1) * ld + min(col, cols - 4));
     return r;
   }
   __device__ __forceinline__ float4 xform(const Raw& r, const Coef&, int row, int col) const {
-    const bool ok = row < rows && col < cols;      // masked AFTER the MFMA phase, never right behind the load
+    const bool ok = EXACT_ || (row < rows && col < cols);      // masked AFTER the MFMA phase, never right behind the load
     const float4 x = Elem<WT>::widen(r.x);
     return make_float4(ok ? x.x : 0.f, ok ? x.y : 0.f, ok ? x.z : 0.f, ok ? x.w : 0.f);
   }
 };
 typedef WLoaderT<float> WLoader;
+template <class L> struct PassBf16 { static constexpr bool value = false; };
+template <class WT, bool E> struct PassBf16<WLoaderT<WT, E>> { static constexpr bool value = WLoaderT<WT, E>::PASS_BF16; };
 
 // ---------------------------------------------------------------------------------------------
 // staging of one [DIM x BK] operand tile through registers into LDS
@@ -474,10 +485,15 @@ struct StagerH {
   template <int S>
   __device__ __forceinline__ void store_piece(const L& l, bf16_t* tile, int tid, int q) {
     int li, ri; coords(tid, q, li, ri);
-    const typename L::Coef& c = coef[TYPE_R ? S : 0];
-    const float4 v = TYPE_R ? l.xform(raw[S][q], c, lane0 + li, red0[S] + ri) : l.xform(raw[S][q], c, red0[S] + ri, lane0 + li);
-    const bf16x4 h = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
-    *reinterpret_cast<bf16x4*>(tile + (TYPE_R ? li * LDRH + ri : ri * LDC + li)) = h;
+    bf16_t* dst = tile + (TYPE_R ? li * LDRH + ri : ri * LDC + li);
+    if constexpr (PassBf16<L>::value) {       // bf16 weights inside the matrix: no arithmetic at all between the load and the LDS store
+      *reinterpret_cast<bf16x4*>(dst) = raw[S][q].x;
+    } else {
+      const typename L::Coef& c = coef[TYPE_R ? S : 0];
+      const float4 v = TYPE_R ? l.xform(raw[S][q], c, lane0 + li, red0[S] + ri) : l.xform(raw[S][q], c, red0[S] + ri, lane0 + li);
+      const bf16x4 h = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
+      *reinterpret_cast<bf16x4*>(dst) = h;
+    }
   }
   template <int S>
   __device__ __forceinline__ void store(const L& l, bf16_t* tile, int tid) {
@@ -499,9 +515,7 @@ __device__ __forceinline__ bf16x8 frag_h(const bf16_t* img, int c0, int st, int 
     const bf16_t* base = img + (k0 + ((lane & 15) >> 2)) * LDC + c0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + 4 * LDC));
-    typedef short s16x8 __attribute__((ext_vector_type(8)));
-    const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8, both);
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
   }
 }
 
@@ -542,8 +556,7 @@ __device__ __forceinline__ void gemm_mainloop_h(SA& sa, SB& sb, const LA& la, co
                                                 int red_end, int a0, int b0, f32x16 (&acc)[TM][TN], int tid) {
   bf16_t* smem = reinterpret_cast<bf16_t*>(smem_f);
   constexpr int STAGE = SA::LDS_ELEMS + SB::LDS_ELEMS;
-  constexpr int ST = BKH / 16, SH_ = ST / 2;
-  constexpr int PIECES = SA::NV + SB::NV, PER = (PIECES + (ST - SH_) - 1) / (ST - SH_);
+  constexpr int ST = BKH / 16;
   const int lane = tid & 63;
   auto nofill = [](int) {};
   sa.template fetch<0>(la, red_begin, tid);
@@ -558,20 +571,17 @@ __device__ __forceinline__ void gemm_mainloop_h(SA& sa, SB& sb, const LA& la, co
     const bf16_t* Bs = As + SA::LDS_ELEMS;
     bf16_t* An = smem + (cur ^ 1) * STAGE;
     bf16_t* Bn = An + SA::LDS_ELEMS;
-    mma_steps_h<TM, TN, AR, DIMA, BR, DIMB, 0, SH_>(As, Bs, a0, b0, acc, lane, nofill);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_steps_h<TM, TN, AR, DIMA, BR, DIMB, SH_, ST>(As, Bs, a0, b0, acc, lane, [&](int step) {
-#pragma unroll
-      for (int j = 0; j < PER; ++j) {
-        const int pc = step * PER + j;
-        if (pc < SA::NV) sa.template store_piece<0>(la, An, tid, pc);
-        else if (pc < PIECES) sb.template store_piece<0>(lb, Bn, tid, pc - SA::NV);
-      }
-    });
+    // Tile t+1 (loaded during the whole of iteration t-1) goes into the other stage FIRST and its registers are refilled with
+    // the loads of tile t+2 right away: a load has a full iteration to land (HBM under load: > 2 us), not half of one.  The
+    // staging VALU of this wave then overlaps the MFMAs of the SIMD's other wave (two workgroups per CU), its own MFMAs follow.
+    sa.template store<0>(la, An, tid);
+    sb.template store<0>(lb, Bn, tid);
     __builtin_amdgcn_sched_barrier(0);
     const int nxt = min(red + 2 * BKH, red_end - BKH);      // clamp instead of branching: the tile past the end re-reads the last
     sa.template fetch<0>(la, nxt, tid);
     sb.template fetch<0>(lb, nxt, tid);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_steps_h<TM, TN, AR, DIMA, BR, DIMB, 0, ST>(As, Bs, a0, b0, acc, lane, nofill);
     __syncthreads();
     cur ^= 1;
   }
@@ -587,13 +597,15 @@ __device__ __forceinline__ void gemm_mainloop_h(SA& sa, SB& sb, const LA& la, co
 struct PathF32 {
   typedef float T;
   typedef WLoaderT<float> WL;            // loader of the layer's weight matrix
+  typedef WLoaderT<float> WLX;           // ... when every tile lies inside the matrix (the fp32 path keeps its one loader)
   static constexpr bool BF16 = false;
   static constexpr int RED = BK;         // reduction depth of an LDS stage
   template <int DIM, bool TYPE_R, class L, int PF> using Stg = Stager<DIM, TYPE_R, L, PF>;
 };
 struct PathBF16 {
   typedef bf16_t T;
-  typedef WLoaderT<bf16_t> WL;           // `w` points at the bf16 copy of the weights (t3d_adam_tf_step's params_bf16)
+  typedef WLoaderT<bf16_t> WL;           // `w` points at the bf16 copy of the weights (t3d_cast_bf16)
+  typedef WLoaderT<bf16_t, true> WLX;
   static constexpr bool BF16 = true;
   static constexpr int RED = BKH;
   template <int DIM, bool TYPE_R, class L, int PF> using Stg = StagerH<DIM, TYPE_R, L>;
@@ -615,7 +627,7 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd(const t3d_pointm
   using LA = ActLoader<HAS_SUB, XT>;
   using YT = typename PR::T;
   constexpr int PF = BN == 64 ? T3D_PF_NARROW : T3D_PF_WIDE;
-  using WL = typename PR::WL;
+  using WL = std::conditional_t<LA::EXACT, typename PR::WLX, typename PR::WL>;      // K % 64 == 0: every weight tile is whole
   using SA = typename PR::template Stg<BM, true, LA, PF>;
   using SB = typename PR::template Stg<BN, false, WL, PF>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -660,6 +672,8 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd(const t3d_pointm
   const bool pool = p.pmax != nullptr;
   const bool store_y = p.y != nullptr;      // Gram-form backward: statistics and pool partials only
   float* red = smem;   // [2][BN] x 6 quantities
+  constexpr int YLD = BN + 8;                                       // bf16 output tile [128][BN + 8] behind `red`
+  bf16_t* ytile = reinterpret_cast<bf16_t*>(smem + 12 * BN);
   float csum[TN], csq[TN], cmax[TN], cmin[TN];
   int amax[TN], amin[TN];
   // keep flags of this lane's 32 rows, loaded once (they were re-read per column group inside the compare chain)
@@ -688,7 +702,13 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd(const t3d_pointm
       for (int r = 0; r < 16; ++r) {
         // bf16 storage: statistics (and the pool's candidates) of the value as it is stored, i.e. as every reader sees it
         const float v = store_y ? Elem<YT>::rnd(acc[tm][tn][r] + add) : acc[tm][tn][r] + add;
-        if (store_y) Elem<YT>::st1(p.y, off0 + (unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)p.N, v);
+        if constexpr (Elem<YT>::BF16) {
+          // bf16: the tile goes through LDS (the stages are free now) and leaves as 16-byte row-contiguous stores below -- 64
+          // two-byte global stores per thread were half of a workgroup's lifetime on the narrow layers (tools/trace_blocks.py)
+          if (store_y) ytile[(wm * 64 + 4 * h + tm * 32 + (r & 3) + 8 * (r >> 2)) * YLD + wn * (BN / 2) + tn * 32 + l31] = (bf16_t)v;
+        } else {
+          acc[tm][tn][r] = v;           // stored after the last barrier (below)
+        }
         s += v;
         ss = fmaf(v, v, ss);
         if (pool) {                                  // selects: same results as the branches they replace, no exec-mask juggling
@@ -744,6 +764,30 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd(const t3d_pointm
       p.pmax[o] = mx; p.pmin[o] = mn; p.pamax[o] = ax; p.pamin[o] = an;
     }
   }
+  // The output tile is stored LAST: a __syncthreads() behind a global store waits for the store to complete, so with the stores
+  // in front of the two barriers of the statistics exchange every workgroup sat out two write round trips (4-11 us per
+  // workgroup, tools/trace_blocks.py); issued here they drain while the CU already runs the next workgroup.
+  if (store_y) {
+    if constexpr (Elem<YT>::BF16) {
+      constexpr int CPR = BN / 8;                                   // 16-byte chunks per tile row
+      bf16_t* yg = reinterpret_cast<bf16_t*>(p.y);
+#pragma unroll
+      for (int i = 0; i < 128 * CPR / NT; ++i) {
+        const int c = tid + NT * i, row = c / CPR, ch = c % CPR;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(ytile + row * YLD + ch * 8);
+        *reinterpret_cast<bf16x8*>(yg + (size_t)(row0 + row) * p.N + col0 + ch * 8) = v;
+      }
+    } else {
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const unsigned off0 = (unsigned)(row0 + wm * 64 + 4 * h) * (unsigned)p.N + (unsigned)(col0 + wn * (BN / 2) + tn * 32 + l31);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) p.y[off0 + (unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)p.N] = acc[tm][tn][r];
+      }
+    }
+  }
   T3D_TRACE_MARK(2);
 }
 
@@ -789,6 +833,24 @@ __device__ __forceinline__ void dgrad_epilogue_body(const DgradEpilogue& p, f32x
         live |= (unsigned)((f.x != 0) | ((f.y != 0) << 1) | ((f.z != 0) << 2) | ((f.w != 0) << 3)) << (tm * 16 + 4 * j);
       }
   }
+  // bf16: the producer's raw output (and a dense add_in) come in and the gradient goes out through LDS tiles, moved with 16-byte
+  // row-contiguous accesses -- 64 two-byte gathers and 64 two-byte stores per thread were most of a workgroup's epilogue.
+  // `red` holds 2 x 2 x BN floats; the tiles sit behind the forward epilogue's 12 x BN floats (one allocation rule for both).
+  constexpr int YLD = BN + 8, CPR = BN / 8;
+  bf16_t* ptile = reinterpret_cast<bf16_t*>(red + 12 * BN);         // prev_y in, out (same element, same thread) out
+  bf16_t* atile = ptile + 128 * YLD;                                // dense add_in
+  if constexpr (Elem<T>::BF16) {
+    const bf16_t* pg = reinterpret_cast<const bf16_t*>(p.prev_y);
+    const bf16_t* ag = reinterpret_cast<const bf16_t*>(p.add_in);
+#pragma unroll
+    for (int i = 0; i < 128 * CPR / NT; ++i) {
+      const int c = tid + NT * i, row = c / CPR, ch = c % CPR;
+      const size_t go = (size_t)(row0 + row) * K + col0 + ch * 8;
+      if (MASK) *reinterpret_cast<bf16x8*>(ptile + row * YLD + ch * 8) = *reinterpret_cast<const bf16x8*>(pg + go);
+      if (ADD == 1) *reinterpret_cast<bf16x8*>(atile + row * YLD + ch * 8) = *reinterpret_cast<const bf16x8*>(ag + go);
+    }
+    __syncthreads();
+  }
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int col = col0 + wn * (BN / 2) + tn * 32 + l31;
@@ -796,6 +858,26 @@ __device__ __forceinline__ void dgrad_epilogue_body(const DgradEpilogue& p, f32x
     const float cc = p.colconst ? p.colconst[col] : 0.f;
     const unsigned off0 = (unsigned)(row0 + wm * 64 + 4 * h) * K + (unsigned)col;
     float s1 = 0.f, s2 = 0.f;
+    if constexpr (Elem<T>::BF16) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int lr = wm * 64 + 4 * h + tm * 32 + (r & 3) + 8 * (r >> 2), li = lr * YLD + wn * (BN / 2) + tn * 32 + l31;
+          const float ypv = MASK ? (float)ptile[li] : 0.f;
+          float ad = 0.f;
+          if (ADD == 1) ad = (float)atile[li];
+          if (ADD == 2) ad = ((live >> (tm * 16 + r)) & 1u) ? p.add_in[off0 + (unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) * K] : 0.f;
+          float v = Elem<T>::rnd(acc[tm][tn][r] + cc + ad);
+          if (MASK) {
+            if (!(fmaf(ypv, psc, psh) > 0.f)) v = 0.f;
+            s1 += v;
+            s2 = fmaf(v, ypv, s2);
+          }
+          ptile[li] = (bf16_t)v;
+        }
+      }
+    } else {
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       constexpr int EB = 8;
@@ -824,16 +906,21 @@ __device__ __forceinline__ void dgrad_epilogue_body(const DgradEpilogue& p, f32x
             s1 += v;
             s2 = fmaf(v, yp[e], s2);
           }
-          Elem<T>::st1(p.out, o, v);
+          acc[tm][tn][r] = v;           // stored after the last barrier (below)
         }
       }
+    }
     }
     s1 += __shfl_xor(s1, 32, 64);
     s2 += __shfl_xor(s2, 32, 64);
     cs1[tn] = s1; cs2[tn] = s2;
   }
+  // The global stores of the gradient tile are issued LAST: a __syncthreads() behind a global store waits until that store has
+  // completed (workgroup-scope release), i.e. the whole workgroup sat out a write round trip at each of the two barriers of the
+  // partial-sum exchange below (4-5 us of a 10-25 us workgroup lifetime, tools/trace_blocks.py); behind the last barrier the
+  // stores drain while the CU already runs the next workgroup.
+  if (stats || Elem<T>::BF16) __syncthreads();      // bf16: the LDS tile is complete
   if (stats) {
-    __syncthreads();
     if (h == 0) {
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
@@ -847,6 +934,23 @@ __device__ __forceinline__ void dgrad_epilogue_body(const DgradEpilogue& p, f32x
       const size_t o = (size_t)tile_m * p.K + col0 + tid;
       p.psum_dz[o] = red[(0 * 2 + 0) * BN + tid] + red[(0 * 2 + 1) * BN + tid];
       p.psum_dzy[o] = red[(1 * 2 + 0) * BN + tid] + red[(1 * 2 + 1) * BN + tid];
+    }
+  }
+  if constexpr (Elem<T>::BF16) {
+    bf16_t* og = reinterpret_cast<bf16_t*>(p.out);
+#pragma unroll
+    for (int i = 0; i < 128 * CPR / NT; ++i) {
+      const int c = tid + NT * i, row = c / CPR, ch = c % CPR;
+      *reinterpret_cast<bf16x8*>(og + (size_t)(row0 + row) * K + col0 + ch * 8) = *reinterpret_cast<const bf16x8*>(ptile + row * YLD + ch * 8);
+    }
+  } else {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const unsigned off0 = (unsigned)(row0 + wm * 64 + 4 * h) * K + (unsigned)(col0 + wn * (BN / 2) + tn * 32 + l31);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p.out[off0 + (unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) * K] = acc[tm][tn][r];
     }
   }
 }
@@ -871,7 +975,7 @@ __device__ __forceinline__ void dgrad_body(const t3d_pointmlp_dgrad_args& p, flo
   constexpr int BM = 128, TM = 2, TN = BN / 64;
   constexpr int PF = BN == 64 ? T3D_PF_NARROW : T3D_PF_WIDE;
   using LA = DyLoader<POOLED, typename PR::T>;
-  using WL = typename PR::WL;
+  using WL = typename PR::WLX;            // bf16: K % 64 == 0 and N % 64 == 0 (launcher-checked), every tile is whole
   using SA = typename PR::template Stg<BM, true, LA, PF>;
   using SB = typename PR::template Stg<BN, true, WL, PF>;
 
@@ -1355,9 +1459,13 @@ constexpr size_t lds_dgrad(int bn) { return 2 * (size_t)(128 * LDR + bn * LDR) *
 constexpr size_t lds_wgrad(int bmk, int bn) { return 2 * (size_t)BK * (bmk + bn) * sizeof(float); }
 // bf16 path: two stages of R images [dim][BKH + 8] / C images [BKH][dim + 32] of 2-byte elements; never less than the epilogues'
 // cross-wave scratch (6 x 2 x BN floats)
-constexpr size_t lds_min(size_t b, int bn) { return b > (size_t)12 * bn * sizeof(float) ? b : (size_t)12 * bn * sizeof(float); }
+constexpr size_t lds_epi(int bn) { return (size_t)12 * bn * sizeof(float) + (size_t)128 * (bn + 8) * 2; }      // red + the bf16 output tile
+constexpr size_t lds_min(size_t b, int bn) { return b > lds_epi(bn) ? b : lds_epi(bn); }
 constexpr size_t lds_fwd_h(int bn) { return lds_min(2 * (size_t)(128 * LDRH + BKH * (bn + 32)) * 2, bn); }
-constexpr size_t lds_dgrad_h(int bn) { return lds_min(2 * (size_t)(128 * LDRH + bn * LDRH) * 2, bn); }
+constexpr size_t lds_dgram_h(int bn) { return lds_fwd_h(bn) > (size_t)12 * bn * 4 + 2 * (size_t)128 * (bn + 8) * 2 ? lds_fwd_h(bn) : (size_t)12 * bn * 4 + 2 * (size_t)128 * (bn + 8) * 2; }
+constexpr size_t lds_epi2(int bn) { return (size_t)12 * bn * sizeof(float) + 2 * (size_t)128 * (bn + 8) * 2; }  // red + prev_y/out tile + add_in tile
+constexpr size_t lds_max(size_t a, size_t b) { return a > b ? a : b; }
+constexpr size_t lds_dgrad_h(int bn) { return lds_max(2 * (size_t)(128 * LDRH + bn * LDRH) * 2, lds_epi2(bn)); }
 constexpr size_t lds_wgrad_h(int bmk, int bn) { return 2 * (size_t)BKH * (bmk + 32 + bn + 32) * 2; }
 
 bool dtype_ok(int dt) { return dt == T3D_F32 || dt == T3D_BF16; }
@@ -1387,6 +1495,7 @@ extern "C" int t3d_pointmlp_fwd(const t3d_pointmlp_fwd_args* a, t3d_stream_t str
     // bf16 storage + bf16 MFMA (configs[4]); the input is fp32 for the raw point cloud / Box-PC representation, bf16 for a layer output
     const bool wide = T3D_FORCE_TILE != 64 && a->N % 128 == 0 && (T3D_FORCE_TILE == 128 || (long)tiles_m * (a->N / 128) >= 512);
     const bool xh = a->a.dtype == T3D_BF16;
+    if (xh && a->K % BKH) return T3D_ERR_SHAPE;      // a bf16 input is a layer output: whole 64-deep k-tiles (the loaders do not mask)
     const dim3 grid(tiles_m * (a->N / (wide ? 128 : 64)));
     const size_t lds = wide ? lds_fwd_h(128) : lds_fwd_h(64);
 #define T3D_FWD_H(BN_)                                                                                          \
@@ -1516,6 +1625,7 @@ static int check_wgrad(const t3d_pointmlp_wgrad_args* a) {
       a->rows_per_frustum % red || a->M % a->rows_per_frustum)
     return T3D_ERR_SHAPE;
   if (a->dy.dtype == T3D_F32 && a->a.dtype != T3D_F32) return T3D_ERR_ARG;
+  if (a->a.dtype == T3D_BF16 && a->K % 64) return T3D_ERR_SHAPE;      // bf16 input: whole tiles (the loaders do not mask)
   return T3D_OK;
 }
 // tile choice: the plan's tile if the caller used t3d_wgrad_plan's split, else by shape
@@ -1589,8 +1699,8 @@ extern "C" int t3d_pointmlp_dgrad_gram(const t3d_pointmlp_dgrad_gram_args* a, t3
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int tiles_m = a->M / 128;
   if (a->dtype == T3D_BF16) {
-    if (dgrad_gram_wide(a)) launch_lds(k_pointmlp_dgrad_gram<128, PathBF16>, dim3(tiles_m * (a->K / 128)), lds_fwd_h(128), s, *a);
-    else launch_lds(k_pointmlp_dgrad_gram<64, PathBF16>, dim3(tiles_m * (a->K / 64)), lds_fwd_h(64), s, *a);
+    if (dgrad_gram_wide(a)) launch_lds(k_pointmlp_dgrad_gram<128, PathBF16>, dim3(tiles_m * (a->K / 128)), lds_dgram_h(128), s, *a);
+    else launch_lds(k_pointmlp_dgrad_gram<64, PathBF16>, dim3(tiles_m * (a->K / 64)), lds_dgram_h(64), s, *a);
   } else if (dgrad_gram_wide(a))
     launch_lds(k_pointmlp_dgrad_gram<128>, dim3(tiles_m * (a->K / 128)), lds_fwd(128), s, *a);
   else
@@ -1722,7 +1832,7 @@ extern "C" int t3d_pool_bwd_stage2(const t3d_pool_wgrad_finish_args* f, const t3
   const dim3 grid(n_finish + n_d);
   const bool bf16 = d->dtype == T3D_BF16;
   if (f->a.dtype != d->a.dtype) return T3D_ERR_ARG;
-  size_t lds = bf16 ? (wide ? lds_fwd_h(128) : lds_fwd_h(64)) : (wide ? lds_fwd(128) : lds_fwd(64));
+  size_t lds = bf16 ? (wide ? lds_dgram_h(128) : lds_dgram_h(64)) : (wide ? lds_fwd(128) : lds_fwd(64));
   if (finish_lds(f->K) > lds) lds = finish_lds(f->K);
 #define T3D_ST2(BN_, PR_)                                                              \
   do {                                                                                 \
