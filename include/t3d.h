@@ -354,7 +354,8 @@ int t3d_pool_bwd_stage2(const t3d_pool_wgrad_finish_args* finish, const t3d_poin
 typedef struct {
   const float* in;  int ld_in;  int K;
   const float* in2; int ld_in2; int K2;      /* optional concat (one_hot_vec), K2 = 0 if none */
-  const float* w;                            /* [K+K2, N] */
+  const float* w;                            /* [K+K2, N]; NULL = identity (K == N, K2 == 0): y = in, i.e. a standalone
+                                              * tf_util.batch_norm_for_fc (tf_util.py:1666-1677) / tf_util.dropout (1720-1741) node */
   const float* bias;                         /* [N] or NULL */
   const float* gamma; const float* beta;     /* NULL -> no batch-norm */
   float* moving_mean; float* moving_var;
@@ -781,6 +782,20 @@ int t3d_schedule_step(float* hyper, const t3d_schedule* s, t3d_stream_t stream);
 int t3d_adam_tf_step(float* params, const float* grads, float* m, float* v, int64_t n,
                      const float* hyper, float beta1, float beta2, float eps, float grad_scale,
                      t3d_stream_t stream);
+
+/* Standalone tf_util.dropout on a per-point tensor (tf_util.py:1720-1741; the reference's one call site, conv9 -> dp1 -> conv10 of
+ * v1_inst_seg, semisup_models.py:131, is fused into t3d_seg_head on the hot path): materialises
+ *   out[m,k] = act(a)[m,k] * mask[m,k] / keep_prob          (mask == NULL or keep_prob >= 1: out = act(a))
+ * from the lazy activation operand, fp32 [M,K] row-major. */
+typedef struct {
+  t3d_act_src a;
+  const float* mask;       /* [M,K] 0/1 keep flags or NULL */
+  float keep_prob;
+  float* out;              /* [M,K] */
+  int M, K;
+  int rows_per_frustum;
+} t3d_act_dropout_args;
+int t3d_act_dropout(const t3d_act_dropout_args* args, t3d_stream_t stream);
 
 /* dst[i] = bf16(src[i]): the copy of the weights the T3D_BF16 GEMMs read (`w` of t3d_pointmlp_fwd / _dgrad / _bwd then points into
  * it); run once per step after the optimiser.  The fp32 master copy stays what Adam updates and what checkpoints hold. */

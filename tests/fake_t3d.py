@@ -695,7 +695,7 @@ class FakeLib:
         p = _struct(a)
         B, N = p.B, p.N
         x = self._fc_in(p)
-        y = x @ arr(p.w, p.K + p.K2, N).astype(np.float64)
+        y = x @ arr(p.w, p.K + p.K2, N).astype(np.float64) if p.w else x.copy()      # w == NULL: identity (standalone BN / dropout)
         if p.bias:
             y = y + arr(p.bias, N)
         y = y.astype(np.float32).astype(np.float64)
@@ -723,6 +723,14 @@ class FakeLib:
         if p.add_in:
             z[:, :p.add_n] += arr(p.add_in, B, p.ld_add)[:, :p.add_n]
         arr(p.out, B, p.ld_out)[:, :N] = z
+        return 0
+
+    def t3d_act_dropout(self, a, stream):
+        p = _struct(a)
+        v = _act(p.a, p.M, p.K, p.rows_per_frustum)
+        if p.mask:
+            v = v * arr(p.mask, p.M, p.K) / (p.keep_prob if p.keep_prob < 1.0 else 1.0)
+        arr(p.out, p.M, p.K)[:] = v
         return 0
 
     def t3d_fc_bwd(self, a, stream):

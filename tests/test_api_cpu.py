@@ -13,6 +13,12 @@ from transferable3d_amd.engine import Runtime
 from transferable3d_amd.synthetic import make_batch
 
 
+def _runtime():
+    """CPU: the NumPy specification library.  tests/test_api_gpu.py re-runs this module's tests with the HIP library on the
+    MI355X by replacing this factory."""
+    return Runtime(device='cpu', lib=FakeLib())
+
+
 def _flags(extra=()):
     return make_parser().parse_special_args(['--SEMI_MODEL', 'A', '--WEAK_WEIGHT_REPROJECTION', '0',
                                              '--WEAK_WEIGHT_SURFACE', '0'] + list(extra))
@@ -22,7 +28,7 @@ def test_reference_call_sequence_runs_a_training_step():
     B, N, C = 4, 128, 4
     FLAGS = _flags()
     batch = make_batch(B, N, C, seed=8, dropout_scopes={'inst_seg/dp1': ((B, N, 128), 0.5)})
-    with api.Graph(rt=Runtime(device='cpu', lib=FakeLib()), seed=3).as_default() as g:
+    with api.Graph(rt=_runtime(), seed=3).as_default() as g:
         pls = MODEL.placeholder_inputs(B, N, C)
         pc_pl, bg_pc_pl, img_pl, one_hot_vec_pl, y_seg_pl, y_centers_pl, y_orient_cls_pl, y_orient_reg_pl, y_dims_cls_pl, \
             y_dims_reg_pl, R0_rect_pl, P_pl, Rtilt_pl, K_pl, rot_frust_pl, box2D_pl, img_dim_pl, is_data_2D_pl = pls
@@ -83,7 +89,7 @@ def test_forward_only_fetch_compiles_the_inference_plan():
     B, N, C = 2, 128, 4
     FLAGS = _flags()
     batch = make_batch(B, N, C, seed=9)
-    with api.Graph(rt=Runtime(device='cpu', lib=FakeLib()), seed=4).as_default() as g:
+    with api.Graph(rt=_runtime(), seed=4).as_default() as g:
         pls = MODEL.placeholder_inputs(B, N, C)
         pred, end_points = MODEL.get_semi_model(pls[0], pls[1], pls[2], pls[3], False, use_one_hot=False, c=FLAGS)
         sess = api.Session()
@@ -103,7 +109,7 @@ def test_unknown_semi_model_raises_like_the_reference():
     import pytest
     FLAGS = _flags()
     FLAGS.SEMI_MODEL = 'Z'
-    with api.Graph(rt=Runtime(device='cpu', lib=FakeLib())).as_default():
+    with api.Graph(rt=_runtime()).as_default():
         pls = MODEL.placeholder_inputs(2, 128, 4)
         with pytest.raises(Exception, match='Not implemented SEMI_MODEL'):
             MODEL.get_semi_model(pls[0], pls[1], pls[2], pls[3], True, False, c=FLAGS)
@@ -115,7 +121,7 @@ def test_boxpc_reference_call_sequence():
     B, N, C = 4, 256, 4
     FLAGS = make_parser().parse_special_args(['--BOX_PC_MASK_REPRESENTATION', 'A', '--BOXPC_WEIGHT_DELTA', '4'])
     batch = make_batch(B, N, C, seed=12, boxpc=True)
-    with api.Graph(rt=Runtime(device='cpu', lib=FakeLib()), seed=5).as_default() as g:
+    with api.Graph(rt=_runtime(), seed=5).as_default() as g:
         pls = BOXPC.placeholder_inputs(B, N, C)
         pc_pl, one_hot_vec_pl, y_seg_pl, x_center_pl, x_orient_cls_pl, x_orient_reg_pl, x_dims_cls_pl, x_dims_reg_pl, \
             y_box_iou_pl, y_center_delta_pl, y_dims_delta_pl, y_orient_delta_pl = pls
@@ -156,7 +162,7 @@ def test_stage_c_reference_call_sequence_with_var_list():
                                               '--WEAK_WEIGHT_REPROJECTION', '0', '--SEMI_MULTIPLIER_FOR_WEAK_LOSS', '0.05',
                                               '--SEMI_BOXPC_FIT_ONLY_ON_2D_CLS', '1', '--SEMI_WEIGHT_BOXPC_FIT_LOSS', '1'])
     batch = stage_c_batch(B, N, C, seed=3, n2d=2)
-    with api.Graph(rt=Runtime(device='cpu', lib=FakeLib()), seed=6).as_default() as g:
+    with api.Graph(rt=_runtime(), seed=6).as_default() as g:
         pls = MODEL.placeholder_inputs(B, N, C)
         pred, end_points = MODEL.get_semi_model(pls[0], pls[1], pls[2], pls[3], True, use_one_hot=True, c=FLAGS)
         end_points.update({'intraclsdims_train_classes': TRAIN_CLASSES})
@@ -203,7 +209,7 @@ def test_is_training_placeholder_selects_train_and_eval_schedules_of_one_graph()
     FLAGS = _flags()
     batch = make_batch(B, N, C, seed=8, dropout_scopes={'inst_seg/dp1': ((B, N, 128), 0.5)})
     held_out = make_batch(B, N, C, seed=9)
-    with api.Graph(rt=Runtime(device='cpu', lib=FakeLib()), seed=3).as_default() as g:
+    with api.Graph(rt=_runtime(), seed=3).as_default() as g:
         pls = MODEL.placeholder_inputs(B, N, C)
         pc_pl, bg_pc_pl, img_pl, one_hot_vec_pl, y_seg_pl, y_centers_pl, y_orient_cls_pl, y_orient_reg_pl, y_dims_cls_pl, \
             y_dims_reg_pl, R0_rect_pl, P_pl, Rtilt_pl, K_pl, rot_frust_pl, box2D_pl, img_dim_pl, is_data_2D_pl = pls
@@ -243,7 +249,7 @@ def test_inline_dropout_graph_rejects_an_explicit_mask():
     B, N, C = 4, 128, 4
     FLAGS = _flags()
     batch = make_batch(B, N, C, seed=8, dropout_scopes={'inst_seg/dp1': ((B, N, 128), 0.5)})
-    with api.Graph(rt=Runtime(device='cpu', lib=FakeLib()), seed=3, inline_dropout=True).as_default() as g:
+    with api.Graph(rt=_runtime(), seed=3, inline_dropout=True).as_default() as g:
         pls = MODEL.placeholder_inputs(B, N, C)
         pred, end_points = MODEL.get_semi_model(pls[0], pls[1], pls[2], pls[3], True, use_one_hot=False, norm_box2D=None, bn_decay=None, c=FLAGS)
         loss = MODEL.get_semi_loss(pred, tuple(pls[4:]), end_points, c=FLAGS)
@@ -255,3 +261,11 @@ def test_inline_dropout_graph_rejects_an_explicit_mask():
             sess.run([loss, train_op], feed_dict=dict(feed, **{'inst_seg/dp1': batch['dropout_masks']['inst_seg/dp1']}))
         l1, _ = sess.run([loss, train_op], feed_dict=feed)
         assert np.isfinite(l1) and 'inst_seg/dp1' not in g.engine.dropout_masks and len(sess.steps['train'].pre) == 1   # schedule only
+
+
+@pytest.mark.parametrize('is_training', [True, False])
+def test_operator_wrappers_called_one_by_one(is_training):
+    """tf_util.conv2d (bn / no bn / 2 output channels), batch_norm_for_conv2d, batch_norm_for_fc, dropout (per-point and [B,N]),
+    max_pool2d, fully_connected as separate nodes, against the oracle's restatements of the same ops."""
+    from op_surface_check import check_operator_surface
+    assert check_operator_surface(_runtime(), is_training)

@@ -173,6 +173,10 @@ class SegHeadArgs(C.Structure):
                 ('dtype', i32)]
 
 
+class ActDropoutArgs(C.Structure):
+    _fields_ = [('a', ActSrc), ('mask', F), ('keep_prob', f32), ('out', F), ('M', i32), ('K', i32), ('rows_per_frustum', i32)]
+
+
 class SegFinalizeArgs(C.Structure):
     _fields_ = [('part', F), ('dw_part', F), ('B', i32), ('tiles_per_frustum', i32), ('rows_per_frustum', i32),
                 ('K', i32), ('mask_xyz_mean', F), ('seg_loss', F), ('dw', F), ('dbias', F), ('n_correct', F)]
@@ -264,6 +268,7 @@ ENTRY_POINTS = {
     't3d_fc_dinput': [C.POINTER(FcDinputArgs), VP],
     't3d_seg_head': [C.POINTER(SegHeadArgs), VP],
     't3d_seg_finalize': [C.POINTER(SegFinalizeArgs), VP],
+    't3d_act_dropout': [C.POINTER(ActDropoutArgs), VP],
     't3d_strong_loss': [C.POINTER(StrongLossArgs), VP],
     't3d_boxpc_rep': [C.POINTER(BoxPcRepArgs), VP],
     't3d_boxpc_rep_bwd': [C.POINTER(BoxPcRepBwdArgs), VP],

@@ -211,6 +211,16 @@ class Session:
         if key in self.steps:
             return self.steps[key]
         from .engine import Plan
+        if g.assembly is None:
+            # operator-level graph (tf_util.conv2d / fully_connected / dropout / batch_norm_for_* called one by one): the launches
+            # were recorded into the engine's forward plan as the ops were built; a run = the dropout-mask generators + that plan
+            if 'ops' not in self.steps:
+                pre = Plan(e.rt)
+                e.emit_dropout_masks(pre, seed=self.dropout_seed)
+                if not e.finalized:
+                    e.finalize()
+                self.steps['ops'] = _Step(self, pre, e.fwd, None, None, False)
+            return self.steps['ops']
         # the training schedule reserves the weight-gradient slabs: it is compiled first, whatever is run first
         if not train and g.train_op is not None and not e.finalized:
             self._compile(True, True)
@@ -293,7 +303,7 @@ class _Step:
         from .step import TrainStep
         self.sess, self.pre, self.fwd, self.bwd, self.opt, self.train = sess, pre, fwd, bwd, opt, train
         e = sess.g.engine
-        self.impl = TrainStep(e, pre, fwd, bwd if train else None, opt if train else None, process_group=sess.pg,
+        self.impl = TrainStep(e, pre if (train or len(pre)) else None, fwd, bwd if train else None, opt if train else None, process_group=sess.pg,
                               use_hip_graph=sess.use_hip_graph, force_dist=sess.force_dist)
 
     @property

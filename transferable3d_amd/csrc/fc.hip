@@ -186,12 +186,20 @@ __global__ __launch_bounds__(NTH) void k_fc_fwd(const t3d_fc_fwd_args p) {
   const bool cok = c < p.N;
 
   FC_MARK(0);
-  f32x16 acc[RBT];
-  RowSrc src{p.in, p.ld_in, p.K, p.in2, p.ld_in2, p.K2, p.B};
-  wave_gemm<false, RBT>(acc, src, p.w, p.N, p.K + p.K2, c0, nvalid, wave, lane);
-  FC_MARK(1);
   float y[NVAL];
-  reduce_tiles<RBT>(acc, sm, y);
+  if (p.w != nullptr) {          // workgroup-uniform
+    f32x16 acc[RBT];
+    RowSrc src{p.in, p.ld_in, p.K, p.in2, p.ld_in2, p.K2, p.B};
+    wave_gemm<false, RBT>(acc, src, p.w, p.N, p.K + p.K2, c0, nvalid, wave, lane);
+    FC_MARK(1);
+    reduce_tiles<RBT>(acc, sm, y);
+  } else {                       // identity: a standalone batch-norm / dropout node on a [B,N] tensor
+#pragma unroll
+    for (int j = 0; j < NVAL; ++j) {
+      const int r = rg + RG * j;
+      y[j] = (r < p.B && cok) ? p.in[(size_t)r * p.ld_in + c] : 0.f;
+    }
+  }
   FC_MARK(2);
 
   const float bias = (cok && p.bias) ? p.bias[c] : 0.f;
@@ -447,7 +455,8 @@ size_t fc_lds_bytes(int B) {
 }  // namespace
 
 extern "C" int t3d_fc_fwd(const t3d_fc_fwd_args* a, t3d_stream_t stream) {
-  if (!a || !a->in || !a->w || !a->out || (a->K2 > 0 && !a->in2)) return T3D_ERR_ARG;
+  if (!a || !a->in || !a->out || (a->K2 > 0 && !a->in2)) return T3D_ERR_ARG;
+  if (!a->w && (a->K != a->N || a->K2 != 0)) return T3D_ERR_SHAPE;      // identity form
   if (a->gamma && (!a->beta || !a->moving_mean || !a->moving_var || !a->mean || !a->invstd || !a->y)) return T3D_ERR_ARG;
   if (a->gamma && a->is_training && !a->decay) return T3D_ERR_ARG;
   if (a->B <= 0 || a->B > 32 * MAXRB || a->N <= 0 || a->K <= 0) return T3D_ERR_SHAPE;

@@ -407,6 +407,35 @@ __global__ __launch_bounds__(1024) void k_strong_loss(const t3d_strong_loss_args
 
 }  // namespace
 
+namespace {
+// out[m,k] = act(a)[m,k] * mask / keep (t3d.h: standalone tf_util.dropout on a per-point tensor)
+__global__ __launch_bounds__(256) void k_act_dropout(const t3d_act_dropout_args p) {
+  const size_t n = (size_t)p.M * p.K;
+  const float inv_keep = (p.mask && p.keep_prob < 1.f) ? 1.0f / p.keep_prob : 1.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t m = i / p.K;
+    const int k = (int)(i - m * p.K);
+    float v = ld_elem(p.a.x, m * p.a.ldx + p.a.coff + k, p.a.dtype);
+    if (p.a.scale) v = fmaf(v, p.a.scale[k], p.a.shift[k]);
+    if (p.a.relu) v = fmaxf(v, 0.f);
+    if (p.a.sub) v -= p.a.sub[(m / p.rows_per_frustum) * p.a.sub_ld + k];
+    if (p.mask) v *= p.mask[i] * inv_keep;
+    p.out[i] = v;
+  }
+}
+}  // namespace
+
+extern "C" int t3d_act_dropout(const t3d_act_dropout_args* a, t3d_stream_t stream) {
+  if (!a || !a->a.x || !a->out || (a->a.scale && !a->a.shift)) return T3D_ERR_ARG;
+  if (a->M <= 0 || a->K <= 0 || a->rows_per_frustum <= 0 || a->keep_prob <= 0.f) return T3D_ERR_SHAPE;
+  const size_t n = (size_t)a->M * a->K;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  T3D_LAUNCH(k_act_dropout, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
 extern "C" int t3d_seg_head(const t3d_seg_head_args* a, t3d_stream_t stream) {
   if (!a || !a->y || !a->scale || !a->shift || !a->w || !a->bias || !a->pc || !a->logits || !a->mask || !a->part)
     return T3D_ERR_ARG;

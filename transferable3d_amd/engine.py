@@ -341,8 +341,13 @@ def wgrad_rows_per_split(lib, M, K, N):
 class PointLayer:
     """tf_util.conv2d 1x1 (+ batch_norm + ReLU) over M = B*N point rows (tf_util.py:1258-1323)."""
 
-    def __init__(self, g, scope, K, N, w=None, bias=None, kernel_1xD=False, w_name=None, w_row0=0, pool=False, gram=None):
+    def __init__(self, g, scope, K, N, w=None, bias=None, kernel_1xD=False, w_name=None, w_row0=0, pool=False, gram=None, bn=True,
+                 n_alloc=None):
+        """bn=False: tf_util.conv2d(bn=False) -- no batch-norm variables, the forward emits the GEMM only (forward-only surface:
+        the hot path has no such layer except conv10, which lives in the segmentation head).  n_alloc: padded column count of the
+        GEMM (N < 64 outputs: the weights are copied into a zero-padded [K, n_alloc] matrix in front of the launch)."""
         self.g, self.scope, self.K, self.N = g, scope, K, N
+        self.bn = bn
         # pooled layers: Gram-form backward (t3d.h K11e) -- the [M,N] output is never stored
         self.gram = (pool and os.environ.get('T3D_POOL_GRAM', '1') != '0') if gram is None else (gram and pool)
         self.w_name, self.w_row0 = w_name, w_row0
@@ -361,10 +366,16 @@ class PointLayer:
         self.w_mm = vs.bf16_view(w) if self.dt == abi.BF16 else w
         assert not (self.dt == abi.BF16 and pool and not self.gram), "bf16: max-pooled layers take the Gram-form backward"
         self.bias = bias if bias is not None else vs.const(scope + '/biases', (N,), 0.0)
-        self.gamma = vs.const(scope + '/bn/gamma', (N,), 1.0)
-        self.beta = vs.const(scope + '/bn/beta', (N,), 0.0)
-        self.mm = vs.const(scope + '/bn/moving_mean', (N,), 0.0, trainable=False)
-        self.mv = vs.const(scope + '/bn/moving_variance', (N,), 1.0, trainable=False)
+        if bn:
+            self.gamma = vs.const(scope + '/bn/gamma', (N,), 1.0)
+            self.beta = vs.const(scope + '/bn/beta', (N,), 0.0)
+            self.mm = vs.const(scope + '/bn/moving_mean', (N,), 0.0, trainable=False)
+            self.mv = vs.const(scope + '/bn/moving_variance', (N,), 1.0, trainable=False)
+        self.NA = n_alloc or N               # columns of the GEMM (>= N, multiple of 64)
+        if self.NA != N:
+            assert not pool and self.dt == abi.F32
+            self.w_pad, self.b_pad = rt.zeros(K, self.NA), rt.zeros(self.NA)
+        N = self.NA
         self.y = None if self.gram else rt.zeros(M, N, dtype=self.adt)
         self.psum, self.psumsq = rt.zeros(T, N), rt.zeros(T, N)
         self.scale, self.shift = rt.zeros(N), rt.zeros(N)
@@ -389,12 +400,19 @@ class PointLayer:
         a.a = src.struct()
         a.w, a.bias, a.rowbias, a.y = fptr(self.w_mm), fptr(self.bias), fptr(rowbias), fptr(self.y)
         a.dtype = self.dt
+        if self.NA != self.N:                 # fewer than 64 output channels: zero-padded copy of the weights, refreshed per run
+            wp, bp, w, b, n = self.w_pad, self.b_pad, self.w, self.bias, self.N
+            plan.add_raw('pad_weights', lambda s: (wp[:, :n].copy_(w), bp[:n].copy_(b), 0)[2])
+            a.w, a.bias = fptr(wp), fptr(bp)
         a.psum, a.psumsq = fptr(self.psum), fptr(self.psumsq)
         if pool:
             a.rowmask = fptr(rowmask)
             a.pmax, a.pmin, a.pamax, a.pamin = fptr(self.pmax), fptr(self.pmin), iptr(self.pamax), iptr(self.pamin)
-        a.M, a.K, a.N, a.rows_per_frustum = self.M, self.K, self.N, g.rpf
+        a.M, a.K, a.N, a.rows_per_frustum = self.M, self.K, self.NA, g.rpf
         plan.add('t3d_pointmlp_fwd', a)
+        if not self.bn:
+            self.out = ActSpec(self.y, self.NA, self.N, 0, None, None, False, producer=self)
+            return self.out
         f = abi.BnFwdFinalizeArgs()
         f.psum, f.psumsq, f.n_tiles, f.count, f.N = fptr(self.psum), fptr(self.psumsq), self.T, self.M, self.N
         f.gamma, f.beta, f.moving_mean, f.moving_var = fptr(self.gamma), fptr(self.beta), fptr(self.mm), fptr(self.mv)
@@ -652,11 +670,17 @@ class PointLayer:
 class FcLayer:
     """tf_util.fully_connected (+ batch_norm over the batch + activation) + following dropout."""
 
-    def __init__(self, g, scope, K, N, bn=True, act='relu', K2=0, w=None, bias='own', keep_prob=None, drop_scope=None):
+    IDENTITY = 'identity'      # w=IDENTITY: no matmul (a standalone batch_norm_for_fc / dropout node on a [B,N] tensor)
+
+    def __init__(self, g, scope, K, N, bn=True, act='relu', K2=0, w=None, bias='own', keep_prob=None, drop_scope=None, bn_scope=None):
         self.g, self.scope, self.K, self.K2, self.N, self.bn, self.act = g, scope, K, K2, N, bn, act
         rt, vs = g.rt, g.vars
         B = g.B
-        if w is None:
+        bn_scope = bn_scope or scope + '/bn'
+        if isinstance(w, str) and w == FcLayer.IDENTITY:
+            assert K == N and K2 == 0
+            w, self.w_grad = None, None
+        elif w is None:
             w = vs.xavier(scope + '/weights', (K + K2, N), K + K2, N)
             self.w_grad = vs.grad(scope + '/weights')
         else:
@@ -668,10 +692,10 @@ class FcLayer:
         else:
             self.bias, self.bias_grad = bias, None
         if bn:
-            self.gamma = vs.const(scope + '/bn/gamma', (N,), 1.0)
-            self.beta = vs.const(scope + '/bn/beta', (N,), 0.0)
-            self.mm = vs.const(scope + '/bn/moving_mean', (N,), 0.0, trainable=False)
-            self.mv = vs.const(scope + '/bn/moving_variance', (N,), 1.0, trainable=False)
+            self.gamma = vs.const(bn_scope + '/gamma', (N,), 1.0)
+            self.beta = vs.const(bn_scope + '/beta', (N,), 0.0)
+            self.mm = vs.const(bn_scope + '/moving_mean', (N,), 0.0, trainable=False)
+            self.mv = vs.const(bn_scope + '/moving_variance', (N,), 1.0, trainable=False)
             self.mean, self.invstd = rt.zeros(N), rt.zeros(N)
         self.y = rt.zeros(B, N)
         self.out = rt.zeros(B, N)

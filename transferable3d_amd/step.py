@@ -49,7 +49,7 @@ class TrainStep:
 
     def _program(self, generate_masks):
         """[('run', Plan) | ('allreduce', i) | ('wait', i)] in issue order."""
-        plans = ([self.pre] if self.train else []) + [self.fwd] + ([self.bwd, self.opt] if self.train else [])
+        plans = ([self.pre] if self.pre is not None else []) + [self.fwd] + ([self.bwd, self.opt] if self.train else [])
         calls, lanes, two = [], [], False
         for p in plans:
             for (name, call, arg), lane in zip(p.calls, p.lanes):
@@ -159,7 +159,7 @@ class TrainStep:
         self._run_program(ent['cprog'], ent['graphs'])
 
     def n_launches(self):
-        return sum(len(p) for p in ([self.pre] if self.train else []) + [self.fwd] + ([self.bwd, self.opt] if self.train else []))
+        return sum(len(p) for p in ([self.pre] if self.pre is not None else []) + [self.fwd] + ([self.bwd, self.opt] if self.train else []))
 
     def n_graph_segments(self, generate_masks=True):
         ent = self.cache.get(bool(generate_masks))

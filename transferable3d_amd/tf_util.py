@@ -7,11 +7,16 @@ Semantics that differ from an eager op library, all consequences of fusing (DESI
     and ReLU are applied by whichever op consumes it.
   * a global max-pool over the points is an epilogue of the producing conv2d, so it must be requested there
     (`pool_over_points=True`, optional `rowmask`); `max_pool2d` then just returns that pooled tensor.
-Unsupported argument combinations raise NotImplementedError naming the reference behaviour that is missing."""
+  * dropout / batch_norm_for_conv2d / batch_norm_for_fc exist as nodes of their own (small launches, or lazy scale/shift fused
+    into the consumer); on the hot path they are parts of the fused layers.
+Ops built here go into the graph's forward schedule (forward-only surface); the training step is emitted by the fused
+sub-networks of semisup_models.  Unsupported argument combinations raise NotImplementedError naming the reference behaviour that
+is missing."""
 import numpy as np
 
-from . import api
-from .constants import MEAN_DIMS_ARR, NUM_HEADING_BIN, ORIENT_ANCHORS
+from . import abi, api
+from .abi import fptr
+from .constants import BN_EPS, MEAN_DIMS_ARR, NUM_HEADING_BIN, ORIENT_ANCHORS
 from .engine import ActSpec, FcLayer, PointLayer
 
 
@@ -22,6 +27,19 @@ class PointTensor(api.Tensor):
         e = ctx.engine
         api.Tensor.__init__(self, ctx, None, (e.B, e.rpf, 1, spec.K), 'point_tensor', producer=layer)
         self.spec, self.layer = spec, layer
+
+    def numpy(self):
+        """The value the consumers see: relu?(x * scale + shift) - sub, evaluated at fetch time on the host (the tensor itself is
+        never materialised on the device)."""
+        s, e = self.spec, self.ctx.engine
+        v = s.x.detach().float().cpu()[:, s.coff:s.coff + s.K]
+        if s.scale is not None:
+            v = v * s.scale.detach().cpu() + s.shift.detach().cpu()
+        if s.relu:
+            v = v.clamp(min=0)
+        if s.sub is not None:
+            v = v - s.sub.detach().cpu()[:, :s.K].repeat_interleave(e.rpf, 0)
+        return v.numpy().reshape(self._shape)
 
 
 def _as_spec(ctx, inputs):
@@ -39,19 +57,28 @@ def _as_spec(ctx, inputs):
 def conv2d(inputs, num_output_channels, kernel_size, scope, stride=[1, 1], padding='SAME', data_format='NHWC',
            use_xavier=True, stddev=1e-3, weight_decay=None, activation_fn='relu', bn=False, bn_decay=None,
            is_training=None, pool_over_points=False, rowmask=None):
-    """2-D convolution with a 1x1 (or [1,D] over a one-channel image) kernel == the per-point shared MLP layer."""
+    """2-D convolution with a 1x1 (or [1,D] over a one-channel image) kernel == the per-point shared MLP layer
+    (tf_util.py:1258-1323).  bn=True: batch-norm statistics in the GEMM's epilogue, batch-norm + ReLU applied by whichever op
+    consumes the result.  bn=False (tf_util.py:1316 skipped): the bare convolution + bias, activation_fn None or 'relu' (applied on
+    load by the consumer); a following batch_norm_for_conv2d turns it into the bn=True form.  Forward-only on this surface: the
+    training step of the hot path is emitted by the fused sub-networks (semisup_models)."""
     ctx = api.get_default_graph()
     if list(stride) != [1, 1] or data_format != 'NHWC' or not use_xavier or weight_decay is not None:
         raise NotImplementedError('conv2d: only stride 1, NHWC, xavier init, no weight decay are on the hot path')
-    if not bn or activation_fn not in ('relu',):
-        raise NotImplementedError('conv2d without batch-norm+ReLU (the conv10 logits layer) is fused into the '
-                                  'segmentation head: use semisup_models.v1_inst_seg')
+    if activation_fn not in ('relu', None) or (bn and activation_fn != 'relu'):
+        raise NotImplementedError('conv2d: activation_fn is tf.nn.relu or None at every call site of the reference')
     spec = _as_spec(ctx, inputs)
     kh, kw = kernel_size
     if kh != 1 or kw not in (1, spec.K):
         raise NotImplementedError('conv2d: kernel must be [1,1] or [1,D]')
-    layer = PointLayer(ctx.engine, scope, spec.K, num_output_channels, kernel_1xD=(kw != 1), pool=pool_over_points)
+    if not bn and pool_over_points:
+        raise NotImplementedError('conv2d: the fused max-pool follows a batch-normed layer at every call site of the reference')
+    n_alloc = (num_output_channels + 63) // 64 * 64
+    layer = PointLayer(ctx.engine, scope, spec.K, num_output_channels, kernel_1xD=(kw != 1), pool=pool_over_points, bn=bn,
+                       n_alloc=None if n_alloc == num_output_channels else n_alloc, gram=False)      # (the output tensor exists: an op graph may read it)
     out = layer.fwd(ctx.engine.fwd, spec, bool(is_training), rowmask=rowmask.buf if rowmask is not None else None)
+    if not bn:
+        out.relu = activation_fn == 'relu'
     return PointTensor(ctx, out, layer)
 
 
@@ -75,16 +102,74 @@ def fully_connected(inputs, num_outputs, scope, use_xavier=True, stddev=1e-3, we
 
 
 def dropout(inputs, is_training, scope, keep_prob=0.5, noise_shape=None):
-    raise NotImplementedError('dropout is fused into its producer (FcLayer keep_prob / the segmentation head); '
-                              'standalone tf_util.dropout nodes are not on the hot path')
+    """tf.cond(is_training, tf.nn.dropout(inputs, keep_prob), inputs) (tf_util.py:1720-1741) as a node of its own.  The keep mask
+    lives in a buffer registered under `scope` (generated per step by t3d_dropout_mask in a training schedule, or fed through
+    Session.run(feed_dict={scope: mask})).  [B,N] tensors: an identity-weight t3d_fc_fwd; per-point tensors: t3d_act_dropout
+    materialises the dropped-out activation (on the hot path the reference's one such node, conv9 -> dp1 -> conv10, is inside
+    t3d_seg_head)."""
+    if noise_shape is not None:
+        raise NotImplementedError('dropout: noise_shape is None at every call site of the reference')
+    ctx = api.get_default_graph()
+    e = ctx.engine
+    if isinstance(inputs, PointTensor):
+        spec = inputs.spec
+        out = e.rt.zeros(e.M, spec.K)
+        a = abi.ActDropoutArgs()
+        a.a, a.out, a.M, a.K, a.rows_per_frustum, a.keep_prob = spec.struct(), fptr(out), e.M, spec.K, e.rpf, float(keep_prob)
+        if bool(is_training):
+            mask = e.rt.full((e.M, spec.K), 1.0)
+            e.dropout_masks[scope] = (mask, float(keep_prob))
+            a.mask = fptr(mask)
+        a._keep = (spec, out)
+        e.fwd.add('t3d_act_dropout', a)
+        return PointTensor(ctx, ActSpec(out, spec.K, spec.K), None)
+    N = inputs.shape[-1]
+    layer = FcLayer(e, scope, N, N, bn=False, act=None, w=FcLayer.IDENTITY, bias=None, keep_prob=float(keep_prob), drop_scope=scope)
+    out = layer.fwd(e.fwd, inputs.buf, N, bool(is_training))
+    return api.Tensor(ctx, out, (e.B, N), scope, producer=layer)
 
 
 def batch_norm_for_conv2d(inputs, is_training, bn_decay, scope, data_format='NHWC'):
-    raise NotImplementedError('batch-norm is part of conv2d(bn=True) (statistics in its epilogue, apply on load)')
+    """tf.contrib.layers.batch_norm over (batch, points) per channel (tf_util.py:1693-1705 -> batch_norm_template 1645-1664) on
+    the output of conv2d(bn=False, activation_fn=None): the statistics come from the partial sums that GEMM's epilogue already
+    wrote (t3d_bn_fwd_finalize; variables <scope>/{beta,gamma,moving_mean,moving_variance}), the normalisation is applied by the
+    consumer while it loads the tensor."""
+    if data_format != 'NHWC':
+        raise NotImplementedError('batch_norm_for_conv2d: NHWC only')
+    if not isinstance(inputs, PointTensor) or inputs.layer is None or inputs.layer.bn or inputs.spec.relu:
+        raise NotImplementedError('batch_norm_for_conv2d follows conv2d(bn=False, activation_fn=None)')
+    ctx = api.get_default_graph()
+    e, lay, vs = ctx.engine, inputs.layer, ctx.engine.vars
+    N = lay.N
+    if isinstance(bn_decay, (int, float)):
+        e.hyper[2] = float(bn_decay)
+    gamma, beta = vs.const(scope + '/gamma', (N,), 1.0), vs.const(scope + '/beta', (N,), 0.0)
+    mm = vs.const(scope + '/moving_mean', (N,), 0.0, trainable=False)
+    mv = vs.const(scope + '/moving_variance', (N,), 1.0, trainable=False)
+    scale, shift, mean, invstd = (e.rt.zeros(N) for _ in range(4))
+    f = abi.BnFwdFinalizeArgs()
+    f.psum, f.psumsq, f.n_tiles, f.count, f.N = fptr(lay.psum), fptr(lay.psumsq), lay.T, lay.M, N
+    if lay.NA != N:            # padded GEMM: the partials have NA columns per tile
+        raise NotImplementedError('batch_norm_for_conv2d on a layer with fewer than 64 channels')
+    f.gamma, f.beta, f.moving_mean, f.moving_var = fptr(gamma), fptr(beta), fptr(mm), fptr(mv)
+    f.decay, f.eps, f.is_training, f.unbiased_ema = fptr(e.bn_decay_ptr), BN_EPS, int(bool(is_training)), int(e.unbiased_ema)
+    f.scale, f.shift, f.mean, f.invstd = fptr(scale), fptr(shift), fptr(mean), fptr(invstd)
+    f._keep = (gamma, beta, mm, mv, scale, shift, mean, invstd)
+    e.fwd.add('t3d_bn_fwd_finalize', f)
+    return PointTensor(ctx, ActSpec(lay.y, N, N, 0, scale, shift, False, producer=lay), lay)
 
 
 def batch_norm_for_fc(inputs, is_training, bn_decay, scope):
-    raise NotImplementedError('batch-norm is part of fully_connected(bn=True)')
+    """Batch-norm over the B rows of a [B,N] tensor (tf_util.py:1666-1677) as a node of its own: an identity-weight t3d_fc_fwd
+    (variables <scope>/{beta,gamma,moving_mean,moving_variance}), no activation."""
+    ctx = api.get_default_graph()
+    e = ctx.engine
+    if isinstance(bn_decay, (int, float)):
+        e.hyper[2] = float(bn_decay)
+    N = inputs.shape[-1]
+    layer = FcLayer(e, scope, N, N, bn=True, act=None, w=FcLayer.IDENTITY, bias=None, bn_scope=scope)
+    out = layer.fwd(e.fwd, inputs.buf, N, bool(is_training))
+    return api.Tensor(ctx, out, (e.B, N), scope, producer=layer)
 
 
 # ---- host-side geometry helpers (tiny, per-frustum; run on NumPy arrays) ----------------------------------------
