@@ -183,20 +183,22 @@ def lib_source_hash():
 
 
 def pmc_traffic(label, args):
-    """HBM bytes per launch of `label` from the committed PMC summary (tools/pmc_traffic.py; counters cannot be read from inside
-    the process being timed).  None unless the summary was taken for THIS workload, problem size and dtype; `stale_build` tells
-    whether the kernels' sources changed since."""
-    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-    try:
-        with open(path) as fh:
-            z = json.load(fh)
-        meta = z.get('_meta', {})
-        want = {'workload': args.workload, 'B': args.batch_size, 'N': args.num_point, 'C': args.num_channel, 'dtype': args.dtype}
-        if any(meta.get(k) != v for k, v in want.items()):
-            return None, None
-        return z['kernels'][label]['bytes_per_launch'], meta.get('lib_source_hash') != lib_source_hash()
-    except (OSError, KeyError, ValueError):
-        return None, None
+    """HBM bytes per launch of `label` from a committed PMC summary (profiles/*pmc_traffic*.json, written by tools/pmc_traffic.py;
+    counters cannot be read from inside the process being timed).  Only a summary taken for THIS workload, problem size and dtype
+    counts (the newest by file name); `stale` tells whether the kernels' sources changed since it was taken."""
+    import glob
+    want = {'workload': args.workload, 'B': args.batch_size, 'N': args.num_point, 'C': args.num_channel, 'dtype': args.dtype}
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*pmc_traffic*.json')), reverse=True):
+        try:
+            with open(path) as fh:
+                z = json.load(fh)
+            meta = z.get('_meta', {})
+            if any(meta.get(k) != v for k, v in want.items()):
+                continue
+            return z['kernels'][label]['bytes_per_launch'], meta.get('lib_source_hash') != lib_source_hash()
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
 def cpu_model():

@@ -20,13 +20,44 @@ import sys
 csv.field_size_limit(1 << 30)
 
 
+def lib_source_hash():
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('t3d_bench', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py'))
+    src = open(spec.origin).read()
+    ns = {'os': os, 'ROOT': os.path.dirname(spec.origin)}
+    start = src.index('def lib_source_hash():')
+    end = src.index('def pmc_traffic(')
+    exec(src[start:end], ns)
+    return ns['lib_source_hash']()
+
+
 def label(kernel_name):
-    m = re.search(r'(k_\w+)(?:<([^>]*)>)?\(', kernel_name)
-    if not m:
-        return None
-    name, targs = m.group(1), [t.strip() for t in (m.group(2) or '').split(',') if t.strip()]
-    ints = [t for t in targs if t.isdigit()]          # tile sizes; the bool template flags are not part of the label
-    if name.startswith('k_pointmlp') and ints:
+    """bench.py's label of a kernel: GEMM kernels by name + integer template arguments (tile sizes), the others by bare name.
+    rocprofv3 leaves names with a __bf16 template argument mangled (_ZN12_GLOBAL__N_114k_pointmlp_fwdILi128ELb0ENS_8PathBF16EDF16bEE...):
+    both spellings are handled."""
+    if kernel_name.startswith('_Z'):
+        m = re.search(r'(\d+)k_', kernel_name)
+        if not m:
+            return None
+        digits, pos = m.group(1), m.end() - 2
+        name = rest = None
+        for i in range(len(digits)):          # "..._114k_pointmlp_fwd": the length prefix is a suffix of the digit run
+            n = int(digits[i:])
+            cand, nxt = kernel_name[pos:pos + n], kernel_name[pos + n:pos + n + 1]
+            if len(cand) == n and nxt in ('I', 'E') and re.fullmatch(r'k_\w+', cand):
+                name, rest = cand, kernel_name[pos + n:]
+                break
+        if name is None:
+            return None
+        ints = re.findall(r'Li(\d+)E', rest.split('Ev', 1)[0]) if rest.startswith('I') else []
+    else:
+        m = re.search(r'(k_\w+)(?:<([^>]*)>)?\(', kernel_name)
+        if not m:
+            return None
+        name, targs = m.group(1), [t.strip() for t in (m.group(2) or '').split(',') if t.strip()]
+        ints = [t for t in targs if t.isdigit()]          # tile sizes; the bool / type template arguments are not part of the label
+    if name.startswith(('k_pointmlp', 'k_pool_bwd_stage')) and ints:
         return '%s<%s>' % (name, ','.join(ints))
     return name
 
@@ -55,10 +86,19 @@ def main():
     ap.add_argument('write_dir')
     ap.add_argument('-o', '--out', default='profiles/pmc_traffic.json')
     ap.add_argument('--note', default='')
+    ap.add_argument('--workload', default='A')
+    ap.add_argument('--batch_size', type=int, default=32)
+    ap.add_argument('--num_point', type=int, default=1024)
+    ap.add_argument('--num_channel', type=int, default=4)
+    ap.add_argument('--dtype', default='f32')
     a = ap.parse_args()
     fe, wr = collect(a.fetch_dir, 'FETCH_SIZE'), collect(a.write_dir, 'WRITE_SIZE')
     out = {'_doc': 'per-launch HBM traffic from rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); '
                    'bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts 128-B requests at 64 B)', '_note': a.note,
+           # what the summary was taken for: bench.py reports `traffic` only for the same workload / size / dtype and flags a
+           # summary that predates the current kernel sources
+           '_meta': {'workload': a.workload, 'B': a.batch_size, 'N': a.num_point, 'C': a.num_channel, 'dtype': a.dtype,
+                     'lib_source_hash': lib_source_hash()},
            'kernels': {}}
     for k in sorted(set(fe) | set(wr)):
         f, nf = fe.get(k, (0.0, 0))

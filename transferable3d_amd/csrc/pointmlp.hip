@@ -707,7 +707,7 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd(const t3d_pointm
           // two-byte global stores per thread were half of a workgroup's lifetime on the narrow layers (tools/trace_blocks.py)
           if (store_y) ytile[(wm * 64 + 4 * h + tm * 32 + (r & 3) + 8 * (r >> 2)) * YLD + wn * (BN / 2) + tn * 32 + l31] = (bf16_t)v;
         } else {
-          acc[tm][tn][r] = v;           // stored after the last barrier (below)
+          if (store_y) p.y[off0 + (unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)p.N] = v;
         }
         s += v;
         ss = fmaf(v, v, ss);
@@ -764,9 +764,10 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd(const t3d_pointm
       p.pmax[o] = mx; p.pmin[o] = mn; p.pamax[o] = ax; p.pamin[o] = an;
     }
   }
-  // The output tile is stored LAST: a __syncthreads() behind a global store waits for the store to complete, so with the stores
-  // in front of the two barriers of the statistics exchange every workgroup sat out two write round trips (4-11 us per
-  // workgroup, tools/trace_blocks.py); issued here they drain while the CU already runs the next workgroup.
+  // bf16: the output tile leaves the LDS image LAST, as 16-byte row-contiguous stores behind the last barrier (they drain while
+  // the CU already runs the next workgroup).  The fp32 path keeps its in-loop stores: moving them behind the barriers measured
+  // 1-2 % SLOWER at B=32 (1.628 vs 1.60 ms per step) -- with two workgroups per CU the wait at the barrier is covered by the other
+  // workgroup's MFMAs, and the second pass over the accumulators costs more than it saves.
   if (store_y) {
     if constexpr (Elem<YT>::BF16) {
       constexpr int CPR = BN / 8;                                   // 16-byte chunks per tile row
@@ -776,15 +777,6 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd(const t3d_pointm
         const int c = tid + NT * i, row = c / CPR, ch = c % CPR;
         const bf16x8 v = *reinterpret_cast<const bf16x8*>(ytile + row * YLD + ch * 8);
         *reinterpret_cast<bf16x8*>(yg + (size_t)(row0 + row) * p.N + col0 + ch * 8) = v;
-      }
-    } else {
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        const unsigned off0 = (unsigned)(row0 + wm * 64 + 4 * h) * (unsigned)p.N + (unsigned)(col0 + wn * (BN / 2) + tn * 32 + l31);
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) p.y[off0 + (unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)p.N] = acc[tm][tn][r];
       }
     }
   }
@@ -906,7 +898,7 @@ __device__ __forceinline__ void dgrad_epilogue_body(const DgradEpilogue& p, f32x
             s1 += v;
             s2 = fmaf(v, yp[e], s2);
           }
-          acc[tm][tn][r] = v;           // stored after the last barrier (below)
+          Elem<T>::st1(p.out, o, v);
         }
       }
     }
@@ -915,10 +907,7 @@ __device__ __forceinline__ void dgrad_epilogue_body(const DgradEpilogue& p, f32x
     s2 += __shfl_xor(s2, 32, 64);
     cs1[tn] = s1; cs2[tn] = s2;
   }
-  // The global stores of the gradient tile are issued LAST: a __syncthreads() behind a global store waits until that store has
-  // completed (workgroup-scope release), i.e. the whole workgroup sat out a write round trip at each of the two barriers of the
-  // partial-sum exchange below (4-5 us of a 10-25 us workgroup lifetime, tools/trace_blocks.py); behind the last barrier the
-  // stores drain while the CU already runs the next workgroup.
+  // bf16: the gradient tile leaves its LDS image behind the last barrier (see the forward epilogue); fp32 stored it in the loop
   if (stats || Elem<T>::BF16) __syncthreads();      // bf16: the LDS tile is complete
   if (stats) {
     if (h == 0) {
@@ -942,15 +931,6 @@ __device__ __forceinline__ void dgrad_epilogue_body(const DgradEpilogue& p, f32x
     for (int i = 0; i < 128 * CPR / NT; ++i) {
       const int c = tid + NT * i, row = c / CPR, ch = c % CPR;
       *reinterpret_cast<bf16x8*>(og + (size_t)(row0 + row) * K + col0 + ch * 8) = *reinterpret_cast<const bf16x8*>(ptile + row * YLD + ch * 8);
-    }
-  } else {
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      const unsigned off0 = (unsigned)(row0 + wm * 64 + 4 * h) * K + (unsigned)(col0 + wn * (BN / 2) + tn * 32 + l31);
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) p.out[off0 + (unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) * K] = acc[tm][tn][r];
     }
   }
 }
