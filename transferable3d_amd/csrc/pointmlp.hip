@@ -73,8 +73,90 @@ __device__ unsigned long long* t3d_trace_ptr = nullptr;
 // All loads are UNCONDITIONAL on clamped addresses and masked afterwards with selects: a per-lane
 // `cond ? load : 0` compiles to an exec-masked branch with its own s_waitcnt, which serialises the global
 // latency of every k-tile (seen in the first version's ISA).  Only wave-uniform conditions branch.
-template <bool HAS_SUB, class XT = float>      // XT: element type of the source tensor (t3d_act_src.dtype)
+// fp32 loaders: the code of round 1, textually apart from the typed loaders of the bf16 path below (routing fp32 through the
+// typed templates changed the compiler's addressing / schedule of the fp32 main loops: k_pointmlp_bwd<64,64,64> 30.0 -> 35.0 us
+// on one box, same-box A/B)
+template <bool HAS_SUB>
 struct ActLoader {
+  static constexpr bool EXACT = false;
+  t3d_act_src s;
+  int K;     // valid columns
+  int rpf;   // rows per frustum
+  struct Raw { float4 x; };
+  struct Coef { float4 sc, sh; };
+  __device__ __forceinline__ Coef fetch_coef(int col) const {
+    Coef c;
+    c.sc = make_float4(1.f, 1.f, 1.f, 1.f);
+    c.sh = f4zero();
+    if (s.scale != nullptr) {                 // uniform; scale/shift hold >= roundup4(K) floats (host contract)
+      const int cc = min(col, ((K + 3) & ~3) - 4);
+      c.sc = *reinterpret_cast<const float4*>(s.scale + cc);
+      c.sh = *reinterpret_cast<const float4*>(s.shift + cc);
+    }
+    return c;
+  }
+  __device__ __forceinline__ Raw fetch(int row, int col) const {
+    Raw r;
+    const int cc = min(col, ((K + 3) & ~3) - 4);
+    r.x = *reinterpret_cast<const float4*>(s.x + (size_t)row * s.ldx + s.coff + cc);
+    return r;
+  }
+  // straight-line (no branches): identity scale/shift when there is no batch-norm, ReLU floor -inf when off
+  __device__ __forceinline__ float4 xform(const Raw& r, const Coef& c, int row, int col) const {
+    float v[4] = {r.x.x, r.x.y, r.x.z, r.x.w};
+    const float sc[4] = {c.sc.x, c.sc.y, c.sc.z, c.sc.w};
+    const float sh[4] = {c.sh.x, c.sh.y, c.sh.z, c.sh.w};
+    const float floor_ = s.relu ? 0.f : -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), floor_);
+    if (HAS_SUB) {                            // raw point inputs only (K <= 4)
+      const int b = row / rpf;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] -= s.sub[(size_t)b * s.sub_ld + min(col + e, K - 1)];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (col + e < K) ? v[e] : 0.f;
+    return make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+
+template <bool POOLED>
+struct DyLoader {      // N % 32 == 0: every tile column is valid
+  t3d_dy_src s;
+  int N;
+  int rpf;
+  struct Raw { float4 dz, y; };
+  struct Coef { float4 c0, c1, c2; };
+  __device__ __forceinline__ Coef fetch_coef(int col) const {
+    Coef c;
+    c.c0 = *reinterpret_cast<const float4*>(s.coef + col);
+    c.c1 = *reinterpret_cast<const float4*>(s.coef + N + col);
+    c.c2 = *reinterpret_cast<const float4*>(s.coef + 2 * N + col);
+    return c;
+  }
+  __device__ __forceinline__ Raw fetch(int row, int col) const {
+    Raw r;
+    r.y = *reinterpret_cast<const float4*>(s.y + (size_t)row * N + col);
+    if (!POOLED) {
+      r.dz = *reinterpret_cast<const float4*>(s.dz + (size_t)row * N + col);
+    } else {
+      const int b = row / rpf, rin = row - b * rpf;
+      const int4 a = *reinterpret_cast<const int4*>(s.argidx + (size_t)b * N + col);
+      const float4 g = *reinterpret_cast<const float4*>(s.dpool + (size_t)b * N + col);
+      r.dz = make_float4(a.x == rin ? g.x : 0.f, a.y == rin ? g.y : 0.f, a.z == rin ? g.z : 0.f,
+                         a.w == rin ? g.w : 0.f);
+    }
+    return r;
+  }
+  __device__ __forceinline__ float4 xform(const Raw& r, const Coef& c, int, int) const {
+    return make_float4(fmaf(c.c0.x, r.dz.x, fmaf(c.c1.x, r.y.x, c.c2.x)), fmaf(c.c0.y, r.dz.y, fmaf(c.c1.y, r.y.y, c.c2.y)),
+                       fmaf(c.c0.z, r.dz.z, fmaf(c.c1.z, r.y.z, c.c2.z)), fmaf(c.c0.w, r.dz.w, fmaf(c.c1.w, r.y.w, c.c2.w)));
+  }
+};
+
+// typed loaders (T3D_BF16 path)
+template <bool HAS_SUB, class XT>      // XT: element type of the source tensor (t3d_act_src.dtype)
+struct ActLoaderT {
   t3d_act_src s;
   int K;     // valid columns
   int rpf;   // rows per frustum
@@ -121,8 +203,8 @@ struct ActLoader {
   }
 };
 
-template <bool POOLED, class T = float>      // T: element type of dz and y (t3d_dy_src.dtype); the pooled-sparse form is fp32 only
-struct DyLoader {      // N % 32 == 0: every tile column is valid
+template <bool POOLED, class T>      // T: element type of dz and y (t3d_dy_src.dtype); the pooled-sparse form is fp32 only
+struct DyLoaderT {      // N % 32 == 0: every tile column is valid
   t3d_dy_src s;
   int N;
   int rpf;
@@ -596,6 +678,8 @@ __device__ __forceinline__ void gemm_mainloop_h(SA& sa, SB& sb, const LA& la, co
 // Arithmetic of a GEMM kernel: which staging / MFMA loop, and the element type T of the layer tensors it writes.
 struct PathF32 {
   typedef float T;
+  template <bool HAS_SUB, class XT> using Act = ActLoader<HAS_SUB>;
+  template <bool POOLED> using Dy = DyLoader<POOLED>;
   typedef WLoaderT<float> WL;            // loader of the layer's weight matrix
   typedef WLoaderT<float> WLX;           // ... when every tile lies inside the matrix (the fp32 path keeps its one loader)
   static constexpr bool BF16 = false;
@@ -604,6 +688,8 @@ struct PathF32 {
 };
 struct PathBF16 {
   typedef bf16_t T;
+  template <bool HAS_SUB, class XT> using Act = ActLoaderT<HAS_SUB, XT>;
+  template <bool POOLED> using Dy = DyLoaderT<POOLED, bf16_t>;
   typedef WLoaderT<bf16_t> WL;           // `w` points at the bf16 copy of the weights (t3d_cast_bf16)
   typedef WLoaderT<bf16_t, true> WLX;
   static constexpr bool BF16 = true;
@@ -624,7 +710,7 @@ __device__ __forceinline__ void run_mainloop(SA& sa, SB& sb, const LA& la, const
 template <int BN, bool HAS_SUB, class PR = PathF32, class XT = float>
 __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd(const t3d_pointmlp_fwd_args p) {
   constexpr int BM = 128, TM = 2, TN = BN / 64;
-  using LA = ActLoader<HAS_SUB, XT>;
+  using LA = typename PR::template Act<HAS_SUB, XT>;
   using YT = typename PR::T;
   constexpr int PF = BN == 64 ? T3D_PF_NARROW : T3D_PF_WIDE;
   using WL = std::conditional_t<LA::EXACT, typename PR::WLX, typename PR::WL>;      // K % 64 == 0: every weight tile is whole
@@ -807,8 +893,90 @@ struct DgradEpilogue {
 // are issued ahead of the batch's stores: `out` may alias the inputs as far as the compiler knows, so a load placed
 // after a store is never hoisted above it and every element would pay a full memory round trip.
 // ADD: 0 = no add_in, 1 = dense add_in, 2 = add_in gated by the per-row flags (rows without a flag are never read).
-template <int BN, int TM, int TN, int ADD, bool MASK, class T>     // T: element type of prev_y, out and a dense add_in
+// fp32 epilogue: the code of round 1, kept textually apart from the bf16 variant below (sharing one body behind `if constexpr`
+// changed the compiler's schedule of this one: k_pointmlp_bwd<64,64,64> 28.4 -> 30.6 us at B=32)
+template <int BN, int TM, int TN, int ADD, bool MASK>
 __device__ __forceinline__ void dgrad_epilogue_body(const DgradEpilogue& p, f32x16 (&acc)[TM][TN], float* red, int tid,
+                                                    int row0, int col0, int tile_m) {
+  const int lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+  const bool stats = MASK && p.psum_dz != nullptr;
+  const unsigned K = (unsigned)p.K;
+  float cs1[TN], cs2[TN];
+  unsigned live = 0u;                    // bit tm*16 + r: the lane's accumulator row (tm, r) has something to add
+  if (ADD == 2) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int4 f = *reinterpret_cast<const int4*>(p.add_live + row0 + wm * 64 + 4 * h + tm * 32 + 8 * j);
+        live |= (unsigned)((f.x != 0) | ((f.y != 0) << 1) | ((f.z != 0) << 2) | ((f.w != 0) << 3)) << (tm * 16 + 4 * j);
+      }
+  }
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int col = col0 + wn * (BN / 2) + tn * 32 + l31;
+    const float psc = MASK ? p.prev_scale[col] : 0.f, psh = MASK ? p.prev_shift[col] : 0.f;
+    const float cc = p.colconst ? p.colconst[col] : 0.f;
+    const unsigned off0 = (unsigned)(row0 + wm * 64 + 4 * h) * K + (unsigned)col;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      constexpr int EB = 8;
+#pragma unroll
+      for (int r0 = 0; r0 < 16; r0 += EB) {
+        float yp[EB], ad[EB];
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+          const int r = r0 + e;
+          const unsigned o = off0 + (unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) * K;
+#ifdef T3D_ABL_DG_NOLOAD
+          yp[e] = psc + (float)r;
+#else
+          yp[e] = MASK ? p.prev_y[o] : 0.f;
+#endif
+          if (ADD == 2) ad[e] = ((live >> (tm * 16 + r)) & 1u) ? p.add_in[o] : 0.f;
+          else ad[e] = ADD ? p.add_in[o] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+          const int r = r0 + e;
+          const unsigned o = off0 + (unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) * K;
+          float v = acc[tm][tn][r] + cc + ad[e];
+          if (MASK) {
+            if (!(fmaf(yp[e], psc, psh) > 0.f)) v = 0.f;
+            s1 += v;
+            s2 = fmaf(v, yp[e], s2);
+          }
+          p.out[o] = v;
+        }
+      }
+    }
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    cs1[tn] = s1; cs2[tn] = s2;
+  }
+  if (stats) {
+    __syncthreads();
+    if (h == 0) {
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int c = wn * (BN / 2) + tn * 32 + l31;
+        red[(0 * 2 + wm) * BN + c] = cs1[tn];
+        red[(1 * 2 + wm) * BN + c] = cs2[tn];
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const size_t o = (size_t)tile_m * p.K + col0 + tid;
+      p.psum_dz[o] = red[(0 * 2 + 0) * BN + tid] + red[(0 * 2 + 1) * BN + tid];
+      p.psum_dzy[o] = red[(1 * 2 + 0) * BN + tid] + red[(1 * 2 + 1) * BN + tid];
+    }
+  }
+}
+
+template <int BN, int TM, int TN, int ADD, bool MASK, class T>     // T: element type of prev_y, out and a dense add_in
+__device__ __forceinline__ void dgrad_epilogue_body_h(const DgradEpilogue& p, f32x16 (&acc)[TM][TN], float* red, int tid,
                                                     int row0, int col0, int tile_m) {
   const int lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
   const int l31 = lane & 31, h = lane >> 5;
@@ -939,14 +1107,26 @@ template <int BN, int TM, int TN, class T = float>
 __device__ __forceinline__ void dgrad_epilogue(const DgradEpilogue& p, f32x16 (&acc)[TM][TN], float* red, int tid, int row0,
                                                int col0, int tile_m) {
   const bool add = p.add_in != nullptr, mask = p.prev_y != nullptr;      // workgroup-uniform
-  if (mask) {
-    if (add && p.add_live) dgrad_epilogue_body<BN, TM, TN, 2, true, T>(p, acc, red, tid, row0, col0, tile_m);
-    else if (add) dgrad_epilogue_body<BN, TM, TN, 1, true, T>(p, acc, red, tid, row0, col0, tile_m);
-    else dgrad_epilogue_body<BN, TM, TN, 0, true, T>(p, acc, red, tid, row0, col0, tile_m);
+  if constexpr (Elem<T>::BF16) {
+    if (mask) {
+      if (add && p.add_live) dgrad_epilogue_body_h<BN, TM, TN, 2, true, T>(p, acc, red, tid, row0, col0, tile_m);
+      else if (add) dgrad_epilogue_body_h<BN, TM, TN, 1, true, T>(p, acc, red, tid, row0, col0, tile_m);
+      else dgrad_epilogue_body_h<BN, TM, TN, 0, true, T>(p, acc, red, tid, row0, col0, tile_m);
+    } else {
+      if (add && p.add_live) dgrad_epilogue_body_h<BN, TM, TN, 2, false, T>(p, acc, red, tid, row0, col0, tile_m);
+      else if (add) dgrad_epilogue_body_h<BN, TM, TN, 1, false, T>(p, acc, red, tid, row0, col0, tile_m);
+      else dgrad_epilogue_body_h<BN, TM, TN, 0, false, T>(p, acc, red, tid, row0, col0, tile_m);
+    }
   } else {
-    if (add && p.add_live) dgrad_epilogue_body<BN, TM, TN, 2, false, T>(p, acc, red, tid, row0, col0, tile_m);
-    else if (add) dgrad_epilogue_body<BN, TM, TN, 1, false, T>(p, acc, red, tid, row0, col0, tile_m);
-    else dgrad_epilogue_body<BN, TM, TN, 0, false, T>(p, acc, red, tid, row0, col0, tile_m);
+    if (mask) {
+      if (add && p.add_live) dgrad_epilogue_body<BN, TM, TN, 2, true>(p, acc, red, tid, row0, col0, tile_m);
+      else if (add) dgrad_epilogue_body<BN, TM, TN, 1, true>(p, acc, red, tid, row0, col0, tile_m);
+      else dgrad_epilogue_body<BN, TM, TN, 0, true>(p, acc, red, tid, row0, col0, tile_m);
+    } else {
+      if (add && p.add_live) dgrad_epilogue_body<BN, TM, TN, 2, false>(p, acc, red, tid, row0, col0, tile_m);
+      else if (add) dgrad_epilogue_body<BN, TM, TN, 1, false>(p, acc, red, tid, row0, col0, tile_m);
+      else dgrad_epilogue_body<BN, TM, TN, 0, false>(p, acc, red, tid, row0, col0, tile_m);
+    }
   }
 }
 
@@ -954,7 +1134,7 @@ template <int BN, bool POOLED, class PR = PathF32>   // BN = tile width over the
 __device__ __forceinline__ void dgrad_body(const t3d_pointmlp_dgrad_args& p, float* smem, int bid, int nblocks) {
   constexpr int BM = 128, TM = 2, TN = BN / 64;
   constexpr int PF = BN == 64 ? T3D_PF_NARROW : T3D_PF_WIDE;
-  using LA = DyLoader<POOLED, typename PR::T>;
+  using LA = typename PR::template Dy<POOLED>;
   using WL = typename PR::WLX;            // bf16: K % 64 == 0 and N % 64 == 0 (launcher-checked), every tile is whole
   using SA = typename PR::template Stg<BM, true, LA, PF>;
   using SB = typename PR::template Stg<BN, true, WL, PF>;
@@ -993,7 +1173,7 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_dgrad(const t3d_poin
 template <int BN, class PR = PathF32>
 __device__ __forceinline__ void dgrad_gram_body(const t3d_pointmlp_dgrad_gram_args& p, float* smem, int bid, int nblocks) {
   constexpr int BM = 128, TM = 2, TN = BN / 64;
-  using LA = ActLoader<false, typename PR::T>;
+  using LA = typename PR::template Act<false, typename PR::T>;
   constexpr int PF = BN == 64 ? T3D_PF_NARROW : T3D_PF_GRAM128;
   using SA = typename PR::template Stg<BM, true, LA, PF>;
   using SB = typename PR::template Stg<BN, false, WLoader, PF>;
@@ -1068,8 +1248,8 @@ __device__ __forceinline__ void wgrad_body(const LA& la, const LB& lb, float* sl
 template <int BMK, int BN, bool HAS_SUB, bool POOLED, class PR = PathF32, class XT = float>
 __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_wgrad(const t3d_pointmlp_wgrad_args p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  ActLoader<HAS_SUB, XT> la{p.a, p.K, p.rows_per_frustum};
-  DyLoader<POOLED, typename PR::T> lb{p.dy, p.N, p.rows_per_frustum};
+  typename PR::template Act<HAS_SUB, XT> la{p.a, p.K, p.rows_per_frustum};
+  typename PR::template Dy<POOLED> lb{p.dy, p.N, p.rows_per_frustum};
   wgrad_body<BMK, BN, PR>(la, lb, p.slabs, p.K, p.N, p.rows_per_split, smem, blockIdx.x, gridDim.x);
 }
 
@@ -1077,7 +1257,7 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_wgrad(const t3d_poin
 template <int BMK, int BN, class PR = PathF32>
 __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_gram(const t3d_pointmlp_gram_args p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  ActLoader<false, typename PR::T> la{p.a, p.K, p.rows_per_frustum};
+  typename PR::template Act<false, typename PR::T> la{p.a, p.K, p.rows_per_frustum};
   wgrad_body<BMK, BN, PR>(la, la, p.slabs, p.K, p.K, p.rows_per_split, smem, blockIdx.x, gridDim.x);
 }
 
@@ -1088,8 +1268,8 @@ template <int DBN, int WBMK, int WBN, class PR = PathF32>
 __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_bwd(const t3d_pointmlp_dgrad_args d, const t3d_pointmlp_wgrad_args w,
                                                                 const int n_wgrad, const int interleave) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  ActLoader<false, typename PR::T> la{w.a, w.K, w.rows_per_frustum};
-  DyLoader<false, typename PR::T> lb{w.dy, w.N, w.rows_per_frustum};
+  typename PR::template Act<false, typename PR::T> la{w.a, w.K, w.rows_per_frustum};
+  typename PR::template Dy<false> lb{w.dy, w.N, w.rows_per_frustum};
   if (interleave) {
     // logical order: per row split, its weight-gradient tiles followed by the data-gradient tiles of the same rows; the
     // XCD remap hands each XCD a contiguous piece of that order, so both readers of a dy row range share one L2
@@ -1115,10 +1295,10 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pool_bwd_stage1(const t3d_poi
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x;
   if (b < n_gram) {
-    ActLoader<false, typename PR::T> la{g.a, g.K, g.rows_per_frustum};
+    typename PR::template Act<false, typename PR::T> la{g.a, g.K, g.rows_per_frustum};
     wgrad_body<GT, GT, PR>(la, la, g.slabs, g.K, g.K, g.rows_per_split, smem, b, n_gram);
   } else if (b < n_gram + n_colsum) {
-    act_colsum_body(c, smem, b - n_gram);
+    act_colsum_body<typename PR::T>(c, smem, b - n_gram);
   } else {
     const int r = b - n_gram - n_colsum, kb = q.K / 32;
     pool_bwd_prep_body(q, smem, r % kb, (r / kb) % kb, r / (kb * kb));
@@ -1134,7 +1314,7 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pool_bwd_stage2(const t3d_poo
   const int b = blockIdx.x;
   if (b < n_finish) {
     const int kb = f.K / FK;
-    pool_wgrad_finish_body(f, smem, b % kb, b / kb);
+    pool_wgrad_finish_body<typename PR::T>(f, smem, b % kb, b / kb);
   } else {
     dgrad_gram_body<BN, PR>(d, smem, b - n_finish, gridDim.x - n_finish);
   }

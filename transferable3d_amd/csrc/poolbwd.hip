@@ -11,13 +11,15 @@ __global__ __launch_bounds__(256) void k_pool_sparse_rows(const t3d_pool_sparse_
   extern __shared__ __attribute__((aligned(16))) float smem[];
   pool_sparse_rows_body(p, smem, blockIdx.x, blockIdx.y);
 }
+template <class XT>
 __global__ __launch_bounds__(256) void k_act_colsum(const t3d_act_colsum_args p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  act_colsum_body(p, smem, blockIdx.x);
+  act_colsum_body<XT>(p, smem, blockIdx.x);
 }
+template <class XT>
 __global__ __launch_bounds__(256) void k_pool_wgrad_finish(const t3d_pool_wgrad_finish_args p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  pool_wgrad_finish_body(p, smem, blockIdx.x, blockIdx.y);
+  pool_wgrad_finish_body<XT>(p, smem, blockIdx.x, blockIdx.y);
 }
 
 }  // namespace
@@ -50,7 +52,8 @@ extern "C" int t3d_pool_sparse_rows(const t3d_pool_sparse_rows_args* a, t3d_stre
 extern "C" int t3d_act_colsum(const t3d_act_colsum_args* a, t3d_stream_t stream) {
   const int rc = check_colsum(a);
   if (rc != T3D_OK) return rc;
-  T3D_LAUNCH(k_act_colsum, dim3(a->M / 128), dim3(256), COLSUM_LDS, static_cast<hipStream_t>(stream), *a);
+  if (a->a.dtype == T3D_BF16) T3D_LAUNCH(k_act_colsum<bf16_t>, dim3(a->M / 128), dim3(256), COLSUM_LDS, static_cast<hipStream_t>(stream), *a);
+  else T3D_LAUNCH(k_act_colsum<float>, dim3(a->M / 128), dim3(256), COLSUM_LDS, static_cast<hipStream_t>(stream), *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -59,7 +62,8 @@ extern "C" int t3d_pool_wgrad_finish(const t3d_pool_wgrad_finish_args* a, t3d_st
   const int rc = check_finish(a);
   if (rc != T3D_OK) return rc;
   const size_t lds = finish_lds(a->K);
-  T3D_LAUNCH(k_pool_wgrad_finish, dim3(a->K / FK, a->N / FN), dim3(256), lds, static_cast<hipStream_t>(stream), *a);
+  if (a->a.dtype == T3D_BF16) T3D_LAUNCH(k_pool_wgrad_finish<bf16_t>, dim3(a->K / FK, a->N / FN), dim3(256), lds, static_cast<hipStream_t>(stream), *a);
+  else T3D_LAUNCH(k_pool_wgrad_finish<float>, dim3(a->K / FK, a->N / FN), dim3(256), lds, static_cast<hipStream_t>(stream), *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

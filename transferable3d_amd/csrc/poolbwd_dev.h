@@ -170,6 +170,7 @@ __device__ __forceinline__ float act_elem(const t3d_act_src& s, size_t row, int 
 
 constexpr size_t COLSUM_LDS = 256 * sizeof(float4);
 
+template <class XT = float>      // XT: element type of the activation source (fp32 path: float, the round-1 code)
 __device__ __forceinline__ void act_colsum_body(const t3d_act_colsum_args& p, float* smem, int bx) {
   float4* red = reinterpret_cast<float4*>(smem);
   const int tid = threadIdx.x;
@@ -184,10 +185,9 @@ __device__ __forceinline__ void act_colsum_body(const t3d_act_colsum_args& p, fl
   const float floor_ = p.a.relu ? 0.f : -INFINITY;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   const size_t base = (size_t)(row0 + grp * rows) * p.a.ldx + p.a.coff + 4 * c4;       // element offset (fp32 or bf16 source)
-  const int dt = p.a.dtype;
 #pragma unroll 16
   for (int r = 0; r < rows; ++r) {
-    const float4 x = ld_elem4(p.a.x, base + (size_t)r * p.a.ldx, dt);
+    const float4 x = Elem<XT>::widen(Elem<XT>::ld4(p.a.x, base + (size_t)r * p.a.ldx));
     acc.x += fmaxf(fmaf(x.x, sc.x, sh.x), floor_);
     acc.y += fmaxf(fmaf(x.y, sc.y, sh.y), floor_);
     acc.z += fmaxf(fmaf(x.z, sc.z, sh.z), floor_);
@@ -218,6 +218,7 @@ inline size_t finish_lds(int K) {
   return ((size_t)FK * (K + 1) + (size_t)K * FN + FK * (FN + 1) + 2 * FB * FN) * sizeof(float);
 }
 
+template <class XT = float>
 __device__ __forceinline__ void pool_wgrad_finish_body(const t3d_pool_wgrad_finish_args& p, float* smem, int bx, int by) {
   float* gsm = smem;                               // [FK][K+1]
   float* wsm = gsm + FK * (p.K + 1);               // [K][FN]
@@ -236,7 +237,6 @@ __device__ __forceinline__ void pool_wgrad_finish_body(const t3d_pool_wgrad_fini
     const float sc = p.a.scale ? p.a.scale[k0 + k] : 1.f, sh = p.a.scale ? p.a.shift[k0 + k] : 0.f;
     const float floor_ = p.a.relu ? 0.f : -INFINITY;
     const size_t xk = (size_t)(p.a.coff + k0 + k);
-    const int dt = p.a.dtype;
     float g0 = 0.f, g1 = 0.f;
     for (int b0 = 0; b0 < p.B; b0 += FB) {
       __syncthreads();
@@ -253,8 +253,8 @@ __device__ __forceinline__ void pool_wgrad_finish_body(const t3d_pool_wgrad_fini
 #pragma unroll
       for (int bb = 0; bb < FB; ++bb) {              // 64 independent loads in flight
         const size_t rowbase = (size_t)min(b0 + bb, p.B - 1) * p.rows_per_frustum;
-        x0[bb] = ld_elem(p.a.x, xk + (rowbase + ais[bb * FN + q]) * p.a.ldx, dt);
-        x1[bb] = ld_elem(p.a.x, xk + (rowbase + ais[bb * FN + q + 8]) * p.a.ldx, dt);
+        x0[bb] = Elem<XT>::ld1(p.a.x, xk + (rowbase + ais[bb * FN + q]) * p.a.ldx);
+        x1[bb] = Elem<XT>::ld1(p.a.x, xk + (rowbase + ais[bb * FN + q + 8]) * p.a.ldx);
       }
 #pragma unroll
       for (int bb = 0; bb < FB; ++bb) {
