@@ -15,7 +15,8 @@ Once a few elements differ, the layers behind them see inputs that differ by ~1e
 the net the emulation can only be as close as a fraction of the bf16 noise itself (measured: logits 1-4e-2 against 6e-1 to the
 plain fp64 oracle).  Hence two kinds of bounds:
   * LAYER-WISE, tight: the stored bf16 outputs of the first two layers of the seg net (inputs identical up to batch-norm
-    statistics): at most 2 % of the elements differ, none by more than four bf16 spacings; the T3D_BF16 GEMM kernels one by one
+    statistics): at most 2 % of the elements differ, none by more than four bf16 spacings (plus one operand element rounded the other
+    way); the T3D_BF16 GEMM kernels one by one
     against torch matmuls of the same rounded operands: tests/test_kernels_bf16_gpu.py (one rounding of the output, nothing else);
   * END TO END: forward heads within 6e-2 * max(1, |ref|_max), loss within 1e-2 relative, moving statistics within 1e-2 *
     max(1, |ref|_max); every gradient tensor that carries at least 1 % of the gradient norm within 1.2e-1 relative L2, the median
@@ -72,7 +73,9 @@ def test_bf16_model_a_step_matches_the_bf16_emulating_oracle(hip_lib, B, N, seed
         spacing = 2.0 ** (torch.floor(torch.log2(big)) - 7)                # bf16 spacing at the element's magnitude
         diff = (got - ref).abs()
         frac = float((diff > 0).double().mean())
-        allowed = 4 * spacing + 1e-5 * float(ref.abs().max())              # + fp32 accumulation noise on elements near zero
+        # + fp32 accumulation noise on elements near zero + ONE operand element rounded the other way (the kernel forms
+        # x - centroid / relu(bn(y)) in fp32, the oracle in fp64: one bf16 spacing of an operand of magnitude <= 6 times a weight)
+        allowed = 4 * spacing + 1e-5 * float(ref.abs().max()) + 2.0 ** -7 * 6.0 * float(lay.w.abs().max())
         assert frac < 0.02 and bool((diff <= allowed).all()), (lay.scope, frac, float((diff / allowed).max()))
     e = m.end_points()
     worst = {}
