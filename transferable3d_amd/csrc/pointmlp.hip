@@ -535,9 +535,9 @@ constexpr int LDRH = BKH + 8;
 typedef bf16_t __attribute__((address_space(3))) lds_bf16_t;
 typedef s16x4 __attribute__((address_space(3))) lds_s16x4;
 
-template <int DIM, bool TYPE_R, class L>
+template <int DIM, bool TYPE_R, class L, int PF_ = 1>
 struct StagerH {
-  static constexpr int PF = 1;
+  static constexpr int PF = PF_;
   static constexpr int NV = DIM * (BKH / 4) / NT;
   static constexpr int LDC = DIM + 32;
   static constexpr int LDS_ELEMS = TYPE_R ? DIM * LDRH : BKH * LDC;
@@ -627,50 +627,67 @@ __device__ __forceinline__ void mma_steps_h(const bf16_t* As, const bf16_t* Bs, 
   }
 }
 
-// Two LDS stages, ONE register slot, one barrier per k-tile of BKH reduction indices (the structure of gemm_mainloop with
-// prefetch distance 1).  Iteration t: MFMAs of tile t from stage t&1; tile t+1 (its global loads were issued one iteration
-// earlier) is transformed, rounded to bf16 and written into the other stage between the MFMAs of the second half; then the loads
-// of tile t+2 are issued.  A second register slot was tried first: 350+ VGPRs per lane in the 128-wide kernels (spills).  One
-// slot is enough here because a k-tile is 16-32 KB per workgroup: two workgroups per CU keep >= 32 KB per CU in flight even
-// when every iteration waits out a full HBM round trip, which is more than the bandwidth-delay product per CU (~25 KB).
+// Two LDS stages, one barrier per k-tile of BKH reduction indices.  The A operand (the stream from HBM) has TWO register slots,
+// the B operand one.  Iteration t: tile t+1 (A: slot (t+1)&1, loaded during iterations t-2 and t-1; B: loaded during t-1) is
+// transformed, rounded to bf16 and written into the other LDS stage FIRST, its registers are refilled right away with A tile
+// t+3 and B tile t+2, then the MFMAs of tile t run from stage t&1.  A streamed load therefore has two full iterations to land
+// (HBM under load: > 2 us; with one slot every iteration waited out that round trip -- tools/trace_blocks.py: 2.1 us per
+// k-tile whatever the layer).  Both slots for both operands do not fit (350+ VGPRs in the 128-wide kernels).
+template <int S, int TM, int TN, class SA, class SB, class LA, class LB, bool AR, int DIMA, bool BR, int DIMB>
+__device__ __forceinline__ void h_iter(SA& sa, SB& sb, const LA& la, const LB& lb, bf16_t* smem, int cur, int red_a, int red_b,
+                                       int a0, int b0, f32x16 (&acc)[TM][TN], int tid) {
+  constexpr int STAGE = SA::LDS_ELEMS + SB::LDS_ELEMS;
+  constexpr int ST = BKH / 16;
+  const bf16_t* As = smem + cur * STAGE;
+  const bf16_t* Bs = As + SA::LDS_ELEMS;
+  bf16_t* An = smem + (cur ^ 1) * STAGE;
+  bf16_t* Bn = An + SA::LDS_ELEMS;
+  sa.template store<S>(la, An, tid);
+  sb.template store<0>(lb, Bn, tid);
+  __builtin_amdgcn_sched_barrier(0);
+  sa.template fetch<S>(la, red_a, tid);          // clamped by the caller: past the end the last tile is re-read, never used
+  sb.template fetch<0>(lb, red_b, tid);
+  __builtin_amdgcn_sched_barrier(0);
+  mma_steps_h<TM, TN, AR, DIMA, BR, DIMB, 0, ST>(As, Bs, a0, b0, acc, tid & 63, [](int) {});
+  __syncthreads();
+}
+
 template <int TM, int TN, class SA, class SB, class LA, class LB, bool AR, int DIMA, bool BR, int DIMB>
 __device__ __forceinline__ void gemm_mainloop_h(SA& sa, SB& sb, const LA& la, const LB& lb, float* smem_f, int red_begin,
                                                 int red_end, int a0, int b0, f32x16 (&acc)[TM][TN], int tid) {
+  static_assert(SA::PF == 2 && SB::PF == 1, "A: two register slots, B: one");
   bf16_t* smem = reinterpret_cast<bf16_t*>(smem_f);
   constexpr int STAGE = SA::LDS_ELEMS + SB::LDS_ELEMS;
   constexpr int ST = BKH / 16;
-  const int lane = tid & 63;
-  auto nofill = [](int) {};
+  const int last = red_end - BKH;                              // first reduction index of the last tile
+  auto clampr = [&](int r) { return min(r, last); };
+  // prologue: A tiles 0, 1 -> slots 0, 1; tile 0 into stage 0; then A tile 2 -> slot 0, B tile 1
   sa.template fetch<0>(la, red_begin, tid);
   sb.template fetch<0>(lb, red_begin, tid);
+  sa.template fetch<1>(la, clampr(red_begin + BKH), tid);
   sa.template store<0>(la, smem, tid);
   sb.template store<0>(lb, smem + SA::LDS_ELEMS, tid);
-  if (red_begin + BKH < red_end) { sa.template fetch<0>(la, red_begin + BKH, tid); sb.template fetch<0>(lb, red_begin + BKH, tid); }
+  sa.template fetch<0>(la, clampr(red_begin + 2 * BKH), tid);
+  sb.template fetch<0>(lb, clampr(red_begin + BKH), tid);
   __syncthreads();
-  int cur = 0;
-  for (int red = red_begin; red + BKH < red_end; red += BKH) {
-    const bf16_t* As = smem + cur * STAGE;
-    const bf16_t* Bs = As + SA::LDS_ELEMS;
-    bf16_t* An = smem + (cur ^ 1) * STAGE;
-    bf16_t* Bn = An + SA::LDS_ELEMS;
-    // Tile t+1 (loaded during the whole of iteration t-1) goes into the other stage FIRST and its registers are refilled with
-    // the loads of tile t+2 right away: a load has a full iteration to land (HBM under load: > 2 us), not half of one.  The
-    // staging VALU of this wave then overlaps the MFMAs of the SIMD's other wave (two workgroups per CU), its own MFMAs follow.
-    sa.template store<0>(la, An, tid);
-    sb.template store<0>(lb, Bn, tid);
-    __builtin_amdgcn_sched_barrier(0);
-    const int nxt = min(red + 2 * BKH, red_end - BKH);      // clamp instead of branching: the tile past the end re-reads the last
-    sa.template fetch<0>(la, nxt, tid);
-    sb.template fetch<0>(lb, nxt, tid);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_steps_h<TM, TN, AR, DIMA, BR, DIMB, 0, ST>(As, Bs, a0, b0, acc, lane, nofill);
-    __syncthreads();
+  int cur = 0, red = red_begin;
+  // iteration t (red = its first index) consumes A slot (t+1)&1: unrolled by two so that the slot is a compile-time constant
+  for (; red + 2 * BKH < red_end; red += 2 * BKH) {
+    h_iter<1, TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, cur, clampr(red + 3 * BKH), clampr(red + 2 * BKH), a0, b0,
+                                                         acc, tid);
+    cur ^= 1;
+    h_iter<0, TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, cur, clampr(red + 4 * BKH), clampr(red + 3 * BKH), a0, b0,
+                                                         acc, tid);
+    cur ^= 1;
+  }
+  if (red + BKH < red_end) {                     // two tiles left (workgroup-uniform)
+    h_iter<1, TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, cur, last, last, a0, b0, acc, tid);
     cur ^= 1;
   }
   {
     const bf16_t* As = smem + cur * STAGE;
     const bf16_t* Bs = As + SA::LDS_ELEMS;
-    mma_steps_h<TM, TN, AR, DIMA, BR, DIMB, 0, ST>(As, Bs, a0, b0, acc, lane, nofill);
+    mma_steps_h<TM, TN, AR, DIMA, BR, DIMB, 0, ST>(As, Bs, a0, b0, acc, tid & 63, [](int) {});
   }
   __syncthreads();
 }
@@ -684,7 +701,7 @@ struct PathF32 {
   typedef WLoaderT<float> WLX;           // ... when every tile lies inside the matrix (the fp32 path keeps its one loader)
   static constexpr bool BF16 = false;
   static constexpr int RED = BK;         // reduction depth of an LDS stage
-  template <int DIM, bool TYPE_R, class L, int PF> using Stg = Stager<DIM, TYPE_R, L, PF>;
+  template <int DIM, bool TYPE_R, class L, int PF, bool IS_A = false> using Stg = Stager<DIM, TYPE_R, L, PF>;
 };
 struct PathBF16 {
   typedef bf16_t T;
@@ -694,7 +711,9 @@ struct PathBF16 {
   typedef WLoaderT<bf16_t, true> WLX;
   static constexpr bool BF16 = true;
   static constexpr int RED = BKH;
-  template <int DIM, bool TYPE_R, class L, int PF> using Stg = StagerH<DIM, TYPE_R, L>;
+  // the first operand of every GEMM here is the [M, C] stream from HBM: two register slots (prefetch distance 2); the second
+  // (weights from L2, or the fatter dy operand of the weight gradient) one
+  template <int DIM, bool TYPE_R, class L, int PF, bool IS_A = false> using Stg = StagerH<DIM, TYPE_R, L, IS_A ? 2 : 1>;
 };
 template <class PR, int TM, int TN, class SA, class SB, class LA, class LB, bool AR, int DIMA, bool BR, int DIMB>
 __device__ __forceinline__ void run_mainloop(SA& sa, SB& sb, const LA& la, const LB& lb, float* smem, int red_begin, int red_end,
@@ -714,7 +733,7 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd(const t3d_pointm
   using YT = typename PR::T;
   constexpr int PF = BN == 64 ? T3D_PF_NARROW : T3D_PF_WIDE;
   using WL = std::conditional_t<LA::EXACT, typename PR::WLX, typename PR::WL>;      // K % 64 == 0: every weight tile is whole
-  using SA = typename PR::template Stg<BM, true, LA, PF>;
+  using SA = typename PR::template Stg<BM, true, LA, PF, true>;
   using SB = typename PR::template Stg<BN, false, WL, PF>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -1136,7 +1155,7 @@ __device__ __forceinline__ void dgrad_body(const t3d_pointmlp_dgrad_args& p, flo
   constexpr int PF = BN == 64 ? T3D_PF_NARROW : T3D_PF_WIDE;
   using LA = typename PR::template Dy<POOLED>;
   using WL = typename PR::WLX;            // bf16: K % 64 == 0 and N % 64 == 0 (launcher-checked), every tile is whole
-  using SA = typename PR::template Stg<BM, true, LA, PF>;
+  using SA = typename PR::template Stg<BM, true, LA, PF, true>;
   using SB = typename PR::template Stg<BN, true, WL, PF>;
 
   const int tid = threadIdx.x, wid = tid >> 6;
@@ -1175,7 +1194,7 @@ __device__ __forceinline__ void dgrad_gram_body(const t3d_pointmlp_dgrad_gram_ar
   constexpr int BM = 128, TM = 2, TN = BN / 64;
   using LA = typename PR::template Act<false, typename PR::T>;
   constexpr int PF = BN == 64 ? T3D_PF_NARROW : T3D_PF_GRAM128;
-  using SA = typename PR::template Stg<BM, true, LA, PF>;
+  using SA = typename PR::template Stg<BM, true, LA, PF, true>;
   using SB = typename PR::template Stg<BN, false, WLoader, PF>;
   const int tid = threadIdx.x, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
@@ -1211,7 +1230,7 @@ __device__ __forceinline__ void wgrad_body(const LA& la, const LB& lb, float* sl
                                            float* smem, int bid, int nblocks) {
   constexpr int TM = BMK / 64, TN = BN / 64;
   constexpr int PF = (BMK == 64 && BN == 64) ? T3D_PF_NARROW : T3D_PF_WIDE;
-  using SA = typename PR::template Stg<BMK, false, LA, PF>;
+  using SA = typename PR::template Stg<BMK, false, LA, PF, true>;
   using SB = typename PR::template Stg<BN, false, LB, PF>;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
