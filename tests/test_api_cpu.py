@@ -47,10 +47,12 @@ def test_reference_call_sequence_runs_a_training_step():
         logits_val, loss_val, center_val, _ = sess.run([pred[0], semi_loss, end_points['center'], train_op], feed_dict=feed)
         P1 = g.vars.state_dict()
         hyper = g.engine.hyper.detach().cpu().numpy().copy()
+        from model_check import product_decisions
+        forced = product_decisions(g.assembly)      # the ReLU / arg-max / mask branches this run took (see model_check)
 
     # oracle: same weights, same batch, one TF-form Adam step at lr(step 0), bn_decay(step 0)
     c = R.default_config()
-    loss, ep, grads, ema = R.model_a_forward_backward(P0, batch, c, bn_decay_val=R.bn_decay(0, B))
+    loss, ep, grads, ema = R.model_a_forward_backward(P0, batch, c, bn_decay_val=R.bn_decay(0, B), forced=forced)
     assert logits_val.shape == (B, N, 2)
     ref_l = ep['logits'].detach().numpy()
     assert np.abs(logits_val - ref_l).max() < 1e-4 * max(1.0, np.abs(ref_l).max())      # north-star tolerance, relative to the head's scale
