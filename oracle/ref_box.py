@@ -19,7 +19,7 @@ cases (offset squares, a square against its 45-degree turn, containment, disjoin
 """
 import numpy as np
 
-from transferable3d_amd.constants import MEAN_DIMS_ARR, NUM_HEADING_BIN
+from .ref_constants import MEAN_DIMS_ARR, NUM_HEADING_BIN
 
 
 def roty(t):

@@ -10,8 +10,7 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import 
 """
 import numpy as np
 
-from transferable3d_amd.constants import (NUM_HEADING_BIN as NH, NUM_SIZE_CLUSTER as NS, MEAN_DIMS_ARR,
-                                          ORIENT_ANCHORS, BN_EPS)
+from .ref_constants import NUM_HEADING_BIN as NH, NUM_SIZE_CLUSTER as NS, MEAN_DIMS_ARR, ORIENT_ANCHORS, BN_EPS
 
 MEAN32 = MEAN_DIMS_ARR.astype(np.float32).astype(np.float64)      # tf.constant(..., dtype=tf.float32)
 BINS32 = ORIENT_ANCHORS.astype(np.float32).astype(np.float64)

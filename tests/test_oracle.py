@@ -85,3 +85,17 @@ def test_golden_fixture_reproduces():
     assert np.abs(grads['box_est/fc1/weights'].numpy()[:8] - z['grad/box_est/fc1/weights']).max() < 1e-10
     for k, g in grads.items():
         assert abs(float(g.norm()) - float(z['gradnorm/' + k])) < 1e-9 * max(1.0, float(z['gradnorm/' + k])), k
+
+
+def test_oracle_constants_are_its_own_copy_and_agree_with_the_product():
+    """oracle/ref_constants.py restates roi_seg_box3d_dataset.py:18-35 independently of transferable3d_amd/constants.py (both are
+    also pinned on the reference's recorded values, tests/test_reference_vectors.py)."""
+    from oracle import ref_constants as RC
+    from transferable3d_amd import constants as PC
+    assert RC.type2class == PC.type2class and RC.NUM_HEADING_BIN == PC.NUM_HEADING_BIN and RC.NUM_SIZE_CLUSTER == PC.NUM_SIZE_CLUSTER
+    assert RC.NUM_CLASS == PC.NUM_CLASS and RC.BOX_OUT_DIMS == PC.BOX_OUT_DIMS and RC.BN_EPS == PC.BN_EPS
+    assert np.array_equal(RC.MEAN_DIMS_ARR, PC.MEAN_DIMS_ARR) and np.array_equal(RC.ORIENT_ANCHORS, PC.ORIENT_ANCHORS)
+    import oracle.ref_torch as RT, oracle.ref_np as RN, oracle.ref_box as RB, oracle.ref_data as RD
+    for mod in (RT, RN, RB, RD):
+        src = open(mod.__file__).read()
+        assert 'from transferable3d_amd' not in src and 'import transferable3d_amd' not in src, mod.__name__
