@@ -889,6 +889,164 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd(const t3d_pointm
 }
 
 // ---------------------------------------------------------------------------------------------
+// bf16 forward, activation-resident: one workgroup owns a 128-row tile for ALL column tiles
+// ---------------------------------------------------------------------------------------------
+// The T3D_BF16 kernels are VALU-issue-bound (2 300 VALU instructions per wave against 128 MFMAs in the generic
+// 512 -> 256 forward): with the MFMA 16x faster than in fp32, what a SIMD spends its time on is the staging pass -- widen, fma, max,
+// round, >= 3.5 operations per element -- and the generic kernel repeats that pass for every column tile of a row panel (8 times
+// for the 128 -> 1024 layer).  Here the activated, rounded input panel act(x)[128, K] is staged into LDS ONCE (K <= 256: at most four
+// R images), every load of it in flight together; then, per column tile, only bf16 weight tiles stream through a two-stage ring
+// (copied untouched, from L2) and the epilogue of the generic kernel runs on the tile.  The epilogue's LDS scratch (partial sums +
+// the bf16 output tile) aliases the weight ring: 2 x 64 x (BN + 32) x 2 bytes = 12 x BN x 4 + 128 x (BN + 8) x 2 exactly for BN = 128.
+template <int BN, int KT>      // KT = K / 64 k-tiles resident
+__global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd_res(const t3d_pointmlp_fwd_args p) {
+  constexpr int TM = 2, TN = BN / 64, ST = BKH / 16;
+  using LA = ActLoaderT<false, bf16_t>;
+  using WL = WLoaderT<bf16_t, true>;
+  using SA = StagerH<128, true, LA, KT>;
+  using SB = StagerH<BN, false, WL, 1>;
+  constexpr int A_ELEMS = SA::LDS_ELEMS, B_ELEMS = SB::LDS_ELEMS;
+  static_assert((size_t)2 * B_ELEMS * 2 >= (size_t)12 * BN * 4 + (size_t)128 * (BN + 8) * 2, "the epilogue scratch aliases the weight ring");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  bf16_t* panel = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* bst = panel + KT * A_ELEMS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1, l31 = lane & 31, h = lane >> 5;
+  const int tile_m = xcd_remap(blockIdx.x, gridDim.x), row0 = tile_m * 128;
+  const int b = row0 / p.rows_per_frustum;
+  const bool pool = p.pmax != nullptr, store_y = p.y != nullptr;
+
+  // ---- the activated input panel, once: all KT tiles' loads in flight, then transform + round + store ----
+  {
+    LA la{p.a, p.K, p.rows_per_frustum};
+    SA sa;
+    sa.init(la, row0, tid);
+    sa.template fetch<0>(la, 0, tid);
+    if constexpr (KT > 1) sa.template fetch<1>(la, BKH, tid);
+    if constexpr (KT > 2) { sa.template fetch<2>(la, 2 * BKH, tid); sa.template fetch<3>(la, 3 * BKH, tid); }
+    sa.template store<0>(la, panel, tid);
+    if constexpr (KT > 1) sa.template store<1>(la, panel + A_ELEMS, tid);
+    if constexpr (KT > 2) { sa.template store<2>(la, panel + 2 * A_ELEMS, tid); sa.template store<3>(la, panel + 3 * A_ELEMS, tid); }
+  }
+  unsigned keepbits = 0xffffffffu;          // keep flags of this lane's 32 rows (the same rows for every column tile)
+  if (pool && p.rowmask) {
+    keepbits = 0u;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        keepbits |= (p.rowmask[row0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] != 0.f ? 1u : 0u) << (tm * 16 + r);
+  }
+  const int rin_base = row0 - b * p.rows_per_frustum + wm * 64 + 4 * h;
+  float* red = reinterpret_cast<float*>(bst);
+  constexpr int YLD = BN + 8, CPR = BN / 8;
+  bf16_t* ytile = reinterpret_cast<bf16_t*>(red + 12 * BN);
+  bf16_t* yg = reinterpret_cast<bf16_t*>(p.y);
+
+  WL lb{p.w, p.N, p.K, p.N};
+  SB sb;
+  const int n_tiles = p.N / BN;
+  for (int nt = 0; nt < n_tiles; ++nt) {
+    const int col0 = nt * BN;
+    sb.init(lb, col0, tid);
+    sb.template fetch<0>(lb, 0, tid);
+    f32x16 acc[TM][TN];
+    zero_acc<TM, TN>(acc);
+    __syncthreads();                          // the panel is complete / the previous tile's epilogue has left the ring
+    sb.template store<0>(lb, bst, tid);
+    if constexpr (KT > 1) sb.template fetch<0>(lb, BKH, tid);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      if (t + 1 < KT) {                       // the next weight tile goes into the other stage first, then its registers are refilled
+        sb.template store<0>(lb, bst + ((t + 1) & 1) * B_ELEMS, tid);
+        if (t + 2 < KT) sb.template fetch<0>(lb, (t + 2) * BKH, tid);
+      }
+      mma_steps_h<TM, TN, true, 128, false, BN, 0, ST>(panel + t * A_ELEMS, bst + (t & 1) * B_ELEMS, wm * 64, wn * (BN / 2), acc, lane,
+                                                       [](int) {});
+      __syncthreads();
+    }
+    // ---- epilogue of the column tile (the generic kernel's, bf16 form) ----
+    float csum[TN], csq[TN], cmax[TN], cmin[TN];
+    int amax[TN], amin[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = col0 + wn * (BN / 2) + tn * 32 + l31;
+      float add = p.bias ? p.bias[col] : 0.f;
+      if (p.rowbias) add += p.rowbias[(size_t)b * p.N + col];
+      float s_ = 0.f, ss = 0.f, mx = -INFINITY, mn = INFINITY;
+      int ax = -1, an = -1;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = store_y ? Elem<bf16_t>::rnd(acc[tm][tn][r] + add) : acc[tm][tn][r] + add;
+          if (store_y) ytile[(wm * 64 + 4 * h + tm * 32 + (r & 3) + 8 * (r >> 2)) * YLD + wn * (BN / 2) + tn * 32 + l31] = (bf16_t)v;
+          s_ += v;
+          ss = fmaf(v, v, ss);
+          if (pool) {
+            const bool keep = (keepbits >> (tm * 16 + r)) & 1u;
+            const int rin = rin_base + tm * 32 + (r & 3) + 8 * (r >> 2);
+            const bool up = keep & (v > mx), dn = keep & (v < mn);
+            mx = up ? v : mx;
+            ax = up ? rin : ax;
+            mn = dn ? v : mn;
+            an = dn ? rin : an;
+          }
+        }
+      }
+      s_ += __shfl_xor(s_, 32, 64);
+      ss += __shfl_xor(ss, 32, 64);
+      if (pool) {
+        const float omx = __shfl_xor(mx, 32, 64), omn = __shfl_xor(mn, 32, 64);
+        const int oax = __shfl_xor(ax, 32, 64), oan = __shfl_xor(an, 32, 64);
+        if (oax >= 0 && (omx > mx || ax < 0 || (omx == mx && oax < ax))) { mx = omx; ax = oax; }
+        if (oan >= 0 && (omn < mn || an < 0 || (omn == mn && oan < an))) { mn = omn; an = oan; }
+      }
+      csum[tn] = s_; csq[tn] = ss; cmax[tn] = mx; cmin[tn] = mn; amax[tn] = ax; amin[tn] = an;
+    }
+    if (h == 0) {                             // (the k-loop's last barrier has freed the ring: `red` may be written)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int c = wn * (BN / 2) + tn * 32 + l31;
+        red[(0 * 2 + wm) * BN + c] = csum[tn];
+        red[(1 * 2 + wm) * BN + c] = csq[tn];
+        if (pool) {
+          red[(2 * 2 + wm) * BN + c] = cmax[tn];
+          red[(3 * 2 + wm) * BN + c] = cmin[tn];
+          reinterpret_cast<int*>(red)[(4 * 2 + wm) * BN + c] = amax[tn];
+          reinterpret_cast<int*>(red)[(5 * 2 + wm) * BN + c] = amin[tn];
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const int c = tid;
+      const size_t o = (size_t)tile_m * p.N + col0 + c;
+      p.psum[o] = red[(0 * 2 + 0) * BN + c] + red[(0 * 2 + 1) * BN + c];
+      p.psumsq[o] = red[(1 * 2 + 0) * BN + c] + red[(1 * 2 + 1) * BN + c];
+      if (pool) {
+        float mx = red[(2 * 2 + 0) * BN + c], mn = red[(3 * 2 + 0) * BN + c];
+        int ax = reinterpret_cast<int*>(red)[(4 * 2 + 0) * BN + c], an = reinterpret_cast<int*>(red)[(5 * 2 + 0) * BN + c];
+        const float mx1 = red[(2 * 2 + 1) * BN + c], mn1 = red[(3 * 2 + 1) * BN + c];
+        const int ax1 = reinterpret_cast<int*>(red)[(4 * 2 + 1) * BN + c], an1 = reinterpret_cast<int*>(red)[(5 * 2 + 1) * BN + c];
+        if (ax1 >= 0 && (ax < 0 || mx1 > mx)) { mx = mx1; ax = ax1; }
+        if (an1 >= 0 && (an < 0 || mn1 < mn)) { mn = mn1; an = an1; }
+        p.pmax[o] = mx; p.pmin[o] = mn; p.pamax[o] = ax; p.pamin[o] = an;
+      }
+    }
+    if (store_y) {
+#pragma unroll
+      for (int i = 0; i < 128 * CPR / NT; ++i) {
+        const int c = tid + NT * i, row = c / CPR, ch = c % CPR;
+        *reinterpret_cast<bf16x8*>(yg + (size_t)(row0 + row) * p.N + col0 + ch * 8) = *reinterpret_cast<const bf16x8*>(ytile + row * YLD + ch * 8);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // data gradient
 // ---------------------------------------------------------------------------------------------
 // Shared epilogue of the two data-gradient kernels: + add_in (+ per-column constant), ReLU mask of the producing
@@ -1675,6 +1833,25 @@ extern "C" int t3d_pointmlp_fwd(const t3d_pointmlp_fwd_args* a, t3d_stream_t str
     const bool wide = T3D_FORCE_TILE != 64 && a->N % 128 == 0 && (T3D_FORCE_TILE == 128 || (long)tiles_m * (a->N / 128) >= 512);
     const bool xh = a->a.dtype == T3D_BF16;
     if (xh && a->K % BKH) return T3D_ERR_SHAPE;      // a bf16 input is a layer output: whole 64-deep k-tiles (the loaders do not mask)
+    // activation-resident kernel: the input panel is transformed once for all column tiles (T3D_FWD_RES=0: the generic kernel)
+    static const bool use_res = []() { const char* e = getenv("T3D_FWD_RES"); return !(e && e[0] == '0'); }();
+    // K = 256 (a 74 KB panel: one workgroup per CU) measured SLOWER than the generic kernel (256 -> 512: 257 vs 194 us, 256 -> 128:
+    // 82 vs 61 us at M = 262144); K <= 128 keeps two workgroups per CU: 128 -> 1024 272 -> 219 us, 64 -> 512 144 -> 107 us,
+    // 128 -> 256 73 -> 67 us, the small layers unchanged.  T3D_FWD_RES=2 forces K = 256 on.
+    static const bool res_k256 = []() { const char* e = getenv("T3D_FWD_RES"); return e && e[0] == '2'; }();
+    if (use_res && xh && !sub && (a->K == 64 || a->K == 128 || (a->K == 256 && res_k256))) {
+      const dim3 grid(tiles_m);
+#define T3D_FWD_RES(BN_, KT_)                                                                                    \
+  do {                                                                                                          \
+    constexpr size_t lds = ((size_t)KT_ * 128 * LDRH + 2 * (size_t)BKH * (BN_ + 32)) * 2;                        \
+    launch_lds(k_pointmlp_fwd_res<BN_, KT_>, grid, lds, s, *a);                                                 \
+  } while (0)
+      if (a->N % 128 == 0) { if (a->K == 64) T3D_FWD_RES(128, 1); else if (a->K == 128) T3D_FWD_RES(128, 2); else T3D_FWD_RES(128, 4); }
+      else { if (a->K == 64) T3D_FWD_RES(64, 1); else if (a->K == 128) T3D_FWD_RES(64, 2); else T3D_FWD_RES(64, 4); }
+#undef T3D_FWD_RES
+      T3D_CHECK_LAUNCH();
+      return T3D_OK;
+    }
     const dim3 grid(tiles_m * (a->N / (wide ? 128 : 64)));
     const size_t lds = wide ? lds_fwd_h(128) : lds_fwd_h(64);
 #define T3D_FWD_H(BN_)                                                                                          \
