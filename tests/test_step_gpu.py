@@ -52,8 +52,9 @@ def test_data_parallel_step_on_one_rank_rccl_equals_the_single_replica_step(hip_
     try:
         B, N, C = 8, 256, 4
         out = {}
-        for mode in ('single', 'bucketed', 'flat'):
+        for mode in ('single', 'bucketed', 'flat', 'one_graph_inline', 'one_graph_overlapped'):
             pg = None if mode == 'single' else dist.group.WORLD
+            os.environ['T3D_DP_ONE_GRAPH'] = {'one_graph_inline': '1', 'one_graph_overlapped': '2'}.get(mode, '0')
             g, model, step, loss = build_training_step(Runtime(lib=hip_lib), 'A', B, N, C, process_group=pg, force_dist=mode != 'single',
                                                        flat_allreduce=mode == 'flat', seed=3, use_hip_graph=True)
             for k in range(4):
@@ -61,8 +62,11 @@ def test_data_parallel_step_on_one_rank_rccl_equals_the_single_replica_step(hip_
                 step.run()
             torch.cuda.synchronize()
             out[mode] = (g.vars.params[:g.vars.used].clone(), float(loss), step.n_graph_segments())
-        assert out['single'][2] == 1 and out['bucketed'][2] == 6 and out['flat'][2] == 2, [v[2] for v in out.values()]
-        assert torch.equal(out['single'][0], out['bucketed'][0]) and torch.equal(out['single'][0], out['flat'][0])
-        assert out['single'][1] == out['bucketed'][1] == out['flat'][1]
+        # segments: one graph for a single replica; six around three collectives; two around one; ONE with the collectives captured
+        # inside (in line, or on RCCL's stream as a branch of the graph beside the rest of the backward)
+        assert [out[m][2] for m in ('single', 'bucketed', 'flat', 'one_graph_inline', 'one_graph_overlapped')] == [1, 6, 2, 1, 1]
+        for m in out:
+            assert torch.equal(out['single'][0], out[m][0]) and out['single'][1] == out[m][1], m
     finally:
+        os.environ.pop('T3D_DP_ONE_GRAPH', None)
         dist.destroy_process_group()

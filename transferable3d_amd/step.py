@@ -35,7 +35,7 @@ class TrainStep:
         want = use_hip_graph if use_hip_graph is not None else self.on_gpu
         self.want_graph = bool(want) and self.on_gpu
         if one_graph is None:
-            one_graph = os.environ.get('T3D_DP_ONE_GRAPH', '0') == '1'
+            one_graph = os.environ.get('T3D_DP_ONE_GRAPH', '0') in ('1', '2')
         self.one_graph = one_graph
         self.cache = {}            # generate_masks -> list of program items with captured graphs
         self.n_runs = 0
@@ -121,14 +121,21 @@ class TrainStep:
         s = self._capture_stream
         graphs = {}
         if self.dist and self.one_graph:
-            # the collectives captured in line (RCCL supports stream capture): one replay per step, no overlap
+            # ONE graph per step with the collectives captured inside (RCCL supports stream capture).  T3D_DP_ONE_GRAPH=1: in line
+            # on the capture stream (no overlap); =2: asynchronously on RCCL's stream, which joins the capture through the event
+            # edges torch records around a collective, so that the replayed graph has the bucket's all-reduce on a branch beside the
+            # rest of the backward (no host work and no graph-launch gap between the segments).
+            overlap = os.environ.get('T3D_DP_ONE_GRAPH', '0') == '2'
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=s, capture_error_mode='thread_local'):
-                for kind, x in prog:
-                    if kind == 'run':
-                        x.run()
-                    elif kind == 'allreduce':
-                        self._allreduce(x, async_op=False)
+                if overlap:
+                    self._run_program(prog)
+                else:
+                    for kind, x in prog:
+                        if kind == 'run':
+                            x.run()
+                        elif kind == 'allreduce':
+                            self._allreduce(x, async_op=False)
             return [('run_graph', g)], {0: g}
         for k, (kind, x) in enumerate(prog):
             if kind == 'run':
