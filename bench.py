@@ -99,6 +99,9 @@ def gemm_work(name, a):
         wl, wf, _ = gemm_work('t3d_pointmlp_wgrad', w)
         M, K, N = d.M, d.K, d.N
         by = es(d.dtype) * (2 * M * N + M * K * (2 + (0 if _null(d.add_in) else 1))) + 4.0 * 2 * K * N
+        if d.dtype == 1 and w.a.dtype == 1 and K in (64, 128) and N in (64, 128) and w.rows_per_split % 128 == 0 and \
+                M // w.rows_per_split >= min(256, M // 128) and os.environ.get('T3D_BWD1', '1') != '0':
+            return 'k_pointmlp_bwd1<%d,%d>' % (K, N), df + wf, by      # one-pass form
         return 'k_pointmlp_bwd<%s,%s>' % (dl[dl.index('<') + 1:-1], wl[wl.index('<') + 1:-1]), df + wf, by
     if name == 't3d_pointmlp_dgrad_gram':
         # (the sparse arg-max rows S behind add_live are read only where a row received a hit -- a data-dependent few percent of
@@ -167,7 +170,7 @@ def profile_kernels(plans, steps, repeat=4):
             d[3] += nbytes
             if flops:
                 a0 = (arg[1] if name == 't3d_pool_bwd_stage2' else arg[0]) if isinstance(arg, tuple) else arg
-                dd = detail.setdefault('%s M%d K%d N%d' % (label, a0.M, a0.K, getattr(a0, 'N', a0.K)), [0.0, 0, flops])
+                dd = detail.setdefault('%s M%d K%d N%d' % (label, a0.M, a0.K, getattr(a0, 'N', a0.K)), [0.0, 0, flops, nbytes])
                 dd[0] += dt
                 dd[1] += 1
     return acc, detail
@@ -386,8 +389,10 @@ def main():
                 dims = ' '.join('%s=%d' % (f, getattr(arg, f)) for f in ('M', 'K', 'N', 'B') if arg is not None and hasattr(arg, f))
                 sys.stderr.write('%3d %-28s %-28s %8.1f us\n' % (ci, name, dims, t_ * 1e6))
         if args.gemm_detail:
-            for k, (t_, n_, f_) in sorted(detail.items(), key=lambda kv: -kv[1][0]):
-                sys.stderr.write('%-44s x%d  %8.1f us  %6.1f TF/s\n' % (k, n_ // args.profile_steps, t_ / n_ * 1e6, f_ / (t_ / n_) / 1e12))
+            for k, (t_, n_, f_, b_) in sorted(detail.items(), key=lambda kv: -kv[1][0]):
+                sys.stderr.write('%-52s x%d  %8.1f us  %6.1f TF/s  %6.0f GB/s algorithmic (%.2f of the HBM peak; %.1f us at 6.3 TB/s)\n'
+                                 % (k, n_ // args.profile_steps, t_ / n_ * 1e6, f_ / (t_ / n_) / 1e12, b_ / (t_ / n_) / 1e9,
+                                    b_ / (t_ / n_) / 1e9 / (HBM_PEAK_TBS * 1e3), b_ / 6.3e6))
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'A':
         cpu = cpu_baseline(args, batch)
 

@@ -92,11 +92,16 @@ def test_bf16_forward(hip_lib, M, K, N, rpf, xbf, pool):
         assert bool(((pamax >= 0) == has).all())
 
 
-@pytest.mark.parametrize('M,K,N,rpf,addin', [(512, 64, 128, 256, False), (256, 64, 512, 128, True), (384, 512, 256, 128, False),
-                                             (256, 256, 128, 128, True), (65536, 128, 128, 1024, False)])
-def test_bf16_fused_backward(hip_lib, M, K, N, rpf, addin):
+@pytest.mark.parametrize('M,K,N,rpf,addin,rps_', [
+    (512, 64, 128, 256, False, 0), (256, 64, 512, 128, True, 0), (384, 512, 256, 128, False, 0), (256, 256, 128, 128, True, 0),
+    (65536, 128, 128, 1024, False, 0),
+    # the one-pass form (t3d_bwd_plan's split, or any split of whole 128-row tiles that leaves >= min(256, M/128) workgroups)
+    (512, 64, 64, 256, True, -1), (1024, 128, 64, 256, False, -1), (768, 64, 128, 128, True, -1), (65536, 128, 128, 1024, True, -1),
+    (131072, 128, 128, 2048, False, 512), (65536, 64, 64, 2048, True, 256), (32768, 128, 64, 1024, False, 128)])
+def test_bf16_fused_backward(hip_lib, M, K, N, rpf, addin, rps_):
     """t3d_pointmlp_bwd: dX = dy . W^T with the ReLU mask / batch-norm-backward partials of the producing layer, dW = a^T dy as
-    row-split slabs; dy = c0*dz + c1*y + c2 formed from bf16 dz, y while loading."""
+    row-split slabs; dy = c0*dz + c1*y + c2 formed from bf16 dz, y while loading.  rps_: 0 = t3d_wgrad_plan's split (the split
+    form unless the shape is one-pass eligible and small), -1 = t3d_bwd_plan's, > 0 = that many rows per split."""
     g = torch.Generator(device='cpu').manual_seed(M + K + N + 1)
     T = M // 128
     dz = (torch.randn(M, N, generator=g) * 1e-2).to(BF).to(DEV)
@@ -113,9 +118,16 @@ def test_bf16_fused_backward(hip_lib, M, K, N, rpf, addin):
     out = torch.zeros(M, K, dtype=BF, device=DEV)
     ps1, ps2 = torch.zeros(T, K, device=DEV), torch.zeros(T, K, device=DEV)
     rps, tk, tn = C.c_int(0), C.c_int(0), C.c_int(0)
-    assert hip_lib.t3d_wgrad_plan(M, K, N, C.byref(rps), C.byref(tk), C.byref(tn)) == 0
+    if rps_ == 0:
+        assert hip_lib.t3d_wgrad_plan(M, K, N, C.byref(rps), C.byref(tk), C.byref(tn)) == 0
+    elif rps_ < 0:
+        one = C.c_int(0)
+        assert hip_lib.t3d_bwd_plan(M, K, N, abi.BF16, C.byref(rps), C.byref(one)) == 0
+        assert one.value == 1 and rps.value % 128 == 0 and M // rps.value >= min(256, M // 128)
+    else:
+        rps.value = rps_
     ns = M // rps.value
-    slabs = torch.zeros(ns, K, N, device=DEV)
+    slabs = torch.full((ns, K, N), float('nan'), device=DEV)
     dy = abi.DySrc(fptr(dz), fptr(y), fptr(coef), iptr(None), fptr(None), abi.BF16)
     d = abi.PointMlpDgradArgs()
     d.dy, d.w, d.add_in = dy, fptr(w16), fptr(add if addin else None)

@@ -8,7 +8,7 @@ if not os.path.exists(so):
 lib = ctypes.CDLL(so)
 vp = ctypes.c_void_p
 lib.mb_stage.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
-lib.mb_chain.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp]
+lib.mb_chain.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, ctypes.c_int]
 s = torch.cuda.Stream()
 big = torch.zeros(64 << 20, device='cuda')       # 256 MB: flushes L2 / MALL between replays when touched
 
@@ -30,7 +30,7 @@ def timed(fn, reps=50):
     return (time.perf_counter() - t0) / reps * 1e6
 
 
-for G, width, stride in ((16, 4096, 1), (16, 4096, 8), (32, 4096, 1), (64, 1024, 1), (16, 65536, 1)):
+for G, width, stride, mode in [(G, w, 1, m) for (G, w) in ((16, 4096), (32, 1024), (16, 65536)) for m in (0, 1, 2)]:
     n = 12
     buf = torch.zeros(2 * G * width, device='cuda')
     cnt = torch.zeros(4, dtype=torch.int32, device='cuda')
@@ -42,7 +42,7 @@ for G, width, stride in ((16, 4096, 1), (16, 4096, 8), (32, 4096, 1), (64, 1024,
             assert lib.mb_stage(a, b, G, width, stride, st) == 0
 
     def chain(st):
-        assert lib.mb_chain(buf.data_ptr(), G, width, n, cnt.data_ptr(), stride, st) == 0
+        assert lib.mb_chain(buf.data_ptr(), G, width, n, cnt.data_ptr(), stride, st, mode) == 0
 
     def one(st):
         assert lib.mb_stage(buf.data_ptr(), buf.data_ptr() + G * width * 4, G, width, stride, st) == 0
@@ -53,5 +53,5 @@ for G, width, stride in ((16, 4096, 1), (16, 4096, 8), (32, 4096, 1), (64, 1024,
     torch.cuda.synchronize()
     ok = bool((buf[:G * width] == float(n)).all()) if n % 2 == 0 else bool((buf[G * width:] == float(n)).all())
     t_l, t_c, t_1 = timed(launches), timed(chain), timed(one)
-    print(f'G={G} width={width} xcd_stride={stride}: {n} launches {t_l:.1f} us ({t_l / n:.2f}/stage), one chain launch {t_c:.1f} us '
+    print(f'G={G} width={width} mode={mode}: {n} launches {t_l:.1f} us ({t_l / n:.2f}/stage), one chain launch {t_c:.1f} us '
           f'(stage+barrier {(t_c - t_1) / (n - 1):.2f} us), single launch {t_1:.1f} us, chain result correct: {ok}')

@@ -16,7 +16,7 @@ from transferable3d_amd.abi import fptr
 def main():
     lib = abi.load(os.environ.get('T3D_LIB', 'tools/libt3d_trace.so'))
     lib.t3d_set_trace_fc.argtypes = [C.c_void_p]
-    dev, B = 'cuda', 32
+    dev, B = 'cuda', int(os.environ.get('T3D_B', '32'))
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     junk = torch.zeros(16 << 20, device=dev)
     for K, N in ((512, 512), (1024, 512), (256, 256), (256, 67), (128, 3)):

@@ -9,24 +9,28 @@ namespace {
 
 // 256 threads = 16 channels x 16 tile groups: short, unrolled, independent loads (the 64-iteration serial
 // loop of the first version was pure L2 latency: 19 us per launch in profiles/r01_baseline).
-constexpr int FC_CH = 16, FC_GR = 16;
+// At the row counts of config 4 (2048 row tiles) a 16-group block walks 128 tiles per thread -- eight dependent memory round trips
+// (13.7 us per launch, profiles/r02_bf16_v2): above T3D_FIN_BIG tiles (default 512) the launchers take the GR = 64 instantiation
+// (1024 threads, two round trips; only group 0 walks the 64 LDS partials): fwd finalize 195 -> 163 us per step, bwd 124 -> 112 at
+// B=128 N=2048 (same-box A/B).  Up to 512 tiles GR stays 16, so the results at the sizes of configs 1-3 do not change by a bit.
+constexpr int FC_CH = 16, FC_GR = 16, FC_GR_BIG = 64;
 
 // Sixteen tiles per quantity are in flight per thread (32 loads for the two-quantity reductions): at 256 tiles the whole
 // reduction is ONE memory round trip instead of four.
-template <int NQ>
+template <int NQ, int GR = FC_GR>
 __device__ __forceinline__ void tile_sums(const float* const (&src)[NQ], int n_tiles, int N, int c, int grp, bool ok,
                                           double (&acc)[NQ]) {
   constexpr int U = 16;
 #pragma unroll
   for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
   if (!ok) return;
-  for (int t0 = grp; t0 < n_tiles; t0 += U * FC_GR) {
+  for (int t0 = grp; t0 < n_tiles; t0 += U * GR) {
     float v[NQ][U];
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int t = t0 + u * FC_GR;
+        const int t = t0 + u * GR;
         const float x = src[q][(size_t)min(t, n_tiles - 1) * N + c];     // clamped: no branch around the load
         v[q][u] = t < n_tiles ? x : 0.f;
       }
@@ -40,13 +44,16 @@ __device__ __forceinline__ void tile_sums(const float* const (&src)[NQ], int n_t
   }
 }
 
+template <int GR = FC_GR>
 __device__ __forceinline__ double group_reduce(double v, double (*red)[FC_CH], int grp, int cl) {
   __syncthreads();
   red[grp][cl] = v;
   __syncthreads();
   double s = 0.0;
+  if (GR == FC_GR || grp == 0) {      // only group 0 uses the sum; with 64 groups the other 1008 threads' reads are pure LDS traffic
 #pragma unroll
-  for (int g = 0; g < FC_GR; ++g) s += red[g][cl];
+    for (int g = 0; g < GR; ++g) s += red[g][cl];
+  }
   return s;
 }
 
@@ -89,8 +96,9 @@ __device__ __forceinline__ void pool_pick(const t3d_bn_fwd_finalize_args& p, int
                  p.ld_pooled, p.argidx, p.ysel);
 }
 
-__global__ __launch_bounds__(256) void k_bn_fwd_finalize(const t3d_bn_fwd_finalize_args p) {
-  __shared__ double red[FC_GR][FC_CH];
+template <int GR>
+__global__ __launch_bounds__(GR * FC_CH) void k_bn_fwd_finalize(const t3d_bn_fwd_finalize_args p) {
+  __shared__ double red[GR][FC_CH];
   const int cl = threadIdx.x & (FC_CH - 1), grp = threadIdx.x / FC_CH;
   const int c = blockIdx.x * FC_CH + cl;
   const bool ok = c < p.N;
@@ -100,9 +108,9 @@ __global__ __launch_bounds__(256) void k_bn_fwd_finalize(const t3d_bn_fwd_finali
     const float gam = p.gamma[cc], bet = p.beta[cc], mm = p.moving_mean[cc], mv = p.moving_var[cc], dec = p.decay[0];
     const float* const src[2] = {p.psum, p.psumsq};
     double acc[2];
-    tile_sums<2>(src, p.n_tiles, p.N, c, grp, ok, acc);
-    const double s = group_reduce(acc[0], red, grp, cl);
-    const double ss = group_reduce(acc[1], red, grp, cl);
+    tile_sums<2, GR>(src, p.n_tiles, p.N, c, grp, ok, acc);
+    const double s = group_reduce<GR>(acc[0], red, grp, cl);
+    const double ss = group_reduce<GR>(acc[1], red, grp, cl);
     if (grp == 0 && ok) {
       const double n = (double)p.count;
       const double mean = s / n;
@@ -135,7 +143,7 @@ __global__ __launch_bounds__(256) void k_bn_fwd_finalize(const t3d_bn_fwd_finali
     __syncthreads();
     if (ok) {
       const float sc = s_sc[cl], sh = s_sh[cl];
-      for (int b = grp; b < p.pool_B; b += FC_GR) pool_pick(p, b, c, sc, sh);
+      for (int b = grp; b < p.pool_B; b += GR) pool_pick(p, b, c, sc, sh);
     }
   }
 }
@@ -149,8 +157,9 @@ __global__ __launch_bounds__(256) void k_pool_finalize(const t3d_pool_finalize_a
                  p.argidx, p.ysel);
 }
 
-__global__ __launch_bounds__(256) void k_bn_bwd_finalize(const t3d_bn_bwd_finalize_args p) {
-  __shared__ double red[FC_GR][FC_CH];
+template <int GR>
+__global__ __launch_bounds__(GR * FC_CH) void k_bn_bwd_finalize(const t3d_bn_bwd_finalize_args p) {
+  __shared__ double red[GR][FC_CH];
   const int cl = threadIdx.x & (FC_CH - 1), grp = threadIdx.x / FC_CH;
   const int c = blockIdx.x * FC_CH + cl;
   const bool ok = c < p.N;
@@ -159,9 +168,9 @@ __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const t3d_bn_bwd_finali
   double acc[2] = {0.0, 0.0};   // sum dz, sum dz*y
   if (p.psum_dz != nullptr) {
     const float* const src[2] = {p.psum_dz, p.psum_dzy};
-    tile_sums<2>(src, p.n_tiles, p.N, c, grp, ok, acc);
+    tile_sums<2, GR>(src, p.n_tiles, p.N, c, grp, ok, acc);
   } else if (ok) {
-    for (int b = grp; b < p.B; b += FC_GR) {
+    for (int b = grp; b < p.B; b += GR) {
       const float live = p.pooled[(size_t)b * p.ld_pooled + c] > 0.f ? 1.f : 0.f;
       const float g = p.dpool_in[(size_t)b * p.ld_dpool_in + c] * live;
       p.dpool[(size_t)b * p.N + c] = g;
@@ -169,8 +178,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const t3d_bn_bwd_finali
       acc[1] += (double)g * (double)p.ysel[(size_t)b * p.N + c];
     }
   }
-  const double s1 = group_reduce(acc[0], red, grp, cl);
-  const double s2 = group_reduce(acc[1], red, grp, cl);
+  const double s1 = group_reduce<GR>(acc[0], red, grp, cl);
+  const double s2 = group_reduce<GR>(acc[1], red, grp, cl);
   if (grp == 0 && ok) {
     if (p.frozen) {
       p.coef[c] = p.scale[c];
@@ -348,12 +357,20 @@ __global__ __launch_bounds__(256) void k_dropout_mask(float* __restrict__ mask, 
 
 extern "C" int t3d_abi_version(void) { return 1; }
 
+static int fin_big_tiles() {      // T3D_FIN_BIG: tile count above which the 64-group finalizers run (0 = never)
+  static const int v = []() { const char* e = getenv("T3D_FIN_BIG"); const int x = e ? atoi(e) : 512; return x > 0 ? x : (1 << 30); }();
+  return v;
+}
+
 extern "C" int t3d_bn_fwd_finalize(const t3d_bn_fwd_finalize_args* a, t3d_stream_t stream) {
   if (!a || !a->gamma || !a->beta || !a->moving_mean || !a->moving_var || !a->scale || !a->shift || !a->mean ||
       !a->invstd)
     return T3D_ERR_ARG;
   if (a->is_training && (!a->psum || !a->psumsq || !a->decay || a->count <= 0)) return T3D_ERR_ARG;
-  T3D_LAUNCH(k_bn_fwd_finalize, dim3((a->N + FC_CH - 1) / FC_CH), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+  if (a->is_training && a->n_tiles > fin_big_tiles())
+    T3D_LAUNCH(k_bn_fwd_finalize<FC_GR_BIG>, dim3((a->N + FC_CH - 1) / FC_CH), dim3(FC_GR_BIG * FC_CH), 0, static_cast<hipStream_t>(stream), *a);
+  else
+    T3D_LAUNCH(k_bn_fwd_finalize<FC_GR>, dim3((a->N + FC_CH - 1) / FC_CH), dim3(FC_GR * FC_CH), 0, static_cast<hipStream_t>(stream), *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -373,7 +390,10 @@ extern "C" int t3d_bn_bwd_finalize(const t3d_bn_bwd_finalize_args* a, t3d_stream
   if (a->psum_dz == nullptr && (!a->dpool_in || !a->pooled || !a->ysel || !a->dpool)) return T3D_ERR_ARG;
   if (a->psum_dz != nullptr && !a->psum_dzy) return T3D_ERR_ARG;
   if (a->frozen ? !a->scale : (!a->gamma || !a->mean || !a->invstd)) return T3D_ERR_ARG;
-  T3D_LAUNCH(k_bn_bwd_finalize, dim3((a->N + FC_CH - 1) / FC_CH), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+  if (a->psum_dz != nullptr && a->n_tiles > fin_big_tiles())
+    T3D_LAUNCH(k_bn_bwd_finalize<FC_GR_BIG>, dim3((a->N + FC_CH - 1) / FC_CH), dim3(FC_GR_BIG * FC_CH), 0, static_cast<hipStream_t>(stream), *a);
+  else
+    T3D_LAUNCH(k_bn_bwd_finalize<FC_GR>, dim3((a->N + FC_CH - 1) / FC_CH), dim3(FC_GR * FC_CH), 0, static_cast<hipStream_t>(stream), *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

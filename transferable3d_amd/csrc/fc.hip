@@ -380,16 +380,21 @@ __global__ __launch_bounds__(NTH) void k_fc_bwd(const t3d_fc_bwd_args p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const int k = kb * 32 + l31;
-    for (int g8 = 0; g8 < RB * 4; ++g8) {
-      float a[4], b[4];
+    // the block's input operand is requested 32 loads at a time ahead of their MFMAs: with four loads per dependent round trip,
+    // B = 128 rows walked 16 round trips per block (k_fc_bwd<4>: 33 us per launch, profiles/r02_bf16_v2); all 64 at once spill
+    constexpr int GB = RB * 4 < 8 ? RB * 4 : 8;
+#pragma unroll 1
+    for (int g0 = 0; g0 < RB * 4; g0 += GB) {
+      float a[GB][4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int rr = 8 * g8 + 4 * h + i;
-        a[i] = src.at_nb(rr, k);
-        b[i] = dy_s[rr * LDT + l31];
-      }
+      for (int u = 0; u < GB; ++u)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc, 0, 0, 0);
+        for (int i = 0; i < 4; ++i) a[u][i] = src.at_nb(8 * (g0 + u) + 4 * h + i, k);
+#pragma unroll
+      for (int u = 0; u < GB; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i], dy_s[(8 * (g0 + u) + 4 * h + i) * LDT + l31], acc, 0, 0, 0);
     }
     store_block(kb, acc);
   }

@@ -1463,6 +1463,265 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_bwd(const t3d_pointm
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// one-pass backward of a dense bf16 layer with K, N in {64, 128}
+// ---------------------------------------------------------------------------------------------
+// The split form above reads dz, y and the layer input twice (once per kind of workgroup) and transforms every element twice --
+// and the bf16 kernels are bound by exactly that element-wise VALU work and by HBM.  Here ONE workgroup owns
+// a run of 128-row tiles (rows_per_split rows): per tile it builds dy = c0*dz + c1*y + c2 and a = relu(x*scale + shift) ONCE as
+// LDS images, runs dW += a^T dy (accumulators live in registers across all its tiles) and dX = dy W^T from those images -- the
+// weights of the data gradient sit in registers as MFMA fragments for the whole kernel -- and finishes dX (rounding, ReLU mask of
+// the producing layer, its batch-norm-backward partial sums) against the raw input tile it already holds in LDS.  Every input
+// element is read from HBM once and transformed once.  One fp32 slab per workgroup leaves at the end.  The arithmetic per element
+// is that of the split form (same operand rounding, same MFMA step order along n and along the rows of a tile), so dX is
+// bit-identical and dW differs only by where the row splits fall.
+//
+// ONE image serves both GEMMs: [128 rows][DIM] bf16, no padding, the 16-byte slot index of row m XOR-ed with swz(m):
+//   * dX needs dy with the reduction index n contiguous per lane (one ds_read_b128, 16 lanes = 16 rows per bank pass): rows are
+//     256 B (or 128 B) apart, so without the swizzle all 16 would hit the same slot; swz is a bijection of the row's low four bits;
+//   * dW needs both images through the transposing read (ds_read_b64_tr_b16; reduction index = row): a half-wave addresses 4 rows
+//     x 64 B, and swz's high bits move the four rows to four different 64-byte bank segments.
+template <int DIM>
+__device__ __forceinline__ int swz(int m) {
+  return DIM == 128 ? (((m & 3) << 2) | ((m >> 2) & 3)) : ((((m >> 1) & 1) << 2) | ((m >> 2) & 3));
+}
+template <int DIM>
+__device__ __forceinline__ int img_off(int m, int col) {      // bf16 element offset of (row m, column col)
+  return m * DIM + ((((col >> 3) ^ swz<DIM>(m))) << 3) + (col & 7);
+}
+// operand rows r0 + (lane & 31), reduction indices 16 st + 8 h .. + 7 along the image row
+template <int DIM>
+__device__ __forceinline__ bf16x8 frag_r1(const bf16_t* img, int r0, int st, int lane) {
+  return *reinterpret_cast<const bf16x8*>(img + img_off<DIM>(r0 + (lane & 31), 16 * st + 8 * (lane >> 5)));
+}
+// operand columns c0 + (lane & 31), reduction indices = image rows 16 st + 8 h .. + 7 (transposing read, see frag_h)
+template <int DIM>
+__device__ __forceinline__ bf16x8 frag_c1(const bf16_t* img, int c0, int st, int lane) {
+  const int row = 16 * st + 8 * (lane >> 5) + ((lane & 15) >> 2), col = c0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + img_off<DIM>(row, col)));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + img_off<DIM>(row + 4, col)));
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+// 512 threads, one workgroup per CU.  Wave roles (wv = 0..7), 32 x 32 MFMA tiles:
+//   dW (K/32 x N/32 tiles): 16 tiles -> two k-tiles x one n-tile per wave; 8 tiles -> one per wave; 4 tiles (64 x 64) -> one per
+//      wave PAIR, each wave reducing over half of the tile's 128 rows (the pair's sums meet in LDS once, before the slab is written)
+//   dX (4 x K/32 tiles):    K = 128 -> a 64-row half x one k-tile per wave; K = 64 -> a 32-row block x one k-tile per wave
+// The raw bf16 chunks of tile t+1 (dz, y, x: 48 VGPRs) are requested right after tile t's images are complete and land under its
+// MFMAs and epilogue: 96 KB in flight per CU, which is what the HBM share of a CU needs at ~2 us of latency.
+// LDS: D [128][N], A [128][K] (activated), X [2][128][K] (the producer's RAW output: mask + statistics of the epilogue; the
+// masked gradient overwrites it element by element and leaves as 16-byte rows; two copies so that tile t+1 is staged while slow
+// threads still copy tile t out), 2 x RG x K floats of cross-wave statistics.  Two barriers per tile.
+constexpr int NT1 = 512;
+template <int K, int N>
+__global__ __launch_bounds__(NT1) void k_pointmlp_bwd1(const t3d_pointmlp_dgrad_args d, const t3d_pointmlp_wgrad_args w) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  bf16_t* Dimg = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* Aimg = Dimg + 128 * N;
+  bf16_t* Ximg = Aimg + 128 * K;
+  constexpr int XLD = K + 8;                           // X is never an MFMA operand: plain rows, 16 bytes of padding
+  float* red = reinterpret_cast<float*>(Ximg + 2 * 128 * XLD);
+  constexpr int TNn = N / 32, TILES = (K / 32) * TNn;
+  constexpr int TMW = TILES == 16 ? 2 : 1;
+  constexpr int RS = TILES >= 8 ? 1 : 8 / TILES;
+  constexpr int TMD = K == 128 ? 2 : 1, RG = K == 128 ? 2 : 4;
+  constexpr int STN = N / 16, STW = 8 / RS;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int wt = TILES == 16 ? 0 : wv % TILES;
+  const int kt0 = TILES == 16 ? (wv >> 2) * 2 : wt / TNn, nt = TILES == 16 ? (wv & 3) : wt % TNn;
+  const int rs = TILES >= 8 ? 0 : wv / TILES;
+  const int rg = K == 128 ? (wv >> 2) : (wv >> 1), ct = K == 128 ? (wv & 3) : (wv & 1);
+  const int xr0 = rg * (K == 128 ? 64 : 32);
+  const int split = blockIdx.x;
+  const int row_begin = split * w.rows_per_split, n_tiles = w.rows_per_split / 128;
+
+  const bf16_t* dzg = reinterpret_cast<const bf16_t*>(d.dy.dz);
+  const bf16_t* yg = reinterpret_cast<const bf16_t*>(d.dy.y);
+  const bf16_t* xg = reinterpret_cast<const bf16_t*>(w.a.x);
+  const bf16_t* wg = reinterpret_cast<const bf16_t*>(d.w);
+  const bf16_t* addg = reinterpret_cast<const bf16_t*>(d.add_in);
+  bf16_t* outg = reinterpret_cast<bf16_t*>(d.out);
+  const bool mask = d.prev_y != nullptr, stats = mask && d.psum_dz != nullptr, add = d.add_in != nullptr;      // uniform
+
+  // weights of the data gradient as B fragments: B[n][k] = W[k][n], lane (k = l31, h) holds n = 16 st + 8 h .. + 7
+  bf16x8 wf[STN];
+#pragma unroll
+  for (int st = 0; st < STN; ++st)
+    wf[st] = *reinterpret_cast<const bf16x8*>(wg + (size_t)(ct * 32 + l31) * N + 16 * st + 8 * h);
+
+  // staging maps: a thread owns one 8-column chunk (the same for every row it touches) of each tensor
+  constexpr int CPD = N / 8, RPD = NT1 / CPD, NID = 128 / RPD;
+  constexpr int CPA = K / 8, RPA = NT1 / CPA, NIA = 128 / RPA;
+  const int chd = tid % CPD, rd = tid / CPD, cha = tid % CPA, ra = tid / CPA;
+  const float floor_ = w.a.relu ? 0.f : -INFINITY;
+  const float psc = mask ? d.prev_scale[ct * 32 + l31] : 0.f, psh = mask ? d.prev_shift[ct * 32 + l31] : 0.f;
+
+  bf16x8 rz[NID], ry[NID], rx[NIA];
+  auto load_raw = [&](int row0) {
+#pragma unroll
+    for (int i = 0; i < NID; ++i) {
+      const size_t go = (size_t)(row0 + rd + RPD * i) * N + chd * 8;
+      rz[i] = *reinterpret_cast<const bf16x8*>(dzg + go);
+      ry[i] = *reinterpret_cast<const bf16x8*>(yg + go);
+    }
+#pragma unroll
+    for (int i = 0; i < NIA; ++i)
+      rx[i] = *reinterpret_cast<const bf16x8*>(xg + (size_t)(row0 + ra + RPA * i) * w.a.ldx + w.a.coff + cha * 8);
+  };
+
+  f32x16 accw[TMW];
+#pragma unroll
+  for (int tm = 0; tm < TMW; ++tm)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accw[tm][r] = 0.f;
+
+  load_raw(row_begin);
+  for (int t = 0; t < n_tiles; ++t) {
+    const int row0 = row_begin + t * 128;
+    bf16_t* Xc = Ximg + (t & 1) * 128 * XLD;
+    // registers -> images: dy = c0 * dz + c1 * y + c2 and a = relu(x * scale + shift), rounded to bf16 after the fp32 arithmetic
+    // (as the split form's loaders do); x itself.  The per-column constants are re-read per tile (L1): 40 VGPRs not held.
+    float c0[8], c1[8], c2[8], sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; e += 4) {
+      const float4 a0 = *reinterpret_cast<const float4*>(d.dy.coef + chd * 8 + e);
+      const float4 a1 = *reinterpret_cast<const float4*>(d.dy.coef + N + chd * 8 + e);
+      const float4 a2 = *reinterpret_cast<const float4*>(d.dy.coef + 2 * N + chd * 8 + e);
+      c0[e] = a0.x; c0[e + 1] = a0.y; c0[e + 2] = a0.z; c0[e + 3] = a0.w;
+      c1[e] = a1.x; c1[e + 1] = a1.y; c1[e + 2] = a1.z; c1[e + 3] = a1.w;
+      c2[e] = a2.x; c2[e + 1] = a2.y; c2[e + 2] = a2.z; c2[e + 3] = a2.w;
+      sc[e] = sc[e + 1] = sc[e + 2] = sc[e + 3] = 1.f;
+      sh[e] = sh[e + 1] = sh[e + 2] = sh[e + 3] = 0.f;
+      if (w.a.scale != nullptr) {
+        const float4 b0 = *reinterpret_cast<const float4*>(w.a.scale + cha * 8 + e);
+        const float4 b1 = *reinterpret_cast<const float4*>(w.a.shift + cha * 8 + e);
+        sc[e] = b0.x; sc[e + 1] = b0.y; sc[e + 2] = b0.z; sc[e + 3] = b0.w;
+        sh[e] = b1.x; sh[e + 1] = b1.y; sh[e + 2] = b1.z; sh[e + 3] = b1.w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NID; ++i) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)fmaf(c0[e], (float)rz[i][e], fmaf(c1[e], (float)ry[i][e], c2[e]));
+      *reinterpret_cast<bf16x8*>(Dimg + img_off<N>(rd + RPD * i, chd * 8)) = o;
+    }
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)fmaxf(fmaf((float)rx[i][e], sc[e], sh[e]), floor_);
+      *reinterpret_cast<bf16x8*>(Aimg + img_off<K>(ra + RPA * i, cha * 8)) = o;
+      *reinterpret_cast<bf16x8*>(Xc + (ra + RPA * i) * XLD + cha * 8) = rx[i];
+    }
+    __syncthreads();
+    if (t + 1 < n_tiles) load_raw(row0 + 128);      // workgroup-uniform
+
+    // dW += a^T dy: reduction over the tile's rows (this wave's share of them)
+#pragma unroll
+    for (int s_ = 0; s_ < STW; ++s_) {
+      const int st = rs * STW + s_;
+      bf16x8 fa[TMW];
+#pragma unroll
+      for (int tm = 0; tm < TMW; ++tm) fa[tm] = frag_c1<K>(Aimg, (kt0 + tm) * 32, st, lane);
+      const bf16x8 fb = frag_c1<N>(Dimg, nt * 32, st, lane);
+#pragma unroll
+      for (int tm = 0; tm < TMW; ++tm) accw[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm], fb, accw[tm], 0, 0, 0);
+    }
+    // dX = dy W^T
+    f32x16 accd[TMD];
+#pragma unroll
+    for (int tm = 0; tm < TMD; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accd[tm][r] = 0.f;
+#pragma unroll
+    for (int st = 0; st < STN; ++st) {
+      bf16x8 fa[TMD];
+#pragma unroll
+      for (int tm = 0; tm < TMD; ++tm) fa[tm] = frag_r1<N>(Dimg, xr0 + tm * 32, st, lane);
+#pragma unroll
+      for (int tm = 0; tm < TMD; ++tm) accd[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm], wf[st], accd[tm], 0, 0, 0);
+    }
+    constexpr int ALD = K + 8;
+    if (add) {      // dense add_in tile through LDS (the D image is dead once every wave is past its MFMAs)
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NIA; ++i)
+        *reinterpret_cast<bf16x8*>(Dimg + (ra + RPA * i) * ALD + cha * 8) =
+            *reinterpret_cast<const bf16x8*>(addg + (size_t)(row0 + ra + RPA * i) * K + cha * 8);
+      __syncthreads();
+    }
+    // epilogue: (+ add_in,) round, ReLU mask of the producing layer, its batch-norm-backward partial sums, gradient -> X in place
+    float s1 = 0.f, s2 = 0.f;
+    auto epi = [&](auto mask_c, auto add_c) {      // compile-time flags: no branch around the per-element LDS reads
+      constexpr bool MASK = decltype(mask_c)::value, ADD = decltype(add_c)::value;
+      bf16_t* xb = Xc + (xr0 + 4 * h) * XLD + ct * 32 + l31;
+      const bf16_t* ab = Dimg + (xr0 + 4 * h) * ALD + ct * 32 + l31;
+#pragma unroll
+      for (int tm = 0; tm < TMD; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ro = tm * 32 + (r & 3) + 8 * (r >> 2);
+          const float ypv = MASK ? (float)xb[ro * XLD] : 0.f;
+          const float ad = ADD ? (float)ab[ro * ALD] : 0.f;
+          float v = Elem<bf16_t>::rnd(accd[tm][r] + ad);
+          if (MASK) {
+            if (!(fmaf(ypv, psc, psh) > 0.f)) v = 0.f;
+            s1 += v;
+            s2 = fmaf(v, ypv, s2);
+          }
+          xb[ro * XLD] = (bf16_t)v;
+        }
+    };
+    if (mask) { if (add) epi(std::true_type(), std::true_type()); else epi(std::true_type(), std::false_type()); }
+    else { if (add) epi(std::false_type(), std::true_type()); else epi(std::false_type(), std::false_type()); }
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (stats && h == 0) {
+      red[(0 * RG + rg) * K + ct * 32 + l31] = s1;
+      red[(1 * RG + rg) * K + ct * 32 + l31] = s2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NIA; ++i)
+      *reinterpret_cast<bf16x8*>(outg + (size_t)(row0 + ra + RPA * i) * K + cha * 8) =
+          *reinterpret_cast<const bf16x8*>(Xc + (ra + RPA * i) * XLD + cha * 8);
+    if (stats && tid < K) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int g = 0; g < RG; ++g) { t1 += red[(0 * RG + g) * K + tid]; t2 += red[(1 * RG + g) * K + tid]; }
+      const size_t o = (size_t)(row0 / 128) * K + tid;
+      d.psum_dz[o] = t1;
+      d.psum_dzy[o] = t2;
+    }
+    // no barrier here: the next tile is staged into D, A (every wave is past its reads) and the OTHER X copy; `red` is written
+    // again only behind the next tile's first barrier, which every reader above reaches first
+  }
+
+  if (RS == 2) {      // 64 x 64: the two row halves of a tile meet
+    float* cmb = reinterpret_cast<float*>(Dimg);
+    __syncthreads();
+    if (rs == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cmb[(wt * 16 + r) * 64 + lane] = accw[0][r];
+    }
+    __syncthreads();
+    if (rs == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accw[0][r] += cmb[(wt * 16 + r) * 64 + lane];
+    }
+  }
+  if (rs == 0) {
+    float* slab = w.slabs + (size_t)split * K * N;
+    const int col = nt * 32 + l31;
+#pragma unroll
+    for (int tm = 0; tm < TMW; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        slab[(size_t)((kt0 + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * N + col] = accw[tm][r];
+  }
+}
+
 // Gram-form backward of a pooled layer, stage 1: the three jobs that need nothing but the layer input and the
 // batch-norm-backward coefficients -- Gram slabs a^T a, column sums of a, and the P / rowconst slabs (+ wc) -- in one launch.
 template <int GT, class PR = PathF32>
@@ -1804,6 +2063,7 @@ constexpr size_t lds_epi2(int bn) { return (size_t)12 * bn * sizeof(float) + 2 *
 constexpr size_t lds_max(size_t a, size_t b) { return a > b ? a : b; }
 constexpr size_t lds_dgrad_h(int bn) { return lds_max(2 * (size_t)(128 * LDRH + bn * LDRH) * 2, lds_epi2(bn)); }
 constexpr size_t lds_wgrad_h(int bmk, int bn) { return 2 * (size_t)BKH * (bmk + 32 + bn + 32) * 2; }
+constexpr size_t lds_bwd1(int k, int n) { return (size_t)128 * (n + k + 2 * (k + 8)) * 2 + (size_t)2 * 4 * k * 4; }      // D, A, 2 x X images + the statistics scratch
 
 bool dtype_ok(int dt) { return dt == T3D_F32 || dt == T3D_BF16; }
 bool act_ok(const t3d_act_src& a, int K) {
@@ -1974,6 +2234,29 @@ extern "C" int t3d_wgrad_plan(int M, int K, int N, int* rows_per_split, int* til
   return T3D_OK;
 }
 
+// Plan of the fused backward (t3d_pointmlp_bwd): bf16 layers with K, N in {64, 128} take the one-pass kernel -- one workgroup per
+// run of 128-row tiles, one 512-thread workgroup per CU (fewer, longer runs mean fewer K x N slabs) --
+// everything else the split form with t3d_wgrad_plan's row split.
+static bool bwd1_shape(int M, int K, int N, int dtype) {
+  static const bool on = []() { const char* e = getenv("T3D_BWD1"); return !(e && e[0] == '0'); }();
+  return on && dtype == T3D_BF16 && (K == 64 || K == 128) && (N == 64 || N == 128) && M % 128 == 0;
+}
+extern "C" int t3d_bwd_plan(int M, int K, int N, int dtype, int* rows_per_split, int* one_pass) {
+  if (!rows_per_split || !one_pass) return T3D_ERR_ARG;
+  *one_pass = 0;
+  if (bwd1_shape(M, K, N, dtype)) {
+    static const long target = []() { const char* e = getenv("T3D_BWD1_WGS"); return e ? atol(e) : 256L; }();
+    const int tiles = M / 128;
+    int per = 1;
+    while (tiles / per > target && tiles % (per * 2) == 0) per *= 2;
+    *rows_per_split = 128 * per;
+    *one_pass = 1;
+    return T3D_OK;
+  }
+  int tk = 0, tn = 0;
+  return t3d_wgrad_plan(M, K, N, rows_per_split, &tk, &tn);
+}
+
 static int check_wgrad(const t3d_pointmlp_wgrad_args* a) {
   if (!a || !a->slabs || !act_ok(a->a, a->K) || !dy_ok(a->dy)) return T3D_ERR_ARG;
   const int red = a->dy.dtype == T3D_BF16 ? BKH : BK;
@@ -2107,6 +2390,26 @@ extern "C" int t3d_pointmlp_bwd(const t3d_pointmlp_dgrad_args* d, const t3d_poin
   if (d->dtype != w->dy.dtype || w->a.dtype != d->dtype) return T3D_ERR_ARG;      // one element type per layer
   const bool bf16 = d->dtype == T3D_BF16;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  {   // one-pass form: eligible layer and a row split that leaves enough workgroups (t3d_bwd_plan's does)
+    const int rps = w->rows_per_split, tiles = d->M / 128;
+    if (bwd1_shape(d->M, d->K, d->N, d->dtype) && rps % 128 == 0 && d->M / rps >= (tiles < 256 ? tiles : 256) &&
+        w->a.dtype == T3D_BF16 && w->a.ldx % 8 == 0 && w->a.coff % 8 == 0 && (w->a.scale == nullptr) == (w->a.shift == nullptr)) {
+      const dim3 grid1(d->M / rps);
+#define T3D_BWD1(K_, N_)                                                                         \
+  do {                                                                                           \
+    auto kern = k_pointmlp_bwd1<K_, N_>;                                                         \
+    allow_lds(reinterpret_cast<const void*>(kern), lds_bwd1(K_, N_));                            \
+    T3D_LAUNCH(kern, grid1, dim3(NT1), lds_bwd1(K_, N_), s, *d, *w);                              \
+  } while (0)
+      if (d->K == 128 && d->N == 128) T3D_BWD1(128, 128);
+      else if (d->K == 128) T3D_BWD1(128, 64);
+      else if (d->N == 128) T3D_BWD1(64, 128);
+      else T3D_BWD1(64, 64);
+#undef T3D_BWD1
+      T3D_CHECK_LAUNCH();
+      return T3D_OK;
+    }
+  }
   int tk = 0, tn = 0;
   wgrad_tile(w, &tk, &tn);
   const int n_w = ((w->K + tk - 1) / tk) * (w->N / tn) * (w->M / w->rows_per_split);

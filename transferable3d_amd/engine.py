@@ -338,6 +338,13 @@ def wgrad_rows_per_split(lib, M, K, N):
     return rps.value
 
 
+def bwd_rows_per_split(lib, M, K, N, dtype):
+    """Row split of the fused backward (t3d_bwd_plan): the one-pass form's split where the library takes that form."""
+    rps, one = C.c_int(0), C.c_int(0)
+    abi.check(lib.t3d_bwd_plan(M, K, N, dtype, C.byref(rps), C.byref(one)), 't3d_bwd_plan')
+    return rps.value
+
+
 class PointLayer:
     """tf_util.conv2d 1x1 (+ batch_norm + ReLU) over M = B*N point rows (tf_util.py:1258-1323)."""
 
@@ -604,9 +611,12 @@ class PointLayer:
         with plan.side():
             self._wgrad(plan)
 
-    def _wgrad_args(self):
+    def _wgrad_args(self, fused=False):
         g = self.g
-        rps = wgrad_rows_per_split(g.rt.lib, self.M, self.K, self.N)
+        if fused and self.src.dtype == self.dt:
+            rps = bwd_rows_per_split(g.rt.lib, self.M, self.K, self.N, self.dt)
+        else:
+            rps = wgrad_rows_per_split(g.rt.lib, self.M, self.K, self.N)
         n_slabs = self.M // rps
         goff = g.vars.offset(self.w_name) + self.w_row0 * self.N
         soff = g.ws.reserve(goff, self.K * self.N, n_slabs)
@@ -651,7 +661,7 @@ class PointLayer:
         if self.gram or self.pool or not FUSE_BWD:
             self.wgrad(plan)
             return self.dgrad(plan, out_raw=out_raw, add_in=add_in)
-        d, w = self._dgrad_args(out_raw, add_in), self._wgrad_args()
+        d, w = self._dgrad_args(out_raw, add_in), self._wgrad_args(fused=True)
         fn, dref, wref = self.g.rt.lib.t3d_pointmlp_bwd, C.byref(d), C.byref(w)
         plan.keep.extend([d, w])
         plan.calls.append(('t3d_pointmlp_bwd', lambda s: fn(dref, wref, s), (d, w)))
