@@ -99,7 +99,7 @@ def gemm_work(name, a):
         wl, wf, _ = gemm_work('t3d_pointmlp_wgrad', w)
         M, K, N = d.M, d.K, d.N
         by = es(d.dtype) * (2 * M * N + M * K * (2 + (0 if _null(d.add_in) else 1))) + 4.0 * 2 * K * N
-        if d.dtype == 1 and w.a.dtype == 1 and K in (64, 128) and N in (64, 128) and w.rows_per_split % 128 == 0 and \
+        if d.dtype == 1 and w.a.dtype == 1 and ((K in (64, 128) and N in (64, 128)) or (K, N) in ((256, 128), (128, 256))) and w.rows_per_split % 128 == 0 and \
                 M // w.rows_per_split >= min(256, M // 128) and os.environ.get('T3D_BWD1', '1') != '0':
             return 'k_pointmlp_bwd1<%d,%d>' % (K, N), df + wf, by      # one-pass form
         return 'k_pointmlp_bwd<%s,%s>' % (dl[dl.index('<') + 1:-1], wl[wl.index('<') + 1:-1]), df + wf, by

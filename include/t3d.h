@@ -205,7 +205,7 @@ int t3d_pointmlp_bwd(const t3d_pointmlp_dgrad_args* dgrad, const t3d_pointmlp_wg
 /* Recommended row split (and the tile the launcher will then use) for a K x N weight gradient over M rows. */
 int t3d_wgrad_plan(int M, int K, int N, int* rows_per_split, int* tile_k, int* tile_n);
 /* Recommended row split for t3d_pointmlp_bwd.  bf16 layers (dtype = T3D_BF16 for dy, the input and the output) with K and N in
- * {64, 128} run ONE-PASS (*one_pass = 1): one workgroup per split walks its 128-row tiles, reads dz, y and the input once, keeps
+ * {64, 128}, or K x N = 256 x 128 / 128 x 256, run ONE-PASS (*one_pass = 1): one workgroup per split walks its 128-row tiles, reads dz, y and the input once, keeps
  * dW in registers across the tiles and writes one slab at the end; t3d_pointmlp_bwd takes that form whenever the shape is eligible
  * and M / rows_per_split >= min(256, M / 128).  Everything else: t3d_wgrad_plan's split (*one_pass = 0).  The results are those of
  * the two separate calls up to the fp32 summation order. */

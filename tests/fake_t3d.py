@@ -604,7 +604,7 @@ class FakeLib:
 
     def t3d_bwd_plan(self, M, K, N, dtype, rps, one):
         one._obj.value = 0
-        if dtype == 1 and K in (64, 128) and N in (64, 128) and M % 128 == 0:
+        if dtype == 1 and ((K in (64, 128) and N in (64, 128)) or (K, N) in ((256, 128), (128, 256))) and M % 128 == 0:
             tiles, per = M // 128, 1
             while tiles // per > 512 and tiles % (per * 2) == 0:
                 per *= 2

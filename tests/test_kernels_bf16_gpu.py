@@ -97,7 +97,8 @@ def test_bf16_forward(hip_lib, M, K, N, rpf, xbf, pool):
     (65536, 128, 128, 1024, False, 0),
     # the one-pass form (t3d_bwd_plan's split, or any split of whole 128-row tiles that leaves >= min(256, M/128) workgroups)
     (512, 64, 64, 256, True, -1), (1024, 128, 64, 256, False, -1), (768, 64, 128, 128, True, -1), (65536, 128, 128, 1024, True, -1),
-    (131072, 128, 128, 2048, False, 512), (65536, 64, 64, 2048, True, 256), (32768, 128, 64, 1024, False, 128)])
+    (131072, 128, 128, 2048, False, 512), (65536, 64, 64, 2048, True, 256), (32768, 128, 64, 1024, False, 128),
+    (512, 256, 128, 256, True, -1), (1024, 128, 256, 256, False, -1), (65536, 256, 128, 1024, False, 256), (65536, 128, 256, 2048, True, 256)])
 def test_bf16_fused_backward(hip_lib, M, K, N, rpf, addin, rps_):
     """t3d_pointmlp_bwd: dX = dy . W^T with the ReLU mask / batch-norm-backward partials of the producing layer, dW = a^T dy as
     row-split slabs; dy = c0*dz + c1*y + c2 formed from bf16 dz, y while loading.  rps_: 0 = t3d_wgrad_plan's split (the split

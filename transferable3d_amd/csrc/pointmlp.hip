@@ -1464,7 +1464,7 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_bwd(const t3d_pointm
 }
 
 // ---------------------------------------------------------------------------------------------
-// one-pass backward of a dense bf16 layer with K, N in {64, 128}
+// one-pass backward of a dense bf16 layer with K, N in {64, 128}, or 256 x 128 / 128 x 256
 // ---------------------------------------------------------------------------------------------
 // The split form above reads dz, y and the layer input twice (once per kind of workgroup) and transforms every element twice --
 // and the bf16 kernels are bound by exactly that element-wise VALU work and by HBM.  Here ONE workgroup owns
@@ -1483,7 +1483,7 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_bwd(const t3d_pointm
 //     x 64 B, and swz's high bits move the four rows to four different 64-byte bank segments.
 template <int DIM>
 __device__ __forceinline__ int swz(int m) {
-  return DIM == 128 ? (((m & 3) << 2) | ((m >> 2) & 3)) : ((((m >> 1) & 1) << 2) | ((m >> 2) & 3));
+  return DIM >= 128 ? (((m & 3) << 2) | ((m >> 2) & 3)) : ((((m >> 1) & 1) << 2) | ((m >> 2) & 3));
 }
 template <int DIM>
 __device__ __forceinline__ int img_off(int m, int col) {      // bf16 element offset of (row m, column col)
@@ -1503,37 +1503,45 @@ __device__ __forceinline__ bf16x8 frag_c1(const bf16_t* img, int c0, int st, int
   return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-// 512 threads, one workgroup per CU.  Wave roles (wv = 0..7), 32 x 32 MFMA tiles:
-//   dW (K/32 x N/32 tiles): 16 tiles -> two k-tiles x one n-tile per wave; 8 tiles -> one per wave; 4 tiles (64 x 64) -> one per
-//      wave PAIR, each wave reducing over half of the tile's 128 rows (the pair's sums meet in LDS once, before the slab is written)
-//   dX (4 x K/32 tiles):    K = 128 -> a 64-row half x one k-tile per wave; K = 64 -> a 32-row block x one k-tile per wave
-// The raw bf16 chunks of tile t+1 (dz, y, x: 48 VGPRs) are requested right after tile t's images are complete and land under its
-// MFMAs and epilogue: 96 KB in flight per CU, which is what the HBM share of a CU needs at ~2 us of latency.
-// LDS: D [128][N], A [128][K] (activated), X [2][128][K] (the producer's RAW output: mask + statistics of the epilogue; the
+// 512 threads, one workgroup per CU, row tiles of BM rows (128; 64 for the 256-wide layers, whose images would not fit).
+// Wave roles (wv = 0..7), 32 x 32 MFMA tiles:
+//   dW (K/32 x N/32 tiles): 32 tiles -> 2 x 2 per wave; 16 -> two k-tiles x one n-tile; 8 -> one per wave; 4 (64 x 64) -> one per
+//      wave PAIR, each wave reducing over half of the tile's rows (the pair's sums meet in LDS once, before the slab is written)
+//   dX (BM/32 x K/32 tiles): the K/32 column tiles go to 8 / RG waves each ... RG = 8 / (K/32) row groups of BM / RG rows
+// The raw bf16 chunks of tile t+1 (dz, y, x: 32-48 VGPRs) are requested right after tile t's images are complete and land under
+// its MFMAs and epilogue: ~96 KB in flight per CU, which is what the HBM share of a CU needs at ~2 us of latency.
+// LDS: D [BM][N], A [BM][K] (activated), X [2][BM][K + 8] (the producer's RAW output: mask + statistics of the epilogue; the
 // masked gradient overwrites it element by element and leaves as 16-byte rows; two copies so that tile t+1 is staged while slow
-// threads still copy tile t out), 2 x RG x K floats of cross-wave statistics.  Two barriers per tile.
+// threads still copy tile t out), 2 x 2 x RG x K floats of cross-wave statistics (the batch-norm partials are per 128 rows: two
+// 64-row tiles share one).  Two barriers per tile.
 constexpr int NT1 = 512;
-template <int K, int N>
+template <int K, int N, int BM>
 __global__ __launch_bounds__(NT1) void k_pointmlp_bwd1(const t3d_pointmlp_dgrad_args d, const t3d_pointmlp_wgrad_args w) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   bf16_t* Dimg = reinterpret_cast<bf16_t*>(smem);
-  bf16_t* Aimg = Dimg + 128 * N;
-  bf16_t* Ximg = Aimg + 128 * K;
+  bf16_t* Aimg = Dimg + BM * N;
+  bf16_t* Ximg = Aimg + BM * K;
   constexpr int XLD = K + 8;                           // X is never an MFMA operand: plain rows, 16 bytes of padding
-  float* red = reinterpret_cast<float*>(Ximg + 2 * 128 * XLD);
-  constexpr int TNn = N / 32, TILES = (K / 32) * TNn;
-  constexpr int TMW = TILES == 16 ? 2 : 1;
+  constexpr int CT = K / 32, RG = 8 / CT, TMD = BM / (32 * RG);      // dX: column tiles, row groups, row tiles per wave
+  static_assert(CT == 2 || CT == 4 || CT == 8, "K in {64, 128, 256}");
+  static_assert(TMD >= 1 && TMD * 32 * RG == BM, "dX tiles do not cover the row tile");
+  float* red = reinterpret_cast<float*>(Ximg + 2 * BM * XLD);      // [BM == 64 ? 2 : 1][2][RG][K]
+  constexpr int TNn = N / 32, TILES = CT * TNn;
+  static_assert(TILES == 4 || TILES == 8 || TILES == 16 || TILES == 32, "K x N tiles");
+  constexpr int TMW = TILES >= 16 ? 2 : 1, TNW = TILES == 32 ? 2 : 1;
   constexpr int RS = TILES >= 8 ? 1 : 8 / TILES;
-  constexpr int TMD = K == 128 ? 2 : 1, RG = K == 128 ? 2 : 4;
-  constexpr int STN = N / 16, STW = 8 / RS;
+  static_assert(RS == 1 || BM == 128, "row-split pairs: 128-row tiles only");
+  constexpr int STN = N / 16, STW = BM / 16 / RS;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, h = lane >> 5;
-  const int wt = TILES == 16 ? 0 : wv % TILES;
-  const int kt0 = TILES == 16 ? (wv >> 2) * 2 : wt / TNn, nt = TILES == 16 ? (wv & 3) : wt % TNn;
+  const int wt = TILES >= 16 ? 0 : wv % TILES;
+  // dW tile coordinates (in 32-wide tiles): 32 tiles: wave grid (K/64) x (N/64); 16: (K/64) x (N/32); else one tile
+  const int kt0 = TILES == 32 ? (wv / (N / 64)) * 2 : TILES == 16 ? (wv / TNn) * 2 : wt / TNn;
+  const int nt0 = TILES == 32 ? (wv % (N / 64)) * 2 : TILES == 16 ? (wv % TNn) : wt % TNn;
   const int rs = TILES >= 8 ? 0 : wv / TILES;
-  const int rg = K == 128 ? (wv >> 2) : (wv >> 1), ct = K == 128 ? (wv & 3) : (wv & 1);
-  const int xr0 = rg * (K == 128 ? 64 : 32);
+  const int rg = wv / CT, ct = wv % CT;
+  const int xr0 = rg * (BM / RG);
   const int split = blockIdx.x;
-  const int row_begin = split * w.rows_per_split, n_tiles = w.rows_per_split / 128;
+  const int row_begin = split * w.rows_per_split, n_tiles = w.rows_per_split / BM;
 
   const bf16_t* dzg = reinterpret_cast<const bf16_t*>(d.dy.dz);
   const bf16_t* yg = reinterpret_cast<const bf16_t*>(d.dy.y);
@@ -1550,8 +1558,9 @@ __global__ __launch_bounds__(NT1) void k_pointmlp_bwd1(const t3d_pointmlp_dgrad_
     wf[st] = *reinterpret_cast<const bf16x8*>(wg + (size_t)(ct * 32 + l31) * N + 16 * st + 8 * h);
 
   // staging maps: a thread owns one 8-column chunk (the same for every row it touches) of each tensor
-  constexpr int CPD = N / 8, RPD = NT1 / CPD, NID = 128 / RPD;
-  constexpr int CPA = K / 8, RPA = NT1 / CPA, NIA = 128 / RPA;
+  constexpr int CPD = N / 8, RPD = NT1 / CPD, NID = BM / RPD;
+  constexpr int CPA = K / 8, RPA = NT1 / CPA, NIA = BM / RPA;
+  static_assert(NID >= 1 && NIA >= 1, "row tile shorter than one staging pass");
   const int chd = tid % CPD, rd = tid / CPD, cha = tid % CPA, ra = tid / CPA;
   const float floor_ = w.a.relu ? 0.f : -INFINITY;
   const float psc = mask ? d.prev_scale[ct * 32 + l31] : 0.f, psh = mask ? d.prev_shift[ct * 32 + l31] : 0.f;
@@ -1569,64 +1578,74 @@ __global__ __launch_bounds__(NT1) void k_pointmlp_bwd1(const t3d_pointmlp_dgrad_
       rx[i] = *reinterpret_cast<const bf16x8*>(xg + (size_t)(row0 + ra + RPA * i) * w.a.ldx + w.a.coff + cha * 8);
   };
 
-  f32x16 accw[TMW];
-#pragma unroll
-  for (int tm = 0; tm < TMW; ++tm)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accw[tm][r] = 0.f;
+  f32x16 accw[TMW][TNW];
+  zero_acc<TMW, TNW>(accw);
 
   load_raw(row_begin);
   for (int t = 0; t < n_tiles; ++t) {
-    const int row0 = row_begin + t * 128;
-    bf16_t* Xc = Ximg + (t & 1) * 128 * XLD;
+    const int row0 = row_begin + t * BM;
+    bf16_t* Xc = Ximg + (t & 1) * BM * XLD;
+    float* redc = red + (BM == 64 ? (t & 1) : 0) * 2 * RG * K;
     // registers -> images: dy = c0 * dz + c1 * y + c2 and a = relu(x * scale + shift), rounded to bf16 after the fp32 arithmetic
     // (as the split form's loaders do); x itself.  The per-column constants are re-read per tile (L1): 40 VGPRs not held.
-    float c0[8], c1[8], c2[8], sc[8], sh[8];
+    {
+      float c0[8], c1[8], c2[8];
 #pragma unroll
-    for (int e = 0; e < 8; e += 4) {
-      const float4 a0 = *reinterpret_cast<const float4*>(d.dy.coef + chd * 8 + e);
-      const float4 a1 = *reinterpret_cast<const float4*>(d.dy.coef + N + chd * 8 + e);
-      const float4 a2 = *reinterpret_cast<const float4*>(d.dy.coef + 2 * N + chd * 8 + e);
-      c0[e] = a0.x; c0[e + 1] = a0.y; c0[e + 2] = a0.z; c0[e + 3] = a0.w;
-      c1[e] = a1.x; c1[e + 1] = a1.y; c1[e + 2] = a1.z; c1[e + 3] = a1.w;
-      c2[e] = a2.x; c2[e + 1] = a2.y; c2[e + 2] = a2.z; c2[e + 3] = a2.w;
-      sc[e] = sc[e + 1] = sc[e + 2] = sc[e + 3] = 1.f;
-      sh[e] = sh[e + 1] = sh[e + 2] = sh[e + 3] = 0.f;
-      if (w.a.scale != nullptr) {
-        const float4 b0 = *reinterpret_cast<const float4*>(w.a.scale + cha * 8 + e);
-        const float4 b1 = *reinterpret_cast<const float4*>(w.a.shift + cha * 8 + e);
-        sc[e] = b0.x; sc[e + 1] = b0.y; sc[e + 2] = b0.z; sc[e + 3] = b0.w;
-        sh[e] = b1.x; sh[e + 1] = b1.y; sh[e + 2] = b1.z; sh[e + 3] = b1.w;
+      for (int e = 0; e < 8; e += 4) {
+        const float4 a0 = *reinterpret_cast<const float4*>(d.dy.coef + chd * 8 + e);
+        const float4 a1 = *reinterpret_cast<const float4*>(d.dy.coef + N + chd * 8 + e);
+        const float4 a2 = *reinterpret_cast<const float4*>(d.dy.coef + 2 * N + chd * 8 + e);
+        c0[e] = a0.x; c0[e + 1] = a0.y; c0[e + 2] = a0.z; c0[e + 3] = a0.w;
+        c1[e] = a1.x; c1[e + 1] = a1.y; c1[e + 2] = a1.z; c1[e + 3] = a1.w;
+        c2[e] = a2.x; c2[e + 1] = a2.y; c2[e + 2] = a2.z; c2[e + 3] = a2.w;
+      }
+#pragma unroll
+      for (int i = 0; i < NID; ++i) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)fmaf(c0[e], (float)rz[i][e], fmaf(c1[e], (float)ry[i][e], c2[e]));
+        *reinterpret_cast<bf16x8*>(Dimg + img_off<N>(rd + RPD * i, chd * 8)) = o;
       }
     }
+    {
+      float sc[8], sh[8];
 #pragma unroll
-    for (int i = 0; i < NID; ++i) {
-      bf16x8 o;
+      for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
+      if (w.a.scale != nullptr) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)fmaf(c0[e], (float)rz[i][e], fmaf(c1[e], (float)ry[i][e], c2[e]));
-      *reinterpret_cast<bf16x8*>(Dimg + img_off<N>(rd + RPD * i, chd * 8)) = o;
-    }
+        for (int e = 0; e < 8; e += 4) {
+          const float4 b0 = *reinterpret_cast<const float4*>(w.a.scale + cha * 8 + e);
+          const float4 b1 = *reinterpret_cast<const float4*>(w.a.shift + cha * 8 + e);
+          sc[e] = b0.x; sc[e + 1] = b0.y; sc[e + 2] = b0.z; sc[e + 3] = b0.w;
+          sh[e] = b1.x; sh[e + 1] = b1.y; sh[e + 2] = b1.z; sh[e + 3] = b1.w;
+        }
+      }
 #pragma unroll
-    for (int i = 0; i < NIA; ++i) {
-      bf16x8 o;
+      for (int i = 0; i < NIA; ++i) {
+        bf16x8 o;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)fmaxf(fmaf((float)rx[i][e], sc[e], sh[e]), floor_);
-      *reinterpret_cast<bf16x8*>(Aimg + img_off<K>(ra + RPA * i, cha * 8)) = o;
-      *reinterpret_cast<bf16x8*>(Xc + (ra + RPA * i) * XLD + cha * 8) = rx[i];
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)fmaxf(fmaf((float)rx[i][e], sc[e], sh[e]), floor_);
+        *reinterpret_cast<bf16x8*>(Aimg + img_off<K>(ra + RPA * i, cha * 8)) = o;
+        *reinterpret_cast<bf16x8*>(Xc + (ra + RPA * i) * XLD + cha * 8) = rx[i];
+      }
     }
     __syncthreads();
-    if (t + 1 < n_tiles) load_raw(row0 + 128);      // workgroup-uniform
+    if (t + 1 < n_tiles) load_raw(row0 + BM);      // workgroup-uniform
 
     // dW += a^T dy: reduction over the tile's rows (this wave's share of them)
 #pragma unroll
     for (int s_ = 0; s_ < STW; ++s_) {
       const int st = rs * STW + s_;
-      bf16x8 fa[TMW];
+      bf16x8 fa[TMW], fb[TNW];
 #pragma unroll
       for (int tm = 0; tm < TMW; ++tm) fa[tm] = frag_c1<K>(Aimg, (kt0 + tm) * 32, st, lane);
-      const bf16x8 fb = frag_c1<N>(Dimg, nt * 32, st, lane);
 #pragma unroll
-      for (int tm = 0; tm < TMW; ++tm) accw[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm], fb, accw[tm], 0, 0, 0);
+      for (int tn = 0; tn < TNW; ++tn) fb[tn] = frag_c1<N>(Dimg, (nt0 + tn) * 32, st, lane);
+#pragma unroll
+      for (int tm = 0; tm < TMW; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TNW; ++tn)
+          accw[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm], fb[tn], accw[tm][tn], 0, 0, 0);
     }
     // dX = dy W^T
     f32x16 accd[TMD];
@@ -1643,7 +1662,7 @@ __global__ __launch_bounds__(NT1) void k_pointmlp_bwd1(const t3d_pointmlp_dgrad_
       for (int tm = 0; tm < TMD; ++tm) accd[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm], wf[st], accd[tm], 0, 0, 0);
     }
     constexpr int ALD = K + 8;
-    if (add) {      // dense add_in tile through LDS (the D image is dead once every wave is past its MFMAs)
+    if (add) {      // dense add_in tile through LDS (the D and A images are dead once every wave is past its MFMAs)
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < NIA; ++i)
@@ -1678,24 +1697,29 @@ __global__ __launch_bounds__(NT1) void k_pointmlp_bwd1(const t3d_pointmlp_dgrad_
     s1 += __shfl_xor(s1, 32, 64);
     s2 += __shfl_xor(s2, 32, 64);
     if (stats && h == 0) {
-      red[(0 * RG + rg) * K + ct * 32 + l31] = s1;
-      red[(1 * RG + rg) * K + ct * 32 + l31] = s2;
+      redc[(0 * RG + rg) * K + ct * 32 + l31] = s1;
+      redc[(1 * RG + rg) * K + ct * 32 + l31] = s2;
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NIA; ++i)
       *reinterpret_cast<bf16x8*>(outg + (size_t)(row0 + ra + RPA * i) * K + cha * 8) =
           *reinterpret_cast<const bf16x8*>(Xc + (ra + RPA * i) * XLD + cha * 8);
-    if (stats && tid < K) {
+    if (stats && tid < K && (BM == 128 || (t & 1))) {      // 64-row tiles: the pair (t - 1, t) makes one 128-row partial
       float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-      for (int g = 0; g < RG; ++g) { t1 += red[(0 * RG + g) * K + tid]; t2 += red[(1 * RG + g) * K + tid]; }
+      for (int hb = 0; hb < (BM == 64 ? 2 : 1); ++hb)
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {
+          t1 += red[(hb * 2 * RG + 0 * RG + g) * K + tid];
+          t2 += red[(hb * 2 * RG + 1 * RG + g) * K + tid];
+        }
       const size_t o = (size_t)(row0 / 128) * K + tid;
       d.psum_dz[o] = t1;
       d.psum_dzy[o] = t2;
     }
-    // no barrier here: the next tile is staged into D, A (every wave is past its reads) and the OTHER X copy; `red` is written
-    // again only behind the next tile's first barrier, which every reader above reaches first
+    // no barrier here: the next tile is staged into D, A (every wave is past its reads) and the OTHER X copy; a `red` half is
+    // written again only behind a later tile's first barrier, which every reader above reaches first
   }
 
   if (RS == 2) {      // 64 x 64: the two row halves of a tile meet
@@ -1703,22 +1727,25 @@ __global__ __launch_bounds__(NT1) void k_pointmlp_bwd1(const t3d_pointmlp_dgrad_
     __syncthreads();
     if (rs == 1) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) cmb[(wt * 16 + r) * 64 + lane] = accw[0][r];
+      for (int r = 0; r < 16; ++r) cmb[(wt * 16 + r) * 64 + lane] = accw[0][0][r];
     }
     __syncthreads();
     if (rs == 0) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) accw[0][r] += cmb[(wt * 16 + r) * 64 + lane];
+      for (int r = 0; r < 16; ++r) accw[0][0][r] += cmb[(wt * 16 + r) * 64 + lane];
     }
   }
   if (rs == 0) {
     float* slab = w.slabs + (size_t)split * K * N;
-    const int col = nt * 32 + l31;
 #pragma unroll
-    for (int tm = 0; tm < TMW; ++tm)
+    for (int tn = 0; tn < TNW; ++tn) {
+      const int col = (nt0 + tn) * 32 + l31;
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        slab[(size_t)((kt0 + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * N + col] = accw[tm][r];
+      for (int tm = 0; tm < TMW; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          slab[(size_t)((kt0 + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * N + col] = accw[tm][tn][r];
+    }
   }
 }
 
@@ -2063,7 +2090,7 @@ constexpr size_t lds_epi2(int bn) { return (size_t)12 * bn * sizeof(float) + 2 *
 constexpr size_t lds_max(size_t a, size_t b) { return a > b ? a : b; }
 constexpr size_t lds_dgrad_h(int bn) { return lds_max(2 * (size_t)(128 * LDRH + bn * LDRH) * 2, lds_epi2(bn)); }
 constexpr size_t lds_wgrad_h(int bmk, int bn) { return 2 * (size_t)BKH * (bmk + 32 + bn + 32) * 2; }
-constexpr size_t lds_bwd1(int k, int n) { return (size_t)128 * (n + k + 2 * (k + 8)) * 2 + (size_t)2 * 4 * k * 4; }      // D, A, 2 x X images + the statistics scratch
+constexpr size_t lds_bwd1(int k, int n, int bm) { return (size_t)bm * (n + k + 2 * (k + 8)) * 2 + (size_t)2 * 2 * 4 * k * 4; }      // D, A, 2 x X images + the statistics scratch
 
 bool dtype_ok(int dt) { return dt == T3D_F32 || dt == T3D_BF16; }
 bool act_ok(const t3d_act_src& a, int K) {
@@ -2234,12 +2261,13 @@ extern "C" int t3d_wgrad_plan(int M, int K, int N, int* rows_per_split, int* til
   return T3D_OK;
 }
 
-// Plan of the fused backward (t3d_pointmlp_bwd): bf16 layers with K, N in {64, 128} take the one-pass kernel -- one workgroup per
+// Plan of the fused backward (t3d_pointmlp_bwd): bf16 layers with K, N in {64, 128} (and 256 x 128, 128 x 256) take the one-pass kernel -- one workgroup per
 // run of 128-row tiles, one 512-thread workgroup per CU (fewer, longer runs mean fewer K x N slabs) --
 // everything else the split form with t3d_wgrad_plan's row split.
 static bool bwd1_shape(int M, int K, int N, int dtype) {
   static const bool on = []() { const char* e = getenv("T3D_BWD1"); return !(e && e[0] == '0'); }();
-  return on && dtype == T3D_BF16 && (K == 64 || K == 128) && (N == 64 || N == 128) && M % 128 == 0;
+  const bool narrow = (K == 64 || K == 128) && (N == 64 || N == 128), mid = (K == 256 && N == 128) || (K == 128 && N == 256);
+  return on && dtype == T3D_BF16 && (narrow || mid) && M % 128 == 0;
 }
 extern "C" int t3d_bwd_plan(int M, int K, int N, int dtype, int* rows_per_split, int* one_pass) {
   if (!rows_per_split || !one_pass) return T3D_ERR_ARG;
@@ -2395,16 +2423,18 @@ extern "C" int t3d_pointmlp_bwd(const t3d_pointmlp_dgrad_args* d, const t3d_poin
     if (bwd1_shape(d->M, d->K, d->N, d->dtype) && rps % 128 == 0 && d->M / rps >= (tiles < 256 ? tiles : 256) &&
         w->a.dtype == T3D_BF16 && w->a.ldx % 8 == 0 && w->a.coff % 8 == 0 && (w->a.scale == nullptr) == (w->a.shift == nullptr)) {
       const dim3 grid1(d->M / rps);
-#define T3D_BWD1(K_, N_)                                                                         \
+#define T3D_BWD1(K_, N_, BM_)                                                                    \
   do {                                                                                           \
-    auto kern = k_pointmlp_bwd1<K_, N_>;                                                         \
-    allow_lds(reinterpret_cast<const void*>(kern), lds_bwd1(K_, N_));                            \
-    T3D_LAUNCH(kern, grid1, dim3(NT1), lds_bwd1(K_, N_), s, *d, *w);                              \
+    auto kern = k_pointmlp_bwd1<K_, N_, BM_>;                                                    \
+    allow_lds(reinterpret_cast<const void*>(kern), lds_bwd1(K_, N_, BM_));                       \
+    T3D_LAUNCH(kern, grid1, dim3(NT1), lds_bwd1(K_, N_, BM_), s, *d, *w);                        \
   } while (0)
-      if (d->K == 128 && d->N == 128) T3D_BWD1(128, 128);
-      else if (d->K == 128) T3D_BWD1(128, 64);
-      else if (d->N == 128) T3D_BWD1(64, 128);
-      else T3D_BWD1(64, 64);
+      if (d->K == 256) T3D_BWD1(256, 128, 64);
+      else if (d->N == 256) T3D_BWD1(128, 256, 64);
+      else if (d->K == 128 && d->N == 128) T3D_BWD1(128, 128, 128);
+      else if (d->K == 128) T3D_BWD1(128, 64, 128);
+      else if (d->N == 128) T3D_BWD1(64, 128, 128);
+      else T3D_BWD1(64, 64, 128);
 #undef T3D_BWD1
       T3D_CHECK_LAUNCH();
       return T3D_OK;
