@@ -319,6 +319,12 @@ typedef struct {
 } t3d_pointmlp_gram_args;
 int t3d_pointmlp_gram(const t3d_pointmlp_gram_args* args, t3d_stream_t stream);
 
+/* Recommended row split of the Gram slabs.  bf16 inputs with K = 128 or 256 take the ONE-PASS kernels (*one_pass = 1): t3d_pointmlp_gram
+ * / stage 1 with one workgroup per split (the input read and activated once, the per-tile column sums of t3d_act_colsum from the same
+ * pass) whenever M / rows_per_split >= min(256, M / 128); t3d_pointmlp_dgrad_gram / stage 2 likewise when prev_y is the input
+ * tensor itself (a.x, dense rows) and add_in is absent or the sparse form (add_live).  Otherwise t3d_wgrad_plan(M, K, K)'s split. */
+int t3d_gram_plan(int M, int K, int dtype, int* rows_per_split, int* one_pass);
+
 /* part[t,k] = sum over the 128 rows of tile t of a[m,k]. */
 typedef struct {
   t3d_act_src a;

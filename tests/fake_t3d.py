@@ -602,11 +602,22 @@ class FakeLib:
     def t3d_pointmlp_bwd(self, d, w, stream):
         return self.t3d_pointmlp_dgrad(d, stream) or self.t3d_pointmlp_wgrad(w, stream)
 
+    def t3d_gram_plan(self, M, K, dtype, rps, one):
+        one._obj.value = 0
+        if dtype == 1 and K in (128, 256) and M % 128 == 0:
+            tiles, per = M // 128, 1
+            while tiles // per > 256 and tiles % (per * 2) == 0:
+                per *= 2
+            rps._obj.value, one._obj.value = 128 * per, 1
+            return 0
+        tk, tn = C.c_int(0), C.c_int(0)
+        return self.t3d_wgrad_plan(M, K, K, rps, C.byref(tk), C.byref(tn))
+
     def t3d_bwd_plan(self, M, K, N, dtype, rps, one):
         one._obj.value = 0
         if dtype == 1 and ((K in (64, 128) and N in (64, 128)) or (K, N) in ((256, 128), (128, 256))) and M % 128 == 0:
             tiles, per = M // 128, 1
-            while tiles // per > 512 and tiles % (per * 2) == 0:
+            while tiles // per > 256 and tiles % (per * 2) == 0:
                 per *= 2
             rps._obj.value, one._obj.value = 128 * per, 1
             return 0

@@ -188,3 +188,79 @@ def test_bf16_gram_forms(hip_lib, M, K, rpf):
     ref = a @ rb(P) + rc.double()
     ref = torch.where(prev_y.double() * sc.double() + sh.double() > 0, ref, torch.zeros_like(ref))
     close_bf16(out, ref, 'dX gram', opmax=float(a.abs().max() * P.abs().max()))
+
+
+@pytest.mark.parametrize('M,K,N,rpf', [(4096, 128, 256, 512), (2048, 256, 512, 256), (65536, 128, 1024, 2048), (32768, 256, 512, 1024)])
+def test_bf16_one_pass_gram_stages(hip_lib, M, K, N, rpf):
+    """The one-pass forms of the Gram-form backward (t3d_gram_plan's split; the layer input is also the producer's raw output):
+    stage 1 = Gram slabs + per-tile column sums from ONE pass over the input (+ the P / rowconst / wc job), stage 2 = dW assembly +
+    out = (act(a) . P + rowconst + sparse rows) masked with the producer's batch-norm-backward partials.  GEMM results against fp64
+    on the same rounded operands; the small jobs (their 256-thread bodies run two to a 512-thread block) bit-identical to the
+    stand-alone launches."""
+    g = torch.Generator(device='cpu').manual_seed(M + K + N)
+    B, T = M // rpf, M // 128
+    x = torch.randn(M, K, generator=g).to(BF).to(DEV)
+    sc = (0.5 + torch.rand(K, generator=g)).to(DEV)
+    sh = (torch.randn(K, generator=g) * 0.2).to(DEV)
+    src = abi.ActSrc(fptr(x), K, 0, fptr(sc), fptr(sh), 1, fptr(None), 0, abi.BF16)
+    w = (torch.randn(K, N, generator=g) / np.sqrt(K)).to(DEV)
+    bias = (torch.randn(N, generator=g) * 0.1).to(DEV)
+    coef = torch.randn(3, N, generator=g).to(DEV)
+    argidx = torch.randint(-1, rpf, (B, N), generator=g, dtype=torch.int32).to(DEV)
+    dpool = torch.randn(B, N, generator=g).to(DEV)
+    rps, one = C.c_int(0), C.c_int(0)
+    assert hip_lib.t3d_gram_plan(M, K, abi.BF16, C.byref(rps), C.byref(one)) == 0
+    assert one.value == 1 and rps.value % 128 == 0 and M // rps.value >= min(256, T)
+    S_, nch = M // rps.value, (N + 127) // 128
+    z = lambda *s: torch.zeros(*s, device=DEV)
+    # ---- stage 1 ----
+    gsl, part, ps, rcs, wc = torch.full((S_, K, K), float('nan'), device=DEV), z(T, K), z(nch, K, K), z(nch, K), z(N, K)
+    ga = abi.PointMlpGramArgs(src, fptr(gsl), M, K, rpf, rps.value)
+    ca = abi.ActColsumArgs(src, M, K, rpf, fptr(part))
+    qa = abi.PoolBwdPrepArgs(fptr(w), fptr(bias), fptr(coef), K, N, fptr(ps), fptr(rcs), fptr(wc))
+    assert hip_lib.t3d_pool_bwd_stage1(C.byref(ga), C.byref(ca), C.byref(qa), stream()) == 0
+    torch.cuda.synchronize()
+    a32 = torch.relu(x.float() * sc + sh)
+    a = rb(a32)
+    G = a.t() @ a
+    assert float((gsl.double().sum(0) - G).abs().max()) < 2e-5 * float(G.abs().max()) * max(1.0, np.sqrt(M / 4096))
+    col = a32.double().reshape(T, 128, K).sum(1)
+    assert float((part.double() - col).abs().max()) < 1e-5 * float(col.abs().max())
+    gsl2 = torch.zeros(S_, K, K, device=DEV)                      # stand-alone Gram launch: the same kernel body
+    ga2 = abi.PointMlpGramArgs(src, fptr(gsl2), M, K, rpf, rps.value)
+    assert hip_lib.t3d_pointmlp_gram(C.byref(ga2), stream()) == 0
+    ps2, rcs2, wc2 = z(nch, K, K), z(nch, K), z(N, K)
+    qa2 = abi.PoolBwdPrepArgs(fptr(w), fptr(bias), fptr(coef), K, N, fptr(ps2), fptr(rcs2), fptr(wc2))
+    assert hip_lib.t3d_pool_bwd_prep(C.byref(qa2), stream()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(gsl, gsl2) and torch.equal(ps, ps2) and torch.equal(rcs, rcs2) and torch.equal(wc, wc2)
+    # ---- stage 2 ----
+    Gr, abar, P, rc = gsl.sum(0), part.sum(0), ps.sum(0), rcs.sum(0)
+    live = (torch.rand(M, generator=g) < 0.1).to(torch.int32).to(DEV)
+    Sm = torch.randn(M, K, generator=g).to(DEV)                   # rows without the flag must never be read: leave them non-zero
+    out = torch.zeros(M, K, dtype=BF, device=DEV)
+    dw, s1, s2 = z(K, N), z(T, K), z(T, K)
+    f = abi.PoolWgradFinishArgs()
+    f.a, f.argidx, f.dpool, f.coef, f.w, f.bias = src, iptr(argidx), fptr(dpool), fptr(coef), fptr(w), fptr(bias)
+    f.g, f.abar, f.B, f.K, f.N, f.rows_per_frustum, f.dw = fptr(Gr), fptr(abar), B, K, N, rpf, fptr(dw)
+    d = abi.PointMlpDgradGramArgs()
+    d.a, d.p, d.rowconst, d.add_in, d.add_live = src, fptr(P), fptr(rc), fptr(Sm), iptr(live)
+    d.prev_y, d.prev_scale, d.prev_shift, d.out, d.psum_dz, d.psum_dzy = fptr(x), fptr(sc), fptr(sh), fptr(out), fptr(s1), fptr(s2)
+    d.M, d.K, d.rows_per_frustum, d.dtype = M, K, rpf, abi.BF16
+    assert hip_lib.t3d_pool_bwd_stage2(C.byref(f), C.byref(d), stream()) == 0
+    torch.cuda.synchronize()
+    ref = a @ rb(P) + rc.double() + Sm.double() * live.double().unsqueeze(1)
+    ref = torch.where(x.double() * sc.double() + sh.double() > 0, ref, torch.zeros_like(ref))
+    close_bf16(out, ref, 'dX gram one-pass', opmax=float(a.abs().max() * P.abs().max()))
+    o = out.double().reshape(T, 128, K)
+    assert float((s1.double() - o.sum(1)).abs().max()) < 1e-4 * float(o.abs().sum(1).max() + 1e-9)
+    assert float((s2.double() - (o * x.double().reshape(T, 128, K)).sum(1)).abs().max()) < 1e-4 * float(o.abs().sum(1).max() + 1e-9)
+    dw2 = z(K, N)
+    f.dw = fptr(dw2)
+    assert hip_lib.t3d_pool_wgrad_finish(C.byref(f), stream()) == 0
+    out2, t1, t2 = torch.zeros(M, K, dtype=BF, device=DEV), z(T, K), z(T, K)      # stand-alone dgrad_gram: the same kernel body either way
+    d.out, d.psum_dz, d.psum_dzy = fptr(out2), fptr(t1), fptr(t2)
+    assert hip_lib.t3d_pointmlp_dgrad_gram(C.byref(d), stream()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(dw, dw2) and float(dw.abs().max()) > 0
+    assert torch.equal(out, out2) and torch.equal(s1, t1) and torch.equal(s2, t2)

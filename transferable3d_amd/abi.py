@@ -246,6 +246,7 @@ ENTRY_POINTS = {
     't3d_pointmlp_bwd': [C.POINTER(PointMlpDgradArgs), C.POINTER(PointMlpWgradArgs), VP],
     't3d_wgrad_plan': [i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
     't3d_bwd_plan': [i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)],
+    't3d_gram_plan': [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)],
     't3d_bn_bwd_finalize': [C.POINTER(BnBwdFinalizeArgs), VP],
     't3d_dy_colsum': [C.POINTER(DyColsumArgs), VP],
     't3d_pool_bwd_prep': [C.POINTER(PoolBwdPrepArgs), VP],

@@ -1784,6 +1784,295 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pool_bwd_stage2(const t3d_poo
 }
 
 // ---------------------------------------------------------------------------------------------
+// one-pass forms of the two GEMMs of the Gram-form backward (bf16, K = 128 or 256 input channels)
+// ---------------------------------------------------------------------------------------------
+// Same idea as k_pointmlp_bwd1: 512 threads, one workgroup per CU walking row tiles, the layer input read from HBM once per kernel
+// and activated once, the raw chunks of the next tile requested while the current one is in the MFMAs.
+//   gram1:  G = a^T a slabs (both operands through the transposing read from ONE image) + the per-128-row column sums of a
+//           (t3d_act_colsum's output) from the fp32 values the staging pass holds anyway.  Two images: one barrier per tile.
+//   dgram1: out = (act(a) . P + rowconst + S) masked, with the producer's batch-norm-backward partials; P sits in registers as
+//           B fragments, the raw input tile (= the producer's raw output the mask and the partials need) stays in LDS.
+template <int K, int BM>
+__device__ __forceinline__ void gram1_body(const t3d_pointmlp_gram_args& g, float* part, float* smem, int split) {
+  constexpr int CPA = K / 8, RPA = NT1 / CPA, NIA = BM / RPA;
+  constexpr int KT = K / 32, TMW = KT / 2, TNW = KT / 4;      // wave grid 2 x 4 over the KT x KT tiles
+  bf16_t* Aimg = reinterpret_cast<bf16_t*>(smem);             // [2][BM][K]
+  float* csum = reinterpret_cast<float*>(Aimg + 2 * BM * K);  // [2][RPA][K]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int kt0 = (wv >> 2) * TMW, nt0 = (wv & 3) * TNW;
+  const int cha = tid % CPA, ra = tid / CPA;
+  const int row_begin = split * g.rows_per_split, n_tiles = g.rows_per_split / BM;
+  const bf16_t* xg = reinterpret_cast<const bf16_t*>(g.a.x);
+  const float floor_ = g.a.relu ? 0.f : -INFINITY;
+
+  bf16x8 rx[NIA];
+  auto load_raw = [&](int row0) {
+#pragma unroll
+    for (int i = 0; i < NIA; ++i)
+      rx[i] = *reinterpret_cast<const bf16x8*>(xg + (size_t)(row0 + ra + RPA * i) * g.a.ldx + g.a.coff + cha * 8);
+  };
+  f32x16 acc[TMW][TNW];
+  zero_acc<TMW, TNW>(acc);
+  float pend = 0.f;      // 64-row tiles: the first half of a 128-row column sum
+  load_raw(row_begin);
+  for (int t = 0; t < n_tiles; ++t) {
+    const int row0 = row_begin + t * BM;
+    bf16_t* Ac = Aimg + (t & 1) * BM * K;
+    float* cs = csum + (t & 1) * RPA * K;
+    {
+      float sc[8], sh[8], colp[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; colp[e] = 0.f; }
+      if (g.a.scale != nullptr) {
+#pragma unroll
+        for (int e = 0; e < 8; e += 4) {
+          const float4 b0 = *reinterpret_cast<const float4*>(g.a.scale + cha * 8 + e);
+          const float4 b1 = *reinterpret_cast<const float4*>(g.a.shift + cha * 8 + e);
+          sc[e] = b0.x; sc[e + 1] = b0.y; sc[e + 2] = b0.z; sc[e + 3] = b0.w;
+          sh[e] = b1.x; sh[e + 1] = b1.y; sh[e + 2] = b1.z; sh[e + 3] = b1.w;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NIA; ++i) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float v = fmaxf(fmaf((float)rx[i][e], sc[e], sh[e]), floor_);
+          colp[e] += v;
+          o[e] = (bf16_t)v;
+        }
+        *reinterpret_cast<bf16x8*>(Ac + img_off<K>(ra + RPA * i, cha * 8)) = o;
+      }
+      if (part != nullptr) {
+        *reinterpret_cast<float4*>(cs + ra * K + cha * 8) = make_float4(colp[0], colp[1], colp[2], colp[3]);
+        *reinterpret_cast<float4*>(cs + ra * K + cha * 8 + 4) = make_float4(colp[4], colp[5], colp[6], colp[7]);
+      }
+    }
+    __syncthreads();
+    if (t + 1 < n_tiles) load_raw(row0 + BM);
+#pragma unroll
+    for (int st = 0; st < BM / 16; ++st) {
+      bf16x8 fa[TMW], fb[TNW];
+#pragma unroll
+      for (int tm = 0; tm < TMW; ++tm) fa[tm] = frag_c1<K>(Ac, (kt0 + tm) * 32, st, lane);
+#pragma unroll
+      for (int tn = 0; tn < TNW; ++tn) fb[tn] = frag_c1<K>(Ac, (nt0 + tn) * 32, st, lane);
+#pragma unroll
+      for (int tm = 0; tm < TMW; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TNW; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm], fb[tn], acc[tm][tn], 0, 0, 0);
+    }
+    if (part != nullptr && tid < K) {
+      float s_ = 0.f;
+#pragma unroll
+      for (int r = 0; r < RPA; ++r) s_ += cs[r * K + tid];
+      if (BM == 128) part[(size_t)(row0 / 128) * K + tid] = s_;
+      else if (t & 1) part[(size_t)(row0 / 128) * K + tid] = pend + s_;
+      else pend = s_;
+    }
+    // one barrier per tile: tile t+1 goes into the other image / the other partial buffer, whose readers (tile t-1) every wave left
+    // before it passed this tile's barrier
+  }
+  float* slab = g.slabs + (size_t)split * K * K;
+#pragma unroll
+  for (int tn = 0; tn < TNW; ++tn) {
+    const int col = (nt0 + tn) * 32 + l31;
+#pragma unroll
+    for (int tm = 0; tm < TMW; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        slab[(size_t)((kt0 + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * K + col] = acc[tm][tn][r];
+  }
+}
+constexpr size_t lds_gram1(int k, int bm) { return (size_t)2 * bm * k * 2 + (size_t)2 * (NT1 / (k / 8)) * k * 4; }
+
+template <int K, int BM>
+__device__ __forceinline__ void dgram1_body(const t3d_pointmlp_dgrad_gram_args& p, float* smem, int wg, int nwg) {
+  constexpr int XLD = K + 8, SUB = 128 / BM;
+  constexpr int CT = K / 32, RG = 8 / CT, TMD = BM / (32 * RG), STK = K / 16;
+  constexpr int CPA = K / 8, RPA = NT1 / CPA, NIA = BM / RPA;
+  bf16_t* Aimg = reinterpret_cast<bf16_t*>(smem);                       // [BM][K] activated
+  bf16_t* Ximg = Aimg + BM * K;                                         // [2][BM][K + 8] raw / gradient out
+  float* red = reinterpret_cast<float*>(Ximg + 2 * BM * XLD);           // [SUB][2][RG][K]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int rg = wv / CT, ct = wv % CT, xr0 = rg * (BM / RG);
+  const int cha = tid % CPA, ra = tid / CPA;
+  const bf16_t* xg = reinterpret_cast<const bf16_t*>(p.a.x);
+  bf16_t* outg = reinterpret_cast<bf16_t*>(p.out);
+  const bool mask = p.prev_y != nullptr, stats = mask && p.psum_dz != nullptr, add = p.add_in != nullptr;      // uniform
+  const float floor_ = p.a.relu ? 0.f : -INFINITY;
+  const int col = ct * 32 + l31;
+  const float psc = mask ? p.prev_scale[col] : 0.f, psh = mask ? p.prev_shift[col] : 0.f;
+  const float cc = p.rowconst ? p.rowconst[col] : 0.f;
+
+  // P as B fragments: B[k'][k] = P[k'][k], lane (k = col, h) holds k' = 16 st + 8 h .. + 7 (rounded to bf16 like the split form's loader)
+  bf16x8 pf[STK];
+#pragma unroll
+  for (int st = 0; st < STK; ++st) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = p.p[(size_t)(16 * st + 8 * h + j) * K + col];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pf[st][j] = (bf16_t)v[j];
+  }
+
+  bf16x8 rx[NIA];
+  auto load_raw = [&](int row0) {
+#pragma unroll
+    for (int i = 0; i < NIA; ++i)
+      rx[i] = *reinterpret_cast<const bf16x8*>(xg + (size_t)(row0 + ra + RPA * i) * p.a.ldx + p.a.coff + cha * 8);
+  };
+  const int n_super = p.M / 128;
+  if (wg < n_super) load_raw(wg * 128);
+  int it = 0;
+  for (int su = wg; su < n_super; su += nwg) {
+#pragma unroll 1
+    for (int sub = 0; sub < SUB; ++sub, ++it) {
+      const int row0 = su * 128 + sub * BM;
+      bf16_t* Xc = Ximg + (it & 1) * BM * XLD;
+      float* redc = red + sub * 2 * RG * K;
+      {
+        float sc[8], sh[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
+        if (p.a.scale != nullptr) {
+#pragma unroll
+          for (int e = 0; e < 8; e += 4) {
+            const float4 b0 = *reinterpret_cast<const float4*>(p.a.scale + cha * 8 + e);
+            const float4 b1 = *reinterpret_cast<const float4*>(p.a.shift + cha * 8 + e);
+            sc[e] = b0.x; sc[e + 1] = b0.y; sc[e + 2] = b0.z; sc[e + 3] = b0.w;
+            sh[e] = b1.x; sh[e + 1] = b1.y; sh[e + 2] = b1.z; sh[e + 3] = b1.w;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < NIA; ++i) {
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (bf16_t)fmaxf(fmaf((float)rx[i][e], sc[e], sh[e]), floor_);
+          *reinterpret_cast<bf16x8*>(Aimg + img_off<K>(ra + RPA * i, cha * 8)) = o;
+          *reinterpret_cast<bf16x8*>(Xc + (ra + RPA * i) * XLD + cha * 8) = rx[i];
+        }
+      }
+      __syncthreads();
+      {      // raw chunks of the next tile of this workgroup (workgroup-uniform)
+        const int nrow = sub + 1 < SUB ? row0 + BM : (su + nwg) * 128;
+        if (sub + 1 < SUB || su + nwg < n_super) load_raw(nrow);
+      }
+      f32x16 accd[TMD];
+#pragma unroll
+      for (int tm = 0; tm < TMD; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accd[tm][r] = 0.f;
+#pragma unroll
+      for (int st = 0; st < STK; ++st) {
+        bf16x8 fa[TMD];
+#pragma unroll
+        for (int tm = 0; tm < TMD; ++tm) fa[tm] = frag_r1<K>(Aimg, xr0 + tm * 32, st, lane);
+#pragma unroll
+        for (int tm = 0; tm < TMD; ++tm) accd[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm], pf[st], accd[tm], 0, 0, 0);
+      }
+      unsigned live = 0u;      // bit tm*16 + r: the lane's accumulator row (tm, r) has a sparse arg-max row to add
+      if (add) {
+#pragma unroll
+        for (int tm = 0; tm < TMD; ++tm)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int4 f = *reinterpret_cast<const int4*>(p.add_live + row0 + xr0 + 4 * h + tm * 32 + 8 * j);
+            live |= (unsigned)((f.x != 0) | ((f.y != 0) << 1) | ((f.z != 0) << 2) | ((f.w != 0) << 3)) << (tm * 16 + 4 * j);
+          }
+      }
+      float s1 = 0.f, s2 = 0.f;
+      auto epi = [&](auto mask_c) {
+        constexpr bool MASK = decltype(mask_c)::value;
+        bf16_t* xb = Xc + (xr0 + 4 * h) * XLD + col;
+        const float* sb = p.add_in + (size_t)(row0 + xr0 + 4 * h) * K + col;
+#pragma unroll
+        for (int tm = 0; tm < TMD; ++tm)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int ro = tm * 32 + (r & 3) + 8 * (r >> 2);
+            const float ypv = MASK ? (float)xb[ro * XLD] : 0.f;
+            const float ad = ((live >> (tm * 16 + r)) & 1u) ? sb[(size_t)ro * K] : 0.f;
+            float v = Elem<bf16_t>::rnd(accd[tm][r] + cc + ad);
+            if (MASK) {
+              if (!(fmaf(ypv, psc, psh) > 0.f)) v = 0.f;
+              s1 += v;
+              s2 = fmaf(v, ypv, s2);
+            }
+            xb[ro * XLD] = (bf16_t)v;
+          }
+      };
+      if (mask) epi(std::true_type()); else epi(std::false_type());
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (stats && h == 0) {
+        redc[(0 * RG + rg) * K + col] = s1;
+        redc[(1 * RG + rg) * K + col] = s2;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NIA; ++i)
+        *reinterpret_cast<bf16x8*>(outg + (size_t)(row0 + ra + RPA * i) * K + cha * 8) =
+            *reinterpret_cast<const bf16x8*>(Xc + (ra + RPA * i) * XLD + cha * 8);
+      if (stats && tid < K && sub == SUB - 1) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int hb = 0; hb < SUB; ++hb)
+#pragma unroll
+          for (int gg = 0; gg < RG; ++gg) {
+            t1 += red[(hb * 2 * RG + 0 * RG + gg) * K + tid];
+            t2 += red[(hb * 2 * RG + 1 * RG + gg) * K + tid];
+          }
+        p.psum_dz[(size_t)su * K + tid] = t1;
+        p.psum_dzy[(size_t)su * K + tid] = t2;
+      }
+      // (next staging: the A image is rewritten behind this barrier, X alternates, a `red` half is rewritten only behind a later
+      // tile's first barrier)
+    }
+  }
+}
+constexpr size_t lds_dgram1(int k, int bm) { return (size_t)bm * k * 2 + (size_t)2 * bm * (k + 8) * 2 + (size_t)(128 / bm) * 2 * (8 / (k / 32)) * k * 4; }
+
+template <int K, int BM>
+__global__ __launch_bounds__(NT1) void k_gram1(const t3d_pointmlp_gram_args g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  gram1_body<K, BM>(g, nullptr, smem, blockIdx.x);
+}
+template <int K, int BM>
+__global__ __launch_bounds__(NT1) void k_dgram1(const t3d_pointmlp_dgrad_gram_args p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  dgram1_body<K, BM>(p, smem, blockIdx.x, gridDim.x);
+}
+// The stage launches of the Gram-form backward with the one-pass GEMMs.  The small jobs keep their 256-thread bodies: a 512-thread
+// block runs TWO logical blocks side by side (each half its own LDS region; their barriers span both halves, which execute the same
+// barrier sequence; an odd last block repeats its neighbour's work -- same values to the same addresses).
+template <int K, int BM>
+__global__ __launch_bounds__(NT1) void k_pool_bwd_stage1_h(const t3d_pointmlp_gram_args g, const t3d_act_colsum_args c,
+                                                           const t3d_pool_bwd_prep_args q, const int n_gram) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((int)blockIdx.x < n_gram) {
+    gram1_body<K, BM>(g, c.part, smem, blockIdx.x);
+  } else {
+    const int half = threadIdx.x >> 8, kb = q.K / 32, nlog = kb * kb * ((q.N + PCH - 1) / PCH);
+    const int r = min(2 * ((int)blockIdx.x - n_gram) + half, nlog - 1);
+    pool_bwd_prep_body(q, smem + half * (PREP_LDS / sizeof(float)), r % kb, (r / kb) % kb, r / (kb * kb), threadIdx.x & 255);
+  }
+}
+template <int K, int BM>
+__global__ __launch_bounds__(NT1) void k_pool_bwd_stage2_h(const t3d_pool_wgrad_finish_args f, const t3d_pointmlp_dgrad_gram_args d,
+                                                           const int n_fin2, const int fin_lds_floats) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((int)blockIdx.x < n_fin2) {
+    const int half = threadIdx.x >> 8, kb = f.K / FK, nlog = kb * (f.N / FN);
+    const int b = min(2 * (int)blockIdx.x + half, nlog - 1);
+    pool_wgrad_finish_body<bf16_t>(f, smem + half * fin_lds_floats, b % kb, b / kb, threadIdx.x & 255);
+  } else {
+    dgram1_body<K, BM>(d, smem, blockIdx.x - n_fin2, gridDim.x - n_fin2);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // forward of a max-pooled layer (K = 128 or 256 input channels, no [M,N] store): A-resident, persistent over n
 // ---------------------------------------------------------------------------------------------
 // The pooled layers are the widest (N = 1024 / 512 / 256 columns from K = 128 / 256 inputs) and keep nothing but
@@ -2077,6 +2366,11 @@ void launch_lds(void (*kernel)(const Args), dim3 grid, size_t lds_bytes, hipStre
   allow_lds(reinterpret_cast<const void*>(kernel), lds_bytes);
   T3D_LAUNCH(kernel, grid, dim3(NT), lds_bytes, s, a);
 }
+template <class Args>
+void launch_lds1(void (*kernel)(const Args), dim3 grid, size_t lds_bytes, hipStream_t s, const Args& a) {      // 512-thread kernels
+  allow_lds(reinterpret_cast<const void*>(kernel), lds_bytes);
+  T3D_LAUNCH(kernel, grid, dim3(NT1), lds_bytes, s, a);
+}
 constexpr size_t lds_fwd(int bn) { return 2 * (size_t)(128 * LDR + BK * bn) * sizeof(float); }
 constexpr size_t lds_dgrad(int bn) { return 2 * (size_t)(128 * LDR + bn * LDR) * sizeof(float); }
 constexpr size_t lds_wgrad(int bmk, int bn) { return 2 * (size_t)BK * (bmk + bn) * sizeof(float); }
@@ -2345,6 +2639,42 @@ extern "C" int t3d_pointmlp_wgrad(const t3d_pointmlp_wgrad_args* a, t3d_stream_t
   return T3D_OK;
 }
 
+// One-pass forms of the Gram-form backward (gram1 / dgram1 above): bf16 input with K = 128 or 256 channels.
+static bool gram1_shape(int M, int K, int dtype) {
+  static const bool on = []() { const char* e = getenv("T3D_GRAM1"); return !(e && e[0] == '0'); }();
+  return on && dtype == T3D_BF16 && (K == 128 || K == 256) && M % 128 == 0;
+}
+static bool act_chunks_ok(const t3d_act_src& a) { return a.dtype == T3D_BF16 && a.ldx % 8 == 0 && a.coff % 8 == 0 && (a.scale == nullptr) == (a.shift == nullptr); }
+extern "C" int t3d_gram_plan(int M, int K, int dtype, int* rows_per_split, int* one_pass) {
+  if (!rows_per_split || !one_pass) return T3D_ERR_ARG;
+  *one_pass = 0;
+  if (gram1_shape(M, K, dtype)) {
+    const int tiles = M / 128;
+    int per = 1;
+    while (tiles / per > 256 && tiles % (per * 2) == 0) per *= 2;
+    *rows_per_split = 128 * per;
+    *one_pass = 1;
+    return T3D_OK;
+  }
+  int tk = 0, tn = 0;
+  return t3d_wgrad_plan(M, K, K, rows_per_split, &tk, &tn);
+}
+static bool gram1_ok(const t3d_pointmlp_gram_args* g) {
+  const int tiles = g->M / 128;
+  return gram1_shape(g->M, g->K, g->a.dtype) && g->rows_per_split % 128 == 0 && g->M / g->rows_per_split >= (tiles < 256 ? tiles : 256) &&
+         act_chunks_ok(g->a);
+}
+static bool dgram1_ok(const t3d_pointmlp_dgrad_gram_args* d) {
+  // the raw input tile doubles as the producer's raw output (mask, partials): same tensor, dense rows; the added rows are the sparse form.
+  // K = 256 only by default: at K = 128 the split form has a single column tile already (nothing is staged twice) and its 256-thread
+  // blocks share the CUs with the dW-assembly blocks of stage 2, whose 24 us of gather latency the 512-thread form leaves exposed
+  // (stage 2 at B=128 N=2048: 72 -> 81 us with K = 128, 167 -> 125 us with K = 256).  T3D_DGRAM1=2 takes it for K = 128 as well.
+  static const int mode = []() { const char* e = getenv("T3D_DGRAM1"); return e ? atoi(e) : 1; }();
+  if (mode == 0 || (mode == 1 && d->K != 256)) return false;
+  return gram1_shape(d->M, d->K, d->dtype) && act_chunks_ok(d->a) && d->a.ldx == d->K && d->a.coff == 0 &&
+         (d->prev_y == nullptr || d->prev_y == d->a.x) && (d->add_in == nullptr || d->add_live != nullptr);
+}
+
 static int check_dgrad_gram(const t3d_pointmlp_dgrad_gram_args* a) {
   if (!a || !a->p || !a->out || !act_ok(a->a, a->K) || a->a.sub) return T3D_ERR_ARG;
   if (a->add_live && !a->add_in) return T3D_ERR_ARG;
@@ -2365,6 +2695,13 @@ extern "C" int t3d_pointmlp_dgrad_gram(const t3d_pointmlp_dgrad_gram_args* a, t3
   if (rc != T3D_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int tiles_m = a->M / 128;
+  if (dgram1_ok(a)) {
+    const dim3 grid(tiles_m < 256 ? tiles_m : 256);
+    if (a->K == 128) launch_lds1(k_dgram1<128, 128>, grid, lds_dgram1(128, 128), s, *a);
+    else launch_lds1(k_dgram1<256, 64>, grid, lds_dgram1(256, 64), s, *a);
+    T3D_CHECK_LAUNCH();
+    return T3D_OK;
+  }
   if (a->dtype == T3D_BF16) {
     if (dgrad_gram_wide(a)) launch_lds(k_pointmlp_dgrad_gram<128, PathBF16>, dim3(tiles_m * (a->K / 128)), lds_dgram_h(128), s, *a);
     else launch_lds(k_pointmlp_dgrad_gram<64, PathBF16>, dim3(tiles_m * (a->K / 64)), lds_dgram_h(64), s, *a);
@@ -2392,6 +2729,13 @@ static int gram_tile(const t3d_pointmlp_gram_args* a) {      // square tiles onl
 }
 
 extern "C" int t3d_pointmlp_gram(const t3d_pointmlp_gram_args* a, t3d_stream_t stream) {
+  if (check_gram(a) == T3D_OK && gram1_ok(a)) {
+    const dim3 grid(a->M / a->rows_per_split);
+    if (a->K == 128) launch_lds1(k_gram1<128, 128>, grid, lds_gram1(128, 128), static_cast<hipStream_t>(stream), *a);
+    else launch_lds1(k_gram1<256, 64>, grid, lds_gram1(256, 64), static_cast<hipStream_t>(stream), *a);
+    T3D_CHECK_LAUNCH();
+    return T3D_OK;
+  }
   const int rc = check_gram(a);
   if (rc != T3D_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -2486,6 +2830,22 @@ extern "C" int t3d_pool_bwd_stage1(const t3d_pointmlp_gram_args* g, const t3d_ac
   if ((rc = check_colsum(c)) != T3D_OK) return rc;
   if ((rc = check_prep(q)) != T3D_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (c->a.dtype != g->a.dtype) return T3D_ERR_ARG;
+  if (gram1_ok(g) && c->M == g->M && c->K == g->K && c->a.x == g->a.x && c->a.ldx == g->a.ldx && c->a.coff == g->a.coff) {
+    const int n_gram1 = g->M / g->rows_per_split, n_prep1 = (q->K / 32) * (q->K / 32) * ((q->N + PCH - 1) / PCH);
+    const dim3 grid1(n_gram1 + (n_prep1 + 1) / 2);
+#define T3D_ST1H(K_, BM_)                                                                                  \
+  do {                                                                                                     \
+    const size_t lds1 = lds_max(lds_gram1(K_, BM_), 2 * PREP_LDS);                                         \
+    auto kern = k_pool_bwd_stage1_h<K_, BM_>;                                                              \
+    allow_lds(reinterpret_cast<const void*>(kern), lds1);                                                  \
+    T3D_LAUNCH(kern, grid1, dim3(NT1), lds1, s, *g, *c, *q, n_gram1);                                      \
+  } while (0)
+    if (g->K == 128) T3D_ST1H(128, 128); else T3D_ST1H(256, 64);
+#undef T3D_ST1H
+    T3D_CHECK_LAUNCH();
+    return T3D_OK;
+  }
   const int gt = gram_tile(g);
   const int n_gram = (g->K / gt) * (g->K / gt) * (g->M / g->rows_per_split);
   const int n_colsum = c->M / 128;
@@ -2516,6 +2876,23 @@ extern "C" int t3d_pool_bwd_stage2(const t3d_pool_wgrad_finish_args* f, const t3
   if ((rc = check_dgrad_gram(d)) != T3D_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int n_finish = (f->K / FK) * (f->N / FN);
+  if (f->a.dtype != d->a.dtype) return T3D_ERR_ARG;
+  if (dgram1_ok(d) && f->K == d->K) {
+    const int n_fin2 = (n_finish + 1) / 2, tiles = d->M / 128;
+    const dim3 grid2(n_fin2 + (tiles < 256 ? tiles : 256));
+    const int fin_floats = (int)(finish_lds(f->K) / sizeof(float));
+#define T3D_ST2H(K_, BM_)                                                                                  \
+  do {                                                                                                     \
+    const size_t lds2 = lds_max(lds_dgram1(K_, BM_), 2 * finish_lds(K_));                                  \
+    auto kern = k_pool_bwd_stage2_h<K_, BM_>;                                                              \
+    allow_lds(reinterpret_cast<const void*>(kern), lds2);                                                  \
+    T3D_LAUNCH(kern, grid2, dim3(NT1), lds2, s, *f, *d, n_fin2, fin_floats);                               \
+  } while (0)
+    if (d->K == 128) T3D_ST2H(128, 128); else T3D_ST2H(256, 64);
+#undef T3D_ST2H
+    T3D_CHECK_LAUNCH();
+    return T3D_OK;
+  }
   const bool wide = dgrad_gram_wide(d);
   const int n_d = (d->M / 128) * (d->K / (wide ? 128 : 64));
   const dim3 grid(n_finish + n_d);

@@ -19,12 +19,14 @@ constexpr int PCH = 128;   // columns of w per chunk
 
 constexpr size_t PREP_LDS = (2 * 32 * (PCH + 1) + 2 * PCH) * sizeof(float);
 
-__device__ __forceinline__ void pool_bwd_prep_body(const t3d_pool_bwd_prep_args& p, float* smem, int bi, int bj, int ch) {
+// tid_: thread index within a 256-thread logical block (default: the hardware block IS the logical block); the 512-thread bf16 stage
+// kernels run two logical blocks side by side, every barrier below then simply spans both
+__device__ __forceinline__ void pool_bwd_prep_body(const t3d_pool_bwd_prep_args& p, float* smem, int bi, int bj, int ch, int tid_ = -1) {
   float (*wi)[PCH + 1] = reinterpret_cast<float (*)[PCH + 1]>(smem);
   float (*wj)[PCH + 1] = reinterpret_cast<float (*)[PCH + 1]>(smem + 32 * (PCH + 1));
   float* v = smem + 2 * 32 * (PCH + 1);
   float* c0s = v + PCH;
-  const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+  const int tid = tid_ < 0 ? (int)threadIdx.x : tid_, ti = tid >> 4, tj = tid & 15;
   const int n0 = ch * PCH;
   const bool edge = bj == 0;
   const float* c0 = p.coef;
@@ -219,13 +221,13 @@ inline size_t finish_lds(int K) {
 }
 
 template <class XT = float>
-__device__ __forceinline__ void pool_wgrad_finish_body(const t3d_pool_wgrad_finish_args& p, float* smem, int bx, int by) {
+__device__ __forceinline__ void pool_wgrad_finish_body(const t3d_pool_wgrad_finish_args& p, float* smem, int bx, int by, int tid_ = -1) {
   float* gsm = smem;                               // [FK][K+1]
   float* wsm = gsm + FK * (p.K + 1);               // [K][FN]
   float* gat = wsm + p.K * FN;                     // [FK][FN+1]
   float* dps = gat + FK * (FN + 1);                // [FB][FN]
   int* ais = reinterpret_cast<int*>(dps + FB * FN);// [FB][FN]
-  const int tid = threadIdx.x;
+  const int tid = tid_ < 0 ? (int)threadIdx.x : tid_;
   const int k0 = bx * FK, n0 = by * FN;
   const int ldg = p.K + 1;
   // stage G rows and w columns (coalesced along the fast index)

@@ -345,6 +345,13 @@ def bwd_rows_per_split(lib, M, K, N, dtype):
     return rps.value
 
 
+def gram_rows_per_split(lib, M, K, dtype):
+    """Row split of the Gram slabs of a pooled layer's backward (t3d_gram_plan)."""
+    rps, one = C.c_int(0), C.c_int(0)
+    abi.check(lib.t3d_gram_plan(M, K, dtype, C.byref(rps), C.byref(one)), 't3d_gram_plan')
+    return rps.value
+
+
 class PointLayer:
     """tf_util.conv2d 1x1 (+ batch_norm + ReLU) over M = B*N point rows (tf_util.py:1258-1323)."""
 
@@ -504,7 +511,7 @@ class PointLayer:
         """dW of a pooled layer from the K x K Gram matrix of its input (t3d.h K11e): gram + column sums of the input,
         one slab reduction, then the assembly kernel.  Independent of the dgrad chain."""
         g, rt, K, N = self.g, self.g.rt, self.K, self.N
-        rps = wgrad_rows_per_split(rt.lib, self.M, K, K)
+        rps = gram_rows_per_split(rt.lib, self.M, K, self.src.dtype)
         regions = [('G', K * K, self.M // rps), ('abar', K, self.T)]
         merged = not SIDE_STREAM            # one stream: P / rowconst ride in the same slab reduction (one launch less)
         if merged:
@@ -566,7 +573,7 @@ class PointLayer:
         prev = self.src.producer
         assert prev is not None and not prev.pool
         prev._ensure_bwd_buffers()
-        rps = wgrad_rows_per_split(lib, self.M, K, K)
+        rps = gram_rows_per_split(lib, self.M, K, self.src.dtype)
         nch = (N + 127) // 128
         sl, red, emit_reduce = self._gram_reduce(plan, [('G', K * K, self.M // rps), ('abar', K, self.T), ('P', K * K, nch),
                                                         ('rowconst', K, nch)])
