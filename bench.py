@@ -86,12 +86,19 @@ def gemm_work(name, a):
         q = a[2]
         # the activation panel is read once for G = a'a and the column sums; w, coef in; G, abar, P, rowconst, wc out
         by = es(a[0].a.dtype) * a[0].M * a[0].K + 4.0 * (2 * q.K * q.K + 2 * q.K * q.N + 2 * q.K)
+        g0 = a[0]
+        if g0.a.dtype == 1 and g0.K in (128, 256) and g0.rows_per_split % 128 == 0 and g0.M // g0.rows_per_split >= min(256, g0.M // 128) \
+                and os.environ.get('T3D_GRAM1', '1') != '0':
+            return 'k_pool_bwd_stage1_h<%d,%d>' % (g0.K, 128 if g0.K == 128 else 64), gf + 2.0 * q.K * q.K * q.N, by      # one-pass form
         return 'k_pool_bwd_stage1<%s>' % gl[gl.index('<') + 1:gl.index(',')], gf + 2.0 * q.K * q.K * q.N, by
     if name == 't3d_pool_bwd_stage2':
         dl, df, db = gemm_work('t3d_pointmlp_dgrad_gram', a[1])
         f = a[0]
         # + w in, dW out, G in, the B*N arg-max rows of the input
         by = db + 4.0 * (2 * f.K * f.N + f.K * f.K) + es(f.a.dtype) * f.B * f.N * f.K
+        dm = int(os.environ.get('T3D_DGRAM1', '1'))
+        if a[1].dtype == 1 and os.environ.get('T3D_GRAM1', '1') != '0' and ((dm >= 1 and f.K == 256) or (dm == 2 and f.K == 128)):
+            return 'k_pool_bwd_stage2_h<%d,%d>' % (f.K, 128 if f.K == 128 else 64), df + 2.0 * f.K * f.K * f.N, by      # one-pass form
         return 'k_pool_bwd_stage2<%s>' % dl[dl.index('<') + 1:-1], df + 2.0 * f.K * f.K * f.N, by
     if name == 't3d_pointmlp_bwd':
         d, w = a
@@ -101,7 +108,7 @@ def gemm_work(name, a):
         by = es(d.dtype) * (2 * M * N + M * K * (2 + (0 if _null(d.add_in) else 1))) + 4.0 * 2 * K * N
         if d.dtype == 1 and w.a.dtype == 1 and ((K in (64, 128) and N in (64, 128)) or (K, N) in ((256, 128), (128, 256))) and w.rows_per_split % 128 == 0 and \
                 M // w.rows_per_split >= min(256, M // 128) and os.environ.get('T3D_BWD1', '1') != '0':
-            return 'k_pointmlp_bwd1<%d,%d>' % (K, N), df + wf, by      # one-pass form
+            return 'k_pointmlp_bwd1<%d,%d,%d>' % (K, N, 64 if 256 in (K, N) else 128), df + wf, by      # one-pass form
         return 'k_pointmlp_bwd<%s,%s>' % (dl[dl.index('<') + 1:-1], wl[wl.index('<') + 1:-1]), df + wf, by
     if name == 't3d_pointmlp_dgrad_gram':
         # (the sparse arg-max rows S behind add_live are read only where a row received a hit -- a data-dependent few percent of
