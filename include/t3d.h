@@ -454,6 +454,9 @@ typedef struct {
   uint32_t drop_seed;
   const float* drop_hyper;
   int dtype;                 /* element type of y and dz (T3D_F32 / T3D_BF16) */
+  /* optional: d loss / d soft_mask[m] (soft_mask = softmax(logits)[:,1]) from t3d_weak_loss, added to the logit gradients -- the
+   * head is then run a second time, behind the box losses, and rewrites dz, the partials and dw_part (NULL: none) */
+  const float* dsoft;        /* [M] or NULL */
 } t3d_seg_head_args;
 int t3d_seg_head(const t3d_seg_head_args* args, t3d_stream_t stream);
 
@@ -503,6 +506,50 @@ typedef struct {
   int B;
 } t3d_strong_loss_args;
 int t3d_strong_loss(const t3d_strong_loss_args* args, t3d_stream_t stream);
+
+/* ---- K9b: weak box losses of get_semi_loss_backbone, forward + backward ------------------------------------------------
+ * Replaces weak_losses.get_reprojection_loss (models/weak_losses.py:69-229, with tf_util.tf_rot_box_params_multi 1045-1072,
+ * tf_create_3D_box_by_vertices_multi 841-891, tf_get_2D_bbox_of_(softmax_)projection_sunrgbd_multi 364-449, tf_dilate_2D_bboxes
+ * 486-514, tf_clip_2D_bbox_to_image_dims_multi 517-540) and weak_losses.get_surface_loss (231-259, with
+ * tf_distance_to_closest_3D_box_surface_multi, tf_util.py:610-719) as called at semisup_v1_sunrgbd.py:270-311 on
+ * S_pred_box_reg = (center, reg_dims, reg_theta) -- the outputs of t3d_strong_loss:
+ *   weak[b] = w_reproj * reprojection[b] + w_surface * surface[b]
+ *   total_losses[b] += is_data_2D[b] * multiplier * weak[b];   loss += mean_b of that term
+ *   dbox7[b] = d loss / d (center, reg_dims, reg_theta)[b]     (feed t3d_anchor_reg_bwd)
+ *   dsoft[m] = d loss / d soft_mask[m]   (soft_mask = softmax(logits)[:,1]; the reference multiplies the surface loss by the
+ *              soft mask itself, so this gradient exists whatever WEAK_TRAIN_SEG_W_SURFACE says: feed t3d_seg_head.dsoft)
+ * Run after t3d_strong_loss (in/out: total_losses, loss).  Two launches (per-point surface distances; per-frustum finish). */
+typedef struct {
+  const float* center;       /* [B,3] */
+  const float* reg_dims;     /* [B,3] */
+  const float* reg_theta;    /* [B] */
+  const float* pc; int ld_pc;/* [B*N, ld_pc] xyz in cols 0..2 (surface loss) */
+  const float* logits;       /* [B*N,2] (surface loss) */
+  const float* Rtilt;        /* [B,3,3] */
+  const float* K;            /* [B,3,3] */
+  const float* rot_frust;    /* [B] */
+  const float* box2D;        /* [B,4] left, top, right, bottom */
+  const float* img_dim;      /* [B,2] rows, cols */
+  const int32_t* is_data_2D; /* [B] */
+  float w_reproj, w_surface; /* WEAK_WEIGHT_REPROJECTION, WEAK_WEIGHT_SURFACE */
+  float multiplier;          /* SEMI_MULTIPLIER_FOR_WEAK_LOSS */
+  int use_softmax_proj; float softmax_scale;      /* WEAK_REPROJECTION_USE_SOFTMAX_PROJ, _SOFTMAX_SCALE */
+  float dilate;              /* WEAK_REPROJECTION_DILATE_FACTOR */
+  int clip_lower_b_loss, clip_pred_box;           /* WEAK_REPROJECTION_CLIP_LOWERB_LOSS, _CLIP_PRED_BOX */
+  int loss_mse;              /* WEAK_REPROJECTION_LOSS_TYPE: 0 huber, 1 mse */
+  int32_t train_box_reproj[3];                    /* WEAK_TRAIN_BOX_W_REPROJECTION (centre, dims, theta) */
+  int32_t train_box_surface[3];                   /* WEAK_TRAIN_BOX_W_SURFACE */
+  float surface_margin, surface_scale_dims;       /* WEAK_SURFACE_MARGIN, WEAK_SURFACE_LOSS_SCALE_DIMS */
+  float* surf_part;          /* [B, N/128, 8] scratch */
+  float* dsoft;              /* [B*N] out or NULL */
+  float* reproj;             /* [B] out or NULL */
+  float* surface;            /* [B] out or NULL */
+  float* dbox7;              /* [B,7] out */
+  float* total_losses;       /* [B] in/out or NULL */
+  float* loss;               /* [1] in/out */
+  int B, N;
+} t3d_weak_loss_args;
+int t3d_weak_loss(const t3d_weak_loss_args* args, t3d_stream_t stream);
 
 /* ---- K8: Box-PC representation ----------------------------------------------------------------------
  * Replaces tf_get_box_pc_representation (tf_util.py:764-795) + tf_create_3D_box_by_surface_centers_multi

@@ -609,15 +609,40 @@ def get_strong_loss(pred, labels, ep, c, prefix=''):
     return mask_l, box_l
 
 
+WEAK_DEFAULTS = dict(       # models/config.py:111-162 of the reference
+    WEAK_TRAIN_SEG_W_SURFACE=False, WEAK_TRAIN_BOX_W_REPROJECTION=[True, True, True], WEAK_TRAIN_BOX_W_SURFACE=[True, False, True],
+    WEAK_REPROJECTION_USE_SOFTMAX_PROJ=False, WEAK_REPROJECTION_SOFTMAX_SCALE=10., WEAK_REPROJECTION_ONLY_ON_2D_CLS=False,
+    WEAK_REPROJECTION_CLIP_LOWERB_LOSS=True, WEAK_REPROJECTION_CLIP_PRED_BOX=False, WEAK_REPROJECTION_LOSS_TYPE='huber',
+    WEAK_REPROJECTION_DILATE_FACTOR=1.5, WEAK_SURFACE_MARGIN=0., WEAK_SURFACE_LOSS_WT_FOR_INNER_PTS=0.8,
+    WEAK_SURFACE_LOSS_SCALE_DIMS=0.9)
+
+
+def weak_flag(c, name):
+    return getattr(c, name, WEAK_DEFAULTS[name])
+
+
 def get_semi_loss_backbone(pred, labels, ep, c):
-    """semisup_v1_sunrgbd.py:256-321 with the zero-weight weak losses skipped (SURVEY App. E.4:
-    recipe a sets WEAK_WEIGHT_REPROJECTION = WEAK_WEIGHT_SURFACE = 0)."""
-    assert c.WEAK_WEIGHT_REPROJECTION == 0 and c.WEAK_WEIGHT_SURFACE == 0, \
-        'weak reprojection/surface losses are out of scope (zero weight in every published recipe)'
+    """semisup_v1_sunrgbd.py:256-321.  The weak reprojection / surface losses (oracle/ref_weak.py) are evaluated when their weight
+    is non-zero; their camera inputs (Rtilt, K, rot_frust, box2D, img_dim) come in through ep['weak_inputs']."""
     y_seg, y_center, yoc, yor, ydc, ydr, is2d = labels
     mask_l, box_l = get_strong_loss(pred, (y_seg, y_center, yoc, yor, ydc, ydr), ep, c)
     w3 = (1 - is2d).to(mask_l.dtype)
-    total = w3 * (mask_l + box_l)        # + is2d * 0
+    total = w3 * (mask_l + box_l)
+    if c.WEAK_WEIGHT_REPROJECTION != 0 or c.WEAK_WEIGHT_SURFACE != 0:
+        from . import ref_weak as W
+        wi = ep['weak_inputs']
+        box = ep['S_pred_box_reg']
+        reproj = W.get_reprojection_loss(
+            box, wi['box2D'], wi['Rtilt'], wi['K'], wi['img_dim'], wi['rot_frust'],
+            weak_flag(c, 'WEAK_REPROJECTION_USE_SOFTMAX_PROJ'), weak_flag(c, 'WEAK_REPROJECTION_SOFTMAX_SCALE'),
+            weak_flag(c, 'WEAK_REPROJECTION_DILATE_FACTOR'), weak_flag(c, 'WEAK_REPROJECTION_CLIP_LOWERB_LOSS'),
+            weak_flag(c, 'WEAK_REPROJECTION_CLIP_PRED_BOX'), weak_flag(c, 'WEAK_REPROJECTION_LOSS_TYPE'),
+            weak_flag(c, 'WEAK_TRAIN_BOX_W_REPROJECTION'), ep=ep)
+        surf = W.get_surface_loss(box, ep['point_cloud'][:, :, 0:3], ep['soft_mask'], weak_flag(c, 'WEAK_SURFACE_MARGIN'),
+                                  weak_flag(c, 'WEAK_SURFACE_LOSS_SCALE_DIMS'), weak_flag(c, 'WEAK_TRAIN_BOX_W_SURFACE'), ep=ep)
+        weak = c.WEAK_WEIGHT_REPROJECTION * reproj + c.WEAK_WEIGHT_SURFACE * surf
+        ep['reprojection_loss'], ep['surface_loss'], ep['weak_loss_fns'] = reproj, surf, weak
+        total = total + is2d.to(mask_l.dtype) * (weak * c.SEMI_MULTIPLIER_FOR_WEAK_LOSS)
     ep['total_losses'] = total
     return total.mean()
 
@@ -737,6 +762,8 @@ def model_a_forward_backward(P, batch, c, bn_decay_val=0.5, dtype=torch.float64,
     pc = torch.as_tensor(batch['pc'], dtype=dtype)
     oh = torch.as_tensor(batch['one_hot_vec'], dtype=dtype)
     pred, ep = get_semi_model_backbone(ctx, pc, oh, use_one_hot)
+    if 'Rtilt' in batch:
+        ep['weak_inputs'] = {k: torch.as_tensor(batch[k], dtype=dtype) for k in ('Rtilt', 'K', 'rot_frust', 'box2D', 'img_dim')}
     loss = get_semi_loss_backbone(pred, _labels_to_torch(batch, dtype), ep, c)
     grads = {}
     if want_grads:

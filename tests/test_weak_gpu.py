@@ -1,0 +1,107 @@
+"""GPU: t3d_weak_loss (reprojection + surface loss of get_semi_loss_backbone, forward-mode gradients inside the kernels) against the
+torch-autograd restatement oracle/ref_weak.py: per-frustum values, d loss / d (centre, dims, theta), d loss / d soft_mask."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_weak as W
+from transferable3d_amd import abi
+from transferable3d_amd.abi import fptr, iptr
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def camera_case(B, N, seed):
+    """Boxes 2-6 m in front of a SUN-RGBD-like camera (K as in the data set's calibration files, a small tilt), frustum-rotated."""
+    r = np.random.RandomState(seed)
+    center = np.stack([r.normal(0, 0.4, B), r.normal(0, 0.3, B), r.uniform(2.0, 6.0, B)], 1).astype(np.float32)
+    dims = r.uniform(0.4, 2.0, (B, 3)).astype(np.float32)
+    theta = r.uniform(-np.pi, np.pi, B).astype(np.float32)
+    tilt = r.normal(0, 0.05, B)
+    Rt = np.stack([np.array([[1, 0, 0], [0, np.cos(t), -np.sin(t)], [0, np.sin(t), np.cos(t)]]) for t in tilt]).astype(np.float32)
+    K = np.tile(np.array([[529.5, 0, 365.0], [0, 529.5, 265.0], [0, 0, 1.0]], np.float32), (B, 1, 1))
+    rot = r.normal(0, 0.3, (B, 1)).astype(np.float32)
+    img = np.tile(np.array([530.0, 730.0], np.float32), (B, 1))
+    # label boxes around the projection of a jittered box: some sides violated inwards, some outwards, some image-clipped
+    cx, cy = r.uniform(150, 580, B), r.uniform(100, 430, B)
+    hw, hh = r.uniform(40, 220, B), r.uniform(40, 200, B)
+    box2D = np.stack([cx - hw, cy - hh, cx + hw, cy + hh], 1).astype(np.float32)
+    pc = (center[:, None, :] + r.normal(0, 0.8, (B, N, 3))).astype(np.float32)
+    pc[0, 0] = center[0]                      # one point exactly at a box centre (tf_util.py:655-660)
+    logits = r.normal(0, 1.5, (B, N, 2)).astype(np.float32)
+    is2d = (r.uniform(size=B) < 0.7).astype(np.int32)
+    return dict(center=center, dims=dims, theta=theta, Rtilt=Rt, K=K, rot_frust=rot, img_dim=img, box2D=box2D, pc=pc, logits=logits,
+                is2d=is2d)
+
+
+@pytest.mark.parametrize('soft,clip_pred,clip_lb,loss_type,tb_r,tb_s', [
+    (False, False, True, 'huber', (1, 1, 1), (1, 0, 1)),          # the defaults of models/config.py
+    (True, False, True, 'huber', (1, 1, 1), (1, 1, 1)),
+    (False, True, True, 'mse', (1, 0, 1), (0, 1, 0)),
+    (False, False, False, 'huber', (1, 1, 0), (1, 1, 1)),
+    (True, True, False, 'mse', (1, 1, 1), (1, 0, 1))])
+def test_weak_loss_values_and_gradients(hip_lib, soft, clip_pred, clip_lb, loss_type, tb_r, tb_s):
+    B, N = 16, 256
+    d = camera_case(B, N, seed=3 + int(soft) + 2 * int(clip_pred))
+    w_r, w_s, mult, margin, sdims, dil, sscale = 0.01, 1.0, 0.5, 0.05, 0.9, 1.5, 10.0
+    t = {k: torch.as_tensor(v).to(DEV) for k, v in d.items()}
+    M = B * N
+    ldpc = 4
+    pc4 = torch.zeros(M, ldpc, device=DEV)
+    pc4[:, :3] = t['pc'].reshape(M, 3)
+    part, dsoft = torch.zeros(B, N // 128, 8, device=DEV), torch.zeros(M, device=DEV)
+    reproj, surf, dbox7 = torch.zeros(B, device=DEV), torch.zeros(B, device=DEV), torch.zeros(B, 7, device=DEV)
+    total = torch.full((B,), 0.25, device=DEV)
+    loss = torch.full((1,), 3.0, device=DEV)
+    a = abi.WeakLossArgs()
+    a.center, a.reg_dims, a.reg_theta = fptr(t['center']), fptr(t['dims']), fptr(t['theta'])
+    a.pc, a.ld_pc, a.logits = fptr(pc4), ldpc, fptr(t['logits'])
+    a.Rtilt, a.K, a.rot_frust, a.box2D, a.img_dim, a.is_data_2D = fptr(t['Rtilt']), fptr(t['K']), fptr(t['rot_frust']), fptr(t['box2D']), \
+        fptr(t['img_dim']), iptr(t['is2d'])
+    a.w_reproj, a.w_surface, a.multiplier = w_r, w_s, mult
+    a.use_softmax_proj, a.softmax_scale, a.dilate = int(soft), sscale, dil
+    a.clip_lower_b_loss, a.clip_pred_box, a.loss_mse = int(clip_lb), int(clip_pred), int(loss_type == 'mse')
+    a.train_box_reproj = (C.c_int32 * 3)(*tb_r)
+    a.train_box_surface = (C.c_int32 * 3)(*tb_s)
+    a.surface_margin, a.surface_scale_dims = margin, sdims
+    a.surf_part, a.dsoft, a.reproj, a.surface, a.dbox7 = fptr(part), fptr(dsoft), fptr(reproj), fptr(surf), fptr(dbox7)
+    a.total_losses, a.loss, a.B, a.N = fptr(total), fptr(loss), B, N
+    assert hip_lib.t3d_weak_loss(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    torch.cuda.synchronize()
+
+    # oracle (fp64 on the same fp32 inputs)
+    f64 = lambda k: torch.as_tensor(d[k], dtype=torch.float64)
+    center, dims, theta = f64('center').requires_grad_(True), f64('dims').requires_grad_(True), f64('theta').requires_grad_(True)
+    softm = torch.softmax(f64('logits'), -1)[:, :, 1].detach().requires_grad_(True)
+    box = (center, dims, theta)
+    r_ref = W.get_reprojection_loss(box, f64('box2D'), f64('Rtilt'), f64('K'), f64('img_dim'), f64('rot_frust'), soft, sscale, dil,
+                                    clip_lb, clip_pred, loss_type, [bool(x) for x in tb_r])
+    s_ref = W.get_surface_loss(box, f64('pc'), softm, margin, sdims, [bool(x) for x in tb_s])
+    is2d = f64('is2d')
+    add = is2d * mult * (w_r * r_ref + w_s * s_ref)
+    lref = add.mean()
+    gc, gd, gt, gs = torch.autograd.grad(lref, [center, dims, theta, softm], allow_unused=True)
+    z = lambda g, like: torch.zeros_like(like) if g is None else g
+    g7 = torch.cat([z(gc, center), z(gd, dims), z(gt, theta)[:, None]], 1)
+
+    def close(got, ref, what, rel):
+        got, ref = got.double().cpu(), ref.detach().double()
+        err = float((got - ref).abs().max())
+        assert err <= rel * max(1e-6, float(ref.abs().max())), (what, err, float(ref.abs().max()))
+
+    # fp32 geometry through a projection with focal length 530 and a division by the depth: ~1e-4 relative on pixel coordinates
+    close(reproj, r_ref, 'reprojection', 2e-4)
+    close(surf, s_ref, 'surface', 2e-5)
+    close(total - 0.25, add, 'total_losses increment', 2e-4)
+    close(loss - 3.0, lref.reshape(1), 'loss increment', 2e-4)
+    close(dbox7, g7, 'd loss / d box', 5e-4)
+    close(dsoft, z(gs, softm).reshape(-1), 'd loss / d soft_mask', 2e-5)
+    assert float(g7.abs().max()) > 0 and float(r_ref.abs().max()) > 0 and float(s_ref.abs().max()) > 0
+    # frozen box parts carry no gradient from the loss that froze them (both losses frozen -> exactly zero)
+    for i, (fr, fs) in enumerate(zip(tb_r, tb_s)):
+        if not fr and not fs:
+            cols = slice(3 * i, 3 * i + 3) if i < 2 else slice(6, 7)
+            assert float(dbox7[:, cols].abs().max()) == 0.0

@@ -170,7 +170,16 @@ class SegHeadArgs(C.Structure):
                 ('labels', I), ('is_data_2D', I), ('pc', F), ('ld_pc', i32), ('ce_weight', f32), ('logits', F),
                 ('mask', F), ('part', F), ('dz', F), ('psum_dz', F), ('psum_dzy', F), ('dw_part', F),
                 ('M', i32), ('K', i32), ('rows_per_frustum', i32), ('B', i32), ('drop_seed', C.c_uint32), ('drop_hyper', F),
-                ('dtype', i32)]
+                ('dtype', i32), ('dsoft', F)]
+
+
+class WeakLossArgs(C.Structure):
+    _fields_ = [('center', F), ('reg_dims', F), ('reg_theta', F), ('pc', F), ('ld_pc', i32), ('logits', F), ('Rtilt', F), ('K', F),
+                ('rot_frust', F), ('box2D', F), ('img_dim', F), ('is_data_2D', I), ('w_reproj', f32), ('w_surface', f32),
+                ('multiplier', f32), ('use_softmax_proj', i32), ('softmax_scale', f32), ('dilate', f32), ('clip_lower_b_loss', i32),
+                ('clip_pred_box', i32), ('loss_mse', i32), ('train_box_reproj', i32 * 3), ('train_box_surface', i32 * 3),
+                ('surface_margin', f32), ('surface_scale_dims', f32), ('surf_part', F), ('dsoft', F), ('reproj', F), ('surface', F),
+                ('dbox7', F), ('total_losses', F), ('loss', F), ('B', i32), ('N', i32)]
 
 
 class ActDropoutArgs(C.Structure):
@@ -246,6 +255,7 @@ ENTRY_POINTS = {
     't3d_pointmlp_bwd': [C.POINTER(PointMlpDgradArgs), C.POINTER(PointMlpWgradArgs), VP],
     't3d_wgrad_plan': [i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
     't3d_bwd_plan': [i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)],
+    't3d_weak_loss': [C.POINTER(WeakLossArgs), VP],
     't3d_gram_plan': [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)],
     't3d_bn_bwd_finalize': [C.POINTER(BnBwdFinalizeArgs), VP],
     't3d_dy_colsum': [C.POINTER(DyColsumArgs), VP],

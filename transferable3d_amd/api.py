@@ -70,10 +70,14 @@ class LazyPoints(Tensor):
 class Graph:
     """tf.Graph analogue: owns the runtime, the variable store and the recorded model assembly."""
 
-    def __init__(self, rt=None, seed=0, vars=None, inline_dropout=False):
+    def __init__(self, rt=None, seed=0, vars=None, inline_dropout=False, dtype=None):
         """inline_dropout: the segmentation head draws its dropout mask inside its kernel (no [M,128] mask tensor, no mask launch); a
-        graph built this way cannot be fed an explicit mask for that scope."""
+        graph built this way cannot be fed an explicit mask for that scope.  dtype: 'f32' (default; env T3D_DTYPE) or 'bf16' -- the
+        element type of the per-point layer tensors and of the GEMM operands (t3d.h T3D_BF16: BASELINE configs[4])."""
+        import os
         self._rt, self.seed, self._vars, self.inline_dropout = rt, seed, vars, inline_dropout
+        self.dtype = dtype or os.environ.get('T3D_DTYPE', 'f32')
+        assert self.dtype in ('f32', 'bf16'), self.dtype
         self.engine = None          # nets.Graph, created by the first placeholder_inputs
         self.inputs = None
         self.assembly = None
@@ -101,7 +105,7 @@ class Graph:
     def ensure_engine(self, batch_size, num_point, num_channel):
         if self.engine is None:
             vs = self._vars or VarStore(self.rt, seed=self.seed)
-            self.engine = _EngineGraph(batch_size, num_point, num_channel, rt=self.rt, seed=self.seed, vars=vs)
+            self.engine = _EngineGraph(batch_size, num_point, num_channel, rt=self.rt, seed=self.seed, vars=vs, dtype=self.dtype)
             self.engine.inline_dropout = self.inline_dropout
             self.inputs = Inputs(self.engine)
         else:

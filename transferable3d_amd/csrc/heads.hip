@@ -41,7 +41,9 @@ __device__ __forceinline__ float drop_keep(uint64_t key, size_t i, float keep) {
   return (float)(r >> 8) * (1.0f / 16777216.0f) < keep ? 1.f : 0.f;
 }
 
-template <class T>      // T: element type of conv9's raw output y and of dz (t3d_seg_head_args.dtype)
+// T: element type of conv9's raw output y and of dz (t3d_seg_head_args.dtype).  SOFT: the second run of the head behind the weak
+// surface loss (t3d_weak_loss): d loss / d soft_mask joins the logit gradients (an instantiation of its own: the usual one is untouched)
+template <class T, bool SOFT = false>
 __global__ __launch_bounds__(64 * SH_WAVES) void k_seg_head(const t3d_seg_head_args p) {
   __shared__ float red[SH_WAVES][SH_LD];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -110,6 +112,11 @@ __global__ __launch_bounds__(64 * SH_WAVES) void k_seg_head(const t3d_seg_head_a
     if (bwd) {
       g0 = ownf * wb * (expf(q0 - lse) - (lab == 0 ? 1.f : 0.f));
       g1 = ownf * wb * (expf(q1 - lse) - (lab == 1 ? 1.f : 0.f));
+      if (SOFT) {      // soft_mask = softmax(logits)[1]: d soft / d (q0, q1) = p1 (1 - p1) (-1, +1)
+        const float p1 = expf(q1 - lse), gs = ownf * p.dsoft[row] * p1 * (1.f - p1);
+        g0 -= gs;
+        g1 += gs;
+      }
     }
   }
   cnt = wave_sum_dpp(cnt); sx = wave_sum_dpp(sx); sy = wave_sum_dpp(sy); sz = wave_sum_dpp(sz);
@@ -442,6 +449,14 @@ extern "C" int t3d_seg_head(const t3d_seg_head_args* a, t3d_stream_t stream) {
   if (a->labels && !a->is_data_2D) return T3D_ERR_ARG;
   if (a->dz && (!a->labels || !a->psum_dz || !a->psum_dzy || !a->dw_part)) return T3D_ERR_ARG;
   if (a->K != 128 || a->M % T3D_TILE_ROWS || a->rows_per_frustum % T3D_TILE_ROWS) return T3D_ERR_SHAPE;
+  if (a->dsoft != nullptr) {
+    if (!a->labels || !a->dz) return T3D_ERR_ARG;      // the soft-mask gradient belongs to a training backward
+    if (a->dtype == T3D_BF16) T3D_LAUNCH((k_seg_head<bf16_t, true>), dim3(a->M / 128), dim3(64 * SH_WAVES), 0, static_cast<hipStream_t>(stream), *a);
+    else if (a->dtype == T3D_F32) T3D_LAUNCH((k_seg_head<float, true>), dim3(a->M / 128), dim3(64 * SH_WAVES), 0, static_cast<hipStream_t>(stream), *a);
+    else return T3D_ERR_ARG;
+    T3D_CHECK_LAUNCH();
+    return T3D_OK;
+  }
   if (a->dtype == T3D_BF16) T3D_LAUNCH(k_seg_head<bf16_t>, dim3(a->M / 128), dim3(64 * SH_WAVES), 0, static_cast<hipStream_t>(stream), *a);
   else if (a->dtype == T3D_F32) T3D_LAUNCH(k_seg_head<float>, dim3(a->M / 128), dim3(64 * SH_WAVES), 0, static_cast<hipStream_t>(stream), *a);
   else return T3D_ERR_ARG;

@@ -49,6 +49,8 @@ def build_flags(argv=None):
     cfg.add_argument('--num_channels', type=int, default=None)
     cfg.add_argument('--num_frustums', type=int, default=64)
     cfg.add_argument('--seed', type=int, default=0)
+    cfg.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+                     help='element type of the per-point layer tensors and GEMM operands (bf16: BASELINE configs[4]; weights, statistics, heads, losses and Adam stay fp32)')
     FLAGS = cfg.parse_special_args(argv)
     FLAGS.NUM_CHANNELS = FLAGS.num_channels if FLAGS.num_channels else (3 if FLAGS.no_rgb else 6)
     FLAGS.SEMI_MODEL = FLAGS.semi_type
@@ -62,7 +64,7 @@ def get_model(FLAGS, batch_size, num_point, num_channel, rt=None, state_dict=Non
     FLAGS.SEMI_REFINE_USING_BOXPC_DELTA_NUM = int(FLAGS.refine) if FLAGS.refine is not None else 0
     FLAGS.SEMI_WEIGH_BOXPC_DELTA_DURING_TEST = False                       # test_semisup.py:93
     FLAGS.BOX_PC_MASK_REPRESENTATION = 'A'
-    graph = api.Graph(rt=rt, seed=FLAGS.seed)
+    graph = api.Graph(rt=rt, seed=FLAGS.seed, dtype=FLAGS.dtype)
     with graph.as_default():
         pls = MODEL.placeholder_inputs(batch_size, num_point, num_channel)
         pred, end_points = MODEL.get_semi_model(pls[0], pls[1], pls[2], pls[3], False, use_one_hot=FLAGS.use_one_hot, c=FLAGS)

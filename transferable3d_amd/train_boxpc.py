@@ -45,6 +45,8 @@ def build_flags(argv=None):
     cfg.add_argument('--num_channels', type=int, default=None)
     cfg.add_argument('--steps_per_epoch', type=int, default=None, help='[default: one pass over the data set; 100 for --synthetic batches]')
     cfg.add_argument('--seed', type=int, default=0)
+    cfg.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+                     help='element type of the per-point layer tensors and GEMM operands (bf16: BASELINE configs[4]; weights, statistics, heads, losses and Adam stay fp32)')
     cfg.add_argument('--eval_file', default=None, help='held-out frustum file of the reference for eval_one_epoch (with --frustum_file / --device_data)')
     cfg.add_argument('--frustum_file', default=None, help='train from a frustum file of the reference (frustums/*.zip.pickle) held in HBM')
     cfg.add_argument('--eval_batches', type=int, default=0, help='held-out synthetic batches evaluated after every epoch (eval_one_epoch)')
@@ -61,7 +63,7 @@ def train(FLAGS, rt=None, log=print):
         torch.cuda.set_device(FLAGS.gpu)
     B, N, C = FLAGS.batch_size, FLAGS.num_point, FLAGS.NUM_CHANNELS
     os.makedirs(FLAGS.log_dir, exist_ok=True)
-    with api.Graph(rt=rt, seed=FLAGS.seed).as_default() as g:
+    with api.Graph(rt=rt, seed=FLAGS.seed, dtype=FLAGS.dtype).as_default() as g:
         pls = MODEL.placeholder_inputs(B, N, C)
         pc_pl, one_hot_vec_pl, y_seg_pl, x_center_pl, x_orient_cls_pl, x_orient_reg_pl, x_dims_cls_pl, x_dims_reg_pl, \
             y_box_iou_pl, y_center_delta_pl, y_dims_delta_pl, y_orient_delta_pl = pls

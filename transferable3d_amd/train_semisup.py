@@ -61,6 +61,8 @@ def build_flags(argv=None):
                      help='keep a synthetic data set of F ragged frustums in HBM and assemble every batch on the device '
                           '(t3d_batch_assemble: resample / centre-view rotation / flip / shift / labels)')
     cfg.add_argument('--seed', type=int, default=0)
+    cfg.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+                     help='element type of the per-point layer tensors and GEMM operands (bf16: BASELINE configs[4]; weights, statistics, heads, losses and Adam stay fp32)')
     cfg.add_argument('--eval_file', default=None, help='held-out frustum file of the reference for eval_one_epoch (with --frustum_file / --device_data)')
     cfg.add_argument('--frustum_file', default=None, help='train from a frustum file of the reference (frustums/*.zip.pickle) held in HBM')
     cfg.add_argument('--eval_batches', type=int, default=0, help='held-out synthetic batches evaluated after every epoch (eval_one_epoch)')
@@ -168,7 +170,7 @@ def train(FLAGS, rt=None, log=print):
     os.makedirs(FLAGS.log_dir, exist_ok=True)
     if rank == 0:
         log(FLAGS.config_str)
-    with api.Graph(rt=rt, seed=FLAGS.seed, inline_dropout=True).as_default() as g:
+    with api.Graph(rt=rt, seed=FLAGS.seed, inline_dropout=True, dtype=FLAGS.dtype).as_default() as g:
         pls = MODEL.placeholder_inputs(B, N, C)
         pc_pl, bg_pc_pl, img_pl, one_hot_vec_pl, y_seg_pl, y_centers_pl, y_orient_cls_pl, y_orient_reg_pl, y_dims_cls_pl, \
             y_dims_reg_pl, R0_rect_pl, P_pl, Rtilt_pl, K_pl, rot_frust_pl, box2D_pl, img_dim_pl, is_data_2D_pl = pls

@@ -56,6 +56,8 @@ def build_flags(argv=None):
                      help='keep a synthetic data set of F ragged frustums in HBM; batches (ALTERNATE_BATCH: weak / strong on '
                           'alternate steps) are assembled on the device by t3d_batch_assemble')
     cfg.add_argument('--seed', type=int, default=0)
+    cfg.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+                     help='element type of the per-point layer tensors and GEMM operands (bf16: BASELINE configs[4]; weights, statistics, heads, losses and Adam stay fp32)')
     FLAGS = cfg.parse_special_args(argv)
     FLAGS.NUM_CHANNELS = FLAGS.num_channels if FLAGS.num_channels else (3 if FLAGS.no_rgb else 6)
     FLAGS.TEST_CLS = FLAGS.SUNRGBD_SEMI_TEST_CLS
@@ -149,7 +151,7 @@ def train(FLAGS, rt=None, log=print):
     os.makedirs(FLAGS.log_dir, exist_ok=True)
     if FLAGS.SEMI_TRAIN_BOXPC_MODEL or FLAGS.SEMI_ADV_ITERS_FOR_D:
         raise NotImplementedError('training the Box-PC branch in stage c is dead code in the reference (SEMI_ADV_ITERS_FOR_D = 0)')
-    with api.Graph(rt=rt, seed=FLAGS.seed, inline_dropout=True).as_default() as g:
+    with api.Graph(rt=rt, seed=FLAGS.seed, inline_dropout=True, dtype=FLAGS.dtype).as_default() as g:
         pls = MODEL.placeholder_inputs(B, N, C)
         is_training_pl = api.is_training_placeholder()                    # train_semisup_adv.py:300 (is_training_D stays False)
         pred, end_points = MODEL.get_semi_model(pls[0], pls[1], pls[2], pls[3], is_training_pl, use_one_hot=FLAGS.use_one_hot, c=FLAGS)
