@@ -518,7 +518,8 @@ int t3d_strong_loss(const t3d_strong_loss_args* args, t3d_stream_t stream);
  *   dbox7[b] = d loss / d (center, reg_dims, reg_theta)[b]     (feed t3d_anchor_reg_bwd)
  *   dsoft[m] = d loss / d soft_mask[m]   (soft_mask = softmax(logits)[:,1]; the reference multiplies the surface loss by the
  *              soft mask itself, so this gradient exists whatever WEAK_TRAIN_SEG_W_SURFACE says: feed t3d_seg_head.dsoft)
- * Run after t3d_strong_loss (in/out: total_losses, loss).  Two launches (per-point surface distances; per-frustum finish). */
+ * Run after t3d_strong_loss (in/out: total_losses, loss).  Two launches (per-point surface distances; per-frustum finish).
+ * A loss is evaluated whenever its inputs are given (pc + logits; Rtilt .. img_dim), whatever its weight -- the reference logs both. */
 typedef struct {
   const float* center;       /* [B,3] */
   const float* reg_dims;     /* [B,3] */

@@ -632,6 +632,8 @@ def get_semi_loss_backbone(pred, labels, ep, c):
         from . import ref_weak as W
         wi = ep['weak_inputs']
         box = ep['S_pred_box_reg']
+        if ep.get('forced_S_box') is not None:      # flip-aware checks: the branches of the weak losses at the box the product predicted
+            box = tuple(o + (torch.as_tensor(f, dtype=o.dtype).reshape(o.shape) - o).detach() for o, f in zip(box, ep['forced_S_box']))
         reproj = W.get_reprojection_loss(
             box, wi['box2D'], wi['Rtilt'], wi['K'], wi['img_dim'], wi['rot_frust'],
             weak_flag(c, 'WEAK_REPROJECTION_USE_SOFTMAX_PROJ'), weak_flag(c, 'WEAK_REPROJECTION_SOFTMAX_SCALE'),
@@ -764,6 +766,8 @@ def model_a_forward_backward(P, batch, c, bn_decay_val=0.5, dtype=torch.float64,
     pred, ep = get_semi_model_backbone(ctx, pc, oh, use_one_hot)
     if 'Rtilt' in batch:
         ep['weak_inputs'] = {k: torch.as_tensor(batch[k], dtype=dtype) for k in ('Rtilt', 'K', 'rot_frust', 'box2D', 'img_dim')}
+    if forced and forced.get('S_box') is not None:
+        ep['forced_S_box'] = forced['S_box']
     loss = get_semi_loss_backbone(pred, _labels_to_torch(batch, dtype), ep, c)
     grads = {}
     if want_grads:

@@ -848,6 +848,10 @@ class FakeLib:
                 is2d = arr(p.is_data_2D, B)
                 wb = np.repeat(p.ce_weight * (1 - is2d) / (B * rpf), rpf)
                 g = (np.exp(l64 - lse[:, None]) - np.eye(2)[lab]) * wb[:, None]
+                if p.dsoft:      # d loss / d soft_mask from t3d_weak_loss: soft = softmax(logits)[:,1]
+                    p1 = np.exp(l64[:, 1] - lse)
+                    gs = arr(p.dsoft, M).astype(np.float64) * p1 * (1 - p1)
+                    g = g + np.stack([-gs, gs], 1)
                 part[:, 5:7] = g.reshape(T, 128, 2).sum(1)
                 arr(p.dw_part, T, K, 2)[:] = np.einsum('tik,tij->tkj', d.reshape(T, 128, K), g.reshape(T, 128, 2))
                 dz = np.where(z > 0, (g @ w.T) * keep, 0.0).astype(np.float32)
@@ -855,6 +859,46 @@ class FakeLib:
                 dz64 = dz.astype(np.float64).reshape(T, 128, K)
                 arr(p.psum_dz, T, K)[:] = dz64.sum(1)
                 arr(p.psum_dzy, T, K)[:] = (dz64 * y.reshape(T, 128, K)).sum(1)
+        return 0
+
+    def t3d_weak_loss(self, a, stream):
+        """Specification of the weak box losses: the torch-autograd restatement itself (tests/ may use oracle/)."""
+        import torch
+        from oracle import ref_weak as W
+        p = _struct(a)
+        B, N = p.B, p.N
+        t64 = lambda x, *shape: torch.as_tensor(np.array(arr(x, *shape)), dtype=torch.float64)
+        center, dims, theta = t64(p.center, B, 3).requires_grad_(True), t64(p.reg_dims, B, 3).requires_grad_(True), \
+            t64(p.reg_theta, B).requires_grad_(True)
+        is2d = torch.as_tensor(np.array(arr(p.is_data_2D, B)), dtype=torch.float64)
+        box = (center, dims, theta)
+        reproj = torch.zeros(B, dtype=torch.float64)
+        surf = torch.zeros(B, dtype=torch.float64)
+        soft = None
+        if p.Rtilt:
+            reproj = W.get_reprojection_loss(box, t64(p.box2D, B, 4), t64(p.Rtilt, B, 3, 3), t64(p.K, B, 3, 3), t64(p.img_dim, B, 2),
+                                             t64(p.rot_frust, B), bool(p.use_softmax_proj), p.softmax_scale, p.dilate,
+                                             bool(p.clip_lower_b_loss), bool(p.clip_pred_box), 'mse' if p.loss_mse else 'huber',
+                                             [bool(x) for x in p.train_box_reproj])
+        if p.pc:
+            soft = torch.softmax(t64(p.logits, B, N, 2), -1)[:, :, 1].detach().requires_grad_(True)
+            pc = t64(p.pc, B * N, p.ld_pc)[:, :3].reshape(B, N, 3)
+            surf = W.get_surface_loss(box, pc, soft, p.surface_margin, p.surface_scale_dims, [bool(x) for x in p.train_box_surface])
+        add = is2d * p.multiplier * (p.w_reproj * reproj + p.w_surface * surf)
+        lossv = add.mean()
+        ins = [center, dims, theta] + ([soft] if soft is not None else [])
+        gs = torch.autograd.grad(lossv, ins, allow_unused=True) if lossv.requires_grad else [None] * len(ins)
+        z = lambda g, like: (torch.zeros_like(like) if g is None else g).detach().numpy()
+        arr(p.dbox7, B, 7)[:] = np.concatenate([z(gs[0], center), z(gs[1], dims), z(gs[2], theta)[:, None]], 1)
+        if p.dsoft:
+            arr(p.dsoft, B * N)[:] = z(gs[3], soft).reshape(-1) if soft is not None else 0.0
+        if p.reproj:
+            arr(p.reproj, B)[:] = reproj.detach().numpy()
+        if p.surface:
+            arr(p.surface, B)[:] = surf.detach().numpy()
+        if p.total_losses:
+            arr(p.total_losses, B)[:] += add.detach().numpy()
+        arr(p.loss, 1)[0] += float(lossv.detach())
         return 0
 
     def t3d_seg_finalize(self, a, stream):

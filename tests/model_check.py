@@ -81,6 +81,13 @@ def product_decisions(model):
         # the hard segmentation mask (semisup_models.py:150: logit0 < logit1) is the same kind of decision: a point whose two logits
         # agree to fp32 rounding may fall on either side, which moves the masked centroid and everything behind it
         out['mask'] = seg.mask.detach().cpu().numpy().reshape(seg.g.B, seg.g.rpf)
+    weak, lo = getattr(model, 'weak', None), getattr(model, 'loss_op', None)
+    if weak is not None and lo is not None:
+        # the weak surface / reprojection losses are piecewise functions of the predicted box with a kink per point and face (|.|,
+        # the minimum over six faces, min / max over eight corners, the Huber bands): a forward difference of 3e-5 in the box centre
+        # moved d surface / d centre_y of one sample from +0.002 to -0.023 (tools/diag_weak*.py).  The oracle therefore evaluates
+        # those losses AT the box the product predicted (value substituted, gradient straight through to its own box).
+        out['S_box'] = (lo.center.detach().double().cpu(), lo.reg_dims.detach().double().cpu(), lo.reg_theta.detach().double().cpu())
     return out
 
 

@@ -105,3 +105,41 @@ def test_weak_loss_values_and_gradients(hip_lib, soft, clip_pred, clip_lb, loss_
         if not fr and not fs:
             cols = slice(3 * i, 3 * i + 3) if i < 2 else slice(6, 7)
             assert float(dbox7[:, cols].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('over,seed', [
+    (dict(WEAK_WEIGHT_REPROJECTION=0.01, WEAK_WEIGHT_SURFACE=1.0, SEMI_MULTIPLIER_FOR_WEAK_LOSS=1.0), 3),      # models/config.py defaults
+    (dict(WEAK_WEIGHT_REPROJECTION=0.02, WEAK_WEIGHT_SURFACE=0.5, SEMI_MULTIPLIER_FOR_WEAK_LOSS=0.5,
+          WEAK_REPROJECTION_USE_SOFTMAX_PROJ=True, WEAK_TRAIN_BOX_W_SURFACE=[True, True, True], WEAK_SURFACE_MARGIN=0.05), 4)])
+def test_model_a_with_weak_losses_matches_oracle_on_the_gpu(hip_lib, over, seed):
+    """SEMI_MODEL A forward + backward with the weak losses on, HIP kernels end to end, against the oracle (forward 1e-4, every
+    gradient tensor tight with the branches the run took): the weak term, its way into the box head / T-Net through the anchor->reg
+    conversion and into the seg net through the second run of the fused seg head."""
+    from test_weak_cpu import check_weak_model
+    from transferable3d_amd.engine import Runtime
+    check_weak_model(Runtime(lib=hip_lib), over, seed=seed)
+
+
+def test_training_step_with_default_weak_weights_replays(hip_lib):
+    """The step object with the reference's default weak weights: hipGraph replays are deterministic and the loss decreases."""
+    from transferable3d_amd.config import make_parser
+    from transferable3d_amd.engine import Runtime
+    from transferable3d_amd.step import build_training_step
+    from transferable3d_amd.synthetic import make_batch
+    B, N, Cc = 32, 1024, 4
+    c = make_parser().parse_special_args(['--SEMI_MODEL', 'A'])
+    batch = make_batch(B, N, Cc, seed=9)
+    batch['is_data_2D'] = (np.arange(B) % 2).astype(np.int32)
+    runs = []
+    for rep in range(2):
+        g, model, step, loss = build_training_step(Runtime(lib=hip_lib), 'A', B, N, Cc, c=c, seed=2)
+        assert model.weak is not None
+        model.inputs.load(batch)
+        cur = []
+        for k in range(8):
+            step.run()
+            cur.append(float(loss))
+        torch.cuda.synchronize()
+        runs.append((cur, g.vars.params[:g.vars.used].clone()))
+    assert all(np.isfinite(runs[0][0])) and runs[0][0][-1] < runs[0][0][0], runs[0][0]
+    assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void k_weak_finish(const t3d_weak_loss_args p,
       for (int i = 0; i < 8; ++i) sv[i] += p.surf_part[((size_t)b * tiles + t) * 8 + i];
     // reprojection
     D7 rl = dconst(0.f);
-    if (p.w_reproj != 0.f) {
+    if (p.Rtilt != nullptr) {      // evaluated whenever its inputs are given (the reference logs it at any weight)
       const Box7 x = load_box(p, b, p.train_box_reproj, 1.f);
       D7 u[8], v[8];
       project_corners(p, b, x, u, v);
@@ -302,16 +302,19 @@ __global__ __launch_bounds__(256) void k_weak_finish(const t3d_weak_loss_args p,
 
 extern "C" int t3d_weak_loss(const t3d_weak_loss_args* a, t3d_stream_t stream) {
   if (!a || !a->center || !a->reg_dims || !a->reg_theta || !a->is_data_2D || !a->dbox7 || !a->loss || !a->surf_part) return T3D_ERR_ARG;
-  if (a->w_surface != 0.f && (!a->pc || !a->logits)) return T3D_ERR_ARG;
-  if (a->w_reproj != 0.f && (!a->Rtilt || !a->K || !a->rot_frust || !a->box2D || !a->img_dim)) return T3D_ERR_ARG;
+  const bool surf = a->pc != nullptr, rep = a->Rtilt != nullptr;      // a loss is evaluated when its inputs are given, whatever its weight
+  if (a->w_surface != 0.f && !surf) return T3D_ERR_ARG;
+  if (a->w_reproj != 0.f && !rep) return T3D_ERR_ARG;
+  if (surf && !a->logits) return T3D_ERR_ARG;
+  if (rep && (!a->K || !a->rot_frust || !a->box2D || !a->img_dim)) return T3D_ERR_ARG;
   if (a->B <= 0 || a->B > 256 || a->N <= 0 || a->N % 128) return T3D_ERR_SHAPE;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int tiles = a->N / 128;
-  if (a->w_surface != 0.f) {
+  if (surf) {
     T3D_LAUNCH(k_weak_surface, dim3(tiles, a->B), dim3(128), 0, s, *a);
     T3D_CHECK_LAUNCH();
   }
-  T3D_LAUNCH(k_weak_finish, dim3(1), dim3(256), 0, s, *a, a->w_surface != 0.f ? tiles : 0);
+  T3D_LAUNCH(k_weak_finish, dim3(1), dim3(256), 0, s, *a, surf ? tiles : 0);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

@@ -248,7 +248,19 @@ class InstSegNet:
         if train_seg:
             f.dbias = fptr(g.vars.grad(self.scope + '/conv10/biases'))
         plan.add('t3d_seg_finalize', f)
+        self._head, self._head_slab, self._finalize = h, (soff if train_seg else None), f
         return self.logits
+
+    def emit_head_again(self, plan, dsoft):
+        """Second run of the fused head and its finalize with d loss / d soft_mask added to the logit gradients (weak surface loss,
+        nets.WeakLoss): same forward values, conv9's gradient / partials / conv10 gradients rewritten."""
+        assert self.train_seg, 'the soft-mask gradient needs the training backward of the seg head'
+        h = abi.SegHeadArgs()
+        C.memmove(C.byref(h), C.byref(self._head), C.sizeof(h))
+        h.dsoft = fptr(dsoft)
+        self.g.deferred_slab_ptrs.append((h, 'dw_part', self._head_slab))
+        plan.add('t3d_seg_head', h)
+        plan.add('t3d_seg_finalize', self._finalize)
 
     def bwd(self, plan, part=None):
         """part None: everything; 0 / 1 / 2: conv9..conv7 | conv6, conv5 | conv4..conv1 (the FC_SIDE schedule interleaves the
@@ -410,6 +422,64 @@ class StrongLoss:
         plan.add('t3d_strong_loss', a)
 
 
+WEAK_DEFAULTS = dict(       # models/config.py:119-162 of the reference (for configs built without the flag parser)
+    WEAK_TRAIN_BOX_W_REPROJECTION=[True, True, True], WEAK_TRAIN_BOX_W_SURFACE=[True, False, True],
+    WEAK_REPROJECTION_USE_SOFTMAX_PROJ=False, WEAK_REPROJECTION_SOFTMAX_SCALE=10., WEAK_REPROJECTION_CLIP_LOWERB_LOSS=True,
+    WEAK_REPROJECTION_CLIP_PRED_BOX=False, WEAK_REPROJECTION_LOSS_TYPE='huber', WEAK_REPROJECTION_DILATE_FACTOR=1.5,
+    WEAK_SURFACE_MARGIN=0., WEAK_SURFACE_LOSS_SCALE_DIMS=0.9)
+
+
+class WeakLoss:
+    """The weak reprojection + surface losses of get_semi_loss_backbone (semisup_v1_sunrgbd.py:270-311) on the box the strong loss
+    converted (S_pred_box_reg): `emit` adds them to the loss in the forward plan; `emit_backward` routes their gradients -- into the
+    box head and the T-Net centre through the anchor->reg conversion, and into the segmentation logits through the soft mask (a
+    second run of the fused seg head, which rewrites conv9's gradient, and of its finalize)."""
+
+    def __init__(self, g):
+        self.g = g
+        rt, B, N = g.rt, g.B, g.rpf
+        self.part, self.dsoft = rt.zeros(B, N // TILE, 8), rt.zeros(B * N)
+        self.reproj, self.surface, self.dbox7 = rt.zeros(B), rt.zeros(B), rt.zeros(B, 7)
+
+    @staticmethod
+    def active(c):
+        return getattr(c, 'WEAK_WEIGHT_REPROJECTION', 0) != 0 or getattr(c, 'WEAK_WEIGHT_SURFACE', 0) != 0
+
+    def emit(self, plan, loss_op, seg, x, c):
+        g = self.g
+        f = lambda k: getattr(c, k, WEAK_DEFAULTS[k])
+        a = abi.WeakLossArgs()
+        a.center, a.reg_dims, a.reg_theta = fptr(loss_op.center), fptr(loss_op.reg_dims), fptr(loss_op.reg_theta)
+        a.pc, a.ld_pc, a.logits = fptr(x.pc), g.ldpc, fptr(seg.logits)
+        a.Rtilt, a.K, a.rot_frust, a.box2D, a.img_dim = fptr(x.Rtilt), fptr(x.K), fptr(x.rot_frust), fptr(x.box2D), fptr(x.img_dim)
+        a.is_data_2D = iptr(x.is_data_2D)
+        a.w_reproj, a.w_surface = float(c.WEAK_WEIGHT_REPROJECTION), float(c.WEAK_WEIGHT_SURFACE)
+        a.multiplier = float(c.SEMI_MULTIPLIER_FOR_WEAK_LOSS)
+        a.use_softmax_proj, a.softmax_scale = int(bool(f('WEAK_REPROJECTION_USE_SOFTMAX_PROJ'))), float(f('WEAK_REPROJECTION_SOFTMAX_SCALE'))
+        a.dilate = float(f('WEAK_REPROJECTION_DILATE_FACTOR'))
+        a.clip_lower_b_loss, a.clip_pred_box = int(bool(f('WEAK_REPROJECTION_CLIP_LOWERB_LOSS'))), int(bool(f('WEAK_REPROJECTION_CLIP_PRED_BOX')))
+        lt = f('WEAK_REPROJECTION_LOSS_TYPE')
+        if lt not in ('huber', 'mse'):
+            raise Exception('Not implemented: %s' % lt)                      # weak_losses.py:33-34
+        a.loss_mse = int(lt == 'mse')
+        a.train_box_reproj = (C.c_int32 * 3)(*[int(bool(v)) for v in f('WEAK_TRAIN_BOX_W_REPROJECTION')])
+        a.train_box_surface = (C.c_int32 * 3)(*[int(bool(v)) for v in f('WEAK_TRAIN_BOX_W_SURFACE')])
+        a.surface_margin, a.surface_scale_dims = float(f('WEAK_SURFACE_MARGIN')), float(f('WEAK_SURFACE_LOSS_SCALE_DIMS'))
+        a.surf_part, a.dsoft = fptr(self.part), fptr(self.dsoft)
+        a.reproj, a.surface, a.dbox7 = fptr(self.reproj), fptr(self.surface), fptr(self.dbox7)
+        a.total_losses, a.loss, a.B, a.N = fptr(loss_op.total_losses), fptr(loss_op.loss), g.B, g.rpf
+        self.surface_on = a.w_surface != 0
+        plan.add('t3d_weak_loss', a)
+
+    def emit_backward(self, plan, loss_op, seg, box_head_out):
+        a = abi.AnchorRegBwdArgs()
+        a.box, a.ld_box, a.dbox7, a.dbox, a.dstage1, a.B = fptr(box_head_out), BOX_OUT_DIMS, fptr(self.dbox7), fptr(loss_op.dbox), \
+            fptr(loss_op.dstage1), self.g.B
+        plan.add('t3d_anchor_reg_bwd', a)
+        if self.surface_on:
+            seg.emit_head_again(plan, self.dsoft)
+
+
 def emit_box_head_iou(g, plan, box, stage1_center, labels, iou2d, iou3d):
     """compute_box3d_iou on raw box heads (roi_seg_box3d_dataset.py:103-140) as its own launch: the `W_` summary of stage c."""
     y_center, y_orient_cls, y_orient_reg, y_dims_cls, y_dims_reg, _ = labels
@@ -428,7 +498,11 @@ class Inputs:
               ('y_dims_cls', torch.int32, lambda B, N, C: (B,)), ('y_dims_reg', torch.float32, lambda B, N, C: (B, 3)),
               ('is_data_2D', torch.int32, lambda B, N, C: (B,)),
               ('y_box_iou', torch.float32, lambda B, N, C: (B,)), ('y_center_delta', torch.float32, lambda B, N, C: (B, 3)),
-              ('y_dims_delta', torch.float32, lambda B, N, C: (B, 3)), ('y_orient_delta', torch.float32, lambda B, N, C: (B,))]
+              ('y_dims_delta', torch.float32, lambda B, N, C: (B, 3)), ('y_orient_delta', torch.float32, lambda B, N, C: (B,)),
+              # camera side of the weak losses (semisup_v1_sunrgbd.py:52-62)
+              ('Rtilt', torch.float32, lambda B, N, C: (B, 9)), ('K', torch.float32, lambda B, N, C: (B, 9)),
+              ('rot_frust', torch.float32, lambda B, N, C: (B,)), ('box2D', torch.float32, lambda B, N, C: (B, 4)),
+              ('img_dim', torch.float32, lambda B, N, C: (B, 2))]
 
     def __init__(self, g):
         self.g = g
@@ -459,6 +533,7 @@ class ModelAssembly:
         self.g, self.c, self.use_one_hot = g, c, use_one_hot
         self.inputs = inputs or Inputs(g)
         self.seg = self.tnet = self.box = self.loss_op = None
+        self.weak = None
 
     def emit_forward(self, plan, is_training, with_loss):
         g, x, c = self.g, self.inputs, self.c
@@ -478,9 +553,15 @@ class ModelAssembly:
         if with_loss:
             lab = (x.y_center, x.y_orient_cls, x.y_orient_reg, x.y_dims_cls, x.y_dims_reg, x.is_data_2D)
             self.loss_op.emit(plan, box, s1, self.seg.seg_loss, lab, c)
+            if WeakLoss.active(c):       # reprojection / surface losses with non-zero weight (the reference's DEFAULT flags)
+                if self.weak is None:
+                    self.weak = WeakLoss(g)
+                self.weak.emit(plan, self.loss_op, self.seg, x, c)
 
     def emit_backward(self, plan):
         from .engine import FC_SIDE
+        if self.weak is not None:        # weak-loss gradients join dbox / dstage1 and conv9's gradient before anything reads them
+            self.weak.emit_backward(plan, self.loss_op, self.seg, self.box.box_params)
         if FC_SIDE and self.seg.train_seg:
             plan.two_streams = True
             with plan.side():
@@ -531,6 +612,8 @@ class ModelAssembly:
                        'total_losses': self.loss_op.total_losses, 'loss': self.loss_op.loss,
                        'S_dims': self.loss_op.reg_dims, 'S_theta': self.loss_op.reg_theta,
                        'iou2ds': self.loss_op.iou2d, 'iou3ds': self.loss_op.iou3d})
+        if self.weak is not None:
+            ep.update({'reprojection_loss': self.weak.reproj, 'surface_loss': self.weak.surface})
         return ep
 
 

@@ -11,8 +11,8 @@ INPUT_IMG_CHANNELS = 3
 
 
 def placeholder_inputs(batch_size, num_point, num_channel):
-    """The reference's 18 placeholders, same order.  Those that feed only out-of-scope paths (bg_pc, img, KITTI
-    and SUN-RGBD camera matrices, 2-D boxes: weak losses with zero weight) are accepted and ignored."""
+    """The reference's 18 placeholders, same order.  bg_pc, img and the KITTI matrices (R0_rect, P) feed nothing on the SUN-RGBD
+    path and are accepted and ignored; Rtilt, K, rot_frust, box2D, img_dim feed the weak reprojection loss."""
     ctx = api.get_default_graph()
     ctx.ensure_engine(batch_size, num_point, num_channel)
     B, N, C = batch_size, num_point, num_channel
@@ -20,8 +20,8 @@ def placeholder_inputs(batch_size, num_point, num_channel):
     return (P('pc', (B, N, C)), P(None, (B, N, C), name='bg_pc'), P(None, (B, None, None, INPUT_IMG_CHANNELS), name='img'),
             P('one_hot_vec', (B, NUM_CLASS)), P('y_seg', (B, N)), P('y_center', (B, 3)), P('y_orient_cls', (B,)),
             P('y_orient_reg', (B,)), P('y_dims_cls', (B,)), P('y_dims_reg', (B, 3)), P(None, (B, 3, 3), name='R0_rect'),
-            P(None, (B, 3, 4), name='P'), P(None, (B, 3, 3), name='Rtilt'), P(None, (B, 3, 3), name='K'),
-            P(None, (B, 1), name='rot_frust'), P(None, (B, 4), name='box2D'), P(None, (B, 2), name='img_dim'),
+            P(None, (B, 3, 4), name='P'), P('Rtilt', (B, 3, 3)), P('K', (B, 3, 3)),
+            P('rot_frust', (B, 1)), P('box2D', (B, 4)), P('img_dim', (B, 2)),
             P('is_data_2D', (B,)))
 
 
@@ -192,11 +192,9 @@ def get_semi_loss_final(pred, labels, end_points, reduce_loss=True, c=None):
 
 
 def get_semi_loss_backbone(pred, labels, end_points, reduce_loss=True, c=None):
-    """mean_b (1-is2D)*(seg CE + strong box loss) (semisup_v1_sunrgbd.py:256-321).  The weak reprojection / surface
-    losses have weight 0 in the published recipe a (README.md:65-66) and are not evaluated (documented deviation)."""
-    if c.WEAK_WEIGHT_REPROJECTION != 0 or c.WEAK_WEIGHT_SURFACE != 0:
-        raise NotImplementedError('weak reprojection / surface losses are out of scope (zero weight in recipe a); '
-                                  'pass --WEAK_WEIGHT_REPROJECTION 0 --WEAK_WEIGHT_SURFACE 0')
+    """mean_b [(1-is2D)*(seg CE + strong box loss) + is2D*SEMI_MULTIPLIER*(w_r*reprojection + w_s*surface)]
+    (semisup_v1_sunrgbd.py:256-321).  The weak losses (nets.WeakLoss, t3d_weak_loss) are part of the graph whenever their weight
+    is non-zero -- the reference's default flags; recipe a of its README sets both to 0."""
     logits = pred[0]
     ctx = logits.ctx
     asm, B = ctx.assembly, ctx.engine.B
@@ -205,6 +203,12 @@ def get_semi_loss_backbone(pred, labels, end_points, reduce_loss=True, c=None):
     end_points['center'] = T(asm.loss_op.center, (B, 3), 'center')
     end_points['iou2ds'] = T(asm.loss_op.iou2d, (B,), 'iou2ds')          # get_iou_summary (semisup_v1_sunrgbd.py:236-246,316)
     end_points['iou3ds'] = T(asm.loss_op.iou3d, (B,), 'iou3ds')
+    from .nets import WeakLoss
+    if WeakLoss.active(c) and asm.weak is None:
+        asm.weak = WeakLoss(ctx.engine)
+    if asm.weak is not None:
+        end_points['reproj_loss'] = T(asm.weak.reproj, (B,), 'reproj_loss')          # weak_losses.py:226
+        end_points['surface_loss'] = T(asm.weak.surface, (B,), 'surface_loss')       # weak_losses.py:257
     total = T(asm.loss_op.loss, (), 'semi_loss')
     ctx.loss = total if reduce_loss else T(asm.loss_op.total_losses, (B,), 'semi_losses')
     return ctx.loss

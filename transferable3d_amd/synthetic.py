@@ -39,6 +39,17 @@ def make_batch(batch_size=32, num_point=1024, num_channel=4, seed=1234, is_data_
         'is_data_2D': np.full((B,), int(is_data_2D), np.int32),
     }
     assert NUM_SIZE_CLUSTER == NUM_CLASS
+    # camera side of the weak losses (semisup_v1_sunrgbd.placeholder_inputs: Rtilt, K, rot_frust, box2D, img_dim): a SUN-RGBD-like
+    # calibration, a small tilt, a frustum angle, and a 2-D label box around the image centre.  Drawn from a generator of its own so
+    # that the fields above are what they were before these existed (committed golden fixtures).
+    r2 = np.random.RandomState(seed + 7919)
+    tilt = r2.normal(0, 0.05, size=B)
+    batch['Rtilt'] = np.stack([np.array([[1, 0, 0], [0, np.cos(t), -np.sin(t)], [0, np.sin(t), np.cos(t)]]) for t in tilt]).astype(np.float32)
+    batch['K'] = np.tile(np.array([[529.5, 0, 365.0], [0, 529.5, 265.0], [0, 0, 1.0]], np.float32), (B, 1, 1))
+    batch['rot_frust'] = r2.normal(0, 0.3, size=(B, 1)).astype(np.float32)
+    batch['img_dim'] = np.tile(np.array([530.0, 730.0], np.float32), (B, 1))
+    cx, cy, hw, hh = r2.uniform(150, 580, B), r2.uniform(100, 430, B), r2.uniform(40, 220, B), r2.uniform(40, 200, B)
+    batch['box2D'] = np.stack([cx - hw, cy - hh, cx + hw, cy + hh], 1).astype(np.float32)
     if boxpc:
         batch['y_box_iou'] = r.uniform(0, 1, size=B).astype(np.float32)
         batch['y_center_delta'] = r.uniform(-0.2, 0.2, size=(B, 3)).astype(np.float32)
