@@ -753,6 +753,16 @@ typedef struct {
    * (roi_semi_dataset.py:383-452): resampled and rotated to the centre view, but NOT flipped or shifted ("2D Classes cannot be
    * augmented because the projection will no longer be accurate"), and every 3-D label (y_seg, y_center, orientation and size
    * class / residual) is written as zero; one_hot and rot_angle are kept. */
+  /* optional camera side of the weak losses: per-frustum calibration and 2-D box of the data set (roi_semi_dataset.py:243-246,
+   * 355-359) copied to the batch slot (the frustum rotation the reprojection loss undoes is rot_angle).  cam_rtilt == NULL: none */
+  const float* cam_rtilt;      /* [F,9] */
+  const float* cam_k;          /* [F,9] */
+  const float* cam_box2d;      /* [F,4] left, top, right, bottom */
+  const float* cam_img_dim;    /* [F,2] rows, cols */
+  float* Rtilt;                /* [B,9] out */
+  float* K;                    /* [B,9] out */
+  float* box2D;                /* [B,4] out */
+  float* img_dim;              /* [B,2] out */
 } t3d_batch_assemble_args;
 int t3d_batch_assemble(const t3d_batch_assemble_args* args, t3d_stream_t stream);
 

@@ -436,6 +436,12 @@ class FakeLib:
             oh[b, cls[f]] = 1
             if p.rot_angle:
                 arr(p.rot_angle, B)[b] = rot
+            if p.cam_rtilt:
+                F_ = len(cls)
+                arr(p.Rtilt, B, 9)[b] = arr(p.cam_rtilt, F_, 9)[f]
+                arr(p.K, B, 9)[b] = arr(p.cam_k, F_, 9)[f]
+                arr(p.box2D, B, 4)[b] = arr(p.cam_box2d, F_, 4)[f]
+                arr(p.img_dim, B, 2)[b] = arr(p.cam_img_dim, F_, 2)[f]
             if is2d:                        # get_classes2D: every 3-D label is zero
                 yseg[b] = 0
                 arr(p.y_orient_cls, B)[b] = 0

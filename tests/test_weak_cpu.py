@@ -107,3 +107,18 @@ def test_builder_api_with_the_reference_default_flags():
     assert np.abs(surf - ep['surface_loss'].detach().numpy()).max() < 2e-4 * max(1.0, float(ep['surface_loss'].abs().max()))
     moved = max(float(np.abs(P1[k].astype(np.float64).reshape(P0[k].shape) - P0[k].numpy()).max()) for k in R.trainable_names(P0))
     assert moved > 1e-4      # Adam stepped
+
+
+def test_train_cli_with_the_default_flags_host_fed_and_device_assembled(tmp_path):
+    """`train_semisup.py --SEMI_MODEL A` without zeroing the weak weights (the reference's defaults): synthetic batches fed from the
+    host, and a device-resident data set whose calibration / 2-D boxes t3d_batch_assemble copies into the batch slots."""
+    from transferable3d_amd.train_semisup import build_flags, train
+    for i, extra in enumerate((['--synthetic', '--steps_per_epoch', '3'], ['--device_data', '40'])):
+        FLAGS = build_flags(['--SEMI_MODEL', 'A', '--num_point', '128', '--batch_size', '4', '--num_channels', '4', '--max_epoch', '1',
+                             '--eval_batches', '1', '--log_dir', str(tmp_path / str(i))] + extra)
+        assert FLAGS.WEAK_WEIGHT_REPROJECTION == 0.01 and FLAGS.WEAK_WEIGHT_SURFACE == 1.0
+        logs = []
+        _, last = train(FLAGS, rt=Runtime(device='cpu', lib=FakeLib()), log=logs.append)
+        assert np.isfinite(last)
+        ev = [l for l in logs if l.startswith('eval mean loss')]
+        assert ev and np.isfinite(float(ev[0].split(':')[1]))

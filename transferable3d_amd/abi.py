@@ -127,7 +127,8 @@ class BatchAssembleArgs(C.Structure):
                 ('rotate_to_center', i32), ('random_flip', i32), ('random_shift', i32), ('seed', C.c_uint32), ('hyper', F), ('pc', F),
                 ('y_seg', I), ('y_center', F), ('y_orient_cls', I), ('y_orient_reg', F), ('y_dims_cls', I), ('y_dims_reg', F),
                 ('one_hot', F), ('rot_angle', F), ('sample2', I), ('sample2_len', i32), ('is_data_2D', I), ('frustum_is_2D', I), ('ld_pc', i32),
-                ('slot_is_2D', I)]
+                ('slot_is_2D', I), ('cam_rtilt', F), ('cam_k', F), ('cam_box2d', F), ('cam_img_dim', F), ('Rtilt', F), ('K', F), ('box2D', F),
+                ('img_dim', F)]
 
 
 class BnBwdFinalizeArgs(C.Structure):

@@ -34,6 +34,14 @@ class DeviceFrustumSet:
         rt.allocs.extend([self.points, self.seg, self.offsets, self.frustum_angle, self.box_center, self.heading, self.size, self.cls,
                           self.perm])
 
+    def set_camera(self, rtilt, k, box2d, img_dims):
+        """Camera side of the weak losses, per frustum: Rtilt [F,3,3], K [F,3,3], 2-D box [F,4] (left, top, right, bottom), image
+        (rows, cols) [F,2] (roi_semi_dataset.py:243-246).  t3d_batch_assemble copies them to the batch slots."""
+        up = lambda a, n: torch.as_tensor(np.ascontiguousarray(np.asarray(a, np.float32).reshape(self.F, n))).to(self.rt.device)
+        self.cam = (up(rtilt, 9), up(k, 9), up(box2d, 4), up(img_dims, 2))
+        self.rt.allocs.extend(self.cam)
+        return self
+
     @classmethod
     def from_lists(cls, rt, points_l, label_l, frustum_angle_l, box3d_center_l, heading_l, size_l, cls_id_l):
         """The reference's per-frustum lists (roi_semi_dataset.py:240-252; box centre = (corner0 + corner6) / 2)."""
@@ -48,7 +56,8 @@ class DeviceFrustumSet:
         roi_semi_dataset.py:204-252 / box_pc_fit_dataset.py:59-60): a gzip'd pickle of 13 lists [idx, box2d, box3d (8,3), image_crop,
         points (n,6), label (n,), cls_type (str), heading, size (l,w,h), rtilt, k, frustum_angle, img_dims].  `classes`: keep only these
         class names (the dataset classes' `classes` argument)."""
-        idx_l, box2d_l, box3d_l, _, points_l, label_l, cls_type_l, heading_l, size_l, _, _, frustum_angle_l, _ = load_zipped_pickle(path)
+        idx_l, box2d_l, box3d_l, _, points_l, label_l, cls_type_l, heading_l, size_l, rtilt_l, k_l, frustum_angle_l, img_dims_l = \
+            load_zipped_pickle(path)
         keep = [i for i, t in enumerate(cls_type_l) if classes is None or t in classes]
         if not keep:
             raise ValueError('%s: no frustum of classes %s' % (path, classes))
@@ -59,6 +68,7 @@ class DeviceFrustumSet:
         ds.image_ids = pick(idx_l)
         ds.box3d = [np.asarray(b, np.float64) for b in pick(box3d_l)]        # label corners in camera coordinates (evaluation)
         ds.class_names = pick(cls_type_l)
+        ds.set_camera(pick(rtilt_l), pick(k_l), pick(box2d_l), [np.asarray(d)[:2] for d in pick(img_dims_l)])
         return ds
 
     @classmethod
@@ -83,7 +93,8 @@ class DeviceFrustumSet:
     def synthetic(cls, rt, n_frustums, num_channel=6, seed=0, min_points=400, max_points=3000):
         """Frustums of the SURVEY 8d distribution with ragged point counts (real frustums have a few hundred to a few thousand)."""
         host = synthetic_frustums(n_frustums, num_channel, seed, min_points, max_points)
-        return cls(rt, **host)
+        cam = synthetic_cameras(n_frustums, seed)
+        return cls(rt, **host).set_camera(**cam)
 
     def partition(self, rank, world, batch_size, steps=None):
         """One pass over the data set per epoch, shared between `world` data-parallel replicas: every replica draws the SAME epoch
@@ -187,6 +198,11 @@ class DeviceFrustumSet:
         a.y_orient_cls, a.y_orient_reg = iptr(inputs.y_orient_cls), fptr(inputs.y_orient_reg)
         a.y_dims_cls, a.y_dims_reg, a.one_hot = iptr(inputs.y_dims_cls), fptr(inputs.y_dims_reg), fptr(inputs.one_hot_vec)
         a.is_data_2D = iptr(inputs.is_data_2D)
+        a.rot_angle = fptr(getattr(inputs, 'rot_frust', None))          # the reference's rot_frust feed is the batch's rot_angle
+        cam = getattr(self, 'cam', None)
+        if cam is not None and getattr(inputs, 'Rtilt', None) is not None:
+            a.cam_rtilt, a.cam_k, a.cam_box2d, a.cam_img_dim = fptr(cam[0]), fptr(cam[1]), fptr(cam[2]), fptr(cam[3])
+            a.Rtilt, a.K, a.box2D, a.img_dim = fptr(inputs.Rtilt), fptr(inputs.K), fptr(inputs.box2D), fptr(inputs.img_dim)
         a.frustum_is_2D = iptr(getattr(self, 'is_2D', None))
         a.ld_pc = int(inputs.pc.shape[1])
         if alternate:
@@ -263,6 +279,18 @@ def synthetic_frustums(n_frustums, num_channel=6, seed=0, min_points=400, max_po
         seg[lo:hi] = fg
         center[f] = un(cen_c)
     return dict(points=pts, seg=seg, offsets=offsets, frustum_angle=fang, box_center=center, heading=heading, size=size, cls=cls_id)
+
+
+def synthetic_cameras(n_frustums, seed=0):
+    """A SUN-RGBD-like calibration per synthetic frustum: K of the data set's Kinect v2 images, a small tilt, a 2-D box."""
+    r = np.random.RandomState(seed + 7919)
+    tilt = r.normal(0, 0.05, size=n_frustums)
+    rtilt = np.stack([np.array([[1, 0, 0], [0, np.cos(t), -np.sin(t)], [0, np.sin(t), np.cos(t)]]) for t in tilt])
+    k = np.tile(np.array([[529.5, 0, 365.0], [0, 529.5, 265.0], [0, 0, 1.0]]), (n_frustums, 1, 1))
+    cx, cy, hw, hh = r.uniform(150, 580, n_frustums), r.uniform(100, 430, n_frustums), r.uniform(40, 220, n_frustums), \
+        r.uniform(40, 200, n_frustums)
+    return dict(rtilt=rtilt, k=k, box2d=np.stack([cx - hw, cy - hh, cx + hw, cy + hh], 1),
+                img_dims=np.tile(np.array([530.0, 730.0]), (n_frustums, 1)))
 
 
 def open_training_set(rt, FLAGS, num_channel, classes=None, seed=0):

@@ -96,7 +96,8 @@ def eval_one_epoch(sess, ops, FLAGS, epoch, log, source=None):
             lab = b['y_seg']
             feed = {pc_pl: b['pc'], one_hot_vec_pl: b['one_hot_vec'], y_seg_pl: b['y_seg'], y_centers_pl: b['y_center'],
                     y_orient_cls_pl: b['y_orient_cls'], y_orient_reg_pl: b['y_orient_reg'], y_dims_cls_pl: b['y_dims_cls'],
-                    y_dims_reg_pl: b['y_dims_reg'], is_data_2D_pl: np.zeros(B, np.int32), is_training_pl: False}
+                    y_dims_reg_pl: b['y_dims_reg'], is_data_2D_pl: np.zeros(B, np.int32), is_training_pl: False,
+                    pls[12]: b['Rtilt'], pls[13]: b['K'], pls[14]: b['rot_frust'], pls[15]: b['box2D'], pls[16]: b['img_dim']}
         heads = [end_points[k] for k in ('center', 'heading_scores', 'heading_residuals', 'size_scores', 'size_residuals')]
         loss_val, logits, i2, i3, cen, hs, hr, ss, sr = sess.run(
             [semi_loss, end_points_logits(end_points, sess), end_points['iou2ds'], end_points['iou3ds']] + heads, feed_dict=feed)
@@ -237,7 +238,10 @@ def train(FLAGS, rt=None, log=print):
                 feed = {pc_pl: batch['pc'], one_hot_vec_pl: batch['one_hot_vec'], y_seg_pl: batch['y_seg'],
                         y_centers_pl: batch['y_center'], y_orient_cls_pl: batch['y_orient_cls'],
                         y_orient_reg_pl: batch['y_orient_reg'], y_dims_cls_pl: batch['y_dims_cls'],
-                        y_dims_reg_pl: batch['y_dims_reg'], is_data_2D_pl: batch['is_data_2D']}
+                        y_dims_reg_pl: batch['y_dims_reg'], is_data_2D_pl: batch['is_data_2D'],
+                        # camera side of the weak losses (their default weights are non-zero: models/config.py:112-113)
+                        Rtilt_pl: batch['Rtilt'], K_pl: batch['K'], rot_frust_pl: batch['rot_frust'], box2D_pl: batch['box2D'],
+                        img_dim_pl: batch['img_dim']}
                 feed[is_training_pl] = True
                 loss_val, nc, i2, i3, _ = sess.run([semi_loss, n_correct, iou2ds, iou3ds, train_op], feed_dict=feed)
                 loss_sum += float(loss_val)
