@@ -518,7 +518,7 @@ int t3d_strong_loss(const t3d_strong_loss_args* args, t3d_stream_t stream);
  *   dbox7[b] = d loss / d (center, reg_dims, reg_theta)[b]     (feed t3d_anchor_reg_bwd)
  *   dsoft[m] = d loss / d soft_mask[m]   (soft_mask = softmax(logits)[:,1]; the reference multiplies the surface loss by the
  *              soft mask itself, so this gradient exists whatever WEAK_TRAIN_SEG_W_SURFACE says: feed t3d_seg_head.dsoft)
- * Run after t3d_strong_loss (in/out: total_losses, loss).  Two launches (per-point surface distances; per-frustum finish).
+ * Run after t3d_strong_loss / t3d_semi_final_loss (in/out: total_losses, loss).  Two launches (per-point surface distances; per-frustum finish).
  * A loss is evaluated whenever its inputs are given (pc + logits; Rtilt .. img_dim), whatever its weight -- the reference logs both. */
 typedef struct {
   const float* center;       /* [B,3] */
@@ -531,7 +531,7 @@ typedef struct {
   const float* rot_frust;    /* [B] */
   const float* box2D;        /* [B,4] left, top, right, bottom */
   const float* img_dim;      /* [B,2] rows, cols */
-  const int32_t* is_data_2D; /* [B] */
+  const int32_t* is_data_2D; /* [B], or NULL: every sample counts (get_semi_loss_final without WEAK_REPROJECTION_ONLY_ON_2D_CLS) */
   float w_reproj, w_surface; /* WEAK_WEIGHT_REPROJECTION, WEAK_WEIGHT_SURFACE */
   float multiplier;          /* SEMI_MULTIPLIER_FOR_WEAK_LOSS */
   int use_softmax_proj; float softmax_scale;      /* WEAK_REPROJECTION_USE_SOFTMAX_PROJ, _SOFTMAX_SCALE */
@@ -549,6 +549,14 @@ typedef struct {
   float* total_losses;       /* [B] in/out or NULL */
   float* loss;               /* [1] in/out */
   int B, N;
+  /* stage c (get_semi_loss_final, semisup_v1_sunrgbd.py:345-359): the inactive-volume loss of the box dims per class
+   * (weak_losses.get_inactive_volume_loss_v1, weak_losses.py:39-67): loss += multiplier * w_inactive * mean over the trained classes
+   * of mean_{b in class} max(0, margin[class] - l*w*h); its gradient joins dbox7[:,3:6].  w_inactive == 0: none */
+  const float* one_hot;      /* [B,10] class one-hot (class_ids = arg-max) or NULL */
+  float w_inactive;          /* WEAK_WEIGHT_INACTIVE_VOLUME */
+  float inactive_margins[10];/* WEAK_INACTIVE_VOL_LOSS_MARGINS */
+  int32_t inactive_train[10];/* end_points['inactive_vol_train_classes'] */
+  float* inactive;           /* [1] out or NULL */
 } t3d_weak_loss_args;
 int t3d_weak_loss(const t3d_weak_loss_args* args, t3d_stream_t stream);
 

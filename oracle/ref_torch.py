@@ -681,7 +681,29 @@ def get_semi_loss_final(pred, labels, ep, c):
         icv = intraclass_variance_loss(F_dims, ep['class_ids'], ep['intraclsdims_train_classes'])
         ep['intraclass_variance_loss'] = icv
         weak = weak + c.WEAK_WEIGHT_INTRACLASSVAR * icv
-    assert c.WEAK_WEIGHT_REPROJECTION == 0 and c.WEAK_WEIGHT_INACTIVE_VOLUME == 0
+    if getattr(c, 'WEAK_WEIGHT_INACTIVE_VOLUME', 0) != 0:       # semisup_v1_sunrgbd.py:348-359
+        from . import ref_weak as W
+        _, F_dims, _ = ep['F_pred_box_reg']
+        iv = W.get_inactive_volume_loss_v1(F_dims, ep['class_ids'], ep['inactive_vol_train_classes'],
+                                           torch.as_tensor(c.WEAK_INACTIVE_VOL_LOSS_MARGINS, dtype=F_dims.dtype))
+        ep['inactive_vol_loss'] = iv
+        weak = weak + c.WEAK_WEIGHT_INACTIVE_VOLUME * iv
+    if c.WEAK_WEIGHT_REPROJECTION != 0:                         # semisup_v1_sunrgbd.py:373-392
+        from . import ref_weak as W
+        wi = ep['weak_inputs']
+        box = ep['F_pred_box_reg']
+        if ep.get('forced_S_box') is not None:                  # see get_semi_loss_backbone
+            box = tuple(o + (torch.as_tensor(f, dtype=o.dtype).reshape(o.shape) - o).detach() for o, f in zip(box, ep['forced_S_box']))
+        reproj = W.get_reprojection_loss(
+            box, wi['box2D'], wi['Rtilt'], wi['K'], wi['img_dim'], wi['rot_frust'],
+            weak_flag(c, 'WEAK_REPROJECTION_USE_SOFTMAX_PROJ'), weak_flag(c, 'WEAK_REPROJECTION_SOFTMAX_SCALE'),
+            weak_flag(c, 'WEAK_REPROJECTION_DILATE_FACTOR'), weak_flag(c, 'WEAK_REPROJECTION_CLIP_LOWERB_LOSS'),
+            weak_flag(c, 'WEAK_REPROJECTION_CLIP_PRED_BOX'), weak_flag(c, 'WEAK_REPROJECTION_LOSS_TYPE'),
+            weak_flag(c, 'WEAK_TRAIN_BOX_W_REPROJECTION'), ep=ep)
+        if weak_flag(c, 'WEAK_REPROJECTION_ONLY_ON_2D_CLS'):
+            reproj = reproj * is2d.to(reproj.dtype)
+        ep['reprojection_loss'] = reproj
+        weak = weak + (c.WEAK_WEIGHT_REPROJECTION * reproj).mean()      # weak_loss = reduce_mean(scalar terms + per-sample term)
     total = strong + c.SEMI_MULTIPLIER_FOR_WEAK_LOSS * weak
     if c.SEMI_WEIGHT_BOXPC_FIT_LOSS != 0:
         fit = -torch.log(0.01 + ep['boxpc_fit_prob'])
@@ -824,6 +846,11 @@ def stage_c_forward_backward(P, batch, c, train_classes, bn_decay_val=0.5, dtype
     ep['boxpc_out'] = ep_b['boxpc_out']
     ep['box_pc_rep'] = ep_b['box_pc_rep']
     ep['intraclsdims_train_classes'] = train_classes
+    ep['inactive_vol_train_classes'] = train_classes      # train_semisup_adv.py sets both lists from the same classes
+    if 'Rtilt' in batch:
+        ep['weak_inputs'] = {k: torch.as_tensor(batch[k], dtype=dtype) for k in ('Rtilt', 'K', 'rot_frust', 'box2D', 'img_dim')}
+    if forced and forced.get('S_box') is not None:
+        ep['forced_S_box'] = forced['S_box']
     loss = get_semi_loss_final(pred, _labels_to_torch(batch, dtype), ep, c)
     grads = {}
     if want_grads:

@@ -876,7 +876,7 @@ class FakeLib:
         t64 = lambda x, *shape: torch.as_tensor(np.array(arr(x, *shape)), dtype=torch.float64)
         center, dims, theta = t64(p.center, B, 3).requires_grad_(True), t64(p.reg_dims, B, 3).requires_grad_(True), \
             t64(p.reg_theta, B).requires_grad_(True)
-        is2d = torch.as_tensor(np.array(arr(p.is_data_2D, B)), dtype=torch.float64)
+        is2d = torch.as_tensor(np.array(arr(p.is_data_2D, B)), dtype=torch.float64) if p.is_data_2D else torch.ones(B, dtype=torch.float64)
         box = (center, dims, theta)
         reproj = torch.zeros(B, dtype=torch.float64)
         surf = torch.zeros(B, dtype=torch.float64)
@@ -892,6 +892,13 @@ class FakeLib:
             surf = W.get_surface_loss(box, pc, soft, p.surface_margin, p.surface_scale_dims, [bool(x) for x in p.train_box_surface])
         add = is2d * p.multiplier * (p.w_reproj * reproj + p.w_surface * surf)
         lossv = add.mean()
+        if p.w_inactive != 0:
+            cls = torch.as_tensor(np.array(arr(p.one_hot, B, 10)).argmax(1))
+            iv = W.get_inactive_volume_loss_v1(dims, cls, [bool(x) for x in p.inactive_train],
+                                               torch.as_tensor([float(x) for x in p.inactive_margins], dtype=torch.float64))
+            lossv = lossv + p.multiplier * p.w_inactive * iv
+            if p.inactive:
+                arr(p.inactive, 1)[0] = float(iv.detach())
         ins = [center, dims, theta] + ([soft] if soft is not None else [])
         gs = torch.autograd.grad(lossv, ins, allow_unused=True) if lossv.requires_grad else [None] * len(ins)
         z = lambda g, like: (torch.zeros_like(like) if g is None else g).detach().numpy()

@@ -122,3 +122,23 @@ def test_train_cli_with_the_default_flags_host_fed_and_device_assembled(tmp_path
         assert np.isfinite(last)
         ev = [l for l in logs if l.startswith('eval mean loss')]
         assert ev and np.isfinite(float(ev[0].split(':')[1]))
+
+
+def test_stage_c_with_reprojection_and_inactive_volume_matches_oracle():
+    """get_semi_loss_final with the reprojection loss of the refined box (the default weight 0.01; all samples, and the
+    ..._ONLY_ON_2D_CLS form) and the inactive-volume loss switched on (semisup_v1_sunrgbd.py:345-392)."""
+    from test_stage_c_cpu import check_stage_c, run_stage_c, stage_c_batch, stage_c_config, stage_c_params
+    B, N, C = 6, 256, 4
+    batch = stage_c_batch(B, N, C, seed=2, n2d=3)
+    P = stage_c_params(C, 1)
+    for over in (dict(WEAK_WEIGHT_REPROJECTION=0.01),
+                 dict(WEAK_WEIGHT_REPROJECTION=0.02, WEAK_REPROJECTION_ONLY_ON_2D_CLS=True, WEAK_WEIGHT_INACTIVE_VOLUME=1.0,
+                      WEAK_INACTIVE_VOL_LOSS_MARGINS=[10.0, 0.5, 3.0, 0.2, 0.2, 1.0, 0.8, 0.3, 1.2, 0.6])):
+        c = stage_c_config()
+        for k, v in over.items():
+            setattr(c, k, v)
+        g, m = run_stage_c(Runtime(device='cpu', lib=FakeLib()), batch, P, c)
+        check_stage_c(g, m, batch, P, c)
+        c0 = stage_c_config()
+        l0 = R.stage_c_forward_backward(P, batch, c0, [i in (1, 2, 6, 7, 8) for i in range(10)], want_grads=False)[0]
+        assert abs(float(m.loss) - float(l0)) > 1e-3 * float(l0)      # the weak terms are in the loss

@@ -143,3 +143,59 @@ def test_training_step_with_default_weak_weights_replays(hip_lib):
         runs.append((cur, g.vars.params[:g.vars.used].clone()))
     assert all(np.isfinite(runs[0][0])) and runs[0][0][-1] < runs[0][0][0], runs[0][0]
     assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
+
+
+def test_stage_c_weak_terms_match_oracle_on_the_gpu(hip_lib):
+    """get_semi_loss_final with the reprojection loss of the refined box and the inactive-volume loss on, HIP kernels end to end."""
+    from test_stage_c_cpu import check_stage_c, run_stage_c, stage_c_batch, stage_c_config, stage_c_params
+    from transferable3d_amd.engine import Runtime
+    B, N, Cc = 6, 256, 4
+    batch = stage_c_batch(B, N, Cc, seed=2, n2d=3)
+    P = stage_c_params(Cc, 1)
+    for over in (dict(WEAK_WEIGHT_REPROJECTION=0.01),
+                 dict(WEAK_WEIGHT_REPROJECTION=0.02, WEAK_REPROJECTION_ONLY_ON_2D_CLS=True, WEAK_WEIGHT_INACTIVE_VOLUME=1.0,
+                      WEAK_INACTIVE_VOL_LOSS_MARGINS=[10.0, 0.5, 3.0, 0.2, 0.2, 1.0, 0.8, 0.3, 1.2, 0.6])):
+        c = stage_c_config()
+        for k, v in over.items():
+            setattr(c, k, v)
+        g, m = run_stage_c(Runtime(lib=hip_lib), batch, P, c)
+        torch.cuda.synchronize()
+        check_stage_c(g, m, batch, P, c)
+
+
+def test_inactive_volume_and_all_sample_reprojection(hip_lib):
+    """t3d_weak_loss in its stage-c form: is_data_2D = NULL (every sample), no surface loss, the inactive-volume term."""
+    B, N = 24, 128
+    d = camera_case(B, N, seed=11)
+    r = np.random.RandomState(5)
+    cls = r.randint(0, 10, B)
+    one_hot = np.eye(10, dtype=np.float32)[cls]
+    margins = r.uniform(0.2, 4.0, 10).astype(np.float32)
+    train = [1, 1, 0, 1, 1, 1, 0, 1, 1, 1]
+    w_r, w_iv, mult = 0.01, 0.7, 0.25
+    t = {k: torch.as_tensor(v).to(DEV) for k, v in d.items()}
+    oh = torch.as_tensor(one_hot).to(DEV)
+    reproj, dbox7, inact = torch.zeros(B, device=DEV), torch.zeros(B, 7, device=DEV), torch.zeros(1, device=DEV)
+    loss = torch.full((1,), 2.0, device=DEV)
+    a = abi.WeakLossArgs()
+    a.center, a.reg_dims, a.reg_theta = fptr(t['center']), fptr(t['dims']), fptr(t['theta'])
+    a.Rtilt, a.K, a.rot_frust, a.box2D, a.img_dim = fptr(t['Rtilt']), fptr(t['K']), fptr(t['rot_frust']), fptr(t['box2D']), fptr(t['img_dim'])
+    a.w_reproj, a.w_surface, a.multiplier, a.dilate, a.clip_lower_b_loss = w_r, 0.0, mult, 1.5, 1
+    a.train_box_reproj = (C.c_int32 * 3)(1, 1, 1)
+    a.reproj, a.dbox7, a.loss, a.B, a.N = fptr(reproj), fptr(dbox7), fptr(loss), B, N
+    a.one_hot, a.w_inactive, a.inactive = fptr(oh), w_iv, fptr(inact)
+    a.inactive_margins = (C.c_float * 10)(*[float(v) for v in margins])
+    a.inactive_train = (C.c_int32 * 10)(*train)
+    assert hip_lib.t3d_weak_loss(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    torch.cuda.synchronize()
+    f64 = lambda k: torch.as_tensor(d[k], dtype=torch.float64)
+    center, dims, theta = f64('center').requires_grad_(True), f64('dims').requires_grad_(True), f64('theta').requires_grad_(True)
+    r_ref = W.get_reprojection_loss((center, dims, theta), f64('box2D'), f64('Rtilt'), f64('K'), f64('img_dim'), f64('rot_frust'), False, 10.,
+                                    1.5, True, False, 'huber', [True] * 3)
+    iv = W.get_inactive_volume_loss_v1(dims, torch.as_tensor(cls), [bool(x) for x in train], torch.as_tensor(margins, dtype=torch.float64))
+    lref = mult * ((w_r * r_ref).mean() + w_iv * iv)
+    gc, gd, gt = torch.autograd.grad(lref, [center, dims, theta])
+    g7 = torch.cat([gc, gd, gt[:, None]], 1)
+    assert abs(float(inact) - float(iv)) < 1e-5 * max(1.0, float(iv)) and float(iv) > 0
+    assert abs(float(loss) - 2.0 - float(lref)) < 2e-4 * float(lref)
+    assert float((dbox7.double().cpu() - g7).abs().max()) < 5e-4 * float(g7.abs().max())

@@ -180,7 +180,8 @@ class WeakLossArgs(C.Structure):
                 ('multiplier', f32), ('use_softmax_proj', i32), ('softmax_scale', f32), ('dilate', f32), ('clip_lower_b_loss', i32),
                 ('clip_pred_box', i32), ('loss_mse', i32), ('train_box_reproj', i32 * 3), ('train_box_surface', i32 * 3),
                 ('surface_margin', f32), ('surface_scale_dims', f32), ('surf_part', F), ('dsoft', F), ('reproj', F), ('surface', F),
-                ('dbox7', F), ('total_losses', F), ('loss', F), ('B', i32), ('N', i32)]
+                ('dbox7', F), ('total_losses', F), ('loss', F), ('B', i32), ('N', i32), ('one_hot', F), ('w_inactive', f32),
+                ('inactive_margins', f32 * 10), ('inactive_train', i32 * 10), ('inactive', F)]
 
 
 class ActDropoutArgs(C.Structure):

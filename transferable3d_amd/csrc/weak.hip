@@ -211,8 +211,28 @@ __device__ __forceinline__ D7 soft_extreme(const D7 (&x)[8], float far_bound, fl
 
 __global__ __launch_bounds__(256) void k_weak_finish(const t3d_weak_loss_args p, const int tiles) {
   __shared__ float tot[256];
+  __shared__ float iv[256];
+  __shared__ float ccount[10];
   const int b = threadIdx.x;
-  float contrib = 0.f;
+  float contrib = 0.f, ivc = 0.f;
+  // inactive-volume loss (weak_losses.py:39-67, stage c): class of a frustum = arg-max of its one-hot vector
+  int cls = 0, T = 0;
+  const bool inact = p.w_inactive != 0.f && p.one_hot != nullptr;
+  if (inact) {
+    if (b < p.B) { const float* oh = p.one_hot + (size_t)b * 10; for (int i = 1; i < 10; ++i) if (oh[i] > oh[cls]) cls = i; }
+    if (b < 10) {
+      float n = 0.f;
+      for (int i = 0; i < p.B; ++i) {
+        const float* oh = p.one_hot + (size_t)i * 10;
+        int ci = 0;
+        for (int k = 1; k < 10; ++k) if (oh[k] > oh[ci]) ci = k;
+        n += ci == b ? 1.f : 0.f;
+      }
+      ccount[b] = n;
+    }
+    for (int i = 0; i < 10; ++i) T += p.inactive_train[i] ? 1 : 0;
+    __syncthreads();
+  }
   if (b < p.B) {
     // surface: tile partials in ascending order
     float sv[8];
@@ -278,7 +298,7 @@ __global__ __launch_bounds__(256) void k_weak_finish(const t3d_weak_loss_args p,
         }
       }
     }
-    const float is2d = (float)p.is_data_2D[b];
+    const float is2d = p.is_data_2D ? (float)p.is_data_2D[b] : 1.f;      // NULL: every sample (stage c without ..._ONLY_ON_2D_CLS)
     const float weak = p.w_reproj * rl.v + p.w_surface * sv[0];
     if (p.reproj) p.reproj[b] = rl.v;
     if (p.surface) p.surface[b] = sv[0];
@@ -288,24 +308,39 @@ __global__ __launch_bounds__(256) void k_weak_finish(const t3d_weak_loss_args p,
     const float add = is2d * p.multiplier * weak;
     if (p.total_losses) p.total_losses[b] += add;
     contrib = add / (float)p.B;
+    if (inact && T > 0 && p.inactive_train[cls]) {      // mean over the trained classes of the class mean of max(0, margin - l w h)
+      const float l = p.reg_dims[b * 3], w = p.reg_dims[b * 3 + 1], h = p.reg_dims[b * 3 + 2];
+      const float vol = l * w * h, viol = p.inactive_margins[cls] - vol;
+      const float wgt = 1.0f / (ccount[cls] * (float)T);
+      if (viol > 0.f) {
+        ivc = viol * wgt;
+        const float k = -p.multiplier * p.w_inactive * wgt;      // a scalar term of the loss: no is_data_2D factor, no 1/B
+        p.dbox7[b * 7 + 3] += k * w * h;
+        p.dbox7[b * 7 + 4] += k * l * h;
+        p.dbox7[b * 7 + 5] += k * l * w;
+      }
+    }
   }
   tot[threadIdx.x] = contrib;
+  iv[threadIdx.x] = ivc;
   __syncthreads();
   if (threadIdx.x == 0) {
-    float s = 0.f;
-    for (int i = 0; i < p.B; ++i) s += tot[i];      // ascending b: reproducible
-    p.loss[0] += s;
+    float s = 0.f, si = 0.f;
+    for (int i = 0; i < p.B; ++i) { s += tot[i]; si += iv[i]; }      // ascending b: reproducible
+    if (p.inactive) p.inactive[0] = si;
+    p.loss[0] += s + p.multiplier * p.w_inactive * si;
   }
 }
 
 }  // namespace
 
 extern "C" int t3d_weak_loss(const t3d_weak_loss_args* a, t3d_stream_t stream) {
-  if (!a || !a->center || !a->reg_dims || !a->reg_theta || !a->is_data_2D || !a->dbox7 || !a->loss || !a->surf_part) return T3D_ERR_ARG;
+  if (!a || !a->center || !a->reg_dims || !a->reg_theta || !a->dbox7 || !a->loss) return T3D_ERR_ARG;
   const bool surf = a->pc != nullptr, rep = a->Rtilt != nullptr;      // a loss is evaluated when its inputs are given, whatever its weight
   if (a->w_surface != 0.f && !surf) return T3D_ERR_ARG;
   if (a->w_reproj != 0.f && !rep) return T3D_ERR_ARG;
-  if (surf && !a->logits) return T3D_ERR_ARG;
+  if (surf && (!a->logits || !a->surf_part)) return T3D_ERR_ARG;
+  if (a->w_inactive != 0.f && !a->one_hot) return T3D_ERR_ARG;
   if (rep && (!a->K || !a->rot_frust || !a->box2D || !a->img_dim)) return T3D_ERR_ARG;
   if (a->B <= 0 || a->B > 256 || a->N <= 0 || a->N % 128) return T3D_ERR_SHAPE;
   hipStream_t s = static_cast<hipStream_t>(stream);

@@ -440,20 +440,32 @@ class WeakLoss:
         rt, B, N = g.rt, g.B, g.rpf
         self.part, self.dsoft = rt.zeros(B, N // TILE, 8), rt.zeros(B * N)
         self.reproj, self.surface, self.dbox7 = rt.zeros(B), rt.zeros(B), rt.zeros(B, 7)
+        self.inactive = rt.zeros(1)
 
     @staticmethod
     def active(c):
         return getattr(c, 'WEAK_WEIGHT_REPROJECTION', 0) != 0 or getattr(c, 'WEAK_WEIGHT_SURFACE', 0) != 0
 
-    def emit(self, plan, loss_op, seg, x, c):
+    @staticmethod
+    def active_final(c):
+        return getattr(c, 'WEAK_WEIGHT_REPROJECTION', 0) != 0 or getattr(c, 'WEAK_WEIGHT_INACTIVE_VOLUME', 0) != 0
+
+    def emit(self, plan, loss_op, seg, x, c, final=None):
+        """final = None: get_semi_loss_backbone (both losses on the 2-D-label samples, in/out loss_op.loss / total_losses).
+        final = (loss buffer, train_classes): get_semi_loss_final (semisup_v1_sunrgbd.py:345-392) -- the reprojection loss of the
+        refined box on every sample (or the 2-D-label ones, WEAK_REPROJECTION_ONLY_ON_2D_CLS) and the inactive-volume loss, added
+        to the stage-c loss; no surface loss there."""
         g = self.g
         f = lambda k: getattr(c, k, WEAK_DEFAULTS[k])
         a = abi.WeakLossArgs()
         a.center, a.reg_dims, a.reg_theta = fptr(loss_op.center), fptr(loss_op.reg_dims), fptr(loss_op.reg_theta)
-        a.pc, a.ld_pc, a.logits = fptr(x.pc), g.ldpc, fptr(seg.logits)
+        if final is None:
+            a.pc, a.ld_pc, a.logits = fptr(x.pc), g.ldpc, fptr(seg.logits)
         a.Rtilt, a.K, a.rot_frust, a.box2D, a.img_dim = fptr(x.Rtilt), fptr(x.K), fptr(x.rot_frust), fptr(x.box2D), fptr(x.img_dim)
-        a.is_data_2D = iptr(x.is_data_2D)
-        a.w_reproj, a.w_surface = float(c.WEAK_WEIGHT_REPROJECTION), float(c.WEAK_WEIGHT_SURFACE)
+        if final is None or getattr(c, 'WEAK_REPROJECTION_ONLY_ON_2D_CLS', False):
+            a.is_data_2D = iptr(x.is_data_2D)
+        a.w_reproj = float(c.WEAK_WEIGHT_REPROJECTION)
+        a.w_surface = float(c.WEAK_WEIGHT_SURFACE) if final is None else 0.0
         a.multiplier = float(c.SEMI_MULTIPLIER_FOR_WEAK_LOSS)
         a.use_softmax_proj, a.softmax_scale = int(bool(f('WEAK_REPROJECTION_USE_SOFTMAX_PROJ'))), float(f('WEAK_REPROJECTION_SOFTMAX_SCALE'))
         a.dilate = float(f('WEAK_REPROJECTION_DILATE_FACTOR'))
@@ -467,7 +479,19 @@ class WeakLoss:
         a.surface_margin, a.surface_scale_dims = float(f('WEAK_SURFACE_MARGIN')), float(f('WEAK_SURFACE_LOSS_SCALE_DIMS'))
         a.surf_part, a.dsoft = fptr(self.part), fptr(self.dsoft)
         a.reproj, a.surface, a.dbox7 = fptr(self.reproj), fptr(self.surface), fptr(self.dbox7)
-        a.total_losses, a.loss, a.B, a.N = fptr(loss_op.total_losses), fptr(loss_op.loss), g.B, g.rpf
+        a.B, a.N = g.B, g.rpf
+        if final is None:
+            a.total_losses, a.loss = fptr(loss_op.total_losses), fptr(loss_op.loss)
+        else:
+            loss_buf, train_classes = final
+            a.loss = fptr(loss_buf)
+            a.w_inactive = float(getattr(c, 'WEAK_WEIGHT_INACTIVE_VOLUME', 0))
+            if a.w_inactive != 0:
+                margins = list(c.WEAK_INACTIVE_VOL_LOSS_MARGINS)
+                assert len(margins) == 10                                      # semisup_v1_sunrgbd.py:350
+                a.one_hot, a.inactive = fptr(x.one_hot_vec), fptr(self.inactive)
+                a.inactive_margins = (C.c_float * 10)(*[float(v) for v in margins])
+                a.inactive_train = (C.c_int32 * 10)(*[int(bool(v)) for v in train_classes])
         self.surface_on = a.w_surface != 0
         plan.add('t3d_weak_loss', a)
 
@@ -765,6 +789,7 @@ class SemiModelF:
         self.terms, self.loss = rt.zeros(2), rt.zeros(1)
         self.W_iou2d, self.W_iou3d = rt.zeros(B), rt.zeros(B)      # get_iou_summary(W_pred_box, ..., 'W_') (semisup_v1_sunrgbd.py:414)
         self.drep, self.dbox7 = rt.zeros(g.M, 8), rt.zeros(B, 7)
+        self.weak = None
         # inference graph (test_semisup.py:95-149): iterated Box-PC refinement of the F_ box
         self.refine_num = None
         self.cur_center, self.cur_dims, self.cur_theta, self.total_delta = rt.zeros(B, 3), rt.zeros(B, 3), rt.zeros(B), rt.zeros(B, 7)
@@ -798,6 +823,10 @@ class SemiModelF:
         a.d_dims, a.dout9, a.fit_prob, a.terms, a.loss, a.B = fptr(self.d_dims), fptr(self.dout9), fptr(self.fit_prob), \
             fptr(self.terms), fptr(self.loss), g.B
         plan.add('t3d_semi_final_loss', a)
+        if with_loss and WeakLoss.active_final(c):      # reprojection of the refined box / inactive volume (semisup_v1_sunrgbd.py:345-392)
+            if self.weak is None:
+                self.weak = WeakLoss(g)
+            self.weak.emit(plan, lo, self.seg, x, c, final=(self.loss, getattr(self, 'inactive_train_classes', self.train_classes)))
 
     def emit_forward_inference(self, plan, refine_num):
         """test_semisup.py:61-149: every net in inference mode; the F_ box in regression form is refined `refine_num`
@@ -837,6 +866,10 @@ class SemiModelF:
         q = abi.AnchorRegBwdArgs(fptr(self.F_out), BOX_OUT_DIMS, fptr(self.dbox7), fptr(self.d_dims), fptr(lo.dbox),
                                  fptr(lo.dstage1), g.B)
         plan.add('t3d_anchor_reg_bwd', q)
+        if self.weak is not None:
+            q2 = abi.AnchorRegBwdArgs(fptr(self.F_out), BOX_OUT_DIMS, fptr(self.weak.dbox7), fptr(None), fptr(lo.dbox),
+                                      fptr(lo.dstage1), g.B)
+            plan.add('t3d_anchor_reg_bwd', q2)
         self.R2.bwd(plan, dout=lo.dbox, ld_dout=BOX_OUT_DIMS)
         self.R1.bwd(plan, nxt=self.R2)
         self.R0.bwd(plan, nxt=self.R1)

@@ -172,16 +172,22 @@ def get_semi_loss(pred, labels, end_points, reduce_loss=True, c=None):
 
 
 def get_semi_loss_final(pred, labels, end_points, reduce_loss=True, c=None):
-    """strong(F_ heads, normalised by the 3-D count) + SEMI_MULTIPLIER*WEAK_WEIGHT_INTRACLASSVAR*intraclass +
-    SEMI_WEIGHT_BOXPC_FIT_LOSS*fit (semisup_v1_sunrgbd.py:323-421)."""
+    """strong(F_ heads, normalised by the 3-D count) + SEMI_MULTIPLIER*(WEAK_WEIGHT_INTRACLASSVAR*intraclass +
+    WEAK_WEIGHT_INACTIVE_VOLUME*inactive volume + WEAK_WEIGHT_REPROJECTION*mean reprojection) + SEMI_WEIGHT_BOXPC_FIT_LOSS*fit
+    (semisup_v1_sunrgbd.py:323-421)."""
     if not reduce_loss:
         raise Exception('Not implemented')                                  # semisup_v1_sunrgbd.py:420-421
-    if c.WEAK_WEIGHT_REPROJECTION != 0 or c.WEAK_WEIGHT_INACTIVE_VOLUME != 0:
-        raise NotImplementedError('reprojection / inactive-volume losses have weight 0 in recipe c (README.md:84-99)')
     ctx = pred[0].ctx
     m = ctx.assembly
     if 'intraclsdims_train_classes' in end_points:
         m.train_classes = list(end_points['intraclsdims_train_classes'])
+    if 'inactive_vol_train_classes' in end_points:
+        m.inactive_train_classes = list(end_points['inactive_vol_train_classes'])
+    from .nets import WeakLoss
+    if WeakLoss.active_final(c) and m.weak is None:      # reprojection of the refined box / inactive volume (semisup_v1_sunrgbd.py:345-392)
+        m.weak = WeakLoss(ctx.engine)
+    if m.weak is not None:
+        end_points['reproj_loss'] = api.Tensor(ctx, m.weak.reproj, (ctx.engine.B,), 'reproj_loss')
     ctx.loss = api.Tensor(ctx, m.loss, (), 'semi_loss')
     B = ctx.engine.B
     end_points['loss_terms'] = api.Tensor(ctx, m.loss_op.terms, (B, 8), 'loss_terms')

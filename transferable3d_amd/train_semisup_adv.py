@@ -113,7 +113,8 @@ def eval_one_epoch(sess, pls, is_training_pl, logits_t, end_points, FLAGS, epoch
         else:
             b = make_batch(B, N, C, seed=FLAGS.seed * 1000003 + 900000 + i)
             feed = {pls[0]: b['pc'], pls[3]: b['one_hot_vec'], pls[4]: b['y_seg'], pls[5]: b['y_center'], pls[6]: b['y_orient_cls'],
-                    pls[7]: b['y_orient_reg'], pls[8]: b['y_dims_cls'], pls[9]: b['y_dims_reg'], pls[17]: np.zeros(B, np.int32)}
+                    pls[7]: b['y_orient_reg'], pls[8]: b['y_dims_cls'], pls[9]: b['y_dims_reg'], pls[17]: np.zeros(B, np.int32),
+                    pls[12]: b['Rtilt'], pls[13]: b['K'], pls[14]: b['rot_frust'], pls[15]: b['box2D'], pls[16]: b['img_dim']}
         feed[is_training_pl] = False
         out = sess.run([logits_t, end_points['iou2ds'], end_points['iou3ds'], end_points['W_iou2ds'], end_points['W_iou3ds']]
                        + heads('F_') + heads('F2_'), feed_dict=feed)
@@ -157,7 +158,10 @@ def train(FLAGS, rt=None, log=print):
         pred, end_points = MODEL.get_semi_model(pls[0], pls[1], pls[2], pls[3], is_training_pl, use_one_hot=FLAGS.use_one_hot, c=FLAGS)
         intraclsdims_train_classes = [(cls_type in FLAGS.TEST_CLS) for cls_type in ALL_CLASSES] \
             if FLAGS.SEMI_INTRACLSDIMS_ONLY_ON_2D_CLS else [True] * len(ALL_CLASSES)
-        end_points.update({'intraclsdims_train_classes': intraclsdims_train_classes})
+        inactive_vol_train_classes = [(cls_type in FLAGS.TEST_CLS) for cls_type in ALL_CLASSES] \
+            if getattr(FLAGS, 'WEAK_INACTIVE_VOL_ONLY_ON_2D_CLS', True) else [True] * len(ALL_CLASSES)      # train_semisup_adv.py:322-325
+        end_points.update({'intraclsdims_train_classes': intraclsdims_train_classes,
+                           'inactive_vol_train_classes': inactive_vol_train_classes})
         semi_loss = MODEL.get_semi_loss(pred, tuple(pls[4:]), end_points, c=FLAGS)
         train_vars = ['class_dependent']
         if FLAGS.SEMI_TRAIN_BOX_TRAIN_CLASS_AG_TNET:
@@ -212,7 +216,8 @@ def train(FLAGS, rt=None, log=print):
                         b['y_dims_cls'] = cls.astype(np.int32)
                         b['is_data_2D'][:] = 1 if iteration == 0 else 0
                     feed = {pls[0]: b['pc'], pls[3]: b['one_hot_vec'], pls[4]: b['y_seg'], pls[5]: b['y_center'], pls[6]: b['y_orient_cls'],
-                            pls[7]: b['y_orient_reg'], pls[8]: b['y_dims_cls'], pls[9]: b['y_dims_reg'], pls[17]: b['is_data_2D']}
+                            pls[7]: b['y_orient_reg'], pls[8]: b['y_dims_cls'], pls[9]: b['y_dims_reg'], pls[17]: b['is_data_2D'],
+                            pls[12]: b['Rtilt'], pls[13]: b['K'], pls[14]: b['rot_frust'], pls[15]: b['box2D'], pls[16]: b['img_dim']}
                     feed[is_training_pl] = True
                     loss_val, _ = sess.run([semi_loss, train_op], feed_dict=feed)
                     loss_sum += float(loss_val)
