@@ -55,3 +55,26 @@ for G, width, stride, mode in [(G, w, 1, m) for (G, w) in ((16, 4096), (32, 1024
     t_l, t_c, t_1 = timed(launches), timed(chain), timed(one)
     print(f'G={G} width={width} mode={mode}: {n} launches {t_l:.1f} us ({t_l / n:.2f}/stage), one chain launch {t_c:.1f} us '
           f'(stage+barrier {(t_c - t_1) / (n - 1):.2f} us), single launch {t_1:.1f} us, chain result correct: {ok}')
+
+# ---- two independent chains of small dependent stages: 2 x n launches vs n launches that each carry both chains' blocks ----
+for G, width in ((16, 4096), (8, 1024)):
+    n = 12
+    bufA, bufB = torch.zeros(2 * G * width, device='cuda'), torch.zeros(2 * G * width, device='cuda')
+    both = torch.zeros(2 * 2 * G * width, device='cuda')
+
+    def separate(st):
+        for k in range(n):
+            for buf in (bufA, bufB):
+                a = buf.data_ptr() + (k & 1) * G * width * 4
+                b = buf.data_ptr() + ((k + 1) & 1) * G * width * 4
+                assert lib.mb_stage(a, b, G, width, 1, st) == 0
+
+    def paired(st):
+        for k in range(n):
+            a = both.data_ptr() + (k & 1) * 2 * G * width * 4
+            b = both.data_ptr() + ((k + 1) & 1) * 2 * G * width * 4
+            assert lib.mb_stage(a, b, 2 * G, width, 1, st) == 0
+
+    t_s, t_p = timed(separate), timed(paired)
+    print(f'two chains of {n} stages, G={G} width={width}: {2 * n} launches {t_s:.1f} us, {n} paired launches {t_p:.1f} us '
+          f'-> {(t_s - t_p) / n:.2f} us saved per pair')
