@@ -884,6 +884,22 @@ int t3d_cast_bf16(const float* src, void* dst, int64_t n, t3d_stream_t stream);
 int t3d_dropout_mask(float* mask, int64_t n, float keep_prob, uint32_t seed, const float* hyper,
                      t3d_stream_t stream);
 
+/* ---- two independent small launches in one ---------------------------------------------------------------------------
+ * a and b must not depend on each other (the box / T-Net backward and the segmentation-net backward: semisup_models.py:150-151).
+ * Same arguments, same results (bit for bit) as the two stand-alone calls; what is saved is one kernel boundary (~3-5 us).
+ * Kinds: t3d_bn_bwd_finalize (up to 512 row tiles), t3d_fc_bwd, t3d_fc_dinput, t3d_dy_colsum. */
+enum { T3D_SMALL_BN_BWD_FINALIZE = 1, T3D_SMALL_FC_BWD = 2, T3D_SMALL_FC_DINPUT = 3, T3D_SMALL_DY_COLSUM = 4 };
+typedef struct {
+  int kind;
+  union {
+    t3d_bn_bwd_finalize_args bn_bwd;
+    t3d_fc_bwd_args fc_bwd;
+    t3d_fc_dinput_args fc_dinput;
+    t3d_dy_colsum_args dy_colsum;
+  } u;
+} t3d_small_op;
+int t3d_small_pair(const t3d_small_op* a, const t3d_small_op* b, t3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

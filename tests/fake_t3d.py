@@ -1209,6 +1209,17 @@ class FakeLib:
         arr(p.loss, 1)[0] = float(arr(p.strong_loss, 1)[0]) + p.w_weak * intra + p.w_fit * fit
         return 0
 
+    def t3d_small_pair(self, a, b, stream):
+        """Two independent small launches in one: by specification the two stand-alone calls."""
+        names = {1: ('t3d_bn_bwd_finalize', 'bn_bwd'), 2: ('t3d_fc_bwd', 'fc_bwd'), 3: ('t3d_fc_dinput', 'fc_dinput'),
+                 4: ('t3d_dy_colsum', 'dy_colsum')}
+        for op in (_struct(a), _struct(b)):
+            fn, field = names[op.kind]
+            rc = getattr(self, fn)(C.byref(getattr(op.u, field)), stream)
+            if rc:
+                return rc
+        return 0
+
     def t3d_anchor_reg_bwd(self, a, stream):
         p = _struct(a)
         B = p.B

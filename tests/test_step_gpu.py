@@ -70,3 +70,33 @@ def test_data_parallel_step_on_one_rank_rccl_equals_the_single_replica_step(hip_
     finally:
         os.environ.pop('T3D_DP_ONE_GRAPH', None)
         dist.destroy_process_group()
+
+
+def test_paired_small_launches_are_bit_identical(hip_lib):
+    """nets.pair_small_launches: the box / T-Net backward and the seg-net backward interleaved so that their small launches share
+    launches (t3d_small_pair): 11 launches fewer per step, weights after four hipGraph-replayed steps bit-identical to the unpaired
+    plan."""
+    from transferable3d_amd import nets
+    from transferable3d_amd.engine import Runtime
+    from transferable3d_amd.step import build_training_step
+    from transferable3d_amd.synthetic import make_batch
+    B, N, C = 32, 1024, 4
+    batch = make_batch(B, N, C, seed=21)
+    res = {}
+    keep = nets.PAIR_SMALL
+    try:
+        for on in (False, True):
+            nets.PAIR_SMALL = on
+            g, model, step, loss = build_training_step(Runtime(lib=hip_lib), 'A', B, N, C, seed=4)
+            model.inputs.load(batch)
+            losses = []
+            for _ in range(4):
+                step.run()
+                losses.append(float(loss))
+            torch.cuda.synchronize()
+            names = [n for n, _, _ in g.bwd.calls if n.startswith('t3d')]
+            res[on] = (losses, g.vars.params[:g.vars.used].clone(), len(names), names.count('t3d_small_pair'))
+    finally:
+        nets.PAIR_SMALL = keep
+    assert res[True][3] >= 8 and res[False][3] == 0 and res[True][2] == res[False][2] - res[True][3]
+    assert res[True][0] == res[False][0] and torch.equal(res[True][1], res[False][1])

@@ -174,6 +174,9 @@ class SegHeadArgs(C.Structure):
                 ('dtype', i32), ('dsoft', F)]
 
 
+SMALL_KIND = {'t3d_bn_bwd_finalize': 1, 't3d_fc_bwd': 2, 't3d_fc_dinput': 3, 't3d_dy_colsum': 4}      # t3d.h T3D_SMALL_*
+
+
 class WeakLossArgs(C.Structure):
     _fields_ = [('center', F), ('reg_dims', F), ('reg_theta', F), ('pc', F), ('ld_pc', i32), ('logits', F), ('Rtilt', F), ('K', F),
                 ('rot_frust', F), ('box2D', F), ('img_dim', F), ('is_data_2D', I), ('w_reproj', f32), ('w_surface', f32),
@@ -247,6 +250,14 @@ class AnchorRegBwdArgs(C.Structure):
 
 VP = C.c_void_p
 # name -> argtypes.  Struct entry points take (const args*, stream).
+
+class SmallOpU(C.Union):
+    _fields_ = [('bn_bwd', BnBwdFinalizeArgs), ('fc_bwd', FcBwdArgs), ('fc_dinput', FcDinputArgs), ('dy_colsum', DyColsumArgs)]
+
+
+class SmallOp(C.Structure):
+    _fields_ = [('kind', i32), ('u', SmallOpU)]
+
 ENTRY_POINTS = {
     't3d_abi_version': [],
     't3d_pointmlp_fwd': [C.POINTER(PointMlpFwdArgs), VP],
@@ -258,6 +269,7 @@ ENTRY_POINTS = {
     't3d_wgrad_plan': [i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
     't3d_bwd_plan': [i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)],
     't3d_weak_loss': [C.POINTER(WeakLossArgs), VP],
+    't3d_small_pair': [C.POINTER(SmallOp), C.POINTER(SmallOp), VP],
     't3d_gram_plan': [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)],
     't3d_bn_bwd_finalize': [C.POINTER(BnBwdFinalizeArgs), VP],
     't3d_dy_colsum': [C.POINTER(DyColsumArgs), VP],

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
 LIB_PATH = os.path.join(HERE, 'libt3d.so')
-SOURCES = ['pointmlp.hip', 'bn_optim.hip', 'fc.hip', 'heads.hip', 'boxpc.hip', 'poolbwd.hip', 'data.hip', 'weak.hip']
+SOURCES = ['pointmlp.hip', 'bn_optim.hip', 'fc.hip', 'heads.hip', 'boxpc.hip', 'poolbwd.hip', 'data.hip', 'weak.hip', 'pair.hip']
 
 
 def _stale():

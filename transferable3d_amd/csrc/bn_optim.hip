@@ -4,58 +4,9 @@
 // (double accumulators), so results are run-to-run reproducible.
 #include "common.h"
 #include "poolbwd_dev.h"
+#include "bn_dev.h"
 
 namespace {
-
-// 256 threads = 16 channels x 16 tile groups: short, unrolled, independent loads (the 64-iteration serial
-// loop of the first version was pure L2 latency: 19 us per launch in profiles/r01_baseline).
-// At the row counts of config 4 (2048 row tiles) a 16-group block walks 128 tiles per thread -- eight dependent memory round trips
-// (13.7 us per launch, profiles/r02_bf16_v2): above T3D_FIN_BIG tiles (default 512) the launchers take the GR = 64 instantiation
-// (1024 threads, two round trips; only group 0 walks the 64 LDS partials): fwd finalize 195 -> 163 us per step, bwd 124 -> 112 at
-// B=128 N=2048 (same-box A/B).  Up to 512 tiles GR stays 16, so the results at the sizes of configs 1-3 do not change by a bit.
-constexpr int FC_CH = 16, FC_GR = 16, FC_GR_BIG = 64;
-
-// Sixteen tiles per quantity are in flight per thread (32 loads for the two-quantity reductions): at 256 tiles the whole
-// reduction is ONE memory round trip instead of four.
-template <int NQ, int GR = FC_GR>
-__device__ __forceinline__ void tile_sums(const float* const (&src)[NQ], int n_tiles, int N, int c, int grp, bool ok,
-                                          double (&acc)[NQ]) {
-  constexpr int U = 16;
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
-  if (!ok) return;
-  for (int t0 = grp; t0 < n_tiles; t0 += U * GR) {
-    float v[NQ][U];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int t = t0 + u * GR;
-        const float x = src[q][(size_t)min(t, n_tiles - 1) * N + c];     // clamped: no branch around the load
-        v[q][u] = t < n_tiles ? x : 0.f;
-      }
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      double a = 0.0;
-#pragma unroll
-      for (int u = 0; u < U; u += 4) a += ((double)v[q][u] + (double)v[q][u + 1]) + ((double)v[q][u + 2] + (double)v[q][u + 3]);
-      acc[q] += a;
-    }
-  }
-}
-
-template <int GR = FC_GR>
-__device__ __forceinline__ double group_reduce(double v, double (*red)[FC_CH], int grp, int cl) {
-  __syncthreads();
-  red[grp][cl] = v;
-  __syncthreads();
-  double s = 0.0;
-  if (GR == FC_GR || grp == 0) {      // only group 0 uses the sum; with 64 groups the other 1008 threads' reads are pure LDS traffic
-#pragma unroll
-    for (int g = 0; g < GR; ++g) s += red[g][cl];
-  }
-  return s;
-}
 
 // pooled[b,c], argidx, ysel from the per-tile max/min partials (shared by k_pool_finalize and the fused finalize)
 __device__ __forceinline__ void pool_pick_impl(const float* pmax, const float* pmin, const int32_t* pamax, const int32_t* pamin,
@@ -159,62 +110,10 @@ __global__ __launch_bounds__(256) void k_pool_finalize(const t3d_pool_finalize_a
 
 template <int GR>
 __global__ __launch_bounds__(GR * FC_CH) void k_bn_bwd_finalize(const t3d_bn_bwd_finalize_args p) {
-  __shared__ double red[GR][FC_CH];
-  const int cl = threadIdx.x & (FC_CH - 1), grp = threadIdx.x / FC_CH;
-  const int c = blockIdx.x * FC_CH + cl;
-  const bool ok = c < p.N;
-  const int cc = ok ? c : 0;
-  const float mean_f = p.mean[cc], invstd_f = p.invstd[cc], gamma_f = p.gamma[cc];   // ahead of the reduction
-  double acc[2] = {0.0, 0.0};   // sum dz, sum dz*y
-  if (p.psum_dz != nullptr) {
-    const float* const src[2] = {p.psum_dz, p.psum_dzy};
-    tile_sums<2, GR>(src, p.n_tiles, p.N, c, grp, ok, acc);
-  } else if (ok) {
-    for (int b = grp; b < p.B; b += GR) {
-      const float live = p.pooled[(size_t)b * p.ld_pooled + c] > 0.f ? 1.f : 0.f;
-      const float g = p.dpool_in[(size_t)b * p.ld_dpool_in + c] * live;
-      p.dpool[(size_t)b * p.N + c] = g;
-      acc[0] += (double)g;
-      acc[1] += (double)g * (double)p.ysel[(size_t)b * p.N + c];
-    }
-  }
-  const double s1 = group_reduce<GR>(acc[0], red, grp, cl);
-  const double s2 = group_reduce<GR>(acc[1], red, grp, cl);
-  if (grp == 0 && ok) {
-    if (p.frozen) {
-      p.coef[c] = p.scale[c];
-      p.coef[p.N + c] = 0.f;
-      p.coef[2 * p.N + c] = 0.f;
-      return;
-    }
-    const double mean = mean_f, invstd = invstd_f, gamma = gamma_f, n = p.count;
-    const double dbeta = s1;
-    const double dgamma = invstd * (s2 - mean * s1);       // sum dz * xhat
-    if (p.dbeta) p.dbeta[c] = (float)dbeta;
-    if (p.dgamma) p.dgamma[c] = (float)dgamma;
-    // dy = gamma*invstd*(dz - dbeta/n - xhat*dgamma/n), xhat = (y-mean)*invstd
-    const double c1 = gamma * invstd;
-    const double k3 = dgamma / n * invstd;
-    p.coef[c] = (float)c1;
-    p.coef[p.N + c] = (float)(-c1 * k3);
-    p.coef[2 * p.N + c] = (float)(c1 * (k3 * mean - dbeta / n));
-  }
+  bn_bwd_finalize_body<GR>(p, blockIdx.x, threadIdx.x);
 }
 
-__global__ __launch_bounds__(256) void k_dy_colsum(const t3d_dy_colsum_args p) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= p.B * p.N) return;
-  const int b = i / p.N, c = i % p.N;
-  double sdz = 0.0, sy = 0.0;
-  for (int t = 0; t < p.tiles_per_frustum; ++t) {
-    const size_t o = (size_t)(b * p.tiles_per_frustum + t) * p.N + c;
-    sdz += (double)p.psum_dz[o];
-    sy += (double)p.psum_y[o];
-  }
-  const double v = (double)p.coef[c] * sdz + (double)p.coef[p.N + c] * sy +
-                   (double)p.coef[2 * p.N + c] * (double)p.rows_per_frustum;
-  p.out[i] = (float)((double)p.alpha * v);
-}
+__global__ __launch_bounds__(256) void k_dy_colsum(const t3d_dy_colsum_args p) { dy_colsum_body(p, blockIdx.x, threadIdx.x); }
 
 // every slab region starts 16-byte aligned and numel % 4 == 0 for the engine's allocations (float4 path); anything
 // else takes the scalar path.  A block = 32 float4 elements x 8 slab groups: thread (e, g) sums slabs g, g+8, ... with

@@ -1,0 +1,56 @@
+// Two INDEPENDENT small launches in one: the backward of the box / T-Net side and the backward of the segmentation net do not depend
+// on each other (semisup_models.py:150-151 blocks the gradient), and each carries a dozen launches of 16-64 workgroups -- batch-norm
+// backward finalizers, the FC head kernels, per-frustum column sums -- whose cost is the ~3-5 us coherence round trip of a kernel
+// boundary, not their work.  One launch that runs the blocks of one op of each chain pays that once (tools/micro/grid_barrier.py:
+// 2-4 us saved per pair).  The bodies are the stand-alone kernels' own (fc_dev.h, bn_dev.h): results are bit-identical.
+// The host side (nets.pair_small_launches) interleaves the two chains so that their small launches meet.
+#include "fc_dev.h"
+#include "bn_dev.h"
+
+namespace {
+
+template <int RBT>
+__device__ __forceinline__ void run_small(const t3d_small_op& o, float* sm, const int bid) {
+  switch (o.kind) {      // workgroup-uniform
+    case T3D_SMALL_BN_BWD_FINALIZE: bn_bwd_finalize_body<FC_GR>(o.u.bn_bwd, bid, threadIdx.x); break;
+    case T3D_SMALL_FC_BWD: fc_bwd_body<RBT>(o.u.fc_bwd, sm, bid); break;
+    case T3D_SMALL_FC_DINPUT: fc_dinput_body<RBT>(o.u.fc_dinput, sm, bid); break;
+    case T3D_SMALL_DY_COLSUM: dy_colsum_body(o.u.dy_colsum, bid, threadIdx.x); break;
+    default: break;
+  }
+}
+
+template <int RBT>
+__global__ __launch_bounds__(NTH) void k_small_pair(const t3d_small_op a, const t3d_small_op b, const int n_a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  if ((int)blockIdx.x < n_a) run_small<RBT>(a, sm, blockIdx.x);
+  else run_small<RBT>(b, sm, blockIdx.x - n_a);
+}
+
+int small_blocks(const t3d_small_op& o, int* rows) {
+  switch (o.kind) {
+    case T3D_SMALL_BN_BWD_FINALIZE:
+      if (!o.u.bn_bwd.coef || (o.u.bn_bwd.psum_dz != nullptr && o.u.bn_bwd.n_tiles > 512)) return -1;      // (the 64-group form stays alone)
+      return (o.u.bn_bwd.N + FC_CH - 1) / FC_CH;
+    case T3D_SMALL_FC_BWD: *rows = o.u.fc_bwd.B; return (o.u.fc_bwd.N + CB - 1) / CB;
+    case T3D_SMALL_FC_DINPUT: *rows = o.u.fc_dinput.B; return (o.u.fc_dinput.K + CB - 1) / CB;
+    case T3D_SMALL_DY_COLSUM: return (o.u.dy_colsum.B * o.u.dy_colsum.N + 255) / 256;
+    default: return -1;
+  }
+}
+
+}  // namespace
+
+extern "C" int t3d_small_pair(const t3d_small_op* a, const t3d_small_op* b, t3d_stream_t stream) {
+  if (!a || !b) return T3D_ERR_ARG;
+  int rows_a = 0, rows_b = 0;
+  const int na = small_blocks(*a, &rows_a), nb = small_blocks(*b, &rows_b);
+  if (na <= 0 || nb <= 0) return T3D_ERR_ARG;
+  const int rows = rows_a > rows_b ? rows_a : rows_b;
+  if (rows > 32 * MAXRB || (rows_a && rows_b && (rows_a <= 32) != (rows_b <= 32))) return T3D_ERR_SHAPE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (rows <= 32) T3D_LAUNCH(k_small_pair<1>, dim3(na + nb), dim3(NTH), fc_lds_bytes(32), s, *a, *b, na);
+  else T3D_LAUNCH(k_small_pair<MAXRB>, dim3(na + nb), dim3(NTH), fc_lds_bytes(128), s, *a, *b, na);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}

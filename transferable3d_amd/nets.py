@@ -8,6 +8,7 @@ plans, the kernel launches of its forward pass and (separately) of its backward 
   StrongLoss  <- get_strong_loss (semisup_v1_sunrgbd.py:423-553) + anchor->reg (tf_util.py:1001-1041)
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -396,6 +397,51 @@ class BoxEstNet:
         return self.bwd_convs(plan, self.bwd_fc(plan, dbox), 512, dstage1_in)
 
 
+PAIR_SMALL = os.environ.get('T3D_PAIR', '1') != '0'
+
+
+def pair_small_launches(plan, i0, i1, i2):
+    """Interleave two INDEPENDENT chains of a plan -- calls [i0, i1) and [i1, i2) -- so that their small launches (batch-norm backward
+    finalizers, FC head kernels, column sums: 16-64 workgroups each, bound by the kernel boundary, not by their work) share
+    launches pairwise (t3d_small_pair, csrc/pair.hip).  Each chain keeps its own order; a chain waits at a small launch until the
+    other one has reached one too.  Results are bit-identical to the unpaired plan (same kernels, same arguments)."""
+    lib = plan.rt.lib
+    if not hasattr(lib, 't3d_small_pair'):
+        return 0
+    kinds = abi.SMALL_KIND
+    A = list(zip(plan.calls[i0:i1], plan.lanes[i0:i1]))
+    S = list(zip(plan.calls[i1:i2], plan.lanes[i1:i2]))
+
+    def small(entry):
+        (name, _, arg), _lane = entry
+        if name not in kinds or arg is None:
+            return False
+        if name == 't3d_bn_bwd_finalize' and arg.psum_dz and arg.n_tiles > 512:      # the 64-group form runs alone
+            return False
+        return True
+
+    out, n_pairs = [], 0
+    while A and S:
+        if small(A[0]) and small(S[0]):
+            ((na, _, aa), _), ((nb, _, ab), _) = A.pop(0), S.pop(0)
+            oa, ob = abi.SmallOp(), abi.SmallOp()
+            for o, n_, a_ in ((oa, na, aa), (ob, nb, ab)):
+                o.kind = kinds[n_]
+                C.memmove(C.byref(o.u), C.byref(a_), C.sizeof(a_))
+            fn, ra, rb = lib.t3d_small_pair, C.byref(oa), C.byref(ob)
+            plan.keep.extend([oa, ob])
+            out.append((('t3d_small_pair', (lambda s, fn=fn, ra=ra, rb=rb: fn(ra, rb, s)), (oa, ob)), 0))
+            n_pairs += 1
+        elif not small(A[0]):
+            out.append(A.pop(0))
+        else:
+            out.append(S.pop(0))
+    out += A + S
+    plan.calls[i0:i2] = [c for c, _ in out]
+    plan.lanes[i0:i2] = [l for _, l in out]
+    return n_pairs
+
+
 class StrongLoss:
     def __init__(self, g):
         self.g = g
@@ -603,10 +649,12 @@ class ModelAssembly:
             self.seg.bwd(plan, part=2)
             self.g.emit_reduce_slabs(plan)
             return
+        i0 = len(plan.calls)
         ds1 = self.box.bwd(plan, self.loss_op.dbox, self.loss_op.dstage1)
         plan.flush()                     # box-net weight gradients run beside the T-Net / seg-net dgrad chain
         self.tnet.bwd(plan, ds1)
         plan.flush()
+        i1 = len(plan.calls)
         # data parallel: the box / T-Net gradients are complete here and nothing the seg net computes touches
         # them (semisup_models.py:150-151), so their all-reduce runs beside the seg net's backward; the seg net's own gradients
         # go in two buckets, conv10..conv6 (2.9 MB, ready after conv6) and conv5..conv1 (0.6 MB, the exposed tail)
@@ -616,6 +664,11 @@ class ModelAssembly:
         self.seg.bwd(plan, part=1)
         g.declare_bucket(plan, [sp + 'conv%d/' % i for i in (6, 7, 8, 9, 10)])
         self.seg.bwd(plan, part=2)
+        if PAIR_SMALL and not g.dp_buckets and self.seg.train_seg:
+            # single replica: the box / T-Net backward [i0, i1) and the seg-net backward [i1, here) are independent
+            # (semisup_models.py:150-151): their small launches pair up (data parallel keeps the chains apart -- the first bucket's
+            # all-reduce is to start as early as possible)
+            self.n_pairs = pair_small_launches(plan, i0, i1, len(plan.calls))
         if g.dp_buckets:
             g.declare_bucket(plan, [sp + 'conv%d/' % i for i in (1, 2, 3, 4, 5)])
         else:
