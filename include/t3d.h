@@ -55,7 +55,7 @@ int t3d_abi_version(void);
 /* A per-point activation operand produced lazily from the RAW output of the previous layer:
  *   a[m,k] = relu?( x[m, coff+k] * scale[k] + shift[k] ) - sub[b(m), k]
  * scale/shift (batch-norm apply, tf_util.py:1316-1322) and sub (per-frustum recentring,
- * semisup_models.py:159,207) are optional (NULL).  ldx and coff must be multiples of 4. */
+ * semisup_models.py:159,207) are optional (NULL).  ldx and coff must be multiples of 4 (of 8 for a T3D_BF16 source: 16-byte reads). */
 typedef struct {
   const float* x;
   int ldx;

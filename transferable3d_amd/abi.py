@@ -322,7 +322,7 @@ def load(path=None):
     # torch bundles its own libamdhip64: import it FIRST so that libt3d.so binds to the same HIP runtime
     # instance that owns torch's streams and allocations (two runtimes in one process cannot share them).
     import torch  # noqa: F401
-    path = path or LIB_PATH
+    path = path or os.environ.get('T3D_LIB') or LIB_PATH      # T3D_LIB: an alternative build (tools/build_variant.sh) for same-box A/B
     if not os.path.exists(path):
         raise T3DError('HIP library %s not built: run `python -m transferable3d_amd.build` (no CPU fallback exists)' % path)
     lib = C.CDLL(path)

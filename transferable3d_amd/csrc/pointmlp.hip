@@ -164,6 +164,12 @@ struct ActLoaderT {
   struct Coef { float4 sc, sh; };
   // a bf16 source is a layer output: K is a multiple of the 64-deep k-tile (launcher-checked), so no column is clamped or masked
   static constexpr bool EXACT = Elem<XT>::BF16;
+  static constexpr bool HAS8 = Elem<XT>::BF16 && !HAS_SUB;      // 16-byte granules (StagerH8): two adjacent Raw from one load
+  __device__ __forceinline__ void fetch8(int row, int col, Raw& lo, Raw& hi) const {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(s.x) + (size_t)row * s.ldx + s.coff + col);
+    lo.x = __builtin_shufflevector(v, v, 0, 1, 2, 3);
+    hi.x = __builtin_shufflevector(v, v, 4, 5, 6, 7);
+  }
   __device__ __forceinline__ Coef fetch_coef(int col) const {
     Coef c;
     c.sc = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -210,6 +216,14 @@ struct DyLoaderT {      // N % 32 == 0: every tile column is valid
   int rpf;
   struct Raw { typename Elem<T>::V4 dz, y; };
   struct Coef { float4 c0, c1, c2; };
+  static constexpr bool HAS8 = Elem<T>::BF16 && !POOLED;
+  __device__ __forceinline__ void fetch8(int row, int col, Raw& lo, Raw& hi) const {
+    const size_t o = (size_t)row * N + col;
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(s.y) + o);
+    const bf16x8 b = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(s.dz) + o);
+    lo.y = __builtin_shufflevector(a, a, 0, 1, 2, 3); hi.y = __builtin_shufflevector(a, a, 4, 5, 6, 7);
+    lo.dz = __builtin_shufflevector(b, b, 0, 1, 2, 3); hi.dz = __builtin_shufflevector(b, b, 4, 5, 6, 7);
+  }
   __device__ __forceinline__ Coef fetch_coef(int col) const {
     Coef c;
     c.c0 = *reinterpret_cast<const float4*>(s.coef + col);
@@ -247,9 +261,17 @@ struct WLoaderT {
   int ld;
   int rows, cols;   // valid extent; cols % 4 == 0
   static constexpr bool PASS_BF16 = EXACT_ && Elem<WT>::BF16;
+  static constexpr bool HAS8 = EXACT_ && Elem<WT>::BF16;
   struct Raw { typename Elem<WT>::V4 x; };
   struct Coef {};
   __device__ __forceinline__ Coef fetch_coef(int) const { return Coef(); }
+  __device__ __forceinline__ void fetch8(int row, int col, Raw& lo, Raw& hi) const {      // HAS8 only
+    if constexpr (Elem<WT>::BF16) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(w) + (size_t)row * ld + col);
+      lo.x = __builtin_shufflevector(v, v, 0, 1, 2, 3);
+      hi.x = __builtin_shufflevector(v, v, 4, 5, 6, 7);
+    }
+  }
   __device__ __forceinline__ Raw fetch(int row, int col) const {
     Raw r;
     if (EXACT_) r.x = Elem<WT>::ld4(w, (size_t)row * ld + col);
@@ -584,6 +606,68 @@ struct StagerH {
   }
 };
 
+// The same stager with 16-byte granules (loaders with HAS8: bf16 sources inside the matrix): ONE global load and ONE LDS store per
+// eight elements instead of two of each -- the arithmetic per element is unchanged, the loads, address computations and stores,
+// a third of the staging pass's instructions, halve.  A granule is two adjacent Raw of the 4-wide interface (L::fetch8), so the
+// loaders' xform is shared and the values are bit-identical to StagerH's.
+template <int DIM, bool TYPE_R, class L, int PF_ = 1>
+struct StagerH8 {
+  static constexpr int PF = PF_;
+  static constexpr int NV = DIM * (BKH / 8) / NT;
+  static constexpr int LDC = DIM + 32;
+  static constexpr int LDS_ELEMS = TYPE_R ? DIM * LDRH : BKH * LDC;
+  static_assert(NV >= 1, "tile too small for 16-byte granules");
+  typename L::Raw raw[PF][NV][2];
+  typename L::Coef coef[PF][2];
+  int lane0, red0[PF];
+
+  __device__ __forceinline__ static void coords(int tid, int q, int& lane_i, int& red_i) {
+    const int f = tid + NT * q;
+    if (TYPE_R) { constexpr int CH = BKH / 8; lane_i = f / CH; red_i = (f % CH) * 8; }
+    else { constexpr int C8 = DIM / 8; red_i = f / C8; lane_i = (f % C8) * 8; }
+  }
+  __device__ __forceinline__ void init(const L& l, int lane0_, int tid) {
+    lane0 = lane0_;
+    if (!TYPE_R) { int li, ri; coords(tid, 0, li, ri); coef[0][0] = l.fetch_coef(lane0 + li); coef[0][1] = l.fetch_coef(lane0 + li + 4); }
+  }
+  template <int S>
+  __device__ __forceinline__ void fetch(const L& l, int red0_, int tid) {
+    red0[S] = red0_;
+    if (TYPE_R) { int li, ri; coords(tid, 0, li, ri); coef[S][0] = l.fetch_coef(red0_ + ri); coef[S][1] = l.fetch_coef(red0_ + ri + 4); }
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      int li, ri; coords(tid, q, li, ri);
+      if (TYPE_R) l.fetch8(lane0 + li, red0_ + ri, raw[S][q][0], raw[S][q][1]);
+      else l.fetch8(red0_ + ri, lane0 + li, raw[S][q][0], raw[S][q][1]);
+    }
+  }
+  template <int S>
+  __device__ __forceinline__ void store(const L& l, bf16_t* tile, int tid) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      int li, ri; coords(tid, q, li, ri);
+      bf16_t* dst = tile + (TYPE_R ? li * LDRH + ri : ri * LDC + li);
+      if constexpr (PassBf16<L>::value) {
+        *reinterpret_cast<bf16x8*>(dst) = __builtin_shufflevector(raw[S][q][0].x, raw[S][q][1].x, 0, 1, 2, 3, 4, 5, 6, 7);
+      } else {
+        const typename L::Coef& c0 = coef[TYPE_R ? S : 0][0];
+        const typename L::Coef& c1 = coef[TYPE_R ? S : 0][1];
+        const float4 a = TYPE_R ? l.xform(raw[S][q][0], c0, lane0 + li, red0[S] + ri) : l.xform(raw[S][q][0], c0, red0[S] + ri, lane0 + li);
+        const float4 b = TYPE_R ? l.xform(raw[S][q][1], c1, lane0 + li, red0[S] + ri + 4) : l.xform(raw[S][q][1], c1, red0[S] + ri, lane0 + li + 4);
+        const bf16x8 h = {(bf16_t)a.x, (bf16_t)a.y, (bf16_t)a.z, (bf16_t)a.w, (bf16_t)b.x, (bf16_t)b.y, (bf16_t)b.z, (bf16_t)b.w};
+        *reinterpret_cast<bf16x8*>(dst) = h;
+      }
+    }
+  }
+};
+template <class L, class = void> struct Has8 { static constexpr bool value = false; };
+template <class L> struct Has8<L, typename std::enable_if<L::HAS8>::type> { static constexpr bool value = true; };
+#ifndef T3D_STAGE8
+#define T3D_STAGE8 1       // 0: the 8-byte granules everywhere (A/B of the 16-byte stager)
+#endif
+template <int DIM, bool TYPE_R, class L, int PF>
+using StagerHSel = typename std::conditional<(T3D_STAGE8 != 0) && Has8<L>::value, StagerH8<DIM, TYPE_R, L, PF>, StagerH<DIM, TYPE_R, L, PF>>::type;
+
 // fragment of MFMA step `st` (16 reduction indices) for the 32 operand rows / columns starting at `c0`
 template <bool TYPE_R, int DIM>
 __device__ __forceinline__ bf16x8 frag_h(const bf16_t* img, int c0, int st, int lane) {
@@ -713,7 +797,7 @@ struct PathBF16 {
   static constexpr int RED = BKH;
   // the first operand of every GEMM here is the [M, C] stream from HBM: two register slots (prefetch distance 2); the second
   // (weights from L2, or the fatter dy operand of the weight gradient) one
-  template <int DIM, bool TYPE_R, class L, int PF, bool IS_A = false> using Stg = StagerH<DIM, TYPE_R, L, IS_A ? 2 : 1>;
+  template <int DIM, bool TYPE_R, class L, int PF, bool IS_A = false> using Stg = StagerHSel<DIM, TYPE_R, L, IS_A ? 2 : 1>;
 };
 template <class PR, int TM, int TN, class SA, class SB, class LA, class LB, bool AR, int DIMA, bool BR, int DIMB>
 __device__ __forceinline__ void run_mainloop(SA& sa, SB& sb, const LA& la, const LB& lb, float* smem, int red_begin, int red_end,
@@ -903,8 +987,8 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd_res(const t3d_po
   constexpr int TM = 2, TN = BN / 64, ST = BKH / 16;
   using LA = ActLoaderT<false, bf16_t>;
   using WL = WLoaderT<bf16_t, true>;
-  using SA = StagerH<128, true, LA, KT>;
-  using SB = StagerH<BN, false, WL, 1>;
+  using SA = StagerHSel<128, true, LA, KT>;
+  using SB = StagerHSel<BN, false, WL, 1>;
   constexpr int A_ELEMS = SA::LDS_ELEMS, B_ELEMS = SB::LDS_ELEMS;
   static_assert((size_t)2 * B_ELEMS * 2 >= (size_t)12 * BN * 4 + (size_t)128 * (BN + 8) * 2, "the epilogue scratch aliases the weight ring");
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -2389,7 +2473,8 @@ constexpr size_t lds_bwd1(int k, int n, int bm) { return (size_t)bm * (n + k + 2
 bool dtype_ok(int dt) { return dt == T3D_F32 || dt == T3D_BF16; }
 bool act_ok(const t3d_act_src& a, int K) {
   return a.x != nullptr && (a.ldx % 4) == 0 && (a.coff % 4) == 0 && a.coff + (K + 3) / 4 * 4 <= a.ldx &&
-         (a.scale == nullptr || a.shift != nullptr) && dtype_ok(a.dtype) && !(a.dtype == T3D_BF16 && a.sub != nullptr);
+         (a.scale == nullptr || a.shift != nullptr) && dtype_ok(a.dtype) && !(a.dtype == T3D_BF16 && a.sub != nullptr) &&
+         !(a.dtype == T3D_BF16 && ((a.ldx | a.coff) & 7));      // bf16 sources are read in 16-byte granules
 }
 bool dy_ok(const t3d_dy_src& d) {
   return d.y != nullptr && d.coef != nullptr && (d.dz != nullptr || (d.argidx != nullptr && d.dpool != nullptr)) && dtype_ok(d.dtype) &&
