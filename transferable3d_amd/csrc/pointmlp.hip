@@ -1131,6 +1131,82 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd_res(const t3d_po
 }
 
 // ---------------------------------------------------------------------------------------------
+// bf16 forward of the first layer of a net: K <= 4 raw input channels (xyz [+ 1]), fp32 source, N = 64 or 128
+// ---------------------------------------------------------------------------------------------
+// The generic kernel pads K to a 64-deep k-tile and runs it through the staging / MFMA machinery: 41 us per launch at B=128 N=2048
+// for 3 x 128 multiply-adds per row, against 11 us of HBM time for the output.  Here a thread owns 8 output columns: the (<= 4) x 8
+// weights sit in registers, a row costs one 16-byte load, K x 8 FMAs on operands rounded to bf16 exactly as the MFMA path rounds them
+// (products of two bf16 values are exact in fp32; the sum over <= 4 terms runs in k order), the bias, the output rounding, the two
+// statistics, one 16-byte store.
+template <int N>
+__global__ __launch_bounds__(NT) void k_pointmlp_fwd_tinyk(const t3d_pointmlp_fwd_args p) {
+  constexpr int CPR = N / 8, RPP = NT / CPR, NP = 128 / RPP;      // column chunks per row, rows per pass, passes
+  __shared__ float red[2][RPP][N];
+  const int tid = threadIdx.x, ch = tid % CPR, r0 = tid / CPR;
+  const int tile = blockIdx.x, row0 = tile * 128, b = row0 / p.rows_per_frustum;
+  const bf16_t* wg = reinterpret_cast<const bf16_t*>(p.w);
+  float w[4][8], add[8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(wg + (size_t)min(k, p.K - 1) * p.N + ch * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) w[k][e] = k < p.K ? (float)v[e] : 0.f;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) add[e] = p.bias ? p.bias[ch * 8 + e] : 0.f;
+  float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f}, sub[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p.a.scale != nullptr) {      // (raw inputs carry none; kept for the interface)
+    const float4 a = *reinterpret_cast<const float4*>(p.a.scale), c = *reinterpret_cast<const float4*>(p.a.shift);
+    sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sh[0] = c.x; sh[1] = c.y; sh[2] = c.z; sh[3] = c.w;
+  }
+  if (p.a.sub != nullptr) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sub[k] = p.a.sub[(size_t)b * p.a.sub_ld + min(k, p.K - 1)];
+  }
+  const float floor_ = p.a.relu ? 0.f : -INFINITY;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  bf16_t* yg = reinterpret_cast<bf16_t*>(p.y);
+  float4 xs[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) xs[i] = *reinterpret_cast<const float4*>(p.a.x + (size_t)(row0 + r0 + RPP * i) * p.a.ldx + p.a.coff);
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const float xv[4] = {xs[i].x, xs[i].y, xs[i].z, xs[i].w};
+    float a[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float t = fmaxf(fmaf(xv[k], sc[k], sh[k]), floor_) - sub[k];
+      a[k] = k < p.K ? Elem<bf16_t>::rnd(t) : 0.f;      // operand rounding of the bf16 GEMM
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float acc = a[0] * w[0][e];
+      acc = fmaf(a[1], w[1][e], acc);
+      acc = fmaf(a[2], w[2][e], acc);
+      acc = fmaf(a[3], w[3][e], acc);
+      const float v = Elem<bf16_t>::rnd(acc + add[e]);
+      o[e] = (bf16_t)v;
+      s1[e] += v;
+      s2[e] = fmaf(v, v, s2[e]);
+    }
+    *reinterpret_cast<bf16x8*>(yg + (size_t)(row0 + r0 + RPP * i) * p.N + ch * 8) = o;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { red[0][r0][ch * 8 + e] = s1[e]; red[1][r0][ch * 8 + e] = s2[e]; }
+  __syncthreads();
+  if (tid < N) {
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < RPP; ++r) { t1 += red[0][r][tid]; t2 += red[1][r][tid]; }
+    p.psum[(size_t)tile * p.N + tid] = t1;
+    p.psumsq[(size_t)tile * p.N + tid] = t2;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // data gradient
 // ---------------------------------------------------------------------------------------------
 // Shared epilogue of the two data-gradient kernels: + add_in (+ per-column constant), ReLU mask of the producing
@@ -2499,6 +2575,15 @@ extern "C" int t3d_pointmlp_fwd(const t3d_pointmlp_fwd_args* a, t3d_stream_t str
     const bool wide = T3D_FORCE_TILE != 64 && a->N % 128 == 0 && (T3D_FORCE_TILE == 128 || (long)tiles_m * (a->N / 128) >= 512);
     const bool xh = a->a.dtype == T3D_BF16;
     if (xh && a->K % BKH) return T3D_ERR_SHAPE;      // a bf16 input is a layer output: whole 64-deep k-tiles (the loaders do not mask)
+    // first layer of a net (xyz [+ 1 channel], fp32 source): the register kernel (T3D_FWD_TINYK=0: the generic one)
+    static const bool use_tiny = []() { const char* e = getenv("T3D_FWD_TINYK"); return !(e && e[0] == '0'); }();
+    if (use_tiny && !xh && a->K <= 4 && a->y && !a->pmax && !a->rowbias && (a->N == 64 || a->N == 128) && a->a.ldx % 4 == 0 &&
+        a->a.coff % 4 == 0 && a->a.coff + 4 <= a->a.ldx) {
+      if (a->N == 64) T3D_LAUNCH(k_pointmlp_fwd_tinyk<64>, dim3(tiles_m), dim3(NT), 0, s, *a);
+      else T3D_LAUNCH(k_pointmlp_fwd_tinyk<128>, dim3(tiles_m), dim3(NT), 0, s, *a);
+      T3D_CHECK_LAUNCH();
+      return T3D_OK;
+    }
     // activation-resident kernel: the input panel is transformed once for all column tiles (T3D_FWD_RES=0: the generic kernel)
     static const bool use_res = []() { const char* e = getenv("T3D_FWD_RES"); return !(e && e[0] == '0'); }();
     // K = 256 (a 74 KB panel: one workgroup per CU) measured SLOWER than the generic kernel (256 -> 512: 257 vs 194 us, 256 -> 128:
