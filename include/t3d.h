@@ -208,7 +208,8 @@ int t3d_wgrad_plan(int M, int K, int N, int* rows_per_split, int* tile_k, int* t
  * {64, 128}, or K x N = 256 x 128 / 128 x 256, run ONE-PASS (*one_pass = 1): one workgroup per split walks its 128-row tiles, reads dz, y and the input once, keeps
  * dW in registers across the tiles and writes one slab at the end; t3d_pointmlp_bwd takes that form whenever the shape is eligible
  * and M / rows_per_split >= min(256, M / 128).  Everything else: t3d_wgrad_plan's split (*one_pass = 0).  The results are those of
- * the two separate calls up to the fp32 summation order. */
+ * the two separate calls up to the fp32 summation order.  fp32 layers with K, N in {64, 128} have a one-pass form too (64-row tiles); it is
+ * planned when a workgroup gets at least 256 rows (M >= 65536) or when M < 32768 -- at M = 32768 the split form ties and stays. */
 int t3d_bwd_plan(int M, int K, int N, int dtype, int* rows_per_split, int* one_pass);
 
 /* ---- K11c: batch-norm backward statistics -> dgamma, dbeta and the three dy coefficients -------

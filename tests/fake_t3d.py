@@ -614,19 +614,22 @@ class FakeLib:
             tiles, per = M // 128, 1
             while tiles // per > 256 and tiles % (per * 2) == 0:
                 per *= 2
-            rps._obj.value, one._obj.value = 128 * per, 1
-            return 0
+            if dtype == 1 or tiles < 256 or 128 * per >= 256:
+                rps._obj.value, one._obj.value = 128 * per, 1
+                return 0
         tk, tn = C.c_int(0), C.c_int(0)
         return self.t3d_wgrad_plan(M, K, K, rps, C.byref(tk), C.byref(tn))
 
     def t3d_bwd_plan(self, M, K, N, dtype, rps, one):
         one._obj.value = 0
-        if dtype == 1 and ((K in (64, 128) and N in (64, 128)) or (K, N) in ((256, 128), (128, 256))) and M % 128 == 0:
+        narrow = K in (64, 128) and N in (64, 128)
+        if ((dtype == 1 and (narrow or (K, N) in ((256, 128), (128, 256)))) or (dtype == 0 and narrow)) and M % 128 == 0:
             tiles, per = M // 128, 1
             while tiles // per > 256 and tiles % (per * 2) == 0:
                 per *= 2
-            rps._obj.value, one._obj.value = 128 * per, 1
-            return 0
+            if dtype == 1 or tiles < 256 or 128 * per >= 256:
+                rps._obj.value, one._obj.value = 128 * per, 1
+                return 0
         tk, tn = C.c_int(0), C.c_int(0)
         return self.t3d_wgrad_plan(M, K, N, rps, C.byref(tk), C.byref(tn))
 

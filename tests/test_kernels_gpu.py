@@ -925,9 +925,91 @@ def test_fused_bwd_equals_separate_dgrad_and_wgrad(hip_lib, M, K, N, rpf, mode):
             assert hip_lib.t3d_pointmlp_wgrad(C.byref(w), st) == 0
         torch.cuda.synchronize()
         res.append((out, s1, s2, slabs))
-    for a, b, what in zip(res[0], res[1], ('out', 'psum_dz', 'psum_dzy', 'slabs')):
-        assert torch.equal(a, b), what
+    # the fused launch takes the one-pass form where the shape and this split allow it (t3d.h, t3d_bwd_plan): dX stays bit-identical
+    # (same MFMA step order), the statistics and the slab SUM differ by the fp32 summation order only
+    one_pass = rps.value % 128 == 0 and S >= min(256, T) and (T < 256 or rps.value >= 256) and K in (64, 128) and N in (64, 128)
+    assert torch.equal(res[0][0], res[1][0]), 'out'
+    if not one_pass:
+        for a, b, what in zip(res[0][1:], res[1][1:], ('psum_dz', 'psum_dzy', 'slabs')):
+            assert torch.equal(a, b), what
+    else:
+        sd = float(res[0][0].abs().max())
+        _close(res[0][1].cpu(), res[1][1].cpu(), 1e-4, 2e-5 * sd, 'psum_dz')
+        _close(res[0][2].cpu(), res[1][2].cpu(), 1e-4, 1e-4 * sd, 'psum_dzy')
+        dw0, dw1 = res[0][3].sum(0), res[1][3].sum(0)
+        _close(dw0.cpu(), dw1.cpu(), 1e-4, 2e-5 * float(dw0.abs().max()), 'dW')
     assert float(res[1][3].abs().max()) > 0 and float(res[1][0].abs().max()) > 0
+
+
+@pytest.mark.parametrize('M,K,N,rpf,mode,rps_', [
+    (256, 64, 64, 128, 'mask', -1), (512, 128, 128, 256, 'mask_addin', -1), (1024, 64, 128, 256, 'raw', -1), (768, 128, 64, 128, 'mask', -1),
+    (384, 128, 128, 128, 'raw_addin', 128), (65536, 128, 128, 1024, 'mask', -1), (65536, 64, 128, 2048, 'mask_addin', 256),
+    (65536, 128, 64, 1024, 'mask', 256), (65536, 64, 64, 1024, 'mask', -1), (1024, 128, 128, 256, 'mask_nostats', -1), (131072, 128, 128, 1024, 'mask_addin', 512)])
+def test_fp32_one_pass_backward(hip_lib, M, K, N, rpf, mode, rps_):
+    """k_pointmlp_bwd1f (the one-pass form t3d_pointmlp_bwd takes for fp32 layers with K, N in {64, 128}) against float64, and its dX
+    bit for bit against t3d_pointmlp_dgrad.  rps_: -1 = t3d_bwd_plan's split, > 0 = that many rows per split (whole 128-row tiles,
+    >= min(256, M / 128) workgroups, and >= 256 rows per workgroup once M >= 32768: below that the launcher keeps the split form)."""
+    g = torch.Generator(device='cpu').manual_seed(M + 3 * K + 7 * N + len(mode))
+    dev, T = 'cuda', M // 128
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dz = (torch.randn(M, N, generator=g) * 1e-2).to(dev)
+    y = torch.randn(M, N, generator=g).to(dev)
+    coef = torch.randn(3, N, generator=g)
+    coef[2] *= 1e-3
+    coef = coef.to(dev)
+    w_ = (torch.randn(K, N, generator=g) / np.sqrt(N)).to(dev)
+    x = torch.randn(M, K, generator=g).to(dev)
+    psc, psh = (0.5 + torch.rand(K, generator=g)).to(dev), (torch.randn(K, generator=g) * 0.3).to(dev)
+    add = (torch.randn(M, K, generator=g) * 1e-2).to(dev)
+    rps, one = C.c_int(0), C.c_int(0)
+    assert hip_lib.t3d_bwd_plan(M, K, N, abi.F32, C.byref(rps), C.byref(one)) == 0
+    assert one.value == 1 and rps.value % 128 == 0 and M // rps.value >= min(256, T)
+    if rps_ > 0:
+        rps.value = rps_
+        assert M // rps_ >= min(256, T) and (T < 256 or rps_ >= 256)
+    masked, stats, addin = 'mask' in mode, 'mask' in mode and 'nostats' not in mode, 'addin' in mode
+    dy = abi.DySrc(fptr(dz), fptr(y), fptr(coef), iptr(None), fptr(None))
+    outs = []
+    for fused in (True, False):
+        out = torch.full((M, K), float('nan'), device=dev)
+        s1, s2 = torch.full((T, K), float('nan'), device=dev), torch.full((T, K), float('nan'), device=dev)
+        slabs = torch.full((M // rps.value, K, N), float('nan'), device=dev)
+        d = abi.PointMlpDgradArgs()
+        d.dy, d.w, d.out, d.add_in = dy, fptr(w_), fptr(out), fptr(add if addin else None)
+        if masked:
+            d.prev_y, d.prev_scale, d.prev_shift = fptr(x), fptr(psc), fptr(psh)
+        if stats:
+            d.psum_dz, d.psum_dzy = fptr(s1), fptr(s2)
+        d.M, d.K, d.N, d.rows_per_frustum = M, K, N, rpf
+        wa = abi.PointMlpWgradArgs()
+        wa.a = abi.ActSrc(fptr(x), K, 0, fptr(psc), fptr(psh), 1, fptr(None), 0) if masked else \
+            abi.ActSrc(fptr(x), K, 0, fptr(None), fptr(None), 0, fptr(None), 0)
+        wa.dy, wa.slabs = dy, fptr(slabs)
+        wa.M, wa.K, wa.N, wa.rows_per_frustum, wa.rows_per_split = M, K, N, rpf, rps.value
+        if fused:
+            assert hip_lib.t3d_pointmlp_bwd(C.byref(d), C.byref(wa), st) == 0
+        else:
+            assert hip_lib.t3d_pointmlp_dgrad(C.byref(d), st) == 0
+        torch.cuda.synchronize()
+        outs.append((out, s1, s2, slabs))
+    out, s1, s2, slabs = outs[0]
+    assert torch.equal(out, outs[1][0]), 'dX: one-pass vs t3d_pointmlp_dgrad'
+    dyv = coef[0].double() * dz.double() + coef[1].double() * y.double() + coef[2].double()
+    ref = dyv @ w_.double().t() + (add.double() if addin else 0)
+    z = x.double() * psc.double() + psh.double()
+    if masked:
+        ref = torch.where(z > 0, ref, torch.zeros_like(ref))
+    sd = float(ref.abs().max())
+    assert float((out.double() - ref).abs().max()) < 1e-5 * sd * max(1.0, np.sqrt(N / 64))
+    if stats:
+        o = out.double().reshape(T, 128, K)
+        assert float((s1.double() - o.sum(1)).abs().max()) < 2e-5 * float(o.abs().sum(1).max() + 1e-9)
+        assert float((s2.double() - (o * x.double().reshape(T, 128, K)).sum(1)).abs().max()) < 1e-5 * float(o.abs().sum(1).max() + 1e-9)
+    a = torch.relu(z) if masked else x.double()
+    dw_ref = a.t() @ dyv
+    dw = slabs.double().sum(0)
+    assert not bool(torch.isnan(dw).any())
+    assert float((dw - dw_ref).abs().max()) < 2e-6 * float(dw_ref.abs().max()) * max(1.0, np.sqrt(M / 512))
 
 
 def test_fused_pool_stages_equal_the_separate_launches(hip_lib):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""The fused backward of one dense T3D_BF16 layer, split form vs one-pass form (same arguments, different row split):
-  python tools/bench_bwd_bf16.py K N [M] [reps] [rows_per_split of the one-pass form]
+"""The fused backward of one dense layer (T3D_BF16, or fp32 with a trailing `f32`), split form vs one-pass form (same arguments,
+different row split: t3d_wgrad_plan's split leaves too few workgroups for the one-pass form at the sizes this tool is for):
+  python tools/bench_bwd_bf16.py K N [M] [reps] [rows_per_split of the one-pass form, 0 = the plan's] [f32]
 Prints us per launch and the algorithmic HBM rate (every tensor once: dz, y, the input, dz_prev out)."""
 import ctypes as C
 import os
@@ -16,8 +17,10 @@ def main():
     K, N = int(sys.argv[1]), int(sys.argv[2])
     M = int(sys.argv[3]) if len(sys.argv) > 3 else 262144
     reps = int(sys.argv[4]) if len(sys.argv) > 4 else 10
+    f32 = len(sys.argv) > 6 and sys.argv[6] == 'f32'
     lib = abi.load()
-    dev, T, BF = 'cuda', M // 128, torch.bfloat16
+    dev, T, BF = 'cuda', M // 128, (torch.float32 if f32 else torch.bfloat16)
+    DT, es = (abi.F32 if f32 else abi.BF16), (4.0 if f32 else 2.0)
     dz = (torch.randn(M, N, device=dev) * 1e-2).to(BF)
     y = torch.randn(M, N, device=dev).to(BF)
     coef = torch.randn(3, N, device=dev)
@@ -30,22 +33,22 @@ def main():
     rps, tk, tn, one = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
     assert lib.t3d_wgrad_plan(M, K, N, C.byref(rps), C.byref(tk), C.byref(tn)) == 0
     forms = [('split', rps.value)]
-    assert lib.t3d_bwd_plan(M, K, N, abi.BF16, C.byref(rps), C.byref(one)) == 0
+    assert lib.t3d_bwd_plan(M, K, N, DT, C.byref(rps), C.byref(one)) == 0
     if one.value:
-        forms.append(('one-pass', int(sys.argv[5]) if len(sys.argv) > 5 else rps.value))
-    by = 2.0 * (2 * M * N + 2 * M * K)
+        forms.append(('one-pass', int(sys.argv[5]) if len(sys.argv) > 5 and int(sys.argv[5]) > 0 else rps.value))
+    by = es * (2 * M * N + 2 * M * K)
     res = {}
     for name, r in forms:
         slabs = torch.zeros(M // r, K, N, device=dev)
-        dy = abi.DySrc(fptr(dz), fptr(y), fptr(coef), iptr(None), fptr(None), abi.BF16)
+        dy = abi.DySrc(fptr(dz), fptr(y), fptr(coef), iptr(None), fptr(None), DT)
         d = abi.PointMlpDgradArgs()
         d.dy, d.w, d.add_in = dy, fptr(w16), fptr(None)
         d.prev_y, d.prev_scale, d.prev_shift, d.out, d.psum_dz, d.psum_dzy = fptr(prev_y), fptr(psc), fptr(psh), fptr(out), fptr(ps1), fptr(ps2)
-        d.M, d.K, d.N, d.rows_per_frustum, d.dtype = M, K, N, 2048, abi.BF16
+        d.M, d.K, d.N, d.rows_per_frustum, d.dtype = M, K, N, 1024, DT
         wa = abi.PointMlpWgradArgs()
-        wa.a = abi.ActSrc(fptr(prev_y), K, 0, fptr(psc), fptr(psh), 1, fptr(None), 0, abi.BF16)
+        wa.a = abi.ActSrc(fptr(prev_y), K, 0, fptr(psc), fptr(psh), 1, fptr(None), 0, DT)
         wa.dy, wa.slabs = dy, fptr(slabs)
-        wa.M, wa.K, wa.N, wa.rows_per_frustum, wa.rows_per_split = M, K, N, 2048, r
+        wa.M, wa.K, wa.N, wa.rows_per_frustum, wa.rows_per_split = M, K, N, 1024, r
         for _ in range(2):
             assert lib.t3d_pointmlp_bwd(C.byref(d), C.byref(wa), s) == 0
         torch.cuda.synchronize()

@@ -1909,6 +1909,269 @@ __global__ __launch_bounds__(NT1) void k_pointmlp_bwd1(const t3d_pointmlp_dgrad_
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// one-pass backward of a dense fp32 layer with K, N in {64, 128}
+// ---------------------------------------------------------------------------------------------
+// The fp32 twin of k_pointmlp_bwd1 on v_mfma_f32_32x32x2_f32: ONE 512-thread workgroup per CU owns rows_per_split rows and walks
+// them in 64-row tiles.  Per tile it builds dy = c0*dz + c1*y + c2 and a = relu(x*scale + shift) once as padded row-major LDS
+// images ([64][DIM + 4]: a ds_read_b128 along the row for the data gradient's A operand, conflict-free ds_read_b32 down a column
+// for both operands of the weight gradient), keeps the raw x tile beside them for the epilogue (ReLU mask and batch-norm-backward
+// partial sums of the producing layer), and holds W as register fragments for the whole kernel.  dz, y and x are read from HBM
+// once; the raw float4 chunks of tile t+1 are requested right behind the barrier that completes tile t's images and land under
+// its MFMAs.  dW accumulates in registers across the tiles; one K x N slab per workgroup leaves at the end.
+// MFMA steps run in the split form's order (k-groups of 8 ascending, lane half h takes indices 8g + 4h + i), so dX is
+// bit-identical to k_pointmlp_dgrad and dW differs only by where the row splits fall.
+// Wave roles (wv = 0..7): every 64-row tile has (64/32) x (K/32) data-gradient tiles of N/2 MFMA steps and (K/32) x (N/32)
+// weight-gradient tiles of 32 steps -- the same MFMA count on both sides for all four shapes:
+//   K = 128: all eight waves own one dX tile (row group wv / 4, column tile wv % 4) AND 16 / 8 (N = 128) or 8 / 8 dW tiles;
+//   K = 64 : waves 0-3 own the four dX tiles, waves 4-7 the dW tiles (two k-tiles of one n-tile each for N = 128, one for N = 64).
+template <int K, int N, bool ADD>
+__global__ __launch_bounds__(NT1) void k_pointmlp_bwd1f(const t3d_pointmlp_dgrad_args d, const t3d_pointmlp_wgrad_args w) {
+  static_assert((K == 64 || K == 128) && (N == 64 || N == 128), "K, N in {64, 128}");
+  constexpr int BM = 64, DLD = N + 4, ALD = K + 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Dimg = smem;                      // [BM][DLD]  dy
+  float* Aimg = Dimg + BM * DLD;           // [BM][ALD]  activated input
+  float* Ximg = Aimg + BM * ALD;           // [2][BM][ALD]  raw input; the epilogue overwrites it with the finished gradient, which
+                                           // leaves as whole rows one tile later (see the loop)
+  constexpr int CT = K / 32, RG = 2;       // dX: column tiles, row groups of 32 rows
+  float* red = Ximg + 2 * BM * ALD;        // [2 tiles of a 128-row pair][2 sums][RG][K]
+  float* cof = red + 2 * 2 * RG * K;       // [3][N] dy coefficients, [2][K] scale / shift of the input: read from HBM/L2 ONCE -- a
+                                           // global load at the top of a tile would be waited for with vmcnt(0), i.e. behind the
+                                           // previous tile's stores and a full L2 round trip per tile
+  constexpr bool ROLES = K == 64;          // K = 64: 4 dX tiles -> waves 0-3, dW -> waves 4-7
+  constexpr int TNn = N / 32;
+  constexpr int TMW = (K == 128 && N == 64) || (K == 64 && N == 64) ? 1 : 2;      // k-tiles of one n-tile per dW wave
+  constexpr int NG = N / 8;                // k-groups of the data gradient
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const bool do_dx = !ROLES || wv < 4, do_dw = !ROLES || wv >= 4;      // wave-uniform
+  const int xw = ROLES ? (wv & 3) : wv;
+  const int rg = xw / CT, ct = xw % CT, xr0 = rg * 32;
+  const int ww = ROLES ? (wv & 3) : wv;
+  // dW tiles of this wave: k-tiles kt0 .. kt0 + TMW - 1 of n-tile nt0
+  const int kt0 = K == 128 ? (N == 128 ? (ww / TNn) * 2 : ww / TNn) : (N == 128 ? 0 : ww / TNn);
+  const int nt0 = ww % TNn;
+  const int split = blockIdx.x;
+  const int row_begin = split * w.rows_per_split, n_tiles = w.rows_per_split / BM;
+
+  const bool mask = d.prev_y != nullptr, stats = mask && d.psum_dz != nullptr;      // uniform
+
+  // weights of the data gradient as B fragments: lane (k = ct*32 + l31, h) holds W[k][8g + 4h .. + 3]
+  float4 wf[NG];
+  if (do_dx) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) wf[g] = *reinterpret_cast<const float4*>(d.w + (size_t)(ct * 32 + l31) * N + 8 * g + 4 * h);
+  } else {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) wf[g] = f4zero();
+  }
+
+  // staging maps: a thread owns one float4 column chunk (the same for every row it touches) of each tensor
+  constexpr int CPD = N / 4, RPD = NT1 / CPD, NID = BM / RPD;
+  constexpr int CPA = K / 4, RPA = NT1 / CPA, NIA = BM / RPA;
+  static_assert(NID >= 1 && NIA >= 1, "row tile shorter than one staging pass");
+  const int chd = tid % CPD, rd = tid / CPD, cha = tid % CPA, ra = tid / CPA;
+  const float floor_ = w.a.relu ? 0.f : -INFINITY;
+  const float psc = mask ? d.prev_scale[ct * 32 + l31] : 0.f, psh = mask ? d.prev_shift[ct * 32 + l31] : 0.f;
+
+  float4 rz[NID], ry[NID], rx[NIA];
+  auto load_raw = [&](int row0) {
+#pragma unroll
+    for (int i = 0; i < NID; ++i) {
+      const size_t go = (size_t)(row0 + rd + RPD * i) * N + chd * 4;
+      rz[i] = *reinterpret_cast<const float4*>(d.dy.dz + go);
+      ry[i] = *reinterpret_cast<const float4*>(d.dy.y + go);
+    }
+#pragma unroll
+    for (int i = 0; i < NIA; ++i)
+      rx[i] = *reinterpret_cast<const float4*>(w.a.x + (size_t)(row0 + ra + RPA * i) * w.a.ldx + w.a.coff + cha * 4);
+  };
+
+  f32x16 accw[TMW];
+#pragma unroll
+  for (int tm = 0; tm < TMW; ++tm)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accw[tm][r] = 0.f;
+
+  load_raw(row_begin);
+  for (int i = tid; i < 3 * N + 2 * K; i += NT1) {
+    float v;
+    if (i < 3 * N) v = d.dy.coef[i];
+    else if (w.a.scale == nullptr) v = i < 3 * N + K ? 1.f : 0.f;
+    else v = i < 3 * N + K ? w.a.scale[i - 3 * N] : w.a.shift[i - 3 * N - K];
+    cof[i] = v;
+  }
+  __syncthreads();
+  // Order of the memory operations of one tile: [rows of tile t-1 out] [add_in of tile t] [raw chunks of tile t+1] -- all behind
+  // the barrier that completes tile t's images, i.e. under its MFMAs.  vmcnt is one in-order counter for loads AND stores, and
+  // the waits at the top of the loop are vmcnt(0) whatever was issued (the compiler merges the loop's entry states): stores placed
+  // behind the prefetch, e.g. in the epilogue, would be waited for -- a full write round trip per tile -- before the next tile
+  // could even be staged.
+  auto rows_out = [&](int row0, const float* Xp) {
+#pragma unroll
+    for (int i = 0; i < NIA; ++i)
+      *reinterpret_cast<float4*>(d.out + (size_t)(row0 + ra + RPA * i) * K + cha * 4) =
+          *reinterpret_cast<const float4*>(Xp + (ra + RPA * i) * ALD + cha * 4);
+  };
+#ifdef T3D_TRACE
+  unsigned long long tr_a = 0, tr_b = 0, tr_c = 0, tr_0 = wall_clock64(), tr_t = tr_0;      // staging / MFMA / epilogue, 10 ns ticks
+#define T3D_PHASE(acc) do { const unsigned long long n_ = wall_clock64(); acc += n_ - tr_t; tr_t = n_; } while (0)
+#else
+#define T3D_PHASE(acc) do {} while (0)
+#endif
+  for (int t = 0; t < n_tiles; ++t) {
+    const int row0 = row_begin + t * BM;
+    float* Xc = Ximg + (t & 1) * BM * ALD;
+    float* redc = red + (t & 1) * 2 * RG * K;
+    {      // registers -> images (the per-column constants come from LDS per tile: 20 VGPRs not held)
+      const float4 c0 = *reinterpret_cast<const float4*>(cof + chd * 4);
+      const float4 c1 = *reinterpret_cast<const float4*>(cof + N + chd * 4);
+      const float4 c2 = *reinterpret_cast<const float4*>(cof + 2 * N + chd * 4);
+#pragma unroll
+      for (int i = 0; i < NID; ++i) {
+        const float4 v = make_float4(fmaf(c0.x, rz[i].x, fmaf(c1.x, ry[i].x, c2.x)), fmaf(c0.y, rz[i].y, fmaf(c1.y, ry[i].y, c2.y)),
+                                     fmaf(c0.z, rz[i].z, fmaf(c1.z, ry[i].z, c2.z)), fmaf(c0.w, rz[i].w, fmaf(c1.w, ry[i].w, c2.w)));
+        *reinterpret_cast<float4*>(Dimg + (rd + RPD * i) * DLD + chd * 4) = v;
+      }
+      const float4 sc = *reinterpret_cast<const float4*>(cof + 3 * N + cha * 4);
+      const float4 sh = *reinterpret_cast<const float4*>(cof + 3 * N + K + cha * 4);
+#pragma unroll
+      for (int i = 0; i < NIA; ++i) {
+        const float4 v = make_float4(fmaxf(fmaf(rx[i].x, sc.x, sh.x), floor_), fmaxf(fmaf(rx[i].y, sc.y, sh.y), floor_),
+                                     fmaxf(fmaf(rx[i].z, sc.z, sh.z), floor_), fmaxf(fmaf(rx[i].w, sc.w, sh.w), floor_));
+        *reinterpret_cast<float4*>(Aimg + (ra + RPA * i) * ALD + cha * 4) = v;
+        *reinterpret_cast<float4*>(Xc + (ra + RPA * i) * ALD + cha * 4) = rx[i];
+      }
+    }
+    __syncthreads();
+    T3D_PHASE(tr_a);
+    if (t > 0) rows_out(row0 - BM, Ximg + ((t - 1) & 1) * BM * ALD);
+    f32x16 accd;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accd[r] = 0.f;
+    float ad[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ad[r] = 0.f;
+    if (ADD && do_dx) {
+      const unsigned ob = (unsigned)(row0 + xr0 + 4 * h) * (unsigned)K + (unsigned)(ct * 32 + l31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ad[r] = d.add_in[ob + (unsigned)((r & 3) + 8 * (r >> 2)) * K];
+    }
+    if (t + 1 < n_tiles) load_raw(row0 + BM);      // workgroup-uniform
+    if (do_dx) {
+      // dX = dy W^T: reduction over n
+      const float* ap = Dimg + (xr0 + l31) * DLD + 4 * h;
+      float4 fa[2];
+      fa[0] = *reinterpret_cast<const float4*>(ap);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) fa[(g + 1) & 1] = *reinterpret_cast<const float4*>(ap + 8 * (g + 1));
+#ifndef T3D_BWD1F_NOPIN
+        __builtin_amdgcn_sched_barrier(0);      // keep the next group's read AHEAD of this group's four dependent MFMAs
+#endif
+        const float4 a = fa[g & 1], b = wf[g];
+        accd = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, accd, 0, 0, 0);
+        accd = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, accd, 0, 0, 0);
+        accd = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, accd, 0, 0, 0);
+        accd = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, accd, 0, 0, 0);
+      }
+    }
+    if (do_dw) {
+      // dW += a^T dy: reduction over the tile's rows, k-groups of 8 rows (lane half h: rows 8g + 4h + i)
+      const float* ap = Aimg + 4 * h * ALD + kt0 * 32 + l31;
+      const float* bp = Dimg + 4 * h * DLD + nt0 * 32 + l31;
+      float fa[2][TMW][4], fb[2][4];
+      auto ldf = [&](int s_, int g) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          fb[s_][i] = bp[(8 * g + i) * DLD];
+#pragma unroll
+          for (int tm = 0; tm < TMW; ++tm) fa[s_][tm][i] = ap[(8 * g + i) * ALD + tm * 32];
+        }
+      };
+      ldf(0, 0);
+#pragma unroll
+      for (int g = 0; g < BM / 8; ++g) {
+        if (g + 1 < BM / 8) ldf((g + 1) & 1, g + 1);
+#ifndef T3D_BWD1F_NOPIN
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int tm = 0; tm < TMW; ++tm)
+            accw[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][tm][i], fb[g & 1][i], accw[tm], 0, 0, 0);
+      }
+    }
+    // epilogue of the data gradient: (+ add_in,) ReLU mask of the producing layer, its batch-norm-backward partial sums; the
+    // finished gradient replaces the raw input element it was masked with
+    T3D_PHASE(tr_b);
+    if (do_dx) {
+      float s1 = 0.f, s2 = 0.f;
+      float* xb = Xc + (xr0 + 4 * h) * ALD + ct * 32 + l31;
+      auto epi = [&](auto mask_c) {
+        constexpr bool MASK = decltype(mask_c)::value;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ro = (r & 3) + 8 * (r >> 2);
+          const float ypv = MASK ? xb[ro * ALD] : 0.f;
+          float v = accd[r] + ad[r];
+          if (MASK) {
+            if (!(fmaf(ypv, psc, psh) > 0.f)) v = 0.f;
+            s1 += v;
+            s2 = fmaf(v, ypv, s2);
+          }
+          xb[ro * ALD] = v;
+        }
+      };
+      if (mask) epi(std::true_type()); else epi(std::false_type());
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (stats && h == 0) {
+        redc[(0 * RG + rg) * K + ct * 32 + l31] = s1;
+        redc[(1 * RG + rg) * K + ct * 32 + l31] = s2;
+      }
+    }
+    __syncthreads();      // D and A free for the next tile; gradient rows and statistics of this tile visible
+    T3D_PHASE(tr_c);
+    if (stats && tid < K && (t & 1)) {      // the pair (t - 1, t) makes one 128-row partial
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {
+          t1 += red[(hb * 2 * RG + 0 * RG + g) * K + tid];
+          t2 += red[(hb * 2 * RG + 1 * RG + g) * K + tid];
+        }
+      const size_t o = (size_t)(row0 / 128) * K + tid;
+      d.psum_dz[o] = t1;
+      d.psum_dzy[o] = t2;
+    }
+    // a `red` half is written again only behind a later tile's first barrier, which every reader above reaches first; the X copy
+    // of this tile is staged again two tiles on, behind the next tile's second barrier -- its rows leave before that
+  }
+  rows_out(row_begin + (n_tiles - 1) * BM, Ximg + ((n_tiles - 1) & 1) * BM * ALD);
+#ifdef T3D_TRACE
+  if (tid == 0 && t3d_trace_ptr) {
+    t3d_trace_ptr[(size_t)blockIdx.x * 4 + 0] = tr_a;
+    t3d_trace_ptr[(size_t)blockIdx.x * 4 + 1] = tr_b;
+    t3d_trace_ptr[(size_t)blockIdx.x * 4 + 2] = tr_c;
+    t3d_trace_ptr[(size_t)blockIdx.x * 4 + 3] = wall_clock64() - tr_0;
+  }
+#endif
+#undef T3D_PHASE
+
+  if (do_dw) {
+    float* slab = w.slabs + (size_t)split * K * N;
+    const int col = nt0 * 32 + l31;
+#pragma unroll
+    for (int tm = 0; tm < TMW; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        slab[(size_t)((kt0 + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * N + col] = accw[tm][r];
+  }
+}
+
 // Gram-form backward of a pooled layer, stage 1: the three jobs that need nothing but the layer input and the
 // batch-norm-backward coefficients -- Gram slabs a^T a, column sums of a, and the P / rowconst slabs (+ wc) -- in one launch.
 template <int GT, class PR = PathF32>
@@ -2544,6 +2807,7 @@ constexpr size_t lds_epi2(int bn) { return (size_t)12 * bn * sizeof(float) + 2 *
 constexpr size_t lds_max(size_t a, size_t b) { return a > b ? a : b; }
 constexpr size_t lds_dgrad_h(int bn) { return lds_max(2 * (size_t)(128 * LDRH + bn * LDRH) * 2, lds_epi2(bn)); }
 constexpr size_t lds_wgrad_h(int bmk, int bn) { return 2 * (size_t)BKH * (bmk + 32 + bn + 32) * 2; }
+constexpr size_t lds_bwd1f(int k, int n) { return (size_t)(64 * ((n + 4) + 3 * (k + 4)) + 2 * 2 * 2 * k + 3 * n + 2 * k) * 4; }      // D, A, 2 x X images, statistics scratch, per-column constants
 constexpr size_t lds_bwd1(int k, int n, int bm) { return (size_t)bm * (n + k + 2 * (k + 8)) * 2 + (size_t)2 * 2 * 4 * k * 4; }      // D, A, 2 x X images + the statistics scratch
 
 bool dtype_ok(int dt) { return dt == T3D_F32 || dt == T3D_BF16; }
@@ -2730,8 +2994,17 @@ extern "C" int t3d_wgrad_plan(int M, int K, int N, int* rows_per_split, int* til
 // everything else the split form with t3d_wgrad_plan's row split.
 static bool bwd1_shape(int M, int K, int N, int dtype) {
   static const bool on = []() { const char* e = getenv("T3D_BWD1"); return !(e && e[0] == '0'); }();
+  static const bool onf = []() { const char* e = getenv("T3D_BWD1F"); return !(e && e[0] == '0'); }();
   const bool narrow = (K == 64 || K == 128) && (N == 64 || N == 128), mid = (K == 256 && N == 128) || (K == 128 && N == 256);
+  if (dtype == T3D_F32) return onf && narrow && M % 128 == 0;
   return on && dtype == T3D_BF16 && (narrow || mid) && M % 128 == 0;
+}
+// fp32: the one-pass form pays from about four 64-row tiles per workgroup (measured per shape on MI355X, DESIGN.md section 4: at
+// B=32 N=1024 -- 256 workgroups of two tiles -- it ties with the split form, its first load and its phase-synchronous tiles exposed);
+// when the rows cannot fill 256 workgroups anyway (M < 32768) the choice does not matter and the one-pass form is taken.
+static bool bwd1_split_ok(int M, int rps, int dtype) {
+  static const bool force = []() { const char* e = getenv("T3D_BWD1F"); return e && e[0] == '2'; }();
+  return dtype != T3D_F32 || force || M / 128 < 256 || rps >= 256;
 }
 extern "C" int t3d_bwd_plan(int M, int K, int N, int dtype, int* rows_per_split, int* one_pass) {
   if (!rows_per_split || !one_pass) return T3D_ERR_ARG;
@@ -2741,9 +3014,11 @@ extern "C" int t3d_bwd_plan(int M, int K, int N, int dtype, int* rows_per_split,
     const int tiles = M / 128;
     int per = 1;
     while (tiles / per > target && tiles % (per * 2) == 0) per *= 2;
-    *rows_per_split = 128 * per;
-    *one_pass = 1;
-    return T3D_OK;
+    if (bwd1_split_ok(M, 128 * per, dtype)) {
+      *rows_per_split = 128 * per;
+      *one_pass = 1;
+      return T3D_OK;
+    }
   }
   int tk = 0, tn = 0;
   return t3d_wgrad_plan(M, K, N, rows_per_split, &tk, &tn);
@@ -2822,9 +3097,11 @@ extern "C" int t3d_gram_plan(int M, int K, int dtype, int* rows_per_split, int* 
     const int tiles = M / 128;
     int per = 1;
     while (tiles / per > 256 && tiles % (per * 2) == 0) per *= 2;
-    *rows_per_split = 128 * per;
-    *one_pass = 1;
-    return T3D_OK;
+    if (bwd1_split_ok(M, 128 * per, dtype)) {
+      *rows_per_split = 128 * per;
+      *one_pass = 1;
+      return T3D_OK;
+    }
   }
   int tk = 0, tn = 0;
   return t3d_wgrad_plan(M, K, K, rows_per_split, &tk, &tn);
@@ -2934,8 +3211,34 @@ extern "C" int t3d_pointmlp_bwd(const t3d_pointmlp_dgrad_args* d, const t3d_poin
   hipStream_t s = static_cast<hipStream_t>(stream);
   {   // one-pass form: eligible layer and a row split that leaves enough workgroups (t3d_bwd_plan's does)
     const int rps = w->rows_per_split, tiles = d->M / 128;
-    if (bwd1_shape(d->M, d->K, d->N, d->dtype) && rps % 128 == 0 && d->M / rps >= (tiles < 256 ? tiles : 256) &&
-        w->a.dtype == T3D_BF16 && w->a.ldx % 8 == 0 && w->a.coff % 8 == 0 && (w->a.scale == nullptr) == (w->a.shift == nullptr)) {
+    // the epilogue takes the producer's raw output from the input tile it already holds: prev_y must BE the input tensor
+    const bool own_x = d->prev_y == nullptr || (d->prev_y == w->a.x && w->a.coff == 0 && w->a.ldx == d->K);
+    const bool shape1 = bwd1_shape(d->M, d->K, d->N, d->dtype) && rps % 128 == 0 && d->M / rps >= (tiles < 256 ? tiles : 256) && own_x &&
+                        bwd1_split_ok(d->M, rps, d->dtype) &&
+                        (w->a.scale == nullptr) == (w->a.shift == nullptr);
+    if (shape1 && !bf16 && w->a.ldx % 4 == 0 && w->a.coff % 4 == 0) {
+      const dim3 grid1(d->M / rps);
+#define T3D_BWD1F(K_, N_)                                                                        \
+  do {                                                                                           \
+    if (d->add_in) {                                                                             \
+      auto kern = k_pointmlp_bwd1f<K_, N_, true>;                                                \
+      allow_lds(reinterpret_cast<const void*>(kern), lds_bwd1f(K_, N_));                         \
+      T3D_LAUNCH(kern, grid1, dim3(NT1), lds_bwd1f(K_, N_), s, *d, *w);                          \
+    } else {                                                                                     \
+      auto kern = k_pointmlp_bwd1f<K_, N_, false>;                                               \
+      allow_lds(reinterpret_cast<const void*>(kern), lds_bwd1f(K_, N_));                         \
+      T3D_LAUNCH(kern, grid1, dim3(NT1), lds_bwd1f(K_, N_), s, *d, *w);                          \
+    }                                                                                            \
+  } while (0)
+      if (d->K == 128 && d->N == 128) T3D_BWD1F(128, 128);
+      else if (d->K == 128) T3D_BWD1F(128, 64);
+      else if (d->N == 128) T3D_BWD1F(64, 128);
+      else T3D_BWD1F(64, 64);
+#undef T3D_BWD1F
+      T3D_CHECK_LAUNCH();
+      return T3D_OK;
+    }
+    if (shape1 && bf16 && w->a.dtype == T3D_BF16 && w->a.ldx % 8 == 0 && w->a.coff % 8 == 0) {
       const dim3 grid1(d->M / rps);
 #define T3D_BWD1(K_, N_, BM_)                                                                    \
   do {                                                                                           \
