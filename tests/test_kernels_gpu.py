@@ -1186,6 +1186,83 @@ def test_bn_fwd_finalize_with_fused_pool_pick(hip_lib):
     assert float(res[1]['pooled'].abs().max()) > 0
 
 
+@pytest.mark.parametrize('T,tpf,N', [(640, 8, 192), (2048, 16, 128), (2304, 8, 72), (4096, 16, 64), (2048, 16, 256)])
+def test_bn_finalizers_many_tiles(hip_lib, T, tpf, N):
+    """The finalizers at the tile counts of config 4 (B=128 N=2048: 2048 row tiles) take other block shapes (64 tile groups above 512
+    tiles, 4 channels x 256 groups from 1024): forward and dense backward against float64, the fused pool pick against
+    t3d_pool_finalize bit for bit."""
+    r = np.random.RandomState(T + N)
+    dev = _dev('cuda')
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    B, M = T // tpf, T * 128
+    psum = (r.normal(size=(T, N)) * 30).astype(np.float32)
+    psumsq = (np.abs(r.normal(size=(T, N))) * 128 + psum.astype(np.float64) ** 2 / 128).astype(np.float32)
+    gamma, beta = r.normal(size=N).astype(np.float32), r.normal(size=N).astype(np.float32)
+    mm, mv = r.normal(size=N).astype(np.float32), (0.5 + r.uniform(size=N)).astype(np.float32)
+    pmax = r.normal(size=(T, N)).astype(np.float32)
+    pmin = (pmax - np.abs(r.normal(size=(T, N)))).astype(np.float32)
+    pamax = (r.randint(0, 128, size=(T, N)) + (np.arange(T) % tpf)[:, None] * 128).astype(np.int32)
+    pamin = (r.randint(0, 128, size=(T, N)) + (np.arange(T) % tpf)[:, None] * 128).astype(np.int32)
+    dead = r.uniform(size=(T, N)) < 0.3
+    pamax[dead] = -1
+    pamin[dead] = -1
+    t = {k: _mk(dev, v) for k, v in dict(psum=psum, psumsq=psumsq, gamma=gamma, beta=beta, decay=np.array([0.7], np.float32),
+                                         pmax=pmax, pmin=pmin, pamax=pamax, pamin=pamin).items()}
+    res = []
+    for fused in (False, True):
+        o = dict(scale=torch.zeros(N, device=dev), shift=torch.zeros(N, device=dev), mean=torch.zeros(N, device=dev),
+                 invstd=torch.zeros(N, device=dev), mm=_mk(dev, mm.copy()), mv=_mk(dev, mv.copy()), pooled=torch.zeros(B, N, device=dev),
+                 argidx=torch.zeros(B, N, dtype=torch.int32, device=dev), ysel=torch.zeros(B, N, device=dev))
+        f = abi.BnFwdFinalizeArgs()
+        f.psum, f.psumsq, f.n_tiles, f.count, f.N = fptr(t['psum']), fptr(t['psumsq']), T, M, N
+        f.gamma, f.beta, f.moving_mean, f.moving_var, f.decay = fptr(t['gamma']), fptr(t['beta']), fptr(o['mm']), fptr(o['mv']), fptr(t['decay'])
+        f.eps, f.is_training, f.unbiased_ema = 1e-3, 1, 1
+        f.scale, f.shift, f.mean, f.invstd = fptr(o['scale']), fptr(o['shift']), fptr(o['mean']), fptr(o['invstd'])
+        if fused:
+            f.pool_pmax, f.pool_pmin, f.pool_pamax, f.pool_pamin = fptr(t['pmax']), fptr(t['pmin']), iptr(t['pamax']), iptr(t['pamin'])
+            f.pool_B, f.pool_tiles_per_frustum, f.pooled, f.ld_pooled, f.argidx, f.ysel = B, tpf, fptr(o['pooled']), N, iptr(o['argidx']), fptr(o['ysel'])
+        assert hip_lib.t3d_bn_fwd_finalize(C.byref(f), st) == 0
+        if not fused:
+            q = abi.PoolFinalizeArgs()
+            q.scale, q.shift, q.pmax, q.pmin, q.pamax, q.pamin = fptr(o['scale']), fptr(o['shift']), fptr(t['pmax']), fptr(t['pmin']), iptr(t['pamax']), iptr(t['pamin'])
+            q.B, q.N, q.tiles_per_frustum, q.pooled, q.ld_pooled, q.argidx, q.ysel = B, N, tpf, fptr(o['pooled']), N, iptr(o['argidx']), fptr(o['ysel'])
+            assert hip_lib.t3d_pool_finalize(C.byref(q), st) == 0
+        torch.cuda.synchronize()
+        res.append(o)
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]), k
+    o = {k: v.cpu().numpy().astype(np.float64) for k, v in res[1].items()}
+    n = float(M)
+    mean = psum.astype(np.float64).sum(0) / n
+    var = np.maximum(psumsq.astype(np.float64).sum(0) / n - mean * mean, 0.0)
+    invstd = 1.0 / np.sqrt(var + 1e-3)
+    sc = gamma.astype(np.float64) * invstd
+    for k, ref in dict(mean=mean, invstd=invstd, scale=sc, shift=beta - mean * sc, mm=mm * 0.7 + mean * (1 - 0.7),
+                       mv=mv * 0.7 + var * n / (n - 1) * (1 - 0.7)).items():
+        assert float(np.abs(o[k] - ref).max()) < 2e-6 * float(np.abs(ref).max() + 1), k
+    # dense backward
+    s1 = r.normal(size=(T, N)).astype(np.float32)
+    s2 = r.normal(size=(T, N)).astype(np.float32)
+    mean_b, invstd_b = r.normal(size=N).astype(np.float32), (0.5 + r.uniform(size=N)).astype(np.float32)
+    tb = {k: _mk(dev, v) for k, v in dict(s1=s1, s2=s2, mean=mean_b, invstd=invstd_b, gamma=gamma).items()}
+    ob = dict(coef=torch.zeros(3, N, device=dev), dgamma=torch.zeros(N, device=dev), dbeta=torch.zeros(N, device=dev))
+    a = abi.BnBwdFinalizeArgs()
+    a.psum_dz, a.psum_dzy, a.n_tiles, a.count, a.N = fptr(tb['s1']), fptr(tb['s2']), T, M, N
+    a.gamma, a.mean, a.invstd = fptr(tb['gamma']), fptr(tb['mean']), fptr(tb['invstd'])
+    a.dgamma, a.dbeta, a.coef = fptr(ob['dgamma']), fptr(ob['dbeta']), fptr(ob['coef'])
+    assert hip_lib.t3d_bn_bwd_finalize(C.byref(a), st) == 0
+    torch.cuda.synchronize()
+    S1, S2 = s1.astype(np.float64).sum(0), s2.astype(np.float64).sum(0)
+    dbeta = S1
+    dgamma = invstd_b * (S2 - mean_b.astype(np.float64) * S1)
+    c1 = gamma.astype(np.float64) * invstd_b
+    k3 = dgamma / n * invstd_b
+    ref = dict(dbeta=dbeta, dgamma=dgamma, coef=np.stack([c1, -c1 * k3, c1 * (k3 * mean_b - dbeta / n)]))
+    for k, v in ref.items():
+        got = ob[k].cpu().numpy().astype(np.float64)
+        assert float(np.abs(got - v).max()) < 2e-6 * float(np.abs(v).max() + 1e-3), k
+
+
 def _sweep_cases(seed, n):
     """Seeded random shapes on the contract of t3d.h (M, rows_per_frustum multiples of 128; widths multiples of 64; K any)."""
     r = np.random.RandomState(seed)

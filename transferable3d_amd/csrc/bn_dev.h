@@ -11,14 +11,20 @@ namespace {
 // (13.7 us per launch, profiles/r02_bf16_v2): above T3D_FIN_BIG tiles (default 512) the launchers take the GR = 64 instantiation
 // (1024 threads, two round trips; only group 0 walks the 64 LDS partials): fwd finalize 195 -> 163 us per step, bwd 124 -> 112 at
 // B=128 N=2048 (same-box A/B).  Up to 512 tiles GR stays 16, so the results at the sizes of configs 1-3 do not change by a bit.
-constexpr int FC_CH = 16, FC_GR = 16, FC_GR_BIG = 64;
+// Still at config 4: N / 16 = 4 .. 32 such blocks per launch read all 2048 x N partials -- eight CUs' worth of address processing for
+// the 128-channel layers, 12 us per launch, 29 launches per step.  Above T3D_FIN_WIDE tiles (default 1024) a block takes FOUR channels
+// and 256 tile groups (`CH`, 1024 threads): four times the blocks, one round trip of eight tiles per thread, and the 256 partials per
+// channel meet in two LDS levels (16 x 16).
+// Back to back at 2048 tiles (tools/bench_finalize.py, us per launch, 64-group -> wide): N = 64 6.9 -> 5.0, 128 7.6 -> 5.3, 256 7.2 -> 7.3,
+// 512 7.2 -> 14.9, 1024 8.6 -> 23.1 -- a 64-byte line then serves four blocks, and from 64 blocks on that traffic is the bound: the
+// wide form is taken for N <= 128 only.
+constexpr int FC_CH = 16, FC_GR = 16, FC_GR_BIG = 64, FC_CH_WIDE = 4, FC_GR_WIDE = 256, FC_WIDE_MAX_N = 128;
 
 // Sixteen tiles per quantity are in flight per thread (32 loads for the two-quantity reductions): at 256 tiles the whole
 // reduction is ONE memory round trip instead of four.
-template <int NQ, int GR = FC_GR>
+template <int NQ, int GR = FC_GR, int U = 16>
 __device__ __forceinline__ void tile_sums(const float* const (&src)[NQ], int n_tiles, int N, int c, int grp, bool ok,
                                           double (&acc)[NQ]) {
-  constexpr int U = 16;
 #pragma unroll
   for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
   if (!ok) return;
@@ -42,13 +48,27 @@ __device__ __forceinline__ void tile_sums(const float* const (&src)[NQ], int n_t
   }
 }
 
-template <int GR = FC_GR>
-__device__ __forceinline__ double group_reduce(double v, double (*red)[FC_CH], int grp, int cl, bool act = true) {
+template <int GR = FC_GR, int CH = FC_CH>
+__device__ __forceinline__ double group_reduce(double v, double (*red)[CH], int grp, int cl, bool act = true) {
   __syncthreads();
   if (act) red[grp][cl] = v;
   __syncthreads();
   double s = 0.0;
-  if (GR == FC_GR || grp == 0) {      // only group 0 uses the sum; with 64 groups the other 1008 threads' reads are pure LDS traffic
+  if (GR > 64) {      // two levels: groups 0..15 sum 16 partials each, group 0 sums those (fixed order: reproducible)
+    static_assert(GR <= 64 || GR == 256, "two-level reduction: 16 x 16 groups");
+    if (grp < 16) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) s += red[grp * 16 + g][cl];
+    }
+    __syncthreads();
+    if (grp < 16) red[grp][cl] = s;
+    __syncthreads();
+    s = 0.0;
+    if (grp == 0) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) s += red[g][cl];
+    }
+  } else if (GR == FC_GR || grp == 0) {      // only group 0 uses the sum; with 64 groups the other 1008 threads' reads are pure LDS traffic
 #pragma unroll
     for (int g = 0; g < GR; ++g) s += red[g][cl];
   }
@@ -56,19 +76,19 @@ __device__ __forceinline__ double group_reduce(double v, double (*red)[FC_CH], i
 }
 
 // `tid` may exceed GR * FC_CH (the 512-thread paired launch, pair.hip): the extra threads take part in the barriers only
-template <int GR>
+template <int GR, int CH = FC_CH>
 __device__ __forceinline__ void bn_bwd_finalize_body(const t3d_bn_bwd_finalize_args& p, const int bid, const int tid) {
-  __shared__ double red[GR][FC_CH];
-  const bool act = tid < GR * FC_CH;
-  const int cl = tid & (FC_CH - 1), grp = act ? tid / FC_CH : 0;
-  const int c = bid * FC_CH + cl;
+  __shared__ double red[GR][CH];
+  const bool act = tid < GR * CH;
+  const int cl = tid & (CH - 1), grp = act ? tid / CH : 0;
+  const int c = bid * CH + cl;
   const bool ok = act && c < p.N;
   const int cc = ok ? c : 0;
   const float mean_f = p.mean[cc], invstd_f = p.invstd[cc], gamma_f = p.gamma[cc];   // ahead of the reduction
   double acc[2] = {0.0, 0.0};   // sum dz, sum dz*y
   if (p.psum_dz != nullptr) {
     const float* const src[2] = {p.psum_dz, p.psum_dzy};
-    tile_sums<2, GR>(src, p.n_tiles, p.N, c, grp, ok, acc);
+    tile_sums<2, GR, (GR > 64 ? 8 : 16)>(src, p.n_tiles, p.N, c, grp, ok, acc);
   } else if (ok) {
     for (int b = grp; b < p.B; b += GR) {
       const float live = p.pooled[(size_t)b * p.ld_pooled + c] > 0.f ? 1.f : 0.f;
@@ -78,8 +98,8 @@ __device__ __forceinline__ void bn_bwd_finalize_body(const t3d_bn_bwd_finalize_a
       acc[1] += (double)g * (double)p.ysel[(size_t)b * p.N + c];
     }
   }
-  const double s1 = group_reduce<GR>(acc[0], red, grp, cl, act);
-  const double s2 = group_reduce<GR>(acc[1], red, grp, cl, act);
+  const double s1 = group_reduce<GR, CH>(acc[0], red, grp, cl, act);
+  const double s2 = group_reduce<GR, CH>(acc[1], red, grp, cl, act);
   if (grp == 0 && ok) {
     if (p.frozen) {
       p.coef[c] = p.scale[c];

@@ -47,11 +47,11 @@ __device__ __forceinline__ void pool_pick(const t3d_bn_fwd_finalize_args& p, int
                  p.ld_pooled, p.argidx, p.ysel);
 }
 
-template <int GR>
-__global__ __launch_bounds__(GR * FC_CH) void k_bn_fwd_finalize(const t3d_bn_fwd_finalize_args p) {
-  __shared__ double red[GR][FC_CH];
-  const int cl = threadIdx.x & (FC_CH - 1), grp = threadIdx.x / FC_CH;
-  const int c = blockIdx.x * FC_CH + cl;
+template <int GR, int CH = FC_CH>
+__global__ __launch_bounds__(GR * CH) void k_bn_fwd_finalize(const t3d_bn_fwd_finalize_args p) {
+  __shared__ double red[GR][CH];
+  const int cl = threadIdx.x & (CH - 1), grp = threadIdx.x / CH;
+  const int c = blockIdx.x * CH + cl;
   const bool ok = c < p.N;
   if (p.is_training) {
     // parameters first: their latency hides under the tile reduction instead of following it
@@ -59,9 +59,9 @@ __global__ __launch_bounds__(GR * FC_CH) void k_bn_fwd_finalize(const t3d_bn_fwd
     const float gam = p.gamma[cc], bet = p.beta[cc], mm = p.moving_mean[cc], mv = p.moving_var[cc], dec = p.decay[0];
     const float* const src[2] = {p.psum, p.psumsq};
     double acc[2];
-    tile_sums<2, GR>(src, p.n_tiles, p.N, c, grp, ok, acc);
-    const double s = group_reduce<GR>(acc[0], red, grp, cl);
-    const double ss = group_reduce<GR>(acc[1], red, grp, cl);
+    tile_sums<2, GR, (GR > 64 ? 8 : 16)>(src, p.n_tiles, p.N, c, grp, ok, acc);
+    const double s = group_reduce<GR, CH>(acc[0], red, grp, cl);
+    const double ss = group_reduce<GR, CH>(acc[1], red, grp, cl);
     if (grp == 0 && ok) {
       const double n = (double)p.count;
       const double mean = s / n;
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(GR * FC_CH) void k_bn_fwd_finalize(const t3d_bn_fwd
   }
   // optional K3: the max-pool pick of the same 16 channels (scale/shift handed over through LDS, not through memory)
   if (p.pool_pmax != nullptr) {
-    __shared__ float s_sc[FC_CH], s_sh[FC_CH];
+    __shared__ float s_sc[CH], s_sh[CH];
     __syncthreads();
     if (grp == 0 && ok) { s_sc[cl] = p.scale[c]; s_sh[cl] = p.shift[c]; }     // this thread's own stores: visible to itself
     __syncthreads();
@@ -108,9 +108,9 @@ __global__ __launch_bounds__(256) void k_pool_finalize(const t3d_pool_finalize_a
                  p.argidx, p.ysel);
 }
 
-template <int GR>
-__global__ __launch_bounds__(GR * FC_CH) void k_bn_bwd_finalize(const t3d_bn_bwd_finalize_args p) {
-  bn_bwd_finalize_body<GR>(p, blockIdx.x, threadIdx.x);
+template <int GR, int CH = FC_CH>
+__global__ __launch_bounds__(GR * CH) void k_bn_bwd_finalize(const t3d_bn_bwd_finalize_args p) {
+  bn_bwd_finalize_body<GR, CH>(p, blockIdx.x, threadIdx.x);
 }
 
 __global__ __launch_bounds__(256) void k_dy_colsum(const t3d_dy_colsum_args p) { dy_colsum_body(p, blockIdx.x, threadIdx.x); }
@@ -261,12 +261,20 @@ static int fin_big_tiles() {      // T3D_FIN_BIG: tile count above which the 64-
   return v;
 }
 
+static int fin_wide_tiles() {      // T3D_FIN_WIDE: tile count from which the 4-channel x 256-group finalizers run (0 = never)
+  static const int v = []() { const char* e = getenv("T3D_FIN_WIDE"); const int x = e ? atoi(e) : 1024; return x > 0 ? x : (1 << 30); }();
+  return v;
+}
+
 extern "C" int t3d_bn_fwd_finalize(const t3d_bn_fwd_finalize_args* a, t3d_stream_t stream) {
   if (!a || !a->gamma || !a->beta || !a->moving_mean || !a->moving_var || !a->scale || !a->shift || !a->mean ||
       !a->invstd)
     return T3D_ERR_ARG;
   if (a->is_training && (!a->psum || !a->psumsq || !a->decay || a->count <= 0)) return T3D_ERR_ARG;
-  if (a->is_training && a->n_tiles > fin_big_tiles())
+  if (a->is_training && a->n_tiles >= fin_wide_tiles() && a->N <= FC_WIDE_MAX_N)
+    T3D_LAUNCH((k_bn_fwd_finalize<FC_GR_WIDE, FC_CH_WIDE>), dim3((a->N + FC_CH_WIDE - 1) / FC_CH_WIDE), dim3(FC_GR_WIDE * FC_CH_WIDE), 0,
+               static_cast<hipStream_t>(stream), *a);
+  else if (a->is_training && a->n_tiles > fin_big_tiles())
     T3D_LAUNCH(k_bn_fwd_finalize<FC_GR_BIG>, dim3((a->N + FC_CH - 1) / FC_CH), dim3(FC_GR_BIG * FC_CH), 0, static_cast<hipStream_t>(stream), *a);
   else
     T3D_LAUNCH(k_bn_fwd_finalize<FC_GR>, dim3((a->N + FC_CH - 1) / FC_CH), dim3(FC_GR * FC_CH), 0, static_cast<hipStream_t>(stream), *a);
@@ -289,7 +297,10 @@ extern "C" int t3d_bn_bwd_finalize(const t3d_bn_bwd_finalize_args* a, t3d_stream
   if (a->psum_dz == nullptr && (!a->dpool_in || !a->pooled || !a->ysel || !a->dpool)) return T3D_ERR_ARG;
   if (a->psum_dz != nullptr && !a->psum_dzy) return T3D_ERR_ARG;
   if (a->frozen ? !a->scale : (!a->gamma || !a->mean || !a->invstd)) return T3D_ERR_ARG;
-  if (a->psum_dz != nullptr && a->n_tiles > fin_big_tiles())
+  if (a->psum_dz != nullptr && a->n_tiles >= fin_wide_tiles() && a->N <= FC_WIDE_MAX_N)
+    T3D_LAUNCH((k_bn_bwd_finalize<FC_GR_WIDE, FC_CH_WIDE>), dim3((a->N + FC_CH_WIDE - 1) / FC_CH_WIDE), dim3(FC_GR_WIDE * FC_CH_WIDE), 0,
+               static_cast<hipStream_t>(stream), *a);
+  else if (a->psum_dz != nullptr && a->n_tiles > fin_big_tiles())
     T3D_LAUNCH(k_bn_bwd_finalize<FC_GR_BIG>, dim3((a->N + FC_CH - 1) / FC_CH), dim3(FC_GR_BIG * FC_CH), 0, static_cast<hipStream_t>(stream), *a);
   else
     T3D_LAUNCH(k_bn_bwd_finalize<FC_GR>, dim3((a->N + FC_CH - 1) / FC_CH), dim3(FC_GR * FC_CH), 0, static_cast<hipStream_t>(stream), *a);
