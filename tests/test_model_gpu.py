@@ -92,6 +92,21 @@ def test_full_size_against_the_oracle_and_properties(hip_lib):
     assert rel < 1e-3, rel
 
 
+def test_twice_the_baseline_batch_against_the_oracle(hip_lib):
+    """B=64, N=1024 (M = 65 536 rows in the seg net): the size from which the fp32 layers with K, N in {64, 128} take the one-pass
+    backward (t3d_bwd_plan) -- forward heads / loss within 1e-4 of the fp64 oracle, every gradient tensor tight (flip-aware)."""
+    B, N, C = 64, 1024, 4
+    import ctypes as C_
+    from transferable3d_amd import abi
+    rps, one = C_.c_int(0), C_.c_int(0)
+    assert hip_lib.t3d_bwd_plan(B * N, 128, 128, abi.F32, C_.byref(rps), C_.byref(one)) == 0 and one.value == 1 and rps.value == 256
+    batch = make_batch(B, N, C, seed=4321, dropout_scopes={'inst_seg/dp1': ((B, N, 128), 0.5)})
+    P = _params(C, 17)
+    c = R.default_config()
+    g, m = run_model_a(Runtime(lib=hip_lib), batch, P, c)
+    print(check_against_oracle(g, m, batch, P, c))
+
+
 def test_boxpc_step_matches_oracle(hip_lib):
     """BASELINE config 2: Box-PC Fit net (train_boxpc.py path), forward + backward on the GPU vs the oracle."""
     from test_boxpc_cpu import SCOPES, check_boxpc, run_boxpc
