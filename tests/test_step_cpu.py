@@ -51,7 +51,7 @@ def test_bucketed_data_parallel_program_equals_the_single_replica_step():
             if mode == 'single':
                 assert kinds == ['run']
             elif mode == 'bucketed':
-                assert kinds == ['run', 'allreduce', 'run', 'allreduce', 'run', 'allreduce', 'wait', 'run', 'wait', 'run', 'wait', 'run']
+                assert kinds == ['run', 'allreduce', 'run', 'allreduce', 'run', 'allreduce', 'wait', 'wait', 'wait', 'run']
                 assert len(g.buckets) == 3 and sum(n for b in g.buckets for _, n in b) == g.vars.used
                 # box + T-Net first (ready before the seg net's backward starts), the seg net's first layers last
                 assert g.buckets[0][0][0] == g.vars.offset('tnet/conv-reg1-stage1/weights')

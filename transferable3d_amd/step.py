@@ -84,6 +84,22 @@ class TrainStep:
             cur.calls.append((name, call, arg))
             cur.lanes.append(lane)
         close()
+        # The optimiser plan waits for a bucket right before that bucket's Adam launch; as host-issued program that made a graph
+        # segment per bucket (≈23 us of graph launch each, and Adam is 7 us in all).  The waits move ahead of the first Adam segment
+        # (a wait only adds a dependency earlier) and the Adam launches share ONE segment: [... allreduce, wait, wait, wait, run].
+        k = len(prog)
+        while k > 0 and (prog[k - 1][0] == 'wait' or (prog[k - 1][0] == 'run' and
+                                                      all(c[0] in ('t3d_adam_tf_step', Plan.JOIN) for c in prog[k - 1][1].calls))):
+            k -= 1
+        tail = prog[k:]
+        if sum(1 for kind, _ in tail if kind == 'run') > 1:
+            merged = Plan(self.rt)
+            merged.two_streams = two
+            for kind, x in tail:
+                if kind == 'run':
+                    merged.calls.extend(x.calls)
+                    merged.lanes.extend(x.lanes)
+            prog = prog[:k] + [t for t in tail if t[0] == 'wait'] + [('run', merged)]
         return prog
 
     # ---- execution ------------------------------------------------------------------------------------------------------------
@@ -137,8 +153,18 @@ class TrainStep:
                         elif kind == 'allreduce':
                             self._allreduce(x, async_op=False)
             return [('run_graph', g)], {0: g}
+        # Only the FIRST segment (schedules, forward, the backward up to the first bucket: ~1.1 of the step's 1.6 ms) is replayed as
+        # a graph; the segments behind a collective are launched kernel by kernel.  A graph launch costs ~30 us on the GPU before
+        # its first kernel starts (rocprofv3 timeline of the one-rank RCCL step, tools/dp_timeline.py: 30 + 29 + 39 us at the three
+        # later segment starts), while the host, a millisecond ahead of the GPU at that point, has the eager launches queued long
+        # before they can run.  T3D_DP_GRAPH_ALL=1: every segment as a graph (the earlier behaviour).
+        first_only = self.dist and os.environ.get('T3D_DP_GRAPH_ALL', '0') != '1'
+        seen = False
         for k, (kind, x) in enumerate(prog):
             if kind == 'run':
+                if seen and first_only:
+                    continue
+                seen = True
                 g = torch.cuda.CUDAGraph()
                 # thread_local: calls of other threads (the RCCL watchdog) during capture must not invalidate it
                 with torch.cuda.graph(g, stream=s, capture_error_mode='thread_local'):
