@@ -19,6 +19,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the host driver of this pool supports dmabuf IPC only: without it RCCL's buffer exchange between the ranks fails with
+# hipIpcGetMemHandle: invalid argument.  Must be in the environment before the HIP runtime starts.
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 import numpy as np   # noqa: E402
 import torch         # noqa: E402

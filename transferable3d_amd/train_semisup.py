@@ -158,6 +158,7 @@ def train(FLAGS, rt=None, log=print):
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC (RCCL between the ranks of one node)
         on_gpu = torch.cuda.is_available() and rt is None
         if on_gpu:
             torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
