@@ -112,6 +112,10 @@ def gemm_work(name, a):
         if d.dtype == 1 and w.a.dtype == 1 and ((K in (64, 128) and N in (64, 128)) or (K, N) in ((256, 128), (128, 256))) and w.rows_per_split % 128 == 0 and \
                 M // w.rows_per_split >= min(256, M // 128) and os.environ.get('T3D_BWD1', '1') != '0':
             return 'k_pointmlp_bwd1<%d,%d,%d>' % (K, N, 64 if 256 in (K, N) else 128), df + wf, by      # one-pass form
+        if d.dtype == 0 and w.a.dtype == 0 and K in (64, 128) and N in (64, 128) and w.rows_per_split % 128 == 0 and \
+                M // w.rows_per_split >= min(256, M // 128) and os.environ.get('T3D_BWD1F', '1') != '0' and \
+                (M // 128 < 256 or w.rows_per_split >= 256 or os.environ.get('T3D_BWD1F') == '2'):
+            return 'k_pointmlp_bwd1f<%d,%d>' % (K, N), df + wf, by      # fp32 one-pass form (not taken at the headline size)
         return 'k_pointmlp_bwd<%s,%s>' % (dl[dl.index('<') + 1:-1], wl[wl.index('<') + 1:-1]), df + wf, by
     if name == 't3d_pointmlp_dgrad_gram':
         # (the sparse arg-max rows S behind add_live are read only where a row received a hit -- a data-dependent few percent of
