@@ -178,30 +178,27 @@ def profile_kernels(plans, steps, repeat=4):
         for ci, (name, arg, e0, e1) in enumerate(evs):
             dt = e0.elapsed_time(e1) * 1e-3 / repeat
             CALLS.setdefault(ci, [name, arg, 0.0])[2] += dt / steps
-            label, flops, nbytes = (gemm_work(name, arg) if name.startswith(('t3d_pointmlp', 't3d_pool_bwd_stage')) and
-                                    name != 't3d_pointmlp_dgrad_narrow' else (name, 0.0, 0.0))
+            # `_r`: the same GEMM with small launches of an independent chain riding in it (schedule.py); kernel name k_..._r<...>
+            base = name[:-2] if name.endswith('_r') else name
+            label, flops, nbytes = (gemm_work(base, arg) if base.startswith(('t3d_pointmlp', 't3d_pool_bwd_stage')) and
+                                    base != 't3d_pointmlp_dgrad_narrow' else (name, 0.0, 0.0))
+            if base != name and '<' in label and label.split('<')[0] in ('k_pointmlp_fwd', 'k_pointmlp_bwd', 'k_pointmlp_wgrad',
+                                                                        'k_pool_bwd_stage1', 'k_pool_bwd_stage2'):
+                label = label.replace('<', '_r<', 1)
             d = acc.setdefault(label, [0.0, 0, 0.0, 0.0])
             d[0] += dt
             d[1] += 1
             d[2] += flops
             d[3] += nbytes
             if flops:
-                a0 = (arg[1] if name == 't3d_pool_bwd_stage2' else arg[0]) if isinstance(arg, tuple) else arg
+                a0 = (arg[1] if base == 't3d_pool_bwd_stage2' else arg[0]) if isinstance(arg, tuple) else arg
                 dd = detail.setdefault('%s M%d K%d N%d' % (label, a0.M, a0.K, getattr(a0, 'N', a0.K)), [0.0, 0, flops, nbytes])
                 dd[0] += dt
                 dd[1] += 1
     return acc, detail
 
 
-def lib_source_hash():
-    """sha256 (16 hex digits) over the HIP sources + the ABI header: identifies the build a PMC summary was taken with."""
-    import hashlib
-    h = hashlib.sha256()
-    csrc = os.path.join(ROOT, 'transferable3d_amd', 'csrc')
-    for f in sorted(os.listdir(csrc)) + [os.path.join(ROOT, 'include', 't3d.h')]:
-        with open(f if os.path.isabs(f) else os.path.join(csrc, f), 'rb') as fh:
-            h.update(fh.read())
-    return h.hexdigest()[:16]
+from transferable3d_amd.build import lib_source_hash   # noqa: E402  (shared with tools/pmc_traffic.py)
 
 
 def pmc_traffic(label, args):
@@ -236,7 +233,7 @@ def cpu_model():
 
 def cpu_baseline(args, batch):
     """The oracle's torch-CPU fp32 restatement of the identical step (fwd + bwd + TF-form Adam) on this host's cores: 3 warm-up +
-    `--cpu_steps` (>= 5) timed steps on `--cpu_threads` threads, then one warm-up + one timed step on ONE thread.  TF1 itself
+    `--cpu_steps` (>= 5) timed steps on `--cpu_threads` threads, then one warm-up + three timed steps (median) on ONE thread.  TF1 itself
     cannot run, so kind = "port".  Baseline, not target."""
     from oracle import ref_torch as R
     C = args.num_channel
@@ -263,12 +260,12 @@ def cpu_baseline(args, batch):
 
     threads = min(os.cpu_count(), args.cpu_threads)
     t_multi = timed(threads, 3, max(args.cpu_steps, 5))
-    t_one = timed(1, 1, 1) if args.cpu_one_thread else None
+    t_one = timed(1, 1, 3) if args.cpu_one_thread else None      # median of 3 timed steps
     return {'value': args.batch_size / t_multi, 'unit': 'frustums/s', 'cores': threads, 'kind': 'port',
             'host_cpu': cpu_model(), 'host_logical_cpus': os.cpu_count(),
             'one_thread_value': (args.batch_size / t_one) if t_one else None,
             'sample': '%d timed steps (median; after 3 warm-up) of the same B=%d N=%d C=%d fp32 fwd+bwd+Adam step on %d threads, '
-                      'and 1 timed step (after 1 warm-up) on one thread; torch-CPU restatement of the reference graph '
+                      'and 3 timed steps (median; after 1 warm-up) on one thread; torch-CPU restatement of the reference graph '
                       '(oracle/ref_torch.py; TF1 not installable)' % (max(args.cpu_steps, 5), args.batch_size, args.num_point, C, threads)}
 
 
@@ -353,7 +350,10 @@ def main():
     cpu = None
     if rank == 0 and args.profile_steps > 0:
         # per-kernel timing for the roofline object (eager, per-launch events on the launch stream)
-        acc, detail = profile_kernels([g.pre, g.fwd, g.bwd, g.opt], args.profile_steps)
+        # the launches of the program that was timed (the scheduled one: step.TrainStep._overlap), not of the plans it was made from
+        prog = trainstep.cache[True]['prog'] if True in trainstep.cache else []
+        plans = [x for kind, x in prog if kind == 'run'] if (prog and all(kind == 'run' for kind, _ in prog)) else [g.pre, g.fwd, g.bwd, g.opt]
+        acc, detail = profile_kernels(plans, args.profile_steps)
         total = sum(v[0] for v in acc.values())
         dom = max((k for k in acc if k.startswith(('k_pointmlp', 'k_pool_bwd_stage'))), key=lambda k: acc[k][0])
         tsec, n, fl, nby = acc[dom]
@@ -421,7 +421,10 @@ def main():
                'config': {'workload': '%s, B=%d N=%d C=%d %s per GPU, dp%d' % (desc, B, N, C, 'fp32' if args.dtype == 'f32' else 'bf16', world),
                           'global_batch': B * world, 'hipgraph': use_graph, 'graph_segments_per_step': trainstep.n_graph_segments(),
                           'gradient_buckets': len(g.buckets) if trainstep.dist else 0,
-                          'launches_per_step': len(g.pre) + len(g.fwd) + len(g.bwd) + len(g.opt), 'final_loss': loss},
+                          'launches_per_step': (sum(len(x) for kind, x in trainstep.cache[True]['prog'] if kind == 'run')
+                                                if True in trainstep.cache else len(g.pre) + len(g.fwd) + len(g.bwd) + len(g.opt)),
+                          'schedule': ({k: v for k, v in trainstep.schedule_report.items() if k != 'lines'}
+                                       if trainstep.schedule_report else None), 'final_loss': loss},
                'roofline': roofline, 'cpu_baseline': cpu}
     if dist is not None:
         dist.barrier()                        # rank 0 profiled its kernels meanwhile: every rank leaves together

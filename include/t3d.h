@@ -889,17 +889,59 @@ int t3d_dropout_mask(float* mask, int64_t n, float keep_prob, uint32_t seed, con
  * a and b must not depend on each other (the box / T-Net backward and the segmentation-net backward: semisup_models.py:150-151).
  * Same arguments, same results (bit for bit) as the two stand-alone calls; what is saved is one kernel boundary (~3-5 us).
  * Kinds: t3d_bn_bwd_finalize (up to 512 row tiles), t3d_fc_bwd, t3d_fc_dinput, t3d_dy_colsum. */
-enum { T3D_SMALL_BN_BWD_FINALIZE = 1, T3D_SMALL_FC_BWD = 2, T3D_SMALL_FC_DINPUT = 3, T3D_SMALL_DY_COLSUM = 4 };
+enum { T3D_SMALL_BN_BWD_FINALIZE = 1, T3D_SMALL_FC_BWD = 2, T3D_SMALL_FC_DINPUT = 3, T3D_SMALL_DY_COLSUM = 4,
+       T3D_SMALL_BN_FWD_FINALIZE = 5, T3D_SMALL_FC_FWD = 6 };      /* 5, 6: rider sets only */
 typedef struct {
   int kind;
+  int depends;            /* rider sets: 1 = reads what the PREVIOUS op of its set wrote (a barrier among the set's workgroups goes in
+                             front of it); 0 = independent of it.  Ignored by t3d_small_pair. */
   union {
     t3d_bn_bwd_finalize_args bn_bwd;
     t3d_fc_bwd_args fc_bwd;
     t3d_fc_dinput_args fc_dinput;
     t3d_dy_colsum_args dy_colsum;
+    t3d_bn_fwd_finalize_args bn_fwd;
+    t3d_fc_fwd_args fc_fwd;
   } u;
 } t3d_small_op;
 int t3d_small_pair(const t3d_small_op* a, const t3d_small_op* b, t3d_stream_t stream);
+
+/* ---- riders: small launches of one chain inside the GEMM launches of an independent chain ---------------------------------------
+ * The reference runs its graph op by op (sess.run, train_semisup.py:405-411) and TensorFlow's executor overlaps whatever is
+ * independent.  Here the independence that matters is one: nothing the T-Net / box net compute (forward, loss, backward) reaches the
+ * segmentation net's backward -- `mask` is a hard comparison (semisup_models.py:150-151).  A rider SET is a run of small ops
+ * (batch-norm finalizers, FC heads and their backward, column sums: the kinds above) executed in order by the first `n_wg`
+ * 256-thread workgroups of a GEMM launch that does not depend on them and that they do not depend on; the GEMM's own tiles are the
+ * workgroups behind.  An op with `depends` waits for its predecessor behind a barrier among the rider workgroups (agent-scope
+ * release / acquire; the GEMM's workgroups never wait).  Results are bit-identical to the stand-alone launches of the same ops.
+ *   ops        the set, in chain order (passed to the kernel by value: at most T3D_RIDER_MAX_OPS of them)
+ *   n_wg       rider workgroups (<= 32) and
+ *   lds_bytes  dynamic LDS the rider bodies need: both filled in by t3d_riders_plan
+ *   sync       DEVICE, 2 * T3D_RIDER_MAX_OPS + 2 zero-initialised 32-bit words owned by this set (self-resetting: graph replays need
+ *              no memset); the last but one word is set to 1 if a barrier ever gave up waiting (poisoned state; results invalid)
+ * The `_r` launchers take `riders == NULL` (then they ARE the plain entry points).  Where the kernel variant a launch selects has no
+ * rider form (bf16 kernels, the one-pass backward, the activation-resident pooled forward) the set runs as its own launch in front
+ * of the GEMM (t3d_run_riders) -- same results, nothing hidden. */
+#define T3D_RIDER_MAX_OPS 10
+typedef struct {
+  t3d_small_op ops[T3D_RIDER_MAX_OPS];
+  int n_ops;
+  int n_wg;
+  int lds_bytes;
+  unsigned* sync;
+} t3d_rider_set;
+/* validates the set's ops (kinds, shapes that can ride: B <= 32 for the FC ops, <= 512 row tiles for the finalizers) and fills in n_wg and
+ * lds_bytes; T3D_ERR_ARG / T3D_ERR_SHAPE if one of them cannot ride */
+int t3d_riders_plan(t3d_rider_set* riders);
+int t3d_run_riders(const t3d_rider_set* riders, t3d_stream_t stream);      /* the set as a launch of its own */
+int t3d_pointmlp_fwd_r(const t3d_pointmlp_fwd_args* args, const t3d_rider_set* riders, t3d_stream_t stream);
+int t3d_pointmlp_wgrad_r(const t3d_pointmlp_wgrad_args* args, const t3d_rider_set* riders, t3d_stream_t stream);
+int t3d_pointmlp_bwd_r(const t3d_pointmlp_dgrad_args* dgrad, const t3d_pointmlp_wgrad_args* wgrad, const t3d_rider_set* riders,
+                       t3d_stream_t stream);
+int t3d_pool_bwd_stage1_r(const t3d_pointmlp_gram_args* gram, const t3d_act_colsum_args* colsum, const t3d_pool_bwd_prep_args* prep,
+                          const t3d_rider_set* riders, t3d_stream_t stream);
+int t3d_pool_bwd_stage2_r(const t3d_pool_wgrad_finish_args* finish, const t3d_pointmlp_dgrad_gram_args* dgrad,
+                          const t3d_rider_set* riders, t3d_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1223,6 +1223,54 @@ class FakeLib:
                 return rc
         return 0
 
+    # ---- riders (t3d.h: small ops of one chain inside a GEMM launch of an independent chain): by specification the stand-alone
+    # calls of the set's ops in order, then the GEMM -- in either order, the two do not depend on each other
+    _RIDER = {1: ('t3d_bn_bwd_finalize', 'bn_bwd'), 2: ('t3d_fc_bwd', 'fc_bwd'), 3: ('t3d_fc_dinput', 'fc_dinput'),
+              4: ('t3d_dy_colsum', 'dy_colsum'), 5: ('t3d_bn_fwd_finalize', 'bn_fwd'), 6: ('t3d_fc_fwd', 'fc_fwd')}
+
+    def t3d_riders_plan(self, r):
+        rs = _struct(r)
+        if rs.n_ops <= 0 or rs.n_ops > abi.RIDER_MAX_OPS:
+            return -1
+        for k in range(rs.n_ops):
+            o = rs.ops[k]
+            if o.kind not in self._RIDER:
+                return -1
+            u = getattr(o.u, self._RIDER[o.kind][1])
+            if o.kind in (2, 3, 6) and u.B > 32:
+                return -2
+            if (o.kind == 5 and u.n_tiles > 512) or (o.kind == 1 and u.psum_dz and u.n_tiles > 512):
+                return -2
+        rs.n_wg, rs.lds_bytes = 1, 0
+        return 0
+
+    def t3d_run_riders(self, r, stream):
+        if not r:
+            return 0
+        rs = _struct(r)
+        for k in range(rs.n_ops):
+            o = rs.ops[k]
+            fn, field = self._RIDER[o.kind]
+            rc = getattr(self, fn)(C.byref(getattr(o.u, field)), stream)
+            if rc:
+                return rc
+        return 0
+
+    def t3d_pointmlp_fwd_r(self, a, r, stream):
+        return self.t3d_run_riders(r, stream) or self.t3d_pointmlp_fwd(a, stream)
+
+    def t3d_pointmlp_wgrad_r(self, a, r, stream):
+        return self.t3d_run_riders(r, stream) or self.t3d_pointmlp_wgrad(a, stream)
+
+    def t3d_pointmlp_bwd_r(self, d, w, r, stream):
+        return self.t3d_pointmlp_bwd(d, w, stream) or self.t3d_run_riders(r, stream)
+
+    def t3d_pool_bwd_stage1_r(self, g, c, q, r, stream):
+        return self.t3d_pool_bwd_stage1(g, c, q, stream) or self.t3d_run_riders(r, stream)
+
+    def t3d_pool_bwd_stage2_r(self, f, d, r, stream):
+        return self.t3d_run_riders(r, stream) or self.t3d_pool_bwd_stage2(f, d, stream)
+
     def t3d_anchor_reg_bwd(self, a, stream):
         p = _struct(a)
         B = p.B

@@ -1,0 +1,134 @@
+"""GPU: the scheduled step (transferable3d_amd/schedule.py -- small launches of the T-Net / box chain riding in the segmentation net's
+backward GEMM launches and vice versa, csrc/rider_dev.h) against the unscheduled one, bit for bit; a rider set with in-launch
+barriers between dependent ops, replayed many times under load, against the stand-alone launches."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from transferable3d_amd import abi
+from transferable3d_amd.abi import fptr
+
+pytestmark = pytest.mark.gpu
+
+
+def _steps(hip_lib, overlap, B, N, n_steps, workload='A'):
+    from transferable3d_amd import nets
+    from transferable3d_amd.engine import Runtime
+    from transferable3d_amd.step import build_training_step
+    from transferable3d_amd.synthetic import make_batch
+    keep = nets.OVERLAP
+    nets.OVERLAP = overlap
+    try:
+        g, model, step, loss = build_training_step(Runtime(lib=hip_lib), workload, B, N, 4, seed=4)
+        losses = []
+        for k in range(n_steps):
+            model.inputs.load(make_batch(B, N, 4, seed=21 + k))
+            step.run()
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        state = {k: v.clone() for k, v in (('params', g.vars.params[:g.vars.used]), ('state', g.vars.state[:g.vars.state_used]),
+                                          ('m', g.vars.adam_m[:g.vars.used]), ('v', g.vars.adam_v[:g.vars.used]))}
+        return losses, state, step
+    finally:
+        nets.OVERLAP = keep
+
+
+@pytest.mark.parametrize('B,N', [(32, 1024), (8, 256)])
+def test_scheduled_step_is_bit_identical_to_the_unscheduled_step(hip_lib, B, N):
+    """Five steps (one eager, the capture, three hipGraph replays) with a new batch each: losses, weights, moving statistics and Adam
+    moments of the scheduled program equal the plain one's bit for bit; riders were really hosted; no barrier ever timed out."""
+    l0, s0, st0 = _steps(hip_lib, False, B, N, 5)
+    l1, s1, st1 = _steps(hip_lib, True, B, N, 5)
+    rep = st1.schedule_report
+    assert st0.schedule_report is None and rep is not None
+    assert rep['hosted'] >= 5 and rep['rider_ops'] >= rep['hosted'], rep
+    assert st1._sets.timeouts() == 0
+    assert l0 == l1, (l0, l1)
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
+    print('schedule: %d launches hosted %d small ops, %d pairs, model %.0f -> %.0f us' %
+          (rep['hosted'], rep['rider_ops'], rep['pairs'], rep['serial_us'], rep['scheduled_us']))
+
+
+def _fc_chain(dev, B, dims, seed):
+    """A dependent chain of FC layers (batch-norm + ReLU) in -> h1 -> h2 ...: argument structs of the stand-alone launches."""
+    r = np.random.RandomState(seed)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    x = t(r.randn(B, dims[0]))
+    keep, ops, outs = [x], [], []
+    cur = x
+    for K, N in zip(dims[:-1], dims[1:]):
+        w, bias = t(r.randn(K, N) / np.sqrt(K)), t(0.1 * r.randn(N))
+        gamma, beta = t(1 + 0.1 * r.randn(N)), t(0.1 * r.randn(N))
+        mm, mv, mean, invstd = t(np.zeros(N)), t(np.ones(N)), t(np.zeros(N)), t(np.zeros(N))
+        y, out, decay = t(np.zeros((B, N))), t(np.zeros((B, N))), t([0.9])
+        a = abi.FcFwdArgs()
+        a.in_, a.ld_in, a.K, a.w, a.bias = fptr(cur), K, K, fptr(w), fptr(bias)
+        a.gamma, a.beta, a.moving_mean, a.moving_var, a.decay = fptr(gamma), fptr(beta), fptr(mm), fptr(mv), fptr(decay)
+        a.eps, a.is_training, a.unbiased_ema, a.act = 1e-3, 1, 1, abi.ACT_RELU
+        a.y, a.mean, a.invstd, a.out, a.ld_out, a.B, a.N = fptr(y), fptr(mean), fptr(invstd), fptr(out), N, B, N
+        keep += [w, bias, gamma, beta, mm, mv, mean, invstd, y, out, decay]
+        ops.append(a)
+        outs.append((out, mm, mv))
+        cur = out
+    return ops, outs, keep
+
+
+def test_rider_set_with_barriers_equals_the_separate_launches_under_load(hip_lib):
+    """FC chain 256 -> 512 -> 512 -> 256 -> 64 (every op reads what the previous one wrote, through another workgroup's stores): as ONE
+    rider set -- alone (t3d_run_riders) and inside a forward GEMM launch that fills the chip -- 40 times each, against the four
+    stand-alone launches.  Outputs and moving statistics bit for bit; the consumer workgroups' L1 holds the previous repetition's
+    lines when the next one starts (the stale-read case of cdna_hip_programming.md Guideline 16)."""
+    from transferable3d_amd import schedule
+    from transferable3d_amd.engine import Runtime
+    dev = torch.device('cuda')
+    rt = Runtime(lib=hip_lib)
+    B, dims = 32, (256, 512, 512, 256, 64)
+    s = rt.stream()
+
+    def fresh(seed):
+        return _fc_chain(dev, B, dims, seed)
+
+    # reference: stand-alone launches, one repetition per seed
+    def reference(seed, reps):
+        ops, outs, keep = fresh(seed)
+        for _ in range(reps):
+            for a in ops:
+                abi.check(hip_lib.t3d_fc_fwd(C.byref(a), s), 'fc_fwd')
+        torch.cuda.synchronize()
+        return [tuple(t.clone() for t in o) for o in outs]
+
+    # a host GEMM: 32768 x 128 x 128 forward (512 workgroups: exactly the chip's resident slots)
+    M, K, N = 32768, 128, 128
+    r = np.random.RandomState(5)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    xg, wg = t(r.randn(M, K)), t(r.randn(K, N) / 11.0)
+    yg, ps, pq = t(np.zeros((M, N))), t(np.zeros((M // 128, N))), t(np.zeros((M // 128, N)))
+    fa = abi.PointMlpFwdArgs()
+    fa.a = abi.ActSrc(fptr(xg), K, 0, None, None, 0, None, 0, abi.F32)
+    fa.w, fa.y, fa.psum, fa.psumsq, fa.M, fa.K, fa.N, fa.rows_per_frustum, fa.dtype = fptr(wg), fptr(yg), fptr(ps), fptr(pq), M, K, N, 1024, abi.F32
+    abi.check(hip_lib.t3d_pointmlp_fwd(C.byref(fa), s), 'fwd')
+    torch.cuda.synchronize()
+    y_ref = yg.clone()
+
+    for mode in ('alone', 'hosted'):
+        reps = 40
+        ref = reference(7, reps)
+        ops, outs, keep = fresh(7)
+        sets = schedule.RiderSets(rt)
+        rs = sets.make([('t3d_fc_fwd', a) for a in ops])
+        assert rs.n_ops == 4 and 1 <= rs.n_wg <= 32
+        yg.zero_()
+        for _ in range(reps):
+            if mode == 'alone':
+                abi.check(hip_lib.t3d_run_riders(C.byref(rs), s), 'run_riders')
+            else:
+                abi.check(hip_lib.t3d_pointmlp_fwd_r(C.byref(fa), C.byref(rs), s), 'fwd_r')
+        torch.cuda.synchronize()
+        assert sets.timeouts() == 0
+        for (o, mm, mv), (ro, rmm, rmv) in zip(outs, ref):
+            assert torch.equal(o, ro) and torch.equal(mm, rmm) and torch.equal(mv, rmv), mode
+        if mode == 'hosted':
+            assert torch.equal(yg, y_ref)

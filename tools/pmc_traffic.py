@@ -22,14 +22,8 @@ csv.field_size_limit(1 << 30)
 
 def lib_source_hash():
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    import importlib.util
-    spec = importlib.util.spec_from_file_location('t3d_bench', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py'))
-    src = open(spec.origin).read()
-    ns = {'os': os, 'ROOT': os.path.dirname(spec.origin)}
-    start = src.index('def lib_source_hash():')
-    end = src.index('def pmc_traffic(')
-    exec(src[start:end], ns)
-    return ns['lib_source_hash']()
+    from transferable3d_amd.build import lib_source_hash as h
+    return h()
 
 
 def label(kernel_name):
@@ -91,7 +85,7 @@ def main():
     ap.add_argument('--num_point', type=int, default=1024)
     ap.add_argument('--num_channel', type=int, default=4)
     ap.add_argument('--dtype', default='f32')
-    a = ap.parse_args()
+    a, _unknown = ap.parse_known_args()      # profile_round.sh forwards the bench flags; only the workload keys matter here
     fe, wr = collect(a.fetch_dir, 'FETCH_SIZE'), collect(a.write_dir, 'WRITE_SIZE')
     out = {'_doc': 'per-launch HBM traffic from rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); '
                    'bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts 128-B requests at 64 B)', '_note': a.note,

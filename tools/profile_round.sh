@@ -5,8 +5,8 @@
 # Pass 1: kernel trace + stats of the bench command.  Passes 2/3: HBM traffic counters, one PMC pass each
 # (FETCH_SIZE costs 3 of the 4 TCC slots, WRITE_SIZE 2 -- MI355X_MICROARCH.md "rocprofv3 PMC slots"), no other trace domain.
 # Pass 4: MFMA-busy cycles + clock.
-tag=${1:-r02}
-shift
+tag=${1:-r03}
+[ $# -gt 0 ] && shift
 flags="$@"
 root=$(pwd)
 out=$root/gpurun_out/$tag
@@ -22,5 +22,6 @@ cd $root
 python3 tools/pmc_traffic.py $out/pmc_fetch $out/pmc_write -o $out/pmc_traffic.json $(echo "$flags" | sed 's/--steps [0-9]*//; s/--warmup [0-9]*//') > $out/pmc_traffic.txt 2>&1
 python3 tools/pmc_mfma.py $out/pmc_mfma -o $out/pmc_mfma.json > $out/pmc_mfma.txt 2>&1
 cp $(find $out/trace -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv 2>/dev/null
-rm -rf $out/trace $out/pmc_fetch $out/pmc_write $out/pmc_mfma      # raw traces are large; the summaries stay
+# raw traces are large; they go only once every summary exists
+[ -s $out/pmc_traffic.json ] && [ -s $out/pmc_mfma.json ] && [ -s $out/kernel_stats.csv ] && rm -rf $out/trace $out/pmc_fetch $out/pmc_write $out/pmc_mfma
 ls -la $out

@@ -1,7 +1,7 @@
 #!/bin/bash
 # diagnostic: the fp32 one-pass backward -- kernel tests, per-shape timings against the split form, phase trace, step A/B on one box
+cd "$(dirname "$0")/.." || exit 1
 mkdir -p gpurun_out/bwd1f
-cd "$(dirname "$0")/.."
 timeout 600 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "one_pass or fused_bwd" > gpurun_out/bwd1f/tests.log 2>&1
 tail -3 gpurun_out/bwd1f/tests.log
 for kn in "128 128" "128 64" "64 128" "64 64"; do

@@ -1,7 +1,7 @@
 #!/bin/bash
 # diagnostic: the many-tile finalizers -- tests, then the config-4 step with the block shapes of round 2 (T3D_FIN_WIDE=0) and the wide ones
+cd "$(dirname "$0")/.." || exit 1
 mkdir -p gpurun_out/fin
-cd "$(dirname "$0")/.."
 timeout 600 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "finaliz" > gpurun_out/fin/tests.log 2>&1; tail -3 gpurun_out/fin/tests.log
 for i in 1 2; do
   for v in 0 1024; do

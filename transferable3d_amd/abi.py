@@ -174,7 +174,9 @@ class SegHeadArgs(C.Structure):
                 ('dtype', i32), ('dsoft', F)]
 
 
-SMALL_KIND = {'t3d_bn_bwd_finalize': 1, 't3d_fc_bwd': 2, 't3d_fc_dinput': 3, 't3d_dy_colsum': 4}      # t3d.h T3D_SMALL_*
+SMALL_KIND = {'t3d_bn_bwd_finalize': 1, 't3d_fc_bwd': 2, 't3d_fc_dinput': 3, 't3d_dy_colsum': 4}      # t3d.h T3D_SMALL_* (t3d_small_pair)
+RIDER_KIND = dict(SMALL_KIND, t3d_bn_fwd_finalize=5, t3d_fc_fwd=6)                                      # kinds a rider set takes
+RIDER_FIELD = {1: 'bn_bwd', 2: 'fc_bwd', 3: 'fc_dinput', 4: 'dy_colsum', 5: 'bn_fwd', 6: 'fc_fwd'}
 
 
 class WeakLossArgs(C.Structure):
@@ -252,11 +254,20 @@ VP = C.c_void_p
 # name -> argtypes.  Struct entry points take (const args*, stream).
 
 class SmallOpU(C.Union):
-    _fields_ = [('bn_bwd', BnBwdFinalizeArgs), ('fc_bwd', FcBwdArgs), ('fc_dinput', FcDinputArgs), ('dy_colsum', DyColsumArgs)]
+    _fields_ = [('bn_bwd', BnBwdFinalizeArgs), ('fc_bwd', FcBwdArgs), ('fc_dinput', FcDinputArgs), ('dy_colsum', DyColsumArgs),
+                ('bn_fwd', BnFwdFinalizeArgs), ('fc_fwd', FcFwdArgs)]
 
 
 class SmallOp(C.Structure):
-    _fields_ = [('kind', i32), ('u', SmallOpU)]
+    _fields_ = [('kind', i32), ('depends', i32), ('u', SmallOpU)]
+
+
+RIDER_MAX_OPS = 10            # t3d.h T3D_RIDER_MAX_OPS
+
+
+class RiderSet(C.Structure):
+    _fields_ = [('ops', SmallOp * RIDER_MAX_OPS), ('n_ops', i32), ('n_wg', i32), ('lds_bytes', i32), ('sync', C.POINTER(C.c_uint32))]
+
 
 ENTRY_POINTS = {
     't3d_abi_version': [],
@@ -270,6 +281,13 @@ ENTRY_POINTS = {
     't3d_bwd_plan': [i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)],
     't3d_weak_loss': [C.POINTER(WeakLossArgs), VP],
     't3d_small_pair': [C.POINTER(SmallOp), C.POINTER(SmallOp), VP],
+    't3d_riders_plan': [C.POINTER(RiderSet)],
+    't3d_run_riders': [C.POINTER(RiderSet), VP],
+    't3d_pointmlp_fwd_r': [C.POINTER(PointMlpFwdArgs), C.POINTER(RiderSet), VP],
+    't3d_pointmlp_wgrad_r': [C.POINTER(PointMlpWgradArgs), C.POINTER(RiderSet), VP],
+    't3d_pointmlp_bwd_r': [C.POINTER(PointMlpDgradArgs), C.POINTER(PointMlpWgradArgs), C.POINTER(RiderSet), VP],
+    't3d_pool_bwd_stage1_r': [C.POINTER(PointMlpGramArgs), C.POINTER(ActColsumArgs), C.POINTER(PoolBwdPrepArgs), C.POINTER(RiderSet), VP],
+    't3d_pool_bwd_stage2_r': [C.POINTER(PoolWgradFinishArgs), C.POINTER(PointMlpDgradGramArgs), C.POINTER(RiderSet), VP],
     't3d_gram_plan': [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)],
     't3d_bn_bwd_finalize': [C.POINTER(BnBwdFinalizeArgs), VP],
     't3d_dy_colsum': [C.POINTER(DyColsumArgs), VP],

@@ -10,6 +10,19 @@ LIB_PATH = os.path.join(HERE, 'libt3d.so')
 SOURCES = ['pointmlp.hip', 'bn_optim.hip', 'fc.hip', 'heads.hip', 'boxpc.hip', 'poolbwd.hip', 'data.hip', 'weak.hip', 'pair.hip']
 
 
+def lib_source_hash():
+    """sha256 (16 hex digits) over the HIP sources + the ABI header: identifies the build a PMC summary was taken with
+    (bench.py `traffic_summary_predates_this_build`, tools/pmc_traffic.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        with open(os.path.join(CSRC, f), 'rb') as fh:
+            h.update(fh.read())
+    with open(os.path.join(INCLUDE, 't3d.h'), 'rb') as fh:
+        h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _stale():
     if not os.path.exists(LIB_PATH):
         return True

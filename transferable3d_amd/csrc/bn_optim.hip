@@ -8,95 +8,11 @@
 
 namespace {
 
-// pooled[b,c], argidx, ysel from the per-tile max/min partials (shared by k_pool_finalize and the fused finalize)
-__device__ __forceinline__ void pool_pick_impl(const float* pmax, const float* pmin, const int32_t* pamax, const int32_t* pamin,
-                                               int tiles_per_frustum, int N, int b, int c, float sc, float sh, float* pooled,
-                                               int ld_pooled, int32_t* argidx, float* ysel) {
-  const bool use_max = sc >= 0.f;
-  float best = use_max ? -INFINITY : INFINITY;
-  int arg = -1;
-  // only the side the sign of the scale selects is read; eight tiles' loads are in flight together (clamped, then masked)
-  const float* pv = use_max ? pmax : pmin;
-  const int32_t* pa = use_max ? pamax : pamin;
-  for (int t0 = 0; t0 < tiles_per_frustum; t0 += 8) {
-    float v[8];
-    int a[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const size_t o = (size_t)(b * tiles_per_frustum + min(t0 + u, tiles_per_frustum - 1)) * N + c;
-      v[u] = pv[o];
-      a[u] = pa[o];
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const bool take = (t0 + u < tiles_per_frustum) && a[u] >= 0 && (arg < 0 || (use_max ? v[u] > best : v[u] < best));
-      best = take ? v[u] : best;
-      arg = take ? a[u] : arg;
-    }
-  }
-  float out = 0.f;
-  if (arg >= 0) out = fmaxf(fmaf(best, sc, sh), 0.f);
-  const bool live = out > 0.f;
-  const size_t i = (size_t)b * N + c;
-  pooled[(size_t)b * ld_pooled + c] = out;
-  argidx[i] = live ? arg : -1;
-  ysel[i] = live ? best : 0.f;
-}
-__device__ __forceinline__ void pool_pick(const t3d_bn_fwd_finalize_args& p, int b, int c, float sc, float sh) {
-  pool_pick_impl(p.pool_pmax, p.pool_pmin, p.pool_pamax, p.pool_pamin, p.pool_tiles_per_frustum, p.N, b, c, sc, sh, p.pooled,
-                 p.ld_pooled, p.argidx, p.ysel);
-}
-
 template <int GR, int CH = FC_CH>
 __global__ __launch_bounds__(GR * CH) void k_bn_fwd_finalize(const t3d_bn_fwd_finalize_args p) {
   __shared__ double red[GR][CH];
-  const int cl = threadIdx.x & (CH - 1), grp = threadIdx.x / CH;
-  const int c = blockIdx.x * CH + cl;
-  const bool ok = c < p.N;
-  if (p.is_training) {
-    // parameters first: their latency hides under the tile reduction instead of following it
-    const int cc = ok ? c : 0;
-    const float gam = p.gamma[cc], bet = p.beta[cc], mm = p.moving_mean[cc], mv = p.moving_var[cc], dec = p.decay[0];
-    const float* const src[2] = {p.psum, p.psumsq};
-    double acc[2];
-    tile_sums<2, GR, (GR > 64 ? 8 : 16)>(src, p.n_tiles, p.N, c, grp, ok, acc);
-    const double s = group_reduce<GR, CH>(acc[0], red, grp, cl);
-    const double ss = group_reduce<GR, CH>(acc[1], red, grp, cl);
-    if (grp == 0 && ok) {
-      const double n = (double)p.count;
-      const double mean = s / n;
-      double var = ss / n - mean * mean;
-      if (var < 0.0) var = 0.0;
-      const double invstd = 1.0 / sqrt(var + (double)p.eps);
-      const double sc = (double)gam * invstd;
-      p.scale[c] = (float)sc;
-      p.shift[c] = (float)((double)bet - mean * sc);
-      p.mean[c] = (float)mean;
-      p.invstd[c] = (float)invstd;
-      const double d = (double)dec;
-      const double var_ema = p.unbiased_ema ? var * (n / (n > 1.0 ? n - 1.0 : 1.0)) : var;
-      p.moving_mean[c] = (float)((double)mm * d + mean * (1.0 - d));
-      p.moving_var[c] = (float)((double)mv * d + var_ema * (1.0 - d));
-    }
-  } else if (grp == 0 && ok) {
-    const double invstd = 1.0 / sqrt((double)p.moving_var[c] + (double)p.eps);
-    const double sc = (double)p.gamma[c] * invstd;
-    p.scale[c] = (float)sc;
-    p.shift[c] = (float)((double)p.beta[c] - (double)p.moving_mean[c] * sc);
-    p.mean[c] = p.moving_mean[c];
-    p.invstd[c] = (float)invstd;
-  }
-  // optional K3: the max-pool pick of the same 16 channels (scale/shift handed over through LDS, not through memory)
-  if (p.pool_pmax != nullptr) {
-    __shared__ float s_sc[CH], s_sh[CH];
-    __syncthreads();
-    if (grp == 0 && ok) { s_sc[cl] = p.scale[c]; s_sh[cl] = p.shift[c]; }     // this thread's own stores: visible to itself
-    __syncthreads();
-    if (ok) {
-      const float sc = s_sc[cl], sh = s_sh[cl];
-      for (int b = grp; b < p.pool_B; b += GR) pool_pick(p, b, c, sc, sh);
-    }
-  }
+  __shared__ float s_scsh[2 * CH];
+  bn_fwd_finalize_body<GR, CH>(p, red, s_scsh, blockIdx.x);
 }
 
 // one thread per (frustum, channel)
@@ -110,7 +26,8 @@ __global__ __launch_bounds__(256) void k_pool_finalize(const t3d_pool_finalize_a
 
 template <int GR, int CH = FC_CH>
 __global__ __launch_bounds__(GR * CH) void k_bn_bwd_finalize(const t3d_bn_bwd_finalize_args p) {
-  bn_bwd_finalize_body<GR, CH>(p, blockIdx.x, threadIdx.x);
+  __shared__ double red[GR][CH];
+  bn_bwd_finalize_body<GR, CH>(p, red, blockIdx.x, threadIdx.x);
 }
 
 __global__ __launch_bounds__(256) void k_dy_colsum(const t3d_dy_colsum_args p) { dy_colsum_body(p, blockIdx.x, threadIdx.x); }

@@ -12,6 +12,9 @@ constexpr int NW = 8;        // waves per workgroup (the reduction dimension is 
 constexpr int NTH = NW * 64;
 constexpr int RG = NTH / 32; // row groups of the epilogue thread map
 constexpr int LDT = 33;      // padded row stride of the LDS tiles
+// The bodies are written for NW waves / NTH threads.  As RIDERS inside a 256-thread GEMM launch (rider_dev.h) they run with
+// NWP = 4 physical waves: every physical wave / thread then plays V = NW / NWP of the NW-wave form's waves / threads in turn
+// (virtual wave pw + NWP*v, virtual row group rgp + (NWP*2)*v), so every sum is formed in the same order: bit-identical results.
 
 #ifdef T3D_TRACE             // diagnostic builds: per-workgroup phase clock (tools/trace_fc.py)
 __device__ unsigned long long* t3d_trace_fc_ptr = nullptr;
@@ -58,10 +61,11 @@ struct RowSrc {              // [in | in2] row-concatenated input, B valid rows
 // are loaded before the first MFMA of a batch: these layers are pure latency (operands tiny, read once per step from
 // HBM/L2), so memory-level parallelism per wave is what matters -- with RBT = 1 a wave has its whole share of a
 // K <= 1024 reduction in flight at once.
-template <bool WT, int RBT>
+// (GIF_ = 0: the default batch; the 256-thread rider form asks for 8 -- it only changes how many loads are in flight, not the sums)
+template <bool WT, int RBT, int GIF_ = 0>
 __device__ __forceinline__ void wave_gemm(f32x16 (&acc)[RBT], const RowSrc& src, const float* __restrict__ w, int ldw,
                                           int Kred, int c0, int ncols, int wave, int lane) {
-  constexpr int GIF = RBT == 1 ? 16 : 4;
+  constexpr int GIF = GIF_ > 0 ? GIF_ : (RBT == 1 ? 16 : 4);
   const int l31 = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int rb = 0; rb < RBT; ++rb)
@@ -109,41 +113,52 @@ __device__ __forceinline__ void wave_gemm(f32x16 (&acc)[RBT], const RowSrc& src,
   }
 }
 
-// Sum the NW waves' tiles through LDS.  Afterwards thread t owns column (t & 31) and rows (t >> 5) + RG*j.
-template <int RBT>
-__device__ __forceinline__ void reduce_tiles(const f32x16 (&acc)[RBT], float* red, float (&val)[RBT * 32 / RG]) {
-  constexpr int RB = RBT, NVAL = RBT * 32 / RG;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+// Sum the NW waves' tiles through LDS.  Afterwards (virtual) thread t owns column (t & 31) and rows (t >> 5) + RG*j.
+template <int RBT, int NWP = NW>
+__device__ __forceinline__ void reduce_tiles(const f32x16 (&acc)[NW / NWP][RBT], float* red, float (&val)[NW / NWP][RBT * 32 / RG]) {
+  constexpr int RB = RBT, NVAL = RBT * 32 / RG, V = NW / NWP, RGP = NWP * 2;
+  const int tid = threadIdx.x, lane = tid & 63, pw = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int rows = RB * 32;
 #pragma unroll
-  for (int rb = 0; rb < RBT; ++rb)
-    {
+  for (int v = 0; v < V; ++v) {
+    const int wave = pw + NWP * v;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        red[(wave * rows + row) * LDT + l31] = acc[rb][r];
+    for (int rb = 0; rb < RBT; ++rb)
+      {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          red[(wave * rows + row) * LDT + l31] = acc[v][rb][r];
+        }
       }
-    }
+  }
   __syncthreads();
-  const int col = tid & 31, rg = tid >> 5;
+  const int col = tid & 31, rgp = tid >> 5;
 #pragma unroll
-  for (int j = 0; j < NVAL; ++j) {
-    const int row = rg + RG * j;
-    float s = 0.f;
-    if (row < rows) {
+  for (int v = 0; v < V; ++v) {
+    const int rg = rgp + RGP * v;
 #pragma unroll
-      for (int wv = 0; wv < NW; ++wv) s += red[(wv * rows + row) * LDT + col];
+    for (int j = 0; j < NVAL; ++j) {
+      const int row = rg + RG * j;
+      float s = 0.f;
+      if (row < rows) {
+#pragma unroll
+        for (int wv = 0; wv < NW; ++wv) s += red[(wv * rows + row) * LDT + col];
+      }
+      val[v][j] = s;
     }
-    val[j] = s;
   }
   __syncthreads();
 }
 
-// sum over all rows of the workgroup's per-thread partial, per column; result broadcast to every thread
-__device__ __forceinline__ float col_reduce(float part, float* red) {
-  const int tid = threadIdx.x, col = tid & 31, rg = tid >> 5;
+// sum over all rows of the workgroup's per-(virtual-)thread partials, per column; result broadcast to every thread
+template <int NWP = NW>
+__device__ __forceinline__ float col_reduce(const float (&part)[NW / NWP], float* red) {
+  constexpr int V = NW / NWP, RGP = NWP * 2;
+  const int tid = threadIdx.x, col = tid & 31, rgp = tid >> 5;
   __syncthreads();
-  red[rg * CB + col] = part;
+#pragma unroll
+  for (int v = 0; v < V; ++v) red[(rgp + RGP * v) * CB + col] = part[v];
   __syncthreads();
   float s = 0.f;
 #pragma unroll
@@ -168,52 +183,63 @@ __device__ __forceinline__ float act_bwd(float z, int act, float alpha) {
   }
 }
 
-template <int RBT>
+template <int RBT, int NWP = NW>
 __device__ __forceinline__ void fc_fwd_body(const t3d_fc_fwd_args& p, float* sm, const int bid) {
-  constexpr int RB = RBT, NVAL = RBT * 32 / RG;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int col = tid & 31, rg = tid >> 5;
+  constexpr int RB = RBT, NVAL = RBT * 32 / RG, V = NW / NWP, RGP = NWP * 2;
+  const int tid = threadIdx.x, lane = tid & 63, pw = tid >> 6;
+  const int col = tid & 31, rgp = tid >> 5;
   const int c0 = bid * CB, c = c0 + col;
   const int nvalid = min(CB, p.N - c0);
   const bool cok = c < p.N;
 
   FC_MARK(0);
-  float y[NVAL];
+  float y[V][NVAL];
   if (p.w != nullptr) {          // workgroup-uniform
-    f32x16 acc[RBT];
+    f32x16 acc[V][RBT];
     RowSrc src{p.in, p.ld_in, p.K, p.in2, p.ld_in2, p.K2, p.B};
-    wave_gemm<false, RBT>(acc, src, p.w, p.N, p.K + p.K2, c0, nvalid, wave, lane);
+#pragma unroll
+    for (int v = 0; v < V; ++v) { wave_gemm<false, RBT, (NWP < NW ? 8 : 0)>(acc[v], src, p.w, p.N, p.K + p.K2, c0, nvalid, pw + NWP * v, lane); if (V > 1) __builtin_amdgcn_sched_barrier(0); }
     FC_MARK(1);
-    reduce_tiles<RBT>(acc, sm, y);
+    reduce_tiles<RBT, NWP>(acc, sm, y);
   } else {                       // identity: a standalone batch-norm / dropout node on a [B,N] tensor
 #pragma unroll
-    for (int j = 0; j < NVAL; ++j) {
-      const int r = rg + RG * j;
-      y[j] = (r < p.B && cok) ? p.in[(size_t)r * p.ld_in + c] : 0.f;
-    }
+    for (int v = 0; v < V; ++v)
+#pragma unroll
+      for (int j = 0; j < NVAL; ++j) {
+        const int r = rgp + RGP * v + RG * j;
+        y[v][j] = (r < p.B && cok) ? p.in[(size_t)r * p.ld_in + c] : 0.f;
+      }
   }
   FC_MARK(2);
 
   const float bias = (cok && p.bias) ? p.bias[c] : 0.f;
-  float part = 0.f;
+  float part[V];
 #pragma unroll
-  for (int j = 0; j < NVAL; ++j) {
-    y[j] += bias;
-    if (rg + RG * j < p.B) part += y[j];
+  for (int v = 0; v < V; ++v) {
+    part[v] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NVAL; ++j) {
+      y[v][j] += bias;
+      if (rgp + RGP * v + RG * j < p.B) part[v] += y[v][j];
+    }
   }
   const bool bn = p.gamma != nullptr;
   float mean = 0.f, invstd = 1.f, g = 1.f, be = 0.f;
   if (bn) {
     if (cok) { g = p.gamma[c]; be = p.beta[c]; }
     if (p.is_training) {
-      mean = col_reduce(part, sm) / (float)p.B;
-      float vpart = 0.f;
+      mean = col_reduce<NWP>(part, sm) / (float)p.B;
+      float vpart[V];
 #pragma unroll
-      for (int j = 0; j < NVAL; ++j)
-        if (rg + RG * j < p.B) { const float d = y[j] - mean; vpart = fmaf(d, d, vpart); }
-      const float var = col_reduce(vpart, sm) / (float)p.B;
+      for (int v = 0; v < V; ++v) {
+        vpart[v] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NVAL; ++j)
+          if (rgp + RGP * v + RG * j < p.B) { const float d = y[v][j] - mean; vpart[v] = fmaf(d, d, vpart[v]); }
+      }
+      const float var = col_reduce<NWP>(vpart, sm) / (float)p.B;
       invstd = 1.0f / sqrtf(var + p.eps);
-      if (cok && rg == 0) {
+      if (cok && rgp == 0) {
         const float d = p.decay[0];
         const float var_ema = p.unbiased_ema ? var * ((float)p.B / (float)max(p.B - 1, 1)) : var;
         p.moving_mean[c] = p.moving_mean[c] * d + mean * (1.f - d);
@@ -223,63 +249,68 @@ __device__ __forceinline__ void fc_fwd_body(const t3d_fc_fwd_args& p, float* sm,
       mean = p.moving_mean[c];
       invstd = 1.0f / sqrtf(p.moving_var[c] + p.eps);
     }
-    if (cok && rg == 0) { p.mean[c] = mean; p.invstd[c] = invstd; }
+    if (cok && rgp == 0) { p.mean[c] = mean; p.invstd[c] = invstd; }
   }
   FC_MARK(3);
   if (!cok) return;
   const float inv_keep = p.drop_mask ? 1.0f / p.keep_prob : 1.f;
 #pragma unroll
-  for (int j = 0; j < NVAL; ++j) {
-    const int r = rg + RG * j;
-    if (r < p.B) {
-      const float yv = y[j];
-      if (p.y) p.y[(size_t)r * p.N + c] = yv;
-      float z = bn ? (yv - mean) * invstd * g + be : yv;
-      z = act_fwd(z, p.act, p.leaky_alpha);
-      if (p.drop_mask) z *= p.drop_mask[(size_t)r * p.N + c] * inv_keep;
-      if (p.add_in && c < p.add_n) z += p.add_in[(size_t)r * p.ld_add + c];
-      p.out[(size_t)r * p.ld_out + c] = z;
+  for (int v = 0; v < V; ++v)
+#pragma unroll
+    for (int j = 0; j < NVAL; ++j) {
+      const int r = rgp + RGP * v + RG * j;
+      if (r < p.B) {
+        const float yv = y[v][j];
+        if (p.y) p.y[(size_t)r * p.N + c] = yv;
+        float z = bn ? (yv - mean) * invstd * g + be : yv;
+        z = act_fwd(z, p.act, p.leaky_alpha);
+        if (p.drop_mask) z *= p.drop_mask[(size_t)r * p.N + c] * inv_keep;
+        if (p.add_in && c < p.add_n) z += p.add_in[(size_t)r * p.ld_add + c];
+        p.out[(size_t)r * p.ld_out + c] = z;
+      }
     }
-  }
   FC_MARK(4);
 }
 
-template <int RBT>
+template <int RBT, int NWP = NW>
 __device__ __forceinline__ void fc_bwd_body(const t3d_fc_bwd_args& p, float* sm, const int bid) {
-  constexpr int RB = RBT, NVAL = RBT * 32 / RG;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int col = tid & 31, rg = tid >> 5;
+  constexpr int RB = RBT, NVAL = RBT * 32 / RG, V = NW / NWP, RGP = NWP * 2;
+  const int tid = threadIdx.x, lane = tid & 63, pw = tid >> 6;
+  const int col = tid & 31, rgp = tid >> 5;
   const int c0 = bid * CB, c = c0 + col;
   const int nvalid = min(CB, p.N - c0);
   const bool cok = c < p.N;
 
   // the dW phase's input operand does not depend on anything computed here: request it first, it lands under (a)-(c)
-  constexpr int XKB = RBT == 1 ? 4 : 0;                  // 32-channel blocks per wave held in registers
+  constexpr int XKB = RBT == 1 ? (NWP < NW ? 2 : 4) : 0;   // 32-channel blocks per wave held in registers
   float xa[XKB > 0 ? XKB : 1][16];
   const int Kt = p.K + p.K2, nkb = (Kt + 31) / 32;
   if (XKB > 0 && p.dw != nullptr) {
     RowSrc xs{p.in, p.ld_in, p.K, p.in2, p.ld_in2, p.K2, p.B};
 #pragma unroll
     for (int j = 0; j < XKB; ++j) {
-      const int k = (wave + NW * j) * 32 + (lane & 31);
+      const int k = (pw + NWP * j) * 32 + (lane & 31);
 #pragma unroll
       for (int e = 0; e < 16; ++e) xa[j][e] = xs.at_nb(8 * (e >> 2) + 4 * (lane >> 5) + (e & 3), k);   // k >= Kt reads as 0
     }
   }
 
   // (a) gradient w.r.t. this layer's output: given, or dy_next . w_next^T on the fly
-  float gout[NVAL];
+  float gout[V][NVAL];
   if (p.dout != nullptr) {
 #pragma unroll
-    for (int j = 0; j < NVAL; ++j) {
-      const int r = rg + RG * j;
-      gout[j] = (r < p.B && cok) ? p.dout[(size_t)r * p.ld_dout + c] : 0.f;
-    }
+    for (int v = 0; v < V; ++v)
+#pragma unroll
+      for (int j = 0; j < NVAL; ++j) {
+        const int r = rgp + RGP * v + RG * j;
+        gout[v][j] = (r < p.B && cok) ? p.dout[(size_t)r * p.ld_dout + c] : 0.f;
+      }
   } else {
-    f32x16 acc[RBT];
+    f32x16 acc[V][RBT];
     RowSrc src{p.dy_next, p.N_next, p.N_next, nullptr, 0, 0, p.B};
-    wave_gemm<true, RBT>(acc, src, p.w_next, p.N_next, p.N_next, c0, nvalid, wave, lane);
-    reduce_tiles<RBT>(acc, sm, gout);
+#pragma unroll
+    for (int v = 0; v < V; ++v) { wave_gemm<true, RBT, (NWP < NW ? 8 : 0)>(acc[v], src, p.w_next, p.N_next, p.N_next, c0, nvalid, pw + NWP * v, lane); if (V > 1) __builtin_amdgcn_sched_barrier(0); }
+    reduce_tiles<RBT, NWP>(acc, sm, gout);
   }
 
   // (b) dropout / activation backward, (c) batch-norm backward over the B rows
@@ -287,61 +318,73 @@ __device__ __forceinline__ void fc_bwd_body(const t3d_fc_bwd_args& p, float* sm,
   float mean = 0.f, invstd = 1.f, g = 1.f, be = 0.f;
   if (bn && cok) { mean = p.mean[c]; invstd = p.invstd[c]; g = p.gamma[c]; be = p.beta[c]; }
   const float inv_keep = p.drop_mask ? 1.0f / p.keep_prob : 1.f;
-  float xh[NVAL];
-  float s1 = 0.f, s2 = 0.f;
+  float xh[V][NVAL];
+  float s1[V], s2[V];
 #pragma unroll
-  for (int j = 0; j < NVAL; ++j) {
-    const int r = rg + RG * j;
-    float dz = 0.f, x = 0.f;
-    if (r < p.B && cok) {
-      const float yv = p.y ? p.y[(size_t)r * p.N + c] : 0.f;
-      x = bn ? (yv - mean) * invstd : yv;
-      const float z = bn ? x * g + be : yv;
-      dz = gout[j];
-      if (p.drop_mask) dz *= p.drop_mask[(size_t)r * p.N + c] * inv_keep;
-      dz *= act_bwd(z, p.act, p.leaky_alpha);
-      s1 += dz;
-      s2 = fmaf(dz, x, s2);
+  for (int v = 0; v < V; ++v) {
+    s1[v] = 0.f;
+    s2[v] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NVAL; ++j) {
+      const int r = rgp + RGP * v + RG * j;
+      float dz = 0.f, x = 0.f;
+      if (r < p.B && cok) {
+        const float yv = p.y ? p.y[(size_t)r * p.N + c] : 0.f;
+        x = bn ? (yv - mean) * invstd : yv;
+        const float z = bn ? x * g + be : yv;
+        dz = gout[v][j];
+        if (p.drop_mask) dz *= p.drop_mask[(size_t)r * p.N + c] * inv_keep;
+        dz *= act_bwd(z, p.act, p.leaky_alpha);
+        s1[v] += dz;
+        s2[v] = fmaf(dz, x, s2[v]);
+      }
+      gout[v][j] = dz;
+      xh[v][j] = x;
     }
-    gout[j] = dz;
-    xh[j] = x;
   }
   float dbias = 0.f;
   if (bn && p.bn_training) {
-    const float dbeta = col_reduce(s1, sm);
-    const float dgamma = col_reduce(s2, sm);
-    if (cok && rg == 0) {
+    const float dbeta = col_reduce<NWP>(s1, sm);
+    const float dgamma = col_reduce<NWP>(s2, sm);
+    if (cok && rgp == 0) {
       if (p.dbeta) p.dbeta[c] = dbeta;
       if (p.dgamma) p.dgamma[c] = dgamma;
     }
     const float invB = 1.0f / (float)p.B, c1 = g * invstd;
 #pragma unroll
-    for (int j = 0; j < NVAL; ++j) gout[j] = c1 * (gout[j] - dbeta * invB - xh[j] * dgamma * invB);
+    for (int v = 0; v < V; ++v)
+#pragma unroll
+      for (int j = 0; j < NVAL; ++j) gout[v][j] = c1 * (gout[v][j] - dbeta * invB - xh[v][j] * dgamma * invB);
   } else if (bn) {
     const float c1 = g * invstd;
 #pragma unroll
-    for (int j = 0; j < NVAL; ++j) gout[j] *= c1;
+    for (int v = 0; v < V; ++v)
+#pragma unroll
+      for (int j = 0; j < NVAL; ++j) gout[v][j] *= c1;
   } else {
-    dbias = col_reduce(s1, sm);
+    dbias = col_reduce<NWP>(s1, sm);
   }
-  if (cok && rg == 0 && p.dbias) p.dbias[c] = dbias;   // exactly 0 under training-mode BN
+  if (cok && rgp == 0 && p.dbias) p.dbias[c] = dbias;   // exactly 0 under training-mode BN
 
   // dy -> global and LDS ([rows][LDT], zero padded)
   float* dy_s = sm;
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < NVAL; ++j) {
-    const int r = rg + RG * j;
-    if (r < RB * 32) {
-      const float v = (r < p.B && cok) ? gout[j] : 0.f;
-      dy_s[r * LDT + col] = v;
-      if (r < p.B && cok) p.dy[(size_t)r * p.N + c] = v;
+  for (int v = 0; v < V; ++v)
+#pragma unroll
+    for (int j = 0; j < NVAL; ++j) {
+      const int r = rgp + RGP * v + RG * j;
+      if (r < RB * 32) {
+        const float val = (r < p.B && cok) ? gout[v][j] : 0.f;
+        dy_s[r * LDT + col] = val;
+        if (r < p.B && cok) p.dy[(size_t)r * p.N + c] = val;
+      }
     }
-  }
   __syncthreads();
   if (p.dw == nullptr) return;
 
-  // (d) dW[k, c] = sum_r in[r,k] * dy[r,c]: one 32x32 MFMA tile per 32 input channels, reduction over rows
+  // (d) dW[k, c] = sum_r in[r,k] * dy[r,c]: one 32x32 MFMA tile per 32 input channels, reduction over rows (a block is computed
+  // whole by one wave, in the same MFMA order whichever wave takes it and whether its operand was prefetched or not)
   RowSrc src{p.in, p.ld_in, p.K, p.in2, p.ld_in2, p.K2, p.B};
   const int l31 = lane & 31, h = lane >> 5;
   auto store_block = [&](int kb, const f32x16& acc) {
@@ -355,7 +398,7 @@ __device__ __forceinline__ void fc_bwd_body(const t3d_fc_bwd_args& p, float* sm,
   };
 #pragma unroll
   for (int j = 0; j < XKB; ++j) {                        // blocks whose operand was prefetched at kernel start
-    const int kb = wave + NW * j;
+    const int kb = pw + NWP * j;
     if (kb < nkb) {
       f32x16 acc;
 #pragma unroll
@@ -366,7 +409,7 @@ __device__ __forceinline__ void fc_bwd_body(const t3d_fc_bwd_args& p, float* sm,
       store_block(kb, acc);
     }
   }
-  for (int kb = wave + NW * XKB; kb < nkb; kb += NW) {
+  for (int kb = pw + NWP * XKB; kb < nkb; kb += NWP) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -391,39 +434,45 @@ __device__ __forceinline__ void fc_bwd_body(const t3d_fc_bwd_args& p, float* sm,
   }
 }
 
-template <int RBT>
+template <int RBT, int NWP = NW>
 __device__ __forceinline__ void fc_dinput_body(const t3d_fc_dinput_args& p, float* sm, const int bid) {
-  constexpr int RB = RBT, NVAL = RBT * 32 / RG;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int col = tid & 31, rg = tid >> 5;
+  constexpr int RB = RBT, NVAL = RBT * 32 / RG, V = NW / NWP, RGP = NWP * 2;
+  const int tid = threadIdx.x, lane = tid & 63, pw = tid >> 6;
+  const int col = tid & 31, rgp = tid >> 5;
   const int c0 = bid * CB, c = c0 + col;
   const int nvalid = min(CB, p.K - c0);
-  f32x16 acc[RBT];
+  f32x16 acc[V][RBT];
   RowSrc src{p.dy, p.N, p.N, nullptr, 0, 0, p.B};
-  wave_gemm<true, RBT>(acc, src, p.w, p.N, p.N, c0, nvalid, wave, lane);
-  float v[NVAL];
-  reduce_tiles<RBT>(acc, sm, v);
-  const bool cok = c < p.K;
-  float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-  for (int j = 0; j < NVAL; ++j) {
-    const int r = rg + RG * j;
-    if (r < p.B && cok) {
-      float o = p.alpha * v[j];
-      if (p.add_in) o += p.add_in[(size_t)r * p.ld_add + c];
-      p.din[(size_t)r * p.ld_din + c] = o;
-      if (p.bn_coef) {            // pooled form of the batch-norm backward statistics on this column (K11c)
-        const float live = p.bn_pooled[(size_t)r * p.bn_ld_pooled + c] > 0.f ? 1.f : 0.f;
-        const float g = o * live;
-        p.bn_dpool[(size_t)r * p.K + c] = g;
-        s1 += g;
-        s2 = fmaf(g, p.bn_ysel[(size_t)r * p.K + c], s2);
+  for (int v = 0; v < V; ++v) wave_gemm<true, RBT, (NWP < NW ? 8 : 0)>(acc[v], src, p.w, p.N, p.N, c0, nvalid, pw + NWP * v, lane);
+  float val[V][NVAL];
+  reduce_tiles<RBT, NWP>(acc, sm, val);
+  const bool cok = c < p.K;
+  float s1[V], s2[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    s1[v] = 0.f;
+    s2[v] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NVAL; ++j) {
+      const int r = rgp + RGP * v + RG * j;
+      if (r < p.B && cok) {
+        float o = p.alpha * val[v][j];
+        if (p.add_in) o += p.add_in[(size_t)r * p.ld_add + c];
+        p.din[(size_t)r * p.ld_din + c] = o;
+        if (p.bn_coef) {            // pooled form of the batch-norm backward statistics on this column (K11c)
+          const float live = p.bn_pooled[(size_t)r * p.bn_ld_pooled + c] > 0.f ? 1.f : 0.f;
+          const float g = o * live;
+          p.bn_dpool[(size_t)r * p.K + c] = g;
+          s1[v] += g;
+          s2[v] = fmaf(g, p.bn_ysel[(size_t)r * p.K + c], s2[v]);
+        }
       }
     }
   }
   if (p.bn_coef == nullptr) return;          // workgroup-uniform
-  const float t1 = col_reduce(s1, sm), t2 = col_reduce(s2, sm);
-  if (cok && rg == 0) {
+  const float t1 = col_reduce<NWP>(s1, sm), t2 = col_reduce<NWP>(s2, sm);
+  if (cok && rgp == 0) {
     if (p.bn_frozen) {
       p.bn_coef[c] = p.bn_scale[c];
       p.bn_coef[p.K + c] = 0.f;

@@ -4,15 +4,14 @@
 // boundary, not their work.  One launch that runs the blocks of one op of each chain pays that once (tools/micro/grid_barrier.py:
 // 2-4 us saved per pair).  The bodies are the stand-alone kernels' own (fc_dev.h, bn_dev.h): results are bit-identical.
 // The host side (nets.pair_small_launches) interleaves the two chains so that their small launches meet.
-#include "fc_dev.h"
-#include "bn_dev.h"
+#include "rider_dev.h"
 
 namespace {
 
 template <int RBT>
 __device__ __forceinline__ void run_small(const t3d_small_op& o, float* sm, const int bid) {
   switch (o.kind) {      // workgroup-uniform
-    case T3D_SMALL_BN_BWD_FINALIZE: bn_bwd_finalize_body<FC_GR>(o.u.bn_bwd, bid, threadIdx.x); break;
+    case T3D_SMALL_BN_BWD_FINALIZE: bn_bwd_finalize_body<FC_GR>(o.u.bn_bwd, reinterpret_cast<double (*)[FC_CH]>(sm), bid, threadIdx.x); break;
     case T3D_SMALL_FC_BWD: fc_bwd_body<RBT>(o.u.fc_bwd, sm, bid); break;
     case T3D_SMALL_FC_DINPUT: fc_dinput_body<RBT>(o.u.fc_dinput, sm, bid); break;
     case T3D_SMALL_DY_COLSUM: dy_colsum_body(o.u.dy_colsum, bid, threadIdx.x); break;
@@ -39,7 +38,34 @@ int small_blocks(const t3d_small_op& o, int* rows) {
   }
 }
 
+// a rider set as a launch of its own (what a `_r` launcher falls back to, and the scheduler's choice for a run of small ops that found no
+// GEMM to ride in: one launch instead of one per op)
+__global__ __launch_bounds__(RIDER_NT) void k_riders(const t3d_rider_set r) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  run_riders(r, sm);
+}
+
 }  // namespace
+
+extern "C" int t3d_riders_plan(t3d_rider_set* r) {
+  if (!r || r->n_ops <= 0 || r->n_ops > T3D_RIDER_MAX_OPS) return T3D_ERR_ARG;
+  int m = 1;
+  for (int i = 0; i < r->n_ops; ++i) {
+    const int nb = rider_op_blocks(r->ops[i]);
+    if (nb <= 0) return r->ops[i].kind >= 1 && r->ops[i].kind <= 6 ? T3D_ERR_SHAPE : T3D_ERR_ARG;
+    if (nb > m) m = nb;
+  }
+  r->n_wg = m < RIDER_MAX_WG ? m : RIDER_MAX_WG;
+  r->lds_bytes = (int)rider_lds_bytes();
+  return T3D_OK;
+}
+
+extern "C" int t3d_run_riders(const t3d_rider_set* r, t3d_stream_t stream) {
+  if (!r || !r->sync || r->n_ops <= 0 || r->n_ops > T3D_RIDER_MAX_OPS || r->n_wg <= 0 || r->n_wg > RIDER_MAX_WG || r->lds_bytes < 0) return T3D_ERR_ARG;
+  T3D_LAUNCH(k_riders, dim3(r->n_wg), dim3(RIDER_NT), (size_t)r->lds_bytes, static_cast<hipStream_t>(stream), *r);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
 
 extern "C" int t3d_small_pair(const t3d_small_op* a, const t3d_small_op* b, t3d_stream_t stream) {
   if (!a || !b) return T3D_ERR_ARG;

@@ -13,6 +13,7 @@
 // format can be paired with either.
 #include "common.h"
 #include "poolbwd_dev.h"
+#include "rider_dev.h"
 
 #include <cstdlib>
 #include <mutex>
@@ -811,7 +812,7 @@ __device__ __forceinline__ void run_mainloop(SA& sa, SB& sb, const LA& la, const
 // ---------------------------------------------------------------------------------------------
 // PR: arithmetic + element type of y (PathF32 / PathBF16); XT: element type of the input tensor (fp32 for the raw inputs)
 template <int BN, bool HAS_SUB, class PR = PathF32, class XT = float>
-__global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd(const t3d_pointmlp_fwd_args p) {
+__device__ __forceinline__ void fwd_body(const t3d_pointmlp_fwd_args& p, float* smem, const int bid, const int nblk) {
   constexpr int BM = 128, TM = 2, TN = BN / 64;
   using LA = typename PR::template Act<HAS_SUB, XT>;
   using YT = typename PR::T;
@@ -819,12 +820,11 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd(const t3d_pointm
   using WL = std::conditional_t<LA::EXACT, typename PR::WLX, typename PR::WL>;      // K % 64 == 0: every weight tile is whole
   using SA = typename PR::template Stg<BM, true, LA, PF, true>;
   using SB = typename PR::template Stg<BN, false, WL, PF>;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int tiles_n = p.N / BN;
-  const int lin = xcd_remap(blockIdx.x, gridDim.x);
+  const int lin = xcd_remap(bid, nblk);
   const int tile_m = lin / tiles_n, tile_n = lin % tiles_n;
   const int row0 = tile_m * BM, col0 = tile_n * BN;
   T3D_TRACE_MARK(0);
@@ -970,6 +970,21 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd(const t3d_pointm
     }
   }
   T3D_TRACE_MARK(2);
+}
+
+template <int BN, bool HAS_SUB, class PR = PathF32, class XT = float>
+__global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd(const t3d_pointmlp_fwd_args p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  fwd_body<BN, HAS_SUB, PR, XT>(p, smem, blockIdx.x, gridDim.x);
+}
+
+// Rider forms (rider_dev.h): the launch's first r.n_wg workgroups run a set of small ops of an independent chain and leave; the
+// GEMM's tiles are the workgroups behind them.  fp32 split-form kernels only; the plain kernels above and below are untouched.
+template <int BN, bool HAS_SUB>
+__global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd_r(const t3d_pointmlp_fwd_args p, const t3d_rider_set r) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((int)blockIdx.x < r.n_wg) { run_riders(r, smem); return; }
+  fwd_body<BN, HAS_SUB, PathF32, float>(p, smem, blockIdx.x - r.n_wg, gridDim.x - r.n_wg);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1623,6 +1638,28 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_bwd(const t3d_pointm
   }
 }
 
+template <int DBN, int WBMK, int WBN>
+__global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_bwd_r(const t3d_pointmlp_dgrad_args d, const t3d_pointmlp_wgrad_args w,
+                                                                  const int n_wgrad, const t3d_rider_set r) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((int)blockIdx.x < r.n_wg) { run_riders(r, smem); return; }
+  const int bid = blockIdx.x - r.n_wg, nblk = gridDim.x - r.n_wg;
+  typename PathF32::template Act<false, float> la{w.a, w.K, w.rows_per_frustum};
+  typename PathF32::template Dy<false> lb{w.dy, w.N, w.rows_per_frustum};
+  if (bid < n_wgrad) wgrad_body<WBMK, WBN, PathF32>(la, lb, w.slabs, w.K, w.N, w.rows_per_split, smem, bid, n_wgrad);
+  else dgrad_body<DBN, false, PathF32>(d, smem, bid - n_wgrad, nblk - n_wgrad);
+}
+
+// first layer of a net (raw points in, no data gradient): the weight gradient alone
+template <int BMK, int BN, bool HAS_SUB, bool POOLED>
+__global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_wgrad_r(const t3d_pointmlp_wgrad_args p, const t3d_rider_set r) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((int)blockIdx.x < r.n_wg) { run_riders(r, smem); return; }
+  typename PathF32::template Act<HAS_SUB, float> la{p.a, p.K, p.rows_per_frustum};
+  typename PathF32::template Dy<POOLED> lb{p.dy, p.N, p.rows_per_frustum};
+  wgrad_body<BMK, BN, PathF32>(la, lb, p.slabs, p.K, p.N, p.rows_per_split, smem, blockIdx.x - r.n_wg, gridDim.x - r.n_wg);
+}
+
 // ---------------------------------------------------------------------------------------------
 // one-pass backward of a dense bf16 layer with K, N in {64, 128}, or 256 x 128 / 128 x 256
 // ---------------------------------------------------------------------------------------------
@@ -2203,6 +2240,39 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pool_bwd_stage2(const t3d_poo
     pool_wgrad_finish_body<typename PR::T>(f, smem, b % kb, b / kb);
   } else {
     dgrad_gram_body<BN, PR>(d, smem, b - n_finish, gridDim.x - n_finish);
+  }
+}
+
+template <int GT>
+__global__ __launch_bounds__(NT, T3D_WAVES) void k_pool_bwd_stage1_r(const t3d_pointmlp_gram_args g, const t3d_act_colsum_args c,
+                                                                     const t3d_pool_bwd_prep_args q, const int n_gram,
+                                                                     const int n_colsum, const t3d_rider_set r) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((int)blockIdx.x < r.n_wg) { run_riders(r, smem); return; }
+  const int b = blockIdx.x - r.n_wg;
+  if (b < n_gram) {
+    typename PathF32::template Act<false, float> la{g.a, g.K, g.rows_per_frustum};
+    wgrad_body<GT, GT, PathF32>(la, la, g.slabs, g.K, g.K, g.rows_per_split, smem, b, n_gram);
+  } else if (b < n_gram + n_colsum) {
+    act_colsum_body<float>(c, smem, b - n_gram);
+  } else {
+    const int rr = b - n_gram - n_colsum, kb = q.K / 32;
+    pool_bwd_prep_body(q, smem, rr % kb, (rr / kb) % kb, rr / (kb * kb));
+  }
+}
+
+template <int BN>
+__global__ __launch_bounds__(NT, T3D_WAVES) void k_pool_bwd_stage2_r(const t3d_pool_wgrad_finish_args f,
+                                                                     const t3d_pointmlp_dgrad_gram_args d, const int n_finish,
+                                                                     const t3d_rider_set r) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((int)blockIdx.x < r.n_wg) { run_riders(r, smem); return; }
+  const int b = blockIdx.x - r.n_wg;
+  if (b < n_finish) {
+    const int kb = f.K / FK;
+    pool_wgrad_finish_body<float>(f, smem, b % kb, b / kb);
+  } else {
+    dgrad_gram_body<BN, PathF32>(d, smem, b - n_finish, (int)gridDim.x - r.n_wg - n_finish);
   }
 }
 
@@ -2790,6 +2860,12 @@ void launch_lds(void (*kernel)(const Args), dim3 grid, size_t lds_bytes, hipStre
   T3D_LAUNCH(kernel, grid, dim3(NT), lds_bytes, s, a);
 }
 template <class Args>
+void launch_lds_r(void (*kernel)(const Args, const t3d_rider_set), dim3 grid, size_t lds_bytes, hipStream_t s, const Args& a,
+                  const t3d_rider_set& r) {
+  allow_lds(reinterpret_cast<const void*>(kernel), lds_bytes);
+  T3D_LAUNCH(kernel, grid, dim3(NT), lds_bytes, s, a, r);
+}
+template <class Args>
 void launch_lds1(void (*kernel)(const Args), dim3 grid, size_t lds_bytes, hipStream_t s, const Args& a) {      // 512-thread kernels
   allow_lds(reinterpret_cast<const void*>(kernel), lds_bytes);
   T3D_LAUNCH(kernel, grid, dim3(NT1), lds_bytes, s, a);
@@ -2821,9 +2897,26 @@ bool dy_ok(const t3d_dy_src& d) {
          !(d.dtype == T3D_BF16 && d.dz == nullptr);      // bf16: dense form only (pooled layers take the Gram path)
 }
 
+bool riders_ok(const t3d_rider_set* r) {
+  return r->sync != nullptr && r->n_ops > 0 && r->n_ops <= T3D_RIDER_MAX_OPS && r->n_wg > 0 && r->n_wg <= RIDER_MAX_WG && r->lds_bytes >= 0;
+}
+size_t lds_with(size_t lds, const t3d_rider_set* r) { return r && (size_t)r->lds_bytes > lds ? (size_t)r->lds_bytes : lds; }
+
 }  // namespace
 
-extern "C" int t3d_pointmlp_fwd(const t3d_pointmlp_fwd_args* a, t3d_stream_t stream) {
+// a launch whose kernel variant has no rider form: the set runs as a launch of its own in front of it
+#define T3D_RIDERS_FIRST(r, stream)                         \
+  do {                                                      \
+    if (r) {                                                \
+      const int rc__ = t3d_run_riders(r, stream);           \
+      if (rc__ != T3D_OK) return rc__;                      \
+    }                                                       \
+  } while (0)
+
+extern "C" int t3d_pointmlp_fwd(const t3d_pointmlp_fwd_args* a, t3d_stream_t stream) { return t3d_pointmlp_fwd_r(a, nullptr, stream); }
+
+extern "C" int t3d_pointmlp_fwd_r(const t3d_pointmlp_fwd_args* a, const t3d_rider_set* r, t3d_stream_t stream) {
+  if (r && !riders_ok(r)) return T3D_ERR_ARG;
   if (!a || !a->w || !a->psum || !a->psumsq || !act_ok(a->a, a->K)) return T3D_ERR_ARG;
   if (a->pmax && (!a->pmin || !a->pamax || !a->pamin)) return T3D_ERR_ARG;
   if (a->M <= 0 || a->K <= 0 || a->N <= 0 || a->M % T3D_TILE_ROWS || a->rows_per_frustum % T3D_TILE_ROWS ||
@@ -2835,6 +2928,7 @@ extern "C" int t3d_pointmlp_fwd(const t3d_pointmlp_fwd_args* a, t3d_stream_t str
   const bool sub = a->a.sub != nullptr;
   if (!dtype_ok(a->dtype)) return T3D_ERR_ARG;
   if (a->dtype == T3D_BF16) {
+    T3D_RIDERS_FIRST(r, stream);
     // bf16 storage + bf16 MFMA (configs[4]); the input is fp32 for the raw point cloud / Box-PC representation, bf16 for a layer output
     const bool wide = T3D_FORCE_TILE != 64 && a->N % 128 == 0 && (T3D_FORCE_TILE == 128 || (long)tiles_m * (a->N / 128) >= 512);
     const bool xh = a->a.dtype == T3D_BF16;
@@ -2888,6 +2982,7 @@ extern "C" int t3d_pointmlp_fwd(const t3d_pointmlp_fwd_args* a, t3d_stream_t str
   // (109 vs 100 us on 256->512); K = 128: 92 vs 100 us on 128->1024, 26 vs 33 us on 128->256.  T3D_FWD_POOL=2 forces it on.
   static const bool fp_k256 = []() { const char* e = getenv("T3D_FWD_POOL"); return e && e[0] == '2'; }();
   if (use_pool_kernel && !a->y && a->pmax && !sub && a->N % 128 == 0 && a->N >= 256 && (a->K == 128 || (a->K == 256 && fp_k256))) {
+    T3D_RIDERS_FIRST(r, stream);      // (a 512-thread kernel)
 #ifndef T3D_FP_WAVES
 #define T3D_FP_WAVES 8
 #endif
@@ -2906,12 +3001,18 @@ extern "C" int t3d_pointmlp_fwd(const t3d_pointmlp_fwd_args* a, t3d_stream_t str
     return T3D_OK;
   }
   if (T3D_FORCE_TILE != 64 && a->N % 128 == 0 && (T3D_FORCE_TILE == 128 || (long)tiles_m * (a->N / 128) >= 512)) {
-    const dim3 grid(tiles_m * (a->N / 128));
-    if (sub) launch_lds(k_pointmlp_fwd<128, true>, grid, lds_fwd(128), s, *a);
+    const dim3 grid(tiles_m * (a->N / 128) + (r ? r->n_wg : 0));
+    if (r) {
+      if (sub) launch_lds_r(k_pointmlp_fwd_r<128, true>, grid, lds_with(lds_fwd(128), r), s, *a, *r);
+      else launch_lds_r(k_pointmlp_fwd_r<128, false>, grid, lds_with(lds_fwd(128), r), s, *a, *r);
+    } else if (sub) launch_lds(k_pointmlp_fwd<128, true>, grid, lds_fwd(128), s, *a);
     else launch_lds(k_pointmlp_fwd<128, false>, grid, lds_fwd(128), s, *a);
   } else {
-    const dim3 grid(tiles_m * (a->N / 64));
-    if (sub) launch_lds(k_pointmlp_fwd<64, true>, grid, lds_fwd(64), s, *a);
+    const dim3 grid(tiles_m * (a->N / 64) + (r ? r->n_wg : 0));
+    if (r) {
+      if (sub) launch_lds_r(k_pointmlp_fwd_r<64, true>, grid, lds_with(lds_fwd(64), r), s, *a, *r);
+      else launch_lds_r(k_pointmlp_fwd_r<64, false>, grid, lds_with(lds_fwd(64), r), s, *a, *r);
+    } else if (sub) launch_lds(k_pointmlp_fwd<64, true>, grid, lds_fwd(64), s, *a);
     else launch_lds(k_pointmlp_fwd<64, false>, grid, lds_fwd(64), s, *a);
   }
   T3D_CHECK_LAUNCH();
@@ -3042,7 +3143,10 @@ static void wgrad_tile(const t3d_pointmlp_wgrad_args* a, int* tk, int* tn) {
   *tn = a->N % 128 == 0 ? 128 : 64;
 }
 
-extern "C" int t3d_pointmlp_wgrad(const t3d_pointmlp_wgrad_args* a, t3d_stream_t stream) {
+extern "C" int t3d_pointmlp_wgrad(const t3d_pointmlp_wgrad_args* a, t3d_stream_t stream) { return t3d_pointmlp_wgrad_r(a, nullptr, stream); }
+
+extern "C" int t3d_pointmlp_wgrad_r(const t3d_pointmlp_wgrad_args* a, const t3d_rider_set* r, t3d_stream_t stream) {
+  if (r && !riders_ok(r)) return T3D_ERR_ARG;
   const int rc = check_wgrad(a);
   if (rc != T3D_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -3050,8 +3154,11 @@ extern "C" int t3d_pointmlp_wgrad(const t3d_pointmlp_wgrad_args* a, t3d_stream_t
   int tk = 0, tn = 0;
   wgrad_tile(a, &tk, &tn);
   const int tiles_k = (a->K + tk - 1) / tk, tiles_n = a->N / tn;
-  const dim3 grid(tiles_k * tiles_n * splits);
   const bool sub = a->a.sub != nullptr, pooled = a->dy.dz == nullptr;
+  // rider form: the 64 x 64 tiling of a first layer's weight gradient (K <= 4 raw channels, fp32) only
+  const bool host = r && a->dy.dtype != T3D_BF16 && tk == 64 && tn == 64 && !pooled;
+  if (r && !host) { T3D_RIDERS_FIRST(r, stream); r = nullptr; }
+  const dim3 grid(tiles_k * tiles_n * splits + (r ? r->n_wg : 0));
   if (a->dy.dtype == T3D_BF16) {
     const bool xh = a->a.dtype == T3D_BF16;
 #define T3D_WGH(TK, TN_)                                                                                                     \
@@ -3075,7 +3182,10 @@ extern "C" int t3d_pointmlp_wgrad(const t3d_pointmlp_wgrad_args* a, t3d_stream_t
     else if (pooled) launch_lds(k_pointmlp_wgrad<TK, TN_, false, true>, grid, lds_wgrad(TK, TN_), s, *a);          \
     else launch_lds(k_pointmlp_wgrad<TK, TN_, false, false>, grid, lds_wgrad(TK, TN_), s, *a);                     \
   } while (0)
-  if (tk == 128 && tn == 128) T3D_WG(128, 128);
+  if (r) {
+    if (sub) launch_lds_r(k_pointmlp_wgrad_r<64, 64, true, false>, grid, lds_with(lds_wgrad(64, 64), r), s, *a, *r);
+    else launch_lds_r(k_pointmlp_wgrad_r<64, 64, false, false>, grid, lds_with(lds_wgrad(64, 64), r), s, *a, *r);
+  } else if (tk == 128 && tn == 128) T3D_WG(128, 128);
   else if (tk == 128) T3D_WG(128, 64);
   else if (tn == 128) T3D_WG(64, 128);
   else T3D_WG(64, 64);
@@ -3199,6 +3309,12 @@ extern "C" int t3d_pointmlp_gram(const t3d_pointmlp_gram_args* a, t3d_stream_t s
 }
 
 extern "C" int t3d_pointmlp_bwd(const t3d_pointmlp_dgrad_args* d, const t3d_pointmlp_wgrad_args* w, t3d_stream_t stream) {
+  return t3d_pointmlp_bwd_r(d, w, nullptr, stream);
+}
+
+extern "C" int t3d_pointmlp_bwd_r(const t3d_pointmlp_dgrad_args* d, const t3d_pointmlp_wgrad_args* w, const t3d_rider_set* r,
+                                  t3d_stream_t stream) {
+  if (r && !riders_ok(r)) return T3D_ERR_ARG;
   int rc = check_dgrad(d);
   if (rc != T3D_OK) return rc;
   rc = check_wgrad(w);
@@ -3217,6 +3333,7 @@ extern "C" int t3d_pointmlp_bwd(const t3d_pointmlp_dgrad_args* d, const t3d_poin
                         bwd1_split_ok(d->M, rps, d->dtype) &&
                         (w->a.scale == nullptr) == (w->a.shift == nullptr);
     if (shape1 && !bf16 && w->a.ldx % 4 == 0 && w->a.coff % 4 == 0) {
+      T3D_RIDERS_FIRST(r, stream);
       const dim3 grid1(d->M / rps);
 #define T3D_BWD1F(K_, N_)                                                                        \
   do {                                                                                           \
@@ -3239,6 +3356,7 @@ extern "C" int t3d_pointmlp_bwd(const t3d_pointmlp_dgrad_args* d, const t3d_poin
       return T3D_OK;
     }
     if (shape1 && bf16 && w->a.dtype == T3D_BF16 && w->a.ldx % 8 == 0 && w->a.coff % 8 == 0) {
+      T3D_RIDERS_FIRST(r, stream);
       const dim3 grid1(d->M / rps);
 #define T3D_BWD1(K_, N_, BM_)                                                                    \
   do {                                                                                           \
@@ -3262,7 +3380,8 @@ extern "C" int t3d_pointmlp_bwd(const t3d_pointmlp_dgrad_args* d, const t3d_poin
   const int n_w = ((w->K + tk - 1) / tk) * (w->N / tn) * (w->M / w->rows_per_split);
   const bool wide = dgrad_wide(d);
   const int n_d = (d->M / 128) * (d->K / (wide ? 128 : 64));
-  const dim3 grid(n_w + n_d);
+  if (bf16) { T3D_RIDERS_FIRST(r, stream); r = nullptr; }
+  const dim3 grid(n_w + n_d + (r ? r->n_wg : 0));
   // interleaving the two kinds of tile by row range (so that both readers of a dy row range share an L2) measured SLOWER
   // than weight-gradient tiles first (1.683 vs 1.630 ms per step): the long wgrad tiles are better started early.
   static const bool il = []() { const char* e = getenv("T3D_BWD_INTERLEAVE"); return e && e[0] == '1'; }();
@@ -3274,6 +3393,11 @@ extern "C" int t3d_pointmlp_bwd(const t3d_pointmlp_dgrad_args* d, const t3d_poin
       auto kern = k_pointmlp_bwd<DBN, TK, TN_, PathBF16>;                                                           \
       allow_lds(reinterpret_cast<const void*>(kern), lds);                                                          \
       T3D_LAUNCH(kern, grid, dim3(NT), lds, s, *d, *w, n_w, interleave);                                            \
+    } else if (r) {                                                                                                 \
+      const size_t lds = lds_with(lds_dgrad(DBN) > lds_wgrad(TK, TN_) ? lds_dgrad(DBN) : lds_wgrad(TK, TN_), r);    \
+      auto kern = k_pointmlp_bwd_r<DBN, TK, TN_>;                                                                   \
+      allow_lds(reinterpret_cast<const void*>(kern), lds);                                                          \
+      T3D_LAUNCH(kern, grid, dim3(NT), lds, s, *d, *w, n_w, *r);                                                    \
     } else {                                                                                                        \
       const size_t lds = lds_dgrad(DBN) > lds_wgrad(TK, TN_) ? lds_dgrad(DBN) : lds_wgrad(TK, TN_);                 \
       auto kern = k_pointmlp_bwd<DBN, TK, TN_>;                                                                     \
@@ -3298,6 +3422,12 @@ extern "C" int t3d_pointmlp_bwd(const t3d_pointmlp_dgrad_args* d, const t3d_poin
 
 extern "C" int t3d_pool_bwd_stage1(const t3d_pointmlp_gram_args* g, const t3d_act_colsum_args* c,
                                    const t3d_pool_bwd_prep_args* q, t3d_stream_t stream) {
+  return t3d_pool_bwd_stage1_r(g, c, q, nullptr, stream);
+}
+
+extern "C" int t3d_pool_bwd_stage1_r(const t3d_pointmlp_gram_args* g, const t3d_act_colsum_args* c,
+                                     const t3d_pool_bwd_prep_args* q, const t3d_rider_set* r, t3d_stream_t stream) {
+  if (r && !riders_ok(r)) return T3D_ERR_ARG;
   int rc = check_gram(g);
   if (rc != T3D_OK) return rc;
   if ((rc = check_colsum(c)) != T3D_OK) return rc;
@@ -3305,6 +3435,7 @@ extern "C" int t3d_pool_bwd_stage1(const t3d_pointmlp_gram_args* g, const t3d_ac
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (c->a.dtype != g->a.dtype) return T3D_ERR_ARG;
   if (gram1_ok(g) && c->M == g->M && c->K == g->K && c->a.x == g->a.x && c->a.ldx == g->a.ldx && c->a.coff == g->a.coff) {
+    T3D_RIDERS_FIRST(r, stream);
     const int n_gram1 = g->M / g->rows_per_split, n_prep1 = (q->K / 32) * (q->K / 32) * ((q->N + PCH - 1) / PCH);
     const dim3 grid1(n_gram1 + (n_prep1 + 1) / 2);
 #define T3D_ST1H(K_, BM_)                                                                                  \
@@ -3323,20 +3454,30 @@ extern "C" int t3d_pool_bwd_stage1(const t3d_pointmlp_gram_args* g, const t3d_ac
   const int n_gram = (g->K / gt) * (g->K / gt) * (g->M / g->rows_per_split);
   const int n_colsum = c->M / 128;
   const int n_prep = (q->K / 32) * (q->K / 32) * ((q->N + PCH - 1) / PCH);
-  const dim3 grid(n_gram + n_colsum + n_prep);
   const bool bf16 = g->a.dtype == T3D_BF16;
   if (c->a.dtype != g->a.dtype) return T3D_ERR_ARG;
+  if (bf16) { T3D_RIDERS_FIRST(r, stream); r = nullptr; }
+  const dim3 grid(n_gram + n_colsum + n_prep + (r ? r->n_wg : 0));
   size_t lds = bf16 ? lds_wgrad_h(gt, gt) : lds_wgrad(gt, gt);
   if (PREP_LDS > lds) lds = PREP_LDS;
   if (COLSUM_LDS > lds) lds = COLSUM_LDS;
+  lds = lds_with(lds, r);
 #define T3D_ST1(GT_, PR_)                                                              \
   do {                                                                                 \
     auto kern = k_pool_bwd_stage1<GT_, PR_>;                                           \
     allow_lds(reinterpret_cast<const void*>(kern), lds);                               \
     T3D_LAUNCH(kern, grid, dim3(NT), lds, s, *g, *c, *q, n_gram, n_colsum);            \
   } while (0)
-  if (bf16) { if (gt == 128) T3D_ST1(128, PathBF16); else T3D_ST1(64, PathBF16); }
+#define T3D_ST1R(GT_)                                                                  \
+  do {                                                                                 \
+    auto kern = k_pool_bwd_stage1_r<GT_>;                                              \
+    allow_lds(reinterpret_cast<const void*>(kern), lds);                               \
+    T3D_LAUNCH(kern, grid, dim3(NT), lds, s, *g, *c, *q, n_gram, n_colsum, *r);        \
+  } while (0)
+  if (r) { if (gt == 128) T3D_ST1R(128); else T3D_ST1R(64); }
+  else if (bf16) { if (gt == 128) T3D_ST1(128, PathBF16); else T3D_ST1(64, PathBF16); }
   else { if (gt == 128) T3D_ST1(128, PathF32); else T3D_ST1(64, PathF32); }
+#undef T3D_ST1R
 #undef T3D_ST1
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -3344,6 +3485,12 @@ extern "C" int t3d_pool_bwd_stage1(const t3d_pointmlp_gram_args* g, const t3d_ac
 
 extern "C" int t3d_pool_bwd_stage2(const t3d_pool_wgrad_finish_args* f, const t3d_pointmlp_dgrad_gram_args* d,
                                    t3d_stream_t stream) {
+  return t3d_pool_bwd_stage2_r(f, d, nullptr, stream);
+}
+
+extern "C" int t3d_pool_bwd_stage2_r(const t3d_pool_wgrad_finish_args* f, const t3d_pointmlp_dgrad_gram_args* d,
+                                     const t3d_rider_set* r, t3d_stream_t stream) {
+  if (r && !riders_ok(r)) return T3D_ERR_ARG;
   int rc = check_finish(f);
   if (rc != T3D_OK) return rc;
   if ((rc = check_dgrad_gram(d)) != T3D_OK) return rc;
@@ -3351,6 +3498,7 @@ extern "C" int t3d_pool_bwd_stage2(const t3d_pool_wgrad_finish_args* f, const t3
   const int n_finish = (f->K / FK) * (f->N / FN);
   if (f->a.dtype != d->a.dtype) return T3D_ERR_ARG;
   if (dgram1_ok(d) && f->K == d->K) {
+    T3D_RIDERS_FIRST(r, stream);
     const int n_fin2 = (n_finish + 1) / 2, tiles = d->M / 128;
     const dim3 grid2(n_fin2 + (tiles < 256 ? tiles : 256));
     const int fin_floats = (int)(finish_lds(f->K) / sizeof(float));
@@ -3368,19 +3516,29 @@ extern "C" int t3d_pool_bwd_stage2(const t3d_pool_wgrad_finish_args* f, const t3
   }
   const bool wide = dgrad_gram_wide(d);
   const int n_d = (d->M / 128) * (d->K / (wide ? 128 : 64));
-  const dim3 grid(n_finish + n_d);
   const bool bf16 = d->dtype == T3D_BF16;
   if (f->a.dtype != d->a.dtype) return T3D_ERR_ARG;
+  if (bf16) { T3D_RIDERS_FIRST(r, stream); r = nullptr; }
+  const dim3 grid(n_finish + n_d + (r ? r->n_wg : 0));
   size_t lds = bf16 ? (wide ? lds_dgram_h(128) : lds_dgram_h(64)) : (wide ? lds_fwd(128) : lds_fwd(64));
   if (finish_lds(f->K) > lds) lds = finish_lds(f->K);
+  lds = lds_with(lds, r);
 #define T3D_ST2(BN_, PR_)                                                              \
   do {                                                                                 \
     auto kern = k_pool_bwd_stage2<BN_, PR_>;                                           \
     allow_lds(reinterpret_cast<const void*>(kern), lds);                               \
     T3D_LAUNCH(kern, grid, dim3(NT), lds, s, *f, *d, n_finish);                        \
   } while (0)
-  if (bf16) { if (wide) T3D_ST2(128, PathBF16); else T3D_ST2(64, PathBF16); }
+#define T3D_ST2R(BN_)                                                                  \
+  do {                                                                                 \
+    auto kern = k_pool_bwd_stage2_r<BN_>;                                              \
+    allow_lds(reinterpret_cast<const void*>(kern), lds);                               \
+    T3D_LAUNCH(kern, grid, dim3(NT), lds, s, *f, *d, n_finish, *r);                    \
+  } while (0)
+  if (r) { if (wide) T3D_ST2R(128); else T3D_ST2R(64); }
+  else if (bf16) { if (wide) T3D_ST2(128, PathBF16); else T3D_ST2(64, PathBF16); }
   else { if (wide) T3D_ST2(128, PathF32); else T3D_ST2(64, PathF32); }
+#undef T3D_ST2R
 #undef T3D_ST2
   T3D_CHECK_LAUNCH();
   return T3D_OK;

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(128) void k_weak_surface(const t3d_weak_loss_args p
   const float soft = 1.0f / (1.0f + expf(q0 - q1));
   const float invN = 1.0f / (float)p.N;
   // scale of d total_loss / d surface_loss[b]: is_data_2D * SEMI_MULTIPLIER * w_surface / B
-  const float sb = (float)p.is_data_2D[b] * p.multiplier * p.w_surface / (float)p.B;
+  const float sb = (p.is_data_2D ? (float)p.is_data_2D[b] : 1.f) * p.multiplier * p.w_surface / (float)p.B;
   if (p.dsoft) p.dsoft[m] = sb * e.v * invN;
   float val[8];
   val[0] = e.v * soft;

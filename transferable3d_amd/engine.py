@@ -84,6 +84,7 @@ class Plan:
     serial schedule."""
 
     JOIN, FLUSH = '__join__', '__flush__'
+    MARK = '__mark__'                             # chain boundaries for schedule.overlap_chains (step.TrainStep); no-ops when run
     BUCKET, WAIT = '__bucket__', '__wait__'       # data-parallel markers (step.TrainStep): gradient bucket i complete / needed
 
     def __init__(self, rt):
@@ -113,6 +114,11 @@ class Plan:
         self.keep.extend(keep)
         self.calls.append((name, thunk, None))
         self.lanes.append(self._lane)
+
+    def mark(self, tag):
+        """Names a point of the plan (the boundaries of the two independent chains the step scheduler interleaves)."""
+        self.calls.append((Plan.MARK, lambda s: 0, tag))
+        self.lanes.append(0)
 
     def join(self):
         """Everything recorded so far (both lanes) completes before what follows."""

@@ -398,6 +398,7 @@ class BoxEstNet:
 
 
 PAIR_SMALL = os.environ.get('T3D_PAIR', '1') != '0'
+OVERLAP = os.environ.get('T3D_OVERLAP', '1') != '0'      # schedule.py: riders + pairs over [T-Net/box fwd, loss, bwd] || [seg bwd]
 PAIR_POLICY = int(os.environ.get('T3D_PAIR_POLICY', '1'))      # both heads large: 1 = first chain first, 2 = second chain first (no
 #                                                                 measurable difference: 1.5764 vs 1.5759 ms, three same-box A/B pairs)
 
@@ -415,8 +416,8 @@ def pair_small_launches(plan, i0, i1, i2):
     S = list(zip(plan.calls[i1:i2], plan.lanes[i1:i2]))
 
     def small(entry):
-        (name, _, arg), _lane = entry
-        if name not in kinds or arg is None:
+        (name, _, arg), lane = entry
+        if lane != 0 or name not in kinds or arg is None:      # a side-lane op keeps its own queue order (Plan._run_two_streams)
             return False
         if name == 't3d_bn_bwd_finalize' and arg.psum_dz and arg.n_tiles > 512:      # the 64-group form runs alone
             return False
@@ -616,6 +617,8 @@ class ModelAssembly:
         self.seg.fwd(plan, x.pc, oh, labels, x.is_data_2D, is_training, train_seg, ce_weight=c.STRONG_WEIGHT_CROSS_ENTROPY)
         if self.tnet is None:
             return
+        if train_seg:
+            plan.mark('T_begin')        # from here to the seg net's backward: the chain the seg backward does not depend on (schedule.py)
         s1 = self.tnet.fwd(plan, x.pc, self.seg.mask, self.seg.mask_xyz_mean, oh, is_training)
         if self.box is None:
             return
@@ -662,11 +665,18 @@ class ModelAssembly:
         # go in two buckets, conv10..conv6 (2.9 MB, ready after conv6) and conv5..conv1 (0.6 MB, the exposed tail)
         g, sp = self.g, self.seg.scope + '/'
         g.declare_bucket(plan, [self.tnet.scope + '/', self.box.scope + '/'])
+        # single replica, no weak-loss gradient into the seg net: the seg backward is independent of everything since `T_begin`
+        # (semisup_models.py:150-151) -- the step scheduler interleaves the two chains (schedule.py); T3D_OVERLAP=0: the pairing below
+        overlap = OVERLAP and not g.dp_buckets and self.seg.train_seg and self.weak is None
+        if overlap:
+            plan.mark('S_begin')
         self.seg.bwd(plan, part=0)
         self.seg.bwd(plan, part=1)
         g.declare_bucket(plan, [sp + 'conv%d/' % i for i in (6, 7, 8, 9, 10)])
         self.seg.bwd(plan, part=2)
-        if PAIR_SMALL and not g.dp_buckets and self.seg.train_seg:
+        if overlap:
+            plan.mark('S_end')
+        elif PAIR_SMALL and not g.dp_buckets and self.seg.train_seg:
             # single replica: the box / T-Net backward [i0, i1) and the seg-net backward [i1, here) are independent
             # (semisup_models.py:150-151): their small launches pair up (data parallel keeps the chains apart -- the first bucket's
             # all-reduce is to start as early as possible)

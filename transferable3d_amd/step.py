@@ -40,6 +40,8 @@ class TrainStep:
         self.cache = {}            # generate_masks -> list of program items with captured graphs
         self.n_runs = 0
         self._capture_stream = None
+        self._sets = None            # schedule.RiderSets of the scheduled program (device op tables, barrier words)
+        self.schedule_report = None
 
     # ---- program --------------------------------------------------------------------------------------------------------------
     def _buckets(self):
@@ -65,6 +67,8 @@ class TrainStep:
             k = next((i for i, c in enumerate(calls) if c[0] == 't3d_adam_tf_step'), len(calls))
             calls[k:k] = [(Plan.BUCKET, lambda s: 0, 0), (Plan.WAIT, lambda s: 0, 0)]
             lanes[k:k] = [0, 0]
+        if not self.dist and not two:
+            calls, lanes = self._overlap(calls, lanes)
         prog, cur = [], Plan(self.rt)
         cur.two_streams = two
 
@@ -101,6 +105,25 @@ class TrainStep:
                     merged.lanes.extend(x.lanes)
             prog = prog[:k] + [t for t in tail if t[0] == 'wait'] + [('run', merged)]
         return prog
+
+    def _overlap(self, calls, lanes):
+        """Interleave the two independent chains the plans marked (nets.ModelAssembly: `T_begin` in the forward plan, `S_begin` /
+        `S_end` around the segmentation net's backward) -- schedule.overlap_chains.  Single replica, single stream."""
+        from . import schedule
+        tags = {c[2]: i for i, c in enumerate(calls) if c[0] == Plan.MARK}
+        if not all(t in tags for t in ('T_begin', 'S_begin', 'S_end')) or not hasattr(self.rt.lib, 't3d_pointmlp_bwd_r'):
+            return calls, lanes
+        tb, sb, se = tags['T_begin'], tags['S_begin'], tags['S_end']
+        if not tb < sb < se:
+            return calls, lanes
+        real = lambda cs: [c for c in cs if not c[0].startswith('__')]
+        if any(c[0] in (Plan.BUCKET, Plan.WAIT) for c in calls[tb:se]):
+            return calls, lanes
+        if self._sets is None:
+            self._sets = schedule.RiderSets(self.rt)
+        merged, self.schedule_report = schedule.overlap_chains(self.rt, real(calls[sb:se]), real(calls[tb:sb]), self._sets)
+        calls = calls[:tb] + merged + calls[se + 1:]
+        return calls, [0] * len(calls)
 
     # ---- execution ------------------------------------------------------------------------------------------------------------
     def _allreduce(self, i, async_op):
