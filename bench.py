@@ -45,6 +45,8 @@ def parse():
                     help='A = BASELINE configs[1] (the metric); boxpc / F = configs[2] / configs[3], informational')
     ap.add_argument('--no_graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--no_cpu_baseline', action='store_true')
+    ap.add_argument('--no_other_configs', action='store_true',
+                    help='skip the informational side runs of configs[2..4] (child processes, <= 20 steps each)')
     ap.add_argument('--cpu_steps', type=int, default=5)
     ap.add_argument('--cpu_one_thread', type=int, default=1, help='also time one step of the CPU baseline on a single thread')
     ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32',
@@ -269,8 +271,48 @@ def cpu_baseline(args, batch):
                       '(oracle/ref_torch.py; TF1 not installable)' % (max(args.cpu_steps, 5), args.batch_size, args.num_point, C, threads)}
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks as CHILD processes (torch.distributed.run) before this process has
+    touched the GPU, hand their one JSON line through, exit with their code.  (A process that has initialised the GPU must never be
+    replaced by exec on this pool; a child is fine.)"""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, T3D_BENCH_CHILD='1')
+    return subprocess.call(cmd, env=env)
+
+
+def other_configs(args):
+    """BASELINE.json configs[2], configs[3] (one replica) and configs[4] (one replica): <= 20 timed steps each in a child process of
+    this script (own Runtime, own hipGraph), reported beside the headline -- informational, never `value`."""
+    import subprocess
+    runs = [('boxpc', 'f32', []), ('F', 'f32', []), ('A', 'bf16', ['--batch_size', '128', '--num_point', '2048'])]
+    out = []
+    for wl, dt, extra in runs:
+        cmd = [sys.executable, os.path.abspath(__file__), '--workload', wl, '--dtype', dt, '--steps', '20', '--warmup', '5',
+               '--profile_steps', '2', '--no_cpu_baseline', '--no_other_configs'] + extra
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0'))
+            d = json.loads(r.stdout.strip().split('\n')[-1])
+            rf = d.get('roofline') or {}
+            out.append({'workload': d['config']['workload'], 'dtype': d['dtype'], 'value': d['value'], 'unit': d['unit'],
+                        'ms_per_step': d['ms_per_step'], 'steps': d['steps'],
+                        'roofline': {'kernel': rf.get('kernel'), 'bound': rf.get('bound'), 'frac': rf.get('frac'),
+                                     'avg_launch_us': rf.get('avg_launch_us')}})
+        except Exception as e:      # a failed side run must not cost the headline line
+            out.append({'workload': wl, 'dtype': dt, 'error': repr(e)[:200]})
+    return out
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -311,7 +353,7 @@ def main():
     # seg head's in-kernel dropout, forward, backward, TF-form Adam; data parallel: gradient buckets all-reduced beside the backward
     g, model, trainstep, loss_t = build_training_step(
         rt, args.workload, B, N, C, world=world, rank=rank, process_group=dist.group.WORLD if use_dist else None,
-        force_dist=use_dist and world == 1, flat_allreduce=os.environ.get('T3D_DP_FLAT', '0') == '1',
+        force_dist=use_dist and world == 1, flat_allreduce=os.environ.get('T3D_DP_FLAT', '1') == '1',
         use_hip_graph=not args.no_graph, inline_dropout=True, dropout_seed=1234, seed=0, dtype=args.dtype)
     loss_buf = lambda: loss_t
     batch = make_batch(B, N, C, seed=1234 + rank, boxpc=args.workload == 'boxpc')  # per-rank shard (weak scaling)
@@ -343,6 +385,12 @@ def main():
         t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if trainstep.dist:          # five more steps (every rank) with events around the bucket waits: the exposed all-reduce time
+        trainstep.time_waits = True
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        trainstep.time_waits = False
     loss = float(loss_buf().item())
     assert np.isfinite(loss), 'non-finite loss'
 
@@ -410,6 +458,10 @@ def main():
                 sys.stderr.write('%-52s x%d  %8.1f us  %6.1f TF/s  %6.0f GB/s algorithmic (%.2f of the HBM peak; %.1f us at 6.3 TB/s)\n'
                                  % (k, n_ // args.profile_steps, t_ / n_ * 1e6, f_ / (t_ / n_) / 1e12, b_ / (t_ / n_) / 1e9,
                                     b_ / (t_ / n_) / 1e9 / (HBM_PEAK_TBS * 1e3), b_ / 6.3e6))
+    others = None
+    default_workload = args.workload == 'A' and args.dtype == 'f32' and (B, N, C) == (32, 1024, 4)
+    if rank == 0 and world == 1 and default_workload and not args.no_other_configs:
+        others = other_configs(args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'A':
         cpu = cpu_baseline(args, batch)
 
@@ -425,7 +477,9 @@ def main():
                                                 if True in trainstep.cache else len(g.pre) + len(g.fwd) + len(g.bwd) + len(g.opt)),
                           'schedule': ({k: v for k, v in trainstep.schedule_report.items() if k != 'lines'}
                                        if trainstep.schedule_report else None), 'final_loss': loss},
-               'roofline': roofline, 'cpu_baseline': cpu}
+               'roofline': roofline, 'cpu_baseline': cpu, 'other_configs': others}
+        if trainstep.dist:
+            out['config']['dp'] = trainstep.dp_report()
     if dist is not None:
         dist.barrier()                        # rank 0 profiled its kernels meanwhile: every rank leaves together
         torch.cuda.synchronize()

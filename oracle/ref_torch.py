@@ -133,7 +133,7 @@ class Ctx:
         # Flip-aware gradient checks (tests/model_check.py): an fp32 implementation and this fp64 restatement can disagree on the
         # side of a ReLU input that is within fp32 rounding of zero, or on which of two near-equal rows is the max-pool's arg-max;
         # either moves every gradient below it by one element's contribution.  A test may therefore hand over the decisions the
-        # implementation under test actually took -- `forced_gates[scope]` (1 where its ReLU passed) and `forced_argmax[scope]`
+        # implementation under test actually took -- `forced_gates[scope]` (1 where its ReLU passed, 0 where not, -1 = not handed over) and `forced_argmax[scope]`
         # ((B, C) row index, -1 = keep the natural one) -- and the restatement differentiates THAT branch of the piecewise-linear
         # function; forward values move by the size of the disputed pre-activations (~1e-6).  `flips` counts the disagreements.
         self.forced_gates = {}
@@ -148,6 +148,14 @@ class Ctx:
         self.forced_mask = None      # (B, N) 0/1: the hard segmentation mask the implementation under test took (logit0 < logit1 with
         #                              the two logits within fp32 rounding of each other is the same kind of decision)
         self.flips = {}
+        # What a forced decision may cost: per site (numel, flips, worst margin, scale).  The margin of a flipped decision is THIS
+        # restatement's own distance from the boundary -- |post-batch-norm pre-activation| of a flipped ReLU gate, natural maximum
+        # minus the forced row's value of a flipped arg-max, |logit0 - logit1| of a flipped mask point -- and `scale` the magnitude
+        # of the tensor it is measured in.  An implementation that decides differently only where the decision is within rounding of
+        # the boundary has margins of ~1e-6 * scale and a handful of flips; one that gates, pools or masks WRONGLY on some subset
+        # shows margins of the order of the activations themselves.  tests/model_check.check_decision_margins bounds both, so the
+        # product cannot drag this oracle's gradient along a branch the reference would not take.
+        self.margins = {}
 
     def training_for(self, scope):
         for pre, val in self.is_training_override.items():
@@ -184,7 +192,12 @@ def _act(x, activation, ctx=None, scope=None):
     gate = ctx.forced_gates.get(scope) if ctx is not None else None
     if gate is not None and activation in ('relu', 'leaky_relu'):
         gate = torch.as_tensor(gate).reshape(x.shape).to(x.dtype)
-        ctx.flips[scope] = int(((x.detach() > 0).to(x.dtype) != gate).sum())
+        nat = (x.detach() > 0).to(x.dtype)
+        gate = torch.where(gate < 0, nat, gate)                  # -1: no decision handed over for this element
+        diff = nat != gate
+        ctx.flips[scope] = int(diff.sum())
+        ctx.margins[scope] = (x.numel(), int(diff.sum()), float(x.detach().abs()[diff].max()) if bool(diff.any()) else 0.0,
+                              float(x.detach().abs().max()))
         return x * gate if activation == 'relu' else x * (gate + 0.2 * (1 - gate))
     if activation == 'relu':
         return torch.relu(x)
@@ -252,7 +265,10 @@ def max_pool_points(x, ctx=None, scope=None):
     idx = torch.as_tensor(forced).reshape(nat.shape).to(nat.dtype)
     idx = torch.where(idx < 0, nat, idx)
     ctx.flips[scope + '#argmax'] = int((idx != nat).sum())
-    return torch.gather(x, 1, idx[:, None, :]).squeeze(1)
+    picked = torch.gather(x, 1, idx[:, None, :]).squeeze(1)
+    gap = (x.detach().max(dim=1).values - picked.detach())                 # >= 0: how far below the natural maximum the forced row is
+    ctx.margins[scope + '#argmax'] = (idx.numel(), int((idx != nat).sum()), float(gap.max()), float(x.detach().abs().max()))
+    return picked
 
 
 # ----------------------------------------------------------------------------------------------
@@ -289,7 +305,11 @@ def subtract_points_mean(pc, logits, ctx=None):
     mask = (logits[:, :, 0:1] < logits[:, :, 1:2]).to(pc.dtype)      # (B,N,1)
     if ctx is not None and ctx.forced_mask is not None:
         forced = torch.as_tensor(ctx.forced_mask).reshape(mask.shape).to(pc.dtype)
-        ctx.flips['mask'] = int((forced != mask).sum())
+        diff = forced != mask
+        ctx.flips['mask'] = int(diff.sum())
+        dl = (logits[:, :, 0:1] - logits[:, :, 1:2]).detach().abs()
+        ctx.margins['mask'] = (mask.numel(), int(diff.sum()), float(dl[diff].max()) if bool(diff.any()) else 0.0,
+                               float(logits.detach().abs().max()))
         mask = forced
     mask_count = mask.sum(dim=1, keepdim=True).expand(-1, -1, 3)
     xyz = pc[:, :, 0:3]
@@ -796,6 +816,7 @@ def model_a_forward_backward(P, batch, c, bn_decay_val=0.5, dtype=torch.float64,
         gl = torch.autograd.grad(loss, [Pl[k] for k in names], allow_unused=True)
         grads = {k: (g if g is not None else torch.zeros_like(Pl[k])) for k, g in zip(names, gl)}
     ep['__flips__'] = dict(ctx.flips)
+    ep['__margins__'] = dict(ctx.margins)
     return loss, ep, grads, ctx.ema_updates
 
 
@@ -824,6 +845,7 @@ def boxpc_forward_backward(P, batch, c, bn_decay_val=0.5, dtype=torch.float64, i
         gl = torch.autograd.grad(loss, [Pl[k] for k in names], allow_unused=True)
         grads = {k: (g if g is not None else torch.zeros_like(Pl[k])) for k, g in zip(names, gl)}
     ep['__flips__'] = dict(ctx.flips)
+    ep['__margins__'] = dict(ctx.margins)
     return loss, ep, grads, ctx.ema_updates
 
 
@@ -857,6 +879,7 @@ def stage_c_forward_backward(P, batch, c, train_classes, bn_decay_val=0.5, dtype
         gl = torch.autograd.grad(loss, [Pl[k] for k in names], allow_unused=True)
         grads = {k: (g if g is not None else torch.zeros_like(Pl[k])) for k, g in zip(names, gl)}
     ep['__flips__'] = dict(ctx.flips)
+    ep['__margins__'] = dict(ctx.margins)
     return loss, ep, grads, ctx.ema_updates
 
 

@@ -272,3 +272,11 @@ def test_operator_wrappers_called_one_by_one(is_training):
     max_pool2d, fully_connected as separate nodes, against the oracle's restatements of the same ops."""
     from op_surface_check import check_operator_surface
     assert check_operator_surface(_runtime(), is_training)
+
+
+@pytest.mark.parametrize('use_one_hot', [False, True])
+def test_operator_surface_takes_the_reference_inst_seg_call_sequence(use_one_hot):
+    """semisup_models.py:69-139 re-typed with `tf.` -> `api.`: ordinary conv2d + max_pool2d([num_point,1], 'VALID'), concat / tile of
+    the global feature, dropout, conv10 -- against oracle.v1_inst_seg."""
+    from op_surface_check import check_reference_inst_seg_call_sequence
+    assert check_reference_inst_seg_call_sequence(_runtime(), use_one_hot)

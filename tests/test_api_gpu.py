@@ -38,3 +38,8 @@ def test_is_training_placeholder_selects_train_and_eval_schedules_of_one_graph()
 @pytest.mark.parametrize('is_training', [True, False])
 def test_operator_wrappers_called_one_by_one(is_training):
     T.test_operator_wrappers_called_one_by_one(is_training)
+
+
+@pytest.mark.parametrize('use_one_hot', [False, True])
+def test_operator_surface_takes_the_reference_inst_seg_call_sequence(use_one_hot):
+    C.test_operator_surface_takes_the_reference_inst_seg_call_sequence(use_one_hot)

@@ -32,12 +32,19 @@ from .nets import Graph as _EngineGraph, Inputs, ModelAssembly, make_schedule
 _stack = []
 
 
+class Shape(tuple):
+    """tf.TensorShape as far as the reference uses it: indexable, and `.as_list()` (semisup_models.py:72)."""
+
+    def as_list(self):
+        return list(self)
+
+
 class Tensor:
     """Handle of a device buffer that holds a value after `Session.run` (the analogue of a tf.Tensor)."""
 
     def __init__(self, ctx, buf=None, shape=None, name=None, producer=None, field=None):
         self.ctx, self.buf, self.name, self.producer, self.field = ctx, buf, name, producer, field
-        self._shape = tuple(shape) if shape is not None else (tuple(buf.shape) if buf is not None else None)
+        self._shape = Shape(shape) if shape is not None else (Shape(buf.shape) if buf is not None else None)
 
     def get_shape(self):
         return self._shape
@@ -134,6 +141,156 @@ class Graph:
         return self.assembly
 
 
+# ---- the handful of tf.* graph functions the reference's sub-network bodies use between tf_util calls ------------------------------
+# (semisup_models.py:69-139: variable_scope, expand_dims, concat, tile, squeeze; 150-162, 184-185: multiply by the mask).  They build
+# LAZY handles -- a tiled global feature or a point-tensor/global concat never exists in memory; tf_util.conv2d recognises the handle
+# and emits the split form (per-point GEMM + one per-frustum FC as a row bias).
+class GlobalVec(Tensor):
+    """(B, 1, 1, C) per-frustum vector made of column blocks [(device buffer [B, >= n], n)] (pooled feature [+ one-hot])."""
+
+    def __init__(self, ctx, parts, name='global_vec'):
+        Tensor.__init__(self, ctx, None, (ctx.engine.B, 1, 1, sum(n for _, n in parts)), name)
+        self.parts = parts
+
+    def numpy(self):
+        return np.concatenate([b.detach().float().cpu().numpy()[:, :n] for b, n in self.parts], axis=1).reshape(self._shape)
+
+
+class TiledGlobal(Tensor):
+    """tf.tile(global, [1, num_point, 1, 1]): (B, N, 1, C), never materialised."""
+
+    def __init__(self, ctx, vec):
+        Tensor.__init__(self, ctx, None, (ctx.engine.B, ctx.engine.rpf, 1, vec.shape[-1]), 'tiled_global')
+        self.vec = vec
+
+
+class ConcatPointGlobal(Tensor):
+    """tf.concat(axis=3, values=[point tensor, tiled global]) (semisup_models.py:107-108), never materialised."""
+
+    def __init__(self, ctx, point, tiled):
+        Tensor.__init__(self, ctx, None, (ctx.engine.B, ctx.engine.rpf, 1, point.shape[-1] + tiled.shape[-1]), 'concat_point_global')
+        self.point, self.tiled = point, tiled
+
+
+class _VariableScope:
+    def __init__(self, name):
+        self.name = name
+
+
+@contextlib.contextmanager
+def variable_scope(name_or_scope, *args, **kwargs):
+    """tf.variable_scope: prefixes the `scope` of the tf_util layers built inside (variables <outer>/<scope>/weights, ...)."""
+    g = get_default_graph()
+    name = name_or_scope.name if isinstance(name_or_scope, _VariableScope) else (name_or_scope or '')
+    stack = g.__dict__.setdefault('_scope_stack', [])
+    stack.append(name)
+    try:
+        yield _VariableScope('/'.join(x for x in stack if x))
+    finally:
+        stack.pop()
+
+
+def scoped(scope):
+    """`scope` under the variable scopes currently open on the default graph."""
+    stack = get_default_graph().__dict__.get('_scope_stack', [])
+    return '/'.join([x for x in stack if x] + [scope])
+
+
+def _as_global_vec(ctx, t):
+    if isinstance(t, GlobalVec):
+        return t
+    n = t.shape[-1]
+    if t.buf is None or int(np.prod(t.shape)) != ctx.engine.B * n:
+        raise NotImplementedError('expected a per-frustum [B, ..., C] tensor, got %r' % (t,))
+    return GlobalVec(ctx, [(t.buf, n)], t.name)
+
+
+def expand_dims(t, axis=-1):
+    """tf.expand_dims on a handle: a pure shape change (the point cloud as a one-channel image [B,N,C,1]; a [B,C] vector as
+    [B,1,C] / [B,1,1,C])."""
+    shp = list(t.shape)
+    ax = axis if axis >= 0 else len(shp) + 1 + axis
+    shp.insert(ax, 1)
+    import copy
+    out = copy.copy(t)
+    out._shape = Shape(shp)
+    return out
+
+
+def squeeze(t, axis=None):
+    shp = [d for i, d in enumerate(t.shape) if not ((axis is None and d == 1) or (axis is not None and i in [a % len(t.shape) for a in axis]))]
+    import copy
+    out = copy.copy(t)
+    out._shape = Shape(shp)
+    return out
+
+
+def tile(t, multiples):
+    ctx = get_default_graph()
+    if list(multiples) != [1, ctx.engine.rpf, 1, 1] or len(t.shape) != 4 or t.shape[1] != 1:
+        raise NotImplementedError('tile: only a [B,1,1,C] global feature over the num_point axis (semisup_models.py:107)')
+    return TiledGlobal(ctx, _as_global_vec(ctx, t))
+
+
+def concat(values=None, axis=None, **kw):
+    """tf.concat(values, axis) / tf.concat(axis=, values=) for the two forms of semisup_models.py:101-108: per-frustum vectors along
+    the channel axis, and [point tensor, tiled global] along the channel axis."""
+    if isinstance(values, int) and isinstance(axis, (list, tuple)):      # TF 0.x argument order
+        values, axis = axis, values
+    ctx = get_default_graph()
+    vals = list(values)
+    if axis not in (3, -1) or len(vals) != 2:
+        raise NotImplementedError('concat: two tensors along the channel axis')
+    a, b = vals
+    if isinstance(b, TiledGlobal):
+        return ConcatPointGlobal(ctx, a, b)
+    va, vb = _as_global_vec(ctx, a), _as_global_vec(ctx, b)
+    return GlobalVec(ctx, va.parts + vb.parts)
+
+
+def multiply(x, y):
+    """tf.multiply(net, mask) in front of a max-pool (semisup_models.py:184-185, 240-241): the mask becomes the pooled layer's row
+    mask (the masked tensor itself is never written)."""
+    import copy
+    if hasattr(x, 'spec') and getattr(y, 'buf', None) is not None and int(np.prod(y.shape)) == x.ctx.engine.M:
+        out = copy.copy(x)
+        out.rowmask = y.buf
+        return out
+    raise NotImplementedError('multiply: a per-point tensor times the [B,N,1,1] mask')
+
+
+class nn:
+    """tf.nn.* activation functions as the `activation_fn` argument of the tf_util layers (tf_util.py:1321-1322)."""
+
+    @staticmethod
+    def relu(x):
+        raise NotImplementedError('api.nn.relu is an activation_fn marker for the tf_util layers')
+
+    @staticmethod
+    def leaky_relu(x, alpha=0.2):
+        raise NotImplementedError('api.nn.leaky_relu is an activation_fn marker for the tf_util layers')
+
+    @staticmethod
+    def tanh(x):
+        raise NotImplementedError('api.nn.tanh is an activation_fn marker for the tf_util layers')
+
+
+tanh = nn.tanh
+
+
+def activation_name(fn):
+    """'relu' / 'leaky_relu' / 'tanh' / None from the reference's activation_fn (a callable of this module's nn namespace, a torch /
+    numpy function of the same name, or already a string)."""
+    if fn is None or isinstance(fn, str):
+        return fn
+    if fn in (nn.relu, nn.leaky_relu, nn.tanh):
+        return {nn.relu: 'relu', nn.leaky_relu: 'leaky_relu', nn.tanh: 'tanh'}[fn]
+    name = getattr(fn, '__name__', '')
+    if name in ('relu', 'leaky_relu', 'tanh'):
+        return name
+    raise NotImplementedError('activation_fn %r: tf.nn.relu, tf.nn.leaky_relu, tf.tanh or None at every call site of the reference' % (fn,))
+
+
 def get_default_graph():
     if not _stack:
         _stack.append(Graph())
@@ -183,6 +340,12 @@ class AdamOptimizer:
         """var_list: iterable of scope prefixes (tf.get_collection(scope=...) regex-prefix semantics,
         train_semisup_adv.py:415-422) or None for every trainable variable."""
         ctx = loss.ctx
+        if ctx.assembly is None:
+            raise NotImplementedError(
+                'minimize: the loss was built from operator-level tf_util calls, which are a forward-only surface (launches go into '
+                'the forward schedule as they are called); the training step -- backward + Adam -- is emitted for graphs built from '
+                'the fused sub-networks (semisup_models.v1_inst_seg / v1_tnet / v1_box_est, semisup_v1_sunrgbd.get_semi_model, '
+                'boxpc_sunrgbd.get_model), whose variables and outputs are the same')
         sched = make_schedule(ctx.engine.B * self.world_size, self.lr, self.decay_step, self.decay_rate, beta1=self.b1,
                               beta2=self.b2)
         ctx.train_op = TrainOp(ctx, loss, list(var_list) if var_list is not None else None, sched)
@@ -203,7 +366,8 @@ class Session:
         self.dropout_seed = dropout_seed
         self.pg = process_group
         self.force_dist = (os.environ.get('T3D_FORCE_DIST', '0') == '1') if force_dist is None else bool(force_dist)
-        self.dp_flat = os.environ.get('T3D_DP_FLAT', '0') == '1'      # one all-reduce between backward and Adam (the A/B of the buckets)
+        self.dp_flat = os.environ.get('T3D_DP_FLAT', '1') == '1'      # one all-reduce between backward and Adam (default since round 3: the
+        #                                                                scheduled backward of step.TrainStep._overlap has no early bucket); 0: three buckets
         self.steps = {}
 
     # -- compilation ------------------------------------------------------------------------------------

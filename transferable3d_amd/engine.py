@@ -430,6 +430,7 @@ class PointLayer:
             a.pmax, a.pmin, a.pamax, a.pamin = fptr(self.pmax), fptr(self.pmin), iptr(self.pamax), iptr(self.pamin)
         a.M, a.K, a.N, a.rows_per_frustum = self.M, self.K, self.NA, g.rpf
         plan.add('t3d_pointmlp_fwd', a)
+        self._fwd_args, self._fin_args = a, None
         if not self.bn:
             self.out = ActSpec(self.y, self.NA, self.N, 0, None, None, False, producer=self)
             return self.out
@@ -443,8 +444,32 @@ class PointLayer:
             f.pool_B, f.pool_tiles_per_frustum = g.B, g.rpf // TILE
             f.pooled, f.ld_pooled, f.argidx, f.ysel = fptr(self.pooled), self.N, iptr(self.argidx), fptr(self.ysel)
         plan.add('t3d_bn_fwd_finalize', f)
+        self._fin_args = f
         self.out = None if self.gram else ActSpec(self.y, self.N, self.N, 0, self.scale, self.shift, True, producer=self)
         return self.out
+
+    def enable_pool(self, rowmask=None):
+        """Turn an already-emitted batch-normed layer into one that ALSO yields its global max-pool over the points: the recorded
+        argument structs of its GEMM (per-tile max / min / arg partials in the epilogue) and of its finalize (the pick) are
+        completed in place.  This is how tf_util.max_pool2d(net, [num_point, 1]) after an ordinary tf_util.conv2d gets the fused
+        form (the reference decides at the max_pool2d call, semisup_models.py:96; the launch schedule is not captured before the
+        first Session.run, so the structs are still open)."""
+        g, rt = self.g, self.g.rt
+        assert self.bn and self._fin_args is not None and self.NA == self.N, 'enable_pool: a batch-normed layer with >= 64 channels'
+        if not self.pool:
+            T, N, B = self.T, self.N, g.B
+            self.pmax, self.pmin = rt.zeros(T, N), rt.zeros(T, N)
+            self.pamax, self.pamin = rt.zeros(T, N, dtype=torch.int32), rt.zeros(T, N, dtype=torch.int32)
+            self.pooled, self.argidx, self.ysel = rt.zeros(B, N), rt.zeros(B, N, dtype=torch.int32), rt.zeros(B, N)
+            self.pool = True
+        a, f = self._fwd_args, self._fin_args
+        self.rowmask = rowmask
+        a.rowmask = fptr(rowmask)
+        a.pmax, a.pmin, a.pamax, a.pamin = fptr(self.pmax), fptr(self.pmin), iptr(self.pamax), iptr(self.pamin)
+        f.pool_pmax, f.pool_pmin, f.pool_pamax, f.pool_pamin = fptr(self.pmax), fptr(self.pmin), iptr(self.pamax), iptr(self.pamin)
+        f.pool_B, f.pool_tiles_per_frustum = g.B, g.rpf // TILE
+        f.pooled, f.ld_pooled, f.argidx, f.ysel = fptr(self.pooled), self.N, iptr(self.argidx), fptr(self.ysel)
+        return self.pooled
 
     # ---- backward ------------------------------------------------------------------------------
     def _ensure_bwd_buffers(self):

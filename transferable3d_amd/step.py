@@ -40,6 +40,8 @@ class TrainStep:
         self.cache = {}            # generate_masks -> list of program items with captured graphs
         self.n_runs = 0
         self._capture_stream = None
+        self.time_waits = False      # bench.py: events around the bucket waits of the host-issued program
+        self._wait_events = []
         self._sets = None            # schedule.RiderSets of the scheduled program (device op tables, barrier words)
         self.schedule_report = None
 
@@ -67,7 +69,7 @@ class TrainStep:
             k = next((i for i, c in enumerate(calls) if c[0] == 't3d_adam_tf_step'), len(calls))
             calls[k:k] = [(Plan.BUCKET, lambda s: 0, 0), (Plan.WAIT, lambda s: 0, 0)]
             lanes[k:k] = [0, 0]
-        if not self.dist and not two:
+        if not two:       # (data parallel: the flat form -- no bucket marker inside the backward -- takes the scheduled program too)
             calls, lanes = self._overlap(calls, lanes)
         prog, cur = [], Plan(self.rt)
         cur.two_streams = two
@@ -145,9 +147,16 @@ class TrainStep:
             elif kind == 'allreduce':
                 pending[x] = self._allreduce(x, async_op=self.on_gpu)
             else:
+                ev = None
+                if self.time_waits and self.on_gpu:      # how long the launch stream stands still for this bucket (exposed all-reduce)
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record()
                 for w in pending.pop(x, []):
                     if w is not None:
                         w.wait()           # GPU: the current stream waits for the collective; the host does not block
+                if ev is not None:
+                    ev[1].record()
+                    self._wait_events.append(ev)
         for ws in pending.values():
             for w in ws:
                 if w is not None:
@@ -213,6 +222,24 @@ class TrainStep:
             ent['graphs'][0].replay()
             return
         self._run_program(ent['cprog'], ent['graphs'])
+
+    def dp_report(self):
+        """How the data-parallel step is issued, and -- from the events `time_waits` put around the bucket waits -- the time per step
+        the launch stream stood still waiting for an all-reduce."""
+        mode = 'flat' if len(self._buckets()) == 1 else 'bucketed'
+        if self.one_graph:
+            mode += ', collectives captured in ONE graph (T3D_DP_ONE_GRAPH=%s)' % os.environ.get('T3D_DP_ONE_GRAPH', '0')
+        else:
+            mode += ', host-issued collectives between graph segments'
+        exposed = None
+        if self._wait_events:
+            torch.cuda.synchronize()
+            n_wait = max(1, sum(1 for kind, _ in self.cache[True]['prog'] if kind == 'wait'))
+            steps = max(1, len(self._wait_events) // n_wait)
+            exposed = sum(a.elapsed_time(b) for a, b in self._wait_events) * 1e3 / steps
+        return {'mode': mode, 'world': self.world, 'gradient_buckets': len(self._buckets()),
+                'bucket_floats': [sum(n for _, n in b) for b in self._buckets()],
+                'exposed_allreduce_us_per_step': exposed}
 
     def n_launches(self):
         return sum(len(p) for p in ([self.pre] if self.pre is not None else []) + [self.fwd] + ([self.bwd, self.opt] if self.train else []))

@@ -5,8 +5,8 @@
 Semantics that differ from an eager op library, all consequences of fusing ("lazy tensors"):
   * conv2d returns a LAZY activation: the layer writes its raw matmul output and per-tile statistics; batch-norm
     and ReLU are applied by whichever op consumes it.
-  * a global max-pool over the points is an epilogue of the producing conv2d, so it must be requested there
-    (`pool_over_points=True`, optional `rowmask`); `max_pool2d` then just returns that pooled tensor.
+  * a global max-pool over the points is an epilogue of the producing conv2d: `max_pool2d(net, [num_point, 1])` -- the reference's
+    call -- switches it on in that layer's recorded launches (PointLayer.enable_pool) and returns the pooled tensor.
   * dropout / batch_norm_for_conv2d / batch_norm_for_fc exist as nodes of their own (small launches, or lazy scale/shift fused
     into the consumer); on the hot path they are parts of the fused layers.
 Ops built here go into the graph's forward schedule (forward-only surface); the training step is emitted by the fused
@@ -59,16 +59,40 @@ def conv2d(inputs, num_output_channels, kernel_size, scope, stride=[1, 1], paddi
            is_training=None, pool_over_points=False, rowmask=None):
     """2-D convolution with a 1x1 (or [1,D] over a one-channel image) kernel == the per-point shared MLP layer
     (tf_util.py:1258-1323).  bn=True: batch-norm statistics in the GEMM's epilogue, batch-norm + ReLU applied by whichever op
-    consumes the result.  bn=False (tf_util.py:1316 skipped): the bare convolution + bias, activation_fn None or 'relu' (applied on
-    load by the consumer); a following batch_norm_for_conv2d turns it into the bn=True form.  Forward-only on this surface: the
-    training step of the hot path is emitted by the fused sub-networks (semisup_models)."""
+    consumes the result.  bn=False (tf_util.py:1316 skipped): the bare convolution + bias, activation_fn None or relu (applied on
+    load by the consumer); a following batch_norm_for_conv2d turns it into the bn=True form.  `activation_fn`: api.nn.relu (the
+    reference's default tf.nn.relu), None, or the strings.  `inputs` may be the lazy concat of a point tensor with a tiled
+    per-frustum vector (api.concat of api.tile, semisup_models.py:107-108): the layer is then emitted in its split form -- a
+    per-point GEMM on the point part plus ONE [B, Cg] x [Cg, N] product added as a per-frustum row bias -- over the one weight
+    variable <scope>/weights [1,1,Cp+Cg,N] the reference has.  A following max_pool2d(net, [num_point,1]) fuses into this layer
+    (PointLayer.enable_pool); `pool_over_points` / `rowmask` request that at build time (the fused sub-networks' own use).
+    Forward-only on this surface: the training step of the hot path is emitted by the fused sub-networks (semisup_models)."""
     ctx = api.get_default_graph()
+    scope = api.scoped(scope)
+    activation_fn = api.activation_name(activation_fn)
     if list(stride) != [1, 1] or data_format != 'NHWC' or not use_xavier or weight_decay is not None:
         raise NotImplementedError('conv2d: only stride 1, NHWC, xavier init, no weight decay are on the hot path')
     if activation_fn not in ('relu', None) or (bn and activation_fn != 'relu'):
         raise NotImplementedError('conv2d: activation_fn is tf.nn.relu or None at every call site of the reference')
-    spec = _as_spec(ctx, inputs)
     kh, kw = kernel_size
+    if isinstance(inputs, api.ConcatPointGlobal):
+        if not bn or (kh, kw) != (1, 1) or pool_over_points:
+            raise NotImplementedError('conv2d on a [point | tiled global] concat: the batch-normed 1x1 form of semisup_models.py:111')
+        e, vs = ctx.engine, ctx.engine.vars
+        pspec, parts = _as_spec(ctx, inputs.point), inputs.tiled.vec.parts
+        if len(parts) > 2:
+            raise NotImplementedError('conv2d: a tiled global vector of at most two blocks (pooled feature [+ one-hot])')
+        Kp, Kg = pspec.K, sum(n for _, n in parts)
+        N = num_output_channels
+        w = vs.xavier(scope + '/weights', (1, 1, Kp + Kg, N), Kp + Kg, N).view(Kp + Kg, N)
+        layer = PointLayer(e, scope, Kp, N, w=w[0:Kp], w_name=scope + '/weights', w_row0=0, gram=False)
+        glob = FcLayer(e, scope + '/global', parts[0][1], N, bn=False, act=None, K2=parts[1][1] if len(parts) == 2 else 0, w=w[Kp:],
+                       bias=None)
+        rb = glob.fwd(e.fwd, parts[0][0], parts[0][0].shape[-1], bool(is_training),
+                      in2=parts[1][0] if len(parts) == 2 else None, ld_in2=parts[1][0].shape[-1] if len(parts) == 2 else 0)
+        out = layer.fwd(e.fwd, pspec, bool(is_training), rowbias=rb)
+        return PointTensor(ctx, out, layer)
+    spec = _as_spec(ctx, inputs)
     if kh != 1 or kw not in (1, spec.K):
         raise NotImplementedError('conv2d: kernel must be [1,1] or [1,D]')
     if not bn and pool_over_points:
@@ -83,18 +107,25 @@ def conv2d(inputs, num_output_channels, kernel_size, scope, stride=[1, 1], paddi
 
 
 def max_pool2d(inputs, kernel_size, scope, stride=[2, 2], padding='VALID'):
-    """Global max over the point axis of a conv2d output built with pool_over_points=True -> (B,1,1,C)."""
+    """tf_util.max_pool2d(net, [num_point, 1], padding='VALID', scope=...) (tf_util.py:1501-1524 at semisup_models.py:96, 188, 244,
+    375): the global max over the point axis -> (B,1,1,C).  The pool is an epilogue of the conv2d that produced `inputs` (per-tile
+    max / min / arg partials, picked in the batch-norm finalize): it is switched on in that layer's recorded launches here, when the
+    reference asks for it.  `inputs` multiplied by the mask first (api.multiply): the mask becomes the pool's row mask."""
     layer = getattr(inputs, 'layer', None)
     ctx = api.get_default_graph()
-    if layer is None or not layer.pool or kernel_size[0] != ctx.engine.rpf or kernel_size[1] != 1:
-        raise NotImplementedError('max_pool2d: only the global pool over all N points, fused into the producing '
-                                  'conv2d(pool_over_points=True)')
-    return api.Tensor(ctx, layer.pooled, (ctx.engine.B, 1, 1, layer.N), scope, producer=layer)
+    if layer is None or not layer.bn or kernel_size[0] != ctx.engine.rpf or kernel_size[1] != 1 or padding != 'VALID':
+        raise NotImplementedError('max_pool2d: only the global pool over all N points of a batch-normed conv2d output '
+                                  '(every call site of the reference)')
+    mask = getattr(inputs, 'rowmask', None)
+    if not layer.pool or mask is not None:
+        layer.enable_pool(rowmask=mask)
+    return api.Tensor(ctx, layer.pooled, (ctx.engine.B, 1, 1, layer.N), api.scoped(scope), producer=layer)
 
 
 def fully_connected(inputs, num_outputs, scope, use_xavier=True, stddev=1e-3, weight_decay=None, activation_fn='relu',
                     bn=False, bn_decay=None, is_training=None):
     ctx = api.get_default_graph()
+    scope, activation_fn = api.scoped(scope), api.activation_name(activation_fn)
     K = inputs.shape[-1]
     layer = FcLayer(ctx.engine, scope, K, num_outputs, bn=bn, act=activation_fn)
     out = layer.fwd(ctx.engine.fwd, inputs.buf, K, bool(is_training))
@@ -110,6 +141,7 @@ def dropout(inputs, is_training, scope, keep_prob=0.5, noise_shape=None):
     if noise_shape is not None:
         raise NotImplementedError('dropout: noise_shape is None at every call site of the reference')
     ctx = api.get_default_graph()
+    scope = api.scoped(scope)
     e = ctx.engine
     if isinstance(inputs, PointTensor):
         spec = inputs.spec
@@ -139,6 +171,7 @@ def batch_norm_for_conv2d(inputs, is_training, bn_decay, scope, data_format='NHW
     if not isinstance(inputs, PointTensor) or inputs.layer is None or inputs.layer.bn or inputs.spec.relu:
         raise NotImplementedError('batch_norm_for_conv2d follows conv2d(bn=False, activation_fn=None)')
     ctx = api.get_default_graph()
+    scope = api.scoped(scope)
     e, lay, vs = ctx.engine, inputs.layer, ctx.engine.vars
     N = lay.N
     if isinstance(bn_decay, (int, float)):
@@ -163,6 +196,7 @@ def batch_norm_for_fc(inputs, is_training, bn_decay, scope):
     """Batch-norm over the B rows of a [B,N] tensor (tf_util.py:1666-1677) as a node of its own: an identity-weight t3d_fc_fwd
     (variables <scope>/{beta,gamma,moving_mean,moving_variance}), no activation."""
     ctx = api.get_default_graph()
+    scope = api.scoped(scope)
     e = ctx.engine
     if isinstance(bn_decay, (int, float)):
         e.hyper[2] = float(bn_decay)
