@@ -133,9 +133,9 @@ def gemm_work(name, a):
     flops = 2.0 * a.M * a.K * a.N
     if name == 't3d_pointmlp_fwd':
         by = es(a.a.dtype) * a.M * a.K + es(a.dtype) * (a.K * a.N + (0 if _null(a.y) else a.M * a.N))
-        if a.dtype == 1 and a.a.dtype == 0 and a.K <= 4 and not _null(a.y) and _null(a.pmax) and _null(a.rowbias) and a.N in (64, 128) \
+        if a.a.dtype == 0 and a.K <= 4 and not _null(a.y) and _null(a.pmax) and _null(a.rowbias) and a.N in (64, 128) \
                 and os.environ.get('T3D_FWD_TINYK', '1') != '0':
-            return 'k_pointmlp_fwd_tinyk<%d>' % a.N, flops, by      # first layer of a net, bf16: the register kernel
+            return 'k_pointmlp_fwd_tinyk<%d>' % a.N, flops, by      # first layer of a net: the register kernel (bf16 and fp32)
         if a.dtype == 1 and a.a.dtype == 1 and _null(a.a.sub) and (a.K in (64, 128) or (a.K == 256 and os.environ.get('T3D_FWD_RES', '1') == '2')) and os.environ.get('T3D_FWD_RES', '1') != '0':
             return 'k_pointmlp_fwd_res<%d,%d>' % (128 if a.N % 128 == 0 else 64, a.K // 64), flops, by      # activation-resident bf16 forward
         if a.dtype == 0 and os.environ.get('T3D_FWD_POOL', '1') != '0' and _null(a.y) and not _null(a.pmax) and _null(a.a.sub) and a.K == 128 and \

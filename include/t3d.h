@@ -890,7 +890,15 @@ int t3d_dropout_mask(float* mask, int64_t n, float keep_prob, uint32_t seed, con
  * Same arguments, same results (bit for bit) as the two stand-alone calls; what is saved is one kernel boundary (~3-5 us).
  * Kinds: t3d_bn_bwd_finalize (up to 512 row tiles), t3d_fc_bwd, t3d_fc_dinput, t3d_dy_colsum. */
 enum { T3D_SMALL_BN_BWD_FINALIZE = 1, T3D_SMALL_FC_BWD = 2, T3D_SMALL_FC_DINPUT = 3, T3D_SMALL_DY_COLSUM = 4,
-       T3D_SMALL_BN_FWD_FINALIZE = 5, T3D_SMALL_FC_FWD = 6 };      /* 5, 6: rider sets only */
+       T3D_SMALL_BN_FWD_FINALIZE = 5, T3D_SMALL_FC_FWD = 6, T3D_SMALL_POOL_BWD_MID = 7 };      /* 5 .. 7: rider sets only */
+/* the arguments of t3d_pool_bwd_mid as a struct (kind 7: a WIDE rider -- hundreds of workgroups, alone in its set, no barrier) */
+typedef struct {
+  const float* slab_base;
+  float* grad_base;
+  const t3d_slab_desc* table_dev;
+  int n_tensors, max_numel;
+  t3d_pool_sparse_rows_args sparse;
+} t3d_pool_bwd_mid_args;
 typedef struct {
   int kind;
   int depends;            /* rider sets: 1 = reads what the PREVIOUS op of its set wrote (a barrier among the set's workgroups goes in
@@ -902,6 +910,7 @@ typedef struct {
     t3d_dy_colsum_args dy_colsum;
     t3d_bn_fwd_finalize_args bn_fwd;
     t3d_fc_fwd_args fc_fwd;
+    t3d_pool_bwd_mid_args mid;
   } u;
 } t3d_small_op;
 int t3d_small_pair(const t3d_small_op* a, const t3d_small_op* b, t3d_stream_t stream);
@@ -915,7 +924,8 @@ int t3d_small_pair(const t3d_small_op* a, const t3d_small_op* b, t3d_stream_t st
  * workgroups behind.  An op with `depends` waits for its predecessor behind a barrier among the rider workgroups (agent-scope
  * release / acquire; the GEMM's workgroups never wait).  Results are bit-identical to the stand-alone launches of the same ops.
  *   ops        the set, in chain order (passed to the kernel by value: at most T3D_RIDER_MAX_OPS of them)
- *   n_wg       rider workgroups (<= 32) and
+ *   n_wg       rider workgroups (<= 32; a set that is ONE t3d_pool_bwd_mid -- slab reduction + sparse arg-max rows of a pooled layer's
+ *              backward, hundreds of latency-bound workgroups that use a fraction of the chip -- gets one workgroup per block) and
  *   lds_bytes  dynamic LDS the rider bodies need: both filled in by t3d_riders_plan
  *   sync       DEVICE, 2 * T3D_RIDER_MAX_OPS + 2 zero-initialised 32-bit words owned by this set (self-resetting: graph replays need
  *              no memset); the last but one word is set to 1 if a barrier ever gave up waiting (poisoned state; results invalid)

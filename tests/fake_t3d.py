@@ -1226,7 +1226,8 @@ class FakeLib:
     # ---- riders (t3d.h: small ops of one chain inside a GEMM launch of an independent chain): by specification the stand-alone
     # calls of the set's ops in order, then the GEMM -- in either order, the two do not depend on each other
     _RIDER = {1: ('t3d_bn_bwd_finalize', 'bn_bwd'), 2: ('t3d_fc_bwd', 'fc_bwd'), 3: ('t3d_fc_dinput', 'fc_dinput'),
-              4: ('t3d_dy_colsum', 'dy_colsum'), 5: ('t3d_bn_fwd_finalize', 'bn_fwd'), 6: ('t3d_fc_fwd', 'fc_fwd')}
+              4: ('t3d_dy_colsum', 'dy_colsum'), 5: ('t3d_bn_fwd_finalize', 'bn_fwd'), 6: ('t3d_fc_fwd', 'fc_fwd'),
+              7: ('t3d_pool_bwd_mid', 'mid')}
 
     def t3d_riders_plan(self, r):
         rs = _struct(r)
@@ -1237,6 +1238,12 @@ class FakeLib:
             if o.kind not in self._RIDER:
                 return -1
             u = getattr(o.u, self._RIDER[o.kind][1])
+            if o.kind == 7:
+                if rs.n_ops != 1:
+                    return -1
+                if 128 * 128 * 4 + (4 * u.sparse.N + 128) * 4 > 76 * 1024:
+                    return -2
+                continue
             if o.kind in (2, 3, 6) and u.B > 32:
                 return -2
             if (o.kind == 5 and u.n_tiles > 512) or (o.kind == 1 and u.psum_dz and u.n_tiles > 512):
@@ -1251,7 +1258,11 @@ class FakeLib:
         for k in range(rs.n_ops):
             o = rs.ops[k]
             fn, field = self._RIDER[o.kind]
-            rc = getattr(self, fn)(C.byref(getattr(o.u, field)), stream)
+            if o.kind == 7:
+                m = o.u.mid
+                rc = self.t3d_pool_bwd_mid(m.slab_base, m.grad_base, m.table_dev, m.n_tensors, m.max_numel, C.byref(m.sparse), stream)
+            else:
+                rc = getattr(self, fn)(C.byref(getattr(o.u, field)), stream)
             if rc:
                 return rc
         return 0

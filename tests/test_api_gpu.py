@@ -42,4 +42,4 @@ def test_operator_wrappers_called_one_by_one(is_training):
 
 @pytest.mark.parametrize('use_one_hot', [False, True])
 def test_operator_surface_takes_the_reference_inst_seg_call_sequence(use_one_hot):
-    C.test_operator_surface_takes_the_reference_inst_seg_call_sequence(use_one_hot)
+    T.test_operator_surface_takes_the_reference_inst_seg_call_sequence(use_one_hot)

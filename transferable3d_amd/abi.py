@@ -175,8 +175,9 @@ class SegHeadArgs(C.Structure):
 
 
 SMALL_KIND = {'t3d_bn_bwd_finalize': 1, 't3d_fc_bwd': 2, 't3d_fc_dinput': 3, 't3d_dy_colsum': 4}      # t3d.h T3D_SMALL_* (t3d_small_pair)
-RIDER_KIND = dict(SMALL_KIND, t3d_bn_fwd_finalize=5, t3d_fc_fwd=6)                                      # kinds a rider set takes
-RIDER_FIELD = {1: 'bn_bwd', 2: 'fc_bwd', 3: 'fc_dinput', 4: 'dy_colsum', 5: 'bn_fwd', 6: 'fc_fwd'}
+RIDER_KIND = dict(SMALL_KIND, t3d_bn_fwd_finalize=5, t3d_fc_fwd=6, t3d_pool_bwd_mid=7)                  # kinds a rider set takes
+RIDER_FIELD = {1: 'bn_bwd', 2: 'fc_bwd', 3: 'fc_dinput', 4: 'dy_colsum', 5: 'bn_fwd', 6: 'fc_fwd', 7: 'mid'}
+RIDER_WIDE = ('t3d_pool_bwd_mid',)      # hundreds of workgroups, alone in its set
 
 
 class WeakLossArgs(C.Structure):
@@ -253,9 +254,14 @@ class AnchorRegBwdArgs(C.Structure):
 VP = C.c_void_p
 # name -> argtypes.  Struct entry points take (const args*, stream).
 
+class PoolBwdMidArgs(C.Structure):
+    _fields_ = [('slab_base', F), ('grad_base', F), ('table_dev', C.POINTER(SlabDesc)), ('n_tensors', i32), ('max_numel', i32),
+                ('sparse', PoolSparseRowsArgs)]
+
+
 class SmallOpU(C.Union):
     _fields_ = [('bn_bwd', BnBwdFinalizeArgs), ('fc_bwd', FcBwdArgs), ('fc_dinput', FcDinputArgs), ('dy_colsum', DyColsumArgs),
-                ('bn_fwd', BnFwdFinalizeArgs), ('fc_fwd', FcFwdArgs)]
+                ('bn_fwd', BnFwdFinalizeArgs), ('fc_fwd', FcFwdArgs), ('mid', PoolBwdMidArgs)]
 
 
 class SmallOp(C.Structure):

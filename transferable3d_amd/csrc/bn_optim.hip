@@ -32,74 +32,6 @@ __global__ __launch_bounds__(GR * CH) void k_bn_bwd_finalize(const t3d_bn_bwd_fi
 
 __global__ __launch_bounds__(256) void k_dy_colsum(const t3d_dy_colsum_args p) { dy_colsum_body(p, blockIdx.x, threadIdx.x); }
 
-// every slab region starts 16-byte aligned and numel % 4 == 0 for the engine's allocations (float4 path); anything
-// else takes the scalar path.  A block = 32 float4 elements x 8 slab groups: thread (e, g) sums slabs g, g+8, ... with
-// four loads in flight, the 8 group sums are combined through LDS in a fixed order.  Splitting the slab chain over
-// threads is what keeps the many-slab / few-element tensors (64x64 layers with 256 slabs) from being one long latency
-// chain while the rest of the chip idles.
-__device__ __forceinline__ void reduce_slabs_body(const float* __restrict__ slab_base, float* __restrict__ grad_base,
-                                                  const t3d_slab_desc* __restrict__ table, float4 (*part)[32], int bx, int by,
-                                                  int gx) {
-  const t3d_slab_desc d = table[by];
-  const bool vec = ((d.slab_off | d.grad_off | (int64_t)d.numel) & 3) == 0;
-  const int n4 = vec ? (d.numel >> 2) : 0;
-  const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  for (int e0 = bx * 32; e0 < n4; e0 += gx * 32) {
-    const int e = e0 + el;
-    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
-    if (e < n4) {
-      const float4* s = reinterpret_cast<const float4*>(slab_base + d.slab_off) + e;
-      int k = grp;
-      for (; k + 56 < d.n_slabs; k += 64) {            // eight slabs in flight per thread
-        float4 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = s[(size_t)(k + 8 * u) * n4];
-#pragma unroll
-        for (int u = 0; u < 8; u += 4) {
-          a0.x += v[u].x; a0.y += v[u].y; a0.z += v[u].z; a0.w += v[u].w;
-          a1.x += v[u + 1].x; a1.y += v[u + 1].y; a1.z += v[u + 1].z; a1.w += v[u + 1].w;
-          a2.x += v[u + 2].x; a2.y += v[u + 2].y; a2.z += v[u + 2].z; a2.w += v[u + 2].w;
-          a3.x += v[u + 3].x; a3.y += v[u + 3].y; a3.z += v[u + 3].z; a3.w += v[u + 3].w;
-        }
-      }
-      for (; k + 24 < d.n_slabs; k += 32) {
-        const float4 v0 = s[(size_t)(k + 0) * n4], v1 = s[(size_t)(k + 8) * n4], v2 = s[(size_t)(k + 16) * n4],
-                     v3 = s[(size_t)(k + 24) * n4];
-        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
-        a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
-        a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
-        a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
-      }
-      for (; k < d.n_slabs; k += 8) {
-        const float4 v = s[(size_t)k * n4];
-        a0.x += v.x; a0.y += v.y; a0.z += v.z; a0.w += v.w;
-      }
-    }
-    float4 r;
-    r.x = (a0.x + a1.x) + (a2.x + a3.x); r.y = (a0.y + a1.y) + (a2.y + a3.y);
-    r.z = (a0.z + a1.z) + (a2.z + a3.z); r.w = (a0.w + a1.w) + (a2.w + a3.w);
-    part[grp][el] = r;
-    __syncthreads();
-    if (grp == 0 && e < n4) {
-      float4 t = part[0][el];
-#pragma unroll
-      for (int g = 1; g < 8; ++g) {
-        const float4 u = part[g][el];
-        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
-      }
-      reinterpret_cast<float4*>(grad_base + d.grad_off)[e] = t;
-    }
-    __syncthreads();
-  }
-  if (!vec) {
-    for (int e = bx * blockDim.x + threadIdx.x; e < d.numel; e += gx * blockDim.x) {
-      float acc = 0.f;
-      for (int k = 0; k < d.n_slabs; ++k) acc += slab_base[d.slab_off + (size_t)k * d.numel + e];
-      grad_base[d.grad_off + e] = acc;
-    }
-  }
-}
-
 __global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ slab_base, float* __restrict__ grad_base,
                                                       const t3d_slab_desc* __restrict__ table) {
   __shared__ float4 part[8][32];

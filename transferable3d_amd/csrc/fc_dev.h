@@ -198,7 +198,7 @@ __device__ __forceinline__ void fc_fwd_body(const t3d_fc_fwd_args& p, float* sm,
     f32x16 acc[V][RBT];
     RowSrc src{p.in, p.ld_in, p.K, p.in2, p.ld_in2, p.K2, p.B};
 #pragma unroll
-    for (int v = 0; v < V; ++v) { wave_gemm<false, RBT, (NWP < NW ? 8 : 0)>(acc[v], src, p.w, p.N, p.K + p.K2, c0, nvalid, pw + NWP * v, lane); if (V > 1) __builtin_amdgcn_sched_barrier(0); }
+    for (int v = 0; v < V; ++v) { wave_gemm<false, RBT, (NWP < NW ? 6 : 0)>(acc[v], src, p.w, p.N, p.K + p.K2, c0, nvalid, pw + NWP * v, lane); if (V > 1) __builtin_amdgcn_sched_barrier(0); }
     FC_MARK(1);
     reduce_tiles<RBT, NWP>(acc, sm, y);
   } else {                       // identity: a standalone batch-norm / dropout node on a [B,N] tensor
@@ -309,7 +309,7 @@ __device__ __forceinline__ void fc_bwd_body(const t3d_fc_bwd_args& p, float* sm,
     f32x16 acc[V][RBT];
     RowSrc src{p.dy_next, p.N_next, p.N_next, nullptr, 0, 0, p.B};
 #pragma unroll
-    for (int v = 0; v < V; ++v) { wave_gemm<true, RBT, (NWP < NW ? 8 : 0)>(acc[v], src, p.w_next, p.N_next, p.N_next, c0, nvalid, pw + NWP * v, lane); if (V > 1) __builtin_amdgcn_sched_barrier(0); }
+    for (int v = 0; v < V; ++v) { wave_gemm<true, RBT, (NWP < NW ? 6 : 0)>(acc[v], src, p.w_next, p.N_next, p.N_next, c0, nvalid, pw + NWP * v, lane); if (V > 1) __builtin_amdgcn_sched_barrier(0); }
     reduce_tiles<RBT, NWP>(acc, sm, gout);
   }
 
@@ -444,7 +444,7 @@ __device__ __forceinline__ void fc_dinput_body(const t3d_fc_dinput_args& p, floa
   f32x16 acc[V][RBT];
   RowSrc src{p.dy, p.N, p.N, nullptr, 0, 0, p.B};
 #pragma unroll
-  for (int v = 0; v < V; ++v) wave_gemm<true, RBT, (NWP < NW ? 8 : 0)>(acc[v], src, p.w, p.N, p.N, c0, nvalid, pw + NWP * v, lane);
+  for (int v = 0; v < V; ++v) wave_gemm<true, RBT, (NWP < NW ? 6 : 0)>(acc[v], src, p.w, p.N, p.N, c0, nvalid, pw + NWP * v, lane);
   float val[V][NVAL];
   reduce_tiles<RBT, NWP>(acc, sm, val);
   const bool cok = c < p.K;

@@ -50,18 +50,27 @@ __global__ __launch_bounds__(RIDER_NT) void k_riders(const t3d_rider_set r) {
 extern "C" int t3d_riders_plan(t3d_rider_set* r) {
   if (!r || r->n_ops <= 0 || r->n_ops > T3D_RIDER_MAX_OPS) return T3D_ERR_ARG;
   int m = 1;
+  size_t lds = 0;
   for (int i = 0; i < r->n_ops; ++i) {
     const int nb = rider_op_blocks(r->ops[i]);
-    if (nb <= 0) return r->ops[i].kind >= 1 && r->ops[i].kind <= 6 ? T3D_ERR_SHAPE : T3D_ERR_ARG;
+    if (nb <= 0) return r->ops[i].kind >= 1 && r->ops[i].kind <= 7 ? T3D_ERR_SHAPE : T3D_ERR_ARG;
+    if (r->ops[i].kind == T3D_SMALL_POOL_BWD_MID && r->n_ops != 1) return T3D_ERR_ARG;      // a wide rider is alone in its set
     if (nb > m) m = nb;
+    const size_t l = rider_op_lds(r->ops[i]);
+    if (l > lds) lds = l;
   }
-  r->n_wg = m < RIDER_MAX_WG ? m : RIDER_MAX_WG;
-  r->lds_bytes = (int)rider_lds_bytes();
+  const int cap = r->n_ops == 1 ? RIDER_MAX_WG_WIDE : RIDER_MAX_WG;      // no barrier in a one-op set: no residency requirement
+  r->n_wg = m < cap ? m : cap;
+  if (r->n_ops == 1 && r->ops[0].kind != T3D_SMALL_POOL_BWD_MID && r->n_wg > RIDER_MAX_WG) r->n_wg = RIDER_MAX_WG;
+  r->lds_bytes = (int)lds;
   return T3D_OK;
 }
 
 extern "C" int t3d_run_riders(const t3d_rider_set* r, t3d_stream_t stream) {
-  if (!r || !r->sync || r->n_ops <= 0 || r->n_ops > T3D_RIDER_MAX_OPS || r->n_wg <= 0 || r->n_wg > RIDER_MAX_WG || r->lds_bytes < 0) return T3D_ERR_ARG;
+  if (!r || !r->sync || r->n_ops <= 0 || r->n_ops > T3D_RIDER_MAX_OPS || r->n_wg <= 0 || r->n_wg > (r->n_ops == 1 ? RIDER_MAX_WG_WIDE : RIDER_MAX_WG) ||
+      r->lds_bytes < 0)
+    return T3D_ERR_ARG;
+  if (r->lds_bytes > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_riders), hipFuncAttributeMaxDynamicSharedMemorySize, r->lds_bytes);
   T3D_LAUNCH(k_riders, dim3(r->n_wg), dim3(RIDER_NT), (size_t)r->lds_bytes, static_cast<hipStream_t>(stream), *r);
   T3D_CHECK_LAUNCH();
   return T3D_OK;

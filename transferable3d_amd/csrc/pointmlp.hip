@@ -1153,19 +1153,31 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd_res(const t3d_po
 // weights sit in registers, a row costs one 16-byte load, K x 8 FMAs on operands rounded to bf16 exactly as the MFMA path rounds them
 // (products of two bf16 values are exact in fp32; the sum over <= 4 terms runs in k order), the bias, the output rounding, the two
 // statistics, one 16-byte store.
-template <int N>
+// YT = float (round 3): the same kernel for the fp32 path -- no operand / output rounding, the <= 4-term sum as an fma chain in k
+// order (the MFMA path sums the same products in a permuted k order: results agree to the last bits, not bit for bit).  At
+// B=32 N=1024 the generic kernel took 9.2 us per launch for the two 3 -> 128 layers and 7.6 us for 4 -> 64, against 2.7 / 1.4 us of
+// HBM time for the output.
+template <int N, class YT = bf16_t>
 __global__ __launch_bounds__(NT) void k_pointmlp_fwd_tinyk(const t3d_pointmlp_fwd_args p) {
+  constexpr bool H = Elem<YT>::BF16;
   constexpr int CPR = N / 8, RPP = NT / CPR, NP = 128 / RPP;      // column chunks per row, rows per pass, passes
   __shared__ float red[2][RPP][N];
   const int tid = threadIdx.x, ch = tid % CPR, r0 = tid / CPR;
   const int tile = blockIdx.x, row0 = tile * 128, b = row0 / p.rows_per_frustum;
-  const bf16_t* wg = reinterpret_cast<const bf16_t*>(p.w);
   float w[4][8], add[8];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const bf16x8 v = *reinterpret_cast<const bf16x8*>(wg + (size_t)min(k, p.K - 1) * p.N + ch * 8);
+    if (H) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.w) + (size_t)min(k, p.K - 1) * p.N + ch * 8);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) w[k][e] = k < p.K ? (float)v[e] : 0.f;
+      for (int e = 0; e < 8; ++e) w[k][e] = k < p.K ? (float)v[e] : 0.f;
+    } else {
+      const float4 v0 = *reinterpret_cast<const float4*>(p.w + (size_t)min(k, p.K - 1) * p.N + ch * 8);
+      const float4 v1 = *reinterpret_cast<const float4*>(p.w + (size_t)min(k, p.K - 1) * p.N + ch * 8 + 4);
+      const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) w[k][e] = k < p.K ? v[e] : 0.f;
+    }
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) add[e] = p.bias ? p.bias[ch * 8 + e] : 0.f;
@@ -1182,7 +1194,6 @@ __global__ __launch_bounds__(NT) void k_pointmlp_fwd_tinyk(const t3d_pointmlp_fw
   float s1[8], s2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-  bf16_t* yg = reinterpret_cast<bf16_t*>(p.y);
   float4 xs[NP];
 #pragma unroll
   for (int i = 0; i < NP; ++i) xs[i] = *reinterpret_cast<const float4*>(p.a.x + (size_t)(row0 + r0 + RPP * i) * p.a.ldx + p.a.coff);
@@ -1193,21 +1204,30 @@ __global__ __launch_bounds__(NT) void k_pointmlp_fwd_tinyk(const t3d_pointmlp_fw
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float t = fmaxf(fmaf(xv[k], sc[k], sh[k]), floor_) - sub[k];
-      a[k] = k < p.K ? Elem<bf16_t>::rnd(t) : 0.f;      // operand rounding of the bf16 GEMM
+      a[k] = k < p.K ? Elem<YT>::rnd(t) : 0.f;      // operand rounding of the bf16 GEMM (identity in fp32)
     }
-    bf16x8 o;
+    float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float acc = a[0] * w[0][e];
       acc = fmaf(a[1], w[1][e], acc);
       acc = fmaf(a[2], w[2][e], acc);
       acc = fmaf(a[3], w[3][e], acc);
-      const float v = Elem<bf16_t>::rnd(acc + add[e]);
-      o[e] = (bf16_t)v;
+      const float v = Elem<YT>::rnd(acc + add[e]);
+      o[e] = v;
       s1[e] += v;
       s2[e] = fmaf(v, v, s2[e]);
     }
-    *reinterpret_cast<bf16x8*>(yg + (size_t)(row0 + r0 + RPP * i) * p.N + ch * 8) = o;
+    const size_t off = (size_t)(row0 + r0 + RPP * i) * p.N + ch * 8;
+    if (H) {
+      bf16x8 ob;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ob[e] = (bf16_t)o[e];
+      *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.y) + off) = ob;
+    } else {
+      *reinterpret_cast<float4*>(p.y + off) = make_float4(o[0], o[1], o[2], o[3]);
+      *reinterpret_cast<float4*>(p.y + off + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    }
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) { red[0][r0][ch * 8 + e] = s1[e]; red[1][r0][ch * 8 + e] = s2[e]; }
@@ -2898,7 +2918,7 @@ bool dy_ok(const t3d_dy_src& d) {
 }
 
 bool riders_ok(const t3d_rider_set* r) {
-  return r->sync != nullptr && r->n_ops > 0 && r->n_ops <= T3D_RIDER_MAX_OPS && r->n_wg > 0 && r->n_wg <= RIDER_MAX_WG && r->lds_bytes >= 0;
+  return r->sync != nullptr && r->n_ops > 0 && r->n_ops <= T3D_RIDER_MAX_OPS && r->n_wg > 0 && r->n_wg <= (r->n_ops == 1 ? RIDER_MAX_WG_WIDE : RIDER_MAX_WG) && r->lds_bytes >= 0;
 }
 size_t lds_with(size_t lds, const t3d_rider_set* r) { return r && (size_t)r->lds_bytes > lds ? (size_t)r->lds_bytes : lds; }
 
@@ -2976,6 +2996,17 @@ extern "C" int t3d_pointmlp_fwd_r(const t3d_pointmlp_fwd_args* a, const t3d_ride
     return T3D_OK;
   }
   if (a->a.dtype != T3D_F32) return T3D_ERR_ARG;
+  {   // first layer of a net (xyz [+ 1 channel]): the register kernel (T3D_FWD_TINYK=0: the generic one)
+    static const bool use_tiny32 = []() { const char* e = getenv("T3D_FWD_TINYK"); return !(e && e[0] == '0'); }();
+    if (use_tiny32 && a->K <= 4 && a->y && !a->pmax && !a->rowbias && (a->N == 64 || a->N == 128) && a->a.ldx % 4 == 0 &&
+        a->a.coff % 4 == 0 && a->a.coff + 4 <= a->a.ldx) {
+      T3D_RIDERS_FIRST(r, stream);
+      if (a->N == 64) T3D_LAUNCH((k_pointmlp_fwd_tinyk<64, float>), dim3(tiles_m), dim3(NT), 0, s, *a);
+      else T3D_LAUNCH((k_pointmlp_fwd_tinyk<128, float>), dim3(tiles_m), dim3(NT), 0, s, *a);
+      T3D_CHECK_LAUNCH();
+      return T3D_OK;
+    }
+  }
   // max-pooled layer without an output tensor: the A-resident persistent kernel (T3D_FWD_POOL=0: the generic one)
   static const bool use_pool_kernel = []() { const char* e = getenv("T3D_FWD_POOL"); return !(e && e[0] == '0'); }();
   // K = 256 needs 16-deep weight tiles to fit the 133 KB panel next to them and measured slower than the generic kernel

@@ -16,12 +16,14 @@
 #pragma once
 #include "fc_dev.h"
 #include "bn_dev.h"
+#include "poolbwd_dev.h"
 
 namespace {
 
 constexpr int RIDER_NWP = 4;                  // physical waves of a rider workgroup (= the GEMM kernels' 256 threads)
 constexpr int RIDER_NT = RIDER_NWP * 64;
-constexpr int RIDER_MAX_WG = 32;
+constexpr int RIDER_MAX_WG = 32;                // sets with barriers: every rider workgroup must be resident
+constexpr int RIDER_MAX_WG_WIDE = 2048;         // a one-op set (no barrier): t3d_pool_bwd_mid rides with one workgroup per block
 constexpr unsigned RIDER_SPIN_LIMIT = 1u << 22;
 
 typedef __attribute__((address_space(1))) unsigned rider_gu32;
@@ -59,6 +61,15 @@ __device__ __forceinline__ void rider_barrier(unsigned* sync, int i, int n_wg, i
   __syncthreads();
 }
 
+// t3d_pool_bwd_mid's grid (bn_optim.hip): gx x n_tensors slab-reduction blocks, then the sparse-row tiles
+__host__ __device__ __forceinline__ int mid_gx(int max_numel) {
+  int gx = (max_numel / 4 + 31) / 32;
+  return gx > 256 ? 256 : (gx < 1 ? 1 : gx);
+}
+__host__ __device__ __forceinline__ int mid_sparse_blocks(const t3d_pool_sparse_rows_args& sp) {
+  return (int)(((long)sp.B * sp.rows_per_frustum) / 128) * (sp.K / SR_KC);
+}
+
 // workgroups a rider op is cut into (the stand-alone launchers' grids)
 __device__ __forceinline__ int rider_blocks(const t3d_small_op& o, int kind) {
   switch (kind) {
@@ -68,6 +79,7 @@ __device__ __forceinline__ int rider_blocks(const t3d_small_op& o, int kind) {
     case T3D_SMALL_FC_BWD: return (o.u.fc_bwd.N + CB - 1) / CB;
     case T3D_SMALL_FC_DINPUT: return (o.u.fc_dinput.K + CB - 1) / CB;
     case T3D_SMALL_DY_COLSUM: return (o.u.dy_colsum.B * o.u.dy_colsum.N + 255) / 256;
+    case T3D_SMALL_POOL_BWD_MID: return mid_gx(o.u.mid.max_numel) * o.u.mid.n_tensors + mid_sparse_blocks(o.u.mid.sparse);
     default: return 0;
   }
 }
@@ -97,6 +109,16 @@ __device__ __forceinline__ void run_riders(const t3d_rider_set& r, float* smem) 
         case T3D_SMALL_FC_BWD: fc_bwd_body<1, RIDER_NWP>(o.u.fc_bwd, smem, b); break;
         case T3D_SMALL_FC_DINPUT: fc_dinput_body<1, RIDER_NWP>(o.u.fc_dinput, smem, b); break;
         case T3D_SMALL_DY_COLSUM: dy_colsum_body(o.u.dy_colsum, b, threadIdx.x); break;
+        case T3D_SMALL_POOL_BWD_MID: {
+          const t3d_pool_bwd_mid_args& m = o.u.mid;
+          const int gx = mid_gx(m.max_numel), n_reduce = gx * m.n_tensors;
+          if (b < n_reduce) {
+            reduce_slabs_body(m.slab_base, m.grad_base, m.table_dev, reinterpret_cast<float4(*)[32]>(smem), b % gx, b / gx, gx);
+          } else {
+            const int rr = b - n_reduce, tiles = m.sparse.B * m.sparse.rows_per_frustum / 128;
+            pool_sparse_rows_body(m.sparse, smem, rr % tiles, rr / tiles);
+          }
+        } break;
         default: break;
       }
       __syncthreads();                                      // the next block of this workgroup reuses the LDS scratch
@@ -117,10 +139,21 @@ inline int rider_op_blocks(const t3d_small_op& o) {
     case T3D_SMALL_FC_BWD: return o.u.fc_bwd.B <= 32 ? (o.u.fc_bwd.N + CB - 1) / CB : -1;
     case T3D_SMALL_FC_DINPUT: return o.u.fc_dinput.B <= 32 ? (o.u.fc_dinput.K + CB - 1) / CB : -1;
     case T3D_SMALL_DY_COLSUM: return (o.u.dy_colsum.B * o.u.dy_colsum.N + 255) / 256;
+    case T3D_SMALL_POOL_BWD_MID: {
+      const t3d_pool_bwd_mid_args& m = o.u.mid;
+      if (!m.slab_base || !m.grad_base || !m.table_dev || m.n_tensors <= 0 || check_sparse_rows(&m.sparse) != T3D_OK) return -1;
+      // its LDS (a 128 x 128 fp32 tile + the hit lists: 64 KB + 16 N bytes) becomes the whole launch's: above 76 KB the host GEMM
+      // would drop to one workgroup per CU (N = 1024, the seg net's conv5: stays alone)
+      if (sparse_rows_lds(m.sparse.N) > 76 * 1024) return -1;
+      return mid_gx(m.max_numel) * m.n_tensors + mid_sparse_blocks(m.sparse);
+    }
     default: return -1;
   }
 }
 
-inline size_t rider_lds_bytes() { return fc_lds_bytes(32); }      // the FC bodies' reduction tiles are the largest scratch
+inline size_t rider_op_lds(const t3d_small_op& o) {
+  if (o.kind == T3D_SMALL_POOL_BWD_MID) return sparse_rows_lds(o.u.mid.sparse.N);
+  return fc_lds_bytes(32);      // the FC bodies' reduction tiles are the largest scratch of the other kinds
+}
 
 }  // namespace

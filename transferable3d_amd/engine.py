@@ -534,7 +534,11 @@ class PointLayer:
                 plan.add_raw('t3d_reduce_slabs', lambda s: lib.t3d_reduce_slabs(fptr(slabs), fptr(out), tp(), n, mx, s))
             else:
                 ref = C.byref(sparse)
-                plan.add_raw('t3d_pool_bwd_mid', lambda s: lib.t3d_pool_bwd_mid(fptr(slabs), fptr(out), tp(), n, mx, ref, s), sparse)
+                # (the same arguments as one struct: what the step scheduler needs to let this launch ride in a GEMM, schedule.py)
+                marg = abi.PoolBwdMidArgs(fptr(slabs), fptr(out), tp(), n, mx, sparse)
+                plan.keep.append(sparse)
+                plan.calls.append(('t3d_pool_bwd_mid', lambda s: lib.t3d_pool_bwd_mid(fptr(slabs), fptr(out), tp(), n, mx, ref, s), marg))
+                plan.lanes.append(plan._lane)
         return ({k: slabs[v:] for k, v in soff.items()}, {name: out[ooff[name]:ooff[name] + numel] for name, numel, _ in regions},
                 emit)
 

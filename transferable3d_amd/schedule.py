@@ -33,9 +33,13 @@ MAX_RUN = min(int(os.environ.get('T3D_RIDER_RUN', '10')), abi.RIDER_MAX_OPS)    
 # measured (tools/bench_riders.py, four dependent FC ops, 29 us as four launches): 41 us as one set of its own, 52 us inside a GEMM
 # launch that fills the chip; a 87 us two-round GEMM launch hosting them takes 96 us (the riders' slots push 16 of its tiles into a
 # third round), ONE riding op is free
-RIDER_SLOWDOWN = float(os.environ.get('T3D_RIDER_SLOW', '1.6'))      # a rider run vs the stand-alone launches of its ops
+RIDER_SLOWDOWN = float(os.environ.get('T3D_RIDER_SLOW', '1.85'))      # a rider run vs the stand-alone launches of its ops
 HOST_STRETCH = float(os.environ.get('T3D_RIDER_STRETCH', '0.2'))     # what a hosted run adds to its host, per us of the run
 HOST_OVERHEAD_US = float(os.environ.get('T3D_RIDER_COST', '0.5'))
+# a run may take at most this fraction of its host's own time: riders that outlast their GEMM turn the launch into a latency chain
+# with 500 idle workgroup slots (and make the GEMM kernel's measured duration that of its riders)
+RIDER_MAX_FRAC = float(os.environ.get('T3D_RIDER_MAXFRAC', '1.0'))
+WIDE_SHARE = float(os.environ.get('T3D_RIDER_WIDE', '0.5'))          # of a wide rider's stand-alone time that its host launch grows by (<= 0: never host one)
 
 
 def _first(arg):
@@ -53,7 +57,8 @@ def is_host(name, arg):
             return False
         pool_kernel = (not a.y) and bool(a.pmax) and (not a.a.sub) and a.N % 128 == 0 and a.N >= 256 and a.K == 128 \
             and os.environ.get('T3D_FWD_POOL', '1') != '0'
-        return not pool_kernel                                   # (the activation-resident pooled forward is a 512-thread kernel)
+        tiny = a.K <= 4 and bool(a.y) and not a.pmax and not a.rowbias and a.N in (64, 128) and os.environ.get('T3D_FWD_TINYK', '1') != '0'
+        return not pool_kernel and not tiny                      # (the pooled forward is a 512-thread kernel; K <= 4: the register kernel)
     if name == 't3d_pointmlp_bwd':
         d, w = arg
         if d.dtype != abi.F32:
@@ -81,6 +86,8 @@ def small_op(name, arg, depends=0):
 def can_ride(lib, name, arg):
     if name not in abi.RIDER_KIND or arg is None or isinstance(arg, tuple) or not hasattr(lib, 't3d_riders_plan'):
         return False
+    if name in abi.RIDER_WIDE and WIDE_SHARE <= 0:
+        return False
     rs = abi.RiderSet()
     rs.ops[0], rs.n_ops = small_op(name, arg), 1
     return lib.t3d_riders_plan(C.byref(rs)) == 0
@@ -96,6 +103,8 @@ def can_pair(name, arg):
 def est_us(name, arg):
     a = _first(arg) if arg is not None else None
     if name == 't3d_pointmlp_fwd':
+        if a.K <= 4:
+            return 5.0                                            # register kernel, bound by its output store
         return 6.0 + 2.0 * a.M * a.K * a.N / 1.0e8
     if name == 't3d_pointmlp_bwd':
         return 6.0 + 4.0 * a.M * a.K * a.N / 0.95e8
@@ -108,14 +117,20 @@ def est_us(name, arg):
     if name == 't3d_pool_bwd_stage2':
         f = a
         return 8.0 + 2.0 * arg[1].M * f.K * f.K / 0.85e8
-    if name in ('t3d_fc_fwd', 't3d_fc_bwd', 't3d_fc_dinput'):
-        return 5.0 + 5.0e-6 * a.B * a.K * a.N / 32.0 + (3.0 if name == 't3d_fc_bwd' else 0.0)
+    if name in ('t3d_fc_fwd', 't3d_fc_bwd', 't3d_fc_dinput'):      # 7.4 (256 x 256) ... 9.9 (512 x 512) fwd, 11-14 bwd
+        rb = max(1.0, a.B / 32.0)
+        kn = float(a.K) * a.N * rb
+        return (8.0 + 2.5e-5 * kn) if name == 't3d_fc_bwd' else (5.5 + 1.7e-5 * kn)
+    if name == 't3d_bn_fwd_finalize':
+        return 6.3 if a.pool_pmax else 4.0
+    if name == 't3d_pool_bwd_mid' and a is not None and hasattr(a, 'sparse'):      # 32.6 (N 512, K 256), 24.7 (1024, 128), 18.8 (256, 128)
+        return 15.0 + 1.1e-4 * a.sparse.N * a.sparse.K * max(1.0, a.sparse.B / 32.0)
     return {'t3d_bn_fwd_finalize': 4.0, 't3d_bn_bwd_finalize': 4.3, 't3d_dy_colsum': 4.0, 't3d_strong_loss': 12.0,
             't3d_pool_bwd_mid': 25.0, 't3d_small_pair': 10.0, 't3d_seg_head': 13.0, 't3d_seg_finalize': 4.0}.get(name, 6.0)
 
 
 class _Op:
-    __slots__ = ('call', 'name', 'arg', 'host', 'ride', 'pair', 'us')
+    __slots__ = ('call', 'name', 'arg', 'host', 'ride', 'pair', 'us', 'wide')
 
     def __init__(self, lib, call):
         self.call = call
@@ -124,6 +139,7 @@ class _Op:
         self.ride = can_ride(lib, self.name, self.arg)
         self.pair = can_pair(self.name, self.arg)
         self.us = est_us(self.name, self.arg)
+        self.wide = self.name in abi.RIDER_WIDE
 
 
 def align(S, T, max_run=None):
@@ -161,8 +177,16 @@ def align(S, T, max_run=None):
                     for r in range(1, max_run + 1):
                         if q + r > len(other) or not other[q + r - 1].ride:
                             break
+                        if getattr(other[q + r - 1], 'wide', False):
+                            # a WIDE rider (t3d_pool_bwd_mid: hundreds of latency-bound workgroups) is alone in its set; it is real
+                            # work for the chip: the launch takes the host's time plus a share of the rider's
+                            if r == 1:
+                                relax(*nxt(1, 1), c0 + x.us + WIDE_SHARE * other[q].us + HOST_OVERHEAD_US, ('host', ch, p, q, q + 1, pos))
+                            break
                         run += other[q + r - 1].us
                         rh = run * (RIDER_SLOWDOWN if r > 1 else 1.2)
+                        if rh > RIDER_MAX_FRAC * x.us and r > 1:
+                            break
                         relax(*nxt(1, r), c0 + max(x.us + (HOST_STRETCH * rh if r > 1 else 0.0), rh) + HOST_OVERHEAD_US,
                               ('host', ch, p, q, q + r, pos))
             if i < nS and j < nT and S[i].pair and T[j].pair:
