@@ -150,6 +150,8 @@ def gemm_work(name, a):
     if rps.value != a.rows_per_split:
         tk.value, tn.value = (128 if a.K > 64 else 64), (128 if a.N % 128 == 0 else 64)
     by = es(a.a.dtype) * a.M * a.K + es(a.dy.dtype) * 2 * a.M * a.N + 4.0 * a.K * a.N
+    if a.K <= 4 and a.a.dtype == 0 and a.dy.dtype == 0 and not _null(a.dy.dz) and a.N in (64, 128) and os.environ.get('T3D_WGRAD_TINYK', '1') != '0':
+        return 'k_pointmlp_wgrad_tinyk<%d>' % a.N, flops, by      # first layer of a net, fp32: the register kernel
     return 'k_pointmlp_wgrad<%d,%d>' % (tk.value, tn.value), flops, by
 
 

@@ -1625,6 +1625,85 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_wgrad(const t3d_poin
   wgrad_body<BMK, BN, PR>(la, lb, p.slabs, p.K, p.N, p.rows_per_split, smem, blockIdx.x, gridDim.x);
 }
 
+// Weight gradient of a first layer (K <= 4 raw input channels, fp32, dense dy): the generic kernel pads K to a 64-row tile (10.7 us per
+// launch at M = 32768, N = 128 for 2 x 16.8 MB of input: 0.4 of the HBM rate).  Here a thread owns 8 columns x K accumulators in
+// registers, walks every RPP-th row of its split -- two 16-byte loads each of dz and y, one of the input row -- and the row groups
+// meet through LDS in a fixed order.  One slab [K, N] per split, as the generic kernel writes them.
+template <int N, bool HAS_SUB>
+__global__ __launch_bounds__(NT) void k_pointmlp_wgrad_tinyk(const t3d_pointmlp_wgrad_args p) {
+  constexpr int CPR = N / 8, RPP = NT / CPR;      // column chunks per row, rows per pass
+  __shared__ float red[RPP][4][N];
+  const int tid = threadIdx.x, ch = tid % CPR, r0 = tid / CPR;
+  const int split = blockIdx.x, row_begin = split * p.rows_per_split, row_end = row_begin + p.rows_per_split;
+  float c0[8], c1[8], c2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    c0[e] = p.dy.coef[ch * 8 + e];
+    c1[e] = p.dy.coef[p.N + ch * 8 + e];
+    c2[e] = p.dy.coef[2 * p.N + ch * 8 + e];
+  }
+  float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p.a.scale != nullptr) {
+    const float4 a = *reinterpret_cast<const float4*>(p.a.scale), c = *reinterpret_cast<const float4*>(p.a.shift);
+    sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sh[0] = c.x; sh[1] = c.y; sh[2] = c.z; sh[3] = c.w;
+  }
+  const float floor_ = p.a.relu ? 0.f : -INFINITY;
+  float acc[4][8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[k][e] = 0.f;
+  constexpr int U = 4;                              // rows in flight per thread
+  for (int r = row_begin + r0; r < row_end; r += RPP * U) {
+    float4 dz[U][2], y[U][2], x[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int rr = min(r + u * RPP, row_end - 1);      // clamped: no branch around the loads
+      const size_t off = (size_t)rr * p.N + ch * 8;
+      dz[u][0] = *reinterpret_cast<const float4*>(p.dy.dz + off);
+      dz[u][1] = *reinterpret_cast<const float4*>(p.dy.dz + off + 4);
+      y[u][0] = *reinterpret_cast<const float4*>(p.dy.y + off);
+      y[u][1] = *reinterpret_cast<const float4*>(p.dy.y + off + 4);
+      x[u] = *reinterpret_cast<const float4*>(p.a.x + (size_t)rr * p.a.ldx + p.a.coff);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool live = r + u * RPP < row_end;
+      const float xv[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+      float a[4];
+      float sub[4] = {0.f, 0.f, 0.f, 0.f};
+      if (HAS_SUB) {
+        const int b = min(r + u * RPP, row_end - 1) / p.rows_per_frustum;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sub[k] = p.a.sub[(size_t)b * p.a.sub_ld + min(k, p.K - 1)];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a[k] = (live && k < p.K) ? fmaxf(fmaf(xv[k], sc[k], sh[k]), floor_) - sub[k] : 0.f;
+      const float dzv[8] = {dz[u][0].x, dz[u][0].y, dz[u][0].z, dz[u][0].w, dz[u][1].x, dz[u][1].y, dz[u][1].z, dz[u][1].w};
+      const float yv[8] = {y[u][0].x, y[u][0].y, y[u][0].z, y[u][0].w, y[u][1].x, y[u][1].y, y[u][1].z, y[u][1].w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = fmaf(c0[e], dzv[e], fmaf(c1[e], yv[e], c2[e]));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k][e] = fmaf(a[k], d, acc[k][e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[r0][k][ch * 8 + e] = acc[k][e];
+  __syncthreads();
+  float* slab = p.slabs + (size_t)split * p.K * p.N;
+  for (int i = tid; i < p.K * N; i += NT) {
+    const int k = i / N, n = i % N;
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < RPP; ++g) t += red[g][k][n];
+    slab[(size_t)k * p.N + n] = t;
+  }
+}
+
 // Gram matrix of a layer input, G = a^T a, as split-row slabs (t3d.h K11e).
 template <int BMK, int BN, class PR = PathF32>
 __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_gram(const t3d_pointmlp_gram_args p) {
@@ -3113,6 +3192,9 @@ extern "C" int t3d_wgrad_plan(int M, int K, int N, int* rows_per_split, int* til
   }
   long want = (target + tiles - 1) / tiles;
   if (want > cap) want = cap;
+  // first layers (K <= 4): bound by reading dz and y once, not by MFMA work -- 64-row splits give the register kernel
+  // (k_pointmlp_wgrad_tinyk) two workgroups per CU at M = 32768; their slabs are K x N <= 512 floats each
+  if (K <= 4 && M / 64 > want) want = M / 64;
   int s = 1;
   while ((long)s * 2 <= want && M % (s * 2) == 0 && (M / (s * 2)) % BKH == 0) s *= 2;      // whole k-tiles of either path
   *rows_per_split = M / s;
@@ -3213,6 +3295,15 @@ extern "C" int t3d_pointmlp_wgrad_r(const t3d_pointmlp_wgrad_args* a, const t3d_
     else if (pooled) launch_lds(k_pointmlp_wgrad<TK, TN_, false, true>, grid, lds_wgrad(TK, TN_), s, *a);          \
     else launch_lds(k_pointmlp_wgrad<TK, TN_, false, false>, grid, lds_wgrad(TK, TN_), s, *a);                     \
   } while (0)
+  static const bool use_tiny_w = []() { const char* e = getenv("T3D_WGRAD_TINYK"); return !(e && e[0] == '0'); }();
+  if (use_tiny_w && !r && !pooled && a->K <= 4 && (a->N == 64 || a->N == 128) && a->a.dtype == T3D_F32 && a->a.ldx % 4 == 0 &&
+      a->a.coff % 4 == 0 && a->a.coff + 4 <= a->a.ldx && (a->a.scale == nullptr) == (a->a.shift == nullptr)) {
+    const dim3 gsp(splits);      // one workgroup per row split: the slab layout of the generic kernel
+    if (a->N == 64) { if (sub) T3D_LAUNCH((k_pointmlp_wgrad_tinyk<64, true>), gsp, dim3(NT), 0, s, *a); else T3D_LAUNCH((k_pointmlp_wgrad_tinyk<64, false>), gsp, dim3(NT), 0, s, *a); }
+    else { if (sub) T3D_LAUNCH((k_pointmlp_wgrad_tinyk<128, true>), gsp, dim3(NT), 0, s, *a); else T3D_LAUNCH((k_pointmlp_wgrad_tinyk<128, false>), gsp, dim3(NT), 0, s, *a); }
+    T3D_CHECK_LAUNCH();
+    return T3D_OK;
+  }
   if (r) {
     if (sub) launch_lds_r(k_pointmlp_wgrad_r<64, 64, true, false>, grid, lds_with(lds_wgrad(64, 64), r), s, *a, *r);
     else launch_lds_r(k_pointmlp_wgrad_r<64, 64, false, false>, grid, lds_with(lds_wgrad(64, 64), r), s, *a, *r);

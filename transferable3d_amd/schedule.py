@@ -34,7 +34,9 @@ MAX_RUN = min(int(os.environ.get('T3D_RIDER_RUN', '10')), abi.RIDER_MAX_OPS)    
 # launch that fills the chip; a 87 us two-round GEMM launch hosting them takes 96 us (the riders' slots push 16 of its tiles into a
 # third round), ONE riding op is free
 RIDER_SLOWDOWN = float(os.environ.get('T3D_RIDER_SLOW', '1.85'))      # a rider run vs the stand-alone launches of its ops
-HOST_STRETCH = float(os.environ.get('T3D_RIDER_STRETCH', '0.2'))     # what a hosted run adds to its host, per us of the run
+HOST_STRETCH = float(os.environ.get('T3D_RIDER_STRETCH', '0.2'))     # what a hosted run adds to its host, per us of the run ...
+HOST_STRETCH_MAX = float(os.environ.get('T3D_RIDER_STRETCH_MAX', '8.0'))   # ... at most (us): displaced tiles wait for ONE slot to free
+RIDER_SLOT_SHARE = 16.0 / 512.0                                       # 16 rider workgroups of 512 resident slots
 HOST_OVERHEAD_US = float(os.environ.get('T3D_RIDER_COST', '0.5'))
 # a run may take at most this fraction of its host's own time: riders that outlast their GEMM turn the launch into a latency chain
 # with 500 idle workgroup slots (and make the GEMM kernel's measured duration that of its riders)
@@ -68,6 +70,8 @@ def is_host(name, arg):
             (d.M // 128 < 256 or w.rows_per_split >= 256 or os.environ.get('T3D_BWD1F') == '2')
         return not one_pass
     if name == 't3d_pointmlp_wgrad':
+        if a.K <= 4 and os.environ.get('T3D_WGRAD_TINYK', '1') != '0':
+            return False                                         # the register kernel (no rider form) beats the generic one + a rider
         return a.dy.dtype != abi.BF16 and a.K <= 64 and a.N <= 128 and bool(a.dy.dz)
     if name == 't3d_pool_bwd_stage1':
         return a.a.dtype == abi.F32
@@ -109,6 +113,8 @@ def est_us(name, arg):
     if name == 't3d_pointmlp_bwd':
         return 6.0 + 4.0 * a.M * a.K * a.N / 0.95e8
     if name == 't3d_pointmlp_wgrad':
+        if a.K <= 4:
+            return 7.0
         return 6.0 + 2.0 * a.M * max(a.K, 8) * a.N / 0.5e8
     if name == 't3d_pointmlp_dgrad':
         return 6.0 + 2.0 * a.M * a.K * a.N / 0.9e8
@@ -187,8 +193,10 @@ def align(S, T, max_run=None):
                         rh = run * (RIDER_SLOWDOWN if r > 1 else 1.2)
                         if rh > RIDER_MAX_FRAC * x.us and r > 1:
                             break
-                        relax(*nxt(1, r), c0 + max(x.us + (HOST_STRETCH * rh if r > 1 else 0.0), rh) + HOST_OVERHEAD_US,
-                              ('host', ch, p, q, q + r, pos))
+                        # what the riders' slots cost the host: their share of the chip for the run's duration, plus the tiles of
+                        # a one- or two-round launch that slip into another round (bounded by a fraction of the run)
+                        stretch = (RIDER_SLOT_SHARE * rh + min(HOST_STRETCH * rh, HOST_STRETCH_MAX)) if r > 1 else 0.0
+                        relax(*nxt(1, r), c0 + max(x.us + stretch, rh) + HOST_OVERHEAD_US, ('host', ch, p, q, q + r, pos))
             if i < nS and j < nT and S[i].pair and T[j].pair:
                 relax(i + 1, j + 1, c0 + max(S[i].us, T[j].us) + 0.5, ('pair', i, j, pos))
     steps, pos = [], (nS, nT)
