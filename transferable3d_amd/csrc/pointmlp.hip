@@ -740,12 +740,33 @@ __device__ __forceinline__ void h_iter(SA& sa, SB& sb, const LA& la, const LB& l
 template <int TM, int TN, class SA, class SB, class LA, class LB, bool AR, int DIMA, bool BR, int DIMB>
 __device__ __forceinline__ void gemm_mainloop_h(SA& sa, SB& sb, const LA& la, const LB& lb, float* smem_f, int red_begin,
                                                 int red_end, int a0, int b0, f32x16 (&acc)[TM][TN], int tid) {
-  static_assert(SA::PF == 2 && SB::PF == 1, "A: two register slots, B: one");
+  static_assert((SA::PF == 2 || SA::PF == 1) && SB::PF == 1, "A: two register slots (or one), B: one");
   bf16_t* smem = reinterpret_cast<bf16_t*>(smem_f);
   constexpr int STAGE = SA::LDS_ELEMS + SB::LDS_ELEMS;
   constexpr int ST = BKH / 16;
   const int last = red_end - BKH;                              // first reduction index of the last tile
   auto clampr = [&](int r) { return min(r, last); };
+  if constexpr (SA::PF == 1) {
+    // one register slot per operand (the 128-column data-gradient tilings: the second A slot spilled 10-27 VGPRs to scratch):
+    // iteration t stores tile t+1 -- requested during iteration t-1 -- into the other stage, then requests tile t+2
+    sa.template fetch<0>(la, red_begin, tid);
+    sb.template fetch<0>(lb, red_begin, tid);
+    sa.template store<0>(la, smem, tid);
+    sb.template store<0>(lb, smem + SA::LDS_ELEMS, tid);
+    sa.template fetch<0>(la, clampr(red_begin + BKH), tid);
+    sb.template fetch<0>(lb, clampr(red_begin + BKH), tid);
+    __syncthreads();
+    int cur1 = 0;
+    for (int red1 = red_begin; red1 + BKH < red_end; red1 += BKH) {
+      h_iter<0, TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, cur1, clampr(red1 + 2 * BKH), clampr(red1 + 2 * BKH), a0, b0,
+                                                           acc, tid);
+      cur1 ^= 1;
+    }
+    const bf16_t* As1 = smem + cur1 * STAGE;
+    mma_steps_h<TM, TN, AR, DIMA, BR, DIMB, 0, ST>(As1, As1 + SA::LDS_ELEMS, a0, b0, acc, tid & 63, [](int) {});
+    __syncthreads();
+    return;
+  }
   // prologue: A tiles 0, 1 -> slots 0, 1; tile 0 into stage 0; then A tile 2 -> slot 0, B tile 1
   sa.template fetch<0>(la, red_begin, tid);
   sb.template fetch<0>(lb, red_begin, tid);
@@ -798,7 +819,8 @@ struct PathBF16 {
   static constexpr int RED = BKH;
   // the first operand of every GEMM here is the [M, C] stream from HBM: two register slots (prefetch distance 2); the second
   // (weights from L2, or the fatter dy operand of the weight gradient) one
-  template <int DIM, bool TYPE_R, class L, int PF, bool IS_A = false> using Stg = StagerHSel<DIM, TYPE_R, L, IS_A ? 2 : 1>;
+  // (PF == 0: one slot for the first operand too -- the 128-column data-gradient tilings, whose second slot spilled 10-27 VGPRs to scratch)
+  template <int DIM, bool TYPE_R, class L, int PF, bool IS_A = false> using Stg = StagerHSel<DIM, TYPE_R, L, (IS_A && PF != 0) ? 2 : 1>;
 };
 template <class PR, int TM, int TN, class SA, class SB, class LA, class LB, bool AR, int DIMA, bool BR, int DIMB>
 __device__ __forceinline__ void run_mainloop(SA& sa, SB& sb, const LA& la, const LB& lb, float* smem, int red_begin, int red_end,
@@ -818,7 +840,8 @@ __device__ __forceinline__ void fwd_body(const t3d_pointmlp_fwd_args& p, float* 
   using YT = typename PR::T;
   constexpr int PF = BN == 64 ? T3D_PF_NARROW : T3D_PF_WIDE;
   using WL = std::conditional_t<LA::EXACT, typename PR::WLX, typename PR::WL>;      // K % 64 == 0: every weight tile is whole
-  using SA = typename PR::template Stg<BM, true, LA, PF, true>;
+  // (bf16 arithmetic on an fp32 source -- a raw input wider than 4 channels, e.g. the Box-PC representation -- at 128 columns: one slot)
+  using SA = typename PR::template Stg<BM, true, LA, (PR::BF16 && BN == 128 && !Elem<XT>::BF16) ? 0 : PF, true>;
   using SB = typename PR::template Stg<BN, false, WL, PF>;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1508,7 +1531,7 @@ __device__ __forceinline__ void dgrad_body(const t3d_pointmlp_dgrad_args& p, flo
   constexpr int PF = BN == 64 ? T3D_PF_NARROW : T3D_PF_WIDE;
   using LA = typename PR::template Dy<POOLED>;
   using WL = typename PR::WLX;            // bf16: K % 64 == 0 and N % 64 == 0 (launcher-checked), every tile is whole
-  using SA = typename PR::template Stg<BM, true, LA, PF, true>;
+  using SA = typename PR::template Stg<BM, true, LA, (PR::BF16 && BN == 128) ? 0 : PF, true>;
   using SB = typename PR::template Stg<BN, true, WL, PF>;
 
   const int tid = threadIdx.x, wid = tid >> 6;
@@ -1547,7 +1570,7 @@ __device__ __forceinline__ void dgrad_gram_body(const t3d_pointmlp_dgrad_gram_ar
   constexpr int BM = 128, TM = 2, TN = BN / 64;
   using LA = typename PR::template Act<false, typename PR::T>;
   constexpr int PF = BN == 64 ? T3D_PF_NARROW : T3D_PF_GRAM128;
-  using SA = typename PR::template Stg<BM, true, LA, PF, true>;
+  using SA = typename PR::template Stg<BM, true, LA, (PR::BF16 && BN == 128) ? 0 : PF, true>;
   using SB = typename PR::template Stg<BN, false, WLoader, PF>;
   const int tid = threadIdx.x, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
@@ -1583,7 +1606,7 @@ __device__ __forceinline__ void wgrad_body(const LA& la, const LB& lb, float* sl
                                            float* smem, int bid, int nblocks) {
   constexpr int TM = BMK / 64, TN = BN / 64;
   constexpr int PF = (BMK == 64 && BN == 64) ? T3D_PF_NARROW : T3D_PF_WIDE;
-  using SA = typename PR::template Stg<BMK, false, LA, PF, true>;
+  using SA = typename PR::template Stg<BMK, false, LA, (PR::BF16 && BMK == 128 && BN == 128) ? 0 : PF, true>;      // (one slot: see PathBF16::Stg)
   using SB = typename PR::template Stg<BN, false, LB, PF>;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
@@ -3193,8 +3216,8 @@ extern "C" int t3d_wgrad_plan(int M, int K, int N, int* rows_per_split, int* til
   long want = (target + tiles - 1) / tiles;
   if (want > cap) want = cap;
   // first layers (K <= 4): bound by reading dz and y once, not by MFMA work -- 64-row splits give the register kernel
-  // (k_pointmlp_wgrad_tinyk) two workgroups per CU at M = 32768; their slabs are K x N <= 512 floats each
-  if (K <= 4 && M / 64 > want) want = M / 64;
+  // (k_pointmlp_wgrad_tinyk) two workgroups per CU at M = 32768 (at most 512 splits); their slabs are K x N <= 512 floats each
+  if (K <= 4) { const long w4 = M / 64 < 512 ? M / 64 : 512; if (w4 > want) want = w4; }
   int s = 1;
   while ((long)s * 2 <= want && M % (s * 2) == 0 && (M / (s * 2)) % BKH == 0) s *= 2;      // whole k-tiles of either path
   *rows_per_split = M / s;
