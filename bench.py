@@ -178,6 +178,23 @@ def profile_kernels(plans, steps, repeat=4):
                     assert rc == 0, (name, rc)
                 e1.record()
                 evs.append((name, arg, e0, e1))
+        # a GEMM launch that hosts riders (`_r`): also time the SAME kernel body on the same arguments without them (the plain
+        # entry point), so that the hosted duration -- which is what the step pays and what rocprofv3 reports for k_..._r -- can be
+        # told apart from the GEMM's own quality
+        alone = {}
+        for ci, (name, arg, _, _) in enumerate(evs):
+            if not name.endswith('_r') or arg is None:
+                continue
+            import ctypes
+            fn = getattr(LIB, name[:-2])
+            refs = [ctypes.byref(a) for a in (arg if isinstance(arg, tuple) else (arg,))]
+            s0 = plans[0].rt.stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _r in range(repeat):
+                assert fn(*refs, s0) == 0
+            e1.record()
+            alone[ci] = (e0, e1)
         torch.cuda.synchronize()
         for ci, (name, arg, e0, e1) in enumerate(evs):
             dt = e0.elapsed_time(e1) * 1e-3 / repeat
@@ -189,11 +206,12 @@ def profile_kernels(plans, steps, repeat=4):
             if base != name and '<' in label and label.split('<')[0] in ('k_pointmlp_fwd', 'k_pointmlp_bwd', 'k_pointmlp_wgrad',
                                                                         'k_pool_bwd_stage1', 'k_pool_bwd_stage2'):
                 label = label.replace('<', '_r<', 1)
-            d = acc.setdefault(label, [0.0, 0, 0.0, 0.0])
+            d = acc.setdefault(label, [0.0, 0, 0.0, 0.0, 0.0])
             d[0] += dt
             d[1] += 1
             d[2] += flops
             d[3] += nbytes
+            d[4] += (alone[ci][0].elapsed_time(alone[ci][1]) * 1e-3 / repeat) if ci in alone else dt      # the GEMM alone
             if flops:
                 a0 = (arg[1] if base == 't3d_pool_bwd_stage2' else arg[0]) if isinstance(arg, tuple) else arg
                 dd = detail.setdefault('%s M%d K%d N%d' % (label, a0.M, a0.K, getattr(a0, 'N', a0.K)), [0.0, 0, flops, nbytes])
@@ -406,7 +424,7 @@ def main():
         acc, detail = profile_kernels(plans, args.profile_steps)
         total = sum(v[0] for v in acc.values())
         dom = max((k for k in acc if k.startswith(('k_pointmlp', 'k_pool_bwd_stage'))), key=lambda k: acc[k][0])
-        tsec, n, fl, nby = acc[dom]
+        tsec, n, fl, nby, tsec_alone = acc[dom]
         # The roofline that bounds the dominant kernel, from its ALGORITHMIC work (gemm_work: every tensor once): the larger of
         # FLOPs / MFMA peak and bytes / HBM peak.  fp32 configs: MFMA; bf16 config 4: HBM.
         mfma_peak = MFMA_F32_PEAK_TFLOPS if args.dtype == 'f32' else MFMA_BF16_PEAK_TFLOPS
@@ -415,6 +433,7 @@ def main():
         hbm_achieved = nby / tsec / 1e9
         is_gemm = lambda k: k.startswith(('k_pointmlp', 'k_pool_bwd_stage'))
         gemm_t = sum(v[0] for k, v in acc.items() if is_gemm(k))
+        gemm_t_alone = sum(v[4] for k, v in acc.items() if is_gemm(k))
         gemm_f = sum(v[2] for k, v in acc.items() if is_gemm(k))
         gemm_b = sum(v[3] for k, v in acc.items() if is_gemm(k))
         traffic, stale = pmc_traffic(dom, args)
@@ -435,10 +454,15 @@ def main():
                     'traffic_over_algorithmic': (traffic / (nby / n)) if traffic else None,
                     'traffic_summary_predates_this_build': stale,
                     'avg_launch_us': tsec / n * 1e6, 'launches_per_step': n // args.profile_steps,
+                    # `_r` kernels: the launch also runs small ops of the independent chain (schedule.py) in its first workgroups and
+                    # lasts as long as the longer of the two; the same GEMM on the same arguments WITHOUT riders:
+                    'gemm_alone': ({'avg_launch_us': tsec_alone / n * 1e6, 'achieved': fl / tsec_alone / 1e12,
+                                    'frac': fl / tsec_alone / 1e12 / mfma_peak} if dom.split('<')[0].endswith('_r') else None),
                     'flops_per_launch': fl / n,
                     'all_gemm_kernels': {'achieved': gemm_f / gemm_t / 1e12, 'frac': gemm_f / gemm_t / 1e12 / mfma_peak,
                                          'hbm_achieved_gbs': gemm_b / gemm_t / 1e9, 'hbm_frac': gemm_b / gemm_t / 1e9 / (HBM_PEAK_TBS * 1e3),
-                                         'share_of_step_kernel_time': gemm_t / total},
+                                         'share_of_step_kernel_time': gemm_t / total,
+                                         'frac_without_riders': gemm_f / gemm_t_alone / 1e12 / mfma_peak},
                     'whole_step': None if args.workload != 'A' else {'gflop_per_frustum_split': step_flops / B / 1e9,
                                    # what the GEMM kernels actually execute (the Gram-form backward of the pooled layers needs
                                    # fewer FLOPs than the split count the roofline figure is quoted on)
