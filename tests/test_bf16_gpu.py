@@ -37,6 +37,21 @@ pytestmark = pytest.mark.gpu
 FWD_TOL, LOSS_TOL, GRAD_PER, GRAD_MED, GRAD_GLOB, EMA_TOL = 6e-2, 1e-2, 1.2e-1, 4e-2, 5e-2, 1e-2
 
 
+def check_bf16_decisions(margins, what):
+    """model_check.check_decision_margins with the bf16 bounds: at most 2 % of a site's decisions taken over from the kernels; their
+    margins by the oracle's own numbers within FOUR bf16 spacings of the tensor's magnitude in the layers in front of the pooled global
+    feature (seg conv1-5: inputs identical up to batch-norm statistics; measured <= 0.2), within SIXTEEN behind it (conv6 adds a
+    1024-term per-frustum product of pooled features that each carry bf16-level noise, and batch-norm re-amplifies it; everything
+    behind the mask inherits that: measured up to 6.9 on fresh weights, 11.3 after three Adam steps)."""
+    from model_check import check_decision_margins
+    front = lambda site: site.startswith('inst_seg/conv') and site.split('#')[0][-1] in '12345' and 'conv10' not in site
+    a = {k: v for k, v in margins.items() if front(k)}
+    b = {k: v for k, v in margins.items() if not front(k)}
+    out = dict(check_decision_margins(a, flip_frac=0.02, flip_floor=8, margin_tol=4 * 2.0 ** -8, what=what))
+    out.update(check_decision_margins(b, flip_frac=0.02, flip_floor=8, margin_tol=16 * 2.0 ** -8, what=what))
+    return out
+
+
 def run(rt, batch, P, c, dtype):
     B, N, C = batch['pc'].shape
     g = Graph(B, N, C, rt=rt, dtype=dtype)
@@ -92,21 +107,19 @@ def test_bf16_model_a_step_matches_the_bf16_emulating_oracle(hip_lib, B, N, seed
     d64 = {k: float(np.abs(e[k].float().cpu().numpy().reshape(ep64[k].shape) - ep64[k].detach().numpy()).max()) for k in FWD_KEYS}
     print('bf16 vs emulating oracle: fwd', worst, 'loss', (lm, lr), 'grad worst', top, 'median', med, 'global', glob,
           'decisions differing', sum(ep['__flips__'].values()), '| vs plain fp64 oracle: max abs', d64, 'loss', float(loss64))
-    # the decisions the emulating oracle took over from the kernels: at most 2 % of a site's elements, each within EIGHT bf16 spacings
-    # of the tensor's magnitude from the boundary by the oracle's own numbers (model_check.check_decision_margins; fp32 runs: 1e-4 /
-    # 1e-4).  The first layers sit within one or two spacings; behind the pooled global feature (conv6 ...) the emulation itself is
-    # only as close as the bf16 noise that has decorrelated by then (module docstring): measured up to 5.6 spacings at conv6.
-    from model_check import check_decision_margins
     mg = ep['__margins__']
     print('forced decisions: site (flips / elements, oracle margin in bf16 spacings of the tensor scale):',
           {k: ('%d/%d' % (v[1], v[0]), round(v[2] / (2.0 ** -8 * max(1.0, v[3])), 2)) for k, v in mg.items() if v[1]})
-    check_decision_margins(mg, flip_frac=0.02, flip_floor=8, margin_tol=8 * 2.0 ** -8, what='bf16')
+    check_bf16_decisions(mg, 'bf16')
     for k, err in worst.items():
         assert err < FWD_TOL, (k, err)
     assert abs(lm - lr) < LOSS_TOL * abs(lr), (lm, lr)
     total = np.sqrt(sum(float(np.linalg.norm(v.numpy())) ** 2 for v in grads.values()))
     big = {k: v for k, v in per.items() if float(np.linalg.norm(grads[k].numpy())) >= 1e-2 * total}
     assert max(big.values()) < GRAD_PER and med < GRAD_MED and glob < GRAD_GLOB, (sorted(big.items(), key=lambda kv: -kv[1])[:3], med, glob)
+    # ... and EVERY tensor, however small its share of the gradient norm, within 2.5e-1 (a wrongly wired small tensor is off by O(1))
+    print('all gradient tensors: worst', top[0], 'of', len(per))
+    assert top[0][1] < 2.5e-1, top
     for k, v in ema.items():
         mine = g.vars.get(k).detach().cpu().numpy()
         assert np.abs(mine - v.detach().numpy()).max() < EMA_TOL * max(1.0, float(v.abs().max())), k
@@ -161,3 +174,81 @@ def test_bf16_stage_b_and_c_steps_stay_close_to_fp32_and_train(hip_lib, workload
     assert all(np.isfinite(b0[0])) and b0[0][-1] < b0[0][0], b0[0]
     assert abs(b0[0][0] - f32[0][0]) < (3e-2 if workload == 'boxpc' else 8e-2) * abs(f32[0][0]), (b0[0][0], f32[0][0])
     assert b0[0] == b1[0] and torch.equal(b0[1], b1[1])
+
+
+def test_bf16_four_step_trajectory_adam_master_weights_and_the_bf16_copy(hip_lib):
+    """Four consecutive bf16 steps of the step object (the capture and two hipGraph replays among them), each checked from the state
+    the product held before it: (1) its gradients against the bf16-emulating oracle along the product's branches -- EVERY tensor (no
+    share-of-the-norm filter), per tensor / median / global; (2) Adam: moments and fp32 MASTER weights are the TF-form update of the
+    previous state with the PRODUCT's gradient (fp32 rounding only: this is the optimiser's arithmetic, independent of how noisy the
+    bf16 gradient is); (3) the bf16 copy the GEMMs read during the step equals the master weights the step started from, rounded once
+    (t3d_cast_bf16 runs first in the forward plan); (4) moving statistics against the oracle."""
+    from fake_t3d import hash_keep_mask
+    from model_check import trajectory_batch
+    from transferable3d_amd.step import build_training_step
+    B, N, C = 8, 256, 4
+    P0 = R.init_params(np.random.RandomState(41), R.layer_table(C, 'A'))
+    c = R.default_config()
+    rt = Runtime(lib=hip_lib)
+    g, model, step, loss_buf = build_training_step(rt, 'A', B, N, C, dtype='bf16', inline_dropout=True, dropout_seed=1234,
+                                                   state_dict={k: v.detach().cpu().numpy() for k, v in P0.items()})
+    vs = g.vars
+    names = [k for k, (off, shape, tr) in vs.index.items() if tr]
+
+    def flat(buf, k):
+        off, shape, _ = vs.index[k]
+        return torch.as_tensor(buf[off:off + int(np.prod(shape))].detach().float().cpu().numpy().astype(np.float64)).reshape(shape)
+
+    worst = dict(grad=0.0, med=0.0, w=0.0)
+    for k in range(4):
+        batch = trajectory_batch('A', B, N, C, seed=900 + k)
+        Pk = {n_: torch.as_tensor(v.astype(np.float64)) for n_, v in vs.state_dict().items()}
+        m0 = {n_: flat(vs.adam_m, n_) for n_ in names}
+        v0 = {n_: flat(vs.adam_v, n_) for n_ in names}
+        model.inputs.load(batch)
+        torch.cuda.synchronize()
+        step.run()
+        torch.cuda.synchronize()
+        # (3) the bf16 copy used by this step's GEMMs == bf16(master weights before the step)
+        for n_ in names:
+            if n_.endswith('/weights') and 'conv' in n_ and 'conv10' not in n_:
+                off, shape, _ = vs.index[n_]
+                cp = vs.params16[off:off + int(np.prod(shape))].float().cpu()
+                ref = Pk[n_].to(torch.float32).to(torch.bfloat16).float().reshape(-1)
+                assert torch.equal(cp, ref), ('bf16 copy', n_, k)
+        masks = {'inst_seg/dp1': hash_keep_mask((g.dropout_seed + 0x5EED) & 0xffffffff, k + 1, B * N * 128, 0.5).reshape(B, N, 128)}
+        ob = dict(batch)
+        ob['dropout_masks'] = masks
+        forced = product_decisions(model)
+        forced['bf16'] = True
+        bn_d, lr = R.bn_decay(k, B), R.learning_rate(k, B)
+        loss, ep, grads, ema = R.model_a_forward_backward(Pk, ob, c, bn_decay_val=bn_d, forced=forced)
+        check_bf16_decisions(ep['__margins__'], 'bf16 step %d' % k)
+        assert abs(float(loss_buf) - float(loss)) < 2e-2 * max(1.0, abs(float(loss))), (k, float(loss_buf), float(loss))
+        # (1) every gradient tensor
+        per, glob = grad_errors(g, {n_: v.numpy() for n_, v in grads.items()})
+        top = sorted(per.items(), key=lambda kv: -kv[1])[:3]
+        med = float(np.median(list(per.values())))
+        assert top[0][1] < 4e-2 and med < GRAD_MED and glob < GRAD_GLOB, (k, top, med, glob)      # EVERY tensor <= 4e-2 (measured 1.6e-2)
+        worst['grad'], worst['med'] = max(worst['grad'], top[0][1]), max(worst['med'], med)
+        # (2) Adam on the PRODUCT's gradient
+        gp = {n_: flat(vs.grads, n_) for n_ in grads}
+        Pn = {n_: Pk[n_].clone() for n_ in grads}
+        m1 = {n_: m0[n_].clone() for n_ in grads}
+        v1 = {n_: v0[n_].clone() for n_ in grads}
+        R.adam_tf_step(Pn, gp, m1, v1, k + 1, lr)
+        for n_ in grads:
+            mscale, vscale = max(float(m1[n_].abs().max()), 1e-30), max(float(v1[n_].max()), 1e-60)
+            assert float((flat(vs.adam_m, n_) - m1[n_]).abs().max()) < 1e-5 * mscale, ('adam m', n_, k)
+            assert float((flat(vs.adam_v, n_) - v1[n_]).abs().max()) < 5e-5 * vscale, ('adam v', n_, k)      # g*g, then the blend: two fp32 roundings
+            sel = torch.sqrt(v1[n_]) > 1e-2 * np.sqrt(vscale)            # entries whose second moment is above fp32 noise
+            if bool(sel.any()):
+                werr = float((flat(vs.params, n_) - Pn[n_]).abs()[sel].max())
+                assert werr < 2e-5, ('master weights', n_, k, werr)
+                worst['w'] = max(worst['w'], werr)
+        # (4) moving statistics
+        for n_, v in ema.items():
+            mine = vs.get(n_).detach().cpu().numpy()
+            assert np.abs(mine - v.detach().numpy()).max() < EMA_TOL * max(1.0, float(v.abs().max())), (n_, k)
+    print('bf16 trajectory: worst per-tensor gradient error %.3g, worst median %.3g, worst master-weight error %.3g' %
+          (worst['grad'], worst['med'], worst['w']))
