@@ -371,15 +371,29 @@ def main():
             'F': 'SEMI_MODEL F stage c (frozen seg + Box-PC branch, var_list optimiser) fwd+bwd+Adam'}[args.workload]
     # the SAME step object the drivers run and tests/test_step_gpu.py checks against the oracle trajectory: device schedules, the
     # seg head's in-kernel dropout, forward, backward, TF-form Adam; data parallel: gradient buckets all-reduced beside the backward
-    g, model, trainstep, loss_t = build_training_step(
-        rt, args.workload, B, N, C, world=world, rank=rank, process_group=dist.group.WORLD if use_dist else None,
-        force_dist=use_dist and world == 1, flat_allreduce=os.environ.get('T3D_DP_FLAT', '1') == '1',
-        use_hip_graph=not args.no_graph, inline_dropout=True, dropout_seed=1234, seed=0, dtype=args.dtype)
-    loss_buf = lambda: loss_t
-    batch = make_batch(B, N, C, seed=1234 + rank, boxpc=args.workload == 'boxpc')  # per-rank shard (weak scaling)
-    if args.workload == 'F':
-        batch['is_data_2D'][::2] = 1
-    model.inputs.load(batch)
+    # T3D_PIPELINE=1 (single replica, SEMI_MODEL A, fp32): the software-pipelined step (step.PipelinedStep: the seg forward of step
+    # k+1 beside the T-Net / box chain of step k; bit-identical to the one-step-at-a-time program).  Measured SLOWER on one MI355X
+    # (1.501 vs 1.486 ms, same-box A/B gpurun_out/r03/ab_v5): off by default.
+    pipelined = (world == 1 and not use_dist and args.workload == 'A' and args.dtype == 'f32' and
+                 os.environ.get('T3D_PIPELINE', '0') == '1')
+    if pipelined:
+        from transferable3d_amd.step import build_pipelined_step
+        trainstep, ctxs = build_pipelined_step(rt, B, N, C, use_hip_graph=not args.no_graph, inline_dropout=True, dropout_seed=1234, seed=0)
+        g, model = ctxs[0]['g'], ctxs[0]['model']
+        batch = make_batch(B, N, C, seed=1234 + rank)
+        for cx in ctxs:                             # the same synthetic batch every step: both contexts hold it
+            cx['model'].inputs.load(batch)
+        loss_buf = lambda: trainstep.loss(trainstep.n_runs - 1)
+    else:
+        g, model, trainstep, loss_t = build_training_step(
+            rt, args.workload, B, N, C, world=world, rank=rank, process_group=dist.group.WORLD if use_dist else None,
+            force_dist=use_dist and world == 1, flat_allreduce=os.environ.get('T3D_DP_FLAT', '1') == '1',
+            use_hip_graph=not args.no_graph, inline_dropout=True, dropout_seed=1234, seed=0, dtype=args.dtype)
+        loss_buf = lambda: loss_t
+        batch = make_batch(B, N, C, seed=1234 + rank, boxpc=args.workload == 'boxpc')  # per-rank shard (weak scaling)
+        if args.workload == 'F':
+            batch['is_data_2D'][::2] = 1
+        model.inputs.load(batch)
     torch.cuda.synchronize()
     use_graph = trainstep.want_graph
     step = trainstep.run
@@ -419,8 +433,13 @@ def main():
     if rank == 0 and args.profile_steps > 0:
         # per-kernel timing for the roofline object (eager, per-launch events on the launch stream)
         # the launches of the program that was timed (the scheduled one: step.TrainStep._overlap), not of the plans it was made from
-        prog = trainstep.cache[True]['prog'] if True in trainstep.cache else []
-        plans = [x for kind, x in prog if kind == 'run'] if (prog and all(kind == 'run' for kind, _ in prog)) else [g.pre, g.fwd, g.bwd, g.opt]
+        if pipelined:
+            trainstep.run(last=True)      # (untimed) finish the step whose forward the last timed call started: no forward is pending
+            torch.cuda.synchronize()
+            plans = trainstep.profile_plans()
+        else:
+            prog = trainstep.cache[True]['prog'] if True in trainstep.cache else []
+            plans = [x for kind, x in prog if kind == 'run'] if (prog and all(kind == 'run' for kind, _ in prog)) else [g.pre, g.fwd, g.bwd, g.opt]
         acc, detail = profile_kernels(plans, args.profile_steps)
         total = sum(v[0] for v in acc.values())
         dom = max((k for k in acc if k.startswith(('k_pointmlp', 'k_pool_bwd_stage'))), key=lambda k: acc[k][0])
@@ -499,8 +518,10 @@ def main():
                'config': {'workload': '%s, B=%d N=%d C=%d %s per GPU, dp%d' % (desc, B, N, C, 'fp32' if args.dtype == 'f32' else 'bf16', world),
                           'global_batch': B * world, 'hipgraph': use_graph, 'graph_segments_per_step': trainstep.n_graph_segments(),
                           'gradient_buckets': len(g.buckets) if trainstep.dist else 0,
-                          'launches_per_step': (sum(len(x) for kind, x in trainstep.cache[True]['prog'] if kind == 'run')
+                          'launches_per_step': (trainstep.n_launches() if pipelined else
+                                                sum(len(x) for kind, x in trainstep.cache[True]['prog'] if kind == 'run')
                                                 if True in trainstep.cache else len(g.pre) + len(g.fwd) + len(g.bwd) + len(g.opt)),
+                          'pipelined': pipelined,
                           'schedule': ({k: v for k, v in trainstep.schedule_report.items() if k != 'lines'}
                                        if trainstep.schedule_report else None), 'final_loss': loss},
                'roofline': roofline, 'cpu_baseline': cpu, 'other_configs': others}

@@ -853,6 +853,8 @@ typedef struct {
   float bn_init_decay, bn_decay_rate, bn_decay_step, bn_decay_clip;
   float beta1, beta2;
   int batch_size;
+  int step_offset;         /* the step this call runs is hyper[0] + step_offset (0: every call advances one counter; 1: two counters
+                            * advance alternately -- the two contexts of the software-pipelined step, step.PipelinedStep) */
 } t3d_schedule;
 int t3d_schedule_step(float* hyper, const t3d_schedule* s, t3d_stream_t stream);
 

@@ -1316,7 +1316,7 @@ class FakeLib:
     def t3d_schedule_step(self, hyper, s, stream):
         h = arr(hyper, 4)
         s = _struct(s)
-        step = float(h[0])
+        step = float(h[0]) + s.step_offset
         seen = step * s.batch_size
         lr = s.base_lr * s.lr_decay_rate ** math.floor(seen / s.lr_decay_step)
         bnd = min(s.bn_decay_clip, 1 - s.bn_init_decay * s.bn_decay_rate ** math.floor(seen / s.bn_decay_step))

@@ -218,7 +218,7 @@ class SlabDesc(C.Structure):
 class Schedule(C.Structure):
     _fields_ = [('base_lr', f32), ('lr_decay_rate', f32), ('lr_decay_step', f32), ('bn_init_decay', f32),
                 ('bn_decay_rate', f32), ('bn_decay_step', f32), ('bn_decay_clip', f32), ('beta1', f32), ('beta2', f32),
-                ('batch_size', i32)]
+                ('batch_size', i32), ('step_offset', i32)]
 
 
 class BoxPcRepArgs(C.Structure):

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_pool_bwd_mid(const float* __restrict__ 
 __global__ void k_schedule_step(float* hyper, const t3d_schedule s) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   // global step BEFORE this update drives lr / bn_decay (tf: minimize() increments after use)
-  const double step = (double)hyper[0];
+  const double step = (double)hyper[0] + (double)s.step_offset;
   const double seen = step * (double)s.batch_size;
   const double lr = (double)s.base_lr * pow((double)s.lr_decay_rate, floor(seen / (double)s.lr_decay_step));
   const double bnm = (double)s.bn_init_decay * pow((double)s.bn_decay_rate, floor(seen / (double)s.bn_decay_step));

@@ -173,7 +173,7 @@ def make_schedule(batch_size, base_lr=1e-3, decay_step=800000, decay_rate=0.5, b
                   bn_decay_rate=0.5, bn_decay_clip=0.99, beta1=0.9, beta2=0.999):
     """train_semisup.py:53-67,127-145 defaults."""
     return abi.Schedule(base_lr, decay_rate, float(decay_step), bn_init_decay, bn_decay_rate, float(decay_step),
-                        bn_decay_clip, beta1, beta2, batch_size)
+                        bn_decay_clip, beta1, beta2, batch_size, 0)
 
 
 class InstSegNet:
@@ -655,6 +655,14 @@ class ModelAssembly:
             self.g.emit_reduce_slabs(plan)
             return
         i0 = len(plan.calls)
+        head_reduce = None
+        if getattr(self.g, 'split_opt', False):
+            # pipelined step: the slabs recorded by the FORWARD (conv10's weight-gradient partials, written by the seg head) belong to
+            # the seg net's chain: their reduction is recorded now (before the T-Net / box entries join the table) and placed behind
+            # `S_begin` below
+            from .engine import Plan as _Plan
+            head_reduce = _Plan(self.g.rt)
+            self.g.emit_reduce_slabs(head_reduce)
         ds1 = self.box.bwd(plan, self.loss_op.dbox, self.loss_op.dstage1)
         plan.flush()                     # box-net weight gradients run beside the T-Net / seg-net dgrad chain
         self.tnet.bwd(plan, ds1)
@@ -668,8 +676,16 @@ class ModelAssembly:
         # single replica, no weak-loss gradient into the seg net: the seg backward is independent of everything since `T_begin`
         # (semisup_models.py:150-151) -- the step scheduler interleaves the two chains (schedule.py); T3D_OVERLAP=0: the pairing below
         overlap = OVERLAP and not g.dp_buckets and self.seg.train_seg and self.weak is None
+        if overlap and getattr(g, 'split_opt', False):
+            g.emit_reduce_slabs(plan)      # software-pipelined step (step.PipelinedStep): the T chain ends with ITS slab reduction + Adam
         if overlap:
             plan.mark('S_begin')
+        if head_reduce is not None:
+            assert overlap, 'split_opt needs the two-chain backward'
+            for cl, ln in zip(head_reduce.calls, head_reduce.lanes):
+                if not cl[0].startswith('__'):
+                    plan.calls.append(cl)
+                    plan.lanes.append(ln)
         self.seg.bwd(plan, part=0)
         self.seg.bwd(plan, part=1)
         g.declare_bucket(plan, [sp + 'conv%d/' % i for i in (6, 7, 8, 9, 10)])

@@ -304,3 +304,155 @@ def build_training_step(rt, workload, B, N, C, world=1, rank=0, process_group=No
     step = TrainStep(g, g.pre, g.fwd, g.bwd, g.opt, process_group=process_group, use_hip_graph=use_hip_graph,
                      force_dist=force_dist)
     return g, model, step, loss
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# software-pipelined training step (single replica, SEMI_MODEL A)
+# ------------------------------------------------------------------------------------------------------------------------------------
+class _Program:
+    """A launch list that is run eagerly once, captured into a hipGraph on its second run, replayed afterwards."""
+
+    def __init__(self, rt, calls, want_graph):
+        self.plan = Plan(rt)
+        self.plan.calls, self.plan.lanes = list(calls), [0] * len(calls)
+        self.want_graph, self.runs, self.graph = want_graph, 0, None
+
+    def run(self, stream_holder):
+        self.runs += 1
+        if not self.want_graph or self.runs == 1:
+            return self.plan.run()
+        if self.graph is None:
+            torch.cuda.synchronize()
+            if stream_holder[0] is None:
+                stream_holder[0] = torch.cuda.Stream()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream_holder[0], capture_error_mode='thread_local'):
+                self.plan.run()
+            self.graph = g
+        self.graph.replay()
+
+
+class PipelinedStep:
+    """SEMI_MODEL A with the forward of step k+1 running beside the rest of step k.
+
+    The segmentation net's forward of step k+1 needs only the seg net's weights after step k -- i.e. the seg BACKWARD of step k and
+    its Adam update -- not the T-Net / box net chain of step k (forward, loss, backward, their Adam), which is the longer of the two
+    chains of a step (718 vs 454 us alone at B=32 N=1024; schedule.py).  So the steady-state unit of work is not
+    [forward | backward] but two chains of equal standing,
+
+        SF_k = seg backward of step k -> slab reduction + Adam of the seg net -> schedules + seg forward of step k+1
+        T_k  = T-Net / box forward, loss, backward of step k -> slab reduction + Adam of T-Net / box net
+
+    aligned launch by launch by schedule.overlap_chains like the two chains of a single step: the ten finalizers, the global-feature
+    FC and the head of the seg forward (80 us with nothing to hide behind in a one-step schedule) ride in T's GEMM launches, and T's
+    small launches find ten more GEMM launches to ride in.  Every variable still sees its updates in the sequential order (seg:
+    S_k, Adam, F_k+1; T-Net / box: T_k, Adam, T_k+1), so weights, Adam moments, losses and moving statistics are bit-identical to the
+    one-step-at-a-time program (tests/test_pipeline_gpu.py, tests/test_pipeline_cpu.py).
+
+    Two CONTEXTS (engine graphs with their own activations, inputs and schedule counters, one shared variable store) alternate:
+    step k runs in context k % 2, its forward was started by the previous call.  Protocol: the inputs of step k+1 must be loaded
+    (`inputs(k + 1).load(batch)`) before `run()` of step k; `run(last=True)` finishes step k without starting a forward (state equal
+    to the sequential program after k+1 steps, moving statistics included)."""
+
+    def __init__(self, rt, ctxs, use_hip_graph=None):
+        from . import schedule
+        self.rt, self.ctxs = rt, ctxs
+        self.on_gpu = rt.device.type == 'cuda'
+        self.want_graph = (bool(use_hip_graph) if use_hip_graph is not None else self.on_gpu) and self.on_gpu
+        self.dist, self.world, self.time_waits = False, 1, False
+        self._sets = schedule.RiderSets(rt)
+        self._stream = [None]
+        self.n_runs = 0
+        self.fwd_pending = False
+        ch = [self._chains(c) for c in ctxs]
+        mk = lambda calls: _Program(rt, calls, self.want_graph)
+        self.head, self.steady, self.tail, self.reports = [], [], [], []
+        for i in (0, 1):
+            me, nxt = ch[i], ch[1 - i]
+            self.head.append(mk(me['pre'] + me['F']))
+            t_chain = me['Tf'] + me['Tb'] + me['adam_T']
+            calls, rep = schedule.overlap_chains(rt, me['S'] + me['reduce_S'] + me['adam_S'] + nxt['pre'] + nxt['F'], t_chain, self._sets)
+            self.steady.append(mk(calls))
+            self.reports.append(rep)
+            calls, _ = schedule.overlap_chains(rt, me['S'] + me['reduce_S'] + me['adam_S'], t_chain, self._sets)
+            self.tail.append(mk(calls))
+        self.schedule_report = self.reports[0]
+
+    @staticmethod
+    def _chains(ctx):
+        g = ctx['g']
+        real = lambda cs: [c for c in cs if not c[0].startswith('__')]
+
+        def split(calls, tag):
+            k = next(i for i, c in enumerate(calls) if c[0] == Plan.MARK and c[2] == tag)
+            return calls[:k], calls[k + 1:]
+        F, Tf = split(g.fwd.calls, 'T_begin')
+        Tb, rest = split(g.bwd.calls, 'S_begin')
+        S, after = split(rest, 'S_end')
+        return dict(pre=real(g.pre.calls), F=real(F), Tf=real(Tf), Tb=real(Tb), S=real(S), reduce_S=real(after),
+                    adam_T=real(ctx['opt_T'].calls), adam_S=real(ctx['opt_S'].calls))
+
+    def inputs(self, k=None):
+        """nets.Inputs of the context step k runs in (default: the step the next run() call completes)."""
+        return self.ctxs[(self.n_runs if k is None else k) % 2]['model'].inputs
+
+    def loss(self, k):
+        return self.ctxs[k % 2]['loss']
+
+    def run(self, last=False):
+        """Completes step k = n_runs (its forward runs first if no earlier call started it) and, unless `last`, starts the forward
+        of step k+1 beside it."""
+        i = self.n_runs % 2
+        if not self.fwd_pending:
+            self.head[i].run(self._stream)
+        (self.tail if last else self.steady)[i].run(self._stream)
+        self.fwd_pending = not last
+        self.n_runs += 1
+
+    # ---- what bench.py asks of a step object -------------------------------------------------------------------------------
+    def profile_plans(self):
+        return [self.steady[0].plan]
+
+    def n_launches(self):
+        return len(self.steady[0].plan)
+
+    def n_graph_segments(self, generate_masks=True):
+        return 1 if self.steady[0].graph is not None else 0
+
+    def rider_timeouts(self):
+        return self._sets.timeouts()
+
+
+def build_pipelined_step(rt, B, N, C, use_hip_graph=None, inline_dropout=True, dropout_seed=1234, seed=0, state_dict=None, c=None):
+    """Two contexts of SEMI_MODEL A over one variable store + the PipelinedStep that alternates them.  Returns (step, contexts):
+    context = dict(g, model, loss, ...); `contexts[0]['g'].vars` is the shared store."""
+    from .nets import Graph, SemiModelA, make_schedule
+    c = c if c is not None else workload_flags('A')
+    ctxs, vs = [], None
+    for i in (0, 1):
+        g = Graph(B, N, C, rt=rt, seed=seed, vars=vs)
+        vs = g.vars
+        g.inline_dropout, g.dropout_seed = inline_dropout, dropout_seed
+        g.split_opt = True
+        model = SemiModelA(g, c)
+        if i == 0 and state_dict is not None:
+            g.vars.load_state_dict(state_dict)
+        sched = make_schedule(B)
+        sched.step_offset = 1                       # this context runs every other step: step = its counter + 1 ...
+        g.hyper[0] = float(i - 1)                   # ... starting at step i
+        g.emit_schedule(g.pre, sched)
+        g.emit_dropout_masks(g.pre, seed=dropout_seed)
+        model.emit_forward(g.fwd, True, True)
+        model.emit_backward(g.bwd)
+        assert any(cl[0] == Plan.MARK and cl[2] == 'S_begin' for cl in g.bwd.calls), 'the pipelined step needs the two-chain backward'
+        opt_T, opt_S = Plan(rt), Plan(rt)
+        g.emit_adam(opt_T, prefixes=[model.tnet.scope + '/', model.box.scope + '/'])
+        g.emit_adam(opt_S, prefixes=[model.seg.scope + '/'])
+        g.trained_prefixes = None
+        g.finalize()
+        ctxs.append(dict(g=g, model=model, loss=model.loss_op.loss, opt_T=opt_T, opt_S=opt_S))
+    n_tr = sum(n for _, n in vs.trainable_ranges(None))
+    n_cov = sum(n for pre in ([ctxs[0]['model'].tnet.scope + '/', ctxs[0]['model'].box.scope + '/'], [ctxs[0]['model'].seg.scope + '/'])
+                for _, n in vs.trainable_ranges(pre))
+    assert n_tr == n_cov, 'the two optimiser launches must cover every trainable variable'
+    return PipelinedStep(rt, ctxs, use_hip_graph=use_hip_graph), ctxs
