@@ -74,4 +74,9 @@ print('(b) one rider set, in-launch barriers   %7.1f us' % timed(lambda st: lib.
 print('(d) the GEMM alone                      %7.1f us' % timed(lambda st: lib.t3d_pointmlp_fwd(C.byref(fa), st)))
 print('(c) the GEMM with the set riding        %7.1f us' % timed(lambda st: lib.t3d_pointmlp_fwd_r(C.byref(fa), C.byref(rs), st)))
 print("(c') the GEMM with ONE op riding         %7.1f us" % timed(lambda st: lib.t3d_pointmlp_fwd_r(C.byref(fa), C.byref(rs1[1]), st)))
+# the `_r` kernel with a rider that does next to nothing (one block of a 256-element column sum): what the rider form itself costs the GEMM
+cs_psum, cs_coef, cs_out = t(np.zeros((8, 32))), t(np.ones((3, 32))), t(np.zeros((8, 32)))
+cs = abi.DyColsumArgs(fptr(cs_psum), fptr(cs_psum), fptr(cs_coef), 8, 32, 1, 128, 1.0, fptr(cs_out))
+rs0 = sets.make([('t3d_dy_colsum', cs)])
+print("(c0) the GEMM's rider form, trivial rider    %7.1f us" % timed(lambda st: lib.t3d_pointmlp_fwd_r(C.byref(fa), C.byref(rs0), st)))
 print('timeouts', sets.timeouts())
