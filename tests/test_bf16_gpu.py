@@ -19,8 +19,9 @@ plain fp64 oracle).  Hence two kinds of bounds:
     way); the T3D_BF16 GEMM kernels one by one
     against torch matmuls of the same rounded operands: tests/test_kernels_bf16_gpu.py (one rounding of the output, nothing else);
   * END TO END: forward heads within 6e-2 * max(1, |ref|_max), loss within 1e-2 relative, moving statistics within 1e-2 *
-    max(1, |ref|_max); every gradient tensor that carries at least 1 % of the gradient norm within 1.2e-1 relative L2, the median
-    tensor within 4e-2, all gradients together within 5e-2.
+    max(1, |ref|_max); every gradient tensor that carries at least 1 % of the gradient norm within 5e-2 relative L2, the median
+    tensor within 2.5e-2, all gradients together within 3.5e-2; EVERY tensor within 2.5e-1 or absolutely negligible; a four-step
+    trajectory (every tensor within 4e-2 there, Adam on the master weights, the bf16 copy).
 The distance to the un-emulated fp64 oracle is printed, not asserted."""
 import numpy as np
 import pytest
@@ -34,7 +35,7 @@ from transferable3d_amd.synthetic import make_batch
 
 pytestmark = pytest.mark.gpu
 
-FWD_TOL, LOSS_TOL, GRAD_PER, GRAD_MED, GRAD_GLOB, EMA_TOL = 6e-2, 1e-2, 1.2e-1, 4e-2, 5e-2, 1e-2
+FWD_TOL, LOSS_TOL, GRAD_PER, GRAD_MED, GRAD_GLOB, EMA_TOL = 6e-2, 1e-2, 5e-2, 2.5e-2, 3.5e-2, 1e-2      # (round 2: 1.2e-1, 4e-2, 5e-2; measured 3.6e-2, 1.2e-2, 2.3e-2)
 
 
 def check_bf16_decisions(margins, what):
