@@ -427,6 +427,10 @@ def main():
         trainstep.time_waits = False
     loss = float(loss_buf().item())
     assert np.isfinite(loss), 'non-finite loss'
+    # a rider barrier that ever gave up waiting (t3d.h t3d_rider_set.sync) would mean wrong results: fail loudly
+    sets = getattr(trainstep, '_sets', None)
+    rider_timeouts = sets.timeouts() if sets is not None else 0
+    assert rider_timeouts == 0, 'a rider barrier timed out: the results of the step are invalid'
 
     roofline = None
     cpu = None
@@ -522,8 +526,9 @@ def main():
                                                 sum(len(x) for kind, x in trainstep.cache[True]['prog'] if kind == 'run')
                                                 if True in trainstep.cache else len(g.pre) + len(g.fwd) + len(g.bwd) + len(g.opt)),
                           'pipelined': pipelined,
-                          'schedule': ({k: v for k, v in trainstep.schedule_report.items() if k != 'lines'}
-                                       if trainstep.schedule_report else None), 'final_loss': loss},
+                          'schedule': (dict({k: v for k, v in trainstep.schedule_report.items() if k != 'lines'},
+                                            rider_barrier_timeouts=rider_timeouts) if trainstep.schedule_report else None),
+                          'final_loss': loss},
                'roofline': roofline, 'cpu_baseline': cpu, 'other_configs': others}
         if trainstep.dist:
             out['config']['dp'] = trainstep.dp_report()
