@@ -594,7 +594,10 @@ int t3d_boxpc_rep_bwd(const t3d_boxpc_rep_bwd_args* args, t3d_stream_t stream);
 
 /* Box-PC loss, forward + backward (boxpc_sunrgbd.py:106-193, huber form): out[B,9] = [dcentre(3), dsize(3), dangle,
  * fit logits(2)];  loss = mean_b( w_cls*CE(logits, iou > fit_bound) + w_delta*wl*(w_center*mean3 Huber + w_size*mean3
- * Huber + w_angle*Huber) ).  terms[B,4] = (CE, delta loss, p_fit, total). */
+ * Huber + w_angle*Huber) ).  terms[B,4] = (CE, delta loss, p_fit, total).
+ * weigh_pred_by_cls_conf (BOXPC_WEIGH_DELTA_PRED_BY_CLS_CONF, boxpc_sunrgbd.py:84-92): the Huber terms see the PREDICTED deltas
+ * times (1 - p_fit).  grad_cls_via_delta = !BOXPC_STOP_GRAD_OF_CLS_VIA_DELTA (boxpc_sunrgbd.py:73-74): p_fit inside wl / the
+ * prediction weight is differentiated (the gradient reaches the fit logits); 0 = stop_gradient, the recipes' setting. */
 typedef struct {
   const float* out;               /* [B,9] */
   const float* y_box_iou; const float* y_center_delta; const float* y_dims_delta; const float* y_orient_delta;
@@ -604,6 +607,8 @@ typedef struct {
   float* terms;                   /* [B,4] */
   float* loss;                    /* [1] */
   int B;
+  int weigh_pred_by_cls_conf, grad_cls_via_delta;
+  int delta_loss_mse;             /* BOXPC_DELTA_LOSS_TYPE == 'mse' (boxpc_sunrgbd.py:158-164): squared error instead of Huber */
 } t3d_boxpc_loss_args;
 int t3d_boxpc_loss(const t3d_boxpc_loss_args* args, t3d_stream_t stream);
 
@@ -657,7 +662,9 @@ typedef struct {
 int t3d_anchor_reg_bwd(const t3d_anchor_reg_bwd_args* args, t3d_stream_t stream);
 
 /* One step of the iterated Box-PC refinement of the inference graph (test_semisup.py:101-134):
- *   p_fit = softmax(out9[:,7:9])[:,1];  w = weigh_by_conf ? 1 - p_fit : 1   (SEMI_WEIGH_BOXPC_DELTA_DURING_TEST)
+ *   p_fit = softmax(out9[:,7:9])[:,1];  w = (1 - p_fit)^weigh_by_conf, weigh_by_conf = 0, 1 or 2: one factor for
+ *   SEMI_WEIGH_BOXPC_DELTA_DURING_TEST (test_semisup.py:119-121), one for BOXPC_WEIGH_DELTA_PRED_BY_CLS_CONF (the Box-PC
+ *   model's own weighting of its predicted deltas, boxpc_sunrgbd.py:84-92)
  *   box_out = box_in - w * out9[:,0:7]  (centre 0:3, size 3:6, angle 6);  total (+)= w * out9[:,0:7]  (`first`: =)
  * The F2_ heads are the F_ heads minus `total` (test_semisup.py:136-142). */
 typedef struct {
@@ -671,6 +678,26 @@ typedef struct {
   int B;
 } t3d_box_refine_step_args;
 int t3d_box_refine_step(const t3d_box_refine_step_args* args, t3d_stream_t stream);
+
+/* Backward of one refinement step inside the TRAINING graph (train_semisup_adv.py:362-386 with SEMI_REFINE_USING_BOXPC_DELTA_NUM > 1
+ * and SEMI_BOXPC_MIN_FIT_LOSS_AFT_REFINE: the fit loss reads the Box-PC evaluation of the box refined NUM-1 times, so its gradient
+ * runs back through every step  box_next = box - w * out9[:,0:7],  w = (1 - p_fit)^weigh_by_conf):
+ *   tot = dbox_rep + carry            gradient w.r.t. box_next: through the next evaluation's representation (t3d_boxpc_rep_bwd)
+ *                                     + what flows past it to the steps behind (carry, NULL at the last step)
+ *   tot_out = tot                     (the identity path: the carry of the step before)
+ *   dout9[:,0:7] = -w * tot;  dout9[:,7:9] = (grad_via_conf ? d w / d logits . sum_k tot_k * (-out9_k) : 0)
+ * With out9 == NULL only tot_out is written (the total gradient w.r.t. the unrefined box). */
+typedef struct {
+  const float* out9;              /* [B,9] Box-PC output of THIS step's evaluation, or NULL */
+  const float* dbox_rep;          /* [B,7] */
+  const float* carry;             /* [B,7] or NULL */
+  float* tot_out;                 /* [B,7] (may alias carry or dbox_rep) */
+  float* dout9;                   /* [B,9], required with out9 */
+  int weigh_by_conf;              /* as t3d_box_refine_step */
+  int grad_via_conf;              /* !BOXPC_STOP_GRAD_OF_CLS_VIA_DELTA (boxpc_sunrgbd.py:73-74) */
+  int B;
+} t3d_box_refine_step_bwd_args;
+int t3d_box_refine_step_bwd(const t3d_box_refine_step_bwd_args* args, t3d_stream_t stream);
 
 /* ---- K13: 3-D IoU of upright boxes ---------------------------------------------------------------------
  * Replaces box_util.box3d_iou (the Frustum-PointNets module the reference imports but does not ship) at its call sites:
@@ -695,6 +722,19 @@ typedef struct {
   int n;
 } t3d_box3d_iou_corners_args;
 int t3d_box3d_iou_corners(const t3d_box3d_iou_corners_args* args, t3d_stream_t stream);
+
+/* The extra fully-connected input columns of v1_tnet / v1_box_est under USE_NORMALIZED_BOX2D_AS_FEATS
+ * (semisup_models.py:192-195, 249-252: concat [pooled | one_hot | norm_box2D]): out[B, n_oh + 4] = [one_hot (n_oh = 0 or 10) |
+ * tf_util.tf_normalize_2D_bboxes(box2D, img_dim) (tf_util.py:466-484) = left/cols, top/rows, right/cols, bottom/rows with
+ * img_dim = (rows, cols)].  Inputs are placeholders: no gradient. */
+typedef struct {
+  const float* one_hot; int n_oh;        /* [B, n_oh] or NULL with n_oh = 0 */
+  const float* box2D;                    /* [B,4] */
+  const float* img_dim;                  /* [B,2] */
+  float* out;                            /* [B, n_oh + 4] */
+  int B;
+} t3d_box2d_feats_args;
+int t3d_box2d_feats(const t3d_box2d_feats_args* args, t3d_stream_t stream);
 
 /* compute_box3d_iou on raw box heads (roi_seg_box3d_dataset.py:103-140): box[B,67] = [centre - stage1_center (3), heading scores
  * (12), normalised heading residuals (12), size scores (10), normalised size residuals (10x3)]; predicted box from the arg-max

@@ -14,6 +14,7 @@ a flat dict keyed by the reference's TF variable names (`<scope>/weights`, `<sco
 `<scope>/bn/{beta,gamma,moving_mean,moving_variance}`).
 """
 import math
+import re
 from types import SimpleNamespace
 
 import numpy as np
@@ -28,7 +29,7 @@ from .ref_constants import NUM_HEADING_BIN, NUM_SIZE_CLUSTER, NUM_CLASS, MEAN_DI
 # ----------------------------------------------------------------------------------------------
 # (scope, kind, Cin, Cout, bn) in creation order.  kind: 'conv' = tf_util.conv2d per-point layer,
 # 'fc' = tf_util.fully_connected.  `cin` of the first conv of each net is filled from the channels.
-def layer_table(num_channels, model='A', use_one_hot=False, prefix_agnostic='', boxpc_channels=None):
+def layer_table(num_channels, model='A', use_one_hot=False, prefix_agnostic='', boxpc_channels=None, norm_box2D=False):
     """Layer list of the nets on the path.
 
     model 'A': inst_seg + tnet + box_est (semisup_models.py:69-291).
@@ -40,6 +41,7 @@ def layer_table(num_channels, model='A', use_one_hot=False, prefix_agnostic='', 
     if model in ('A', 'F'):
         p = 'class_agnostic/' if model == 'F' else ''
         ohA = oh if model == 'A' else 0      # model F never feeds one_hot to the agnostic nets
+        nb = 4 if norm_box2D else 0          # USE_NORMALIZED_BOX2D_AS_FEATS: fc1 of the T-Net / box net reads 4 more columns (semisup_models.py:194-195, 251-252)
         seg = [('conv1', num_channels, 64), ('conv2', 64, 64), ('conv3', 64, 64), ('conv4', 64, 128),
                ('conv5', 128, 1024), ('conv6', 64 + 1024 + ohA, 512), ('conv7', 512, 256),
                ('conv8', 256, 128), ('conv9', 128, 128)]
@@ -49,13 +51,13 @@ def layer_table(num_channels, model='A', use_one_hot=False, prefix_agnostic='', 
         for n, ci, co in [('conv-reg1-stage1', 3, 128), ('conv-reg2-stage1', 128, 128),
                           ('conv-reg3-stage1', 128, 256)]:
             L.append((p + 'tnet/' + n, 'conv', ci, co, True))
-        L.append((p + 'tnet/fc1-stage1', 'fc', 256 + ohA, 256, True))
+        L.append((p + 'tnet/fc1-stage1', 'fc', 256 + ohA + nb, 256, True))
         L.append((p + 'tnet/fc2-stage1', 'fc', 256, 128, True))
         L.append((p + 'tnet/fc3-stage1', 'fc', 128, 3, False))
         for n, ci, co in [('conv-reg1', 3, 128), ('conv-reg2', 128, 128), ('conv-reg3', 128, 256),
                           ('conv-reg4', 256, 512)]:
             L.append((p + 'box_est/' + n, 'conv', ci, co, True))
-        L.append((p + 'box_est/fc1', 'fc', 512 + ohA, 512, True))
+        L.append((p + 'box_est/fc1', 'fc', 512 + ohA + nb, 512, True))
         L.append((p + 'box_est/fc2', 'fc', 512, 256, True))
         L.append((p + 'box_est/fc3', 'fc', 256, BOX_OUT_DIMS, False))
         if model == 'F':
@@ -110,6 +112,25 @@ def init_params(rng, table, dtype=torch.float64, first_conv_kernel_is_1xD=True):
             P[scope + '/bn/moving_mean'] = torch.zeros(co, dtype=dtype)
             P[scope + '/bn/moving_variance'] = torch.ones(co, dtype=dtype)
     return P
+
+
+class SharedParams(dict):
+    """Variables looked up under a RE-USED scope (tf.variable_scope('D_boxpc_branch', reuse=True), train_semisup_adv.py:341-369): the
+    k-th further evaluation of the Box-PC net runs under the scope tag `D_boxpc_branch@k/`, which reads the variables of
+    `D_boxpc_branch/` while keeping its per-scope records (forced decisions, margins) apart from the other evaluations'."""
+
+    @staticmethod
+    def _k(k):
+        return re.sub(r'@\d+/', '/', k)
+
+    def __getitem__(self, k):
+        return dict.__getitem__(self, self._k(k))
+
+    def __contains__(self, k):
+        return dict.__contains__(self, self._k(k))
+
+    def get(self, k, d=None):
+        return dict.get(self, self._k(k), d)
 
 
 def trainable_names(P):
@@ -317,7 +338,21 @@ def subtract_points_mean(pc, logits, ctx=None):
     return mask, mean, xyz, xyz - mean
 
 
-def v1_tnet(ctx, xyz_stage1, mask, mask_xyz_mean, one_hot_vec, ep, scope='tnet'):
+def tf_normalize_2D_bboxes(box2D, image_dim):
+    """tf_util.py:466-484: image_dim = (rows, cols); [left/cols, top/rows, right/cols, bottom/rows]."""
+    rows, cols = image_dim[:, 0], image_dim[:, 1]
+    return torch.stack([box2D[:, 0] / cols, box2D[:, 1] / rows, box2D[:, 2] / cols, box2D[:, 3] / rows], dim=1)
+
+
+def batch_norm_box2D(batch, c, dtype):
+    """norm_box2D as the drivers build it (train_semisup.py:240), or None unless USE_NORMALIZED_BOX2D_AS_FEATS
+    (semisup_v1_sunrgbd.py:97,145)."""
+    if not getattr(c, 'USE_NORMALIZED_BOX2D_AS_FEATS', False):
+        return None
+    return tf_normalize_2D_bboxes(torch.as_tensor(batch['box2D'], dtype=dtype), torch.as_tensor(batch['img_dim'], dtype=dtype))
+
+
+def v1_tnet(ctx, xyz_stage1, mask, mask_xyz_mean, one_hot_vec, ep, scope='tnet', norm_box2D=None):
     """semisup_models.py:164-202."""
     net = conv2d(ctx, xyz_stage1, scope + '/conv-reg1-stage1')
     net = conv2d(ctx, net, scope + '/conv-reg2-stage1')
@@ -326,6 +361,8 @@ def v1_tnet(ctx, xyz_stage1, mask, mask_xyz_mean, one_hot_vec, ep, scope='tnet')
     ep['tnet_feats'] = net
     if one_hot_vec is not None:
         net = torch.cat([net, one_hot_vec], dim=1)
+    if norm_box2D is not None:
+        net = torch.cat([net, norm_box2D], dim=1)
     net = fully_connected(ctx, net, scope + '/fc1-stage1', bn=True)
     net = fully_connected(ctx, net, scope + '/fc2-stage1', bn=True)
     c = fully_connected(ctx, net, scope + '/fc3-stage1', activation=None)
@@ -352,7 +389,7 @@ def _slice_box_heads(out, stage1_center, ep, prefix, dtype):
             ep[prefix + 'heading_scores'], ep[prefix + 'heading_residuals'])
 
 
-def v1_box_est(ctx, xyz_submean, stage1_center, mask, one_hot_vec, ep, prefix='', scope='box_est'):
+def v1_box_est(ctx, xyz_submean, stage1_center, mask, one_hot_vec, ep, prefix='', scope='box_est', norm_box2D=None):
     """semisup_models.py:215-291."""
     net = conv2d(ctx, xyz_submean, scope + '/conv-reg1')
     net = conv2d(ctx, net, scope + '/conv-reg2')
@@ -362,6 +399,8 @@ def v1_box_est(ctx, xyz_submean, stage1_center, mask, one_hot_vec, ep, prefix=''
     ep[prefix + 'feats_lv1'] = net
     if one_hot_vec is not None:
         net = torch.cat([net, one_hot_vec], dim=1)
+    if norm_box2D is not None:
+        net = torch.cat([net, norm_box2D], dim=1)
     net = fully_connected(ctx, net, scope + '/fc1', bn=True)
     ep[prefix + 'feats_lv2'] = net
     net = fully_connected(ctx, net, scope + '/fc2', bn=True)
@@ -385,7 +424,7 @@ def anchor_to_reg(pred_box, dtype):
     return center, dims, theta
 
 
-def get_semi_model_backbone(ctx, pc, one_hot_vec, use_one_hot=False):
+def get_semi_model_backbone(ctx, pc, one_hot_vec, use_one_hot=False, norm_box2D=None):
     """semisup_v1_sunrgbd.py:81-130 (SEMI_MODEL A)."""
     ep = {'point_cloud': pc, 'class_one_hot': one_hot_vec,
           'class_ids': torch.argmax(one_hot_vec, dim=1).to(torch.int32)}
@@ -396,9 +435,9 @@ def get_semi_model_backbone(ctx, pc, one_hot_vec, use_one_hot=False):
     mask, mean, xyz, xyz1 = subtract_points_mean(pc, logits, ctx)
     ep['mask'] = mask
     ep['mask_xyz_mean'] = mean
-    s1 = v1_tnet(ctx, xyz1, mask, mean, oh, ep, 'tnet')
+    s1 = v1_tnet(ctx, xyz1, mask, mean, oh, ep, 'tnet', norm_box2D=norm_box2D)
     xyz2 = xyz - s1[:, None, :]
-    pred_box = v1_box_est(ctx, xyz2, s1, mask, oh, ep, '', 'box_est')
+    pred_box = v1_box_est(ctx, xyz2, s1, mask, oh, ep, '', 'box_est', norm_box2D=norm_box2D)
     ep['S_pred_box'] = pred_box
     ep['S_pred_box_reg'] = anchor_to_reg(pred_box, pc.dtype)
     return (logits, pred_box), ep
@@ -415,7 +454,7 @@ def mlps_with_dropout(ctx, x, scope, n_layers, activations, keep_probs):
     return net
 
 
-def get_semi_model_final(ctx, pc, one_hot_vec, use_one_hot, c):
+def get_semi_model_final(ctx, pc, one_hot_vec, use_one_hot, c, norm_box2D=None):
     """semisup_v1_sunrgbd.py:132-230 (SEMI_MODEL F)."""
     ep = {'point_cloud': pc, 'class_one_hot': one_hot_vec,
           'class_ids': torch.argmax(one_hot_vec, dim=1).to(torch.int32)}
@@ -425,9 +464,9 @@ def get_semi_model_final(ctx, pc, one_hot_vec, use_one_hot, c):
     mask, mean, xyz, xyz1 = subtract_points_mean(pc, logits, ctx)
     ep['mask'] = mask
     ep['mask_xyz_mean'] = mean
-    s1 = v1_tnet(ctx, xyz1, mask, mean, None, ep, p + 'tnet')
+    s1 = v1_tnet(ctx, xyz1, mask, mean, None, ep, p + 'tnet', norm_box2D=norm_box2D)
     xyz2 = xyz - s1[:, None, :]
-    W_pred_box = v1_box_est(ctx, xyz2, s1, mask, None, ep, '', p + 'box_est')
+    W_pred_box = v1_box_est(ctx, xyz2, s1, mask, None, ep, '', p + 'box_est', norm_box2D=norm_box2D)
     feat = ep['feats_lv1']
     if use_one_hot:
         feat = torch.cat([feat, one_hot_vec], dim=1)
@@ -517,9 +556,16 @@ def boxpc_get_loss(pred, labels, ep, c, reduce_loss=True):
     y_iou, (ydc, yds, yda) = labels
     cls = (y_iou > c.BOXPC_FIT_BOUNDS[0]).long()
     cls_losses = F.cross_entropy(logits, cls, reduction='none')
-    lc = tf_huber(ydc, dc).mean(1)
-    ls = tf_huber(yds, ds).mean(1)
-    la = tf_huber(yda, da)
+    if c.BOXPC_DELTA_LOSS_TYPE == 'huber':                 # boxpc_sunrgbd.py:151-157
+        elem = tf_huber
+    elif c.BOXPC_DELTA_LOSS_TYPE == 'mse':                 # 158-164: tf.losses.mean_squared_error, reduction NONE = squared difference
+        elem = lambda labels, pred: (pred - labels) ** 2
+    else:
+        raise ValueError(c.BOXPC_DELTA_LOSS_TYPE)
+    assert not (c.BOXPC_WEIGH_DELTA_LOSS_BY_CLS_CONF and c.BOXPC_WEIGH_DELTA_LOSS_BY_CLS_GT)     # 166
+    lc = elem(ydc, dc).mean(1)
+    ls = elem(yds, ds).mean(1)
+    la = elem(yda, da)
     wl = 1.0
     if c.BOXPC_WEIGH_DELTA_LOSS_BY_CLS_CONF:
         wl = 1.0 - ep['logits_for_weigh']
@@ -772,7 +818,8 @@ def default_config(**over):
         BOXPC_WEIGH_DELTA_PRED_BY_CLS_CONF=False, BOXPC_WEIGH_DELTA_LOSS_BY_CLS_CONF=False,
         BOXPC_WEIGH_DELTA_LOSS_BY_CLS_GT=False, BOXPC_WEIGHT_CLS=1.0, BOXPC_WEIGHT_DELTA=1.0,
         BOXPC_WEIGHT_DELTA_CENTER_PERCENT=0.34, BOXPC_WEIGHT_DELTA_SIZE_PERCENT=0.33,
-        BOXPC_WEIGHT_DELTA_ANGLE_PERCENT=0.33, BOXPC_DELTA_LOSS_TYPE='huber', BOX_PC_MASK_REPRESENTATION='A')
+        BOXPC_WEIGHT_DELTA_ANGLE_PERCENT=0.33, BOXPC_DELTA_LOSS_TYPE='huber', BOX_PC_MASK_REPRESENTATION='A',
+        USE_NORMALIZED_BOX2D_AS_FEATS=False)
     for k, val in over.items():
         setattr(c, k, val)
     return c
@@ -805,7 +852,7 @@ def model_a_forward_backward(P, batch, c, bn_decay_val=0.5, dtype=torch.float64,
     _apply_forced(ctx, forced)
     pc = torch.as_tensor(batch['pc'], dtype=dtype)
     oh = torch.as_tensor(batch['one_hot_vec'], dtype=dtype)
-    pred, ep = get_semi_model_backbone(ctx, pc, oh, use_one_hot)
+    pred, ep = get_semi_model_backbone(ctx, pc, oh, use_one_hot, norm_box2D=batch_norm_box2D(batch, c, dtype))
     if 'Rtilt' in batch:
         ep['weak_inputs'] = {k: torch.as_tensor(batch[k], dtype=dtype) for k in ('Rtilt', 'K', 'rot_frust', 'box2D', 'img_dim')}
     if forced and forced.get('S_box') is not None:
@@ -857,16 +904,37 @@ def stage_c_forward_backward(P, batch, c, train_classes, bn_decay_val=0.5, dtype
     names = [k for k in trainable_names(P) if any(k.startswith(p) for p in var_prefixes)]
     Pl = {k: (val.detach().to(dtype).requires_grad_(k in names and want_grads)) for k, val in P.items()}
     masks = {k: torch.as_tensor(val) for k, val in batch.get('dropout_masks', {}).items()}
-    ctx = Ctx(Pl, is_training=True, bn_decay=bn_decay_val, dropout_masks=masks)
-    ctx.is_training_override['D_boxpc_branch/'] = False
+    ctx = Ctx(SharedParams(Pl), is_training=True, bn_decay=bn_decay_val, dropout_masks=masks)
+    ctx.is_training_override['D_boxpc_branch'] = False           # is_training_D (train_semisup_adv.py:337), every evaluation
     _apply_forced(ctx, forced)
     pc = torch.as_tensor(batch['pc'], dtype=dtype)
     oh = torch.as_tensor(batch['one_hot_vec'], dtype=dtype)
-    pred, ep = get_semi_model_final(ctx, pc, oh, use_one_hot, c)
+    pred, ep = get_semi_model_final(ctx, pc, oh, use_one_hot, c, norm_box2D=batch_norm_box2D(batch, c, dtype))
     _, ep_b = boxpc_get_model(ctx, ep['F_pred_box_reg'], pc, oh, False, c, scope_prefix='D_boxpc_branch/')
-    ep['boxpc_fit_prob'] = torch.softmax(ep_b['boxpc_fit_logits'], dim=-1)[:, 1]
+    fit_prob = torch.softmax(ep_b['boxpc_fit_logits'], dim=-1)[:, 1]
     ep['boxpc_out'] = ep_b['boxpc_out']
     ep['box_pc_rep'] = ep_b['box_pc_rep']
+    # the refinement loop of the training graph (train_semisup_adv.py:362-399).  Its first evaluation sees the same box as the one
+    # above (same variables, same input: the same values and the same gradient), so that evaluation is shared here.
+    cur = ep['F_pred_box_reg']
+    tot_c, tot_s, tot_a = torch.zeros_like(cur[0]), torch.zeros_like(cur[1]), torch.zeros_like(cur[2])
+    ep_i, outs = ep_b, []
+    for i in range(int(c.SEMI_REFINE_USING_BOXPC_DELTA_NUM)):
+        if i > 0:
+            _, ep_i = boxpc_get_model(ctx, cur, pc, oh, False, c, scope_prefix='D_boxpc_branch@%d/' % i)
+        outs.append(ep_i['boxpc_out'])
+        w = (1 - ep_i['logits_for_weigh']) if c.SEMI_WEIGH_BOXPC_DELTA_DURING_TEST else torch.ones_like(fit_prob)
+        dc, da, ds = ep_i['boxpc_delta_center'] * w[:, None], ep_i['boxpc_delta_angle'] * w, ep_i['boxpc_delta_size'] * w[:, None]
+        cur = (cur[0] - dc, cur[1] - ds, cur[2] - da)
+        tot_c, tot_s, tot_a = tot_c + dc, tot_s + ds, tot_a + da
+    if c.SEMI_BOXPC_MIN_FIT_LOSS_AFT_REFINE:                     # train_semisup_adv.py:388-389: the LAST evaluation's fit probability
+        fit_prob = torch.softmax(ep_i['boxpc_fit_logits'], dim=-1)[:, 1]
+    ep['boxpc_fit_prob'] = fit_prob
+    ep['boxpc_outs'] = outs
+    ep['total_delta'] = torch.cat([tot_c, tot_s, tot_a[:, None]], dim=1)
+    ep['F2_center'] = ep['F_center'] - tot_c
+    ep['F2_heading_residuals'] = ep['F_heading_residuals'] - tot_a[:, None]
+    ep['F2_size_residuals'] = ep['F_size_residuals'] - tot_s[:, None, :]
     ep['intraclsdims_train_classes'] = train_classes
     ep['inactive_vol_train_classes'] = train_classes      # train_semisup_adv.py sets both lists from the same classes
     if 'Rtilt' in batch:
@@ -892,7 +960,7 @@ def stage_c_inference(P, batch, c, refine_num, dtype=torch.float64, use_one_hot=
     ctx = Ctx(Pl, is_training=False, bn_decay=0.5, dropout_masks={})
     pc = torch.as_tensor(batch['pc'], dtype=dtype)
     oh = torch.as_tensor(batch['one_hot_vec'], dtype=dtype)
-    pred, ep = get_semi_model_final(ctx, pc, oh, use_one_hot, c)
+    pred, ep = get_semi_model_final(ctx, pc, oh, use_one_hot, c, norm_box2D=batch_norm_box2D(batch, c, dtype))
     cur = ep['F_pred_box_reg']
     tot_c, tot_s, tot_a = torch.zeros_like(cur[0]), torch.zeros_like(cur[1]), torch.zeros_like(cur[2])
     fit = None
@@ -931,8 +999,8 @@ def inference_scores(logits, heading_scores, size_scores, boxpc_fit_prob=None):
     return s
 
 
-def stage_c_params(rng, num_channels, dtype=torch.float64, use_one_hot=True):
+def stage_c_params(rng, num_channels, dtype=torch.float64, use_one_hot=True, norm_box2D=False):
     """Variables of the stage-c graph: model F under class_agnostic/ + class_dependent/, Box-PC under D_boxpc_branch/."""
-    P = init_params(rng, layer_table(num_channels, 'F', use_one_hot=use_one_hot), dtype)
+    P = init_params(rng, layer_table(num_channels, 'F', use_one_hot=use_one_hot, norm_box2D=norm_box2D), dtype)
     P.update(init_params(rng, layer_table(num_channels, 'boxpc', prefix_agnostic='D_boxpc_branch/'), dtype))
     return P

@@ -584,7 +584,7 @@ class FakeLib:
         o = arr(p.out9, B, 9).astype(np.float64)
         z = o[:, 7:9] - o[:, 7:9].max(1, keepdims=True)
         pfit = np.exp(z[:, 1]) / np.exp(z).sum(1)
-        w = (1.0 - pfit) if p.weigh_by_conf else np.ones(B)
+        w = (1.0 - pfit) ** int(p.weigh_by_conf)
         if p.fit_prob:
             arr(p.fit_prob, B)[:] = pfit
         d = o[:, :7] * w[:, None]
@@ -594,6 +594,29 @@ class FakeLib:
         arr(p.theta_out, B)[:] = tin - d[:, 6]
         tot = arr(p.total, B, 7)
         tot[:] = d if p.first else tot + d
+        return 0
+
+    def t3d_box_refine_step_bwd(self, a, stream):
+        p = _struct(a)
+        B = p.B
+        tot = arr(p.dbox_rep, B, 7).astype(np.float64)
+        if p.carry:
+            tot = tot + arr(p.carry, B, 7)
+        arr(p.tot_out, B, 7)[:] = tot
+        if not p.out9:
+            return 0
+        o = arr(p.out9, B, 9).astype(np.float64)
+        z = o[:, 7:9] - o[:, 7:9].max(1, keepdims=True)
+        pf = np.exp(z[:, 1]) / np.exp(z).sum(1)
+        q, n = 1.0 - pf, int(p.weigh_by_conf)
+        w = q ** n
+        g = arr(p.dout9, B, 9)
+        g[:, :7] = -w[:, None] * tot
+        t = np.zeros(B)
+        if p.grad_via_conf and n > 0:
+            dot = -(tot * o[:, :7]).sum(1)
+            t = dot * (-n * q ** (n - 1)) * pf * q
+        g[:, 7], g[:, 8] = -t, t
         return 0
 
     def t3d_pool_bwd_mid(self, slab_base, grad_base, table, n, mx, sparse, stream):
@@ -1154,17 +1177,45 @@ class FakeLib:
             wl = 1 - iou
         if p.weigh_by_cls_conf:
             wl = 1 - prob[:, 1]
-        hub = lambda e: 0.5 * np.minimum(np.abs(e), 1) ** 2 + (np.abs(e) - np.minimum(np.abs(e), 1))
-        ec, es, ea = o[:, 0:3] - arr(p.y_center_delta, B, 3), o[:, 3:6] - arr(p.y_dims_delta, B, 3), o[:, 6] - arr(p.y_orient_delta, B)
-        delta = wl * (p.w_center * hub(ec).mean(1) + p.w_size * hub(es).mean(1) + p.w_angle * hub(ea))
+        if p.delta_loss_mse:
+            hub, hubd = (lambda e: e * e), (lambda e: 2 * e)
+        else:
+            hub = lambda e: 0.5 * np.minimum(np.abs(e), 1) ** 2 + (np.abs(e) - np.minimum(np.abs(e), 1))
+            hubd = lambda e: np.clip(e, -1, 1)
+        wp = 1 - prob[:, 1] if p.weigh_pred_by_cls_conf else np.ones(B)
+        ec, es, ea = o[:, 0:3] * wp[:, None] - arr(p.y_center_delta, B, 3), o[:, 3:6] * wp[:, None] - arr(p.y_dims_delta, B, 3), \
+            o[:, 6] * wp - arr(p.y_orient_delta, B)
+        unw = p.w_center * hub(ec).mean(1) + p.w_size * hub(es).mean(1) + p.w_angle * hub(ea)
+        delta = wl * unw
         total = p.w_cls * ce + p.w_delta * delta
         g = arr(p.dout, B, 9)
         g[:, 7:9] = p.w_cls * (prob - np.eye(2)[cls]) / B
-        g[:, 0:3] = p.w_delta * p.w_center * wl[:, None] * np.clip(ec, -1, 1) / 3 / B
-        g[:, 3:6] = p.w_delta * p.w_size * wl[:, None] * np.clip(es, -1, 1) / 3 / B
-        g[:, 6] = p.w_delta * p.w_angle * wl * np.clip(ea, -1, 1) / B
+        gc, gs, ga = p.w_center * hubd(ec) / 3, p.w_size * hubd(es) / 3, p.w_angle * hubd(ea)
+        g[:, 0:3] = p.w_delta * (wl * wp)[:, None] * gc / B
+        g[:, 3:6] = p.w_delta * (wl * wp)[:, None] * gs / B
+        g[:, 6] = p.w_delta * wl * wp * ga / B
+        if p.grad_cls_via_delta:
+            dp1 = np.zeros(B)
+            if p.weigh_by_cls_conf:
+                dp1 -= unw
+            if p.weigh_pred_by_cls_conf:
+                dp1 -= wl * ((gc * o[:, 0:3]).sum(1) + (gs * o[:, 3:6]).sum(1) + ga * o[:, 6])
+            t = p.w_delta * dp1 * prob[:, 1] * prob[:, 0] / B
+            g[:, 7] -= t
+            g[:, 8] += t
         arr(p.terms, B, 4)[:] = np.stack([ce, delta, prob[:, 1], total], 1)
         arr(p.loss, 1)[0] = total.mean()
+        return 0
+
+    def t3d_box2d_feats(self, a, stream):
+        p = _struct(a)
+        B, oh = p.B, p.n_oh
+        out = arr(p.out, B, oh + 4)
+        if oh:
+            out[:, :oh] = arr(p.one_hot, B, oh)
+        box, dim = arr(p.box2D, B, 4), arr(p.img_dim, B, 2)
+        rows, cols = dim[:, 0], dim[:, 1]
+        out[:, oh:] = np.stack([box[:, 0] / cols, box[:, 1] / rows, box[:, 2] / cols, box[:, 3] / rows], 1)
         return 0
 
     # ---- stage-c glue --------------------------------------------------------------------------------

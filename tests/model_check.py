@@ -61,11 +61,12 @@ def product_decisions(model):
             if getattr(o, 'src', None) is None:
                 return                                         # never emitted (a net built but not on this graph's path)
             B, Np = o.g.B, o.g.rpf
+            key = getattr(o, 'decision_scope', o.scope)     # a re-used scope's further evaluations: oracle.SharedParams
             if o.pool:
-                argmax[o.scope] = o.argidx.detach().cpu().numpy().reshape(B, o.N).astype(np.int64)
+                argmax[key] = o.argidx.detach().cpu().numpy().reshape(B, o.N).astype(np.int64)
             if o.y is not None:
                 z = o.y.double() * o.scale.double() + o.shift.double()
-                gates[o.scope] = (z > 0).cpu().numpy().reshape(B, Np, o.N)
+                gates[key] = (z > 0).cpu().numpy().reshape(B, Np, o.N)
             return
         if isinstance(o, FcLayer):
             if o.act in ('relu', 'leaky_relu') and getattr(o, 'x', None) is not None:
@@ -76,7 +77,11 @@ def product_decisions(model):
                 gate = (o.out > 0).to(torch.int8)
                 if getattr(o, 'use_drop', False) and o.is_training:
                     gate = torch.where(o.drop_mask > 0, gate, torch.full_like(gate, -1))
-                gates[o.scope] = gate.cpu().numpy()
+                gates[getattr(o, 'decision_scope', o.scope)] = gate.cpu().numpy()
+            return
+        if isinstance(o, (list, tuple)):
+            for v in o:
+                walk(v, depth + 1)
             return
         if hasattr(o, '__dict__') and type(o).__module__.startswith('transferable3d_amd'):
             for v in vars(o).values():
@@ -138,7 +143,15 @@ def grad_errors(g, ref_grads):
         r = np.asarray(r, dtype=np.float64).reshape(mine.shape)
         e, n = np.linalg.norm(mine - r), np.linalg.norm(r)
         if n > 1e-9:
-            per[k] = e / n
+            # A tensor all of whose entries are <= 1e-3 of the step's largest gradient entry AND agree with the oracle to 1e-6 of that
+            # entry sits at the fp32 noise floor of the sums it is made of (its terms cancel: e.g. the beta of box_est/conv-reg4 in
+            # stage c, 511 analytically-zero entries and one of 5e-4 beside gammas of 0.4 -- 1.8e-7 of rounding noise per entry reads
+            # as 2.7e-3 "relative").  Its relative error says nothing; the absolute agreement is the check (observed on MI355X,
+            # tests/test_off_recipe_gpu.py, stage c with norm_box2D, step 1).
+            if np.abs(r).max() <= 1e-3 * gscale and np.abs(mine - r).max() <= 1e-6 * gscale:
+                per[k] = min(e / n, 1e-6)
+            else:
+                per[k] = e / n
         else:
             # analytically-zero gradients (a bias or beta feeding a batch-norm): rounding noise only
             assert np.abs(mine).max() < 1e-5 * gscale, (k, float(np.abs(mine).max()), gscale)
@@ -319,9 +332,9 @@ def check_golden_stage_c(rt):
 # the TIMED step against an oracle trajectory: transferable3d_amd.step.build_training_step is what bench.py
 # runs; here the same object is replayed for several steps and every step is checked against the oracle
 # ------------------------------------------------------------------------------------------------------------------------------
-def _stage_c_like_params(C, seed):
+def _stage_c_like_params(C, seed, norm_box2D=False):
     import test_stage_c_cpu as TC
-    return TC.stage_c_params(C, seed)
+    return TC.stage_c_params(C, seed, norm_box2D=norm_box2D)
 
 
 def trajectory_batch(workload, B, N, C, seed):
@@ -346,10 +359,13 @@ def _fwd_pairs(workload, e, ep):
         return [(k, e[k], ep[k]) for k in FWD_KEYS]
     if workload == 'boxpc':
         return [('boxpc_out', e['boxpc_out'], ep['boxpc_out'])]
-    return [(mine, e[mine], ref) for mine, ref in (
+    pairs = [(mine, e[mine], ref) for mine, ref in (
         ('logits', ep['logits']), ('stage1_center', ep['stage1_center']), ('feats_lv1', ep['feats_lv1']),
         ('F_box_params', ep['F_box_params']), ('F_center', ep['F_center']), ('boxpc_out', ep['boxpc_out']),
         ('boxpc_fit_prob', ep['boxpc_fit_prob']), ('F_dims', ep['F_pred_box_reg'][1]), ('F_theta', ep['F_pred_box_reg'][2]))]
+    if len(ep.get('boxpc_outs', ())) > 1:      # several refinement steps in the training graph: the last evaluation and the totals behind F2_
+        pairs += [('boxpc_out_last', e['boxpc_out_last'], ep['boxpc_outs'][-1]), ('total_delta', e['total_delta'], ep['total_delta'])]
+    return pairs
 
 
 def oracle_config(workload):
@@ -362,7 +378,7 @@ def oracle_config(workload):
 
 
 def trajectory_check(rt, workload='A', steps=4, B=8, N=256, C=4, use_hip_graph=None, process_group=None, force_dist=False,
-                     flat_allreduce=False, param_seed=31, fwd_tol=1e-4, weight_tol=2e-5, verbose=False):
+                     flat_allreduce=False, param_seed=31, fwd_tol=1e-4, weight_tol=2e-5, verbose=False, config_over=None):
     """Runs `steps` consecutive steps of the step object bench.py times (pre: device schedules + dropout masks; forward with the
     seg head's in-kernel dropout; backward; TF-form Adam; hipGraph replay from the second step on) and checks EVERY step against
     the oracle started from the state the product held before that step (weights, moving statistics, Adam moments, step counter):
@@ -374,19 +390,28 @@ def trajectory_check(rt, workload='A', steps=4, B=8, N=256, C=4, use_hip_graph=N
     diverges from ANY fp32 implementation in the entries whose gradient is rounding noise -- that says nothing about the kernels.
     Returns per-step diagnostics (incl. the free-running loss curve of the product)."""
     from fake_t3d import hash_keep_mask
-    from transferable3d_amd.step import build_training_step
+    from transferable3d_amd.step import build_training_step, workload_flags
+    over = dict(config_over or {})          # off-recipe flags, set on the product's FLAGS and on the oracle's config alike
+    nb = bool(over.get('USE_NORMALIZED_BOX2D_AS_FEATS', False))
     if workload == 'A':
-        P0 = R.init_params(np.random.RandomState(param_seed), R.layer_table(C, 'A'))
+        P0 = R.init_params(np.random.RandomState(param_seed), R.layer_table(C, 'A', norm_box2D=nb))
     elif workload == 'boxpc':
         P0 = R.init_params(np.random.RandomState(param_seed), R.layer_table(C, 'boxpc'))
     else:
-        P0 = _stage_c_like_params(C, param_seed)
+        P0 = _stage_c_like_params(C, param_seed, norm_box2D=nb)
     c = oracle_config(workload)
+    flags = None
+    if over:
+        flags = workload_flags(workload)
+        for k_, v_ in over.items():
+            assert hasattr(flags, k_) and hasattr(c, k_), k_
+            setattr(flags, k_, v_)
+            setattr(c, k_, v_)
     world = process_group.size() if process_group is not None else 1
     g, model, step, loss_buf = build_training_step(rt, workload, B, N, C, world=world, process_group=process_group,
                                                    force_dist=force_dist, flat_allreduce=flat_allreduce,
                                                    use_hip_graph=use_hip_graph, inline_dropout=True, dropout_seed=1234,
-                                                   state_dict={k: v.detach().cpu().numpy() for k, v in P0.items()})
+                                                   state_dict={k: v.detach().cpu().numpy() for k, v in P0.items()}, c=flags)
     vs = g.vars
     names = [k for k, (off, shape, tr) in vs.index.items() if tr]
     sync = (lambda: torch.cuda.synchronize()) if rt.device.type == 'cuda' else (lambda: None)

@@ -27,8 +27,8 @@ def stage_c_batch(B, N, C, seed, n2d):
     return b
 
 
-def stage_c_params(C, seed):
-    P = R.stage_c_params(np.random.RandomState(seed), C)
+def stage_c_params(C, seed, norm_box2D=False):
+    P = R.stage_c_params(np.random.RandomState(seed), C, norm_box2D=norm_box2D)
     r = np.random.RandomState(seed + 1)
     for k in P:                                  # a "pre-trained" frozen Box-PC net: non-trivial moving statistics
         if k.startswith('D_boxpc') and k.endswith('moving_variance'):

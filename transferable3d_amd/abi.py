@@ -234,7 +234,17 @@ class BoxPcRepBwdArgs(C.Structure):
 class BoxPcLossArgs(C.Structure):
     _fields_ = [('out', F), ('y_box_iou', F), ('y_center_delta', F), ('y_dims_delta', F), ('y_orient_delta', F),
                 ('fit_bound', f32), ('w_cls', f32), ('w_delta', f32), ('w_center', f32), ('w_size', f32), ('w_angle', f32),
-                ('weigh_by_cls_conf', i32), ('weigh_by_cls_gt', i32), ('dout', F), ('terms', F), ('loss', F), ('B', i32)]
+                ('weigh_by_cls_conf', i32), ('weigh_by_cls_gt', i32), ('dout', F), ('terms', F), ('loss', F), ('B', i32),
+                ('weigh_pred_by_cls_conf', i32), ('grad_cls_via_delta', i32), ('delta_loss_mse', i32)]
+
+
+class BoxRefineStepBwdArgs(C.Structure):
+    _fields_ = [('out9', F), ('dbox_rep', F), ('carry', F), ('tot_out', F), ('dout9', F), ('weigh_by_conf', i32),
+                ('grad_via_conf', i32), ('B', i32)]
+
+
+class Box2dFeatsArgs(C.Structure):
+    _fields_ = [('one_hot', F), ('n_oh', i32), ('box2D', F), ('img_dim', F), ('out', F), ('B', i32)]
 
 
 class DgradNarrowArgs(C.Structure):
@@ -305,11 +315,13 @@ ENTRY_POINTS = {
     't3d_pool_wgrad_finish': [C.POINTER(PoolWgradFinishArgs), VP],
     't3d_batch_assemble': [C.POINTER(BatchAssembleArgs), VP],
     't3d_box_refine_step': [C.POINTER(BoxRefineStepArgs), VP],
+    't3d_box_refine_step_bwd': [C.POINTER(BoxRefineStepBwdArgs), VP],
     't3d_boxpc_perturb': [C.POINTER(BoxPcPerturbArgs), VP],
     't3d_sample_equal_classes': [C.POINTER(SampleEqualClassesArgs), VP],
     't3d_box3d_iou': [C.POINTER(Box3dIouArgs), VP],
     't3d_box3d_iou_corners': [C.POINTER(Box3dIouCornersArgs), VP],
     't3d_box_head_iou': [C.POINTER(BoxHeadIouArgs), VP],
+    't3d_box2d_feats': [C.POINTER(Box2dFeatsArgs), VP],
     't3d_pool_bwd_stage1': [C.POINTER(PointMlpGramArgs), C.POINTER(ActColsumArgs), C.POINTER(PoolBwdPrepArgs), VP],
     't3d_pool_bwd_mid': [F, F, C.POINTER(SlabDesc), i32, i32, C.POINTER(PoolSparseRowsArgs), VP],
     't3d_pool_bwd_stage2': [C.POINTER(PoolWgradFinishArgs), C.POINTER(PointMlpDgradGramArgs), VP],

@@ -46,17 +46,23 @@ def get_model(boxpc, is_training, one_hot_vec, use_one_hot_vec=False, bn_decay=N
                                             (B,), 'class_ids')}
     if not use_one_hot_vec:
         one_hot_vec = None
-    if c.BOXPC_WEIGH_DELTA_PRED_BY_CLS_CONF:
-        raise NotImplementedError('BOXPC_WEIGH_DELTA_PRED_BY_CLS_CONF is off in every published recipe (config.py default)')
     output, feats = semisup_models.box_pc_mask_features_model(box_reg, pc, None, 2 + 7, is_training, end_points=end_points,
                                                               reuse=False, bn_for_output=False, one_hot_vec=one_hot_vec,
                                                               norm_box2D=None, bn_decay=bn_decay, c=c, scope='box_pc_mask_model')
     out = output.buf
     T = lambda buf, shape, name: api.Tensor(ctx, buf, shape, name)
     logits = T(out[:, 7:9], (B, 2), 'boxpc_fit_logits')
-    dc, ds, da = T(out[:, 0:3], (B, 3), 'boxpc_delta_center'), T(out[:, 3:6], (B, 3), 'boxpc_delta_size'), T(out[:, 6], (B,), 'boxpc_delta_angle')
     terms = ctx.assembly.loss_op.terms
     lw = T(terms[:, 2], (B,), 'logits_for_weigh')
+    if c.BOXPC_WEIGH_DELTA_PRED_BY_CLS_CONF:       # boxpc_sunrgbd.py:84-92: the deltas the model hands on are (1 - p_fit) * raw; the loss kernel
+        # weighs its own copy (t3d_boxpc_loss.weigh_pred_by_cls_conf), these handles are evaluated on the host at fetch time
+        full = T(out, (B, 9), 'boxpc_out')
+        wd = lambda: 1.0 - lw.numpy()
+        dc = SlicedTensor(full, lambda: full.numpy()[:, 0:3] * wd()[:, None], (B, 3), 'boxpc_delta_center')
+        ds = SlicedTensor(full, lambda: full.numpy()[:, 3:6] * wd()[:, None], (B, 3), 'boxpc_delta_size')
+        da = SlicedTensor(full, lambda: full.numpy()[:, 6] * wd(), (B,), 'boxpc_delta_angle')
+    else:
+        dc, ds, da = T(out[:, 0:3], (B, 3), 'boxpc_delta_center'), T(out[:, 3:6], (B, 3), 'boxpc_delta_size'), T(out[:, 6], (B,), 'boxpc_delta_angle')
     end_points.update({'boxpc_feats_dict': feats, 'boxpc_fit_logits': logits,
                        'pred_boxpc_fit': SlicedTensor(lw, lambda: (lw.numpy() > 0.5).astype(np.int32), (B,), 'pred_boxpc_fit'),
                        'logits_for_weigh': lw, 'boxpc_delta_center': dc, 'boxpc_delta_size': ds, 'boxpc_delta_angle': da})

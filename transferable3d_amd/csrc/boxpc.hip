@@ -120,19 +120,33 @@ __global__ __launch_bounds__(1024) void k_boxpc_loss(const t3d_boxpc_loss_args p
     g[8] = inv * p.w_cls * (p1 - (cls == 1 ? 1.f : 0.f));
     float wl = 1.f;
     if (p.weigh_by_cls_gt) wl = 1.f - p.y_box_iou[b];
-    if (p.weigh_by_cls_conf) wl = 1.f - p1;            // logits_for_weigh is stop_gradient (boxpc_sunrgbd.py:74)
-    float lc = 0.f, ls = 0.f;
+    if (p.weigh_by_cls_conf) wl = 1.f - p1;            // logits_for_weigh (boxpc_sunrgbd.py:73-74)
+    const float wp = p.weigh_pred_by_cls_conf ? 1.f - p1 : 1.f;      // the predicted deltas are weighed (boxpc_sunrgbd.py:84-92)
+    const bool mse = p.delta_loss_mse != 0;
+    float lc = 0.f, ls = 0.f, dwp = 0.f;               // dwp = d(delta loss / wl) / d wp
     for (int d = 0; d < 3; ++d) {
-      const float ec = o[d] - p.y_center_delta[b * 3 + d], es = o[3 + d] - p.y_dims_delta[b * 3 + d];
-      lc += hub(ec) * (1.f / 3.f);
-      ls += hub(es) * (1.f / 3.f);
-      g[d] = inv * p.w_delta * p.w_center * wl * hubd(ec) * (1.f / 3.f);
-      g[3 + d] = inv * p.w_delta * p.w_size * wl * hubd(es) * (1.f / 3.f);
+      const float ec = o[d] * wp - p.y_center_delta[b * 3 + d], es = o[3 + d] * wp - p.y_dims_delta[b * 3 + d];
+      lc += (mse ? ec * ec : hub(ec)) * (1.f / 3.f);
+      ls += (mse ? es * es : hub(es)) * (1.f / 3.f);
+      const float gc = p.w_center * (mse ? 2.f * ec : hubd(ec)) * (1.f / 3.f), gs = p.w_size * (mse ? 2.f * es : hubd(es)) * (1.f / 3.f);
+      g[d] = inv * p.w_delta * wl * wp * gc;
+      g[3 + d] = inv * p.w_delta * wl * wp * gs;
+      dwp += gc * o[d] + gs * o[3 + d];
     }
-    const float ea = o[6] - p.y_orient_delta[b];
-    const float la = hub(ea);
-    g[6] = inv * p.w_delta * p.w_angle * wl * hubd(ea);
-    const float delta = wl * (p.w_center * lc + p.w_size * ls + p.w_angle * la);
+    const float ea = o[6] * wp - p.y_orient_delta[b];
+    const float la = mse ? ea * ea : hub(ea), ga = mse ? 2.f * ea : hubd(ea);
+    g[6] = inv * p.w_delta * p.w_angle * wl * wp * ga;
+    dwp += p.w_angle * ga * o[6];
+    const float unw = p.w_center * lc + p.w_size * ls + p.w_angle * la;
+    const float delta = wl * unw;
+    if (p.grad_cls_via_delta) {                        // p_fit inside wl / wp is differentiated: d p1 / d(l0, l1) = p1 (1 - p1) (-1, +1)
+      float dp1 = 0.f;
+      if (p.weigh_by_cls_conf) dp1 -= unw;
+      if (p.weigh_pred_by_cls_conf) dp1 -= wl * dwp;
+      const float t = inv * p.w_delta * dp1 * p1 * (1.f - p1);
+      g[7] -= t;
+      g[8] += t;
+    }
     total = p.w_cls * ce + p.w_delta * delta;
     for (int i = 0; i < 9; ++i) p.dout[(size_t)b * 9 + i] = g[i];
     p.terms[b * 4 + 0] = ce; p.terms[b * 4 + 1] = delta; p.terms[b * 4 + 2] = p1; p.terms[b * 4 + 3] = total;
@@ -298,7 +312,7 @@ __global__ __launch_bounds__(256) void k_box_refine_step(const t3d_box_refine_st
   const float mx = fmaxf(o[7], o[8]);
   const float e0 = expf(o[7] - mx), e1 = expf(o[8] - mx);
   const float pfit = e1 / (e0 + e1);
-  const float w = p.weigh_by_conf ? 1.f - pfit : 1.f;
+  const float w = p.weigh_by_conf == 0 ? 1.f : (p.weigh_by_conf == 1 ? 1.f - pfit : (1.f - pfit) * (1.f - pfit));
   if (p.fit_prob) p.fit_prob[b] = pfit;
   float* tot = p.total + (size_t)b * 7;
 #pragma unroll
@@ -314,7 +328,45 @@ __global__ __launch_bounds__(256) void k_box_refine_step(const t3d_box_refine_st
   tot[6] = (p.first ? 0.f : tot[6]) + da;
 }
 
+__global__ __launch_bounds__(256) void k_box_refine_step_bwd(const t3d_box_refine_step_bwd_args p) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= p.B) return;
+  float tot[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) tot[k] = p.dbox_rep[b * 7 + k] + (p.carry ? p.carry[b * 7 + k] : 0.f);
+#pragma unroll
+  for (int k = 0; k < 7; ++k) p.tot_out[b * 7 + k] = tot[k];
+  if (!p.out9) return;
+  const float* o = p.out9 + (size_t)b * 9;
+  const float mx = fmaxf(o[7], o[8]);
+  const float e0 = expf(o[7] - mx), e1 = expf(o[8] - mx);
+  const float pfit = e1 / (e0 + e1), q = 1.f - pfit;
+  const int n = p.weigh_by_conf;
+  const float w = n == 0 ? 1.f : (n == 1 ? q : q * q);
+  float dot = 0.f;                                       // d L / d w = sum_k tot_k * (-out9_k)
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    p.dout9[(size_t)b * 9 + k] = -w * tot[k];
+    dot -= tot[k] * o[k];
+  }
+  float t = 0.f;
+  if (p.grad_via_conf && n > 0) {                        // w = q^n, d w / d p = -n q^(n-1); d p / d(l0, l1) = p q (-1, +1)
+    const float dw_dp = n == 1 ? -1.f : -2.f * q;
+    t = dot * dw_dp * pfit * q;
+  }
+  p.dout9[(size_t)b * 9 + 7] = -t;
+  p.dout9[(size_t)b * 9 + 8] = t;
+}
+
 }  // namespace
+
+extern "C" int t3d_box_refine_step_bwd(const t3d_box_refine_step_bwd_args* a, t3d_stream_t stream) {
+  if (!a || !a->dbox_rep || !a->tot_out || (a->out9 && !a->dout9)) return T3D_ERR_ARG;
+  if (a->B <= 0 || a->weigh_by_conf < 0 || a->weigh_by_conf > 2) return T3D_ERR_SHAPE;
+  T3D_LAUNCH(k_box_refine_step_bwd, dim3((a->B + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
 
 extern "C" int t3d_box_refine_step(const t3d_box_refine_step_args* a, t3d_stream_t stream) {
   if (!a || !a->out9 || !a->center_in || !a->dims_in || !a->theta_in || !a->center_out || !a->dims_out || !a->theta_out ||

@@ -484,6 +484,28 @@ extern "C" int t3d_strong_loss(const t3d_strong_loss_args* a, t3d_stream_t strea
   return T3D_OK;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void k_box2d_feats(const t3d_box2d_feats_args p) {
+  const int W = p.n_oh + 4;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.B * W) return;
+  const int b = i / W, j = i - b * W;
+  if (j < p.n_oh) { p.out[i] = p.one_hot[b * p.n_oh + j]; return; }
+  const int q = j - p.n_oh;                                  // 0 left, 1 top, 2 right, 3 bottom
+  const float d = (q & 1) ? p.img_dim[b * 2 + 0] : p.img_dim[b * 2 + 1];      // rows for top / bottom, cols for left / right
+  p.out[i] = p.box2D[b * 4 + q] / d;
+}
+}  // namespace
+
+extern "C" int t3d_box2d_feats(const t3d_box2d_feats_args* a, t3d_stream_t stream) {
+  if (!a || !a->box2D || !a->img_dim || !a->out || (a->n_oh > 0 && !a->one_hot)) return T3D_ERR_ARG;
+  if (a->B <= 0 || a->n_oh < 0) return T3D_ERR_SHAPE;
+  const int n = a->B * (a->n_oh + 4);
+  T3D_LAUNCH(k_box2d_feats, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
 extern "C" int t3d_box_head_iou(const t3d_box_head_iou_args* a, t3d_stream_t stream) {
   if (!a || !a->box || !a->y_center || !a->y_orient_cls || !a->y_orient_reg || !a->y_dims_cls || !a->y_dims_reg || !a->iou2d ||
       !a->iou3d)

@@ -301,10 +301,10 @@ class InstSegNet:
 
 
 class TNet:
-    def __init__(self, g, scope, use_one_hot):
+    def __init__(self, g, scope, use_one_hot, box2d=False):
         self.g, self.scope = g, scope
         s = scope + '/'
-        oh = NUM_CLASS if use_one_hot else 0
+        oh = (NUM_CLASS if use_one_hot else 0) + (4 if box2d else 0)      # fc1 reads [pooled | one_hot | norm_box2D] (semisup_models.py:192-195)
         self.oh = oh
         self.T1 = PointLayer(g, s + 'conv-reg1-stage1', 3, 128)
         self.T2 = PointLayer(g, s + 'conv-reg2-stage1', 128, 128)
@@ -313,13 +313,14 @@ class TNet:
         self.F2 = FcLayer(g, s + 'fc2-stage1', 256, 128)
         self.F3 = FcLayer(g, s + 'fc3-stage1', 128, 3, bn=False, act=None)
 
-    def fwd(self, plan, pc, mask, mask_xyz_mean, one_hot, is_training):
+    def fwd(self, plan, pc, mask, mask_xyz_mean, one_hot, is_training, ld_oh=NUM_CLASS):
+        """`one_hot` = the extra FC-input block [B, ld_oh]: the one-hot vector, or ExtraFeats' [one_hot | norm_box2D]."""
         g = self.g
         a = ActSpec(pc, g.ldpc, 3, sub=mask_xyz_mean, sub_ld=3)
         a = self.T1.fwd(plan, a, is_training)
         a = self.T2.fwd(plan, a, is_training)
         self.T3.fwd(plan, a, is_training, rowmask=mask)
-        x = self.F1.fwd(plan, self.T3.pooled, 256, is_training, in2=one_hot if self.oh else None, ld_in2=NUM_CLASS)
+        x = self.F1.fwd(plan, self.T3.pooled, 256, is_training, in2=one_hot if self.oh else None, ld_in2=ld_oh)
         x = self.F2.fwd(plan, x, 256, is_training)
         self.stage1_center = self.F3.fwd(plan, x, 128, is_training, add_in=mask_xyz_mean, ld_add=3, add_n=3)
         return self.stage1_center
@@ -343,10 +344,10 @@ class TNet:
 
 
 class BoxEstNet:
-    def __init__(self, g, scope, use_one_hot):
+    def __init__(self, g, scope, use_one_hot, box2d=False):
         self.g, self.scope = g, scope
         s = scope + '/'
-        oh = NUM_CLASS if use_one_hot else 0
+        oh = (NUM_CLASS if use_one_hot else 0) + (4 if box2d else 0)      # fc1 reads [pooled | one_hot | norm_box2D] (semisup_models.py:249-252)
         self.oh = oh
         self.B1 = PointLayer(g, s + 'conv-reg1', 3, 128)
         self.B2 = PointLayer(g, s + 'conv-reg2', 128, 128)
@@ -356,7 +357,7 @@ class BoxEstNet:
         self.G2 = FcLayer(g, s + 'fc2', 512, 256)
         self.G3 = FcLayer(g, s + 'fc3', 256, BOX_OUT_DIMS, bn=False, act=None)
 
-    def fwd(self, plan, pc, mask, stage1_center, one_hot, is_training):
+    def fwd(self, plan, pc, mask, stage1_center, one_hot, is_training, ld_oh=NUM_CLASS):
         g = self.g
         a = ActSpec(pc, g.ldpc, 3, sub=stage1_center, sub_ld=3)
         a = self.B1.fwd(plan, a, is_training)
@@ -365,7 +366,7 @@ class BoxEstNet:
         self.B4.fwd(plan, a, is_training, rowmask=mask)
         self.feats_lv1 = self.B4.pooled
         self.feats_lv2 = self.G1.fwd(plan, self.feats_lv1, 512, is_training, in2=one_hot if self.oh else None,
-                                     ld_in2=NUM_CLASS)
+                                     ld_in2=ld_oh)
         self.feats_lv3 = self.G2.fwd(plan, self.feats_lv2, 512, is_training)
         self.box_params = self.G3.fwd(plan, self.feats_lv3, 256, is_training)
         return self.box_params
@@ -561,6 +562,22 @@ def emit_box_head_iou(g, plan, box, stage1_center, labels, iou2d, iou3d):
     plan.add('t3d_box_head_iou', a)
 
 
+class ExtraFeats:
+    """[one_hot | norm_box2D] per frustum, the extra FC-input block of the T-Net and the box net under
+    USE_NORMALIZED_BOX2D_AS_FEATS (semisup_v1_sunrgbd.py:97,145; train_semisup.py:240 norm_box2D =
+    tf_util.tf_normalize_2D_bboxes(box2D_pl, img_dim_pl)); one tiny launch at the head of the forward (t3d_box2d_feats)."""
+
+    def __init__(self, g, n_oh):
+        self.g, self.n_oh, self.ld = g, n_oh, n_oh + 4
+        self.buf = g.rt.zeros(g.B, self.ld)
+
+    def emit(self, plan, x):
+        a = abi.Box2dFeatsArgs(fptr(x.one_hot_vec) if self.n_oh else None, self.n_oh, fptr(x.box2D), fptr(x.img_dim), fptr(self.buf),
+                               self.g.B)
+        plan.add('t3d_box2d_feats', a)
+        return self.buf, self.ld
+
+
 class Inputs:
     """Device-resident feed buffers in the reference's batch layout (roi_semi_dataset.py:531-534;
     semisup_v1_sunrgbd.placeholder_inputs 37-67).  `load(batch)` copies a NumPy batch in (H2D)."""
@@ -607,22 +624,26 @@ class ModelAssembly:
         self.inputs = inputs or Inputs(g)
         self.seg = self.tnet = self.box = self.loss_op = None
         self.weak = None
+        self.box2d = bool(getattr(c, 'USE_NORMALIZED_BOX2D_AS_FEATS', False))
+        self.extra = ExtraFeats(g, NUM_CLASS if use_one_hot else 0) if self.box2d else None
 
     def emit_forward(self, plan, is_training, with_loss):
         g, x, c = self.g, self.inputs, self.c
         g.emit_cast_weights(plan)
         labels = x.y_seg if with_loss else None
         train_seg = with_loss and is_training
-        oh = x.one_hot_vec
+        oh, ld_oh = x.one_hot_vec, NUM_CLASS
         self.seg.fwd(plan, x.pc, oh, labels, x.is_data_2D, is_training, train_seg, ce_weight=c.STRONG_WEIGHT_CROSS_ENTROPY)
         if self.tnet is None:
             return
+        if self.extra is not None:       # the seg net never sees norm_box2D (semisup_models.py:69)
+            oh, ld_oh = self.extra.emit(plan, x)
         if train_seg:
             plan.mark('T_begin')        # from here to the seg net's backward: the chain the seg backward does not depend on (schedule.py)
-        s1 = self.tnet.fwd(plan, x.pc, self.seg.mask, self.seg.mask_xyz_mean, oh, is_training)
+        s1 = self.tnet.fwd(plan, x.pc, self.seg.mask, self.seg.mask_xyz_mean, oh, is_training, ld_oh=ld_oh)
         if self.box is None:
             return
-        box = self.box.fwd(plan, x.pc, self.seg.mask, s1, oh, is_training)
+        box = self.box.fwd(plan, x.pc, self.seg.mask, s1, oh, is_training, ld_oh=ld_oh)
         if self.loss_op is None:
             self.loss_op = StrongLoss(g)
         if with_loss:
@@ -730,8 +751,8 @@ class SemiModelA(ModelAssembly):
     def __init__(self, g, c, use_one_hot=False, scope_prefix='', inputs=None):
         ModelAssembly.__init__(self, g, c, inputs, use_one_hot)
         self.seg = InstSegNet(g, scope_prefix + 'inst_seg', use_one_hot)
-        self.tnet = TNet(g, scope_prefix + 'tnet', use_one_hot)
-        self.box = BoxEstNet(g, scope_prefix + 'box_est', use_one_hot)
+        self.tnet = TNet(g, scope_prefix + 'tnet', use_one_hot, box2d=self.box2d)
+        self.box = BoxEstNet(g, scope_prefix + 'box_est', use_one_hot, box2d=self.box2d)
         self.loss_op = StrongLoss(g)
 
 
@@ -804,7 +825,9 @@ class BoxPCLoss:
                               c.BOXPC_FIT_BOUNDS[0], c.BOXPC_WEIGHT_CLS, c.BOXPC_WEIGHT_DELTA, c.BOXPC_WEIGHT_DELTA_CENTER_PERCENT,
                               c.BOXPC_WEIGHT_DELTA_SIZE_PERCENT, c.BOXPC_WEIGHT_DELTA_ANGLE_PERCENT,
                               int(c.BOXPC_WEIGH_DELTA_LOSS_BY_CLS_CONF), int(c.BOXPC_WEIGH_DELTA_LOSS_BY_CLS_GT),
-                              fptr(self.dout), fptr(self.terms), fptr(self.loss), self.g.B)
+                              fptr(self.dout), fptr(self.terms), fptr(self.loss), self.g.B,
+                              int(bool(c.BOXPC_WEIGH_DELTA_PRED_BY_CLS_CONF)), int(not c.BOXPC_STOP_GRAD_OF_CLS_VIA_DELTA),
+                              int(c.BOXPC_DELTA_LOSS_TYPE == 'mse'))
         plan.add('t3d_boxpc_loss', a)
 
 
@@ -813,7 +836,8 @@ class BoxPCModel:
 
     def __init__(self, g, c, use_one_hot=False, inputs=None):
         assert c.BOX_PC_MASK_REPRESENTATION in ('A', ''), 'representation B is in no published recipe (out of scope)'
-        assert c.BOXPC_DELTA_LOSS_TYPE == 'huber' and not c.BOXPC_WEIGH_DELTA_PRED_BY_CLS_CONF
+        assert c.BOXPC_DELTA_LOSS_TYPE in ('huber', 'mse'), c.BOXPC_DELTA_LOSS_TYPE
+        assert not (c.BOXPC_WEIGH_DELTA_LOSS_BY_CLS_CONF and c.BOXPC_WEIGH_DELTA_LOSS_BY_CLS_GT)       # boxpc_sunrgbd.py:166
         self.g, self.c = g, c
         self.inputs = inputs or Inputs(g)
         self.net = BoxPCNet(g, '', use_one_hot)
@@ -851,8 +875,10 @@ class SemiModelF:
         self.inputs = inputs or Inputs(g)
         p = 'class_agnostic/'
         self.seg = InstSegNet(g, p + 'inst_seg', False)
-        self.tnet = TNet(g, p + 'tnet', False)
-        self.box = BoxEstNet(g, p + 'box_est', False)
+        self.box2d = bool(getattr(c, 'USE_NORMALIZED_BOX2D_AS_FEATS', False))      # semisup_v1_sunrgbd.py:145,168,176
+        self.extra = ExtraFeats(g, 0) if self.box2d else None
+        self.tnet = TNet(g, p + 'tnet', False, box2d=self.box2d)
+        self.box = BoxEstNet(g, p + 'box_est', False, box2d=self.box2d)
         q = 'class_dependent/box_refine/'
         oh = NUM_CLASS if use_one_hot else 0
         self.oh = oh
@@ -864,12 +890,23 @@ class SemiModelF:
         self.R2 = FcLayer(g, q + 'fc2', 256, BOX_OUT_DIMS, bn=False, act=None)
         self.loss_op = StrongLoss(g)
         self.boxpc = BoxPCNet(g, 'D_boxpc_branch/', False)
+        # SEMI_REFINE_USING_BOXPC_DELTA_NUM > 1 in the TRAINING graph (train_semisup_adv.py:362-386): one evaluation of the frozen
+        # Box-PC net per refinement step -- the same variables (reuse=True), own activations, because with
+        # SEMI_BOXPC_MIN_FIT_LOSS_AFT_REFINE the fit loss reads the LAST evaluation and its gradient runs back through every step
+        self.refine_train = max(1, int(c.SEMI_REFINE_USING_BOXPC_DELTA_NUM))
+        self.boxpc_nets = [self.boxpc] + [BoxPCNet(g, 'D_boxpc_branch/', False) for _ in range(self.refine_train - 1)]
+        for i, net in enumerate(self.boxpc_nets[1:], 1):      # names under which tests read the decisions of the i-th further evaluation
+            for lay in (net.P1, net.P2, net.P3, net.P4, net.F1, net.F2, net.F3):
+                lay.decision_scope = lay.scope.replace('D_boxpc_branch/', 'D_boxpc_branch@%d/' % i, 1)
+        self.loss_eval = self.refine_train - 1 if c.SEMI_BOXPC_MIN_FIT_LOSS_AFT_REFINE else 0
+        self.refine_w = int(bool(c.SEMI_WEIGH_BOXPC_DELTA_DURING_TEST)) + int(bool(c.BOXPC_WEIGH_DELTA_PRED_BY_CLS_CONF))
         self.train_classes = list(train_classes) if train_classes is not None else [True] * NUM_CLASS
         rt, B = g.rt, g.B
         self.d_dims, self.dout9, self.fit_prob = rt.zeros(B, 3), rt.zeros(B, 9), rt.zeros(B)
         self.terms, self.loss = rt.zeros(2), rt.zeros(1)
         self.W_iou2d, self.W_iou3d = rt.zeros(B), rt.zeros(B)      # get_iou_summary(W_pred_box, ..., 'W_') (semisup_v1_sunrgbd.py:414)
         self.drep, self.dbox7 = rt.zeros(g.M, 8), rt.zeros(B, 7)
+        self.carry, self.dout9_chain = rt.zeros(B, 7), rt.zeros(B, 9)
         self.weak = None
         # inference graph (test_semisup.py:95-149): iterated Box-PC refinement of the F_ box
         self.refine_num = None
@@ -882,8 +919,9 @@ class SemiModelF:
         g.emit_cast_weights(plan)
         self.seg.fwd(plan, x.pc, x.one_hot_vec, x.y_seg if with_loss else None, x.is_data_2D, is_training, False,
                      ce_weight=c.STRONG_WEIGHT_CROSS_ENTROPY)
-        s1 = self.tnet.fwd(plan, x.pc, self.seg.mask, self.seg.mask_xyz_mean, x.one_hot_vec, is_training)
-        self.box.fwd(plan, x.pc, self.seg.mask, s1, x.one_hot_vec, is_training)
+        ex, ld_ex = self.extra.emit(plan, x) if self.extra is not None else (x.one_hot_vec, NUM_CLASS)
+        s1 = self.tnet.fwd(plan, x.pc, self.seg.mask, self.seg.mask_xyz_mean, ex, is_training, ld_oh=ld_ex)
+        self.box.fwd(plan, x.pc, self.seg.mask, s1, ex, is_training, ld_oh=ld_ex)
         f = self.R0.fwd(plan, self.box.feats_lv1, 512, is_training, in2=x.one_hot_vec if self.oh else None, ld_in2=NUM_CLASS)
         f = self.R1.fwd(plan, f, 512, is_training)
         self.F_out = self.R2.fwd(plan, f, 256, is_training)
@@ -893,7 +931,17 @@ class SemiModelF:
             emit_box_head_iou(g, plan, self.box.box_params, s1, lab, self.W_iou2d, self.W_iou3d)
         # frozen Box-PC net on F_pred_box_reg (is_training_D = False: eval-mode batch-norm, no dropout)
         lo = self.loss_op
-        out9 = self.boxpc.fwd(plan, x.pc, lo.center, lo.reg_dims, lo.reg_theta, x.one_hot_vec, False)
+        src = (lo.center, lo.reg_dims, lo.reg_theta)
+        cur = (self.cur_center, self.cur_dims, self.cur_theta)
+        self.outs9 = []
+        for i, net in enumerate(self.boxpc_nets):
+            self.outs9.append(net.fwd(plan, x.pc, src[0], src[1], src[2], x.one_hot_vec, False))
+            if self.refine_train > 1:      # box <- box - w * delta(box, pc); the totals give the F2_ heads (train_semisup_adv.py:376-399)
+                r = abi.BoxRefineStepArgs(fptr(self.outs9[i]), fptr(src[0]), fptr(src[1]), fptr(src[2]), fptr(cur[0]), fptr(cur[1]),
+                                          fptr(cur[2]), fptr(self.total_delta), None, self.refine_w, int(i == 0), g.B)
+                plan.add('t3d_box_refine_step', r)
+                src = cur
+        out9 = self.outs9[self.loss_eval]
         a = abi.SemiFinalLossArgs()
         a.strong_loss, a.reg_dims, a.one_hot, a.is_data_2D, a.out9 = fptr(lo.loss), fptr(lo.reg_dims), fptr(x.one_hot_vec), \
             iptr(x.is_data_2D), fptr(out9)
@@ -917,8 +965,9 @@ class SemiModelF:
         g, x, c = self.g, self.inputs, self.c
         g.emit_cast_weights(plan)
         self.seg.fwd(plan, x.pc, x.one_hot_vec, None, x.is_data_2D, False, False, ce_weight=c.STRONG_WEIGHT_CROSS_ENTROPY)
-        s1 = self.tnet.fwd(plan, x.pc, self.seg.mask, self.seg.mask_xyz_mean, x.one_hot_vec, False)
-        self.box.fwd(plan, x.pc, self.seg.mask, s1, x.one_hot_vec, False)
+        ex, ld_ex = self.extra.emit(plan, x) if self.extra is not None else (x.one_hot_vec, NUM_CLASS)
+        s1 = self.tnet.fwd(plan, x.pc, self.seg.mask, self.seg.mask_xyz_mean, ex, False, ld_oh=ld_ex)
+        self.box.fwd(plan, x.pc, self.seg.mask, s1, ex, False, ld_oh=ld_ex)
         f = self.R0.fwd(plan, self.box.feats_lv1, 512, False, in2=x.one_hot_vec if self.oh else None, ld_in2=NUM_CLASS)
         f = self.R1.fwd(plan, f, 512, False)
         self.F_out = self.R2.fwd(plan, f, 256, False)
@@ -930,19 +979,30 @@ class SemiModelF:
         for i in range(int(refine_num)):
             out9 = self.boxpc.fwd(plan, x.pc, src[0], src[1], src[2], x.one_hot_vec, False)
             a = abi.BoxRefineStepArgs(fptr(out9), fptr(src[0]), fptr(src[1]), fptr(src[2]), fptr(cur[0]), fptr(cur[1]), fptr(cur[2]),
-                                      fptr(self.total_delta), fptr(self.fit_prob), int(bool(c.SEMI_WEIGH_BOXPC_DELTA_DURING_TEST)),
+                                      fptr(self.total_delta), fptr(self.fit_prob),
+                                      int(bool(c.SEMI_WEIGH_BOXPC_DELTA_DURING_TEST)) + int(bool(c.BOXPC_WEIGH_DELTA_PRED_BY_CLS_CONF)),
                                       int(i == 0), g.B)
             plan.add('t3d_box_refine_step', a)
             src = cur
 
     def emit_backward(self, plan):
         g, x = self.g, self.inputs
-        bp = self.boxpc
-        bp.bwd(plan, self.dout9, param_grads=False)
-        n = abi.DgradNarrowArgs(bp.P1.dy_struct(), fptr(bp.P1.w), g.C, 6, fptr(self.drep), 8, g.M, 128)
-        plan.add('t3d_pointmlp_dgrad_narrow', n)
-        r = abi.BoxPcRepBwdArgs(fptr(x.pc), g.ldpc, fptr(bp.box7), fptr(self.drep), 8, 0, fptr(self.dbox7), g.B, g.rpf)
-        plan.add('t3d_boxpc_rep_bwd', r)
+        dout, carry = self.dout9, None
+        for i in range(self.loss_eval, -1, -1):       # the evaluation the fit loss read, then back through the refinement steps before it
+            bp = self.boxpc_nets[i]
+            bp.bwd(plan, dout, param_grads=False)
+            n = abi.DgradNarrowArgs(bp.P1.dy_struct(), fptr(bp.P1.w), g.C, 6, fptr(self.drep), 8, g.M, 128)
+            plan.add('t3d_pointmlp_dgrad_narrow', n)
+            r = abi.BoxPcRepBwdArgs(fptr(x.pc), g.ldpc, fptr(bp.box7), fptr(self.drep), 8, 0, fptr(self.dbox7), g.B, g.rpf)
+            plan.add('t3d_boxpc_rep_bwd', r)
+            if i > 0:        # box_i = box_{i-1} - w * delta_{i-1}: gradient into evaluation i-1's deltas, and past it (carry)
+                q = abi.BoxRefineStepBwdArgs(fptr(self.outs9[i - 1]), fptr(self.dbox7), fptr(carry), fptr(self.carry),
+                                             fptr(self.dout9_chain), self.refine_w, int(not self.c.BOXPC_STOP_GRAD_OF_CLS_VIA_DELTA), g.B)
+                plan.add('t3d_box_refine_step_bwd', q)
+                dout, carry = self.dout9_chain, self.carry
+            elif carry is not None:                      # total gradient w.r.t. the unrefined F_ box
+                q = abi.BoxRefineStepBwdArgs(None, fptr(self.dbox7), fptr(carry), fptr(self.dbox7), None, 0, 0, g.B)
+                plan.add('t3d_box_refine_step_bwd', q)
         lo = self.loss_op
         q = abi.AnchorRegBwdArgs(fptr(self.F_out), BOX_OUT_DIMS, fptr(self.dbox7), fptr(self.d_dims), fptr(lo.dbox),
                                  fptr(lo.dstage1), g.B)
@@ -968,7 +1028,7 @@ class SemiModelF:
         return {'logits': self.seg.logits.view(B, N, 2), 'stage1_center': self.tnet.stage1_center,
                 'feats_lv1': self.box.feats_lv1, 'box_params': self.box.box_params, 'F_box_params': self.F_out,
                 'F_center': lo.center, 'F_dims': lo.reg_dims, 'F_theta': lo.reg_theta, 'boxpc_fit_prob': self.fit_prob,
-                'boxpc_out': self.boxpc.F3.out, 'loss': self.loss, 'strong_loss': lo.loss, 'terms': self.terms,
+                'boxpc_out': self.boxpc.F3.out, 'boxpc_out_last': self.boxpc_nets[-1].F3.out, 'loss': self.loss, 'strong_loss': lo.loss, 'terms': self.terms,
                 'loss_terms': lo.terms, 'iou2ds': lo.iou2d, 'iou3ds': lo.iou3d, 'W_iou2ds': self.W_iou2d, 'W_iou3ds': self.W_iou3d,
                 'total_delta': self.total_delta, 'refined_center': self.cur_center,
                 'refined_dims': self.cur_dims, 'refined_theta': self.cur_theta}

@@ -16,6 +16,19 @@ def _asm(ctx, use_one_hot):
     return asm
 
 
+def _box2d_feats(asm, one_hot_vec, norm_box2D):
+    """norm_box2D joins the FC input of the T-Net / box net behind the one-hot vector (semisup_models.py:192-195, 249-252): the
+    assembly gets the [one_hot | norm_box2D] block (nets.ExtraFeats) those layers read."""
+    if norm_box2D is None:
+        return
+    from .nets import ExtraFeats
+    from .constants import NUM_CLASS
+    n_oh = NUM_CLASS if one_hot_vec is not None else 0
+    if asm.extra is None or asm.extra.n_oh != n_oh:
+        asm.extra = ExtraFeats(asm.g, n_oh)
+    asm.box2d = True
+
+
 def v1_inst_seg(point_cloud, img_feats, one_hot_vec, end_points, is_training, bn_decay=None, scope=None):
     """Instance-segmentation PointNet -> per-point logits (B,N,2)."""
     ctx = point_cloud.ctx
@@ -42,11 +55,10 @@ def subtract_points_mean(point_cloud, logits, scope=None):
 
 def v1_tnet(point_cloud_xyz_stage1, mask, mask_xyz_mean, one_hot_vec, end_points, is_training, norm_box2D=None,
             bn_decay=None, scope=None):
-    if norm_box2D is not None:
-        raise NotImplementedError('USE_NORMALIZED_BOX2D_AS_FEATS is off in every published recipe')
     ctx = point_cloud_xyz_stage1.ctx
     asm = _asm(ctx, one_hot_vec is not None)
-    asm.tnet = TNet(ctx.engine, scope, one_hot_vec is not None)
+    _box2d_feats(asm, one_hot_vec, norm_box2D)
+    asm.tnet = TNet(ctx.engine, scope, one_hot_vec is not None, box2d=norm_box2D is not None)
     s1 = api.Tensor(ctx, asm.tnet.F3.out, (ctx.engine.B, 3), scope + '/stage1_center', producer=asm.tnet)
     end_points['stage1_center'] = s1
     return s1
@@ -58,11 +70,10 @@ def subtract_1st_stage_center(point_cloud_xyz, stage1_center, scope=None):
 
 def v1_box_est(point_cloud_xyz_submean, stage1_center, mask, one_hot_vec, end_points, is_training, norm_box2D=None,
                bn_decay=None, prefix='', c=None, scope=None):
-    if norm_box2D is not None:
-        raise NotImplementedError('USE_NORMALIZED_BOX2D_AS_FEATS is off in every published recipe')
     ctx = point_cloud_xyz_submean.ctx
     asm = _asm(ctx, one_hot_vec is not None)
-    asm.box = BoxEstNet(ctx.engine, scope, one_hot_vec is not None)
+    _box2d_feats(asm, one_hot_vec, norm_box2D)
+    asm.box = BoxEstNet(ctx.engine, scope, one_hot_vec is not None, box2d=norm_box2D is not None)
     B = ctx.engine.B
     NH, NS = NUM_HEADING_BIN, NUM_SIZE_CLUSTER
     box = asm.box

@@ -50,6 +50,8 @@ def get_semi_model_final(pc, bg_pc, img, one_hot_vec, is_training, use_one_hot, 
     if isinstance(bn_decay, (int, float)):
         e.hyper[2] = float(bn_decay)
     train_classes = getattr(c, 'intraclsdims_train_classes', None)
+    if c.USE_NORMALIZED_BOX2D_AS_FEATS and norm_box2D is None:        # semisup_v1_sunrgbd.py:145,168,176
+        raise ValueError('USE_NORMALIZED_BOX2D_AS_FEATS needs norm_box2D = tf_util.tf_normalize_2D_bboxes(box2D_pl, img_dim_pl)')
     m = SemiModelF(e, c, use_one_hot=use_one_hot, train_classes=train_classes, inputs=ctx.inputs)
     ctx.assembly = m
     ctx.is_training = is_training if isinstance(is_training, api.BoolPlaceholder) else bool(is_training)
@@ -71,10 +73,23 @@ def get_semi_model_final(pc, bg_pc, img, one_hot_vec, is_training, use_one_hot, 
     # Box-PC branch outputs and the refined F2_ heads (train_semisup_adv.py:376-411), evaluated on the host at fetch time
     out9 = T(m.boxpc.F3.out, (B, 9), 'boxpc_out')
     end_points['boxpc_fit_prob'] = T(m.fit_prob, (B,), 'boxpc_fit_prob')
-    end_points['boxpc_delta_center'] = T(m.boxpc.F3.out[:, 0:3], (B, 3), 'boxpc_delta_center')
-    end_points['boxpc_delta_size'] = T(m.boxpc.F3.out[:, 3:6], (B, 3), 'boxpc_delta_size')
-    end_points['boxpc_delta_angle'] = T(m.boxpc.F3.out[:, 6], (B,), 'boxpc_delta_angle')
     ST = semisup_models.SlicedTensor
+
+    def delta_heads(buf):
+        """boxpc_delta_{center,size,angle} of one Box-PC evaluation (boxpc_sunrgbd.py:79-95): columns of its output, times
+        (1 - p_fit) under BOXPC_WEIGH_DELTA_PRED_BY_CLS_CONF (evaluated on the host at fetch time)."""
+        if not c.BOXPC_WEIGH_DELTA_PRED_BY_CLS_CONF:
+            return T(buf[:, 0:3], (B, 3), 'boxpc_delta_center'), T(buf[:, 3:6], (B, 3), 'boxpc_delta_size'), T(buf[:, 6], (B,), 'boxpc_delta_angle')
+        full = T(buf, (B, 9), 'boxpc_out')
+
+        def wd():
+            l = full.numpy()[:, 7:9].astype(np.float64)
+            e = np.exp(l - l.max(1, keepdims=True))
+            return (1.0 - e[:, 1] / e.sum(1)).astype(np.float32)
+        return (ST(full, lambda: full.numpy()[:, 0:3] * wd()[:, None], (B, 3), 'boxpc_delta_center'),
+                ST(full, lambda: full.numpy()[:, 3:6] * wd()[:, None], (B, 3), 'boxpc_delta_size'),
+                ST(full, lambda: full.numpy()[:, 6] * wd(), (B,), 'boxpc_delta_angle'))
+    end_points['boxpc_delta_center'], end_points['boxpc_delta_size'], end_points['boxpc_delta_angle'] = delta_heads(m.boxpc.F3.out)
     if not ctx.is_training:
         # inference graph (test_semisup.py:95-149): SEMI_REFINE_USING_BOXPC_DELTA_NUM refinement steps on the device,
         # F2_ = F_ - accumulated deltas
@@ -89,17 +104,27 @@ def get_semi_model_final(pc, bg_pc, img, one_hot_vec, is_training, use_one_hot, 
                                              (B, 10, 3), 'F2_size_residuals')
         return (logits, W.pred_box(), F.pred_box()), end_points
 
-    # training form of the stage-c glue (train_semisup_adv.py:362-399): one Box-PC evaluation on F_pred_box_reg serves the fit
-    # probability and the single refinement step of the published recipe (SEMI_REFINE_USING_BOXPC_DELTA_NUM = 1).  With one step
+    # training form of the stage-c glue (train_semisup_adv.py:362-399).  With SEMI_REFINE_USING_BOXPC_DELTA_NUM = 1 (the published
+    # recipe) one Box-PC evaluation on F_pred_box_reg serves the fit probability and the refinement step, and
     # SEMI_BOXPC_MIN_FIT_LOSS_AFT_REFINE (set in recipe c) changes nothing: the loop's evaluation sees the same unrefined box.
-    if int(c.SEMI_REFINE_USING_BOXPC_DELTA_NUM) > 1:
-        raise NotImplementedError('SEMI_REFINE_USING_BOXPC_DELTA_NUM > 1 in the training graph (the published recipe uses 1; the '
-                                  'inference graph of test_semisup supports any number through --refine)')
+    if m.refine_train > 1:
+        # one evaluation per step on the device (nets.SemiModelF.boxpc_nets); the fit probability is the first evaluation's, or the
+        # last one's with SEMI_BOXPC_MIN_FIT_LOSS_AFT_REFINE (train_semisup_adv.py:388-389); delta heads = the last evaluation's
+        end_points['boxpc_delta_center'], end_points['boxpc_delta_size'], end_points['boxpc_delta_angle'] = \
+            delta_heads(m.boxpc_nets[-1].F3.out)
+        tot = T(m.total_delta, (B, 7), 'total_delta')
+        end_points['F2_center'] = ST(tot, lambda: end_points['F_center'].numpy() - tot.numpy()[:, 0:3], (B, 3), 'F2_center')
+        end_points['F2_heading_scores'] = end_points['F_heading_scores']
+        end_points['F2_heading_residuals'] = ST(tot, lambda: end_points['F_heading_residuals'].numpy() - tot.numpy()[:, 6:7],
+                                                (B, 12), 'F2_heading_residuals')
+        end_points['F2_size_scores'] = end_points['F_size_scores']
+        end_points['F2_size_residuals'] = ST(tot, lambda: end_points['F_size_residuals'].numpy() - tot.numpy()[:, None, 3:6],
+                                             (B, 10, 3), 'F2_size_residuals')
+        return (logits, W.pred_box(), F.pred_box()), end_points
 
     def wgt():
-        if c.SEMI_WEIGH_BOXPC_DELTA_DURING_TEST:
-            return 1.0 - end_points['boxpc_fit_prob'].numpy()
-        return np.ones(B, np.float32)
+        n = int(bool(c.SEMI_WEIGH_BOXPC_DELTA_DURING_TEST)) + int(bool(c.BOXPC_WEIGH_DELTA_PRED_BY_CLS_CONF))    # boxpc_sunrgbd.py:84-92
+        return (1.0 - end_points['boxpc_fit_prob'].numpy()) ** n
     end_points['F2_center'] = ST(out9, lambda: end_points['F_center'].numpy() - out9.numpy()[:, 0:3] * wgt()[:, None], (B, 3), 'F2_center')
     end_points['F2_heading_scores'] = end_points['F_heading_scores']
     end_points['F2_heading_residuals'] = ST(out9, lambda: end_points['F_heading_residuals'].numpy() - (out9.numpy()[:, 6] * wgt())[:, None],
@@ -141,6 +166,8 @@ def get_semi_model_backbone(pc, bg_pc, img, one_hot_vec, is_training, use_one_ho
         raise NotImplementedError
     if not c.USE_NORMALIZED_BOX2D_AS_FEATS:
         norm_box2D = None
+    elif norm_box2D is None:
+        raise ValueError('USE_NORMALIZED_BOX2D_AS_FEATS needs norm_box2D = tf_util.tf_normalize_2D_bboxes(box2D_pl, img_dim_pl)')
     logits = semisup_models.v1_inst_seg(pc, None, one_hot_vec, end_points, is_training, bn_decay=bn_decay, scope='inst_seg')
     mask, mask_xyz_mean, pc_xyz, pc_xyz_stage1 = semisup_models.subtract_points_mean(pc, logits, scope='subtract_points_mean')
     stage1_center = semisup_models.v1_tnet(pc_xyz_stage1, mask, mask_xyz_mean, one_hot_vec, end_points, is_training,

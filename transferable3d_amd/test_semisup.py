@@ -16,7 +16,7 @@ import numpy as np
 
 if __package__ in (None, ''):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from transferable3d_amd import api, semisup_v1_sunrgbd as MODEL        # noqa: E402
+from transferable3d_amd import api, tf_util, semisup_v1_sunrgbd as MODEL        # noqa: E402
 from transferable3d_amd.config import make_parser                        # noqa: E402
 from transferable3d_amd.constants import NUM_HEADING_BIN, NUM_SIZE_CLUSTER   # noqa: E402
 from transferable3d_amd.synthetic import make_batch                      # noqa: E402
@@ -67,7 +67,9 @@ def get_model(FLAGS, batch_size, num_point, num_channel, rt=None, state_dict=Non
     graph = api.Graph(rt=rt, seed=FLAGS.seed, dtype=FLAGS.dtype)
     with graph.as_default():
         pls = MODEL.placeholder_inputs(batch_size, num_point, num_channel)
-        pred, end_points = MODEL.get_semi_model(pls[0], pls[1], pls[2], pls[3], False, use_one_hot=FLAGS.use_one_hot, c=FLAGS)
+        norm_box2D = tf_util.tf_normalize_2D_bboxes(pls[15], pls[16])       # test_semisup.py:74
+        pred, end_points = MODEL.get_semi_model(pls[0], pls[1], pls[2], pls[3], False, use_one_hot=FLAGS.use_one_hot,
+                                                norm_box2D=norm_box2D, c=FLAGS)
         sess = api.Session()
     if state_dict is not None:
         graph.vars.load_state_dict(state_dict, strict=False)

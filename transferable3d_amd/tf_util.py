@@ -207,8 +207,24 @@ def batch_norm_for_fc(inputs, is_training, bn_decay, scope):
 
 
 # ---- host-side geometry helpers (tiny, per-frustum; run on NumPy arrays) ----------------------------------------
+class NormBox2D(api.Tensor):
+    """tf_normalize_2D_bboxes of the box2D / img_dim placeholders: a lazy handle -- the division runs in t3d_box2d_feats at the head of
+    the forward, which writes it straight into the [one_hot | norm_box2D] input block of the T-Net / box net FC layers."""
+
+    def __init__(self, ctx, box2D, image_dim):
+        api.Tensor.__init__(self, ctx, None, (ctx.engine.B, 4), 'norm_box2D')
+        self.box2D, self.image_dim = box2D, image_dim
+
+    def numpy(self):
+        return tf_normalize_2D_bboxes(self.box2D.numpy(), self.image_dim.numpy())
+
+
 def tf_normalize_2D_bboxes(box2D, image_dim):
     """tf_util.py:466-484: [left/cols, top/rows, right/cols, bottom/rows]."""
+    if isinstance(box2D, api.Tensor):
+        if getattr(box2D, 'field', None) != 'box2D' or getattr(image_dim, 'field', None) != 'img_dim':
+            raise NotImplementedError('tf_normalize_2D_bboxes takes the box2D and img_dim placeholders (train_semisup.py:240)')
+        return NormBox2D(box2D.ctx, box2D, image_dim)
     box2D, image_dim = np.asarray(box2D, np.float32), np.asarray(image_dim, np.float32)
     rows, cols = image_dim[:, 0], image_dim[:, 1]
     return np.stack([box2D[:, 0] / cols, box2D[:, 1] / rows, box2D[:, 2] / cols, box2D[:, 3] / rows], axis=1)

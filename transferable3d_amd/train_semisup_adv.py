@@ -16,7 +16,7 @@ import numpy as np
 
 if __package__ in (None, ''):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from transferable3d_amd import api, semisup_v1_sunrgbd as MODEL        # noqa: E402
+from transferable3d_amd import api, tf_util, semisup_v1_sunrgbd as MODEL        # noqa: E402
 from transferable3d_amd.config import make_parser                        # noqa: E402
 from transferable3d_amd.constants import type2class                      # noqa: E402
 from transferable3d_amd.synthetic import make_batch                      # noqa: E402
@@ -155,7 +155,9 @@ def train(FLAGS, rt=None, log=print):
     with api.Graph(rt=rt, seed=FLAGS.seed, inline_dropout=True, dtype=FLAGS.dtype).as_default() as g:
         pls = MODEL.placeholder_inputs(B, N, C)
         is_training_pl = api.is_training_placeholder()                    # train_semisup_adv.py:300 (is_training_D stays False)
-        pred, end_points = MODEL.get_semi_model(pls[0], pls[1], pls[2], pls[3], is_training_pl, use_one_hot=FLAGS.use_one_hot, c=FLAGS)
+        norm_box2D = tf_util.tf_normalize_2D_bboxes(pls[15], pls[16])       # train_semisup_adv.py:315
+        pred, end_points = MODEL.get_semi_model(pls[0], pls[1], pls[2], pls[3], is_training_pl, use_one_hot=FLAGS.use_one_hot,
+                                                norm_box2D=norm_box2D, c=FLAGS)
         intraclsdims_train_classes = [(cls_type in FLAGS.TEST_CLS) for cls_type in ALL_CLASSES] \
             if FLAGS.SEMI_INTRACLSDIMS_ONLY_ON_2D_CLS else [True] * len(ALL_CLASSES)
         inactive_vol_train_classes = [(cls_type in FLAGS.TEST_CLS) for cls_type in ALL_CLASSES] \
