@@ -64,8 +64,14 @@ __device__ unsigned long long* t3d_trace_ptr = nullptr;
             (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | ((32 - 1) << 11));                 \
     }                                                                                                         \
   } while (0)
+// eight marks per workgroup (tools/trace_fwd_res.py): the phases of the FIRST row tile of the resident bf16 forward
+#define T3D_TRACE_MARK8(slot)                                                                                 \
+  do {                                                                                                        \
+    if (threadIdx.x == 0 && t3d_trace_ptr) t3d_trace_ptr[(size_t)blockIdx.x * 8 + (slot)] = wall_clock64();  \
+  } while (0)
 #else
 #define T3D_TRACE_MARK(slot) do {} while (0)
+#define T3D_TRACE_MARK8(slot) do {} while (0)
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -587,6 +593,20 @@ struct StagerH {
       raw[S][q] = TYPE_R ? l.fetch(lane0 + li, red0_ + ri) : l.fetch(red0_ + ri, lane0 + li);
     }
   }
+  // the two halves of fetch(), for callers that request the data early and the per-channel coefficients late (k_pointmlp_fwd_res)
+  template <int S>
+  __device__ __forceinline__ void fetch_raw(const L& l, int red0_, int tid) {
+    red0[S] = red0_;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      int li, ri; coords(tid, q, li, ri);
+      raw[S][q] = TYPE_R ? l.fetch(lane0 + li, red0_ + ri) : l.fetch(red0_ + ri, lane0 + li);
+    }
+  }
+  template <int S>
+  __device__ __forceinline__ void fetch_coefs(const L& l, int red0_, int tid) {
+    if (TYPE_R) { int li, ri; coords(tid, 0, li, ri); coef[S] = l.fetch_coef(red0_ + ri); }
+  }
   template <int S>
   __device__ __forceinline__ void store_piece(const L& l, bf16_t* tile, int tid, int q) {
     int li, ri; coords(tid, q, li, ri);
@@ -641,6 +661,20 @@ struct StagerH8 {
       if (TYPE_R) l.fetch8(lane0 + li, red0_ + ri, raw[S][q][0], raw[S][q][1]);
       else l.fetch8(red0_ + ri, lane0 + li, raw[S][q][0], raw[S][q][1]);
     }
+  }
+  template <int S>
+  __device__ __forceinline__ void fetch_raw(const L& l, int red0_, int tid) {
+    red0[S] = red0_;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      int li, ri; coords(tid, q, li, ri);
+      if (TYPE_R) l.fetch8(lane0 + li, red0_ + ri, raw[S][q][0], raw[S][q][1]);
+      else l.fetch8(red0_ + ri, lane0 + li, raw[S][q][0], raw[S][q][1]);
+    }
+  }
+  template <int S>
+  __device__ __forceinline__ void fetch_coefs(const L& l, int red0_, int tid) {
+    if (TYPE_R) { int li, ri; coords(tid, 0, li, ri); coef[S][0] = l.fetch_coef(red0_ + ri); coef[S][1] = l.fetch_coef(red0_ + ri + 4); }
   }
   template <int S>
   __device__ __forceinline__ void store(const L& l, bf16_t* tile, int tid) {
@@ -858,6 +892,19 @@ __device__ __forceinline__ void fwd_body(const t3d_pointmlp_fwd_args& p, float* 
   sa.init(la, row0, tid);
   sb.init(lb, col0, tid);
 
+  // the epilogue's per-column additive terms (bias, conv6's per-frustum row bias), requested BEFORE the main loop: loaded at the
+  // head of the epilogue they were a dependent L2 round trip in front of every launch's stores (round 3, tools/trace_fwd_res.py)
+  float addv[TN];
+  {
+    const int l31_ = lane & 31, b_ = row0 / p.rows_per_frustum;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = col0 + wn * (BN / 2) + tn * 32 + l31_;
+      float add = p.bias ? p.bias[col] : 0.f;
+      if (p.rowbias) add += p.rowbias[(size_t)b_ * p.N + col];
+      addv[tn] = add;
+    }
+  }
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
   const int kred = (p.K + PR::RED - 1) / PR::RED * PR::RED;
@@ -899,52 +946,66 @@ __device__ __forceinline__ void fwd_body(const t3d_pointmlp_fwd_args& p, float* 
         keepbits |= (p.rowmask[row0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] != 0.f ? 1u : 0u) << (tm * 16 + r);
   }
   const int rin_base = row0 - b * p.rows_per_frustum + wm * 64 + 4 * h;
+  // `store_y` and `pool` are compile-time inside the element loop (round 3): as run-time flags hipcc compiled each into a BRANCH
+  // PER ELEMENT -- two s_cbranch per output element in every forward kernel, fp32 and bf16 alike (tools/kernel_branches.py: 155
+  // branches in k_pointmlp_fwd<128>), and the fp32 store addresses into a 64-bit multiply-add per element.  The arithmetic and its
+  // order are unchanged.
+  const unsigned n4 = (unsigned)p.N * 4u;                            // row pitch in bytes (uniform)
+  char* const yb = reinterpret_cast<char*>(p.y);
+  auto epi = [&](auto sy_tag, auto pl_tag) {
+    constexpr bool SY = decltype(sy_tag)::value, PL = decltype(pl_tag)::value;
 #pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
-    const int col = col0 + wn * (BN / 2) + tn * 32 + l31;
-    float add = p.bias ? p.bias[col] : 0.f;
-    if (p.rowbias) add += p.rowbias[(size_t)b * p.N + col];
-    float s = 0.f, ss = 0.f, mx = -INFINITY, mn = INFINITY;
-    int ax = -1, an = -1;
-    // 32-bit element offsets (M*N < 2^30 is checked by the launcher): one VGPR per store instead of an address pair
-    const unsigned off0 = (unsigned)(row0 + wm * 64 + 4 * h) * (unsigned)p.N + (unsigned)col;
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = col0 + wn * (BN / 2) + tn * 32 + l31;
+      const float add = addv[tn];
+      float s = 0.f, ss = 0.f, mx = -INFINITY, mn = INFINITY;
+      int ax = -1, an = -1;
+      // 32-bit byte offsets (M*N < 2^30 is checked by the launcher): one VGPR add per store on top of the uniform base; the
+      // per-lane part is opaque to the optimiser so that it is not folded back into a 64-bit product per element
+      unsigned boff0 = ((unsigned)(row0 + wm * 64 + 4 * h) * (unsigned)p.N + (unsigned)col) * 4u;
+      asm volatile("" : "+v"(boff0));
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
+      for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        // bf16 storage: statistics (and the pool's candidates) of the value as it is stored, i.e. as every reader sees it
-        const float v = store_y ? Elem<YT>::rnd(acc[tm][tn][r] + add) : acc[tm][tn][r] + add;
-        if constexpr (Elem<YT>::BF16) {
-          // bf16: the tile goes through LDS (the stages are free now) and leaves as 16-byte row-contiguous stores below -- 64
-          // two-byte global stores per thread were half of a workgroup's lifetime on the narrow layers (tools/trace_blocks.py)
-          if (store_y) ytile[(wm * 64 + 4 * h + tm * 32 + (r & 3) + 8 * (r >> 2)) * YLD + wn * (BN / 2) + tn * 32 + l31] = (bf16_t)v;
-        } else {
-          if (store_y) p.y[off0 + (unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)p.N] = v;
-        }
-        s += v;
-        ss = fmaf(v, v, ss);
-        if (pool) {                                  // selects: same results as the branches they replace, no exec-mask juggling
-          const bool keep = (keepbits >> (tm * 16 + r)) & 1u;
-          const int rin = rin_base + tm * 32 + (r & 3) + 8 * (r >> 2);
-          const bool up = keep & (v > mx), dn = keep & (v < mn);
-          mx = up ? v : mx;
-          ax = up ? rin : ax;
-          mn = dn ? v : mn;
-          an = dn ? rin : an;
+        for (int r = 0; r < 16; ++r) {
+          // bf16 storage: statistics (and the pool's candidates) of the value as it is stored, i.e. as every reader sees it
+          const float v = SY ? Elem<YT>::rnd(acc[tm][tn][r] + add) : acc[tm][tn][r] + add;
+          if constexpr (SY) {
+            if constexpr (Elem<YT>::BF16) {
+              // bf16: the tile goes through LDS (the stages are free now) and leaves as 16-byte row-contiguous stores below -- 64
+              // two-byte global stores per thread were half of a workgroup's lifetime on the narrow layers (tools/trace_blocks.py)
+              ytile[(wm * 64 + 4 * h + tm * 32 + (r & 3) + 8 * (r >> 2)) * YLD + wn * (BN / 2) + tn * 32 + l31] = (bf16_t)v;
+            } else {
+              *reinterpret_cast<float*>(yb + (boff0 + (unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) * n4)) = v;
+            }
+          }
+          s += v;
+          ss = fmaf(v, v, ss);
+          if constexpr (PL) {                          // selects: same results as the branches they replace, no exec-mask juggling
+            const bool keep = (keepbits >> (tm * 16 + r)) & 1u;
+            const int rin = rin_base + tm * 32 + (r & 3) + 8 * (r >> 2);
+            const bool up = keep & (v > mx), dn = keep & (v < mn);
+            mx = up ? v : mx;
+            ax = up ? rin : ax;
+            mn = dn ? v : mn;
+            an = dn ? rin : an;
+          }
         }
       }
+      // combine the two lane halves (rows +4): lower row index wins ties
+      s += __shfl_xor(s, 32, 64);
+      ss += __shfl_xor(ss, 32, 64);
+      if constexpr (PL) {
+        const float omx = __shfl_xor(mx, 32, 64), omn = __shfl_xor(mn, 32, 64);
+        const int oax = __shfl_xor(ax, 32, 64), oan = __shfl_xor(an, 32, 64);
+        if (oax >= 0 && (omx > mx || ax < 0 || (omx == mx && oax < ax))) { mx = omx; ax = oax; }
+        if (oan >= 0 && (omn < mn || an < 0 || (omn == mn && oan < an))) { mn = omn; an = oan; }
+      }
+      csum[tn] = s; csq[tn] = ss; cmax[tn] = mx; cmin[tn] = mn; amax[tn] = ax; amin[tn] = an;
     }
-    // combine the two lane halves (rows +4): lower row index wins ties
-    s += __shfl_xor(s, 32, 64);
-    ss += __shfl_xor(ss, 32, 64);
-    if (pool) {
-      const float omx = __shfl_xor(mx, 32, 64), omn = __shfl_xor(mn, 32, 64);
-      const int oax = __shfl_xor(ax, 32, 64), oan = __shfl_xor(an, 32, 64);
-      if (oax >= 0 && (omx > mx || ax < 0 || (omx == mx && oax < ax))) { mx = omx; ax = oax; }
-      if (oan >= 0 && (omn < mn || an < 0 || (omn == mn && oan < an))) { mn = omn; an = oan; }
-    }
-    csum[tn] = s; csq[tn] = ss; cmax[tn] = mx; cmin[tn] = mn; amax[tn] = ax; amin[tn] = an;
-  }
+  };
+  if (store_y) { if (pool) epi(std::true_type{}, std::true_type{}); else epi(std::true_type{}, std::false_type{}); }
+  else { if (pool) epi(std::false_type{}, std::true_type{}); else epi(std::false_type{}, std::false_type{}); }
   __syncthreads();
   if (h == 0) {
 #pragma unroll
@@ -1033,24 +1094,74 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd_res(const t3d_po
   bf16_t* panel = reinterpret_cast<bf16_t*>(smem);
   bf16_t* bst = panel + KT * A_ELEMS;
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1, l31 = lane & 31, h = lane >> 5;
-  const int tile_m = xcd_remap(blockIdx.x, gridDim.x), row0 = tile_m * 128;
-  const int b = row0 / p.rows_per_frustum;
+  // Everything derived from the thread index is re-derived inside the row loop from a laundered copy: hoisted out of the loop
+  // (LICM) the address arithmetic of the epilogue and of the stagers stays live across the whole tile -- 171 -> 256 VGPRs + 48
+  // spilled when the loop was first wrapped around the kernel.
+  const int tid0 = threadIdx.x;
+  int tid = tid0, lane = tid & 63, wid = tid >> 6;
+  int wm = wid >> 1, wn = wid & 1, l31 = lane & 31, h = lane >> 5;
   const bool pool = p.pmax != nullptr, store_y = p.y != nullptr;
-
-  // ---- the activated input panel, once: all KT tiles' loads in flight, then transform + round + store ----
-  {
-    LA la{p.a, p.K, p.rows_per_frustum};
-    SA sa;
-    sa.init(la, row0, tid);
-    sa.template fetch<0>(la, 0, tid);
-    if constexpr (KT > 1) sa.template fetch<1>(la, BKH, tid);
-    if constexpr (KT > 2) { sa.template fetch<2>(la, 2 * BKH, tid); sa.template fetch<3>(la, 3 * BKH, tid); }
-    sa.template store<0>(la, panel, tid);
-    if constexpr (KT > 1) sa.template store<1>(la, panel + A_ELEMS, tid);
-    if constexpr (KT > 2) { sa.template store<2>(la, panel + 2 * A_ELEMS, tid); sa.template store<3>(la, panel + 3 * A_ELEMS, tid); }
-  }
+  // Round 3: the workgroup is PERSISTENT over row tiles slot, slot + G, slot + 2 G, ... (G = gridDim.x, two workgroups per CU) and
+  // every global load is requested one phase ahead of its use.  A phase trace of the one-tile-per-workgroup form (tools/trace_fwd_res.py,
+  // 128 -> 128 at M = 262144) showed a tile as a chain of exposed latencies: 3.0 us until the panel is staged, 3.1 us until the first
+  // weight tile is in LDS, 1.3 us of MFMAs, 3.4 us of epilogue that starts with the bias load -- 12 us per tile, two tiles per CU at a
+  // time.  vmcnt retires IN ORDER (loads and stores alike on gfx9), so the order of issue is what makes a prefetch a prefetch:
+  //   * the next row tile's panel is requested right behind the LAST weight-tile fetch of the current row tile (nothing younger is
+  //     waited for until the next row tile's panel store);
+  //   * the first weight tile and the bias / row-bias terms of the next column tile (or of the next row tile's first column tile)
+  //     are requested AHEAD of the current tile's y stores, so waiting for them does not wait for the stores.
+  const int tiles_m = p.M / 128, G = gridDim.x;
+  LA la{p.a, p.K, p.rows_per_frustum};
+  SA sa;
+  // KT <= 2 (K <= 128): the next panel's raw chunks (16 VGPRs per k-tile) travel in registers across the current tile's column
+  // tiles; its per-channel coefficients (another 16 per k-tile) are requested late, with the next weight tile -- both held across the
+  // epilogue would spill.  KT = 4 (off by default): no prefetch, the panel is requested at the top of its tile.
+  constexpr bool PREF = KT <= 2;
+  auto fetch_panel = [&](int t_m) {
+    sa.init(la, t_m * 128, tid);
+    sa.template fetch_raw<0>(la, 0, tid);
+    if constexpr (KT > 1) sa.template fetch_raw<1>(la, BKH, tid);
+    if constexpr (KT > 2) { sa.template fetch_raw<2>(la, 2 * BKH, tid); sa.template fetch_raw<3>(la, 3 * BKH, tid); }
+  };
+  auto fetch_panel_coefs = [&]() {
+    sa.template fetch_coefs<0>(la, 0, tid);
+    if constexpr (KT > 1) sa.template fetch_coefs<1>(la, BKH, tid);
+    if constexpr (KT > 2) { sa.template fetch_coefs<2>(la, 2 * BKH, tid); sa.template fetch_coefs<3>(la, 3 * BKH, tid); }
+  };
+  WL lb{p.w, p.N, p.K, p.N};
+  SB sb;
+  const int n_tiles = p.N / BN;
+  float addv[TN];                           // bias (+ conv6's per-frustum row bias) of this lane's columns in the current column tile
+  auto fetch_w0 = [&](int c0, int bb) {
+    sb.init(lb, c0, tid);
+    sb.template fetch<0>(lb, 0, tid);
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = c0 + wn * (BN / 2) + tn * 32 + l31;
+      float add = p.bias ? p.bias[col] : 0.f;
+      if (p.rowbias) add += p.rowbias[(size_t)bb * p.N + col];
+      addv[tn] = add;
+    }
+  };
+  int tile_m = xcd_remap(blockIdx.x, G);
+  T3D_TRACE_MARK8(0);
+  if constexpr (PREF) { fetch_panel(tile_m); fetch_panel_coefs(); }
+  fetch_w0(0, (tile_m * 128) / p.rows_per_frustum);
+#pragma unroll 1
+ for (; tile_m < tiles_m; tile_m += G) {
+  const bool tr_first = tile_m < G;
+  tid = tid0;
+  asm volatile("" : "+v"(tid));
+  lane = tid & 63; wid = tid >> 6; wm = wid >> 1; wn = wid & 1; l31 = lane & 31; h = lane >> 5;
+  const int row0 = tile_m * 128;
+  const int b = row0 / p.rows_per_frustum;
+  // ---- the activated input panel, once per row tile: transform + round + store (the previous tile's MFMAs have left the panel:
+  // its k-loop ends with a barrier) ----
+  if constexpr (!PREF) { fetch_panel(tile_m); fetch_panel_coefs(); }
+  sa.template store<0>(la, panel, tid);
+  if constexpr (KT > 1) sa.template store<1>(la, panel + A_ELEMS, tid);
+  if constexpr (KT > 2) { sa.template store<2>(la, panel + 2 * A_ELEMS, tid); sa.template store<3>(la, panel + 3 * A_ELEMS, tid); }
+  if (tr_first) T3D_TRACE_MARK8(1);
   unsigned keepbits = 0xffffffffu;          // keep flags of this lane's 32 rows (the same rows for every column tile)
   if (pool && p.rowmask) {
     keepbits = 0u;
@@ -1066,68 +1177,80 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd_res(const t3d_po
   bf16_t* ytile = reinterpret_cast<bf16_t*>(red + 12 * BN);
   bf16_t* yg = reinterpret_cast<bf16_t*>(p.y);
 
-  WL lb{p.w, p.N, p.K, p.N};
-  SB sb;
-  const int n_tiles = p.N / BN;
-  for (int nt = 0; nt < n_tiles; ++nt) {
+  // Prefetches are UNCONDITIONAL on clamped indices (a conditional one keeps the stale registers alive through the other arm: the
+  // raw chunks and coefficients of the panel stayed live across every column tile, 256 VGPRs + 38 spilled): the last column tile
+  // is its own copy of the body (LAST), and a workgroup without a next row tile re-requests its own tile (L2 hits).
+  const int tile_nx = tile_m + G < tiles_m ? tile_m + G : tile_m;
+  auto col_tile = [&](const int nt, auto last_tag) {
+    constexpr bool LAST = decltype(last_tag)::value;
     const int col0 = nt * BN;
-    sb.init(lb, col0, tid);
-    sb.template fetch<0>(lb, 0, tid);
+    constexpr bool pf_panel = PREF && LAST;      // behind this column tile's last weight fetch
     f32x16 acc[TM][TN];
     zero_acc<TM, TN>(acc);
     __syncthreads();                          // the panel is complete / the previous tile's epilogue has left the ring
-    sb.template store<0>(lb, bst, tid);
+    sb.template store<0>(lb, bst, tid);       // (requested one column tile ago: fetch_w0)
     if constexpr (KT > 1) sb.template fetch<0>(lb, BKH, tid);
+    if constexpr (KT <= 2 && pf_panel) fetch_panel(tile_nx);
     __syncthreads();
+    if (tr_first && nt == 0) T3D_TRACE_MARK8(2);
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
       if (t + 1 < KT) {                       // the next weight tile goes into the other stage first, then its registers are refilled
         sb.template store<0>(lb, bst + ((t + 1) & 1) * B_ELEMS, tid);
-        if (t + 2 < KT) sb.template fetch<0>(lb, (t + 2) * BKH, tid);
+        if (t + 2 < KT) {
+          sb.template fetch<0>(lb, (t + 2) * BKH, tid);
+          if constexpr (pf_panel) { if (t + 2 == KT - 1) fetch_panel(tile_nx); }
+        }
       }
       mma_steps_h<TM, TN, true, 128, false, BN, 0, ST>(panel + t * A_ELEMS, bst + (t & 1) * B_ELEMS, wm * 64, wn * (BN / 2), acc, lane,
                                                        [](int) {});
       __syncthreads();
     }
+    if (tr_first && nt == 0) T3D_TRACE_MARK8(3);
     // ---- epilogue of the column tile (the generic kernel's, bf16 form) ----
     float csum[TN], csq[TN], cmax[TN], cmin[TN];
     int amax[TN], amin[TN];
+    // `store_y` and `pool` are compile-time inside the element loop: as run-time flags hipcc turned each into a BRANCH PER ELEMENT
+    // (s_cbranch around every ds_write_b16 and around every max / min update: the 3.3 us "epilogue math" of the phase trace).
+    auto epi = [&](auto sy_tag, auto pl_tag) {
+      constexpr bool SY = decltype(sy_tag)::value, PL = decltype(pl_tag)::value;
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      const int col = col0 + wn * (BN / 2) + tn * 32 + l31;
-      float add = p.bias ? p.bias[col] : 0.f;
-      if (p.rowbias) add += p.rowbias[(size_t)b * p.N + col];
-      float s_ = 0.f, ss = 0.f, mx = -INFINITY, mn = INFINITY;
-      int ax = -1, an = -1;
+      for (int tn = 0; tn < TN; ++tn) {
+        const float add = addv[tn];
+        float s_ = 0.f, ss = 0.f, mx = -INFINITY, mn = INFINITY;
+        int ax = -1, an = -1;
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm) {
+        for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = store_y ? Elem<bf16_t>::rnd(acc[tm][tn][r] + add) : acc[tm][tn][r] + add;
-          if (store_y) ytile[(wm * 64 + 4 * h + tm * 32 + (r & 3) + 8 * (r >> 2)) * YLD + wn * (BN / 2) + tn * 32 + l31] = (bf16_t)v;
-          s_ += v;
-          ss = fmaf(v, v, ss);
-          if (pool) {
-            const bool keep = (keepbits >> (tm * 16 + r)) & 1u;
-            const int rin = rin_base + tm * 32 + (r & 3) + 8 * (r >> 2);
-            const bool up = keep & (v > mx), dn = keep & (v < mn);
-            mx = up ? v : mx;
-            ax = up ? rin : ax;
-            mn = dn ? v : mn;
-            an = dn ? rin : an;
+          for (int r = 0; r < 16; ++r) {
+            const float v = SY ? Elem<bf16_t>::rnd(acc[tm][tn][r] + add) : acc[tm][tn][r] + add;
+            if constexpr (SY) ytile[(wm * 64 + 4 * h + tm * 32 + (r & 3) + 8 * (r >> 2)) * YLD + wn * (BN / 2) + tn * 32 + l31] = (bf16_t)v;
+            s_ += v;
+            ss = fmaf(v, v, ss);
+            if constexpr (PL) {
+              const bool keep = (keepbits >> (tm * 16 + r)) & 1u;
+              const int rin = rin_base + tm * 32 + (r & 3) + 8 * (r >> 2);
+              const bool up = keep & (v > mx), dn = keep & (v < mn);
+              mx = up ? v : mx;
+              ax = up ? rin : ax;
+              mn = dn ? v : mn;
+              an = dn ? rin : an;
+            }
           }
         }
+        s_ += __shfl_xor(s_, 32, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        if constexpr (PL) {
+          const float omx = __shfl_xor(mx, 32, 64), omn = __shfl_xor(mn, 32, 64);
+          const int oax = __shfl_xor(ax, 32, 64), oan = __shfl_xor(an, 32, 64);
+          if (oax >= 0 && (omx > mx || ax < 0 || (omx == mx && oax < ax))) { mx = omx; ax = oax; }
+          if (oan >= 0 && (omn < mn || an < 0 || (omn == mn && oan < an))) { mn = omn; an = oan; }
+        }
+        csum[tn] = s_; csq[tn] = ss; cmax[tn] = mx; cmin[tn] = mn; amax[tn] = ax; amin[tn] = an;
       }
-      s_ += __shfl_xor(s_, 32, 64);
-      ss += __shfl_xor(ss, 32, 64);
-      if (pool) {
-        const float omx = __shfl_xor(mx, 32, 64), omn = __shfl_xor(mn, 32, 64);
-        const int oax = __shfl_xor(ax, 32, 64), oan = __shfl_xor(an, 32, 64);
-        if (oax >= 0 && (omx > mx || ax < 0 || (omx == mx && oax < ax))) { mx = omx; ax = oax; }
-        if (oan >= 0 && (omn < mn || an < 0 || (omn == mn && oan < an))) { mn = omn; an = oan; }
-      }
-      csum[tn] = s_; csq[tn] = ss; cmax[tn] = mx; cmin[tn] = mn; amax[tn] = ax; amin[tn] = an;
-    }
+    };
+    if (store_y) { if (pool) epi(std::true_type{}, std::true_type{}); else epi(std::true_type{}, std::false_type{}); }
+    else { if (pool) epi(std::false_type{}, std::true_type{}); else epi(std::false_type{}, std::false_type{}); }
     if (h == 0) {                             // (the k-loop's last barrier has freed the ring: `red` may be written)
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
@@ -1142,6 +1265,7 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd_res(const t3d_po
         }
       }
     }
+    if (tr_first && nt == 0) T3D_TRACE_MARK8(4);
     __syncthreads();
     if (tid < BN) {
       const int c = tid;
@@ -1158,6 +1282,14 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd_res(const t3d_po
         p.pmax[o] = mx; p.pmin[o] = mn; p.pamax[o] = ax; p.pamin[o] = an;
       }
     }
+    if (tr_first && nt == 0) T3D_TRACE_MARK8(5);
+    // the next column tile's (or the next row tile's first) weight tile and additive terms, AHEAD of the y stores
+    if constexpr (LAST) {
+      fetch_w0(0, (tile_nx * 128) / p.rows_per_frustum);
+      if constexpr (PREF) fetch_panel_coefs();
+    } else {
+      fetch_w0(col0 + BN, b);
+    }
     if (store_y) {
 #pragma unroll
       for (int i = 0; i < 128 * CPR / NT; ++i) {
@@ -1165,7 +1297,13 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd_res(const t3d_po
         *reinterpret_cast<bf16x8*>(yg + (size_t)(row0 + row) * p.N + col0 + ch * 8) = *reinterpret_cast<const bf16x8*>(ytile + row * YLD + ch * 8);
       }
     }
-  }
+    if (tr_first && nt == 0) T3D_TRACE_MARK8(6);
+  };
+#pragma unroll 1
+  for (int nt = 0; nt < n_tiles - 1; ++nt) col_tile(nt, std::false_type{});
+  col_tile(n_tiles - 1, std::true_type{});
+ }
+  T3D_TRACE_MARK8(7);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1625,6 +1763,24 @@ __device__ __forceinline__ void wgrad_body(const LA& la, const LB& lb, float* sl
                                                                   wm * (BMK / 2), wn * (BN / 2), acc, tid);
   const int l31 = lane & 31, h = lane >> 5;
   float* slab = slabs + (size_t)split * K * N;
+  if (k0 + BMK <= K) {
+    // the tile lies inside the matrix (every layer but the K <= 4 first ones): no bounds test per element -- as a test it was an
+    // exec-mask BRANCH and a 64-bit multiply-add per stored element (tools/kernel_branches.py) -- and one 32-bit offset add per store
+    // on top of the uniform slab base (a slab is K x N <= 2^21 floats, t3d_wgrad_plan)
+    char* const sbase = reinterpret_cast<char*>(slab);
+    const unsigned n4 = (unsigned)N * 4u;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      unsigned boff = ((unsigned)(k0 + wm * (BMK / 2) + 4 * h) * (unsigned)N + (unsigned)(n0 + wn * (BN / 2) + tn * 32 + l31)) * 4u;
+      asm volatile("" : "+v"(boff));
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          *reinterpret_cast<float*>(sbase + (boff + (unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) * n4)) = acc[tm][tn][r];
+    }
+    return;
+  }
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int col = n0 + wn * (BN / 2) + tn * 32 + l31;
@@ -3067,18 +3223,19 @@ extern "C" int t3d_pointmlp_fwd_r(const t3d_pointmlp_fwd_args* a, const t3d_ride
     // activation-resident kernel: the input panel is transformed once for all column tiles (T3D_FWD_RES=0: the generic kernel)
     static const bool use_res = []() { const char* e = getenv("T3D_FWD_RES"); return !(e && e[0] == '0'); }();
     // K = 256 (a 74 KB panel: one workgroup per CU) measured SLOWER than the generic kernel (256 -> 512: 257 vs 194 us, 256 -> 128:
-    // 82 vs 61 us at M = 262144); K <= 128 keeps two workgroups per CU: 128 -> 1024 272 -> 219 us, 64 -> 512 144 -> 107 us,
-    // 128 -> 256 73 -> 67 us, the small layers unchanged.  T3D_FWD_RES=2 forces K = 256 on.
-    static const bool res_k256 = []() { const char* e = getenv("T3D_FWD_RES"); return e && e[0] == '2'; }();
-    if (use_res && xh && !sub && (a->K == 64 || a->K == 128 || (a->K == 256 && res_k256))) {
-      const dim3 grid(tiles_m);
+    // 82 vs 61 us at M = 262144) and its instantiation was dropped in round 3; K <= 128 keeps two workgroups per CU: 128 -> 1024
+    // 272 -> 219 us, 64 -> 512 144 -> 107 us, 128 -> 256 73 -> 67 us, the small layers unchanged (round 2; round 3: see the kernel).
+    if (use_res && xh && !sub && (a->K == 64 || a->K == 128)) {
+      // persistent workgroups (two per CU) walking the row tiles; T3D_FWD_RES_WGS=0: one workgroup per tile as before
+      static const int res_wgs = []() { const char* e = getenv("T3D_FWD_RES_WGS"); return e ? atoi(e) : 512; }();
+      const dim3 grid(res_wgs > 0 && tiles_m > res_wgs ? res_wgs : tiles_m);
 #define T3D_FWD_RES(BN_, KT_)                                                                                    \
   do {                                                                                                          \
     constexpr size_t lds = ((size_t)KT_ * 128 * LDRH + 2 * (size_t)BKH * (BN_ + 32)) * 2;                        \
     launch_lds(k_pointmlp_fwd_res<BN_, KT_>, grid, lds, s, *a);                                                 \
   } while (0)
-      if (a->N % 128 == 0) { if (a->K == 64) T3D_FWD_RES(128, 1); else if (a->K == 128) T3D_FWD_RES(128, 2); else T3D_FWD_RES(128, 4); }
-      else { if (a->K == 64) T3D_FWD_RES(64, 1); else if (a->K == 128) T3D_FWD_RES(64, 2); else T3D_FWD_RES(64, 4); }
+      if (a->N % 128 == 0) { if (a->K == 64) T3D_FWD_RES(128, 1); else T3D_FWD_RES(128, 2); }
+      else { if (a->K == 64) T3D_FWD_RES(64, 1); else T3D_FWD_RES(64, 2); }
 #undef T3D_FWD_RES
       T3D_CHECK_LAUNCH();
       return T3D_OK;
