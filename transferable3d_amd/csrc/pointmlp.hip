@@ -894,17 +894,18 @@ __device__ __forceinline__ void fwd_body(const t3d_pointmlp_fwd_args& p, float* 
 
   // the epilogue's per-column additive terms (bias, conv6's per-frustum row bias), requested BEFORE the main loop: loaded at the
   // head of the epilogue they were a dependent L2 round trip in front of every launch's stores (round 3, tools/trace_fwd_res.py)
-  float addv[TN];
+  // (the two terms stay apart until the epilogue adds them: summed here, the sum would wait for both loads at the kernel's head)
+  float addv[TN], addr[TN];
   {
     const int l31_ = lane & 31, b_ = row0 / p.rows_per_frustum;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
       const int col = col0 + wn * (BN / 2) + tn * 32 + l31_;
-      float add = p.bias ? p.bias[col] : 0.f;
-      if (p.rowbias) add += p.rowbias[(size_t)b_ * p.N + col];
-      addv[tn] = add;
+      addv[tn] = p.bias ? p.bias[col] : 0.f;
+      addr[tn] = p.rowbias ? p.rowbias[(size_t)b_ * p.N + col] : 0.f;
     }
   }
+  const bool has_rowbias = p.rowbias != nullptr;
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
   const int kred = (p.K + PR::RED - 1) / PR::RED * PR::RED;
@@ -957,7 +958,7 @@ __device__ __forceinline__ void fwd_body(const t3d_pointmlp_fwd_args& p, float* 
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
       const int col = col0 + wn * (BN / 2) + tn * 32 + l31;
-      const float add = addv[tn];
+      const float add = has_rowbias ? addv[tn] + addr[tn] : addv[tn];
       float s = 0.f, ss = 0.f, mx = -INFINITY, mn = INFINITY;
       int ax = -1, an = -1;
       // 32-bit byte offsets (M*N < 2^30 is checked by the launcher): one VGPR add per store on top of the uniform base; the
@@ -1131,16 +1132,16 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd_res(const t3d_po
   WL lb{p.w, p.N, p.K, p.N};
   SB sb;
   const int n_tiles = p.N / BN;
-  float addv[TN];                           // bias (+ conv6's per-frustum row bias) of this lane's columns in the current column tile
+  float addv[TN], addr[TN];                 // bias and conv6's per-frustum row bias of this lane's columns in the current column tile
+  const bool has_rowbias = p.rowbias != nullptr;          // (added in the epilogue: summed at the load they would be waited for there)
   auto fetch_w0 = [&](int c0, int bb) {
     sb.init(lb, c0, tid);
     sb.template fetch<0>(lb, 0, tid);
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
       const int col = c0 + wn * (BN / 2) + tn * 32 + l31;
-      float add = p.bias ? p.bias[col] : 0.f;
-      if (p.rowbias) add += p.rowbias[(size_t)bb * p.N + col];
-      addv[tn] = add;
+      addv[tn] = p.bias ? p.bias[col] : 0.f;
+      addr[tn] = has_rowbias ? p.rowbias[(size_t)bb * p.N + col] : 0.f;
     }
   };
   int tile_m = xcd_remap(blockIdx.x, G);
@@ -1216,7 +1217,7 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd_res(const t3d_po
       constexpr bool SY = decltype(sy_tag)::value, PL = decltype(pl_tag)::value;
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
-        const float add = addv[tn];
+        const float add = has_rowbias ? addv[tn] + addr[tn] : addv[tn];
         float s_ = 0.f, ss = 0.f, mx = -INFINITY, mn = INFINITY;
         int ax = -1, an = -1;
 #pragma unroll
@@ -1451,7 +1452,14 @@ __device__ __forceinline__ void dgrad_epilogue_body(const DgradEpilogue& p, f32x
     const int col = col0 + wn * (BN / 2) + tn * 32 + l31;
     const float psc = MASK ? p.prev_scale[col] : 0.f, psh = MASK ? p.prev_shift[col] : 0.f;
     const float cc = p.colconst ? p.colconst[col] : 0.f;
-    const unsigned off0 = (unsigned)(row0 + wm * 64 + 4 * h) * K + (unsigned)col;
+    // prev_y, add_in and out share ONE 32-bit byte offset per element on top of their uniform bases (M*K < 2^30: launcher); as
+    // element indices into three pointers hipcc formed three 64-bit addresses per element (v_lshlrev_b64 + v_lshl_add_u64 each)
+    unsigned boff0 = ((unsigned)(row0 + wm * 64 + 4 * h) * K + (unsigned)col) * 4u;
+    asm volatile("" : "+v"(boff0));
+    const unsigned k4 = K * 4u;
+    const char* const pyb = reinterpret_cast<const char*>(p.prev_y);
+    const char* const adb = reinterpret_cast<const char*>(p.add_in);
+    char* const outb = reinterpret_cast<char*>(p.out);
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
@@ -1462,26 +1470,26 @@ __device__ __forceinline__ void dgrad_epilogue_body(const DgradEpilogue& p, f32x
 #pragma unroll
         for (int e = 0; e < EB; ++e) {
           const int r = r0 + e;
-          const unsigned o = off0 + (unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) * K;
+          const unsigned o = boff0 + (unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) * k4;
 #ifdef T3D_ABL_DG_NOLOAD
           yp[e] = psc + (float)r;
 #else
-          yp[e] = MASK ? p.prev_y[o] : 0.f;
+          yp[e] = MASK ? *reinterpret_cast<const float*>(pyb + o) : 0.f;
 #endif
-          if (ADD == 2) ad[e] = ((live >> (tm * 16 + r)) & 1u) ? p.add_in[o] : 0.f;
-          else ad[e] = ADD ? p.add_in[o] : 0.f;
+          if (ADD == 2) ad[e] = ((live >> (tm * 16 + r)) & 1u) ? *reinterpret_cast<const float*>(adb + o) : 0.f;
+          else ad[e] = ADD ? *reinterpret_cast<const float*>(adb + o) : 0.f;
         }
 #pragma unroll
         for (int e = 0; e < EB; ++e) {
           const int r = r0 + e;
-          const unsigned o = off0 + (unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) * K;
+          const unsigned o = boff0 + (unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) * k4;
           float v = acc[tm][tn][r] + cc + ad[e];
           if (MASK) {
             if (!(fmaf(yp[e], psc, psh) > 0.f)) v = 0.f;
             s1 += v;
             s2 = fmaf(v, yp[e], s2);
           }
-          p.out[o] = v;
+          *reinterpret_cast<float*>(outb + o) = v;
         }
       }
     }
