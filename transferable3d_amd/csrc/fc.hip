@@ -14,9 +14,9 @@
 namespace {
 
 template <int RBT>
-__global__ __launch_bounds__(NTH) void k_fc_fwd(const t3d_fc_fwd_args p) {
+__global__ __launch_bounds__(NTH) void k_fc_fwd(const t3d_fc_fwd_args p, const int cb) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  fc_fwd_body<RBT>(p, sm, blockIdx.x);
+  fc_fwd_body<RBT>(p, sm, blockIdx.x, cb);
 }
 template <int RBT>
 __global__ __launch_bounds__(NTH) void k_fc_bwd(const t3d_fc_bwd_args p) {
@@ -38,8 +38,13 @@ extern "C" int t3d_fc_fwd(const t3d_fc_fwd_args* a, t3d_stream_t stream) {
   if (a->gamma && (!a->beta || !a->moving_mean || !a->moving_var || !a->mean || !a->invstd || !a->y)) return T3D_ERR_ARG;
   if (a->gamma && a->is_training && !a->decay) return T3D_ERR_ARG;
   if (a->B <= 0 || a->B > 32 * MAXRB || a->N <= 0 || a->K <= 0) return T3D_ERR_SHAPE;
-  if (a->B <= 32) T3D_LAUNCH(k_fc_fwd<1>, dim3((a->N + CB - 1) / CB), dim3(NTH), fc_lds_bytes(32), static_cast<hipStream_t>(stream), *a);
-  else T3D_LAUNCH(k_fc_fwd<MAXRB>, dim3((a->N + CB - 1) / CB), dim3(NTH), fc_lds_bytes(128), static_cast<hipStream_t>(stream), *a);
+  // columns per workgroup: 32.  T3D_FC_CB=16 / 8 cuts a wide layer with a long reduction into narrower column runs (the
+  // 1024 -> 512 row-bias layer of conv6 then runs on 32 / 64 CUs instead of 16) -- measured on MI355X: 12.4 / 12.3 / 12.6 us per launch
+  // at 32 / 16 / 8 columns, step 1.4489 / 1.4480 / 1.4476 ms: the launch is a latency chain, not a bandwidth problem per CU; off.
+  static const int narrow = []() { const char* e = getenv("T3D_FC_CB"); const int v = e ? atoi(e) : 32; return (v == 8 || v == 16 || v == 32) ? v : 32; }();
+  const int cb = (a->w && (long)a->K * a->N >= (1L << 18) && a->N >= 8 * narrow) ? narrow : CB;
+  if (a->B <= 32) T3D_LAUNCH(k_fc_fwd<1>, dim3((a->N + cb - 1) / cb), dim3(NTH), fc_lds_bytes(32), static_cast<hipStream_t>(stream), *a, cb);
+  else T3D_LAUNCH(k_fc_fwd<MAXRB>, dim3((a->N + cb - 1) / cb), dim3(NTH), fc_lds_bytes(128), static_cast<hipStream_t>(stream), *a, cb);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

@@ -41,16 +41,24 @@ struct RowSrc {              // [in | in2] row-concatenated input, B valid rows
     const float v = base[off];
     return valid ? v : 0.f;
   }
-  // 4 consecutive reduction elements of one row
-  __device__ __forceinline__ void load4(int r, int k, float (&v)[4]) const {
-    if (r >= B) { v[0] = v[1] = v[2] = v[3] = 0.f; return; }
-    if (k + 3 < K && (ld_in & 3) == 0) {
-      const float4 t = *reinterpret_cast<const float4*>(in + (size_t)r * ld_in + k);
-      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    } else {
+  // 4 consecutive reduction elements of one row: load4_raw only issues loads (clamped addresses), valid() says without touching
+  // memory which values count; wave_gemm masks where it consumes (see there).
+  __device__ __forceinline__ void load4_raw(int r, int k, float (&v)[4]) const {      // four clamped scalar loads, nothing else
+    const int rc = min(r, B - 1);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = at(r, k + e);
+    for (int e = 0; e < 4; ++e) {
+      const int ke = k + e;
+      const bool first = ke < K || in2 == nullptr;
+      const float* base = first ? in : in2;
+      const size_t off = first ? (size_t)rc * ld_in + min(ke, K - 1) : (size_t)rc * ld_in2 + min(ke - K, K2 - 1);
+      v[e] = base[off];
     }
+  }
+  __device__ __forceinline__ bool valid(int r, int k) const { return r < B && k < K + K2; }
+  __device__ __forceinline__ void load4(int r, int k, float (&v)[4]) const {
+    load4_raw(r, k, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = valid(r, k + e) ? v[e] : 0.f;
   }
 };
 
@@ -64,8 +72,9 @@ struct RowSrc {              // [in | in2] row-concatenated input, B valid rows
 // (GIF_ = 0: the default batch; the 256-thread rider form asks for 8 -- it only changes how many loads are in flight, not the sums)
 template <bool WT, int RBT, int GIF_ = 0>
 __device__ __forceinline__ void wave_gemm(f32x16 (&acc)[RBT], const RowSrc& src, const float* __restrict__ w, int ldw,
-                                          int Kred, int c0, int ncols, int wave, int lane) {
+                                          int Kred, int c0, int ncols, int wave_, int lane) {
   constexpr int GIF = GIF_ > 0 ? GIF_ : (RBT == 1 ? 16 : 4);
+  const int wave = __builtin_amdgcn_readfirstlane(wave_);      // provably wave-uniform: the k-group bounds below are scalar branches
   const int l31 = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int rb = 0; rb < RBT; ++rb)
@@ -73,43 +82,77 @@ __device__ __forceinline__ void wave_gemm(f32x16 (&acc)[RBT], const RowSrc& src,
     for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
   const int ngroups = (Kred + 7) >> 3;
   const bool cok = l31 < ncols;
+  const int cc = c0 + min(l31, ncols - 1);
   // every wave owns a CONTIGUOUS run of k-groups: the four loads that share a 128-byte line of an input row (32 reduction
   // elements) are then issued back to back by one wave and hit the line while it is in flight; with the groups dealt out round
   // robin over the waves each line was fetched by four different waves (load + MFMA phase of the 512x512 layer 7.2 -> 6.2 us,
   // tools/trace_fc.py)
   const int gpw = (ngroups + NW - 1) / NW, gbeg = wave * gpw, gend = min(gbeg + gpw, ngroups);
-  for (int g0 = gbeg; g0 < gend; g0 += GIF) {
-    float a[GIF][RBT][4], b[GIF][4];
+  // Round 3: loads and masks apart, and the 16-byte and the scalar load forms in SEPARATE loops.  The former per-lane form (row
+  // test, vector-or-scalar test, zero fill, each with its select right behind the load) compiled into exec-masked regions with an
+  // `s_waitcnt vmcnt(0)` each: the "16 k-groups in flight" were 16 SERIAL round trips per wave in every FC kernel
+  // (tools/kernel_branches.py: 260 branches in k_fc_fwd<1>).  A wave-uniform branch between the two forms INSIDE one loop is no
+  // better: hipcc merges the arms into four dword loads on selected addresses.  So: groups that lie entirely inside the first input
+  // block (and the weight rows, for the transposed form) take the vector loop -- nothing but 16-byte loads on clamped indices, then
+  // masks + MFMAs; the few groups behind them (the one-hot / norm_box2D block, a ragged end) take the scalar loop.
+  const bool vec_ok = (src.ld_in & 3) == 0 && (!WT || (ldw & 3) == 0);
+  const int gfull = vec_ok ? ((WT ? min(src.K, Kred) : src.K) >> 3) : 0;      // groups [0, gfull) have k + 7 < K
+  const int gv_end = min(gend, gfull);
+  constexpr int GT = 2;                       // k-groups per batch of the scalar loop (it sees the one-hot block or a ragged end: 1-2 groups)
+  auto mma_batch = [&](const int g0, const int glim, auto& a, auto& b, auto nb_tag) {
+    constexpr int NB = decltype(nb_tag)::value;
 #pragma unroll
-    for (int u = 0; u < GIF; ++u) {
-      const int g = g0 + u;
-      const int k = 8 * g + 4 * h;
-      if (g < gend) {                         // wave-uniform: groups past the end issue nothing
+    for (int u = 0; u < NB; ++u) {
+      if (g0 + u < glim) {                    // scalar branch
+        const int k = 8 * (g0 + u) + 4 * h;
 #pragma unroll
-        for (int rb = 0; rb < RBT; ++rb) src.load4(rb * 32 + l31, k, a[u][rb]);
-        if (!WT) {
+        for (int i = 0; i < 4; ++i) {
+          const float bv = (cok && k + i < Kred) ? b[u][i] : 0.f;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) b[u][i] = (cok && k + i < Kred) ? w[(size_t)(k + i) * ldw + c0 + l31] : 0.f;
-        } else {
-          if (cok && k + 3 < Kred && (ldw & 3) == 0) {
-            const float4 t = *reinterpret_cast<const float4*>(w + (size_t)(c0 + l31) * ldw + k);
-            b[u][0] = t.x; b[u][1] = t.y; b[u][2] = t.z; b[u][3] = t.w;
-          } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) b[u][i] = (cok && k + i < Kred) ? w[(size_t)(c0 + l31) * ldw + k + i] : 0.f;
+          for (int rb = 0; rb < RBT; ++rb) {
+            const float av = src.valid(rb * 32 + l31, k + i) ? a[u][rb][i] : 0.f;
+            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[rb], 0, 0, 0);
           }
         }
       }
     }
+  };
+  for (int g0 = gbeg; g0 < gv_end; g0 += GIF) {
+    float a[GIF][RBT][4], b[GIF][4];
 #pragma unroll
     for (int u = 0; u < GIF; ++u) {
-      if (g0 + u < gend) {
+      if (g0 + u < gv_end) {                  // scalar branch with nothing but loads inside (a group past the run issues nothing)
+        const int k = 8 * (g0 + u) + 4 * h;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int rb = 0; rb < RBT; ++rb) {
+          const float4 t = *reinterpret_cast<const float4*>(src.in + (size_t)min(rb * 32 + l31, src.B - 1) * src.ld_in + k);
+          a[u][rb][0] = t.x; a[u][rb][1] = t.y; a[u][rb][2] = t.z; a[u][rb][3] = t.w;
+        }
+        if (!WT) {
 #pragma unroll
-          for (int rb = 0; rb < RBT; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][rb][i], b[u][i], acc[rb], 0, 0, 0);
+          for (int i = 0; i < 4; ++i) b[u][i] = w[(size_t)(k + i) * ldw + cc];
+        } else {
+          const float4 t = *reinterpret_cast<const float4*>(w + (size_t)cc * ldw + k);
+          b[u][0] = t.x; b[u][1] = t.y; b[u][2] = t.z; b[u][3] = t.w;
+        }
       }
     }
+    mma_batch(g0, gv_end, a, b, std::integral_constant<int, GIF>{});
+  }
+  for (int g0 = max(gbeg, gfull); g0 < gend; g0 += GT) {
+    float a[GT][RBT][4], b[GT][4];
+#pragma unroll
+    for (int u = 0; u < GT; ++u) {
+      if (g0 + u < gend) {                    // scalar branch; loads only inside
+        const int k = 8 * (g0 + u) + 4 * h;
+#pragma unroll
+        for (int rb = 0; rb < RBT; ++rb) src.load4_raw(rb * 32 + l31, k, a[u][rb]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          b[u][i] = WT ? w[(size_t)cc * ldw + min(k + i, Kred - 1)] : w[(size_t)min(k + i, Kred - 1) * ldw + cc];
+      }
+    }
+    mma_batch(g0, gend, a, b, std::integral_constant<int, GT>{});
   }
 }
 
@@ -184,13 +227,16 @@ __device__ __forceinline__ float act_bwd(float z, int act, float alpha) {
 }
 
 template <int RBT, int NWP = NW>
-__device__ __forceinline__ void fc_fwd_body(const t3d_fc_fwd_args& p, float* sm, const int bid) {
+__device__ __forceinline__ void fc_fwd_body(const t3d_fc_fwd_args& p, float* sm, const int bid, const int cb = CB) {
   constexpr int RB = RBT, NVAL = RBT * 32 / RG, V = NW / NWP, RGP = NWP * 2;
   const int tid = threadIdx.x, lane = tid & 63, pw = tid >> 6;
   const int col = tid & 31, rgp = tid >> 5;
-  const int c0 = bid * CB, c = c0 + col;
-  const int nvalid = min(CB, p.N - c0);
-  const bool cok = c < p.N;
+  // cb <= CB columns per workgroup (round 3): the batch statistics are per column, so a layer may be cut into narrower column
+  // runs and a wide layer spans more than N / 32 CUs (the 1024 -> 512 row-bias layer of conv6: 16 workgroups before); lanes past
+  // cb idle in the MFMA and in the epilogue.
+  const int c0 = bid * cb, c = c0 + col;
+  const int nvalid = min(cb, p.N - c0);
+  const bool cok = col < nvalid;
 
   FC_MARK(0);
   float y[V][NVAL];
