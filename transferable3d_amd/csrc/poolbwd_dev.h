@@ -131,16 +131,27 @@ __device__ __forceinline__ void pool_sparse_rows_body(const t3d_pool_sparse_rows
   for (int i0 = 0; i0 < cnt; i0 += SR_UNROLL) {
     float2 wv[SR_UNROLL];
     float g[SR_UNROLL];
-    int rr[SR_UNROLL];
+    int rr[SR_UNROLL], en[SR_UNROLL];
+    // Round 3: the batch's list entries are read FIRST, all of them, then the global loads go out, then the hit flags are stored.
+    // With the flag store between two list reads (it may alias the list as far as the compiler knows) every entry was an LDS
+    // round trip of its own in front of its loads -- 16 serial ds_read + wait per batch -- and the guarded dpool load an
+    // exec-masked region per hit.  Indices past the list's end repeat its last entry (valid addresses); their g is masked to 0.
+#pragma unroll
+    for (int u = 0; u < SR_UNROLL; ++u) en[u] = mine[min(i0 + u, cnt - 1)];
 #pragma unroll
     for (int u = 0; u < SR_UNROLL; ++u) {
-      const int e = mine[min(i0 + u, cnt - 1)];
-      const int n = e & 0xffff;
-      rr[u] = e >> 16;
-      hitrow[rr[u]] = 1;                // same value from every lane; rows of this wave only
-      g[u] = (i0 + u < cnt) ? p.dpool[(size_t)b * p.N + n] : 0.f;
+      const int n = en[u] & 0xffff;
+      rr[u] = en[u] >> 16;
+      g[u] = p.dpool[(size_t)b * p.N + n];
       wv[u] = *reinterpret_cast<const float2*>(p.wc + (size_t)n * p.K + kc0 + 2 * lane);
     }
+#pragma unroll
+    for (int u = 0; u < SR_UNROLL; ++u) {
+      hitrow[rr[u]] = 1;                // same value from every lane; rows of this wave only
+      g[u] = (i0 + u < cnt) ? g[u] : 0.f;
+    }
+    // (two hits per LDS round trip -- both rows read together, a same-row pair summed in registers behind a scalar branch -- is
+    // bit-identical and measured SLOWER: 26.4 / 19.6 vs 24.1 / 17.1 us for the box / seg layers' launches)
 #pragma unroll
     for (int u = 0; u < SR_UNROLL; ++u) {
       float2* t = reinterpret_cast<float2*>(tile + rr[u] * SR_KC + 2 * lane);
