@@ -260,9 +260,18 @@ __global__ __launch_bounds__(1024) void k_box_head_iou(const t3d_box_head_iou_ar
   p.iou2d[b] = i2;
 }
 
+// GL: the per-frustum gradient vector g[67] and the head outputs o[67] live in LDS (B <= 128).  Both are indexed by the label /
+// arg-max bins, i.e. dynamically: as private arrays they went to scratch (272 B per thread), every access a memory round trip in
+// a program that is one serial chain per frustum; an LDS access costs a quarter of that.  Row stride 67 (odd): conflict-free.
+template <bool GL>
 __global__ __launch_bounds__(1024) void k_strong_loss(const t3d_strong_loss_args p) {
   __shared__ float red[1024];
   __shared__ float s_norm;
+  __shared__ float g_lds[GL ? 128 * 67 : 1];
+  __shared__ float o_lds[GL ? 128 * 67 : 1];
+  if (GL) {          // the head outputs, staged coalesced
+    for (int f = threadIdx.x; f < p.B * 67; f += 1024) o_lds[f] = p.box[(size_t)(f / 67) * p.ld_box + f % 67];
+  }
   const int b = threadIdx.x;
   const bool ok = b < p.B;
   const float w3d = ok ? (float)(1 - p.is_data_2D[b]) : 0.f;
@@ -277,10 +286,11 @@ __global__ __launch_bounds__(1024) void k_strong_loss(const t3d_strong_loss_args
   const float norm = s_norm;
   float total = 0.f;
   if (ok) {
-    const float* o = p.box + (size_t)b * p.ld_box;
+    const float* o = GL ? o_lds + b * 67 : p.box + (size_t)b * p.ld_box;
     const t3d_strong_weights& W = p.wts;
     const float gs = w3d * norm;
-    float g[67];
+    float g_priv[GL ? 1 : 67];
+    float* g = GL ? g_lds + b * 67 : g_priv;
     for (int i = 0; i < 67; ++i) g[i] = 0.f;
     float gc[3] = {0.f, 0.f, 0.f}, gs1[3] = {0.f, 0.f, 0.f};
     const float s1[3] = {p.stage1_center[b * 3], p.stage1_center[b * 3 + 1], p.stage1_center[b * 3 + 2]};
@@ -391,7 +401,7 @@ __global__ __launch_bounds__(1024) void k_strong_loss(const t3d_strong_loss_args
   // the IoU summary of frustum f on thread 512 + f: a different wave than the loss of f, so the two serial chains overlap
   if (p.iou3d && p.B <= 512 && b >= 512 && b - 512 < p.B) {
     const int f = b - 512;
-    const float* o = p.box + (size_t)f * p.ld_box;
+    const float* o = GL ? o_lds + f * 67 : p.box + (size_t)f * p.ld_box;
     float cen[3], yc[3], ydr[3];
     for (int d = 0; d < 3; ++d) {
       cen[d] = o[d] + p.stage1_center[f * 3 + d];
@@ -479,7 +489,8 @@ extern "C" int t3d_strong_loss(const t3d_strong_loss_args* a, t3d_stream_t strea
     return T3D_ERR_ARG;
   if (a->B <= 0 || a->B > 1024) return T3D_ERR_SHAPE;
   if ((a->iou2d == nullptr) != (a->iou3d == nullptr)) return T3D_ERR_ARG;
-  T3D_LAUNCH(k_strong_loss, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), *a);
+  if (a->B <= 128) T3D_LAUNCH(k_strong_loss<true>, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), *a);
+  else T3D_LAUNCH(k_strong_loss<false>, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

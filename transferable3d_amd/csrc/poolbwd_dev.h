@@ -258,7 +258,8 @@ __device__ __forceinline__ void pool_wgrad_finish_body(const t3d_pool_wgrad_fini
         const bool ok = b < p.B;
         const size_t o = (size_t)min(b, p.B - 1) * p.N + n0 + f % FN;
         const int ai = p.argidx[o];
-        dps[f] = (ok && ai >= 0) ? p.dpool[o] : 0.f;
+        const float dpv = p.dpool[o];                    // unconditional (o is a valid address): in flight with argidx, not behind it
+        dps[f] = (ok && ai >= 0) ? dpv : 0.f;
         ais[f] = max(ai, 0);
       }
       __syncthreads();
