@@ -198,13 +198,24 @@ __device__ __forceinline__ void act_colsum_body(const t3d_act_colsum_args& p, fl
   const float floor_ = p.a.relu ? 0.f : -INFINITY;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   const size_t base = (size_t)(row0 + grp * rows) * p.a.ldx + p.a.coff + 4 * c4;       // element offset (fp32 or bf16 source)
-#pragma unroll 16
-  for (int r = 0; r < rows; ++r) {
-    const float4 x = Elem<XT>::widen(Elem<XT>::ld4(p.a.x, base + (size_t)r * p.a.ldx));
-    acc.x += fmaxf(fmaf(x.x, sc.x, sh.x), floor_);
-    acc.y += fmaxf(fmaf(x.y, sc.y, sh.y), floor_);
-    acc.z += fmaxf(fmaf(x.z, sc.z, sh.z), floor_);
-    acc.w += fmaxf(fmaf(x.w, sc.w, sh.w), floor_);
+  // Round 3: explicit batches of 16 loads (rows is 8 ... 64, a multiple of 8).  The `#pragma unroll 16` loop it replaces compiled
+  // into load -> s_waitcnt vmcnt(0) -> add, sixteen times over (one destination register quad re-used): 16-32 SERIAL round trips
+  // per workgroup inside every stage-1 launch.  Same sums in the same order.
+  constexpr int CSB = 16;
+  for (int r0 = 0; r0 < rows; r0 += CSB) {
+    typename Elem<XT>::V4 raw[CSB];
+#pragma unroll
+    for (int u = 0; u < CSB; ++u) raw[u] = Elem<XT>::ld4(p.a.x, base + (size_t)min(r0 + u, rows - 1) * p.a.ldx);
+#pragma unroll
+    for (int u = 0; u < CSB; ++u) {
+      if (r0 + u < rows) {                     // workgroup-uniform
+        const float4 x = Elem<XT>::widen(raw[u]);
+        acc.x += fmaxf(fmaf(x.x, sc.x, sh.x), floor_);
+        acc.y += fmaxf(fmaf(x.y, sc.y, sh.y), floor_);
+        acc.z += fmaxf(fmaf(x.z, sc.z, sh.z), floor_);
+        acc.w += fmaxf(fmaf(x.w, sc.w, sh.w), floor_);
+      }
+    }
   }
   red[tid] = acc;
   __syncthreads();
