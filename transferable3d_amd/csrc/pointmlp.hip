@@ -50,6 +50,23 @@ constexpr int NT = 256;
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
+// Keep flags of a lane's 32 accumulator rows (row = base + tm * 32 + (r & 3) + 8 * (r >> 2), bit tm * 16 + r) from a per-row mask:
+// eight 16-byte loads requested together, then the compares.  Written as 32 scalar loads OR-ed into one word, hipcc formed the
+// same eight loads but consumed each before requesting the next (one register quad, `s_waitcnt vmcnt(0)` eight times): eight
+// serial round trips in the prologue of every pooled forward (round 3, device assembly of k_pointmlp_fwd_pool).
+__device__ __forceinline__ unsigned keep_bits32(const float* __restrict__ rowmask, int base) {
+  float4 m[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) m[q] = *reinterpret_cast<const float4*>(rowmask + base + (q >> 2) * 32 + (q & 3) * 8);
+  unsigned bits = 0u;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const unsigned nib = (m[q].x != 0.f ? 1u : 0u) | (m[q].y != 0.f ? 2u : 0u) | (m[q].z != 0.f ? 4u : 0u) | (m[q].w != 0.f ? 8u : 0u);
+    bits |= nib << ((q >> 2) * 16 + (q & 3) * 4);
+  }
+  return bits;
+}
+
 // Diagnostic builds (-DT3D_TRACE, tools/trace_blocks.py): every workgroup records the 100 MHz wall clock at kernel entry,
 // after the main loop and at exit, plus its XCC / HW id, into a buffer installed with t3d_set_trace().
 #ifdef T3D_TRACE
@@ -939,12 +956,8 @@ __device__ __forceinline__ void fwd_body(const t3d_pointmlp_fwd_args& p, float* 
   // keep flags of this lane's 32 rows, loaded once (they were re-read per column group inside the compare chain)
   unsigned keepbits = 0xffffffffu;
   if (pool && p.rowmask) {
-    keepbits = 0u;
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        keepbits |= (p.rowmask[row0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] != 0.f ? 1u : 0u) << (tm * 16 + r);
+    static_assert(TM == 2, "keep_bits32 covers two 32-row blocks");
+    keepbits = keep_bits32(p.rowmask, row0 + wm * 64 + 4 * h);
   }
   const int rin_base = row0 - b * p.rows_per_frustum + wm * 64 + 4 * h;
   // `store_y` and `pool` are compile-time inside the element loop (round 3): as run-time flags hipcc compiled each into a BRANCH
@@ -1165,12 +1178,8 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd_res(const t3d_po
   if (tr_first) T3D_TRACE_MARK8(1);
   unsigned keepbits = 0xffffffffu;          // keep flags of this lane's 32 rows (the same rows for every column tile)
   if (pool && p.rowmask) {
-    keepbits = 0u;
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        keepbits |= (p.rowmask[row0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] != 0.f ? 1u : 0u) << (tm * 16 + r);
+    static_assert(TM == 2, "keep_bits32 covers two 32-row blocks");
+    keepbits = keep_bits32(p.rowmask, row0 + wm * 64 + 4 * h);
   }
   const int rin_base = row0 - b * p.rows_per_frustum + wm * 64 + 4 * h;
   float* red = reinterpret_cast<float*>(bst);
@@ -1438,12 +1447,17 @@ __device__ __forceinline__ void dgrad_epilogue_body(const DgradEpilogue& p, f32x
   const unsigned K = (unsigned)p.K;
   float cs1[TN], cs2[TN];
   unsigned live = 0u;                    // bit tm*16 + r: the lane's accumulator row (tm, r) has something to add
-  if (ADD == 2) {
+  if (ADD == 2) {      // all flag loads requested together, then the compares (cf. keep_bits32)
+    int4 fl[TM][4];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fl[tm][j] = *reinterpret_cast<const int4*>(p.add_live + row0 + wm * 64 + 4 * h + tm * 32 + 8 * j);
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int4 f = *reinterpret_cast<const int4*>(p.add_live + row0 + wm * 64 + 4 * h + tm * 32 + 8 * j);
+        const int4 f = fl[tm][j];
         live |= (unsigned)((f.x != 0) | ((f.y != 0) << 1) | ((f.z != 0) << 2) | ((f.w != 0) << 3)) << (tm * 16 + 4 * j);
       }
   }
@@ -1525,12 +1539,17 @@ __device__ __forceinline__ void dgrad_epilogue_body_h(const DgradEpilogue& p, f3
   const unsigned K = (unsigned)p.K;
   float cs1[TN], cs2[TN];
   unsigned live = 0u;                    // bit tm*16 + r: the lane's accumulator row (tm, r) has something to add
-  if (ADD == 2) {
+  if (ADD == 2) {      // all flag loads requested together, then the compares (cf. keep_bits32)
+    int4 fl[TM][4];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fl[tm][j] = *reinterpret_cast<const int4*>(p.add_live + row0 + wm * 64 + 4 * h + tm * 32 + 8 * j);
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int4 f = *reinterpret_cast<const int4*>(p.add_live + row0 + wm * 64 + 4 * h + tm * 32 + 8 * j);
+        const int4 f = fl[tm][j];
         live |= (unsigned)((f.x != 0) | ((f.y != 0) << 1) | ((f.z != 0) << 2) | ((f.w != 0) << 3)) << (tm * 16 + 4 * j);
       }
   }
@@ -3074,14 +3093,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_pointmlp_fwd_pool(const t3d
     // keep flags of this lane's 32 rows (the same rows for every column tile)
     unsigned bits = 0xffffffffu;
     if (p.rowmask) {
-      bits = 0u;
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = f.row0 + f.wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * f.h;
-          bits |= (p.rowmask[row] != 0.f ? 1u : 0u) << (tm * 16 + r);
-        }
+      bits = keep_bits32(p.rowmask, f.row0 + f.wm * 64 + 4 * f.h);
     }
     f.keepbits = bits;
   }
