@@ -41,7 +41,11 @@ def close_bf16(got, ref, what, acc_rel=2e-5, opmax=0.0):
 @pytest.mark.parametrize('M,K,N,rpf,xbf,pool', [(512, 64, 64, 256, True, False), (256, 4, 64, 128, False, False),
                                                 (256, 3, 128, 128, False, False), (512, 128, 256, 256, True, True),
                                                 (256, 64, 512, 128, True, False), (384, 512, 256, 128, True, False),
-                                                (65536, 128, 128, 1024, True, False)])
+                                                (65536, 128, 128, 1024, True, False),
+                                                # more row tiles than persistent workgroups (536 > 512): the resident forward walks a second tile
+                                                # with its panel / weight / bias prefetched (k_pointmlp_fwd_res, round 3)
+                                                (68608, 128, 256, 1024, True, False), (68608, 128, 256, 1024, True, True),
+                                                (68608, 64, 128, 1024, True, False)])
 def test_bf16_forward(hip_lib, M, K, N, rpf, xbf, pool):
     g = torch.Generator(device='cpu').manual_seed(M + K + N)
     ldx = 4 if K <= 4 else K
