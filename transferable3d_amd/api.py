@@ -407,7 +407,10 @@ class Session:
                     e.emit_boxpc_perturb(pre, g.inputs, perturb, seed=opts.get('seed', 0) ^ 0x5bd1e995)
             e.emit_schedule(pre, top.sched)
             e.emit_dropout_masks(pre, seed=self.dropout_seed)
-        asm.emit_forward(fwd, is_training, with_loss)
+        if train and type(asm).__name__ == 'SemiModelF':
+            asm.emit_forward(fwd, is_training, with_loss, train=True)      # (the W_ heads become a chain of their own: nets.SemiModelF)
+        else:
+            asm.emit_forward(fwd, is_training, with_loss)
         if train:
             # data parallel: the backward declares its gradient buckets (all-reduce of a finished bucket beside the rest)
             e.dp_buckets = self.pg is not None and (self.pg.size() > 1 or self.force_dist) and not self.dp_flat

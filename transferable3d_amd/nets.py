@@ -358,6 +358,10 @@ class BoxEstNet:
         self.G3 = FcLayer(g, s + 'fc3', 256, BOX_OUT_DIMS, bn=False, act=None)
 
     def fwd(self, plan, pc, mask, stage1_center, one_hot, is_training, ld_oh=NUM_CLASS):
+        self.fwd_convs(plan, pc, mask, stage1_center, is_training)
+        return self.fwd_heads(plan, one_hot, is_training, ld_oh)
+
+    def fwd_convs(self, plan, pc, mask, stage1_center, is_training):
         g = self.g
         a = ActSpec(pc, g.ldpc, 3, sub=stage1_center, sub_ld=3)
         a = self.B1.fwd(plan, a, is_training)
@@ -365,6 +369,11 @@ class BoxEstNet:
         a = self.B3.fwd(plan, a, is_training)
         self.B4.fwd(plan, a, is_training, rowmask=mask)
         self.feats_lv1 = self.B4.pooled
+        return self.feats_lv1
+
+    def fwd_heads(self, plan, one_hot, is_training, ld_oh=NUM_CLASS):
+        """fc1-fc3 on the pooled feature (semisup_models.py:249-262).  Separate from the convolutions: in SEMI_MODEL F these heads feed
+        end points only (W_pred_box), so the stage-c step runs them as a chain of its own beside the refinement branch."""
         self.feats_lv2 = self.G1.fwd(plan, self.feats_lv1, 512, is_training, in2=one_hot if self.oh else None,
                                      ld_in2=ld_oh)
         self.feats_lv3 = self.G2.fwd(plan, self.feats_lv2, 512, is_training)
@@ -912,7 +921,11 @@ class SemiModelF:
         self.refine_num = None
         self.cur_center, self.cur_dims, self.cur_theta, self.total_delta = rt.zeros(B, 3), rt.zeros(B, 3), rt.zeros(B), rt.zeros(B, 7)
 
-    def emit_forward(self, plan, is_training, with_loss):
+    def emit_forward(self, plan, is_training, with_loss, train=False):
+        """`train`: a backward plan follows (api.Session / step.build_training_step say so).  Then the class-agnostic box heads
+        fc1-fc3 and the W_ IoU summary -- they feed end points only, nothing of the loss or the backward reads them -- are emitted
+        at the END of the backward plan as a chain of their own (`S_begin` / `S_end`), and everything from the refinement branch on
+        is the other chain (`T_begin`): schedule.overlap_chains lets the three FC launches ride in the Box-PC net's GEMM launches."""
         if not is_training and self.refine_num is not None:
             return self.emit_forward_inference(plan, self.refine_num)
         g, x, c = self.g, self.inputs, self.c
@@ -921,13 +934,19 @@ class SemiModelF:
                      ce_weight=c.STRONG_WEIGHT_CROSS_ENTROPY)
         ex, ld_ex = self.extra.emit(plan, x) if self.extra is not None else (x.one_hot_vec, NUM_CLASS)
         s1 = self.tnet.fwd(plan, x.pc, self.seg.mask, self.seg.mask_xyz_mean, ex, is_training, ld_oh=ld_ex)
-        self.box.fwd(plan, x.pc, self.seg.mask, s1, ex, is_training, ld_oh=ld_ex)
+        self.box.fwd_convs(plan, x.pc, self.seg.mask, s1, is_training)
+        self._deferred = None
+        if train and OVERLAP and is_training and not g.dp_buckets:
+            self._deferred = (ex, ld_ex, is_training, with_loss, s1)
+            plan.mark('T_begin')
+        else:
+            self.box.fwd_heads(plan, ex, is_training, ld_oh=ld_ex)
         f = self.R0.fwd(plan, self.box.feats_lv1, 512, is_training, in2=x.one_hot_vec if self.oh else None, ld_in2=NUM_CLASS)
         f = self.R1.fwd(plan, f, 512, is_training)
         self.F_out = self.R2.fwd(plan, f, 256, is_training)
         lab = (x.y_center, x.y_orient_cls, x.y_orient_reg, x.y_dims_cls, x.y_dims_reg, x.is_data_2D)
         self.loss_op.emit(plan, self.F_out, s1, self.seg.seg_loss, lab, c, normalize_by_3d_count=True)
-        if with_loss:
+        if with_loss and self._deferred is None:
             emit_box_head_iou(g, plan, self.box.box_params, s1, lab, self.W_iou2d, self.W_iou3d)
         # frozen Box-PC net on F_pred_box_reg (is_training_D = False: eval-mode batch-norm, no dropout)
         lo = self.loss_op
@@ -1017,6 +1036,14 @@ class SemiModelF:
         dfeat = self.R0.dinput(plan, K=512, bn_bwd_of=self.box.B4)
         ds1 = self.box.bwd_convs(plan, dfeat, 512, lo.dstage1)
         self.tnet.bwd(plan, ds1)
+        if getattr(self, '_deferred', None) is not None:      # the W_ heads, as the second chain (emit_forward)
+            ex, ld_ex, is_training, with_loss, s1 = self._deferred
+            plan.mark('S_begin')
+            self.box.fwd_heads(plan, ex, is_training, ld_oh=ld_ex)
+            if with_loss:
+                lab = (x.y_center, x.y_orient_cls, x.y_orient_reg, x.y_dims_cls, x.y_dims_reg, x.is_data_2D)
+                emit_box_head_iou(g, plan, self.box.box_params, s1, lab, self.W_iou2d, self.W_iou3d)
+            plan.mark('S_end')
         g.emit_reduce_slabs(plan)
 
     VAR_LIST = ('class_dependent', 'class_agnostic/tnet', 'class_agnostic/box')

@@ -297,7 +297,10 @@ def build_training_step(rt, workload, B, N, C, world=1, rank=0, process_group=No
     g.dp_buckets = dist_on and not flat_allreduce
     g.emit_schedule(g.pre, make_schedule(B * world))
     g.emit_dropout_masks(g.pre, seed=dropout_seed + rank)
-    model.emit_forward(g.fwd, True, True)
+    if workload == 'F':
+        model.emit_forward(g.fwd, True, True, train=True)
+    else:
+        model.emit_forward(g.fwd, True, True)
     model.emit_backward(g.bwd)
     g.emit_adam(g.opt, prefixes=prefixes, grad_scale=1.0 / world)
     g.finalize()
