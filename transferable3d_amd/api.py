@@ -248,14 +248,29 @@ def concat(values=None, axis=None, **kw):
     return GlobalVec(ctx, va.parts + vb.parts)
 
 
+class MaskedPoints:
+    """tf.multiply(net, mask): a per-point tensor times the hard [B,N,1,1] mask.  Never materialised -- the only consumer the
+    reference has for it is the max-pool right behind it (semisup_models.py:184-188, 240-244), which takes `mask` as its row mask.
+    A type of its own so that every OTHER consumer (conv2d, dropout, a fetch) fails instead of silently reading the unmasked
+    activations."""
+
+    def __init__(self, points, mask_buf):
+        self.points, self.rowmask = points, mask_buf
+        self.layer, self.ctx = getattr(points, 'layer', None), points.ctx
+        self.shape = points.shape
+
+    def get_shape(self):
+        return self.points.get_shape()
+
+    def numpy(self):
+        raise NotImplementedError('a masked per-point tensor (api.multiply) can only feed tf_util.max_pool2d')
+
+
 def multiply(x, y):
     """tf.multiply(net, mask) in front of a max-pool (semisup_models.py:184-185, 240-241): the mask becomes the pooled layer's row
     mask (the masked tensor itself is never written)."""
-    import copy
     if hasattr(x, 'spec') and getattr(y, 'buf', None) is not None and int(np.prod(y.shape)) == x.ctx.engine.M:
-        out = copy.copy(x)
-        out.rowmask = y.buf
-        return out
+        return MaskedPoints(x, y.buf)
     raise NotImplementedError('multiply: a per-point tensor times the [B,N,1,1] mask')
 
 
@@ -424,6 +439,12 @@ class Session:
         self.steps[key] = step
         g.compiled[key] = True
         return step
+
+    def check_riders(self):
+        """Raises schedule.RiderBarrierTimeout if a rider barrier of any compiled step ever timed out (step.TrainStep.check_riders;
+        run() looks every T3D_RIDER_CHECK_EVERY steps by itself, the drivers call this before they write a checkpoint)."""
+        for st in self.steps.values():
+            st.impl.check_riders()
 
     def run(self, fetches, feed_dict=None):
         single = not isinstance(fetches, (list, tuple))

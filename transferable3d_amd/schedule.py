@@ -208,12 +208,28 @@ def align(S, T, max_run=None):
     return steps, float(cost[nS, nT])
 
 
+class RiderBarrierTimeout(RuntimeError):
+    """A rider barrier gave up waiting (csrc/rider_dev.h: bounded spin): the ops behind it ran on incomplete inputs, so every
+    result of the affected steps -- weights, Adam moments, moving statistics -- is invalid."""
+
+
 class RiderSets:
-    """Owner of the device-side op tables and barrier words of a program's rider sets."""
+    """Owner of the barrier words of a program's rider sets: ONE pooled device buffer (a row of 2 * RIDER_MAX_OPS + 2 words per set,
+    the set's timeout word at [-2]), so that the training loop can look at every timeout word with one 4-byte read."""
+    POOL = 128
 
     def __init__(self, rt):
         self.rt = rt
-        self.sets = []       # (RiderSet struct, -, sync tensor, -)
+        self.sets = []       # (RiderSet struct | None, keep-alive ...)
+        self.width = 2 * abi.RIDER_MAX_OPS + 2
+        self.pools, self.used = [], 0
+
+    def _row(self):
+        if self.used == len(self.pools) * self.POOL:
+            self.pools.append(torch.zeros((self.POOL, self.width), dtype=torch.int32, device=self.rt.device))
+        row = self.pools[-1][self.used % self.POOL]
+        self.used += 1
+        return row
 
     def make(self, ops):
         """ops: [(name, arg struct)] in chain order -> abi.RiderSet (ops by value, zeroed barrier words on the device)."""
@@ -223,14 +239,27 @@ class RiderSets:
             rs.ops[k] = small_op(name, arg, depends=1 if k > 0 else 0)
         rs.n_ops = n
         abi.check(lib.t3d_riders_plan(C.byref(rs)), 't3d_riders_plan')
-        sync = torch.zeros(2 * abi.RIDER_MAX_OPS + 2, dtype=torch.int32, device=self.rt.device)
+        sync = self._row()
         rs.sync = C.cast(C.c_void_p(sync.data_ptr()), C.POINTER(C.c_uint32))
         self.sets.append((rs, None, sync, None))
         return rs
 
     def timeouts(self):
-        """Number of sets whose barrier ever gave up waiting (must be 0; t3d.h t3d_rider_set.sync)."""
-        return sum(int(sync[-2].item() != 0) for rs, _, sync, _ in self.sets if rs is not None)
+        """Number of sets whose barrier ever gave up waiting (must be 0; t3d.h t3d_rider_set.sync).  One device reduction + one
+        4-byte read per pool of 128 sets (a step has ~20)."""
+        n = 0
+        for k, pool in enumerate(self.pools):
+            rows = min(self.POOL, self.used - k * self.POOL)
+            n += int((pool[:rows, self.width - 2] != 0).sum().item())
+        return n
+
+    def check(self):
+        n = self.timeouts()
+        if n:
+            raise RiderBarrierTimeout(
+                '%d rider set(s) report a barrier time-out (csrc/rider_dev.h): the small ops behind that barrier ran before their '
+                'inputs were complete, so the weights / Adam moments / moving statistics written since the last check are invalid.  '
+                'Restore the last checkpoint; T3D_OVERLAP=0 runs the step without riders.' % n)
 
 
 def _host_call(lib, op, rs):

@@ -44,6 +44,10 @@ class TrainStep:
         self._wait_events = []
         self._sets = None            # schedule.RiderSets of the scheduled program (device op tables, barrier words)
         self.schedule_report = None
+        # A rider barrier that gives up waiting (csrc/rider_dev.h) leaves wrong weights behind: the training loop looks at the
+        # sets' time-out words every `rider_check_every` steps (one 4-byte read) and raises schedule.RiderBarrierTimeout; the
+        # drivers also call check_riders() before they write a checkpoint.  0: only on request.
+        self.rider_check_every = int(os.environ.get('T3D_RIDER_CHECK_EVERY', '64'))
 
     # ---- program --------------------------------------------------------------------------------------------------------------
     def _buckets(self):
@@ -118,6 +122,10 @@ class TrainStep:
         tb, sb, se = tags['T_begin'], tags['S_begin'], tags['S_end']
         if not tb < sb < se:
             return calls, lanes
+        if self._shares_gpu():
+            # the rider barrier's liveness rests on all <= 32 rider workgroups of a set being resident together; with another
+            # process's kernels on the same chip (several ranks on one GPU) that is no longer this process's to guarantee
+            return calls, lanes
         real = lambda cs: [c for c in cs if not c[0].startswith('__')]
         if any(c[0] in (Plan.BUCKET, Plan.WAIT) for c in calls[tb:se]):
             return calls, lanes
@@ -126,6 +134,22 @@ class TrainStep:
         merged, self.schedule_report = schedule.overlap_chains(self.rt, real(calls[sb:se]), real(calls[tb:sb]), self._sets)
         calls = calls[:tb] + merged + calls[se + 1:]
         return calls, [0] * len(calls)
+
+    def _shares_gpu(self):
+        """More ranks on this node than GPUs (two ranks on one GPU over gloo: tests, bench.py --gpus 2 on a one-GPU box).
+        T3D_RIDERS_SHARED_GPU=1 keeps the riders anyway."""
+        if not self.on_gpu or os.environ.get('T3D_RIDERS_SHARED_GPU', '0') == '1':
+            return False
+        local_ranks = int(os.environ.get('LOCAL_WORLD_SIZE', self.world))      # (one node: SURVEY 8e)
+        return local_ranks > torch.cuda.device_count()
+
+    def rider_timeouts(self):
+        return self._sets.timeouts() if self._sets is not None else 0
+
+    def check_riders(self):
+        """Raises schedule.RiderBarrierTimeout if a rider barrier of this step's program ever timed out (drains the stream)."""
+        if self._sets is not None:
+            self._sets.check()
 
     # ---- execution ------------------------------------------------------------------------------------------------------------
     def _allreduce(self, i, async_op):
@@ -208,6 +232,11 @@ class TrainStep:
         """One step.  The first run of a variant is eager (it also loads the code objects); the second captures (capturing
         executes nothing) and replays; later runs replay."""
         self.n_runs += 1
+        self._issue(generate_masks)
+        if self._sets is not None and self.rider_check_every > 0 and self.n_runs % self.rider_check_every == 0:
+            self.check_riders()
+
+    def _issue(self, generate_masks):
         key = bool(generate_masks)
         ent = self.cache.get(key)
         if ent is None:
@@ -364,6 +393,7 @@ class PipelinedStep:
         self.want_graph = (bool(use_hip_graph) if use_hip_graph is not None else self.on_gpu) and self.on_gpu
         self.dist, self.world, self.time_waits = False, 1, False
         self._sets = schedule.RiderSets(rt)
+        self.rider_check_every = int(os.environ.get('T3D_RIDER_CHECK_EVERY', '64'))
         self._stream = [None]
         self.n_runs = 0
         self.fwd_pending = False
@@ -411,6 +441,8 @@ class PipelinedStep:
         (self.tail if last else self.steady)[i].run(self._stream)
         self.fwd_pending = not last
         self.n_runs += 1
+        if self.rider_check_every > 0 and self.n_runs % self.rider_check_every == 0:
+            self.check_riders()
 
     # ---- what bench.py asks of a step object -------------------------------------------------------------------------------
     def profile_plans(self):
@@ -424,6 +456,9 @@ class PipelinedStep:
 
     def rider_timeouts(self):
         return self._sets.timeouts()
+
+    def check_riders(self):
+        self._sets.check()
 
 
 def build_pipelined_step(rt, B, N, C, use_hip_graph=None, inline_dropout=True, dropout_seed=1234, seed=0, state_dict=None, c=None):

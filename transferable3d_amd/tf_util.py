@@ -51,6 +51,8 @@ def _as_spec(ctx, inputs):
     if isinstance(inputs, api.Placeholder):          # the raw point cloud (B,N,C)
         e = ctx.engine
         return ActSpec(inputs.buf, e.ldpc, e.C)
+    if isinstance(inputs, api.MaskedPoints):
+        raise NotImplementedError('a masked per-point tensor (api.multiply) can only feed tf_util.max_pool2d (semisup_models.py:184-188)')
     raise TypeError('conv2d input must be a point tensor, got %r' % (inputs,))
 
 
@@ -140,6 +142,8 @@ def dropout(inputs, is_training, scope, keep_prob=0.5, noise_shape=None):
     t3d_seg_head)."""
     if noise_shape is not None:
         raise NotImplementedError('dropout: noise_shape is None at every call site of the reference')
+    if isinstance(inputs, api.MaskedPoints):
+        raise NotImplementedError('a masked per-point tensor (api.multiply) can only feed tf_util.max_pool2d (semisup_models.py:184-188)')
     ctx = api.get_default_graph()
     scope = api.scoped(scope)
     e = ctx.engine

@@ -152,6 +152,7 @@ def train(FLAGS, rt=None, log=print):
                 if FLAGS.eval_batches > 0:
                     eval_one_epoch(epoch)
                 if epoch % 5 == 0:
+                    sess.check_riders()      # never checkpoint weights a timed-out rider barrier may have corrupted
                     log('Model saved in file: %s' % save_model(FLAGS.log_dir, epoch, g, FLAGS.ckpt_format))
                 continue
             stats = new_stats()
@@ -169,8 +170,10 @@ def train(FLAGS, rt=None, log=print):
             if FLAGS.eval_batches > 0:
                 eval_one_epoch(epoch)
             if epoch % 5 == 0:
+                sess.check_riders()      # never checkpoint weights a timed-out rider barrier may have corrupted
                 path = save_model(FLAGS.log_dir, epoch, g, FLAGS.ckpt_format)
                 log('Model saved in file: %s' % path)
+        sess.check_riders()
         return g.vars.state_dict(), mean_loss
 
 

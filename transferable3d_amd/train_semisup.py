@@ -262,8 +262,10 @@ def train(FLAGS, rt=None, log=print):
                 eval_one_epoch(sess, (pls, is_training_pl, semi_loss, n_correct, end_points), FLAGS, epoch, log, eval_source)
             if rank == 0:
                 if epoch % 5 == 0:                       # train_semisup.py:316-318
+                    sess.check_riders()      # never checkpoint weights a timed-out rider barrier may have corrupted
                     path = save_model(FLAGS.log_dir, epoch, g, FLAGS.ckpt_format)
                     log('Model saved in file: %s' % path)
+        sess.check_riders()
         final = g.vars.state_dict()
     if world > 1:
         import torch.distributed as dist

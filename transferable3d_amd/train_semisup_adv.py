@@ -234,8 +234,10 @@ def train(FLAGS, rt=None, log=print):
                 log('**** EPOCH %03d ****  mean loss: %f  (%.1f frustums/s incl. host batch synthesis)' % (
                     epoch, mean_loss, FLAGS.steps_per_epoch * iters * B / (time.time() - t0)))
             if epoch % 5 == 0:
+                sess.check_riders()      # never checkpoint weights a timed-out rider barrier may have corrupted
                 path = save_model(FLAGS.log_dir, epoch, g, FLAGS.ckpt_format, optimizer_scopes=train_vars)
                 log('Model saved in file: %s' % path)
+        sess.check_riders()
         return g.vars.state_dict(), mean_loss
 
 
