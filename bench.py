@@ -307,6 +307,37 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+class Watchdog:
+    """Exits the process (a plain exit: no exec, no re-launch) with a message if the guarded section takes longer than `seconds` --
+    a collective that never completes must end the run with an explanation, not hang the node until the driver's limit.  `on_fire`
+    may print what is already known first."""
+
+    def __init__(self, seconds, what, on_fire=None, code=3):
+        import threading
+        self.what, self.seconds, self.on_fire, self.code = what, seconds, on_fire, code
+        self.t = threading.Timer(seconds, self._fire)
+        self.t.daemon = True
+
+    def _fire(self):
+        sys.stderr.write('bench.py: %s did not finish within %d s (rank %s of %s) -- giving up\n' %
+                         (self.what, self.seconds, os.environ.get('RANK', '0'), os.environ.get('WORLD_SIZE', '1')))
+        sys.stderr.flush()
+        code = self.code
+        try:
+            if self.on_fire is not None:
+                code = self.on_fire()
+        finally:
+            os._exit(code)
+
+    def __enter__(self):
+        self.t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.t.cancel()
+        return False
+
+
 def other_configs(args):
     """BASELINE.json configs[2], configs[3] (one replica) and configs[4] (one replica): <= 20 timed steps each in a child process of
     this script (own Runtime, own hipGraph), reported beside the headline -- informational, never `value`."""
@@ -322,6 +353,7 @@ def other_configs(args):
             rf = d.get('roofline') or {}
             out.append({'workload': d['config']['workload'], 'dtype': d['dtype'], 'value': d['value'], 'unit': d['unit'],
                         'ms_per_step': d['ms_per_step'], 'steps': d['steps'],
+                        'rider_barrier_timeouts': ((d['config'].get('schedule') or {}).get('rider_barrier_timeouts', 0)),
                         'roofline': {'kernel': rf.get('kernel'), 'bound': rf.get('bound'), 'frac': rf.get('frac'),
                                      'avg_launch_us': rf.get('avg_launch_us')}})
         except Exception as e:      # a failed side run must not cost the headline line
@@ -354,10 +386,22 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
         backend = os.environ.get('T3D_DIST_BACKEND', 'nccl')       # 'gloo': the multi-rank flow on a box with fewer GPUs than ranks
-        if backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        import datetime
+        tmo = datetime.timedelta(seconds=int(os.environ.get('T3D_DIST_TIMEOUT_S', '120')))
+        with Watchdog(int(tmo.total_seconds()) + 30, 'the rendezvous of the %d ranks (init_process_group, %s)' % (world, backend)):
+            if backend == 'nccl':
+                dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank), timeout=tmo)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
+        assert dist.get_world_size() == world and (world == args.gpus or os.environ.get('T3D_FORCE_DIST', '0') == '1'), \
+            'process group of %d ranks, --gpus %d' % (dist.get_world_size(), args.gpus)
+        # the first collective (communicator set-up over xGMI) under a watchdog of its own: it either completes or the run ends with a
+        # message -- it must not be able to hang the one scaling run the driver makes
+        with Watchdog(int(os.environ.get('T3D_FIRST_COLLECTIVE_TIMEOUT_S', '180')), 'the first all-reduce of the %d ranks (%s)' % (world, backend)):
+            probe = torch.ones(1024, device='cuda')
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            assert float(probe[0].item()) == float(world), 'first all-reduce returned %r, expected %d' % (float(probe[0].item()), world)
 
     from transferable3d_amd.engine import Runtime
     from transferable3d_amd.step import build_training_step
@@ -367,6 +411,8 @@ def main():
     rt = Runtime()
     global LIB
     LIB = rt.lib
+    from transferable3d_amd import abi as _abi
+    lib_hash = _abi.source_hash_of(rt.lib)      # (abi.load has already refused a library that was not built from these sources)
     desc = {'A': 'seg-PointNet + T-Net + box-est fwd+bwd+Adam (SEMI_MODEL A)', 'boxpc': 'Box-PC Fit net fwd+bwd+Adam (train_boxpc.py path)',
             'F': 'SEMI_MODEL F stage c (frozen seg + Box-PC branch, var_list optimiser) fwd+bwd+Adam'}[args.workload]
     # the SAME step object the drivers run and tests/test_step_gpu.py checks against the oracle trajectory: device schedules, the
@@ -407,18 +453,30 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    # the metric is B / MEDIAN step time.  Events on the launch stream every `chunk` steps (ten chunks over the timed
+    # region) give the distribution; the wall clock over exactly K steps between the barriers gives the mean (second field).
+    chunk = max(1, args.steps // 10)
+    marks = [torch.cuda.Event(enable_timing=True)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         step()
+        if (i + 1) % chunk == 0 or i + 1 == args.steps:
+            marks.append(torch.cuda.Event(enable_timing=True))
+            marks[-1].record()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    bounds = list(range(chunk, args.steps, chunk)) + [args.steps]
+    per_step = [marks[k + 1].elapsed_time(marks[k + 2]) * 1e-3 / (bounds[k + 1] - bounds[k]) for k in range(len(bounds) - 1)]
+    per_step.insert(0, marks[0].elapsed_time(marks[1]) * 1e-3 / bounds[0])
+    median_step = float(np.median(per_step))
     if dist is not None:
-        t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+        t = torch.tensor([elapsed, median_step], device='cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, median_step = float(t[0].item()), float(t[1].item())
     if trainstep.dist:          # five more steps (every rank) with events around the bucket waits: the exposed all-reduce time
         trainstep.time_waits = True
         for _ in range(5):
@@ -428,8 +486,7 @@ def main():
     loss = float(loss_buf().item())
     assert np.isfinite(loss), 'non-finite loss'
     # a rider barrier that ever gave up waiting (t3d.h t3d_rider_set.sync) would mean wrong results: fail loudly
-    sets = getattr(trainstep, '_sets', None)
-    rider_timeouts = sets.timeouts() if sets is not None else 0
+    rider_timeouts = trainstep.rider_timeouts()
     assert rider_timeouts == 0, 'a rider barrier timed out: the results of the step are invalid'
 
     roofline = None
@@ -490,11 +547,11 @@ def main():
                                    # what the GEMM kernels actually execute (the Gram-form backward of the pooled layers needs
                                    # fewer FLOPs than the split count the roofline figure is quoted on)
                                    'gflop_per_frustum_executed': gemm_f / args.profile_steps / B / 1e9,
-                                   'achieved_executed': gemm_f / args.profile_steps * args.steps / elapsed / 1e12,
-                                   'achieved': step_flops * args.steps / elapsed / 1e12,
-                                   'frac': step_flops * args.steps / elapsed / 1e12 / mfma_peak,
+                                   'achieved_executed': gemm_f / args.profile_steps / median_step / 1e12,
+                                   'achieved': step_flops / median_step / 1e12,
+                                   'frac': step_flops / median_step / 1e12 / mfma_peak,
                                    'algorithmic_gemm_bytes_per_step': gemm_b / args.profile_steps,
-                                   'hbm_frac': gemm_b / args.profile_steps * args.steps / elapsed / (HBM_PEAK_TBS * 1e12)},
+                                   'hbm_frac': gemm_b / args.profile_steps / median_step / (HBM_PEAK_TBS * 1e12)},
                     'per_kernel_us_per_step': {k: v[0] / args.profile_steps * 1e6 for k, v in sorted(acc.items(), key=lambda kv: -kv[1][0])}}
         if args.call_detail:
             for ci in sorted(CALLS):
@@ -515,9 +572,13 @@ def main():
         cpu = cpu_baseline(args, batch)
 
     if rank == 0:
-        value = B * world * args.steps / elapsed
+        value = B * world / median_step
         out = {'metric': 'frustums/sec fwd+bwd', 'value': value, 'unit': 'frustums/s', 'n_gpus': world, 'steps': args.steps,
-               'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
+               'warmup': args.warmup, 'ms_per_step': median_step * 1e3,
+               'timing': {'value_from': 'median over %d chunks of %d step(s), HIP events on the launch stream, max over ranks (SURVEY 8d)' % (len(per_step), chunk),
+                          'ms_per_step_mean': elapsed / args.steps * 1e3, 'value_mean': B * world * args.steps / elapsed,
+                          'ms_per_step_min': min(per_step) * 1e3, 'ms_per_step_max': max(per_step) * 1e3},
+               'lib_source_hash': lib_hash, 'higher_is_better': True,
                'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
                'config': {'workload': '%s, B=%d N=%d C=%d %s per GPU, dp%d' % (desc, B, N, C, 'fp32' if args.dtype == 'f32' else 'bf16', world),
                           'global_batch': B * world, 'hipgraph': use_graph, 'graph_segments_per_step': trainstep.n_graph_segments(),
@@ -532,10 +593,64 @@ def main():
                'roofline': roofline, 'cpu_baseline': cpu, 'other_configs': others}
         if trainstep.dist:
             out['config']['dp'] = trainstep.dp_report()
+    def emit_and_leave():
+        """Watchdog exit behind the timed region: the headline line is complete -- print it, then leave."""
+        if rank == 0:
+            if saved_stdout is not None:
+                os.dup2(saved_stdout, 1)
+            os.write(1, (json.dumps(out) + '\n').encode())
+        return 0
+
+    flat_default = os.environ.get('T3D_DP_FLAT', '1') == '1'
+    if (trainstep.dist and world > 1 and args.workload == 'A' and not pipelined and os.environ.get('T3D_DP_BOTH_MODES', '1') == '1'):
+        # One driver run decides flat vs bucketed (DESIGN section 6 only has a paper estimate): <= 20 timed steps of the NON-default
+        # data-parallel mode on a second step object, reported beside the default's.  Under a watchdog that prints the headline line
+        # (already complete) and leaves if this extra leg does not finish.
+        name_default, name_alt = ('flat', 'bucketed') if flat_default else ('bucketed', 'flat')
+        if rank == 0:
+            out['config']['dp']['modes'] = {name_default: {'ms_per_step': median_step * 1e3,
+                                                           'exposed_allreduce_us': out['config']['dp'].get('exposed_allreduce_us_per_step')}}
+
+        def give_up():
+            if rank == 0:
+                out['config']['dp']['modes'][name_alt] = 'did not finish'
+            return emit_and_leave()
+
+        with Watchdog(int(os.environ.get('T3D_DP_ALT_TIMEOUT_S', '150')), 'the %s data-parallel mode (informational leg)' % name_alt, give_up):
+            dist.barrier()
+            g2, model2, step2, _ = build_training_step(
+                rt, args.workload, B, N, C, world=world, rank=rank, process_group=dist.group.WORLD, force_dist=False,
+                flat_allreduce=not flat_default, use_hip_graph=not args.no_graph, inline_dropout=True, dropout_seed=1234, seed=0,
+                dtype=args.dtype)
+            model2.inputs.load(batch)
+            n_alt = min(20, args.steps)
+            for _ in range(2 + 5):
+                step2.run()
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n_alt):
+                step2.run()
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t_alt = torch.tensor([time.perf_counter() - t1], device='cuda', dtype=torch.float64)
+            dist.all_reduce(t_alt, op=dist.ReduceOp.MAX)
+            step2.time_waits = True
+            for _ in range(5):
+                step2.run()
+            torch.cuda.synchronize()
+            rep2 = step2.dp_report()
+            if rank == 0:
+                out['config']['dp']['modes'][name_alt] = {'ms_per_step': float(t_alt.item()) / n_alt * 1e3, 'steps': n_alt,
+                                                          'exposed_allreduce_us': rep2.get('exposed_allreduce_us_per_step'),
+                                                          'mode': rep2.get('mode')}
     if dist is not None:
-        dist.barrier()                        # rank 0 profiled its kernels meanwhile: every rank leaves together
-        torch.cuda.synchronize()
-        dist.destroy_process_group()
+        with Watchdog(120, 'the final barrier', emit_and_leave):
+            dist.barrier()                        # rank 0 profiled its kernels meanwhile: every rank leaves together
+            torch.cuda.synchronize()
+            dist.destroy_process_group()
     if saved_stdout is not None:
         import ctypes
         sys.stdout.flush()

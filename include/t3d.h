@@ -49,6 +49,10 @@ enum { T3D_ACT_NONE = 0, T3D_ACT_RELU = 1, T3D_ACT_LEAKY_RELU = 2, T3D_ACT_TANH 
 enum { T3D_F32 = 0, T3D_BF16 = 1 };
 
 int t3d_abi_version(void);
+/* Hash (16 hex digits + NUL) over the HIP sources and this header the library was built from (csrc/version.hip; "unknown" for a
+ * build outside transferable3d_amd/build.py).  `cap` >= 17.  The host side refuses a library whose hash differs from the sources
+ * next to it (abi.load). */
+int t3d_source_hash(char* out, int cap);
 
 /* ---- operand descriptors ------------------------------------------------------------------ */
 
@@ -903,6 +907,12 @@ int t3d_schedule_step(float* hyper, const t3d_schedule* s, t3d_stream_t stream);
 int t3d_adam_tf_step(float* params, const float* grads, float* m, float* v, int64_t n,
                      const float* hyper, float beta1, float beta2, float eps, float grad_scale,
                      t3d_stream_t stream);
+
+/* tf.train.MomentumOptimizer(learning_rate, momentum) of `--optimizer momentum` (train_semisup.py:226-228, train_boxpc.py:247,
+ * train_semisup_adv.py:296), TF form without Nesterov: accum = momentum * accum + g * grad_scale;  w -= lr * accum, with
+ * lr = hyper[1] (the staircase schedule t3d_schedule_step evaluates).  `accum` is the variable's `Momentum` slot. */
+int t3d_momentum_step(float* params, const float* grads, float* accum, int64_t n, const float* hyper, float momentum,
+                      float grad_scale, t3d_stream_t stream);
 
 /* Standalone tf_util.dropout on a per-point tensor (tf_util.py:1720-1741; the reference's one call site, conv9 -> dp1 -> conv10 of
  * v1_inst_seg, semisup_models.py:131, is fused into t3d_seg_head on the hot path): materialises

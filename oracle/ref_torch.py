@@ -801,6 +801,14 @@ def adam_tf_step(P, grads, m, v, t, lr, beta1=0.9, beta2=0.999, eps=1e-8):
         P[k] = P[k] - lr_t * m[k] / (torch.sqrt(v[k]) + eps)
 
 
+def momentum_tf_step(P, grads, accum, lr, momentum=0.9):
+    """tf.train.MomentumOptimizer(learning_rate, momentum) of `--optimizer momentum` (train_semisup.py:226-228), use_nesterov=False
+    (TF's ApplyMomentum kernel): accum = momentum * accum + g;  w -= lr * accum."""
+    for k, g in grads.items():
+        accum[k] = momentum * accum[k] + g
+        P[k] = P[k] - lr * accum[k]
+
+
 # ----------------------------------------------------------------------------------------------
 # one full training step (what bench.py's cpu_baseline leg times and the fixtures freeze)
 # ----------------------------------------------------------------------------------------------

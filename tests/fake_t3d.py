@@ -136,6 +136,9 @@ class FakeLib:
     def t3d_abi_version(self):
         return 1
 
+    def t3d_source_hash(self, out, cap):
+        return -1          # (the specification library is not a build of csrc/)
+
     def t3d_pointmlp_fwd(self, a, stream):
         p = _struct(a)
         M, K, N, rpf = p.M, p.K, p.N, p.rows_per_frustum
@@ -1384,6 +1387,13 @@ class FakeLib:
         mm[:] = np.float32(b1) * mm + np.float32(1 - b1) * gi
         vv[:] = np.float32(b2) * vv + np.float32(1 - b2) * gi * gi
         w[:] = w - lr_t * mm / (np.sqrt(vv) + np.float32(eps))
+        return 0
+
+    def t3d_momentum_step(self, params, grads, accum, n, hyper, momentum, gscale, stream):
+        w, g, a = arr(params, n), arr(grads, n), arr(accum, n)
+        lr = arr(hyper, 4)[1]
+        a[:] = np.float32(momentum) * a + g * np.float32(gscale)
+        w[:] = w - lr * a
         return 0
 
     def t3d_dropout_mask(self, mask, n, keep, seed, hyper, stream):

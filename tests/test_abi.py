@@ -24,6 +24,28 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert lib.t3d_abi_version() == 1
 
 
+def test_library_is_bound_to_the_sources_it_was_built_from(tmp_path, monkeypatch):
+    """csrc/version.hip carries sha256(csrc/*, include/t3d.h); abi.load() refuses a library built from other sources (*.so files are
+    git-ignored but ship to the GPU box: a stale file must not be tested or benchmarked as HEAD)."""
+    import shutil
+    import pytest
+    from transferable3d_amd import build as B
+    B.build()
+    lib = abi.load()
+    assert abi.source_hash_of(lib) == B.lib_source_hash() == B.embedded_hash()
+    # a source tree that differs from what the library was built from
+    fake = tmp_path / 'csrc'
+    shutil.copytree(B.CSRC, fake)
+    with open(fake / 'version.hip', 'a') as fh:
+        fh.write('// edited after the build\n')
+    monkeypatch.setattr(B, 'CSRC', str(fake))
+    assert B._stale()
+    with pytest.raises(abi.T3DError, match='built from other sources'):
+        abi.load()
+    monkeypatch.setenv('T3D_ALLOW_STALE_LIB', '1')
+    abi.load()
+
+
 def test_ctypes_structs_follow_header_field_order():
     h = _header()
     pairs = {'t3d_act_src': abi.ActSrc, 't3d_dy_src': abi.DySrc, 't3d_pointmlp_fwd_args': abi.PointMlpFwdArgs,

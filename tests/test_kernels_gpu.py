@@ -493,6 +493,20 @@ def test_reduce_slabs_adam_schedule_dropout(hip_lib):
         _close(vs[0], vs[1].cpu(), 1e-4, 1e-12, 'adam v')
     assert abs(float(hc[1]) - 5e-4) < 1e-9 and abs(float(hc[2]) - 0.75) < 1e-7      # 25000*32 >= 800000
 
+    # tf.train.MomentumOptimizer (--optimizer momentum, train_semisup.py:226-228): three steps against the oracle's restatement in fp64
+    from oracle import ref_torch as R
+    hg = torch.tensor([0.0, 0, 0, 0]).cuda()
+    wg, ag, gg2 = torch.as_tensor(w0.copy()).cuda(), torch.zeros(n).cuda(), torch.as_tensor(g0).cuda()
+    P, acc = {'w': torch.as_tensor(w0.astype(np.float64))}, {'w': torch.zeros(n, dtype=torch.float64)}
+    for it in range(3):
+        assert hip_lib.t3d_schedule_step(fptr(hg), C.byref(sched), s) == 0
+        assert hip_lib.t3d_momentum_step(fptr(wg), fptr(gg2), fptr(ag), n, fptr(hg), 0.9, 0.5, s) == 0
+        R.momentum_tf_step(P, {'w': torch.as_tensor(g0.astype(np.float64)) * 0.5}, acc, 1e-3, 0.9)
+    torch.cuda.synchronize()
+    _close(P['w'].float(), wg.cpu(), 1e-6, 1e-7, 'momentum w')
+    _close(acc['w'].float(), ag.cpu(), 1e-6, 1e-9, 'momentum accumulator')
+    assert hip_lib.t3d_momentum_step(None, fptr(gg2), fptr(ag), n, fptr(hg), 0.9, 0.5, s) == -1      # T3D_ERR_ARG
+
     # dropout mask: 0/1 valued, keep fraction, fresh per step
     n = 1 << 20
     m1, m2 = torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')

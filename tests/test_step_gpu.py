@@ -24,9 +24,11 @@ def test_five_replayed_steps_follow_the_oracle(hip_lib, workload):
     assert all(r['weight_entries_checked'] > 1000 for r in rep[:-1])
 
 
-def test_three_replayed_steps_at_the_headline_size_follow_the_oracle(hip_lib):
-    """BASELINE configs[1] itself: B=32, N=1024, C=4."""
-    rep = trajectory_check(Runtime(lib=hip_lib), 'A', steps=3, B=32, N=1024, use_hip_graph=True, verbose=True)
+@pytest.mark.parametrize('workload', ['A', 'boxpc', 'F'])
+def test_three_replayed_steps_at_the_headline_size_follow_the_oracle(hip_lib, workload):
+    """BASELINE configs[1], [2], [3] at their own size: B=32, N=1024, C=4 (the plans differ from the small cases': tile widths,
+    weight-gradient splits, which launches host riders)."""
+    rep = trajectory_check(Runtime(lib=hip_lib), workload, steps=3, B=32, N=1024, use_hip_graph=True, verbose=True)
     assert rep[-1]['graph_segments'] == 1
 
 

@@ -287,6 +287,7 @@ class RiderSet(C.Structure):
 
 ENTRY_POINTS = {
     't3d_abi_version': [],
+    't3d_source_hash': [C.c_char_p, C.c_int],
     't3d_pointmlp_fwd': [C.POINTER(PointMlpFwdArgs), VP],
     't3d_bn_fwd_finalize': [C.POINTER(BnFwdFinalizeArgs), VP],
     't3d_pool_finalize': [C.POINTER(PoolFinalizeArgs), VP],
@@ -341,6 +342,7 @@ ENTRY_POINTS = {
     't3d_reduce_slabs': [F, F, C.POINTER(SlabDesc), i32, i32, VP],
     't3d_schedule_step': [F, C.POINTER(Schedule), VP],
     't3d_adam_tf_step': [F, F, F, F, C.c_int64, F, f32, f32, f32, f32, VP],
+    't3d_momentum_step': [F, F, F, C.c_int64, F, f32, f32, VP],
     't3d_dropout_mask': [F, C.c_int64, f32, C.c_uint32, F, VP],
     't3d_cast_bf16': [F, VP, C.c_int64, VP],
 }
@@ -353,12 +355,21 @@ class T3DError(RuntimeError):
     pass
 
 
+def source_hash_of(lib):
+    """The source hash compiled into a loaded library (csrc/version.hip)."""
+    buf = C.create_string_buffer(64)
+    check(lib.t3d_source_hash(buf, 64), 't3d_source_hash')
+    return buf.value.decode()
+
+
 def load(path=None):
-    """dlopen libt3d.so and bind every entry point of include/t3d.h; raises if anything is missing."""
+    """dlopen libt3d.so and bind every entry point of include/t3d.h; raises if anything is missing, and if the library was built
+    from other sources than the ones lying next to it (T3D_ALLOW_STALE_LIB=1: experiments only)."""
     # torch bundles its own libamdhip64: import it FIRST so that libt3d.so binds to the same HIP runtime
     # instance that owns torch's streams and allocations (two runtimes in one process cannot share them).
     import torch  # noqa: F401
-    path = path or os.environ.get('T3D_LIB') or LIB_PATH      # T3D_LIB: an alternative build (tools/build_variant.sh) for same-box A/B
+    variant = path or os.environ.get('T3D_LIB')                # T3D_LIB: an alternative build (tools/build_variant.sh) for same-box A/B
+    path = variant or LIB_PATH
     if not os.path.exists(path):
         raise T3DError('HIP library %s not built: run `python -m transferable3d_amd.build` (no CPU fallback exists)' % path)
     lib = C.CDLL(path)
@@ -368,6 +379,12 @@ def load(path=None):
             raise T3DError('%s does not export %s' % (path, name))
         fn.argtypes = argtypes
         fn.restype = C.c_int
+    from .build import CSRC, lib_source_hash
+    if not variant and os.path.isdir(CSRC) and os.environ.get('T3D_ALLOW_STALE_LIB', '0') != '1':
+        built, src = source_hash_of(lib), lib_source_hash()
+        if built != src:
+            raise T3DError('%s was built from other sources (library %s, csrc/ + include/t3d.h %s): run '
+                           '`python -m transferable3d_amd.build`' % (path, built, src))
     return lib
 
 

@@ -368,6 +368,57 @@ class AdamOptimizer:
         return ctx.train_op
 
 
+class MomentumOptimizer(AdamOptimizer):
+    """tf.train.MomentumOptimizer(learning_rate, momentum=MOMENTUM) of `--optimizer momentum` (train_semisup.py:226-228,
+    train_boxpc.py:247, train_semisup_adv.py:296): accum = momentum * accum + g; w -= lr * accum, with the same staircase schedules."""
+
+    def __init__(self, learning_rate=1e-3, momentum=0.9, decay_step=800000, decay_rate=0.5, world_size=1):
+        AdamOptimizer.__init__(self, learning_rate, decay_step=decay_step, decay_rate=decay_rate, world_size=world_size)
+        self.momentum = float(momentum)
+
+
+def make_optimizer(FLAGS, world_size=1):
+    """The optimiser the reference's drivers pick from --optimizer / --momentum (train_semisup.py:226-231)."""
+    kind = getattr(FLAGS, 'optimizer', 'adam')
+    if kind == 'adam':
+        return AdamOptimizer(FLAGS.learning_rate, decay_step=FLAGS.decay_step, decay_rate=FLAGS.decay_rate, world_size=world_size)
+    if kind == 'momentum':
+        return MomentumOptimizer(FLAGS.learning_rate, momentum=getattr(FLAGS, 'momentum', 0.9), decay_step=FLAGS.decay_step,
+                                 decay_rate=FLAGS.decay_rate, world_size=world_size)
+    raise ValueError('--optimizer %r: adam or momentum (train_semisup.py:39)' % (kind,))
+
+
+def init_data_parallel(rt=None, gpu=0):
+    """One process per GPU: reads WORLD_SIZE / RANK / LOCAL_RANK (torch.distributed.run), joins the process group -- RCCL
+    on the GPUs, gloo with a CPU runtime -- and returns (world, rank, process group or None).  The three training drivers call this
+    where the reference selects its one GPU (train_semisup.py:31,205)."""
+    import os
+    import torch
+    world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+    if world > 1:
+        import datetime
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC (RCCL between the ranks of one node)
+        on_gpu = torch.cuda.is_available() and rt is None
+        if on_gpu:
+            torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count())
+        if not dist.is_initialized():
+            dist.init_process_group('nccl' if on_gpu else 'gloo',
+                                    timeout=datetime.timedelta(seconds=int(os.environ.get('T3D_DIST_TIMEOUT_S', '600'))))
+        return world, rank, dist.group.WORLD
+    if rt is None and torch.cuda.is_available():
+        torch.cuda.set_device(gpu)
+    return 1, 0, None
+
+
+def finish_data_parallel(world):
+    if world > 1:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
 class Session:
     """tf.Session analogue.  run(fetches, feed_dict): H2D copies of the fed arrays, one replay of the compiled
     launch schedule, D2H of the fetched tensors."""
@@ -432,7 +483,10 @@ class Session:
             asm.emit_backward(bwd)
             o = g.optimizer
             world = self.pg.size() if self.pg is not None else 1
-            e.emit_adam(opt, prefixes=top.var_prefixes, beta1=o.b1, beta2=o.b2, eps=o.eps, grad_scale=1.0 / world)
+            if isinstance(o, MomentumOptimizer):
+                e.emit_momentum(opt, prefixes=top.var_prefixes, momentum=o.momentum, grad_scale=1.0 / world)
+            else:
+                e.emit_adam(opt, prefixes=top.var_prefixes, beta1=o.b1, beta2=o.b2, eps=o.eps, grad_scale=1.0 / world)
         if not e.finalized:
             e.finalize()
         step = _Step(self, pre, fwd, bwd, opt, train)

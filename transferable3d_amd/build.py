@@ -7,7 +7,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
 LIB_PATH = os.path.join(HERE, 'libt3d.so')
-SOURCES = ['pointmlp.hip', 'bn_optim.hip', 'fc.hip', 'heads.hip', 'boxpc.hip', 'poolbwd.hip', 'data.hip', 'weak.hip', 'pair.hip']
+SOURCES = ['pointmlp.hip', 'bn_optim.hip', 'fc.hip', 'heads.hip', 'boxpc.hip', 'poolbwd.hip', 'data.hip', 'weak.hip', 'pair.hip', 'version.hip']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
+MARKER = b'T3D_SOURCE_HASH='
 
 
 def lib_source_hash():
@@ -23,22 +25,45 @@ def lib_source_hash():
     return h.hexdigest()[:16]
 
 
+def embedded_hash(path=LIB_PATH):
+    """The source hash compiled into a built library (csrc/version.hip), read from the file without loading it; None if absent."""
+    try:
+        with open(path, 'rb') as fh:
+            data = fh.read()
+    except OSError:
+        return None
+    k = data.find(MARKER)
+    if k < 0:
+        return None
+    return data[k + len(MARKER):k + len(MARKER) + 16].decode('ascii', 'replace')
+
+
 def _stale():
-    if not os.path.exists(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, 't3d.h')]
-    return any(os.path.getmtime(d) > t for d in deps)
+    """The library is current iff the hash compiled into it equals the hash of the sources (mtimes say nothing about a file that
+    travelled through a snapshot or a checkout)."""
+    return embedded_hash() != lib_source_hash()
+
+
+def _object_key(src, extra_flags):
+    """What an object file depends on: its source, every header of csrc/ and the ABI header, the flags."""
+    import hashlib
+    h = hashlib.sha256()
+    deps = [os.path.join(CSRC, src)] + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')) + [os.path.join(INCLUDE, 't3d.h')]
+    for d in deps:
+        with open(d, 'rb') as fh:
+            h.update(fh.read())
+    h.update(' '.join(FLAGS + list(extra_flags)).encode())
+    return h.hexdigest()
 
 
 # Kernels that may spill vector registers to scratch (mangled-name substrings -> why).  Everything else must not: a spill in a GEMM
 # main loop is a silent 10-30 % (round-2 review: five bf16 kernels spilled 10-49 VGPRs unnoticed).  build() parses hipcc's
 # -Rpass-analysis=kernel-resource-usage remarks and fails on any other kernel with `VGPRs Spill` > 0.
-SPILL_ALLOWED = {
-    'k_pointmlp_bwd1ILi256ELi128ELi64E': 'one-pass bf16 backward 256 -> 128: 5 VGPRs (20 B) in the epilogue, hand-scheduled kernel at the 256-register cap',
-    'k_pointmlp_bwd1ILi128ELi256ELi64E': 'one-pass bf16 backward 128 -> 256: 11 VGPRs (48 B), same',
-    'k_pointmlp_fwd_resILi128ELi2E': 'persistent activation-resident bf16 forward, K = 128: 3 VGPRs (16 B) -- the next panel\'s raw chunks travel in registers across the epilogue (round 3: 3.72 -> 3.55 ms per config-4 step with it)',
-    'k_strong_loss': 'scalar loss program: a dynamically indexed 67-float private array (not a spill of the allocator, reported as scratch)',
+SPILL_ALLOWED = {      # substring of the mangled name -> (most VGPRs it may spill, why)
+    'k_pointmlp_bwd1ILi256ELi128ELi64E': (8, 'one-pass bf16 backward 256 -> 128: 5 VGPRs (20 B) in the epilogue, hand-scheduled kernel at the 256-register cap'),
+    'k_pointmlp_bwd1ILi128ELi256ELi64E': (16, 'one-pass bf16 backward 128 -> 256: 11 VGPRs (48 B), same'),
+    'k_pointmlp_fwd_resILi128ELi2E': (6, 'persistent activation-resident bf16 forward, K = 128: 3 VGPRs (16 B) -- the next panel\'s raw chunks travel in registers across the epilogue (round 3: 3.72 -> 3.55 ms per config-4 step with it)'),
+    'k_strong_loss': (0, 'scalar loss program: a dynamically indexed 67-float private array (not a spill of the allocator, reported as scratch)'),
 }
 
 
@@ -62,52 +87,66 @@ def parse_resource_remarks(text):
 
 
 def check_spills(remarks_by_source):
-    """Raises if a kernel outside SPILL_ALLOWED spills VGPRs; returns the report that is written next to the library."""
+    """Raises if a kernel spills more VGPRs than SPILL_ALLOWED grants it (nothing, for a kernel that is not listed); returns the
+    report that is written next to the library.  T3D_ALLOW_SPILLS=1 turns the error into a warning (another hipcc version may
+    allocate differently: the library is functional either way, only slower)."""
     bad, report = [], {}
     for src, text in remarks_by_source.items():
         for name, r in parse_resource_remarks(text).items():
-            if r.get('vgpr_spill', 0) > 0 or r.get('scratch', 0) > 0:
+            n = r.get('vgpr_spill', 0)
+            if n > 0 or r.get('scratch', 0) > 0:
                 report[name] = dict(r, source=src)
-            if r.get('vgpr_spill', 0) > 0 and not any(k in name for k in SPILL_ALLOWED):
-                bad.append((src, name, r))
-    if bad and not os.environ.get('T3D_ALLOW_SPILLS'):       # (experiments only: a build for a same-box A/B of a kernel that is not finished)
-        raise RuntimeError('VGPR spills in kernels that must not spill (transferable3d_amd/build.py SPILL_ALLOWED):\n' +
-                           '\n'.join('  %s: %s %s' % b for b in bad))
+            cap = max([v[0] for k, v in SPILL_ALLOWED.items() if k in name] or [0])
+            if n > cap:
+                bad.append((src, name, 'spills %d VGPRs (allowed: %d)' % (n, cap)))
+    if bad:
+        msg = ('VGPR spills beyond transferable3d_amd/build.py SPILL_ALLOWED (set T3D_ALLOW_SPILLS=1 to build anyway; the spills are '
+               'listed in transferable3d_amd/build/kernel_scratch_report.json):\n' + '\n'.join('  %s: %s %s' % b for b in bad))
+        if not os.environ.get('T3D_ALLOW_SPILLS'):
+            raise RuntimeError(msg)
+        sys.stderr.write('warning: ' + msg + '\n')
     return report
 
 
 def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -shared -fPIC csrc/*.hip -> transferable3d_amd/libt3d.so; fails on an unexpected register spill."""
+    """hipcc --offload-arch=gfx950 -shared -fPIC csrc/*.hip -> transferable3d_amd/libt3d.so; fails on an unexpected register spill.
+    Objects are reused when their source, the headers and the flags are unchanged; the library carries the hash of its sources."""
     if not force and not _stale():
         return LIB_PATH
+    import json
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    objs = []
-    procs = []
-    os.makedirs(os.path.join(HERE, 'build'), exist_ok=True)
+    bdir = os.path.join(HERE, 'build')
+    os.makedirs(bdir, exist_ok=True)
+    src_hash = lib_source_hash()
+    objs, procs, remarks = [], [], {}
     for src in SOURCES:
         path = os.path.join(CSRC, src)
-        if not os.path.exists(path):
+        obj = os.path.join(bdir, src.replace('.hip', '.o'))
+        extra = ['-DT3D_SOURCE_HASH="%s"' % src_hash] if src == 'version.hip' else []
+        key, keyfile, remfile = _object_key(src, extra), obj + '.key', obj + '.remarks'
+        objs.append(obj)
+        if not force and os.path.exists(obj) and os.path.exists(keyfile) and os.path.exists(remfile) and open(keyfile).read() == key:
+            remarks[src] = open(remfile).read()
             continue
-        obj = os.path.join(HERE, 'build', src.replace('.hip', '.o'))
-        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I', INCLUDE, '-Rpass-analysis=kernel-resource-usage',
-               '-c', path, '-o', obj]
+        cmd = [hipcc] + FLAGS + extra + ['-I', INCLUDE, '-Rpass-analysis=kernel-resource-usage', '-c', path, '-o', obj]
         if verbose:
             print(' '.join(cmd))
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-        objs.append(obj)
-    remarks = {}
-    for src, pr in procs:
+        procs.append((src, key, keyfile, remfile, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, key, keyfile, remfile, pr in procs:
         out, _ = pr.communicate()
         if pr.returncode != 0:
             sys.stderr.write('\n'.join(l for l in out.decode().splitlines() if 'kernel-resource-usage' not in l))
             raise RuntimeError('hipcc failed on %s' % src)
         remarks[src] = out.decode()
+        with open(remfile, 'w') as fh:
+            fh.write(remarks[src])
+        with open(keyfile, 'w') as fh:
+            fh.write(key)
     report = check_spills(remarks)
-    import json
-    with open(os.path.join(HERE, 'build', 'kernel_scratch_report.json'), 'w') as fh:
+    with open(os.path.join(bdir, 'kernel_scratch_report.json'), 'w') as fh:
         json.dump(report, fh, indent=1, sort_keys=True)
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs
-    subprocess.check_call(cmd)
+    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs)
+    assert embedded_hash() == src_hash, 'the library does not carry the hash of its sources'
     return LIB_PATH
 
 

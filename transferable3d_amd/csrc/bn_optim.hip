@@ -83,6 +83,17 @@ __global__ __launch_bounds__(256) void k_adam_tf(float* __restrict__ w, const fl
   }
 }
 
+// tf.train.MomentumOptimizer (train_semisup.py:226-228; use_nesterov = False): accum = momentum * accum + g; w -= lr * accum
+__global__ __launch_bounds__(256) void k_momentum_tf(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ acc,
+                                                     int64_t n, const float* __restrict__ hyper, float momentum, float gscale) {
+  const float lr = hyper[1];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float a = fmaf(momentum, acc[i], g[i] * gscale);
+    acc[i] = a;
+    w[i] -= lr * a;
+  }
+}
+
 // counter-based generator: 2 rounds of a 64-bit mix over (seed, step, index)
 __device__ __forceinline__ uint32_t mix_u32(uint64_t x) {
   x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
@@ -190,6 +201,17 @@ extern "C" int t3d_adam_tf_step(float* params, const float* grads, float* m, flo
   if (blocks > 2048) blocks = 2048;
   T3D_LAUNCH(k_adam_tf, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), params, grads, m,
                      v, n, hyper, beta1, beta2, eps, grad_scale);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_momentum_step(float* params, const float* grads, float* accum, int64_t n, const float* hyper, float momentum,
+                                 float grad_scale, t3d_stream_t stream) {
+  if (!params || !grads || !accum || !hyper || n <= 0) return T3D_ERR_ARG;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  T3D_LAUNCH(k_momentum_tf, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), params, grads, accum, n, hyper,
+             momentum, grad_scale);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

@@ -147,13 +147,30 @@ class Graph:
         """TF-form Adam over the trained ranges.  With gradient buckets declared by the backward (data parallel): one launch per
         bucket range behind that bucket's wait marker, in the order the buckets complete."""
         lib, vs, hyper = self.rt.lib, self.vars, self.hyper
-        self.trained_prefixes = prefixes
+        vs.optimizer_kind = 'adam'
 
         def adam(off, n):
             plan.add_raw('t3d_adam_tf_step',
                          lambda s, off=off, n=n: lib.t3d_adam_tf_step(
                              fptr(vs.params[off:]), fptr(vs.grads[off:]), fptr(vs.adam_m[off:]), fptr(vs.adam_v[off:]),
                              n, fptr(hyper), beta1, beta2, eps, grad_scale, s))
+        self._emit_optimizer(plan, prefixes, adam)
+
+    def emit_momentum(self, plan, prefixes=None, momentum=0.9, grad_scale=1.0):
+        """tf.train.MomentumOptimizer (`--optimizer momentum`, train_semisup.py:226-228) over the trained ranges; the accumulator
+        (TF slot `Momentum`) lives in the first moment buffer."""
+        lib, vs, hyper = self.rt.lib, self.vars, self.hyper
+        vs.optimizer_kind = 'momentum'
+
+        def mom(off, n):
+            plan.add_raw('t3d_momentum_step',
+                         lambda s, off=off, n=n: lib.t3d_momentum_step(
+                             fptr(vs.params[off:]), fptr(vs.grads[off:]), fptr(vs.adam_m[off:]), n, fptr(hyper), momentum, grad_scale, s))
+        self._emit_optimizer(plan, prefixes, mom)
+
+    def _emit_optimizer(self, plan, prefixes, launch):
+        vs = self.vars
+        self.trained_prefixes = prefixes
         ranges = vs.trainable_ranges(prefixes)
         if self.buckets:
             covered = sorted(r for b in self.buckets for r in b)
@@ -163,10 +180,10 @@ class Graph:
             for i, b in enumerate(self.buckets):
                 plan.bucket_wait(i)
                 for off, n in b:
-                    adam(off, n)
+                    launch(off, n)
             return
         for off, n in ranges:
-            adam(off, n)
+            launch(off, n)
 
 
 def make_schedule(batch_size, base_lr=1e-3, decay_step=800000, decay_rate=0.5, bn_init_decay=0.5,

@@ -19,6 +19,9 @@ from . import abi
 from .engine import Plan
 
 
+OPTIMIZER_CALLS = ('t3d_adam_tf_step', 't3d_momentum_step')
+
+
 class TrainStep:
     def __init__(self, engine, pre, fwd, bwd=None, opt=None, process_group=None, use_hip_graph=None, force_dist=False,
                  one_graph=None):
@@ -70,7 +73,7 @@ class TrainStep:
             two = two or p.two_streams
         if self.dist and not any(c[0] == Plan.BUCKET for c in calls):
             # a backward plan without markers: ONE bucket (every trained range), reduced between the backward and the optimiser
-            k = next((i for i, c in enumerate(calls) if c[0] == 't3d_adam_tf_step'), len(calls))
+            k = next((i for i, c in enumerate(calls) if c[0] in OPTIMIZER_CALLS), len(calls))
             calls[k:k] = [(Plan.BUCKET, lambda s: 0, 0), (Plan.WAIT, lambda s: 0, 0)]
             lanes[k:k] = [0, 0]
         if not two:       # (data parallel: the flat form -- no bucket marker inside the backward -- takes the scheduled program too)
@@ -99,7 +102,7 @@ class TrainStep:
         # (a wait only adds a dependency earlier) and the Adam launches share ONE segment: [... allreduce, wait, wait, wait, run].
         k = len(prog)
         while k > 0 and (prog[k - 1][0] == 'wait' or (prog[k - 1][0] == 'run' and
-                                                      all(c[0] in ('t3d_adam_tf_step', Plan.JOIN) for c in prog[k - 1][1].calls))):
+                                                      all(c[0] in OPTIMIZER_CALLS + (Plan.JOIN,) for c in prog[k - 1][1].calls))):
             k -= 1
         tail = prog[k:]
         if sum(1 for kind, _ in tail if kind == 'run') > 1:

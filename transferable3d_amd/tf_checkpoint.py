@@ -420,12 +420,17 @@ def saver_variables(vars_, global_step, beta1=0.9, beta2=0.999, step_names=('Var
     t = int(global_step)
     for n in step_names:
         out[n] = np.asarray(t, np.int32)
-    out['beta1_power'] = np.asarray(beta1 ** (t + 1), np.float32)
-    out['beta2_power'] = np.asarray(beta2 ** (t + 1), np.float32)
+    momentum = getattr(vars_, 'optimizer_kind', 'adam') == 'momentum'      # tf.train.MomentumOptimizer: one slot, `<var>/Momentum`
+    if not momentum:
+        out['beta1_power'] = np.asarray(beta1 ** (t + 1), np.float32)
+        out['beta2_power'] = np.asarray(beta2 ** (t + 1), np.float32)
     for name, (off, shape, trainable) in vars_.index.items():
         if not trainable or (optimizer_scopes is not None and not any(name.startswith(p) for p in optimizer_scopes)):
             continue
         n = int(np.prod(shape))
+        if momentum:
+            out[name + '/Momentum'] = vars_.adam_m[off:off + n].detach().cpu().numpy().reshape(shape).copy()
+            continue
         out[name + '/Adam'] = vars_.adam_m[off:off + n].detach().cpu().numpy().reshape(shape).copy()
         out[name + '/Adam_1'] = vars_.adam_v[off:off + n].detach().cpu().numpy().reshape(shape).copy()
     return out
@@ -446,6 +451,8 @@ def restore_variables(vars_, tensors, strict=False):
         if trainable and name + '/Adam' in tensors:
             vars_.adam_m[off:off + n].copy_(torch.as_tensor(np.asarray(tensors[name + '/Adam'], np.float32)).reshape(-1))
             vars_.adam_v[off:off + n].copy_(torch.as_tensor(np.asarray(tensors[name + '/Adam_1'], np.float32)).reshape(-1))
+        if trainable and name + '/Momentum' in tensors:
+            vars_.adam_m[off:off + n].copy_(torch.as_tensor(np.asarray(tensors[name + '/Momentum'], np.float32)).reshape(-1))
     return len(model), (int(tensors['Variable']) if 'Variable' in tensors else None)
 
 

@@ -34,7 +34,8 @@ def build_flags(argv=None):
     cfg.add_argument('--max_epoch', type=int, default=31)
     cfg.add_argument('--batch_size', type=int, default=32)
     cfg.add_argument('--learning_rate', type=float, default=0.001)
-    cfg.add_argument('--optimizer', default='adam')
+    cfg.add_argument('--momentum', type=float, default=0.9)
+    cfg.add_argument('--optimizer', default='adam', help='adam or momentum [default: adam]')
     cfg.add_argument('--decay_step', type=int, default=800000)
     cfg.add_argument('--decay_rate', type=float, default=0.5)
     cfg.add_argument('--use_one_hot', action='store_true')
@@ -58,9 +59,10 @@ def build_flags(argv=None):
 
 
 def train(FLAGS, rt=None, log=print):
-    import torch
-    if rt is None and torch.cuda.is_available():
-        torch.cuda.set_device(FLAGS.gpu)
+    # data parallel: one process per GPU, own samples per replica, one all-reduce of the gradients per step; rank 0 logs
+    world, rank, pg = api.init_data_parallel(rt, FLAGS.gpu)
+    if rank != 0:
+        log = lambda *a, **k: None
     B, N, C = FLAGS.batch_size, FLAGS.num_point, FLAGS.NUM_CHANNELS
     os.makedirs(FLAGS.log_dir, exist_ok=True)
     with api.Graph(rt=rt, seed=FLAGS.seed, dtype=FLAGS.dtype).as_default() as g:
@@ -72,8 +74,8 @@ def train(FLAGS, rt=None, log=print):
         is_training_pl = api.is_training_placeholder()                   # train_boxpc.py:228
         pred, end_points = MODEL.get_model((box_reg, pc_pl), is_training_pl, one_hot_vec_pl, use_one_hot_vec=FLAGS.use_one_hot, c=FLAGS)
         loss = MODEL.get_loss(pred, (y_box_iou_pl, (y_center_delta_pl, y_dims_delta_pl, y_orient_delta_pl)), end_points, c=FLAGS)
-        train_op = api.AdamOptimizer(FLAGS.learning_rate, decay_step=FLAGS.decay_step, decay_rate=FLAGS.decay_rate).minimize(loss)
-        sess = api.Session()
+        train_op = api.make_optimizer(FLAGS, world_size=world).minimize(loss)      # train_boxpc.py:245-250
+        sess = api.Session(process_group=pg, dropout_seed=1234 + rank)
         if FLAGS.restore_model_path:
             restore_model(g, FLAGS.restore_model_path)
         step, mean_loss = 0, 0.0
@@ -117,16 +119,16 @@ def train(FLAGS, rt=None, log=print):
         ds = eval_source = None
         from transferable3d_amd.dataset import open_eval_source, open_training_set
         # BoxPCFitDataset(classes=FLAGS.TRAIN_CLS, ...) (train_boxpc.py:100-108)
-        ds = open_training_set(g.rt, FLAGS, C, classes=list(FLAGS.SUNRGBD_SEMI_TRAIN_CLS) if FLAGS.frustum_file else None, seed=FLAGS.seed)
+        ds = open_training_set(g.rt, FLAGS, C, classes=list(FLAGS.SUNRGBD_SEMI_TRAIN_CLS) if FLAGS.frustum_file else None, seed=FLAGS.seed + 17 * rank)
         if ds is not None:
             if FLAGS.eval_batches > 0 or FLAGS.eval_file:
                 eval_source = open_eval_source(g, FLAGS, classes=list(FLAGS.SUNRGBD_SEMI_TRAIN_CLS), boxpc_perturb=FLAGS)
             # BOXPC_SAMPLING_METHOD 'SAMPLE': class-balanced batches with probability BOXPC_SAMPLE_EQUAL_CLASS_WITH_PROB
             # (train_boxpc.py:323-328); 'BATCH': the epoch permutation
             eq = float(FLAGS.BOXPC_SAMPLE_EQUAL_CLASS_WITH_PROB) if FLAGS.BOXPC_SAMPLING_METHOD == 'SAMPLE' else 0.0
-            g.use_device_dataset(ds, seed=FLAGS.seed * 7919, boxpc_perturb=FLAGS, equal_class_prob=eq)
+            g.use_device_dataset(ds, seed=FLAGS.seed * 7919 + rank, boxpc_perturb=FLAGS, equal_class_prob=eq)
             if eq == 0.0:            # 'BATCH': an epoch is at most one pass over the data set (whole batches, train_boxpc.py:316-321)
-                FLAGS.steps_per_epoch = ds.partition(0, 1, B, FLAGS.steps_per_epoch)
+                FLAGS.steps_per_epoch = ds.partition(rank, world, B, FLAGS.steps_per_epoch)
         if not FLAGS.steps_per_epoch:
             FLAGS.steps_per_epoch = 100
         for epoch in range(FLAGS.max_epoch):
@@ -149,15 +151,15 @@ def train(FLAGS, rt=None, log=print):
                 log('**** EPOCH %03d ****  mean loss: %f  (%.1f frustums/s, samples made on the device)' % (
                     epoch, mean_loss, FLAGS.steps_per_epoch * B / (time.time() - t0)))
                 report('train (every 10th step)', stats)
-                if FLAGS.eval_batches > 0:
+                if FLAGS.eval_batches > 0 and rank == 0:
                     eval_one_epoch(epoch)
-                if epoch % 5 == 0:
+                if epoch % 5 == 0 and rank == 0:
                     sess.check_riders()      # never checkpoint weights a timed-out rider barrier may have corrupted
                     log('Model saved in file: %s' % save_model(FLAGS.log_dir, epoch, g, FLAGS.ckpt_format))
                 continue
             stats = new_stats()
             for _ in range(FLAGS.steps_per_epoch):
-                feed = feed_of(make_batch(B, N, C, seed=FLAGS.seed * 1000003 + step, boxpc=True))
+                feed = feed_of(make_batch(B, N, C, seed=FLAGS.seed * 1000003 + step * world + rank, boxpc=True))
                 feed[is_training_pl] = True
                 out = sess.run(fetch_stats + [train_op], feed_dict=feed)
                 record_batch(stats[0], stats[1], stats[2], fit_lo, out[0], out[1], out[2:5], g.inputs)
@@ -167,14 +169,16 @@ def train(FLAGS, rt=None, log=print):
             log('**** EPOCH %03d ****  mean loss: %f  (%.1f frustums/s incl. host batch synthesis)' % (
                 epoch, mean_loss, FLAGS.steps_per_epoch * B / (time.time() - t0)))
             report('train', stats)
-            if FLAGS.eval_batches > 0:
+            if FLAGS.eval_batches > 0 and rank == 0:
                 eval_one_epoch(epoch)
-            if epoch % 5 == 0:
+            if epoch % 5 == 0 and rank == 0:
                 sess.check_riders()      # never checkpoint weights a timed-out rider barrier may have corrupted
                 path = save_model(FLAGS.log_dir, epoch, g, FLAGS.ckpt_format)
                 log('Model saved in file: %s' % path)
         sess.check_riders()
-        return g.vars.state_dict(), mean_loss
+        final = g.vars.state_dict()
+    api.finish_data_parallel(world)
+    return final, mean_loss
 
 
 if __name__ == '__main__':

@@ -151,23 +151,7 @@ def end_points_logits(end_points, sess):
 
 
 def train(FLAGS, rt=None, log=print):
-    import torch
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    pg = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC (RCCL between the ranks of one node)
-        on_gpu = torch.cuda.is_available() and rt is None
-        if on_gpu:
-            torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
-        dist.init_process_group('nccl' if on_gpu else 'gloo')
-        pg = dist.group.WORLD
-    elif rt is None and torch.cuda.is_available():
-        torch.cuda.set_device(FLAGS.gpu)
-    if FLAGS.optimizer != 'adam':
-        raise NotImplementedError('only --optimizer adam (every published recipe) is on the hot path')
+    world, rank, pg = api.init_data_parallel(rt, FLAGS.gpu)
     B, N, C = FLAGS.batch_size, FLAGS.num_point, FLAGS.NUM_CHANNELS
     os.makedirs(FLAGS.log_dir, exist_ok=True)
     if rank == 0:
@@ -183,8 +167,7 @@ def train(FLAGS, rt=None, log=print):
         labels = (y_seg_pl, y_centers_pl, y_orient_cls_pl, y_orient_reg_pl, y_dims_cls_pl, y_dims_reg_pl, R0_rect_pl, P_pl,
                   Rtilt_pl, K_pl, rot_frust_pl, box2D_pl, img_dim_pl, is_data_2D_pl)
         semi_loss = MODEL.get_semi_loss(pred, labels, end_points, c=FLAGS)
-        optimizer = api.AdamOptimizer(FLAGS.learning_rate, decay_step=FLAGS.decay_step, decay_rate=FLAGS.decay_rate,
-                                      world_size=world)
+        optimizer = api.make_optimizer(FLAGS, world_size=world)      # train_semisup.py:226-231 (--optimizer adam | momentum)
         train_op = optimizer.minimize(semi_loss)
         sess = api.Session(process_group=pg, dropout_seed=1234 + rank)
         if FLAGS.restore_model_path:
@@ -267,9 +250,7 @@ def train(FLAGS, rt=None, log=print):
                     log('Model saved in file: %s' % path)
         sess.check_riders()
         final = g.vars.state_dict()
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    api.finish_data_parallel(world)
     return final, loss_sum / max(FLAGS.steps_per_epoch, 1)
 
 

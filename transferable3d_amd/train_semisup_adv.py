@@ -36,7 +36,8 @@ def build_flags(argv=None):
     cfg.add_argument('--max_epoch', type=int, default=31)
     cfg.add_argument('--batch_size', type=int, default=32)
     cfg.add_argument('--learning_rate', type=float, default=0.001)
-    cfg.add_argument('--optimizer', default='adam')
+    cfg.add_argument('--momentum', type=float, default=0.9)
+    cfg.add_argument('--optimizer', default='adam', help='adam or momentum [default: adam]')
     cfg.add_argument('--decay_step', type=int, default=800000)
     cfg.add_argument('--decay_rate', type=float, default=0.5)
     cfg.add_argument('--use_one_hot', action='store_true')
@@ -145,9 +146,11 @@ def eval_one_epoch(sess, pls, is_training_pl, logits_t, end_points, FLAGS, epoch
 
 
 def train(FLAGS, rt=None, log=print):
-    import torch
-    if rt is None and torch.cuda.is_available():
-        torch.cuda.set_device(FLAGS.gpu)
+    # data parallel (BASELINE configs[3] is the 8-GPU config): one process per GPU, every replica its own batches, ONE
+    # all-reduce of the var_list's gradient range per optimiser step, rank 0 logs and checkpoints
+    world, rank, pg = api.init_data_parallel(rt, FLAGS.gpu)
+    if rank != 0:
+        log = lambda *a, **k: None
     B, N, C = FLAGS.batch_size, FLAGS.num_point, FLAGS.NUM_CHANNELS
     os.makedirs(FLAGS.log_dir, exist_ok=True)
     if FLAGS.SEMI_TRAIN_BOXPC_MODEL or FLAGS.SEMI_ADV_ITERS_FOR_D:
@@ -170,9 +173,8 @@ def train(FLAGS, rt=None, log=print):
             train_vars.append('class_agnostic/tnet')
         if FLAGS.SEMI_TRAIN_BOX_TRAIN_CLASS_AG_BOX:
             train_vars.append('class_agnostic/box')
-        train_op = api.AdamOptimizer(FLAGS.learning_rate, decay_step=FLAGS.decay_step, decay_rate=FLAGS.decay_rate).minimize(
-            semi_loss, var_list=train_vars)
-        sess = api.Session()
+        train_op = api.make_optimizer(FLAGS, world_size=world).minimize(semi_loss, var_list=train_vars)      # train_semisup_adv.py:296-298, 415-422
+        sess = api.Session(process_group=pg, dropout_seed=1234 + rank)
         if FLAGS.init_class_ag_path:
             log('restored %d class_agnostic variables' % load_variable_scopes_from_ckpt(
                 g.vars, FLAGS.init_class_ag_path, 'class_agnostic', adam_scopes=[v for v in train_vars if v.startswith('class_agnostic')]))
@@ -186,11 +188,11 @@ def train(FLAGS, rt=None, log=print):
         iters = 2 if FLAGS.SEMI_SAMPLING_METHOD == 'ALTERNATE_BATCH' else 1
         ds = eval_source = None
         from transferable3d_amd.dataset import open_training_set
-        ds = open_training_set(g.rt, FLAGS, C, classes=None, seed=FLAGS.seed)
+        ds = open_training_set(g.rt, FLAGS, C, classes=None, seed=FLAGS.seed + 17 * rank)
         if ds is not None:
             if iters == 2:
                 ds.split_by_class(test_ids)
-            g.use_device_dataset(ds, seed=FLAGS.seed * 7919, alternate=(iters == 2),
+            g.use_device_dataset(ds, seed=FLAGS.seed * 7919 + rank, alternate=(iters == 2),
                                  equal_class_prob=float(FLAGS.SEMI_SAMPLE_EQUAL_CLASS_WITH_PROB))   # train_semisup_adv.py:557,573
         for epoch in range(FLAGS.max_epoch):
             t0, loss_sum = time.time(), 0.0
@@ -207,13 +209,13 @@ def train(FLAGS, rt=None, log=print):
                     step += 1
                 mean_loss = loss_sum / n_logged
                 log('**** EPOCH %03d ****  mean loss: %f  (%.1f frustums/s, batches assembled on the device)' % (
-                    epoch, mean_loss, n_steps * B / (time.time() - t0)))
+                    epoch, mean_loss, n_steps * B * world / (time.time() - t0)))
             for _ in range(0 if ds is not None else FLAGS.steps_per_epoch):
                 for iteration in range(iters):
-                    b = make_batch(B, N, C, seed=FLAGS.seed * 1000003 + step)
+                    b = make_batch(B, N, C, seed=FLAGS.seed * 1000003 + step * world + rank)
                     if iters == 2:                         # all-2D batch (classes without 3-D labels), then all-3D batch
                         ids = test_ids if iteration == 0 else train_ids
-                        cls = np.asarray(ids)[np.random.RandomState(step).randint(0, len(ids), size=B)]
+                        cls = np.asarray(ids)[np.random.RandomState(step * world + rank).randint(0, len(ids), size=B)]
                         b['one_hot_vec'] = np.eye(10, dtype=np.float32)[cls]
                         b['y_dims_cls'] = cls.astype(np.int32)
                         b['is_data_2D'][:] = 1 if iteration == 0 else 0
@@ -224,7 +226,7 @@ def train(FLAGS, rt=None, log=print):
                     loss_val, _ = sess.run([semi_loss, train_op], feed_dict=feed)
                     loss_sum += float(loss_val)
                     step += 1
-            if FLAGS.eval_batches > 0 or FLAGS.eval_file:
+            if rank == 0 and (FLAGS.eval_batches > 0 or FLAGS.eval_file):
                 if ds is not None and eval_source is None:
                     from transferable3d_amd.dataset import open_eval_source
                     eval_source = open_eval_source(g, FLAGS, classes=list(FLAGS.TEST_CLS))
@@ -232,13 +234,15 @@ def train(FLAGS, rt=None, log=print):
             if ds is None:
                 mean_loss = loss_sum / (FLAGS.steps_per_epoch * iters)
                 log('**** EPOCH %03d ****  mean loss: %f  (%.1f frustums/s incl. host batch synthesis)' % (
-                    epoch, mean_loss, FLAGS.steps_per_epoch * iters * B / (time.time() - t0)))
-            if epoch % 5 == 0:
+                    epoch, mean_loss, FLAGS.steps_per_epoch * iters * B * world / (time.time() - t0)))
+            if epoch % 5 == 0 and rank == 0:
                 sess.check_riders()      # never checkpoint weights a timed-out rider barrier may have corrupted
                 path = save_model(FLAGS.log_dir, epoch, g, FLAGS.ckpt_format, optimizer_scopes=train_vars)
                 log('Model saved in file: %s' % path)
         sess.check_riders()
-        return g.vars.state_dict(), mean_loss
+        final = g.vars.state_dict()
+    api.finish_data_parallel(world)
+    return final, mean_loss
 
 
 if __name__ == '__main__':
