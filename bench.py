@@ -602,7 +602,7 @@ def main():
         return 0
 
     flat_default = os.environ.get('T3D_DP_FLAT', '1') == '1'
-    if (trainstep.dist and world > 1 and args.workload == 'A' and not pipelined and os.environ.get('T3D_DP_BOTH_MODES', '1') == '1'):
+    if (trainstep.dist and args.workload == 'A' and not pipelined and os.environ.get('T3D_DP_BOTH_MODES', '1') == '1'):      # (world 1: T3D_FORCE_DIST=1)
         # One driver run decides flat vs bucketed (DESIGN section 6 only has a paper estimate): <= 20 timed steps of the NON-default
         # data-parallel mode on a second step object, reported beside the default's.  Under a watchdog that prints the headline line
         # (already complete) and leaves if this extra leg does not finish.
@@ -619,7 +619,7 @@ def main():
         with Watchdog(int(os.environ.get('T3D_DP_ALT_TIMEOUT_S', '150')), 'the %s data-parallel mode (informational leg)' % name_alt, give_up):
             dist.barrier()
             g2, model2, step2, _ = build_training_step(
-                rt, args.workload, B, N, C, world=world, rank=rank, process_group=dist.group.WORLD, force_dist=False,
+                rt, args.workload, B, N, C, world=world, rank=rank, process_group=dist.group.WORLD, force_dist=world == 1,
                 flat_allreduce=not flat_default, use_hip_graph=not args.no_graph, inline_dropout=True, dropout_seed=1234, seed=0,
                 dtype=args.dtype)
             model2.inputs.load(batch)

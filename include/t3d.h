@@ -462,6 +462,10 @@ typedef struct {
   /* optional: d loss / d soft_mask[m] (soft_mask = softmax(logits)[:,1]) from t3d_weak_loss, added to the logit gradients -- the
    * head is then run a second time, behind the box losses, and rewrites dz, the partials and dw_part (NULL: none) */
   const float* dsoft;        /* [M] or NULL */
+  /* optional: the `oracle_mask` of get_semi_model_final (semisup_v1_sunrgbd.py:161-162; test_semisup.py:75 feeds y_seg): the
+   * logits that leave the head -- written, masked on, fed to the cross-entropy -- are stack([1 - m, m]) instead of conv10's; no
+   * gradient reaches conv9 then (the stacked tensor is a constant of the graph). */
+  const int32_t* oracle_mask; /* [M] or NULL */
 } t3d_seg_head_args;
 int t3d_seg_head(const t3d_seg_head_args* args, t3d_stream_t stream);
 
@@ -582,6 +586,9 @@ typedef struct {
   float* rep; int ld_rep;         /* [M, ld_rep] */
   float* box_out;                 /* [B,7] or NULL */
   int M, rows_per_frustum;
+  /* optional: `--mask_pc_for_boxpc` of test_semisup.py:103-105 -- the net sees pc * mask (every channel of a background point is 0,
+   * so its six distances are those of the origin) */
+  const float* rowmask;           /* [M] 0/1 or NULL */
 } t3d_boxpc_rep_args;
 int t3d_boxpc_rep(const t3d_boxpc_rep_args* args, t3d_stream_t stream);
 

@@ -454,12 +454,15 @@ def mlps_with_dropout(ctx, x, scope, n_layers, activations, keep_probs):
     return net
 
 
-def get_semi_model_final(ctx, pc, one_hot_vec, use_one_hot, c, norm_box2D=None):
-    """semisup_v1_sunrgbd.py:132-230 (SEMI_MODEL F)."""
+def get_semi_model_final(ctx, pc, one_hot_vec, use_one_hot, c, norm_box2D=None, oracle_mask=None):
+    """semisup_v1_sunrgbd.py:132-230 (SEMI_MODEL F).  oracle_mask [B,N] (161-162): logits = stack([1 - m, m], axis=2)."""
     ep = {'point_cloud': pc, 'class_one_hot': one_hot_vec,
           'class_ids': torch.argmax(one_hot_vec, dim=1).to(torch.int32)}
     p = 'class_agnostic/'
     logits = v1_inst_seg(ctx, pc, None, p + 'inst_seg', ep)
+    if oracle_mask is not None:
+        om = torch.as_tensor(oracle_mask).to(pc.dtype)
+        logits = torch.stack([1 - om, om], dim=2)
     ep['logits'] = logits
     mask, mean, xyz, xyz1 = subtract_points_mean(pc, logits, ctx)
     ep['mask'] = mask
@@ -959,21 +962,24 @@ def stage_c_forward_backward(P, batch, c, train_classes, bn_decay_val=0.5, dtype
     return loss, ep, grads, ctx.ema_updates
 
 
-def stage_c_inference(P, batch, c, refine_num, dtype=torch.float64, use_one_hot=True):
+def stage_c_inference(P, batch, c, refine_num, dtype=torch.float64, use_one_hot=True, use_oracle_mask=False, mask_pc_for_boxpc=False):
     """The inference graph of test_semisup.py:61-149 for SEMI_MODEL F: every net in inference mode (moving statistics,
     no dropout); the F_ box in regression form is refined `refine_num` times by the Box-PC net,
     box <- box - w * delta(box, pc), w = 1 - p_fit if SEMI_WEIGH_BOXPC_DELTA_DURING_TEST else 1; the F2_ heads are
-    the F_ heads minus the accumulated deltas (136-142)."""
+    the F_ heads minus the accumulated deltas (136-142).  use_oracle_mask (test_semisup.py:75): y_seg replaces the seg logits;
+    mask_pc_for_boxpc (103-105): the Box-PC net sees pc * float(argmax(logits, 2))."""
     Pl = {k: val.detach().to(dtype) for k, val in P.items()}
     ctx = Ctx(Pl, is_training=False, bn_decay=0.5, dropout_masks={})
     pc = torch.as_tensor(batch['pc'], dtype=dtype)
     oh = torch.as_tensor(batch['one_hot_vec'], dtype=dtype)
-    pred, ep = get_semi_model_final(ctx, pc, oh, use_one_hot, c, norm_box2D=batch_norm_box2D(batch, c, dtype))
+    pred, ep = get_semi_model_final(ctx, pc, oh, use_one_hot, c, norm_box2D=batch_norm_box2D(batch, c, dtype),
+                                    oracle_mask=batch['y_seg'] if use_oracle_mask else None)
     cur = ep['F_pred_box_reg']
     tot_c, tot_s, tot_a = torch.zeros_like(cur[0]), torch.zeros_like(cur[1]), torch.zeros_like(cur[2])
     fit = None
+    pc_boxpc = pc * torch.argmax(ep['logits'], dim=2).to(dtype)[:, :, None] if mask_pc_for_boxpc else pc
     for _ in range(int(refine_num)):
-        _, ep_b = boxpc_get_model(ctx, cur, pc, oh, False, c, scope_prefix='D_boxpc_branch/')
+        _, ep_b = boxpc_get_model(ctx, cur, pc_boxpc, oh, False, c, scope_prefix='D_boxpc_branch/')
         fit = torch.softmax(ep_b['boxpc_fit_logits'], dim=-1)[:, 1]
         w = (1 - ep_b['logits_for_weigh']) if c.SEMI_WEIGH_BOXPC_DELTA_DURING_TEST else torch.ones_like(fit)
         dc, da, ds = ep_b['boxpc_delta_center'] * w[:, None], ep_b['boxpc_delta_angle'] * w, ep_b['boxpc_delta_size'] * w[:, None]

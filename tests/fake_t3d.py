@@ -863,6 +863,9 @@ class FakeLib:
         d = np.maximum(z, 0) * keep
         w = arr(p.w, K, 2).astype(np.float64)
         logits = (d @ w + arr(p.bias, 2)).astype(np.float32)
+        if p.oracle_mask:      # semisup_v1_sunrgbd.py:161-162
+            om = arr(p.oracle_mask, M).astype(np.float32)
+            logits = np.stack([1 - om, om], 1)
         arr(p.logits, M, 2)[:] = logits
         mask = (logits[:, 0] < logits[:, 1]).astype(np.float32)
         arr(p.mask, M)[:] = mask
@@ -887,6 +890,8 @@ class FakeLib:
                     p1 = np.exp(l64[:, 1] - lse)
                     gs = arr(p.dsoft, M).astype(np.float64) * p1 * (1 - p1)
                     g = g + np.stack([-gs, gs], 1)
+                if p.oracle_mask:
+                    g = np.zeros_like(g)
                 part[:, 5:7] = g.reshape(T, 128, 2).sum(1)
                 arr(p.dw_part, T, K, 2)[:] = np.einsum('tik,tij->tkj', d.reshape(T, 128, K), g.reshape(T, 128, 2))
                 dz = np.where(z > 0, (g @ w.T) * keep, 0.0).astype(np.float32)
@@ -1133,6 +1138,8 @@ class FakeLib:
         if p.box_out:
             arr(p.box_out, B, 7)[:] = np.concatenate([center, dims, theta[:, None]], 1)
         pc = arr(p.pc, M, p.ld_pc).astype(np.float64)
+        if p.rowmask:          # test_semisup.py:103-105
+            pc = pc * arr(p.rowmask, M).astype(np.float64)[:, None]
         rep = arr(p.rep, M, p.ld_rep)
         rep[:] = 0
         rep[:, :Cc] = pc[:, :Cc]

@@ -245,14 +245,16 @@ def check_config0_single_frustum_forward(rt, seed=5):
     return worst
 
 
-def check_stage_c_inference(rt, refine):
+def check_stage_c_inference(rt, refine, use_oracle_mask=False, mask_pc_for_boxpc=False):
     """test_semisup.py:61-262 on synthetic frustums: the inference graph of SEMI_MODEL F (inference-mode batch-norm, no
-    dropout, `--refine` Box-PC refinement steps), the F2_ heads and the detection score, against the oracle."""
+    dropout, `--refine` Box-PC refinement steps), the F2_ heads and the detection score, against the oracle.  use_oracle_mask
+    (test_semisup.py:61,75, semisup_v1_sunrgbd.py:161-162) and --mask_pc_for_boxpc (test_semisup.py:103-105) on both sides."""
     from transferable3d_amd import test_semisup as TS
     from transferable3d_amd.synthetic import make_batch
     B, N, C = 4, 256, 4
     FLAGS = TS.build_flags(['--semi_type', 'F', '--use_one_hot', '--num_point', str(N), '--num_channels', str(C), '--batch_size', str(B),
-                            '--refine', str(refine), '--pred_prefix', 'F2_', '--use_boxpc_fit_prob' if refine else '--synthetic'])
+                            '--refine', str(refine), '--pred_prefix', 'F2_', '--use_boxpc_fit_prob' if refine else '--synthetic'] +
+                           (['--mask_pc_for_boxpc'] if mask_pc_for_boxpc else []))
     rng = np.random.RandomState(3)
     P = R.stage_c_params(rng, C)
     for k in P:                                     # non-trivial moving statistics
@@ -261,13 +263,17 @@ def check_stage_c_inference(rt, refine):
         elif k.endswith('moving_variance'):
             P[k] = torch.as_tensor(0.5 + rng.uniform(size=tuple(P[k].shape)))
     sess, ops = TS.get_model(FLAGS, B, N, C, rt=rt,
-                             state_dict={k: v.numpy() for k, v in P.items()})
+                             state_dict={k: v.numpy() for k, v in P.items()}, use_oracle_mask=use_oracle_mask)
     batches = [make_batch(B, N, C, seed=40 + i) for i in range(2)]
     pc, oh = np.concatenate([b['pc'] for b in batches]), np.concatenate([b['one_hot_vec'] for b in batches])
-    seg, centers, hcls, hres, scls, sres, scores = TS.inference(sess, ops, pc, oh, B, prefix='F2_', use_boxpc_fit_prob=bool(refine))
+    seg_gt = np.concatenate([b['y_seg'] for b in batches])
+    seg, centers, hcls, hres, scls, sres, scores = TS.inference(sess, ops, pc, oh, B, prefix='F2_', use_boxpc_fit_prob=bool(refine),
+                                                                oracle_mask=seg_gt if use_oracle_mask else None)
+    if use_oracle_mask:
+        assert np.array_equal(seg, seg_gt)                      # argmax(stack([1 - m, m])) = m
     c = R.default_config(SEMI_REFINE_USING_BOXPC_DELTA_NUM=refine)
     for i, b in enumerate(batches):
-        pred, ep = R.stage_c_inference(P, b, c, refine)
+        pred, ep = R.stage_c_inference(P, b, c, refine, use_oracle_mask=use_oracle_mask, mask_pc_for_boxpc=mask_pc_for_boxpc)
         sl = slice(i * B, (i + 1) * B)
         num = lambda t: t.detach().numpy()
         assert np.abs(centers[sl] - num(ep['F2_center'])).max() < 1e-4

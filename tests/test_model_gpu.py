@@ -144,6 +144,13 @@ def test_inference_graph_with_iterated_boxpc_refinement(hip_lib, refine):
     check_stage_c_inference(Runtime(lib=hip_lib), refine)
 
 
+@pytest.mark.parametrize('oracle,mask_pc', [(True, False), (False, True)])
+def test_inference_graph_with_oracle_mask_and_masked_boxpc_input(hip_lib, oracle, mask_pc):
+    """use_oracle_mask (test_semisup.py:61,75 -> semisup_v1_sunrgbd.py:161-162) and --mask_pc_for_boxpc (test_semisup.py:103-105)."""
+    from model_check import check_stage_c_inference
+    check_stage_c_inference(Runtime(lib=hip_lib), 2, use_oracle_mask=oracle, mask_pc_for_boxpc=mask_pc)
+
+
 def test_boxpc_and_stage_c_match_golden_vectors(hip_lib):
     from model_check import check_golden_boxpc, check_golden_stage_c
     check_golden_boxpc(Runtime(lib=hip_lib))

@@ -108,6 +108,13 @@ def test_inference_graph_with_iterated_boxpc_refinement(refine):
     check_stage_c_inference(Runtime(device='cpu', lib=FakeLib()), refine)
 
 
+@pytest.mark.parametrize('oracle,mask_pc', [(True, False), (False, True), (True, True)])
+def test_inference_graph_with_oracle_mask_and_masked_boxpc_input(oracle, mask_pc):
+    """use_oracle_mask (test_semisup.py:61,75 -> semisup_v1_sunrgbd.py:161-162) and --mask_pc_for_boxpc (test_semisup.py:103-105)."""
+    from model_check import check_stage_c_inference
+    check_stage_c_inference(Runtime(device='cpu', lib=FakeLib()), 2, use_oracle_mask=oracle, mask_pc_for_boxpc=mask_pc)
+
+
 def test_stage_c_and_inference_match_golden_vectors():
     from model_check import check_golden_stage_c
     check_golden_stage_c(Runtime(device='cpu', lib=FakeLib()))

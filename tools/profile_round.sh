@@ -13,15 +13,20 @@ out=$root/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 python3 $root/bench.py $flags > $out/bench.json 2> $out/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o run -- python3 $root/bench.py $flags --no_cpu_baseline > $out/trace_bench.json 2> $out/trace.log
-small="--steps 4 --warmup 2 --no_cpu_baseline --no_graph --profile_steps 0"
+# (--no_other_configs in every profiler pass: the side runs of configs[2..4] are child processes that inherit the profiler and would
+# write their own counter / stats files into the same directories)
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o run -- python3 $root/bench.py $flags --no_cpu_baseline --no_other_configs > $out/trace_bench.json 2> $out/trace.log
+small="--steps 4 --warmup 2 --no_cpu_baseline --no_other_configs --no_graph --profile_steps 0"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o run -- python3 $root/bench.py $flags $small > $out/pmc_fetch.json 2> $out/pmc_fetch.log
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o run -- python3 $root/bench.py $flags $small > $out/pmc_write.json 2> $out/pmc_write.log
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_mfma -o run -- python3 $root/bench.py $flags $small > $out/pmc_mfma.json 2> $out/pmc_mfma.log
 cd $root
 python3 tools/pmc_traffic.py $out/pmc_fetch $out/pmc_write -o $out/pmc_traffic.json $(echo "$flags" | sed 's/--steps [0-9]*//; s/--warmup [0-9]*//') > $out/pmc_traffic.txt 2>&1
 python3 tools/pmc_mfma.py $out/pmc_mfma -o $out/pmc_mfma.json > $out/pmc_mfma.txt 2>&1
-cp $(find $out/trace -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv 2>/dev/null
+# the one process that was profiled wrote one stats file; more than one means a child slipped in: take the largest and say so
+nstats=$(find $out/trace -name "*kernel_stats.csv" | wc -l)
+[ "$nstats" != "1" ] && echo "WARNING: $nstats kernel_stats.csv files under $out/trace" | tee -a $out/trace.log
+cp "$(find $out/trace -name "*kernel_stats.csv" -printf '%s %p\n' | sort -nr | head -1 | cut -d' ' -f2-)" $out/kernel_stats.csv 2>/dev/null
 # raw traces are large; they go only once every summary exists
 [ -s $out/pmc_traffic.json ] && [ -s $out/pmc_mfma.json ] && [ -s $out/kernel_stats.csv ] && rm -rf $out/trace $out/pmc_fetch $out/pmc_write $out/pmc_mfma
 ls -la $out

@@ -171,7 +171,7 @@ class SegHeadArgs(C.Structure):
                 ('labels', I), ('is_data_2D', I), ('pc', F), ('ld_pc', i32), ('ce_weight', f32), ('logits', F),
                 ('mask', F), ('part', F), ('dz', F), ('psum_dz', F), ('psum_dzy', F), ('dw_part', F),
                 ('M', i32), ('K', i32), ('rows_per_frustum', i32), ('B', i32), ('drop_seed', C.c_uint32), ('drop_hyper', F),
-                ('dtype', i32), ('dsoft', F)]
+                ('dtype', i32), ('dsoft', F), ('oracle_mask', I)]
 
 
 SMALL_KIND = {'t3d_bn_bwd_finalize': 1, 't3d_fc_bwd': 2, 't3d_fc_dinput': 3, 't3d_dy_colsum': 4}      # t3d.h T3D_SMALL_* (t3d_small_pair)
@@ -223,7 +223,7 @@ class Schedule(C.Structure):
 
 class BoxPcRepArgs(C.Structure):
     _fields_ = [('pc', F), ('ld_pc', i32), ('C', i32), ('center', F), ('dims', F), ('theta', F), ('y_dims_cls', I),
-                ('y_orient_cls', I), ('rep', F), ('ld_rep', i32), ('box_out', F), ('M', i32), ('rows_per_frustum', i32)]
+                ('y_orient_cls', I), ('rep', F), ('ld_rep', i32), ('box_out', F), ('M', i32), ('rows_per_frustum', i32), ('rowmask', F)]
 
 
 class BoxPcRepBwdArgs(C.Structure):

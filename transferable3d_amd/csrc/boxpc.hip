@@ -51,8 +51,9 @@ __global__ __launch_bounds__(256) void k_boxpc_rep(const t3d_boxpc_rep_args p) {
   const Box x = load_box(p, b);
   const float* src = p.pc + (size_t)m * p.ld_pc;
   float* dst = p.rep + (size_t)m * p.ld_rep;
-  for (int i = 0; i < p.C; ++i) dst[i] = src[i];
-  const float tx = src[0] - x.cx, ty = src[1] - x.cy, tz = src[2] - x.cz;
+  const float km = p.rowmask ? p.rowmask[m] : 1.f;      // --mask_pc_for_boxpc (test_semisup.py:103-105): the net sees pc * mask
+  for (int i = 0; i < p.C; ++i) dst[i] = src[i] * km;
+  const float tx = src[0] * km - x.cx, ty = src[1] * km - x.cy, tz = src[2] * km - x.cz;
   const float u = x.c * tx - x.s * tz, q = x.s * tx + x.c * tz;
   dst[p.C + 0] = 0.5f * x.l - u;
   dst[p.C + 1] = 0.5f * x.l + u;

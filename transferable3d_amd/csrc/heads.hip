@@ -94,6 +94,8 @@ __global__ __launch_bounds__(64 * SH_WAVES) void k_seg_head(const t3d_seg_head_a
   for (int i = 1; i < SH_ROWS; ++i) { q0 = lane == i ? q0r[i] : q0; q1 = lane == i ? q1r[i] : q1; }
   const bool own = lane < SH_ROWS;
   const int row = rbase + (lane & (SH_ROWS - 1));
+  const bool oracle = p.oracle_mask != nullptr;      // uniform: logits = stack([1 - m, m]) (semisup_v1_sunrgbd.py:161-162)
+  if (oracle) { const float om = (float)p.oracle_mask[row]; q0 = 1.f - om; q1 = om; }
   const float m = q0 < q1 ? 1.f : 0.f;
   if (own) {
     *reinterpret_cast<float2*>(p.logits + (size_t)row * 2) = make_float2(q0, q1);
@@ -117,6 +119,7 @@ __global__ __launch_bounds__(64 * SH_WAVES) void k_seg_head(const t3d_seg_head_a
         g0 -= gs;
         g1 += gs;
       }
+      if (oracle) { g0 = 0.f; g1 = 0.f; }      // the stacked logits are a constant: nothing flows back into conv10 / conv9
     }
   }
   cnt = wave_sum_dpp(cnt); sx = wave_sum_dpp(sx); sy = wave_sum_dpp(sy); sz = wave_sum_dpp(sz);

@@ -225,8 +225,9 @@ class InstSegNet:
         self.part = rt.zeros(T, 8)
         self.mask_xyz_mean, self.seg_loss, self.n_correct = rt.zeros(B, 3), rt.zeros(B), rt.zeros(1)
 
-    def fwd(self, plan, pc, one_hot, labels, is_data_2D, is_training, train_seg, ce_weight=1.0):
-        """`train_seg`: emit the seg-loss backward (dz of conv9 etc.) inside the head kernel."""
+    def fwd(self, plan, pc, one_hot, labels, is_data_2D, is_training, train_seg, ce_weight=1.0, oracle_mask=None):
+        """`train_seg`: emit the seg-loss backward (dz of conv9 etc.) inside the head kernel.  `oracle_mask` ([B,N] int32, the
+        y_seg buffer): the head's logits become stack([1 - m, m]) (semisup_v1_sunrgbd.py:161-162)."""
         g, rt = self.g, self.g.rt
         M, T = g.M, g.M // TILE
         a = ActSpec(pc, g.ldpc, g.C)
@@ -259,6 +260,7 @@ class InstSegNet:
             soff = g.ws.reserve(g.vars.offset(self.scope + '/conv10/weights'), 256, T)
             g.deferred_slab_ptrs.append((h, 'dw_part', soff))
         h.M, h.K, h.rows_per_frustum, h.B, h.dtype = M, 128, g.rpf, g.B, g.dt
+        h.oracle_mask = iptr(oracle_mask)
         plan.add('t3d_seg_head', h)
         f = abi.SegFinalizeArgs()
         f.part, f.B, f.tiles_per_frustum, f.rows_per_frustum, f.K = fptr(self.part), g.B, g.rpf // TILE, g.rpf, 128
@@ -804,10 +806,11 @@ class BoxPCNet:
         self.F2 = FcLayer(g, s + 'fc2', 512, 256, keep_prob=0.7, drop_scope=s + 'dp2')
         self.F3 = FcLayer(g, s + 'fc3', 256, 9, bn=False, act=None)
 
-    def fwd(self, plan, pc, center, dims, theta, one_hot, is_training, y_dims_cls=None, y_orient_cls=None):
+    def fwd(self, plan, pc, center, dims, theta, one_hot, is_training, y_dims_cls=None, y_orient_cls=None, rowmask=None):
+        """`rowmask` ([M] 0/1): the net sees pc * mask (--mask_pc_for_boxpc, test_semisup.py:103-105)."""
         g = self.g
         a = abi.BoxPcRepArgs(fptr(pc), g.ldpc, g.C, fptr(center), fptr(dims), fptr(theta), iptr(y_dims_cls), iptr(y_orient_cls),
-                             fptr(self.rep), self.ld_rep, fptr(self.box7), g.M, g.rpf)
+                             fptr(self.rep), self.ld_rep, fptr(self.box7), g.M, g.rpf, fptr(rowmask))
         plan.add('t3d_boxpc_rep', a)
         x = ActSpec(self.rep, self.ld_rep, g.C + 6)
         x = self.P1.fwd(plan, x, is_training)
@@ -896,9 +899,12 @@ class SemiModelF:
     Backward follows the var_list of train_semisup_adv.py:415-422: nothing for the seg net, box_est/fc1-3 receive no
     gradient (the loss never reads the class-agnostic heads); the Box-PC net back-propagates data gradients only."""
 
-    def __init__(self, g, c, use_one_hot=True, train_classes=None, inputs=None):
+    def __init__(self, g, c, use_one_hot=True, train_classes=None, inputs=None, oracle_mask=False, mask_pc_for_boxpc=False):
+        """oracle_mask: the seg logits are replaced by stack([1 - y_seg, y_seg]) (semisup_v1_sunrgbd.py:161-162; test_semisup.py:75);
+        mask_pc_for_boxpc: the Box-PC net of the inference graph sees pc * mask (test_semisup.py:103-105)."""
         self.g, self.c = g, c
         self.inputs = inputs or Inputs(g)
+        self.oracle_mask, self.mask_pc_for_boxpc = bool(oracle_mask), bool(mask_pc_for_boxpc)
         p = 'class_agnostic/'
         self.seg = InstSegNet(g, p + 'inst_seg', False)
         self.box2d = bool(getattr(c, 'USE_NORMALIZED_BOX2D_AS_FEATS', False))      # semisup_v1_sunrgbd.py:145,168,176
@@ -948,7 +954,7 @@ class SemiModelF:
         g, x, c = self.g, self.inputs, self.c
         g.emit_cast_weights(plan)
         self.seg.fwd(plan, x.pc, x.one_hot_vec, x.y_seg if with_loss else None, x.is_data_2D, is_training, False,
-                     ce_weight=c.STRONG_WEIGHT_CROSS_ENTROPY)
+                     ce_weight=c.STRONG_WEIGHT_CROSS_ENTROPY, oracle_mask=x.y_seg if self.oracle_mask else None)
         ex, ld_ex = self.extra.emit(plan, x) if self.extra is not None else (x.one_hot_vec, NUM_CLASS)
         s1 = self.tnet.fwd(plan, x.pc, self.seg.mask, self.seg.mask_xyz_mean, ex, is_training, ld_oh=ld_ex)
         self.box.fwd_convs(plan, x.pc, self.seg.mask, s1, is_training)
@@ -1000,7 +1006,8 @@ class SemiModelF:
         buffers hold; its loss values are not part of this graph)."""
         g, x, c = self.g, self.inputs, self.c
         g.emit_cast_weights(plan)
-        self.seg.fwd(plan, x.pc, x.one_hot_vec, None, x.is_data_2D, False, False, ce_weight=c.STRONG_WEIGHT_CROSS_ENTROPY)
+        self.seg.fwd(plan, x.pc, x.one_hot_vec, None, x.is_data_2D, False, False, ce_weight=c.STRONG_WEIGHT_CROSS_ENTROPY,
+                     oracle_mask=x.y_seg if self.oracle_mask else None)
         ex, ld_ex = self.extra.emit(plan, x) if self.extra is not None else (x.one_hot_vec, NUM_CLASS)
         s1 = self.tnet.fwd(plan, x.pc, self.seg.mask, self.seg.mask_xyz_mean, ex, False, ld_oh=ld_ex)
         self.box.fwd(plan, x.pc, self.seg.mask, s1, ex, False, ld_oh=ld_ex)
@@ -1013,7 +1020,9 @@ class SemiModelF:
         src = (lo.center, lo.reg_dims, lo.reg_theta)
         cur = (self.cur_center, self.cur_dims, self.cur_theta)
         for i in range(int(refine_num)):
-            out9 = self.boxpc.fwd(plan, x.pc, src[0], src[1], src[2], x.one_hot_vec, False)
+            # (mask = argmax(logits) = the head's hard mask: both are 0 on a tie)
+            out9 = self.boxpc.fwd(plan, x.pc, src[0], src[1], src[2], x.one_hot_vec, False,
+                                  rowmask=self.seg.mask if self.mask_pc_for_boxpc else None)
             a = abi.BoxRefineStepArgs(fptr(out9), fptr(src[0]), fptr(src[1]), fptr(src[2]), fptr(cur[0]), fptr(cur[1]), fptr(cur[2]),
                                       fptr(self.total_delta), fptr(self.fit_prob),
                                       int(bool(c.SEMI_WEIGH_BOXPC_DELTA_DURING_TEST)) + int(bool(c.BOXPC_WEIGH_DELTA_PRED_BY_CLS_CONF)),

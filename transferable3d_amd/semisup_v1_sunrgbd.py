@@ -45,14 +45,16 @@ def get_semi_model_final(pc, bg_pc, img, one_hot_vec, is_training, use_one_hot, 
     from .nets import SemiModelF
     ctx = pc.ctx
     e = ctx.engine
-    if oracle_mask is not None:
-        raise NotImplementedError('oracle_mask (debug path, semisup_v1_sunrgbd.py:161-162) is not on the hot path')
+    if oracle_mask is not None and getattr(oracle_mask, 'field', None) != 'y_seg':
+        # (the one call site of the reference, test_semisup.py:75, passes y_seg_pl)
+        raise NotImplementedError('oracle_mask must be the y_seg placeholder (semisup_v1_sunrgbd.py:161-162, test_semisup.py:75)')
     if isinstance(bn_decay, (int, float)):
         e.hyper[2] = float(bn_decay)
     train_classes = getattr(c, 'intraclsdims_train_classes', None)
     if c.USE_NORMALIZED_BOX2D_AS_FEATS and norm_box2D is None:        # semisup_v1_sunrgbd.py:145,168,176
         raise ValueError('USE_NORMALIZED_BOX2D_AS_FEATS needs norm_box2D = tf_util.tf_normalize_2D_bboxes(box2D_pl, img_dim_pl)')
-    m = SemiModelF(e, c, use_one_hot=use_one_hot, train_classes=train_classes, inputs=ctx.inputs)
+    m = SemiModelF(e, c, use_one_hot=use_one_hot, train_classes=train_classes, inputs=ctx.inputs, oracle_mask=oracle_mask is not None,
+                   mask_pc_for_boxpc=bool(getattr(c, 'mask_pc_for_boxpc', False)))
     ctx.assembly = m
     ctx.is_training = is_training if isinstance(is_training, api.BoolPlaceholder) else bool(is_training)
     B, N = e.B, e.rpf

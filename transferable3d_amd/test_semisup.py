@@ -37,7 +37,8 @@ def build_flags(argv=None):
     cfg.add_argument('--refine', default=None)
     cfg.add_argument('--output', default=None)
     cfg.add_argument('--no_rgb', action='store_true')
-    cfg.add_argument('--mask_pc_for_boxpc', action='store_true')
+    cfg.add_argument('--mask_pc_for_boxpc', action='store_true', help='Mask the PC before giving to BoxPC network.')
+    cfg.add_argument('--use_oracle_mask', action='store_true', help='ground-truth segmentation instead of the seg net\'s (use_oracle_mask of the reference\'s get_model / test)')
     cfg.add_argument('--use_boxpc_fit_prob', action='store_true')
     cfg.add_argument('--use_one_hot', action='store_true')
     cfg.add_argument('--batch_size', type=int, default=32)
@@ -57,10 +58,10 @@ def build_flags(argv=None):
     return FLAGS
 
 
-def get_model(FLAGS, batch_size, num_point, num_channel, rt=None, state_dict=None):
-    """test_semisup.py:61-180: the inference graph; returns (sess, ops)."""
-    if FLAGS.mask_pc_for_boxpc:
-        raise NotImplementedError('--mask_pc_for_boxpc is in no published recipe')
+def get_model(FLAGS, batch_size, num_point, num_channel, rt=None, state_dict=None, use_oracle_mask=False):
+    """test_semisup.py:61-180: the inference graph; returns (sess, ops).  `use_oracle_mask` (test_semisup.py:61,75): the ground-truth
+    segmentation replaces the seg net's logits (SEMI_MODEL F only, as in the reference).  FLAGS.mask_pc_for_boxpc
+    (test_semisup.py:103-105): the Box-PC net of the refinement loop sees pc * mask."""
     FLAGS.SEMI_REFINE_USING_BOXPC_DELTA_NUM = int(FLAGS.refine) if FLAGS.refine is not None else 0
     FLAGS.SEMI_WEIGH_BOXPC_DELTA_DURING_TEST = False                       # test_semisup.py:93
     FLAGS.BOX_PC_MASK_REPRESENTATION = 'A'
@@ -69,11 +70,11 @@ def get_model(FLAGS, batch_size, num_point, num_channel, rt=None, state_dict=Non
         pls = MODEL.placeholder_inputs(batch_size, num_point, num_channel)
         norm_box2D = tf_util.tf_normalize_2D_bboxes(pls[15], pls[16])       # test_semisup.py:74
         pred, end_points = MODEL.get_semi_model(pls[0], pls[1], pls[2], pls[3], False, use_one_hot=FLAGS.use_one_hot,
-                                                norm_box2D=norm_box2D, c=FLAGS)
+                                                oracle_mask=pls[4] if use_oracle_mask else None, norm_box2D=norm_box2D, c=FLAGS)
         sess = api.Session()
     if state_dict is not None:
         graph.vars.load_state_dict(state_dict, strict=False)
-    ops = {'pc_pl': pls[0], 'one_hot_vec_pl': pls[3], 'logits': pred[0], 'end_points': end_points, 'graph': graph}
+    ops = {'pc_pl': pls[0], 'one_hot_vec_pl': pls[3], 'y_seg_pl': pls[4], 'logits': pred[0], 'end_points': end_points, 'graph': graph}
     return sess, ops
 
 
@@ -93,9 +94,10 @@ def detection_scores(logits, heading_logits, size_logits, fit_prob=None):
     return s if fit_prob is None else s + np.log(fit_prob + 0.01)
 
 
-def inference(sess, ops, pc, one_hot_vec, batch_size, prefix='', use_boxpc_fit_prob=False, source=None, n_batches=None):
+def inference(sess, ops, pc, one_hot_vec, batch_size, prefix='', use_boxpc_fit_prob=False, source=None, n_batches=None, oracle_mask=None):
     """test_semisup.py:188-262, same return tuple: (pred_seg, centers, orient_cls, orient_reg, dims_cls, dims_reg, scores).
-    `source` (dataset.DeviceEvalSource): the batches are assembled on the device from a frustum file instead of being fed."""
+    `source` (dataset.DeviceEvalSource): the batches are assembled on the device from a frustum file instead of being fed.
+    `oracle_mask` [n, N] (test_semisup.py:207-208): fed to y_seg_pl of a graph built with use_oracle_mask."""
     if source is not None:
         n, npts = n_batches * batch_size, sess.g.engine.rpf
     else:
@@ -117,7 +119,10 @@ def inference(sess, ops, pc, one_hot_vec, batch_size, prefix='', use_boxpc_fit_p
             source.load(i)
             out = sess.run(run_ops)
         else:
-            out = sess.run(run_ops, feed_dict={ops['pc_pl']: pc[sl], ops['one_hot_vec_pl']: one_hot_vec[sl]})
+            feed = {ops['pc_pl']: pc[sl], ops['one_hot_vec_pl']: one_hot_vec[sl]}
+            if oracle_mask is not None:
+                feed[ops['y_seg_pl']] = np.asarray(oracle_mask[sl], np.int32)
+            out = sess.run(run_ops, feed_dict=feed)
         logits[sl], centers[sl], heading_logits[sl], heading_residuals[sl], size_logits[sl], size_residuals[sl] = out[:6]
         scores[sl] = detection_scores(out[0], out[2], out[4], out[6] if use_boxpc_fit_prob else None)
     heading_cls, size_cls = np.argmax(heading_logits, 1), np.argmax(size_logits, 1)
@@ -132,7 +137,8 @@ def test(FLAGS, rt=None, log=print):
     if FLAGS.boxpc_model_path:
         sd = dict(sd or {})
         sd.update({'D_boxpc_branch/' + k: v for k, v in load_state(FLAGS.boxpc_model_path).items()})
-    sess, ops = get_model(FLAGS, B, N, C, rt=rt, state_dict=sd)
+    use_oracle = bool(getattr(FLAGS, 'use_oracle_mask', False))
+    sess, ops = get_model(FLAGS, B, N, C, rt=rt, state_dict=sd, use_oracle_mask=use_oracle)
     if FLAGS.data_path:
         return test_on_frustum_file(FLAGS, sess, ops, log)
     n = (FLAGS.num_frustums + B - 1) // B * B                     # the reference pads the last batch (test_semisup.py:450-471)
@@ -141,7 +147,8 @@ def test(FLAGS, rt=None, log=print):
     oh = np.concatenate([b['one_hot_vec'] for b in batches])
     seg_gt = np.concatenate([b['y_seg'] for b in batches])
     seg, centers, hcls, hres, scls, sres, scores = inference(sess, ops, pc, oh, B, prefix=FLAGS.pred_prefix,
-                                                             use_boxpc_fit_prob=FLAGS.use_boxpc_fit_prob)
+                                                             use_boxpc_fit_prob=FLAGS.use_boxpc_fit_prob,
+                                                             oracle_mask=seg_gt if use_oracle else None)
     iou = np.mean([(np.logical_and(seg[i], seg_gt[i]).sum() + 1e-9) / (np.logical_or(seg[i], seg_gt[i]).sum() + 1e-9) for i in range(n)])
     log('Mean segmentation IOU: %f' % iou)
     # test_semisup.py:509-511: [ps, seg_gt, seg_pred, center, heading_cls, heading_res, size_cls, size_res, rot_angle, score, cls,
