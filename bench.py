@@ -86,6 +86,11 @@ def gemm_work(name, a):
       Gram forms       the same with K in place of N (the [M,N] tensor does not exist)."""
     import ctypes
     es = lambda dt: 2.0 if dt == 1 else 4.0       # bytes per element of a [M, C] layer tensor (t3d.h T3D_BF16 / T3D_F32)
+    # fp32 layers run on the bf16 matrix pipe with three-term operands unless T3D_X3=0 (csrc/pointmlp.hip PathX3): k_..._x3<...>
+    x3 = os.environ.get('T3D_X3', '1') != '0'
+    x3f = lambda K, N: x3 and K * N >= int(os.environ.get('T3D_X3_MINKN', '1'))
+    x3b = lambda K, N: x3 and K * N >= int(os.environ.get('T3D_X3_MINKN_BWD', os.environ.get('T3D_X3_MINKN', '1')))
+    tag = lambda label: label.replace('<', '_x3<', 1)
     if name == 't3d_pool_bwd_stage1':
         gl, gf, gb = gemm_work('t3d_pointmlp_gram', a[0])
         q = a[2]
@@ -95,7 +100,8 @@ def gemm_work(name, a):
         if g0.a.dtype == 1 and g0.K in (128, 256) and g0.rows_per_split % 128 == 0 and g0.M // g0.rows_per_split >= min(256, g0.M // 128) \
                 and os.environ.get('T3D_GRAM1', '1') != '0':
             return 'k_pool_bwd_stage1_h<%d,%d>' % (g0.K, 128 if g0.K == 128 else 64), gf + 2.0 * q.K * q.K * q.N, by      # one-pass form
-        return 'k_pool_bwd_stage1<%s>' % gl[gl.index('<') + 1:gl.index(',')], gf + 2.0 * q.K * q.K * q.N, by
+        lab = 'k_pool_bwd_stage1<%s>' % gl[gl.index('<') + 1:gl.index(',')]
+        return (tag(lab) if g0.a.dtype == 0 and x3b(g0.K, g0.K) else lab), gf + 2.0 * q.K * q.K * q.N, by
     if name == 't3d_pool_bwd_stage2':
         dl, df, db = gemm_work('t3d_pointmlp_dgrad_gram', a[1])
         f = a[0]
@@ -104,7 +110,8 @@ def gemm_work(name, a):
         dm = int(os.environ.get('T3D_DGRAM1', '1'))
         if a[1].dtype == 1 and os.environ.get('T3D_GRAM1', '1') != '0' and ((dm >= 1 and f.K == 256) or (dm == 2 and f.K == 128)):
             return 'k_pool_bwd_stage2_h<%d,%d>' % (f.K, 128 if f.K == 128 else 64), df + 2.0 * f.K * f.K * f.N, by      # one-pass form
-        return 'k_pool_bwd_stage2<%s>' % dl[dl.index('<') + 1:-1], df + 2.0 * f.K * f.K * f.N, by
+        lab = 'k_pool_bwd_stage2<%s>' % dl[dl.index('<') + 1:-1]
+        return (tag(lab) if a[1].dtype == 0 and f.K % 16 == 0 and x3b(f.K, f.K) else lab), df + 2.0 * f.K * f.K * f.N, by
     if name == 't3d_pointmlp_bwd':
         d, w = a
         dl, df, _ = gemm_work('t3d_pointmlp_dgrad', d)
@@ -118,18 +125,21 @@ def gemm_work(name, a):
                 M // w.rows_per_split >= min(256, M // 128) and os.environ.get('T3D_BWD1F', '1') != '0' and \
                 (M // 128 < 256 or w.rows_per_split >= 256 or os.environ.get('T3D_BWD1F') == '2'):
             return 'k_pointmlp_bwd1f<%d,%d>' % (K, N), df + wf, by      # fp32 one-pass form (not taken at the headline size)
-        return 'k_pointmlp_bwd<%s,%s>' % (dl[dl.index('<') + 1:-1], wl[wl.index('<') + 1:-1]), df + wf, by
+        lab = 'k_pointmlp_bwd<%s,%s>' % (dl[dl.index('<') + 1:-1], wl[wl.index('<') + 1:-1])
+        return (tag(lab) if d.dtype == 0 and N % 16 == 0 and K % 64 == 0 and x3b(K, N) else lab), df + wf, by
     if name == 't3d_pointmlp_dgrad_gram':
         # (the sparse arg-max rows S behind add_live are read only where a row received a hit -- a data-dependent few percent of
         # the rows: not counted; a dense add_in is a full pass)
         dense_add = (not _null(a.add_in)) and _null(a.add_live)
         by = es(a.dtype) * a.M * a.K * (2 + (0 if _null(a.prev_y) else 1) + (1 if dense_add else 0)) + 4.0 * a.K * a.K
-        return 'k_pointmlp_dgrad_gram<%d>' % (128 if a.K % 128 == 0 and (a.M // 128) * (a.K // 128) >= 512 else 64), 2.0 * a.M * a.K * a.K, by
+        lab = 'k_pointmlp_dgrad_gram<%d>' % (128 if a.K % 128 == 0 and (a.M // 128) * (a.K // 128) >= 512 else 64)
+        return (tag(lab) if a.dtype == 0 and a.K % 16 == 0 and x3b(a.K, a.K) else lab), 2.0 * a.M * a.K * a.K, by
     if name == 't3d_pointmlp_gram':
         rps, tk, tn = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
         LIB.t3d_wgrad_plan(a.M, a.K, a.K, ctypes.byref(rps), ctypes.byref(tk), ctypes.byref(tn))
         t = tk.value if (rps.value == a.rows_per_split and tk.value == tn.value) else 64
-        return 'k_pointmlp_gram<%d,%d>' % (t, t), 2.0 * a.M * a.K * a.K, es(a.a.dtype) * a.M * a.K + 4.0 * a.K * a.K
+        lab = 'k_pointmlp_gram<%d,%d>' % (t, t)
+        return (tag(lab) if a.a.dtype == 0 and x3b(a.K, a.K) else lab), 2.0 * a.M * a.K * a.K, es(a.a.dtype) * a.M * a.K + 4.0 * a.K * a.K
     flops = 2.0 * a.M * a.K * a.N
     if name == 't3d_pointmlp_fwd':
         by = es(a.a.dtype) * a.M * a.K + es(a.dtype) * (a.K * a.N + (0 if _null(a.y) else a.M * a.N))
@@ -138,13 +148,16 @@ def gemm_work(name, a):
             return 'k_pointmlp_fwd_tinyk<%d>' % a.N, flops, by      # first layer of a net: the register kernel (bf16 and fp32)
         if a.dtype == 1 and a.a.dtype == 1 and _null(a.a.sub) and (a.K in (64, 128) or (a.K == 256 and os.environ.get('T3D_FWD_RES', '1') == '2')) and os.environ.get('T3D_FWD_RES', '1') != '0':
             return 'k_pointmlp_fwd_res<%d,%d>' % (128 if a.N % 128 == 0 else 64, a.K // 64), flops, by      # activation-resident bf16 forward
+        if a.dtype == 0 and a.a.dtype == 0 and _null(a.a.sub) and a.K % 16 == 0 and x3f(a.K, a.N):
+            return 'k_pointmlp_fwd_x3<%d>' % (128 if a.N % 128 == 0 and (a.M // 128) * (a.N // 128) >= 512 else 64), flops, by
         if a.dtype == 0 and os.environ.get('T3D_FWD_POOL', '1') != '0' and _null(a.y) and not _null(a.pmax) and _null(a.a.sub) and a.K == 128 and \
                 a.N % 128 == 0 and a.N >= 256:
             return 'k_pointmlp_fwd_pool<128,32,8>', flops, by
         return 'k_pointmlp_fwd<%d>' % (128 if a.N % 128 == 0 and (a.M // 128) * (a.N // 128) >= 512 else 64), flops, by
     if name == 't3d_pointmlp_dgrad':
         by = es(a.dtype) * (2 * a.M * a.N + a.K * a.N + a.M * a.K * (1 + (0 if _null(a.prev_y) else 1) + (0 if _null(a.add_in) else 1)))
-        return 'k_pointmlp_dgrad<%d>' % (128 if a.K % 128 == 0 and (a.M // 128) * (a.K // 128) >= 512 else 64), flops, by
+        lab = 'k_pointmlp_dgrad<%d>' % (128 if a.K % 128 == 0 and (a.M // 128) * (a.K // 128) >= 512 else 64)
+        return (tag(lab) if a.dtype == 0 and not _null(a.dy.dz) and a.N % 16 == 0 and x3b(a.K, a.N) else lab), flops, by
     rps, tk, tn = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
     LIB.t3d_wgrad_plan(a.M, a.K, a.N, ctypes.byref(rps), ctypes.byref(tk), ctypes.byref(tn))
     if rps.value != a.rows_per_split:
@@ -152,7 +165,8 @@ def gemm_work(name, a):
     by = es(a.a.dtype) * a.M * a.K + es(a.dy.dtype) * 2 * a.M * a.N + 4.0 * a.K * a.N
     if a.K <= 4 and a.a.dtype == 0 and a.dy.dtype == 0 and not _null(a.dy.dz) and a.N in (64, 128) and os.environ.get('T3D_WGRAD_TINYK', '1') != '0':
         return 'k_pointmlp_wgrad_tinyk<%d>' % a.N, flops, by      # first layer of a net, fp32: the register kernel
-    return 'k_pointmlp_wgrad<%d,%d>' % (tk.value, tn.value), flops, by
+    lab = 'k_pointmlp_wgrad<%d,%d>' % (tk.value, tn.value)
+    return (tag(lab) if a.dy.dtype == 0 and a.a.dtype == 0 and _null(a.a.sub) and not _null(a.dy.dz) and a.K % 64 == 0 and x3b(a.K, a.N) else lab), flops, by
 
 
 def profile_kernels(plans, steps, repeat=4):
@@ -204,7 +218,8 @@ def profile_kernels(plans, steps, repeat=4):
             label, flops, nbytes = (gemm_work(base, arg) if base.startswith(('t3d_pointmlp', 't3d_pool_bwd_stage')) and
                                     base != 't3d_pointmlp_dgrad_narrow' else (name, 0.0, 0.0))
             if base != name and '<' in label and label.split('<')[0] in ('k_pointmlp_fwd', 'k_pointmlp_bwd', 'k_pointmlp_wgrad',
-                                                                        'k_pool_bwd_stage1', 'k_pool_bwd_stage2'):
+                                                                        'k_pool_bwd_stage1', 'k_pool_bwd_stage2', 'k_pointmlp_fwd_x3',
+                                                                        'k_pointmlp_bwd_x3', 'k_pool_bwd_stage1_x3', 'k_pool_bwd_stage2_x3'):
                 label = label.replace('<', '_r<', 1)
             d = acc.setdefault(label, [0.0, 0, 0.0, 0.0, 0.0])
             d[0] += dt
@@ -521,7 +536,15 @@ def main():
             sys.stderr.write('WARNING: algorithmic bytes per launch of %s (%.1f MB) exceed the PMC-measured HBM traffic (%.1f MB): the '
                              'byte model over-counts or profiles/pmc_traffic.json is stale\n' % (dom, nby / n / 1e6, traffic / 1e6))
         step_flops = SPLIT_GFLOP_PER_FRUSTUM * (N / 1024.0) * 1e9 * B        # per-point terms dominate: scale with N
+        emulated = args.dtype == 'f32' and '_x3' in dom.split('<')[0]
         roofline = {'bound': 'mfma' if mfma_bound else 'hbm', 'kernel': dom,
+                    # fp32 layers on the bf16 matrix pipe: every operand is the exact sum of three bf16 terms, six bf16 MFMAs with fp32
+                    # accumulation per fp32 multiply-add (csrc/pointmlp.hip PathX3; results agree with the fp32-MFMA kernels to fp32
+                    # rounding, tests/ run both).  `peak` stays the fp32-MFMA peak the fp32 FLOP count is priced against; the
+                    # emulation's own ceiling is the dense bf16 peak / 6.
+                    'emulated': 'bf16x3' if emulated else None,
+                    'emulated_ceiling_tflops': (MFMA_BF16_PEAK_TFLOPS / 6.0) if emulated else None,
+                    'frac_of_emulated_ceiling': (achieved / (MFMA_BF16_PEAK_TFLOPS / 6.0)) if emulated else None,
                     'achieved': achieved if mfma_bound else hbm_achieved,
                     'peak': mfma_peak if mfma_bound else HBM_PEAK_TBS * 1e3,
                     'unit': 'TFLOP/s' if mfma_bound else 'GB/s',

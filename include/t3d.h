@@ -1011,6 +1011,14 @@ int t3d_pool_bwd_stage1_r(const t3d_pointmlp_gram_args* gram, const t3d_act_cols
                           const t3d_rider_set* riders, t3d_stream_t stream);
 int t3d_pool_bwd_stage2_r(const t3d_pool_wgrad_finish_args* finish, const t3d_pointmlp_dgrad_gram_args* dgrad,
                           const t3d_rider_set* riders, t3d_stream_t stream);
+/* Would the `_r` launcher run a rider set INSIDE the GEMM launch for these arguments (1), or as a launch of its own in front of it
+ * (0)?  Answered by the launchers' own dispatch (kernel variant, T3D_X3, tile widths, ...), so a scheduler needs no copy of those
+ * rules.  Negative: the arguments would be rejected. */
+int t3d_pointmlp_fwd_hosts_riders(const t3d_pointmlp_fwd_args* args);
+int t3d_pointmlp_wgrad_hosts_riders(const t3d_pointmlp_wgrad_args* args);
+int t3d_pointmlp_bwd_hosts_riders(const t3d_pointmlp_dgrad_args* dgrad, const t3d_pointmlp_wgrad_args* wgrad);
+int t3d_pool_bwd_stage1_hosts_riders(const t3d_pointmlp_gram_args* gram, const t3d_act_colsum_args* colsum, const t3d_pool_bwd_prep_args* prep);
+int t3d_pool_bwd_stage2_hosts_riders(const t3d_pool_wgrad_finish_args* finish, const t3d_pointmlp_dgrad_gram_args* dgrad);
 
 #ifdef __cplusplus
 }

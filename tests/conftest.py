@@ -18,3 +18,19 @@ def hip_lib():
     """The real HIP library; GPU tests fail loudly if it is missing (no fallback)."""
     from transferable3d_amd import abi
     return abi.load()
+
+
+@pytest.fixture
+def fp32_mfma(monkeypatch):
+    """The fp32-MFMA GEMM kernels (v_mfma_f32_32x32x2_f32) instead of the default three-term bf16 form (csrc/pointmlp.hip PathX3):
+    for tests that pin relations BETWEEN fp32-MFMA kernels (one-pass vs split form bit for bit, ...).  The library reads T3D_X3 at
+    every launch."""
+    monkeypatch.setenv('T3D_X3', '0')
+
+
+@pytest.fixture(params=['x3', 'fp32_mfma'])
+def gemm_arithmetic(request, monkeypatch):
+    """Runs a test under both GEMM arithmetics of the fp32 path: 'x3' (default: bf16 matrix pipe, three bf16 terms per operand, six
+    products) and 'fp32_mfma' (T3D_X3=0)."""
+    monkeypatch.setenv('T3D_X3', '1' if request.param == 'x3' else '0')
+    return request.param

@@ -1312,6 +1312,23 @@ class FakeLib:
         rs.n_wg, rs.lds_bytes = 1, 0
         return 0
 
+    # (specification library: every fp32 GEMM launch "hosts" -- the set simply runs beside it)
+    def t3d_pointmlp_fwd_hosts_riders(self, a):
+        return int(_struct(a).dtype == 0)
+
+    def t3d_pointmlp_wgrad_hosts_riders(self, a):
+        p = _struct(a)
+        return int(p.dy.dtype == 0 and p.K <= 64 and p.N <= 128 and bool(p.dy.dz))
+
+    def t3d_pointmlp_bwd_hosts_riders(self, d, w):
+        return int(_struct(d).dtype == 0)
+
+    def t3d_pool_bwd_stage1_hosts_riders(self, g, c, q):
+        return int(_struct(g).a.dtype == 0)
+
+    def t3d_pool_bwd_stage2_hosts_riders(self, f, d):
+        return int(_struct(d).dtype == 0)
+
     def t3d_run_riders(self, r, stream):
         if not r:
             return 0

@@ -45,7 +45,7 @@ def _close(a, b, rtol, atol, what):
 @pytest.mark.parametrize('M,K,N,rpf,mode', [
     (512, 64, 64, 256, 'bn'), (512, 4, 64, 128, 'raw'), (256, 3, 128, 128, 'sub'), (512, 128, 256, 256, 'bn_pool'),
     (256, 64, 512, 128, 'bn_rowbias'), (256, 128, 1024, 128, 'bn_pool_nomask'), (384, 512, 256, 128, 'bn')])
-def test_pointmlp_fwd(hip_lib, M, K, N, rpf, mode):
+def test_pointmlp_fwd(hip_lib, gemm_arithmetic, M, K, N, rpf, mode):
     r = np.random.RandomState(hash((M, K, N)) % 1000)
     B, T = M // rpf, M // 128
     ldx = 4 if K <= 4 else K
@@ -98,7 +98,7 @@ def test_pointmlp_fwd(hip_lib, M, K, N, rpf, mode):
 @pytest.mark.parametrize('M,K,N,rpf,mode', [(512, 64, 128, 256, 'dense'), (256, 128, 256, 128, 'pooled'),
                                             (256, 64, 512, 128, 'raw_addin'), (384, 512, 256, 128, 'dense'),
                                             (256, 256, 128, 128, 'dense_addin')])
-def test_pointmlp_dgrad(hip_lib, M, K, N, rpf, mode):
+def test_pointmlp_dgrad(hip_lib, gemm_arithmetic, M, K, N, rpf, mode):
     r = np.random.RandomState(hash((M, K, N, 1)) % 1000)
     B, T = M // rpf, M // 128
     dz = (r.normal(size=(M, N)) * 1e-2).astype(np.float32)
@@ -143,7 +143,7 @@ def test_pointmlp_dgrad(hip_lib, M, K, N, rpf, mode):
 @pytest.mark.parametrize('M,K,N,rpf,rps,mode', [(512, 64, 64, 256, 128, 'dense'), (512, 3, 128, 128, 256, 'sub'),
                                                 (256, 128, 1024, 128, 64, 'pooled'), (512, 256, 128, 256, 512, 'dense'),
                                                 (256, 4, 64, 128, 32, 'raw'), (256, 512, 256, 128, 128, 'dense')])
-def test_pointmlp_wgrad(hip_lib, M, K, N, rpf, rps, mode):
+def test_pointmlp_wgrad(hip_lib, gemm_arithmetic, M, K, N, rpf, rps, mode):
     r = np.random.RandomState(hash((M, K, N, 2)) % 1000)
     B, S = M // rpf, M // rps
     ldx = 4 if K <= 4 else K
@@ -708,7 +708,7 @@ def test_pool_sparse_rows(hip_lib, M, K, N, rpf):
 
 
 @pytest.mark.parametrize('M,K,rpf', [(512, 128, 256), (256, 256, 128), (8192, 128, 1024)])
-def test_pointmlp_dgrad_gram(hip_lib, M, K, rpf):
+def test_pointmlp_dgrad_gram(hip_lib, gemm_arithmetic, M, K, rpf):
     r = np.random.RandomState(M + K)
     T = M // 128
     x = r.normal(size=(M, K)).astype(np.float32)
@@ -737,7 +737,7 @@ def test_pointmlp_dgrad_gram(hip_lib, M, K, rpf):
 
 @pytest.mark.parametrize('M,K,N,rpf,masked', [(512, 128, 1024, 256, True), (4096, 256, 512, 1024, True), (8192, 128, 256, 1024, True),
                                               (1024, 128, 256, 256, False)])
-def test_row_gated_sparse_rows_and_dgrad_gram_equal_the_dense_form(hip_lib, M, K, N, rpf, masked):
+def test_row_gated_sparse_rows_and_dgrad_gram_equal_the_dense_form(hip_lib, gemm_arithmetic, M, K, N, rpf, masked):
     """row_live / add_live: rows of S without an arg-max hit are neither written nor read (they hold NaN here), the flags
     are exactly the hit rows, and the data gradient is bit-identical to the every-row-written form."""
     d = _pool_case(M, K, N, rpf, M + K + N)
@@ -776,7 +776,7 @@ def test_row_gated_sparse_rows_and_dgrad_gram_equal_the_dense_form(hip_lib, M, K
 
 
 @pytest.mark.parametrize('M,K,rpf', [(1024, 128, 256), (512, 256, 128), (4096, 64, 1024)])
-def test_pointmlp_gram_and_act_colsum(hip_lib, M, K, rpf):
+def test_pointmlp_gram_and_act_colsum(hip_lib, gemm_arithmetic, M, K, rpf):
     d = _pool_case(M, K, 64, rpf, M + 3 * K)
     rps, tk, tn = C.c_int(0), C.c_int(0), C.c_int(0)
     assert hip_lib.t3d_wgrad_plan(M, K, K, C.byref(rps), C.byref(tk), C.byref(tn)) == 0
@@ -792,6 +792,7 @@ def test_pointmlp_gram_and_act_colsum(hip_lib, M, K, rpf):
     c, g = _run_both(hip_lib, make_g, 't3d_pointmlp_gram')
     _close(c['slabs'], g['slabs'], 1e-4, 1e-5 * float(c['slabs'].abs().max()), 'gram slabs')
     gs = g['slabs'].sum(0)
+    # (x3: the six partial products of G[i][j] and G[j][i] come in another order -- three accumulator sets make the sum order-free)
     assert torch.equal(gs, gs.T.contiguous()), 'Gram matrix must be bitwise symmetric (finish kernel reads it transposed)'
 
     def make_c(dev):
@@ -827,7 +828,7 @@ def test_pool_wgrad_finish(hip_lib, M, K, N, rpf):
     _close(c['dw'], g['dw'], 1e-4, 1e-5 * float(c['dw'].abs().max()), 'dw')
 
 
-def test_pointmlp_fwd_without_y_store_gives_the_same_statistics(hip_lib):
+def test_pointmlp_fwd_without_y_store_gives_the_same_statistics(hip_lib, gemm_arithmetic):
     M, K, N, rpf = 512, 128, 256, 256
     r = np.random.RandomState(11)
     x, w = r.normal(size=(M, K)).astype(np.float32), (r.normal(size=(K, N)) / np.sqrt(K)).astype(np.float32)
@@ -850,7 +851,7 @@ def test_pointmlp_fwd_without_y_store_gives_the_same_statistics(hip_lib):
         assert torch.equal(outs[0][k], outs[1][k]), k
 
 
-def test_gram_form_equals_direct_form_through_the_kernels(hip_lib):
+def test_gram_form_equals_direct_form_through_the_kernels(hip_lib, gemm_arithmetic):
     """da and dW of a pooled layer: Gram-form kernel chain vs the direct pooled-sparse dgrad / wgrad kernels."""
     M, K, N, rpf = 1024, 128, 512, 256
     B, T = M // rpf, M // 128
@@ -904,7 +905,7 @@ def test_gram_form_equals_direct_form_through_the_kernels(hip_lib):
 
 @pytest.mark.parametrize('M,K,N,rpf,mode', [(1024, 128, 128, 256, 'mask'), (512, 64, 512, 128, 'raw'), (1024, 512, 256, 256, 'mask_addin'),
                                             (65536, 64, 64, 1024, 'mask')])
-def test_fused_bwd_equals_separate_dgrad_and_wgrad(hip_lib, M, K, N, rpf, mode):
+def test_fused_bwd_equals_separate_dgrad_and_wgrad(hip_lib, gemm_arithmetic, M, K, N, rpf, mode):
     """t3d_pointmlp_bwd is the two kernels in one launch: bit-identical outputs."""
     r = np.random.RandomState(M + K + N)
     dev = _dev('cuda')
@@ -942,7 +943,12 @@ def test_fused_bwd_equals_separate_dgrad_and_wgrad(hip_lib, M, K, N, rpf, mode):
     # the fused launch takes the one-pass form where the shape and this split allow it (t3d.h, t3d_bwd_plan): dX stays bit-identical
     # (same MFMA step order), the statistics and the slab SUM differ by the fp32 summation order only
     one_pass = rps.value % 128 == 0 and S >= min(256, T) and (T < 256 or rps.value >= 256) and K in (64, 128) and N in (64, 128)
-    assert torch.equal(res[0][0], res[1][0]), 'out'
+    if one_pass and gemm_arithmetic == 'x3':
+        # the one-pass kernel multiplies on the fp32 matrix pipe, the separate launches on the bf16 one with three-term operands
+        # (csrc/pointmlp.hip PathX3): same values to fp32 rounding, another summation order
+        _close(res[0][0].cpu(), res[1][0].cpu(), 1e-4, 2e-6 * float(res[0][0].abs().max()), 'out (one-pass fp32-MFMA vs x3)')
+    else:
+        assert torch.equal(res[0][0], res[1][0]), 'out'
     if not one_pass:
         for a, b, what in zip(res[0][1:], res[1][1:], ('psum_dz', 'psum_dzy', 'slabs')):
             assert torch.equal(a, b), what
@@ -959,7 +965,7 @@ def test_fused_bwd_equals_separate_dgrad_and_wgrad(hip_lib, M, K, N, rpf, mode):
     (256, 64, 64, 128, 'mask', -1), (512, 128, 128, 256, 'mask_addin', -1), (1024, 64, 128, 256, 'raw', -1), (768, 128, 64, 128, 'mask', -1),
     (384, 128, 128, 128, 'raw_addin', 128), (65536, 128, 128, 1024, 'mask', -1), (65536, 64, 128, 2048, 'mask_addin', 256),
     (65536, 128, 64, 1024, 'mask', 256), (65536, 64, 64, 1024, 'mask', -1), (1024, 128, 128, 256, 'mask_nostats', -1), (131072, 128, 128, 1024, 'mask_addin', 512)])
-def test_fp32_one_pass_backward(hip_lib, M, K, N, rpf, mode, rps_):
+def test_fp32_one_pass_backward(hip_lib, fp32_mfma, M, K, N, rpf, mode, rps_):
     """k_pointmlp_bwd1f (the one-pass form t3d_pointmlp_bwd takes for fp32 layers with K, N in {64, 128}) against float64, and its dX
     bit for bit against t3d_pointmlp_dgrad.  rps_: -1 = t3d_bwd_plan's split, > 0 = that many rows per split (whole 128-row tiles,
     >= min(256, M / 128) workgroups, and >= 256 rows per workgroup once M >= 32768: below that the launcher keeps the split form)."""
@@ -1026,7 +1032,7 @@ def test_fp32_one_pass_backward(hip_lib, M, K, N, rpf, mode, rps_):
     assert float((dw - dw_ref).abs().max()) < 2e-6 * float(dw_ref.abs().max()) * max(1.0, np.sqrt(M / 512))
 
 
-def test_fused_pool_stages_equal_the_separate_launches(hip_lib):
+def test_fused_pool_stages_equal_the_separate_launches(hip_lib, gemm_arithmetic):
     """t3d_pool_bwd_stage1 / stage2 are the separate K11e launches sharing a grid: bit-identical outputs."""
     M, K, N, rpf = 2048, 128, 512, 512
     B, T = M // rpf, M // 128
@@ -1097,7 +1103,7 @@ def test_box_refine_step(hip_lib, weigh, first):
 
 @pytest.mark.parametrize('M,K,N,rpf,masked', [(512, 128, 1024, 256, True), (1024, 256, 512, 512, True), (256, 128, 256, 128, False),
                                               (32768, 128, 1024, 1024, True)])
-def test_pooled_forward_kernel_equals_generic_kernel(hip_lib, M, K, N, rpf, masked):
+def test_pooled_forward_kernel_equals_generic_kernel(hip_lib, fp32_mfma, M, K, N, rpf, masked):
     """y = NULL on a pooled layer with K in {128, 256} takes the A-resident persistent kernel; with a y buffer the generic
     kernel runs.  Same accumulation and reduction order by construction: statistics and pool partials bit-identical."""
     r = np.random.RandomState(M + K + N)
@@ -1291,7 +1297,7 @@ def _sweep_cases(seed, n):
 
 
 @pytest.mark.parametrize('M,K,N,rpf', _sweep_cases(2024, 14))
-def test_pointmlp_shape_sweep_fwd_bwd_against_spec(hip_lib, M, K, N, rpf):
+def test_pointmlp_shape_sweep_fwd_bwd_against_spec(hip_lib, gemm_arithmetic, M, K, N, rpf):
     """Tile-edge coverage: widths that are not multiples of the 128-wide tile, reduction lengths that are not multiples of
     the 32-deep k-tile, single-tile grids; forward, fused backward (when K % 64 == 0) or weight gradient alone."""
     r = np.random.RandomState(M + 7 * K + 13 * N)

@@ -36,7 +36,7 @@ def _steps(hip_lib, overlap, B, N, n_steps, workload='A'):
 
 
 @pytest.mark.parametrize('workload,B,N', [('A', 32, 1024), ('A', 8, 256), ('F', 32, 1024), ('F', 8, 256), ('boxpc', 32, 1024)])
-def test_scheduled_step_is_bit_identical_to_the_unscheduled_step(hip_lib, workload, B, N):
+def test_scheduled_step_is_bit_identical_to_the_unscheduled_step(hip_lib, gemm_arithmetic, workload, B, N):
     """Five steps (one eager, the capture, three hipGraph replays) with a new batch each: losses, weights, moving statistics and Adam
     moments of the scheduled program equal the plain one's bit for bit; riders were really hosted; no barrier ever timed out.
     'A': seg backward || T-Net / box chain; 'F' (stage c): the class-agnostic heads + W_ IoU summary || the refinement branch

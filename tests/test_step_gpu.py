@@ -25,9 +25,10 @@ def test_five_replayed_steps_follow_the_oracle(hip_lib, workload):
 
 
 @pytest.mark.parametrize('workload', ['A', 'boxpc', 'F'])
-def test_three_replayed_steps_at_the_headline_size_follow_the_oracle(hip_lib, workload):
+def test_three_replayed_steps_at_the_headline_size_follow_the_oracle(hip_lib, gemm_arithmetic, workload):
     """BASELINE configs[1], [2], [3] at their own size: B=32, N=1024, C=4 (the plans differ from the small cases': tile widths,
-    weight-gradient splits, which launches host riders)."""
+    weight-gradient splits, which launches host riders), under both GEMM arithmetics of the fp32 path (the default three-term bf16
+    form and the fp32-MFMA kernels)."""
     rep = trajectory_check(Runtime(lib=hip_lib), workload, steps=3, B=32, N=1024, use_hip_graph=True, verbose=True)
     assert rep[-1]['graph_segments'] == 1
 

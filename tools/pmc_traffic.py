@@ -51,6 +51,8 @@ def label(kernel_name):
             return None
         name, targs = m.group(1), [t.strip() for t in (m.group(2) or '').split(',') if t.strip()]
         ints = [t for t in targs if t.isdigit()]          # tile sizes; the bool / type template arguments are not part of the label
+    if 'PathX3' in kernel_name:          # fp32 layers on the bf16 matrix pipe (three-term operands): k_..._x3<...> / k_..._x3_r<...>
+        name = name[:-2] + '_x3_r' if name.endswith('_r') else name + '_x3'
     if name.startswith(('k_pointmlp', 'k_pool_bwd_stage')) and ints:
         return '%s<%s>' % (name, ','.join(ints))
     return name

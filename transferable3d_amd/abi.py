@@ -305,6 +305,11 @@ ENTRY_POINTS = {
     't3d_pointmlp_bwd_r': [C.POINTER(PointMlpDgradArgs), C.POINTER(PointMlpWgradArgs), C.POINTER(RiderSet), VP],
     't3d_pool_bwd_stage1_r': [C.POINTER(PointMlpGramArgs), C.POINTER(ActColsumArgs), C.POINTER(PoolBwdPrepArgs), C.POINTER(RiderSet), VP],
     't3d_pool_bwd_stage2_r': [C.POINTER(PoolWgradFinishArgs), C.POINTER(PointMlpDgradGramArgs), C.POINTER(RiderSet), VP],
+    't3d_pointmlp_fwd_hosts_riders': [C.POINTER(PointMlpFwdArgs)],
+    't3d_pointmlp_wgrad_hosts_riders': [C.POINTER(PointMlpWgradArgs)],
+    't3d_pointmlp_bwd_hosts_riders': [C.POINTER(PointMlpDgradArgs), C.POINTER(PointMlpWgradArgs)],
+    't3d_pool_bwd_stage1_hosts_riders': [C.POINTER(PointMlpGramArgs), C.POINTER(ActColsumArgs), C.POINTER(PoolBwdPrepArgs)],
+    't3d_pool_bwd_stage2_hosts_riders': [C.POINTER(PoolWgradFinishArgs), C.POINTER(PointMlpDgradGramArgs)],
     't3d_gram_plan': [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)],
     't3d_bn_bwd_finalize': [C.POINTER(BnBwdFinalizeArgs), VP],
     't3d_dy_colsum': [C.POINTER(DyColsumArgs), VP],

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
 LIB_PATH = os.path.join(HERE, 'libt3d.so')
-SOURCES = ['pointmlp.hip', 'bn_optim.hip', 'fc.hip', 'heads.hip', 'boxpc.hip', 'poolbwd.hip', 'data.hip', 'weak.hip', 'pair.hip', 'version.hip']
+SOURCES = ['pointmlp.hip', 'pointmlp_x3.hip', 'bn_optim.hip', 'fc.hip', 'heads.hip', 'boxpc.hip', 'poolbwd.hip', 'data.hip', 'weak.hip', 'pair.hip', 'version.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
 MARKER = b'T3D_SOURCE_HASH='
 
@@ -49,6 +49,8 @@ def _object_key(src, extra_flags):
     import hashlib
     h = hashlib.sha256()
     deps = [os.path.join(CSRC, src)] + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')) + [os.path.join(INCLUDE, 't3d.h')]
+    if src == 'pointmlp_x3.hip':
+        deps.append(os.path.join(CSRC, 'pointmlp.hip'))      # (it is that file, compiled with T3D_X3_TU)
     for d in deps:
         with open(d, 'rb') as fh:
             h.update(fh.read())

@@ -849,6 +849,193 @@ __device__ __forceinline__ void gemm_mainloop_h(SA& sa, SB& sb, const LA& la, co
   __syncthreads();
 }
 
+// ---------------------------------------------------------------------------------------------
+// fp32 GEMMs on the bf16 matrix pipe: every operand split into three bf16 terms (T3D_X3)
+// ---------------------------------------------------------------------------------------------
+// gfx950 has no TF32 and its fp32 MFMA (v_mfma_f32_32x32x2_f32, 64 FLOP / cycle / SIMD) runs at 1/16 of the bf16 rate.  An fp32 value
+// is the exact sum of three bf16 values, x = h + m + l with h = bf16(x), m = bf16(x - h), l = bf16(x - h - m) (8 + 8 + 8 significand
+// bits; both subtractions are exact in fp32), and the product of two bf16 values is exact in fp32.  So
+//     x y = hh + (hm + mh) + (hl + lh + mm) + [ml + lm + ll]
+// where the bracket is below 2^-24 |x y|: SIX bf16 MFMAs with fp32 accumulation reproduce the fp32 product to fp32 rounding (the
+// dropped terms are of the size of the rounding of the fp32 fma chain they replace) at 16 / 6 = 2.7x the fp32 MFMA rate.  Storage,
+// loaders, fused element-wise work and epilogues are the fp32 path's; only the LDS images (three bf16 planes per operand tile, in the
+// layouts of the bf16 path) and the main loop differ.  Results agree with the fp32 MFMA kernels to the last bits, not bit for bit
+// (another summation order): the launchers take this path only when asked (T3D_X3, see t3d_pointmlp_fwd_r).
+constexpr int BKX = 16;             // reduction depth of an LDS stage = ONE step of v_mfma_f32_32x32x16_bf16
+constexpr int LDRX = BKX + 8;       // R image row: 24 bf16 = 48 B = 12 dwords: the 16 lanes of a ds_read_b128 tile the 64 banks
+
+__device__ __forceinline__ void split3(const float4& v, bf16x4& h, bf16x4& m, bf16x4& l) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+#ifdef T3D_ABL_X3_FAKESPLIT      // timing ablation (wrong results): one conversion, no residuals
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { h[e] = (bf16_t)x[e]; m[e] = h[e]; l[e] = h[e]; }
+  return;
+#endif
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const bf16_t a = (bf16_t)x[e];
+    const float r1 = x[e] - (float)a;          // exact
+    const bf16_t b = (bf16_t)r1;
+    const float r2 = r1 - (float)b;            // exact
+    h[e] = a; m[e] = b; l[e] = (bf16_t)r2;
+  }
+}
+
+// one [DIM x BKX] operand tile: fp32 loader -> registers -> three bf16 planes in LDS (R image [DIM][LDRX] / C image [BKX][DIM + 32])
+template <int DIM, bool TYPE_R, class L>
+struct StagerX3 {
+  static constexpr int PF = 1;
+  static constexpr int NV = DIM * (BKX / 4) / NT;
+  static constexpr int LDC = DIM + 32;
+  static constexpr int PLANE = TYPE_R ? DIM * LDRX : BKX * LDC;      // bf16 elements of one plane
+  static constexpr int LDS_ELEMS = 3 * PLANE;
+  static_assert(NV >= 1, "tile smaller than one staging pass");
+  typename L::Raw raw[NV];
+  typename L::Coef coef;
+  int lane0, red0;
+
+  __device__ __forceinline__ static void coords(int tid, int q, int& lane_i, int& red_i) {
+    const int f = tid + NT * q;
+    if (TYPE_R) { constexpr int CH = BKX / 4; lane_i = f / CH; red_i = (f % CH) * 4; }
+    else { constexpr int C4 = DIM / 4; red_i = f / C4; lane_i = (f % C4) * 4; }
+  }
+  __device__ __forceinline__ void init(const L& l, int lane0_, int tid) {
+    lane0 = lane0_;
+    if (!TYPE_R) { int li, ri; coords(tid, 0, li, ri); coef = l.fetch_coef(lane0 + li); }
+  }
+  __device__ __forceinline__ void fetch(const L& l, int red0_, int tid) {
+    red0 = red0_;
+    if (TYPE_R) { int li, ri; coords(tid, 0, li, ri); coef = l.fetch_coef(red0_ + ri); }
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      int li, ri; coords(tid, q, li, ri);
+      raw[q] = TYPE_R ? l.fetch(lane0 + li, red0_ + ri) : l.fetch(red0_ + ri, lane0 + li);
+    }
+  }
+  __device__ __forceinline__ void store_piece(const L& l, bf16_t* tile, int tid, int q) {
+    int li, ri; coords(tid, q, li, ri);
+    const float4 v = TYPE_R ? l.xform(raw[q], coef, lane0 + li, red0 + ri) : l.xform(raw[q], coef, red0 + ri, lane0 + li);
+    bf16x4 h, m, lo;
+    split3(v, h, m, lo);
+    bf16_t* dst = tile + (TYPE_R ? li * LDRX + ri : ri * LDC + li);
+    *reinterpret_cast<bf16x4*>(dst) = h;
+    *reinterpret_cast<bf16x4*>(dst + PLANE) = m;
+    *reinterpret_cast<bf16x4*>(dst + 2 * PLANE) = lo;
+  }
+  __device__ __forceinline__ void store(const L& l, bf16_t* tile, int tid) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q) store_piece(l, tile, tid, q);
+  }
+};
+
+// fragment of the tile's one MFMA step for the 32 operand rows / columns starting at c0 (cf. frag_h)
+template <bool TYPE_R, int DIM>
+__device__ __forceinline__ bf16x8 frag_x(const bf16_t* img, int c0, int lane) {
+  if (TYPE_R) {
+    return *reinterpret_cast<const bf16x8*>(img + (c0 + (lane & 31)) * LDRX + 8 * (lane >> 5));
+  } else {
+    constexpr int LDC = DIM + 32;
+    const int k0 = 8 * (lane >> 5);
+    const bf16_t* base = img + (k0 + ((lane & 15) >> 2)) * LDC + c0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + 4 * LDC));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+  }
+}
+
+// The six products of one 16-deep step, smallest terms first; after each product's TM*TN MFMAs `filler(p)` runs (staging pieces of the
+// next tile: their conversions issue in the shadows of the MFMAs).
+// SYM (Gram matrices, both operands the same tensor): the result must be BITWISE symmetric -- the weight-gradient assembly reads G
+// transposed (t3d_pool_wgrad_finish) -- but G[i][j] sums l_i h_j, h_i l_j, ... and G[j][i] the same values in another order.  Three
+// accumulators make the order irrelevant: A takes l h and m h, B takes h l and h m, C the symmetric m m and h h; then A[j][i] is
+// bit for bit B[i][j], C is symmetric, and (A + B) + C is the same number on both sides (two-term fp32 addition commutes).
+template <bool SYM, int TM, int TN, bool AR, int DIMA, int PLA, bool BR, int DIMB, int PLB, class F>
+__device__ __forceinline__ void mma_x3(const bf16_t* As, const bf16_t* Bs, int a0, int b0, f32x16 (&acc)[TM][TN], f32x16 (&accb)[SYM ? TM : 1][SYM ? TN : 1],
+                                       f32x16 (&accc)[SYM ? TM : 1][SYM ? TN : 1], int lane, F&& filler) {
+  bf16x8 fa[3][TM], fb[3][TN];
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) fa[pl][tm] = frag_x<AR, DIMA>(As + pl * PLA, a0 + tm * 32, lane);
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) fb[pl][tn] = frag_x<BR, DIMB>(Bs + pl * PLB, b0 + tn * 32, lane);
+  }
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};      // l h, h l, m m, m h, h m, h h
+  constexpr int TG[6] = {0, 1, 2, 0, 1, 2};                                  // SYM: which accumulator
+#pragma unroll
+  for (int p = 0; p < 6; ++p) {
+#ifdef T3D_ABL_X3_1PROD      // timing ablation (wrong results): one product instead of six
+    if (p == 5)
+#endif
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        if constexpr (SYM) {
+          if (TG[p] == 0) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[p]][tm], fb[PB[p]][tn], acc[tm][tn], 0, 0, 0);
+          else if (TG[p] == 1) accb[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[p]][tm], fb[PB[p]][tn], accb[tm][tn], 0, 0, 0);
+          else accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[p]][tm], fb[PB[p]][tn], accc[tm][tn], 0, 0, 0);
+        } else {
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[p]][tm], fb[PB[p]][tn], acc[tm][tn], 0, 0, 0);
+        }
+      }
+    filler(p);
+  }
+}
+
+// Two LDS stages, one barrier per 16-deep k-tile, one register slot per operand: iteration t multiplies tile t from stage t&1 while
+// tile t+1 (requested one iteration earlier) is transformed, split and written into the other stage between the MFMAs, then
+// requests tile t+2.
+template <bool SYM, int TM, int TN, class SA, class SB, class LA, class LB, bool AR, int DIMA, bool BR, int DIMB>
+__device__ __forceinline__ void gemm_mainloop_x3(SA& sa, SB& sb, const LA& la, const LB& lb, float* smem_f, int red_begin, int red_end,
+                                                 int a0, int b0, f32x16 (&acc)[TM][TN], int tid) {
+  static_assert(!SYM || TM * TN == 1, "symmetric accumulation: 64 x 64 tiles (three accumulator sets)");
+  f32x16 accb[SYM ? TM : 1][SYM ? TN : 1], accc[SYM ? TM : 1][SYM ? TN : 1];
+  if constexpr (SYM) { zero_acc<TM, TN>(accb); zero_acc<TM, TN>(accc); }
+  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_f);
+  constexpr int STAGE = SA::LDS_ELEMS + SB::LDS_ELEMS;
+  static_assert(SA::NV + SB::NV <= 6, "staging pieces must fit the six product groups");
+  const int lane = tid & 63;
+  const int last = red_end - BKX;
+  sa.fetch(la, red_begin, tid);
+  sb.fetch(lb, red_begin, tid);
+  sa.store(la, smem, tid);
+  sb.store(lb, smem + SA::LDS_ELEMS, tid);
+  sa.fetch(la, min(red_begin + BKX, last), tid);
+  sb.fetch(lb, min(red_begin + BKX, last), tid);
+  __syncthreads();
+  int cur = 0;
+  for (int red = red_begin; red + BKX < red_end; red += BKX) {
+    const bf16_t* As = smem + cur * STAGE;
+    const bf16_t* Bs = As + SA::LDS_ELEMS;
+    bf16_t* An = smem + (cur ^ 1) * STAGE;
+    bf16_t* Bn = An + SA::LDS_ELEMS;
+    mma_x3<SYM, TM, TN, AR, DIMA, SA::PLANE, BR, DIMB, SB::PLANE>(As, Bs, a0, b0, acc, accb, accc, lane, [&](int p) {
+      if (p < SA::NV) sa.store_piece(la, An, tid, p);
+      else if (p - SA::NV < SB::NV) sb.store_piece(lb, Bn, tid, p - SA::NV);
+    });
+    __builtin_amdgcn_sched_barrier(0);      // the new loads stay behind every wait on the previous batch (vmcnt counts in issue order)
+    const int nxt = min(red + 2 * BKX, last);
+    sa.fetch(la, nxt, tid);
+    sb.fetch(lb, nxt, tid);
+    __syncthreads();
+    cur ^= 1;
+  }
+  {
+    const bf16_t* As = smem + cur * STAGE;
+    mma_x3<SYM, TM, TN, AR, DIMA, SA::PLANE, BR, DIMB, SB::PLANE>(As, As + SA::LDS_ELEMS, a0, b0, acc, accb, accc, lane, [](int) {});
+  }
+  if constexpr (SYM) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tm][tn][r] = (acc[tm][tn][r] + accb[tm][tn][r]) + accc[tm][tn][r];
+  }
+  __syncthreads();
+}
+
 // Arithmetic of a GEMM kernel: which staging / MFMA loop, and the element type T of the layer tensors it writes.
 struct PathF32 {
   typedef float T;
@@ -857,6 +1044,7 @@ struct PathF32 {
   typedef WLoaderT<float> WL;            // loader of the layer's weight matrix
   typedef WLoaderT<float> WLX;           // ... when every tile lies inside the matrix (the fp32 path keeps its one loader)
   static constexpr bool BF16 = false;
+  static constexpr bool X3 = false;
   static constexpr int RED = BK;         // reduction depth of an LDS stage
   template <int DIM, bool TYPE_R, class L, int PF, bool IS_A = false> using Stg = Stager<DIM, TYPE_R, L, PF>;
 };
@@ -867,16 +1055,30 @@ struct PathBF16 {
   typedef WLoaderT<bf16_t> WL;           // `w` points at the bf16 copy of the weights (t3d_cast_bf16)
   typedef WLoaderT<bf16_t, true> WLX;
   static constexpr bool BF16 = true;
+  static constexpr bool X3 = false;
   static constexpr int RED = BKH;
   // the first operand of every GEMM here is the [M, C] stream from HBM: two register slots (prefetch distance 2); the second
   // (weights from L2, or the fatter dy operand of the weight gradient) one
   // (PF == 0: one slot for the first operand too -- the 128-column data-gradient tilings, whose second slot spilled 10-27 VGPRs to scratch)
   template <int DIM, bool TYPE_R, class L, int PF, bool IS_A = false> using Stg = StagerHSel<DIM, TYPE_R, L, (IS_A && PF != 0) ? 2 : 1>;
 };
-template <class PR, int TM, int TN, class SA, class SB, class LA, class LB, bool AR, int DIMA, bool BR, int DIMB>
+// fp32 storage and loaders, bf16 x 3 arithmetic (see above)
+struct PathX3 {
+  typedef float T;
+  template <bool HAS_SUB, class XT> using Act = ActLoader<HAS_SUB>;
+  template <bool POOLED> using Dy = DyLoader<POOLED>;
+  typedef WLoaderT<float> WL;
+  typedef WLoaderT<float> WLX;
+  static constexpr bool BF16 = false;
+  static constexpr bool X3 = true;
+  static constexpr int RED = BKX;
+  template <int DIM, bool TYPE_R, class L, int PF, bool IS_A = false> using Stg = StagerX3<DIM, TYPE_R, L>;
+};
+template <class PR, int TM, int TN, class SA, class SB, class LA, class LB, bool AR, int DIMA, bool BR, int DIMB, bool SYM = false>
 __device__ __forceinline__ void run_mainloop(SA& sa, SB& sb, const LA& la, const LB& lb, float* smem, int red_begin, int red_end,
                                              int a0, int b0, f32x16 (&acc)[TM][TN], int tid) {
-  if constexpr (PR::BF16) gemm_mainloop_h<TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, red_begin, red_end, a0, b0, acc, tid);
+  if constexpr (PR::X3) gemm_mainloop_x3<SYM, TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, red_begin, red_end, a0, b0, acc, tid);
+  else if constexpr (PR::BF16) gemm_mainloop_h<TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, red_begin, red_end, a0, b0, acc, tid);
   else gemm_mainloop<TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, red_begin, red_end, a0, b0, acc, tid);
 }
 
@@ -1078,11 +1280,11 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd(const t3d_pointm
 
 // Rider forms (rider_dev.h): the launch's first r.n_wg workgroups run a set of small ops of an independent chain and leave; the
 // GEMM's tiles are the workgroups behind them.  fp32 split-form kernels only; the plain kernels above and below are untouched.
-template <int BN, bool HAS_SUB>
+template <int BN, bool HAS_SUB, class PR = PathF32>
 __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd_r(const t3d_pointmlp_fwd_args p, const t3d_rider_set r) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if ((int)blockIdx.x < r.n_wg) { run_riders(r, smem); return; }
-  fwd_body<BN, HAS_SUB, PathF32, float>(p, smem, blockIdx.x - r.n_wg, gridDim.x - r.n_wg);
+  fwd_body<BN, HAS_SUB, PR, float>(p, smem, blockIdx.x - r.n_wg, gridDim.x - r.n_wg);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1766,7 +1968,7 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_dgrad_gram(const t3d
 // weight gradient (split over rows)
 // ---------------------------------------------------------------------------------------------
 // slab[split][k0.., n0..] = sum over the split's rows of A[m,k] B[m,n]; both operands type C (row index = reduction).
-template <int BMK, int BN, class PR = PathF32, class LA, class LB>
+template <int BMK, int BN, class PR = PathF32, bool SYM = false, class LA, class LB>      // SYM: see mma_x3 (Gram matrices on the x3 path)
 __device__ __forceinline__ void wgrad_body(const LA& la, const LB& lb, float* slabs, int K, int N, int rows_per_split,
                                            float* smem, int bid, int nblocks) {
   constexpr int TM = BMK / 64, TN = BN / 64;
@@ -1786,8 +1988,8 @@ __device__ __forceinline__ void wgrad_body(const LA& la, const LB& lb, float* sl
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
   const int m_begin = split * rows_per_split;
-  run_mainloop<PR, TM, TN, SA, SB, LA, LB, false, BMK, false, BN>(sa, sb, la, lb, smem, m_begin, m_begin + rows_per_split,
-                                                                  wm * (BMK / 2), wn * (BN / 2), acc, tid);
+  run_mainloop<PR, TM, TN, SA, SB, LA, LB, false, BMK, false, BN, SYM && PR::X3>(sa, sb, la, lb, smem, m_begin, m_begin + rows_per_split,
+                                                                                 wm * (BMK / 2), wn * (BN / 2), acc, tid);
   const int l31 = lane & 31, h = lane >> 5;
   float* slab = slabs + (size_t)split * K * N;
   if (k0 + BMK <= K) {
@@ -1915,7 +2117,7 @@ template <int BMK, int BN, class PR = PathF32>
 __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_gram(const t3d_pointmlp_gram_args p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   typename PR::template Act<false, typename PR::T> la{p.a, p.K, p.rows_per_frustum};
-  wgrad_body<BMK, BN, PR>(la, la, p.slabs, p.K, p.K, p.rows_per_split, smem, blockIdx.x, gridDim.x);
+  wgrad_body<BMK, BN, PR, true>(la, la, p.slabs, p.K, p.K, p.rows_per_split, smem, blockIdx.x, gridDim.x);
 }
 
 // One launch for both gradients of a dense layer: the first `n_wgrad` workgroups run weight-gradient tiles, the rest
@@ -1943,16 +2145,16 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_bwd(const t3d_pointm
   }
 }
 
-template <int DBN, int WBMK, int WBN>
+template <int DBN, int WBMK, int WBN, class PR = PathF32>
 __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_bwd_r(const t3d_pointmlp_dgrad_args d, const t3d_pointmlp_wgrad_args w,
                                                                   const int n_wgrad, const t3d_rider_set r) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if ((int)blockIdx.x < r.n_wg) { run_riders(r, smem); return; }
   const int bid = blockIdx.x - r.n_wg, nblk = gridDim.x - r.n_wg;
-  typename PathF32::template Act<false, float> la{w.a, w.K, w.rows_per_frustum};
-  typename PathF32::template Dy<false> lb{w.dy, w.N, w.rows_per_frustum};
-  if (bid < n_wgrad) wgrad_body<WBMK, WBN, PathF32>(la, lb, w.slabs, w.K, w.N, w.rows_per_split, smem, bid, n_wgrad);
-  else dgrad_body<DBN, false, PathF32>(d, smem, bid - n_wgrad, nblk - n_wgrad);
+  typename PR::template Act<false, float> la{w.a, w.K, w.rows_per_frustum};
+  typename PR::template Dy<false> lb{w.dy, w.N, w.rows_per_frustum};
+  if (bid < n_wgrad) wgrad_body<WBMK, WBN, PR>(la, lb, w.slabs, w.K, w.N, w.rows_per_split, smem, bid, n_wgrad);
+  else dgrad_body<DBN, false, PR>(d, smem, bid - n_wgrad, nblk - n_wgrad);
 }
 
 // first layer of a net (raw points in, no data gradient): the weight gradient alone
@@ -2524,7 +2726,7 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pool_bwd_stage1(const t3d_poi
   const int b = blockIdx.x;
   if (b < n_gram) {
     typename PR::template Act<false, typename PR::T> la{g.a, g.K, g.rows_per_frustum};
-    wgrad_body<GT, GT, PR>(la, la, g.slabs, g.K, g.K, g.rows_per_split, smem, b, n_gram);
+    wgrad_body<GT, GT, PR, true>(la, la, g.slabs, g.K, g.K, g.rows_per_split, smem, b, n_gram);
   } else if (b < n_gram + n_colsum) {
     act_colsum_body<typename PR::T>(c, smem, b - n_gram);
   } else {
@@ -2548,7 +2750,7 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pool_bwd_stage2(const t3d_poo
   }
 }
 
-template <int GT>
+template <int GT, class PR = PathF32>
 __global__ __launch_bounds__(NT, T3D_WAVES) void k_pool_bwd_stage1_r(const t3d_pointmlp_gram_args g, const t3d_act_colsum_args c,
                                                                      const t3d_pool_bwd_prep_args q, const int n_gram,
                                                                      const int n_colsum, const t3d_rider_set r) {
@@ -2556,8 +2758,8 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pool_bwd_stage1_r(const t3d_p
   if ((int)blockIdx.x < r.n_wg) { run_riders(r, smem); return; }
   const int b = blockIdx.x - r.n_wg;
   if (b < n_gram) {
-    typename PathF32::template Act<false, float> la{g.a, g.K, g.rows_per_frustum};
-    wgrad_body<GT, GT, PathF32>(la, la, g.slabs, g.K, g.K, g.rows_per_split, smem, b, n_gram);
+    typename PR::template Act<false, float> la{g.a, g.K, g.rows_per_frustum};
+    wgrad_body<GT, GT, PR, true>(la, la, g.slabs, g.K, g.K, g.rows_per_split, smem, b, n_gram);
   } else if (b < n_gram + n_colsum) {
     act_colsum_body<float>(c, smem, b - n_gram);
   } else {
@@ -2566,7 +2768,7 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pool_bwd_stage1_r(const t3d_p
   }
 }
 
-template <int BN>
+template <int BN, class PR = PathF32>
 __global__ __launch_bounds__(NT, T3D_WAVES) void k_pool_bwd_stage2_r(const t3d_pool_wgrad_finish_args f,
                                                                      const t3d_pointmlp_dgrad_gram_args d, const int n_finish,
                                                                      const t3d_rider_set r) {
@@ -2577,7 +2779,7 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pool_bwd_stage2_r(const t3d_p
     const int kb = f.K / FK;
     pool_wgrad_finish_body<float>(f, smem, b % kb, b / kb);
   } else {
-    dgrad_gram_body<BN, PathF32>(d, smem, b - n_finish, (int)gridDim.x - r.n_wg - n_finish);
+    dgrad_gram_body<BN, PR>(d, smem, b - n_finish, (int)gridDim.x - r.n_wg - n_finish);
   }
 }
 
@@ -3181,10 +3383,25 @@ constexpr size_t lds_epi2(int bn) { return (size_t)12 * bn * sizeof(float) + 2 *
 constexpr size_t lds_max(size_t a, size_t b) { return a > b ? a : b; }
 constexpr size_t lds_dgrad_h(int bn) { return lds_max(2 * (size_t)(128 * LDRH + bn * LDRH) * 2, lds_epi2(bn)); }
 constexpr size_t lds_wgrad_h(int bmk, int bn) { return 2 * (size_t)BKH * (bmk + 32 + bn + 32) * 2; }
+// x3 path: two stages of three bf16 planes per operand (R image [dim][LDRX] / C image [BKX][dim + 32])
+constexpr size_t lds_x3_r(int dim) { return (size_t)3 * dim * LDRX * 2; }
+constexpr size_t lds_x3_c(int dim) { return (size_t)3 * BKX * (dim + 32) * 2; }
+constexpr size_t lds_fwd_x3(int bn) { return lds_max(2 * (lds_x3_r(128) + lds_x3_c(bn)), (size_t)12 * bn * sizeof(float)); }
+constexpr size_t lds_dgrad_x3(int bn) { return lds_max(2 * (lds_x3_r(128) + lds_x3_r(bn)), (size_t)12 * bn * sizeof(float)); }
+constexpr size_t lds_wgrad_x3(int bmk, int bn) { return 2 * (lds_x3_c(bmk) + lds_x3_c(bn)); }
 constexpr size_t lds_bwd1f(int k, int n) { return (size_t)(64 * ((n + 4) + 3 * (k + 4)) + 2 * 2 * 2 * k + 3 * n + 2 * k) * 4; }      // D, A, 2 x X images, statistics scratch, per-column constants
 constexpr size_t lds_bwd1(int k, int n, int bm) { return (size_t)bm * (n + k + 2 * (k + 8)) * 2 + (size_t)2 * 2 * 4 * k * 4; }      // D, A, 2 x X images + the statistics scratch
 
 bool dtype_ok(int dt) { return dt == T3D_F32 || dt == T3D_BF16; }
+// fp32 layers run on the bf16 matrix pipe with three-term operands (PathX3) unless T3D_X3=0 (the fp32-MFMA kernels); T3D_X3_MINKN /
+// T3D_X3_MINKN_BWD: only launches with K x N at least that (default 1: every launch -- measured on the B=32 N=1024 step, one MI355X:
+// 1.440 ms fp32-MFMA, 1.304 with K x N >= 128 x 128, 1.295 with every launch).
+// (read at every launch -- a getenv is nanoseconds and a captured graph keeps what was launched -- so that one process can compare both)
+int x3_mode() { const char* e = getenv("T3D_X3"); return e ? atoi(e) : 1; }
+long x3_min_kn() { const char* e = getenv("T3D_X3_MINKN"); return e ? atol(e) : 1L; }
+long x3_min_kn_bwd() { const char* e = getenv("T3D_X3_MINKN_BWD"); return e ? atol(e) : x3_min_kn(); }
+bool x3_layer(int K, int N) { return x3_mode() != 0 && (long)K * N >= x3_min_kn(); }            // forward launches
+bool x3_layer_bwd(int K, int N) { return x3_mode() != 0 && (long)K * N >= x3_min_kn_bwd(); }    // backward launches (dense and Gram form)
 bool act_ok(const t3d_act_src& a, int K) {
   return a.x != nullptr && (a.ldx % 4) == 0 && (a.coff % 4) == 0 && a.coff + (K + 3) / 4 * 4 <= a.ldx &&
          (a.scale == nullptr || a.shift != nullptr) && dtype_ok(a.dtype) && !(a.dtype == T3D_BF16 && a.sub != nullptr) &&
@@ -3202,9 +3419,159 @@ size_t lds_with(size_t lds, const t3d_rider_set* r) { return r && (size_t)r->lds
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------
+// The T3D_X3 kernels are instantiated in a translation unit of their own (csrc/pointmlp_x3.hip = this file with T3D_X3_TU defined:
+// the device templates above, these launch helpers, none of the entry points below): hipcc spends two minutes on this file as it is.
+// ---------------------------------------------------------------------------------------------
+int t3d_x3_fwd(const t3d_pointmlp_fwd_args* a, const t3d_rider_set* r, hipStream_t s);
+int t3d_x3_bwd(const t3d_pointmlp_dgrad_args* d, const t3d_pointmlp_wgrad_args* w, const t3d_rider_set* r, int tk, int tn, bool wide,
+               int n_w, int n_d, hipStream_t s);
+int t3d_x3_stage1(const t3d_pointmlp_gram_args* g, const t3d_act_colsum_args* c, const t3d_pool_bwd_prep_args* q, const t3d_rider_set* r,
+                  int gt, int n_gram, int n_colsum, int n_prep, size_t lds_other, hipStream_t s);
+int t3d_x3_stage2(const t3d_pool_wgrad_finish_args* f, const t3d_pointmlp_dgrad_gram_args* d, const t3d_rider_set* r, bool wide,
+                  int n_finish, int n_d, size_t lds_other, hipStream_t s);
+int t3d_x3_dgrad(const t3d_pointmlp_dgrad_args* a, bool wide, hipStream_t s);
+int t3d_x3_wgrad(const t3d_pointmlp_wgrad_args* a, int tk, int tn, int n_blocks, hipStream_t s);
+int t3d_x3_gram(const t3d_pointmlp_gram_args* a, int tk, int n_blocks, hipStream_t s);
+int t3d_x3_dgrad_gram(const t3d_pointmlp_dgrad_gram_args* a, bool wide, hipStream_t s);
+
+#ifdef T3D_X3_TU
+int t3d_x3_dgrad(const t3d_pointmlp_dgrad_args* a, bool wide, hipStream_t s) {
+  const int tiles_m = a->M / 128;
+  if (wide) launch_lds(k_pointmlp_dgrad<128, false, PathX3>, dim3(tiles_m * (a->K / 128)), lds_dgrad_x3(128), s, *a);
+  else launch_lds(k_pointmlp_dgrad<64, false, PathX3>, dim3(tiles_m * (a->K / 64)), lds_dgrad_x3(64), s, *a);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+int t3d_x3_wgrad(const t3d_pointmlp_wgrad_args* a, int tk, int tn, int n_blocks, hipStream_t s) {
+  const dim3 grid(n_blocks);
+#define T3D_WGX(TK, TN_) launch_lds(k_pointmlp_wgrad<TK, TN_, false, false, PathX3, float>, grid, lds_wgrad_x3(TK, TN_), s, *a)
+  if (tk == 128 && tn == 128) T3D_WGX(128, 128);
+  else if (tk == 128) T3D_WGX(128, 64);
+  else if (tn == 128) T3D_WGX(64, 128);
+  else T3D_WGX(64, 64);
+#undef T3D_WGX
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+int t3d_x3_gram(const t3d_pointmlp_gram_args* a, int tk, int n_blocks, hipStream_t s) {
+  if (tk != 64) return T3D_ERR_ARG;      // (64 x 64 tiles: the symmetric accumulation keeps three accumulator sets)
+  launch_lds(k_pointmlp_gram<64, 64, PathX3>, dim3(n_blocks), lds_wgrad_x3(64, 64), s, *a);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+int t3d_x3_dgrad_gram(const t3d_pointmlp_dgrad_gram_args* a, bool wide, hipStream_t s) {
+  const int tiles_m = a->M / 128;
+  if (wide) launch_lds(k_pointmlp_dgrad_gram<128, PathX3>, dim3(tiles_m * (a->K / 128)), lds_fwd_x3(128), s, *a);
+  else launch_lds(k_pointmlp_dgrad_gram<64, PathX3>, dim3(tiles_m * (a->K / 64)), lds_fwd_x3(64), s, *a);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+int t3d_x3_fwd(const t3d_pointmlp_fwd_args* a, const t3d_rider_set* r, hipStream_t s) {
+  const int tiles_m = a->M / 128, nr = r ? r->n_wg : 0;
+  if (a->N % 128 == 0 && (long)tiles_m * (a->N / 128) >= 512) {
+    const dim3 grid(tiles_m * (a->N / 128) + nr);
+    if (r) launch_lds_r(k_pointmlp_fwd_r<128, false, PathX3>, grid, lds_with(lds_fwd_x3(128), r), s, *a, *r);
+    else launch_lds(k_pointmlp_fwd<128, false, PathX3, float>, grid, lds_fwd_x3(128), s, *a);
+  } else {
+    const dim3 grid(tiles_m * (a->N / 64) + nr);
+    if (r) launch_lds_r(k_pointmlp_fwd_r<64, false, PathX3>, grid, lds_with(lds_fwd_x3(64), r), s, *a, *r);
+    else launch_lds(k_pointmlp_fwd<64, false, PathX3, float>, grid, lds_fwd_x3(64), s, *a);
+  }
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+int t3d_x3_bwd(const t3d_pointmlp_dgrad_args* d, const t3d_pointmlp_wgrad_args* w, const t3d_rider_set* r, int tk, int tn, bool wide,
+               int n_w, int n_d, hipStream_t s) {
+  const dim3 grid(n_w + n_d + (r ? r->n_wg : 0));
+#define T3D_BWDX(DBN, TK, TN_)                                                                    \
+  do {                                                                                             \
+    const size_t lds = lds_max(lds_dgrad_x3(DBN), lds_wgrad_x3(TK, TN_));                          \
+    if (r) {                                                                                       \
+      auto kern = k_pointmlp_bwd_r<DBN, TK, TN_, PathX3>;                                          \
+      allow_lds(reinterpret_cast<const void*>(kern), lds_with(lds, r));                            \
+      T3D_LAUNCH(kern, grid, dim3(NT), lds_with(lds, r), s, *d, *w, n_w, *r);                      \
+    } else {                                                                                       \
+      auto kern = k_pointmlp_bwd<DBN, TK, TN_, PathX3>;                                            \
+      allow_lds(reinterpret_cast<const void*>(kern), lds);                                         \
+      T3D_LAUNCH(kern, grid, dim3(NT), lds, s, *d, *w, n_w, 0);                                    \
+    }                                                                                              \
+  } while (0)
+#define T3D_BWDX_W(DBN)                                  \
+  do {                                                   \
+    if (tk == 128 && tn == 128) T3D_BWDX(DBN, 128, 128); \
+    else if (tk == 128) T3D_BWDX(DBN, 128, 64);          \
+    else if (tn == 128) T3D_BWDX(DBN, 64, 128);          \
+    else T3D_BWDX(DBN, 64, 64);                          \
+  } while (0)
+  if (wide) T3D_BWDX_W(128);
+  else T3D_BWDX_W(64);
+#undef T3D_BWDX_W
+#undef T3D_BWDX
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+int t3d_x3_stage1(const t3d_pointmlp_gram_args* g, const t3d_act_colsum_args* c, const t3d_pool_bwd_prep_args* q, const t3d_rider_set* r,
+                  int gt, int n_gram, int n_colsum, int n_prep, size_t lds_other, hipStream_t s) {
+  const dim3 grid(n_gram + n_colsum + n_prep + (r ? r->n_wg : 0));
+  const size_t lds = lds_with(lds_max(lds_wgrad_x3(gt, gt), lds_other), r);
+#define T3D_ST1X(GT_)                                                                  \
+  do {                                                                                 \
+    if (r) {                                                                           \
+      auto kern = k_pool_bwd_stage1_r<GT_, PathX3>;                                    \
+      allow_lds(reinterpret_cast<const void*>(kern), lds);                             \
+      T3D_LAUNCH(kern, grid, dim3(NT), lds, s, *g, *c, *q, n_gram, n_colsum, *r);      \
+    } else {                                                                           \
+      auto kern = k_pool_bwd_stage1<GT_, PathX3>;                                      \
+      allow_lds(reinterpret_cast<const void*>(kern), lds);                             \
+      T3D_LAUNCH(kern, grid, dim3(NT), lds, s, *g, *c, *q, n_gram, n_colsum);          \
+    }                                                                                  \
+  } while (0)
+  if (gt != 64) return T3D_ERR_ARG;      // (see t3d_x3_gram)
+  T3D_ST1X(64);
+#undef T3D_ST1X
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+int t3d_x3_stage2(const t3d_pool_wgrad_finish_args* f, const t3d_pointmlp_dgrad_gram_args* d, const t3d_rider_set* r, bool wide,
+                  int n_finish, int n_d, size_t lds_other, hipStream_t s) {
+  const dim3 grid(n_finish + n_d + (r ? r->n_wg : 0));
+  const size_t lds = lds_with(lds_max(wide ? lds_fwd_x3(128) : lds_fwd_x3(64), lds_other), r);
+#define T3D_ST2X(BN_)                                                                  \
+  do {                                                                                 \
+    if (r) {                                                                           \
+      auto kern = k_pool_bwd_stage2_r<BN_, PathX3>;                                    \
+      allow_lds(reinterpret_cast<const void*>(kern), lds);                             \
+      T3D_LAUNCH(kern, grid, dim3(NT), lds, s, *f, *d, n_finish, *r);                  \
+    } else {                                                                           \
+      auto kern = k_pool_bwd_stage2<BN_, PathX3>;                                      \
+      allow_lds(reinterpret_cast<const void*>(kern), lds);                             \
+      T3D_LAUNCH(kern, grid, dim3(NT), lds, s, *f, *d, n_finish);                      \
+    }                                                                                  \
+  } while (0)
+  if (wide) T3D_ST2X(128); else T3D_ST2X(64);
+#undef T3D_ST2X
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+#else
+
+// "would this launch host a rider set inside the GEMM's grid?" is answered by the launchers themselves (t3d_*_hosts_riders below
+// call them with this pseudo-stream and a dummy set): at every point where the variant is decided they return 1 (rider form) or 0
+// (the set would run as a launch of its own) instead of launching -- the step scheduler needs no mirror of the dispatch rules.
+#define T3D_QUERY_STREAM (reinterpret_cast<t3d_stream_t>(static_cast<intptr_t>(-1)))
+#define T3D_HOSTED(r, stream) do { if ((stream) == T3D_QUERY_STREAM) return (r) ? 1 : 0; } while (0)
 // a launch whose kernel variant has no rider form: the set runs as a launch of its own in front of it
 #define T3D_RIDERS_FIRST(r, stream)                         \
   do {                                                      \
+    if ((stream) == T3D_QUERY_STREAM) return 0;             \
     if (r) {                                                \
       const int rc__ = t3d_run_riders(r, stream);           \
       if (rc__ != T3D_OK) return rc__;                      \
@@ -3286,6 +3653,10 @@ extern "C" int t3d_pointmlp_fwd_r(const t3d_pointmlp_fwd_args* a, const t3d_ride
       return T3D_OK;
     }
   }
+  if (!sub && a->K % BKX == 0 && x3_layer(a->K, a->N)) {      // (ahead of the A-resident fp32 kernel)
+    T3D_HOSTED(r, stream);
+    return t3d_x3_fwd(a, r, s);
+  }
   // max-pooled layer without an output tensor: the A-resident persistent kernel (T3D_FWD_POOL=0: the generic one)
   static const bool use_pool_kernel = []() { const char* e = getenv("T3D_FWD_POOL"); return !(e && e[0] == '0'); }();
   // K = 256 needs 16-deep weight tiles to fit the 133 KB panel next to them and measured slower than the generic kernel
@@ -3310,6 +3681,7 @@ extern "C" int t3d_pointmlp_fwd_r(const t3d_pointmlp_fwd_args* a, const t3d_ride
     T3D_CHECK_LAUNCH();
     return T3D_OK;
   }
+  T3D_HOSTED(r, stream);
   if (T3D_FORCE_TILE != 64 && a->N % 128 == 0 && (T3D_FORCE_TILE == 128 || (long)tiles_m * (a->N / 128) >= 512)) {
     const dim3 grid(tiles_m * (a->N / 128) + (r ? r->n_wg : 0));
     if (r) {
@@ -3355,6 +3727,7 @@ extern "C" int t3d_pointmlp_dgrad(const t3d_pointmlp_dgrad_args* a, t3d_stream_t
     T3D_CHECK_LAUNCH();
     return T3D_OK;
   }
+  if (!pooled && a->N % BKX == 0 && x3_layer_bwd(a->K, a->N)) return t3d_x3_dgrad(a, dgrad_wide(a), s);
   if (dgrad_wide(a)) {
     const dim3 grid(tiles_m * (a->K / 128));
     if (pooled) launch_lds(k_pointmlp_dgrad<128, true>, grid, lds_dgrad(128), s, *a);
@@ -3469,8 +3842,14 @@ extern "C" int t3d_pointmlp_wgrad_r(const t3d_pointmlp_wgrad_args* a, const t3d_
   const int tiles_k = (a->K + tk - 1) / tk, tiles_n = a->N / tn;
   const bool sub = a->a.sub != nullptr, pooled = a->dy.dz == nullptr;
   // rider form: the 64 x 64 tiling of a first layer's weight gradient (K <= 4 raw channels, fp32) only
-  const bool host = r && a->dy.dtype != T3D_BF16 && tk == 64 && tn == 64 && !pooled;
+  const bool x3w = a->dy.dtype != T3D_BF16 && !sub && !pooled && a->K % 64 == 0 && x3_layer_bwd(a->K, a->N);      // (no rider form)
+  // first layer of a net (K <= 4 raw channels): the register kernel, which has no rider form either and beats the generic kernel + a rider
+  static const bool use_tiny_w = []() { const char* e = getenv("T3D_WGRAD_TINYK"); return !(e && e[0] == '0'); }();
+  const bool tiny_w = use_tiny_w && a->dy.dtype != T3D_BF16 && !pooled && a->K <= 4 && (a->N == 64 || a->N == 128) && a->a.dtype == T3D_F32 &&
+                      a->a.ldx % 4 == 0 && a->a.coff % 4 == 0 && a->a.coff + 4 <= a->a.ldx && (a->a.scale == nullptr) == (a->a.shift == nullptr);
+  const bool host = r && a->dy.dtype != T3D_BF16 && tk == 64 && tn == 64 && !pooled && !x3w && !tiny_w;
   if (r && !host) { T3D_RIDERS_FIRST(r, stream); r = nullptr; }
+  T3D_HOSTED(r, stream);
   const dim3 grid(tiles_k * tiles_n * splits + (r ? r->n_wg : 0));
   if (a->dy.dtype == T3D_BF16) {
     const bool xh = a->a.dtype == T3D_BF16;
@@ -3495,15 +3874,14 @@ extern "C" int t3d_pointmlp_wgrad_r(const t3d_pointmlp_wgrad_args* a, const t3d_
     else if (pooled) launch_lds(k_pointmlp_wgrad<TK, TN_, false, true>, grid, lds_wgrad(TK, TN_), s, *a);          \
     else launch_lds(k_pointmlp_wgrad<TK, TN_, false, false>, grid, lds_wgrad(TK, TN_), s, *a);                     \
   } while (0)
-  static const bool use_tiny_w = []() { const char* e = getenv("T3D_WGRAD_TINYK"); return !(e && e[0] == '0'); }();
-  if (use_tiny_w && !r && !pooled && a->K <= 4 && (a->N == 64 || a->N == 128) && a->a.dtype == T3D_F32 && a->a.ldx % 4 == 0 &&
-      a->a.coff % 4 == 0 && a->a.coff + 4 <= a->a.ldx && (a->a.scale == nullptr) == (a->a.shift == nullptr)) {
+  if (tiny_w) {
     const dim3 gsp(splits);      // one workgroup per row split: the slab layout of the generic kernel
     if (a->N == 64) { if (sub) T3D_LAUNCH((k_pointmlp_wgrad_tinyk<64, true>), gsp, dim3(NT), 0, s, *a); else T3D_LAUNCH((k_pointmlp_wgrad_tinyk<64, false>), gsp, dim3(NT), 0, s, *a); }
     else { if (sub) T3D_LAUNCH((k_pointmlp_wgrad_tinyk<128, true>), gsp, dim3(NT), 0, s, *a); else T3D_LAUNCH((k_pointmlp_wgrad_tinyk<128, false>), gsp, dim3(NT), 0, s, *a); }
     T3D_CHECK_LAUNCH();
     return T3D_OK;
   }
+  if (x3w) return t3d_x3_wgrad(a, tk, tn, tiles_k * tiles_n * splits, s);
   if (r) {
     if (sub) launch_lds_r(k_pointmlp_wgrad_r<64, 64, true, false>, grid, lds_with(lds_wgrad(64, 64), r), s, *a, *r);
     else launch_lds_r(k_pointmlp_wgrad_r<64, 64, false, false>, grid, lds_with(lds_wgrad(64, 64), r), s, *a, *r);
@@ -3584,6 +3962,8 @@ extern "C" int t3d_pointmlp_dgrad_gram(const t3d_pointmlp_dgrad_gram_args* a, t3
   if (a->dtype == T3D_BF16) {
     if (dgrad_gram_wide(a)) launch_lds(k_pointmlp_dgrad_gram<128, PathBF16>, dim3(tiles_m * (a->K / 128)), lds_dgram_h(128), s, *a);
     else launch_lds(k_pointmlp_dgrad_gram<64, PathBF16>, dim3(tiles_m * (a->K / 64)), lds_dgram_h(64), s, *a);
+  } else if (a->K % BKX == 0 && x3_layer_bwd(a->K, a->K)) {
+    return t3d_x3_dgrad_gram(a, dgrad_gram_wide(a), s);
   } else if (dgrad_gram_wide(a))
     launch_lds(k_pointmlp_dgrad_gram<128>, dim3(tiles_m * (a->K / 128)), lds_fwd(128), s, *a);
   else
@@ -3619,11 +3999,14 @@ extern "C" int t3d_pointmlp_gram(const t3d_pointmlp_gram_args* a, t3d_stream_t s
   if (rc != T3D_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int splits = a->M / a->rows_per_split;
-  const int tk = gram_tile(a), tn = tk;
+  const bool x3g = a->a.dtype != T3D_BF16 && x3_layer_bwd(a->K, a->K);
+  const int tk = x3g ? 64 : gram_tile(a), tn = tk;
   const dim3 grid((a->K / tk) * (a->K / tn) * splits);
   if (a->a.dtype == T3D_BF16) {
     if (tk == 128) launch_lds(k_pointmlp_gram<128, 128, PathBF16>, grid, lds_wgrad_h(128, 128), s, *a);
     else launch_lds(k_pointmlp_gram<64, 64, PathBF16>, grid, lds_wgrad_h(64, 64), s, *a);
+  } else if (x3g) {
+    return t3d_x3_gram(a, tk, (a->K / tk) * (a->K / tn) * splits, s);
   } else if (tk == 128) launch_lds(k_pointmlp_gram<128, 128>, grid, lds_wgrad(128, 128), s, *a);
   else launch_lds(k_pointmlp_gram<64, 64>, grid, lds_wgrad(64, 64), s, *a);
   T3D_CHECK_LAUNCH();
@@ -3703,6 +4086,8 @@ extern "C" int t3d_pointmlp_bwd_r(const t3d_pointmlp_dgrad_args* d, const t3d_po
   const bool wide = dgrad_wide(d);
   const int n_d = (d->M / 128) * (d->K / (wide ? 128 : 64));
   if (bf16) { T3D_RIDERS_FIRST(r, stream); r = nullptr; }
+  T3D_HOSTED(r, stream);      // (bf16 has left above: both fp32 forms below host the set)
+  if (!bf16 && d->N % BKX == 0 && w->K % 64 == 0 && x3_layer_bwd(d->K, d->N)) return t3d_x3_bwd(d, w, r, tk, tn, wide, n_w, n_d, s);
   const dim3 grid(n_w + n_d + (r ? r->n_wg : 0));
   // interleaving the two kinds of tile by row range (so that both readers of a dy row range share an L2) measured SLOWER
   // than weight-gradient tiles first (1.683 vs 1.630 ms per step): the long wgrad tiles are better started early.
@@ -3772,7 +4157,8 @@ extern "C" int t3d_pool_bwd_stage1_r(const t3d_pointmlp_gram_args* g, const t3d_
     T3D_CHECK_LAUNCH();
     return T3D_OK;
   }
-  const int gt = gram_tile(g);
+  const bool x3g = g->a.dtype != T3D_BF16 && x3_layer_bwd(g->K, g->K);
+  const int gt = x3g ? 64 : gram_tile(g);      // (x3: 64 x 64 tiles, see mma_x3)
   const int n_gram = (g->K / gt) * (g->K / gt) * (g->M / g->rows_per_split);
   const int n_colsum = c->M / 128;
   const int n_prep = (q->K / 32) * (q->K / 32) * ((q->N + PCH - 1) / PCH);
@@ -3783,6 +4169,8 @@ extern "C" int t3d_pool_bwd_stage1_r(const t3d_pointmlp_gram_args* g, const t3d_
   size_t lds = bf16 ? lds_wgrad_h(gt, gt) : lds_wgrad(gt, gt);
   if (PREP_LDS > lds) lds = PREP_LDS;
   if (COLSUM_LDS > lds) lds = COLSUM_LDS;
+  T3D_HOSTED(r, stream);
+  if (x3g) return t3d_x3_stage1(g, c, q, r, gt, n_gram, n_colsum, n_prep, lds_max(PREP_LDS, COLSUM_LDS), s);
   lds = lds_with(lds, r);
 #define T3D_ST1(GT_, PR_)                                                              \
   do {                                                                                 \
@@ -3844,6 +4232,8 @@ extern "C" int t3d_pool_bwd_stage2_r(const t3d_pool_wgrad_finish_args* f, const 
   const dim3 grid(n_finish + n_d + (r ? r->n_wg : 0));
   size_t lds = bf16 ? (wide ? lds_dgram_h(128) : lds_dgram_h(64)) : (wide ? lds_fwd(128) : lds_fwd(64));
   if (finish_lds(f->K) > lds) lds = finish_lds(f->K);
+  T3D_HOSTED(r, stream);
+  if (!bf16 && d->K % BKX == 0 && x3_layer_bwd(d->K, d->K)) return t3d_x3_stage2(f, d, r, wide, n_finish, n_d, finish_lds(f->K), s);
   lds = lds_with(lds, r);
 #define T3D_ST2(BN_, PR_)                                                              \
   do {                                                                                 \
@@ -3866,6 +4256,23 @@ extern "C" int t3d_pool_bwd_stage2_r(const t3d_pool_wgrad_finish_args* f, const 
   return T3D_OK;
 }
 
+// ---- does the `_r` launcher host a rider set for these arguments? (1 / 0; negative: the arguments are rejected) ----
+static const t3d_rider_set* query_set() {
+  static const t3d_rider_set q = []() { t3d_rider_set r{}; r.n_ops = 1; r.n_wg = 1; r.sync = reinterpret_cast<unsigned*>(16); return r; }();
+  return &q;
+}
+extern "C" int t3d_pointmlp_fwd_hosts_riders(const t3d_pointmlp_fwd_args* a) { return t3d_pointmlp_fwd_r(a, query_set(), T3D_QUERY_STREAM); }
+extern "C" int t3d_pointmlp_wgrad_hosts_riders(const t3d_pointmlp_wgrad_args* a) { return t3d_pointmlp_wgrad_r(a, query_set(), T3D_QUERY_STREAM); }
+extern "C" int t3d_pointmlp_bwd_hosts_riders(const t3d_pointmlp_dgrad_args* d, const t3d_pointmlp_wgrad_args* w) {
+  return t3d_pointmlp_bwd_r(d, w, query_set(), T3D_QUERY_STREAM);
+}
+extern "C" int t3d_pool_bwd_stage1_hosts_riders(const t3d_pointmlp_gram_args* g, const t3d_act_colsum_args* c, const t3d_pool_bwd_prep_args* q) {
+  return t3d_pool_bwd_stage1_r(g, c, q, query_set(), T3D_QUERY_STREAM);
+}
+extern "C" int t3d_pool_bwd_stage2_hosts_riders(const t3d_pool_wgrad_finish_args* f, const t3d_pointmlp_dgrad_gram_args* d) {
+  return t3d_pool_bwd_stage2_r(f, d, query_set(), T3D_QUERY_STREAM);
+}
+
 #ifdef T3D_TRACE
 // diagnostic builds only (not part of include/t3d.h): install / remove the per-workgroup trace buffer
 extern "C" int t3d_set_trace(void* buf) {
@@ -3873,3 +4280,5 @@ extern "C" int t3d_set_trace(void* buf) {
   return hipMemcpyToSymbol(HIP_SYMBOL(t3d_trace_ptr), &p, sizeof(p)) == hipSuccess ? T3D_OK : T3D_ERR_LAUNCH;
 }
 #endif
+
+#endif  // !T3D_X3_TU

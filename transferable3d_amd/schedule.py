@@ -48,36 +48,17 @@ def _first(arg):
     return arg[0] if isinstance(arg, tuple) else arg
 
 
-def is_host(name, arg):
-    """Does this GEMM launch have a rider form?  Mirrors the launchers of csrc/pointmlp.hip (fp32 split-form kernels); where the
-    mirror is wrong the `_r` entry point runs the set as its own launch first -- slower, never wrong."""
+def is_host(lib, name, arg):
+    """Does this GEMM launch have a rider form?  Asked of the library itself (t3d_*_hosts_riders: the `_r` launcher's own dispatch
+    run without launching), so the kernel-selection rules -- tile widths, register kernels, one-pass forms, T3D_X3 -- live in ONE
+    place.  Where a launch has no rider form the `_r` entry point would run the set as its own launch first: slower, never wrong."""
     if name not in HOST_FN or arg is None:
         return False
-    a = _first(arg)
-    if name == 't3d_pointmlp_fwd':
-        if a.dtype != abi.F32 or a.a.dtype != abi.F32:
-            return False
-        pool_kernel = (not a.y) and bool(a.pmax) and (not a.a.sub) and a.N % 128 == 0 and a.N >= 256 and a.K == 128 \
-            and os.environ.get('T3D_FWD_POOL', '1') != '0'
-        tiny = a.K <= 4 and bool(a.y) and not a.pmax and not a.rowbias and a.N in (64, 128) and os.environ.get('T3D_FWD_TINYK', '1') != '0'
-        return not pool_kernel and not tiny                      # (the pooled forward is a 512-thread kernel; K <= 4: the register kernel)
-    if name == 't3d_pointmlp_bwd':
-        d, w = arg
-        if d.dtype != abi.F32:
-            return False
-        one_pass = d.K in (64, 128) and d.N in (64, 128) and w.rows_per_split % 128 == 0 and \
-            d.M // w.rows_per_split >= min(256, d.M // 128) and os.environ.get('T3D_BWD1F', '1') != '0' and \
-            (d.M // 128 < 256 or w.rows_per_split >= 256 or os.environ.get('T3D_BWD1F') == '2')
-        return not one_pass
-    if name == 't3d_pointmlp_wgrad':
-        if a.K <= 4 and os.environ.get('T3D_WGRAD_TINYK', '1') != '0':
-            return False                                         # the register kernel (no rider form) beats the generic one + a rider
-        return a.dy.dtype != abi.BF16 and a.K <= 64 and a.N <= 128 and bool(a.dy.dz)
-    if name == 't3d_pool_bwd_stage1':
-        return a.a.dtype == abi.F32
-    if name == 't3d_pool_bwd_stage2':
-        return arg[1].dtype == abi.F32
-    return False
+    fn = getattr(lib, name + '_hosts_riders', None)
+    if fn is None:
+        return False
+    args = arg if isinstance(arg, tuple) else (arg,)
+    return fn(*[C.byref(a) for a in args]) == 1
 
 
 def small_op(name, arg, depends=0):
@@ -141,7 +122,7 @@ class _Op:
     def __init__(self, lib, call):
         self.call = call
         self.name, _, self.arg = call
-        self.host = is_host(self.name, self.arg)
+        self.host = is_host(lib, self.name, self.arg)
         self.ride = can_ride(lib, self.name, self.arg)
         self.pair = can_pair(self.name, self.arg)
         self.us = est_us(self.name, self.arg)
