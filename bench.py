@@ -89,7 +89,7 @@ def gemm_work(name, a):
     # fp32 layers run on the bf16 matrix pipe with three-term operands unless T3D_X3=0 (csrc/pointmlp.hip PathX3): k_..._x3<...>
     x3 = os.environ.get('T3D_X3', '1') != '0'
     x3f = lambda K, N: x3 and K * N >= int(os.environ.get('T3D_X3_MINKN', '1'))
-    x3b = lambda K, N: x3 and K * N >= int(os.environ.get('T3D_X3_MINKN_BWD', os.environ.get('T3D_X3_MINKN', '1')))
+    x3b = lambda K, N: x3 and K * N >= int(os.environ.get('T3D_X3_MINKN_BWD', os.environ.get('T3D_X3_MINKN', '1'))) and (N <= 4 * K or K >= 128)
     tag = lambda label: label.replace('<', '_x3<', 1)
     if name == 't3d_pool_bwd_stage1':
         gl, gf, gb = gemm_work('t3d_pointmlp_gram', a[0])

@@ -1062,13 +1062,44 @@ struct PathBF16 {
   // (PF == 0: one slot for the first operand too -- the 128-column data-gradient tilings, whose second slot spilled 10-27 VGPRs to scratch)
   template <int DIM, bool TYPE_R, class L, int PF, bool IS_A = false> using Stg = StagerHSel<DIM, TYPE_R, L, (IS_A && PF != 0) ? 2 : 1>;
 };
+// The fp32 activation loader for layers whose channel count is a multiple of the k-tile (the launchers take the x3 path only then):
+// no clamped addresses, no column masks -- four selects and a min per chunk less in a staging pass that bounds these kernels.
+struct ActLoaderE {
+  static constexpr bool EXACT = true;
+  t3d_act_src s;
+  int K;
+  int rpf;
+  struct Raw { float4 x; };
+  struct Coef { float4 sc, sh; };
+  __device__ __forceinline__ Coef fetch_coef(int col) const {
+    Coef c;
+    c.sc = make_float4(1.f, 1.f, 1.f, 1.f);
+    c.sh = f4zero();
+    if (s.scale != nullptr) {
+      c.sc = *reinterpret_cast<const float4*>(s.scale + col);
+      c.sh = *reinterpret_cast<const float4*>(s.shift + col);
+    }
+    return c;
+  }
+  __device__ __forceinline__ Raw fetch(int row, int col) const {
+    Raw r;
+    r.x = *reinterpret_cast<const float4*>(s.x + (size_t)row * s.ldx + s.coff + col);
+    return r;
+  }
+  __device__ __forceinline__ float4 xform(const Raw& r, const Coef& c, int, int) const {
+    const float floor_ = s.relu ? 0.f : -INFINITY;
+    return make_float4(fmaxf(fmaf(r.x.x, c.sc.x, c.sh.x), floor_), fmaxf(fmaf(r.x.y, c.sc.y, c.sh.y), floor_),
+                       fmaxf(fmaf(r.x.z, c.sc.z, c.sh.z), floor_), fmaxf(fmaf(r.x.w, c.sc.w, c.sh.w), floor_));
+  }
+};
+
 // fp32 storage and loaders, bf16 x 3 arithmetic (see above)
 struct PathX3 {
   typedef float T;
-  template <bool HAS_SUB, class XT> using Act = ActLoader<HAS_SUB>;
+  template <bool HAS_SUB, class XT> using Act = std::conditional_t<HAS_SUB, ActLoader<true>, ActLoaderE>;
   template <bool POOLED> using Dy = DyLoader<POOLED>;
   typedef WLoaderT<float> WL;
-  typedef WLoaderT<float> WLX;
+  typedef WLoaderT<float, true> WLX;
   static constexpr bool BF16 = false;
   static constexpr bool X3 = true;
   static constexpr int RED = BKX;
@@ -3401,7 +3432,10 @@ int x3_mode() { const char* e = getenv("T3D_X3"); return e ? atoi(e) : 1; }
 long x3_min_kn() { const char* e = getenv("T3D_X3_MINKN"); return e ? atol(e) : 1L; }
 long x3_min_kn_bwd() { const char* e = getenv("T3D_X3_MINKN_BWD"); return e ? atol(e) : x3_min_kn(); }
 bool x3_layer(int K, int N) { return x3_mode() != 0 && (long)K * N >= x3_min_kn(); }            // forward launches
-bool x3_layer_bwd(int K, int N) { return x3_mode() != 0 && (long)K * N >= x3_min_kn_bwd(); }    // backward launches (dense and Gram form)
+// backward launches (dense and Gram form).  Not the layers with few input and many output channels (64 -> 512, conv6's per-point part):
+// their data gradient is ONE 64-column tile over a long reduction, half the MFMA work per staged element, and measured slower than the
+// fp32-MFMA form (54.1 vs 50.7 us alone, 69.5 vs 62.9 us hosted at M = 32768)
+bool x3_layer_bwd(int K, int N) { return x3_mode() != 0 && (long)K * N >= x3_min_kn_bwd() && (N <= 4 * K || K >= 128); }
 bool act_ok(const t3d_act_src& a, int K) {
   return a.x != nullptr && (a.ldx % 4) == 0 && (a.coff % 4) == 0 && a.coff + (K + 3) / 4 * 4 <= a.ldx &&
          (a.scale == nullptr || a.shift != nullptr) && dtype_ok(a.dtype) && !(a.dtype == T3D_BF16 && a.sub != nullptr) &&

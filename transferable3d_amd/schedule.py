@@ -87,12 +87,14 @@ def can_pair(name, arg):
 # ---- duration model (us on one MI355X, from bench.py --call_detail at B=32 N=1024; only the ORDER of magnitude steers the alignment) ----
 def est_us(name, arg):
     a = _first(arg) if arg is not None else None
+    # fp32 GEMMs on the bf16 matrix pipe (csrc/pointmlp.hip PathX3, the default) are 1.1-1.5x faster than the fp32-MFMA kernels
+    x3 = os.environ.get('T3D_X3', '1') != '0' and a is not None and getattr(a, 'dtype', 0) == abi.F32
     if name == 't3d_pointmlp_fwd':
         if a.K <= 4:
             return 5.0                                            # register kernel, bound by its output store
-        return 6.0 + 2.0 * a.M * a.K * a.N / 1.0e8
+        return 6.0 + 2.0 * a.M * a.K * a.N / (1.6e8 if x3 else 1.0e8)
     if name == 't3d_pointmlp_bwd':
-        return 6.0 + 4.0 * a.M * a.K * a.N / 0.95e8
+        return 6.0 + 4.0 * a.M * a.K * a.N / (1.25e8 if x3 else 0.95e8)
     if name == 't3d_pointmlp_wgrad':
         if a.K <= 4:
             return 7.0
@@ -103,7 +105,7 @@ def est_us(name, arg):
         return 6.0 + 2.0 * a.M * a.K * a.K / 0.9e8
     if name == 't3d_pool_bwd_stage2':
         f = a
-        return 8.0 + 2.0 * arg[1].M * f.K * f.K / 0.85e8
+        return 8.0 + 2.0 * arg[1].M * f.K * f.K / (1.0e8 if os.environ.get('T3D_X3', '1') != '0' else 0.85e8)
     if name in ('t3d_fc_fwd', 't3d_fc_bwd', 't3d_fc_dinput'):      # 7.4 (256 x 256) ... 9.9 (512 x 512) fwd, 11-14 bwd
         rb = max(1.0, a.B / 32.0)
         kn = float(a.K) * a.N * rb
