@@ -114,6 +114,10 @@ typedef struct {
   int M, K, N;
   int rows_per_frustum;
   int dtype;             /* element type of y and arithmetic of the GEMM (a.dtype may still be T3D_F32: the raw inputs) */
+  /* optional (fp32 layers on the three-term bf16 path, see t3d_split_x3): the same [K,N] matrix already split into three bf16 planes,
+   * plane p at w_x3 + p * w_x3_stride (bf16 elements).  NULL: the kernel splits w while it stages it -- same results bit for bit. */
+  const void* w_x3;
+  int64_t w_x3_stride;
 } t3d_pointmlp_fwd_args;
 int t3d_pointmlp_fwd(const t3d_pointmlp_fwd_args* args, t3d_stream_t stream);
 
@@ -187,6 +191,8 @@ typedef struct {
   int M, K, N;
   int rows_per_frustum;
   int dtype;               /* element type of prev_y, out and add_in, and the arithmetic; must equal dy.dtype */
+  const void* w_x3;        /* optional: w as three bf16 planes (t3d_pointmlp_fwd_args.w_x3) */
+  int64_t w_x3_stride;
 } t3d_pointmlp_dgrad_args;
 int t3d_pointmlp_dgrad(const t3d_pointmlp_dgrad_args* args, t3d_stream_t stream);
 
@@ -914,6 +920,11 @@ int t3d_schedule_step(float* hyper, const t3d_schedule* s, t3d_stream_t stream);
 int t3d_adam_tf_step(float* params, const float* grads, float* m, float* v, int64_t n,
                      const float* hyper, float beta1, float beta2, float eps, float grad_scale,
                      t3d_stream_t stream);
+
+/* fp32 GEMMs on the bf16 matrix pipe (csrc/pointmlp.hip PathX3): x = h + m + l exactly with h = bf16(x), m = bf16(x - h),
+ * l = bf16(x - h - m).  Writes the three planes of src[0..n): planes[p * plane_stride + i] (bf16 elements, plane_stride >= n).  The
+ * optimiser's fp32 weights are split ONCE per step this way instead of once per tile that stages them. */
+int t3d_split_x3(const float* src, void* planes, int64_t n, int64_t plane_stride, t3d_stream_t stream);
 
 /* tf.train.MomentumOptimizer(learning_rate, momentum) of `--optimizer momentum` (train_semisup.py:226-228, train_boxpc.py:247,
  * train_semisup_adv.py:296), TF form without Nesterov: accum = momentum * accum + g * grad_scale;  w -= lr * accum, with

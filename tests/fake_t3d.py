@@ -1413,6 +1413,9 @@ class FakeLib:
         w[:] = w - lr_t * mm / (np.sqrt(vv) + np.float32(eps))
         return 0
 
+    def t3d_split_x3(self, src, planes, n, stride, stream):
+        return 0          # (the specification library multiplies in fp64: no operand planes)
+
     def t3d_momentum_step(self, params, grads, accum, n, hyper, momentum, gscale, stream):
         w, g, a = arr(params, n), arr(grads, n), arr(accum, n)
         lr = arr(hyper, 4)[1]

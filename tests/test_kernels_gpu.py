@@ -1482,3 +1482,48 @@ def test_seg_head_inline_dropout_equals_the_stored_mask(hip_lib):
     # the specification draws the same mask
     from fake_t3d import hash_keep_mask
     assert np.array_equal(hash_keep_mask(4321, 7, M * K, 0.5).reshape(M, K), mask.cpu().numpy())
+
+
+def test_x3_weight_planes_are_exact_and_equal_the_in_kernel_split(hip_lib):
+    """t3d_split_x3: every fp32 value is EXACTLY the sum of its three bf16 planes; a forward / data-gradient launch that reads the
+    pre-split planes (t3d_pointmlp_fwd_args.w_x3) gives bit for bit what the launch that splits the fp32 matrix while staging it gives."""
+    dev, st = _dev('cuda'), C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    r = np.random.RandomState(5)
+    n = 4099
+    src = torch.as_tensor((r.normal(size=n) * np.exp(r.uniform(-20, 20, size=n))).astype(np.float32)).to(dev)
+    stride = 4104
+    planes = torch.zeros(3 * stride, dtype=torch.bfloat16, device=dev)
+    assert hip_lib.t3d_split_x3(fptr(src), C.c_void_p(planes.data_ptr()), n, stride, st) == 0
+    torch.cuda.synchronize()
+    p = planes.view(3, stride)[:, :n].double().cpu()
+    assert torch.equal(p[0] + p[1] + p[2], src.double().cpu())                   # exact
+    assert float((p[1].abs() / p[0].abs().clamp_min(1e-300)).max()) <= 2.0 ** -7   # each term below the previous one's last bit
+    M, K, N, rpf = 512, 256, 128, 256
+    x, w = _mk(dev, r.normal(size=(M, K)).astype(np.float32)), _mk(dev, (r.normal(size=(K, N)) / 16).astype(np.float32))
+    wpl = torch.zeros(3 * K * N, dtype=torch.bfloat16, device=dev)
+    assert hip_lib.t3d_split_x3(fptr(w), C.c_void_p(wpl.data_ptr()), K * N, K * N, st) == 0
+    outs = []
+    for pre in (False, True):
+        y = torch.zeros(M, N, device=dev)
+        p1, p2 = torch.zeros(M // 128, N, device=dev), torch.zeros(M // 128, N, device=dev)
+        a = abi.PointMlpFwdArgs()
+        a.a = abi.ActSrc(fptr(x), K, 0, fptr(None), fptr(None), 0, fptr(None), 0)
+        a.w, a.y, a.psum, a.psumsq = fptr(w), fptr(y), fptr(p1), fptr(p2)
+        a.M, a.K, a.N, a.rows_per_frustum = M, K, N, rpf
+        if pre:
+            a.w_x3, a.w_x3_stride = wpl.data_ptr(), K * N
+        assert hip_lib.t3d_pointmlp_fwd(C.byref(a), st) == 0
+        dz, yv = _mk(dev, r.normal(size=(M, N)).astype(np.float32) * 0 + 1e-2), _mk(dev, np.ones((M, N), np.float32))
+        coef = _mk(dev, np.stack([np.ones(N), np.full(N, 0.5), np.zeros(N)]).astype(np.float32))
+        out = torch.zeros(M, K, device=dev)
+        d = abi.PointMlpDgradArgs()
+        d.dy, d.w, d.out = abi.DySrc(fptr(dz), fptr(yv), fptr(coef), iptr(None), fptr(None)), fptr(w), fptr(out)
+        d.M, d.K, d.N, d.rows_per_frustum = M, K, N, rpf
+        if pre:
+            d.w_x3, d.w_x3_stride = wpl.data_ptr(), K * N
+        assert hip_lib.t3d_pointmlp_dgrad(C.byref(d), st) == 0
+        torch.cuda.synchronize()
+        outs.append((y.cpu(), p1.cpu(), out.cpu()))
+    for a_, b_, what in zip(outs[0], outs[1], ('y', 'psum', 'dX')):
+        assert torch.equal(a_, b_), what
+    assert float(outs[0][0].abs().max()) > 0 and float(outs[0][2].abs().max()) > 0

@@ -29,7 +29,7 @@ class DySrc(C.Structure):
 class PointMlpFwdArgs(C.Structure):
     _fields_ = [('a', ActSrc), ('w', F), ('bias', F), ('rowbias', F), ('y', F), ('psum', F), ('psumsq', F),
                 ('rowmask', F), ('pmax', F), ('pmin', F), ('pamax', I), ('pamin', I),
-                ('M', i32), ('K', i32), ('N', i32), ('rows_per_frustum', i32), ('dtype', i32)]
+                ('M', i32), ('K', i32), ('N', i32), ('rows_per_frustum', i32), ('dtype', i32), ('w_x3', C.c_void_p), ('w_x3_stride', C.c_int64)]
 
 
 class BnFwdFinalizeArgs(C.Structure):
@@ -49,7 +49,7 @@ class PoolFinalizeArgs(C.Structure):
 class PointMlpDgradArgs(C.Structure):
     _fields_ = [('dy', DySrc), ('w', F), ('add_in', F), ('prev_y', F), ('prev_scale', F), ('prev_shift', F),
                 ('out', F), ('psum_dz', F), ('psum_dzy', F), ('M', i32), ('K', i32), ('N', i32),
-                ('rows_per_frustum', i32), ('dtype', i32)]
+                ('rows_per_frustum', i32), ('dtype', i32), ('w_x3', C.c_void_p), ('w_x3_stride', C.c_int64)]
 
 
 class PointMlpWgradArgs(C.Structure):
@@ -348,6 +348,7 @@ ENTRY_POINTS = {
     't3d_schedule_step': [F, C.POINTER(Schedule), VP],
     't3d_adam_tf_step': [F, F, F, F, C.c_int64, F, f32, f32, f32, f32, VP],
     't3d_momentum_step': [F, F, F, C.c_int64, F, f32, f32, VP],
+    't3d_split_x3': [F, VP, C.c_int64, C.c_int64, VP],
     't3d_dropout_mask': [F, C.c_int64, f32, C.c_uint32, F, VP],
     't3d_cast_bf16': [F, VP, C.c_int64, VP],
 }

@@ -450,6 +450,7 @@ class Session:
             # were recorded into the engine's forward plan as the ops were built; a run = the dropout-mask generators + that plan
             if 'ops' not in self.steps:
                 pre = Plan(e.rt)
+                e.emit_cast_weights(pre)      # (the GEMM kernels' copies of the weights: bf16 twin / three bf16 planes)
                 e.emit_dropout_masks(pre, seed=self.dropout_seed)
                 if not e.finalized:
                     e.finalize()

@@ -862,7 +862,21 @@ __device__ __forceinline__ void gemm_mainloop_h(SA& sa, SB& sb, const LA& la, co
 // layouts of the bf16 path) and the main loop differ.  Results agree with the fp32 MFMA kernels to the last bits, not bit for bit
 // (another summation order): the launchers take this path only when asked (T3D_X3, see t3d_pointmlp_fwd_r).
 constexpr int BKX = 16;             // reduction depth of an LDS stage = ONE step of v_mfma_f32_32x32x16_bf16
-constexpr int LDRX = BKX + 8;       // R image row: 24 bf16 = 48 B = 12 dwords: the 16 lanes of a ds_read_b128 tile the 64 banks
+// LDS budget: three planes per operand.  With the bf16 path's padded images (R rows of 16 + 8, C rows of DIM + 32) a 128 x 128 forward
+// tile needs 67.6 KB for its two stages: two workgroups per CU.  Alternative: the R image UNPADDED -- rows of 16 bf16 = 32 B, the two
+// 16-byte halves of row r swapped when bit 3 of r is set, so that the 16 lanes a ds_read_b128 serves together (16 consecutive rows,
+// one half) hit 16 different 16-byte slots -- and the C image is padded by 16 (two-way conflicts on its transposing reads, 12 per
+// k-tile): 52.2 KB, THREE workgroups per CU (T3D_X3_LDS=1).
+#ifndef T3D_X3_LDS
+#define T3D_X3_LDS 0                // 1: that layout.  Measured (B=32 N=1024 step, same box): 1.246 vs 1.241 ms -- most launches have
+                                    // exactly two tiles per CU, a third slot stays empty; the conflict-free images stay the default
+#endif
+constexpr int LDRX = T3D_X3_LDS ? BKX : BKX + 8;
+constexpr int LDCX_PAD = T3D_X3_LDS ? 16 : 32;
+__device__ __forceinline__ int x3_r_off(int row, int red) {      // bf16 element offset of (row, reduction index red) in an R image plane
+  if constexpr (T3D_X3_LDS != 0) return row * LDRX + ((((red >> 3) ^ (row >> 3)) & 1) << 3) + (red & 7);
+  else return row * LDRX + red;
+}
 
 __device__ __forceinline__ void split3(const float4& v, bf16x4& h, bf16x4& m, bf16x4& l) {
   const float x[4] = {v.x, v.y, v.z, v.w};
@@ -881,18 +895,46 @@ __device__ __forceinline__ void split3(const float4& v, bf16x4& h, bf16x4& m, bf
   }
 }
 
+// A [K, N] fp32 matrix that was split into three bf16 planes beforehand (t3d_split_x3: the optimiser's weights, once per step): the
+// tile is COPIED into the LDS planes -- no arithmetic between the load and the store.  Tiles lie inside the matrix (launcher-checked).
+struct WLoaderX3 {
+  static constexpr bool PRESPLIT = true;
+  const bf16_t* p;      // plane 0
+  long stride;          // elements between planes
+  int ld;
+  struct Raw { bf16x4 h, m, l; };
+  struct Coef {};
+  __device__ __forceinline__ Coef fetch_coef(int) const { return Coef(); }
+  __device__ __forceinline__ Raw fetch(int row, int col) const {
+    const bf16_t* q = p + (size_t)row * ld + col;
+    Raw r;
+    r.h = *reinterpret_cast<const bf16x4*>(q);
+    r.m = *reinterpret_cast<const bf16x4*>(q + stride);
+    r.l = *reinterpret_cast<const bf16x4*>(q + 2 * stride);
+    return r;
+  }
+};
+template <class L, class = void> struct PreSplit { static constexpr bool value = false; };
+template <class L> struct PreSplit<L, typename std::enable_if<L::PRESPLIT>::type> { static constexpr bool value = true; };
+
 // one [DIM x BKX] operand tile: fp32 loader -> registers -> three bf16 planes in LDS (R image [DIM][LDRX] / C image [BKX][DIM + 32])
+#ifndef T3D_X3_PF
+#define T3D_X3_PF 1                 // register slots = k-tiles in flight per operand (see gemm_mainloop_x3)
+#endif
+#ifndef T3D_X3_PIECEWISE
+#define T3D_X3_PIECEWISE 1          // refill a slot piece by piece, right behind each piece's store
+#endif
 template <int DIM, bool TYPE_R, class L>
 struct StagerX3 {
-  static constexpr int PF = 1;
+  static constexpr int PF = T3D_X3_PF;
   static constexpr int NV = DIM * (BKX / 4) / NT;
-  static constexpr int LDC = DIM + 32;
+  static constexpr int LDC = DIM + LDCX_PAD;
   static constexpr int PLANE = TYPE_R ? DIM * LDRX : BKX * LDC;      // bf16 elements of one plane
   static constexpr int LDS_ELEMS = 3 * PLANE;
   static_assert(NV >= 1, "tile smaller than one staging pass");
-  typename L::Raw raw[NV];
-  typename L::Coef coef;
-  int lane0, red0;
+  typename L::Raw raw[PF][NV];
+  typename L::Coef coef[PF];      // TYPE_C uses coef[0] only (the thread's column chunk never changes)
+  int lane0, red0[PF];
 
   __device__ __forceinline__ static void coords(int tid, int q, int& lane_i, int& red_i) {
     const int f = tid + NT * q;
@@ -901,30 +943,50 @@ struct StagerX3 {
   }
   __device__ __forceinline__ void init(const L& l, int lane0_, int tid) {
     lane0 = lane0_;
-    if (!TYPE_R) { int li, ri; coords(tid, 0, li, ri); coef = l.fetch_coef(lane0 + li); }
+    if (!TYPE_R) { int li, ri; coords(tid, 0, li, ri); coef[0] = l.fetch_coef(lane0 + li); }
   }
+  template <int S>
   __device__ __forceinline__ void fetch(const L& l, int red0_, int tid) {
-    red0 = red0_;
-    if (TYPE_R) { int li, ri; coords(tid, 0, li, ri); coef = l.fetch_coef(red0_ + ri); }
+    red0[S] = red0_;
+    if (TYPE_R) { int li, ri; coords(tid, 0, li, ri); coef[S] = l.fetch_coef(red0_ + ri); }
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
       int li, ri; coords(tid, q, li, ri);
-      raw[q] = TYPE_R ? l.fetch(lane0 + li, red0_ + ri) : l.fetch(red0_ + ri, lane0 + li);
+      raw[S][q] = TYPE_R ? l.fetch(lane0 + li, red0_ + ri) : l.fetch(red0_ + ri, lane0 + li);
     }
   }
+  // one piece of fetch<S>(): requested right behind the store of the piece that held the register (the slot is refilled piece by piece,
+  // so every load has a whole iteration to land instead of the tail of one)
+  template <int S>
+  __device__ __forceinline__ void fetch_piece(const L& l, int red0_, int tid, int q) {
+    int li, ri; coords(tid, q, li, ri);
+    raw[S][q] = TYPE_R ? l.fetch(lane0 + li, red0_ + ri) : l.fetch(red0_ + ri, lane0 + li);
+  }
+  template <int S>
+  __device__ __forceinline__ void fetch_head(const L& l, int red0_, int tid) {      // behind the LAST piece's store: the slot's coordinates
+    red0[S] = red0_;
+    if (TYPE_R) { int li, ri; coords(tid, 0, li, ri); coef[S] = l.fetch_coef(red0_ + ri); }
+  }
+  template <int S>
   __device__ __forceinline__ void store_piece(const L& l, bf16_t* tile, int tid, int q) {
     int li, ri; coords(tid, q, li, ri);
-    const float4 v = TYPE_R ? l.xform(raw[q], coef, lane0 + li, red0 + ri) : l.xform(raw[q], coef, red0 + ri, lane0 + li);
     bf16x4 h, m, lo;
-    split3(v, h, m, lo);
-    bf16_t* dst = tile + (TYPE_R ? li * LDRX + ri : ri * LDC + li);
+    if constexpr (PreSplit<L>::value) {
+      h = raw[S][q].h; m = raw[S][q].m; lo = raw[S][q].l;
+    } else {
+      const typename L::Coef& c = coef[TYPE_R ? S : 0];
+      const float4 v = TYPE_R ? l.xform(raw[S][q], c, lane0 + li, red0[S] + ri) : l.xform(raw[S][q], c, red0[S] + ri, lane0 + li);
+      split3(v, h, m, lo);
+    }
+    bf16_t* dst = tile + (TYPE_R ? x3_r_off(li, ri) : ri * LDC + li);
     *reinterpret_cast<bf16x4*>(dst) = h;
     *reinterpret_cast<bf16x4*>(dst + PLANE) = m;
     *reinterpret_cast<bf16x4*>(dst + 2 * PLANE) = lo;
   }
+  template <int S>
   __device__ __forceinline__ void store(const L& l, bf16_t* tile, int tid) {
 #pragma unroll
-    for (int q = 0; q < NV; ++q) store_piece(l, tile, tid, q);
+    for (int q = 0; q < NV; ++q) store_piece<S>(l, tile, tid, q);
   }
 };
 
@@ -932,9 +994,9 @@ struct StagerX3 {
 template <bool TYPE_R, int DIM>
 __device__ __forceinline__ bf16x8 frag_x(const bf16_t* img, int c0, int lane) {
   if (TYPE_R) {
-    return *reinterpret_cast<const bf16x8*>(img + (c0 + (lane & 31)) * LDRX + 8 * (lane >> 5));
+    return *reinterpret_cast<const bf16x8*>(img + x3_r_off(c0 + (lane & 31), 8 * (lane >> 5)));
   } else {
-    constexpr int LDC = DIM + 32;
+    constexpr int LDC = DIM + LDCX_PAD;
     const int k0 = 8 * (lane >> 5);
     const bf16_t* base = img + (k0 + ((lane & 15) >> 2)) * LDC + c0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base));
@@ -983,47 +1045,92 @@ __device__ __forceinline__ void mma_x3(const bf16_t* As, const bf16_t* Bs, int a
   }
 }
 
-// Two LDS stages, one barrier per 16-deep k-tile, one register slot per operand: iteration t multiplies tile t from stage t&1 while
-// tile t+1 (requested one iteration earlier) is transformed, split and written into the other stage between the MFMAs, then
-// requests tile t+2.
+// Two LDS stages, one barrier per 16-deep k-tile, PF register slots per operand.  A k-tile is only 24 MFMAs of 32 cycles per wave
+// (0.3 us): with ONE tile in flight the loop ran at one k-tile per memory round trip (1.7 us per k-tile measured on 512 -> 256, the
+// matrix pipe a third busy; splitting the weights beforehand or a third workgroup per CU changed nothing -- the loop was waiting for its
+// loads).  Tile j travels in slot j % PF: iteration t multiplies tile t from LDS stage t & 1, stores tile t + 1 (requested PF iterations
+// earlier) into the other stage between the MFMAs, and refills that slot with tile t + 1 + PF.
+template <int S, bool SYM, int TM, int TN, class SA, class SB, class LA, class LB, bool AR, int DIMA, bool BR, int DIMB>
+__device__ __forceinline__ void x3_iter(SA& sa, SB& sb, const LA& la, const LB& lb, bf16_t* smem, int cur, int red_fetch, int a0, int b0,
+                                        f32x16 (&acc)[TM][TN], f32x16 (&accb)[SYM ? TM : 1][SYM ? TN : 1],
+                                        f32x16 (&accc)[SYM ? TM : 1][SYM ? TN : 1], int tid) {
+  constexpr int STAGE = SA::LDS_ELEMS + SB::LDS_ELEMS;
+  const bf16_t* As = smem + cur * STAGE;
+  const bf16_t* Bs = As + SA::LDS_ELEMS;
+  bf16_t* An = smem + (cur ^ 1) * STAGE;
+  bf16_t* Bn = An + SA::LDS_ELEMS;
+#if T3D_X3_PIECEWISE
+  mma_x3<SYM, TM, TN, AR, DIMA, SA::PLANE, BR, DIMB, SB::PLANE>(As, Bs, a0, b0, acc, accb, accc, tid & 63, [&](int p) {
+    if (p < SA::NV) {
+      sa.template store_piece<S>(la, An, tid, p);
+      sa.template fetch_piece<S>(la, red_fetch, tid, p);
+      if (p == SA::NV - 1) sa.template fetch_head<S>(la, red_fetch, tid);
+    } else if (p - SA::NV < SB::NV) {
+      sb.template store_piece<S>(lb, Bn, tid, p - SA::NV);
+      sb.template fetch_piece<S>(lb, red_fetch, tid, p - SA::NV);
+      if (p - SA::NV == SB::NV - 1) sb.template fetch_head<S>(lb, red_fetch, tid);
+    }
+  });
+#else
+  mma_x3<SYM, TM, TN, AR, DIMA, SA::PLANE, BR, DIMB, SB::PLANE>(As, Bs, a0, b0, acc, accb, accc, tid & 63, [&](int p) {
+    if (p < SA::NV) sa.template store_piece<S>(la, An, tid, p);
+    else if (p - SA::NV < SB::NV) sb.template store_piece<S>(lb, Bn, tid, p - SA::NV);
+  });
+  __builtin_amdgcn_sched_barrier(0);      // the new loads stay behind every wait on the older ones (vmcnt counts in issue order)
+  sa.template fetch<S>(la, red_fetch, tid);
+  sb.template fetch<S>(lb, red_fetch, tid);
+#endif
+  __syncthreads();
+}
+
 template <bool SYM, int TM, int TN, class SA, class SB, class LA, class LB, bool AR, int DIMA, bool BR, int DIMB>
 __device__ __forceinline__ void gemm_mainloop_x3(SA& sa, SB& sb, const LA& la, const LB& lb, float* smem_f, int red_begin, int red_end,
                                                  int a0, int b0, f32x16 (&acc)[TM][TN], int tid) {
   static_assert(!SYM || TM * TN == 1, "symmetric accumulation: 64 x 64 tiles (three accumulator sets)");
+  static_assert(SA::PF == SB::PF && SA::PF >= 1 && SA::PF <= 4, "one to four register slots");
+  constexpr int PF = SA::PF;
   f32x16 accb[SYM ? TM : 1][SYM ? TN : 1], accc[SYM ? TM : 1][SYM ? TN : 1];
   if constexpr (SYM) { zero_acc<TM, TN>(accb); zero_acc<TM, TN>(accc); }
   bf16_t* smem = reinterpret_cast<bf16_t*>(smem_f);
   constexpr int STAGE = SA::LDS_ELEMS + SB::LDS_ELEMS;
   static_assert(SA::NV + SB::NV <= 6, "staging pieces must fit the six product groups");
-  const int lane = tid & 63;
   const int last = red_end - BKX;
-  sa.fetch(la, red_begin, tid);
-  sb.fetch(lb, red_begin, tid);
-  sa.store(la, smem, tid);
-  sb.store(lb, smem + SA::LDS_ELEMS, tid);
-  sa.fetch(la, min(red_begin + BKX, last), tid);
-  sb.fetch(lb, min(red_begin + BKX, last), tid);
+  auto tile_red = [&](int j) { return min(red_begin + j * BKX, last); };      // past the end the last tile is re-read, never used
+  sa.template fetch<0>(la, tile_red(0), tid);
+  sb.template fetch<0>(lb, tile_red(0), tid);
+  if constexpr (PF > 1) { sa.template fetch<1>(la, tile_red(1), tid); sb.template fetch<1>(lb, tile_red(1), tid); }
+  if constexpr (PF > 2) { sa.template fetch<2>(la, tile_red(2), tid); sb.template fetch<2>(lb, tile_red(2), tid); }
+  if constexpr (PF > 3) { sa.template fetch<3>(la, tile_red(3), tid); sb.template fetch<3>(lb, tile_red(3), tid); }
+  sa.template store<0>(la, smem, tid);
+  sb.template store<0>(lb, smem + SA::LDS_ELEMS, tid);
+  sa.template fetch<0>(la, tile_red(PF), tid);
+  sb.template fetch<0>(lb, tile_red(PF), tid);
   __syncthreads();
+  const int nt = (red_end - red_begin) / BKX;
   int cur = 0;
-  for (int red = red_begin; red + BKX < red_end; red += BKX) {
-    const bf16_t* As = smem + cur * STAGE;
-    const bf16_t* Bs = As + SA::LDS_ELEMS;
-    bf16_t* An = smem + (cur ^ 1) * STAGE;
-    bf16_t* Bn = An + SA::LDS_ELEMS;
-    mma_x3<SYM, TM, TN, AR, DIMA, SA::PLANE, BR, DIMB, SB::PLANE>(As, Bs, a0, b0, acc, accb, accc, lane, [&](int p) {
-      if (p < SA::NV) sa.store_piece(la, An, tid, p);
-      else if (p - SA::NV < SB::NV) sb.store_piece(lb, Bn, tid, p - SA::NV);
-    });
-    __builtin_amdgcn_sched_barrier(0);      // the new loads stay behind every wait on the previous batch (vmcnt counts in issue order)
-    const int nxt = min(red + 2 * BKX, last);
-    sa.fetch(la, nxt, tid);
-    sb.fetch(lb, nxt, tid);
-    __syncthreads();
+#define T3D_X3_ITER(S_) x3_iter<S_, SYM, TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, cur, tile_red(t + 1 + PF), a0, b0, acc, accb, accc, tid)
+  constexpr int S1 = (PF > 1) ? 1 : 0, S2 = (PF > 2) ? 2 : 0, S3 = (PF > 3) ? 3 : 0;
+  int t = 0;
+  if constexpr (PF == 2) {      // slot and LDS stage have the same period: a branch-free body of two iterations
+    for (; t + 2 < nt; t += 2) {
+      T3D_X3_ITER(1);
+      cur ^= 1;
+      ++t; T3D_X3_ITER(0); --t;
+      cur ^= 1;
+    }
+  }
+  for (; t + 1 < nt; ++t) {      // (the slot is workgroup-uniform: a scalar branch per k-tile)
+    const int slot = (t + 1) % PF;
+    if (PF == 1 || slot == 0) T3D_X3_ITER(0);
+    else if (PF == 2 || slot == 1) T3D_X3_ITER(S1);
+    else if (PF == 3 || slot == 2) T3D_X3_ITER(S2);
+    else T3D_X3_ITER(S3);
     cur ^= 1;
   }
+#undef T3D_X3_ITER
   {
     const bf16_t* As = smem + cur * STAGE;
-    mma_x3<SYM, TM, TN, AR, DIMA, SA::PLANE, BR, DIMB, SB::PLANE>(As, As + SA::LDS_ELEMS, a0, b0, acc, accb, accc, lane, [](int) {});
+    mma_x3<SYM, TM, TN, AR, DIMA, SA::PLANE, BR, DIMB, SB::PLANE>(As, As + SA::LDS_ELEMS, a0, b0, acc, accb, accc, tid & 63, [](int) {});
   }
   if constexpr (SYM) {
 #pragma unroll
@@ -1105,6 +1212,16 @@ struct PathX3 {
   static constexpr int RED = BKX;
   template <int DIM, bool TYPE_R, class L, int PF, bool IS_A = false> using Stg = StagerX3<DIM, TYPE_R, L>;
 };
+// the loader of a layer's [K, N] weight matrix for a path (fp32 / bf16 copy: rows x cols with bounds; x3 planes: whole tiles)
+template <class WL, class Args>
+__device__ __forceinline__ WL make_wloader(const Args& p) {
+  if constexpr (PreSplit<WL>::value) return WL{reinterpret_cast<const bf16_t*>(p.w_x3), (long)p.w_x3_stride, p.N};
+  else return WL{p.w, p.N, p.K, p.N};
+}
+struct PathX3P : PathX3 {      // ... with the layer's weight matrix split beforehand (t3d_pointmlp_fwd_args.w_x3)
+  typedef WLoaderX3 WL;
+  typedef WLoaderX3 WLX;
+};
 template <class PR, int TM, int TN, class SA, class SB, class LA, class LB, bool AR, int DIMA, bool BR, int DIMB, bool SYM = false>
 __device__ __forceinline__ void run_mainloop(SA& sa, SB& sb, const LA& la, const LB& lb, float* smem, int red_begin, int red_end,
                                              int a0, int b0, f32x16 (&acc)[TM][TN], int tid) {
@@ -1137,7 +1254,7 @@ __device__ __forceinline__ void fwd_body(const t3d_pointmlp_fwd_args& p, float* 
   T3D_TRACE_MARK(0);
 
   LA la{p.a, p.K, p.rows_per_frustum};
-  WL lb{p.w, p.N, p.K, p.N};
+  WL lb = make_wloader<WL>(p);
   SA sa; SB sb;
   sa.init(la, row0, tid);
   sb.init(lb, col0, tid);
@@ -1940,7 +2057,7 @@ __device__ __forceinline__ void dgrad_body(const t3d_pointmlp_dgrad_args& p, flo
   const int row0 = tile_m * BM, col0 = tile_n * BN;
 
   LA la{p.dy, p.N, p.rows_per_frustum};
-  WL lb{p.w, p.N, p.K, p.N};
+  WL lb = make_wloader<WL>(p);
   SA sa; SB sb;
   sa.init(la, row0, tid);
   sb.init(lb, col0, tid);
@@ -3416,7 +3533,7 @@ constexpr size_t lds_dgrad_h(int bn) { return lds_max(2 * (size_t)(128 * LDRH + 
 constexpr size_t lds_wgrad_h(int bmk, int bn) { return 2 * (size_t)BKH * (bmk + 32 + bn + 32) * 2; }
 // x3 path: two stages of three bf16 planes per operand (R image [dim][LDRX] / C image [BKX][dim + 32])
 constexpr size_t lds_x3_r(int dim) { return (size_t)3 * dim * LDRX * 2; }
-constexpr size_t lds_x3_c(int dim) { return (size_t)3 * BKX * (dim + 32) * 2; }
+constexpr size_t lds_x3_c(int dim) { return (size_t)3 * BKX * (dim + LDCX_PAD) * 2; }
 constexpr size_t lds_fwd_x3(int bn) { return lds_max(2 * (lds_x3_r(128) + lds_x3_c(bn)), (size_t)12 * bn * sizeof(float)); }
 constexpr size_t lds_dgrad_x3(int bn) { return lds_max(2 * (lds_x3_r(128) + lds_x3_r(bn)), (size_t)12 * bn * sizeof(float)); }
 constexpr size_t lds_wgrad_x3(int bmk, int bn) { return 2 * (lds_x3_c(bmk) + lds_x3_c(bn)); }
@@ -3464,15 +3581,47 @@ int t3d_x3_stage1(const t3d_pointmlp_gram_args* g, const t3d_act_colsum_args* c,
                   int gt, int n_gram, int n_colsum, int n_prep, size_t lds_other, hipStream_t s);
 int t3d_x3_stage2(const t3d_pool_wgrad_finish_args* f, const t3d_pointmlp_dgrad_gram_args* d, const t3d_rider_set* r, bool wide,
                   int n_finish, int n_d, size_t lds_other, hipStream_t s);
+int t3d_x3_split(const float* src, void* planes, int64_t n, int64_t plane_stride, hipStream_t s);
 int t3d_x3_dgrad(const t3d_pointmlp_dgrad_args* a, bool wide, hipStream_t s);
 int t3d_x3_wgrad(const t3d_pointmlp_wgrad_args* a, int tk, int tn, int n_blocks, hipStream_t s);
 int t3d_x3_gram(const t3d_pointmlp_gram_args* a, int tk, int n_blocks, hipStream_t s);
 int t3d_x3_dgrad_gram(const t3d_pointmlp_dgrad_gram_args* a, bool wide, hipStream_t s);
 
 #ifdef T3D_X3_TU
+namespace {
+__global__ __launch_bounds__(256) void k_split_x3(const float* __restrict__ src, bf16_t* __restrict__ planes, long n, long stride) {
+  const long step = (long)gridDim.x * 256 * 4;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += step) {
+    if (i + 4 <= n) {
+      bf16x4 h, m, l;
+      split3(*reinterpret_cast<const float4*>(src + i), h, m, l);
+      *reinterpret_cast<bf16x4*>(planes + i) = h;
+      *reinterpret_cast<bf16x4*>(planes + stride + i) = m;
+      *reinterpret_cast<bf16x4*>(planes + 2 * stride + i) = l;
+    } else {
+      for (long j = i; j < n; ++j) {
+        bf16x4 h, m, l;
+        split3(make_float4(src[j], 0.f, 0.f, 0.f), h, m, l);
+        planes[j] = h[0]; planes[stride + j] = m[0]; planes[2 * stride + j] = l[0];
+      }
+    }
+  }
+}
+}  // namespace
+int t3d_x3_split(const float* src, void* planes, int64_t n, int64_t plane_stride, hipStream_t s) {
+  long blocks = (n + 1023) / 1024;
+  if (blocks > 2048) blocks = 2048;
+  T3D_LAUNCH(k_split_x3, dim3((unsigned)blocks), dim3(256), 0, s, src, static_cast<bf16_t*>(planes), (long)n, (long)plane_stride);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
 int t3d_x3_dgrad(const t3d_pointmlp_dgrad_args* a, bool wide, hipStream_t s) {
   const int tiles_m = a->M / 128;
-  if (wide) launch_lds(k_pointmlp_dgrad<128, false, PathX3>, dim3(tiles_m * (a->K / 128)), lds_dgrad_x3(128), s, *a);
+  if (a->w_x3) {
+    if (wide) launch_lds(k_pointmlp_dgrad<128, false, PathX3P>, dim3(tiles_m * (a->K / 128)), lds_dgrad_x3(128), s, *a);
+    else launch_lds(k_pointmlp_dgrad<64, false, PathX3P>, dim3(tiles_m * (a->K / 64)), lds_dgrad_x3(64), s, *a);
+  } else if (wide) launch_lds(k_pointmlp_dgrad<128, false, PathX3>, dim3(tiles_m * (a->K / 128)), lds_dgrad_x3(128), s, *a);
   else launch_lds(k_pointmlp_dgrad<64, false, PathX3>, dim3(tiles_m * (a->K / 64)), lds_dgrad_x3(64), s, *a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -3507,13 +3656,18 @@ int t3d_x3_dgrad_gram(const t3d_pointmlp_dgrad_gram_args* a, bool wide, hipStrea
 
 int t3d_x3_fwd(const t3d_pointmlp_fwd_args* a, const t3d_rider_set* r, hipStream_t s) {
   const int tiles_m = a->M / 128, nr = r ? r->n_wg : 0;
+  const bool pre = a->w_x3 != nullptr;      // the weights arrive as three bf16 planes (t3d_split_x3)
   if (a->N % 128 == 0 && (long)tiles_m * (a->N / 128) >= 512) {
     const dim3 grid(tiles_m * (a->N / 128) + nr);
-    if (r) launch_lds_r(k_pointmlp_fwd_r<128, false, PathX3>, grid, lds_with(lds_fwd_x3(128), r), s, *a, *r);
+    if (r && pre) launch_lds_r(k_pointmlp_fwd_r<128, false, PathX3P>, grid, lds_with(lds_fwd_x3(128), r), s, *a, *r);
+    else if (r) launch_lds_r(k_pointmlp_fwd_r<128, false, PathX3>, grid, lds_with(lds_fwd_x3(128), r), s, *a, *r);
+    else if (pre) launch_lds(k_pointmlp_fwd<128, false, PathX3P, float>, grid, lds_fwd_x3(128), s, *a);
     else launch_lds(k_pointmlp_fwd<128, false, PathX3, float>, grid, lds_fwd_x3(128), s, *a);
   } else {
     const dim3 grid(tiles_m * (a->N / 64) + nr);
-    if (r) launch_lds_r(k_pointmlp_fwd_r<64, false, PathX3>, grid, lds_with(lds_fwd_x3(64), r), s, *a, *r);
+    if (r && pre) launch_lds_r(k_pointmlp_fwd_r<64, false, PathX3P>, grid, lds_with(lds_fwd_x3(64), r), s, *a, *r);
+    else if (r) launch_lds_r(k_pointmlp_fwd_r<64, false, PathX3>, grid, lds_with(lds_fwd_x3(64), r), s, *a, *r);
+    else if (pre) launch_lds(k_pointmlp_fwd<64, false, PathX3P, float>, grid, lds_fwd_x3(64), s, *a);
     else launch_lds(k_pointmlp_fwd<64, false, PathX3, float>, grid, lds_fwd_x3(64), s, *a);
   }
   T3D_CHECK_LAUNCH();
@@ -3523,19 +3677,20 @@ int t3d_x3_fwd(const t3d_pointmlp_fwd_args* a, const t3d_rider_set* r, hipStream
 int t3d_x3_bwd(const t3d_pointmlp_dgrad_args* d, const t3d_pointmlp_wgrad_args* w, const t3d_rider_set* r, int tk, int tn, bool wide,
                int n_w, int n_d, hipStream_t s) {
   const dim3 grid(n_w + n_d + (r ? r->n_wg : 0));
-#define T3D_BWDX(DBN, TK, TN_)                                                                    \
+#define T3D_BWDX_P(DBN, TK, TN_, PR_)                                                             \
   do {                                                                                             \
     const size_t lds = lds_max(lds_dgrad_x3(DBN), lds_wgrad_x3(TK, TN_));                          \
     if (r) {                                                                                       \
-      auto kern = k_pointmlp_bwd_r<DBN, TK, TN_, PathX3>;                                          \
+      auto kern = k_pointmlp_bwd_r<DBN, TK, TN_, PR_>;                                             \
       allow_lds(reinterpret_cast<const void*>(kern), lds_with(lds, r));                            \
       T3D_LAUNCH(kern, grid, dim3(NT), lds_with(lds, r), s, *d, *w, n_w, *r);                      \
     } else {                                                                                       \
-      auto kern = k_pointmlp_bwd<DBN, TK, TN_, PathX3>;                                            \
+      auto kern = k_pointmlp_bwd<DBN, TK, TN_, PR_>;                                               \
       allow_lds(reinterpret_cast<const void*>(kern), lds);                                         \
       T3D_LAUNCH(kern, grid, dim3(NT), lds, s, *d, *w, n_w, 0);                                    \
     }                                                                                              \
   } while (0)
+#define T3D_BWDX(DBN, TK, TN_) do { if (d->w_x3) T3D_BWDX_P(DBN, TK, TN_, PathX3P); else T3D_BWDX_P(DBN, TK, TN_, PathX3); } while (0)
 #define T3D_BWDX_W(DBN)                                  \
   do {                                                   \
     if (tk == 128 && tn == 128) T3D_BWDX(DBN, 128, 128); \
@@ -3547,6 +3702,7 @@ int t3d_x3_bwd(const t3d_pointmlp_dgrad_args* d, const t3d_pointmlp_wgrad_args* 
   else T3D_BWDX_W(64);
 #undef T3D_BWDX_W
 #undef T3D_BWDX
+#undef T3D_BWDX_P
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -4288,6 +4444,13 @@ extern "C" int t3d_pool_bwd_stage2_r(const t3d_pool_wgrad_finish_args* f, const 
 #undef T3D_ST2
   T3D_CHECK_LAUNCH();
   return T3D_OK;
+}
+
+extern "C" int t3d_split_x3(const float* src, void* planes, int64_t n, int64_t plane_stride, t3d_stream_t stream) {
+  if (!src || !planes || n <= 0 || plane_stride < n || (reinterpret_cast<uintptr_t>(src) & 15) || (reinterpret_cast<uintptr_t>(planes) & 7) ||
+      (plane_stride & 3))
+    return T3D_ERR_ARG;
+  return t3d_x3_split(src, planes, n, plane_stride, static_cast<hipStream_t>(stream));
 }
 
 // ---- does the `_r` launcher host a rider set for these arguments? (1 / 0; negative: the arguments are rejected) ----

@@ -190,6 +190,11 @@ class Plan:
         return sum(1 for name, _, _ in self.calls if not name.startswith('__'))
 
 
+# (measured on the B=32 N=1024 step, same box: 1.276 ms with the planes, 1.257 ms with the split in the kernels -- three 8-byte loads
+# per chunk instead of one 16-byte load cost more than the conversions they save; off by default)
+X3_PRESPLIT = os.environ.get('T3D_X3', '1') != '0' and os.environ.get('T3D_X3_PRESPLIT', '0') == '1'
+
+
 class VarStore:
     """TF-named variables as views of flat fp32 buffers (params | grads | adam m | adam v, and a
     separate flat buffer for the non-trainable moving statistics).  Names follow the reference's
@@ -235,6 +240,22 @@ class VarStore:
         if self.params16 is None:
             self.params16 = self.rt.zeros(self.params.numel(), dtype=torch.bfloat16)
         return self.params16
+
+    def enable_x3(self):
+        """Three bf16 planes of `params` (x = h + m + l exactly; t3d_split_x3, refreshed once per step by Graph.emit_cast_weights): what
+        the fp32 GEMM kernels on the bf16 matrix pipe (csrc/pointmlp.hip PathX3) read as the weight operand instead of splitting the
+        fp32 matrix again in every tile that stages it."""
+        if getattr(self, 'params_x3', None) is None:
+            self.params_x3 = self.rt.zeros(3 * self.params.numel(), dtype=torch.bfloat16)
+        return self.params_x3
+
+    def x3_ptr(self, w):
+        """(device address of plane 0, elements between planes) of the x3 twin of a contiguous view `w` of the fp32 parameter buffer;
+        (None, 0) if `w` does not live there."""
+        off = (w.data_ptr() - self.params.data_ptr()) // 4
+        if not (0 <= off and off + w.numel() <= self.params.numel() and w.is_contiguous()) or off % 4:
+            return None, 0
+        return self.enable_x3().data_ptr() + 2 * off, self.params.numel()
 
     def bf16_view(self, w):
         """The bf16 twin of a view `w` of the fp32 parameter buffer (same element offset, same shape)."""
@@ -384,6 +405,8 @@ class PointLayer:
         self.dt, self.adt = g.dt, g.adt                  # abi.F32 / abi.BF16 and the torch dtype of the [M, C] layer tensors
         # what the GEMM kernels read as `w`: the fp32 weights, or their bf16 copy (refreshed every step: Graph.emit_cast_weights)
         self.w_mm = vs.bf16_view(w) if self.dt == abi.BF16 else w
+        # fp32 layers on the three-term bf16 path: the weights pre-split once per step (T3D_X3_PRESPLIT=0: split in every tile)
+        self.w_x3 = vs.x3_ptr(w) if (self.dt == abi.F32 and X3_PRESPLIT and rt.device.type == 'cuda') else (None, 0)
         assert not (self.dt == abi.BF16 and pool and not self.gram), "bf16: max-pooled layers take the Gram-form backward"
         self.bias = bias if bias is not None else vs.const(scope + '/biases', (N,), 0.0)
         if bn:
@@ -420,6 +443,7 @@ class PointLayer:
         a.a = src.struct()
         a.w, a.bias, a.rowbias, a.y = fptr(self.w_mm), fptr(self.bias), fptr(rowbias), fptr(self.y)
         a.dtype = self.dt
+        a.w_x3, a.w_x3_stride = self.w_x3 if self.NA == self.N else (None, 0)
         if self.NA != self.N:                 # fewer than 64 output channels: zero-padded copy of the weights, refreshed per run
             wp, bp, w, b, n = self.w_pad, self.b_pad, self.w, self.bias, self.N
             plan.add_raw('pad_weights', lambda s: (wp[:, :n].copy_(w), bp[:n].copy_(b), 0)[2])
@@ -677,6 +701,7 @@ class PointLayer:
         prev = self.src.producer if out_raw is None else None
         a = abi.PointMlpDgradArgs()
         a.dy, a.w, a.add_in, a.dtype = self.dy_struct(), fptr(self.w_mm), fptr(add_in), self.dt
+        a.w_x3, a.w_x3_stride = self.w_x3 if self.NA == self.N else (None, 0)
         if prev is not None:
             prev._ensure_bwd_buffers()
             assert not prev.pool

@@ -85,10 +85,15 @@ class Graph:
         plan.add_raw('t3d_reduce_slabs', thunk)
 
     def emit_cast_weights(self, plan):
-        """bf16 path: refresh the bf16 copy of the weights the GEMM kernels read (the optimiser updates the fp32 master copy)."""
-        if self.dt != abi.BF16:
-            return
+        """bf16 path: refresh the bf16 copy of the weights the GEMM kernels read (the optimiser updates the fp32 master copy).
+        fp32 path on the bf16 matrix pipe: refresh the three bf16 planes of the weights (t3d_split_x3), if any layer asked for them."""
         vs, lib = self.vars, self.rt.lib
+        if self.dt != abi.BF16:
+            px = getattr(vs, 'params_x3', None)
+            if px is not None and hasattr(lib, 't3d_split_x3'):
+                plan.add_raw('t3d_split_x3', lambda s: lib.t3d_split_x3(fptr(vs.params), C.c_void_p(px.data_ptr()), (vs.used + 3) // 4 * 4,
+                                                                        vs.params.numel(), s))
+            return
         p16 = vs.enable_bf16()
         plan.add_raw('t3d_cast_bf16', lambda s: lib.t3d_cast_bf16(fptr(vs.params), C.c_void_p(p16.data_ptr()), vs.used, s))
 

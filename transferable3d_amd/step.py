@@ -250,6 +250,8 @@ class TrainStep:
         if ent['graphs'] is None:
             prog, graphs = self._capture(ent['prog'])
             ent['cprog'], ent['graphs'] = prog, graphs
+            if self._sets is not None:
+                self._sets.timeouts()      # (loads the two torch kernels of the check now, not in the middle of a timed loop: ~100 ms once)
         if ent['cprog'] and ent['cprog'][0][0] == 'run_graph':
             ent['graphs'][0].replay()
             return
