@@ -158,3 +158,37 @@ def test_rider_set_with_barriers_equals_the_separate_launches_under_load(hip_lib
             assert torch.equal(o, ro) and torch.equal(mm, rmm) and torch.equal(mv, rmv), mode
         if mode == 'hosted':
             assert torch.equal(yg, y_ref)
+
+
+@pytest.mark.parametrize('dtype,B,N', [('f32', 8, 256), ('bf16', 16, 512)])
+def test_two_stream_overlap_is_bit_identical_to_the_serial_step(hip_lib, monkeypatch, dtype, B, N):
+    """T3D_OVERLAP_STREAMS=1 (the default of large bf16 batches, where nothing can ride: step.TrainStep._two_stream_overlap): the seg
+    net's backward on a second stream beside the T-Net / box chain, one fork and one join, parallel branches of the captured graph.
+    Same kernels and arguments, disjoint outputs: losses, weights, moving statistics, Adam moments bit for bit the serial step's."""
+    from transferable3d_amd import nets
+    from transferable3d_amd.engine import Runtime
+    from transferable3d_amd.step import build_training_step
+    from transferable3d_amd.synthetic import make_batch
+
+    def run(overlap, streams):
+        monkeypatch.setenv('T3D_OVERLAP_STREAMS', streams)
+        keep = nets.OVERLAP
+        nets.OVERLAP = overlap
+        try:
+            g, model, step, loss = build_training_step(Runtime(lib=hip_lib), 'A', B, N, 4, seed=4, dtype=dtype)
+            losses = []
+            for k in range(5):
+                model.inputs.load(make_batch(B, N, 4, seed=21 + k))
+                step.run()
+                losses.append(float(loss))
+            torch.cuda.synchronize()
+            return losses, [t.clone() for t in (g.vars.params[:g.vars.used], g.vars.state[:g.vars.state_used], g.vars.adam_m[:g.vars.used],
+                                                g.vars.adam_v[:g.vars.used])], step
+        finally:
+            nets.OVERLAP = keep
+    l0, s0, st0 = run(False, '0')
+    l1, s1, st1 = run(True, '1')
+    assert st1.schedule_report is not None and st1.schedule_report.get('mode') == 'two streams' and st1.n_graph_segments() == 1
+    assert l0 == l1, (l0, l1)
+    for a, b in zip(s0, s1):
+        assert torch.equal(a, b)

@@ -78,6 +78,7 @@ class TrainStep:
             lanes[k:k] = [0, 0]
         if not two:       # (data parallel: the flat form -- no bucket marker inside the backward -- takes the scheduled program too)
             calls, lanes = self._overlap(calls, lanes)
+            two = two or getattr(self, 'two_stream', False)
         prog, cur = [], Plan(self.rt)
         cur.two_streams = two
 
@@ -132,11 +133,40 @@ class TrainStep:
         real = lambda cs: [c for c in cs if not c[0].startswith('__')]
         if any(c[0] in (Plan.BUCKET, Plan.WAIT) for c in calls[tb:se]):
             return calls, lanes
+        S_calls, T_calls = real(calls[sb:se]), real(calls[tb:sb])
+        if self._two_stream_overlap(S_calls + T_calls):
+            # Large batches (BASELINE configs[4]: bf16, B=128 N=2048) -- no launch of these chains has a rider form (bf16 kernels; FC
+            # ops of 128 rows, finalizers over 2048 tiles cannot ride) but every GEMM launch is several rounds of workgroups, so a
+            # small launch on a SECOND queue finds a free slot within a fraction of the GEMM beside it (at B=32 a GEMM launch is one
+            # round and the other queue waits the whole launch: DESIGN.md section 5).  Chain S on the side stream between ONE fork
+            # and ONE join, chain T on the main stream; in the captured graph the two are parallel branches.  Same kernels, same
+            # arguments, disjoint outputs: bit-identical to the serial program.
+            self.two_stream = True
+            lanes2 = [0] * tb + [1] * len(S_calls) + [0] + [0] * len(T_calls) + [0]
+            merged = S_calls + [(Plan.FLUSH, lambda s: 0, None)] + T_calls + [(Plan.JOIN, lambda s: 0, None)]
+            calls = calls[:tb] + merged + calls[se + 1:]
+            lanes2 += [0] * (len(calls) - len(lanes2))
+            self.schedule_report = {'mode': 'two streams', 'S_launches': len(S_calls), 'T_launches': len(T_calls), 'hosted': 0, 'rider_ops': 0,
+                                    'pairs': 0, 'solo': len(S_calls) + len(T_calls)}
+            return calls, lanes2
         if self._sets is None:
             self._sets = schedule.RiderSets(self.rt)
-        merged, self.schedule_report = schedule.overlap_chains(self.rt, real(calls[sb:se]), real(calls[tb:sb]), self._sets)
+        merged, self.schedule_report = schedule.overlap_chains(self.rt, S_calls, T_calls, self._sets)
         calls = calls[:tb] + merged + calls[se + 1:]
         return calls, [0] * len(calls)
+
+    def _two_stream_overlap(self, chain_calls):
+        """T3D_OVERLAP_STREAMS: 1 = the two chains on two streams, 0 = riders (the scheduled single stream); default: two streams for
+        large batches.  Measured, same box: B=32 N=1024 fp32 1.217 ms with riders vs 1.248 ms on two streams; B=128 N=2048 bf16
+        3.49 ms serial vs 3.26 ms on two streams."""
+        mode = os.environ.get('T3D_OVERLAP_STREAMS', '')
+        if mode in ('0', '1'):
+            return mode == '1' and self.on_gpu
+        if not self.on_gpu:
+            return False
+        # from B x N = 131072 rows on the FC ops (more than 32 rows) and the finalizers (more than 512 row tiles) cannot ride whatever the
+        # arithmetic, and the GEMM launches are four and more rounds deep
+        return self.e.M >= 4 * 32768
 
     def _shares_gpu(self):
         """More ranks on this node than GPUs (two ranks on one GPU over gloo: tests, bench.py --gpus 2 on a one-GPU box).
