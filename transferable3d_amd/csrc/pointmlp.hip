@@ -924,6 +924,9 @@ template <class L> struct PreSplit<L, typename std::enable_if<L::PRESPLIT>::type
 #ifndef T3D_X3_PIECEWISE
 #define T3D_X3_PIECEWISE 1          // refill a slot piece by piece, right behind each piece's store
 #endif
+#ifndef T3D_X3_SGB
+#define T3D_X3_SGB 0                // > 0: sched_group_barrier pipeline, that many VALU instructions behind each MFMA (see x3_iter)
+#endif
 template <int DIM, bool TYPE_R, class L>
 struct StagerX3 {
   static constexpr int PF = T3D_X3_PF;
@@ -1071,6 +1074,17 @@ __device__ __forceinline__ void x3_iter(SA& sa, SB& sb, const LA& la, const LB& 
       if (p - SA::NV == SB::NV - 1) sb.template fetch_head<S>(lb, red_fetch, tid);
     }
   });
+#if T3D_X3_SGB
+  // Prescribe the interleave of this iteration's instructions: hipcc clumps the staging pass into runs of 11-13 VALU instructions
+  // with no MFMA between them (the matrix pipe idles through each run), and the four MFMAs of a product group back to back (the wave
+  // cannot issue the VALU work behind them until the fourth has been accepted).  One MFMA, then its share of the VALU / LDS work.
+#pragma unroll
+  for (int i = 0; i < 6 * TM * TN; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               // one MFMA
+    __builtin_amdgcn_sched_group_barrier(0x002, T3D_X3_SGB, 0);      // VALU
+    __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);               // one LDS access (fragment read / plane write)
+  }
+#endif
 #else
   mma_x3<SYM, TM, TN, AR, DIMA, SA::PLANE, BR, DIMB, SB::PLANE>(As, Bs, a0, b0, acc, accb, accc, tid & 63, [&](int p) {
     if (p < SA::NV) sa.template store_piece<S>(la, An, tid, p);
