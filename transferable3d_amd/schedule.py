@@ -33,7 +33,8 @@ MAX_RUN = min(int(os.environ.get('T3D_RIDER_RUN', '10')), abi.RIDER_MAX_OPS)    
 # measured (tools/bench_riders.py, four dependent FC ops, 29 us as four launches): 41 us as one set of its own, 52 us inside a GEMM
 # launch that fills the chip; a 87 us two-round GEMM launch hosting them takes 96 us (the riders' slots push 16 of its tiles into a
 # third round), ONE riding op is free
-RIDER_SLOWDOWN = float(os.environ.get('T3D_RIDER_SLOW', '1.85'))      # a rider run vs the stand-alone launches of its ops
+# (round 4, hosts on the three-term bf16 path: re-swept on the whole step, same box: 1.85 -> 1.262 ms, 1.5 -> 1.244, 1.3 -> 1.248)
+RIDER_SLOWDOWN = float(os.environ.get('T3D_RIDER_SLOW', '1.5' if os.environ.get('T3D_X3', '1') != '0' else '1.85'))      # a rider run vs the stand-alone launches of its ops
 HOST_STRETCH = float(os.environ.get('T3D_RIDER_STRETCH', '0.2'))     # what a hosted run adds to its host, per us of the run ...
 HOST_STRETCH_MAX = float(os.environ.get('T3D_RIDER_STRETCH_MAX', '8.0'))   # ... at most (us): displaced tiles wait for ONE slot to free
 RIDER_SLOT_SHARE = 16.0 / 512.0                                       # 16 rider workgroups of 512 resident slots
