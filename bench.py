@@ -610,6 +610,11 @@ def main():
                                                 sum(len(x) for kind, x in trainstep.cache[True]['prog'] if kind == 'run')
                                                 if True in trainstep.cache else len(g.pre) + len(g.fwd) + len(g.bwd) + len(g.opt)),
                           'pipelined': pipelined,
+                          # how the fp32 per-point GEMMs multiply (storage, element-wise work, accumulation and statistics are fp32 either way)
+                          'gemm_arithmetic': ('bf16 operands, fp32 accumulate' if args.dtype == 'bf16' else
+                                              'fp32 MFMA (T3D_X3=0)' if os.environ.get('T3D_X3', '1') == '0' else
+                                              'fp32 operands as three exact bf16 terms, six bf16 MFMAs per multiply-add, fp32 accumulate '
+                                              '(errors vs fp64 at or below the fp32-MFMA kernels: profiles/r04_x3_accuracy.log)'),
                           'schedule': (dict({k: v for k, v in trainstep.schedule_report.items() if k != 'lines'},
                                             rider_barrier_timeouts=rider_timeouts) if trainstep.schedule_report else None),
                           'final_loss': loss},
