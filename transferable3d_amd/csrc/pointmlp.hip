@@ -3916,7 +3916,10 @@ static int check_dgrad(const t3d_pointmlp_dgrad_args* a) {
   return T3D_OK;
 }
 static bool dgrad_wide(const t3d_pointmlp_dgrad_args* a) {
-  return T3D_FORCE_TILE != 64 && a->K % 128 == 0 && (T3D_FORCE_TILE == 128 || (long)(a->M / 128) * (a->K / 128) >= 512);
+  // (T3D_DGRAD_WIDE_MIN: fewest 128-wide tiles for which the data gradient takes them; experiments)
+  const char* e = getenv("T3D_DGRAD_WIDE_MIN");
+  const long min_tiles = e ? atol(e) : 512;
+  return T3D_FORCE_TILE != 64 && a->K % 128 == 0 && (T3D_FORCE_TILE == 128 || (long)(a->M / 128) * (a->K / 128) >= min_tiles);
 }
 
 extern "C" int t3d_pointmlp_dgrad(const t3d_pointmlp_dgrad_args* a, t3d_stream_t stream) {
