@@ -983,8 +983,14 @@ struct StagerX3 {
     }
     bf16_t* dst = tile + (TYPE_R ? x3_r_off(li, ri) : ri * LDC + li);
     *reinterpret_cast<bf16x4*>(dst) = h;
+#ifdef T3D_ABL_X3_WRITE1        // timing ablation (wrong results): one plane written instead of three
+    if (ri == 12345) {
+#endif
     *reinterpret_cast<bf16x4*>(dst + PLANE) = m;
     *reinterpret_cast<bf16x4*>(dst + 2 * PLANE) = lo;
+#ifdef T3D_ABL_X3_WRITE1
+    }
+#endif
   }
   template <int S>
   __device__ __forceinline__ void store(const L& l, bf16_t* tile, int tid) {
@@ -1020,6 +1026,15 @@ __device__ __forceinline__ void mma_x3(const bf16_t* As, const bf16_t* Bs, int a
   bf16x8 fa[3][TM], fb[3][TN];
 #pragma unroll
   for (int pl = 0; pl < 3; ++pl) {
+#ifdef T3D_ABL_X3_READ1         // timing ablation (wrong results): the fragments of one plane read instead of three
+    if (pl > 0) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) fa[pl][tm] = fa[0][tm];
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) fb[pl][tn] = fb[0][tn];
+      continue;
+    }
+#endif
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) fa[pl][tm] = frag_x<AR, DIMA>(As + pl * PLA, a0 + tm * 32, lane);
 #pragma unroll
