@@ -33,7 +33,10 @@ def main():
     dev = 'cuda'
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     torch.manual_seed(0)
+    only = os.environ.get('T3D_ONLY')            # "fwd:512x256" / "bwd:128x128": that one case (for counter passes)
     for K, N, pooled in FWD:
+        if only and only != 'fwd:%dx%d' % (K, N):
+            continue
         x = torch.randn(M, K, device=dev)
         sc, sh = torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev) * 0.1
         w = torch.randn(K, N, device=dev) / K ** 0.5
@@ -72,6 +75,8 @@ def main():
             out['0'][1] / out['1'][1]))
     # ---- fused backward (data gradient + weight gradient slabs) ----
     for K, N in [(512, 256), (256, 128), (128, 256), (128, 128), (64, 512), (64, 128), (64, 64)]:
+        if only and only != 'bwd:%dx%d' % (K, N):
+            continue
         x = torch.randn(M, K, device=dev)
         sc, sh = torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev) * 0.1
         w = torch.randn(K, N, device=dev) / K ** 0.5

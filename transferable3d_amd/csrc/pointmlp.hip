@@ -1124,7 +1124,11 @@ __device__ __forceinline__ void gemm_mainloop_x3(SA& sa, SB& sb, const LA& la, c
   constexpr int STAGE = SA::LDS_ELEMS + SB::LDS_ELEMS;
   static_assert(SA::NV + SB::NV <= 6, "staging pieces must fit the six product groups");
   const int last = red_end - BKX;
+#ifdef T3D_ABL_X3_SAMETILE      // timing ablation (wrong results): every k-tile re-reads the first one (cache hits: no memory latency)
+  auto tile_red = [&](int j) { return min(red_begin + (j & 1) * BKX, last); };
+#else
   auto tile_red = [&](int j) { return min(red_begin + j * BKX, last); };      // past the end the last tile is re-read, never used
+#endif
   sa.template fetch<0>(la, tile_red(0), tid);
   sb.template fetch<0>(lb, tile_red(0), tid);
   if constexpr (PF > 1) { sa.template fetch<1>(la, tile_red(1), tid); sb.template fetch<1>(lb, tile_red(1), tid); }
@@ -3686,7 +3690,9 @@ int t3d_x3_dgrad_gram(const t3d_pointmlp_dgrad_gram_args* a, bool wide, hipStrea
 int t3d_x3_fwd(const t3d_pointmlp_fwd_args* a, const t3d_rider_set* r, hipStream_t s) {
   const int tiles_m = a->M / 128, nr = r ? r->n_wg : 0;
   const bool pre = a->w_x3 != nullptr;      // the weights arrive as three bf16 planes (t3d_split_x3)
-  if (a->N % 128 == 0 && (long)tiles_m * (a->N / 128) >= 512) {
+  const char* e = getenv("T3D_X3_FWD128_MIN");      // (fewest 128-wide tiles for which the forward takes them; experiments)
+  const long min_tiles = e ? atol(e) : 512;
+  if (a->N % 128 == 0 && (long)tiles_m * (a->N / 128) >= min_tiles) {
     const dim3 grid(tiles_m * (a->N / 128) + nr);
     if (r && pre) launch_lds_r(k_pointmlp_fwd_r<128, false, PathX3P>, grid, lds_with(lds_fwd_x3(128), r), s, *a, *r);
     else if (r) launch_lds_r(k_pointmlp_fwd_r<128, false, PathX3>, grid, lds_with(lds_fwd_x3(128), r), s, *a, *r);
