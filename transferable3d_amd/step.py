@@ -152,8 +152,8 @@ class TrainStep:
         if self._sets is None:
             self._sets = schedule.RiderSets(self.rt)
         merged, self.schedule_report = schedule.overlap_chains(self.rt, S_calls, T_calls, self._sets)
-        calls = calls[:tb] + merged + calls[se + 1:]
-        return calls, [0] * len(calls)
+        # (the launches outside the two chains keep their lanes; inside, the scheduled order is a single-stream program)
+        return calls[:tb] + merged + calls[se + 1:], lanes[:tb] + [0] * len(merged) + lanes[se + 1:]
 
     def _two_stream_overlap(self, chain_calls):
         """T3D_OVERLAP_STREAMS: 1 = the two chains on two streams, 0 = riders (the scheduled single stream); default: two streams for
