@@ -924,6 +924,9 @@ template <class L> struct PreSplit<L, typename std::enable_if<L::PRESPLIT>::type
 #ifndef T3D_X3_PIECEWISE
 #define T3D_X3_PIECEWISE 1          // refill a slot piece by piece, right behind each piece's store
 #endif
+#ifndef T3D_X3_FRAGPF
+#define T3D_X3_FRAGPF 1             // 1: the next tile's fragments are read behind a mid-iteration barrier (see x3_iter_fp)
+#endif
 #ifndef T3D_X3_SGB
 #define T3D_X3_SGB 0                // > 0: sched_group_barrier pipeline, that many VALU instructions behind each MFMA (see x3_iter)
 #endif
@@ -1063,6 +1066,74 @@ __device__ __forceinline__ void mma_x3(const bf16_t* As, const bf16_t* Bs, int a
   }
 }
 
+// ---- fragments carried across the barrier (T3D_X3_FRAGPF) ---------------------------------------------------------------------------
+// In the loop above every iteration begins behind its barrier with twelve fragment reads whose latency nothing covers (the MFMAs need
+// them).  Here the barrier sits in the MIDDLE of an iteration: the staging pieces of tile t + 1 go into the other stage behind the FIRST
+// product groups, then the barrier, then the fragment reads of tile t + 1 into a second register set while the last product groups of
+// tile t still run; iteration t + 1 starts with its fragments in registers.  Still two stages and one barrier per k-tile: the stage
+// written in iteration t held tile t - 1, whose fragments every wave had consumed before it passed the barrier of iteration t - 1.
+template <int TM, int TN> struct FragsX3 { bf16x8 a[3][TM], b[3][TN]; };
+
+template <bool AR, int DIMA, int PLA, bool BR, int DIMB, int PLB, int TM, int TN>
+__device__ __forceinline__ void load_frags_x3(const bf16_t* As, const bf16_t* Bs, int a0, int b0, int lane, FragsX3<TM, TN>& f) {
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) f.a[pl][tm] = frag_x<AR, DIMA>(As + pl * PLA, a0 + tm * 32, lane);
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) f.b[pl][tn] = frag_x<BR, DIMB>(Bs + pl * PLB, b0 + tn * 32, lane);
+  }
+}
+
+template <bool SYM, int TM, int TN, class F>
+__device__ __forceinline__ void mma_x3_f(const FragsX3<TM, TN>& f, f32x16 (&acc)[TM][TN], f32x16 (&accb)[SYM ? TM : 1][SYM ? TN : 1],
+                                         f32x16 (&accc)[SYM ? TM : 1][SYM ? TN : 1], F&& filler) {
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};      // l h, h l, m m, m h, h m, h h
+  constexpr int TG[6] = {0, 1, 2, 0, 1, 2};
+#pragma unroll
+  for (int p = 0; p < 6; ++p) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        if constexpr (SYM) {
+          if (TG[p] == 0) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[PA[p]][tm], f.b[PB[p]][tn], acc[tm][tn], 0, 0, 0);
+          else if (TG[p] == 1) accb[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[PA[p]][tm], f.b[PB[p]][tn], accb[tm][tn], 0, 0, 0);
+          else accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[PA[p]][tm], f.b[PB[p]][tn], accc[tm][tn], 0, 0, 0);
+        } else {
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[PA[p]][tm], f.b[PB[p]][tn], acc[tm][tn], 0, 0, 0);
+        }
+      }
+    filler(p);
+  }
+}
+
+template <bool SYM, int TM, int TN, class SA, class SB, class LA, class LB, bool AR, int DIMA, bool BR, int DIMB>
+__device__ __forceinline__ void x3_iter_fp(SA& sa, SB& sb, const LA& la, const LB& lb, bf16_t* smem, int cur, int red_fetch, int a0, int b0,
+                                           const FragsX3<TM, TN>& fc, FragsX3<TM, TN>& fn, f32x16 (&acc)[TM][TN],
+                                           f32x16 (&accb)[SYM ? TM : 1][SYM ? TN : 1], f32x16 (&accc)[SYM ? TM : 1][SYM ? TN : 1], int tid) {
+  constexpr int STAGE = SA::LDS_ELEMS + SB::LDS_ELEMS;
+  constexpr int NP = SA::NV + SB::NV;
+  static_assert(NP <= 5, "at least one product group behind the barrier");
+  bf16_t* An = smem + (cur ^ 1) * STAGE;
+  bf16_t* Bn = An + SA::LDS_ELEMS;
+  mma_x3_f<SYM, TM, TN>(fc, acc, accb, accc, [&](int p) {
+    if (p < SA::NV) {
+      sa.template store_piece<0>(la, An, tid, p);
+      sa.template fetch_piece<0>(la, red_fetch, tid, p);
+      if (p == SA::NV - 1) sa.template fetch_head<0>(la, red_fetch, tid);
+    } else if (p < NP) {
+      sb.template store_piece<0>(lb, Bn, tid, p - SA::NV);
+      sb.template fetch_piece<0>(lb, red_fetch, tid, p - SA::NV);
+      if (p == NP - 1) sb.template fetch_head<0>(lb, red_fetch, tid);
+    }
+    if (p == NP - 1) {
+      __syncthreads();
+      load_frags_x3<AR, DIMA, SA::PLANE, BR, DIMB, SB::PLANE>(An, Bn, a0, b0, tid & 63, fn);
+    }
+  });
+}
+
 // Two LDS stages, one barrier per 16-deep k-tile, PF register slots per operand.  A k-tile is only 24 MFMAs of 32 cycles per wave
 // (0.3 us): with ONE tile in flight the loop ran at one k-tile per memory round trip (1.7 us per k-tile measured on 512 -> 256, the
 // matrix pipe a third busy; splitting the weights beforehand or a third workgroup per CU changed nothing -- the loop was waiting for its
@@ -1141,6 +1212,26 @@ __device__ __forceinline__ void gemm_mainloop_x3(SA& sa, SB& sb, const LA& la, c
   __syncthreads();
   const int nt = (red_end - red_begin) / BKX;
   int cur = 0;
+#if T3D_X3_FRAGPF
+  static_assert(PF == 1, "fragments across the barrier: one register slot");
+  {
+    FragsX3<TM, TN> f0, f1;
+    load_frags_x3<AR, DIMA, SA::PLANE, BR, DIMB, SB::PLANE>(smem, smem + SA::LDS_ELEMS, a0, b0, tid & 63, f0);
+    int t = 0;
+    for (; t + 2 < nt; t += 2) {
+      x3_iter_fp<SYM, TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, cur, tile_red(t + 2), a0, b0, f0, f1, acc, accb, accc, tid);
+      cur ^= 1;
+      x3_iter_fp<SYM, TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, cur, tile_red(t + 3), a0, b0, f1, f0, acc, accb, accc, tid);
+      cur ^= 1;
+    }
+    if (t + 1 < nt) {      // two tiles left
+      x3_iter_fp<SYM, TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, cur, tile_red(t + 2), a0, b0, f0, f1, acc, accb, accc, tid);
+      mma_x3_f<SYM, TM, TN>(f1, acc, accb, accc, [](int) {});
+    } else {
+      mma_x3_f<SYM, TM, TN>(f0, acc, accb, accc, [](int) {});
+    }
+  }
+#else
 #define T3D_X3_ITER(S_) x3_iter<S_, SYM, TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, cur, tile_red(t + 1 + PF), a0, b0, acc, accb, accc, tid)
   constexpr int S1 = (PF > 1) ? 1 : 0, S2 = (PF > 2) ? 2 : 0, S3 = (PF > 3) ? 3 : 0;
   int t = 0;
@@ -1165,6 +1256,7 @@ __device__ __forceinline__ void gemm_mainloop_x3(SA& sa, SB& sb, const LA& la, c
     const bf16_t* As = smem + cur * STAGE;
     mma_x3<SYM, TM, TN, AR, DIMA, SA::PLANE, BR, DIMB, SB::PLANE>(As, As + SA::LDS_ELEMS, a0, b0, acc, accb, accc, tid & 63, [](int) {});
   }
+#endif
   if constexpr (SYM) {
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
