@@ -1108,7 +1108,7 @@ __device__ __forceinline__ void mma_x3_f(const FragsX3<TM, TN>& f, f32x16 (&acc)
   }
 }
 
-template <bool SYM, int TM, int TN, class SA, class SB, class LA, class LB, bool AR, int DIMA, bool BR, int DIMB>
+template <int S, bool SYM, int TM, int TN, class SA, class SB, class LA, class LB, bool AR, int DIMA, bool BR, int DIMB>
 __device__ __forceinline__ void x3_iter_fp(SA& sa, SB& sb, const LA& la, const LB& lb, bf16_t* smem, int cur, int red_fetch, int a0, int b0,
                                            const FragsX3<TM, TN>& fc, FragsX3<TM, TN>& fn, f32x16 (&acc)[TM][TN],
                                            f32x16 (&accb)[SYM ? TM : 1][SYM ? TN : 1], f32x16 (&accc)[SYM ? TM : 1][SYM ? TN : 1], int tid) {
@@ -1119,13 +1119,13 @@ __device__ __forceinline__ void x3_iter_fp(SA& sa, SB& sb, const LA& la, const L
   bf16_t* Bn = An + SA::LDS_ELEMS;
   mma_x3_f<SYM, TM, TN>(fc, acc, accb, accc, [&](int p) {
     if (p < SA::NV) {
-      sa.template store_piece<0>(la, An, tid, p);
-      sa.template fetch_piece<0>(la, red_fetch, tid, p);
-      if (p == SA::NV - 1) sa.template fetch_head<0>(la, red_fetch, tid);
+      sa.template store_piece<S>(la, An, tid, p);
+      sa.template fetch_piece<S>(la, red_fetch, tid, p);
+      if (p == SA::NV - 1) sa.template fetch_head<S>(la, red_fetch, tid);
     } else if (p < NP) {
-      sb.template store_piece<0>(lb, Bn, tid, p - SA::NV);
-      sb.template fetch_piece<0>(lb, red_fetch, tid, p - SA::NV);
-      if (p == NP - 1) sb.template fetch_head<0>(lb, red_fetch, tid);
+      sb.template store_piece<S>(lb, Bn, tid, p - SA::NV);
+      sb.template fetch_piece<S>(lb, red_fetch, tid, p - SA::NV);
+      if (p == NP - 1) sb.template fetch_head<S>(lb, red_fetch, tid);
     }
     if (p == NP - 1) {
       __syncthreads();
@@ -1213,23 +1213,27 @@ __device__ __forceinline__ void gemm_mainloop_x3(SA& sa, SB& sb, const LA& la, c
   const int nt = (red_end - red_begin) / BKX;
   int cur = 0;
 #if T3D_X3_FRAGPF
-  static_assert(PF == 1, "fragments across the barrier: one register slot");
+  static_assert(PF == 1 || PF == 2, "fragments across the barrier: one or two register slots");
   {
+#define T3D_X3_ITER_FP(S_, T_, FC_, FN_) \
+  x3_iter_fp<S_, SYM, TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, cur, tile_red((T_) + 1 + PF), a0, b0, FC_, FN_, acc, accb, accc, tid)
+    constexpr int SODD = PF == 2 ? 1 : 0;      // the slot of tile t + 1 for even t
     FragsX3<TM, TN> f0, f1;
     load_frags_x3<AR, DIMA, SA::PLANE, BR, DIMB, SB::PLANE>(smem, smem + SA::LDS_ELEMS, a0, b0, tid & 63, f0);
     int t = 0;
     for (; t + 2 < nt; t += 2) {
-      x3_iter_fp<SYM, TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, cur, tile_red(t + 2), a0, b0, f0, f1, acc, accb, accc, tid);
+      T3D_X3_ITER_FP(SODD, t, f0, f1);
       cur ^= 1;
-      x3_iter_fp<SYM, TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, cur, tile_red(t + 3), a0, b0, f1, f0, acc, accb, accc, tid);
+      T3D_X3_ITER_FP(0, t + 1, f1, f0);
       cur ^= 1;
     }
     if (t + 1 < nt) {      // two tiles left
-      x3_iter_fp<SYM, TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, cur, tile_red(t + 2), a0, b0, f0, f1, acc, accb, accc, tid);
+      T3D_X3_ITER_FP(SODD, t, f0, f1);
       mma_x3_f<SYM, TM, TN>(f1, acc, accb, accc, [](int) {});
     } else {
       mma_x3_f<SYM, TM, TN>(f0, acc, accb, accc, [](int) {});
     }
+#undef T3D_X3_ITER_FP
   }
 #else
 #define T3D_X3_ITER(S_) x3_iter<S_, SYM, TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, cur, tile_red(t + 1 + PF), a0, b0, acc, accb, accc, tid)
