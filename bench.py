@@ -86,10 +86,10 @@ def gemm_work(name, a):
       Gram forms       the same with K in place of N (the [M,N] tensor does not exist)."""
     import ctypes
     es = lambda dt: 2.0 if dt == 1 else 4.0       # bytes per element of a [M, C] layer tensor (t3d.h T3D_BF16 / T3D_F32)
-    # fp32 layers run on the bf16 matrix pipe with three-term operands unless T3D_X3=0 (csrc/pointmlp.hip PathX3): k_..._x3<...>
-    x3 = os.environ.get('T3D_X3', '1') != '0'
-    x3f = lambda K, N: x3 and K * N >= int(os.environ.get('T3D_X3_MINKN', '1'))
-    x3b = lambda K, N: x3 and K * N >= int(os.environ.get('T3D_X3_MINKN_BWD', os.environ.get('T3D_X3_MINKN', '1'))) and (N <= 4 * K or K >= 128)
+    # fp32 layers run on the bf16 matrix pipe with three-term operands (csrc/pointmlp.hip PathX3: k_..._x3<...>) when the launch struct
+    # asks for it AND the launcher's own rule takes it: the library says which (t3d_gemm_arithmetic), nothing here reads the environment
+    x3f = lambda st, K, N: LIB.t3d_gemm_arithmetic(st.arith, 0, K, N, 0) == 2
+    x3b = lambda st, K, N: LIB.t3d_gemm_arithmetic(st.arith, 0, K, N, 1) == 2
     tag = lambda label: label.replace('<', '_x3<', 1)
     if name == 't3d_pool_bwd_stage1':
         gl, gf, gb = gemm_work('t3d_pointmlp_gram', a[0])
@@ -101,7 +101,7 @@ def gemm_work(name, a):
                 and os.environ.get('T3D_GRAM1', '1') != '0':
             return 'k_pool_bwd_stage1_h<%d,%d>' % (g0.K, 128 if g0.K == 128 else 64), gf + 2.0 * q.K * q.K * q.N, by      # one-pass form
         lab = 'k_pool_bwd_stage1<%s>' % gl[gl.index('<') + 1:gl.index(',')]
-        return (tag(lab) if g0.a.dtype == 0 and x3b(g0.K, g0.K) else lab), gf + 2.0 * q.K * q.K * q.N, by
+        return (tag(lab) if g0.a.dtype == 0 and x3b(g0, g0.K, g0.K) else lab), gf + 2.0 * q.K * q.K * q.N, by
     if name == 't3d_pool_bwd_stage2':
         dl, df, db = gemm_work('t3d_pointmlp_dgrad_gram', a[1])
         f = a[0]
@@ -111,7 +111,7 @@ def gemm_work(name, a):
         if a[1].dtype == 1 and os.environ.get('T3D_GRAM1', '1') != '0' and ((dm >= 1 and f.K == 256) or (dm == 2 and f.K == 128)):
             return 'k_pool_bwd_stage2_h<%d,%d>' % (f.K, 128 if f.K == 128 else 64), df + 2.0 * f.K * f.K * f.N, by      # one-pass form
         lab = 'k_pool_bwd_stage2<%s>' % dl[dl.index('<') + 1:-1]
-        return (tag(lab) if a[1].dtype == 0 and f.K % 16 == 0 and x3b(f.K, f.K) else lab), df + 2.0 * f.K * f.K * f.N, by
+        return (tag(lab) if a[1].dtype == 0 and f.K % 16 == 0 and x3b(a[1], f.K, f.K) else lab), df + 2.0 * f.K * f.K * f.N, by
     if name == 't3d_pointmlp_bwd':
         d, w = a
         dl, df, _ = gemm_work('t3d_pointmlp_dgrad', d)
@@ -126,20 +126,23 @@ def gemm_work(name, a):
                 (M // 128 < 256 or w.rows_per_split >= 256 or os.environ.get('T3D_BWD1F') == '2'):
             return 'k_pointmlp_bwd1f<%d,%d>' % (K, N), df + wf, by      # fp32 one-pass form (not taken at the headline size)
         lab = 'k_pointmlp_bwd<%s,%s>' % (dl[dl.index('<') + 1:-1], wl[wl.index('<') + 1:-1])
-        return (tag(lab) if d.dtype == 0 and N % 16 == 0 and K % 64 == 0 and x3b(K, N) else lab), df + wf, by
+        return (tag(lab) if d.dtype == 0 and N % 16 == 0 and K % 64 == 0 and x3b(d, K, N) else lab), df + wf, by
     if name == 't3d_pointmlp_dgrad_gram':
         # (the sparse arg-max rows S behind add_live are read only where a row received a hit -- a data-dependent few percent of
         # the rows: not counted; a dense add_in is a full pass)
         dense_add = (not _null(a.add_in)) and _null(a.add_live)
         by = es(a.dtype) * a.M * a.K * (2 + (0 if _null(a.prev_y) else 1) + (1 if dense_add else 0)) + 4.0 * a.K * a.K
         lab = 'k_pointmlp_dgrad_gram<%d>' % (128 if a.K % 128 == 0 and (a.M // 128) * (a.K // 128) >= 512 else 64)
-        return (tag(lab) if a.dtype == 0 and a.K % 16 == 0 and x3b(a.K, a.K) else lab), 2.0 * a.M * a.K * a.K, by
+        return (tag(lab) if a.dtype == 0 and a.K % 16 == 0 and x3b(a, a.K, a.K) else lab), 2.0 * a.M * a.K * a.K, by
     if name == 't3d_pointmlp_gram':
         rps, tk, tn = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
         LIB.t3d_wgrad_plan(a.M, a.K, a.K, ctypes.byref(rps), ctypes.byref(tk), ctypes.byref(tn))
         t = tk.value if (rps.value == a.rows_per_split and tk.value == tn.value) else 64
+        x3g = a.a.dtype == 0 and x3b(a, a.K, a.K)
+        if x3g:
+            t = 64      # (the x3 Gram kernels exist for 64 x 64 tiles only: three accumulator sets keep G bitwise symmetric)
         lab = 'k_pointmlp_gram<%d,%d>' % (t, t)
-        return (tag(lab) if a.a.dtype == 0 and x3b(a.K, a.K) else lab), 2.0 * a.M * a.K * a.K, es(a.a.dtype) * a.M * a.K + 4.0 * a.K * a.K
+        return (tag(lab) if x3g else lab), 2.0 * a.M * a.K * a.K, es(a.a.dtype) * a.M * a.K + 4.0 * a.K * a.K
     flops = 2.0 * a.M * a.K * a.N
     if name == 't3d_pointmlp_fwd':
         by = es(a.a.dtype) * a.M * a.K + es(a.dtype) * (a.K * a.N + (0 if _null(a.y) else a.M * a.N))
@@ -148,7 +151,7 @@ def gemm_work(name, a):
             return 'k_pointmlp_fwd_tinyk<%d>' % a.N, flops, by      # first layer of a net: the register kernel (bf16 and fp32)
         if a.dtype == 1 and a.a.dtype == 1 and _null(a.a.sub) and (a.K in (64, 128) or (a.K == 256 and os.environ.get('T3D_FWD_RES', '1') == '2')) and os.environ.get('T3D_FWD_RES', '1') != '0':
             return 'k_pointmlp_fwd_res<%d,%d>' % (128 if a.N % 128 == 0 else 64, a.K // 64), flops, by      # activation-resident bf16 forward
-        if a.dtype == 0 and a.a.dtype == 0 and _null(a.a.sub) and a.K % 16 == 0 and x3f(a.K, a.N):
+        if a.dtype == 0 and a.a.dtype == 0 and _null(a.a.sub) and a.K % 16 == 0 and x3f(a, a.K, a.N):
             return 'k_pointmlp_fwd_x3<%d>' % (128 if a.N % 128 == 0 and (a.M // 128) * (a.N // 128) >= 512 else 64), flops, by
         if a.dtype == 0 and os.environ.get('T3D_FWD_POOL', '1') != '0' and _null(a.y) and not _null(a.pmax) and _null(a.a.sub) and a.K == 128 and \
                 a.N % 128 == 0 and a.N >= 256:
@@ -157,7 +160,7 @@ def gemm_work(name, a):
     if name == 't3d_pointmlp_dgrad':
         by = es(a.dtype) * (2 * a.M * a.N + a.K * a.N + a.M * a.K * (1 + (0 if _null(a.prev_y) else 1) + (0 if _null(a.add_in) else 1)))
         lab = 'k_pointmlp_dgrad<%d>' % (128 if a.K % 128 == 0 and (a.M // 128) * (a.K // 128) >= 512 else 64)
-        return (tag(lab) if a.dtype == 0 and not _null(a.dy.dz) and a.N % 16 == 0 and x3b(a.K, a.N) else lab), flops, by
+        return (tag(lab) if a.dtype == 0 and not _null(a.dy.dz) and a.N % 16 == 0 and x3b(a, a.K, a.N) else lab), flops, by
     rps, tk, tn = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
     LIB.t3d_wgrad_plan(a.M, a.K, a.N, ctypes.byref(rps), ctypes.byref(tk), ctypes.byref(tn))
     if rps.value != a.rows_per_split:
@@ -166,7 +169,34 @@ def gemm_work(name, a):
     if a.K <= 4 and a.a.dtype == 0 and a.dy.dtype == 0 and not _null(a.dy.dz) and a.N in (64, 128) and os.environ.get('T3D_WGRAD_TINYK', '1') != '0':
         return 'k_pointmlp_wgrad_tinyk<%d>' % a.N, flops, by      # first layer of a net, fp32: the register kernel
     lab = 'k_pointmlp_wgrad<%d,%d>' % (tk.value, tn.value)
-    return (tag(lab) if a.dy.dtype == 0 and a.a.dtype == 0 and _null(a.a.sub) and not _null(a.dy.dz) and a.K % 64 == 0 and x3b(a.K, a.N) else lab), flops, by
+    return (tag(lab) if a.dy.dtype == 0 and a.a.dtype == 0 and _null(a.a.sub) and not _null(a.dy.dz) and a.K % 64 == 0 and x3b(a, a.K, a.N) else lab), flops, by
+
+
+def gemm_arithmetic_report(rt, plans, dtype):
+    """What the per-point GEMM launches of the step multiply with, as the LIBRARY answers for each launch struct of the plans
+    (t3d_gemm_arithmetic on the struct's `arith` request, element type and shape) -- not what the environment of this process says."""
+    from transferable3d_amd import abi
+    counts, other = {}, []
+    for plan in plans:
+        for name, _, arg in plan.calls:
+            base = name[:-2] if name.endswith('_r') else name
+            if not base.startswith(('t3d_pointmlp', 't3d_pool_bwd_stage')) or base == 't3d_pointmlp_dgrad_narrow' or arg is None:
+                continue
+            st = (arg[1] if base == 't3d_pool_bwd_stage2' else arg[0]) if isinstance(arg, tuple) else arg
+            K, N = st.K, getattr(st, 'N', st.K)
+            dt = st.dtype if hasattr(st, 'dtype') else (st.dy.dtype if hasattr(st, 'dy') else st.a.dtype)
+            took = abi.ARITH_NAMES[LIB.t3d_gemm_arithmetic(st.arith, dt, K, N, 0 if base == 't3d_pointmlp_fwd' else 1)]
+            counts[took] = counts.get(took, 0) + 1
+            if dt == 0 and took != rt.gemm_arithmetic:
+                other.append('%s %dx%d' % (base[4:], K, N))
+    text = {'bf16': 'bf16 operands, fp32 accumulate',
+            'fp32_mfma': 'fp32 MFMA (v_mfma_f32_32x32x2_f32)',
+            'bf16x3': 'fp32 operands as three exact bf16 terms, six bf16 MFMAs per multiply-add, fp32 accumulate (errors vs fp64 at or below '
+                      'the fp32-MFMA kernels: profiles/r04_x3_accuracy.log)'}
+    return {'requested': 'bf16' if dtype == 'bf16' else rt.gemm_arithmetic, 'launches_by_arithmetic': counts,
+            'launches_not_on_the_requested_arithmetic': other,
+            'reported_by': 't3d_gemm_arithmetic (the library, per launch struct)',
+            'description': text['bf16' if dtype == 'bf16' else rt.gemm_arithmetic]}
 
 
 def profile_kernels(plans, steps, repeat=4):
@@ -357,7 +387,9 @@ def other_configs(args):
     """BASELINE.json configs[2], configs[3] (one replica) and configs[4] (one replica): <= 20 timed steps each in a child process of
     this script (own Runtime, own hipGraph), reported beside the headline -- informational, never `value`."""
     import subprocess
-    runs = [('boxpc', 'f32', []), ('F', 'f32', []), ('A', 'bf16', ['--batch_size', '128', '--num_point', '2048'])]
+    # ... and the reference's own problem size (train_semisup.py:34-36,61: 2048 points, RGB on): B=32 N=2048 C=6 fp32
+    runs = [('boxpc', 'f32', []), ('F', 'f32', []), ('A', 'bf16', ['--batch_size', '128', '--num_point', '2048']),
+            ('A', 'f32', ['--num_point', '2048', '--num_channel', '6'])]
     out = []
     for wl, dt, extra in runs:
         cmd = [sys.executable, os.path.abspath(__file__), '--workload', wl, '--dtype', dt, '--steps', '20', '--warmup', '5',
@@ -611,30 +643,37 @@ def main():
                                                 if True in trainstep.cache else len(g.pre) + len(g.fwd) + len(g.bwd) + len(g.opt)),
                           'pipelined': pipelined,
                           # how the fp32 per-point GEMMs multiply (storage, element-wise work, accumulation and statistics are fp32 either way)
-                          'gemm_arithmetic': ('bf16 operands, fp32 accumulate' if args.dtype == 'bf16' else
-                                              'fp32 MFMA (T3D_X3=0)' if os.environ.get('T3D_X3', '1') == '0' else
-                                              'fp32 operands as three exact bf16 terms, six bf16 MFMAs per multiply-add, fp32 accumulate '
-                                              '(errors vs fp64 at or below the fp32-MFMA kernels: profiles/r04_x3_accuracy.log)'),
+                          'gemm_arithmetic': gemm_arithmetic_report(rt, [g.fwd, g.bwd], args.dtype),
                           'schedule': (dict({k: v for k, v in trainstep.schedule_report.items() if k != 'lines'},
                                             rider_barrier_timeouts=rider_timeouts) if trainstep.schedule_report else None),
                           'final_loss': loss},
                'roofline': roofline, 'cpu_baseline': cpu, 'other_configs': others}
         if trainstep.dist:
             out['config']['dp'] = trainstep.dp_report()
-    def emit_and_leave():
-        """Watchdog exit behind the timed region: the headline line is complete -- print it, then leave."""
+    def emit_and_leave(what='the final barrier', code=4):
+        """Watchdog exit behind the timed region: the headline line is complete -- print it with a `hang` field saying what did not
+        finish, then leave with a NON-ZERO code (a hung collective must not read as a clean run; only the purely informational
+        second data-parallel leg leaves with 0)."""
         if rank == 0:
+            out['hang'] = '%s did not finish; the headline figures were complete before it' % what
             if saved_stdout is not None:
                 os.dup2(saved_stdout, 1)
             os.write(1, (json.dumps(out) + '\n').encode())
-        return 0
+        return code
 
     flat_default = os.environ.get('T3D_DP_FLAT', '1') == '1'
-    if (trainstep.dist and args.workload == 'A' and not pipelined and os.environ.get('T3D_DP_BOTH_MODES', '1') == '1'):      # (world 1: T3D_FORCE_DIST=1)
-        # One driver run decides flat vs bucketed (DESIGN section 6 only has a paper estimate): <= 20 timed steps of the NON-default
-        # data-parallel mode on a second step object, reported beside the default's.  Under a watchdog that prints the headline line
-        # (already complete) and leaves if this extra leg does not finish.
-        name_default, name_alt = ('flat', 'bucketed') if flat_default else ('bucketed', 'flat')
+    if (trainstep.dist and not pipelined and os.environ.get('T3D_DP_BOTH_MODES', '1') == '1'):      # (world 1: T3D_FORCE_DIST=1)
+        # One driver run compares two forms of the data-parallel step: <= 20 timed steps of a second form on a second step object,
+        # reported beside the default's.  RCCL default = the step and its one flat all-reduce captured in ONE graph; second form = the
+        # same collective issued by the host between graph segments (the default of rounds 2-4).  gloo (no capture): flat vs bucketed.
+        # Under a watchdog that prints the headline line (already complete) and leaves if this extra leg does not finish.
+        bucketing = 'flat' if flat_default else 'bucketed'
+        if trainstep.one_graph:
+            name_default, name_alt = bucketing + ', one graph', bucketing + ', host-issued'
+            alt_kw = dict(flat_allreduce=flat_default, one_graph=False)
+        else:
+            name_default, name_alt = bucketing + ', host-issued', ('bucketed' if flat_default else 'flat') + ', host-issued'
+            alt_kw = dict(flat_allreduce=not flat_default, one_graph=False)
         if rank == 0:
             out['config']['dp']['modes'] = {name_default: {'ms_per_step': median_step * 1e3,
                                                            'exposed_allreduce_us': out['config']['dp'].get('exposed_allreduce_us_per_step')}}
@@ -642,14 +681,13 @@ def main():
         def give_up():
             if rank == 0:
                 out['config']['dp']['modes'][name_alt] = 'did not finish'
-            return emit_and_leave()
+            return emit_and_leave('the %s data-parallel mode (informational leg)' % name_alt, code=0)
 
         with Watchdog(int(os.environ.get('T3D_DP_ALT_TIMEOUT_S', '150')), 'the %s data-parallel mode (informational leg)' % name_alt, give_up):
             dist.barrier()
             g2, model2, step2, _ = build_training_step(
                 rt, args.workload, B, N, C, world=world, rank=rank, process_group=dist.group.WORLD, force_dist=world == 1,
-                flat_allreduce=not flat_default, use_hip_graph=not args.no_graph, inline_dropout=True, dropout_seed=1234, seed=0,
-                dtype=args.dtype)
+                use_hip_graph=not args.no_graph, inline_dropout=True, dropout_seed=1234, seed=0, dtype=args.dtype, **alt_kw)
             model2.inputs.load(batch)
             n_alt = min(20, args.steps)
             for _ in range(2 + 5):

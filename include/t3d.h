@@ -31,6 +31,13 @@ extern "C" {
 #define T3D_ERR_ARG (-1)     /* null / inconsistent argument */
 #define T3D_ERR_SHAPE (-2)   /* unsupported shape (alignment, divisibility) */
 #define T3D_ERR_LAUNCH (-3)  /* HIP launch failure */
+#define T3D_ERR_ABI (-4)     /* an argument struct of another size than this library was built for (see `struct_size`) */
+
+/* ABI version 2.  Version 1 structs were plain; fields appended to four of them in round 4 (w_x3, oracle_mask, rowmask) made a caller
+ * built against the older header pass structs the library read past.  Since version 2 every argument struct that has grown, or may
+ * grow, starts with `struct_size`: the caller stores sizeof(the struct as its header declares it) there and every entry point that
+ * takes the struct returns T3D_ERR_ABI unless it equals the library's own sizeof.  New fields are only ever appended. */
+#define T3D_ABI_VERSION 2
 
 #define T3D_TILE_ROWS 128
 
@@ -47,6 +54,20 @@ enum { T3D_ACT_NONE = 0, T3D_ACT_RELU = 1, T3D_ACT_LEAKY_RELU = 2, T3D_ACT_TANH 
  *             representation) stay fp32.
  * Every `dtype` field below takes one of these; 0 (fp32) is what a zero-initialised struct means. */
 enum { T3D_F32 = 0, T3D_BF16 = 1 };
+
+/* Arithmetic of an fp32 (dtype = T3D_F32) per-point GEMM launch -- the `arith` field of the GEMM argument structs:
+ *   T3D_ARITH_FP32_MFMA  v_mfma_f32_32x32x2_f32: the fp32 fma chain, 157 TFLOP/s peak
+ *   T3D_ARITH_BF16X3     every fp32 operand as the exact sum of three bf16 terms, six v_mfma_f32_32x32x16_bf16 per multiply-add with
+ *                        fp32 accumulation (csrc/pointmlp.hip, "fp32 GEMMs on the bf16 matrix pipe"); a launch whose shape has no such
+ *                        kernel, or for which the launcher's rule prefers the fp32 MFMA (t3d_gemm_arithmetic says which), takes that
+ *   T3D_ARITH_AUTO       (0, a zero-initialised struct) the library's default = T3D_ARITH_BF16X3; the only value for which the
+ *                        experiment variables T3D_X3 / T3D_X3_MINKN of the tools are consulted
+ * A host fixes the value when it builds its plan (transferable3d_amd.engine.Runtime.gemm_arithmetic), so a captured graph, an eager
+ * launch and the line bench.py prints cannot disagree.  Ignored by T3D_BF16 launches. */
+enum { T3D_ARITH_AUTO = 0, T3D_ARITH_FP32_MFMA = 1, T3D_ARITH_BF16X3 = 2, T3D_ARITH_BF16 = 3 };
+/* The arithmetic a per-point GEMM launch of this request takes: T3D_ARITH_FP32_MFMA, T3D_ARITH_BF16X3 or T3D_ARITH_BF16 (dtype =
+ * T3D_BF16).  K x N: the layer's weight matrix (a Gram-form launch: N = K); backward != 0: a data / weight gradient launch. */
+int t3d_gemm_arithmetic(int arith, int dtype, int K, int N, int backward);
 
 int t3d_abi_version(void);
 /* Hash (16 hex digits + NUL) over the HIP sources and this header the library was built from (csrc/version.hip; "unknown" for a
@@ -99,6 +120,7 @@ typedef struct {
  * their row indices within the frustum (the finalize kernel picks max or min by the sign of the
  * batch-norm scale). */
 typedef struct {
+  uint32_t struct_size;    /* = sizeof(t3d_pointmlp_fwd_args); T3D_ERR_ABI otherwise */
   t3d_act_src a;
   const float* w;        /* [K,N] */
   const float* bias;     /* [N] or NULL */
@@ -118,6 +140,7 @@ typedef struct {
    * plane p at w_x3 + p * w_x3_stride (bf16 elements).  NULL: the kernel splits w while it stages it -- same results bit for bit. */
   const void* w_x3;
   int64_t w_x3_stride;
+  int arith;               /* T3D_ARITH_* (fp32 launches) */
 } t3d_pointmlp_fwd_args;
 int t3d_pointmlp_fwd(const t3d_pointmlp_fwd_args* args, t3d_stream_t stream);
 
@@ -179,6 +202,7 @@ int t3d_pool_finalize(const t3d_pool_finalize_args* args, t3d_stream_t stream);
  * producer's batch-norm-backward partials in the epilogue:
  *   out = da * 1[prev_y*prev_scale + prev_shift > 0];  psum_dz = sum out;  psum_dzy = sum out*prev_y */
 typedef struct {
+  uint32_t struct_size;    /* = sizeof(t3d_pointmlp_dgrad_args); T3D_ERR_ABI otherwise */
   t3d_dy_src dy;
   const float* w;          /* [K,N] */
   const float* add_in;     /* [M,K] or NULL */
@@ -193,6 +217,7 @@ typedef struct {
   int dtype;               /* element type of prev_y, out and add_in, and the arithmetic; must equal dy.dtype */
   const void* w_x3;        /* optional: w as three bf16 planes (t3d_pointmlp_fwd_args.w_x3) */
   int64_t w_x3_stride;
+  int arith;               /* T3D_ARITH_* (fp32 launches) */
 } t3d_pointmlp_dgrad_args;
 int t3d_pointmlp_dgrad(const t3d_pointmlp_dgrad_args* args, t3d_stream_t stream);
 
@@ -200,12 +225,14 @@ int t3d_pointmlp_dgrad(const t3d_pointmlp_dgrad_args* args, t3d_stream_t stream)
  *   slab[s,k,n] = sum_{m in split s} a[m,k] dy[m,n],  s = 0 .. M/rows_per_split - 1
  * t3d_reduce_slabs sums the slabs in a fixed order (deterministic). rows_per_split % 32 == 0. */
 typedef struct {
+  uint32_t struct_size;    /* = sizeof(t3d_pointmlp_wgrad_args); T3D_ERR_ABI otherwise */
   t3d_act_src a;
   t3d_dy_src dy;
   float* slabs;            /* [M/rows_per_split, K, N] */
   int M, K, N;
   int rows_per_frustum;
   int rows_per_split;      /* the arithmetic follows dy.dtype (bf16: rows_per_split % 64 == 0); slabs are fp32 either way */
+  int arith;               /* T3D_ARITH_* (fp32 launches) */
 } t3d_pointmlp_wgrad_args;
 int t3d_pointmlp_wgrad(const t3d_pointmlp_wgrad_args* args, t3d_stream_t stream);
 /* K11a + K11b of one dense layer in ONE launch (the two are independent; sharing a launch saves a kernel's fill/drain
@@ -302,6 +329,7 @@ int t3d_pool_sparse_rows(const t3d_pool_sparse_rows_args* args, t3d_stream_t str
 /* out = (a.p + rowconst + add_in) * 1[prev_y*prev_scale + prev_shift > 0], with the producer's
  * batch-norm-backward partials, exactly like the epilogue of K11a. */
 typedef struct {
+  uint32_t struct_size;    /* = sizeof(t3d_pointmlp_dgrad_gram_args); T3D_ERR_ABI otherwise */
   t3d_act_src a;           /* [M,K] input of the pooled layer */
   const float* p;          /* [K,K] */
   const float* rowconst;   /* [K] or NULL */
@@ -317,16 +345,19 @@ typedef struct {
   int rows_per_frustum;
   int dtype;               /* element type of prev_y and out, and the arithmetic (a.dtype gives the operand's); add_in with
                             * add_live (the sparse rows S) is fp32 either way, a dense add_in has this type */
+  int arith;               /* T3D_ARITH_* (fp32 launches) */
 } t3d_pointmlp_dgrad_gram_args;
 int t3d_pointmlp_dgrad_gram(const t3d_pointmlp_dgrad_gram_args* args, t3d_stream_t stream);
 
 /* slab[s] = a_s^T a_s over the rows of split s; rows_per_split from t3d_wgrad_plan(M, K, K). */
 typedef struct {
+  uint32_t struct_size;    /* = sizeof(t3d_pointmlp_gram_args); T3D_ERR_ABI otherwise */
   t3d_act_src a;
   float* slabs;            /* [M/rows_per_split, K, K] */
   int M, K;
   int rows_per_frustum;
   int rows_per_split;      /* the arithmetic follows a.dtype */
+  int arith;               /* T3D_ARITH_* (fp32 launches) */
 } t3d_pointmlp_gram_args;
 int t3d_pointmlp_gram(const t3d_pointmlp_gram_args* args, t3d_stream_t stream);
 
@@ -442,6 +473,7 @@ int t3d_fc_dinput(const t3d_fc_dinput_args* args, t3d_stream_t stream);
  * gradients back to conv9's batch-norm output.
  * Per-frustum loss weight: w_b = ce_weight * (1 - is_data_2D[b]) / (B * rows_per_frustum). */
 typedef struct {
+  uint32_t struct_size;    /* = sizeof(t3d_seg_head_args); T3D_ERR_ABI otherwise */
   const float* y;            /* [M,K] raw conv9 output */
   const float* scale; const float* shift;
   const float* drop_mask;    /* [M,K] 0/1 or NULL */
@@ -583,6 +615,7 @@ int t3d_weak_loss(const t3d_weak_loss_args* args, t3d_stream_t stream);
  * residuals and the box is max(anchor[cls] + res, 1e-5) / bin[cls] + res (boxpc_sunrgbd.py:206-230).
  * box_out[B,7] (optional) receives (cx,cy,cz,l,w,h,theta) for the backward.  rows_per_frustum % 256 == 0. */
 typedef struct {
+  uint32_t struct_size;    /* = sizeof(t3d_boxpc_rep_args); T3D_ERR_ABI otherwise */
   const float* pc; int ld_pc; int C;
   const float* center;            /* [B,3] */
   const float* dims;              /* [B,3] */

@@ -8,6 +8,7 @@ way the product obtains a library object and it raises when libt3d.so is missing
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 
@@ -97,8 +98,15 @@ def arr(ptr, *shape):
     return np.ctypeslib.as_array(ptr, shape=(n,)).reshape(shape)
 
 
+class AbiSizeError(ValueError):
+    """What the library answers with T3D_ERR_ABI: an argument struct whose `struct_size` is not the size this side knows."""
+
+
 def _struct(a):
-    return a._obj if hasattr(a, '_obj') else a.contents
+    p = a._obj if hasattr(a, '_obj') else a.contents
+    if hasattr(type(p), 'struct_size') and p.struct_size != C.sizeof(type(p)):
+        raise AbiSizeError('%s: struct_size %d, expected %d' % (type(p).__name__, p.struct_size, C.sizeof(type(p))))
+    return p
 
 
 def _act(src, M, K, rpf):
@@ -134,7 +142,19 @@ class FakeLib:
     """Drop-in for the ctypes library object (same call signatures, host pointers)."""
 
     def t3d_abi_version(self):
-        return 1
+        return 2
+
+    def t3d_gemm_arithmetic(self, arith, dtype, K, N, backward):
+        """The specification library has one arithmetic (float64 products rounded once): it reports what the product's rule would take."""
+        if dtype == abi.BF16:
+            return abi.ARITH_BF16
+        if arith == abi.ARITH_FP32_MFMA or (arith == abi.ARITH_AUTO and os.environ.get('T3D_X3', '1') == '0'):
+            return abi.ARITH_FP32_MFMA
+        if backward:
+            ok = N % 16 == 0 and K % 64 == 0 and (K <= 64 or K % 128 == 0) and (N <= 4 * K or K >= 128)
+        else:
+            ok = K % 16 == 0
+        return abi.ARITH_BF16X3 if ok else abi.ARITH_FP32_MFMA
 
     def t3d_source_hash(self, out, cap):
         return -1          # (the specification library is not a build of csrc/)

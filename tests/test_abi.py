@@ -21,7 +21,8 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert declared == set(abi.ENTRY_POINTS), declared ^ set(abi.ENTRY_POINTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.t3d_abi_version() == 1
+    assert lib.t3d_abi_version() == abi.ABI_VERSION == 2
+    assert int(re.search(r'#define T3D_ABI_VERSION (\d+)', _header()).group(1)) == 2
 
 
 def test_library_is_bound_to_the_sources_it_was_built_from(tmp_path, monkeypatch):
@@ -81,3 +82,76 @@ def test_load_fails_loudly_without_the_library(tmp_path):
     import pytest
     with pytest.raises(abi.T3DError):
         abi.load(str(tmp_path / 'missing.so'))
+
+
+SIZED = {'t3d_pointmlp_fwd_args': 'PointMlpFwdArgs', 't3d_pointmlp_dgrad_args': 'PointMlpDgradArgs', 't3d_pointmlp_wgrad_args': 'PointMlpWgradArgs',
+         't3d_pointmlp_gram_args': 'PointMlpGramArgs', 't3d_pointmlp_dgrad_gram_args': 'PointMlpDgradGramArgs',
+         't3d_seg_head_args': 'SegHeadArgs', 't3d_boxpc_rep_args': 'BoxPcRepArgs'}
+
+
+def test_sized_structs_have_the_size_the_c_compiler_gives_them(tmp_path):
+    """ABI version 2: the structs that have grown start with `struct_size`.  gcc's sizeof of every one of them (and of a few plain
+    ones) equals the ctypes mirror's, and the mirror fills the field in by itself."""
+    import ctypes as C
+    import subprocess
+    plain = {'t3d_act_src': 'ActSrc', 't3d_dy_src': 'DySrc', 't3d_fc_fwd_args': 'FcFwdArgs', 't3d_bn_fwd_finalize_args': 'BnFwdFinalizeArgs',
+             't3d_rider_set': 'RiderSet', 't3d_small_op': 'SmallOp'}
+    names = list(SIZED) + list(plain)
+    src = tmp_path / 'sizes.c'
+    src.write_text('#include <stdio.h>\n#include "t3d.h"\nint main(void) {\n' +
+                   ''.join('  printf("%s %%zu\\n", sizeof(%s));\n' % (n, n) for n in names) + '  return 0;\n}\n')
+    exe = tmp_path / 'sizes'
+    subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, pyname in {**SIZED, **plain}.items():
+        cls = getattr(abi, pyname)
+        assert int(got[cname]) == C.sizeof(cls), (cname, got[cname], C.sizeof(cls))
+    for pyname in SIZED.values():
+        cls = getattr(abi, pyname)
+        assert cls._fields_[0][0] == 'struct_size' and cls().struct_size == C.sizeof(cls)
+
+
+def test_a_struct_of_another_size_is_refused_before_anything_is_launched():
+    """A caller built against an older header passes a shorter struct: every entry point that takes a sized struct answers T3D_ERR_ABI
+    (no GPU needed: the check is the first thing a launcher does)."""
+    import ctypes as C
+    lib = abi.load()
+    null = C.c_void_p(0)
+
+    def short(cls):
+        a = cls()
+        a.struct_size -= 8
+        return a
+    f, d, w = short(abi.PointMlpFwdArgs), short(abi.PointMlpDgradArgs), short(abi.PointMlpWgradArgs)
+    g, dg = short(abi.PointMlpGramArgs), short(abi.PointMlpDgradGramArgs)
+    assert lib.t3d_pointmlp_fwd(C.byref(f), null) == abi.ERR_ABI
+    assert lib.t3d_pointmlp_fwd_hosts_riders(C.byref(f)) == abi.ERR_ABI
+    assert lib.t3d_pointmlp_dgrad(C.byref(d), null) == abi.ERR_ABI
+    assert lib.t3d_pointmlp_wgrad(C.byref(w), null) == abi.ERR_ABI
+    assert lib.t3d_pointmlp_bwd(C.byref(d), C.byref(abi.PointMlpWgradArgs()), null) == abi.ERR_ABI
+    assert lib.t3d_pointmlp_bwd(C.byref(abi.PointMlpDgradArgs()), C.byref(w), null) in (abi.ERR_ABI, -1)      # (the intact one is checked first: empty)
+    assert lib.t3d_pointmlp_gram(C.byref(g), null) == abi.ERR_ABI
+    assert lib.t3d_pointmlp_dgrad_gram(C.byref(dg), null) == abi.ERR_ABI
+    assert lib.t3d_seg_head(C.byref(short(abi.SegHeadArgs)), null) == abi.ERR_ABI
+    assert lib.t3d_boxpc_rep(C.byref(short(abi.BoxPcRepArgs)), null) == abi.ERR_ABI
+    # the right size gets past the check (and is then refused for its null pointers)
+    assert lib.t3d_pointmlp_fwd(C.byref(abi.PointMlpFwdArgs()), null) == -1
+
+
+def test_gemm_arithmetic_is_a_request_in_the_launch_struct_not_an_environment_variable(monkeypatch):
+    """t3d_gemm_arithmetic: what a launch of this request and shape takes.  An explicit request ignores T3D_X3; only T3D_ARITH_AUTO
+    (a zero-initialised struct) reads it."""
+    lib = abi.load()
+    for env in ('0', '1'):
+        monkeypatch.setenv('T3D_X3', env)
+        assert lib.t3d_gemm_arithmetic(abi.ARITH_BF16X3, abi.F32, 512, 256, 0) == abi.ARITH_BF16X3
+        assert lib.t3d_gemm_arithmetic(abi.ARITH_FP32_MFMA, abi.F32, 512, 256, 0) == abi.ARITH_FP32_MFMA
+        assert lib.t3d_gemm_arithmetic(abi.ARITH_BF16X3, abi.F32, 64, 512, 1) == abi.ARITH_FP32_MFMA      # the launcher's own rule
+        assert lib.t3d_gemm_arithmetic(abi.ARITH_BF16X3, abi.F32, 4, 64, 0) == abi.ARITH_FP32_MFMA        # no x3 kernel for K = 4
+        assert lib.t3d_gemm_arithmetic(abi.ARITH_BF16X3, abi.BF16, 512, 256, 0) == abi.ARITH_BF16
+        assert lib.t3d_gemm_arithmetic(abi.ARITH_AUTO, abi.F32, 512, 256, 0) == (abi.ARITH_BF16X3 if env == '1' else abi.ARITH_FP32_MFMA)
+    import fake_t3d
+    fake = fake_t3d.FakeLib()
+    for req in (abi.ARITH_BF16X3, abi.ARITH_FP32_MFMA):
+        for (K, N, bwd) in ((512, 256, 0), (64, 512, 1), (4, 64, 0), (128, 128, 1), (192, 64, 1)):
+            assert fake.t3d_gemm_arithmetic(req, abi.F32, K, N, bwd) == lib.t3d_gemm_arithmetic(req, abi.F32, K, N, bwd), (req, K, N, bwd)

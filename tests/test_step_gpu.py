@@ -33,6 +33,14 @@ def test_three_replayed_steps_at_the_headline_size_follow_the_oracle(hip_lib, ge
     assert rep[-1]['graph_segments'] == 1
 
 
+def test_three_replayed_steps_at_the_reference_problem_size_follow_the_oracle(hip_lib, gemm_arithmetic):
+    """The reference's own defaults (train_semisup.py:34-36,61: --num_point 2048, batch 32, RGB channels on: C = 6): M = 65536 rows --
+    six-channel first layers (K = 6: neither the register kernels of K <= 4 nor a whole x3 k-tile) and the plan rules that switch at
+    65536 rows (the one-pass fp32 backward of the <= 128-channel layers, 128-wide tiles where they give >= 512 workgroups)."""
+    rep = trajectory_check(Runtime(lib=hip_lib), 'A', steps=3, B=32, N=2048, C=6, use_hip_graph=True, verbose=True)
+    assert rep[-1]['graph_segments'] == 1
+
+
 def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -77,6 +85,50 @@ def test_data_parallel_step_on_one_rank_rccl_equals_the_single_replica_step(hip_
             assert torch.equal(out['single'][0], out[m][0]) and out['single'][1] == out[m][1], m
     finally:
         os.environ.pop('T3D_DP_ONE_GRAPH', None)
+        dist.destroy_process_group()
+
+
+def test_default_rccl_step_is_one_graph_and_equals_the_host_issued_and_the_single_replica_steps(hip_lib):
+    """On RCCL the data-parallel step is ONE captured graph with the (flat) gradient all-reduce inside it -- the default, no
+    environment variable.  For the three workloads, at one rank: weights, Adam moments, moving statistics and the loss after 5 steps
+    (3 of them replays of that graph) are bit-identical to the host-issued program (collective between two graph segments: the
+    default of rounds 2-4) and to the single-replica step."""
+    import torch.distributed as dist
+    from transferable3d_amd.step import build_training_step
+    from transferable3d_amd.synthetic import make_batch
+    torch.cuda.set_device(0)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    assert 'T3D_DP_ONE_GRAPH' not in os.environ
+    dist.init_process_group('nccl', rank=0, world_size=1, init_method='tcp://127.0.0.1:%d' % _free_port(),
+                            device_id=torch.device('cuda', 0))
+    try:
+        B, N, C = 8, 256, 4
+        for workload in ('A', 'boxpc', 'F'):
+            out = {}
+            for mode in ('single', 'default', 'host_issued'):
+                pg = None if mode == 'single' else dist.group.WORLD
+                g, model, step, loss = build_training_step(Runtime(lib=hip_lib), workload, B, N, C, process_group=pg, force_dist=mode != 'single',
+                                                           flat_allreduce=True, seed=5, use_hip_graph=True,
+                                                           one_graph=False if mode == 'host_issued' else None)
+                for k in range(5):
+                    b = make_batch(B, N, C, seed=90 + k, boxpc=workload == 'boxpc')
+                    if workload == 'F':
+                        b['is_data_2D'][::2] = 1
+                    model.inputs.load(b)
+                    step.run()
+                torch.cuda.synchronize()
+                v = g.vars
+                out[mode] = (v.params[:v.used].clone(), v.adam_m[:v.used].clone(), v.adam_v[:v.used].clone(), v.state[:v.state_used].clone(),
+                             float(loss), step.one_graph, [kind for kind, _ in step.cache[True]['cprog']], step.dp_report()['mode'])
+            assert out['default'][5] and not out['host_issued'][5] and not out['single'][5]
+            assert out['default'][6] == ['run_graph'], out['default'][6]                       # the whole step: one replayed graph
+            assert out['host_issued'][6] == ['run', 'allreduce', 'wait', 'run'], out['host_issued'][6]
+            assert 'ONE graph' in out['default'][7] and 'host-issued' in out['host_issued'][7]
+            for m in ('default', 'host_issued'):
+                for i in range(4):
+                    assert torch.equal(out['single'][i], out[m][i]), (workload, m, i)
+                assert out['single'][4] == out[m][4], (workload, m)
+    finally:
         dist.destroy_process_group()
 
 

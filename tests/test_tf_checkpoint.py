@@ -145,3 +145,54 @@ def test_three_stage_hand_off_through_saver_bundles(tmp_path):
     assert int(ck2['Variable']) == 4
     # ... and trained on
     assert not np.array_equal(ck2['inst_seg/conv1/weights'], ck['inst_seg/conv1/weights'])
+
+
+def test_saver_keeps_the_last_five_checkpoints_it_wrote(tmp_path):
+    """tf.train.Saver(max_to_keep=5) of the drivers (train_semisup.py:259): the sixth save removes the first, in both formats; files the
+    saver did not write stay; the TensorFlow state file lists the kept prefixes."""
+    import os
+    import types
+    import numpy as np
+    from transferable3d_amd import tf_checkpoint as T
+
+    class Vars:
+        index = {'a/weights': (0, (2, 3), True), 'a/bn/moving_mean': (0, (3,), False)}
+        adam_m = adam_v = None
+
+        def state_dict(self):
+            return {'a/weights': np.arange(6, dtype=np.float32).reshape(2, 3), 'a/bn/moving_mean': np.zeros(3, np.float32)}
+
+    g = types.SimpleNamespace(vars=Vars(), hyper=np.array([7.0], np.float32))
+    d = str(tmp_path)
+    open(os.path.join(d, 'model_epoch_99.npz'), 'wb').close()           # somebody else's file
+    s = T.Saver(max_to_keep=5)
+    for epoch in range(8):
+        p = s.save(d, epoch, g, 'npz')
+        assert os.path.exists(p)
+    left = sorted(f for f in os.listdir(d) if f.endswith('.npz'))
+    assert left == ['model_epoch_%d.npz' % e for e in (3, 4, 5, 6, 7)] + ['model_epoch_99.npz'], left
+    assert [os.path.basename(p) for p in s.last_checkpoints] == ['model_epoch_%d.npz' % e for e in (3, 4, 5, 6, 7)]
+    # TensorFlow bundles: index + data shard removed together, state file rewritten
+    d2 = tmp_path / 'tf'
+    d2.mkdir()
+    real_sv = T.saver_variables
+    T.saver_variables = lambda vars_, step, optimizer_scopes=None: dict(vars_.state_dict(), Variable=np.asarray(step, np.int32))
+    try:
+        s2 = T.Saver(max_to_keep=2)
+        for epoch in range(4):
+            s2.save(str(d2), epoch, g, 'tf')
+    finally:
+        T.saver_variables = real_sv
+    names = sorted(os.listdir(str(d2)))
+    assert names == ['checkpoint', 'model_epoch_2.ckpt.data-00000-of-00001', 'model_epoch_2.ckpt.index',
+                     'model_epoch_3.ckpt.data-00000-of-00001', 'model_epoch_3.ckpt.index'], names
+    assert T.latest_checkpoint(str(d2)).endswith('model_epoch_3.ckpt')
+    assert T._state_paths(os.path.join(str(d2), 'checkpoint')) == ['model_epoch_2.ckpt', 'model_epoch_3.ckpt']
+    assert T.read_checkpoint(T.latest_checkpoint(str(d2)))['a/weights'].shape == (2, 3)
+    # max_to_keep=None keeps everything
+    s3 = T.Saver(max_to_keep=None)
+    d3 = tmp_path / 'all'
+    d3.mkdir()
+    for epoch in range(7):
+        s3.save(str(d3), epoch, g, 'npz')
+    assert len(os.listdir(str(d3))) == 7

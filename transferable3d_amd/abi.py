@@ -13,8 +13,21 @@ i32, f32 = C.c_int, C.c_float
 TILE_ROWS = 128
 F32, BF16 = 0, 1              # t3d.h: T3D_F32 / T3D_BF16 (element type of the per-point layer tensors + GEMM arithmetic)
 DTYPE_BY_NAME = {'f32': F32, 'bf16': BF16}
+ARITH_AUTO, ARITH_FP32_MFMA, ARITH_BF16X3, ARITH_BF16 = 0, 1, 2, 3      # t3d.h: T3D_ARITH_* (arithmetic of an fp32 GEMM launch)
+ARITH_BY_NAME = {'auto': ARITH_AUTO, 'fp32_mfma': ARITH_FP32_MFMA, 'bf16x3': ARITH_BF16X3}
+ARITH_NAMES = {ARITH_FP32_MFMA: 'fp32_mfma', ARITH_BF16X3: 'bf16x3', ARITH_BF16: 'bf16'}
+ABI_VERSION = 2
+ERR_ABI = -4
 ACT_NONE, ACT_RELU, ACT_LEAKY_RELU, ACT_TANH = 0, 1, 2, 3
 ACT_BY_NAME = {None: ACT_NONE, 'relu': ACT_RELU, 'leaky_relu': ACT_LEAKY_RELU, 'tanh': ACT_TANH}
+
+
+class Sized(C.Structure):
+    """An argument struct of ABI version 2 that starts with `struct_size` (t3d.h): filled in here, so positional construction
+    keeps listing the fields behind it."""
+
+    def __init__(self, *args, **kw):
+        super().__init__(C.sizeof(type(self)), *args, **kw)
 
 
 class ActSrc(C.Structure):
@@ -26,10 +39,10 @@ class DySrc(C.Structure):
     _fields_ = [('dz', F), ('y', F), ('coef', F), ('argidx', I), ('dpool', F), ('dtype', i32)]
 
 
-class PointMlpFwdArgs(C.Structure):
-    _fields_ = [('a', ActSrc), ('w', F), ('bias', F), ('rowbias', F), ('y', F), ('psum', F), ('psumsq', F),
+class PointMlpFwdArgs(Sized):
+    _fields_ = [('struct_size', C.c_uint32), ('a', ActSrc), ('w', F), ('bias', F), ('rowbias', F), ('y', F), ('psum', F), ('psumsq', F),
                 ('rowmask', F), ('pmax', F), ('pmin', F), ('pamax', I), ('pamin', I),
-                ('M', i32), ('K', i32), ('N', i32), ('rows_per_frustum', i32), ('dtype', i32), ('w_x3', C.c_void_p), ('w_x3_stride', C.c_int64)]
+                ('M', i32), ('K', i32), ('N', i32), ('rows_per_frustum', i32), ('dtype', i32), ('w_x3', C.c_void_p), ('w_x3_stride', C.c_int64), ('arith', i32)]
 
 
 class BnFwdFinalizeArgs(C.Structure):
@@ -46,15 +59,15 @@ class PoolFinalizeArgs(C.Structure):
                 ('argidx', I), ('ysel', F)]
 
 
-class PointMlpDgradArgs(C.Structure):
-    _fields_ = [('dy', DySrc), ('w', F), ('add_in', F), ('prev_y', F), ('prev_scale', F), ('prev_shift', F),
+class PointMlpDgradArgs(Sized):
+    _fields_ = [('struct_size', C.c_uint32), ('dy', DySrc), ('w', F), ('add_in', F), ('prev_y', F), ('prev_scale', F), ('prev_shift', F),
                 ('out', F), ('psum_dz', F), ('psum_dzy', F), ('M', i32), ('K', i32), ('N', i32),
-                ('rows_per_frustum', i32), ('dtype', i32), ('w_x3', C.c_void_p), ('w_x3_stride', C.c_int64)]
+                ('rows_per_frustum', i32), ('dtype', i32), ('w_x3', C.c_void_p), ('w_x3_stride', C.c_int64), ('arith', i32)]
 
 
-class PointMlpWgradArgs(C.Structure):
-    _fields_ = [('a', ActSrc), ('dy', DySrc), ('slabs', F), ('M', i32), ('K', i32), ('N', i32),
-                ('rows_per_frustum', i32), ('rows_per_split', i32)]
+class PointMlpWgradArgs(Sized):
+    _fields_ = [('struct_size', C.c_uint32), ('a', ActSrc), ('dy', DySrc), ('slabs', F), ('M', i32), ('K', i32), ('N', i32),
+                ('rows_per_frustum', i32), ('rows_per_split', i32), ('arith', i32)]
 
 
 class PoolBwdPrepArgs(C.Structure):
@@ -66,14 +79,14 @@ class PoolSparseRowsArgs(C.Structure):
                 ('row_live', I)]
 
 
-class PointMlpDgradGramArgs(C.Structure):
-    _fields_ = [('a', ActSrc), ('p', F), ('rowconst', F), ('add_in', F), ('add_live', I), ('prev_y', F), ('prev_scale', F),
+class PointMlpDgradGramArgs(Sized):
+    _fields_ = [('struct_size', C.c_uint32), ('a', ActSrc), ('p', F), ('rowconst', F), ('add_in', F), ('add_live', I), ('prev_y', F), ('prev_scale', F),
                 ('prev_shift', F),
-                ('out', F), ('psum_dz', F), ('psum_dzy', F), ('M', i32), ('K', i32), ('rows_per_frustum', i32), ('dtype', i32)]
+                ('out', F), ('psum_dz', F), ('psum_dzy', F), ('M', i32), ('K', i32), ('rows_per_frustum', i32), ('dtype', i32), ('arith', i32)]
 
 
-class PointMlpGramArgs(C.Structure):
-    _fields_ = [('a', ActSrc), ('slabs', F), ('M', i32), ('K', i32), ('rows_per_frustum', i32), ('rows_per_split', i32)]
+class PointMlpGramArgs(Sized):
+    _fields_ = [('struct_size', C.c_uint32), ('a', ActSrc), ('slabs', F), ('M', i32), ('K', i32), ('rows_per_frustum', i32), ('rows_per_split', i32), ('arith', i32)]
 
 
 class ActColsumArgs(C.Structure):
@@ -166,8 +179,8 @@ class FcDinputArgs(C.Structure):
                 ('bn_invstd', F), ('bn_scale', F), ('bn_frozen', i32), ('bn_dgamma', F), ('bn_dbeta', F), ('bn_coef', F)]
 
 
-class SegHeadArgs(C.Structure):
-    _fields_ = [('y', F), ('scale', F), ('shift', F), ('drop_mask', F), ('keep_prob', f32), ('w', F), ('bias', F),
+class SegHeadArgs(Sized):
+    _fields_ = [('struct_size', C.c_uint32), ('y', F), ('scale', F), ('shift', F), ('drop_mask', F), ('keep_prob', f32), ('w', F), ('bias', F),
                 ('labels', I), ('is_data_2D', I), ('pc', F), ('ld_pc', i32), ('ce_weight', f32), ('logits', F),
                 ('mask', F), ('part', F), ('dz', F), ('psum_dz', F), ('psum_dzy', F), ('dw_part', F),
                 ('M', i32), ('K', i32), ('rows_per_frustum', i32), ('B', i32), ('drop_seed', C.c_uint32), ('drop_hyper', F),
@@ -221,8 +234,8 @@ class Schedule(C.Structure):
                 ('batch_size', i32), ('step_offset', i32)]
 
 
-class BoxPcRepArgs(C.Structure):
-    _fields_ = [('pc', F), ('ld_pc', i32), ('C', i32), ('center', F), ('dims', F), ('theta', F), ('y_dims_cls', I),
+class BoxPcRepArgs(Sized):
+    _fields_ = [('struct_size', C.c_uint32), ('pc', F), ('ld_pc', i32), ('C', i32), ('center', F), ('dims', F), ('theta', F), ('y_dims_cls', I),
                 ('y_orient_cls', I), ('rep', F), ('ld_rep', i32), ('box_out', F), ('M', i32), ('rows_per_frustum', i32), ('rowmask', F)]
 
 
@@ -287,6 +300,7 @@ class RiderSet(C.Structure):
 
 ENTRY_POINTS = {
     't3d_abi_version': [],
+    't3d_gemm_arithmetic': [i32, i32, i32, i32, i32],
     't3d_source_hash': [C.c_char_p, C.c_int],
     't3d_pointmlp_fwd': [C.POINTER(PointMlpFwdArgs), VP],
     't3d_bn_fwd_finalize': [C.POINTER(BnFwdFinalizeArgs), VP],
@@ -385,6 +399,8 @@ def load(path=None):
             raise T3DError('%s does not export %s' % (path, name))
         fn.argtypes = argtypes
         fn.restype = C.c_int
+    if lib.t3d_abi_version() != ABI_VERSION:      # every library, the variants of the tools included
+        raise T3DError('%s speaks ABI version %d, this host side version %d (include/t3d.h): rebuild it' % (path, lib.t3d_abi_version(), ABI_VERSION))
     from .build import CSRC, lib_source_hash
     if not variant and os.path.isdir(CSRC) and os.environ.get('T3D_ALLOW_STALE_LIB', '0') != '1':
         built, src = source_hash_of(lib), lib_source_hash()

@@ -9,6 +9,8 @@ INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
 LIB_PATH = os.path.join(HERE, 'libt3d.so')
 SOURCES = ['pointmlp.hip', 'pointmlp_x3.hip', 'bn_optim.hip', 'fc.hip', 'heads.hip', 'boxpc.hip', 'poolbwd.hip', 'data.hip', 'weak.hip', 'pair.hip', 'version.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
+# per-source flags (none at present: -fno-slp-vectorize on the x3 unit made every rider kernel spill two registers)
+EXTRA_FLAGS = {}
 MARKER = b'T3D_SOURCE_HASH='
 
 
@@ -124,7 +126,7 @@ def build(force=False, verbose=False):
     for src in SOURCES:
         path = os.path.join(CSRC, src)
         obj = os.path.join(bdir, src.replace('.hip', '.o'))
-        extra = ['-DT3D_SOURCE_HASH="%s"' % src_hash] if src == 'version.hip' else []
+        extra = ['-DT3D_SOURCE_HASH="%s"' % src_hash] if src == 'version.hip' else list(EXTRA_FLAGS.get(src, []))
         key, keyfile, remfile = _object_key(src, extra), obj + '.key', obj + '.remarks'
         objs.append(obj)
         if not force and os.path.exists(obj) and os.path.exists(keyfile) and os.path.exists(remfile) and open(keyfile).read() == key:

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_dropout_mask(float* __restrict__ mask, 
 
 }  // namespace
 
-extern "C" int t3d_abi_version(void) { return 1; }
+extern "C" int t3d_abi_version(void) { return T3D_ABI_VERSION; }
 
 static int fin_big_tiles() {      // T3D_FIN_BIG: tile count above which the 64-group finalizers run (0 = never)
   static const int v = []() { const char* e = getenv("T3D_FIN_BIG"); const int x = e ? atoi(e) : 512; return x > 0 ? x : (1 << 30); }();

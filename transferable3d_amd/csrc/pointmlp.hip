@@ -878,6 +878,9 @@ __device__ __forceinline__ int x3_r_off(int row, int red) {      // bf16 element
   else return row * LDRX + red;
 }
 
+#ifndef T3D_X3_SPLIT_ASM
+#define T3D_X3_SPLIT_ASM 1
+#endif
 __device__ __forceinline__ void split3(const float4& v, bf16x4& h, bf16x4& m, bf16x4& l) {
   const float x[4] = {v.x, v.y, v.z, v.w};
 #ifdef T3D_ABL_X3_FAKESPLIT      // timing ablation (wrong results): one conversion, no residuals
@@ -885,6 +888,40 @@ __device__ __forceinline__ void split3(const float4& v, bf16x4& h, bf16x4& m, bf
   for (int e = 0; e < 4; ++e) { h[e] = (bf16_t)x[e]; m[e] = h[e]; l[e] = h[e]; }
   return;
 #endif
+#if T3D_X3_SPLIT_ASM
+  // Two elements at a time, twelve vector instructions per pair: one packed conversion per term, the two halves widened with a shift
+  // and a mask, scalar subtractions.  Written out because from the per-element casts below hipcc (a) converts every other element
+  // twice -- once alone for the residual, once packed for the store -- and (b) SLP-packs the subtractions into v_pk_add_f32, which
+  // holds the issue port of a SIMD several times as long as two v_sub_f32 beside MFMAs.  Same roundings (v_cvt_pk_bf16_f32: nearest even) and exact subtractions: bit-identical to the form below.
+  unsigned hp[2], mp[2], lp[2];
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  auto pk = [](float a, float b) { const f32x2_ v = {a, b}; return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); };
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const float x0 = x[2 * e], x1 = x[2 * e + 1];
+    hp[e] = pk(x0, x1);
+#if T3D_X3_SPLIT_ASM == 2      // the subtractions as instructions (hipcc then pads the hazards it cannot see with s_nop)
+    float r0, r1, s0, s1;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r0) : "v"(x0), "v"(hp[e] << 16));
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r1) : "v"(x1), "v"(hp[e] & 0xffff0000u));
+    mp[e] = pk(r0, r1);
+    asm("v_sub_f32 %0, %1, %2" : "=v"(s0) : "v"(r0), "v"(mp[e] << 16));
+    asm("v_sub_f32 %0, %1, %2" : "=v"(s1) : "v"(r1), "v"(mp[e] & 0xffff0000u));
+#else                          // plain subtractions; the empty statements keep the SLP vectoriser from pairing them
+    float r0 = x0 - __uint_as_float(hp[e] << 16);
+    asm("" : "+v"(r0));
+    const float r1 = x1 - __uint_as_float(hp[e] & 0xffff0000u);
+    mp[e] = pk(r0, r1);
+    float s0 = r0 - __uint_as_float(mp[e] << 16);
+    asm("" : "+v"(s0));
+    const float s1 = r1 - __uint_as_float(mp[e] & 0xffff0000u);
+#endif
+    lp[e] = pk(s0, s1);
+  }
+  h = __builtin_bit_cast(bf16x4, make_uint2(hp[0], hp[1]));
+  m = __builtin_bit_cast(bf16x4, make_uint2(mp[0], mp[1]));
+  l = __builtin_bit_cast(bf16x4, make_uint2(lp[0], lp[1]));
+#else
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const bf16_t a = (bf16_t)x[e];
@@ -893,6 +930,7 @@ __device__ __forceinline__ void split3(const float4& v, bf16x4& h, bf16x4& m, bf
     const float r2 = r1 - (float)b;            // exact
     h[e] = a; m[e] = b; l[e] = (bf16_t)r2;
   }
+#endif
 }
 
 // A [K, N] fp32 matrix that was split into three bf16 planes beforehand (t3d_split_x3: the optimiser's weights, once per step): the
@@ -930,9 +968,9 @@ template <class L> struct PreSplit<L, typename std::enable_if<L::PRESPLIT>::type
 #ifndef T3D_X3_SGB
 #define T3D_X3_SGB 0                // > 0: sched_group_barrier pipeline, that many VALU instructions behind each MFMA (see x3_iter)
 #endif
-template <int DIM, bool TYPE_R, class L>
+template <int DIM, bool TYPE_R, class L, int PF_ = T3D_X3_PF>
 struct StagerX3 {
-  static constexpr int PF = T3D_X3_PF;
+  static constexpr int PF = PF_;
   static constexpr int NV = DIM * (BKX / 4) / NT;
   static constexpr int LDC = DIM + LDCX_PAD;
   static constexpr int PLANE = TYPE_R ? DIM * LDRX : BKX * LDC;      // bf16 elements of one plane
@@ -1272,6 +1310,131 @@ __device__ __forceinline__ void gemm_mainloop_x3(SA& sa, SB& sb, const LA& la, c
   __syncthreads();
 }
 
+
+// ---- producer / consumer wave roles (PathX3PC; 512-thread workgroups) -----------------------------------------------------------------
+// The loop above gives every wave both jobs -- load, batch-norm / ReLU, three-way split, LDS stores AND the six products -- in ONE in-order
+// instruction stream: ~147 vector instructions per wave and 16-deep k-tile queue behind and in front of 24 MFMAs, and the counters say
+// the matrix pipe idles 0.6 of a launch while a SIMD has nothing to issue 0.4 of it (docs/EXPERIMENTS.md, round 4).  Here a workgroup is
+// EIGHT waves: waves 0-3 (consumers, tid 0..255: the 2 x 2 wave grid of the output tile, the only ones with accumulators and an
+// epilogue) issue nothing but fragment reads and MFMAs; waves 4-7 (producers) run the staging pass of the whole tile and end.  A SIMD
+// hosts one wave of each role, so the staging pass's vector instructions issue in the 24 of every 32 cycles an MFMA leaves free instead
+// of in the same stream.  Three LDS stages, one workgroup barrier per k-tile, tile j in stage j % 3:
+//     iteration t   consumers: read the fragments of tile t + 1 into the other register set, multiply tile t from registers
+//                   producers: convert + store tile t + 2 (register slot (t + 2) % 3), request tile t + 5 into that slot
+//     barrier t + 1: tile t + 2 is complete; every fragment of tile t has been consumed
+// Stage (t + 2) % 3 held tile t - 1, whose fragments were read in iteration t - 2: no wave can still be reading it.  Same products in the
+// same order as the loop above: results are bit-identical.
+constexpr int X3_RING = 3;
+#ifdef T3D_ABL_PC_NOBAR      // timing ablation (wrong results; with _NOPROD and _NOFRAG: the products alone)
+#define T3D_PC_BAR() do {} while (0)
+#else
+#define T3D_PC_BAR() __syncthreads()
+#endif
+template <bool SYM, int TM, int TN, class SA, class SB, class LA, class LB, bool AR, int DIMA, bool BR, int DIMB>
+__device__ __forceinline__ void gemm_mainloop_x3_pc(SA& sa, SB& sb, const LA& la, const LB& lb, float* smem_f, int red_begin, int red_end,
+                                                    int a0, int b0, f32x16 (&acc)[TM][TN], int tid) {
+  static_assert(!SYM || TM * TN == 1, "symmetric accumulation: 64 x 64 tiles (three accumulator sets)");
+  static_assert(SA::PF == X3_RING && SB::PF == X3_RING, "three register slots: slot and LDS stage of a tile share their period");
+  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_f);
+  constexpr int STAGE = SA::LDS_ELEMS + SB::LDS_ELEMS;
+  const int last = red_end - BKX;
+  const int nt = (red_end - red_begin) / BKX;
+  auto tile_red = [&](int j) { return min(red_begin + j * BKX, last); };      // past the end the last tile is re-read, never used
+  const bool producer = __builtin_amdgcn_readfirstlane((int)threadIdx.x) >= NT;
+#ifdef T3D_PC_PRIO      // 1: the consumers (matrix instructions) above the producers; 2: the producers above the consumers
+  if ((T3D_PC_PRIO == 1) != producer) __builtin_amdgcn_s_setprio(2);
+#endif
+  if (producer) {
+#ifdef T3D_ABL_PC_NOPROD      // timing ablation (wrong results): producers that only keep the barrier count
+#define T3D_PC_PRODUCE(S_, J_) do {} while (0)
+#else
+#define T3D_PC_PRODUCE(S_, J_)                                                                         \
+  do {                                                                                                 \
+    bf16_t* At_ = smem + (S_) * STAGE;                                                                 \
+    bf16_t* Bt_ = At_ + SA::LDS_ELEMS;                                                                 \
+    const int rf_ = tile_red((J_) + X3_RING);                                                          \
+    _Pragma("unroll") for (int q = 0; q < SA::NV; ++q) {                                               \
+      sa.template store_piece<S_>(la, At_, tid, q);                                                    \
+      sa.template fetch_piece<S_>(la, rf_, tid, q);                                                    \
+    }                                                                                                  \
+    sa.template fetch_head<S_>(la, rf_, tid);                                                          \
+    _Pragma("unroll") for (int q = 0; q < SB::NV; ++q) {                                               \
+      sb.template store_piece<S_>(lb, Bt_, tid, q);                                                    \
+      sb.template fetch_piece<S_>(lb, rf_, tid, q);                                                    \
+    }                                                                                                  \
+    sb.template fetch_head<S_>(lb, rf_, tid);                                                          \
+  } while (0)
+#endif
+    sa.template fetch<0>(la, tile_red(0), tid);
+    sb.template fetch<0>(lb, tile_red(0), tid);
+    sa.template fetch<1>(la, tile_red(1), tid);
+    sb.template fetch<1>(lb, tile_red(1), tid);
+    sa.template fetch<2>(la, tile_red(2), tid);
+    sb.template fetch<2>(lb, tile_red(2), tid);
+    T3D_PC_PRODUCE(0, 0);
+    T3D_PC_PRODUCE(1, 1);
+    T3D_PC_BAR();
+    // Branch-free body of three iterations (a conditional staging pass is a join in front of which hipcc waits for nearly every load in
+    // flight: `s_waitcnt vmcnt(2)` with twelve outstanding): tiles past the end are the last tile again, stored into stages whose tiles
+    // have been consumed (tile nt + i lands on tile nt + i - 3), and the consumers pad their barrier count to the same multiple of three.
+    for (int t = 0; t < nt; t += X3_RING) {
+      T3D_PC_PRODUCE(2, t + 2);
+      T3D_PC_BAR();
+      T3D_PC_PRODUCE(0, t + 3);
+      T3D_PC_BAR();
+      T3D_PC_PRODUCE(1, t + 4);
+      T3D_PC_BAR();
+    }
+#undef T3D_PC_PRODUCE
+    __builtin_amdgcn_endpgm();      // a producer has no accumulators and no epilogue; s_barrier counts the surviving waves only
+  }
+  f32x16 accb[SYM ? TM : 1][SYM ? TN : 1], accc[SYM ? TM : 1][SYM ? TN : 1];
+  if constexpr (SYM) { zero_acc<TM, TN>(accb); zero_acc<TM, TN>(accc); }
+  FragsX3<TM, TN> f0, f1;
+  const int lane = tid & 63;
+  T3D_PC_BAR();
+  load_frags_x3<AR, DIMA, SA::PLANE, BR, DIMB, SB::PLANE>(smem, smem + SA::LDS_ELEMS, a0, b0, lane, f0);
+  int nxt = 1;      // LDS stage of tile t + 1
+  // (the fragments of the tile behind the last one are read from a stage that holds a repeat of the last tile, and never used)
+#ifdef T3D_ABL_PC_NOMMA       // timing ablations (wrong results): consumers without products / without fragment reads
+#define T3D_PC_MMA(FC_) do {} while (0)
+#else
+#define T3D_PC_MMA(FC_) mma_x3_f<SYM, TM, TN>(FC_, acc, accb, accc, [](int) {})
+#endif
+#ifdef T3D_ABL_PC_NOFRAG
+#define T3D_PC_LOADFRAGS(FN_) do {} while (0)
+#else
+#define T3D_PC_LOADFRAGS(FN_) load_frags_x3<AR, DIMA, SA::PLANE, BR, DIMB, SB::PLANE>(smem + nxt * STAGE, smem + nxt * STAGE + SA::LDS_ELEMS, a0, b0, lane, FN_)
+#endif
+#define T3D_PC_CONSUME(FC_, FN_)                                                                                                       \
+  do {                                                                                                                                 \
+    T3D_PC_LOADFRAGS(FN_);                                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);      /* the reads in front of the products (hipcc sinks them to the end, right before their wait) */ \
+    T3D_PC_MMA(FC_);                                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);      /* the barrier behind the products, not in front of them (hipcc hoists it over the MFMAs) */ \
+    T3D_PC_BAR();                                                                                                                   \
+    nxt = nxt == X3_RING - 1 ? 0 : nxt + 1;                                                                                            \
+  } while (0)
+  int t = 0;
+  for (; t + 2 <= nt; t += 2) {
+    T3D_PC_CONSUME(f0, f1);
+    T3D_PC_CONSUME(f1, f0);
+  }
+  if (t < nt) { T3D_PC_CONSUME(f0, f1); ++t; }
+#undef T3D_PC_CONSUME
+#undef T3D_PC_MMA
+#undef T3D_PC_LOADFRAGS
+  for (const int tb = (nt + X3_RING - 1) / X3_RING * X3_RING; t < tb; ++t) T3D_PC_BAR();      // the producers' barrier count
+  if constexpr (SYM) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tm][tn][r] = (acc[tm][tn][r] + accb[tm][tn][r]) + accc[tm][tn][r];
+  }
+}
+
 // Arithmetic of a GEMM kernel: which staging / MFMA loop, and the element type T of the layer tensors it writes.
 struct PathF32 {
   typedef float T;
@@ -1281,6 +1444,7 @@ struct PathF32 {
   typedef WLoaderT<float> WLX;           // ... when every tile lies inside the matrix (the fp32 path keeps its one loader)
   static constexpr bool BF16 = false;
   static constexpr bool X3 = false;
+  static constexpr bool PC = false;
   static constexpr int RED = BK;         // reduction depth of an LDS stage
   template <int DIM, bool TYPE_R, class L, int PF, bool IS_A = false> using Stg = Stager<DIM, TYPE_R, L, PF>;
 };
@@ -1292,6 +1456,7 @@ struct PathBF16 {
   typedef WLoaderT<bf16_t, true> WLX;
   static constexpr bool BF16 = true;
   static constexpr bool X3 = false;
+  static constexpr bool PC = false;
   static constexpr int RED = BKH;
   // the first operand of every GEMM here is the [M, C] stream from HBM: two register slots (prefetch distance 2); the second
   // (weights from L2, or the fatter dy operand of the weight gradient) one
@@ -1309,12 +1474,20 @@ struct ActLoaderE {
   struct Coef { float4 sc, sh; };
   __device__ __forceinline__ Coef fetch_coef(int col) const {
     Coef c;
+#ifdef T3D_X3_COEF_SELECT      // unconditional loads + selects (no join inside the staging loop)
+    const bool has = s.scale != nullptr;
+    const float4 a = *reinterpret_cast<const float4*>((has ? s.scale : s.x) + col);
+    const float4 b = *reinterpret_cast<const float4*>((has ? s.shift : s.x) + col);
+    c.sc = has ? a : make_float4(1.f, 1.f, 1.f, 1.f);
+    c.sh = has ? b : f4zero();
+#else
     c.sc = make_float4(1.f, 1.f, 1.f, 1.f);
     c.sh = f4zero();
     if (s.scale != nullptr) {
       c.sc = *reinterpret_cast<const float4*>(s.scale + col);
       c.sh = *reinterpret_cast<const float4*>(s.shift + col);
     }
+#endif
     return c;
   }
   __device__ __forceinline__ Raw fetch(int row, int col) const {
@@ -1338,6 +1511,7 @@ struct PathX3 {
   typedef WLoaderT<float, true> WLX;
   static constexpr bool BF16 = false;
   static constexpr bool X3 = true;
+  static constexpr bool PC = false;
   static constexpr int RED = BKX;
   template <int DIM, bool TYPE_R, class L, int PF, bool IS_A = false> using Stg = StagerX3<DIM, TYPE_R, L>;
 };
@@ -1351,10 +1525,16 @@ struct PathX3P : PathX3 {      // ... with the layer's weight matrix split befor
   typedef WLoaderX3 WL;
   typedef WLoaderX3 WLX;
 };
+// ... in 512-thread workgroups with producer and consumer waves (gemm_mainloop_x3_pc): three register slots per operand
+struct PathX3PC : PathX3 {
+  static constexpr bool PC = true;
+  template <int DIM, bool TYPE_R, class L, int PF, bool IS_A = false> using Stg = StagerX3<DIM, TYPE_R, L, X3_RING>;
+};
 template <class PR, int TM, int TN, class SA, class SB, class LA, class LB, bool AR, int DIMA, bool BR, int DIMB, bool SYM = false>
 __device__ __forceinline__ void run_mainloop(SA& sa, SB& sb, const LA& la, const LB& lb, float* smem, int red_begin, int red_end,
                                              int a0, int b0, f32x16 (&acc)[TM][TN], int tid) {
-  if constexpr (PR::X3) gemm_mainloop_x3<SYM, TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, red_begin, red_end, a0, b0, acc, tid);
+  if constexpr (PR::PC) gemm_mainloop_x3_pc<SYM, TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, red_begin, red_end, a0, b0, acc, tid);
+  else if constexpr (PR::X3) gemm_mainloop_x3<SYM, TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, red_begin, red_end, a0, b0, acc, tid);
   else if constexpr (PR::BF16) gemm_mainloop_h<TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, red_begin, red_end, a0, b0, acc, tid);
   else gemm_mainloop<TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, red_begin, red_end, a0, b0, acc, tid);
 }
@@ -1374,7 +1554,8 @@ __device__ __forceinline__ void fwd_body(const t3d_pointmlp_fwd_args& p, float* 
   using SA = typename PR::template Stg<BM, true, LA, (PR::BF16 && BN == 128 && !Elem<XT>::BF16) ? 0 : PF, true>;
   using SB = typename PR::template Stg<BN, false, WL, PF>;
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  // (producer / consumer workgroups: the second 256 threads are the staging waves of the same tile coordinates; they end in the main loop)
+  const int tid = PR::PC ? (int)(threadIdx.x & (NT - 1)) : (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int tiles_n = p.N / BN;
   const int lin = xcd_remap(bid, nblk);
@@ -1553,6 +1734,12 @@ template <int BN, bool HAS_SUB, class PR = PathF32, class XT = float>
 __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd(const t3d_pointmlp_fwd_args p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   fwd_body<BN, HAS_SUB, PR, XT>(p, smem, blockIdx.x, gridDim.x);
+}
+
+template <int BN, class PR>      // producer / consumer form (gemm_mainloop_x3_pc): eight waves, one workgroup per CU
+__global__ __launch_bounds__(2 * NT) void k_pointmlp_fwd_pc(const t3d_pointmlp_fwd_args p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  fwd_body<BN, false, PR, float>(p, smem, blockIdx.x, gridDim.x);
 }
 
 // Rider forms (rider_dev.h): the launch's first r.n_wg workgroups run a set of small ops of an independent chain and leave; the
@@ -3664,24 +3851,31 @@ constexpr size_t lds_wgrad_h(int bmk, int bn) { return 2 * (size_t)BKH * (bmk + 
 constexpr size_t lds_x3_r(int dim) { return (size_t)3 * dim * LDRX * 2; }
 constexpr size_t lds_x3_c(int dim) { return (size_t)3 * BKX * (dim + LDCX_PAD) * 2; }
 constexpr size_t lds_fwd_x3(int bn) { return lds_max(2 * (lds_x3_r(128) + lds_x3_c(bn)), (size_t)12 * bn * sizeof(float)); }
+constexpr size_t lds_fwd_x3_pc(int bn) { return lds_max(X3_RING * (lds_x3_r(128) + lds_x3_c(bn)), (size_t)12 * bn * sizeof(float)); }
 constexpr size_t lds_dgrad_x3(int bn) { return lds_max(2 * (lds_x3_r(128) + lds_x3_r(bn)), (size_t)12 * bn * sizeof(float)); }
 constexpr size_t lds_wgrad_x3(int bmk, int bn) { return 2 * (lds_x3_c(bmk) + lds_x3_c(bn)); }
 constexpr size_t lds_bwd1f(int k, int n) { return (size_t)(64 * ((n + 4) + 3 * (k + 4)) + 2 * 2 * 2 * k + 3 * n + 2 * k) * 4; }      // D, A, 2 x X images, statistics scratch, per-column constants
 constexpr size_t lds_bwd1(int k, int n, int bm) { return (size_t)bm * (n + k + 2 * (k + 8)) * 2 + (size_t)2 * 2 * 4 * k * 4; }      // D, A, 2 x X images + the statistics scratch
 
 bool dtype_ok(int dt) { return dt == T3D_F32 || dt == T3D_BF16; }
-// fp32 layers run on the bf16 matrix pipe with three-term operands (PathX3) unless T3D_X3=0 (the fp32-MFMA kernels); T3D_X3_MINKN /
-// T3D_X3_MINKN_BWD: only launches with K x N at least that (default 1: every launch -- measured on the B=32 N=1024 step, one MI355X:
-// 1.440 ms fp32-MFMA, 1.304 with K x N >= 128 x 128, 1.295 with every launch).
-// (read at every launch -- a getenv is nanoseconds and a captured graph keeps what was launched -- so that one process can compare both)
-int x3_mode() { const char* e = getenv("T3D_X3"); return e ? atoi(e) : 1; }
-long x3_min_kn() { const char* e = getenv("T3D_X3_MINKN"); return e ? atol(e) : 1L; }
-long x3_min_kn_bwd() { const char* e = getenv("T3D_X3_MINKN_BWD"); return e ? atol(e) : x3_min_kn(); }
-bool x3_layer(int K, int N) { return x3_mode() != 0 && (long)K * N >= x3_min_kn(); }            // forward launches
+// Arithmetic of an fp32 launch (t3d.h: T3D_ARITH_*).  The request travels in the argument struct (`arith`), fixed by the host when it
+// builds its plan; only T3D_ARITH_AUTO (a zero-initialised struct: the tools and the kernel tests) consults the environment -- T3D_X3=0
+// the fp32-MFMA kernels, T3D_X3_MINKN / T3D_X3_MINKN_BWD: only launches with K x N at least that (measured on the B=32 N=1024 step, one
+// MI355X: 1.440 ms fp32-MFMA, 1.304 with K x N >= 128 x 128, 1.295 with every launch) -- read at every launch so that one process can
+// compare both.
+bool x3_on(int arith) {
+  if (arith == T3D_ARITH_FP32_MFMA) return false;
+  if (arith == T3D_ARITH_BF16X3) return true;
+  const char* e = getenv("T3D_X3");
+  return e ? atoi(e) != 0 : true;
+}
+long x3_min_kn(int arith) { const char* e = arith == T3D_ARITH_AUTO ? getenv("T3D_X3_MINKN") : nullptr; return e ? atol(e) : 1L; }
+long x3_min_kn_bwd(int arith) { const char* e = arith == T3D_ARITH_AUTO ? getenv("T3D_X3_MINKN_BWD") : nullptr; return e ? atol(e) : x3_min_kn(arith); }
+bool x3_layer(int arith, int K, int N) { return x3_on(arith) && (long)K * N >= x3_min_kn(arith); }            // forward launches
 // backward launches (dense and Gram form).  Not the layers with few input and many output channels (64 -> 512, conv6's per-point part):
 // their data gradient is ONE 64-column tile over a long reduction, half the MFMA work per staged element, and measured slower than the
 // fp32-MFMA form (54.1 vs 50.7 us alone, 69.5 vs 62.9 us hosted at M = 32768)
-bool x3_layer_bwd(int K, int N) { return x3_mode() != 0 && (long)K * N >= x3_min_kn_bwd() && (N <= 4 * K || K >= 128); }
+bool x3_layer_bwd(int arith, int K, int N) { return x3_on(arith) && (long)K * N >= x3_min_kn_bwd(arith) && (N <= 4 * K || K >= 128); }
 bool act_ok(const t3d_act_src& a, int K) {
   return a.x != nullptr && (a.ldx % 4) == 0 && (a.coff % 4) == 0 && a.coff + (K + 3) / 4 * 4 <= a.ldx &&
          (a.scale == nullptr || a.shift != nullptr) && dtype_ok(a.dtype) && !(a.dtype == T3D_BF16 && a.sub != nullptr) &&
@@ -3788,6 +3982,21 @@ int t3d_x3_fwd(const t3d_pointmlp_fwd_args* a, const t3d_rider_set* r, hipStream
   const bool pre = a->w_x3 != nullptr;      // the weights arrive as three bf16 planes (t3d_split_x3)
   const char* e = getenv("T3D_X3_FWD128_MIN");      // (fewest 128-wide tiles for which the forward takes them; experiments)
   const long min_tiles = e ? atol(e) : 512;
+  const int pc = []() { const char* e_ = getenv("T3D_X3_PC"); return e_ ? atoi(e_) : 0; }();      // producer / consumer kernels (experiment; read per launch like T3D_X3)
+  if (pc && !r && !pre) {
+    const bool wide = a->N % 128 == 0 && (long)tiles_m * (a->N / 128) >= (pc == 2 ? 1 : min_tiles);
+    if (wide) {
+      auto kern = k_pointmlp_fwd_pc<128, PathX3PC>;
+      allow_lds(reinterpret_cast<const void*>(kern), lds_fwd_x3_pc(128));
+      T3D_LAUNCH(kern, dim3(tiles_m * (a->N / 128)), dim3(2 * NT), lds_fwd_x3_pc(128), s, *a);
+    } else {
+      auto kern = k_pointmlp_fwd_pc<64, PathX3PC>;
+      allow_lds(reinterpret_cast<const void*>(kern), lds_fwd_x3_pc(64));
+      T3D_LAUNCH(kern, dim3(tiles_m * (a->N / 64)), dim3(2 * NT), lds_fwd_x3_pc(64), s, *a);
+    }
+    T3D_CHECK_LAUNCH();
+    return T3D_OK;
+  }
   if (a->N % 128 == 0 && (long)tiles_m * (a->N / 128) >= min_tiles) {
     const dim3 grid(tiles_m * (a->N / 128) + nr);
     if (r && pre) launch_lds_r(k_pointmlp_fwd_r<128, false, PathX3P>, grid, lds_with(lds_fwd_x3(128), r), s, *a, *r);
@@ -3902,6 +4111,7 @@ int t3d_x3_stage2(const t3d_pool_wgrad_finish_args* f, const t3d_pointmlp_dgrad_
 extern "C" int t3d_pointmlp_fwd(const t3d_pointmlp_fwd_args* a, t3d_stream_t stream) { return t3d_pointmlp_fwd_r(a, nullptr, stream); }
 
 extern "C" int t3d_pointmlp_fwd_r(const t3d_pointmlp_fwd_args* a, const t3d_rider_set* r, t3d_stream_t stream) {
+  if (a && a->struct_size != sizeof(*a)) return T3D_ERR_ABI;
   if (r && !riders_ok(r)) return T3D_ERR_ARG;
   if (!a || !a->w || !a->psum || !a->psumsq || !act_ok(a->a, a->K)) return T3D_ERR_ARG;
   if (a->pmax && (!a->pmin || !a->pamax || !a->pamin)) return T3D_ERR_ARG;
@@ -3974,7 +4184,7 @@ extern "C" int t3d_pointmlp_fwd_r(const t3d_pointmlp_fwd_args* a, const t3d_ride
       return T3D_OK;
     }
   }
-  if (!sub && a->K % BKX == 0 && x3_layer(a->K, a->N)) {      // (ahead of the A-resident fp32 kernel)
+  if (!sub && a->K % BKX == 0 && x3_layer(a->arith, a->K, a->N)) {      // (ahead of the A-resident fp32 kernel)
     T3D_HOSTED(r, stream);
     return t3d_x3_fwd(a, r, s);
   }
@@ -4023,6 +4233,7 @@ extern "C" int t3d_pointmlp_fwd_r(const t3d_pointmlp_fwd_args* a, const t3d_ride
 }
 
 static int check_dgrad(const t3d_pointmlp_dgrad_args* a) {
+  if (a && a->struct_size != sizeof(*a)) return T3D_ERR_ABI;
   if (!a || !a->w || !a->out || !dy_ok(a->dy)) return T3D_ERR_ARG;
   if (a->prev_y && (!a->prev_scale || !a->prev_shift)) return T3D_ERR_ARG;
   if (a->psum_dz && (!a->psum_dzy || !a->prev_y)) return T3D_ERR_ARG;
@@ -4051,7 +4262,7 @@ extern "C" int t3d_pointmlp_dgrad(const t3d_pointmlp_dgrad_args* a, t3d_stream_t
     T3D_CHECK_LAUNCH();
     return T3D_OK;
   }
-  if (!pooled && a->N % BKX == 0 && x3_layer_bwd(a->K, a->N)) return t3d_x3_dgrad(a, dgrad_wide(a), s);
+  if (!pooled && a->N % BKX == 0 && x3_layer_bwd(a->arith, a->K, a->N)) return t3d_x3_dgrad(a, dgrad_wide(a), s);
   if (dgrad_wide(a)) {
     const dim3 grid(tiles_m * (a->K / 128));
     if (pooled) launch_lds(k_pointmlp_dgrad<128, true>, grid, lds_dgrad(128), s, *a);
@@ -4136,6 +4347,7 @@ extern "C" int t3d_bwd_plan(int M, int K, int N, int dtype, int* rows_per_split,
 }
 
 static int check_wgrad(const t3d_pointmlp_wgrad_args* a) {
+  if (a && a->struct_size != sizeof(*a)) return T3D_ERR_ABI;
   if (!a || !a->slabs || !act_ok(a->a, a->K) || !dy_ok(a->dy)) return T3D_ERR_ARG;
   const int red = a->dy.dtype == T3D_BF16 ? BKH : BK;
   if (a->M <= 0 || a->rows_per_split <= 0 || a->rows_per_split % red || a->M % a->rows_per_split || a->N % 64 ||
@@ -4166,7 +4378,10 @@ extern "C" int t3d_pointmlp_wgrad_r(const t3d_pointmlp_wgrad_args* a, const t3d_
   const int tiles_k = (a->K + tk - 1) / tk, tiles_n = a->N / tn;
   const bool sub = a->a.sub != nullptr, pooled = a->dy.dz == nullptr;
   // rider form: the 64 x 64 tiling of a first layer's weight gradient (K <= 4 raw channels, fp32) only
-  const bool x3w = a->dy.dtype != T3D_BF16 && !sub && !pooled && a->K % 64 == 0 && x3_layer_bwd(a->K, a->N);      // (no rider form)
+  // x3 form: its activation loader (ActLoaderE) has neither column clamp nor mask -- whole k-tiles of an fp32 source only (K = 192 with
+  // 128-row tiles would read scale / shift / x past column K)
+  const bool x3w = a->dy.dtype != T3D_BF16 && a->a.dtype == T3D_F32 && !sub && !pooled && a->K % tk == 0 && a->K % 64 == 0 &&
+                   x3_layer_bwd(a->arith, a->K, a->N);      // (no rider form)
   // first layer of a net (K <= 4 raw channels): the register kernel, which has no rider form either and beats the generic kernel + a rider
   static const bool use_tiny_w = []() { const char* e = getenv("T3D_WGRAD_TINYK"); return !(e && e[0] == '0'); }();
   const bool tiny_w = use_tiny_w && a->dy.dtype != T3D_BF16 && !pooled && a->K <= 4 && (a->N == 64 || a->N == 128) && a->a.dtype == T3D_F32 &&
@@ -4257,6 +4472,7 @@ static bool dgram1_ok(const t3d_pointmlp_dgrad_gram_args* d) {
 }
 
 static int check_dgrad_gram(const t3d_pointmlp_dgrad_gram_args* a) {
+  if (a && a->struct_size != sizeof(*a)) return T3D_ERR_ABI;
   if (!a || !a->p || !a->out || !act_ok(a->a, a->K) || a->a.sub) return T3D_ERR_ARG;
   if (a->add_live && !a->add_in) return T3D_ERR_ARG;
   if (a->prev_y && (!a->prev_scale || !a->prev_shift)) return T3D_ERR_ARG;
@@ -4286,7 +4502,7 @@ extern "C" int t3d_pointmlp_dgrad_gram(const t3d_pointmlp_dgrad_gram_args* a, t3
   if (a->dtype == T3D_BF16) {
     if (dgrad_gram_wide(a)) launch_lds(k_pointmlp_dgrad_gram<128, PathBF16>, dim3(tiles_m * (a->K / 128)), lds_dgram_h(128), s, *a);
     else launch_lds(k_pointmlp_dgrad_gram<64, PathBF16>, dim3(tiles_m * (a->K / 64)), lds_dgram_h(64), s, *a);
-  } else if (a->K % BKX == 0 && x3_layer_bwd(a->K, a->K)) {
+  } else if (a->K % BKX == 0 && x3_layer_bwd(a->arith, a->K, a->K)) {
     return t3d_x3_dgrad_gram(a, dgrad_gram_wide(a), s);
   } else if (dgrad_gram_wide(a))
     launch_lds(k_pointmlp_dgrad_gram<128>, dim3(tiles_m * (a->K / 128)), lds_fwd(128), s, *a);
@@ -4297,6 +4513,7 @@ extern "C" int t3d_pointmlp_dgrad_gram(const t3d_pointmlp_dgrad_gram_args* a, t3
 }
 
 static int check_gram(const t3d_pointmlp_gram_args* a) {
+  if (a && a->struct_size != sizeof(*a)) return T3D_ERR_ABI;
   if (!a || !a->slabs || !act_ok(a->a, a->K) || a->a.sub) return T3D_ERR_ARG;
   const int red = a->a.dtype == T3D_BF16 ? BKH : BK;
   if (a->M <= 0 || a->rows_per_split <= 0 || a->rows_per_split % red || a->M % a->rows_per_split || a->K % 64 ||
@@ -4323,7 +4540,7 @@ extern "C" int t3d_pointmlp_gram(const t3d_pointmlp_gram_args* a, t3d_stream_t s
   if (rc != T3D_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int splits = a->M / a->rows_per_split;
-  const bool x3g = a->a.dtype != T3D_BF16 && x3_layer_bwd(a->K, a->K);
+  const bool x3g = a->a.dtype != T3D_BF16 && x3_layer_bwd(a->arith, a->K, a->K);
   const int tk = x3g ? 64 : gram_tile(a), tn = tk;
   const dim3 grid((a->K / tk) * (a->K / tn) * splits);
   if (a->a.dtype == T3D_BF16) {
@@ -4411,7 +4628,7 @@ extern "C" int t3d_pointmlp_bwd_r(const t3d_pointmlp_dgrad_args* d, const t3d_po
   const int n_d = (d->M / 128) * (d->K / (wide ? 128 : 64));
   if (bf16) { T3D_RIDERS_FIRST(r, stream); r = nullptr; }
   T3D_HOSTED(r, stream);      // (bf16 has left above: both fp32 forms below host the set)
-  if (!bf16 && d->N % BKX == 0 && w->K % 64 == 0 && x3_layer_bwd(d->K, d->N)) return t3d_x3_bwd(d, w, r, tk, tn, wide, n_w, n_d, s);
+  if (!bf16 && d->N % BKX == 0 && w->K % 64 == 0 && w->K % tk == 0 && w->a.dtype == T3D_F32 && x3_layer_bwd(d->arith, d->K, d->N)) return t3d_x3_bwd(d, w, r, tk, tn, wide, n_w, n_d, s);
   const dim3 grid(n_w + n_d + (r ? r->n_wg : 0));
   // interleaving the two kinds of tile by row range (so that both readers of a dy row range share an L2) measured SLOWER
   // than weight-gradient tiles first (1.683 vs 1.630 ms per step): the long wgrad tiles are better started early.
@@ -4481,7 +4698,7 @@ extern "C" int t3d_pool_bwd_stage1_r(const t3d_pointmlp_gram_args* g, const t3d_
     T3D_CHECK_LAUNCH();
     return T3D_OK;
   }
-  const bool x3g = g->a.dtype != T3D_BF16 && x3_layer_bwd(g->K, g->K);
+  const bool x3g = g->a.dtype != T3D_BF16 && x3_layer_bwd(g->arith, g->K, g->K);
   const int gt = x3g ? 64 : gram_tile(g);      // (x3: 64 x 64 tiles, see mma_x3)
   const int n_gram = (g->K / gt) * (g->K / gt) * (g->M / g->rows_per_split);
   const int n_colsum = c->M / 128;
@@ -4557,7 +4774,7 @@ extern "C" int t3d_pool_bwd_stage2_r(const t3d_pool_wgrad_finish_args* f, const 
   size_t lds = bf16 ? (wide ? lds_dgram_h(128) : lds_dgram_h(64)) : (wide ? lds_fwd(128) : lds_fwd(64));
   if (finish_lds(f->K) > lds) lds = finish_lds(f->K);
   T3D_HOSTED(r, stream);
-  if (!bf16 && d->K % BKX == 0 && x3_layer_bwd(d->K, d->K)) return t3d_x3_stage2(f, d, r, wide, n_finish, n_d, finish_lds(f->K), s);
+  if (!bf16 && d->K % BKX == 0 && x3_layer_bwd(d->arith, d->K, d->K)) return t3d_x3_stage2(f, d, r, wide, n_finish, n_d, finish_lds(f->K), s);
   lds = lds_with(lds, r);
 #define T3D_ST2(BN_, PR_)                                                              \
   do {                                                                                 \
@@ -4591,6 +4808,11 @@ extern "C" int t3d_split_x3(const float* src, void* planes, int64_t n, int64_t p
 static const t3d_rider_set* query_set() {
   static const t3d_rider_set q = []() { t3d_rider_set r{}; r.n_ops = 1; r.n_wg = 1; r.sync = reinterpret_cast<unsigned*>(16); return r; }();
   return &q;
+}
+extern "C" int t3d_gemm_arithmetic(int arith, int dtype, int K, int N, int backward) {
+  if (dtype == T3D_BF16) return T3D_ARITH_BF16;
+  const bool x3 = backward ? (N % BKX == 0 && K % 64 == 0 && (K <= 64 || K % 128 == 0) && x3_layer_bwd(arith, K, N)) : (K % BKX == 0 && x3_layer(arith, K, N));
+  return x3 ? T3D_ARITH_BF16X3 : T3D_ARITH_FP32_MFMA;
 }
 extern "C" int t3d_pointmlp_fwd_hosts_riders(const t3d_pointmlp_fwd_args* a) { return t3d_pointmlp_fwd_r(a, query_set(), T3D_QUERY_STREAM); }
 extern "C" int t3d_pointmlp_wgrad_hosts_riders(const t3d_pointmlp_wgrad_args* a) { return t3d_pointmlp_wgrad_r(a, query_set(), T3D_QUERY_STREAM); }

@@ -28,8 +28,16 @@ TILE = abi.TILE_ROWS
 class Runtime:
     """Owns the library handle and the device.  `lib` defaults to the HIP library (no fallback)."""
 
-    def __init__(self, device=None, lib=None):
+    def __init__(self, device=None, lib=None, gemm_arithmetic=None):
+        """`gemm_arithmetic`: arithmetic of the fp32 per-point GEMM launches of every plan built on this runtime -- 'bf16x3' (default:
+        three exact bf16 terms per operand on the bf16 matrix pipe) or 'fp32_mfma' (t3d.h T3D_ARITH_*).  It is fixed HERE, travels in
+        the launch structs, and is what `describe_gemm_arithmetic` reports; the environment (T3D_X3=0 -> 'fp32_mfma') only supplies
+        the default, once."""
         self.lib = lib if lib is not None else abi.load()
+        if gemm_arithmetic is None:
+            gemm_arithmetic = 'fp32_mfma' if os.environ.get('T3D_X3', '1') == '0' else 'bf16x3'
+        self.gemm_arithmetic = gemm_arithmetic
+        self.arith = abi.ARITH_BY_NAME[gemm_arithmetic]
         if device is None:
             if not torch.cuda.is_available():
                 raise abi.T3DError('no GPU visible: the product path runs on an MI355X only')
@@ -440,6 +448,7 @@ class PointLayer:
         pool = self.pool
         self.src, self.rowmask, self.is_training = src, rowmask, is_training
         a = abi.PointMlpFwdArgs()
+        a.arith = self.g.rt.arith
         a.a = src.struct()
         a.w, a.bias, a.rowbias, a.y = fptr(self.w_mm), fptr(self.bias), fptr(rowbias), fptr(self.y)
         a.dtype = self.dt
@@ -578,6 +587,7 @@ class PointLayer:
             regions += [('P', K * K, nch), ('rowconst', K, nch)]
         sl, red, emit_reduce = self._gram_reduce(plan, regions)
         a = abi.PointMlpGramArgs()
+        a.arith = self.g.rt.arith
         a.a, a.slabs = self.src.struct(), fptr(sl['G'])
         a.M, a.K, a.rows_per_frustum, a.rows_per_split = self.M, K, g.rpf, rps
         plan.add('t3d_pointmlp_gram', a)
@@ -617,6 +627,7 @@ class PointLayer:
                                    iptr(self.S_live))
         plan.add('t3d_pool_sparse_rows', r)
         a = abi.PointMlpDgradGramArgs()
+        a.arith = self.g.rt.arith
         a.a, a.p, a.rowconst, a.add_in = self.src.struct(), fptr(red['P']), fptr(red['rowconst']), fptr(self.S)
         a.add_live = iptr(self.S_live)
         a.prev_y, a.prev_scale, a.prev_shift = fptr(prev.y), fptr(prev.scale), fptr(prev.shift)
@@ -637,6 +648,7 @@ class PointLayer:
         sl, red, emit_reduce = self._gram_reduce(plan, [('G', K * K, self.M // rps), ('abar', K, self.T), ('P', K * K, nch),
                                                         ('rowconst', K, nch)])
         ga = abi.PointMlpGramArgs()
+        ga.arith = self.g.rt.arith
         ga.a, ga.slabs = self.src.struct(), fptr(sl['G'])
         ga.M, ga.K, ga.rows_per_frustum, ga.rows_per_split = self.M, K, g.rpf, rps
         ca = abi.ActColsumArgs()
@@ -657,6 +669,7 @@ class PointLayer:
         goff = g.vars.offset(self.w_name) + self.w_row0 * N
         f.dw = fptr(g.vars.grads[goff:goff + K * N])
         d = abi.PointMlpDgradGramArgs()
+        d.arith = self.g.rt.arith
         d.a, d.p, d.rowconst, d.add_in = self.src.struct(), fptr(red['P']), fptr(red['rowconst']), fptr(self.S)
         d.add_live = iptr(self.S_live)
         d.prev_y, d.prev_scale, d.prev_shift = fptr(prev.y), fptr(prev.scale), fptr(prev.shift)
@@ -687,6 +700,7 @@ class PointLayer:
         goff = g.vars.offset(self.w_name) + self.w_row0 * self.N
         soff = g.ws.reserve(goff, self.K * self.N, n_slabs)
         a = abi.PointMlpWgradArgs()
+        a.arith = self.g.rt.arith
         a.a, a.dy = self.src.struct(), self.dy_struct()
         a.M, a.K, a.N, a.rows_per_frustum, a.rows_per_split = self.M, self.K, self.N, g.rpf, rps
         g.deferred_slab_ptrs.append((a, 'slabs', soff))
@@ -700,6 +714,7 @@ class PointLayer:
     def _dgrad_args(self, out_raw=None, add_in=None):
         prev = self.src.producer if out_raw is None else None
         a = abi.PointMlpDgradArgs()
+        a.arith = self.g.rt.arith
         a.dy, a.w, a.add_in, a.dtype = self.dy_struct(), fptr(self.w_mm), fptr(add_in), self.dt
         a.w_x3, a.w_x3_stride = self.w_x3 if self.NA == self.N else (None, 0)
         if prev is not None:

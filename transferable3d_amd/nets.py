@@ -91,7 +91,7 @@ class Graph:
         if self.dt != abi.BF16:
             px = getattr(vs, 'params_x3', None)
             if px is not None and hasattr(lib, 't3d_split_x3'):
-                plan.add_raw('t3d_split_x3', lambda s: lib.t3d_split_x3(fptr(vs.params), C.c_void_p(px.data_ptr()), (vs.used + 3) // 4 * 4,
+                plan.add_raw('t3d_split_x3', lambda s: lib.t3d_split_x3(fptr(vs.params), C.c_void_p(px.data_ptr()), min((vs.used + 3) // 4 * 4, vs.params.numel()),
                                                                         vs.params.numel(), s))
             return
         p16 = vs.enable_bf16()

@@ -85,11 +85,18 @@ def can_pair(name, arg):
     return not (name == 't3d_bn_bwd_finalize' and arg.psum_dz and arg.n_tiles > 512)      # the 64-group form runs alone
 
 
+def _x3_requested(a):
+    """The launch struct asks for the three-term bf16 arithmetic (engine.Runtime.gemm_arithmetic; a struct without the request -- the
+    kernel tests' -- follows the library's default and its T3D_X3 experiment switch)."""
+    req = getattr(a, 'arith', abi.ARITH_AUTO) if a is not None else abi.ARITH_AUTO
+    return req == abi.ARITH_BF16X3 or (req == abi.ARITH_AUTO and os.environ.get('T3D_X3', '1') != '0')
+
+
 # ---- duration model (us on one MI355X, from bench.py --call_detail at B=32 N=1024; only the ORDER of magnitude steers the alignment) ----
 def est_us(name, arg):
     a = _first(arg) if arg is not None else None
     # fp32 GEMMs on the bf16 matrix pipe (csrc/pointmlp.hip PathX3, the default) are 1.1-1.5x faster than the fp32-MFMA kernels
-    x3 = os.environ.get('T3D_X3', '1') != '0' and a is not None and getattr(a, 'dtype', 0) == abi.F32
+    x3 = _x3_requested(a) and getattr(a, 'dtype', 0) == abi.F32
     if name == 't3d_pointmlp_fwd':
         if a.K <= 4:
             return 5.0                                            # register kernel, bound by its output store
@@ -106,7 +113,7 @@ def est_us(name, arg):
         return 6.0 + 2.0 * a.M * a.K * a.K / 0.9e8
     if name == 't3d_pool_bwd_stage2':
         f = a
-        return 8.0 + 2.0 * arg[1].M * f.K * f.K / (1.0e8 if os.environ.get('T3D_X3', '1') != '0' else 0.85e8)
+        return 8.0 + 2.0 * arg[1].M * f.K * f.K / (1.0e8 if _x3_requested(arg[1]) else 0.85e8)
     if name in ('t3d_fc_fwd', 't3d_fc_bwd', 't3d_fc_dinput'):      # 7.4 (256 x 256) ... 9.9 (512 x 512) fwd, 11-14 bwd
         rb = max(1.0, a.B / 32.0)
         kn = float(a.K) * a.N * rb

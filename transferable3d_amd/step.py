@@ -37,9 +37,20 @@ class TrainStep:
         self.on_gpu = self.rt.device.type == 'cuda'
         want = use_hip_graph if use_hip_graph is not None else self.on_gpu
         self.want_graph = bool(want) and self.on_gpu
+        # Data parallel on RCCL: the whole step, the gradient all-reduce included, is ONE captured graph (RCCL collectives can be
+        # stream-captured; nothing is host-issued between the backward and the optimiser, and a replay costs what the single
+        # replica's does).  gloo cannot be captured and keeps the host-issued program, as does T3D_DP_ONE_GRAPH=0.  With ONE bucket
+        # the collective is captured in line on the launch stream (there is nothing to run beside it); with several, on RCCL's own
+        # stream, which joins the capture through the event edges torch records around a collective (T3D_DP_ONE_GRAPH=1 / 2 force
+        # a form).
+        env = os.environ.get('T3D_DP_ONE_GRAPH', '')
         if one_graph is None:
-            one_graph = os.environ.get('T3D_DP_ONE_GRAPH', '0') in ('1', '2')
-        self.one_graph = one_graph
+            if env in ('0', '1', '2'):
+                one_graph = env != '0'
+            else:
+                one_graph = self.dist and self.on_gpu and self._backend() == 'nccl'
+        self.one_graph = bool(one_graph) and self.dist and self.on_gpu
+        self.one_graph_form = env if env in ('1', '2') else None      # None: by the number of buckets
         self.cache = {}            # generate_masks -> list of program items with captured graphs
         self.n_runs = 0
         self._capture_stream = None
@@ -51,6 +62,13 @@ class TrainStep:
         # sets' time-out words every `rider_check_every` steps (one 4-byte read) and raises schedule.RiderBarrierTimeout; the
         # drivers also call check_riders() before they write a checkpoint.  0: only on request.
         self.rider_check_every = int(os.environ.get('T3D_RIDER_CHECK_EVERY', '64'))
+
+    def _backend(self):
+        try:
+            import torch.distributed as dist
+            return str(dist.get_backend(self.pg)).lower()
+        except Exception:      # (no process group, or a stand-in object in a test)
+            return ''
 
     # ---- program --------------------------------------------------------------------------------------------------------------
     def _buckets(self):
@@ -230,7 +248,7 @@ class TrainStep:
             # on the capture stream (no overlap); =2: asynchronously on RCCL's stream, which joins the capture through the event
             # edges torch records around a collective, so that the replayed graph has the bucket's all-reduce on a branch beside the
             # rest of the backward (no host work and no graph-launch gap between the segments).
-            overlap = os.environ.get('T3D_DP_ONE_GRAPH', '0') == '2'
+            overlap = (self.one_graph_form == '2') if self.one_graph_form else len(self._buckets()) > 1
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=s, capture_error_mode='thread_local'):
                 if overlap:
@@ -292,7 +310,7 @@ class TrainStep:
         the launch stream stood still waiting for an all-reduce."""
         mode = 'flat' if len(self._buckets()) == 1 else 'bucketed'
         if self.one_graph:
-            mode += ', collectives captured in ONE graph (T3D_DP_ONE_GRAPH=%s)' % os.environ.get('T3D_DP_ONE_GRAPH', '0')
+            mode += ', the step and its collectives captured in ONE graph'
         else:
             mode += ', host-issued collectives between graph segments'
         exposed = None
@@ -335,7 +353,8 @@ STAGE_C_TRAIN_CLASSES = [i in (1, 2, 6, 7, 8) for i in range(10)]     # SUNRGBD_
 
 
 def build_training_step(rt, workload, B, N, C, world=1, rank=0, process_group=None, force_dist=False, flat_allreduce=False,
-                        use_hip_graph=None, inline_dropout=True, dropout_seed=1234, seed=0, state_dict=None, c=None, dtype='f32'):
+                        use_hip_graph=None, inline_dropout=True, dropout_seed=1234, seed=0, state_dict=None, c=None, dtype='f32',
+                        one_graph=None):
     """The step bench.py times and the trajectory tests check: graph + model of `workload` ('A' = BASELINE configs[1],
     'boxpc' = configs[2], 'F' = configs[3]), the device-side schedules (train_semisup.py:127-145), forward, backward, TF-form Adam
     over the recipe's var_list, wrapped in a TrainStep.  Returns (engine graph, model, step, loss buffer)."""
@@ -369,7 +388,7 @@ def build_training_step(rt, workload, B, N, C, world=1, rank=0, process_group=No
     g.emit_adam(g.opt, prefixes=prefixes, grad_scale=1.0 / world)
     g.finalize()
     step = TrainStep(g, g.pre, g.fwd, g.bwd, g.opt, process_group=process_group, use_hip_graph=use_hip_graph,
-                     force_dist=force_dist)
+                     force_dist=force_dist, one_graph=one_graph)
     return g, model, step, loss
 
 

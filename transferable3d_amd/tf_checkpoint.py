@@ -479,6 +479,42 @@ def save_model(log_dir, epoch, graph, fmt='npz', optimizer_scopes=None):
     return path
 
 
+class Saver:
+    """`tf.train.Saver(max_to_keep=5)` of the three drivers (train_semisup.py:259, train_boxpc.py:261, train_semisup_adv.py:433): `save`
+    writes `LOG_DIR/model_epoch_<n>` like `save_model` and then removes the oldest checkpoint THIS saver wrote once it holds more than
+    `max_to_keep` (files that were in the directory before are never touched, as in TensorFlow); a TensorFlow-format `checkpoint`
+    state file lists the kept prefixes only.  `max_to_keep` None or 0: keep everything."""
+
+    def __init__(self, max_to_keep=5):
+        self.max_to_keep = max_to_keep
+        self.last_checkpoints = []
+
+    def save(self, log_dir, epoch, graph, fmt='npz', optimizer_scopes=None):
+        path = save_model(log_dir, epoch, graph, fmt, optimizer_scopes=optimizer_scopes)
+        if path in self.last_checkpoints:          # the same epoch saved again: it becomes the newest
+            self.last_checkpoints.remove(path)
+        self.last_checkpoints.append(path)
+        while self.max_to_keep and len(self.last_checkpoints) > self.max_to_keep:
+            self._delete(self.last_checkpoints.pop(0))
+        if fmt == 'tf':
+            state = os.path.join(log_dir, 'checkpoint')
+            with open(state, 'w') as f:
+                f.write('model_checkpoint_path: "%s"\n' % os.path.basename(path))
+                for p in self.last_checkpoints:
+                    f.write('all_model_checkpoint_paths: "%s"\n' % os.path.basename(p))
+        return path
+
+    @staticmethod
+    def _delete(path):
+        import glob
+        victims = [path] if path.endswith('.npz') else [path + '.index'] + glob.glob(glob.escape(path) + '.data-*')
+        for v in victims:
+            try:
+                os.remove(v)
+            except FileNotFoundError:
+                pass
+
+
 def restore_model(graph, path):
     """`saver.restore(sess, path)`: weights, moving statistics and — from a Saver bundle — Adam slots and the global step."""
     n, step = restore_variables(graph.vars, load_state(path))

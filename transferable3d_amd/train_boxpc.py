@@ -21,7 +21,7 @@ if __package__ in (None, ''):
 from transferable3d_amd import api, boxpc_sunrgbd as MODEL            # noqa: E402
 from transferable3d_amd.config import make_parser                       # noqa: E402
 from transferable3d_amd.synthetic import make_batch                     # noqa: E402
-from transferable3d_amd.tf_checkpoint import restore_model, save_model  # noqa: E402
+from transferable3d_amd.tf_checkpoint import Saver, restore_model  # noqa: E402
 
 
 def build_flags(argv=None):
@@ -76,6 +76,7 @@ def train(FLAGS, rt=None, log=print):
         loss = MODEL.get_loss(pred, (y_box_iou_pl, (y_center_delta_pl, y_dims_delta_pl, y_orient_delta_pl)), end_points, c=FLAGS)
         train_op = api.make_optimizer(FLAGS, world_size=world).minimize(loss)      # train_boxpc.py:245-250
         sess = api.Session(process_group=pg, dropout_seed=1234 + rank)
+        saver = Saver(max_to_keep=5)      # train_boxpc.py:261
         if FLAGS.restore_model_path:
             restore_model(g, FLAGS.restore_model_path)
         step, mean_loss = 0, 0.0
@@ -155,7 +156,7 @@ def train(FLAGS, rt=None, log=print):
                     eval_one_epoch(epoch)
                 if epoch % 5 == 0 and rank == 0:
                     sess.check_riders()      # never checkpoint weights a timed-out rider barrier may have corrupted
-                    log('Model saved in file: %s' % save_model(FLAGS.log_dir, epoch, g, FLAGS.ckpt_format))
+                    log('Model saved in file: %s' % saver.save(FLAGS.log_dir, epoch, g, FLAGS.ckpt_format))
                 continue
             stats = new_stats()
             for _ in range(FLAGS.steps_per_epoch):
@@ -173,7 +174,7 @@ def train(FLAGS, rt=None, log=print):
                 eval_one_epoch(epoch)
             if epoch % 5 == 0 and rank == 0:
                 sess.check_riders()      # never checkpoint weights a timed-out rider barrier may have corrupted
-                path = save_model(FLAGS.log_dir, epoch, g, FLAGS.ckpt_format)
+                path = saver.save(FLAGS.log_dir, epoch, g, FLAGS.ckpt_format)
                 log('Model saved in file: %s' % path)
         sess.check_riders()
         final = g.vars.state_dict()

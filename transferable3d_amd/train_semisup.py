@@ -25,7 +25,7 @@ if __package__ in (None, ''):
 from transferable3d_amd import api, tf_util, semisup_v1_sunrgbd as MODEL       # noqa: E402
 from transferable3d_amd.config import make_parser                        # noqa: E402
 from transferable3d_amd.synthetic import make_batch                      # noqa: E402
-from transferable3d_amd.tf_checkpoint import restore_model, save_model   # noqa: E402
+from transferable3d_amd.tf_checkpoint import Saver, restore_model   # noqa: E402
 
 
 def build_flags(argv=None):
@@ -170,6 +170,7 @@ def train(FLAGS, rt=None, log=print):
         optimizer = api.make_optimizer(FLAGS, world_size=world)      # train_semisup.py:226-231 (--optimizer adam | momentum)
         train_op = optimizer.minimize(semi_loss)
         sess = api.Session(process_group=pg, dropout_seed=1234 + rank)
+        saver = Saver(max_to_keep=5)      # train_semisup.py:259
         if FLAGS.restore_model_path:
             restore_model(g, FLAGS.restore_model_path)
         n_correct = api.Tensor(g, g.assembly.seg.n_correct, (1,), 'n_correct')
@@ -246,7 +247,7 @@ def train(FLAGS, rt=None, log=print):
             if rank == 0:
                 if epoch % 5 == 0:                       # train_semisup.py:316-318
                     sess.check_riders()      # never checkpoint weights a timed-out rider barrier may have corrupted
-                    path = save_model(FLAGS.log_dir, epoch, g, FLAGS.ckpt_format)
+                    path = saver.save(FLAGS.log_dir, epoch, g, FLAGS.ckpt_format)
                     log('Model saved in file: %s' % path)
         sess.check_riders()
         final = g.vars.state_dict()
