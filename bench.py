@@ -384,21 +384,26 @@ class Watchdog:
 
 
 def other_configs(args):
-    """BASELINE.json configs[2], configs[3] (one replica) and configs[4] (one replica): <= 20 timed steps each in a child process of
-    this script (own Runtime, own hipGraph), reported beside the headline -- informational, never `value`."""
+    """BASELINE.json configs[2], configs[3] (one replica), configs[4] (one replica) and the reference's own problem size: <= 20 timed
+    steps each in a child process of this script (own Runtime, own hipGraph), reported beside the headline -- informational, never
+    `value`."""
     import subprocess
     # ... and the reference's own problem size (train_semisup.py:34-36,61: 2048 points, RGB on): B=32 N=2048 C=6 fp32
-    runs = [('boxpc', 'f32', []), ('F', 'f32', []), ('A', 'bf16', ['--batch_size', '128', '--num_point', '2048']),
-            ('A', 'f32', ['--num_point', '2048', '--num_channel', '6'])]
+    # ... and the headline workload as the software-pipelined program (step.PipelinedStep: the seg forward of step k+1 beside the
+    # T-Net / box chain of step k; bit-identical, opt-in: T3D_PIPELINE=1)
+    runs = [('boxpc', 'f32', [], {}), ('F', 'f32', [], {}), ('A', 'bf16', ['--batch_size', '128', '--num_point', '2048'], {}),
+            ('A', 'f32', ['--num_point', '2048', '--num_channel', '6'], {}), ('A', 'f32', [], {'T3D_PIPELINE': '1'})]
     out = []
-    for wl, dt, extra in runs:
+    for wl, dt, extra, env_over in runs:
         cmd = [sys.executable, os.path.abspath(__file__), '--workload', wl, '--dtype', dt, '--steps', '20', '--warmup', '5',
                '--profile_steps', '2', '--no_cpu_baseline', '--no_other_configs'] + extra
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0'))
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240,
+                               env=dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0', **env_over))
             d = json.loads(r.stdout.strip().split('\n')[-1])
             rf = d.get('roofline') or {}
-            out.append({'workload': d['config']['workload'], 'dtype': d['dtype'], 'value': d['value'], 'unit': d['unit'],
+            out.append({'workload': d['config']['workload'] + (' [software-pipelined program]' if d['config'].get('pipelined') else ''),
+                        'dtype': d['dtype'], 'value': d['value'], 'unit': d['unit'],
                         'ms_per_step': d['ms_per_step'], 'steps': d['steps'],
                         'rider_barrier_timeouts': ((d['config'].get('schedule') or {}).get('rider_barrier_timeouts', 0)),
                         'roofline': {'kernel': rf.get('kernel'), 'bound': rf.get('bound'), 'frac': rf.get('frac'),

@@ -862,6 +862,27 @@ __device__ __forceinline__ void gemm_mainloop_h(SA& sa, SB& sb, const LA& la, co
 // layouts of the bf16 path) and the main loop differ.  Results agree with the fp32 MFMA kernels to the last bits, not bit for bit
 // (another summation order): the launchers take this path only when asked (T3D_X3, see t3d_pointmlp_fwd_r).
 constexpr int BKX = 16;             // reduction depth of an LDS stage = ONE step of v_mfma_f32_32x32x16_bf16
+// Where the accumulators live (an experiment of round 5; T3D_X3_AGPR=1 builds it, the default is 0).  hipcc keeps the C / D matrix of
+// an MFMA builtin in ordinary VGPRs whenever a kernel fits 256 of them ("AGPRs: 0" for every kernel of this file), and in a bare loop a
+// v_mfma whose accumulator is a VGPR block does not let vector instructions run beside it: tools/micro/mfma_valu_overlap.hip (MI355X,
+// two waves per SIMD, [one MFMA, six v_fma_f32] x 4 per iteration) takes 356 cycles per iteration with VGPR accumulators -- the 256
+// cycles of the matrix pipe PLUS the vector instructions -- against 284 with the accumulators in AGPRs, and a wave that only multiplies
+// starves its SIMD partner's vector stream almost completely (which is why the producer / consumer kernels below lose).  The compiler
+// takes the AGPR form of the builtins as soon as the function may use AGPRs at all -- which one (empty) inline-asm statement with an
+// "a" operand tells it.  In THESE kernels it buys nothing: per launch at M = 32768, AGPR vs VGPR form, forward 512 -> 256 55.7 vs
+// 56.1 us, 256 -> 128 26.2 vs 22.5, 128 -> 1024 63.6 vs 61.5, fused backward 512 -> 256 124.7 vs 112.1; the rider kernels, whose
+// small-op bodies need ~240 VGPRs of their own, spill 56-60 registers beside 128 AGPRs and the step goes from 1.205 to 1.257 ms
+// (tools/agpr_ab.sh, same box).  hipcc does interleave the staging pass between the MFMAs in the AGPR build (one MFMA : ~7 vector
+// instructions); what the waves wait for there is their fragment reads (s_waitcnt lgkmcnt in front of every other MFMA), not the
+// vector ports.
+#ifndef T3D_X3_AGPR
+#define T3D_X3_AGPR 0
+#endif
+#if T3D_X3_AGPR
+#define T3D_MFMA_IN_AGPRS() do { float agpr_hint_ = 0.f; asm volatile("; accumulators in AGPRs" : "+a"(agpr_hint_)); } while (0)
+#else
+#define T3D_MFMA_IN_AGPRS() do {} while (0)
+#endif
 // LDS budget: three planes per operand.  With the bf16 path's padded images (R rows of 16 + 8, C rows of DIM + 32) a 128 x 128 forward
 // tile needs 67.6 KB for its two stages: two workgroups per CU.  Alternative: the R image UNPADDED -- rows of 16 bf16 = 32 B, the two
 // 16-byte halves of row r swapped when bit 3 of r is set, so that the 16 lanes a ds_read_b128 serves together (16 consecutive rows,
@@ -940,15 +961,12 @@ struct WLoaderX3 {
   const bf16_t* p;      // plane 0
   long stride;          // elements between planes
   int ld;
-  struct Raw { bf16x4 h, m, l; };
+  struct Raw { bf16x8 v; };      // EIGHT consecutive elements of ONE plane: a 16-byte load and a 16-byte LDS store (StagerX3W)
   struct Coef {};
   __device__ __forceinline__ Coef fetch_coef(int) const { return Coef(); }
-  __device__ __forceinline__ Raw fetch(int row, int col) const {
-    const bf16_t* q = p + (size_t)row * ld + col;
+  __device__ __forceinline__ Raw fetch(int plane, int row, int col) const {
     Raw r;
-    r.h = *reinterpret_cast<const bf16x4*>(q);
-    r.m = *reinterpret_cast<const bf16x4*>(q + stride);
-    r.l = *reinterpret_cast<const bf16x4*>(q + 2 * stride);
+    r.v = *reinterpret_cast<const bf16x8*>(p + (size_t)plane * stride + (size_t)row * ld + col);
     return r;
   }
 };
@@ -1015,9 +1033,7 @@ struct StagerX3 {
   __device__ __forceinline__ void store_piece(const L& l, bf16_t* tile, int tid, int q) {
     int li, ri; coords(tid, q, li, ri);
     bf16x4 h, m, lo;
-    if constexpr (PreSplit<L>::value) {
-      h = raw[S][q].h; m = raw[S][q].m; lo = raw[S][q].l;
-    } else {
+    {
       const typename L::Coef& c = coef[TYPE_R ? S : 0];
       const float4 v = TYPE_R ? l.xform(raw[S][q], c, lane0 + li, red0[S] + ri) : l.xform(raw[S][q], c, red0[S] + ri, lane0 + li);
       split3(v, h, m, lo);
@@ -1032,6 +1048,54 @@ struct StagerX3 {
 #ifdef T3D_ABL_X3_WRITE1
     }
 #endif
+  }
+  template <int S>
+  __device__ __forceinline__ void store(const L& l, bf16_t* tile, int tid) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q) store_piece<S>(l, tile, tid, q);
+  }
+};
+
+// ... of a weight matrix that arrives as three bf16 planes (WLoaderX3): the tile is COPIED, sixteen bytes at a time -- chunk f of the
+// tile's 3 x DIM x BKX / 8 chunks is eight consecutive elements of plane f / (2 DIM); no arithmetic, one load and one ds_write_b128 per
+// 8 elements (round 4's form moved 8-byte pieces, three loads and three stores per 4 elements, and lost to the in-kernel split).
+template <int DIM, bool TYPE_R, class L, int PF_ = T3D_X3_PF>
+struct StagerX3W {
+  static constexpr int PF = PF_;
+  static constexpr int LDC = DIM + LDCX_PAD;
+  static constexpr int PLANE = TYPE_R ? DIM * LDRX : BKX * LDC;
+  static constexpr int LDS_ELEMS = 3 * PLANE;
+  static constexpr int CPP = DIM * BKX / 8;                 // chunks per plane
+  static constexpr int NCH = 3 * CPP;
+  static constexpr int NV = (NCH + NT - 1) / NT;            // 3 (DIM = 128), 2 (DIM = 64: the second pass on half of the waves)
+  static_assert(NCH % 64 == 0, "a pass ends on a wave boundary");
+  typename L::Raw raw[PF][NV];
+  int lane0;
+  __device__ __forceinline__ static bool coords(int tid, int q, int& plane, int& lane_i, int& red_i) {
+    const int f = tid + NT * q;
+    plane = f / CPP;
+    const int c = f % CPP;
+    if (TYPE_R) { lane_i = c / (BKX / 8); red_i = (c % (BKX / 8)) * 8; }
+    else { constexpr int C8 = DIM / 8; red_i = c / C8; lane_i = (c % C8) * 8; }
+    return NCH % NT == 0 || f < NCH;      // (wave-uniform)
+  }
+  __device__ __forceinline__ void init(const L&, int lane0_, int) { lane0 = lane0_; }
+  template <int S>
+  __device__ __forceinline__ void fetch_piece(const L& l, int red0_, int tid, int q) {
+    int pl, li, ri;
+    if (coords(tid, q, pl, li, ri)) raw[S][q] = TYPE_R ? l.fetch(pl, lane0 + li, red0_ + ri) : l.fetch(pl, red0_ + ri, lane0 + li);
+  }
+  template <int S>
+  __device__ __forceinline__ void fetch(const L& l, int red0_, int tid) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q) fetch_piece<S>(l, red0_, tid, q);
+  }
+  template <int S> __device__ __forceinline__ void fetch_head(const L&, int, int) {}
+  template <int S>
+  __device__ __forceinline__ void store_piece(const L&, bf16_t* tile, int tid, int q) {
+    int pl, li, ri;
+    if (coords(tid, q, pl, li, ri))
+      *reinterpret_cast<bf16x8*>(tile + pl * PLANE + (TYPE_R ? x3_r_off(li, ri) : ri * LDC + li)) = raw[S][q].v;
   }
   template <int S>
   __device__ __forceinline__ void store(const L& l, bf16_t* tile, int tid) {
@@ -1226,6 +1290,7 @@ __device__ __forceinline__ void gemm_mainloop_x3(SA& sa, SB& sb, const LA& la, c
                                                  int a0, int b0, f32x16 (&acc)[TM][TN], int tid) {
   static_assert(!SYM || TM * TN == 1, "symmetric accumulation: 64 x 64 tiles (three accumulator sets)");
   static_assert(SA::PF == SB::PF && SA::PF >= 1 && SA::PF <= 4, "one to four register slots");
+  T3D_MFMA_IN_AGPRS();
   constexpr int PF = SA::PF;
   f32x16 accb[SYM ? TM : 1][SYM ? TN : 1], accc[SYM ? TM : 1][SYM ? TN : 1];
   if constexpr (SYM) { zero_acc<TM, TN>(accb); zero_acc<TM, TN>(accc); }
@@ -1311,19 +1376,25 @@ __device__ __forceinline__ void gemm_mainloop_x3(SA& sa, SB& sb, const LA& la, c
 }
 
 
-// ---- producer / consumer wave roles (PathX3PC; 512-thread workgroups) -----------------------------------------------------------------
+// ---- producer / consumer wave roles (PathX3PC; 512-thread workgroups) -- an EXPERIMENT of round 5, not the default ---------------------
 // The loop above gives every wave both jobs -- load, batch-norm / ReLU, three-way split, LDS stores AND the six products -- in ONE in-order
-// instruction stream: ~147 vector instructions per wave and 16-deep k-tile queue behind and in front of 24 MFMAs, and the counters say
+// instruction stream: ~135 vector instructions per wave and 16-deep k-tile queue behind and in front of 24 MFMAs, and the counters say
 // the matrix pipe idles 0.6 of a launch while a SIMD has nothing to issue 0.4 of it (docs/EXPERIMENTS.md, round 4).  Here a workgroup is
 // EIGHT waves: waves 0-3 (consumers, tid 0..255: the 2 x 2 wave grid of the output tile, the only ones with accumulators and an
 // epilogue) issue nothing but fragment reads and MFMAs; waves 4-7 (producers) run the staging pass of the whole tile and end.  A SIMD
-// hosts one wave of each role, so the staging pass's vector instructions issue in the 24 of every 32 cycles an MFMA leaves free instead
-// of in the same stream.  Three LDS stages, one workgroup barrier per k-tile, tile j in stage j % 3:
+// hosts one wave of each role.  Three LDS stages (101 KB: ONE workgroup per CU), one workgroup barrier per k-tile, tile j in stage j % 3:
 //     iteration t   consumers: read the fragments of tile t + 1 into the other register set, multiply tile t from registers
 //                   producers: convert + store tile t + 2 (register slot (t + 2) % 3), request tile t + 5 into that slot
 //     barrier t + 1: tile t + 2 is complete; every fragment of tile t has been consumed
 // Stage (t + 2) % 3 held tile t - 1, whose fragments were read in iteration t - 2: no wave can still be reading it.  Same products in the
-// same order as the loop above: results are bit-identical.
+// same order as the loop above: results are bit-identical (tests/test_kernels_gpu.py).
+// MEASURED (tools/bench_x3_pc.py, MI355X, forward 512 -> 256 at M = 32768): 78-83 us against 56-58 us for the loop above.  Taken apart
+// with timing ablations (tools/pc_abl.sh): the consumers alone (producers only keeping the barrier count) 53 us; the producers alone
+// 52 us; the products alone, no fragment reads and no barrier, 41-44 us -- of which the chip's matrix pipe accounts for 27.7 us (it
+// sustains 1.86 PFLOP/s dense bf16 at the 1.85 GHz it holds under this load, tools/micro/mfma_rate.hip, not the 2.5 PFLOP/s of the
+// data sheet) and the rest is the un-overlapped prologue and epilogue of the one workgroup a CU can hold.  The two roles of a SIMD do NOT
+// run beside each other for free: together they take 1.5 x the longer of the two, whatever the priorities (s_setprio on either role:
+// 78.4 / 82.9 us).  Kept behind T3D_X3_PC=1 for the measurement; nothing selects it.
 constexpr int X3_RING = 3;
 #ifdef T3D_ABL_PC_NOBAR      // timing ablation (wrong results; with _NOPROD and _NOFRAG: the products alone)
 #define T3D_PC_BAR() do {} while (0)
@@ -1474,20 +1545,12 @@ struct ActLoaderE {
   struct Coef { float4 sc, sh; };
   __device__ __forceinline__ Coef fetch_coef(int col) const {
     Coef c;
-#ifdef T3D_X3_COEF_SELECT      // unconditional loads + selects (no join inside the staging loop)
-    const bool has = s.scale != nullptr;
-    const float4 a = *reinterpret_cast<const float4*>((has ? s.scale : s.x) + col);
-    const float4 b = *reinterpret_cast<const float4*>((has ? s.shift : s.x) + col);
-    c.sc = has ? a : make_float4(1.f, 1.f, 1.f, 1.f);
-    c.sh = has ? b : f4zero();
-#else
     c.sc = make_float4(1.f, 1.f, 1.f, 1.f);
     c.sh = f4zero();
     if (s.scale != nullptr) {
       c.sc = *reinterpret_cast<const float4*>(s.scale + col);
       c.sh = *reinterpret_cast<const float4*>(s.shift + col);
     }
-#endif
     return c;
   }
   __device__ __forceinline__ Raw fetch(int row, int col) const {
@@ -1524,6 +1587,8 @@ __device__ __forceinline__ WL make_wloader(const Args& p) {
 struct PathX3P : PathX3 {      // ... with the layer's weight matrix split beforehand (t3d_pointmlp_fwd_args.w_x3)
   typedef WLoaderX3 WL;
   typedef WLoaderX3 WLX;
+  template <int DIM, bool TYPE_R, class L, int PF, bool IS_A = false>
+  using Stg = std::conditional_t<PreSplit<L>::value, StagerX3W<DIM, TYPE_R, L>, StagerX3<DIM, TYPE_R, L>>;
 };
 // ... in 512-thread workgroups with producer and consumer waves (gemm_mainloop_x3_pc): three register slots per operand
 struct PathX3PC : PathX3 {

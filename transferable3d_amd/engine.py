@@ -198,8 +198,12 @@ class Plan:
         return sum(1 for name, _, _ in self.calls if not name.startswith('__'))
 
 
-# (measured on the B=32 N=1024 step, same box: 1.276 ms with the planes, 1.257 ms with the split in the kernels -- three 8-byte loads
-# per chunk instead of one 16-byte load cost more than the conversions they save; off by default)
+# (round 4, 8-byte pieces: 1.276 ms per B=32 N=1024 step with the planes, 1.257 ms with the split in the kernels.  Round 5 rebuilt the
+# copy with 16-byte pieces -- one load and one ds_write_b128 per eight elements, a third of the staging pass's vector instructions
+# gone (csrc/pointmlp.hip StagerX3W) -- bit-identical again, and per launch at M = 32768 (tools/bench_x3_pc.py, modes 0,p): forward
+# 512 -> 256 57.9 -> 61.3 us, 128 -> 1024 61.3 -> 58.0, 256 -> 512 58.3 -> 57.7, 128 -> 256 20.1 -> 18.8, 128 -> 128 13.3 -> 12.4;
+# fused backward 512 -> 256 117 -> 127, 128 -> 256 41.0 -> 42.9, 64 -> 64 9.3 -> 9.9: the count of vector instructions is not what
+# bounds these kernels.  Off by default.)
 X3_PRESPLIT = os.environ.get('T3D_X3', '1') != '0' and os.environ.get('T3D_X3_PRESPLIT', '0') == '1'
 
 

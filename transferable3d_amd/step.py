@@ -249,17 +249,25 @@ class TrainStep:
             # edges torch records around a collective, so that the replayed graph has the bucket's all-reduce on a branch beside the
             # rest of the backward (no host work and no graph-launch gap between the segments).
             overlap = (self.one_graph_form == '2') if self.one_graph_form else len(self._buckets()) > 1
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=s, capture_error_mode='thread_local'):
-                if overlap:
-                    self._run_program(prog)
-                else:
-                    for kind, x in prog:
-                        if kind == 'run':
-                            x.run()
-                        elif kind == 'allreduce':
-                            self._allreduce(x, async_op=False)
-            return [('run_graph', g)], {0: g}
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=s, capture_error_mode='thread_local'):
+                    if overlap:
+                        self._run_program(prog)
+                    else:
+                        for kind, x in prog:
+                            if kind == 'run':
+                                x.run()
+                            elif kind == 'allreduce':
+                                self._allreduce(x, async_op=False)
+                return [('run_graph', g)], {0: g}
+            except Exception as e:      # a collective this RCCL build cannot capture: the host-issued program still works
+                import sys
+                sys.stderr.write('TrainStep: capturing the data-parallel step into one graph failed (%s: %s); falling back to the '
+                                 'host-issued collectives between graph segments\n' % (type(e).__name__, str(e)[:200]))
+                torch.cuda.synchronize()
+                self.one_graph = False
+                self.one_graph_fallback = repr(e)[:200]
         # Only the FIRST segment (schedules, forward, the backward up to the first bucket: ~1.1 of the step's 1.6 ms) is replayed as
         # a graph; the segments behind a collective are launched kernel by kernel.  A graph launch costs ~30 us on the GPU before
         # its first kernel starts (rocprofv3 timeline of the one-rank RCCL step, tools/dp_timeline.py: 30 + 29 + 39 us at the three
@@ -319,6 +327,8 @@ class TrainStep:
             n_wait = max(1, sum(1 for kind, _ in self.cache[True]['prog'] if kind == 'wait'))
             steps = max(1, len(self._wait_events) // n_wait)
             exposed = sum(a.elapsed_time(b) for a, b in self._wait_events) * 1e3 / steps
+        if getattr(self, 'one_graph_fallback', None):
+            mode += ' (one-graph capture failed: %s)' % self.one_graph_fallback
         return {'mode': mode, 'world': self.world, 'gradient_buckets': len(self._buckets()),
                 'bucket_floats': [sum(n for _, n in b) for b in self._buckets()],
                 'exposed_allreduce_us_per_step': exposed}
