@@ -28,6 +28,7 @@ import torch         # noqa: E402
 
 HBM_PEAK_TBS = 8.0                 # MI355X_MICROARCH.md: HBM3E spec peak (about 6.3 TB/s achievable)
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
+MFMA_BF16_SUSTAINED_TFLOPS = 1860.0      # measured (tools/micro/mfma_rate.hip): 32 cycles per 32x32x16 bf16 MFMA per SIMD at 1.85 GHz under load
 MFMA_BF16_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak (~2.5 PFLOP/s; the 5 PF headline includes 2:1 sparsity)
 SPLIT_GFLOP_PER_FRUSTUM = 3.638   # fwd+bwd, split-conv6 count (the algorithm actually run)
 DENSE_GFLOP_PER_FRUSTUM = 6.856   # as-written dense concat count (reported for reference only)
@@ -582,6 +583,10 @@ def main():
                     'emulated': 'bf16x3' if emulated else None,
                     'emulated_ceiling_tflops': (MFMA_BF16_PEAK_TFLOPS / 6.0) if emulated else None,
                     'frac_of_emulated_ceiling': (achieved / (MFMA_BF16_PEAK_TFLOPS / 6.0)) if emulated else None,
+                    # what the bf16 matrix pipe SUSTAINS on this chip: 32 cycles per v_mfma_f32_32x32x16_bf16 at the 1.85 GHz it holds
+                    # under load = 1.86 PFLOP/s (tools/micro/mfma_rate.hip, docs/EXPERIMENTS.md round 5), six products per multiply-add
+                    'emulated_ceiling_sustained_tflops': (MFMA_BF16_SUSTAINED_TFLOPS / 6.0) if emulated else None,
+                    'frac_of_emulated_ceiling_sustained': (achieved / (MFMA_BF16_SUSTAINED_TFLOPS / 6.0)) if emulated else None,
                     'achieved': achieved if mfma_bound else hbm_achieved,
                     'peak': mfma_peak if mfma_bound else HBM_PEAK_TBS * 1e3,
                     'unit': 'TFLOP/s' if mfma_bound else 'GB/s',

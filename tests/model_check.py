@@ -130,7 +130,7 @@ def tight_grad_check(g, ref_grads, per_tol=1e-3, med_tol=None, glob_tol=1e-4, wh
     B = 4), median 7e-6 ... 1.4e-5, global 8e-6 ... 2.4e-5, with up to 50 ReLU decisions differing from the fp64 run.
     `med_tol` follows the GEMM arithmetic the graph's runtime was built with (MED_TOL): 5e-5 for the fp32-MFMA kernels (an fma
     chain), 1e-4 for the three-term bf16 form.  From profiles/r05_x3_traj_errors.log (tools/x3_traj_errors.py: workloads F, A and
-    boxpc x 4 parameter seeds x 5 steps x both arithmetics = 60 step checks each): the typical step sits at 1e-5 under both; the
+    boxpc x 4 parameter seeds x 5 steps x both arithmetics = 59 / 60 step checks): the typical step sits at 1e-5 under both; the
     worst step medians are 2.6e-5 (fp32 MFMA) and 5.7e-5 (three-term bf16) -- one step each in which a batch sum of eight nearly
     cancelling terms (tnet fc3 biases) carries the error of everything above it.  The per-tensor and global bounds are common."""
     if med_tol is None:

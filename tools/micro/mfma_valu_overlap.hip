@@ -110,6 +110,63 @@ __global__ __launch_bounds__(512) void k_il_agpr(const float* __restrict__ in, f
   out[blockIdx.x * blockDim.x + tid] = s;
   if ((tid & 63) == 0) stamps[blockIdx.x * 8 + tid / 64] = s1 - s0;
 }
+// ... and with the vector work of the x3 staging pass (one pair of split3: cvt_pk, shift, mask, two subtractions per term) instead of
+// independent fmas: six instructions per MFMA, AGPR or VGPR accumulators
+template <int G, bool AGPR>
+__global__ __launch_bounds__(512) void k_il_split(const float* __restrict__ in, float* __restrict__ out, unsigned long long* __restrict__ stamps, int iters) {
+  const int tid = threadIdx.x;
+  bf16x8 a, b;
+  for (int e = 0; e < 8; ++e) { a[e] = (__bf16)in[(tid + e) & 1023]; b[e] = (__bf16)in[(tid * 3 + e) & 1023]; }
+  f32x16 acc0, acc1, acc2, acc3;
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; acc3[r] = 0.f; }
+  float x0 = in[tid & 1023], x1 = in[(tid + 64) & 1023];
+  unsigned sink = 0;
+  __syncthreads();
+  const unsigned long long s0 = __builtin_amdgcn_s_memtime();
+#define T3D_M_(ACC)                                                                                         \
+  do {                                                                                                      \
+    if (AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(a), "v"(b));         \
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(ACC) : "v"(a), "v"(b));              \
+  } while (0)
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if ((g & 3) == 0) T3D_M_(acc0); else if ((g & 3) == 1) T3D_M_(acc1); else if ((g & 3) == 2) T3D_M_(acc2); else T3D_M_(acc3);
+      unsigned hp; float r0, r1, h0, h1;
+      asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hp) : "v"(x0), "v"(x1));
+      asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(h0) : "v"(hp));
+      asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(h1) : "v"(hp));
+      asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r0) : "v"(x0), "v"(h0));
+      asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r1) : "v"(x1), "v"(h1));
+      asm volatile("v_xor_b32 %0, %0, %1" : "+v"(sink) : "v"(hp));
+      x0 = r0 + 1.0f; x1 = r1 + 1.0f;      // (two more: the next pair's inputs)
+    }
+  }
+#undef T3D_M_
+  const unsigned long long s1 = __builtin_amdgcn_s_memtime();
+  float s = x0 + x1 + (float)sink;
+  for (int r = 0; r < 16; ++r) s += acc0[r] + acc1[r] + acc2[r] + acc3[r];
+  out[blockIdx.x * blockDim.x + tid] = s;
+  if ((tid & 63) == 0) stamps[blockIdx.x * 8 + tid / 64] = s1 - s0;
+}
+template <int G, bool AGPR>
+void run_il_split(const float* in, float* out, unsigned long long* st, int iters) {
+  double r[2];
+  for (int t = 0; t < 2; ++t) {
+    const int threads = 256 * (t + 1);
+    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((k_il_split<G, AGPR>), dim3(256), dim3(threads), 0, 0, in, out, st, iters);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h(256 * 8);
+    hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost);
+    std::vector<double> c;
+    for (int b = 0; b < 256; ++b) for (int w = 0; w < threads / 64; ++w) c.push_back((double)h[b * 8 + w] / iters);
+    std::sort(c.begin(), c.end());
+    r[t] = c[c.size() / 2];
+  }
+  printf("%s accumulators, [MFMA, 8 instructions of a split3 pair] x %d: 1 wave/SIMD %6.1f cycles per iteration (matrix pipe alone %d), 2 waves/SIMD %6.1f (matrix pipe alone %d)\n",
+         AGPR ? "AGPR" : "VGPR", G, r[0], G * 32, r[1], 2 * G * 32);
+}
+
 template <int G, int V>
 void run_il_agpr(const float* in, float* out, unsigned long long* st, int iters) {
   double r[2];
@@ -226,6 +283,8 @@ int main() {
          run<G, V, false, true>(512, 0, in, out, st, iters), run<G, V, true, true>(512, 0, in, out, st, iters),                     \
          run<G, V, true, true>(512, 64, in, out, st, iters), run<G, V, true, true>(512, 150, in, out, st, iters),                   \
          run<G, V, true, true>(512, 1000, in, out, st, iters), G * 32)
+  run_il_split<4, true>(in, out, st, iters);
+  run_il_split<4, false>(in, out, st, iters);
   run_il_agpr<4, 0>(in, out, st, iters);
   run_il_agpr<4, 8>(in, out, st, iters);
   run_il_agpr<4, 16>(in, out, st, iters);

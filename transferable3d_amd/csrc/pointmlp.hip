@@ -4892,11 +4892,20 @@ extern "C" int t3d_pool_bwd_stage2_hosts_riders(const t3d_pool_wgrad_finish_args
 }
 
 #ifdef T3D_TRACE
-// diagnostic builds only (not part of include/t3d.h): install / remove the per-workgroup trace buffer
+// diagnostic builds only (not part of include/t3d.h): install / remove the per-workgroup trace buffer (each translation unit has its
+// own copy of the pointer: the x3 kernels read the one of csrc/pointmlp_x3.hip)
+int t3d_x3_set_trace(void* buf);
 extern "C" int t3d_set_trace(void* buf) {
   unsigned long long* p = static_cast<unsigned long long*>(buf);
+  if (t3d_x3_set_trace(buf) != T3D_OK) return T3D_ERR_LAUNCH;
   return hipMemcpyToSymbol(HIP_SYMBOL(t3d_trace_ptr), &p, sizeof(p)) == hipSuccess ? T3D_OK : T3D_ERR_LAUNCH;
 }
 #endif
 
 #endif  // !T3D_X3_TU
+#if defined(T3D_X3_TU) && defined(T3D_TRACE)
+int t3d_x3_set_trace(void* buf) {
+  unsigned long long* p = static_cast<unsigned long long*>(buf);
+  return hipMemcpyToSymbol(HIP_SYMBOL(t3d_trace_ptr), &p, sizeof(p)) == hipSuccess ? T3D_OK : T3D_ERR_LAUNCH;
+}
+#endif
