@@ -496,6 +496,12 @@ def main():
     torch.cuda.synchronize()
     use_graph = trainstep.want_graph
     step = trainstep.run
+    # multi-rank: the capture of the step (with its collective inside on RCCL), the warm-up and the timed region run under a watchdog
+    # too -- a replica that never arrives must end every rank with a message, not hang the node until the driver's limit
+    run_guard = Watchdog(int(os.environ.get('T3D_RUN_TIMEOUT_S', '300')), 'the capture / warm-up / timed steps of the %d ranks' % world) \
+        if dist is not None else None
+    if run_guard is not None:
+        run_guard.__enter__()
     step()                     # eager: loads the code objects, sets the communicator up (outside any capture)
     step()                     # captures the hipGraph segment(s) and replays
     torch.cuda.synchronize()
@@ -530,6 +536,8 @@ def main():
         t = torch.tensor([elapsed, median_step], device='cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, median_step = float(t[0].item()), float(t[1].item())
+    if run_guard is not None:
+        run_guard.__exit__(None, None, None)
     if trainstep.dist:          # five more steps (every rank) with events around the bucket waits: the exposed all-reduce time
         trainstep.time_waits = True
         for _ in range(5):
