@@ -142,3 +142,31 @@ def test_stage_c_with_reprojection_and_inactive_volume_matches_oracle():
         c0 = stage_c_config()
         l0 = R.stage_c_forward_backward(P, batch, c0, [i in (1, 2, 6, 7, 8) for i in range(10)], want_grads=False)[0]
         assert abs(float(m.loss) - float(l0)) > 1e-3 * float(l0)      # the weak terms are in the loss
+
+
+def test_weak_losses_evaluated_for_their_summaries_at_zero_weight():
+    """The reference evaluates the reprojection / surface losses for its `Weak_Loss/...` summaries whatever their weights
+    (semisup_v1_sunrgbd.py:270-293); recipe a zeroes both weights.  With `c.WEAK_LOSS_SUMMARIES` (the drivers set it) the product
+    evaluates them too: the values are the oracle's, the loss and EVERY gradient are bit for bit those of the graph without them,
+    and no backward launch is added."""
+    rt = Runtime(lib=FakeLib(), device='cpu')
+    batch = weak_case(seed=6)
+    P = R.init_params(np.random.RandomState(5), R.layer_table(4, 'A'))
+    c0 = R.default_config(WEAK_WEIGHT_REPROJECTION=0.0, WEAK_WEIGHT_SURFACE=0.0)
+    c1 = R.default_config(WEAK_WEIGHT_REPROJECTION=0.0, WEAK_WEIGHT_SURFACE=0.0)
+    c1.WEAK_LOSS_SUMMARIES = True
+    g0, m0 = run_model_a(rt, batch, P, c0)
+    g1, m1 = run_model_a(rt, batch, P, c1)
+    assert m0.weak is None and m1.weak is not None
+    assert [n for n, _, _ in g1.fwd.calls].count('t3d_weak_loss') == 1 and len(g1.fwd) == len(g0.fwd) + 1
+    assert [n for n, _, _ in g1.bwd.calls] == [n for n, _, _ in g0.bwd.calls]            # nothing added to the backward
+    assert float(m1.loss_op.loss) == float(m0.loss_op.loss)
+    assert torch.equal(g1.vars.grads[:g1.vars.used], g0.vars.grads[:g0.vars.used])
+    # the values: the oracle's losses for non-zero weights do not depend on the weights
+    cw = R.default_config(WEAK_WEIGHT_REPROJECTION=0.01, WEAK_WEIGHT_SURFACE=1.0)
+    _, ep, _, _ = R.model_a_forward_backward(P, batch, cw)
+    e = m1.end_points()
+    for k in ('reprojection_loss', 'surface_loss'):
+        r = ep[k].detach().numpy()
+        assert np.abs(e[k].detach().cpu().numpy() - r).max() < 2e-4 * max(1.0, np.abs(r).max()), k
+        assert np.abs(r).max() > 0

@@ -530,6 +530,13 @@ class WeakLoss:
         return getattr(c, 'WEAK_WEIGHT_REPROJECTION', 0) != 0 or getattr(c, 'WEAK_WEIGHT_SURFACE', 0) != 0
 
     @staticmethod
+    def wanted(c):
+        """Evaluate the two losses of get_semi_loss_backbone: when a weight is non-zero, or -- as the reference always does for its
+        `Weak_Loss/...` summaries (semisup_v1_sunrgbd.py:270-293) -- when `c.WEAK_LOSS_SUMMARIES` asks for their values at zero weight
+        (the drivers do; the kernel then adds exactly 0 to the loss and writes zero gradients, and no backward launch is emitted)."""
+        return WeakLoss.active(c) or bool(getattr(c, 'WEAK_LOSS_SUMMARIES', False))
+
+    @staticmethod
     def active_final(c):
         return getattr(c, 'WEAK_WEIGHT_REPROJECTION', 0) != 0 or getattr(c, 'WEAK_WEIGHT_INACTIVE_VOLUME', 0) != 0
 
@@ -682,14 +689,15 @@ class ModelAssembly:
         if with_loss:
             lab = (x.y_center, x.y_orient_cls, x.y_orient_reg, x.y_dims_cls, x.y_dims_reg, x.is_data_2D)
             self.loss_op.emit(plan, box, s1, self.seg.seg_loss, lab, c)
-            if WeakLoss.active(c):       # reprojection / surface losses with non-zero weight (the reference's DEFAULT flags)
+            if WeakLoss.wanted(c):       # reprojection / surface losses with non-zero weight (the reference's DEFAULT flags), or for their summaries
                 if self.weak is None:
                     self.weak = WeakLoss(g)
                 self.weak.emit(plan, self.loss_op, self.seg, x, c)
+                self.weak_trains = WeakLoss.active(c)
 
     def emit_backward(self, plan):
         from .engine import FC_SIDE
-        if self.weak is not None:        # weak-loss gradients join dbox / dstage1 and conv9's gradient before anything reads them
+        if self.weak is not None and getattr(self, 'weak_trains', True):        # weak-loss gradients join dbox / dstage1 and conv9's gradient before anything reads them
             self.weak.emit_backward(plan, self.loss_op, self.seg, self.box.box_params)
         if FC_SIDE and self.seg.train_seg:
             plan.two_streams = True
@@ -729,7 +737,7 @@ class ModelAssembly:
         g.declare_bucket(plan, [self.tnet.scope + '/', self.box.scope + '/'])
         # single replica, no weak-loss gradient into the seg net: the seg backward is independent of everything since `T_begin`
         # (semisup_models.py:150-151) -- the step scheduler interleaves the two chains (schedule.py); T3D_OVERLAP=0: the pairing below
-        overlap = OVERLAP and not g.dp_buckets and self.seg.train_seg and self.weak is None
+        overlap = OVERLAP and not g.dp_buckets and self.seg.train_seg and (self.weak is None or not getattr(self, 'weak_trains', True))
         if overlap and getattr(g, 'split_opt', False):
             g.emit_reduce_slabs(plan)      # software-pipelined step (step.PipelinedStep): the T chain ends with ITS slab reduction + Adam
         if overlap:

@@ -239,7 +239,7 @@ def get_semi_loss_backbone(pred, labels, end_points, reduce_loss=True, c=None):
     end_points['iou2ds'] = T(asm.loss_op.iou2d, (B,), 'iou2ds')          # get_iou_summary (semisup_v1_sunrgbd.py:236-246,316)
     end_points['iou3ds'] = T(asm.loss_op.iou3d, (B,), 'iou3ds')
     from .nets import WeakLoss
-    if WeakLoss.active(c) and asm.weak is None:
+    if WeakLoss.wanted(c) and asm.weak is None:      # non-zero weight, or evaluated for the `Weak_Loss/...` summaries (c.WEAK_LOSS_SUMMARIES)
         asm.weak = WeakLoss(ctx.engine)
     if asm.weak is not None:
         end_points['reproj_loss'] = T(asm.weak.reproj, (B,), 'reproj_loss')          # weak_losses.py:226

@@ -66,7 +66,11 @@ def build_flags(argv=None):
     cfg.add_argument('--eval_file', default=None, help='held-out frustum file of the reference for eval_one_epoch (with --frustum_file / --device_data)')
     cfg.add_argument('--frustum_file', default=None, help='train from a frustum file of the reference (frustums/*.zip.pickle) held in HBM')
     cfg.add_argument('--eval_batches', type=int, default=0, help='held-out synthetic batches evaluated after every epoch (eval_one_epoch)')
+    cfg.add_argument('--no_weak_loss_summaries', action='store_true',
+                     help='do not evaluate the weak reprojection / surface losses when both of their weights are 0 (the reference always '
+                          'evaluates them for its Weak_Loss/... summaries, semisup_v1_sunrgbd.py:270-293; one small launch per step)')
     FLAGS = cfg.parse_special_args(argv)
+    FLAGS.WEAK_LOSS_SUMMARIES = not FLAGS.no_weak_loss_summaries
     FLAGS.NUM_CHANNELS = FLAGS.num_channels if FLAGS.num_channels else (3 if FLAGS.no_rgb else 6)
     return FLAGS
 
@@ -200,13 +204,18 @@ def train(FLAGS, rt=None, log=print):
             loss_sum, correct = 0.0, 0.0
             iou2_sum = iou3_sum = 0.0                 # 'Strong Box IoU (ground/3D)' of train_semisup.py:414-431
             iou2ds, iou3ds = end_points['iou2ds'], end_points['iou3ds']
+            # tf.summary.scalar('Weak_Loss/reprojection_loss' | 'Weak_Loss/surface_loss') of get_semi_loss_backbone: batch means, logged
+            # per epoch (evaluated at zero weight too: --no_weak_loss_summaries)
+            weak_t = [end_points[k] for k in ('reproj_loss', 'surface_loss') if k in end_points]
+            weak_sum, weak_n = np.zeros(len(weak_t)), 0
             if ds is not None:
                 # device pipeline: nothing is fed; the loss is fetched (a D2H sync) every 10th step only
                 ds.shuffle(FLAGS.seed * 1000003 + epoch)      # train_semisup.py:343 (the same permutation on every replica)
                 n_logged = 0
                 for it in range(FLAGS.steps_per_epoch):
                     if it % 10 == 9 or it == FLAGS.steps_per_epoch - 1:
-                        loss_val, nc, i2, i3, _ = sess.run([semi_loss, n_correct, iou2ds, iou3ds, train_op])
+                        loss_val, nc, i2, i3, _, *wk = sess.run([semi_loss, n_correct, iou2ds, iou3ds, train_op] + weak_t)
+                        weak_sum, weak_n = weak_sum + np.array([float(np.mean(v)) for v in wk]), weak_n + 1
                         loss_sum += float(loss_val)
                         correct += float(nc[0])
                         iou2_sum, iou3_sum = iou2_sum + float(np.sum(i2)), iou3_sum + float(np.sum(i3))
@@ -229,7 +238,8 @@ def train(FLAGS, rt=None, log=print):
                         Rtilt_pl: batch['Rtilt'], K_pl: batch['K'], rot_frust_pl: batch['rot_frust'], box2D_pl: batch['box2D'],
                         img_dim_pl: batch['img_dim']}
                 feed[is_training_pl] = True
-                loss_val, nc, i2, i3, _ = sess.run([semi_loss, n_correct, iou2ds, iou3ds, train_op], feed_dict=feed)
+                loss_val, nc, i2, i3, _, *wk = sess.run([semi_loss, n_correct, iou2ds, iou3ds, train_op] + weak_t, feed_dict=feed)
+                weak_sum, weak_n = weak_sum + np.array([float(np.mean(v)) for v in wk]), weak_n + 1
                 loss_sum += float(loss_val)
                 correct += float(nc[0])
                 iou2_sum, iou3_sum = iou2_sum + float(np.sum(i2)), iou3_sum + float(np.sum(i3))
@@ -239,6 +249,9 @@ def train(FLAGS, rt=None, log=print):
                     epoch, loss_sum / FLAGS.steps_per_epoch, correct / (FLAGS.steps_per_epoch * B * N),
                     FLAGS.steps_per_epoch * B * world / (time.time() - t0)))
                 log('Strong Box IoU (ground/3D): %f / %f' % (iou2_sum / (FLAGS.steps_per_epoch * B), iou3_sum / (FLAGS.steps_per_epoch * B)))
+            if rank == 0 and weak_n and len(weak_t) == 2:
+                log('Weak_Loss/reprojection_loss: %f  Weak_Loss/surface_loss: %f  (weights %g / %g)' % (
+                    weak_sum[0] / weak_n, weak_sum[1] / weak_n, FLAGS.WEAK_WEIGHT_REPROJECTION, FLAGS.WEAK_WEIGHT_SURFACE))
             if rank == 0 and (FLAGS.eval_batches > 0 or FLAGS.eval_file):
                 if ds is not None and eval_source is None:
                     from transferable3d_amd.dataset import open_eval_source
