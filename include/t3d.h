@@ -59,7 +59,12 @@ enum { T3D_F32 = 0, T3D_BF16 = 1 };
  *   T3D_ARITH_FP32_MFMA  v_mfma_f32_32x32x2_f32: the fp32 fma chain, 157 TFLOP/s peak
  *   T3D_ARITH_BF16X3     every fp32 operand as the exact sum of three bf16 terms, six v_mfma_f32_32x32x16_bf16 per multiply-add with
  *                        fp32 accumulation (csrc/pointmlp.hip, "fp32 GEMMs on the bf16 matrix pipe"); a launch whose shape has no such
- *                        kernel, or for which the launcher's rule prefers the fp32 MFMA (t3d_gemm_arithmetic says which), takes that
+ *                        kernel, or for which the launcher's rule prefers the fp32 MFMA (t3d_gemm_arithmetic says which), takes that.
+ *                        Two differences from the fp32 MFMA a caller should know: an operand of magnitude >= 3.39e38 (above bf16's
+ *                        largest finite value; fp32 itself reaches 3.40e38) has an infinite leading term and yields inf / NaN where
+ *                        the fma chain would still be finite; and the bf16 MFMA's accumulation is not rounded to nearest -- results
+ *                        lie a little below the exact sum (about -3e-7 of the mean |dW| on a 32768-row weight gradient, bounded in
+ *                        tests/test_kernels_gpu.py), where the fma chain shows no offset
  *   T3D_ARITH_AUTO       (0, a zero-initialised struct) the library's default = T3D_ARITH_BF16X3; the only value for which the
  *                        experiment variables T3D_X3 / T3D_X3_MINKN of the tools are consulted
  * A host fixes the value when it builds its plan (transferable3d_amd.engine.Runtime.gemm_arithmetic), so a captured graph, an eager
