@@ -153,6 +153,9 @@ def gemm_work(name, a):
         if a.dtype == 1 and a.a.dtype == 1 and _null(a.a.sub) and (a.K in (64, 128) or (a.K == 256 and os.environ.get('T3D_FWD_RES', '1') == '2')) and os.environ.get('T3D_FWD_RES', '1') != '0':
             return 'k_pointmlp_fwd_res<%d,%d>' % (128 if a.N % 128 == 0 else 64, a.K // 64), flops, by      # activation-resident bf16 forward
         if a.dtype == 0 and a.a.dtype == 0 and _null(a.a.sub) and a.K % 16 == 0 and x3f(a, a.K, a.N):
+            w8 = int(os.environ.get('T3D_X3_W8', '1'))      # eight-wave 128 x 256 tiles (csrc/pointmlp.hip t3d_x3_fwd)
+            if w8 and _null(a.w_x3) and a.N % 256 == 0 and (w8 == 2 or (a.M // 128) * (a.N // 256) >= 512):
+                return 'k_pointmlp_fwd_w8_x3<256>', flops, by
             return 'k_pointmlp_fwd_x3<%d>' % (128 if a.N % 128 == 0 and (a.M // 128) * (a.N // 128) >= 512 else 64), flops, by
         if a.dtype == 0 and os.environ.get('T3D_FWD_POOL', '1') != '0' and _null(a.y) and not _null(a.pmax) and _null(a.a.sub) and a.K == 128 and \
                 a.N % 128 == 0 and a.N >= 256:
@@ -249,7 +252,7 @@ def profile_kernels(plans, steps, repeat=4):
             label, flops, nbytes = (gemm_work(base, arg) if base.startswith(('t3d_pointmlp', 't3d_pool_bwd_stage')) and
                                     base != 't3d_pointmlp_dgrad_narrow' else (name, 0.0, 0.0))
             if base != name and '<' in label and label.split('<')[0] in ('k_pointmlp_fwd', 'k_pointmlp_bwd', 'k_pointmlp_wgrad',
-                                                                        'k_pool_bwd_stage1', 'k_pool_bwd_stage2', 'k_pointmlp_fwd_x3',
+                                                                        'k_pool_bwd_stage1', 'k_pool_bwd_stage2', 'k_pointmlp_fwd_x3', 'k_pointmlp_fwd_w8_x3',
                                                                         'k_pointmlp_bwd_x3', 'k_pool_bwd_stage1_x3', 'k_pool_bwd_stage2_x3'):
                 label = label.replace('<', '_r<', 1)
             d = acc.setdefault(label, [0.0, 0, 0.0, 0.0, 0.0])

@@ -1589,11 +1589,12 @@ def test_x3_weight_gradient_rounding_bias_is_bounded(hip_lib, sign):
     assert mean_one < 0 and abs(mean_one) > 2.0 * abs(mean_x3) and abs(mean_one) <= 0.75 * rms_one, (mean_one, mean_x3, rms_one)
 
 
-@pytest.mark.parametrize('K,N', [(128, 256), (64, 64)])
+@pytest.mark.parametrize('K,N', [(128, 256), (64, 64), (96, 512)])
 def test_x3_forward_variants_are_bit_identical_to_the_default(hip_lib, monkeypatch, K, N):
     """Two opt-in forms of the x3 forward kernel reproduce the default bit for bit -- every output, statistics and pool partials
     included: the weights pre-split into three bf16 planes (t3d_split_x3 + w_x3, 16-byte copies instead of the in-kernel split) and
-    the producer / consumer workgroups of round 5's experiment (T3D_X3_PC=1: eight waves, three LDS stages)."""
+    the producer / consumer workgroups of round 5's experiment (T3D_X3_PC=1: eight waves, three LDS stages), and the eight-wave
+    128 x 256 tiles that launches of two or more rounds take by default (T3D_X3_W8; forced here at a small M, N % 256 == 0 only)."""
     dev = 'cuda'
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     torch.manual_seed(7)
@@ -1607,8 +1608,10 @@ def test_x3_forward_variants_are_bit_identical_to_the_default(hip_lib, monkeypat
     assert hip_lib.t3d_split_x3(fptr(w), C.c_void_p(planes.data_ptr()), K * N, K * N, st) == 0
     assert torch.equal(planes.float().sum(0), w), 'h + m + l == w exactly'
     res = {}
-    for mode in ('default', 'presplit', 'producer_consumer'):
+    modes = ('default', 'presplit', 'producer_consumer') + (('eight_waves',) if N % 256 == 0 else ())
+    for mode in modes:
         monkeypatch.setenv('T3D_X3_PC', '2' if mode == 'producer_consumer' else '0')
+        monkeypatch.setenv('T3D_X3_W8', '2' if mode == 'eight_waves' else '0')
         o = [torch.zeros(M, N, device=dev)] + [torch.zeros(T, N, device=dev) for _ in range(4)] + \
             [torch.zeros(T, N, dtype=torch.int32, device=dev) for _ in range(2)]
         a = abi.PointMlpFwdArgs()
@@ -1621,8 +1624,9 @@ def test_x3_forward_variants_are_bit_identical_to_the_default(hip_lib, monkeypat
         assert hip_lib.t3d_pointmlp_fwd(C.byref(a), st) == 0
         torch.cuda.synchronize()
         res[mode] = o
-    for mode in ('presplit', 'producer_consumer'):
+    for mode in modes[1:]:
         for u, v in zip(res['default'], res[mode]):
             assert torch.equal(u, v), mode
     ref = torch.relu(x.double() * sc.double() + sh.double()) @ w.double() + bias.double()
     assert float((res['default'][0].double() - ref).abs().max() / ref.abs().max()) < 2e-6
+

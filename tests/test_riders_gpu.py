@@ -102,11 +102,14 @@ def _fc_chain(dev, B, dims, seed):
     return ops, outs, keep
 
 
-def test_rider_set_with_barriers_equals_the_separate_launches_under_load(hip_lib):
+@pytest.mark.parametrize('host', ['four_waves', 'eight_waves'])
+def test_rider_set_with_barriers_equals_the_separate_launches_under_load(hip_lib, host):
     """FC chain 256 -> 512 -> 512 -> 256 -> 64 (every op reads what the previous one wrote, through another workgroup's stores): as ONE
     rider set -- alone (t3d_run_riders) and inside a forward GEMM launch that fills the chip -- 40 times each, against the four
     stand-alone launches.  Outputs and moving statistics bit for bit; the consumer workgroups' L1 holds the previous repetition's
-    lines when the next one starts (the stale-read case of cdna_hip_programming.md Guideline 16)."""
+    lines when the next one starts (the stale-read case of cdna_hip_programming.md Guideline 16).
+    host 'eight_waves': the 128 x 256-tile x3 forward kernel (512-thread workgroups; k_pointmlp_fwd_w8_r runs the riders on the first
+    four waves of theirs, the other four leave before the first barrier)."""
     from transferable3d_amd import schedule
     from transferable3d_amd.engine import Runtime
     dev = torch.device('cuda')
@@ -127,7 +130,7 @@ def test_rider_set_with_barriers_equals_the_separate_launches_under_load(hip_lib
         return [tuple(t.clone() for t in o) for o in outs]
 
     # a host GEMM: 32768 x 128 x 128 forward (512 workgroups: exactly the chip's resident slots)
-    M, K, N = 32768, 128, 128
+    M, K, N = (32768, 128, 128) if host == 'four_waves' else (32768, 128, 512)
     r = np.random.RandomState(5)
     t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
     xg, wg = t(r.randn(M, K)), t(r.randn(K, N) / 11.0)
@@ -135,6 +138,9 @@ def test_rider_set_with_barriers_equals_the_separate_launches_under_load(hip_lib
     fa = abi.PointMlpFwdArgs()
     fa.a = abi.ActSrc(fptr(xg), K, 0, None, None, 0, None, 0, abi.F32)
     fa.w, fa.y, fa.psum, fa.psumsq, fa.M, fa.K, fa.N, fa.rows_per_frustum, fa.dtype = fptr(wg), fptr(yg), fptr(ps), fptr(pq), M, K, N, 1024, abi.F32
+    if host == 'eight_waves':
+        fa.arith = abi.ARITH_BF16X3
+        assert hip_lib.t3d_gemm_arithmetic(fa.arith, abi.F32, K, N, 0) == abi.ARITH_BF16X3
     abi.check(hip_lib.t3d_pointmlp_fwd(C.byref(fa), s), 'fwd')
     torch.cuda.synchronize()
     y_ref = yg.clone()

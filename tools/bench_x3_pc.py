@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Variants of the x3 GEMM kernels against the default form: bit-identity of every output and time per launch on the layer shapes of
 the hot path (M = 32768).  T3D_PC_MODES: comma list of 0 (default), 1 / 2 (producer / consumer waves, T3D_X3_PC), p (the weights
-pre-split into three bf16 planes, t3d_split_x3 + w_x3).  T3D_LIB: alternative library; T3D_ONLY=fwd:512x256 one case."""
+pre-split into three bf16 planes, t3d_split_x3 + w_x3), w (eight-wave 128 x 256 forward tiles, T3D_X3_W8=2).  T3D_LIB: alternative library; T3D_ONLY=fwd:512x256 one case."""
 import ctypes as C
 import os
 import sys
@@ -60,7 +60,8 @@ def main():
         planes = torch.zeros(3, K, N, dtype=torch.bfloat16, device=dev)
         assert lib.t3d_split_x3(fptr(w), C.c_void_p(planes.data_ptr()), K * N, K * N, s) == 0
         for mode in MODES:
-            os.environ['T3D_X3_PC'] = mode if mode != 'p' else '0'
+            os.environ['T3D_X3_PC'] = mode if mode in '012' else '0'
+            os.environ['T3D_X3_W8'] = '2' if mode == 'w' else '0'
             a.w_x3, a.w_x3_stride = (C.c_void_p(planes.data_ptr()), K * N) if mode == 'p' else (None, 0)
             for t_ in [y, p1, p2] + pm:
                 t_.zero_()
@@ -100,7 +101,7 @@ def main():
         planes = torch.zeros(3, K, N, dtype=torch.bfloat16, device=dev)
         assert lib.t3d_split_x3(fptr(w), C.c_void_p(planes.data_ptr()), K * N, K * N, s) == 0
         for mode in MODES:
-            os.environ['T3D_X3_PC'] = mode if mode != 'p' else '0'
+            os.environ['T3D_X3_PC'] = mode if mode in '012' else '0'
             d.w_x3, d.w_x3_stride = (C.c_void_p(planes.data_ptr()), K * N) if mode == 'p' else (None, 0)
             for t_ in (out, slabs, p1, p2):
                 t_.zero_()
@@ -114,6 +115,7 @@ def main():
         print('bwd %4d -> %4d (one_pass %d) ' % (K, N, one.value) +
               '  '.join('pc=%s %7.1f us (%5.1f TF/s)' % (m, us[m], fl / us[m] / 1e6) for m in MODES) + '   identical: %s' % same, flush=True)
     os.environ.pop('T3D_X3_PC', None)
+    os.environ.pop('T3D_X3_W8', None)
     os.environ.pop('T3D_X3', None)
 
 

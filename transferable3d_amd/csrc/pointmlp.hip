@@ -875,6 +875,9 @@ constexpr int BKX = 16;             // reduction depth of an LDS stage = ONE ste
 // (tools/agpr_ab.sh, same box).  hipcc does interleave the staging pass between the MFMAs in the AGPR build (one MFMA : ~7 vector
 // instructions); what the waves wait for there is their fragment reads (s_waitcnt lgkmcnt in front of every other MFMA), not the
 // vector ports.
+#ifndef T3D_X3_W8_DEFAULT
+#define T3D_X3_W8_DEFAULT 1         // eight-wave 128 x 256 forward tiles (PathX3W): the default of T3D_X3_W8
+#endif
 #ifndef T3D_X3_AGPR
 #define T3D_X3_AGPR 0
 #endif
@@ -986,10 +989,10 @@ template <class L> struct PreSplit<L, typename std::enable_if<L::PRESPLIT>::type
 #ifndef T3D_X3_SGB
 #define T3D_X3_SGB 0                // > 0: sched_group_barrier pipeline, that many VALU instructions behind each MFMA (see x3_iter)
 #endif
-template <int DIM, bool TYPE_R, class L, int PF_ = T3D_X3_PF>
+template <int DIM, bool TYPE_R, class L, int PF_ = T3D_X3_PF, int NTX = NT>      // NTX: threads that stage the tile (512: the eight-wave tiles)
 struct StagerX3 {
   static constexpr int PF = PF_;
-  static constexpr int NV = DIM * (BKX / 4) / NT;
+  static constexpr int NV = DIM * (BKX / 4) / NTX;
   static constexpr int LDC = DIM + LDCX_PAD;
   static constexpr int PLANE = TYPE_R ? DIM * LDRX : BKX * LDC;      // bf16 elements of one plane
   static constexpr int LDS_ELEMS = 3 * PLANE;
@@ -999,7 +1002,7 @@ struct StagerX3 {
   int lane0, red0[PF];
 
   __device__ __forceinline__ static void coords(int tid, int q, int& lane_i, int& red_i) {
-    const int f = tid + NT * q;
+    const int f = tid + NTX * q;
     if (TYPE_R) { constexpr int CH = BKX / 4; lane_i = f / CH; red_i = (f % CH) * 4; }
     else { constexpr int C4 = DIM / 4; red_i = f / C4; lane_i = (f % C4) * 4; }
   }
@@ -1590,6 +1593,16 @@ struct PathX3P : PathX3 {      // ... with the layer's weight matrix split befor
   template <int DIM, bool TYPE_R, class L, int PF, bool IS_A = false>
   using Stg = std::conditional_t<PreSplit<L>::value, StagerX3W<DIM, TYPE_R, L>, StagerX3<DIM, TYPE_R, L>>;
 };
+// ... with EIGHT waves per workgroup (2 x 4 waves of 64 x 64: a 128 x 256 output tile).  The staged A tile serves twice the columns: a
+// quarter fewer staged elements -- loads, batch-norm / ReLU, three-way splits, LDS stores -- per MFMA than two 128 x 128 workgroups, which
+// is what the additive model of these kernels (docs/EXPERIMENTS.md, round 5) says their time depends on.  92 KB of LDS: one workgroup per
+// CU, the same eight waves per CU as two four-wave workgroups.
+struct PathX3W : PathX3 {
+  static constexpr int WAVES = 8;
+  template <int DIM, bool TYPE_R, class L, int PF, bool IS_A = false> using Stg = StagerX3<DIM, TYPE_R, L, T3D_X3_PF, 2 * NT>;
+};
+template <class PR, class = void> struct WavesOf { static constexpr int value = 4; };
+template <class PR> struct WavesOf<PR, typename std::enable_if<(PR::WAVES > 0)>::type> { static constexpr int value = PR::WAVES; };
 // ... in 512-thread workgroups with producer and consumer waves (gemm_mainloop_x3_pc): three register slots per operand
 struct PathX3PC : PathX3 {
   static constexpr bool PC = true;
@@ -1610,7 +1623,9 @@ __device__ __forceinline__ void run_mainloop(SA& sa, SB& sb, const LA& la, const
 // PR: arithmetic + element type of y (PathF32 / PathBF16); XT: element type of the input tensor (fp32 for the raw inputs)
 template <int BN, bool HAS_SUB, class PR = PathF32, class XT = float>
 __device__ __forceinline__ void fwd_body(const t3d_pointmlp_fwd_args& p, float* smem, const int bid, const int nblk) {
-  constexpr int BM = 128, TM = 2, TN = BN / 64;
+  constexpr int BM = 128, TM = 2;
+  constexpr int WN = WavesOf<PR>::value / 2, WCOLS = BN / WN, TN = WCOLS / 32;      // wave grid 2 x WN, a wave owns 64 x WCOLS
+  static_assert(TN == 1 || TN == 2, "a wave owns 32 or 64 columns");
   using LA = typename PR::template Act<HAS_SUB, XT>;
   using YT = typename PR::T;
   constexpr int PF = BN == 64 ? T3D_PF_NARROW : T3D_PF_WIDE;
@@ -1621,7 +1636,7 @@ __device__ __forceinline__ void fwd_body(const t3d_pointmlp_fwd_args& p, float* 
 
   // (producer / consumer workgroups: the second 256 threads are the staging waves of the same tile coordinates; they end in the main loop)
   const int tid = PR::PC ? (int)(threadIdx.x & (NT - 1)) : (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1;
+  const int wm = wid / WN, wn = wid % WN;
   const int tiles_n = p.N / BN;
   const int lin = xcd_remap(bid, nblk);
   const int tile_m = lin / tiles_n, tile_n = lin % tiles_n;
@@ -1642,7 +1657,7 @@ __device__ __forceinline__ void fwd_body(const t3d_pointmlp_fwd_args& p, float* 
     const int l31_ = lane & 31, b_ = row0 / p.rows_per_frustum;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
-      const int col = col0 + wn * (BN / 2) + tn * 32 + l31_;
+      const int col = col0 + wn * WCOLS + tn * 32 + l31_;
       addv[tn] = p.bias ? p.bias[col] : 0.f;
       addr[tn] = p.rowbias ? p.rowbias[(size_t)b_ * p.N + col] : 0.f;
     }
@@ -1652,7 +1667,7 @@ __device__ __forceinline__ void fwd_body(const t3d_pointmlp_fwd_args& p, float* 
   zero_acc<TM, TN>(acc);
   const int kred = (p.K + PR::RED - 1) / PR::RED * PR::RED;
   run_mainloop<PR, TM, TN, SA, SB, LA, WL, true, BM, false, BN>(sa, sb, la, lb, smem, 0, kred, wm * 64,
-                                                                     wn * (BN / 2), acc, tid);
+                                                                     wn * WCOLS, acc, tid);
   T3D_TRACE_MARK(1);
 
 #ifdef T3D_ABL_NOEPI
@@ -1695,7 +1710,7 @@ __device__ __forceinline__ void fwd_body(const t3d_pointmlp_fwd_args& p, float* 
     constexpr bool SY = decltype(sy_tag)::value, PL = decltype(pl_tag)::value;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
-      const int col = col0 + wn * (BN / 2) + tn * 32 + l31;
+      const int col = col0 + wn * WCOLS + tn * 32 + l31;
       const float add = has_rowbias ? addv[tn] + addr[tn] : addv[tn];
       float s = 0.f, ss = 0.f, mx = -INFINITY, mn = INFINITY;
       int ax = -1, an = -1;
@@ -1713,7 +1728,7 @@ __device__ __forceinline__ void fwd_body(const t3d_pointmlp_fwd_args& p, float* 
             if constexpr (Elem<YT>::BF16) {
               // bf16: the tile goes through LDS (the stages are free now) and leaves as 16-byte row-contiguous stores below -- 64
               // two-byte global stores per thread were half of a workgroup's lifetime on the narrow layers (tools/trace_blocks.py)
-              ytile[(wm * 64 + 4 * h + tm * 32 + (r & 3) + 8 * (r >> 2)) * YLD + wn * (BN / 2) + tn * 32 + l31] = (bf16_t)v;
+              ytile[(wm * 64 + 4 * h + tm * 32 + (r & 3) + 8 * (r >> 2)) * YLD + wn * WCOLS + tn * 32 + l31] = (bf16_t)v;
             } else {
               *reinterpret_cast<float*>(yb + (boff0 + (unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) * n4)) = v;
             }
@@ -1749,7 +1764,7 @@ __device__ __forceinline__ void fwd_body(const t3d_pointmlp_fwd_args& p, float* 
   if (h == 0) {
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
-      const int c = wn * (BN / 2) + tn * 32 + l31;
+      const int c = wn * WCOLS + tn * 32 + l31;
       red[(0 * 2 + wm) * BN + c] = csum[tn];
       red[(1 * 2 + wm) * BN + c] = csq[tn];
       if (pool) {
@@ -1799,6 +1814,22 @@ template <int BN, bool HAS_SUB, class PR = PathF32, class XT = float>
 __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd(const t3d_pointmlp_fwd_args p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   fwd_body<BN, HAS_SUB, PR, XT>(p, smem, blockIdx.x, gridDim.x);
+}
+
+template <int BN, class PR>      // eight waves, 128 x 256 tile (PathX3W)
+__global__ __launch_bounds__(2 * NT) void k_pointmlp_fwd_w8(const t3d_pointmlp_fwd_args p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  fwd_body<BN, false, PR, float>(p, smem, blockIdx.x, gridDim.x);
+}
+template <int BN, class PR>      // ... hosting riders: the rider workgroups run on their first four waves (the bodies are 256-thread programs)
+__global__ __launch_bounds__(2 * NT) void k_pointmlp_fwd_w8_r(const t3d_pointmlp_fwd_args p, const t3d_rider_set r) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((int)blockIdx.x < r.n_wg) {
+    if (threadIdx.x >= NT) return;      // (s_barrier counts the surviving waves)
+    run_riders(r, smem);
+    return;
+  }
+  fwd_body<BN, false, PR, float>(p, smem, blockIdx.x - r.n_wg, gridDim.x - r.n_wg);
 }
 
 template <int BN, class PR>      // producer / consumer form (gemm_mainloop_x3_pc): eight waves, one workgroup per CU
@@ -4047,6 +4078,25 @@ int t3d_x3_fwd(const t3d_pointmlp_fwd_args* a, const t3d_rider_set* r, hipStream
   const bool pre = a->w_x3 != nullptr;      // the weights arrive as three bf16 planes (t3d_split_x3)
   const char* e = getenv("T3D_X3_FWD128_MIN");      // (fewest 128-wide tiles for which the forward takes them; experiments)
   const long min_tiles = e ? atol(e) : 512;
+  // eight-wave 128 x 256 tiles where a launch has at least two rounds of them (one workgroup per CU: with a single round nothing
+  // covers a workgroup's prologue and epilogue, and 512 -> 256 at M = 32768 measured 57.5 us against 56.7; with two or more, 256 -> 512
+  // 52.3 against 56.6 and 128 -> 1024 57.3 against 60.5, profiles/r05_w8.log).  T3D_X3_W8=0: never; =2: whenever N % 256 == 0
+  const int w8 = []() { const char* e_ = getenv("T3D_X3_W8"); return e_ ? atoi(e_) : T3D_X3_W8_DEFAULT; }();
+  if (w8 && !pre && a->N % 256 == 0 && (w8 == 2 || (long)tiles_m * (a->N / 256) >= 512)) {
+    const dim3 grid(tiles_m * (a->N / 256) + nr);
+    const size_t lds = lds_with(lds_fwd_x3(256), r);
+    if (r) {
+      auto kern = k_pointmlp_fwd_w8_r<256, PathX3W>;
+      allow_lds(reinterpret_cast<const void*>(kern), lds);
+      T3D_LAUNCH(kern, grid, dim3(2 * NT), lds, s, *a, *r);
+    } else {
+      auto kern = k_pointmlp_fwd_w8<256, PathX3W>;
+      allow_lds(reinterpret_cast<const void*>(kern), lds);
+      T3D_LAUNCH(kern, grid, dim3(2 * NT), lds, s, *a);
+    }
+    T3D_CHECK_LAUNCH();
+    return T3D_OK;
+  }
   const int pc = []() { const char* e_ = getenv("T3D_X3_PC"); return e_ ? atoi(e_) : 0; }();      // producer / consumer kernels (experiment; read per launch like T3D_X3)
   if (pc && !r && !pre) {
     const bool wide = a->N % 128 == 0 && (long)tiles_m * (a->N / 128) >= (pc == 2 ? 1 : min_tiles);
