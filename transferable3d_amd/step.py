@@ -160,8 +160,12 @@ class TrainStep:
             # and ONE join, chain T on the main stream; in the captured graph the two are parallel branches.  Same kernels, same
             # arguments, disjoint outputs: bit-identical to the serial program.
             self.two_stream = True
-            lanes2 = [0] * tb + [1] * len(S_calls) + [0] + [0] * len(T_calls) + [0]
-            merged = S_calls + [(Plan.FLUSH, lambda s: 0, None)] + T_calls + [(Plan.JOIN, lambda s: 0, None)]
+            # (which chain is issued first does not matter -- T3D_TWO_STREAM_FIRST=T, and an alternating issue order, eager or
+            # captured: 3.25-3.29 ms in every arrangement, docs/EXPERIMENTS.md round 5; the second queue's first kernel starts a few
+            # hundred us after the fork either way and the step's length is the sum of both chains' work less a fixed overlap)
+            first, second = (T_calls, S_calls) if os.environ.get('T3D_TWO_STREAM_FIRST', 'S') == 'T' else (S_calls, T_calls)
+            lanes2 = [0] * tb + [1] * len(first) + [0] + [0] * len(second) + [0]
+            merged = first + [(Plan.FLUSH, lambda s: 0, None)] + second + [(Plan.JOIN, lambda s: 0, None)]
             calls = calls[:tb] + merged + calls[se + 1:]
             lanes2 += [0] * (len(calls) - len(lanes2))
             self.schedule_report = {'mode': 'two streams', 'S_launches': len(S_calls), 'T_launches': len(T_calls), 'hosted': 0, 'rider_ops': 0,
