@@ -154,6 +154,7 @@ class FakeLib:
             ok = N % 16 == 0 and K % 64 == 0 and (K <= 64 or K % 128 == 0) and (N <= 4 * K or K >= 128)
         else:
             ok = K % 16 == 0
+        ok = ok and K <= 4096 and N <= 4096          # (the identity scale / shift tables of the x3 activation loader)
         return abi.ARITH_BF16X3 if ok else abi.ARITH_FP32_MFMA
 
     def t3d_source_hash(self, out, cap):

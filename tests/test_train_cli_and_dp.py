@@ -116,6 +116,69 @@ def test_data_parallel_world_size_2_gloo(tmp_path):
     assert checked > 10000
 
 
+def _mean_gradient_adam_reference(world):
+    """(state after one TF-form Adam step on the MEAN of the replicas' step-0 gradients, the last graph): what any world size must give."""
+    from oracle import ref_torch as R
+    from transferable3d_amd.nets import Graph, SemiModelA
+    from transferable3d_amd.synthetic import make_batch
+    rt = Runtime(device='cpu', lib=FakeLib())
+    acc, w0, g = None, None, None
+    for rank in range(world):
+        g = Graph(4, 128, 4, rt=rt, seed=0)
+        g.inline_dropout, g.dropout_seed = True, 1234 + rank
+        m = SemiModelA(g, R.default_config())
+        m.emit_forward(g.fwd, True, True)
+        m.emit_backward(g.bwd)
+        g.finalize()
+        g.hyper[0] = 1.0
+        m.inputs.load(make_batch(4, 128, 4, seed=0 * 1000003 + 0 * world + rank))      # the driver's slice of step 0: step * world + rank
+        g.fwd.run()
+        g.bwd.run()
+        gr = g.vars.grads[:g.vars.used].double().numpy()
+        acc = gr if acc is None else acc + gr
+        w0 = g.vars.params[:g.vars.used].double().numpy()
+    mean_grad = acc / world
+    b1, b2, eps, lr = 0.9, 0.999, 1e-8, 1e-3
+    lr_t = lr * np.sqrt(1 - b2) / (1 - b1)
+    return w0 - lr_t * ((1 - b1) * mean_grad) / (np.sqrt((1 - b2) * mean_grad ** 2) + eps), mean_grad, g
+
+
+def _check_world(tmp_path, world):
+    res = _run_dp(str(tmp_path / ('w%d' % world)), world, flat=True)
+    assert sorted(res) == list(range(world))
+    for r in range(1, world):              # every replica holds the same weights, bit for bit
+        for k in res[0]:
+            assert np.array_equal(res[0][k], res[r][k]), (r, k)
+    # rank 0 alone writes the checkpoint (train_semisup.py:316-318 runs on one GPU; here: one writer)
+    assert os.path.exists(os.path.join(str(tmp_path / ('w%d' % world)), 'r0', 'model_epoch_0.npz'))
+    for r in range(1, world):
+        assert not os.path.exists(os.path.join(str(tmp_path / ('w%d' % world)), 'r%d' % r, 'model_epoch_0.npz')), r
+    # == one TF-form Adam step on the mean of the `world` replicas' gradients (grad_scale = 1 / world), each replica on its own slice
+    w1, mean_grad, g = _mean_gradient_adam_reference(world)
+    checked = 0
+    for k, got in res[0].items():
+        o, n = g.vars.offset(k), got.size
+        gk = np.abs(mean_grad[o:o + n])
+        sel = gk > 1e-2 * gk.max()
+        if sel.sum() == 0:
+            continue
+        assert np.abs(got.reshape(-1).astype(np.float64) - w1[o:o + n])[sel].max() < 2e-5, k
+        checked += int(sel.sum())
+    assert checked > 10000
+
+
+def test_data_parallel_world_size_4_gloo(tmp_path):
+    """Four replicas (gloo, the NumPy specification library): identical weights on every rank, equal to the TF-form Adam step on the mean
+    of the four replicas' gradients; disjoint data slices (step * world + rank); one checkpoint writer.  Unmeasured on hardware: no round
+    has had more than one GPU."""
+    _check_world(tmp_path, 4)
+
+
+def test_data_parallel_world_size_8_gloo(tmp_path):
+    """... and eight, the node size BASELINE.json's metric is quoted at."""
+    _check_world(tmp_path, 8)
+
+
 def test_three_stage_recipe_on_synthetic_data(tmp_path):
     """README.md:58-99 in miniature: stage a -> stage b -> stage c restoring both checkpoints by scope prefix."""
     from transferable3d_amd import train_boxpc, train_semisup_adv

@@ -37,7 +37,9 @@ def main():
     for K, N, pooled in FWD:
         if only and only != 'fwd:%dx%d' % (K, N):
             continue
-        x = torch.randn(M, K, device=dev)
+        pad = int(os.environ.get('T3D_LDPAD', '0'))      # experiment: leading dimension of the input K + pad floats (L2 / HBM channel spread)
+        xbuf = torch.randn(M, K + pad, device=dev)
+        x = xbuf[:, :K]
         sc, sh = torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev) * 0.1
         w = torch.randn(K, N, device=dev) / K ** 0.5
         bias = torch.randn(N, device=dev) * 0.1
@@ -45,7 +47,7 @@ def main():
         p1, p2 = torch.zeros(T, N, device=dev), torch.zeros(T, N, device=dev)
         pm = [torch.zeros(T, N, device=dev) for _ in range(2)] + [torch.zeros(T, N, dtype=torch.int32, device=dev) for _ in range(2)]
         a = abi.PointMlpFwdArgs()
-        a.a = abi.ActSrc(fptr(x), K, 0, fptr(sc), fptr(sh), 1, fptr(None), 0)
+        a.a = abi.ActSrc(fptr(xbuf), K + pad, 0, fptr(sc), fptr(sh), 1, fptr(None), 0)
         a.w, a.bias, a.psum, a.psumsq = fptr(w), fptr(bias), fptr(p1), fptr(p2)
         if pooled:
             a.pmax, a.pmin, a.pamax, a.pamin = fptr(pm[0]), fptr(pm[1]), iptr(pm[2]), iptr(pm[3])

@@ -64,6 +64,10 @@ def _object_key(src, extra_flags):
 # main loop is a silent 10-30 % (round-2 review: five bf16 kernels spilled 10-49 VGPRs unnoticed).  build() parses hipcc's
 # -Rpass-analysis=kernel-resource-usage remarks and fails on any other kernel with `VGPRs Spill` > 0.
 SPILL_ALLOWED = {      # substring of the mangled name -> (most VGPRs it may spill, why)
+    'k_pointmlp_bwdILi128ELi128ELi128ENS_7PathX3PE': (2, 'opt-in pre-split-weights form (T3D_X3_PRESPLIT=1, off by default) of the fused x3 backward: 1 VGPR beside the hand-placed iteration'),
+    'k_pointmlp_bwdILi128ELi128ELi64ENS_7PathX3PE': (2, 'same'),
+    'k_pointmlp_bwdILi128ELi64ELi128ENS_7PathX3PE': (2, 'same'),
+    'k_pointmlp_bwdILi128ELi64ELi64ENS_7PathX3PE': (2, 'same'),
     'k_pointmlp_bwd1ILi256ELi128ELi64E': (8, 'one-pass bf16 backward 256 -> 128: 5 VGPRs (20 B) in the epilogue, hand-scheduled kernel at the 256-register cap'),
     'k_pointmlp_bwd1ILi128ELi256ELi64E': (16, 'one-pass bf16 backward 128 -> 256: 11 VGPRs (48 B), same'),
     'k_pointmlp_fwd_resILi128ELi2E': (6, 'persistent activation-resident bf16 forward, K = 128: 3 VGPRs (16 B) -- the next panel\'s raw chunks travel in registers across the epilogue (round 3: 3.72 -> 3.55 ms per config-4 step with it)'),
@@ -112,6 +116,58 @@ def check_spills(remarks_by_source):
     return report
 
 
+# ISA gate of the x3 main loops (round 6).  The hand-placed iteration (csrc/pointmlp.hip: x3_iter_il) is only as good as the code
+# hipcc emits for it: the first builds of round 6 had the IR optimisers move whole staging pieces across ten sched_barrier fences, a
+# flat_load (a const table selected against a kernel argument) forcing `s_waitcnt vmcnt(0)` in front of every use, and register copies
+# of in-flight loads at the loop's back edge -- none visible in a test, each a silent 10-20 %.  build() reads the device assembly of
+# the x3 translation unit (-save-temps) and fails on a main loop (a loop with a barrier and >= 6 MFMAs in a PathX3 / PathX3W kernel)
+# that has: two MFMAs with nothing between them more than ISA_MAX_BURST times in a row, a packed-fp32 vector instruction
+# (v_pk_add/mul/fma_f32), a flat_ access, an `s_waitcnt vmcnt(0)` while the loop issues loads, or more than ISA_MAX_VALU_RUN vector
+# instructions with no MFMA between them.  The map of every such loop is written to build/x3_isa_map.txt (copied to profiles/ per round).
+ISA_MAX_BURST = 2
+ISA_MAX_VALU_RUN = 20      # the longest step is a piece's last: conversion + three plane stores + the refill's address arithmetic
+ISA_GATED = ('PathX3E', 'PathX3WE')      # mangled-name substrings: the default x3 kernels (not the opt-in PathX3P / PathX3PC forms)
+
+
+def check_x3_isa(asm_path, out_path=None):
+    """Raises on a violation (T3D_ALLOW_ISA=1: warns); returns the rows."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), 'tools'))
+    import isa_loops
+    text = open(asm_path).read()
+    rows = [r for r in isa_loops.report(text, ISA_GATED) if r['barriers'] >= 1 and r['lds'] > 0]
+    bad = []
+    for r in rows:
+        why = []
+        if r['mfma_burst'] > ISA_MAX_BURST:
+            why.append('MFMA burst %d' % r['mfma_burst'])
+        if r['valu_run'] > ISA_MAX_VALU_RUN:
+            why.append('VALU run %d' % r['valu_run'])
+        if r['pk_f32']:
+            why.append('%d packed-fp32 instructions' % r['pk_f32'])
+        if r['vmcnt0']:
+            why.append('%d s_waitcnt vmcnt(0)' % r['vmcnt0'])
+        if r['flat']:
+            why.append('%d flat_ accesses' % r['flat'])
+        if why:
+            bad.append('%s %s: %s' % (isa_loops.short(r['kernel']), r['loop'], ', '.join(why)))
+    if out_path:
+        with open(out_path, 'w') as fh:
+            fh.write('# x3 main loops of %s (tools/isa_loops.py; M = MFMA, v = vector ALU, d = LDS, g = global, s = scalar, w = s_waitcnt, b = s_barrier, n = s_nop)\n'
+                     % os.path.basename(asm_path))
+            for r in rows:
+                fh.write('%s %s  MFMA %d  VALU %d (%.1f per MFMA)  LDS %d  VMEM %d | MFMA burst %d  VALU run %d  packed-fp32 %d  vmcnt(0) %d  flat %d\n    %s\n'
+                         % (isa_loops.short(r['kernel']), r['loop'], r['mfma'], r['valu'], r['valu'] / max(r['mfma'], 1), r['lds'], r['vmem'],
+                            r['mfma_burst'], r['valu_run'], r['pk_f32'], r['vmcnt0'], r['flat'], r['seq']))
+    if not rows:
+        bad.append('no x3 main loop found in %s (the gate would pass vacuously)' % asm_path)
+    if bad:
+        msg = 'x3 main-loop ISA gate (transferable3d_amd/build.py check_x3_isa; T3D_ALLOW_ISA=1 builds anyway):\n' + '\n'.join('  ' + b for b in bad)
+        if not os.environ.get('T3D_ALLOW_ISA'):
+            raise RuntimeError(msg)
+        sys.stderr.write('warning: ' + msg + '\n')
+    return rows
+
+
 def build(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 -shared -fPIC csrc/*.hip -> transferable3d_amd/libt3d.so; fails on an unexpected register spill.
     Objects are reused when their source, the headers and the flags are unchanged; the library carries the hash of its sources."""
@@ -127,9 +183,13 @@ def build(force=False, verbose=False):
         path = os.path.join(CSRC, src)
         obj = os.path.join(bdir, src.replace('.hip', '.o'))
         extra = ['-DT3D_SOURCE_HASH="%s"' % src_hash] if src == 'version.hip' else list(EXTRA_FLAGS.get(src, []))
+        asm_ok = True
+        if src == 'pointmlp_x3.hip':
+            extra = extra + ['-save-temps=obj']      # the device assembly stays next to the object: check_x3_isa
+            asm_ok = os.path.exists(os.path.join(bdir, 'pointmlp_x3-hip-amdgcn-amd-amdhsa-gfx950.s'))
         key, keyfile, remfile = _object_key(src, extra), obj + '.key', obj + '.remarks'
         objs.append(obj)
-        if not force and os.path.exists(obj) and os.path.exists(keyfile) and os.path.exists(remfile) and open(keyfile).read() == key:
+        if not force and asm_ok and os.path.exists(obj) and os.path.exists(keyfile) and os.path.exists(remfile) and open(keyfile).read() == key:
             remarks[src] = open(remfile).read()
             continue
         cmd = [hipcc] + FLAGS + extra + ['-I', INCLUDE, '-Rpass-analysis=kernel-resource-usage', '-c', path, '-o', obj]
@@ -147,6 +207,11 @@ def build(force=False, verbose=False):
         with open(keyfile, 'w') as fh:
             fh.write(key)
     report = check_spills(remarks)
+    x3_asm = os.path.join(bdir, 'pointmlp_x3-hip-amdgcn-amd-amdhsa-gfx950.s')
+    if os.path.exists(x3_asm):
+        check_x3_isa(x3_asm, os.path.join(bdir, 'x3_isa_map.txt'))
+    else:
+        raise RuntimeError('no device assembly of pointmlp_x3.hip (-save-temps=obj): the ISA gate cannot run')
     with open(os.path.join(bdir, 'kernel_scratch_report.json'), 'w') as fh:
         json.dump(report, fh, indent=1, sort_keys=True)
     subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs)

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <type_traits>
+#include <utility>
 #include <unordered_map>
 
 namespace {
@@ -103,10 +104,12 @@ __device__ unsigned long long* t3d_trace_ptr = nullptr;
 template <bool HAS_SUB>
 struct ActLoader {
   static constexpr bool EXACT = false;
+  __device__ __forceinline__ static void pin(float4& x) { asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w)); }
   t3d_act_src s;
   int K;     // valid columns
   int rpf;   // rows per frustum
   struct Raw { float4 x; };
+  __device__ __forceinline__ static void pin(Raw& r) { pin(r.x); }
   struct Coef { float4 sc, sh; };
   __device__ __forceinline__ Coef fetch_coef(int col) const {
     Coef c;
@@ -175,6 +178,28 @@ struct DyLoader {      // N % 32 == 0: every tile column is valid
   __device__ __forceinline__ float4 xform(const Raw& r, const Coef& c, int, int) const {
     return make_float4(fmaf(c.c0.x, r.dz.x, fmaf(c.c1.x, r.y.x, c.c2.x)), fmaf(c.c0.y, r.dz.y, fmaf(c.c1.y, r.y.y, c.c2.y)),
                        fmaf(c.c0.z, r.dz.z, fmaf(c.c1.z, r.y.z, c.c2.z)), fmaf(c.c0.w, r.dz.w, fmaf(c.c1.w, r.y.w, c.c2.w)));
+  }
+  // Uniform base + 32-bit per-lane offset (x3_iter_il): the address of a load is (a scalar 64-bit pointer, advanced per k-tile with
+  // scalar instructions) + (a per-lane BYTE offset fixed for the whole kernel) -- the `saddr` form of global_load, no vector
+  // instruction per load; fetch() costs a 64-bit multiply-add and a 64-bit add on the vector ALU per load.
+  static constexpr bool HAS_AT = !POOLED;
+  __device__ __forceinline__ static void pin(Raw& r) {
+    asm volatile("" : "+v"(r.dz.x), "+v"(r.dz.y), "+v"(r.dz.z), "+v"(r.dz.w), "+v"(r.y.x), "+v"(r.y.y), "+v"(r.y.z), "+v"(r.y.w));
+  }
+  __device__ __forceinline__ int ld_elems() const { return N; }
+  __device__ __forceinline__ const float* base_ptr() const { return s.y; }
+  __device__ __forceinline__ Raw fetch_at(size_t uoff, unsigned lbytes) const {
+    Raw r;
+    r.y = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s.y + uoff) + lbytes);
+    r.dz = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s.dz + uoff) + lbytes);
+    return r;
+  }
+  __device__ __forceinline__ Coef fetch_coef_at(int ucol, unsigned lbytes) const {
+    Coef c;
+    c.c0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s.coef + ucol) + lbytes);
+    c.c1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s.coef + N + ucol) + lbytes);
+    c.c2 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s.coef + 2 * N + ucol) + lbytes);
+    return c;
   }
 };
 
@@ -307,6 +332,18 @@ struct WLoaderT {
     const float4 x = Elem<WT>::widen(r.x);
     return make_float4(ok ? x.x : 0.f, ok ? x.y : 0.f, ok ? x.z : 0.f, ok ? x.w : 0.f);
   }
+  static constexpr bool HAS_AT = EXACT_ && !Elem<WT>::BF16;      // (see DyLoader::fetch_at)
+  __device__ __forceinline__ static void pin(Raw& r) {
+    if constexpr (!Elem<WT>::BF16) asm volatile("" : "+v"(r.x.x), "+v"(r.x.y), "+v"(r.x.z), "+v"(r.x.w));
+  }
+  __device__ __forceinline__ int ld_elems() const { return ld; }
+  __device__ __forceinline__ const float* base_ptr() const { return w; }
+  __device__ __forceinline__ Raw fetch_at(size_t uoff, unsigned lbytes) const {
+    Raw r;
+    r.x = *reinterpret_cast<const typename Elem<WT>::V4*>(reinterpret_cast<const char*>(w + uoff) + lbytes);
+    return r;
+  }
+  __device__ __forceinline__ Coef fetch_coef_at(int, unsigned) const { return Coef(); }
 };
 typedef WLoaderT<float> WLoader;
 template <class L> struct PassBf16 { static constexpr bool value = false; };
@@ -973,6 +1010,8 @@ struct WLoaderX3 {
     return r;
   }
 };
+template <class L, class = void> struct HasAt { static constexpr bool value = false; };
+template <class L> struct HasAt<L, typename std::enable_if<L::HAS_AT>::type> { static constexpr bool value = true; };
 template <class L, class = void> struct PreSplit { static constexpr bool value = false; };
 template <class L> struct PreSplit<L, typename std::enable_if<L::PRESPLIT>::type> { static constexpr bool value = true; };
 
@@ -989,6 +1028,14 @@ template <class L> struct PreSplit<L, typename std::enable_if<L::PRESPLIT>::type
 #ifndef T3D_X3_SGB
 #define T3D_X3_SGB 0                // > 0: sched_group_barrier pipeline, that many VALU instructions behind each MFMA (see x3_iter)
 #endif
+#ifndef T3D_X3_IL
+#define T3D_X3_IL 1                 // 1: the hand-placed iteration (x3_iter_il): ONE MFMA, then its share of the staging pass, fenced
+#endif
+template <int... I, class F>
+__device__ __forceinline__ void static_for_seq(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>      // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): compile-time indices (register arrays, if constexpr)
+__device__ __forceinline__ void static_for(F&& f) { static_for_seq(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f)); }
+
 template <int DIM, bool TYPE_R, class L, int PF_ = T3D_X3_PF, int NTX = NT>      // NTX: threads that stage the tile (512: the eight-wave tiles)
 struct StagerX3 {
   static constexpr int PF = PF_;
@@ -1000,6 +1047,9 @@ struct StagerX3 {
   typename L::Raw raw[PF][NV];
   typename L::Coef coef[PF];      // TYPE_C uses coef[0] only (the thread's column chunk never changes)
   int lane0, red0[PF];
+  static constexpr bool AT = T3D_X3_IL && HasAt<L>::value;      // uniform base + per-lane byte offset (L::fetch_at)
+  unsigned lbytes[AT ? NV : 1], cbytes;                          // the lane's byte offsets: piece q of the tile; its coefficient chunk
+  int ld;
 
   __device__ __forceinline__ static void coords(int tid, int q, int& lane_i, int& red_i) {
     const int f = tid + NTX * q;
@@ -1009,6 +1059,37 @@ struct StagerX3 {
   __device__ __forceinline__ void init(const L& l, int lane0_, int tid) {
     lane0 = lane0_;
     if (!TYPE_R) { int li, ri; coords(tid, 0, li, ri); coef[0] = l.fetch_coef(lane0 + li); }
+    if constexpr (AT) {
+      ld = l.ld_elems();
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        int li, ri; coords(tid, q, li, ri);
+        lbytes[q] = (TYPE_R ? (unsigned)li * (unsigned)ld + (unsigned)ri : (unsigned)ri * (unsigned)ld + (unsigned)li) * 4u;
+        asm volatile("" : "+v"(lbytes[q]));      // (opaque: not folded back into a 64-bit product per load)
+      }
+      int li, ri; coords(tid, 0, li, ri);
+      cbytes = (unsigned)ri * 4u;
+      asm volatile("" : "+v"(cbytes));
+    }
+  }
+  // the il_step forms of fetch_piece / fetch_head
+  template <int S>
+  __device__ __forceinline__ void il_fetch_piece(const L& l, int red0_, int tid, int q) {
+    if constexpr (AT) {
+      const size_t uoff = TYPE_R ? (size_t)lane0 * (size_t)ld + (size_t)red0_ : (size_t)red0_ * (size_t)ld + (size_t)lane0;
+      raw[S][q] = l.fetch_at(uoff, lbytes[q]);
+    } else {
+      fetch_piece<S>(l, red0_, tid, q);
+    }
+  }
+  template <int S>
+  __device__ __forceinline__ void il_fetch_head(const L& l, int red0_, int tid) {
+    if constexpr (AT) {
+      red0[S] = red0_;
+      if (TYPE_R) coef[S] = l.fetch_coef_at(red0_, cbytes);
+    } else {
+      fetch_head<S>(l, red0_, tid);
+    }
   }
   template <int S>
   __device__ __forceinline__ void fetch(const L& l, int red0_, int tid) {
@@ -1057,6 +1138,102 @@ struct StagerX3 {
 #pragma unroll
     for (int q = 0; q < NV; ++q) store_piece<S>(l, tile, tid, q);
   }
+  // ---- the same piece in SIX micro-steps (x3_iter_il places one or two behind each MFMA; same roundings, same exact subtractions
+  // as split3: bit-identical planes).  Vector instructions per step: the loader's element-wise work (batch-norm + ReLU: 8; a weight
+  // tile: none), then 5 / 5 / 6 / 5 of the split, then the last conversion with the three plane stores and the slot's refill.
+  static constexpr int NU = 6;
+  static constexpr int XCOST = std::is_empty<typename L::Coef>::value ? 0 : 8;
+  __device__ __forceinline__ static constexpr int il_cost(int u) { return u == 0 ? XCOST : (u == 3 ? 6 : 5); }
+  float ilx[4], ilr0, ilr1;
+  unsigned ilh[2], ilm[2], ill[2];
+  __device__ __forceinline__ static unsigned il_pk(float a, float b) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    const f32x2_ v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+  }
+  template <int E> __device__ __forceinline__ void il_h() {      // first term of pair E and its residuals
+    ilh[E] = il_pk(ilx[2 * E], ilx[2 * E + 1]);
+    ilr0 = ilx[2 * E] - __uint_as_float(ilh[E] << 16);
+    asm("" : "+v"(ilr0));                                        // (keeps the SLP vectoriser from pairing the subtractions: v_pk_add_f32)
+    ilr1 = ilx[2 * E + 1] - __uint_as_float(ilh[E] & 0xffff0000u);
+  }
+  template <int E> __device__ __forceinline__ void il_m() {      // second term, second residuals
+    ilm[E] = il_pk(ilr0, ilr1);
+    float s0 = ilr0 - __uint_as_float(ilm[E] << 16);
+    asm("" : "+v"(s0));
+    ilr1 = ilr1 - __uint_as_float(ilm[E] & 0xffff0000u);
+    ilr0 = s0;
+  }
+  template <int E> __device__ __forceinline__ void il_l() { ill[E] = il_pk(ilr0, ilr1); }
+  // A micro-step ENDS with a volatile empty asm statement on its outputs (and an MFMA with one on its accumulator).  sched_barrier(0) alone
+  // fences the machine schedulers only: the arithmetic between two fences is side-effect free for the IR optimisers and the selection
+  // DAG, and in the fused backward kernels they moved whole pieces across ten fences at a time (ISA of the first round-6 build: ten
+  // empty fence pairs in a row, then 30 vector instructions and five MFMAs in one lump).  Volatile asm statements keep their order
+  // among themselves and with the fences: a value that leaves a step through one cannot be computed after it, and the next step, which
+  // consumes it, not before it.  Not at the FRONT of a step as well: an asm statement that defines a VGPR costs an s_nop in front of
+  // the next instruction that reads it (the compiler cannot see what wrote it), and never on a register a load is still filling (the
+  // wait-count pass treats the asm as its use: s_waitcnt vmcnt(0) in the loop of the first pinned build).
+#define T3D_PIN1(a) asm volatile("" : "+v"(a))
+#define T3D_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))
+#define T3D_PIN3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
+#define T3D_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+  template <int S, int Q, int U>
+  __device__ __forceinline__ void il_step(const L& l, bf16_t* tile, int tid, int red_fetch) {
+    if constexpr (U == 0) {
+      int li, ri; coords(tid, Q, li, ri);
+      const typename L::Coef& c = coef[TYPE_R ? S : 0];
+#ifdef T3D_X3_PIN_RAW
+      l.pin(raw[S][Q]);                                          // (the step that consumes the loaded registers: the wait belongs here)
+#endif
+      const float4 v = TYPE_R ? l.xform(raw[S][Q], c, lane0 + li, red0[S] + ri) : l.xform(raw[S][Q], c, red0[S] + ri, lane0 + li);
+      ilx[0] = v.x; ilx[1] = v.y; ilx[2] = v.z; ilx[3] = v.w;
+      // (not when the loader computes nothing -- a weight tile: the asm would tie single registers to parts of the load's 128-bit
+      // result, the allocator then copies them out at the loop's back edge, behind s_waitcnt vmcnt(0) on a load two gaps old)
+      if constexpr (XCOST != 0) T3D_PIN4(ilx[0], ilx[1], ilx[2], ilx[3]);
+    } else if constexpr (U == 1) {
+      il_h<0>();
+      T3D_PIN3(ilh[0], ilr0, ilr1);
+    } else if constexpr (U == 2) {
+      il_m<0>();
+      T3D_PIN3(ilm[0], ilr0, ilr1);
+    } else if constexpr (U == 3) {
+      il_l<0>();
+      il_h<1>();
+      T3D_PIN4(ill[0], ilh[1], ilr0, ilr1);
+    } else if constexpr (U == 4) {
+      il_m<1>();
+      T3D_PIN3(ilm[1], ilr0, ilr1);
+    } else {
+      asm volatile("" ::: "memory");
+      il_l<1>();
+      int li, ri; coords(tid, Q, li, ri);
+      bf16_t* dst = tile + (TYPE_R ? x3_r_off(li, ri) : ri * LDC + li);
+#ifdef T3D_ABL_IL_NOWRITE      // timing ablation (wrong results): the planes are not written (one conditional store keeps the split alive)
+      if (ilh[0] == 0x12345678u && ill[1] == 0x9abcdef0u && ilm[0] == 0x1u && ilm[1] == ilh[1] && ill[0] == 7u) *reinterpret_cast<uint2*>(dst) = make_uint2(ilh[0], ilh[1]);
+#else
+      *reinterpret_cast<uint2*>(dst) = make_uint2(ilh[0], ilh[1]);
+      *reinterpret_cast<uint2*>(dst + PLANE) = make_uint2(ilm[0], ilm[1]);
+      *reinterpret_cast<uint2*>(dst + 2 * PLANE) = make_uint2(ill[0], ill[1]);
+#endif
+#if defined(T3D_ABL_IL_NOLOAD)       // timing ablation (wrong results): the slot is never refilled (the first tile is staged again and again)
+#elif defined(T3D_ABL_IL_NOLOAD_R)   // ... only type-R operands (the [M, C] stream of forward / data gradient) are not refilled
+      if constexpr (!TYPE_R) { il_fetch_piece<S>(l, red_fetch, tid, Q); if constexpr (Q == NV - 1) il_fetch_head<S>(l, red_fetch, tid); }
+#elif defined(T3D_ABL_IL_NOLOAD_C)   // ... only type-C operands
+      if constexpr (TYPE_R) { il_fetch_piece<S>(l, red_fetch, tid, Q); if constexpr (Q == NV - 1) il_fetch_head<S>(l, red_fetch, tid); }
+#elif defined(T3D_ABL_IL_LOADDUMMY)  // ... the loads are issued, their results never used (issue cost without the waits)
+      if constexpr (AT) {
+        const size_t uoff = TYPE_R ? (size_t)lane0 * (size_t)ld + (size_t)red_fetch : (size_t)red_fetch * (size_t)ld + (size_t)lane0;
+        const char* pp = reinterpret_cast<const char*>(l.base_ptr() + uoff) + lbytes[Q];
+        float4 dummy;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dummy) : "v"(pp) : "memory");
+      }
+#else
+      il_fetch_piece<S>(l, red_fetch, tid, Q);
+      if constexpr (Q == NV - 1) il_fetch_head<S>(l, red_fetch, tid);
+#endif
+      asm volatile("" ::: "memory");
+    }
+  }
 };
 
 // ... of a weight matrix that arrives as three bf16 planes (WLoaderX3): the tile is COPIED, sixteen bytes at a time -- chunk f of the
@@ -1104,6 +1281,15 @@ struct StagerX3W {
   __device__ __forceinline__ void store(const L& l, bf16_t* tile, int tid) {
 #pragma unroll
     for (int q = 0; q < NV; ++q) store_piece<S>(l, tile, tid, q);
+  }
+  static constexpr int NU = 1;      // x3_iter_il: a piece is one copy (ds_write_b128) and its refill
+  __device__ __forceinline__ static constexpr int il_cost(int) { return 3; }
+  template <int S, int Q, int U>
+  __device__ __forceinline__ void il_step(const L& l, bf16_t* tile, int tid, int red_fetch) {
+    asm volatile("" ::: "memory");
+    store_piece<S>(l, tile, tid, Q);
+    fetch_piece<S>(l, red_fetch, tid, Q);
+    asm volatile("" ::: "memory");
   }
 };
 
@@ -1239,6 +1425,113 @@ __device__ __forceinline__ void x3_iter_fp(SA& sa, SB& sb, const LA& la, const L
   });
 }
 
+// ---- the hand-placed iteration (T3D_X3_IL, round 6) ----------------------------------------------------------------------------------
+// x3_iter_fp hands hipcc a product group (TM x TN MFMAs) and then a whole staging piece (~35 vector instructions); the scheduler merges
+// groups further, and the loop it emits has MFMA bursts of 8-12 and runs of 30-67 vector instructions with no MFMA between them
+// (tools/isa_loops.py on round 5's listing).  A wave issues in order: through a burst its vector work cannot start, through a run the
+// matrix pipe has nothing of this wave's to do, and the SIMD's other wave runs the same program.  What the pipe tolerates beside an
+// MFMA is <= 5-6 single-issue vector instructions per 32-cycle gap (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost'; tools/micro/
+// mfma_valu_il.hip: [MFMA, 6 x v_fma_f32] at two waves per SIMD runs at 35.5 cycles per MFMA).  So the iteration is written out as
+//     MFMA_0 | steps of gap 0 | MFMA_1 | steps of gap 1 | ...                    (every `|` a sched_barrier(0): nothing crosses)
+// where the steps are, in order: the micro-steps of every staging piece (StagerX3::il_step: <= 8 vector instructions each, the piece's
+// three plane stores and its slot's refill in the last one), the workgroup barrier, and the fragment reads of the next tile in the
+// order the next iteration's products need them (l h, h l, m m, ...: a2 b0 a0 b2 a1 b1).  ILSched spreads the steps over the gaps by
+// their issue cost at compile time.  Same MFMAs on the same operands in the same order as x3_iter_fp: bit-identical results.
+template <class SA, class SB, int TM, int TN>
+struct ILSched {
+  static constexpr int NM = 6 * TM * TN;                       // MFMAs = gaps of one iteration
+  static constexpr int NSA = SA::NV * SA::NU, NSB = SB::NV * SB::NU;
+  static constexpr int BAR = NSA + NSB;                        // index of the barrier step
+  static constexpr int NF = 3 * (TM + TN);                     // fragment reads (one ds_read_b128 or two ds_read_b64_tr_b16 each)
+  static constexpr int NSTEP = BAR + 1 + NF;
+  __device__ __forceinline__ static constexpr int cost(int k) {
+    if (k < NSA) return SA::il_cost(k % SA::NU);
+    if (k < BAR) return SB::il_cost((k - NSA) % SB::NU);
+    if (k == BAR) return 0;
+    return 2;
+  }
+  __device__ __forceinline__ static constexpr int total() { int w = 0; for (int k = 0; k < NSTEP; ++k) w += cost(k); return w; }
+  __device__ __forceinline__ static constexpr int gap_of(int k) {      // by the midpoint of the step's share of the total cost
+    int before = 0;
+    for (int j = 0; j < k; ++j) before += cost(j);
+    const int g = (2 * before + cost(k)) * NM / (2 * total());
+    return g < NM ? g : NM - 1;
+  }
+  __device__ __forceinline__ static constexpr int first_step(int gap) { int k = 0; while (k < NSTEP && gap_of(k) < gap) ++k; return k; }
+  // fragment read j: which operand, plane and 32-wide block
+  __device__ __forceinline__ static constexpr int frag_group(int j) {      // 0..5 = a2 b0 a0 b2 a1 b1
+    int g = 0;
+    while (true) { const int n = (g & 1) ? TN : TM; if (j < n) return g; j -= n; ++g; }
+  }
+  __device__ __forceinline__ static constexpr int frag_index(int j) {
+    int g = 0;
+    while (true) { const int n = (g & 1) ? TN : TM; if (j < n) return j; j -= n; ++g; }
+  }
+};
+
+template <int S, bool SYM, int TM, int TN, class SA, class SB, class LA, class LB, bool AR, int DIMA, bool BR, int DIMB>
+__device__ __forceinline__ void x3_iter_il(SA& sa, SB& sb, const LA& la, const LB& lb, bf16_t* smem, int cur, int red_fetch, int a0, int b0,
+                                           const FragsX3<TM, TN>& fc, FragsX3<TM, TN>& fn, f32x16 (&acc)[TM][TN],
+                                           f32x16 (&accb)[SYM ? TM : 1][SYM ? TN : 1], f32x16 (&accc)[SYM ? TM : 1][SYM ? TN : 1], int tid) {
+  using SC = ILSched<SA, SB, TM, TN>;
+  constexpr int STAGE = SA::LDS_ELEMS + SB::LDS_ELEMS;
+  bf16_t* An = smem + (cur ^ 1) * STAGE;
+  bf16_t* Bn = An + SA::LDS_ELEMS;
+  const int lane = tid & 63;
+  static_for<SC::NM>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    constexpr int p = i / (TM * TN), tm = (i / TN) % TM, tn = i % TN;
+    constexpr int pa = p == 0 ? 2 : (p == 2 || p == 3) ? 1 : 0;      // l h, h l, m m, m h, h m, h h
+    constexpr int pb = p == 1 ? 2 : (p == 2 || p == 4) ? 1 : 0;
+    // (the MFMA between two volatile asm statements on its accumulator: see StagerX3::il_step)
+    if constexpr (SYM) {
+      if constexpr (p % 3 == 0) {
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc.a[pa][tm], fc.b[pb][tn], acc[tm][tn], 0, 0, 0);
+        T3D_PIN1(acc[tm][tn]);
+      } else if constexpr (p % 3 == 1) {
+        accb[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc.a[pa][tm], fc.b[pb][tn], accb[tm][tn], 0, 0, 0);
+        T3D_PIN1(accb[tm][tn]);
+      } else {
+        accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc.a[pa][tm], fc.b[pb][tn], accc[tm][tn], 0, 0, 0);
+        T3D_PIN1(accc[tm][tn]);
+      }
+    } else {
+      acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc.a[pa][tm], fc.b[pb][tn], acc[tm][tn], 0, 0, 0);
+      T3D_PIN1(acc[tm][tn]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int k0 = SC::first_step(i), k1 = SC::first_step(i + 1);
+    static_for<k1 - k0>([&](auto jc) {
+      constexpr int k = k0 + decltype(jc)::value;
+      if constexpr (k < SC::NSA) {
+#ifndef T3D_ABL_IL_NOSTAGE      // timing ablations (wrong results): no staging pass / no barrier / no fragment reads
+        sa.template il_step<S, k / SA::NU, k % SA::NU>(la, An, tid, red_fetch);
+#endif
+      } else if constexpr (k < SC::BAR) {
+#ifndef T3D_ABL_IL_NOSTAGE
+        sb.template il_step<S, (k - SC::NSA) / SB::NU, (k - SC::NSA) % SB::NU>(lb, Bn, tid, red_fetch);
+#endif
+      } else if constexpr (k == SC::BAR) {
+#ifndef T3D_ABL_IL_NOBAR
+        __syncthreads();
+#endif
+      } else {
+        constexpr int j = k - SC::BAR - 1, g = SC::frag_group(j), x = SC::frag_index(j);
+        constexpr int pl = g < 2 ? (g == 0 ? 2 : 0) : g < 4 ? (g == 2 ? 0 : 2) : 1;
+#ifdef T3D_ABL_IL_NOFRAG
+        if constexpr ((g & 1) == 0) fn.a[pl][x] = fc.a[pl][x]; else fn.b[pl][x] = fc.b[pl][x];
+#else
+        asm volatile("" ::: "memory");
+        if constexpr ((g & 1) == 0) fn.a[pl][x] = frag_x<AR, DIMA>(An + pl * SA::PLANE, a0 + x * 32, lane);
+        else fn.b[pl][x] = frag_x<BR, DIMB>(Bn + pl * SB::PLANE, b0 + x * 32, lane);
+        asm volatile("" ::: "memory");
+#endif
+      }
+    });
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+
 // Two LDS stages, one barrier per 16-deep k-tile, PF register slots per operand.  A k-tile is only 24 MFMAs of 32 cycles per wave
 // (0.3 us): with ONE tile in flight the loop ran at one k-tile per memory round trip (1.7 us per k-tile measured on 512 -> 256, the
 // matrix pipe a third busy; splitting the weights beforehand or a third workgroup per CU changed nothing -- the loop was waiting for its
@@ -1321,8 +1614,13 @@ __device__ __forceinline__ void gemm_mainloop_x3(SA& sa, SB& sb, const LA& la, c
 #if T3D_X3_FRAGPF
   static_assert(PF == 1 || PF == 2, "fragments across the barrier: one or two register slots");
   {
+#if T3D_X3_IL
+#define T3D_X3_ITER_FP(S_, T_, FC_, FN_) \
+  x3_iter_il<S_, SYM, TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, cur, tile_red((T_) + 1 + PF), a0, b0, FC_, FN_, acc, accb, accc, tid)
+#else
 #define T3D_X3_ITER_FP(S_, T_, FC_, FN_) \
   x3_iter_fp<S_, SYM, TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, cur, tile_red((T_) + 1 + PF), a0, b0, FC_, FN_, acc, accb, accc, tid)
+#endif
     constexpr int SODD = PF == 2 ? 1 : 0;      // the slot of tile t + 1 for even t
     FragsX3<TM, TN> f0, f1;
     load_frags_x3<AR, DIMA, SA::PLANE, BR, DIMB, SB::PLANE>(smem, smem + SA::LDS_ELEMS, a0, b0, tid & 63, f0);
@@ -1539,6 +1837,20 @@ struct PathBF16 {
 };
 // The fp32 activation loader for layers whose channel count is a multiple of the k-tile (the launchers take the x3 path only then):
 // no clamped addresses, no column masks -- four selects and a min per chunk less in a staging pass that bounds these kernels.
+// (a layer input without a batch-norm in front of it: scale = 1, shift = 0 from these tables, so that the k-loop has no branch on
+// `scale != nullptr` -- hipcc kept that branch, nine v_mov and two conditional loads, inside every k-tile)
+// (NOT const: a const table lives in the constant address space, the select between it and the caller's pointer is then a generic
+// pointer, and the load a flat_load -- which returns out of order: s_waitcnt vmcnt(0) in front of every use)
+__device__ float t3d_ident_scale[4096] = {
+#define T3D_R16_(x) x, x, x, x, x, x, x, x, x, x, x, x, x, x, x, x
+#define T3D_R256_(x) T3D_R16_(x), T3D_R16_(x), T3D_R16_(x), T3D_R16_(x), T3D_R16_(x), T3D_R16_(x), T3D_R16_(x), T3D_R16_(x), \
+                     T3D_R16_(x), T3D_R16_(x), T3D_R16_(x), T3D_R16_(x), T3D_R16_(x), T3D_R16_(x), T3D_R16_(x), T3D_R16_(x)
+    T3D_R256_(1.f), T3D_R256_(1.f), T3D_R256_(1.f), T3D_R256_(1.f), T3D_R256_(1.f), T3D_R256_(1.f), T3D_R256_(1.f), T3D_R256_(1.f),
+    T3D_R256_(1.f), T3D_R256_(1.f), T3D_R256_(1.f), T3D_R256_(1.f), T3D_R256_(1.f), T3D_R256_(1.f), T3D_R256_(1.f), T3D_R256_(1.f)};
+#undef T3D_R256_
+#undef T3D_R16_
+__device__ float t3d_ident_shift[4096] = {0.f};
+constexpr int T3D_IDENT_MAX = 4096;
 struct ActLoaderE {
   static constexpr bool EXACT = true;
   t3d_act_src s;
@@ -1546,6 +1858,23 @@ struct ActLoaderE {
   int rpf;
   struct Raw { float4 x; };
   struct Coef { float4 sc, sh; };
+  static constexpr bool HAS_AT = true;      // (see DyLoader::fetch_at)
+  __device__ __forceinline__ static void pin(Raw& r) { asm volatile("" : "+v"(r.x.x), "+v"(r.x.y), "+v"(r.x.z), "+v"(r.x.w)); }
+  __device__ __forceinline__ int ld_elems() const { return s.ldx; }
+  __device__ __forceinline__ const float* base_ptr() const { return s.x + s.coff; }
+  __device__ __forceinline__ Raw fetch_at(size_t uoff, unsigned lbytes) const {
+    Raw r;
+    r.x = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s.x + s.coff + uoff) + lbytes);
+    return r;
+  }
+  __device__ __forceinline__ Coef fetch_coef_at(int ucol, unsigned lbytes) const {      // K <= T3D_IDENT_MAX when scale == nullptr (launchers)
+    const float* scp = s.scale != nullptr ? s.scale : t3d_ident_scale;
+    const float* shp = s.scale != nullptr ? s.shift : t3d_ident_shift;
+    Coef c;
+    c.sc = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(scp + ucol) + lbytes);
+    c.sh = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(shp + ucol) + lbytes);
+    return c;
+  }
   __device__ __forceinline__ Coef fetch_coef(int col) const {
     Coef c;
     c.sc = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -3967,11 +4296,12 @@ bool x3_on(int arith) {
 }
 long x3_min_kn(int arith) { const char* e = arith == T3D_ARITH_AUTO ? getenv("T3D_X3_MINKN") : nullptr; return e ? atol(e) : 1L; }
 long x3_min_kn_bwd(int arith) { const char* e = arith == T3D_ARITH_AUTO ? getenv("T3D_X3_MINKN_BWD") : nullptr; return e ? atol(e) : x3_min_kn(arith); }
-bool x3_layer(int arith, int K, int N) { return x3_on(arith) && (long)K * N >= x3_min_kn(arith); }            // forward launches
+// (K, N <= T3D_IDENT_MAX: the identity scale / shift tables of ActLoaderE)
+bool x3_layer(int arith, int K, int N) { return x3_on(arith) && (long)K * N >= x3_min_kn(arith) && K <= 4096 && N <= 4096; }            // forward launches
 // backward launches (dense and Gram form).  Not the layers with few input and many output channels (64 -> 512, conv6's per-point part):
 // their data gradient is ONE 64-column tile over a long reduction, half the MFMA work per staged element, and measured slower than the
 // fp32-MFMA form (54.1 vs 50.7 us alone, 69.5 vs 62.9 us hosted at M = 32768)
-bool x3_layer_bwd(int arith, int K, int N) { return x3_on(arith) && (long)K * N >= x3_min_kn_bwd(arith) && (N <= 4 * K || K >= 128); }
+bool x3_layer_bwd(int arith, int K, int N) { return x3_on(arith) && (long)K * N >= x3_min_kn_bwd(arith) && (N <= 4 * K || K >= 128) && K <= 4096 && N <= 4096; }
 bool act_ok(const t3d_act_src& a, int K) {
   return a.x != nullptr && (a.ldx % 4) == 0 && (a.coff % 4) == 0 && a.coff + (K + 3) / 4 * 4 <= a.ldx &&
          (a.scale == nullptr || a.shift != nullptr) && dtype_ok(a.dtype) && !(a.dtype == T3D_BF16 && a.sub != nullptr) &&

@@ -43,12 +43,16 @@ class TrainStep:
         # the collective is captured in line on the launch stream (there is nothing to run beside it); with several, on RCCL's own
         # stream, which joins the capture through the event edges torch records around a collective (T3D_DP_ONE_GRAPH=1 / 2 force
         # a form).
+        # By default only with ONE rank (force_dist: how a 1-GPU box exercises the data-parallel program, and the only place the
+        # captured collective has ever run): a capture that succeeds says nothing about a replay that hangs on a second GPU, so with
+        # several ranks the host-issued collectives stay the default until the one-graph form has run there (T3D_DP_ONE_GRAPH=1 / 2 or
+        # one_graph=True opt in; the ranks then AGREE on the outcome of the capture, see _capture).
         env = os.environ.get('T3D_DP_ONE_GRAPH', '')
         if one_graph is None:
             if env in ('0', '1', '2'):
                 one_graph = env != '0'
             else:
-                one_graph = self.dist and self.on_gpu and self._backend() == 'nccl'
+                one_graph = self.dist and self.on_gpu and self._backend() == 'nccl' and self.world == 1
         self.one_graph = bool(one_graph) and self.dist and self.on_gpu
         self.one_graph_form = env if env in ('1', '2') else None      # None: by the number of buckets
         self.cache = {}            # generate_masks -> list of program items with captured graphs
@@ -253,6 +257,7 @@ class TrainStep:
             # edges torch records around a collective, so that the replayed graph has the bucket's all-reduce on a branch beside the
             # rest of the backward (no host work and no graph-launch gap between the segments).
             overlap = (self.one_graph_form == '2') if self.one_graph_form else len(self._buckets()) > 1
+            g, err = None, None
             try:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=s, capture_error_mode='thread_local'):
@@ -264,14 +269,26 @@ class TrainStep:
                                 x.run()
                             elif kind == 'allreduce':
                                 self._allreduce(x, async_op=False)
-                return [('run_graph', g)], {0: g}
             except Exception as e:      # a collective this RCCL build cannot capture: the host-issued program still works
-                import sys
-                sys.stderr.write('TrainStep: capturing the data-parallel step into one graph failed (%s: %s); falling back to the '
-                                 'host-issued collectives between graph segments\n' % (type(e).__name__, str(e)[:200]))
+                err = e
                 torch.cuda.synchronize()
-                self.one_graph = False
-                self.one_graph_fallback = repr(e)[:200]
+            # The ranks agree on the outcome: one rank replaying a graph while another issues its collectives from the host would
+            # pair different operations (a hang at best).  One host-issued all-reduce (MIN) of a success flag; every rank falls back
+            # if any rank's capture failed.
+            ok = err is None
+            if self.world > 1:
+                import torch.distributed as dist
+                flag = torch.tensor([1 if ok else 0], device=self.rt.device, dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)
+                ok = bool(int(flag.item()))
+            if ok:
+                return [('run_graph', g)], {0: g}
+            import sys
+            why = '%s: %s' % (type(err).__name__, str(err)[:200]) if err is not None else 'the capture failed on another rank'
+            sys.stderr.write('TrainStep: capturing the data-parallel step into one graph failed (%s); every rank falls back to the '
+                             'host-issued collectives between graph segments\n' % why)
+            self.one_graph = False
+            self.one_graph_fallback = why[:200]
         # Only the FIRST segment (schedules, forward, the backward up to the first bucket: ~1.1 of the step's 1.6 ms) is replayed as
         # a graph; the segments behind a collective are launched kernel by kernel.  A graph launch costs ~30 us on the GPU before
         # its first kernel starts (rocprofv3 timeline of the one-rank RCCL step, tools/dp_timeline.py: 30 + 29 + 39 us at the three
@@ -355,7 +372,13 @@ def workload_flags(workload):
     c = SEMI_MODEL F."""
     from .config import make_parser
     if workload == 'A':
-        return make_parser().parse_special_args(['--SEMI_MODEL', 'A', '--WEAK_WEIGHT_REPROJECTION', '0', '--WEAK_WEIGHT_SURFACE', '0'])
+        c = make_parser().parse_special_args(['--SEMI_MODEL', 'A', '--WEAK_WEIGHT_REPROJECTION', '0', '--WEAK_WEIGHT_SURFACE', '0'])
+        # the program train_semisup.py runs by default evaluates the weak losses at zero weight for the reference's Weak_Loss/...
+        # summaries (one small launch per step; loss, gradients and weights bit-unchanged): bench.py and the trajectory tests time and
+        # check THAT program (T3D_WEAK_SUMMARIES=0: the recipe's graph without them, as --no_weak_loss_summaries)
+        import os
+        c.WEAK_LOSS_SUMMARIES = os.environ.get('T3D_WEAK_SUMMARIES', '1') != '0'
+        return c
     if workload == 'boxpc':
         return make_parser().parse_special_args(['--BOX_PC_MASK_REPRESENTATION', 'A', '--BOXPC_WEIGHT_DELTA', '4'])
     return make_parser().parse_special_args(
