@@ -154,7 +154,7 @@ def gemm_work(name, a):
             return 'k_pointmlp_fwd_res<%d,%d>' % (128 if a.N % 128 == 0 else 64, a.K // 64), flops, by      # activation-resident bf16 forward
         if a.dtype == 0 and a.a.dtype == 0 and _null(a.a.sub) and a.K % 16 == 0 and x3f(a, a.K, a.N):
             w8 = int(os.environ.get('T3D_X3_W8', '1'))      # eight-wave 128 x 256 tiles (csrc/pointmlp.hip t3d_x3_fwd)
-            if w8 and _null(a.w_x3) and a.N % 256 == 0 and (w8 == 2 or (a.M // 128) * (a.N // 256) >= 512):
+            if w8 and a.N % 256 == 0 and (w8 == 2 or (a.M // 128) * (a.N // 256) >= 512):
                 return 'k_pointmlp_fwd_w8_x3<256>', flops, by
             return 'k_pointmlp_fwd_x3<%d>' % (128 if a.N % 128 == 0 and (a.M // 128) * (a.N // 128) >= 512 else 64), flops, by
         if a.dtype == 0 and os.environ.get('T3D_FWD_POOL', '1') != '0' and _null(a.y) and not _null(a.pmax) and _null(a.a.sub) and a.K == 128 and \

@@ -35,9 +35,24 @@ extern "C" {
 
 /* ABI version 2.  Version 1 structs were plain; fields appended to four of them in round 4 (w_x3, oracle_mask, rowmask) made a caller
  * built against the older header pass structs the library read past.  Since version 2 every argument struct that has grown, or may
- * grow, starts with `struct_size`: the caller stores sizeof(the struct as its header declares it) there and every entry point that
- * takes the struct returns T3D_ERR_ABI unless it equals the library's own sizeof.  New fields are only ever appended. */
-#define T3D_ABI_VERSION 2
+ * grow, starts with `struct_size`: the caller stores sizeof(the struct as ITS header declares it) there.  New fields are only ever
+ * appended, and 0 is the documented default of every appended field.  An entry point that takes such a struct accepts
+ *     struct_size == the library's sizeof          the same header;
+ *     T3D_V2_SIZE_<struct> <= struct_size < sizeof  an OLDER caller: the fields it does not know read 0 (csrc/abi_take.h copies the
+ *                                                   caller's bytes into a zeroed struct of the library's own declaration);
+ *     struct_size > sizeof, every byte beyond 0     a NEWER caller that uses none of the fields this library does not know;
+ * and returns T3D_ERR_ABI for anything else (a struct shorter than its version-2 size; a newer caller's non-zero unknown field).
+ * (Until round 5 the test was equality: every append would have refused every older caller.)  The structs WITHOUT `struct_size` are
+ * frozen: they never grow -- a change to one of them is a new struct behind a new entry point. */
+#define T3D_ABI_VERSION 3      /* 3: `w_x3` means fragment-order planes (t3d_split_x3_frag); layouts and sizes as version 2 */
+/* sizeof of the growable structs at ABI version 2 (the smallest struct_size an entry point accepts) */
+#define T3D_V2_SIZE_pointmlp_fwd_args 200
+#define T3D_V2_SIZE_pointmlp_dgrad_args 168
+#define T3D_V2_SIZE_pointmlp_wgrad_args 144
+#define T3D_V2_SIZE_pointmlp_dgrad_gram_args 168
+#define T3D_V2_SIZE_pointmlp_gram_args 96
+#define T3D_V2_SIZE_seg_head_args 208
+#define T3D_V2_SIZE_boxpc_rep_args 104
 
 #define T3D_TILE_ROWS 128
 
@@ -125,7 +140,7 @@ typedef struct {
  * their row indices within the frustum (the finalize kernel picks max or min by the sign of the
  * batch-norm scale). */
 typedef struct {
-  uint32_t struct_size;    /* = sizeof(t3d_pointmlp_fwd_args); T3D_ERR_ABI otherwise */
+  uint32_t struct_size;    /* = sizeof(t3d_pointmlp_fwd_args) of the caller's header (see T3D_ABI_VERSION) */
   t3d_act_src a;
   const float* w;        /* [K,N] */
   const float* bias;     /* [N] or NULL */
@@ -141,8 +156,11 @@ typedef struct {
   int M, K, N;
   int rows_per_frustum;
   int dtype;             /* element type of y and arithmetic of the GEMM (a.dtype may still be T3D_F32: the raw inputs) */
-  /* optional (fp32 layers on the three-term bf16 path, see t3d_split_x3): the same [K,N] matrix already split into three bf16 planes,
-   * plane p at w_x3 + p * w_x3_stride (bf16 elements).  NULL: the kernel splits w while it stages it -- same results bit for bit. */
+  /* optional (fp32 layers on the three-term bf16 path): the same [K,N] matrix already split into three bf16 planes IN FRAGMENT ORDER,
+   * FORWARD arrangement (t3d_split_x3_frag: planes_fwd + the matrix's offset), plane p at w_x3 + p * w_x3_stride (bf16 elements).
+   * The kernel then reads the weight operand of every MFMA straight from these planes (one 16-byte load per lane), without an LDS
+   * image.  NULL: the kernel splits w while it stages it through LDS -- same results bit for bit.  (ABI version 3: until version 2 the
+   * planes were row-major copies of w, t3d_split_x3.) */
   const void* w_x3;
   int64_t w_x3_stride;
   int arith;               /* T3D_ARITH_* (fp32 launches) */
@@ -207,7 +225,7 @@ int t3d_pool_finalize(const t3d_pool_finalize_args* args, t3d_stream_t stream);
  * producer's batch-norm-backward partials in the epilogue:
  *   out = da * 1[prev_y*prev_scale + prev_shift > 0];  psum_dz = sum out;  psum_dzy = sum out*prev_y */
 typedef struct {
-  uint32_t struct_size;    /* = sizeof(t3d_pointmlp_dgrad_args); T3D_ERR_ABI otherwise */
+  uint32_t struct_size;    /* = sizeof(t3d_pointmlp_dgrad_args) of the caller's header (see T3D_ABI_VERSION) */
   t3d_dy_src dy;
   const float* w;          /* [K,N] */
   const float* add_in;     /* [M,K] or NULL */
@@ -220,7 +238,7 @@ typedef struct {
   int M, K, N;
   int rows_per_frustum;
   int dtype;               /* element type of prev_y, out and add_in, and the arithmetic; must equal dy.dtype */
-  const void* w_x3;        /* optional: w as three bf16 planes (t3d_pointmlp_fwd_args.w_x3) */
+  const void* w_x3;        /* optional: w as three bf16 fragment-order planes, DATA-GRADIENT arrangement (t3d_split_x3_frag: planes_dgrad + offset) */
   int64_t w_x3_stride;
   int arith;               /* T3D_ARITH_* (fp32 launches) */
 } t3d_pointmlp_dgrad_args;
@@ -230,7 +248,7 @@ int t3d_pointmlp_dgrad(const t3d_pointmlp_dgrad_args* args, t3d_stream_t stream)
  *   slab[s,k,n] = sum_{m in split s} a[m,k] dy[m,n],  s = 0 .. M/rows_per_split - 1
  * t3d_reduce_slabs sums the slabs in a fixed order (deterministic). rows_per_split % 32 == 0. */
 typedef struct {
-  uint32_t struct_size;    /* = sizeof(t3d_pointmlp_wgrad_args); T3D_ERR_ABI otherwise */
+  uint32_t struct_size;    /* = sizeof(t3d_pointmlp_wgrad_args) of the caller's header (see T3D_ABI_VERSION) */
   t3d_act_src a;
   t3d_dy_src dy;
   float* slabs;            /* [M/rows_per_split, K, N] */
@@ -334,7 +352,7 @@ int t3d_pool_sparse_rows(const t3d_pool_sparse_rows_args* args, t3d_stream_t str
 /* out = (a.p + rowconst + add_in) * 1[prev_y*prev_scale + prev_shift > 0], with the producer's
  * batch-norm-backward partials, exactly like the epilogue of K11a. */
 typedef struct {
-  uint32_t struct_size;    /* = sizeof(t3d_pointmlp_dgrad_gram_args); T3D_ERR_ABI otherwise */
+  uint32_t struct_size;    /* = sizeof(t3d_pointmlp_dgrad_gram_args) of the caller's header (see T3D_ABI_VERSION) */
   t3d_act_src a;           /* [M,K] input of the pooled layer */
   const float* p;          /* [K,K] */
   const float* rowconst;   /* [K] or NULL */
@@ -356,7 +374,7 @@ int t3d_pointmlp_dgrad_gram(const t3d_pointmlp_dgrad_gram_args* args, t3d_stream
 
 /* slab[s] = a_s^T a_s over the rows of split s; rows_per_split from t3d_wgrad_plan(M, K, K). */
 typedef struct {
-  uint32_t struct_size;    /* = sizeof(t3d_pointmlp_gram_args); T3D_ERR_ABI otherwise */
+  uint32_t struct_size;    /* = sizeof(t3d_pointmlp_gram_args) of the caller's header (see T3D_ABI_VERSION) */
   t3d_act_src a;
   float* slabs;            /* [M/rows_per_split, K, K] */
   int M, K;
@@ -478,7 +496,7 @@ int t3d_fc_dinput(const t3d_fc_dinput_args* args, t3d_stream_t stream);
  * gradients back to conv9's batch-norm output.
  * Per-frustum loss weight: w_b = ce_weight * (1 - is_data_2D[b]) / (B * rows_per_frustum). */
 typedef struct {
-  uint32_t struct_size;    /* = sizeof(t3d_seg_head_args); T3D_ERR_ABI otherwise */
+  uint32_t struct_size;    /* = sizeof(t3d_seg_head_args) of the caller's header (see T3D_ABI_VERSION) */
   const float* y;            /* [M,K] raw conv9 output */
   const float* scale; const float* shift;
   const float* drop_mask;    /* [M,K] 0/1 or NULL */
@@ -620,7 +638,7 @@ int t3d_weak_loss(const t3d_weak_loss_args* args, t3d_stream_t stream);
  * residuals and the box is max(anchor[cls] + res, 1e-5) / bin[cls] + res (boxpc_sunrgbd.py:206-230).
  * box_out[B,7] (optional) receives (cx,cy,cz,l,w,h,theta) for the backward.  rows_per_frustum % 256 == 0. */
 typedef struct {
-  uint32_t struct_size;    /* = sizeof(t3d_boxpc_rep_args); T3D_ERR_ABI otherwise */
+  uint32_t struct_size;    /* = sizeof(t3d_boxpc_rep_args) of the caller's header (see T3D_ABI_VERSION) */
   const float* pc; int ld_pc; int C;
   const float* center;            /* [B,3] */
   const float* dims;              /* [B,3] */
@@ -963,6 +981,24 @@ int t3d_adam_tf_step(float* params, const float* grads, float* m, float* v, int6
  * l = bf16(x - h - m).  Writes the three planes of src[0..n): planes[p * plane_stride + i] (bf16 elements, plane_stride >= n).  The
  * optimiser's fp32 weights are split ONCE per step this way instead of once per tile that stages them. */
 int t3d_split_x3(const float* src, void* planes, int64_t n, int64_t plane_stride, t3d_stream_t stream);
+
+/* ... and in MFMA-FRAGMENT ORDER, which is what the x3 GEMM kernels take as `w_x3` (ABI version 3): for every [K, N] matrix of the
+ * device table (K % 32 == 0, N % 32 == 0, off % 8 == 0) the three planes are written at planes_*[p * plane_stride + off ...] as
+ *     fragment f = (rt * NB + nb) * 64 + lane  ->  eight bf16 at element off + 8 f:  Op[nb * 32 + (lane & 31)][rt * 16 + 8 * (lane >> 5) + j]
+ * with Op[n][k] = w[k][n], NB = N / 32 (planes_fwd: the forward's weight operand) and Op[k][n] = w[k][n], NB = K / 32 (planes_dgrad:
+ * the data gradient's) -- the B operand of one v_mfma_f32_32x32x16_bf16 per 64 x 16 bytes.  One launch for every layer, once per step
+ * behind the optimiser.  `fwd` / `dgrad` select the arrangements an entry needs.  Replaces nothing in the reference: TensorFlow's
+ * conv2d reads its fp32 weights (models/tf_util.py:1308). */
+typedef struct {
+  int64_t off;             /* element offset of the matrix in `params` (and of its planes in every plane buffer) */
+  int32_t K, N;
+  int32_t fwd, dgrad;      /* write the forward / the data-gradient arrangement */
+  int32_t blk0;            /* first workgroup of this matrix: ascending over the table, matrix e owns ceil(K N / 2048) workgroups */
+  int32_t reserved;
+} t3d_x3_frag_entry;
+/* n_blocks = the sum of ceil(K N / 2048) over the table (one 256-thread workgroup per 256 eight-element fragments) */
+int t3d_split_x3_frag(const float* params, void* planes_fwd, void* planes_dgrad, int64_t plane_stride, const t3d_x3_frag_entry* table,
+                      int n_entries, int n_blocks, t3d_stream_t stream);
 
 /* tf.train.MomentumOptimizer(learning_rate, momentum) of `--optimizer momentum` (train_semisup.py:226-228, train_boxpc.py:247,
  * train_semisup_adv.py:296), TF form without Nesterov: accum = momentum * accum + g * grad_scale;  w -= lr * accum, with

@@ -142,7 +142,7 @@ class FakeLib:
     """Drop-in for the ctypes library object (same call signatures, host pointers)."""
 
     def t3d_abi_version(self):
-        return 2
+        return 3
 
     def t3d_gemm_arithmetic(self, arith, dtype, K, N, backward):
         """The specification library has one arithmetic (float64 products rounded once): it reports what the product's rule would take."""
@@ -1436,6 +1436,9 @@ class FakeLib:
 
     def t3d_split_x3(self, src, planes, n, stride, stream):
         return 0          # (the specification library multiplies in fp64: no operand planes)
+
+    def t3d_split_x3_frag(self, params, planes_fwd, planes_dgrad, stride, table, n, n_blocks, stream):
+        return 0          # (same: the launch structs' w_x3 is ignored)
 
     def t3d_momentum_step(self, params, grads, accum, n, hyper, momentum, gscale, stream):
         w, g, a = arr(params, n), arr(grads, n), arr(accum, n)

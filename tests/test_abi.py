@@ -21,8 +21,8 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert declared == set(abi.ENTRY_POINTS), declared ^ set(abi.ENTRY_POINTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.t3d_abi_version() == abi.ABI_VERSION == 2
-    assert int(re.search(r'#define T3D_ABI_VERSION (\d+)', _header()).group(1)) == 2
+    assert lib.t3d_abi_version() == abi.ABI_VERSION == 3
+    assert int(re.search(r'#define T3D_ABI_VERSION (\d+)', _header()).group(1)) == 3
 
 
 def test_library_is_bound_to_the_sources_it_was_built_from(tmp_path, monkeypatch):
@@ -136,6 +136,70 @@ def test_a_struct_of_another_size_is_refused_before_anything_is_launched():
     assert lib.t3d_boxpc_rep(C.byref(short(abi.BoxPcRepArgs)), null) == abi.ERR_ABI
     # the right size gets past the check (and is then refused for its null pointers)
     assert lib.t3d_pointmlp_fwd(C.byref(abi.PointMlpFwdArgs()), null) == -1
+
+
+def test_a_newer_caller_with_zeroed_unknown_fields_is_accepted_a_non_zero_one_refused():
+    """struct_size > the library's sizeof: a caller built against a LATER header (fields appended).  Accepted while every byte the library
+    does not know is 0 (the documented default of an appended field), T3D_ERR_ABI once one is not.  No GPU needed."""
+    import ctypes as C
+    lib = abi.load()
+    null = C.c_void_p(0)
+    for cls, fn in ((abi.PointMlpFwdArgs, lib.t3d_pointmlp_fwd), (abi.PointMlpDgradArgs, lib.t3d_pointmlp_dgrad),
+                    (abi.PointMlpWgradArgs, lib.t3d_pointmlp_wgrad), (abi.PointMlpGramArgs, lib.t3d_pointmlp_gram),
+                    (abi.PointMlpDgradGramArgs, lib.t3d_pointmlp_dgrad_gram), (abi.SegHeadArgs, lib.t3d_seg_head),
+                    (abi.BoxPcRepArgs, lib.t3d_boxpc_rep)):
+        n = C.sizeof(cls)
+        buf = (C.c_ubyte * (n + 16))()
+        C.memmove(buf, C.byref(cls()), n)
+        C.cast(buf, C.POINTER(C.c_uint32))[0] = n + 16            # struct_size of the "newer" header
+        assert fn(C.cast(buf, C.POINTER(cls)), null) == -1, cls   # past the ABI gate: refused for its null pointers (T3D_ERR_ARG)
+        buf[n + 4] = 1                                            # a field this library does not know, in use
+        assert fn(C.cast(buf, C.POINTER(cls)), null) == abi.ERR_ABI, cls
+
+
+def test_an_older_callers_struct_is_completed_with_zeros(tmp_path):
+    """csrc/abi_take.h against a struct that has GROWN: the library's declaration has one field more than the caller's.  The caller's
+    bytes arrive intact, the field it does not know reads 0, a struct shorter than the version-2 size is refused, the same size is
+    used in place (compiled with g++: the header has no HIP dependency)."""
+    src = tmp_path / 't.cpp'
+    src.write_text('''
+#include <stdio.h>
+#include "abi_take.h"
+struct old_args { uint32_t struct_size; int M; const float* x; int K; };                 // the caller's header (version 2)
+struct new_args { uint32_t struct_size; int M; const float* x; int K; long long appended; };   // the library's header: one field appended (past the padding)
+static_assert(sizeof(new_args) > sizeof(old_args), "the struct grew");
+static int entry(const new_args* a, int* seen_K, int* seen_appended, int* in_place) {
+  const new_args* a0 = a;
+  new_args local;
+  const int e = t3d_abi_take(a, local, (uint32_t)sizeof(old_args));
+  if (e) return e;
+  *seen_K = a->K; *seen_appended = (int)a->appended; *in_place = (a == a0);
+  return 0;
+}
+int main() {
+  float x = 1.f;
+  int K, ap, ip;
+  old_args o = {(uint32_t)sizeof(old_args), 128, &x, 64};
+  unsigned char buf[sizeof(new_args) + 8];
+  memset(buf, 0xff, sizeof(buf));                       // whatever lies behind the caller's struct must not leak in
+  memcpy(buf, &o, sizeof(o));
+  int e = entry(reinterpret_cast<const new_args*>(buf), &K, &ap, &ip);
+  if (e != 0 || K != 64 || ap != 0 || ip != 0) { printf("older caller: e=%d K=%d appended=%d in_place=%d\\n", e, K, ap, ip); return 1; }
+  new_args n = {(uint32_t)sizeof(new_args), 128, &x, 64, 7};
+  e = entry(&n, &K, &ap, &ip);
+  if (e != 0 || K != 64 || ap != 7 || ip != 1) { printf("same header: e=%d\\n", e); return 2; }
+  o.struct_size = (uint32_t)sizeof(old_args) - 4;
+  memcpy(buf, &o, sizeof(o));
+  if (entry(reinterpret_cast<const new_args*>(buf), &K, &ap, &ip) != -4) return 3;
+  printf("ok\\n");
+  return 0;
+}
+''')
+    import subprocess
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'transferable3d_amd', 'csrc')
+    exe = str(tmp_path / 't')
+    subprocess.check_call(['g++', '-std=c++17', '-O1', '-I', csrc, str(src), '-o', exe])
+    assert subprocess.check_output([exe]).decode().strip() == 'ok'
 
 
 def test_gemm_arithmetic_is_a_request_in_the_launch_struct_not_an_environment_variable(monkeypatch):

@@ -1484,6 +1484,19 @@ def test_seg_head_inline_dropout_equals_the_stored_mask(hip_lib):
     assert np.array_equal(hash_keep_mask(4321, 7, M * K, 0.5).reshape(M, K), mask.cpu().numpy())
 
 
+def _x3_frag_planes(hip_lib, w, st):
+    """(forward planes, data-gradient planes, plane stride) of one [K, N] matrix through t3d_split_x3_frag (a one-entry device table)."""
+    K, N = w.shape
+    stride = (K * N + 7) // 8 * 8
+    pf = torch.zeros(3 * stride, dtype=torch.bfloat16, device=w.device)
+    pd = torch.zeros(3 * stride, dtype=torch.bfloat16, device=w.device)
+    raw, nblk = abi.x3_frag_table([(0, K, N)])
+    tab = torch.from_numpy(raw).to(w.device)
+    assert hip_lib.t3d_split_x3_frag(fptr(w), C.c_void_p(pf.data_ptr()), C.c_void_p(pd.data_ptr()), stride, C.c_void_p(tab.data_ptr()), 1, nblk, st) == 0
+    torch.cuda.synchronize()
+    return pf, pd, stride
+
+
 def test_x3_weight_planes_are_exact_and_equal_the_in_kernel_split(hip_lib):
     """t3d_split_x3: every fp32 value is EXACTLY the sum of its three bf16 planes; a forward / data-gradient launch that reads the
     pre-split planes (t3d_pointmlp_fwd_args.w_x3) gives bit for bit what the launch that splits the fp32 matrix while staging it gives."""
@@ -1500,8 +1513,14 @@ def test_x3_weight_planes_are_exact_and_equal_the_in_kernel_split(hip_lib):
     assert float((p[1].abs() / p[0].abs().clamp_min(1e-300)).max()) <= 2.0 ** -7   # each term below the previous one's last bit
     M, K, N, rpf = 512, 256, 128, 256
     x, w = _mk(dev, r.normal(size=(M, K)).astype(np.float32)), _mk(dev, (r.normal(size=(K, N)) / 16).astype(np.float32))
-    wpl = torch.zeros(3 * K * N, dtype=torch.bfloat16, device=dev)
-    assert hip_lib.t3d_split_x3(fptr(w), C.c_void_p(wpl.data_ptr()), K * N, K * N, st) == 0
+    # fragment order (what the kernels take as w_x3): plane p, k-tile rt, 32-wide block nb, lane, eight elements -- and still exact
+    pf, pd, fstride = _x3_frag_planes(hip_lib, w, st)
+    wc = w.cpu()
+    for planes, op in ((pf, wc.t().contiguous()), (pd, wc)):      # Op[n][k] = w[k][n] forward, Op[k][n] = w[k][n] data gradient
+        L, R = op.shape                                              # lane index, reduction index
+        fr = planes.view(3, fstride)[:, :K * N].double().cpu().sum(0).view(R // 16, L // 32, 2, 32, 8)      # [rt, nb, lane >> 5, lane & 31, j]
+        back = fr.permute(1, 3, 0, 2, 4).reshape(L, R)               # [nb * 32 + (lane & 31)][rt * 16 + 8 * (lane >> 5) + j]
+        assert torch.equal(back, op.double())
     outs = []
     for pre in (False, True):
         y = torch.zeros(M, N, device=dev)
@@ -1511,7 +1530,7 @@ def test_x3_weight_planes_are_exact_and_equal_the_in_kernel_split(hip_lib):
         a.w, a.y, a.psum, a.psumsq = fptr(w), fptr(y), fptr(p1), fptr(p2)
         a.M, a.K, a.N, a.rows_per_frustum = M, K, N, rpf
         if pre:
-            a.w_x3, a.w_x3_stride = wpl.data_ptr(), K * N
+            a.w_x3, a.w_x3_stride = pf.data_ptr(), fstride
         assert hip_lib.t3d_pointmlp_fwd(C.byref(a), st) == 0
         dz, yv = _mk(dev, r.normal(size=(M, N)).astype(np.float32) * 0 + 1e-2), _mk(dev, np.ones((M, N), np.float32))
         coef = _mk(dev, np.stack([np.ones(N), np.full(N, 0.5), np.zeros(N)]).astype(np.float32))
@@ -1520,7 +1539,7 @@ def test_x3_weight_planes_are_exact_and_equal_the_in_kernel_split(hip_lib):
         d.dy, d.w, d.out = abi.DySrc(fptr(dz), fptr(yv), fptr(coef), iptr(None), fptr(None)), fptr(w), fptr(out)
         d.M, d.K, d.N, d.rows_per_frustum = M, K, N, rpf
         if pre:
-            d.w_x3, d.w_x3_stride = wpl.data_ptr(), K * N
+            d.w_x3, d.w_x3_stride = pd.data_ptr(), fstride
         assert hip_lib.t3d_pointmlp_dgrad(C.byref(d), st) == 0
         torch.cuda.synchronize()
         outs.append((y.cpu(), p1.cpu(), out.cpu()))
@@ -1604,14 +1623,12 @@ def test_x3_forward_variants_are_bit_identical_to_the_default(hip_lib, monkeypat
     sc, sh = torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev) * 0.1
     w = torch.randn(K, N, device=dev) / K ** 0.5
     bias = torch.randn(N, device=dev) * 0.1
-    planes = torch.zeros(3, K, N, dtype=torch.bfloat16, device=dev)
-    assert hip_lib.t3d_split_x3(fptr(w), C.c_void_p(planes.data_ptr()), K * N, K * N, st) == 0
-    assert torch.equal(planes.float().sum(0), w), 'h + m + l == w exactly'
+    pf, _, fstride = _x3_frag_planes(hip_lib, w, st)
     res = {}
-    modes = ('default', 'presplit', 'producer_consumer') + (('eight_waves',) if N % 256 == 0 else ())
+    modes = ('default', 'presplit', 'producer_consumer') + (('eight_waves', 'presplit_eight_waves') if N % 256 == 0 else ())
     for mode in modes:
         monkeypatch.setenv('T3D_X3_PC', '2' if mode == 'producer_consumer' else '0')
-        monkeypatch.setenv('T3D_X3_W8', '2' if mode == 'eight_waves' else '0')
+        monkeypatch.setenv('T3D_X3_W8', '2' if mode in ('eight_waves', 'presplit_eight_waves') else '0')
         o = [torch.zeros(M, N, device=dev)] + [torch.zeros(T, N, device=dev) for _ in range(4)] + \
             [torch.zeros(T, N, dtype=torch.int32, device=dev) for _ in range(2)]
         a = abi.PointMlpFwdArgs()
@@ -1619,8 +1636,8 @@ def test_x3_forward_variants_are_bit_identical_to_the_default(hip_lib, monkeypat
         a.w, a.bias, a.y, a.psum, a.psumsq = fptr(w), fptr(bias), fptr(o[0]), fptr(o[1]), fptr(o[2])
         a.pmax, a.pmin, a.pamax, a.pamin = fptr(o[3]), fptr(o[4]), iptr(o[5]), iptr(o[6])
         a.M, a.K, a.N, a.rows_per_frustum, a.arith = M, K, N, rpf, abi.ARITH_BF16X3
-        if mode == 'presplit':
-            a.w_x3, a.w_x3_stride = C.c_void_p(planes.data_ptr()), K * N
+        if mode in ('presplit', 'presplit_eight_waves'):
+            a.w_x3, a.w_x3_stride = C.c_void_p(pf.data_ptr()), fstride
         assert hip_lib.t3d_pointmlp_fwd(C.byref(a), st) == 0
         torch.cuda.synchronize()
         res[mode] = o

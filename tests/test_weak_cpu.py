@@ -146,7 +146,7 @@ def test_stage_c_with_reprojection_and_inactive_volume_matches_oracle():
 
 def test_weak_losses_evaluated_for_their_summaries_at_zero_weight():
     """The reference evaluates the reprojection / surface losses for its `Weak_Loss/...` summaries whatever their weights
-    (semisup_v1_sunrgbd.py:270-293); recipe a zeroes both weights.  With `c.WEAK_LOSS_SUMMARIES` (the drivers set it) the product
+    (semisup_v1_sunrgbd.py:270-293); recipe a zeroes both weights.  With `c.WEAK_LOSS_SUMMARIES` (the drivers set it with --weak_loss_summaries) the product
     evaluates them too: the values are the oracle's, the loss and EVERY gradient are bit for bit those of the graph without them,
     and no backward launch is added."""
     rt = Runtime(lib=FakeLib(), device='cpu')

@@ -202,7 +202,7 @@ def test_inactive_volume_and_all_sample_reprojection(hip_lib):
 
 
 def test_weak_loss_summaries_at_zero_weight_leave_the_step_bit_identical(hip_lib):
-    """`c.WEAK_LOSS_SUMMARIES` (the drivers' default) with the recipe's zero weights on the HIP path: the scheduled hipGraph step with
+    """`c.WEAK_LOSS_SUMMARIES` (the drivers' --weak_loss_summaries) with the recipe's zero weights on the HIP path: the scheduled hipGraph step with
     the extra launch keeps loss and weights of 4 steps bit for bit, and reports the two batch means the reference logs as
     `Weak_Loss/reprojection_loss` / `Weak_Loss/surface_loss` (values against the oracle: tests/test_weak_cpu.py on the specification
     library, test_weak_loss_values_and_gradients above on the kernel)."""

@@ -26,8 +26,23 @@ def timed(fn, R=20):
     return e0.elapsed_time(e1) / R * 1e3
 
 
+def frag_planes(lib, w, s):
+    """(forward planes, data-gradient planes, stride) of one [K, N] matrix in fragment order (t3d_split_x3_frag)"""
+    import numpy as np
+    K, N = w.shape
+    stride = (K * N + 7) // 8 * 8
+    pf = torch.zeros(3 * stride, dtype=torch.bfloat16, device=w.device)
+    pd = torch.zeros(3 * stride, dtype=torch.bfloat16, device=w.device)
+    raw, nblk = abi.x3_frag_table([(0, K, N)])
+    tab = torch.from_numpy(raw).to(w.device)
+    assert lib.t3d_split_x3_frag(fptr(w), C.c_void_p(pf.data_ptr()), C.c_void_p(pd.data_ptr()), stride, C.c_void_p(tab.data_ptr()), 1, nblk, s) == 0
+    torch.cuda.synchronize()
+    return pf, pd, stride
+
+
 def main():
     lib = abi.load(os.environ.get('T3D_LIB'))
+    frag = os.environ.get('T3D_BENCH_FRAG', '1') == '1'      # the weights as fragment-order planes (the engine's default); 0: in-kernel split
     M, rpf = int(os.environ.get('T3D_M', '32768')), 1024
     T = M // 128
     dev = 'cuda'
@@ -54,6 +69,9 @@ def main():
         else:
             a.y = fptr(y)
         a.M, a.K, a.N, a.rows_per_frustum = M, K, N, rpf
+        if frag and K % 32 == 0:
+            keep = frag_planes(lib, w, s)
+            a.w_x3, a.w_x3_stride = keep[0].data_ptr(), keep[2]
         act = torch.relu(x.double() * sc.double() + sh.double())
         ref = act[:4096] @ w.double() + bias.double()
         refsum = None
@@ -95,6 +113,9 @@ def main():
         d.w, d.out = fptr(w), fptr(out)
         d.prev_y, d.prev_scale, d.prev_shift, d.psum_dz, d.psum_dzy = fptr(x), fptr(sc), fptr(sh), fptr(p1), fptr(p2)
         d.M, d.K, d.N, d.rows_per_frustum = M, K, N, rpf
+        if frag and K % 32 == 0:
+            keep = frag_planes(lib, w, s)
+            d.w_x3, d.w_x3_stride = keep[1].data_ptr(), keep[2]
         wa = abi.PointMlpWgradArgs()
         wa.a = abi.ActSrc(fptr(x), K, 0, fptr(sc), fptr(sh), 1, fptr(None), 0)
         wa.dy, wa.slabs = d.dy, fptr(slabs)

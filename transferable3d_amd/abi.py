@@ -16,7 +16,7 @@ DTYPE_BY_NAME = {'f32': F32, 'bf16': BF16}
 ARITH_AUTO, ARITH_FP32_MFMA, ARITH_BF16X3, ARITH_BF16 = 0, 1, 2, 3      # t3d.h: T3D_ARITH_* (arithmetic of an fp32 GEMM launch)
 ARITH_BY_NAME = {'auto': ARITH_AUTO, 'fp32_mfma': ARITH_FP32_MFMA, 'bf16x3': ARITH_BF16X3}
 ARITH_NAMES = {ARITH_FP32_MFMA: 'fp32_mfma', ARITH_BF16X3: 'bf16x3', ARITH_BF16: 'bf16'}
-ABI_VERSION = 2
+ABI_VERSION = 3
 ERR_ABI = -4
 ACT_NONE, ACT_RELU, ACT_LEAKY_RELU, ACT_TANH = 0, 1, 2, 3
 ACT_BY_NAME = {None: ACT_NONE, 'relu': ACT_RELU, 'leaky_relu': ACT_LEAKY_RELU, 'tanh': ACT_TANH}
@@ -224,6 +224,21 @@ class StrongLossArgs(C.Structure):
                 ('total_losses', F), ('loss', F), ('center', F), ('reg_dims', F), ('reg_theta', F), ('iou2d', F), ('iou3d', F), ('B', i32)]
 
 
+class X3FragEntry(C.Structure):      # t3d_x3_frag_entry (t3d_split_x3_frag)
+    _fields_ = [('off', C.c_int64), ('K', C.c_int32), ('N', C.c_int32), ('fwd', C.c_int32), ('dgrad', C.c_int32), ('blk0', C.c_int32), ('reserved', C.c_int32)]
+
+
+def x3_frag_table(entries):
+    """(bytes of a t3d_x3_frag_entry table as a NumPy uint8 array, number of workgroups) for [(off, K, N), ...] (both arrangements)"""
+    import numpy as np
+    rec = np.zeros(len(entries), dtype=np.dtype([('off', '<i8'), ('K', '<i4'), ('N', '<i4'), ('fwd', '<i4'), ('dgrad', '<i4'), ('blk0', '<i4'), ('reserved', '<i4')]))
+    blk = 0
+    for i, (off, K, N) in enumerate(entries):
+        rec[i] = (off, K, N, 1, 1, blk, 0)
+        blk += (K * N // 8 + 255) // 256
+    return rec.view(np.uint8).copy(), blk
+
+
 class SlabDesc(C.Structure):
     _fields_ = [('slab_off', C.c_int64), ('grad_off', C.c_int64), ('numel', C.c_int32), ('n_slabs', C.c_int32)]
 
@@ -363,6 +378,7 @@ ENTRY_POINTS = {
     't3d_adam_tf_step': [F, F, F, F, C.c_int64, F, f32, f32, f32, f32, VP],
     't3d_momentum_step': [F, F, F, C.c_int64, F, f32, f32, VP],
     't3d_split_x3': [F, VP, C.c_int64, C.c_int64, VP],
+    't3d_split_x3_frag': [F, VP, VP, C.c_int64, VP, i32, i32, VP],
     't3d_dropout_mask': [F, C.c_int64, f32, C.c_uint32, F, VP],
     't3d_cast_bf16': [F, VP, C.c_int64, VP],
 }

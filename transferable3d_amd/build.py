@@ -126,7 +126,7 @@ def check_spills(remarks_by_source):
 # instructions with no MFMA between them.  The map of every such loop is written to build/x3_isa_map.txt (copied to profiles/ per round).
 ISA_MAX_BURST = 2
 ISA_MAX_VALU_RUN = 20      # the longest step is a piece's last: conversion + three plane stores + the refill's address arithmetic
-ISA_GATED = ('PathX3E', 'PathX3WE')      # mangled-name substrings: the default x3 kernels (not the opt-in PathX3P / PathX3PC forms)
+ISA_GATED = ('PathX3E', 'PathX3WE', 'PathX3PE', 'PathX3WPE')      # mangled-name substrings: the x3 kernels of the default program (not the PathX3PC experiment)
 
 
 def check_x3_isa(asm_path, out_path=None):

@@ -380,6 +380,7 @@ extern "C" int t3d_box_refine_step(const t3d_box_refine_step_args* a, t3d_stream
 }
 
 extern "C" int t3d_boxpc_rep(const t3d_boxpc_rep_args* a, t3d_stream_t stream) {
+  T3D_ABI_TAKE(boxpc_rep_args, a);
   if (a && a->struct_size != sizeof(*a)) return T3D_ERR_ABI;
   if (!a || !a->pc || !a->center || !a->dims || !a->theta || !a->rep) return T3D_ERR_ARG;
   if (a->y_dims_cls && !a->y_orient_cls) return T3D_ERR_ARG;

@@ -457,6 +457,7 @@ extern "C" int t3d_act_dropout(const t3d_act_dropout_args* a, t3d_stream_t strea
 }
 
 extern "C" int t3d_seg_head(const t3d_seg_head_args* a, t3d_stream_t stream) {
+  T3D_ABI_TAKE(seg_head_args, a);
   if (a && a->struct_size != sizeof(*a)) return T3D_ERR_ABI;
   if (!a || !a->y || !a->scale || !a->shift || !a->w || !a->bias || !a->pc || !a->logits || !a->mask || !a->part)
     return T3D_ERR_ARG;

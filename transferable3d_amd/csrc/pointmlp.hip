@@ -1010,6 +1010,28 @@ struct WLoaderX3 {
     return r;
   }
 };
+// A [K, N] fp32 weight matrix split beforehand into three bf16 planes IN MFMA-FRAGMENT ORDER (t3d_split_x3_frag, once per step behind
+// the optimiser): plane p, 16-deep reduction tile rt, 32-wide block nb of the other index, then the 64 lanes' eight elements
+//     frag[((p * RT + rt) * NB + nb) * 64 + lane][j] = Op[nb * 32 + (lane & 31)][rt * 16 + 8 * (lane >> 5) + j]
+// (Op[n][k] = w[k][n] for the forward, Op[k][n] = w[k][n] for the data gradient): exactly the B operand of one
+// v_mfma_f32_32x32x16_bf16, so a wave reads a fragment with ONE global_load_dwordx4 per lane -- 1 KB contiguous, no LDS image, no
+// conversion, no ds_write, no ds_read.  Round 6's ablations of the hand-placed iteration (profiles/r06_il_ablations.log) put the cost
+// of a k-tile in its LDS and global INSTRUCTIONS as much as in its vector ALU work (a ds_write_b64 or a fragment read costs the wave two
+// to three vector-instruction slots, a global load six); the weight operand was a third of all three.
+struct WLoaderX3F {
+  static constexpr bool FRAG = true;
+  const bf16_t* p;      // plane 0
+  long stride;          // elements between planes (= K * N)
+  int nb;               // 32-wide blocks of the lane index (N / 32 forward, K / 32 data gradient)
+  struct Raw {};
+  struct Coef {};
+  __device__ __forceinline__ bf16x8 gfrag(int plane, int c0, int red0, int lane) const {
+    const size_t uoff = (size_t)plane * (size_t)stride + ((size_t)(red0 >> 4) * (size_t)nb + (size_t)(c0 >> 5)) * 512u;      // uniform
+    return *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(p + uoff) + (unsigned)lane * 16u);
+  }
+};
+template <class L, class = void> struct IsFrag { static constexpr bool value = false; };
+template <class L> struct IsFrag<L, typename std::enable_if<L::FRAG>::type> { static constexpr bool value = true; };
 template <class L, class = void> struct HasAt { static constexpr bool value = false; };
 template <class L> struct HasAt<L, typename std::enable_if<L::HAS_AT>::type> { static constexpr bool value = true; };
 template <class L, class = void> struct PreSplit { static constexpr bool value = false; };
@@ -1027,6 +1049,9 @@ template <class L> struct PreSplit<L, typename std::enable_if<L::PRESPLIT>::type
 #endif
 #ifndef T3D_X3_SGB
 #define T3D_X3_SGB 0                // > 0: sched_group_barrier pipeline, that many VALU instructions behind each MFMA (see x3_iter)
+#endif
+#ifndef T3D_X3_LATE_M
+#define T3D_X3_LATE_M 1             // x3_iter_il: the m-plane fragments are read at the head of the iteration that multiplies them (ILSched)
 #endif
 #ifndef T3D_X3_IL
 #define T3D_X3_IL 1                 // 1: the hand-placed iteration (x3_iter_il): ONE MFMA, then its share of the staging pass, fenced
@@ -1143,7 +1168,7 @@ struct StagerX3 {
   // tile: none), then 5 / 5 / 6 / 5 of the split, then the last conversion with the three plane stores and the slot's refill.
   static constexpr int NU = 6;
   static constexpr int XCOST = std::is_empty<typename L::Coef>::value ? 0 : 8;
-  __device__ __forceinline__ static constexpr int il_cost(int u) { return u == 0 ? XCOST : (u == 3 ? 6 : 5); }
+  __host__ __device__ __forceinline__ static constexpr int il_cost(int u) { return u == 0 ? XCOST : (u == 3 ? 6 : 5); }
   float ilx[4], ilr0, ilr1;
   unsigned ilh[2], ilm[2], ill[2];
   __device__ __forceinline__ static unsigned il_pk(float a, float b) {
@@ -1190,6 +1215,12 @@ struct StagerX3 {
       // (not when the loader computes nothing -- a weight tile: the asm would tie single registers to parts of the load's 128-bit
       // result, the allocator then copies them out at the loop's back edge, behind s_waitcnt vmcnt(0) on a load two gaps old)
       if constexpr (XCOST != 0) T3D_PIN4(ilx[0], ilx[1], ilx[2], ilx[3]);
+      // The slot's coefficients (batch-norm scale / shift, dy's c0 c1 c2) are requested HERE, right behind their last use, not with
+      // the last piece's refill: as the youngest loads of the iteration, a register copy of them at the loop's back edge (the
+      // allocator's, for a v_fmac that accumulates into one) waited with s_waitcnt vmcnt(0) on loads two gaps old.
+#ifndef T3D_ABL_IL_NOLOAD
+      if constexpr (Q == NV - 1) { asm volatile("" ::: "memory"); il_fetch_head<S>(l, red_fetch, tid); asm volatile("" ::: "memory"); }
+#endif
     } else if constexpr (U == 1) {
       il_h<0>();
       T3D_PIN3(ilh[0], ilr0, ilr1);
@@ -1217,9 +1248,9 @@ struct StagerX3 {
 #endif
 #if defined(T3D_ABL_IL_NOLOAD)       // timing ablation (wrong results): the slot is never refilled (the first tile is staged again and again)
 #elif defined(T3D_ABL_IL_NOLOAD_R)   // ... only type-R operands (the [M, C] stream of forward / data gradient) are not refilled
-      if constexpr (!TYPE_R) { il_fetch_piece<S>(l, red_fetch, tid, Q); if constexpr (Q == NV - 1) il_fetch_head<S>(l, red_fetch, tid); }
+      if constexpr (!TYPE_R) il_fetch_piece<S>(l, red_fetch, tid, Q);
 #elif defined(T3D_ABL_IL_NOLOAD_C)   // ... only type-C operands
-      if constexpr (TYPE_R) { il_fetch_piece<S>(l, red_fetch, tid, Q); if constexpr (Q == NV - 1) il_fetch_head<S>(l, red_fetch, tid); }
+      if constexpr (TYPE_R) il_fetch_piece<S>(l, red_fetch, tid, Q);
 #elif defined(T3D_ABL_IL_LOADDUMMY)  // ... the loads are issued, their results never used (issue cost without the waits)
       if constexpr (AT) {
         const size_t uoff = TYPE_R ? (size_t)lane0 * (size_t)ld + (size_t)red_fetch : (size_t)red_fetch * (size_t)ld + (size_t)lane0;
@@ -1229,7 +1260,6 @@ struct StagerX3 {
       }
 #else
       il_fetch_piece<S>(l, red_fetch, tid, Q);
-      if constexpr (Q == NV - 1) il_fetch_head<S>(l, red_fetch, tid);
 #endif
       asm volatile("" ::: "memory");
     }
@@ -1283,7 +1313,7 @@ struct StagerX3W {
     for (int q = 0; q < NV; ++q) store_piece<S>(l, tile, tid, q);
   }
   static constexpr int NU = 1;      // x3_iter_il: a piece is one copy (ds_write_b128) and its refill
-  __device__ __forceinline__ static constexpr int il_cost(int) { return 3; }
+  __host__ __device__ __forceinline__ static constexpr int il_cost(int) { return 3; }
   template <int S, int Q, int U>
   __device__ __forceinline__ void il_step(const L& l, bf16_t* tile, int tid, int red_fetch) {
     asm volatile("" ::: "memory");
@@ -1292,6 +1322,23 @@ struct StagerX3W {
     asm volatile("" ::: "memory");
   }
 };
+
+// ... of a weight matrix in fragment order (WLoaderX3F): nothing is staged -- the main loop reads the fragments from global memory
+template <int DIM, bool TYPE_R, class L, int PF_ = T3D_X3_PF>
+struct StagerX3F {
+  static constexpr int PF = PF_;
+  static constexpr bool FROM_GLOBAL = true;
+  static constexpr int NV = 0, NU = 1, PLANE = 0, LDS_ELEMS = 0;
+  __host__ __device__ __forceinline__ static constexpr int il_cost(int) { return 0; }
+  int lane0;      // first column of the workgroup's tile (the fragment planes are indexed by absolute column)
+  __device__ __forceinline__ void init(const L&, int lane0_, int) { lane0 = lane0_; }
+  __device__ __forceinline__ bf16x8 gfrag(const L& l, int plane, int c_rel, int red0, int lane) const { return l.gfrag(plane, lane0 + c_rel, red0, lane); }
+  template <int S> __device__ __forceinline__ void fetch(const L&, int, int) {}
+  template <int S> __device__ __forceinline__ void store(const L&, bf16_t*, int) {}
+  template <int S, int Q, int U> __device__ __forceinline__ void il_step(const L&, bf16_t*, int, int) {}
+};
+template <class SB, class = void> struct FromGlobal { static constexpr bool value = false; };
+template <class SB> struct FromGlobal<SB, typename std::enable_if<SB::FROM_GLOBAL>::type> { static constexpr bool value = true; };
 
 // fragment of the tile's one MFMA step for the 32 operand rows / columns starting at c0 (cf. frag_h)
 template <bool TYPE_R, int DIM>
@@ -1440,43 +1487,70 @@ __device__ __forceinline__ void x3_iter_fp(SA& sa, SB& sb, const LA& la, const L
 template <class SA, class SB, int TM, int TN>
 struct ILSched {
   static constexpr int NM = 6 * TM * TN;                       // MFMAs = gaps of one iteration
+  // T3D_X3_LATE_M: the m-plane fragments of a tile (first needed by product 2, MFMA 2 TM TN) are read at the HEAD of the iteration that
+  // multiplies them, into the fragment set it is consuming, instead of with the other planes behind the barrier of the iteration before:
+  // 12 instead of 18 LDS reads queue behind the barrier (the four waves of a workgroup pass it together; SQ_LDS_CMD_FIFO_FULL and
+  // SQ_WAIT_INST_LDS doubled when the hand-placed iteration packed the 18 reads into four gaps), 6 are spread over the first gaps.
+  static constexpr bool GB = FromGlobal<SB>::value;            // the second operand's fragments come from global memory (StagerX3F)
+  static constexpr int NG = GB ? 3 * TN : 0;                   // ... 3 TN loads of the NEXT tile's fragments, first in the list (they wait for nothing)
+  static constexpr int NLA = (T3D_X3_IL && T3D_X3_LATE_M) ? TM : 0, NLB = (T3D_X3_IL && T3D_X3_LATE_M && !GB) ? TN : 0;
+  static constexpr int NL = NLA + NLB;                         // late reads: a1[*] then b1[*] of the CURRENT tile
   static constexpr int NSA = SA::NV * SA::NU, NSB = SB::NV * SB::NU;
-  static constexpr int BAR = NSA + NSB;                        // index of the barrier step
-  static constexpr int NF = 3 * (TM + TN);                     // fragment reads (one ds_read_b128 or two ds_read_b64_tr_b16 each)
+  static constexpr int L0 = 0;                                 // first late read: FIRST in the list (product 2 needs them at MFMA 2 TM TN)
+  static constexpr int G0 = NL;                                // first global fragment load
+  static constexpr int ST0 = NG + NL;                          // first staging step
+  static constexpr int BAR = ST0 + NSA + NSB;                  // index of the barrier step
+  // fragment reads of the NEXT tile from LDS behind the barrier, in groups a2 b0 a0 b2 [a1 b1] (b groups only when B is staged in LDS)
+  static constexpr int NGRP = (NLA ? 2 : 3) * (GB ? 1 : 2);
+  __host__ __device__ __forceinline__ static constexpr int grp_is_b(int g) { return GB ? 0 : (g & 1); }
+  __host__ __device__ __forceinline__ static constexpr int grp_plane(int g) {
+    const int o = GB ? g : g / 2;                              // 0, 1, 2 -> the pair (a2 b0), (a0 b2), (a1 b1)
+    return o == 0 ? (grp_is_b(g) ? 0 : 2) : o == 1 ? (grp_is_b(g) ? 2 : 0) : 1;
+  }
+  __host__ __device__ __forceinline__ static constexpr int grp_n(int g) { return grp_is_b(g) ? TN : TM; }
+  __host__ __device__ __forceinline__ static constexpr int count_nf() { int n = 0; for (int g = 0; g < NGRP; ++g) n += grp_n(g); return n; }
+  static constexpr int NF = count_nf();
   static constexpr int NSTEP = BAR + 1 + NF;
-  __device__ __forceinline__ static constexpr int cost(int k) {
-    if (k < NSA) return SA::il_cost(k % SA::NU);
-    if (k < BAR) return SB::il_cost((k - NSA) % SB::NU);
+  __host__ __device__ __forceinline__ static constexpr int cost(int k) {
+    if (k < NL) return 2;
+    if (k < ST0) return 6;
+    if (k < ST0 + NSA) return SA::il_cost((k - ST0) % SA::NU);
+    if (k < BAR) return SB::il_cost((k - ST0 - NSA) % SB::NU);
     if (k == BAR) return 0;
     return 2;
   }
-  __device__ __forceinline__ static constexpr int total() { int w = 0; for (int k = 0; k < NSTEP; ++k) w += cost(k); return w; }
-  __device__ __forceinline__ static constexpr int gap_of(int k) {      // by the midpoint of the step's share of the total cost
+  __host__ __device__ __forceinline__ static constexpr int total() { int w = 0; for (int k = 0; k < NSTEP; ++k) w += cost(k); return w; }
+  __host__ __device__ __forceinline__ static constexpr int gap_of(int k) {      // by the midpoint of the step's share of the total cost
     int before = 0;
     for (int j = 0; j < k; ++j) before += cost(j);
     const int g = (2 * before + cost(k)) * NM / (2 * total());
     return g < NM ? g : NM - 1;
   }
-  __device__ __forceinline__ static constexpr int first_step(int gap) { int k = 0; while (k < NSTEP && gap_of(k) < gap) ++k; return k; }
-  // fragment read j: which operand, plane and 32-wide block
-  __device__ __forceinline__ static constexpr int frag_group(int j) {      // 0..5 = a2 b0 a0 b2 a1 b1
+  __host__ __device__ __forceinline__ static constexpr int first_step(int gap) { int k = 0; while (k < NSTEP && gap_of(k) < gap) ++k; return k; }
+  // fragment read j behind the barrier: its group and its 32-wide block
+  __host__ __device__ __forceinline__ static constexpr int frag_group(int j) {
     int g = 0;
-    while (true) { const int n = (g & 1) ? TN : TM; if (j < n) return g; j -= n; ++g; }
+    while (true) { const int n = grp_n(g); if (j < n) return g; j -= n; ++g; }
   }
-  __device__ __forceinline__ static constexpr int frag_index(int j) {
+  __host__ __device__ __forceinline__ static constexpr int frag_index(int j) {
     int g = 0;
-    while (true) { const int n = (g & 1) ? TN : TM; if (j < n) return j; j -= n; ++g; }
+    while (true) { const int n = grp_n(g); if (j < n) return j; j -= n; ++g; }
   }
 };
 
 template <int S, bool SYM, int TM, int TN, class SA, class SB, class LA, class LB, bool AR, int DIMA, bool BR, int DIMB>
-__device__ __forceinline__ void x3_iter_il(SA& sa, SB& sb, const LA& la, const LB& lb, bf16_t* smem, int cur, int red_fetch, int a0, int b0,
-                                           const FragsX3<TM, TN>& fc, FragsX3<TM, TN>& fn, f32x16 (&acc)[TM][TN],
+__device__ __forceinline__ void x3_iter_il(SA& sa, SB& sb, const LA& la, const LB& lb, bf16_t* smem, int cur, int red_next, int red_fetch, int a0, int b0,
+                                           FragsX3<TM, TN>& fc, FragsX3<TM, TN>& fn, f32x16 (&acc)[TM][TN],
                                            f32x16 (&accb)[SYM ? TM : 1][SYM ? TN : 1], f32x16 (&accc)[SYM ? TM : 1][SYM ? TN : 1], int tid) {
   using SC = ILSched<SA, SB, TM, TN>;
+  // the late reads land in gaps well ahead of the first MFMA of product 2 (index 2 TM TN), which multiplies them: a schedule that put
+  // them behind the global fragment loads had the eight-wave tiles multiply the m planes of the tile before last
+  static_assert(SC::NL == 0 || SC::gap_of(SC::NL - 1) + 1 < 2 * TM * TN, "late m-plane reads too late for product 2");
   constexpr int STAGE = SA::LDS_ELEMS + SB::LDS_ELEMS;
   bf16_t* An = smem + (cur ^ 1) * STAGE;
   bf16_t* Bn = An + SA::LDS_ELEMS;
+  const bf16_t* Ac = smem + cur * STAGE;
+  const bf16_t* Bc = Ac + SA::LDS_ELEMS;
   const int lane = tid & 63;
   static_for<SC::NM>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
@@ -1503,13 +1577,26 @@ __device__ __forceinline__ void x3_iter_il(SA& sa, SB& sb, const LA& la, const L
     constexpr int k0 = SC::first_step(i), k1 = SC::first_step(i + 1);
     static_for<k1 - k0>([&](auto jc) {
       constexpr int k = k0 + decltype(jc)::value;
-      if constexpr (k < SC::NSA) {
+      if constexpr (k < SC::NL) {                  // the current tile's m planes (T3D_X3_LATE_M)
+        constexpr int q = k - SC::L0;
+        asm volatile("" ::: "memory");
+        if constexpr (q < TM) fc.a[1][q] = frag_x<AR, DIMA>(Ac + SA::PLANE, a0 + q * 32, lane);
+        else fc.b[1][q - TM] = frag_x<BR, DIMB>(Bc + SB::PLANE, b0 + (q - TM) * 32, lane);
+        asm volatile("" ::: "memory");
+      } else if constexpr (k < SC::ST0) {          // the NEXT tile's weight fragments, straight from global memory (WLoaderX3F)
+        constexpr int kg = k - SC::G0, o = kg / TN, x = kg % TN, pl = o == 0 ? 0 : o == 1 ? 2 : 1;      // b0, b2, b1: the order the next products need them
+        if constexpr (SC::GB) {
+          asm volatile("" ::: "memory");
+          fn.b[pl][x] = sb.gfrag(lb, pl, b0 + x * 32, red_next, lane);
+          asm volatile("" ::: "memory");
+        }
+      } else if constexpr (k < SC::ST0 + SC::NSA) {
 #ifndef T3D_ABL_IL_NOSTAGE      // timing ablations (wrong results): no staging pass / no barrier / no fragment reads
-        sa.template il_step<S, k / SA::NU, k % SA::NU>(la, An, tid, red_fetch);
+        sa.template il_step<S, (k - SC::ST0) / SA::NU, (k - SC::ST0) % SA::NU>(la, An, tid, red_fetch);
 #endif
       } else if constexpr (k < SC::BAR) {
 #ifndef T3D_ABL_IL_NOSTAGE
-        sb.template il_step<S, (k - SC::NSA) / SB::NU, (k - SC::NSA) % SB::NU>(lb, Bn, tid, red_fetch);
+        sb.template il_step<S, (k - SC::ST0 - SC::NSA) / SB::NU, (k - SC::ST0 - SC::NSA) % SB::NU>(lb, Bn, tid, red_fetch);
 #endif
       } else if constexpr (k == SC::BAR) {
 #ifndef T3D_ABL_IL_NOBAR
@@ -1517,12 +1604,13 @@ __device__ __forceinline__ void x3_iter_il(SA& sa, SB& sb, const LA& la, const L
 #endif
       } else {
         constexpr int j = k - SC::BAR - 1, g = SC::frag_group(j), x = SC::frag_index(j);
-        constexpr int pl = g < 2 ? (g == 0 ? 2 : 0) : g < 4 ? (g == 2 ? 0 : 2) : 1;
+        constexpr int pl = SC::grp_plane(g);
+        constexpr bool isb = SC::grp_is_b(g) != 0;
 #ifdef T3D_ABL_IL_NOFRAG
-        if constexpr ((g & 1) == 0) fn.a[pl][x] = fc.a[pl][x]; else fn.b[pl][x] = fc.b[pl][x];
+        if constexpr (!isb) fn.a[pl][x] = fc.a[pl][x]; else fn.b[pl][x] = fc.b[pl][x];
 #else
         asm volatile("" ::: "memory");
-        if constexpr ((g & 1) == 0) fn.a[pl][x] = frag_x<AR, DIMA>(An + pl * SA::PLANE, a0 + x * 32, lane);
+        if constexpr (!isb) fn.a[pl][x] = frag_x<AR, DIMA>(An + pl * SA::PLANE, a0 + x * 32, lane);
         else fn.b[pl][x] = frag_x<BR, DIMB>(Bn + pl * SB::PLANE, b0 + x * 32, lane);
         asm volatile("" ::: "memory");
 #endif
@@ -1616,14 +1704,24 @@ __device__ __forceinline__ void gemm_mainloop_x3(SA& sa, SB& sb, const LA& la, c
   {
 #if T3D_X3_IL
 #define T3D_X3_ITER_FP(S_, T_, FC_, FN_) \
-  x3_iter_il<S_, SYM, TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, cur, tile_red((T_) + 1 + PF), a0, b0, FC_, FN_, acc, accb, accc, tid)
+  x3_iter_il<S_, SYM, TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, cur, tile_red((T_) + 1), tile_red((T_) + 1 + PF), a0, b0, FC_, FN_, acc, accb, accc, tid)
 #else
 #define T3D_X3_ITER_FP(S_, T_, FC_, FN_) \
   x3_iter_fp<S_, SYM, TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, cur, tile_red((T_) + 1 + PF), a0, b0, FC_, FN_, acc, accb, accc, tid)
 #endif
     constexpr int SODD = PF == 2 ? 1 : 0;      // the slot of tile t + 1 for even t
     FragsX3<TM, TN> f0, f1;
-    load_frags_x3<AR, DIMA, SA::PLANE, BR, DIMB, SB::PLANE>(smem, smem + SA::LDS_ELEMS, a0, b0, tid & 63, f0);
+    if constexpr (FromGlobal<SB>::value) {      // (A from the LDS image, the weight fragments from global memory)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) f0.a[pl][tm] = frag_x<AR, DIMA>(smem + pl * SA::PLANE, a0 + tm * 32, tid & 63);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) f0.b[pl][tn] = sb.gfrag(lb, pl, b0 + tn * 32, tile_red(0), tid & 63);
+      }
+    } else {
+      load_frags_x3<AR, DIMA, SA::PLANE, BR, DIMB, SB::PLANE>(smem, smem + SA::LDS_ELEMS, a0, b0, tid & 63, f0);
+    }
     int t = 0;
     for (; t + 2 < nt; t += 2) {
       T3D_X3_ITER_FP(SODD, t, f0, f1);
@@ -1631,10 +1729,23 @@ __device__ __forceinline__ void gemm_mainloop_x3(SA& sa, SB& sb, const LA& la, c
       T3D_X3_ITER_FP(0, t + 1, f1, f0);
       cur ^= 1;
     }
+    // (T3D_X3_LATE_M: the m planes of the last tile are read here -- no iteration follows that would read them at its head)
+    auto load_m = [&](FragsX3<TM, TN>& f, const bf16_t* st) {
+#if T3D_X3_IL && T3D_X3_LATE_M
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) f.a[1][tm] = frag_x<AR, DIMA>(st + SA::PLANE, a0 + tm * 32, tid & 63);
+      if constexpr (!FromGlobal<SB>::value) {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) f.b[1][tn] = frag_x<BR, DIMB>(st + SA::LDS_ELEMS + SB::PLANE, b0 + tn * 32, tid & 63);
+      }
+#endif
+    };
     if (t + 1 < nt) {      // two tiles left
       T3D_X3_ITER_FP(SODD, t, f0, f1);
+      load_m(f1, smem + (cur ^ 1) * STAGE);
       mma_x3_f<SYM, TM, TN>(f1, acc, accb, accc, [](int) {});
     } else {
+      load_m(f0, smem + cur * STAGE);
       mma_x3_f<SYM, TM, TN>(f0, acc, accb, accc, [](int) {});
     }
 #undef T3D_X3_ITER_FP
@@ -1911,16 +2022,16 @@ struct PathX3 {
   template <int DIM, bool TYPE_R, class L, int PF, bool IS_A = false> using Stg = StagerX3<DIM, TYPE_R, L>;
 };
 // the loader of a layer's [K, N] weight matrix for a path (fp32 / bf16 copy: rows x cols with bounds; x3 planes: whole tiles)
-template <class WL, class Args>
+template <class WL, bool FWD = true, class Args>      // FWD: the forward arrangement of the fragment planes (lane index = N); else the data gradient's (= K)
 __device__ __forceinline__ WL make_wloader(const Args& p) {
-  if constexpr (PreSplit<WL>::value) return WL{reinterpret_cast<const bf16_t*>(p.w_x3), (long)p.w_x3_stride, p.N};
+  if constexpr (IsFrag<WL>::value) return WL{reinterpret_cast<const bf16_t*>(p.w_x3), (long)p.w_x3_stride, FWD ? p.N / 32 : p.K / 32};
   else return WL{p.w, p.N, p.K, p.N};
 }
-struct PathX3P : PathX3 {      // ... with the layer's weight matrix split beforehand (t3d_pointmlp_fwd_args.w_x3)
-  typedef WLoaderX3 WL;
-  typedef WLoaderX3 WLX;
+struct PathX3P : PathX3 {      // ... with the layer's weight matrix split beforehand, in fragment order (t3d_pointmlp_fwd_args.w_x3: WLoaderX3F)
+  typedef WLoaderX3F WL;
+  typedef WLoaderX3F WLX;
   template <int DIM, bool TYPE_R, class L, int PF, bool IS_A = false>
-  using Stg = std::conditional_t<PreSplit<L>::value, StagerX3W<DIM, TYPE_R, L>, StagerX3<DIM, TYPE_R, L>>;
+  using Stg = std::conditional_t<IsFrag<L>::value, StagerX3F<DIM, TYPE_R, L>, StagerX3<DIM, TYPE_R, L>>;
 };
 // ... with EIGHT waves per workgroup (2 x 4 waves of 64 x 64: a 128 x 256 output tile).  The staged A tile serves twice the columns: a
 // quarter fewer staged elements -- loads, batch-norm / ReLU, three-way splits, LDS stores -- per MFMA than two 128 x 128 workgroups, which
@@ -1929,6 +2040,12 @@ struct PathX3P : PathX3 {      // ... with the layer's weight matrix split befor
 struct PathX3W : PathX3 {
   static constexpr int WAVES = 8;
   template <int DIM, bool TYPE_R, class L, int PF, bool IS_A = false> using Stg = StagerX3<DIM, TYPE_R, L, T3D_X3_PF, 2 * NT>;
+};
+struct PathX3WP : PathX3W {      // ... and the weights in fragment order
+  typedef WLoaderX3F WL;
+  typedef WLoaderX3F WLX;
+  template <int DIM, bool TYPE_R, class L, int PF, bool IS_A = false>
+  using Stg = std::conditional_t<IsFrag<L>::value, StagerX3F<DIM, TYPE_R, L>, StagerX3<DIM, TYPE_R, L, T3D_X3_PF, 2 * NT>>;
 };
 template <class PR, class = void> struct WavesOf { static constexpr int value = 4; };
 template <class PR> struct WavesOf<PR, typename std::enable_if<(PR::WAVES > 0)>::type> { static constexpr int value = PR::WAVES; };
@@ -2798,7 +2915,7 @@ __device__ __forceinline__ void dgrad_body(const t3d_pointmlp_dgrad_args& p, flo
   const int row0 = tile_m * BM, col0 = tile_n * BN;
 
   LA la{p.dy, p.N, p.rows_per_frustum};
-  WL lb = make_wloader<WL>(p);
+  WL lb = make_wloader<WL, false>(p);
   SA sa; SB sb;
   sa.init(la, row0, tid);
   sb.init(lb, col0, tid);
@@ -4331,6 +4448,7 @@ int t3d_x3_stage1(const t3d_pointmlp_gram_args* g, const t3d_act_colsum_args* c,
 int t3d_x3_stage2(const t3d_pool_wgrad_finish_args* f, const t3d_pointmlp_dgrad_gram_args* d, const t3d_rider_set* r, bool wide,
                   int n_finish, int n_d, size_t lds_other, hipStream_t s);
 int t3d_x3_split(const float* src, void* planes, int64_t n, int64_t plane_stride, hipStream_t s);
+int t3d_x3_split_frag(const float* params, void* pf, void* pd, int64_t stride, const t3d_x3_frag_entry* tab, int n, int n_blocks, hipStream_t s);
 int t3d_x3_dgrad(const t3d_pointmlp_dgrad_args* a, bool wide, hipStream_t s);
 int t3d_x3_wgrad(const t3d_pointmlp_wgrad_args* a, int tk, int tn, int n_blocks, hipStream_t s);
 int t3d_x3_gram(const t3d_pointmlp_gram_args* a, int tk, int n_blocks, hipStream_t s);
@@ -4357,6 +4475,61 @@ __global__ __launch_bounds__(256) void k_split_x3(const float* __restrict__ src,
   }
 }
 }  // namespace
+// the weights of every x3 layer as fragment-order planes (WLoaderX3F), both arrangements, ONE launch per step: entry e of the device
+// table = a [K, N] matrix at params + off; its planes live at the same offset of the plane buffers (a plane is as long as `params`)
+namespace {
+__global__ __launch_bounds__(256) void k_split_x3_frag(const float* __restrict__ params, bf16_t* __restrict__ pf, bf16_t* __restrict__ pd, long stride,
+                                                       const t3d_x3_frag_entry* __restrict__ tab, int n) {
+  // block -> (matrix, its 256 fragments): the table carries each matrix's first block (ascending); every matrix in parallel (one
+  // after the other, the ~20 matrices of a step took 16 us of dependent round trips for 20 MB)
+  int e = 0;
+  while (e + 1 < n && (int)blockIdx.x >= tab[e + 1].blk0) ++e;
+  const t3d_x3_frag_entry en = tab[e];
+  const float* w = params + en.off;
+  const long nfr = (long)en.K * en.N / 8;      // eight-element fragments per plane
+  const long f = (long)((int)blockIdx.x - en.blk0) * 256 + threadIdx.x;
+  if (f >= nfr) return;
+  const int lane = (int)(f & 63);
+  const long q = f >> 6;
+  float4 v0, v1, u0, u1;
+  if (en.fwd) {             // Op[n][k] = w[k][n]: lane index n, reduction k
+    const int NB = en.N / 32, nb = (int)(q % NB);
+    const long k0 = (q / NB) * 16 + 8 * (lane >> 5);
+    const float* src = w + k0 * en.N + nb * 32 + (lane & 31);
+    v0 = make_float4(src[0], src[en.N], src[2 * (long)en.N], src[3 * (long)en.N]);
+    v1 = make_float4(src[4 * (long)en.N], src[5 * (long)en.N], src[6 * (long)en.N], src[7 * (long)en.N]);
+  }
+  if (en.dgrad) {           // Op[k][n] = w[k][n]: lane index k, reduction n
+    const int KB = en.K / 32, kb = (int)(q % KB);
+    const long n0 = (q / KB) * 16 + 8 * (lane >> 5);
+    const float* src = w + (long)(kb * 32 + (lane & 31)) * en.N + n0;
+    u0 = *reinterpret_cast<const float4*>(src);
+    u1 = *reinterpret_cast<const float4*>(src + 4);
+  }
+  bf16x4 h0, m0, l0, h1, m1, l1;
+  if (en.fwd) {
+    split3(v0, h0, m0, l0);
+    split3(v1, h1, m1, l1);
+    bf16_t* d = pf + en.off + f * 8;
+    *reinterpret_cast<bf16x8*>(d) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+    *reinterpret_cast<bf16x8*>(d + stride) = __builtin_shufflevector(m0, m1, 0, 1, 2, 3, 4, 5, 6, 7);
+    *reinterpret_cast<bf16x8*>(d + 2 * stride) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+  if (en.dgrad) {
+    split3(u0, h0, m0, l0);
+    split3(u1, h1, m1, l1);
+    bf16_t* d = pd + en.off + f * 8;
+    *reinterpret_cast<bf16x8*>(d) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+    *reinterpret_cast<bf16x8*>(d + stride) = __builtin_shufflevector(m0, m1, 0, 1, 2, 3, 4, 5, 6, 7);
+    *reinterpret_cast<bf16x8*>(d + 2 * stride) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+}
+}  // namespace
+int t3d_x3_split_frag(const float* params, void* pf, void* pd, int64_t stride, const t3d_x3_frag_entry* tab, int n, int n_blocks, hipStream_t s) {
+  T3D_LAUNCH(k_split_x3_frag, dim3(n_blocks), dim3(256), 0, s, params, static_cast<bf16_t*>(pf), static_cast<bf16_t*>(pd), (long)stride, tab, n);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
 int t3d_x3_split(const float* src, void* planes, int64_t n, int64_t plane_stride, hipStream_t s) {
   long blocks = (n + 1023) / 1024;
   if (blocks > 2048) blocks = 2048;
@@ -4367,6 +4540,7 @@ int t3d_x3_split(const float* src, void* planes, int64_t n, int64_t plane_stride
 
 int t3d_x3_dgrad(const t3d_pointmlp_dgrad_args* a, bool wide, hipStream_t s) {
   const int tiles_m = a->M / 128;
+  if (a->w_x3 && (a->K % 32 != 0 || a->N % 16 != 0 || a->w_x3_stride < (int64_t)a->K * a->N)) return T3D_ERR_SHAPE;      // (fragment planes: whole blocks)
   if (a->w_x3) {
     if (wide) launch_lds(k_pointmlp_dgrad<128, false, PathX3P>, dim3(tiles_m * (a->K / 128)), lds_dgrad_x3(128), s, *a);
     else launch_lds(k_pointmlp_dgrad<64, false, PathX3P>, dim3(tiles_m * (a->K / 64)), lds_dgrad_x3(64), s, *a);
@@ -4405,20 +4579,29 @@ int t3d_x3_dgrad_gram(const t3d_pointmlp_dgrad_gram_args* a, bool wide, hipStrea
 
 int t3d_x3_fwd(const t3d_pointmlp_fwd_args* a, const t3d_rider_set* r, hipStream_t s) {
   const int tiles_m = a->M / 128, nr = r ? r->n_wg : 0;
-  const bool pre = a->w_x3 != nullptr;      // the weights arrive as three bf16 planes (t3d_split_x3)
+  const bool pre = a->w_x3 != nullptr;      // the weights arrive as three bf16 planes in fragment order (t3d_split_x3_frag, forward arrangement)
+  if (pre && (a->N % 32 != 0 || a->K % 16 != 0 || a->w_x3_stride < (int64_t)a->K * a->N)) return T3D_ERR_SHAPE;
   const char* e = getenv("T3D_X3_FWD128_MIN");      // (fewest 128-wide tiles for which the forward takes them; experiments)
   const long min_tiles = e ? atol(e) : 512;
   // eight-wave 128 x 256 tiles where a launch has at least two rounds of them (one workgroup per CU: with a single round nothing
   // covers a workgroup's prologue and epilogue, and 512 -> 256 at M = 32768 measured 57.5 us against 56.7; with two or more, 256 -> 512
   // 52.3 against 56.6 and 128 -> 1024 57.3 against 60.5, profiles/r05_w8.log).  T3D_X3_W8=0: never; =2: whenever N % 256 == 0
   const int w8 = []() { const char* e_ = getenv("T3D_X3_W8"); return e_ ? atoi(e_) : T3D_X3_W8_DEFAULT; }();
-  if (w8 && !pre && a->N % 256 == 0 && (w8 == 2 || (long)tiles_m * (a->N / 256) >= 512)) {
+  if (w8 && a->N % 256 == 0 && (w8 == 2 || (long)tiles_m * (a->N / 256) >= 512)) {
     const dim3 grid(tiles_m * (a->N / 256) + nr);
     const size_t lds = lds_with(lds_fwd_x3(256), r);
-    if (r) {
+    if (r && pre) {
+      auto kern = k_pointmlp_fwd_w8_r<256, PathX3WP>;
+      allow_lds(reinterpret_cast<const void*>(kern), lds);
+      T3D_LAUNCH(kern, grid, dim3(2 * NT), lds, s, *a, *r);
+    } else if (r) {
       auto kern = k_pointmlp_fwd_w8_r<256, PathX3W>;
       allow_lds(reinterpret_cast<const void*>(kern), lds);
       T3D_LAUNCH(kern, grid, dim3(2 * NT), lds, s, *a, *r);
+    } else if (pre) {
+      auto kern = k_pointmlp_fwd_w8<256, PathX3WP>;
+      allow_lds(reinterpret_cast<const void*>(kern), lds);
+      T3D_LAUNCH(kern, grid, dim3(2 * NT), lds, s, *a);
     } else {
       auto kern = k_pointmlp_fwd_w8<256, PathX3W>;
       allow_lds(reinterpret_cast<const void*>(kern), lds);
@@ -4461,6 +4644,7 @@ int t3d_x3_fwd(const t3d_pointmlp_fwd_args* a, const t3d_rider_set* r, hipStream
 
 int t3d_x3_bwd(const t3d_pointmlp_dgrad_args* d, const t3d_pointmlp_wgrad_args* w, const t3d_rider_set* r, int tk, int tn, bool wide,
                int n_w, int n_d, hipStream_t s) {
+  if (d->w_x3 && (d->K % 32 != 0 || d->N % 16 != 0 || d->w_x3_stride < (int64_t)d->K * d->N)) return T3D_ERR_SHAPE;
   const dim3 grid(n_w + n_d + (r ? r->n_wg : 0));
 #define T3D_BWDX_P(DBN, TK, TN_, PR_)                                                             \
   do {                                                                                             \
@@ -4556,6 +4740,7 @@ int t3d_x3_stage2(const t3d_pool_wgrad_finish_args* f, const t3d_pointmlp_dgrad_
 extern "C" int t3d_pointmlp_fwd(const t3d_pointmlp_fwd_args* a, t3d_stream_t stream) { return t3d_pointmlp_fwd_r(a, nullptr, stream); }
 
 extern "C" int t3d_pointmlp_fwd_r(const t3d_pointmlp_fwd_args* a, const t3d_rider_set* r, t3d_stream_t stream) {
+  T3D_ABI_TAKE(pointmlp_fwd_args, a);
   if (a && a->struct_size != sizeof(*a)) return T3D_ERR_ABI;
   if (r && !riders_ok(r)) return T3D_ERR_ARG;
   if (!a || !a->w || !a->psum || !a->psumsq || !act_ok(a->a, a->K)) return T3D_ERR_ARG;
@@ -4696,6 +4881,7 @@ static bool dgrad_wide(const t3d_pointmlp_dgrad_args* a) {
 }
 
 extern "C" int t3d_pointmlp_dgrad(const t3d_pointmlp_dgrad_args* a, t3d_stream_t stream) {
+  T3D_ABI_TAKE(pointmlp_dgrad_args, a);
   const int rc = check_dgrad(a);
   if (rc != T3D_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -4813,6 +4999,7 @@ static void wgrad_tile(const t3d_pointmlp_wgrad_args* a, int* tk, int* tn) {
 extern "C" int t3d_pointmlp_wgrad(const t3d_pointmlp_wgrad_args* a, t3d_stream_t stream) { return t3d_pointmlp_wgrad_r(a, nullptr, stream); }
 
 extern "C" int t3d_pointmlp_wgrad_r(const t3d_pointmlp_wgrad_args* a, const t3d_rider_set* r, t3d_stream_t stream) {
+  T3D_ABI_TAKE(pointmlp_wgrad_args, a);
   if (r && !riders_ok(r)) return T3D_ERR_ARG;
   const int rc = check_wgrad(a);
   if (rc != T3D_OK) return rc;
@@ -4933,6 +5120,7 @@ static bool dgrad_gram_wide(const t3d_pointmlp_dgrad_gram_args* a) {
 }
 
 extern "C" int t3d_pointmlp_dgrad_gram(const t3d_pointmlp_dgrad_gram_args* a, t3d_stream_t stream) {
+  T3D_ABI_TAKE(pointmlp_dgrad_gram_args, a);
   const int rc = check_dgrad_gram(a);
   if (rc != T3D_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -4974,6 +5162,7 @@ static int gram_tile(const t3d_pointmlp_gram_args* a) {      // square tiles onl
 }
 
 extern "C" int t3d_pointmlp_gram(const t3d_pointmlp_gram_args* a, t3d_stream_t stream) {
+  T3D_ABI_TAKE(pointmlp_gram_args, a);
   if (check_gram(a) == T3D_OK && gram1_ok(a)) {
     const dim3 grid(a->M / a->rows_per_split);
     if (a->K == 128) launch_lds1(k_gram1<128, 128>, grid, lds_gram1(128, 128), static_cast<hipStream_t>(stream), *a);
@@ -5005,6 +5194,8 @@ extern "C" int t3d_pointmlp_bwd(const t3d_pointmlp_dgrad_args* d, const t3d_poin
 
 extern "C" int t3d_pointmlp_bwd_r(const t3d_pointmlp_dgrad_args* d, const t3d_pointmlp_wgrad_args* w, const t3d_rider_set* r,
                                   t3d_stream_t stream) {
+  T3D_ABI_TAKE(pointmlp_dgrad_args, d);
+  T3D_ABI_TAKE(pointmlp_wgrad_args, w);
   if (r && !riders_ok(r)) return T3D_ERR_ARG;
   int rc = check_dgrad(d);
   if (rc != T3D_OK) return rc;
@@ -5120,6 +5311,7 @@ extern "C" int t3d_pool_bwd_stage1(const t3d_pointmlp_gram_args* g, const t3d_ac
 
 extern "C" int t3d_pool_bwd_stage1_r(const t3d_pointmlp_gram_args* g, const t3d_act_colsum_args* c,
                                      const t3d_pool_bwd_prep_args* q, const t3d_rider_set* r, t3d_stream_t stream) {
+  T3D_ABI_TAKE(pointmlp_gram_args, g);
   if (r && !riders_ok(r)) return T3D_ERR_ARG;
   int rc = check_gram(g);
   if (rc != T3D_OK) return rc;
@@ -5186,6 +5378,7 @@ extern "C" int t3d_pool_bwd_stage2(const t3d_pool_wgrad_finish_args* f, const t3
 
 extern "C" int t3d_pool_bwd_stage2_r(const t3d_pool_wgrad_finish_args* f, const t3d_pointmlp_dgrad_gram_args* d,
                                      const t3d_rider_set* r, t3d_stream_t stream) {
+  T3D_ABI_TAKE(pointmlp_dgrad_gram_args, d);
   if (r && !riders_ok(r)) return T3D_ERR_ARG;
   int rc = check_finish(f);
   if (rc != T3D_OK) return rc;
@@ -5247,6 +5440,14 @@ extern "C" int t3d_split_x3(const float* src, void* planes, int64_t n, int64_t p
       (plane_stride & 3))
     return T3D_ERR_ARG;
   return t3d_x3_split(src, planes, n, plane_stride, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int t3d_split_x3_frag(const float* params, void* planes_fwd, void* planes_dgrad, int64_t plane_stride, const t3d_x3_frag_entry* table,
+                                 int n_entries, int n_blocks, t3d_stream_t stream) {
+  if (!params || !planes_fwd || !planes_dgrad || !table || n_entries <= 0 || n_blocks <= 0 || plane_stride <= 0 || (plane_stride & 7) ||
+      (reinterpret_cast<uintptr_t>(params) & 15) || (reinterpret_cast<uintptr_t>(planes_fwd) & 15) || (reinterpret_cast<uintptr_t>(planes_dgrad) & 15))
+    return T3D_ERR_ARG;
+  return t3d_x3_split_frag(params, planes_fwd, planes_dgrad, plane_stride, table, n_entries, n_blocks, static_cast<hipStream_t>(stream));
 }
 
 // ---- does the `_r` launcher host a rider set for these arguments? (1 / 0; negative: the arguments are rejected) ----

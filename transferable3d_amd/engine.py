@@ -204,7 +204,10 @@ class Plan:
 # 512 -> 256 57.9 -> 61.3 us, 128 -> 1024 61.3 -> 58.0, 256 -> 512 58.3 -> 57.7, 128 -> 256 20.1 -> 18.8, 128 -> 128 13.3 -> 12.4;
 # fused backward 512 -> 256 117 -> 127, 128 -> 256 41.0 -> 42.9, 64 -> 64 9.3 -> 9.9: the count of vector instructions is not what
 # bounds these kernels.  Off by default.)
-X3_PRESPLIT = os.environ.get('T3D_X3', '1') != '0' and os.environ.get('T3D_X3_PRESPLIT', '0') == '1'
+# Round 6: the planes are written in MFMA-FRAGMENT order (t3d_split_x3_frag, one launch per step for every layer, a forward and a
+# data-gradient arrangement) and the kernels read the weight operand of every MFMA straight from them -- no LDS image, no conversion, no
+# ds_write, no fragment ds_read for that operand.  On by default (T3D_X3_PRESPLIT=0: the in-kernel split of rounds 4-5).
+X3_PRESPLIT = os.environ.get('T3D_X3', '1') != '0' and os.environ.get('T3D_X3_PRESPLIT', '1') == '1'
 
 
 class VarStore:
@@ -268,6 +271,34 @@ class VarStore:
         if not (0 <= off and off + w.numel() <= self.params.numel() and w.is_contiguous()) or off % 4:
             return None, 0
         return self.enable_x3().data_ptr() + 2 * off, self.params.numel()
+
+    def x3_frag(self, w, K, N):
+        """Registers the [K, N] view `w` of the parameter buffer for t3d_split_x3_frag (both arrangements) and returns
+        ((forward planes address, plane stride), (data-gradient planes address, plane stride)); ((None, 0), (None, 0)) if the view
+        cannot take part (not in the buffer, offset not a multiple of 8 elements, K or N not a multiple of 32)."""
+        off = (w.data_ptr() - self.params.data_ptr()) // 4
+        none = ((None, 0), (None, 0))
+        if not (0 <= off and off + w.numel() <= self.params.numel() and w.is_contiguous()) or off % 8 or K % 32 or N % 32 or w.numel() != K * N:
+            return none
+        n = self.params.numel()
+        stride = (n + 7) // 8 * 8
+        if getattr(self, 'x3_frag_planes', None) is None:
+            self.x3_frag_planes = (self.rt.zeros(3 * stride, dtype=torch.bfloat16), self.rt.zeros(3 * stride, dtype=torch.bfloat16))
+            self.x3_frag_entries, self.x3_frag_stride, self.x3_frag_table = {}, stride, None
+        self.x3_frag_entries[off] = (K, N)
+        self.x3_frag_table = None            # rebuilt by frag_table()
+        pf, pd = self.x3_frag_planes
+        return (pf.data_ptr() + 2 * off, stride), (pd.data_ptr() + 2 * off, stride)
+
+    def frag_table(self):
+        """(device table of t3d_x3_frag_entry, number of entries, number of workgroups) of every registered matrix; None if there is none."""
+        ent = getattr(self, 'x3_frag_entries', None)
+        if not ent:
+            return None
+        if self.x3_frag_table is None:
+            raw, blocks = abi.x3_frag_table([(off, K, N) for off, (K, N) in sorted(ent.items())])
+            self.x3_frag_table = (torch.from_numpy(raw).to(self.rt.device), len(ent), blocks)
+        return self.x3_frag_table
 
     def bf16_view(self, w):
         """The bf16 twin of a view `w` of the fp32 parameter buffer (same element offset, same shape)."""
@@ -418,7 +449,8 @@ class PointLayer:
         # what the GEMM kernels read as `w`: the fp32 weights, or their bf16 copy (refreshed every step: Graph.emit_cast_weights)
         self.w_mm = vs.bf16_view(w) if self.dt == abi.BF16 else w
         # fp32 layers on the three-term bf16 path: the weights pre-split once per step (T3D_X3_PRESPLIT=0: split in every tile)
-        self.w_x3 = vs.x3_ptr(w) if (self.dt == abi.F32 and X3_PRESPLIT and rt.device.type == 'cuda') else (None, 0)
+        self.w_x3, self.w_x3_d = vs.x3_frag(w, K, N) if (self.dt == abi.F32 and X3_PRESPLIT and rt.device.type == 'cuda' and rt.arith != abi.ARITH_FP32_MFMA) \
+            else ((None, 0), (None, 0))
         assert not (self.dt == abi.BF16 and pool and not self.gram), "bf16: max-pooled layers take the Gram-form backward"
         self.bias = bias if bias is not None else vs.const(scope + '/biases', (N,), 0.0)
         if bn:
@@ -720,7 +752,7 @@ class PointLayer:
         a = abi.PointMlpDgradArgs()
         a.arith = self.g.rt.arith
         a.dy, a.w, a.add_in, a.dtype = self.dy_struct(), fptr(self.w_mm), fptr(add_in), self.dt
-        a.w_x3, a.w_x3_stride = self.w_x3 if self.NA == self.N else (None, 0)
+        a.w_x3, a.w_x3_stride = self.w_x3_d if self.NA == self.N else (None, 0)      # (the data-gradient arrangement of the fragment planes)
         if prev is not None:
             prev._ensure_bwd_buffers()
             assert not prev.pool

@@ -89,10 +89,12 @@ class Graph:
         fp32 path on the bf16 matrix pipe: refresh the three bf16 planes of the weights (t3d_split_x3), if any layer asked for them."""
         vs, lib = self.vars, self.rt.lib
         if self.dt != abi.BF16:
-            px = getattr(vs, 'params_x3', None)
-            if px is not None and hasattr(lib, 't3d_split_x3'):
-                plan.add_raw('t3d_split_x3', lambda s: lib.t3d_split_x3(fptr(vs.params), C.c_void_p(px.data_ptr()), min((vs.used + 3) // 4 * 4, vs.params.numel()),
-                                                                        vs.params.numel(), s))
+            tab = vs.frag_table() if hasattr(vs, 'frag_table') else None
+            if tab is not None and hasattr(lib, 't3d_split_x3_frag'):
+                t, n, nblk = tab
+                pf, pd = vs.x3_frag_planes
+                plan.add_raw('t3d_split_x3_frag', lambda s: lib.t3d_split_x3_frag(fptr(vs.params), C.c_void_p(pf.data_ptr()), C.c_void_p(pd.data_ptr()),
+                                                                                  vs.x3_frag_stride, C.c_void_p(t.data_ptr()), n, nblk, s))
             return
         p16 = vs.enable_bf16()
         plan.add_raw('t3d_cast_bf16', lambda s: lib.t3d_cast_bf16(fptr(vs.params), C.c_void_p(p16.data_ptr()), vs.used, s))

@@ -66,11 +66,14 @@ def build_flags(argv=None):
     cfg.add_argument('--eval_file', default=None, help='held-out frustum file of the reference for eval_one_epoch (with --frustum_file / --device_data)')
     cfg.add_argument('--frustum_file', default=None, help='train from a frustum file of the reference (frustums/*.zip.pickle) held in HBM')
     cfg.add_argument('--eval_batches', type=int, default=0, help='held-out synthetic batches evaluated after every epoch (eval_one_epoch)')
-    cfg.add_argument('--no_weak_loss_summaries', action='store_true',
-                     help='do not evaluate the weak reprojection / surface losses when both of their weights are 0 (the reference always '
-                          'evaluates them for its Weak_Loss/... summaries, semisup_v1_sunrgbd.py:270-293; one small launch per step)')
+    cfg.add_argument('--weak_loss_summaries', action='store_true',
+                     help='evaluate the weak reprojection / surface losses also when both of their weights are 0, for the reference\'s '
+                          'Weak_Loss/... summaries (semisup_v1_sunrgbd.py:270-293; logged per epoch).  Off by default since round 6: the two '
+                          'launches cost 22 us of a 1.2 ms step (+1.9 %%) and change nothing that is trained -- SURVEY Appendix E item 4 '
+                          'sanctions skipping zero-weight terms; with a non-zero weight they are always evaluated')
+    cfg.add_argument('--no_weak_loss_summaries', action='store_true', help='(accepted for round-5 command lines: the default now)')
     FLAGS = cfg.parse_special_args(argv)
-    FLAGS.WEAK_LOSS_SUMMARIES = not FLAGS.no_weak_loss_summaries
+    FLAGS.WEAK_LOSS_SUMMARIES = bool(FLAGS.weak_loss_summaries) and not FLAGS.no_weak_loss_summaries
     FLAGS.NUM_CHANNELS = FLAGS.num_channels if FLAGS.num_channels else (3 if FLAGS.no_rgb else 6)
     return FLAGS
 
