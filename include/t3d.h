@@ -33,7 +33,7 @@ extern "C" {
 #define T3D_ERR_LAUNCH (-3)  /* HIP launch failure */
 #define T3D_ERR_ABI (-4)     /* an argument struct of another size than this library was built for (see `struct_size`) */
 
-/* ABI version 2.  Version 1 structs were plain; fields appended to four of them in round 4 (w_x3, oracle_mask, rowmask) made a caller
+/* ABI versions 2 and 3.  Version 1 structs were plain; fields appended to four of them in round 4 (w_x3, oracle_mask, rowmask) made a caller
  * built against the older header pass structs the library read past.  Since version 2 every argument struct that has grown, or may
  * grow, starts with `struct_size`: the caller stores sizeof(the struct as ITS header declares it) there.  New fields are only ever
  * appended, and 0 is the documented default of every appended field.  An entry point that takes such a struct accepts

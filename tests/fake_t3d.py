@@ -151,7 +151,7 @@ class FakeLib:
         if arith == abi.ARITH_FP32_MFMA or (arith == abi.ARITH_AUTO and os.environ.get('T3D_X3', '1') == '0'):
             return abi.ARITH_FP32_MFMA
         if backward:
-            ok = N % 16 == 0 and K % 64 == 0 and (K <= 64 or K % 128 == 0) and (N <= 4 * K or K >= 128)
+            ok = N % 16 == 0 and K % 64 == 0 and (K <= 64 or K % 128 == 0) and (N <= 4 * K or K >= 128 or os.environ.get('T3D_X3_BWD_NARROW', '1') != '0')
         else:
             ok = K % 16 == 0
         ok = ok and K <= 4096 and N <= 4096          # (the identity scale / shift tables of the x3 activation loader)

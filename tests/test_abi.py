@@ -210,7 +210,8 @@ def test_gemm_arithmetic_is_a_request_in_the_launch_struct_not_an_environment_va
         monkeypatch.setenv('T3D_X3', env)
         assert lib.t3d_gemm_arithmetic(abi.ARITH_BF16X3, abi.F32, 512, 256, 0) == abi.ARITH_BF16X3
         assert lib.t3d_gemm_arithmetic(abi.ARITH_FP32_MFMA, abi.F32, 512, 256, 0) == abi.ARITH_FP32_MFMA
-        assert lib.t3d_gemm_arithmetic(abi.ARITH_BF16X3, abi.F32, 64, 512, 1) == abi.ARITH_FP32_MFMA      # the launcher's own rule
+        assert lib.t3d_gemm_arithmetic(abi.ARITH_BF16X3, abi.F32, 64, 512, 1) == abi.ARITH_BF16X3         # (round 6: the narrow-input backward too)
+        assert lib.t3d_gemm_arithmetic(abi.ARITH_BF16X3, abi.F32, 192, 64, 1) == abi.ARITH_FP32_MFMA      # the launcher's own rule (K % 128)
         assert lib.t3d_gemm_arithmetic(abi.ARITH_BF16X3, abi.F32, 4, 64, 0) == abi.ARITH_FP32_MFMA        # no x3 kernel for K = 4
         assert lib.t3d_gemm_arithmetic(abi.ARITH_BF16X3, abi.BF16, 512, 256, 0) == abi.ARITH_BF16
         assert lib.t3d_gemm_arithmetic(abi.ARITH_AUTO, abi.F32, 512, 256, 0) == (abi.ARITH_BF16X3 if env == '1' else abi.ARITH_FP32_MFMA)

@@ -4415,10 +4415,14 @@ long x3_min_kn(int arith) { const char* e = arith == T3D_ARITH_AUTO ? getenv("T3
 long x3_min_kn_bwd(int arith) { const char* e = arith == T3D_ARITH_AUTO ? getenv("T3D_X3_MINKN_BWD") : nullptr; return e ? atol(e) : x3_min_kn(arith); }
 // (K, N <= T3D_IDENT_MAX: the identity scale / shift tables of ActLoaderE)
 bool x3_layer(int arith, int K, int N) { return x3_on(arith) && (long)K * N >= x3_min_kn(arith) && K <= 4096 && N <= 4096; }            // forward launches
-// backward launches (dense and Gram form).  Not the layers with few input and many output channels (64 -> 512, conv6's per-point part):
-// their data gradient is ONE 64-column tile over a long reduction, half the MFMA work per staged element, and measured slower than the
-// fp32-MFMA form (54.1 vs 50.7 us alone, 69.5 vs 62.9 us hosted at M = 32768)
-bool x3_layer_bwd(int arith, int K, int N) { return x3_on(arith) && (long)K * N >= x3_min_kn_bwd(arith) && (N <= 4 * K || K >= 128) && K <= 4096 && N <= 4096; }
+// backward launches (dense and Gram form).  Until round 5 not the layers with few input and many output channels (64 -> 512, conv6's
+// per-point part: their data gradient is ONE 64-column tile over a long reduction, and the compiler-scheduled x3 loop lost to the
+// fp32-MFMA form, 54.1 vs 50.7 us alone); with the hand-placed iteration the x3 form wins there too (44.0 vs 52.1 us alone at
+// M = 32768, 1.1874 vs 1.1947 ms per step, same box: profiles/r06_narrow_bwd.log).  T3D_X3_BWD_NARROW=0 restores the exclusion.
+bool x3_bwd_narrow() { const char* e = getenv("T3D_X3_BWD_NARROW"); return e ? atoi(e) != 0 : true; }
+bool x3_layer_bwd(int arith, int K, int N) {
+  return x3_on(arith) && (long)K * N >= x3_min_kn_bwd(arith) && (N <= 4 * K || K >= 128 || x3_bwd_narrow()) && K <= 4096 && N <= 4096;
+}
 bool act_ok(const t3d_act_src& a, int K) {
   return a.x != nullptr && (a.ldx % 4) == 0 && (a.coff % 4) == 0 && a.coff + (K + 3) / 4 * 4 <= a.ldx &&
          (a.scale == nullptr || a.shift != nullptr) && dtype_ok(a.dtype) && !(a.dtype == T3D_BF16 && a.sub != nullptr) &&

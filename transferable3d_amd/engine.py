@@ -449,8 +449,10 @@ class PointLayer:
         # what the GEMM kernels read as `w`: the fp32 weights, or their bf16 copy (refreshed every step: Graph.emit_cast_weights)
         self.w_mm = vs.bf16_view(w) if self.dt == abi.BF16 else w
         # fp32 layers on the three-term bf16 path: the weights pre-split once per step (T3D_X3_PRESPLIT=0: split in every tile)
-        self.w_x3, self.w_x3_d = vs.x3_frag(w, K, N) if (self.dt == abi.F32 and X3_PRESPLIT and rt.device.type == 'cuda' and rt.arith != abi.ARITH_FP32_MFMA) \
-            else ((None, 0), (None, 0))
+        # (vs.x3_frag_enabled = False: a program that does not refresh the planes between EVERY optimiser launch and the next use of its
+        # weights -- step.PipelinedStep, whose two chains update their halves of the variables at different times -- keeps the in-kernel split)
+        self.w_x3, self.w_x3_d = vs.x3_frag(w, K, N) if (self.dt == abi.F32 and X3_PRESPLIT and rt.device.type == 'cuda' and rt.arith != abi.ARITH_FP32_MFMA and
+                                                       getattr(vs, 'x3_frag_enabled', True)) else ((None, 0), (None, 0))
         assert not (self.dt == abi.BF16 and pool and not self.gram), "bf16: max-pooled layers take the Gram-form backward"
         self.bias = bias if bias is not None else vs.const(scope + '/biases', (N,), 0.0)
         if bn:

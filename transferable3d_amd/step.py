@@ -561,6 +561,7 @@ def build_pipelined_step(rt, B, N, C, use_hip_graph=None, inline_dropout=True, d
     for i in (0, 1):
         g = Graph(B, N, C, rt=rt, seed=seed, vars=vs)
         vs = g.vars
+        vs.x3_frag_enabled = False      # (the seg forward of step k+1 starts before the T-Net / box optimiser of step k: no single refresh point)
         g.inline_dropout, g.dropout_seed = inline_dropout, dropout_seed
         g.split_opt = True
         model = SemiModelA(g, c)
