@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
 """Variants of the x3 GEMM kernels against the default form: bit-identity of every output and time per launch on the layer shapes of
 the hot path (M = 32768).  T3D_PC_MODES: comma list of 0 (default), 1 / 2 (producer / consumer waves, T3D_X3_PC), p (the weights
-pre-split into three bf16 planes, t3d_split_x3 + w_x3), w (eight-wave 128 x 256 forward tiles, T3D_X3_W8=2).  T3D_LIB: alternative library; T3D_ONLY=fwd:512x256 one case."""
+pre-split into three bf16 planes in fragment order, t3d_split_x3_frag + w_x3), w (eight-wave 128 x 256 forward tiles, T3D_X3_W8=2).  T3D_LIB: alternative library; T3D_ONLY=fwd:512x256 one case."""
 import ctypes as C
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from transferable3d_amd import abi
 from transferable3d_amd.abi import fptr, iptr
 
@@ -57,12 +58,12 @@ def main():
             a.y = fptr(y)
         a.M, a.K, a.N, a.rows_per_frustum = M, K, N, rpf
         outs, us = {}, {}
-        planes = torch.zeros(3, K, N, dtype=torch.bfloat16, device=dev)
-        assert lib.t3d_split_x3(fptr(w), C.c_void_p(planes.data_ptr()), K * N, K * N, s) == 0
+        from bench_x3 import frag_planes      # (round 6: `w_x3` = fragment-order planes, t3d_split_x3_frag)
+        pf, pd, fstride = frag_planes(lib, w, s) if K % 32 == 0 else (None, None, 0)
         for mode in MODES:
             os.environ['T3D_X3_PC'] = mode if mode in '012' else '0'
             os.environ['T3D_X3_W8'] = '2' if mode == 'w' else '0'
-            a.w_x3, a.w_x3_stride = (C.c_void_p(planes.data_ptr()), K * N) if mode == 'p' else (None, 0)
+            a.w_x3, a.w_x3_stride = (C.c_void_p(pf.data_ptr()), fstride) if (mode == 'p' and pf is not None) else (None, 0)
             for t_ in [y, p1, p2] + pm:
                 t_.zero_()
             rc = lib.t3d_pointmlp_fwd(C.byref(a), s)
@@ -98,11 +99,11 @@ def main():
         wa.dy, wa.slabs = d.dy, fptr(slabs)
         wa.M, wa.K, wa.N, wa.rows_per_frustum, wa.rows_per_split = M, K, N, rpf, rps.value
         outs, us = {}, {}
-        planes = torch.zeros(3, K, N, dtype=torch.bfloat16, device=dev)
-        assert lib.t3d_split_x3(fptr(w), C.c_void_p(planes.data_ptr()), K * N, K * N, s) == 0
+        from bench_x3 import frag_planes
+        pf, pd, fstride = frag_planes(lib, w, s) if K % 32 == 0 else (None, None, 0)
         for mode in MODES:
             os.environ['T3D_X3_PC'] = mode if mode in '012' else '0'
-            d.w_x3, d.w_x3_stride = (C.c_void_p(planes.data_ptr()), K * N) if mode == 'p' else (None, 0)
+            d.w_x3, d.w_x3_stride = (C.c_void_p(pd.data_ptr()), fstride) if (mode == 'p' and pd is not None) else (None, 0)
             for t_ in (out, slabs, p1, p2):
                 t_.zero_()
             rc = lib.t3d_pointmlp_bwd(C.byref(d), C.byref(wa), s)

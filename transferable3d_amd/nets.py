@@ -89,12 +89,17 @@ class Graph:
         fp32 path on the bf16 matrix pipe: refresh the three bf16 planes of the weights (t3d_split_x3), if any layer asked for them."""
         vs, lib = self.vars, self.rt.lib
         if self.dt != abi.BF16:
-            tab = vs.frag_table() if hasattr(vs, 'frag_table') else None
-            if tab is not None and hasattr(lib, 't3d_split_x3_frag'):
-                t, n, nblk = tab
-                pf, pd = vs.x3_frag_planes
-                plan.add_raw('t3d_split_x3_frag', lambda s: lib.t3d_split_x3_frag(fptr(vs.params), C.c_void_p(pf.data_ptr()), C.c_void_p(pd.data_ptr()),
-                                                                                  vs.x3_frag_stride, C.c_void_p(t.data_ptr()), n, nblk, s))
+            from .engine import X3_PRESPLIT
+            if (X3_PRESPLIT and self.rt.device.type == 'cuda' and self.rt.arith != abi.ARITH_FP32_MFMA and getattr(vs, 'x3_frag_enabled', True)
+                    and hasattr(lib, 't3d_split_x3_frag')):
+                def thunk(s):      # (the table is read when the launch is issued: every layer registered by then is in it)
+                    if not getattr(vs, 'x3_frag_entries', None):
+                        return 0
+                    t, n, nblk = vs.frag_table()
+                    pf, pd = vs.x3_frag_planes
+                    return lib.t3d_split_x3_frag(fptr(vs.params), C.c_void_p(pf.data_ptr()), C.c_void_p(pd.data_ptr()), vs.x3_frag_stride,
+                                                 C.c_void_p(t.data_ptr()), n, nblk, s)
+                plan.add_raw('t3d_split_x3_frag', thunk)
             return
         p16 = vs.enable_bf16()
         plan.add_raw('t3d_cast_bf16', lambda s: lib.t3d_cast_bf16(fptr(vs.params), C.c_void_p(p16.data_ptr()), vs.used, s))

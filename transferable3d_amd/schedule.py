@@ -100,9 +100,9 @@ def est_us(name, arg):
     if name == 't3d_pointmlp_fwd':
         if a.K <= 4:
             return 5.0                                            # register kernel, bound by its output store
-        return 6.0 + 2.0 * a.M * a.K * a.N / (1.6e8 if x3 else 1.0e8)
+        return 6.0 + 2.0 * a.M * a.K * a.N / (float(os.environ.get('T3D_SCHED_FWD_RATE', '1.6e8')) if x3 else 1.0e8)
     if name == 't3d_pointmlp_bwd':
-        return 6.0 + 4.0 * a.M * a.K * a.N / (1.25e8 if x3 else 0.95e8)
+        return 6.0 + 4.0 * a.M * a.K * a.N / (float(os.environ.get('T3D_SCHED_BWD_RATE', '1.25e8')) if x3 else 0.95e8)
     if name == 't3d_pointmlp_wgrad':
         if a.K <= 4:
             return 7.0
