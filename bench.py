@@ -90,7 +90,7 @@ def gemm_work(name, a):
     # fp32 layers run on the bf16 matrix pipe with three-term operands (csrc/pointmlp.hip PathX3: k_..._x3<...>) when the launch struct
     # asks for it AND the launcher's own rule takes it: the library says which (t3d_gemm_arithmetic), nothing here reads the environment
     x3f = lambda st, K, N: LIB.t3d_gemm_arithmetic(st.arith, 0, K, N, 0) == 2
-    x3b = lambda st, K, N: LIB.t3d_gemm_arithmetic(st.arith, 0, K, N, 1) == 2
+    x3b = lambda st, K, N, kind=1: LIB.t3d_gemm_arithmetic(st.arith, 0, K, N, kind) == 2      # kind: t3d.h T3D_GEMM_* (the launcher asked)
     tag = lambda label: label.replace('<', '_x3<', 1)
     if name == 't3d_pool_bwd_stage1':
         gl, gf, gb = gemm_work('t3d_pointmlp_gram', a[0])
@@ -102,7 +102,7 @@ def gemm_work(name, a):
                 and os.environ.get('T3D_GRAM1', '1') != '0':
             return 'k_pool_bwd_stage1_h<%d,%d>' % (g0.K, 128 if g0.K == 128 else 64), gf + 2.0 * q.K * q.K * q.N, by      # one-pass form
         lab = 'k_pool_bwd_stage1<%s>' % gl[gl.index('<') + 1:gl.index(',')]
-        return (tag(lab) if g0.a.dtype == 0 and x3b(g0, g0.K, g0.K) else lab), gf + 2.0 * q.K * q.K * q.N, by
+        return (tag(lab) if g0.a.dtype == 0 and x3b(g0, g0.K, g0.K, 4) else lab), gf + 2.0 * q.K * q.K * q.N, by
     if name == 't3d_pool_bwd_stage2':
         dl, df, db = gemm_work('t3d_pointmlp_dgrad_gram', a[1])
         f = a[0]
@@ -112,7 +112,7 @@ def gemm_work(name, a):
         if a[1].dtype == 1 and os.environ.get('T3D_GRAM1', '1') != '0' and ((dm >= 1 and f.K == 256) or (dm == 2 and f.K == 128)):
             return 'k_pool_bwd_stage2_h<%d,%d>' % (f.K, 128 if f.K == 128 else 64), df + 2.0 * f.K * f.K * f.N, by      # one-pass form
         lab = 'k_pool_bwd_stage2<%s>' % dl[dl.index('<') + 1:-1]
-        return (tag(lab) if a[1].dtype == 0 and f.K % 16 == 0 and x3b(a[1], f.K, f.K) else lab), df + 2.0 * f.K * f.K * f.N, by
+        return (tag(lab) if a[1].dtype == 0 and x3b(a[1], f.K, f.K, 5) else lab), df + 2.0 * f.K * f.K * f.N, by
     if name == 't3d_pointmlp_bwd':
         d, w = a
         dl, df, _ = gemm_work('t3d_pointmlp_dgrad', d)
@@ -127,19 +127,19 @@ def gemm_work(name, a):
                 (M // 128 < 256 or w.rows_per_split >= 256 or os.environ.get('T3D_BWD1F') == '2'):
             return 'k_pointmlp_bwd1f<%d,%d>' % (K, N), df + wf, by      # fp32 one-pass form (not taken at the headline size)
         lab = 'k_pointmlp_bwd<%s,%s>' % (dl[dl.index('<') + 1:-1], wl[wl.index('<') + 1:-1])
-        return (tag(lab) if d.dtype == 0 and N % 16 == 0 and K % 64 == 0 and x3b(d, K, N) else lab), df + wf, by
+        return (tag(lab) if d.dtype == 0 and w.a.dtype == 0 and x3b(d, K, N, 1) else lab), df + wf, by
     if name == 't3d_pointmlp_dgrad_gram':
         # (the sparse arg-max rows S behind add_live are read only where a row received a hit -- a data-dependent few percent of
         # the rows: not counted; a dense add_in is a full pass)
         dense_add = (not _null(a.add_in)) and _null(a.add_live)
         by = es(a.dtype) * a.M * a.K * (2 + (0 if _null(a.prev_y) else 1) + (1 if dense_add else 0)) + 4.0 * a.K * a.K
         lab = 'k_pointmlp_dgrad_gram<%d>' % (128 if a.K % 128 == 0 and (a.M // 128) * (a.K // 128) >= 512 else 64)
-        return (tag(lab) if a.dtype == 0 and a.K % 16 == 0 and x3b(a, a.K, a.K) else lab), 2.0 * a.M * a.K * a.K, by
+        return (tag(lab) if a.dtype == 0 and x3b(a, a.K, a.K, 5) else lab), 2.0 * a.M * a.K * a.K, by
     if name == 't3d_pointmlp_gram':
         rps, tk, tn = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
         LIB.t3d_wgrad_plan(a.M, a.K, a.K, ctypes.byref(rps), ctypes.byref(tk), ctypes.byref(tn))
         t = tk.value if (rps.value == a.rows_per_split and tk.value == tn.value) else 64
-        x3g = a.a.dtype == 0 and x3b(a, a.K, a.K)
+        x3g = a.a.dtype == 0 and x3b(a, a.K, a.K, 4)
         if x3g:
             t = 64      # (the x3 Gram kernels exist for 64 x 64 tiles only: three accumulator sets keep G bitwise symmetric)
         lab = 'k_pointmlp_gram<%d,%d>' % (t, t)
@@ -164,7 +164,7 @@ def gemm_work(name, a):
     if name == 't3d_pointmlp_dgrad':
         by = es(a.dtype) * (2 * a.M * a.N + a.K * a.N + a.M * a.K * (1 + (0 if _null(a.prev_y) else 1) + (0 if _null(a.add_in) else 1)))
         lab = 'k_pointmlp_dgrad<%d>' % (128 if a.K % 128 == 0 and (a.M // 128) * (a.K // 128) >= 512 else 64)
-        return (tag(lab) if a.dtype == 0 and not _null(a.dy.dz) and a.N % 16 == 0 and x3b(a, a.K, a.N) else lab), flops, by
+        return (tag(lab) if a.dtype == 0 and not _null(a.dy.dz) and x3b(a, a.K, a.N, 2) else lab), flops, by
     rps, tk, tn = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
     LIB.t3d_wgrad_plan(a.M, a.K, a.N, ctypes.byref(rps), ctypes.byref(tk), ctypes.byref(tn))
     if rps.value != a.rows_per_split:
@@ -173,7 +173,7 @@ def gemm_work(name, a):
     if a.K <= 4 and a.a.dtype == 0 and a.dy.dtype == 0 and not _null(a.dy.dz) and a.N in (64, 128) and os.environ.get('T3D_WGRAD_TINYK', '1') != '0':
         return 'k_pointmlp_wgrad_tinyk<%d>' % a.N, flops, by      # first layer of a net, fp32: the register kernel
     lab = 'k_pointmlp_wgrad<%d,%d>' % (tk.value, tn.value)
-    return (tag(lab) if a.dy.dtype == 0 and a.a.dtype == 0 and _null(a.a.sub) and not _null(a.dy.dz) and a.K % 64 == 0 and x3b(a, a.K, a.N) else lab), flops, by
+    return (tag(lab) if a.dy.dtype == 0 and a.a.dtype == 0 and _null(a.a.sub) and not _null(a.dy.dz) and a.K % tk.value == 0 and x3b(a, a.K, a.N, 3) else lab), flops, by
 
 
 def gemm_arithmetic_report(rt, plans, dtype):
@@ -189,7 +189,9 @@ def gemm_arithmetic_report(rt, plans, dtype):
             st = (arg[1] if base == 't3d_pool_bwd_stage2' else arg[0]) if isinstance(arg, tuple) else arg
             K, N = st.K, getattr(st, 'N', st.K)
             dt = st.dtype if hasattr(st, 'dtype') else (st.dy.dtype if hasattr(st, 'dy') else st.a.dtype)
-            took = abi.ARITH_NAMES[LIB.t3d_gemm_arithmetic(st.arith, dt, K, N, 0 if base == 't3d_pointmlp_fwd' else 1)]
+            kind = {'t3d_pointmlp_fwd': 0, 't3d_pointmlp_bwd': 1, 't3d_pointmlp_dgrad': 2, 't3d_pointmlp_wgrad': 3, 't3d_pointmlp_gram': 4,
+                    't3d_pool_bwd_stage1': 4, 't3d_pointmlp_dgrad_gram': 5, 't3d_pool_bwd_stage2': 5}.get(base, 1)      # t3d.h T3D_GEMM_*
+            took = abi.ARITH_NAMES[LIB.t3d_gemm_arithmetic(st.arith, dt, K, N, kind)]
             counts[took] = counts.get(took, 0) + 1
             if dt == 0 and took != rt.gemm_arithmetic:
                 other.append('%s %dx%d' % (base[4:], K, N))

@@ -87,7 +87,9 @@ enum { T3D_F32 = 0, T3D_BF16 = 1 };
 enum { T3D_ARITH_AUTO = 0, T3D_ARITH_FP32_MFMA = 1, T3D_ARITH_BF16X3 = 2, T3D_ARITH_BF16 = 3 };
 /* The arithmetic a per-point GEMM launch of this request takes: T3D_ARITH_FP32_MFMA, T3D_ARITH_BF16X3 or T3D_ARITH_BF16 (dtype =
  * T3D_BF16).  K x N: the layer's weight matrix (a Gram-form launch: N = K); backward != 0: a data / weight gradient launch. */
-int t3d_gemm_arithmetic(int arith, int dtype, int K, int N, int backward);
+/* `kind`: which launcher is asked (0 and 1 are what round 5's `backward` flag meant) */
+enum { T3D_GEMM_FWD = 0, T3D_GEMM_BWD = 1, T3D_GEMM_DGRAD = 2, T3D_GEMM_WGRAD = 3, T3D_GEMM_GRAM = 4, T3D_GEMM_DGRAD_GRAM = 5 };
+int t3d_gemm_arithmetic(int arith, int dtype, int K, int N, int kind);
 
 int t3d_abi_version(void);
 /* Hash (16 hex digits + NUL) over the HIP sources and this header the library was built from (csrc/version.hip; "unknown" for a

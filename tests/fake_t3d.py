@@ -144,17 +144,30 @@ class FakeLib:
     def t3d_abi_version(self):
         return 3
 
-    def t3d_gemm_arithmetic(self, arith, dtype, K, N, backward):
-        """The specification library has one arithmetic (float64 products rounded once): it reports what the product's rule would take."""
+    def t3d_gemm_arithmetic(self, arith, dtype, K, N, kind):
+        """The specification library has one arithmetic (float64 products rounded once): it reports what the product's rule would take
+        (kind: t3d.h T3D_GEMM_FWD / _BWD / _DGRAD / _WGRAD / _GRAM / _DGRAD_GRAM)."""
         if dtype == abi.BF16:
             return abi.ARITH_BF16
         if arith == abi.ARITH_FP32_MFMA or (arith == abi.ARITH_AUTO and os.environ.get('T3D_X3', '1') == '0'):
             return abi.ARITH_FP32_MFMA
-        if backward:
-            ok = N % 16 == 0 and K % 64 == 0 and (K <= 64 or K % 128 == 0) and (N <= 4 * K or K >= 128 or os.environ.get('T3D_X3_BWD_NARROW', '1') != '0')
+        narrow = os.environ.get('T3D_X3_BWD_NARROW', '1') != '0'
+        bwd_rule = lambda k, n: (n <= 4 * k or k >= 128 or narrow) and k <= 4096 and n <= 4096
+        whole = K % 64 == 0 and (K <= 64 or K % 128 == 0)
+        if kind == 0:
+            ok = K % 16 == 0 and K <= 4096 and N <= 4096
+        elif kind == 1:
+            ok = N % 16 == 0 and whole and bwd_rule(K, N)
+        elif kind == 2:
+            ok = N % 16 == 0 and bwd_rule(K, N)
+        elif kind == 3:
+            ok = whole and bwd_rule(K, N)
+        elif kind == 4:
+            ok = bwd_rule(K, K)
+        elif kind == 5:
+            ok = K % 16 == 0 and bwd_rule(K, K)
         else:
-            ok = K % 16 == 0
-        ok = ok and K <= 4096 and N <= 4096          # (the identity scale / shift tables of the x3 activation loader)
+            return -1
         return abi.ARITH_BF16X3 if ok else abi.ARITH_FP32_MFMA
 
     def t3d_source_hash(self, out, cap):

@@ -218,5 +218,9 @@ def test_gemm_arithmetic_is_a_request_in_the_launch_struct_not_an_environment_va
     import fake_t3d
     fake = fake_t3d.FakeLib()
     for req in (abi.ARITH_BF16X3, abi.ARITH_FP32_MFMA):
-        for (K, N, bwd) in ((512, 256, 0), (64, 512, 1), (4, 64, 0), (128, 128, 1), (192, 64, 1)):
-            assert fake.t3d_gemm_arithmetic(req, abi.F32, K, N, bwd) == lib.t3d_gemm_arithmetic(req, abi.F32, K, N, bwd), (req, K, N, bwd)
+        for (K, N) in ((512, 256), (64, 512), (4, 64), (128, 128), (192, 64), (96, 512), (128, 1024), (8192, 64)):
+            for kind in range(6):      # T3D_GEMM_FWD ... T3D_GEMM_DGRAD_GRAM: every launcher's own rule
+                assert fake.t3d_gemm_arithmetic(req, abi.F32, K, N, kind) == lib.t3d_gemm_arithmetic(req, abi.F32, K, N, kind), (req, K, N, kind)
+    assert lib.t3d_gemm_arithmetic(abi.ARITH_BF16X3, abi.F32, 192, 64, 2) == abi.ARITH_BF16X3      # a data gradient alone takes K = 192 ...
+    assert lib.t3d_gemm_arithmetic(abi.ARITH_BF16X3, abi.F32, 192, 64, 1) == abi.ARITH_FP32_MFMA   # ... the fused backward does not
+    assert lib.t3d_gemm_arithmetic(abi.ARITH_BF16X3, abi.F32, 192, 64, 9) < 0

@@ -5459,9 +5459,18 @@ static const t3d_rider_set* query_set() {
   static const t3d_rider_set q = []() { t3d_rider_set r{}; r.n_ops = 1; r.n_wg = 1; r.sync = reinterpret_cast<unsigned*>(16); return r; }();
   return &q;
 }
-extern "C" int t3d_gemm_arithmetic(int arith, int dtype, int K, int N, int backward) {
+extern "C" int t3d_gemm_arithmetic(int arith, int dtype, int K, int N, int kind) {
   if (dtype == T3D_BF16) return T3D_ARITH_BF16;
-  const bool x3 = backward ? (N % BKX == 0 && K % 64 == 0 && (K <= 64 || K % 128 == 0) && x3_layer_bwd(arith, K, N)) : (K % BKX == 0 && x3_layer(arith, K, N));
+  bool x3 = false;
+  switch (kind) {      // each launcher's own shape rule (the element-type / pointer conditions of a launch are the caller's to know)
+    case T3D_GEMM_FWD: x3 = K % BKX == 0 && x3_layer(arith, K, N); break;                                                   // t3d_pointmlp_fwd[_r]
+    case T3D_GEMM_BWD: x3 = N % BKX == 0 && K % 64 == 0 && (K <= 64 || K % 128 == 0) && x3_layer_bwd(arith, K, N); break;    // t3d_pointmlp_bwd[_r]: both tile kinds
+    case T3D_GEMM_DGRAD: x3 = N % BKX == 0 && x3_layer_bwd(arith, K, N); break;                                             // t3d_pointmlp_dgrad (dense dy)
+    case T3D_GEMM_WGRAD: x3 = K % 64 == 0 && (K <= 64 || K % 128 == 0) && x3_layer_bwd(arith, K, N); break;                  // t3d_pointmlp_wgrad[_r]: whole k-tiles of an fp32 source
+    case T3D_GEMM_GRAM: x3 = x3_layer_bwd(arith, K, K); break;                                                              // t3d_pointmlp_gram, t3d_pool_bwd_stage1 (N ignored)
+    case T3D_GEMM_DGRAD_GRAM: x3 = K % BKX == 0 && x3_layer_bwd(arith, K, K); break;                                        // t3d_pointmlp_dgrad_gram, t3d_pool_bwd_stage2
+    default: return T3D_ERR_ARG;
+  }
   return x3 ? T3D_ARITH_BF16X3 : T3D_ARITH_FP32_MFMA;
 }
 extern "C" int t3d_pointmlp_fwd_hosts_riders(const t3d_pointmlp_fwd_args* a) { return t3d_pointmlp_fwd_r(a, query_set(), T3D_QUERY_STREAM); }
