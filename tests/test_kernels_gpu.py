@@ -1511,7 +1511,19 @@ def test_x3_weight_planes_are_exact_and_equal_the_in_kernel_split(hip_lib):
     p = planes.view(3, stride)[:, :n].double().cpu()
     assert torch.equal(p[0] + p[1] + p[2], src.double().cpu())                   # exact
     assert float((p[1].abs() / p[0].abs().clamp_min(1e-300)).max()) <= 2.0 ** -7   # each term below the previous one's last bit
-    M, K, N, rpf = 512, 256, 128, 256
+    _planes_equal_in_kernel_split(hip_lib, dev, st, r, 512, 256, 128)
+
+
+@pytest.mark.parametrize('M,K,N', [(32768, 256, 256), (8192, 64, 512)])
+def test_x3_fragment_planes_equal_the_in_kernel_split_on_the_wide_tiles_and_in_the_fused_backward(hip_lib, M, K, N):
+    """... at sizes whose launches take the 128-wide forward / data-gradient tiles (M = 32768: two workgroups per CU) and the narrow-input
+    wide-output backward, and through the fused t3d_pointmlp_bwd: bit for bit the launch that splits the weights while it stages them."""
+    dev, st = _dev('cuda'), C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _planes_equal_in_kernel_split(hip_lib, dev, st, np.random.RandomState(9), M, K, N, fused=True)
+
+
+def _planes_equal_in_kernel_split(hip_lib, dev, st, r, M, K, N, fused=False):
+    rpf = 256
     x, w = _mk(dev, r.normal(size=(M, K)).astype(np.float32)), _mk(dev, (r.normal(size=(K, N)) / 16).astype(np.float32))
     # fragment order (what the kernels take as w_x3): plane p, k-tile rt, 32-wide block nb, lane, eight elements -- and still exact
     pf, pd, fstride = _x3_frag_planes(hip_lib, w, st)
@@ -1542,10 +1554,25 @@ def test_x3_weight_planes_are_exact_and_equal_the_in_kernel_split(hip_lib):
             d.w_x3, d.w_x3_stride = pd.data_ptr(), fstride
         assert hip_lib.t3d_pointmlp_dgrad(C.byref(d), st) == 0
         torch.cuda.synchronize()
-        outs.append((y.cpu(), p1.cpu(), out.cpu()))
-    for a_, b_, what in zip(outs[0], outs[1], ('y', 'psum', 'dX')):
+        res = [y.cpu(), p1.cpu(), out.cpu()]
+        if fused:      # data gradient + weight gradient in one launch (t3d_pointmlp_bwd): the data-gradient tiles read the planes
+            rps, one = C.c_int(0), C.c_int(0)
+            assert hip_lib.t3d_bwd_plan(M, K, N, 0, C.byref(rps), C.byref(one)) == 0
+            slabs, out2 = torch.zeros(M // rps.value, K, N, device=dev), torch.zeros(M, K, device=dev)
+            d.out = fptr(out2)
+            wa = abi.PointMlpWgradArgs()
+            wa.a = abi.ActSrc(fptr(x), K, 0, fptr(None), fptr(None), 0, fptr(None), 0)
+            wa.dy, wa.slabs = d.dy, fptr(slabs)
+            wa.M, wa.K, wa.N, wa.rows_per_frustum, wa.rows_per_split = M, K, N, rpf, rps.value
+            assert hip_lib.t3d_pointmlp_bwd(C.byref(d), C.byref(wa), st) == 0
+            torch.cuda.synchronize()
+            res += [out2.cpu(), slabs.sum(0).cpu()]
+        outs.append(res)
+    for a_, b_, what in zip(outs[0], outs[1], ('y', 'psum', 'dX', 'dX (fused)', 'dW (fused)')):
         assert torch.equal(a_, b_), what
     assert float(outs[0][0].abs().max()) > 0 and float(outs[0][2].abs().max()) > 0
+    if fused:
+        assert torch.equal(outs[0][2], outs[0][3]), 'fused data gradient == the stand-alone launch'
 
 
 @pytest.mark.parametrize('sign', ['positive', 'random'])
