@@ -125,7 +125,11 @@ def check_spills(remarks_by_source):
 # (v_pk_add/mul/fma_f32), a flat_ access, an `s_waitcnt vmcnt(0)` while the loop issues loads, or more than ISA_MAX_VALU_RUN vector
 # instructions with no MFMA between them.  The map of every such loop is written to build/x3_isa_map.txt (copied to profiles/ per round).
 ISA_MAX_BURST = 2
-ISA_MAX_VALU_RUN = 20      # the longest step is a piece's last: conversion + three plane stores + the refill's address arithmetic
+# longest run of vector instructions between two MFMAs.  A 128-wide loop (48 MFMAs per two k-tiles) averages 3.2-5.9 per MFMA and its
+# longest step is a piece's element-wise work + the coefficient refill: 14.  The 64-wide loops (24 / 12 MFMAs) carry 6-11 vector
+# instructions per MFMA by construction (half or a quarter of the MFMAs per staged element) and two micro-steps share a gap: 20.
+ISA_MAX_VALU_RUN = 20
+ISA_MAX_VALU_RUN_WIDE = 14
 ISA_GATED = ('PathX3E', 'PathX3WE', 'PathX3PE', 'PathX3WPE')      # mangled-name substrings: the x3 kernels of the default program (not the PathX3PC experiment)
 
 
@@ -140,7 +144,7 @@ def check_x3_isa(asm_path, out_path=None):
         why = []
         if r['mfma_burst'] > ISA_MAX_BURST:
             why.append('MFMA burst %d' % r['mfma_burst'])
-        if r['valu_run'] > ISA_MAX_VALU_RUN:
+        if r['valu_run'] > (ISA_MAX_VALU_RUN_WIDE if r['mfma'] >= 48 else ISA_MAX_VALU_RUN):
             why.append('VALU run %d' % r['valu_run'])
         if r['pk_f32']:
             why.append('%d packed-fp32 instructions' % r['pk_f32'])
