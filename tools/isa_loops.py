@@ -121,6 +121,10 @@ def report(text, filters=(), want_map=False, min_mfma=6):
             continue
         for a, b in loops(blocks):
             ops = [o for blk in blocks[a:b + 1] for o in blk[1]]
+            # the last block runs on to the next label in the listing: the loop ends at its (last) branch back to the header
+            back = [i for i, (op, s_) in enumerate(ops) if op.startswith(('s_cbranch', 's_branch')) and s_.split()[-1] == blocks[a][0]]
+            if back:
+                ops = ops[:back[-1] + 1]
             r = analyse(ops)
             if r['mfma'] < min_mfma:
                 continue

@@ -201,6 +201,21 @@ struct DyLoader {      // N % 32 == 0: every tile column is valid
     c.c2 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s.coef + 2 * N + ucol) + lbytes);
     return c;
   }
+  // The per-channel coefficients of the WHOLE reduction range as a table in LDS (T3D_X3_COEF_LDS, gemm_mainloop_x3): a k-tile's
+  // coefficients then cost two or three ds_read_b128 instead of as many global loads -- each of which holds the wave ~50-60 cycles
+  // beside MFMAs for 128 bytes of data every lane group shares (round 6: the memory INSTRUCTIONS bound these loops).
+  static constexpr bool HAS_CTAB = !POOLED;
+  __device__ __forceinline__ int ctab_floats() const { return 3 * N; }
+  __device__ __forceinline__ void ctab_fill(float* tab, int tid, int nthreads) const {
+    for (int i = tid * 4; i < 3 * N; i += nthreads * 4) *reinterpret_cast<float4*>(tab + i) = *reinterpret_cast<const float4*>(s.coef + i);
+  }
+  __device__ __forceinline__ Coef ctab_coef(const float* tab, int col) const {
+    Coef c;
+    c.c0 = *reinterpret_cast<const float4*>(tab + col);
+    c.c1 = *reinterpret_cast<const float4*>(tab + N + col);
+    c.c2 = *reinterpret_cast<const float4*>(tab + 2 * N + col);
+    return c;
+  }
 };
 
 // typed loaders (T3D_BF16 path)
@@ -1025,6 +1040,16 @@ struct WLoaderX3F {
   int nb;               // 32-wide blocks of the lane index (N / 32 forward, K / 32 data gradient)
   struct Raw {};
   struct Coef {};
+  // one dword of every 128-byte line of the 3 x TN fragments of a wave's k-tile: lane -> (plane, block, line); the lanes past the last
+  // line repeat it.  A prefetch into the XCD's L2 (see x3_iter_il), not a read of the data.
+  template <int TN>
+  __device__ __forceinline__ unsigned touch(int c0, int red0, int lane) const {
+    const int l = lane < 24 * TN ? lane : 24 * TN - 1;
+    const int plane = l / (8 * TN), x = (l / 8) % TN, line = l % 8;
+    const size_t uoff = ((size_t)(red0 >> 4) * (size_t)nb + (size_t)(c0 >> 5)) * 512u;      // uniform
+    return *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(p + uoff) + ((size_t)plane * (size_t)stride + (size_t)x * 512u) * 2u +
+                                              (unsigned)line * 128u);
+  }
   __device__ __forceinline__ bf16x8 gfrag(int plane, int c0, int red0, int lane) const {
     const size_t uoff = (size_t)plane * (size_t)stride + ((size_t)(red0 >> 4) * (size_t)nb + (size_t)(c0 >> 5)) * 512u;      // uniform
     return *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(p + uoff) + (unsigned)lane * 16u);
@@ -1032,6 +1057,8 @@ struct WLoaderX3F {
 };
 template <class L, class = void> struct IsFrag { static constexpr bool value = false; };
 template <class L> struct IsFrag<L, typename std::enable_if<L::FRAG>::type> { static constexpr bool value = true; };
+template <class L, class = void> struct HasCtab { static constexpr bool value = false; };
+template <class L> struct HasCtab<L, typename std::enable_if<L::HAS_CTAB>::type> { static constexpr bool value = true; };
 template <class L, class = void> struct HasAt { static constexpr bool value = false; };
 template <class L> struct HasAt<L, typename std::enable_if<L::HAS_AT>::type> { static constexpr bool value = true; };
 template <class L, class = void> struct PreSplit { static constexpr bool value = false; };
@@ -1049,6 +1076,20 @@ template <class L> struct PreSplit<L, typename std::enable_if<L::PRESPLIT>::type
 #endif
 #ifndef T3D_X3_SGB
 #define T3D_X3_SGB 0                // > 0: sched_group_barrier pipeline, that many VALU instructions behind each MFMA (see x3_iter)
+#endif
+#ifndef T3D_X3_BRING
+// Two experiments of round 6 on the LATENCY of the global weight-fragment loads, both measured SLOWER and off (step 1.213 / 1.216 against
+// 1.194 ms, same box; forward 512 -> 256 51.6 / 49.8 against 49.5 us): T3D_X3_BRING=1 keeps the fragments in a ring of three register
+// sets loaded two tiles ahead (the 128-wide kernels then spill 10-22 VGPRs); T3D_X3_BTOUCH=n touches the fragment lines of the tile n
+// tiles ahead with one dword load per lane.  What the fragment loads cost is their ISSUE (a global load holds its wave ~50-60 cycles
+// beside MFMAs), not their latency: one more load per iteration only adds to it.
+#define T3D_X3_BRING 0
+#endif
+#ifndef T3D_X3_BTOUCH
+#define T3D_X3_BTOUCH 0
+#endif
+#ifndef T3D_X3_COEF_LDS
+#define T3D_X3_COEF_LDS 1           // fragment-weight kernels: the first operand's per-channel coefficients from a table in LDS (DyLoader::ctab_fill)
 #endif
 #ifndef T3D_X3_LATE_M
 #define T3D_X3_LATE_M 1             // x3_iter_il: the m-plane fragments are read at the head of the iteration that multiplies them (ILSched)
@@ -1107,11 +1148,16 @@ struct StagerX3 {
       fetch_piece<S>(l, red0_, tid, q);
     }
   }
-  template <int S>
-  __device__ __forceinline__ void il_fetch_head(const L& l, int red0_, int tid) {
+  template <int S, bool CT = false>      // CT: the coefficients come from the loader's table in LDS (T3D_X3_COEF_LDS; `ctab`)
+  __device__ __forceinline__ void il_fetch_head(const L& l, int red0_, int tid, const float* ctab = nullptr) {
     if constexpr (AT) {
       red0[S] = red0_;
-      if (TYPE_R) coef[S] = l.fetch_coef_at(red0_, cbytes);
+      if constexpr (CT && TYPE_R && HasCtab<L>::value) {
+        int li, ri; coords(tid, 0, li, ri);
+        coef[S] = l.ctab_coef(ctab, red0_ + ri);
+      } else {
+        if (TYPE_R) coef[S] = l.fetch_coef_at(red0_, cbytes);
+      }
     } else {
       fetch_head<S>(l, red0_, tid);
     }
@@ -1202,8 +1248,8 @@ struct StagerX3 {
 #define T3D_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))
 #define T3D_PIN3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
 #define T3D_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
-  template <int S, int Q, int U>
-  __device__ __forceinline__ void il_step(const L& l, bf16_t* tile, int tid, int red_fetch) {
+  template <int S, int Q, int U, bool CT = false>
+  __device__ __forceinline__ void il_step(const L& l, bf16_t* tile, int tid, int red_fetch, const float* ctab = nullptr) {
     if constexpr (U == 0) {
       int li, ri; coords(tid, Q, li, ri);
       const typename L::Coef& c = coef[TYPE_R ? S : 0];
@@ -1219,7 +1265,7 @@ struct StagerX3 {
       // the last piece's refill: as the youngest loads of the iteration, a register copy of them at the loop's back edge (the
       // allocator's, for a v_fmac that accumulates into one) waited with s_waitcnt vmcnt(0) on loads two gaps old.
 #ifndef T3D_ABL_IL_NOLOAD
-      if constexpr (Q == NV - 1) { asm volatile("" ::: "memory"); il_fetch_head<S>(l, red_fetch, tid); asm volatile("" ::: "memory"); }
+      if constexpr (Q == NV - 1) { asm volatile("" ::: "memory"); il_fetch_head<S, CT>(l, red_fetch, tid, ctab); asm volatile("" ::: "memory"); }
 #endif
     } else if constexpr (U == 1) {
       il_h<0>();
@@ -1333,6 +1379,7 @@ struct StagerX3F {
   int lane0;      // first column of the workgroup's tile (the fragment planes are indexed by absolute column)
   __device__ __forceinline__ void init(const L&, int lane0_, int) { lane0 = lane0_; }
   __device__ __forceinline__ bf16x8 gfrag(const L& l, int plane, int c_rel, int red0, int lane) const { return l.gfrag(plane, lane0 + c_rel, red0, lane); }
+  template <int TN> __device__ __forceinline__ unsigned touch(const L& l, int c_rel, int red0, int lane) const { return l.template touch<TN>(lane0 + c_rel, red0, lane); }
   template <int S> __device__ __forceinline__ void fetch(const L&, int, int) {}
   template <int S> __device__ __forceinline__ void store(const L&, bf16_t*, int) {}
   template <int S, int Q, int U> __device__ __forceinline__ void il_step(const L&, bf16_t*, int, int) {}
@@ -1421,6 +1468,27 @@ __device__ __forceinline__ void load_frags_x3(const bf16_t* As, const bf16_t* Bs
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) f.b[pl][tn] = frag_x<BR, DIMB>(Bs + pl * PLB, b0 + tn * 32, lane);
   }
+}
+
+template <bool SYM, int TM, int TN>      // the six products of one tile from fragment arrays (the last tile of the ring form)
+__device__ __forceinline__ void mma_x3_ab(const bf16x8 (&a)[3][TM], const bf16x8 (&b)[3][TN], f32x16 (&acc)[TM][TN],
+                                          f32x16 (&accb)[SYM ? TM : 1][SYM ? TN : 1], f32x16 (&accc)[SYM ? TM : 1][SYM ? TN : 1]) {
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};      // l h, h l, m m, m h, h m, h h
+  constexpr int TG[6] = {0, 1, 2, 0, 1, 2};
+#pragma unroll
+  for (int p = 0; p < 6; ++p)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        if constexpr (SYM) {
+          if (TG[p] == 0) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[p]][tm], b[PB[p]][tn], acc[tm][tn], 0, 0, 0);
+          else if (TG[p] == 1) accb[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[p]][tm], b[PB[p]][tn], accb[tm][tn], 0, 0, 0);
+          else accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[p]][tm], b[PB[p]][tn], accc[tm][tn], 0, 0, 0);
+        } else {
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[p]][tm], b[PB[p]][tn], acc[tm][tn], 0, 0, 0);
+        }
+      }
 }
 
 template <bool SYM, int TM, int TN, class F>
@@ -1540,8 +1608,12 @@ struct ILSched {
 
 template <int S, bool SYM, int TM, int TN, class SA, class SB, class LA, class LB, bool AR, int DIMA, bool BR, int DIMB>
 __device__ __forceinline__ void x3_iter_il(SA& sa, SB& sb, const LA& la, const LB& lb, bf16_t* smem, int cur, int red_next, int red_fetch, int a0, int b0,
-                                           FragsX3<TM, TN>& fc, FragsX3<TM, TN>& fn, f32x16 (&acc)[TM][TN],
+                                           FragsX3<TM, TN>& fc, FragsX3<TM, TN>& fn, bf16x8 (&bcur)[3][TN], bf16x8 (&bload)[3][TN],
+                                           unsigned& touch, int red_touch, f32x16 (&acc)[TM][TN],
                                            f32x16 (&accb)[SYM ? TM : 1][SYM ? TN : 1], f32x16 (&accc)[SYM ? TM : 1][SYM ? TN : 1], int tid) {
+  // bcur: the B fragments this iteration multiplies; bload: where the B fragments it loads go.  LDS-staged B: fc.b / fn.b (the next
+  // tile's).  Global fragment planes (T3D_X3_BRING): a ring of three sets, the loads run TWO tiles ahead (`red_next` is that tile's
+  // offset) -- see gemm_mainloop_x3.
   using SC = ILSched<SA, SB, TM, TN>;
   // the late reads land in gaps well ahead of the first MFMA of product 2 (index 2 TM TN), which multiplies them: a schedule that put
   // them behind the global fragment loads had the eight-wave tiles multiply the m planes of the tile before last
@@ -1552,6 +1624,22 @@ __device__ __forceinline__ void x3_iter_il(SA& sa, SB& sb, const LA& la, const L
   const bf16_t* Ac = smem + cur * STAGE;
   const bf16_t* Bc = Ac + SA::LDS_ELEMS;
   const int lane = tid & 63;
+  // T3D_X3_COEF_LDS: with the second operand read from global memory the LDS its image would take holds the first operand's coefficient
+  // table (gemm_mainloop_x3 fills it); derived from `smem` here so that the reads are ds_read, not flat
+  constexpr bool CTAB = T3D_X3_COEF_LDS && SC::GB && AR && HasCtab<LA>::value;
+  const float* ctab = reinterpret_cast<const float*>(smem + 2 * STAGE);
+#if T3D_X3_BTOUCH
+  if constexpr (SC::GB) {
+    // Every workgroup of an XCD asks for the same k-tile of the weight fragments at about the same time, and the planes were written by
+    // another launch: the first request of a line misses the XCD's L2, and with the fragment loads one tile ahead that miss sat on the
+    // critical path of every iteration (multiply-only timing builds: 48.8 us with global fragments against 37.4 with the LDS-staged
+    // operand, profiles/r06_il_ablations_frag.log).  One dword load per lane, one lane per 128-byte line of the fragments of the tile
+    // T3D_X3_BTOUCH tiles ahead, starts the fill early; its value is "used" one iteration later (an empty asm statement, so that the
+    // wait-count pass sees a use it can place a counted wait for -- by then long satisfied).
+    asm volatile("" :: "v"(touch));
+    touch = sb.template touch<TN>(lb, b0, red_touch, lane);
+  }
+#endif
   static_for<SC::NM>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
     constexpr int p = i / (TM * TN), tm = (i / TN) % TM, tn = i % TN;
@@ -1560,17 +1648,17 @@ __device__ __forceinline__ void x3_iter_il(SA& sa, SB& sb, const LA& la, const L
     // (the MFMA between two volatile asm statements on its accumulator: see StagerX3::il_step)
     if constexpr (SYM) {
       if constexpr (p % 3 == 0) {
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc.a[pa][tm], fc.b[pb][tn], acc[tm][tn], 0, 0, 0);
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc.a[pa][tm], bcur[pb][tn], acc[tm][tn], 0, 0, 0);
         T3D_PIN1(acc[tm][tn]);
       } else if constexpr (p % 3 == 1) {
-        accb[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc.a[pa][tm], fc.b[pb][tn], accb[tm][tn], 0, 0, 0);
+        accb[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc.a[pa][tm], bcur[pb][tn], accb[tm][tn], 0, 0, 0);
         T3D_PIN1(accb[tm][tn]);
       } else {
-        accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc.a[pa][tm], fc.b[pb][tn], accc[tm][tn], 0, 0, 0);
+        accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc.a[pa][tm], bcur[pb][tn], accc[tm][tn], 0, 0, 0);
         T3D_PIN1(accc[tm][tn]);
       }
     } else {
-      acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc.a[pa][tm], fc.b[pb][tn], acc[tm][tn], 0, 0, 0);
+      acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc.a[pa][tm], bcur[pb][tn], acc[tm][tn], 0, 0, 0);
       T3D_PIN1(acc[tm][tn]);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1581,18 +1669,22 @@ __device__ __forceinline__ void x3_iter_il(SA& sa, SB& sb, const LA& la, const L
         constexpr int q = k - SC::L0;
         asm volatile("" ::: "memory");
         if constexpr (q < TM) fc.a[1][q] = frag_x<AR, DIMA>(Ac + SA::PLANE, a0 + q * 32, lane);
-        else fc.b[1][q - TM] = frag_x<BR, DIMB>(Bc + SB::PLANE, b0 + (q - TM) * 32, lane);
+        else bcur[1][q - TM] = frag_x<BR, DIMB>(Bc + SB::PLANE, b0 + (q - TM) * 32, lane);
         asm volatile("" ::: "memory");
       } else if constexpr (k < SC::ST0) {          // the NEXT tile's weight fragments, straight from global memory (WLoaderX3F)
         constexpr int kg = k - SC::G0, o = kg / TN, x = kg % TN, pl = o == 0 ? 0 : o == 1 ? 2 : 1;      // b0, b2, b1: the order the next products need them
         if constexpr (SC::GB) {
+#ifdef T3D_ABL_IL_NOGB      // timing ablation (wrong results): the weight fragments are not reloaded
+          bload[pl][x] = bcur[pl][x];
+#else
           asm volatile("" ::: "memory");
-          fn.b[pl][x] = sb.gfrag(lb, pl, b0 + x * 32, red_next, lane);
+          bload[pl][x] = sb.gfrag(lb, pl, b0 + x * 32, red_next, lane);
           asm volatile("" ::: "memory");
+#endif
         }
       } else if constexpr (k < SC::ST0 + SC::NSA) {
 #ifndef T3D_ABL_IL_NOSTAGE      // timing ablations (wrong results): no staging pass / no barrier / no fragment reads
-        sa.template il_step<S, (k - SC::ST0) / SA::NU, (k - SC::ST0) % SA::NU>(la, An, tid, red_fetch);
+        sa.template il_step<S, (k - SC::ST0) / SA::NU, (k - SC::ST0) % SA::NU, CTAB>(la, An, tid, red_fetch, ctab);
 #endif
       } else if constexpr (k < SC::BAR) {
 #ifndef T3D_ABL_IL_NOSTAGE
@@ -1607,11 +1699,11 @@ __device__ __forceinline__ void x3_iter_il(SA& sa, SB& sb, const LA& la, const L
         constexpr int pl = SC::grp_plane(g);
         constexpr bool isb = SC::grp_is_b(g) != 0;
 #ifdef T3D_ABL_IL_NOFRAG
-        if constexpr (!isb) fn.a[pl][x] = fc.a[pl][x]; else fn.b[pl][x] = fc.b[pl][x];
+        if constexpr (!isb) fn.a[pl][x] = fc.a[pl][x]; else bload[pl][x] = bcur[pl][x];
 #else
         asm volatile("" ::: "memory");
         if constexpr (!isb) fn.a[pl][x] = frag_x<AR, DIMA>(An + pl * SA::PLANE, a0 + x * 32, lane);
-        else fn.b[pl][x] = frag_x<BR, DIMB>(Bn + pl * SB::PLANE, b0 + x * 32, lane);
+        else bload[pl][x] = frag_x<BR, DIMB>(Bn + pl * SB::PLANE, b0 + x * 32, lane);
         asm volatile("" ::: "memory");
 #endif
       }
@@ -1696,6 +1788,15 @@ __device__ __forceinline__ void gemm_mainloop_x3(SA& sa, SB& sb, const LA& la, c
   sb.template store<0>(lb, smem + SA::LDS_ELEMS, tid);
   sa.template fetch<0>(la, tile_red(PF), tid);
   sb.template fetch<0>(lb, tile_red(PF), tid);
+#if T3D_X3_IL && T3D_X3_COEF_LDS
+  if constexpr (FromGlobal<SB>::value && AR && HasCtab<LA>::value) {
+    // the launcher sized the dynamic LDS for an image of the second operand as well (lds_fwd_x3 / lds_dgrad_x3); the fragment form does
+    // not use it: bytes behind the two stages, at least those of that image
+    constexpr int FREE_BYTES = 2 * 3 * (BR ? DIMB * LDRX : BKX * (DIMB + LDCX_PAD)) * 2;
+    (void)FREE_BYTES;      // >= 18 KB for every tiling; the launchers take the fragment form for tables of <= 1536 channels only (t3d_x3_fwd ...)
+    la.ctab_fill(reinterpret_cast<float*>(smem + 2 * STAGE), tid, (int)blockDim.x);
+  }
+#endif
   __syncthreads();
   const int nt = (red_end - red_begin) / BKX;
   int cur = 0;
@@ -1704,13 +1805,67 @@ __device__ __forceinline__ void gemm_mainloop_x3(SA& sa, SB& sb, const LA& la, c
   {
 #if T3D_X3_IL
 #define T3D_X3_ITER_FP(S_, T_, FC_, FN_) \
-  x3_iter_il<S_, SYM, TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, cur, tile_red((T_) + 1), tile_red((T_) + 1 + PF), a0, b0, FC_, FN_, acc, accb, accc, tid)
+  x3_iter_il<S_, SYM, TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, cur, tile_red((T_) + 1), tile_red((T_) + 1 + PF), a0, b0, FC_, FN_, (FC_).b, (FN_).b, btouch, tile_red((T_) + (T3D_X3_BTOUCH > 0 ? T3D_X3_BTOUCH : 1)), acc, accb, accc, tid)
 #else
 #define T3D_X3_ITER_FP(S_, T_, FC_, FN_) \
   x3_iter_fp<S_, SYM, TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, cur, tile_red((T_) + 1 + PF), a0, b0, FC_, FN_, acc, accb, accc, tid)
 #endif
     constexpr int SODD = PF == 2 ? 1 : 0;      // the slot of tile t + 1 for even t
     FragsX3<TM, TN> f0, f1;
+    unsigned btouch = 0u;                      // (T3D_X3_BTOUCH: the value of the last prefetch touch, see x3_iter_il)
+#if T3D_X3_IL && T3D_X3_BRING
+    if constexpr (FromGlobal<SB>::value) {
+      // The weight fragments come straight from global memory (WLoaderX3F) and every workgroup of an XCD asks for the same k-tile of
+      // them at the same time: the first request of a k-tile misses the XCD's L2 (the planes were written by another launch), and with
+      // the loads ONE tile ahead that miss was on the critical path of every iteration -- the multiply-only timing build of the
+      // fragment kernels ran 48.8 us against 37.4 for the LDS-staged form (profiles/r06_il_ablations_frag.log).  So the B fragments
+      // live in a ring of THREE register sets and are loaded TWO tiles ahead (3 TN more fragment registers); the A fragments keep their
+      // two sets.  Periods 2 and 3: the steady-state body is six iterations with compile-time set indices.
+      static_assert(PF == 1, "the B ring is written for one register slot per staged operand");
+      bf16x8 br[3][3][TN];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) f0.a[pl][tm] = frag_x<AR, DIMA>(smem + pl * SA::PLANE, a0 + tm * 32, tid & 63);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          br[0][pl][tn] = sb.gfrag(lb, pl, b0 + tn * 32, tile_red(0), tid & 63);
+          br[1][pl][tn] = sb.gfrag(lb, pl, b0 + tn * 32, tile_red(1), tid & 63);
+        }
+      }
+      int t = 0;
+#define T3D_X3_ITER_R(PH_)                                                                                                               \
+  do {                                                                                                                                   \
+    x3_iter_il<0, SYM, TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, cur, tile_red(t + (PH_) + 2), tile_red(t + (PH_) + 2), \
+        a0, b0, ((PH_) & 1) ? f1 : f0, ((PH_) & 1) ? f0 : f1, br[(PH_) % 3], br[((PH_) + 2) % 3], btouch, tile_red(t + (PH_) + 4), acc, accb, accc, tid);                  \
+    cur ^= 1;                                                                                                                            \
+  } while (0)
+      for (; t + 6 < nt; t += 6) {
+        T3D_X3_ITER_R(0); T3D_X3_ITER_R(1); T3D_X3_ITER_R(2); T3D_X3_ITER_R(3); T3D_X3_ITER_R(4); T3D_X3_ITER_R(5);
+      }
+      // one to six tiles left: an iteration for each but the last
+      if (t + 1 < nt) T3D_X3_ITER_R(0);
+      if (t + 2 < nt) T3D_X3_ITER_R(1);
+      if (t + 3 < nt) T3D_X3_ITER_R(2);
+      if (t + 4 < nt) T3D_X3_ITER_R(3);
+      if (t + 5 < nt) T3D_X3_ITER_R(4);
+#undef T3D_X3_ITER_R
+      const int ph = nt - 1 - t;      // phase of the last tile (0 ... 5); `cur` is its LDS stage
+      auto fin = [&](FragsX3<TM, TN>& f, bf16x8 (&b)[3][TN]) {
+#if T3D_X3_LATE_M
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) f.a[1][tm] = frag_x<AR, DIMA>(smem + cur * STAGE + SA::PLANE, a0 + tm * 32, tid & 63);
+#endif
+        mma_x3_ab<SYM, TM, TN>(f.a, b, acc, accb, accc);
+      };
+      if (ph == 0) fin(f0, br[0]);
+      else if (ph == 1) fin(f1, br[1]);
+      else if (ph == 2) fin(f0, br[2]);
+      else if (ph == 3) fin(f1, br[0]);
+      else if (ph == 4) fin(f0, br[1]);
+      else fin(f1, br[2]);
+    } else
+#endif
     if constexpr (FromGlobal<SB>::value) {      // (A from the LDS image, the weight fragments from global memory)
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) {
@@ -1723,6 +1878,9 @@ __device__ __forceinline__ void gemm_mainloop_x3(SA& sa, SB& sb, const LA& la, c
       load_frags_x3<AR, DIMA, SA::PLANE, BR, DIMB, SB::PLANE>(smem, smem + SA::LDS_ELEMS, a0, b0, tid & 63, f0);
     }
     int t = 0;
+#if T3D_X3_IL && T3D_X3_BRING
+    if constexpr (!FromGlobal<SB>::value)
+#endif
     for (; t + 2 < nt; t += 2) {
       T3D_X3_ITER_FP(SODD, t, f0, f1);
       cur ^= 1;
@@ -1740,13 +1898,18 @@ __device__ __forceinline__ void gemm_mainloop_x3(SA& sa, SB& sb, const LA& la, c
       }
 #endif
     };
-    if (t + 1 < nt) {      // two tiles left
-      T3D_X3_ITER_FP(SODD, t, f0, f1);
-      load_m(f1, smem + (cur ^ 1) * STAGE);
-      mma_x3_f<SYM, TM, TN>(f1, acc, accb, accc, [](int) {});
-    } else {
-      load_m(f0, smem + cur * STAGE);
-      mma_x3_f<SYM, TM, TN>(f0, acc, accb, accc, [](int) {});
+#if T3D_X3_IL && T3D_X3_BRING
+    if constexpr (!FromGlobal<SB>::value)
+#endif
+    {
+      if (t + 1 < nt) {      // two tiles left
+        T3D_X3_ITER_FP(SODD, t, f0, f1);
+        load_m(f1, smem + (cur ^ 1) * STAGE);
+        mma_x3_f<SYM, TM, TN>(f1, acc, accb, accc, [](int) {});
+      } else {
+        load_m(f0, smem + cur * STAGE);
+        mma_x3_f<SYM, TM, TN>(f0, acc, accb, accc, [](int) {});
+      }
     }
 #undef T3D_X3_ITER_FP
   }
@@ -1984,6 +2147,22 @@ struct ActLoaderE {
     Coef c;
     c.sc = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(scp + ucol) + lbytes);
     c.sh = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(shp + ucol) + lbytes);
+    return c;
+  }
+  static constexpr bool HAS_CTAB = true;      // (see DyLoader::ctab_fill)
+  __device__ __forceinline__ int ctab_floats() const { return 2 * K; }
+  __device__ __forceinline__ void ctab_fill(float* tab, int tid, int nthreads) const {
+    const float* scp = s.scale != nullptr ? s.scale : t3d_ident_scale;
+    const float* shp = s.scale != nullptr ? s.shift : t3d_ident_shift;
+    for (int i = tid * 4; i < K; i += nthreads * 4) {
+      *reinterpret_cast<float4*>(tab + i) = *reinterpret_cast<const float4*>(scp + i);
+      *reinterpret_cast<float4*>(tab + K + i) = *reinterpret_cast<const float4*>(shp + i);
+    }
+  }
+  __device__ __forceinline__ Coef ctab_coef(const float* tab, int col) const {
+    Coef c;
+    c.sc = *reinterpret_cast<const float4*>(tab + col);
+    c.sh = *reinterpret_cast<const float4*>(tab + K + col);
     return c;
   }
   __device__ __forceinline__ Coef fetch_coef(int col) const {
@@ -4545,7 +4724,7 @@ int t3d_x3_split(const float* src, void* planes, int64_t n, int64_t plane_stride
 int t3d_x3_dgrad(const t3d_pointmlp_dgrad_args* a, bool wide, hipStream_t s) {
   const int tiles_m = a->M / 128;
   if (a->w_x3 && (a->K % 32 != 0 || a->N % 16 != 0 || a->w_x3_stride < (int64_t)a->K * a->N)) return T3D_ERR_SHAPE;      // (fragment planes: whole blocks)
-  if (a->w_x3) {
+  if (a->w_x3 && a->N <= 1536) {      // (dy's coefficient table in LDS: 3 N floats <= 18 KB)
     if (wide) launch_lds(k_pointmlp_dgrad<128, false, PathX3P>, dim3(tiles_m * (a->K / 128)), lds_dgrad_x3(128), s, *a);
     else launch_lds(k_pointmlp_dgrad<64, false, PathX3P>, dim3(tiles_m * (a->K / 64)), lds_dgrad_x3(64), s, *a);
   } else if (wide) launch_lds(k_pointmlp_dgrad<128, false, PathX3>, dim3(tiles_m * (a->K / 128)), lds_dgrad_x3(128), s, *a);
@@ -4583,7 +4762,9 @@ int t3d_x3_dgrad_gram(const t3d_pointmlp_dgrad_gram_args* a, bool wide, hipStrea
 
 int t3d_x3_fwd(const t3d_pointmlp_fwd_args* a, const t3d_rider_set* r, hipStream_t s) {
   const int tiles_m = a->M / 128, nr = r ? r->n_wg : 0;
-  const bool pre = a->w_x3 != nullptr;      // the weights arrive as three bf16 planes in fragment order (t3d_split_x3_frag, forward arrangement)
+  // the weights arrive as three bf16 planes in fragment order (t3d_split_x3_frag, forward arrangement); the fragment kernels keep the
+  // input's scale / shift table in LDS (2 K floats <= 18 KB: K <= 1536 -- a wider layer takes the in-kernel split)
+  const bool pre = a->w_x3 != nullptr && a->K <= 1536;
   if (pre && (a->N % 32 != 0 || a->K % 16 != 0 || a->w_x3_stride < (int64_t)a->K * a->N)) return T3D_ERR_SHAPE;
   const char* e = getenv("T3D_X3_FWD128_MIN");      // (fewest 128-wide tiles for which the forward takes them; experiments)
   const long min_tiles = e ? atol(e) : 512;
@@ -4663,7 +4844,7 @@ int t3d_x3_bwd(const t3d_pointmlp_dgrad_args* d, const t3d_pointmlp_wgrad_args* 
       T3D_LAUNCH(kern, grid, dim3(NT), lds, s, *d, *w, n_w, 0);                                    \
     }                                                                                              \
   } while (0)
-#define T3D_BWDX(DBN, TK, TN_) do { if (d->w_x3) T3D_BWDX_P(DBN, TK, TN_, PathX3P); else T3D_BWDX_P(DBN, TK, TN_, PathX3); } while (0)
+#define T3D_BWDX(DBN, TK, TN_) do { if (d->w_x3 && d->N <= 1536) T3D_BWDX_P(DBN, TK, TN_, PathX3P); else T3D_BWDX_P(DBN, TK, TN_, PathX3); } while (0)
 #define T3D_BWDX_W(DBN)                                  \
   do {                                                   \
     if (tk == 128 && tn == 128) T3D_BWDX(DBN, 128, 128); \
