@@ -53,16 +53,24 @@ __global__ __launch_bounds__(256) void k_pool_bwd_mid(const float* __restrict__ 
   }
 }
 
-__global__ void k_schedule_step(float* hyper, const t3d_schedule s) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// One wave.  The four pow() of the schedule are independent dependent-chains of a few hundred instructions each: lanes 0-3 take one
+// each (same function, same arguments as the one-thread form: bit-identical), lane 0 combines them.
+__global__ __launch_bounds__(64) void k_schedule_step(float* hyper, const t3d_schedule s) {
+  if (blockIdx.x != 0) return;
+  const int lane = threadIdx.x;
   // global step BEFORE this update drives lr / bn_decay (tf: minimize() increments after use)
   const double step = (double)hyper[0] + (double)s.step_offset;
   const double seen = step * (double)s.batch_size;
-  const double lr = (double)s.base_lr * pow((double)s.lr_decay_rate, floor(seen / (double)s.lr_decay_step));
-  const double bnm = (double)s.bn_init_decay * pow((double)s.bn_decay_rate, floor(seen / (double)s.bn_decay_step));
-  const double bnd = fmin((double)s.bn_decay_clip, 1.0 - bnm);
   const double t = step + 1.0;   // Adam's t starts at 1
-  const double lr_t = lr * sqrt(1.0 - pow((double)s.beta2, t)) / (1.0 - pow((double)s.beta1, t));
+  const double base = lane == 0 ? (double)s.lr_decay_rate : lane == 1 ? (double)s.bn_decay_rate : lane == 2 ? (double)s.beta2 : (double)s.beta1;
+  const double expo = lane == 0 ? floor(seen / (double)s.lr_decay_step) : lane == 1 ? floor(seen / (double)s.bn_decay_step) : t;
+  const double pw = lane < 4 ? pow(base, expo) : 0.0;
+  const double p_lr = __shfl(pw, 0), p_bn = __shfl(pw, 1), p_b2 = __shfl(pw, 2), p_b1 = __shfl(pw, 3);
+  if (lane != 0) return;
+  const double lr = (double)s.base_lr * p_lr;
+  const double bnm = (double)s.bn_init_decay * p_bn;
+  const double bnd = fmin((double)s.bn_decay_clip, 1.0 - bnm);
+  const double lr_t = lr * sqrt(1.0 - p_b2) / (1.0 - p_b1);
   hyper[1] = (float)lr;
   hyper[2] = (float)bnd;
   hyper[3] = (float)lr_t;

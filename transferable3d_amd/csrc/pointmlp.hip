@@ -71,13 +71,16 @@ __device__ __forceinline__ unsigned keep_bits32(const float* __restrict__ rowmas
 // Diagnostic builds (-DT3D_TRACE, tools/trace_blocks.py): every workgroup records the 100 MHz wall clock at kernel entry,
 // after the main loop and at exit, plus its XCC / HW id, into a buffer installed with t3d_set_trace().
 #ifdef T3D_TRACE
+#ifndef T3D_TRACE_STRIDE
+#define T3D_TRACE_STRIDE 4      // 8: slot 4 = the x3 main loop's prologue done (first k-tile staged), tools/trace_blocks.py T3D_TRACE_STRIDE=8
+#endif
 __device__ unsigned long long* t3d_trace_ptr = nullptr;
 #define T3D_TRACE_MARK(slot)                                                                                  \
   do {                                                                                                        \
     if (threadIdx.x == 0 && t3d_trace_ptr) {                                                                  \
-      t3d_trace_ptr[(size_t)blockIdx.x * 4 + (slot)] = wall_clock64();                                        \
+      t3d_trace_ptr[(size_t)blockIdx.x * T3D_TRACE_STRIDE + (slot)] = wall_clock64();                         \
       if ((slot) == 0)                                                                                        \
-        t3d_trace_ptr[(size_t)blockIdx.x * 4 + 3] =                                                           \
+        t3d_trace_ptr[(size_t)blockIdx.x * T3D_TRACE_STRIDE + 3] =                                            \
             ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11)) << 32) |        \
             (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | ((32 - 1) << 11));                 \
     }                                                                                                         \
@@ -1088,6 +1091,14 @@ template <class L> struct PreSplit<L, typename std::enable_if<L::PRESPLIT>::type
 #ifndef T3D_X3_BTOUCH
 #define T3D_X3_BTOUCH 0
 #endif
+#ifndef T3D_X3_FAIR
+#define T3D_X3_FAIR 1               // the younger workgroup of a CU pair leads the first part of its k loop at wave priority 1 (gemm_mainloop_x3)
+#endif
+#ifndef T3D_X3_FAIR_NUM
+#define T3D_X3_FAIR_NUM 1
+#define T3D_X3_FAIR_DEN 2
+#endif
+#define T3D_FAIR_CUS 256            // CUs of an MI355X: the first this many workgroups of a launch are the older halves of the CU pairs
 #ifndef T3D_X3_COEF_LDS
 #define T3D_X3_COEF_LDS 1           // fragment-weight kernels: the first operand's per-channel coefficients from a table in LDS (DyLoader::ctab_fill)
 #endif
@@ -1798,6 +1809,9 @@ __device__ __forceinline__ void gemm_mainloop_x3(SA& sa, SB& sb, const LA& la, c
   }
 #endif
   __syncthreads();
+#if defined(T3D_TRACE) && T3D_TRACE_STRIDE >= 8
+  T3D_TRACE_MARK(4);
+#endif
   const int nt = (red_end - red_begin) / BKX;
   int cur = 0;
 #if T3D_X3_FRAGPF
@@ -1878,15 +1892,42 @@ __device__ __forceinline__ void gemm_mainloop_x3(SA& sa, SB& sb, const LA& la, c
       load_frags_x3<AR, DIMA, SA::PLANE, BR, DIMB, SB::PLANE>(smem, smem + SA::LDS_ELEMS, a0, b0, tid & 63, f0);
     }
     int t = 0;
+#if T3D_X3_FAIR
+    // The two workgroups of a CU do not advance together: a SIMD's arbiter takes the OLDER wave whenever both are ready, so the workgroup
+    // dispatched first wins every conflict (matrix pipe, vector ports, LDS, the memory pipeline), finishes its k loop early -- in 256 of
+    // 256 CU pairs of the forward 512 -> 256, by 7.6 us of 46 (tools/trace_blocks.py, profiles/r06_trace_blocks_x3.log) -- and leaves the
+    // other one alone on the CU, one wave per SIMD with nobody to overlap its staging pass, for the rest of the launch.  A launch's
+    // first T3D_FAIR_CUS workgroups land one per CU; the later ones are the younger halves of the pairs (and, in launches of more rounds,
+    // always younger than the workgroup they join).  They run the first T3D_X3_FAIR_NUM / T3D_X3_FAIR_DEN of their k loop at wave
+    // priority 1 -- priority beats age -- and the rest at 0: the younger workgroup leads first, the older one catches up, both leave
+    // the loop together.  Scheduling only: the instruction streams and the results are unchanged.
+    const int fair_sw = ((int)blockIdx.x >= T3D_FAIR_CUS) ? ((nt * T3D_X3_FAIR_NUM / T3D_X3_FAIR_DEN) & ~1) : 0;
+    if (fair_sw > 0) __builtin_amdgcn_s_setprio(1);
+#endif
 #if T3D_X3_IL && T3D_X3_BRING
     if constexpr (!FromGlobal<SB>::value)
 #endif
+#if T3D_X3_FAIR
+    // (two passes over ONE loop body -- the k-tiles in front of the switch, then the rest -- so that the body stays a single basic block)
+#pragma nounroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int lim = pass == 0 ? fair_sw : nt;
+      for (; t + 2 < nt && t < lim; t += 2) {
+        T3D_X3_ITER_FP(SODD, t, f0, f1);
+        cur ^= 1;
+        T3D_X3_ITER_FP(0, t + 1, f1, f0);
+        cur ^= 1;
+      }
+      __builtin_amdgcn_s_setprio(0);
+    }
+#else
     for (; t + 2 < nt; t += 2) {
       T3D_X3_ITER_FP(SODD, t, f0, f1);
       cur ^= 1;
       T3D_X3_ITER_FP(0, t + 1, f1, f0);
       cur ^= 1;
     }
+#endif
     // (T3D_X3_LATE_M: the m planes of the last tile are read here -- no iteration follows that would read them at its head)
     auto load_m = [&](FragsX3<TM, TN>& f, const bf16_t* st) {
 #if T3D_X3_IL && T3D_X3_LATE_M
