@@ -2482,20 +2482,37 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_fwd(const t3d_pointm
   fwd_body<BN, HAS_SUB, PR, XT>(p, smem, blockIdx.x, gridDim.x);
 }
 
+// The eight-wave kernels hold ONE workgroup per CU, so a launch of more tiles than CUs ran in rounds with the CU idle between a
+// workgroup's exit and its successor's first instruction (1.9 us in the timeline of the 256 -> 512 pooled layer, tools/trace_blocks.py)
+// on top of the epilogue and prologue on either side.  T3D_W8_PERSIST: the launch is min(tiles, CUs) workgroups and a workgroup walks
+// tiles b, b + G, b + 2 G, ... itself (same tile -> XCD assignment as the dispatcher's round robin: xcd_remap sees the same index).
+#ifndef T3D_W8_PERSIST
+#define T3D_W8_PERSIST 1
+#endif
 template <int BN, class PR>      // eight waves, 128 x 256 tile (PathX3W)
-__global__ __launch_bounds__(2 * NT) void k_pointmlp_fwd_w8(const t3d_pointmlp_fwd_args p) {
+__global__ __launch_bounds__(2 * NT) void k_pointmlp_fwd_w8(const t3d_pointmlp_fwd_args p, const int n_tiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  fwd_body<BN, false, PR, float>(p, smem, blockIdx.x, gridDim.x);
+  for (int b = blockIdx.x; b < n_tiles; b += gridDim.x) {
+    int bb = b;
+    asm volatile("" : "+s"(bb));      // (nothing derived from the tile index is hoisted out of the loop and kept live across a tile)
+    fwd_body<BN, false, PR, float>(p, smem, bb, n_tiles);
+    __syncthreads();                  // the next tile's staging pass overwrites the epilogue's LDS scratch
+  }
 }
 template <int BN, class PR>      // ... hosting riders: the rider workgroups run on their first four waves (the bodies are 256-thread programs)
-__global__ __launch_bounds__(2 * NT) void k_pointmlp_fwd_w8_r(const t3d_pointmlp_fwd_args p, const t3d_rider_set r) {
+__global__ __launch_bounds__(2 * NT) void k_pointmlp_fwd_w8_r(const t3d_pointmlp_fwd_args p, const t3d_rider_set r, const int n_tiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if ((int)blockIdx.x < r.n_wg) {
     if (threadIdx.x >= NT) return;      // (s_barrier counts the surviving waves)
     run_riders(r, smem);
     return;
   }
-  fwd_body<BN, false, PR, float>(p, smem, blockIdx.x - r.n_wg, gridDim.x - r.n_wg);
+  for (int b = blockIdx.x - r.n_wg; b < n_tiles; b += gridDim.x - r.n_wg) {
+    int bb = b;
+    asm volatile("" : "+s"(bb));
+    fwd_body<BN, false, PR, float>(p, smem, bb, n_tiles);
+    __syncthreads();
+  }
 }
 
 template <int BN, class PR>      // producer / consumer form (gemm_mainloop_x3_pc): eight waves, one workgroup per CU
@@ -4814,24 +4831,25 @@ int t3d_x3_fwd(const t3d_pointmlp_fwd_args* a, const t3d_rider_set* r, hipStream
   // 52.3 against 56.6 and 128 -> 1024 57.3 against 60.5, profiles/r05_w8.log).  T3D_X3_W8=0: never; =2: whenever N % 256 == 0
   const int w8 = []() { const char* e_ = getenv("T3D_X3_W8"); return e_ ? atoi(e_) : T3D_X3_W8_DEFAULT; }();
   if (w8 && a->N % 256 == 0 && (w8 == 2 || (long)tiles_m * (a->N / 256) >= 512)) {
-    const dim3 grid(tiles_m * (a->N / 256) + nr);
+    const int n_tiles = tiles_m * (a->N / 256);
+    const dim3 grid((T3D_W8_PERSIST && n_tiles > T3D_FAIR_CUS ? T3D_FAIR_CUS : n_tiles) + nr);
     const size_t lds = lds_with(lds_fwd_x3(256), r);
     if (r && pre) {
       auto kern = k_pointmlp_fwd_w8_r<256, PathX3WP>;
       allow_lds(reinterpret_cast<const void*>(kern), lds);
-      T3D_LAUNCH(kern, grid, dim3(2 * NT), lds, s, *a, *r);
+      T3D_LAUNCH(kern, grid, dim3(2 * NT), lds, s, *a, *r, n_tiles);
     } else if (r) {
       auto kern = k_pointmlp_fwd_w8_r<256, PathX3W>;
       allow_lds(reinterpret_cast<const void*>(kern), lds);
-      T3D_LAUNCH(kern, grid, dim3(2 * NT), lds, s, *a, *r);
+      T3D_LAUNCH(kern, grid, dim3(2 * NT), lds, s, *a, *r, n_tiles);
     } else if (pre) {
       auto kern = k_pointmlp_fwd_w8<256, PathX3WP>;
       allow_lds(reinterpret_cast<const void*>(kern), lds);
-      T3D_LAUNCH(kern, grid, dim3(2 * NT), lds, s, *a);
+      T3D_LAUNCH(kern, grid, dim3(2 * NT), lds, s, *a, n_tiles);
     } else {
       auto kern = k_pointmlp_fwd_w8<256, PathX3W>;
       allow_lds(reinterpret_cast<const void*>(kern), lds);
-      T3D_LAUNCH(kern, grid, dim3(2 * NT), lds, s, *a);
+      T3D_LAUNCH(kern, grid, dim3(2 * NT), lds, s, *a, n_tiles);
     }
     T3D_CHECK_LAUNCH();
     return T3D_OK;
