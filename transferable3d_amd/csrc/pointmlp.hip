@@ -3388,8 +3388,13 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_bwd(const t3d_pointm
   }
 }
 
+#ifndef T3D_R64_WAVES
+// (experiment of round 6: 3 caps the rider-hosting <64,64,64> backward at 168 VGPRs -- the GEMM bodies need 148 and the plain kernel runs three
+// workgroups per CU -- but the rider bodies then spill 500 bytes per lane and the hosted launch goes from 28.5 to 35.8 us, the step from 1.15 to 1.25 ms)
+#define T3D_R64_WAVES T3D_WAVES
+#endif
 template <int DBN, int WBMK, int WBN, class PR = PathF32>
-__global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_bwd_r(const t3d_pointmlp_dgrad_args d, const t3d_pointmlp_wgrad_args w,
+__global__ __launch_bounds__(NT, (DBN == 64 && WBMK == 64 && WBN == 64) ? T3D_R64_WAVES : T3D_WAVES) void k_pointmlp_bwd_r(const t3d_pointmlp_dgrad_args d, const t3d_pointmlp_wgrad_args w,
                                                                   const int n_wgrad, const t3d_rider_set r) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if ((int)blockIdx.x < r.n_wg) { run_riders(r, smem); return; }
