@@ -132,11 +132,17 @@ def main():
             os.environ['T3D_X3'] = mode
             os.environ['T3D_X3_MINKN'] = '1'
             out.zero_(); slabs.zero_()
-            assert lib.t3d_pointmlp_bwd(C.byref(d), C.byref(wa), s) == 0
+            bwd = lambda: lib.t3d_pointmlp_bwd(C.byref(d), C.byref(wa), s)
+            if os.environ.get('T3D_BENCH_EMPTY_RIDERS') == '1':      # the rider-hosting kernel with an empty rider set: what hosting costs the GEMM by itself
+                rs = abi.RiderSet()
+                sync = torch.zeros(64, dtype=torch.int32, device=dev)
+                rs.n_ops, rs.n_wg, rs.lds_bytes, rs.sync = 0, 0, 0, C.cast(C.c_void_p(sync.data_ptr()), C.POINTER(C.c_uint32))
+                bwd = lambda: lib.t3d_pointmlp_bwd_r(C.byref(d), C.byref(wa), C.byref(rs), s)
+            assert bwd() == 0
             torch.cuda.synchronize()
             e_dx = float((out[:R0].double() - ref_dx).abs().max() / ref_dx.abs().max())
             e_dw = float((slabs.double().sum(0) - ref_dw).abs().max() / ref_dw.abs().max())
-            us = timed(lambda: lib.t3d_pointmlp_bwd(C.byref(d), C.byref(wa), s))
+            us = timed(bwd)
             res[mode] = (e_dx, e_dw, us)
         fl = 4.0 * M * K * N
         print('bwd %4d -> %4d (one_pass %d)  fp32-MFMA: dx %.1e dw %.1e %7.1f us (%5.1f TF/s)   x3: dx %.1e dw %.1e %7.1f us (%5.1f TF/s)   speed-up %.2f' % (
