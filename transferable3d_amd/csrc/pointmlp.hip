@@ -3372,6 +3372,16 @@ __global__ __launch_bounds__(NT, T3D_WAVES) void k_pointmlp_bwd(const t3d_pointm
   extern __shared__ __attribute__((aligned(16))) float smem[];
   typename PR::template Act<false, typename PR::T> la{w.a, w.K, w.rows_per_frustum};
   typename PR::template Dy<false> lb{w.dy, w.N, w.rows_per_frustum};
+#ifdef T3D_TRACE      // (tools/trace_bwd.py: entry, exit and the kind of tile of every workgroup; slot 4 = its main loop's prologue done)
+  T3D_TRACE_MARK(0);
+  if (threadIdx.x == 0 && t3d_trace_ptr) t3d_trace_ptr[(size_t)blockIdx.x * T3D_TRACE_STRIDE + 1] = (int)blockIdx.x < n_wgrad ? 1 : 2;
+  if (!interleave) {
+    if ((int)blockIdx.x < n_wgrad) wgrad_body<WBMK, WBN, PR>(la, lb, w.slabs, w.K, w.N, w.rows_per_split, smem, blockIdx.x, n_wgrad);
+    else dgrad_body<DBN, false, PR>(d, smem, blockIdx.x - n_wgrad, gridDim.x - n_wgrad);
+    T3D_TRACE_MARK(2);
+    return;
+  }
+#endif
   if (interleave) {
     // logical order: per row split, its weight-gradient tiles followed by the data-gradient tiles of the same rows; the
     // XCD remap hands each XCD a contiguous piece of that order, so both readers of a dy row range share one L2
