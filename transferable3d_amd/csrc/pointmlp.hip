@@ -1098,6 +1098,9 @@ template <class L> struct PreSplit<L, typename std::enable_if<L::PRESPLIT>::type
 #define T3D_X3_FAIR_NUM 1
 #define T3D_X3_FAIR_DEN 2
 #endif
+#ifndef T3D_X3_PRIO_WGRAD
+#define T3D_X3_PRIO_WGRAD 1         // weight-gradient / Gram tiles at wave priority 1 for their whole k loop (gemm_mainloop_x3)
+#endif
 #define T3D_FAIR_CUS 256            // CUs of an MI355X: the first this many workgroups of a launch are the older halves of the CU pairs
 #ifndef T3D_X3_COEF_LDS
 #define T3D_X3_COEF_LDS 1           // fragment-weight kernels: the first operand's per-channel coefficients from a table in LDS (DyLoader::ctab_fill)
@@ -1901,8 +1904,13 @@ __device__ __forceinline__ void gemm_mainloop_x3(SA& sa, SB& sb, const LA& la, c
     // always younger than the workgroup they join).  They run the first T3D_X3_FAIR_NUM / T3D_X3_FAIR_DEN of their k loop at wave
     // priority 1 -- priority beats age -- and the rest at 0: the younger workgroup leads first, the older one catches up, both leave
     // the loop together.  Scheduling only: the instruction streams and the results are unchanged.
-    const int fair_sw = ((int)blockIdx.x >= T3D_FAIR_CUS) ? ((nt * T3D_X3_FAIR_NUM / T3D_X3_FAIR_DEN) & ~1) : 0;
-    if (fair_sw > 0) __builtin_amdgcn_s_setprio(1);
+    // In the fused backward launches the rule is another one: the weight-gradient tiles (both operands reduced over rows: !AR && !BR) are few,
+    // long and first in the launch -- one per CU for 42 ... 86 us while two to four rounds of data-gradient tiles pass through the CU's other
+    // slot, and in every layer but the widest the launch ends when THEY end, alone on their CUs (tools/trace_bwd.py).  They run their whole k
+    // loop at priority 1 (T3D_X3_PRIO_WGRAD); the data-gradient tiles (AR && BR) keep priority 0 and no forward rule.
+    constexpr bool WG_TILE = T3D_X3_PRIO_WGRAD && !AR && !BR, FWD_TILE = AR && !BR;
+    const int fair_sw = (FWD_TILE && (int)blockIdx.x >= T3D_FAIR_CUS) ? ((nt * T3D_X3_FAIR_NUM / T3D_X3_FAIR_DEN) & ~1) : 0;
+    if (WG_TILE || fair_sw > 0) __builtin_amdgcn_s_setprio(1);
 #endif
 #if T3D_X3_IL && T3D_X3_BRING
     if constexpr (!FromGlobal<SB>::value)
@@ -1918,7 +1926,7 @@ __device__ __forceinline__ void gemm_mainloop_x3(SA& sa, SB& sb, const LA& la, c
         T3D_X3_ITER_FP(0, t + 1, f1, f0);
         cur ^= 1;
       }
-      __builtin_amdgcn_s_setprio(0);
+      if constexpr (!WG_TILE) __builtin_amdgcn_s_setprio(0);
     }
 #else
     for (; t + 2 < nt; t += 2) {
@@ -1953,6 +1961,9 @@ __device__ __forceinline__ void gemm_mainloop_x3(SA& sa, SB& sb, const LA& la, c
       }
     }
 #undef T3D_X3_ITER_FP
+#if T3D_X3_FAIR
+    if constexpr (T3D_X3_PRIO_WGRAD && !AR && !BR) __builtin_amdgcn_s_setprio(0);
+#endif
   }
 #else
 #define T3D_X3_ITER(S_) x3_iter<S_, SYM, TM, TN, SA, SB, LA, LB, AR, DIMA, BR, DIMB>(sa, sb, la, lb, smem, cur, tile_red(t + 1 + PF), a0, b0, acc, accb, accc, tid)
