@@ -46,8 +46,35 @@ def main():
     idle = []
     stop = threading.Event()
     th = threading.Thread(target=poll, args=(idle, stop)); th.start(); time.sleep(1.0); stop.set(); th.join()
-    print('--- idle'); print(idle[-1][1] if idle else 'no sample')
-    for secs, label in ((4.0, 'back-to-back launches'),):
+    print('--- idle (columns: junction C, memory C, fclk, level, mclk, level, sclk, level, socclk, level, package W)'); print(idle[-1][1] if idle else 'no sample')
+    # the other regimes, for comparison: the same layer on the fp32 MFMA (T3D_X3=0), a latency-bound narrow forward, a pure HBM stream
+    xs = torch.randn(M, 128, device=dev)
+    ws = torch.randn(128, 128, device=dev) / 11.0
+    ys = torch.zeros(M, 128, device=dev)
+    a2 = abi.PointMlpFwdArgs()
+    a2.a = abi.ActSrc(fptr(xs), 128, 0, fptr(sc[:128].contiguous()), fptr(sh[:128].contiguous()), 1, fptr(None), 0)
+    p3, p4 = torch.zeros(M // 128, 128, device=dev), torch.zeros(M // 128, 128, device=dev)
+    a2.w, a2.bias, a2.psum, a2.psumsq, a2.y = fptr(ws), fptr(torch.zeros(128, device=dev)), fptr(p3), fptr(p4), fptr(ys)
+    a2.M, a2.K, a2.N, a2.rows_per_frustum = M, 128, 128, 1024
+    keep2 = frag_planes(lib, ws, s)
+    a2.w_x3, a2.w_x3_stride = keep2[0].data_ptr(), keep2[2]
+    big = torch.zeros(64 << 20, device=dev)
+    big2 = torch.zeros(64 << 20, device=dev)
+
+    def case_x3():
+        os.environ['T3D_X3'] = '1'; lib.t3d_pointmlp_fwd(C.byref(a), s)
+
+    def case_f32():
+        os.environ['T3D_X3'] = '0'; lib.t3d_pointmlp_fwd(C.byref(a), s)
+
+    def case_narrow():
+        os.environ['T3D_X3'] = '1'; lib.t3d_pointmlp_fwd(C.byref(a2), s)
+
+    def case_copy():
+        big2.copy_(big)
+
+    for secs, label, fn in ((4.0, 'forward 512 -> 256, three-term bf16 (the default)', case_x3), (4.0, 'forward 512 -> 256, fp32 MFMA (T3D_X3=0)', case_f32),
+                            (4.0, 'forward 128 -> 128, three-term bf16', case_narrow), (4.0, '256 MB device-to-device copy', case_copy)):
         out, stop = [], threading.Event()
         th = threading.Thread(target=poll, args=(out, stop)); th.start()
         t0 = time.time(); n = 0
@@ -55,14 +82,15 @@ def main():
         e0.record()
         while time.time() - t0 < secs:
             for _ in range(200):
-                lib.t3d_pointmlp_fwd(C.byref(a), s)
+                fn()
             n += 200
             torch.cuda.synchronize()
         e1.record(); torch.cuda.synchronize()
         stop.set(); th.join()
         print('--- %s: %d launches, %.1f us each (incl. host gaps)' % (label, n, e0.elapsed_time(e1) * 1e3 / n))
-        for t, txt in out[1:-1][:6]:
-            print('t=%.2f' % (t - t0)); print(txt)
+        for t, txt in out[1:-1][:4]:
+            row = [l for l in txt.splitlines() if l.startswith('card0')]
+            print('  t=%.2f s  %s' % (t - t0, row[0] if row else txt))
 
 
 if __name__ == '__main__':
