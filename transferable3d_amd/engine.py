@@ -80,6 +80,15 @@ FUSE_BWD = os.environ.get('T3D_FUSE_BWD', '1') != '0'
 FC_SIDE = os.environ.get('T3D_FC_SIDE', '0') == '1'
 # the sparse rows S are written / read only where a row received an arg-max hit (row flags beside S)
 SPARSE_GATED = os.environ.get('T3D_SPARSE_GATED', '1') != '0'
+# EXPERIMENT (round 6, off by default: T3D_DZ_POOL=1): the [M, N] gradient tensors dz between the per-point layers of a net from a small pool
+# of that net instead of one allocation per layer -- a dz lives from the launch that writes it (the next layer's data gradient) to the launch
+# that reads it (its own layer's backward), so two to four buffers serve a net.  The idea: one allocation per layer puts 277 MB of write-once
+# tensors through the chip's 256 MB memory-side cache in every backward pass, and the narrow backward launches take 24 us with their operands
+# in that cache against 35 us without (tools/bench_x3.py, T3D_BENCH_COLD=1).  Measured: 1.1257 against 1.1271 ms per step (four same-box
+# pairs: noise).  The two widest dz of a net are alive together, so the pool only goes from 277 to 217 MB, and the forward activations
+# (277 MB) exceed the cache by themselves.  Never on when launches of one net may run out of their recorded order (weight gradients on a
+# second stream, un-fused backward).
+DZ_POOL = os.environ.get('T3D_DZ_POOL', '0') == '1' and not SIDE_STREAM and not FC_SIDE and FUSE_BWD
 
 
 class Plan:
@@ -555,8 +564,33 @@ class PointLayer:
                     self.S_live = rt.zeros(self.M, dtype=torch.int32) if SPARSE_GATED else None
                     assert self.S_live is not None or self.dt == abi.F32, "bf16: the fp32 sparse rows S need their row flags"
             else:
-                self.dz = rt.zeros(self.M, self.N, dtype=self.adt)
+                self.dz = self._acquire_dz()
                 self.psum_dz, self.psum_dzy = rt.zeros(self.T, self.N), rt.zeros(self.T, self.N)
+
+    def _acquire_dz(self):
+        """[M, N] view of a pooled buffer of this layer's net (DZ_POOL above), or an allocation of its own."""
+        g, rt = self.g, self.g.rt
+        if not (DZ_POOL and getattr(g, 'pool_dz', True)):
+            return rt.zeros(self.M, self.N, dtype=self.adt)
+        pools = g.__dict__.setdefault('_dz_pools', {})
+        free = pools.setdefault((self.scope.rsplit('/', 1)[0], self.adt), [])
+        need = self.M * self.N
+        pick = None
+        for i in range(len(free) - 1, -1, -1):      # the most recently released buffer that is large enough (still in the cache)
+            if free[i].numel() >= need:
+                pick = free.pop(i)
+                break
+        if pick is None:
+            pick = rt.zeros(need, dtype=self.adt)
+        self._dz_buf = pick
+        return pick[:need].view(self.M, self.N)
+
+    def _release_dz(self):
+        """This layer's backward launches are recorded: nothing recorded after them reads its dz."""
+        buf = getattr(self, '_dz_buf', None)
+        if buf is not None:
+            self._dz_buf = None
+            self.g.__dict__.setdefault('_dz_pools', {}).setdefault((self.scope.rsplit('/', 1)[0], self.adt), []).append(buf)
 
     def dy_struct(self):
         if self.pool:
@@ -724,9 +758,11 @@ class PointLayer:
         plan.add('t3d_pool_bwd_prep', q)
 
     def wgrad(self, plan):
-        """Weight gradient: off the critical path, recorded on the plan's side lane."""
+        """Weight gradient: off the critical path, recorded on the plan's side lane.  (Called on its own for the first layer of a net: the
+        last reader of its dz.)"""
         with plan.side():
             self._wgrad(plan)
+        self._release_dz()
 
     def _wgrad_args(self, fused=False):
         g = self.g
@@ -770,8 +806,10 @@ class PointLayer:
         batch-norm-backward partials; otherwise writes the raw gradient into `out_raw`."""
         if self.gram:
             assert out_raw is None and add_in is None
-            return self._dgrad_gram(plan)
-        plan.add('t3d_pointmlp_dgrad', self._dgrad_args(out_raw, add_in))
+            self._dgrad_gram(plan)
+        else:
+            plan.add('t3d_pointmlp_dgrad', self._dgrad_args(out_raw, add_in))
+        self._release_dz()      # (bwd_pair records the weight gradient BEFORE it calls this; alone: a frozen net's layer, no weight gradient)
 
     def bwd_pair(self, plan, out_raw=None, add_in=None):
         """Weight gradient + input gradient.  Dense layers: ONE launch (t3d_pointmlp_bwd); pooled layers: the Gram path."""
@@ -779,13 +817,15 @@ class PointLayer:
             assert out_raw is None and add_in is None
             return self._bwd_pair_gram(plan)
         if self.gram or self.pool or not FUSE_BWD:
-            self.wgrad(plan)
+            with plan.side():
+                self._wgrad(plan)
             return self.dgrad(plan, out_raw=out_raw, add_in=add_in)
         d, w = self._dgrad_args(out_raw, add_in), self._wgrad_args(fused=True)
         fn, dref, wref = self.g.rt.lib.t3d_pointmlp_bwd, C.byref(d), C.byref(w)
         plan.keep.extend([d, w])
         plan.calls.append(('t3d_pointmlp_bwd', lambda s: fn(dref, wref, s), (d, w)))
         plan.lanes.append(0)
+        self._release_dz()
 
     def dy_colsum(self, plan, alpha=1.0):
         """[B,N] per-frustum column sums of dy (dense layers only)."""

@@ -563,6 +563,7 @@ def build_pipelined_step(rt, B, N, C, use_hip_graph=None, inline_dropout=True, d
         vs = g.vars
         vs.x3_frag_enabled = False      # (the seg forward of step k+1 starts before the T-Net / box optimiser of step k: no single refresh point)
         g.inline_dropout, g.dropout_seed = inline_dropout, dropout_seed
+        g.pool_dz = False               # (two contexts in flight: every layer keeps its own gradient tensor)
         g.split_opt = True
         model = SemiModelA(g, c)
         if i == 0 and state_dict is not None:
