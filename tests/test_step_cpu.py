@@ -63,3 +63,32 @@ def test_bucketed_data_parallel_program_equals_the_single_replica_step():
         assert out['single'][1] == out['bucketed'][1] == out['flat'][1]
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('workload', ['A', 'boxpc', 'F'])
+def test_pooled_gradient_tensors_leave_the_step_bit_identical(workload, monkeypatch):
+    """engine.DZ_POOL (T3D_DZ_POOL=1, an opt-in experiment): the [M, N] gradient tensors between the per-point layers of a net come from a
+    small pool of that net -- a buffer is handed on once the launches of the layer that reads it are recorded.  Same launches, same
+    arguments apart from where those tensors live: weights, Adam moments and moving statistics after two steps equal the default's bit
+    for bit, and the pool really shares buffers."""
+    from transferable3d_amd import engine
+    from transferable3d_amd.step import build_training_step
+    from transferable3d_amd.synthetic import make_batch
+    B, N, C = 4, 128, 4
+    out = {}
+    for pooled in (False, True):
+        monkeypatch.setattr(engine, 'DZ_POOL', pooled)
+        rt = Runtime(device='cpu', lib=FakeLib())
+        g, model, step, loss = build_training_step(rt, workload, B, N, C, seed=5)
+        for k in range(2):
+            model.inputs.load(make_batch(B, N, C, seed=40 + k))
+            step.run()
+        out[pooled] = (g.vars.params.clone(), g.vars.adam_m.clone(), g.vars.adam_v.clone(), g.vars.state.clone())
+        pools = getattr(g, '_dz_pools', {})
+        assert bool(pools) == pooled
+        if pooled:
+            import gc
+            lays = [o for o in gc.get_objects() if isinstance(o, engine.PointLayer) and o.g is g and o.dz is not None]
+            assert len({l.dz.data_ptr() for l in lays}) < len(lays)
+    for a, b in zip(out[False], out[True]):
+        assert torch.equal(a, b)
